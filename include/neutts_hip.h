@@ -1,0 +1,162 @@
+/* neutts_hip.h -- C ABI of libneutts_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for the NeuTTS synthesis hot path.  The reference has no FFI of its own:
+ * its seam is two third-party Python calls, and each entry point below names the one it replaces.
+ *
+ *   backbone:  self.backbone.generate(prompt[1,S], max_length, eos_token_id, do_sample, temperature,
+ *              top_k, use_cache, min_new_tokens) -> ids            ref:neutts/neutts.py:338-347
+ *              (transformers Qwen2ForCausalLM + GenerationMixin._sample, un-vendored dependency)
+ *   codec:     self.codec.decode_code(codes[1,1,T]) -> wav[1,1,480*T]   ref:neutts/neutts.py:288-291
+ *              (neucodec NeuCodec.decode_code, un-vendored dependency)
+ *
+ * Conventions
+ *   - plain C types, raw pointers and sizes; no torch / C++ types cross the boundary.
+ *   - every function returns 0 on success, a negative NTTS_E* code on failure, and never throws;
+ *     ntts_last_error() returns the message of the most recent failure on that engine
+ *     (pass NULL for failures of ntts_*_create itself).
+ *   - the CALLER owns every buffer it passes in; the library owns only what it allocates itself
+ *     (weight arena, KV page pool, workspaces), all in the HBM of the device given at create time.
+ *   - an engine is bound to ONE device, is not re-entrant and not thread-safe: serialise calls per
+ *     engine (the Python host holds the GIL across each call).  One process per GPU; there is no
+ *     cross-GPU collective inside any entry point (utterances are independent).
+ *   - work is enqueued on the engine's own HIP stream; functions named *_sync or documented as
+ *     "blocking" wait for it, the others return once the work is enqueued.
+ *   - there is NO CPU fallback: without a gfx950 device ntts_*_create fails with NTTS_ENODEV.
+ */
+#ifndef NEUTTS_HIP_H
+#define NEUTTS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NTTS_ABI_VERSION 1
+
+enum {
+    NTTS_OK = 0,
+    NTTS_EINVAL = -1,   /* bad argument / unknown tensor name / shape mismatch */
+    NTTS_ENODEV = -2,   /* no usable gfx950 device */
+    NTTS_ENOMEM = -3,   /* HBM allocation or KV page pool exhausted */
+    NTTS_ESTATE = -4,   /* call out of order (weights not finalised, slot busy, ...) */
+    NTTS_EHIP = -5      /* a HIP runtime call failed; see ntts_last_error */
+};
+
+enum { NTTS_DT_F32 = 0, NTTS_DT_BF16 = 1, NTTS_DT_I32 = 2 };
+
+/* ------------------------------------------------------------------------------------------ */
+/* Backbone engine: Qwen2-style decoder, paged KV cache, continuous batching over `max_batch`   */
+/* decode slots.  Replaces transformers' Qwen2ForCausalLM.forward + GenerationMixin._sample     */
+/* (hf:models/qwen2/modeling_qwen2.py:342-477, hf:generation/utils.py:2783-2973) behind         */
+/* ref:neutts/neutts.py:338-347.                                                                */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct ntts_backbone ntts_backbone;
+
+typedef struct ntts_backbone_config {
+    int32_t vocab_size;         /* V (lm_head tied to the embedding) */
+    int32_t hidden_size;        /* 896 */
+    int32_t intermediate_size;  /* 4864 */
+    int32_t num_layers;         /* 24 */
+    int32_t num_heads;          /* 14 */
+    int32_t num_kv_heads;       /* 2  (num_heads / num_kv_heads must be <= 16) */
+    int32_t head_dim;           /* 64 (only 64 is implemented) */
+    float rms_eps;              /* 1e-6 */
+    int32_t max_context;        /* ref:neutts/neutts.py:85  (2048) */
+    int32_t max_batch;          /* number of decode slots (rows of the decode step) */
+    int32_t num_pages;          /* KV pool size in pages of NTTS_PAGE_TOKENS tokens; 0 = max_batch * max_context / page */
+    int32_t max_prefill_tokens; /* workspace rows for one packed prefill call; 0 = 16384 */
+} ntts_backbone_config;
+
+#define NTTS_PAGE_TOKENS 32
+
+int ntts_abi_version(void);
+const char* ntts_last_error(const ntts_backbone* e);
+
+int ntts_backbone_create(const ntts_backbone_config* cfg, int device, ntts_backbone** out);
+void ntts_backbone_destroy(ntts_backbone* e);
+
+/* Weight upload.  `name` is the HF state-dict key of Qwen2ForCausalLM ("model.embed_tokens.weight",
+ * "model.layers.{i}.self_attn.q_proj.weight|bias", ..., "model.norm.weight"; "lm_head.weight" is
+ * accepted and must alias the embedding) plus "rope.inv_freq" (fp32 [head_dim/2], the buffer
+ * hf:models/qwen2/modeling_qwen2.py:86 computes).  `data` may be a host or a device pointer
+ * (is_device); dtype NTTS_DT_F32 or NTTS_DT_BF16 (fp32 is rounded to bf16 RNE, like `.to(bfloat16)`).
+ * The tensor is copied into the engine's packed arena (fused QKV rows, gate/up interleaved in 16-row
+ * groups) -- the caller's buffer can be freed on return.  Blocking. */
+int ntts_backbone_load_tensor(ntts_backbone* e, const char* name, const void* data, int dtype,
+                              const int64_t* shape, int ndim, int is_device);
+/* All tensors present?  Builds the RoPE table and freezes the arena. */
+int ntts_backbone_finalize(ntts_backbone* e);
+/* The packed arena (device pointer + bytes): what rank 0 broadcasts over RCCL/xGMI to the other
+ * ranks at start-up instead of every rank reading the checkpoint.  Valid after
+ * finalize on the sender; a receiver calls ntts_backbone_adopt_arena() after the broadcast landed. */
+int ntts_backbone_arena(ntts_backbone* e, void** dev_ptr, size_t* bytes);
+int ntts_backbone_adopt_arena(ntts_backbone* e);
+
+/* Sampling contract of one request = the keyword arguments of the reference's generate() call
+ * (ref:neutts/neutts.py:338-347). */
+typedef struct ntts_sampling {
+    int32_t max_length;      /* total length cap (prompt + new), <= max_context        [2048] */
+    int32_t min_new_tokens;  /* EOS logit = -inf while fewer new tokens than this      [50]   */
+    int32_t eos_token_id;    /* <|SPEECH_GENERATION_END|>                                      */
+    int32_t do_sample;       /* 0 = greedy argmax (first max wins); 1 = top-k + multinomial [1] */
+    int32_t top_k;           /* [50] */
+    float temperature;       /* [1.0] */
+    uint64_t seed;           /* Philox seed for do_sample=1 */
+} ntts_sampling;
+
+/* Prefill `n` prompts (packed back to back in `ids`, prompt i has lens[i] tokens) into the decode
+ * slots slots[i] (each must be free), run the model over them (causal attention, KV written to
+ * freshly allocated pages) and choose each sequence's first new token.  `ids`, `lens`, `slots`,
+ * `samp` are HOST pointers (samp: one entry per prompt).  sum(lens) <= max_prefill_tokens.
+ * Non-blocking on the engine stream except for the small H2D copies. */
+int ntts_backbone_prefill(ntts_backbone* e, int32_t n, const int32_t* ids, const int32_t* lens,
+                          const int32_t* slots, const ntts_sampling* samp);
+
+/* Run `n_steps` decode steps over all `max_batch` rows (one hipGraph replay per step).  Rows whose
+ * slot is free or finished are carried along masked: they attend to nothing and emit nothing.
+ * KV pages for up to n_steps more tokens per running slot are reserved first (NTTS_ENOMEM if the
+ * pool is exhausted; nothing is enqueued then). */
+int ntts_backbone_decode(ntts_backbone* e, int32_t n_steps);
+
+/* Blocking.  Copy out what slot `slot` has generated so far (prompt stripped, like
+ * ref:neutts/neutts.py:348-351): up to `cap` ids into out_ids, the count into *n_out, and
+ * *finished = 1 once EOS was emitted or max_length reached.  The EOS id itself is included, as in
+ * generate()'s return value. */
+int ntts_backbone_read(ntts_backbone* e, int32_t slot, int32_t* out_ids, int32_t cap, int32_t* n_out,
+                       int32_t* finished);
+/* Blocking.  One int32 per slot: 0 free, 1 running, 2 finished; new-token counts in n_new (may be NULL). */
+int ntts_backbone_poll(ntts_backbone* e, int32_t* state, int32_t* n_new);
+/* Return the slot's KV pages to the pool and mark it free. */
+int ntts_backbone_release(ntts_backbone* e, int32_t slot);
+int ntts_backbone_sync(ntts_backbone* e);
+
+/* Test / profiling taps (blocking).  Last-step fp32 logits are only materialised when
+ * `keep_logits` was enabled; row = slot. */
+int ntts_backbone_set_debug(ntts_backbone* e, int32_t keep_logits);
+int ntts_backbone_read_logits(ntts_backbone* e, int32_t slot, float* out, int32_t n);
+/* Timing: elapsed GPU milliseconds (hipEvents on the engine stream) of the most recent
+ * ntts_backbone_decode call (all its steps) and of the most recent prefill. */
+int ntts_backbone_last_timing(ntts_backbone* e, float* prefill_ms, float* decode_ms);
+/* Algorithmic HBM bytes of one decode step at the current slot lengths (SURVEY.md 8d formula:
+ * layer weights + lm_head + sum_b len_b * kv_bytes_per_token + new-token KV writes). */
+int ntts_backbone_step_bytes(ntts_backbone* e, double* bytes);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Kernel-level entry points (used by the parity tests and micro-benchmarks; all pointers are   */
+/* DEVICE pointers, bf16 unless noted, row-major; run on the NULL stream and block).           */
+/* ------------------------------------------------------------------------------------------ */
+/* C[M,N] = A[M,K] (lda) * W[N,K]^T (+ bias[N]); fp32 accumulate on MFMA, one RNE rounding to bf16.
+ * variant: 0 = auto, otherwise a specific tile configuration (see csrc/gemm.h). */
+int ntts_k_gemm_bf16(const void* A, int64_t lda, const void* W, const void* bias, void* C, int64_t ldc,
+                     int32_t M, int32_t N, int32_t K, int32_t variant);
+/* y = rmsnorm(x) * w with Qwen2RMSNorm's rounding (hf:models/qwen2/modeling_qwen2.py:247-252). */
+int ntts_k_rmsnorm_bf16(const void* x, const void* w, void* y, int32_t rows, int32_t cols, float eps);
+/* Achieved HBM copy bandwidth probe: copies `bytes` device->device `iters` times, returns GB/s. */
+int ntts_k_membw(size_t bytes, int32_t iters, double* gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEUTTS_HIP_H */

@@ -1,0 +1,748 @@
+// backbone.cpp -- the backbone engine behind include/neutts_hip.h (compiled as HIP for gfx950).
+//
+// Host side of the path that replaces  backbone.generate(...)  (ref:neutts/neutts.py:338-347):
+// packed weight arena, paged KV pool + page allocator, decode slots (continuous batching), the
+// prefill pass and the hipGraph-captured decode step.  All arithmetic is in csrc/kernels/*.h.
+#include <ntts/dev.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/neutts_hip.h"
+#include "kernels/attn_decode.h"
+#include "kernels/attn_prefill.h"
+#include "kernels/gemm.h"
+#include "kernels/norm.h"
+#include "kernels/sample.h"
+
+using namespace ntts;
+
+static std::string g_create_err;
+
+struct LayerW {
+    bf16_t *ln1, *wqkv, *bqkv, *wo, *ln2, *wgu, *wd;
+};
+
+struct HostSlot {
+    int state = SLOT_FREE;      // host view: FREE / RUNNING (may already be finished on device)
+    int prompt_len = 0, max_len = 0;
+    int pos_upper = 0;          // upper bound of the device-side pos
+    std::vector<int> pages;
+};
+
+struct ntts_backbone {
+    ntts_backbone_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int H = 0, F = 0, NQKV = 0, max_pages = 0;
+
+    // weights
+    bf16_t* arena = nullptr;
+    size_t arena_elems = 0;
+    bf16_t *embed = nullptr, *final_norm = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
+    std::vector<LayerW> layers;
+    std::set<std::string> loaded;
+    float inv_freq[64];
+    bool have_inv_freq = false, finalized = false;
+    int* gu_map_gate = nullptr;  // device row maps for the gate/up packing
+    int* gu_map_up = nullptr;
+
+    // KV pool
+    bf16_t* kv = nullptr;
+    size_t layer_stride = 0, kv_half = 0;  // elements
+    int num_pages = 0;
+    std::vector<int> free_pages;
+    std::vector<HostSlot> slots;
+
+    // device slot state
+    SlotArrays sl{};
+    int* block_table = nullptr;
+    int* ibuf = nullptr;  // backing store of the int arrays
+
+    // decode workspaces
+    bf16_t *h_dec = nullptr, *xn_dec = nullptr, *qkv_dec = nullptr, *attn_dec = nullptr, *act_dec = nullptr;
+    float* slabs = nullptr;
+    float* part_val = nullptr;
+    int* part_idx = nullptr;
+    int n_part = 0;
+    float* logits = nullptr;  // debug
+    int ks_o = 1, ks_d = 1;
+    bool gu_large = false, head_large = true;
+
+    // prefill workspaces
+    int Tmax = 0;
+    bf16_t *h_pf = nullptr, *xn_pf = nullptr, *qkv_pf = nullptr, *attn_pf = nullptr, *o_pf = nullptr, *act_pf = nullptr;
+    int* meta_dev = nullptr;
+    size_t meta_cap = 0;
+
+    hipGraphExec_t graph = nullptr;
+    bool graph_tried = false, use_graph = true;
+    hipEvent_t ev[4]{};
+    bool have_pf_time = false, have_dec_time = false;
+};
+
+static int fail(ntts_backbone* e, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (e) e->err = buf; else g_create_err = buf;
+    return code;
+}
+#define HIPCHK(e, call)                                                                              \
+    do {                                                                                             \
+        hipError_t _s = (call);                                                                      \
+        if (_s != hipSuccess) return fail(e, NTTS_EHIP, "%s failed: %s", #call, hipGetErrorString(_s)); \
+    } while (0)
+
+extern "C" int ntts_abi_version(void) { return NTTS_ABI_VERSION; }
+extern "C" const char* ntts_last_error(const ntts_backbone* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, ntts_backbone** out) {
+    if (!c || !out) return fail(nullptr, NTTS_EINVAL, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device || device < 0)
+        return fail(nullptr, NTTS_ENODEV, "no HIP device %d (found %d): this library has no CPU fallback", device, ndev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, NTTS_ENODEV, "device %d is '%s', kernels are built for gfx950 only", device, prop.gcnArchName);
+    if (c->head_dim != 64) return fail(nullptr, NTTS_EINVAL, "head_dim %d unsupported (64 only)", c->head_dim);
+    if (c->num_heads % c->num_kv_heads || c->num_heads / c->num_kv_heads > kGroupMax)
+        return fail(nullptr, NTTS_EINVAL, "GQA group %d/%d unsupported (<= %d)", c->num_heads, c->num_kv_heads, kGroupMax);
+    if (c->hidden_size % 64 || c->intermediate_size % 64 || c->hidden_size > 2048)
+        return fail(nullptr, NTTS_EINVAL, "hidden/intermediate size must be multiples of 64 (hidden <= 2048)");
+    if (c->max_context > kAttnLMax || c->max_context % kPage) return fail(nullptr, NTTS_EINVAL, "max_context must be <= %d and a multiple of %d", kAttnLMax, kPage);
+    if (c->max_batch < 1 || c->vocab_size < 2) return fail(nullptr, NTTS_EINVAL, "bad max_batch / vocab_size");
+
+    ntts_backbone* e = new ntts_backbone();
+    e->cfg = *c;
+    e->device = device;
+    e->H = c->hidden_size;
+    e->F = c->intermediate_size;
+    e->NQKV = (c->num_heads + 2 * c->num_kv_heads) * 64;
+    e->max_pages = c->max_context / kPage;
+    e->Tmax = c->max_prefill_tokens > 0 ? c->max_prefill_tokens : 16384;
+    e->num_pages = c->num_pages > 0 ? c->num_pages : c->max_batch * e->max_pages;
+    e->use_graph = env_int("NTTS_NO_GRAPH", 0) == 0;
+    const int B = c->max_batch, H = e->H, F = e->F, L = c->num_layers, V = c->vocab_size;
+
+#define CR_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t _s = (call);                                                               \
+        if (_s != hipSuccess) {                                                               \
+            int rc = fail(nullptr, _s == 2 ? NTTS_ENOMEM : NTTS_EHIP, "%s failed: %s", #call, hipGetErrorString(_s)); \
+            ntts_backbone_destroy(e);                                                         \
+            return rc;                                                                        \
+        }                                                                                     \
+    } while (0)
+
+    CR_HIP(hipSetDevice(device));
+    CR_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    for (auto& ev : e->ev) CR_HIP(hipEventCreate(&ev));
+
+    // ---- weight arena (bf16), every tensor 256-byte aligned
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += align_up(n, 128); return o; };
+    const size_t o_embed = take((size_t)V * H);
+    struct LO { size_t ln1, wqkv, bqkv, wo, ln2, wgu, wd; };
+    std::vector<LO> lo(L);
+    for (int i = 0; i < L; ++i) {
+        lo[i].ln1 = take(H); lo[i].wqkv = take((size_t)e->NQKV * H); lo[i].bqkv = take(e->NQKV);
+        lo[i].wo = take((size_t)H * c->num_heads * 64); lo[i].ln2 = take(H);
+        lo[i].wgu = take((size_t)2 * F * H); lo[i].wd = take((size_t)H * F);
+    }
+    const size_t o_fn = take(H), o_cos = take((size_t)c->max_context * 32), o_sin = take((size_t)c->max_context * 32);
+    e->arena_elems = off;
+    CR_HIP(hipMalloc((void**)&e->arena, off * sizeof(bf16_t)));
+    CR_HIP(hipMemset(e->arena, 0, off * sizeof(bf16_t)));
+    e->embed = e->arena + o_embed;
+    e->layers.resize(L);
+    for (int i = 0; i < L; ++i)
+        e->layers[i] = LayerW{e->arena + lo[i].ln1, e->arena + lo[i].wqkv, e->arena + lo[i].bqkv, e->arena + lo[i].wo,
+                              e->arena + lo[i].ln2, e->arena + lo[i].wgu, e->arena + lo[i].wd};
+    e->final_norm = e->arena + o_fn;
+    e->rope_cos = e->arena + o_cos;
+    e->rope_sin = e->arena + o_sin;
+
+    // gate/up packing maps: source feature f -> packed row (see gemm.h EPI_SILU_MUL)
+    {
+        std::vector<int> mg(F), mu(F);
+        for (int f = 0; f < F; ++f) {
+            const int b = f / 32, g = (f % 32) / 8, jj = (f % 8) / 4, r = f % 4;
+            mg[f] = b * 64 + g * 16 + jj * 4 + r;
+            mu[f] = b * 64 + g * 16 + (jj + 2) * 4 + r;
+        }
+        CR_HIP(hipMalloc((void**)&e->gu_map_gate, F * sizeof(int)));
+        CR_HIP(hipMalloc((void**)&e->gu_map_up, F * sizeof(int)));
+        CR_HIP(hipMemcpy(e->gu_map_gate, mg.data(), F * sizeof(int), hipMemcpyHostToDevice));
+        CR_HIP(hipMemcpy(e->gu_map_up, mu.data(), F * sizeof(int), hipMemcpyHostToDevice));
+    }
+
+    // ---- KV pool: per layer [K pages | V^T pages], page-head = 32 tokens x 64 d
+    e->kv_half = (size_t)e->num_pages * c->num_kv_heads * kPage * 64;
+    e->layer_stride = 2 * e->kv_half;
+    CR_HIP(hipMalloc((void**)&e->kv, (size_t)L * e->layer_stride * sizeof(bf16_t)));
+    CR_HIP(hipMemset(e->kv, 0, (size_t)L * e->layer_stride * sizeof(bf16_t)));
+    e->free_pages.reserve(e->num_pages);
+    for (int p = e->num_pages - 1; p >= 0; --p) e->free_pages.push_back(p);
+    e->slots.resize(B);
+
+    // ---- slot state
+    const size_t n_int = (size_t)B * 9 + (size_t)B * c->max_context + (size_t)B * e->max_pages;
+    CR_HIP(hipMalloc((void**)&e->ibuf, n_int * sizeof(int)));
+    CR_HIP(hipMemset(e->ibuf, 0, n_int * sizeof(int)));
+    int* ip = e->ibuf;
+    e->sl.state = ip; ip += B; e->sl.pos = ip; ip += B; e->sl.n_new = ip; ip += B; e->sl.cur_tok = ip; ip += B;
+    e->sl.prompt_len = ip; ip += B; e->sl.min_new = ip; ip += B; e->sl.max_len = ip; ip += B; e->sl.eos = ip; ip += B;
+    e->sl.mask_eos = ip; ip += B;
+    e->sl.out_tokens = ip; ip += (size_t)B * c->max_context;
+    e->sl.out_stride = c->max_context;
+    e->block_table = ip;
+
+    // ---- decode workspaces + tile choices (decode GEMMs are weight-streaming, M = max_batch)
+    const int mblocks_s = (B + 63) / 64;
+    auto pick_split = [&](int nblocks, int ktiles) {
+        int blocks = nblocks * mblocks_s, ks = (224 + blocks - 1) / blocks;
+        if (ks < 1) ks = 1;
+        if (ks > 16) ks = 16;
+        if (ks > ktiles) ks = ktiles;
+        return ks;
+    };
+    e->ks_o = env_int("NTTS_KSPLIT_O", pick_split(H / 64, c->num_heads * 64 / 64));
+    e->ks_d = env_int("NTTS_KSPLIT_D", pick_split(H / 64, F / 64));
+    e->gu_large = env_int("NTTS_GU_LARGE", 0) != 0;
+    e->head_large = env_int("NTTS_HEAD_LARGE", B > 64 ? 1 : 0) != 0;
+    const int max_slabs = 16;
+    if (e->ks_o > max_slabs) e->ks_o = max_slabs;
+    if (e->ks_d > max_slabs) e->ks_d = max_slabs;
+    e->n_part = e->head_large ? ((V + 127) / 128) * 2 : (V + 63) / 64;
+    CR_HIP(hipMalloc((void**)&e->h_dec, (size_t)B * H * 2));
+    CR_HIP(hipMalloc((void**)&e->xn_dec, (size_t)B * H * 2));
+    CR_HIP(hipMalloc((void**)&e->qkv_dec, (size_t)B * e->NQKV * 2));
+    CR_HIP(hipMalloc((void**)&e->attn_dec, (size_t)B * c->num_heads * 64 * 2));
+    CR_HIP(hipMalloc((void**)&e->act_dec, (size_t)B * F * 2));
+    CR_HIP(hipMalloc((void**)&e->slabs, (size_t)max_slabs * B * H * 4));
+    CR_HIP(hipMalloc((void**)&e->part_val, (size_t)B * e->n_part * 4));
+    CR_HIP(hipMalloc((void**)&e->part_idx, (size_t)B * e->n_part * 4));
+    CR_HIP(hipMemset(e->h_dec, 0, (size_t)B * H * 2));
+    CR_HIP(hipMemset(e->xn_dec, 0, (size_t)B * H * 2));
+    CR_HIP(hipMemset(e->qkv_dec, 0, (size_t)B * e->NQKV * 2));
+    CR_HIP(hipMemset(e->attn_dec, 0, (size_t)B * c->num_heads * 64 * 2));
+
+    // ---- prefill workspaces
+    const size_t T = e->Tmax;
+    CR_HIP(hipMalloc((void**)&e->h_pf, T * H * 2));
+    CR_HIP(hipMalloc((void**)&e->xn_pf, T * H * 2));
+    CR_HIP(hipMalloc((void**)&e->qkv_pf, T * e->NQKV * 2));
+    CR_HIP(hipMalloc((void**)&e->attn_pf, T * c->num_heads * 64 * 2));
+    CR_HIP(hipMalloc((void**)&e->o_pf, T * H * 2));
+    CR_HIP(hipMalloc((void**)&e->act_pf, T * F * 2));
+    e->meta_cap = 2 * T + (size_t)B * (8 + e->max_pages) + (T / 64 + B) * 2 + 3 * (size_t)B * e->max_pages + 64;
+    CR_HIP(hipMalloc((void**)&e->meta_dev, e->meta_cap * sizeof(int)));
+    CR_HIP(hipDeviceSynchronize());
+    *out = e;
+    return NTTS_OK;
+}
+
+extern "C" void ntts_backbone_destroy(ntts_backbone* e) {
+    if (!e) return;
+    hipSetDevice(e->device);
+    hipDeviceSynchronize();
+    if (e->graph) hipGraphExecDestroy(e->graph);
+    void* bufs[] = {e->arena, e->gu_map_gate, e->gu_map_up, e->kv, e->ibuf, e->h_dec, e->xn_dec, e->qkv_dec, e->attn_dec,
+                    e->act_dec, e->slabs, e->part_val, e->part_idx, e->logits, e->h_pf, e->xn_pf, e->qkv_pf, e->attn_pf,
+                    e->o_pf, e->act_pf, e->meta_dev};
+    for (void* b : bufs)
+        if (b) hipFree(b);
+    for (auto& ev : e->ev)
+        if (ev) hipEventDestroy(ev);
+    if (e->stream) hipStreamDestroy(e->stream);
+    delete e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weights
+// ------------------------------------------------------------------------------------------------
+static int put_rows(ntts_backbone* e, const void* data, int dtype, int is_device, long rows, long cols, bf16_t* dst,
+                    const int* dst_rows) {
+    const size_t esz = dtype == NTTS_DT_F32 ? 4 : 2;
+    const void* src = data;
+    void* tmp = nullptr;
+    if (!is_device) {
+        HIPCHK(e, hipMalloc(&tmp, (size_t)rows * cols * esz));
+        HIPCHK(e, hipMemcpy(tmp, data, (size_t)rows * cols * esz, hipMemcpyHostToDevice));
+        src = tmp;
+    }
+    NTTS_LAUNCH((pack_rows_kernel), dim3((unsigned)rows), dim3(256), e->stream, src, dtype == NTTS_DT_F32 ? 1 : 0, dst, dst_rows, cols);
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (tmp) HIPCHK(e, hipFree(tmp));
+    return NTTS_OK;
+}
+
+extern "C" int ntts_backbone_load_tensor(ntts_backbone* e, const char* name, const void* data, int dtype,
+                                         const int64_t* shape, int ndim, int is_device) {
+    if (!e || !name || !data || !shape) return fail(e, NTTS_EINVAL, "null argument");
+    if (e->finalized) return fail(e, NTTS_ESTATE, "weights already finalised");
+    HIPCHK(e, hipSetDevice(e->device));
+    const ntts_backbone_config& c = e->cfg;
+    const long H = e->H, F = e->F, QD = c.num_heads * 64, KD = c.num_kv_heads * 64;
+    std::string n(name);
+    auto want = [&](long r, long cc) -> bool {
+        return (cc == 0 && ndim == 1 && shape[0] == r) || (cc != 0 && ndim == 2 && shape[0] == r && shape[1] == cc);
+    };
+    auto bad_shape = [&]() { return fail(e, NTTS_EINVAL, "tensor '%s': unexpected shape", name); };
+    if (n == "rope.inv_freq") {
+        if (dtype != NTTS_DT_F32 || !want(32, 0)) return fail(e, NTTS_EINVAL, "rope.inv_freq must be fp32 [32]");
+        if (is_device) HIPCHK(e, hipMemcpy(e->inv_freq, data, 32 * 4, hipMemcpyDeviceToHost));
+        else memcpy(e->inv_freq, data, 32 * 4);
+        e->have_inv_freq = true;
+        e->loaded.insert(n);
+        return NTTS_OK;
+    }
+    if (dtype != NTTS_DT_F32 && dtype != NTTS_DT_BF16) return fail(e, NTTS_EINVAL, "tensor '%s': dtype must be f32 or bf16", name);
+    int rc = NTTS_EINVAL;
+    if (n == "model.embed_tokens.weight" || n == "lm_head.weight") {
+        if (!want(c.vocab_size, H)) return bad_shape();
+        if (n == "lm_head.weight" && e->loaded.count("model.embed_tokens.weight")) return NTTS_OK;  // tied: same bytes
+        rc = put_rows(e, data, dtype, is_device, c.vocab_size, H, e->embed, nullptr);
+        if (rc == NTTS_OK) e->loaded.insert("model.embed_tokens.weight");
+        return rc;
+    }
+    if (n == "model.norm.weight") {
+        if (!want(H, 0)) return bad_shape();
+        rc = put_rows(e, data, dtype, is_device, 1, H, e->final_norm, nullptr);
+    } else if (n.rfind("model.layers.", 0) == 0) {
+        const char* s = name + 13;
+        char* endp = nullptr;
+        const long li = strtol(s, &endp, 10);
+        if (endp == s || *endp != '.' || li < 0 || li >= c.num_layers) return fail(e, NTTS_EINVAL, "tensor '%s': bad layer index", name);
+        const std::string t(endp + 1);
+        LayerW& w = e->layers[li];
+        if (t == "input_layernorm.weight") { if (!want(H, 0)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, 1, H, w.ln1, nullptr); }
+        else if (t == "post_attention_layernorm.weight") { if (!want(H, 0)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, 1, H, w.ln2, nullptr); }
+        else if (t == "self_attn.q_proj.weight") { if (!want(QD, H)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, QD, H, w.wqkv, nullptr); }
+        else if (t == "self_attn.k_proj.weight") { if (!want(KD, H)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, KD, H, w.wqkv + QD * H, nullptr); }
+        else if (t == "self_attn.v_proj.weight") { if (!want(KD, H)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, KD, H, w.wqkv + (QD + KD) * H, nullptr); }
+        else if (t == "self_attn.q_proj.bias") { if (!want(QD, 0)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, 1, QD, w.bqkv, nullptr); }
+        else if (t == "self_attn.k_proj.bias") { if (!want(KD, 0)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, 1, KD, w.bqkv + QD, nullptr); }
+        else if (t == "self_attn.v_proj.bias") { if (!want(KD, 0)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, 1, KD, w.bqkv + QD + KD, nullptr); }
+        else if (t == "self_attn.o_proj.weight") { if (!want(H, QD)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, H, QD, w.wo, nullptr); }
+        else if (t == "mlp.gate_proj.weight") { if (!want(F, H)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, F, H, w.wgu, e->gu_map_gate); }
+        else if (t == "mlp.up_proj.weight") { if (!want(F, H)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, F, H, w.wgu, e->gu_map_up); }
+        else if (t == "mlp.down_proj.weight") { if (!want(H, F)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, H, F, w.wd, nullptr); }
+        else return fail(e, NTTS_EINVAL, "unknown tensor '%s'", name);
+    } else {
+        return fail(e, NTTS_EINVAL, "unknown tensor '%s'", name);
+    }
+    if (rc == NTTS_OK) e->loaded.insert(n);
+    return rc;
+}
+
+static int build_rope(ntts_backbone* e) {
+    // Qwen2RotaryEmbedding.forward hf:models/qwen2/modeling_qwen2.py:91-102: angle = fp32(pos * inv_freq),
+    // cos/sin in fp32, cast to bf16.  cos/sin are evaluated in double and rounded once to fp32.
+    const int n = e->cfg.max_context;
+    std::vector<bf16_t> c((size_t)n * 32), s((size_t)n * 32);
+    auto tobf = [](float f) {
+        uint32_t u;
+        memcpy(&u, &f, 4);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return (bf16_t)(u >> 16);
+    };
+    for (int p = 0; p < n; ++p)
+        for (int i = 0; i < 32; ++i) {
+            const float ang = (float)p * e->inv_freq[i];
+            c[(size_t)p * 32 + i] = tobf((float)cos((double)ang));
+            s[(size_t)p * 32 + i] = tobf((float)sin((double)ang));
+        }
+    HIPCHK(e, hipMemcpy(e->rope_cos, c.data(), c.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->rope_sin, s.data(), s.size() * 2, hipMemcpyHostToDevice));
+    return NTTS_OK;
+}
+
+extern "C" int ntts_backbone_finalize(ntts_backbone* e) {
+    if (!e) return NTTS_EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t need = 3 + (size_t)e->cfg.num_layers * 12;  // embed, norm, inv_freq + 12 per layer
+    if (!e->have_inv_freq) return fail(e, NTTS_ESTATE, "rope.inv_freq not loaded");
+    if (e->loaded.size() != need) return fail(e, NTTS_ESTATE, "%zu of %zu tensors loaded", e->loaded.size(), need);
+    int rc = build_rope(e);
+    if (rc) return rc;
+    e->finalized = true;
+    return NTTS_OK;
+}
+
+extern "C" int ntts_backbone_arena(ntts_backbone* e, void** dev_ptr, size_t* bytes) {
+    if (!e || !dev_ptr || !bytes) return NTTS_EINVAL;
+    *dev_ptr = e->arena;
+    *bytes = e->arena_elems * sizeof(bf16_t);
+    return NTTS_OK;
+}
+extern "C" int ntts_backbone_adopt_arena(ntts_backbone* e) {
+    if (!e) return NTTS_EINVAL;
+    e->finalized = true;  // arena (incl. the RoPE table) was filled by a broadcast from a finalised engine
+    return NTTS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// model passes
+// ------------------------------------------------------------------------------------------------
+static GemmArgs gemm_args(const bf16_t* X, long ldx, const bf16_t* W, long ldw, const bf16_t* bias, void* out, long ldo,
+                          int M, int N, int K) {
+    GemmArgs a{};
+    a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K;
+    return a;
+}
+
+static void lm_head_and_sample(ntts_backbone* e, int phase) {
+    const int B = e->cfg.max_batch, H = e->H, V = e->cfg.vocab_size;
+    GemmArgs a = gemm_args(e->xn_dec, H, e->embed, H, nullptr, nullptr, 0, B, V, H);
+    a.part_val = e->part_val; a.part_idx = e->part_idx; a.mask_eos = e->sl.mask_eos;
+    a.logits = e->logits; a.ld_logits = V;
+    if (e->head_large) NTTS_GEMM_L(EPI_ARGMAX, a, 1, e->stream); else NTTS_GEMM_S(EPI_ARGMAX, a, 1, e->stream);
+    SampleArgs s{};
+    s.part_val = e->part_val; s.part_idx = e->part_idx; s.n_part = e->n_part; s.sl = e->sl; s.phase = phase;
+    NTTS_LAUNCH((sample_greedy_kernel), dim3(B), dim3(256), e->stream, s);
+}
+
+static void decode_step(ntts_backbone* e) {
+    const ntts_backbone_config& c = e->cfg;
+    const int B = c.max_batch, H = e->H, F = e->F, QD = c.num_heads * 64;
+    hipStream_t st = e->stream;
+    NormArgs n0{};
+    n0.gather_ids = e->sl.cur_tok; n0.embed = e->embed; n0.resid_out = e->h_dec; n0.norm_w = e->layers[0].ln1;
+    n0.normed_out = e->xn_dec; n0.M = B; n0.H = H; n0.eps = c.rms_eps;
+    add_rmsnorm_launch(n0, st);
+    for (int i = 0; i < c.num_layers; ++i) {
+        const LayerW& w = e->layers[i];
+        NTTS_GEMM_S(EPI_BF16, gemm_args(e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H), 1, st);
+        AttnDecodeArgs a{};
+        a.qkv = e->qkv_dec; a.ld_qkv = e->NQKV; a.out = e->attn_dec; a.ld_out = QD;
+        a.kpool = e->kv + (size_t)i * e->layer_stride; a.vpool = a.kpool + e->kv_half;
+        a.block_table = e->block_table; a.max_pages = e->max_pages; a.pos = e->sl.pos; a.state = e->sl.state;
+        a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
+        attn_decode_launch(a, B, st);
+        NTTS_GEMM_S(EPI_SPLITK, gemm_args(e->attn_dec, QD, w.wo, QD, nullptr, e->slabs, H, B, H, QD), e->ks_o, st);
+        NormArgs n1{};
+        n1.slabs = e->slabs; n1.nslab = gemm_nsplit(QD, e->ks_o); n1.slab_rows = B; n1.resid_in = e->h_dec; n1.resid_out = e->h_dec;
+        n1.norm_w = w.ln2; n1.normed_out = e->xn_dec; n1.M = B; n1.H = H; n1.eps = c.rms_eps;
+        add_rmsnorm_launch(n1, st);
+        GemmArgs gu = gemm_args(e->xn_dec, H, w.wgu, H, nullptr, e->act_dec, F, B, 2 * F, H);
+        if (e->gu_large) NTTS_GEMM_L(EPI_SILU_MUL, gu, 1, st); else NTTS_GEMM_S(EPI_SILU_MUL, gu, 1, st);
+        NTTS_GEMM_S(EPI_SPLITK, gemm_args(e->act_dec, F, w.wd, F, nullptr, e->slabs, H, B, H, F), e->ks_d, st);
+        NormArgs n2{};
+        n2.slabs = e->slabs; n2.nslab = gemm_nsplit(F, e->ks_d); n2.slab_rows = B; n2.resid_in = e->h_dec; n2.resid_out = e->h_dec;
+        n2.norm_w = (i + 1 < c.num_layers) ? e->layers[i + 1].ln1 : e->final_norm;
+        n2.normed_out = e->xn_dec; n2.M = B; n2.H = H; n2.eps = c.rms_eps;
+        add_rmsnorm_launch(n2, st);
+    }
+    lm_head_and_sample(e, SLOT_RUNNING);
+}
+
+static int alloc_pages(ntts_backbone* e, HostSlot& s, int tokens) {
+    const int need = (tokens + kPage - 1) / kPage;
+    while ((int)s.pages.size() < need) {
+        if (e->free_pages.empty()) return NTTS_ENOMEM;
+        s.pages.push_back(e->free_pages.back());
+        e->free_pages.pop_back();
+    }
+    return NTTS_OK;
+}
+
+extern "C" int ntts_backbone_prefill(ntts_backbone* e, int32_t n, const int32_t* ids, const int32_t* lens,
+                                     const int32_t* slots, const ntts_sampling* samp) {
+    if (!e || n < 1 || !ids || !lens || !slots || !samp) return fail(e, NTTS_EINVAL, "null/empty argument");
+    if (!e->finalized) return fail(e, NTTS_ESTATE, "weights not finalised");
+    HIPCHK(e, hipSetDevice(e->device));
+    const ntts_backbone_config& c = e->cfg;
+    const int B = c.max_batch, H = e->H, F = e->F, QD = c.num_heads * 64;
+    long T = 0;
+    for (int i = 0; i < n; ++i) {
+        if (slots[i] < 0 || slots[i] >= B) return fail(e, NTTS_EINVAL, "slot %d out of range", slots[i]);
+        if (e->slots[slots[i]].state != SLOT_FREE) return fail(e, NTTS_ESTATE, "slot %d is busy", slots[i]);
+        for (int j = 0; j < i; ++j)
+            if (slots[j] == slots[i]) return fail(e, NTTS_EINVAL, "slot %d given twice", slots[i]);
+        if (lens[i] < 1) return fail(e, NTTS_EINVAL, "empty prompt %d", i);
+        if (samp[i].max_length > c.max_context || samp[i].max_length <= lens[i])
+            return fail(e, NTTS_EINVAL, "prompt %d: need len < max_length <= max_context (%d, %d)", i, lens[i], samp[i].max_length);
+        if (samp[i].do_sample) return fail(e, NTTS_EINVAL, "do_sample=1 (top-k multinomial) is not implemented yet: greedy only");
+        if (samp[i].eos_token_id < 0 || samp[i].eos_token_id >= c.vocab_size) return fail(e, NTTS_EINVAL, "eos id out of range");
+        T += lens[i];
+    }
+    if (T > e->Tmax) return fail(e, NTTS_EINVAL, "%ld prompt tokens exceed max_prefill_tokens %d", T, e->Tmax);
+    for (long t = 0; t < T; ++t)
+        if (ids[t] < 0 || ids[t] >= c.vocab_size) return fail(e, NTTS_EINVAL, "token id %d out of range", ids[t]);
+
+    // ---- pages (roll back on exhaustion)
+    for (int i = 0; i < n; ++i) {
+        HostSlot& s = e->slots[slots[i]];
+        if (alloc_pages(e, s, lens[i]) != NTTS_OK) {
+            for (int j = 0; j <= i; ++j) {
+                HostSlot& r = e->slots[slots[j]];
+                for (int pg : r.pages) e->free_pages.push_back(pg);
+                r.pages.clear();
+            }
+            return fail(e, NTTS_ENOMEM, "KV page pool exhausted (%d pages)", e->num_pages);
+        }
+    }
+    // ---- meta block: [ids T][tok_seq T][tok_base n][seq_len n][slot n][min_new n][max_len n][eos n][last_row n]
+    //                  [tile_seq nt][tile_q0 nt][bt_rows n*max_pages]
+    std::vector<int> tile_seq, tile_q0;
+    std::vector<int> m;
+    m.reserve(2 * T + 8 * n);
+    m.insert(m.end(), ids, ids + T);
+    const size_t o_tok_seq = m.size();
+    for (int i = 0; i < n; ++i) m.insert(m.end(), lens[i], i);
+    const size_t o_base = m.size();
+    long acc = 0;
+    for (int i = 0; i < n; ++i) {
+        m.push_back((int)acc);
+        for (int q = 0; q < lens[i]; q += 64) { tile_seq.push_back(i); tile_q0.push_back(q); }
+        acc += lens[i];
+    }
+    const size_t o_len = m.size();   m.insert(m.end(), lens, lens + n);
+    const size_t o_slot = m.size();  m.insert(m.end(), slots, slots + n);
+    const size_t o_min = m.size();   for (int i = 0; i < n; ++i) m.push_back(samp[i].min_new_tokens);
+    const size_t o_max = m.size();   for (int i = 0; i < n; ++i) m.push_back(samp[i].max_length);
+    const size_t o_eos = m.size();   for (int i = 0; i < n; ++i) m.push_back(samp[i].eos_token_id);
+    const size_t o_last = m.size();
+    acc = 0;
+    for (int i = 0; i < n; ++i) { acc += lens[i]; m.push_back((int)acc - 1); }
+    const size_t o_tseq = m.size();  m.insert(m.end(), tile_seq.begin(), tile_seq.end());
+    const size_t o_tq0 = m.size();   m.insert(m.end(), tile_q0.begin(), tile_q0.end());
+    const size_t o_bt = m.size();
+    for (int i = 0; i < n; ++i) {
+        const HostSlot& s = e->slots[slots[i]];
+        for (int k = 0; k < e->max_pages; ++k) m.push_back(k < (int)s.pages.size() ? s.pages[k] : 0);
+    }
+    if (m.size() > e->meta_cap) return fail(e, NTTS_EINVAL, "prefill meta block too large");
+    hipStream_t st = e->stream;
+    HIPCHK(e, hipMemcpyAsync(e->meta_dev, m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    HIPCHK(e, hipStreamSynchronize(st));  // m is pageable host memory
+    const int* md = e->meta_dev;
+    PrefillMeta meta{md + o_base, md + o_len, md + o_slot, md + o_tok_seq, md + o_tseq, md + o_tq0};
+
+    HIPCHK(e, hipEventRecord(e->ev[0], st));
+    PrefillInit pi{};
+    pi.slot = md + o_slot; pi.seq_len = md + o_len; pi.min_new = md + o_min; pi.max_len = md + o_max; pi.eos = md + o_eos;
+    pi.bt_rows = md + o_bt; pi.block_table = e->block_table; pi.max_pages = e->max_pages; pi.n = n; pi.sl = e->sl;
+    NTTS_LAUNCH((prefill_init_kernel), dim3(n), dim3(64), st, pi);
+
+    const int Ti = (int)T;
+    NormArgs n0{};
+    n0.gather_ids = md; n0.embed = e->embed; n0.resid_out = e->h_pf; n0.norm_w = e->layers[0].ln1; n0.normed_out = e->xn_pf;
+    n0.M = Ti; n0.H = H; n0.eps = c.rms_eps;
+    add_rmsnorm_launch(n0, st);
+    for (int i = 0; i < c.num_layers; ++i) {
+        const LayerW& w = e->layers[i];
+        const bool last = i + 1 == c.num_layers;
+        NTTS_GEMM_L(EPI_BF16, gemm_args(e->xn_pf, H, w.wqkv, H, w.bqkv, e->qkv_pf, e->NQKV, Ti, e->NQKV, H), 1, st);
+        RopeWriteArgs r{};
+        r.qkv = e->qkv_pf; r.ld_qkv = e->NQKV; r.kpool = e->kv + (size_t)i * e->layer_stride; r.vpool = r.kpool + e->kv_half;
+        r.block_table = e->block_table; r.max_pages = e->max_pages; r.meta = meta; r.rope_cos = e->rope_cos; r.rope_sin = e->rope_sin;
+        r.nh = c.num_heads; r.nkv = c.num_kv_heads; r.T = Ti;
+        NTTS_LAUNCH((rope_kv_write_kernel), dim3(Ti), dim3(256), st, r);
+        AttnPrefillArgs a{};
+        a.qkv = e->qkv_pf; a.ld_qkv = e->NQKV; a.out = e->attn_pf; a.ld_out = QD; a.kpool = r.kpool; a.vpool = r.vpool;
+        a.block_table = e->block_table; a.max_pages = e->max_pages; a.meta = meta; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
+        NTTS_LAUNCH((attn_prefill_kernel), dim3((unsigned)tile_seq.size(), c.num_heads), dim3(256), st, a);
+        NTTS_GEMM_L(EPI_BF16, gemm_args(e->attn_pf, QD, w.wo, QD, nullptr, e->o_pf, H, Ti, H, QD), 1, st);
+        NormArgs n1{};
+        n1.o_bf16 = e->o_pf; n1.resid_in = e->h_pf; n1.resid_out = e->h_pf; n1.norm_w = w.ln2; n1.normed_out = e->xn_pf;
+        n1.M = Ti; n1.H = H; n1.eps = c.rms_eps;
+        add_rmsnorm_launch(n1, st);
+        NTTS_GEMM_L(EPI_SILU_MUL, gemm_args(e->xn_pf, H, w.wgu, H, nullptr, e->act_pf, F, Ti, 2 * F, H), 1, st);
+        NTTS_GEMM_L(EPI_BF16, gemm_args(e->act_pf, F, w.wd, F, nullptr, e->o_pf, H, Ti, H, F), 1, st);
+        NormArgs n2{};
+        n2.o_bf16 = e->o_pf; n2.resid_in = e->h_pf; n2.eps = c.rms_eps; n2.H = H;
+        if (!last) {
+            n2.resid_out = e->h_pf; n2.norm_w = e->layers[i + 1].ln1; n2.normed_out = e->xn_pf; n2.M = Ti;
+        } else {  // only each prompt's last position feeds the lm_head: gather it into its decode-slot row
+            n2.resid_out = e->h_dec; n2.norm_w = e->final_norm; n2.normed_out = e->xn_dec; n2.M = n;
+            n2.in_rows = md + o_last; n2.out_rows = md + o_slot;
+        }
+        add_rmsnorm_launch(n2, st);
+    }
+    lm_head_and_sample(e, SLOT_PREFILLED);
+    HIPCHK(e, hipEventRecord(e->ev[1], st));
+    e->have_pf_time = true;
+    HIPCHK(e, hipGetLastError());
+    for (int i = 0; i < n; ++i) {
+        HostSlot& s = e->slots[slots[i]];
+        s.state = SLOT_RUNNING; s.prompt_len = lens[i]; s.max_len = samp[i].max_length; s.pos_upper = lens[i];
+    }
+    return NTTS_OK;
+}
+
+extern "C" int ntts_backbone_decode(ntts_backbone* e, int32_t n_steps) {
+    if (!e || n_steps < 1) return fail(e, NTTS_EINVAL, "bad n_steps");
+    if (!e->finalized) return fail(e, NTTS_ESTATE, "weights not finalised");
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t st = e->stream;
+    // ---- reserve KV pages for the positions these steps can write (pos <= max_len - 2)
+    std::vector<int> trip;
+    std::vector<std::pair<int, size_t>> undo;
+    for (int b = 0; b < e->cfg.max_batch; ++b) {
+        HostSlot& s = e->slots[b];
+        if (s.state != SLOT_RUNNING) continue;
+        int upto = s.pos_upper + n_steps;
+        if (upto > s.max_len - 1) upto = s.max_len - 1;
+        const size_t before = s.pages.size();
+        if (alloc_pages(e, s, upto) != NTTS_OK) {
+            undo.emplace_back(b, before);
+            for (auto& u : undo) {
+                HostSlot& r = e->slots[u.first];
+                while (r.pages.size() > u.second) { e->free_pages.push_back(r.pages.back()); r.pages.pop_back(); }
+            }
+            return fail(e, NTTS_ENOMEM, "KV page pool exhausted (%d pages)", e->num_pages);
+        }
+        undo.emplace_back(b, before);
+        for (size_t k = before; k < s.pages.size(); ++k) { trip.push_back(b); trip.push_back((int)k); trip.push_back(s.pages[k]); }
+        s.pos_upper = upto;
+    }
+    if (!trip.empty()) {
+        if (trip.size() > e->meta_cap) return fail(e, NTTS_EINVAL, "block-table update too large");
+        HIPCHK(e, hipMemcpyAsync(e->meta_dev, trip.data(), trip.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        HIPCHK(e, hipStreamSynchronize(st));
+        const int nt = (int)trip.size() / 3;
+        NTTS_LAUNCH((bt_update_kernel), dim3((nt + 63) / 64), dim3(64), st, (const int*)e->meta_dev, nt, e->block_table, e->max_pages);
+    }
+    if (e->use_graph && !e->graph_tried) {
+        e->graph_tried = true;
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeGlobal) == hipSuccess) {
+            decode_step(e);
+            if (hipStreamEndCapture(st, &g) == hipSuccess && g) {
+                if (hipGraphInstantiate(&e->graph, g, nullptr, nullptr, 0) != hipSuccess) e->graph = nullptr;
+                hipGraphDestroy(g);
+            }
+        }
+        (void)hipGetLastError();
+    }
+    HIPCHK(e, hipEventRecord(e->ev[2], st));
+    for (int s = 0; s < n_steps; ++s) {
+        if (e->graph) HIPCHK(e, hipGraphLaunch(e->graph, st));
+        else decode_step(e);
+    }
+    HIPCHK(e, hipEventRecord(e->ev[3], st));
+    e->have_dec_time = true;
+    HIPCHK(e, hipGetLastError());
+    return NTTS_OK;
+}
+
+extern "C" int ntts_backbone_sync(ntts_backbone* e) {
+    if (!e) return NTTS_EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    return NTTS_OK;
+}
+
+extern "C" int ntts_backbone_poll(ntts_backbone* e, int32_t* state, int32_t* n_new) {
+    if (!e || !state) return NTTS_EINVAL;
+    const int B = e->cfg.max_batch;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(state, e->sl.state, B * sizeof(int), hipMemcpyDeviceToHost));
+    if (n_new) HIPCHK(e, hipMemcpy(n_new, e->sl.n_new, B * sizeof(int), hipMemcpyDeviceToHost));
+    return NTTS_OK;
+}
+
+extern "C" int ntts_backbone_read(ntts_backbone* e, int32_t slot, int32_t* out_ids, int32_t cap, int32_t* n_out,
+                                  int32_t* finished) {
+    if (!e || slot < 0 || slot >= e->cfg.max_batch || !n_out) return fail(e, NTTS_EINVAL, "bad argument");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    int st = 0, nn = 0;
+    HIPCHK(e, hipMemcpy(&st, e->sl.state + slot, sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(&nn, e->sl.n_new + slot, sizeof(int), hipMemcpyDeviceToHost));
+    if (e->slots[slot].state == SLOT_FREE) { st = SLOT_FREE; nn = 0; }
+    const int k = nn < cap ? nn : cap;
+    if (out_ids && k > 0)
+        HIPCHK(e, hipMemcpy(out_ids, e->sl.out_tokens + (size_t)slot * e->sl.out_stride, k * sizeof(int), hipMemcpyDeviceToHost));
+    *n_out = nn;
+    if (finished) *finished = (st == SLOT_FINISHED) ? 1 : 0;
+    return NTTS_OK;
+}
+
+extern "C" int ntts_backbone_release(ntts_backbone* e, int32_t slot) {
+    if (!e || slot < 0 || slot >= e->cfg.max_batch) return fail(e, NTTS_EINVAL, "bad slot");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HostSlot& s = e->slots[slot];
+    for (int pg : s.pages) e->free_pages.push_back(pg);
+    s.pages.clear();
+    s.state = SLOT_FREE;
+    const int zero = SLOT_FREE;
+    HIPCHK(e, hipMemcpy(e->sl.state + slot, &zero, sizeof(int), hipMemcpyHostToDevice));
+    return NTTS_OK;
+}
+
+extern "C" int ntts_backbone_set_debug(ntts_backbone* e, int32_t keep_logits) {
+    if (!e) return NTTS_EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (keep_logits && !e->logits) {
+        HIPCHK(e, hipMalloc((void**)&e->logits, (size_t)e->cfg.max_batch * e->cfg.vocab_size * sizeof(float)));
+        HIPCHK(e, hipMemset(e->logits, 0, (size_t)e->cfg.max_batch * e->cfg.vocab_size * sizeof(float)));
+    } else if (!keep_logits && e->logits) {
+        HIPCHK(e, hipFree(e->logits));
+        e->logits = nullptr;
+    }
+    if (e->graph) { hipGraphExecDestroy(e->graph); e->graph = nullptr; }
+    e->graph_tried = false;  // the logits pointer is baked into the captured step
+    return NTTS_OK;
+}
+
+extern "C" int ntts_backbone_read_logits(ntts_backbone* e, int32_t slot, float* out, int32_t n) {
+    if (!e || !out || slot < 0 || slot >= e->cfg.max_batch) return NTTS_EINVAL;
+    if (!e->logits) return fail(e, NTTS_ESTATE, "logits are not kept: call ntts_backbone_set_debug(e, 1) first");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (n > e->cfg.vocab_size) n = e->cfg.vocab_size;
+    HIPCHK(e, hipMemcpy(out, e->logits + (size_t)slot * e->cfg.vocab_size, n * sizeof(float), hipMemcpyDeviceToHost));
+    return NTTS_OK;
+}
+
+extern "C" int ntts_backbone_last_timing(ntts_backbone* e, float* prefill_ms, float* decode_ms) {
+    if (!e) return NTTS_EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (prefill_ms) { *prefill_ms = 0; if (e->have_pf_time) HIPCHK(e, hipEventElapsedTime(prefill_ms, e->ev[0], e->ev[1])); }
+    if (decode_ms) { *decode_ms = 0; if (e->have_dec_time) HIPCHK(e, hipEventElapsedTime(decode_ms, e->ev[2], e->ev[3])); }
+    return NTTS_OK;
+}
+
+extern "C" int ntts_backbone_step_bytes(ntts_backbone* e, double* bytes) {
+    if (!e || !bytes) return NTTS_EINVAL;
+    const ntts_backbone_config& c = e->cfg;
+    const int B = c.max_batch;
+    std::vector<int> st(B), pos(B);
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(st.data(), e->sl.state, B * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(pos.data(), e->sl.pos, B * sizeof(int), hipMemcpyDeviceToHost));
+    const double H = e->H, F = e->F, QD = c.num_heads * 64, KD = c.num_kv_heads * 64;
+    const double per_layer = (QD + 2 * KD) * H + (QD + 2 * KD) + H * QD + 3 * F * H + 2 * H;
+    const double w_layers = (per_layer * c.num_layers + H) * 2.0, w_head = (double)c.vocab_size * H * 2.0;
+    const double kv_tok = (double)c.num_layers * 2 * KD * 2.0;  // bytes per cached token (K+V, all layers)
+    double kv = 0;
+    for (int b = 0; b < B; ++b)
+        if (st[b] == SLOT_RUNNING) kv += (double)pos[b] * kv_tok + kv_tok;  // read L tokens, write 1
+    *bytes = w_layers + w_head + kv;
+    return NTTS_OK;
+}

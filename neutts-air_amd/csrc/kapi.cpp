@@ -1,0 +1,69 @@
+// kapi.cpp -- kernel-level C entry points (parity tests, micro-benchmarks).  Device pointers in,
+// NULL stream, blocking.  See include/neutts_hip.h.
+#include <ntts/dev.h>
+
+#include "../../include/neutts_hip.h"
+#include "kernels/gemm.h"
+#include "kernels/norm.h"
+
+using namespace ntts;
+
+extern "C" int ntts_k_gemm_bf16(const void* A, int64_t lda, const void* W, const void* bias, void* C, int64_t ldc,
+                                int32_t M, int32_t N, int32_t K, int32_t variant) {
+    if (!A || !W || !C || M < 1 || N < 1 || K < 64 || (K % 64) || (lda % 8) || (ldc % 8)) return NTTS_EINVAL;
+    GemmArgs a{};
+    a.X = (const bf16_t*)A; a.ldx = lda; a.W = (const bf16_t*)W; a.ldw = K; a.bias = (const bf16_t*)bias;
+    a.out = C; a.ldo = ldc; a.M = M; a.N = N; a.K = K;
+    if (variant == 0) variant = M > 64 ? 1 : 2;
+    if (variant == 1) NTTS_GEMM_L(EPI_BF16, a, 1, (hipStream_t)0);
+    else if (variant == 2) NTTS_GEMM_S(EPI_BF16, a, 1, (hipStream_t)0);
+    else if (variant == 3) {  // split-K slabs reduced by the norm kernel (the decode o_proj / down_proj path)
+        if (bias || (N % 16) || ldc != N) return NTTS_EINVAL;
+        const int ks = 4, ns = gemm_nsplit(K, ks);
+        float* slabs = nullptr;
+        if (hipMalloc((void**)&slabs, (size_t)ns * M * N * sizeof(float)) != hipSuccess) return NTTS_ENOMEM;
+        a.out = slabs; a.ldo = N;
+        NTTS_GEMM_S(EPI_SPLITK, a, ks, (hipStream_t)0);
+        NormArgs n{};
+        n.slabs = slabs; n.nslab = ns; n.slab_rows = M; n.resid_out = (bf16_t*)C; n.M = M; n.H = N;
+        add_rmsnorm_launch(n, (hipStream_t)0);
+        if (hipDeviceSynchronize() != hipSuccess) { hipFree(slabs); return NTTS_EHIP; }
+        hipFree(slabs);
+    } else return NTTS_EINVAL;
+    if (hipDeviceSynchronize() != hipSuccess) return NTTS_EHIP;
+    return hipGetLastError() == hipSuccess ? NTTS_OK : NTTS_EHIP;
+}
+
+extern "C" int ntts_k_rmsnorm_bf16(const void* x, const void* w, void* y, int32_t rows, int32_t cols, float eps) {
+    if (!x || !w || !y || rows < 1 || cols < 8 || (cols % 8) || cols > 2048) return NTTS_EINVAL;
+    NormArgs n{};
+    n.o_bf16 = (const bf16_t*)x; n.norm_w = (const bf16_t*)w; n.normed_out = (bf16_t*)y; n.M = rows; n.H = cols; n.eps = eps;
+    add_rmsnorm_launch(n, (hipStream_t)0);
+    if (hipDeviceSynchronize() != hipSuccess) return NTTS_EHIP;
+    return hipGetLastError() == hipSuccess ? NTTS_OK : NTTS_EHIP;
+}
+
+NTTS_KERNEL(256) void membw_copy_kernel(const u32x4* src, u32x4* dst, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+
+extern "C" int ntts_k_membw(size_t bytes, int32_t iters, double* gbps) {
+    if (!gbps || bytes < 4096 || iters < 1) return NTTS_EINVAL;
+    void *a = nullptr, *b = nullptr;
+    if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) { if (a) hipFree(a); return NTTS_ENOMEM; }
+    hipMemset(a, 1, bytes);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const long n = bytes / 16;
+    NTTS_LAUNCH((membw_copy_kernel), dim3(2048), dim3(256), (hipStream_t)0, (const u32x4*)a, (u32x4*)b, n);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i) NTTS_LAUNCH((membw_copy_kernel), dim3(2048), dim3(256), (hipStream_t)0, (const u32x4*)a, (u32x4*)b, n);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    *gbps = ms > 0 ? 2.0 * (double)(n * 16) * iters / (ms * 1e-3) / 1e9 : 0;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(a); hipFree(b);
+    return hipDeviceSynchronize() == hipSuccess ? NTTS_OK : NTTS_EHIP;
+}

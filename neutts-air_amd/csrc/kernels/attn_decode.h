@@ -1,0 +1,235 @@
+// attn_decode.h -- one decode step of GQA attention over the paged KV cache, RoPE + cache append fused.
+//
+// Replaces, for q_len = 1 (hf:models/qwen2/modeling_qwen2.py):
+//   apply_rotary_pos_emb :113-135   DynamicCache.update hf:cache_utils.py:127-146
+//   eager_attention_forward :150-172  (bf16(QK^T) * scaling -> softmax fp32 -> bf16 -> PV, bf16 out)
+//
+// One workgroup (4 waves) per (sequence, kv-head): the 7 query heads of a GQA group share every K/V
+// byte that is read, so KV traffic is the algorithmic minimum  L * 2 * 64 * 2 B  per (seq, kv-head, layer).
+// Layout in HBM (per layer):   K  [page][kv_head][32 tokens][64 d]     (a page-head is 4 KB contiguous)
+//                              V^T[page][kv_head][64 d][32 tokens]     (so PV's B-operand is k-contiguous)
+// Matrix-core mapping: S^T = K Q^T with A = K tile (16 keys x 32 d), B = Q^T (group heads padded to 16):
+// the accumulator then holds 4 consecutive keys of ONE head per lane, which is already the A-operand
+// shape PV needs (k-slot e<4 -> key g*4+e, e>=4 -> key 16+g*4+e-4 of the 32-key page) -- no cross-lane
+// traffic between the two MFMAs; V^T is loaded with the same key permutation.
+// Scores are rounded to bf16 (the eager contract) and parked in LDS, so K is streamed exactly once.
+#pragma once
+#include <ntts/dev.h>
+
+namespace ntts {
+
+constexpr int kPage = 32;        // tokens per KV page  (== NTTS_PAGE_TOKENS)
+constexpr int kAttnLMax = 2048;  // ref:neutts/neutts.py:85 max_context
+constexpr int kGroupMax = 8;     // query heads per kv head handled by one workgroup
+
+struct AttnDecodeArgs {
+    const bf16_t* qkv;     // [B][ld_qkv]: q heads | k heads | v heads, bias already added
+    long ld_qkv;
+    bf16_t* out;           // [B][nh*64]
+    long ld_out;
+    bf16_t* kpool;         // this layer
+    bf16_t* vpool;
+    const int* block_table;  // [B][max_pages]
+    int max_pages;
+    const int* pos;        // [B] tokens already cached == position of the token being decoded
+    const int* state;      // [B] 1 = running
+    const bf16_t* rope_cos;  // [max_ctx][32] bf16 (cos(emb) rounded to bf16 like HF's cos.to(dtype))
+    const bf16_t* rope_sin;
+    int nh, nkv;
+};
+
+// bf16 RoPE of one (x1 = x[i], x2 = x[i+32]) pair: q*cos + rotate_half(q)*sin, every op rounded
+NTTS_D void rope_pair(float x1, float x2, float c, float s, float& o1, float& o2) {
+    o1 = rbf(rbf(x1 * c) + rbf(-x2 * s));
+    o2 = rbf(rbf(x2 * c) + rbf(x1 * s));
+}
+
+NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
+    NTTS_SHARED bf16_t sc[kGroupMax][kAttnLMax + 16];   // rounded scores, 33 KB; +32 B/row de-aliases the LDS banks
+    NTTS_SHARED bf16_t qs[16][64];
+    NTTS_SHARED bf16_t knew[64];
+    NTTS_SHARED bf16_t vnew[64];
+    NTTS_SHARED float wred[4][kGroupMax];
+    NTTS_SHARED float rowmax[kGroupMax];
+    NTTS_SHARED float rowsum[kGroupMax];
+    NTTS_SHARED float ored[4][kGroupMax][64];
+
+    const int b = blockIdx.x, kvh = blockIdx.y;
+    if (p.state[b] != 1) return;  // block-uniform
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int g = lane >> 4, l15 = lane & 15;
+    const int group = p.nh / p.nkv;
+    const int P = p.pos[b];
+    const int L = P + 1;
+    const int npages = (L + kPage - 1) / kPage;
+    const int last_page = npages - 1;
+    const int* bt = p.block_table + (long)b * p.max_pages;
+    const bf16_t* row = p.qkv + (long)b * p.ld_qkv;
+
+    // ---- prologue: RoPE(q), RoPE(k) + append k, v to the cache (and keep them in LDS for this step)
+    for (int t = tid; t < (group + 1) * 32; t += 256) {
+        const int hh = t >> 5, i = t & 31;
+        const float c = bf2f(p.rope_cos[(long)P * 32 + i]), s = bf2f(p.rope_sin[(long)P * 32 + i]);
+        float o1, o2;
+        if (hh < group) {
+            const bf16_t* q = row + (kvh * group + hh) * 64;
+            rope_pair(bf2f(q[i]), bf2f(q[i + 32]), c, s, o1, o2);
+            qs[hh][i] = f2bf(o1);
+            qs[hh][i + 32] = f2bf(o2);
+        } else {
+            const bf16_t* k = row + (p.nh + kvh) * 64;
+            const bf16_t* v = row + (p.nh + p.nkv + kvh) * 64;
+            rope_pair(bf2f(k[i]), bf2f(k[i + 32]), c, s, o1, o2);
+            const bf16_t k1 = f2bf(o1), k2 = f2bf(o2), v1 = v[i], v2 = v[i + 32];
+            knew[i] = k1; knew[i + 32] = k2; vnew[i] = v1; vnew[i + 32] = v2;
+            const long pg = bt[P / kPage];
+            const int slot = P % kPage;
+            bf16_t* kd = p.kpool + ((pg * p.nkv + kvh) * kPage + slot) * 64;
+            kd[i] = k1; kd[i + 32] = k2;
+            bf16_t* vd = p.vpool + (pg * p.nkv + kvh) * 64 * kPage + slot;
+            vd[(long)i * kPage] = v1; vd[(long)(i + 32) * kPage] = v2;
+        }
+    }
+    for (int t = tid; t < (16 - group) * 64; t += 256) qs[group + t / 64][t % 64] = 0;
+    sync();
+
+    bf16x8 qB[2];
+    qB[0] = ld16<bf16x8>(&qs[l15][g * 16]);
+    qB[1] = ld16<bf16x8>(&qs[l15][g * 16 + 8]);
+
+    // ---- pass 1: S^T = K Q^T per 16-key sub-tile, bf16-rounded scores -> LDS, running max
+    float lmax = -INFINITY;
+    auto load_k = [&](int pg, bf16x8 (&k)[2][2]) {
+        const bf16_t* kp = p.kpool + ((long)bt[pg] * p.nkv + kvh) * kPage * 64;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bf16_t* kr = kp + (u * 16 + l15) * 64 + g * 16;
+            k[u][0] = ld16<bf16x8>(kr);
+            k[u][1] = ld16<bf16x8>(kr + 8);
+        }
+    };
+    bf16x8 kc[2][2], kn[2][2];
+    if (w < npages) load_k(w, kc);
+    for (int pg = w; pg < npages; pg += 4) {
+        if (pg + 4 < npages) load_k(pg + 4, kn);
+        if (pg == last_page) {  // the token appended this step comes from LDS, not from HBM
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (pg * kPage + u * 16 + l15 == P) {
+                    kc[u][0] = ld16<bf16x8>(&knew[g * 16]);
+                    kc[u][1] = ld16<bf16x8>(&knew[g * 16 + 8]);
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = mfma16(kc[u][0], qB[0], a);
+            a = mfma16(kc[u][1], qB[1], a);
+            const int key0 = pg * kPage + u * 16 + g * 4;
+            bf16x4 sv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = rbf(rbf(a[r]) * 0.125f);   // matmul out (bf16) * scaling (bf16)
+                if (key0 + r >= L) s = -INFINITY;
+                lmax = fmaxf(lmax, s);
+                sv[r] = (short)f2bf(s);
+            }
+            if (l15 < kGroupMax) *(bf16x4*)&sc[l15][key0] = sv;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { kc[u][0] = kn[u][0]; kc[u][1] = kn[u][1]; }
+    }
+    lmax = fmaxf(lmax, shfl_xor(lmax, 16));
+    lmax = fmaxf(lmax, shfl_xor(lmax, 32));
+    if (g == 0 && l15 < kGroupMax) wred[w][l15] = lmax;
+    sync();
+    if (tid < kGroupMax) rowmax[tid] = fmaxf(fmaxf(wred[0][tid], wred[1][tid]), fmaxf(wred[2][tid], wred[3][tid]));
+    sync();
+
+    // ---- softmax denominator in fp32 (32 threads per head)
+    {
+        const int hh = tid >> 5, i = tid & 31;
+        float sum = 0.f;
+        if (hh < kGroupMax) {
+            const float m = rowmax[hh];
+            for (int key = i; key < L; key += 32) sum += fexp(bf2f(sc[hh][key]) - m);
+        }
+#pragma unroll
+        for (int sh = 1; sh < 32; sh <<= 1) sum += shfl_xor(sum, sh);
+        if (i == 0 && hh < kGroupMax) rowsum[hh] = sum;
+    }
+    sync();
+
+    // ---- pass 2: O = P V with P = bf16(exp(s - m) / sum)
+    f32x4 oacc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) oacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float m_l = l15 < kGroupMax ? rowmax[l15] : 0.f;
+    const float sum_l = l15 < kGroupMax ? rowsum[l15] : 1.f;
+    auto load_v = [&](int pg, bf16x4 (&v)[4][2]) {
+        const bf16_t* vp = p.vpool + ((long)bt[pg] * p.nkv + kvh) * 64 * kPage;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const bf16_t* vr = vp + (nt * 16 + l15) * kPage + g * 4;
+            v[nt][0] = ld16<bf16x4>(vr);
+            v[nt][1] = ld16<bf16x4>(vr + 16);
+        }
+    };
+    bf16x4 vc[4][2], vn[4][2];
+    if (w < npages) load_v(w, vc);
+    for (int pg = w; pg < npages; pg += 4) {
+        if (pg + 4 < npages) load_v(pg + 4, vn);
+        bf16x8 pA;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pA[e] = 0;
+        if (l15 < kGroupMax) {
+            const bf16x4 s0 = *(const bf16x4*)&sc[l15][pg * kPage + g * 4];
+            const bf16x4 s1 = *(const bf16x4*)&sc[l15][pg * kPage + 16 + g * 4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pA[e] = (short)f2bf(fexp(bf2f((bf16_t)s0[e]) - m_l) / sum_l);
+                pA[4 + e] = (short)f2bf(fexp(bf2f((bf16_t)s1[e]) - m_l) / sum_l);
+            }
+        }
+        if (pg == last_page) {  // new token's V from LDS; nothing beyond it may leak in (0 * garbage)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int key = pg * kPage + (e < 4 ? g * 4 + e : 16 + g * 4 + e - 4);
+                    short val = e < 4 ? vc[nt][0][e] : vc[nt][1][e - 4];
+                    if (key == P) val = (short)vnew[nt * 16 + l15];
+                    if (key > P) val = 0;
+                    if (e < 4) vc[nt][0][e] = val; else vc[nt][1][e - 4] = val;
+                }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            bf16x8 vB;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { vB[e] = vc[nt][0][e]; vB[4 + e] = vc[nt][1][e]; }
+            oacc[nt] = mfma16(pA, vB, oacc[nt]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) { vc[nt][0] = vn[nt][0]; vc[nt][1] = vn[nt][1]; }
+    }
+    // D: col = d (l15 within tile nt), row = head g*4 + r
+    if (g < 2) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ored[w][g * 4 + r][nt * 16 + l15] = oacc[nt][r];
+    }
+    sync();
+    for (int t = tid; t < group * 64; t += 256) {
+        const int hh = t >> 6, d = t & 63;
+        const float o = ored[0][hh][d] + ored[1][hh][d] + ored[2][hh][d] + ored[3][hh][d];
+        p.out[(long)b * p.ld_out + (kvh * group + hh) * 64 + d] = f2bf(o);
+    }
+}
+
+inline void attn_decode_launch(const AttnDecodeArgs& p, int batch, hipStream_t s) {
+    NTTS_LAUNCH((attn_decode_kernel), dim3(batch, p.nkv), dim3(256), s, p);
+}
+
+}  // namespace ntts

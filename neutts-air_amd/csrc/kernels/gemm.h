@@ -1,0 +1,287 @@
+// gemm.h -- bf16 "NT" GEMM on the gfx950 matrix cores:  out[M,N] = X[M,K] * W[N,K]^T  (+ epilogue)
+//
+// Replaces every nn.Linear on the path (hf:models/qwen2/modeling_qwen2.py:46-48,206-208,233,464-465;
+// hf:models/xcodec2/modeling_xcodec2.py linears and, through overlapping rows, its Conv1d's).
+// Rounding contract of an nn.Linear in bf16: fp32 accumulate, bias added in fp32, ONE rounding to bf16.
+//
+// Structure (MI355X-first, cdna_hip_programming.md section 5):
+//   * block = WM x WN waves; the wave tile is (TM*16) rows of M  x  64 rows of W (= 64 output columns).
+//   * operands are SWAPPED on the matrix core: A-operand = W fragment (rows = output features),
+//     B-operand = X fragment (cols = tokens).  With W rows stored in LDS "tile-major"
+//     (LDS row j*16 + g*4 + r  <->  feature g*16 + j*4 + r of the wave's 64) each lane ends up owning
+//     16 CONSECUTIVE output features of one token, so the epilogue stores 32 contiguous bytes per lane
+//     and a wave store covers full 128-byte lines (instead of 2-byte scatters of the natural C layout).
+//   * K is consumed in tiles of 64 (= one 128-byte line per row).  Tiles are brought in by LDS-DMA
+//     (global_load_lds_dwordx4): 8 rows x 128 B per wave-instruction, destination lane-linear, bank
+//     conflicts removed by swizzling the SOURCE chunk (c ^ ((row>>1)&7)) and applying the same
+//     involution on the ds_read_b128 side (rule 21 of the guide).  Two LDS buffers, one barrier/tile:
+//     the DMA of tile t+1 is in flight under the MFMAs of tile t.
+//   * blockIdx -> tile mapping is XCD-aware (8 XCDs, private L2s): each XCD walks a contiguous chunk
+//     of a grouped (8 m-blocks x all n-blocks) order so co-resident blocks share W and X panels in L2.
+//   * split-K (gridDim.y) writes fp32 slabs that the consumer kernel reduces (no in-launch hand-off).
+#pragma once
+#include <ntts/dev.h>
+
+namespace ntts {
+
+enum GemmEpi {
+    EPI_BF16 = 0,      // out bf16 [M][N] = bf16(acc + bias)
+    EPI_SILU_MUL = 1,  // W rows packed gate/up (see pack_gate_up); out bf16 [M][N/2] = silu(g)*u, HF rounding
+    EPI_SPLITK = 2,    // out fp32 [split][M][N] raw partial sums
+    EPI_ARGMAX = 3,    // per-row (max, first index) partials over this wave's 64 columns, logits = bf16(acc)
+    EPI_BF16_SILU = 4, // out bf16 = silu(bf16(acc + bias))   (codec MLP fc1)
+    EPI_F32 = 5        // out fp32 [M][N] = acc + bias (no rounding; codec ISTFT head / DFT)
+};
+
+struct GemmArgs {
+    const bf16_t* X;
+    long ldx;
+    const bf16_t* W;
+    long ldw;
+    const bf16_t* bias;  // [N] or nullptr
+    void* out;
+    long ldo;
+    int M, N, K;  // K % 64 == 0
+    int k_tiles_per_split;
+    int mblocks, nblocks;
+    // EPI_ARGMAX
+    float* part_val;
+    int* part_idx;
+    int part_stride;       // partials per row = nblocks * WN
+    const int* mask_eos;   // [M] value e+1 > 0 -> logit[e] = -inf for that row (MinNewTokens processor)
+    float* logits;         // optional fp32 [M][ld_logits] dump of the processed logits
+    long ld_logits;
+};
+
+NTTS_D void gemm_tile_coords(int bid, int mblocks, int nblocks, int& mb, int& nb) {
+    const int ntiles = mblocks * nblocks;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;  // bijective XCD chunking
+    const int GM = 8;
+    const int per_group = GM * nblocks;
+    const int g = t / per_group;
+    const int first_m = g * GM;
+    const int gsz = (mblocks - first_m) < GM ? (mblocks - first_m) : GM;
+    const int in = t - g * per_group;
+    mb = first_m + in % gsz;
+    nb = in / gsz;
+}
+
+NTTS_D float silu_f(float x) { return x / (1.0f + fexp(-x)); }
+
+template <int WM, int WN, int TM, int EPI>
+NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
+    constexpr int BM = WM * TM * 16, BN = WN * 64, NW = WM * WN;
+    constexpr int ROWS = BM + BN;              // LDS rows per buffer, 64 bf16 (128 B) each
+    constexpr int NINST = ROWS / 8;            // wave-instructions per K tile
+    static_assert(NINST % NW == 0, "loader split");
+    constexpr int PER_WAVE = NINST / NW;
+    NTTS_SHARED bf16_t lds[2 * ROWS * 64];
+
+    const int lane = lane_id(), wave = wave_id();
+    const int wm = wave / WN, wn = wave % WN;
+    const int g = lane >> 4, l15 = lane & 15;
+    int mb, nb;
+    gemm_tile_coords(blockIdx.x, p.mblocks, p.nblocks, mb, nb);
+    const int m0 = mb * BM, n0 = nb * BN;
+    const int ktiles = p.K >> 6;
+    const int kt0 = blockIdx.y * p.k_tiles_per_split;
+    int nk = ktiles - kt0;
+    if (nk > p.k_tiles_per_split) nk = p.k_tiles_per_split;
+
+    // ---- loader set-up: which global row feeds each of this lane's LDS-DMA pieces
+    const bf16_t* src[PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int inst = wave + i * NW;
+        const int rho = inst * 8 + (lane >> 3);         // LDS row
+        const int c = (lane & 7) ^ ((rho >> 1) & 7);    // logical 16-byte chunk stored at physical lane&7
+        if (rho < BM) {
+            int m = m0 + rho;
+            if (m > p.M - 1) m = p.M - 1;
+            src[i] = p.X + (long)m * p.ldx + c * 8;
+        } else {
+            const int q = rho - BM;                      // tile-major W row: q = wq*64 + j*16 + i16
+            const int wq = q >> 6, j = (q >> 4) & 3, i16 = q & 15;
+            int n = n0 + wq * 64 + (i16 >> 2) * 16 + j * 4 + (i16 & 3);
+            if (n > p.N - 1) n = p.N - 1;
+            src[i] = p.W + (long)n * p.ldw + c * 8;
+        }
+    }
+    auto stage = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int inst = wave + i * NW;
+            glds16(src[i] + (long)(kt0 + kt) * 64, lds + buf * (ROWS * 64) + inst * 512);
+        }
+    };
+
+    f32x4 acc[TM][4];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment read offsets (elements), swizzle involution on the read side
+    int xoff[TM], woff[4], xsw[TM], wsw[4];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const int rho = wm * TM * 16 + a * 16 + l15;
+        xoff[a] = rho * 64;
+        xsw[a] = (rho >> 1) & 7;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rho = BM + wn * 64 + j * 16 + l15;
+        woff[j] = rho * 64;
+        wsw[j] = (rho >> 1) & 7;
+    }
+
+    if (nk > 0) stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        wait_vmem();
+        sync();  // tile kt landed for every wave; everyone is done reading the other buffer
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        const bf16_t* base = lds + (kt & 1) * (ROWS * 64);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int c = ks * 4 + g;
+            bf16x8 xb[TM], wa[4];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) xb[a] = ld16<bf16x8>(base + xoff[a] + ((c ^ xsw[a]) << 3));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wa[j] = ld16<bf16x8>(base + woff[j] + ((c ^ wsw[j]) << 3));
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[a][j] = mfma16(wa[j], xb[a], acc[a][j]);
+        }
+    }
+
+    // ---- epilogue: lane owns token m (per a) x features nb16 .. nb16+15  (acc[a][j][r] <-> nb16 + j*4 + r)
+    const int nb16 = n0 + wn * 64 + g * 16;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const int m = m0 + wm * TM * 16 + a * 16 + l15;
+        const bool mok = m < p.M;
+        if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_SILU) {
+            alignas(16) bf16_t o[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = nb16 + j * 4 + r;
+                    float v = acc[a][j][r];
+                    if (p.bias && n < p.N) v += bf2f(p.bias[n]);
+                    if constexpr (EPI == EPI_BF16_SILU) v = silu_f(rbf(v));
+                    o[j * 4 + r] = f2bf(v);
+                }
+            if (mok) {
+                bf16_t* dst = (bf16_t*)p.out + (long)m * p.ldo + nb16;
+                if (nb16 + 16 <= p.N) {
+                    *(u32x4*)dst = *(u32x4*)&o[0];
+                    *(u32x4*)(dst + 8) = *(u32x4*)&o[8];
+                } else {
+                    for (int e = 0; e < 16; ++e)
+                        if (nb16 + e < p.N) dst[e] = o[e];
+                }
+            }
+        } else if constexpr (EPI == EPI_F32) {
+            if (mok) {
+                float* dst = (float*)p.out + (long)m * p.ldo + nb16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = nb16 + j * 4 + r;
+                        if (n < p.N) dst[j * 4 + r] = acc[a][j][r] + (p.bias ? bf2f(p.bias[n]) : 0.f);
+                    }
+            }
+        } else if constexpr (EPI == EPI_SILU_MUL) {
+            // packed rows: j = 0,1 -> gate features fb + j*4 + r ; j = 2,3 -> up of the same features
+            alignas(16) bf16_t o[8];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gt = rbf(acc[a][jj][r]);          // gate_proj output (bf16)
+                    const float up = rbf(acc[a][jj + 2][r]);      // up_proj output (bf16)
+                    const float s = rbf(silu_f(gt));              // act_fn output (bf16)
+                    o[jj * 4 + r] = f2bf(s * up);                 // product (bf16)
+                }
+            if (mok) {
+                const int fb = ((n0 + wn * 64) >> 1) + g * 8;
+                if (fb + 8 <= (p.N >> 1)) *(u32x4*)((bf16_t*)p.out + (long)m * p.ldo + fb) = *(u32x4*)&o[0];
+            }
+        } else if constexpr (EPI == EPI_SPLITK) {
+            if (mok && nb16 + 16 <= p.N) {
+                float* dst = (float*)p.out + ((long)blockIdx.y * p.M + m) * p.ldo + nb16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *(f32x4*)(dst + j * 4) = acc[a][j];
+            }
+        } else if constexpr (EPI == EPI_ARGMAX) {
+            float best = -INFINITY;
+            int bidx = 0x7fffffff;
+            const int meos = (mok && p.mask_eos) ? p.mask_eos[m] : 0;   // eos id + 1, or 0
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = nb16 + j * 4 + r;
+                    float v = rbf(acc[a][j][r]);                  // lm_head output is bf16, then .float()
+                    if (n == meos - 1) v = -INFINITY;
+                    if (n < p.N) {
+                        if (mok && p.logits) p.logits[(long)m * p.ld_logits + n] = v;
+                        if (v > best) { best = v; bidx = n; }      // ascending n + strict '>' = first max wins
+                    }
+                }
+#pragma unroll
+            for (int sh = 16; sh <= 32; sh <<= 1) {
+                const float ov = shfl_xor(best, sh);
+                const int oi = shfl_xor(bidx, sh);
+                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+            }
+            if (mok && g == 0) {
+                const long pi = (long)m * p.part_stride + nb * WN + wn;
+                p.part_val[pi] = best;
+                p.part_idx[pi] = bidx;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host launchers
+// ------------------------------------------------------------------------------------------------
+struct GemmShape { int BM, BN, WN; };
+
+template <int WM, int WN, int TM, int EPI>
+inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
+    constexpr int BM = WM * TM * 16, BN = WN * 64;
+    p.mblocks = (p.M + BM - 1) / BM;
+    p.nblocks = (p.N + BN - 1) / BN;
+    const int ktiles = p.K / 64;
+    if (ksplit < 1) ksplit = 1;
+    if (ksplit > ktiles) ksplit = ktiles;
+    p.k_tiles_per_split = (ktiles + ksplit - 1) / ksplit;
+    const int nsplit = (ktiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
+    if constexpr (EPI == EPI_ARGMAX) p.part_stride = p.nblocks * WN;
+    NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI>), dim3(p.mblocks * p.nblocks, nsplit), dim3(WM * WN * 64), s, p);
+}
+
+// tile families:  L = 128x128 (2x2 waves, 64x64 per wave)  -- prefill, lm_head, gate/up, codec
+//                 S = 64x64   (4x1 waves, 16x64 per wave)  -- decode-batch skinny GEMMs (+ split-K)
+#define NTTS_GEMM_L(EPI, p, ks, s) ::ntts::gemm_launch<2, 2, 4, EPI>(p, ks, s)
+#define NTTS_GEMM_S(EPI, p, ks, s) ::ntts::gemm_launch<4, 1, 1, EPI>(p, ks, s)
+
+// number of split-K slabs gemm_launch will produce for (K, ksplit)
+inline int gemm_nsplit(int K, int ksplit) {
+    const int ktiles = K / 64;
+    if (ksplit < 1) ksplit = 1;
+    if (ksplit > ktiles) ksplit = ktiles;
+    const int per = (ktiles + ksplit - 1) / ksplit;
+    return (ktiles + per - 1) / per;
+}
+
+}  // namespace ntts

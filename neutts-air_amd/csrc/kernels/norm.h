@@ -1,0 +1,116 @@
+// norm.h -- residual add + RMSNorm (and the embedding gather), one wave64 per row.
+//
+// Replaces, with their bf16 rounding points:
+//   embed_tokens(ids)                                   hf:models/qwen2/modeling_qwen2.py:356
+//   hidden = residual + hidden                          hf:models/qwen2/modeling_qwen2.py:291,297
+//   Qwen2RMSNorm: w * bf16(x32 * rsqrt(mean(x32^2)+eps)) hf:models/qwen2/modeling_qwen2.py:247-252
+// and is the consumer that reduces a split-K GEMM's fp32 slabs (gemm.h EPI_SPLITK): the sum of
+// the slabs (+bias) is rounded to bf16 once, exactly where the nn.Linear output would be.
+//
+// Memory-bound: every element is read/written once with 16-byte accesses (8 bf16 per lane per chunk).
+#pragma once
+#include <ntts/dev.h>
+
+namespace ntts {
+
+struct NormArgs {
+    // --- the branch input "o" (exactly one of the three):
+    const float* slabs;      // [nslab][slab_rows][H] fp32 split-K partials
+    int nslab;
+    long slab_rows;
+    const bf16_t* o_bf16;    // [*, H] bf16 (already rounded nn.Linear output)
+    const int* gather_ids;   // embedding mode: o = embed[ids[row]]  (then resid_in must be null)
+    const bf16_t* embed;
+    // --- residual stream
+    const bf16_t* resid_in;  // [*, H] or null
+    bf16_t* resid_out;       // [*, H] or null
+    // --- norm
+    const bf16_t* norm_w;    // [H] or null -> no normed output
+    bf16_t* normed_out;      // [*, H]
+    // --- row mapping (prefill tail: gather each prompt's last token into its decode-slot row)
+    const int* in_rows;      // logical row r reads input row in_rows[r]   (null: r)
+    const int* out_rows;     // logical row r writes output row out_rows[r] (null: r)
+    int M, H;
+    float eps;
+};
+
+template <int NCH>  // 16-byte chunks per lane: H <= 512*NCH
+NTTS_KERNEL(256) void add_rmsnorm_kernel(NormArgs p) {
+    const int lane = lane_id();
+    const int row = blockIdx.x * 4 + wave_id();
+    const bool rok = row < p.M;
+    const int r = rok ? row : p.M - 1;           // keep every lane alive for the shuffles
+    const long ri = p.in_rows ? p.in_rows[r] : r;
+    const long ro = p.out_rows ? p.out_rows[r] : r;
+    const int nchunk = p.H >> 3;
+    float v[NCH][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ci = lane + 64 * i;
+        const bool ok = ci < nchunk;
+        const long col = (long)ci * 8;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+        if (ok) {
+            if (p.slabs) {
+                for (int s = 0; s < p.nslab; ++s) {
+                    const float* sp = p.slabs + ((long)s * p.slab_rows + ri) * p.H + col;
+                    const f32x4 a = ld16<f32x4>(sp), b = ld16<f32x4>(sp + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[e] += a[e]; o[4 + e] += b[e]; }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rbf(o[e]);
+            } else {
+                const bf16_t* src = p.gather_ids ? p.embed + (long)p.gather_ids[ri] * p.H + col
+                                                 : p.o_bf16 + ri * p.H + col;
+                const bf16x8 t = ld16<bf16x8>(src);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = bf2f((bf16_t)t[e]);
+            }
+            if (p.resid_in) {
+                const bf16x8 t = ld16<bf16x8>(p.resid_in + ri * p.H + col);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rbf(bf2f((bf16_t)t[e]) + o[e]);
+            }
+            if (p.resid_out && rok) {
+                bf16x8 t;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = (short)f2bf(o[e]);
+                *(bf16x8*)(p.resid_out + ro * p.H + col) = t;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[i][e] = o[e];
+            ss += o[e] * o[e];
+        }
+    }
+    if (!p.norm_w) return;  // wave-uniform
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) ss += shfl_xor(ss, sh);
+    const float inv = frsqrt_exact(ss / (float)p.H + p.eps);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ci = lane + 64 * i;
+        if (ci < nchunk && rok) {
+            const long col = (long)ci * 8;
+            const bf16x8 w = ld16<bf16x8>(p.norm_w + col);
+            bf16x8 t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (short)f2bf(bf2f((bf16_t)w[e]) * rbf(v[i][e] * inv));
+            *(bf16x8*)(p.normed_out + ro * p.H + col) = t;
+        }
+    }
+}
+
+inline void add_rmsnorm_launch(const NormArgs& p, hipStream_t s) {
+    const dim3 grid((p.M + 3) / 4), block(256);
+    if (p.H <= 512) NTTS_LAUNCH((add_rmsnorm_kernel<1>), grid, block, s, p);
+    else if (p.H <= 1024) NTTS_LAUNCH((add_rmsnorm_kernel<2>), grid, block, s, p);
+    else NTTS_LAUNCH((add_rmsnorm_kernel<4>), grid, block, s, p);
+}
+
+}  // namespace ntts

@@ -1,0 +1,64 @@
+// dev.h -- gfx950 device primitives used by every kernel (wave64, MFMA 16x16x32 bf16, LDS-DMA).
+// The kernels only speak this vocabulary, so their logic can also be desk-checked on a CPU by the
+// SIMT emulator under tests/simt_emu/ (test infrastructure, never part of the product build).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NTTS_HD __host__ __device__ __forceinline__
+#define NTTS_D __device__ __forceinline__
+#define NTTS_KERNEL(threads) __global__ __launch_bounds__(threads)
+#define NTTS_SHARED __shared__ __attribute__((aligned(16)))
+
+namespace ntts {
+
+typedef unsigned short bf16_t;  // storage type: bf16 bit pattern
+typedef __attribute__((ext_vector_type(8))) short bf16x8;  // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;   // one MFMA C/D fragment
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+constexpr int kWave = 64;
+
+NTTS_D float bf2f(bf16_t v) { return __builtin_bit_cast(float, (unsigned int)v << 16); }
+// round-to-nearest-even, NaN preserved: lowers to v_cvt_pk_bf16_f32 on gfx950
+NTTS_D bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+// value of a float after one bf16 rounding
+NTTS_D float rbf(float f) { return bf2f(f2bf(f)); }
+
+NTTS_D int lane_id() { return threadIdx.x & 63; }
+NTTS_D int wave_id() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
+
+// D = A(16x32) * B(32x16) + C on the matrix core.  Lane l holds A[row l&15][k (l>>4)*8 .. +7],
+// B[k (l>>4)*8 .. +7][col l&15]; D/C: col l&15, rows (l>>4)*4 + r, r = 0..3.
+NTTS_D f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+NTTS_D float shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
+NTTS_D int shfl_xor(int v, int m) { return __shfl_xor(v, m, 64); }
+NTTS_D float shfl(float v, int src) { return __shfl(v, src, 64); }
+NTTS_D int shfl(int v, int src) { return __shfl(v, src, 64); }
+
+NTTS_D void sync() { __syncthreads(); }
+
+// LDS-DMA: every lane supplies its own 16-byte global source; the wave's 64 pieces land at
+// lds_wave_base + lane*16 (the destination is wave-uniform base + lane-linear, never a scatter).
+NTTS_D void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// all of this wave's outstanding vector-memory ops (incl. LDS-DMA) have landed
+NTTS_D void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+NTTS_D float fexp(float x) { return expf(x); }
+NTTS_D float frsqrt_exact(float x) { return 1.0f / sqrtf(x); }
+
+template <typename T>
+NTTS_D T ld16(const void* p) { return *reinterpret_cast<const T*>(p); }
+
+}  // namespace ntts
+
+// host-side launch: NTTS_LAUNCH((kernel<..>), grid, block, stream, args...)
+#define NTTS_LAUNCH(kern, grid, block, stream, ...) hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__)

@@ -1,0 +1,270 @@
+"""ctypes binding of libneutts_hip.so (include/neutts_hip.h) + thin host-side engine wrappers.
+
+This is the only place the product touches native code.  There is NO CPU fallback: if the
+library is missing it must be built (`python neutts-air_amd/build.py`), and if no gfx950 device is
+present `ntts_backbone_create` fails with NTTS_ENODEV and we raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "libneutts_hip.so")
+
+NTTS_DT_F32, NTTS_DT_BF16, NTTS_DT_I32 = 0, 1, 2
+PAGE_TOKENS = 32
+ERRORS = {-1: "EINVAL", -2: "ENODEV", -3: "ENOMEM", -4: "ESTATE", -5: "EHIP"}
+
+
+class NeuTTSHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libneutts_hip: {ERRORS.get(code, code)}: {msg}")
+        self.code = code
+
+
+class BackboneConfigC(C.Structure):
+    _fields_ = [("vocab_size", C.c_int32), ("hidden_size", C.c_int32), ("intermediate_size", C.c_int32),
+                ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("num_kv_heads", C.c_int32),
+                ("head_dim", C.c_int32), ("rms_eps", C.c_float), ("max_context", C.c_int32),
+                ("max_batch", C.c_int32), ("num_pages", C.c_int32), ("max_prefill_tokens", C.c_int32)]
+
+
+class SamplingC(C.Structure):
+    _fields_ = [("max_length", C.c_int32), ("min_new_tokens", C.c_int32), ("eos_token_id", C.c_int32),
+                ("do_sample", C.c_int32), ("top_k", C.c_int32), ("temperature", C.c_float), ("seed", C.c_uint64)]
+
+
+_LIBS: Dict[str, C.CDLL] = {}
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    path = os.path.abspath(path or os.environ.get("NEUTTS_HIP_LIB", DEFAULT_LIB))
+    if path in _LIBS:
+        return _LIBS[path]
+    if not os.path.exists(path):
+        raise FileNotFoundError(
+            f"{path} not found: build it with `python neutts-air_amd/build.py` (hipcc, gfx950). "
+            "There is no CPU fallback for the NeuTTS hot path.")
+    lib = C.CDLL(path)
+    p, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    sig = {
+        "ntts_abi_version": (C.c_int, []),
+        "ntts_last_error": (C.c_char_p, [p]),
+        "ntts_backbone_create": (C.c_int, [C.POINTER(BackboneConfigC), C.c_int, C.POINTER(p)]),
+        "ntts_backbone_destroy": (None, [p]),
+        "ntts_backbone_load_tensor": (C.c_int, [p, C.c_char_p, p, C.c_int, C.POINTER(i64), C.c_int, C.c_int]),
+        "ntts_backbone_finalize": (C.c_int, [p]),
+        "ntts_backbone_arena": (C.c_int, [p, C.POINTER(p), C.POINTER(C.c_size_t)]),
+        "ntts_backbone_adopt_arena": (C.c_int, [p]),
+        "ntts_backbone_prefill": (C.c_int, [p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(SamplingC)]),
+        "ntts_backbone_decode": (C.c_int, [p, i32]),
+        "ntts_backbone_read": (C.c_int, [p, i32, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(i32)]),
+        "ntts_backbone_poll": (C.c_int, [p, C.POINTER(i32), C.POINTER(i32)]),
+        "ntts_backbone_release": (C.c_int, [p, i32]),
+        "ntts_backbone_sync": (C.c_int, [p]),
+        "ntts_backbone_set_debug": (C.c_int, [p, i32]),
+        "ntts_backbone_read_logits": (C.c_int, [p, i32, C.POINTER(f32), i32]),
+        "ntts_backbone_last_timing": (C.c_int, [p, C.POINTER(f32), C.POINTER(f32)]),
+        "ntts_backbone_step_bytes": (C.c_int, [p, C.POINTER(C.c_double)]),
+        "ntts_k_gemm_bf16": (C.c_int, [p, i64, p, p, p, i64, i32, i32, i32, i32]),
+        "ntts_k_rmsnorm_bf16": (C.c_int, [p, p, p, i32, i32, f32]),
+        "ntts_k_membw": (C.c_int, [C.c_size_t, i32, C.POINTER(C.c_double)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)  # AttributeError here == header/library drift: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _LIBS[path] = lib
+    return lib
+
+
+def _tensor_ptr(t):
+    """(pointer, dtype code, shape, is_device, keepalive) for numpy fp32 / torch fp32|bf16 (cpu|cuda)."""
+    if isinstance(t, np.ndarray):
+        a = np.ascontiguousarray(t, dtype=np.float32)
+        return a.ctypes.data, NTTS_DT_F32, a.shape, 0, a
+    import torch  # plumbing only: tensor containers
+    if isinstance(t, torch.Tensor):
+        tt = t.detach().contiguous()
+        if tt.dtype == torch.bfloat16:
+            code = NTTS_DT_BF16
+        else:
+            tt = tt.to(torch.float32)
+            code = NTTS_DT_F32
+        return tt.data_ptr(), code, tuple(tt.shape), int(tt.is_cuda), tt
+    raise TypeError(f"unsupported tensor type {type(t)}")
+
+
+@dataclass
+class Sampling:
+    """Keyword arguments of the reference's generate() call (ref:neutts/neutts.py:338-347)."""
+    max_length: int = 2048
+    min_new_tokens: int = 50
+    eos_token_id: int = 0
+    do_sample: bool = True
+    top_k: int = 50
+    temperature: float = 1.0
+    seed: int = 0
+
+    def to_c(self) -> SamplingC:
+        return SamplingC(self.max_length, self.min_new_tokens, self.eos_token_id, int(self.do_sample), self.top_k,
+                         self.temperature, self.seed)
+
+
+class BackboneEngine:
+    """One engine per GPU (per process): weights + paged KV + `max_batch` decode slots."""
+
+    def __init__(self, cfg: dict, device: int = 0, lib_path: Optional[str] = None):
+        self.lib = load_library(lib_path)
+        if self.lib.ntts_abi_version() != 1:
+            raise RuntimeError("libneutts_hip ABI mismatch")
+        self.cfg = dict(cfg)
+        c = BackboneConfigC(cfg["vocab_size"], cfg["hidden_size"], cfg["intermediate_size"], cfg["num_layers"],
+                            cfg["num_heads"], cfg["num_kv_heads"], cfg.get("head_dim", 64), cfg.get("rms_eps", 1e-6),
+                            cfg.get("max_context", 2048), cfg.get("max_batch", 1), cfg.get("num_pages", 0),
+                            cfg.get("max_prefill_tokens", 0))
+        h = C.c_void_p()
+        rc = self.lib.ntts_backbone_create(C.byref(c), device, C.byref(h))
+        if rc != 0:
+            raise NeuTTSHipError(rc, (self.lib.ntts_last_error(None) or b"").decode())
+        self.h = h
+        self.max_batch = c.max_batch
+        self.max_context = c.max_context
+        self.vocab_size = c.vocab_size
+
+    # -- plumbing
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise NeuTTSHipError(rc, (self.lib.ntts_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ntts_backbone_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights
+    def load_tensor(self, name: str, t):
+        ptr, code, shape, is_dev, keep = _tensor_ptr(t)
+        shp = (C.c_int64 * len(shape))(*shape)
+        self._chk(self.lib.ntts_backbone_load_tensor(self.h, name.encode(), C.c_void_p(ptr), code, shp, len(shape), is_dev))
+        del keep
+
+    def load_state_dict(self, sd: Dict[str, object], inv_freq=None):
+        """HF Qwen2ForCausalLM state dict (+ rope.inv_freq; computed like hf:...modeling_qwen2.py:86 if absent)."""
+        for k, v in sd.items():
+            if k.endswith("rotary_emb.inv_freq"):
+                continue
+            self.load_tensor(k, v)
+        if inv_freq is None:
+            raise ValueError("inv_freq (fp32 [head_dim/2]) must be supplied: it is a model buffer, not a constant")
+        self.load_tensor("rope.inv_freq", np.asarray(inv_freq, dtype=np.float32))
+        self._chk(self.lib.ntts_backbone_finalize(self.h))
+
+    def arena(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._chk(self.lib.ntts_backbone_arena(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def adopt_arena(self):
+        self._chk(self.lib.ntts_backbone_adopt_arena(self.h))
+
+    # -- requests
+    def prefill(self, prompts: Sequence[Sequence[int]], slots: Sequence[int], sampling: Sequence[Sampling]):
+        n = len(prompts)
+        lens = np.array([len(p) for p in prompts], dtype=np.int32)
+        ids = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.int32) for p in prompts]))
+        sl = np.asarray(slots, dtype=np.int32)
+        sc = (SamplingC * n)(*[s.to_c() for s in sampling])
+        i32p = C.POINTER(C.c_int32)
+        self._chk(self.lib.ntts_backbone_prefill(self.h, n, ids.ctypes.data_as(i32p), lens.ctypes.data_as(i32p),
+                                                 sl.ctypes.data_as(i32p), sc))
+
+    def decode(self, n_steps: int = 1):
+        self._chk(self.lib.ntts_backbone_decode(self.h, n_steps))
+
+    def read(self, slot: int):
+        out = np.empty(self.max_context, dtype=np.int32)
+        n, fin = C.c_int32(), C.c_int32()
+        self._chk(self.lib.ntts_backbone_read(self.h, slot, out.ctypes.data_as(C.POINTER(C.c_int32)), len(out),
+                                              C.byref(n), C.byref(fin)))
+        return out[: n.value].tolist(), bool(fin.value)
+
+    def poll(self):
+        st = np.empty(self.max_batch, dtype=np.int32)
+        nn = np.empty(self.max_batch, dtype=np.int32)
+        i32p = C.POINTER(C.c_int32)
+        self._chk(self.lib.ntts_backbone_poll(self.h, st.ctypes.data_as(i32p), nn.ctypes.data_as(i32p)))
+        return st, nn
+
+    def release(self, slot: int):
+        self._chk(self.lib.ntts_backbone_release(self.h, slot))
+
+    def sync(self):
+        self._chk(self.lib.ntts_backbone_sync(self.h))
+
+    def set_debug(self, keep_logits: bool):
+        self._chk(self.lib.ntts_backbone_set_debug(self.h, int(keep_logits)))
+
+    def read_logits(self, slot: int) -> np.ndarray:
+        out = np.empty(self.vocab_size, dtype=np.float32)
+        self._chk(self.lib.ntts_backbone_read_logits(self.h, slot, out.ctypes.data_as(C.POINTER(C.c_float)), len(out)))
+        return out
+
+    def last_timing(self):
+        a, b = C.c_float(), C.c_float()
+        self._chk(self.lib.ntts_backbone_last_timing(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def step_bytes(self) -> float:
+        d = C.c_double()
+        self._chk(self.lib.ntts_backbone_step_bytes(self.h, C.byref(d)))
+        return d.value
+
+    # -- continuous batching (host scheduler): keep every slot busy until all prompts are done
+    def generate(self, prompts: Sequence[Sequence[int]], sampling, steps_per_poll: int = 16,
+                 prefill_token_budget: Optional[int] = None) -> List[List[int]]:
+        """Batched equivalent of calling ref:neutts/neutts.py:338-351 once per prompt.
+        Returns the NEW ids of each prompt (prompt stripped), in order."""
+        if isinstance(sampling, Sampling):
+            sampling = [sampling] * len(prompts)
+        budget = prefill_token_budget or self.cfg.get("max_prefill_tokens", 0) or 16384
+        results: List[Optional[List[int]]] = [None] * len(prompts)
+        free = list(range(self.max_batch))
+        owner: Dict[int, int] = {}
+        nxt = 0
+        while nxt < len(prompts) or owner:
+            # admit as many waiting prompts as slots / prefill workspace allow
+            while nxt < len(prompts) and free:
+                batch, used = [], 0
+                while nxt < len(prompts) and free and used + len(prompts[nxt]) <= budget:
+                    s = free.pop()
+                    batch.append((nxt, s))
+                    used += len(prompts[nxt])
+                    owner[s] = nxt
+                    nxt += 1
+                if not batch:
+                    if not owner:
+                        raise ValueError("prompt longer than max_prefill_tokens")
+                    break
+                self.prefill([prompts[i] for i, _ in batch], [s for _, s in batch], [sampling[i] for i, _ in batch])
+            st, _ = self.poll()
+            for s in list(owner):
+                if st[s] == 2:  # finished
+                    ids, _ = self.read(s)
+                    results[owner.pop(s)] = ids
+                    self.release(s)
+                    free.append(s)
+            if owner and any(st[s] == 1 for s in owner):
+                self.decode(steps_per_poll)
+        return [r if r is not None else [] for r in results]

@@ -1,0 +1,304 @@
+"""CPU restatement of the NeuTTS backbone hot path (TEST INFRASTRUCTURE, see oracle/__init__.py).
+
+What the reference runs on this path (ref:neutts/neutts.py:334-352):
+    backbone.generate(prompt[1,S], max_length=2048, eos_token_id=<|SPEECH_GENERATION_END|>,
+                      do_sample=True, temperature=1.0, top_k=50, use_cache=True, min_new_tokens=50)
+with backbone = transformers.AutoModelForCausalLM (Qwen2ForCausalLM for NeuTTS-Air).  The
+arithmetic lives in the un-vendored dependency `transformers` (pinned 4.56.1 in
+ref:requirements.txt:8; 5.15.0 installed here).  This file restates it with plain torch CPU
+ops in the same order and with the same rounding points, each function citing the
+transformers file:line (hf: = transformers/) it follows.  tests/test_oracle_pin.py checks it
+bit-for-bit against the real Qwen2ForCausalLM (eager attention), and tests/golden/ holds
+fixtures produced by oracle/gen_golden.py from that same dependency.
+
+Rounding contract: every tensor lives in `dtype` (float32 or
+bfloat16); each torch op therefore rounds exactly where the HF module rounds.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, asdict
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+
+@dataclass(frozen=True)
+class BackboneConfig:
+    vocab_size: int = 217488          # 151 936 base + 65 536 speech + specials
+    hidden_size: int = 896
+    intermediate_size: int = 4864
+    num_layers: int = 24
+    num_heads: int = 14
+    num_kv_heads: int = 2
+    head_dim: int = 64
+    rms_eps: float = 1e-6
+    rope_theta: float = 1e6
+
+    @staticmethod
+    def neutts_air(vocab_size: int = 217488) -> "BackboneConfig":
+        return BackboneConfig(vocab_size=vocab_size)
+
+    @staticmethod
+    def tiny(vocab_size: int = 1024, num_layers: int = 2) -> "BackboneConfig":
+        """Same head geometry (GQA 7:1, d=64) at a size the oracle finishes in milliseconds."""
+        return BackboneConfig(vocab_size=vocab_size, hidden_size=448, intermediate_size=1216,
+                              num_layers=num_layers, num_heads=7, num_kv_heads=1, head_dim=64)
+
+    def to_dict(self):
+        return asdict(self)
+
+
+# --------------------------------------------------------------------------------------
+# deterministic synthetic weights (numpy PCG64: stable across machines / torch versions)
+# --------------------------------------------------------------------------------------
+def make_weights(cfg: BackboneConfig, seed: int = 0, init: str = "unit",
+                 peak_sigma: float = 0.0) -> Dict[str, torch.Tensor]:
+    """HF-named fp32 state dict (hf:models/qwen2/modeling_qwen2.py: names of Qwen2ForCausalLM).
+
+    init="hf":   N(0, 0.02) matrices like HF's `_init_weights`.  With tied
+                 embeddings such a model mostly re-predicts its input token -- a weak id test.
+    init="unit": N(0, 1/fan_in) matrices (unit gain), embedding N(0, 0.02): layer outputs
+                 dominate the residual stream, greedy ids are diverse.  Used for parity + bench.
+    peak_sigma:  multiply embedding row j by exp(N(0, peak_sigma)): heavy-tailed logits whose
+                 top-1/top-2 gap is many bf16 ulps -> free-running greedy ids are comparable
+                 bit-for-bit across implementations with different fp32 summation order.
+    Norm weights are 1 + N(0, 0.1) and biases N(0, 0.02) so every multiply/add is exercised.
+    lm_head is tied to embed_tokens (hf:...modeling_qwen2.py:407 `_tied_weights_keys`).
+    """
+    rng = np.random.default_rng(seed)
+
+    def normal(*shape, s=0.02):
+        return torch.from_numpy(rng.standard_normal(shape, dtype=np.float32) * np.float32(s))
+
+    def mat(n_out, n_in):
+        return normal(n_out, n_in, s=0.02 if init == "hf" else float(n_in) ** -0.5)
+
+    H, F_, nh, nkv, d = cfg.hidden_size, cfg.intermediate_size, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim
+    w: Dict[str, torch.Tensor] = {}
+    emb = normal(cfg.vocab_size, H)
+    if peak_sigma > 0:
+        scale = np.exp(rng.standard_normal(cfg.vocab_size, dtype=np.float32) * np.float32(peak_sigma))
+        emb = emb * torch.from_numpy(scale)[:, None]
+    w["model.embed_tokens.weight"] = emb
+    for i in range(cfg.num_layers):
+        p = f"model.layers.{i}."
+        w[p + "input_layernorm.weight"] = 1.0 + normal(H, s=0.1)
+        w[p + "self_attn.q_proj.weight"] = mat(nh * d, H)
+        w[p + "self_attn.q_proj.bias"] = normal(nh * d)
+        w[p + "self_attn.k_proj.weight"] = mat(nkv * d, H)
+        w[p + "self_attn.k_proj.bias"] = normal(nkv * d)
+        w[p + "self_attn.v_proj.weight"] = mat(nkv * d, H)
+        w[p + "self_attn.v_proj.bias"] = normal(nkv * d)
+        w[p + "self_attn.o_proj.weight"] = mat(H, nh * d)
+        w[p + "post_attention_layernorm.weight"] = 1.0 + normal(H, s=0.1)
+        w[p + "mlp.gate_proj.weight"] = mat(F_, H)
+        w[p + "mlp.up_proj.weight"] = mat(F_, H)
+        w[p + "mlp.down_proj.weight"] = mat(H, F_)
+    w["model.norm.weight"] = 1.0 + normal(H, s=0.1)
+    return w
+
+
+def cast_weights(w: Dict[str, torch.Tensor], dtype: torch.dtype) -> Dict[str, torch.Tensor]:
+    return {k: v.to(dtype) for k, v in w.items()}
+
+
+# --------------------------------------------------------------------------------------
+# modules
+# --------------------------------------------------------------------------------------
+def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    """Qwen2RMSNorm.forward  hf:models/qwen2/modeling_qwen2.py:247-252."""
+    dt = x.dtype
+    x32 = x.to(torch.float32)
+    var = x32.pow(2).mean(-1, keepdim=True)
+    x32 = x32 * torch.rsqrt(var + eps)
+    return weight * x32.to(dt)
+
+
+def rope_inv_freq(cfg: BackboneConfig) -> torch.Tensor:
+    """compute_default_rope_parameters  hf:models/qwen2/modeling_qwen2.py:70-89."""
+    d = cfg.head_dim
+    return 1.0 / (cfg.rope_theta ** (torch.arange(0, d, 2, dtype=torch.float) / d))
+
+
+def rope_cos_sin(cfg: BackboneConfig, positions: torch.Tensor, dtype: torch.dtype):
+    """Qwen2RotaryEmbedding.forward  hf:models/qwen2/modeling_qwen2.py:91-102.
+    positions: int64 [S] -> cos, sin [1, S, d] in `dtype` (fp32 math, then cast)."""
+    inv = rope_inv_freq(cfg)[None, :, None].float()            # [1, d/2, 1]
+    pos = positions[None, None, :].float()                      # [1, 1, S]
+    freqs = (inv @ pos).transpose(1, 2)                         # [1, S, d/2]
+    emb = torch.cat((freqs, freqs), dim=-1)
+    return emb.cos().to(dtype), emb.sin().to(dtype)
+
+
+def rotate_half(x: torch.Tensor) -> torch.Tensor:
+    """hf:models/qwen2/modeling_qwen2.py:105-109."""
+    x1 = x[..., : x.shape[-1] // 2]
+    x2 = x[..., x.shape[-1] // 2:]
+    return torch.cat((-x2, x1), dim=-1)
+
+
+def apply_rope(q, k, cos, sin):
+    """apply_rotary_pos_emb (unsqueeze_dim=1)  hf:models/qwen2/modeling_qwen2.py:113-135."""
+    cos = cos.unsqueeze(1)
+    sin = sin.unsqueeze(1)
+    return (q * cos) + (rotate_half(q) * sin), (k * cos) + (rotate_half(k) * sin)
+
+
+def repeat_kv(x: torch.Tensor, n_rep: int) -> torch.Tensor:
+    """hf:models/qwen2/modeling_qwen2.py:138-147."""
+    b, h, s, d = x.shape
+    if n_rep == 1:
+        return x
+    return x[:, :, None, :, :].expand(b, h, n_rep, s, d).reshape(b, h * n_rep, s, d)
+
+
+def eager_attention(q, k, v, mask, scaling, n_rep):
+    """eager_attention_forward  hf:models/qwen2/modeling_qwen2.py:150-172
+    (the oracle pins attn_implementation="eager": fully specified in Python)."""
+    k = repeat_kv(k, n_rep)
+    v = repeat_kv(v, n_rep)
+    aw = torch.matmul(q, k.transpose(2, 3)) * scaling
+    if mask is not None:
+        aw = aw + mask
+    aw = F.softmax(aw, dim=-1, dtype=torch.float32).to(q.dtype)
+    out = torch.matmul(aw, v)
+    return out.transpose(1, 2).contiguous()
+
+
+def causal_mask(q_len: int, kv_len: int, dtype: torch.dtype) -> Optional[torch.Tensor]:
+    """Additive causal mask as create_causal_mask builds it for the eager path
+    (hf:masking_utils.py: 0 where allowed, finfo.min where masked).  For a single query over a
+    full cache nothing is masked; HF then passes mask=None or all-zeros (same result)."""
+    if q_len == 1:
+        return None
+    past = kv_len - q_len
+    i = torch.arange(q_len)[:, None] + past
+    j = torch.arange(kv_len)[None, :]
+    m = torch.zeros(q_len, kv_len, dtype=dtype)
+    m.masked_fill_(j > i, torch.finfo(dtype).min)
+    return m[None, None]
+
+
+class KVCache:
+    """DynamicLayer.update  hf:cache_utils.py:127-146 -- cat along the sequence axis."""
+
+    def __init__(self, n_layers: int):
+        self.k: List[Optional[torch.Tensor]] = [None] * n_layers
+        self.v: List[Optional[torch.Tensor]] = [None] * n_layers
+
+    def update(self, i, k, v):
+        self.k[i] = k if self.k[i] is None else torch.cat([self.k[i], k], dim=-2)
+        self.v[i] = v if self.v[i] is None else torch.cat([self.v[i], v], dim=-2)
+        return self.k[i], self.v[i]
+
+    def length(self) -> int:
+        return 0 if self.k[0] is None else self.k[0].shape[-2]
+
+
+def decoder_layer(cfg, w, i, h, cos, sin, cache: KVCache, taps=None):
+    """Qwen2DecoderLayer.forward  hf:models/qwen2/modeling_qwen2.py:269-298 with
+    Qwen2Attention.forward :195-234 and Qwen2MLP.forward :46-48 inlined."""
+    p = f"model.layers.{i}."
+    B, S, H = h.shape
+    nh, nkv, d = cfg.num_heads, cfg.num_kv_heads, cfg.head_dim
+    resid = h
+    x = rms_norm(h, w[p + "input_layernorm.weight"], cfg.rms_eps)
+    q = F.linear(x, w[p + "self_attn.q_proj.weight"], w[p + "self_attn.q_proj.bias"]).view(B, S, nh, d).transpose(1, 2)
+    k = F.linear(x, w[p + "self_attn.k_proj.weight"], w[p + "self_attn.k_proj.bias"]).view(B, S, nkv, d).transpose(1, 2)
+    v = F.linear(x, w[p + "self_attn.v_proj.weight"], w[p + "self_attn.v_proj.bias"]).view(B, S, nkv, d).transpose(1, 2)
+    q, k = apply_rope(q, k, cos, sin)
+    kk, vv = cache.update(i, k, v)
+    mask = causal_mask(S, kk.shape[-2], h.dtype)
+    a = eager_attention(q, kk, vv, mask, d ** -0.5, nh // nkv)
+    a = a.reshape(B, S, -1).contiguous()
+    o = F.linear(a, w[p + "self_attn.o_proj.weight"])
+    h = resid + o
+    resid = h
+    x2 = rms_norm(h, w[p + "post_attention_layernorm.weight"], cfg.rms_eps)
+    g = F.linear(x2, w[p + "mlp.gate_proj.weight"])
+    u = F.linear(x2, w[p + "mlp.up_proj.weight"])
+    m = F.linear(F.silu(g) * u, w[p + "mlp.down_proj.weight"])
+    out = resid + m
+    if taps is not None:
+        taps.append(dict(x=x, q=q, k=k, v=v, attn=a, o=o, h_mid=h, x2=x2, act=F.silu(g) * u, mlp=m, h_out=out))
+    return out
+
+
+def model_forward(cfg: BackboneConfig, w, ids: torch.Tensor, cache: KVCache, taps=None) -> torch.Tensor:
+    """Qwen2Model.forward :342-402 + Qwen2ForCausalLM.forward :423-477 (logits of the LAST
+    position only, which is all generate() consumes: hf:generation/utils.py:2894).
+    ids: int64 [1, q].  Returns logits [1, V] in the model dtype."""
+    dtype = w["model.embed_tokens.weight"].dtype
+    past = cache.length()
+    h = F.embedding(ids, w["model.embed_tokens.weight"])
+    pos = torch.arange(past, past + ids.shape[1])
+    cos, sin = rope_cos_sin(cfg, pos, dtype)
+    for i in range(cfg.num_layers):
+        lt = [] if taps is not None else None
+        h = decoder_layer(cfg, w, i, h, cos, sin, cache, lt)
+        if taps is not None:
+            taps.append(lt[0])
+    h = rms_norm(h, w["model.norm.weight"], cfg.rms_eps)
+    return F.linear(h[:, -1, :], w["model.embed_tokens.weight"])  # tied lm_head
+
+
+@dataclass
+class GenResult:
+    ids: List[int]                 # generated ids only (prompt stripped, like ref:neutts/neutts.py:348-351)
+    margins: List[float]           # top1-top2 fp32 logit gap at every step (after EOS masking)
+    logits: Optional[List[torch.Tensor]] = None
+
+
+def generate(cfg: BackboneConfig, w, prompt_ids: List[int], max_length: int, eos_id: int,
+             min_new_tokens: int = 50, do_sample: bool = False, top_k: int = 50,
+             generator: Optional[torch.Generator] = None, keep_logits: bool = False,
+             force_ids: Optional[List[int]] = None) -> GenResult:
+    """GenerationMixin._sample  hf:generation/utils.py:2783-2973, as the reference calls it.
+
+    - logits of the last position are copied to fp32                               (:2894)
+    - MinNewTokensLengthLogitsProcessor: eos=-inf while new tokens < min_new_tokens (hf:generation/logits_process.py:164-236)
+    - greedy: argmax (:2925); sampling: TopK(50) (:542-595) -> softmax -> multinomial (:2920-2923)
+    - stop at EOS or when total length reaches max_length (hf:generation/stopping_criteria.py:58-84,534-582)
+    `force_ids` teacher-forces the continuation (used by the margin-aware parity tests).
+    """
+    cache = KVCache(cfg.num_layers)
+    ids = torch.tensor([list(prompt_ids)], dtype=torch.long)
+    cur = ids
+    out: List[int] = []
+    margins: List[float] = []
+    kept: List[torch.Tensor] = []
+    n_prompt = len(prompt_ids)
+    with torch.no_grad():
+        while n_prompt + len(out) < max_length:
+            logits = model_forward(cfg, w, cur, cache).to(torch.float32)[0].clone()
+            if len(out) < min_new_tokens:
+                logits[eos_id] = -float("inf")
+            top2 = torch.topk(logits, 2).values
+            margins.append(float(top2[0] - top2[1]))
+            if keep_logits:
+                kept.append(logits)
+            if do_sample:
+                kth = torch.topk(logits, min(top_k, logits.numel())).values[-1]
+                sc = logits.masked_fill(logits < kth, -float("inf"))
+                probs = F.softmax(sc, dim=-1)
+                nxt = int(torch.multinomial(probs, 1, generator=generator))
+            else:
+                nxt = int(torch.argmax(logits))
+            # teacher forcing: record the oracle's own choice, feed the forced id
+            nxt_fed = nxt if force_ids is None else int(force_ids[len(out)])
+            out.append(nxt)
+            cur = torch.tensor([[nxt_fed]], dtype=torch.long)
+            if force_ids is None and nxt == eos_id:
+                break
+            if force_ids is not None and len(out) >= len(force_ids):
+                break
+    return GenResult(out, margins, kept if keep_logits else None)
+
+
+def synthetic_prompt(cfg: BackboneConfig, utt_idx: int, length: int = 500) -> List[int]:
+    """randint(0, V) with seed 1234 + utt_idx (numpy PCG64 here so that the
+    GPU box, which has no /root/reference and maybe another torch, draws identical prompts)."""
+    rng = np.random.default_rng(1234 + utt_idx)
+    return rng.integers(0, cfg.vocab_size, size=length, dtype=np.int64).tolist()

@@ -1,0 +1,195 @@
+// SIMT emulator twin of neutts-air_amd/csrc/ntts/dev.h  --  TEST INFRASTRUCTURE ONLY.
+//
+// Compiles the *unchanged* kernel + engine sources for the host CPU so that their indexing,
+// fragment layouts, synchronisation and host logic can be checked against the oracle in the
+// `-m "not gpu"` suite, before any GPU minute is spent.  Each HIP thread is a fiber; wave64
+// collectives (MFMA, shuffles, LDS-DMA) rendezvous the 64 lanes and follow the lane layouts
+// documented for gfx950 (cdna_hip_programming.md section 3).  It is NOT a product path: the
+// library it builds (libneutts_emu.so) lives under tests/ and nothing in neutts-air_amd/
+// loads it; the product library fails loudly without a gfx950 device.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <math.h>
+#include <string.h>
+#include <stdlib.h>
+#include <stdio.h>
+#include <functional>
+
+#define NTTS_EMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define NTTS_HD inline
+#define NTTS_D inline
+#define NTTS_KERNEL(threads) static
+#define NTTS_SHARED static __attribute__((aligned(16)))
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+extern dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+namespace emu {
+void launch(const std::function<void()>& body, dim3 grid, dim3 block);
+void barrier();
+// one rendezvous of the calling lane's wave; returns the double-buffer index (0/1) to use
+struct WaveSlots { alignas(16) unsigned char b[2][64][64]; };
+WaveSlots& wave_slots();
+int wave_parity();          // buffer to DEPOSIT into for the next collective
+void wave_sync();           // all lanes of the wave deposited; flips parity
+int wave_lanes();
+}  // namespace emu
+
+namespace ntts {
+
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+constexpr int kWave = 64;
+
+inline float bf2f(bf16_t v) {
+    uint32_t u = (uint32_t)v << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+inline bf16_t f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+inline float rbf(float f) { return bf2f(f2bf(f)); }
+
+inline int lane_id() { return threadIdx.x & 63; }
+inline int wave_id() { return threadIdx.x >> 6; }
+
+template <typename T>
+inline T emu_exchange(T v, int src_lane) {
+    static_assert(sizeof(T) <= 64, "slot");
+    int p = emu::wave_parity();
+    auto& s = emu::wave_slots();
+    memcpy(s.b[p][lane_id()], &v, sizeof(T));
+    emu::wave_sync();
+    T r;
+    memcpy(&r, s.b[p][src_lane & 63], sizeof(T));
+    return r;
+}
+
+// v_mfma_f32_16x16x32_bf16 with the documented gfx950 layout (see the HIP dev.h).
+// fp32 accumulate, k ascending: the real matrix core's internal order differs, which is exactly
+// the freedom the parity tolerances allow.
+inline f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    struct Dep { bf16x8 a, b; };
+    int p = emu::wave_parity();
+    auto& s = emu::wave_slots();
+    Dep d{a, b};
+    memcpy(s.b[p][lane_id()], &d, sizeof(d));
+    emu::wave_sync();
+    int l = lane_id(), col = l & 15, rg = l >> 4;
+    f32x4 out = c;
+    for (int r = 0; r < 4; ++r) {
+        int row = rg * 4 + r;
+        float acc = c[r];
+        for (int kg = 0; kg < 4; ++kg) {
+            Dep da, db;
+            memcpy(&da, s.b[p][row + 16 * kg], sizeof(Dep));   // lane holding A[row][kg*8..]
+            memcpy(&db, s.b[p][col + 16 * kg], sizeof(Dep));   // lane holding B[kg*8..][col]
+            for (int j = 0; j < 8; ++j)
+                acc += bf2f((bf16_t)da.a[j]) * bf2f((bf16_t)db.b[j]);
+        }
+        out[r] = acc;
+    }
+    return out;
+}
+
+inline float shfl_xor(float v, int m) { return emu_exchange(v, lane_id() ^ m); }
+inline int shfl_xor(int v, int m) { return emu_exchange(v, lane_id() ^ m); }
+inline float shfl(float v, int src) { return emu_exchange(v, src); }
+inline int shfl(int v, int src) { return emu_exchange(v, src); }
+
+inline void sync() { emu::barrier(); }
+
+// LDS-DMA: destination = lane 0's base + lane*16, whatever the other lanes passed (hardware
+// takes the base from M0, i.e. a readfirstlane) -- catches per-lane-destination mistakes.
+inline void glds16(const void* gsrc, void* lds_wave_base) {
+    struct Dep { const void* g; void* l; };
+    int p = emu::wave_parity();
+    auto& s = emu::wave_slots();
+    Dep d{gsrc, lds_wave_base};
+    memcpy(s.b[p][lane_id()], &d, sizeof(d));
+    emu::wave_sync();
+    Dep d0;
+    memcpy(&d0, s.b[p][0], sizeof(d0));
+    memcpy((char*)d0.l + lane_id() * 16, gsrc, 16);
+}
+inline void wait_vmem() {}
+
+inline float fexp(float x) { return expf(x); }
+inline float frsqrt_exact(float x) { return 1.0f / sqrtf(x); }
+
+template <typename T>
+inline T ld16(const void* p) {
+    T v;
+    memcpy(&v, p, sizeof(T));
+    return v;
+}
+
+}  // namespace ntts
+
+#define NTTS_LAUNCH(kern, grid, block, stream, ...) \
+    emu::launch([=]() { kern(__VA_ARGS__); }, grid, block)
+
+// ---------------------------------------------------------------------------------------------
+// minimal HIP runtime facade: device memory is host memory, streams are immediate
+// ---------------------------------------------------------------------------------------------
+typedef int hipError_t;
+typedef void* hipStream_t;
+typedef struct emuEvent { double t; }* hipEvent_t;
+typedef void* hipGraph_t;
+typedef void* hipGraphExec_t;
+enum { hipSuccess = 0, hipErrorNotSupported = 801 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum { hipStreamCaptureModeGlobal = 0, hipStreamNonBlocking = 1 };
+struct hipDeviceProp_t { char gcnArchName[64]; int multiProcessorCount; size_t totalGlobalMem; };
+
+inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+    strcpy(p->gcnArchName, "gfx950:emu"); p->multiProcessorCount = 256; p->totalGlobalMem = 1ull << 34;
+    return hipSuccess;
+}
+inline hipError_t hipMalloc(void** p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256); return *p ? 0 : 2; }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memmove(d, s, n); return 0; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return 0; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline hipError_t hipDeviceSynchronize() { return 0; }
+inline hipError_t hipGetLastError() { return 0; }
+double emu_now_ms();
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emuEvent{0}; return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = emu_now_ms(); return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return 0; }
+// graphs: not emulated -- the engine falls back to direct launches when capture is unsupported
+inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return hipErrorNotSupported; }
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t*) { return hipErrorNotSupported; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t) { return hipErrorNotSupported; }
+inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
+inline hipError_t hipGraphDestroy(hipGraph_t) { return 0; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return 0; }
