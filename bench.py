@@ -1,0 +1,237 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json metric: codec-tokens/s (+ real-time factor), NeuTTS-Air bf16, batch 256 per GPU.
+
+One "step" = one pass of the synthesis hot path over one batch of synthetic input: 256 utterances per GPU,
+each a 500-token prompt (prefill) followed by 250 greedy tokens (1 from the prefill logits + 249 decode
+steps, EOS masked so every run does identical work), through libneutts_hip.so.  Inputs (prompt ids,
+weights) are resident / uploaded before the timed region; `value` = tokens of ALL ranks / max-over-ranks
+wall time of the K timed steps.
+
+    python bench.py                      # N=1, K=3, W=1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W        # one rank per GPU, RCCL weight broadcast, no step collective
+
+Extra legs on rank 0 at N=1: `roofline` (dominant kernel of the decode step, hipEvent-timed in isolation
+at mid-generation slot state) and `cpu_baseline` (the reference's CPU path for this hot path, one
+utterance, on the box's host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "neutts-air_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(cfg, w, prompt, n_new, eos):
+    """The reference's own CPU path for this hot path: transformers Qwen2ForCausalLM.generate called as in
+    ref:neutts/neutts.py:338-347 (fp32, greedy so the work is fixed) when transformers is importable
+    (kind "reference"); otherwise the oracle restatement (kind "port")."""
+    from oracle import backbone_ref as br
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    t0 = time.time()
+    try:
+        from oracle.gen_golden import hf_backbone
+        m = hf_backbone(cfg, w, torch.float32)
+        t1 = time.time()
+        out = m.generate(torch.tensor([prompt]), max_length=len(prompt) + n_new, eos_token_id=eos, pad_token_id=eos,
+                         do_sample=False, use_cache=True, min_new_tokens=n_new)
+        n = out.shape[1] - len(prompt)
+        kind = "reference"
+    except Exception as ex:  # transformers missing on this box
+        log(f"[cpu_baseline] transformers path unavailable ({type(ex).__name__}: {ex}); timing the oracle port")
+        wd = br.cast_weights(w, torch.float32)
+        t1 = time.time()
+        n = len(br.generate(cfg, wd, prompt, len(prompt) + n_new, eos, min_new_tokens=n_new).ids)
+        kind = "port"
+    dt = time.time() - t1
+    return {"value": n / dt, "unit": "codec-tokens/s", "cores": cores, "kind": kind,
+            "sample": f"1 utterance, {len(prompt)} prefill + {n} greedy tokens, fp32 torch CPU "
+                      f"({'transformers Qwen2ForCausalLM.generate' if kind == 'reference' else 'oracle/backbone_ref.generate'}), "
+                      f"{dt:.1f}s (+{t1 - t0:.1f}s model build)",
+            "rtf": dt / (n / 50.0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
+    ap.add_argument("--prefill", type=int, default=500)
+    ap.add_argument("--decode", type=int, default=250)
+    ap.add_argument("--vocab", type=int, default=217488)
+    ap.add_argument("--prefill-chunk", type=int, default=64, help="prompts per prefill call")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--tiny", action="store_true", help="tiny model geometry (plumbing tests only; not a benchmark)")
+    a = ap.parse_args()
+    # Plumbing-test hook (tests/test_dist_gloo.py): run the launch / shard / broadcast / timing logic on CPU
+    # ranks over gloo against the SIMT-emulator build of the library.  Never set for a measurement.
+    emu_lib = os.environ.get("NTTS_BENCH_EMU_LIB")
+
+    from neutts import _hip, dist as ndist
+    from oracle import backbone_ref as br  # weights/prompt generators + cpu_baseline leg only
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        log(f"[bench] WORLD_SIZE={world} but --gpus {a.gpus}: launch with torch.distributed.run --nproc-per-node {a.gpus}")
+        if world == 1 and a.gpus > 1:
+            sys.exit(2)
+    if not emu_lib:
+        assert torch.cuda.is_available(), "bench.py measures the HIP path: it needs the MI355X (no CPU fallback)"
+        torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if emu_lib:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ntts_build", os.path.join(PKG, "build.py"))
+    bmod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bmod)
+    lib = emu_lib or bmod.build(verbose=False)
+
+    cfg = br.BackboneConfig.tiny(vocab_size=512, num_layers=1) if a.tiny else br.BackboneConfig.neutts_air(a.vocab)
+    B, S, N = a.batch, a.prefill, a.decode
+    eng = _hip.BackboneEngine(dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
+                                   intermediate_size=cfg.intermediate_size, num_layers=cfg.num_layers,
+                                   num_heads=cfg.num_heads, num_kv_heads=cfg.num_kv_heads, rms_eps=cfg.rms_eps,
+                                   max_context=((S + N + 31) // 32) * 32, max_batch=B,
+                                   max_prefill_tokens=a.prefill_chunk * S), 0 if emu_lib else local, lib)
+    w = None
+    t0 = time.time()
+    if rank == 0:
+        w = br.make_weights(cfg, 0)            # synthetic N(0,1/fan_in) weights at the exact NeuTTS-Air shapes
+        eng.load_state_dict({k: v.numpy() for k, v in w.items()}, inv_freq=br.rope_inv_freq(cfg).numpy())
+    if world > 1:
+        ndist.broadcast_weights(eng, src=0, device=torch.device("cpu") if emu_lib else None)  # RCCL over xGMI
+    log(f"[bench] rank {rank}: weights ready in {time.time() - t0:.1f}s")
+
+    eos = cfg.vocab_size - 1
+    samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
+    lo = rank * B
+    prompts = [br.synthetic_prompt(cfg, lo + i, S) for i in range(B)]   # seed 1234 + utterance index
+
+    def one_step(collect=False):
+        pf_ms = 0.0
+        for c in range(0, B, a.prefill_chunk):
+            n = min(a.prefill_chunk, B - c)
+            eng.prefill(prompts[c:c + n], list(range(c, c + n)), [samp] * n)
+            if collect:
+                pf_ms += eng.last_timing()[0]
+        eng.decode(N - 1)
+        eng.sync()
+        dec_ms = eng.last_timing()[1] if collect else 0.0
+        out = None
+        if collect:
+            out = [eng.read(s) for s in (0, B - 1)]
+        for s in range(B):
+            eng.release(s)
+        return pf_ms, dec_ms, out
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        if not emu_lib:
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        one_step()
+    barrier()
+    t0 = time.time()
+    for _ in range(a.steps):
+        one_step()
+    barrier()
+    dt = time.time() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if emu_lib else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- untimed extra legs (phase split, roofline of the dominant kernel, CPU baseline)
+    pf_ms, dec_ms, out = one_step(collect=True)
+    assert all(len(ids) == N and fin for ids, fin in out), "bench run did not produce the expected tokens"
+    roof = None
+    step_info = None
+    if rank == 0 and not a.no_roofline:
+        # slot state at mid-generation (mean context S + N/2 ~ 625): prefill everything, decode N/2 steps
+        for c in range(0, B, a.prefill_chunk):
+            n = min(a.prefill_chunk, B - c)
+            eng.prefill(prompts[c:c + n], list(range(c, c + n)), [samp] * n)
+        eng.decode(N // 2)
+        eng.sync()
+        step_bytes = eng.step_bytes()
+        eng.decode(8)
+        eng.sync()
+        step_ms = eng.last_timing()[1] / 8
+        rows = []
+        for k, name in enumerate(_hip.BackboneEngine.KERNELS):
+            ms, nbytes, nl = eng.time_kernel(k, 20)
+            rows.append((ms * nl, name, ms, nbytes, nl))
+            log(f"[roofline] {name:24s} {ms * 1e3:8.1f} us/launch x {nl:3d} = {ms * nl:7.3f} ms/step   "
+                f"{nbytes / 1e6:9.2f} MB/launch   {nbytes / (ms * 1e-3) / 1e9:7.0f} GB/s")
+        rows.sort(reverse=True)
+        _, name, ms, nbytes, nl = rows[0]
+        ach = nbytes / (ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBPS, "traffic": None, "avg_launch_us": ms * 1e3,
+                "alg_bytes_per_launch": nbytes, "launches_per_step": nl}
+        step_info = {"ms": step_ms, "alg_bytes": step_bytes, "achieved_GBps": step_bytes / (step_ms * 1e-3) / 1e9,
+                     "frac_of_hbm_peak": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                     "sum_of_isolated_kernels_ms": sum(r[0] for r in rows)}
+        for s in range(B):
+            eng.release(s)
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, w, prompts[0], N, eos)
+
+    if rank == 0:
+        tokens = world * B * N * a.steps
+        value = tokens / dt
+        rec = {
+            "metric": "codec-tokens/s", "value": value, "unit": "codec-tokens/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"NeuTTS-Air bf16 1xMI355X batch={B} synthetic prompts, {S} prefill / {N} decode tokens, "
+                                   "greedy, continuous-batching engine + hipGraph decode (BASELINE.json configs[2])",
+                       "batch_per_gpu": B, "prefill_tokens": S, "decode_tokens": N, "vocab_size": cfg.vocab_size,
+                       "stages": "backbone prefill + decode loop (NeuCodec decoder not yet in the timed region)",
+                       "parallelism": f"independent shards x{world}, RCCL weight broadcast only"},
+            "tokens_per_s_per_gpu": value / world,
+            "rtf": dt / (tokens / 50.0),
+            "phase_ms": {"prefill": pf_ms, "decode": dec_ms},
+            "roofline": roof, "decode_step": step_info, "cpu_baseline": cpu,
+        }
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

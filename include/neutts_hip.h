@@ -93,6 +93,9 @@ int ntts_backbone_finalize(ntts_backbone* e);
  * finalize on the sender; a receiver calls ntts_backbone_adopt_arena() after the broadcast landed. */
 int ntts_backbone_arena(ntts_backbone* e, void** dev_ptr, size_t* bytes);
 int ntts_backbone_adopt_arena(ntts_backbone* e);
+/* Device-to-device copy between the arena and a caller buffer of exactly the arena size (the staging
+ * tensor torch.distributed broadcasts): to_arena = 0 arena -> buf, 1 buf -> arena.  Blocking. */
+int ntts_backbone_arena_copy(ntts_backbone* e, void* buf, size_t bytes, int to_arena);
 
 /* Sampling contract of one request = the keyword arguments of the reference's generate() call
  * (ref:neutts/neutts.py:338-347). */
@@ -136,9 +139,18 @@ int ntts_backbone_sync(ntts_backbone* e);
  * `keep_logits` was enabled; row = slot. */
 int ntts_backbone_set_debug(ntts_backbone* e, int32_t keep_logits);
 int ntts_backbone_read_logits(ntts_backbone* e, int32_t slot, float* out, int32_t n);
+/* Teacher forcing for the margin-aware parity tests: replace the token slot `slot` emitted last
+ * (and will feed to the next step) by `token`. */
+int ntts_backbone_debug_force(ntts_backbone* e, int32_t slot, int32_t token);
 /* Timing: elapsed GPU milliseconds (hipEvents on the engine stream) of the most recent
  * ntts_backbone_decode call (all its steps) and of the most recent prefill. */
 int ntts_backbone_last_timing(ntts_backbone* e, float* prefill_ms, float* decode_ms);
+/* Replay ONE kernel of the decode step `iters` times at the current slot state and report its average
+ * duration (hipEvents on the engine stream), its algorithmic HBM bytes per launch and how many times a
+ * decode step launches it.  which: 0 paged attention (+RoPE/KV append), 1 QKV GEMM, 2 o_proj GEMM,
+ * 3 gate/up GEMM (+SiLU*mul), 4 down_proj GEMM, 5 lm_head GEMM (+argmax partials), 6 add+RMSNorm. */
+int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_t iters, float* avg_ms, double* alg_bytes,
+                              int32_t* launches_per_step);
 /* Algorithmic HBM bytes of one decode step at the current slot lengths (SURVEY.md 8d formula:
  * layer weights + lm_head + sum_b len_b * kv_bytes_per_token + new-token KV writes). */
 int ntts_backbone_step_bytes(ntts_backbone* e, double* bytes);
@@ -155,6 +167,8 @@ int ntts_k_gemm_bf16(const void* A, int64_t lda, const void* W, const void* bias
 int ntts_k_rmsnorm_bf16(const void* x, const void* w, void* y, int32_t rows, int32_t cols, float eps);
 /* Achieved HBM copy bandwidth probe: copies `bytes` device->device `iters` times, returns GB/s. */
 int ntts_k_membw(size_t bytes, int32_t iters, double* gbps);
+/* Diagnostics: writes 3 x 64 x 4 floats describing the MFMA 16x16x32 lane layout (see csrc/kapi.cpp). */
+int ntts_k_mfma_probe(float* out_dev_768);
 
 #ifdef __cplusplus
 }

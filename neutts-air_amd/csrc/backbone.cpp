@@ -393,6 +393,14 @@ extern "C" int ntts_backbone_arena(ntts_backbone* e, void** dev_ptr, size_t* byt
     *bytes = e->arena_elems * sizeof(bf16_t);
     return NTTS_OK;
 }
+extern "C" int ntts_backbone_arena_copy(ntts_backbone* e, void* buf, size_t bytes, int to_arena) {
+    if (!e || !buf || bytes != e->arena_elems * sizeof(bf16_t)) return fail(e, NTTS_EINVAL, "arena copy: bad buffer / size");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (to_arena) HIPCHK(e, hipMemcpy(e->arena, buf, bytes, hipMemcpyDeviceToDevice));
+    else HIPCHK(e, hipMemcpy(buf, e->arena, bytes, hipMemcpyDeviceToDevice));
+    return NTTS_OK;
+}
 extern "C" int ntts_backbone_adopt_arena(ntts_backbone* e) {
     if (!e) return NTTS_EINVAL;
     e->finalized = true;  // arena (incl. the RoPE table) was filled by a broadcast from a finalised engine
@@ -708,6 +716,18 @@ extern "C" int ntts_backbone_set_debug(ntts_backbone* e, int32_t keep_logits) {
     return NTTS_OK;
 }
 
+extern "C" int ntts_backbone_debug_force(ntts_backbone* e, int32_t slot, int32_t token) {
+    if (!e || slot < 0 || slot >= e->cfg.max_batch || token < 0 || token >= e->cfg.vocab_size) return fail(e, NTTS_EINVAL, "bad argument");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    int nn = 0;
+    HIPCHK(e, hipMemcpy(&nn, e->sl.n_new + slot, sizeof(int), hipMemcpyDeviceToHost));
+    if (nn < 1) return fail(e, NTTS_ESTATE, "slot %d has generated nothing yet", slot);
+    HIPCHK(e, hipMemcpy(e->sl.cur_tok + slot, &token, sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->sl.out_tokens + (size_t)slot * e->sl.out_stride + nn - 1, &token, sizeof(int), hipMemcpyHostToDevice));
+    return NTTS_OK;
+}
+
 extern "C" int ntts_backbone_read_logits(ntts_backbone* e, int32_t slot, float* out, int32_t n) {
     if (!e || !out || slot < 0 || slot >= e->cfg.max_batch) return NTTS_EINVAL;
     if (!e->logits) return fail(e, NTTS_ESTATE, "logits are not kept: call ntts_backbone_set_debug(e, 1) first");
@@ -744,5 +764,84 @@ extern "C" int ntts_backbone_step_bytes(ntts_backbone* e, double* bytes) {
     for (int b = 0; b < B; ++b)
         if (st[b] == SLOT_RUNNING) kv += (double)pos[b] * kv_tok + kv_tok;  // read L tokens, write 1
     *bytes = w_layers + w_head + kv;
+    return NTTS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-kernel timing at the CURRENT slot state (bench.py roofline leg).  Every kernel of the decode
+// step is idempotent with respect to the slot state (the attention kernel re-writes the same K/V
+// entry), so replaying one in isolation does not disturb generation.
+// ------------------------------------------------------------------------------------------------
+extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_t iters, float* avg_ms, double* alg_bytes,
+                                         int32_t* launches_per_step) {
+    if (!e || !avg_ms || !alg_bytes || !launches_per_step || iters < 1) return fail(e, NTTS_EINVAL, "bad argument");
+    if (!e->finalized) return fail(e, NTTS_ESTATE, "weights not finalised");
+    HIPCHK(e, hipSetDevice(e->device));
+    const ntts_backbone_config& c = e->cfg;
+    const int B = c.max_batch, H = e->H, F = e->F, QD = c.num_heads * 64, KD = c.num_kv_heads * 64, L = c.num_layers;
+    hipStream_t st = e->stream;
+    HIPCHK(e, hipStreamSynchronize(st));
+    std::vector<int> sst(B), pos(B);
+    HIPCHK(e, hipMemcpy(sst.data(), e->sl.state, B * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(pos.data(), e->sl.pos, B * sizeof(int), hipMemcpyDeviceToHost));
+    double kv_layer = 0;  // bytes one attention launch must read (+ write): K and V of every cached token
+    for (int b = 0; b < B; ++b)
+        if (sst[b] == SLOT_RUNNING) kv_layer += ((double)pos[b] + 1) * 2 * KD * 2.0;
+    const LayerW& w = e->layers[0];
+    const double act = (double)B * 2.0;
+    auto run = [&](int k) {
+        switch (k) {
+            case 0: {  // paged decode attention (+RoPE, +KV append)
+                AttnDecodeArgs a{};
+                a.qkv = e->qkv_dec; a.ld_qkv = e->NQKV; a.out = e->attn_dec; a.ld_out = QD;
+                a.kpool = e->kv; a.vpool = e->kv + e->kv_half; a.block_table = e->block_table; a.max_pages = e->max_pages;
+                a.pos = e->sl.pos; a.state = e->sl.state; a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
+                a.nh = c.num_heads; a.nkv = c.num_kv_heads;
+                attn_decode_launch(a, B, st);
+                break;
+            }
+            case 1: NTTS_GEMM_S(EPI_BF16, gemm_args(e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H), 1, st); break;
+            case 2: NTTS_GEMM_S(EPI_SPLITK, gemm_args(e->attn_dec, QD, w.wo, QD, nullptr, e->slabs, H, B, H, QD), e->ks_o, st); break;
+            case 3: {
+                GemmArgs gu = gemm_args(e->xn_dec, H, w.wgu, H, nullptr, e->act_dec, F, B, 2 * F, H);
+                if (e->gu_large) NTTS_GEMM_L(EPI_SILU_MUL, gu, 1, st); else NTTS_GEMM_S(EPI_SILU_MUL, gu, 1, st);
+                break;
+            }
+            case 4: NTTS_GEMM_S(EPI_SPLITK, gemm_args(e->act_dec, F, w.wd, F, nullptr, e->slabs, H, B, H, F), e->ks_d, st); break;
+            case 5: {
+                GemmArgs a = gemm_args(e->xn_dec, H, e->embed, H, nullptr, nullptr, 0, B, c.vocab_size, H);
+                a.part_val = e->part_val; a.part_idx = e->part_idx; a.mask_eos = e->sl.mask_eos; a.logits = nullptr; a.ld_logits = c.vocab_size;
+                if (e->head_large) NTTS_GEMM_L(EPI_ARGMAX, a, 1, st); else NTTS_GEMM_S(EPI_ARGMAX, a, 1, st);
+                break;
+            }
+            case 6: {
+                NormArgs n1{};
+                n1.slabs = e->slabs; n1.nslab = gemm_nsplit(QD, e->ks_o); n1.slab_rows = B; n1.resid_in = e->h_dec; n1.resid_out = e->o_pf;
+                n1.norm_w = w.ln2; n1.normed_out = e->xn_pf; n1.M = B; n1.H = H; n1.eps = c.rms_eps;
+                add_rmsnorm_launch(n1, st);
+                break;
+            }
+            default: break;
+        }
+    };
+    switch (which) {
+        case 0: *alg_bytes = kv_layer + act * (e->NQKV + QD); *launches_per_step = L; break;
+        case 1: *alg_bytes = ((double)e->NQKV * H + e->NQKV) * 2.0 + act * (H + e->NQKV); *launches_per_step = L; break;
+        case 2: *alg_bytes = (double)H * QD * 2.0 + act * QD + (double)gemm_nsplit(QD, e->ks_o) * B * H * 4.0; *launches_per_step = L; break;
+        case 3: *alg_bytes = (double)2 * F * H * 2.0 + act * (H + F); *launches_per_step = L; break;
+        case 4: *alg_bytes = (double)H * F * 2.0 + act * F + (double)gemm_nsplit(F, e->ks_d) * B * H * 4.0; *launches_per_step = L; break;
+        case 5: *alg_bytes = (double)c.vocab_size * H * 2.0 + act * H; *launches_per_step = 1; break;
+        case 6: *alg_bytes = (double)gemm_nsplit(QD, e->ks_o) * B * H * 4.0 + act * H * 3; *launches_per_step = 2 * L; break;
+        default: return fail(e, NTTS_EINVAL, "unknown kernel id %d", which);
+    }
+    if (which == 6 && B > e->Tmax) return fail(e, NTTS_EINVAL, "scratch too small");
+    run(which);  // warm
+    HIPCHK(e, hipEventRecord(e->ev[2], st));
+    for (int i = 0; i < iters; ++i) run(which);
+    HIPCHK(e, hipEventRecord(e->ev[3], st));
+    HIPCHK(e, hipStreamSynchronize(st));
+    float ms = 0;
+    HIPCHK(e, hipEventElapsedTime(&ms, e->ev[2], e->ev[3]));
+    *avg_ms = ms / iters;
     return NTTS_OK;
 }

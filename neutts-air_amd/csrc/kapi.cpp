@@ -67,3 +67,31 @@ extern "C" int ntts_k_membw(size_t bytes, int32_t iters, double* gbps) {
     hipFree(a); hipFree(b);
     return hipDeviceSynchronize() == hipSuccess ? NTTS_OK : NTTS_EHIP;
 }
+
+// MFMA lane-layout probe (diagnostics): three products whose results spell out which (row, col) each
+// (lane, reg) of the accumulator holds and whether A and B agree on the k slot.  Expected, under the
+// layout documented in ntts/dev.h:  out[0][l][r] = (l>>4)*4 + r,  out[1][l][r] = l & 15,
+// out[2][l][r] = ((l & 15) * 2 + 1) % 32 + 1.
+NTTS_KERNEL(64) void mfma_probe_kernel(float* out) {
+    const int l = lane_id(), g = l >> 4, c = l & 15;
+    for (int probe = 0; probe < 3; ++probe) {
+        bf16x8 a, b;
+        for (int j = 0; j < 8; ++j) {
+            float av, bv;
+            if (probe == 0) { av = (g == 0 && j == 0) ? (float)c : 0.f; bv = (g == 0 && j == 0) ? 1.f : 0.f; }
+            else if (probe == 1) { av = (g == 0 && j == 0) ? 1.f : 0.f; bv = (g == 0 && j == 0) ? (float)c : 0.f; }
+            else { av = (float)(g * 8 + j + 1); bv = (g * 8 + j == (c * 2 + 1) % 32) ? 1.f : 0.f; }
+            a[j] = (short)f2bf(av);
+            b[j] = (short)f2bf(bv);
+        }
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        d = mfma16(a, b, d);
+        for (int r = 0; r < 4; ++r) out[(probe * 64 + l) * 4 + r] = d[r];
+    }
+}
+
+extern "C" int ntts_k_mfma_probe(float* out_dev_768) {
+    if (!out_dev_768) return NTTS_EINVAL;
+    NTTS_LAUNCH((mfma_probe_kernel), dim3(1), dim3(64), (hipStream_t)0, out_dev_768);
+    return hipDeviceSynchronize() == hipSuccess ? NTTS_OK : NTTS_EHIP;
+}

@@ -61,6 +61,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_backbone_finalize": (C.c_int, [p]),
         "ntts_backbone_arena": (C.c_int, [p, C.POINTER(p), C.POINTER(C.c_size_t)]),
         "ntts_backbone_adopt_arena": (C.c_int, [p]),
+        "ntts_backbone_arena_copy": (C.c_int, [p, p, C.c_size_t, C.c_int]),
+        "ntts_backbone_time_kernel": (C.c_int, [p, i32, i32, C.POINTER(f32), C.POINTER(C.c_double), C.POINTER(i32)]),
         "ntts_backbone_prefill": (C.c_int, [p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(SamplingC)]),
         "ntts_backbone_decode": (C.c_int, [p, i32]),
         "ntts_backbone_read": (C.c_int, [p, i32, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(i32)]),
@@ -69,11 +71,13 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_backbone_sync": (C.c_int, [p]),
         "ntts_backbone_set_debug": (C.c_int, [p, i32]),
         "ntts_backbone_read_logits": (C.c_int, [p, i32, C.POINTER(f32), i32]),
+        "ntts_backbone_debug_force": (C.c_int, [p, i32, i32]),
         "ntts_backbone_last_timing": (C.c_int, [p, C.POINTER(f32), C.POINTER(f32)]),
         "ntts_backbone_step_bytes": (C.c_int, [p, C.POINTER(C.c_double)]),
         "ntts_k_gemm_bf16": (C.c_int, [p, i64, p, p, p, i64, i32, i32, i32, i32]),
         "ntts_k_rmsnorm_bf16": (C.c_int, [p, p, p, i32, i32, f32]),
         "ntts_k_membw": (C.c_int, [C.c_size_t, i32, C.POINTER(C.c_double)]),
+        "ntts_k_mfma_probe": (C.c_int, [p]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here == header/library drift: fail loudly
@@ -176,6 +180,17 @@ class BackboneEngine:
         self._chk(self.lib.ntts_backbone_arena(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def arena_copy(self, buf_ptr: int, nbytes: int, to_arena: bool):
+        self._chk(self.lib.ntts_backbone_arena_copy(self.h, C.c_void_p(buf_ptr), nbytes, int(to_arena)))
+
+    KERNELS = ["attn_decode_kernel", "gemm_qkv", "gemm_o_proj_splitk", "gemm_gate_up_silu", "gemm_down_splitk",
+               "gemm_lm_head_argmax", "add_rmsnorm_kernel"]
+
+    def time_kernel(self, which: int, iters: int = 20):
+        ms, nb, nl = C.c_float(), C.c_double(), C.c_int32()
+        self._chk(self.lib.ntts_backbone_time_kernel(self.h, which, iters, C.byref(ms), C.byref(nb), C.byref(nl)))
+        return ms.value, nb.value, nl.value
+
     def adopt_arena(self):
         self._chk(self.lib.ntts_backbone_adopt_arena(self.h))
 
@@ -220,6 +235,9 @@ class BackboneEngine:
         out = np.empty(self.vocab_size, dtype=np.float32)
         self._chk(self.lib.ntts_backbone_read_logits(self.h, slot, out.ctypes.data_as(C.POINTER(C.c_float)), len(out)))
         return out
+
+    def debug_force(self, slot: int, token: int):
+        self._chk(self.lib.ntts_backbone_debug_force(self.h, slot, token))
 
     def last_timing(self):
         a, b = C.c_float(), C.c_float()

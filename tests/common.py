@@ -1,0 +1,69 @@
+"""Shared helpers for the parity tests (oracle = checker only)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from oracle import backbone_ref as br
+from neutts import _hip
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_fixture(name):
+    z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=True)
+    cfg = br.BackboneConfig(**{k: v for k, v in z["cfg"]})
+    w = br.make_weights(cfg, int(z["seed"]), init=str(z["init"]), peak_sigma=float(z["peak_sigma"]))
+    return z, cfg, w
+
+
+def engine_cfg(cfg: br.BackboneConfig, **kw):
+    d = dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+             num_layers=cfg.num_layers, num_heads=cfg.num_heads, num_kv_heads=cfg.num_kv_heads, rms_eps=cfg.rms_eps)
+    d.update(kw)
+    return d
+
+
+def make_engine(cfg, w, lib, max_batch=2, max_context=128, max_prefill_tokens=512, bf16_upload=False, **kw):
+    eng = _hip.BackboneEngine(engine_cfg(cfg, max_batch=max_batch, max_context=max_context,
+                                         max_prefill_tokens=max_prefill_tokens, **kw), 0, lib)
+    sd = {k: (v.to(torch.bfloat16) if bf16_upload else v.numpy()) for k, v in w.items()}
+    eng.load_state_dict(sd, inv_freq=br.rope_inv_freq(cfg).numpy())
+    return eng
+
+
+def bf16_ulp(x: float) -> float:
+    x = abs(float(x))
+    if x == 0:
+        return 2.0 ** -133
+    return 2.0 ** (np.floor(np.log2(x)) - 7)
+
+
+def teacher_forced_compare(eng, slot, gold_ids, gold_topv, gold_topi, max_ulps=2.0):
+    """Step the engine one token at a time against a golden greedy run.
+
+    A token must equal the golden one unless the golden top-1/top-2 logits are within `max_ulps`
+    bf16 ulps of each other (then fp32 summation order legitimately decides; our token must then be
+    among the golden top-4 with a logit inside that band).  After such a step the golden token is
+    forced so that later steps stay comparable.  Returns (n_exact, n_near_tie)."""
+    n_exact = n_tie = 0
+    n = len(gold_ids)
+    for k in range(n):
+        if k > 0:
+            eng.decode(1)
+        ids, fin = eng.read(slot)
+        assert len(ids) == k + 1, (k, len(ids))
+        tok = ids[-1]
+        if tok == int(gold_ids[k]):
+            n_exact += 1
+        else:
+            band = max_ulps * bf16_ulp(gold_topv[k][0])
+            cand = {int(i): float(v) for i, v in zip(gold_topi[k], gold_topv[k])}
+            assert tok in cand and gold_topv[k][0] - cand[tok] <= band, (
+                f"step {k}: got {tok}, golden {int(gold_ids[k])}, golden top4 {cand}, band {band}")
+            n_tie += 1
+            if k + 1 < n:
+                eng.debug_force(slot, int(gold_ids[k]))
+    return n_exact, n_tie

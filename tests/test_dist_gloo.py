@@ -1,0 +1,58 @@
+"""N>1 path on CPU: world_size 2 over gloo, emulator library (ROOT cause of any failure on the 8-GPU run
+would be host logic: sharding, the one-time arena broadcast, max-over-ranks timing -- all exercised here)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+from neutts import dist as ndist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _torchrun(nproc, script_args, env_extra=None, timeout=600):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + script_args
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 5, 256, 2048, 2049):
+        for world in (1, 2, 3, 8):
+            parts = [ndist.shard_range(n, r, world) for r in range(world)]
+            assert parts[0][0] == 0 and parts[-1][1] == n
+            assert all(parts[i][1] == parts[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in parts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_broadcast_and_sharded_generate_world2(emu_lib):
+    r = _torchrun(2, [os.path.join(ROOT, "tests", "_dist_worker.py"), emu_lib])
+    assert r.returncode == 0 and "DIST_OK 2" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_bench_contract_world2(emu_lib):
+    r = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--tiny", "--batch", "2",
+                      "--prefill", "12", "--decode", "4", "--prefill-chunk", "2", "--no-roofline"],
+                  {"NTTS_BENCH_EMU_LIB": emu_lib})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in rec
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert abs(rec["value"] - 2 * 2 * 4 / (rec["ms_per_step"] / 1e3)) < 1e-6 * rec["value"] + 1e-9

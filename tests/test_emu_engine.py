@@ -1,0 +1,91 @@
+"""The whole backbone engine (C-ABI -> prefill -> decode steps -> sampling/bookkeeping) executed on the
+CPU SIMT emulator and checked against the golden vectors / the oracle.  Same test bodies as the GPU
+parity tests (tests/test_gpu_backbone.py), just a different library file."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import backbone_ref as br
+from neutts import _hip
+from common import load_fixture, make_engine, teacher_forced_compare
+
+
+def test_tiny_teacher_forced(emu_lib):
+    z, cfg, w = load_fixture("backbone_tiny")
+    S, N, mn, eos = int(z["s_len"]), 12, int(z["min_new"]), int(z["eos"])
+    eng = make_engine(cfg, w, emu_lib, max_batch=2)
+    samp = _hip.Sampling(max_length=S + N, min_new_tokens=mn, eos_token_id=eos, do_sample=False)
+    eng.prefill([br.synthetic_prompt(cfg, 0, S), br.synthetic_prompt(cfg, 1, S)], [1, 0], [samp, samp])
+    # slots are decoded together; compare slot 1 (utt 0) step by step, slot 0 (utt 1) at the end
+    ex, tie = teacher_forced_compare(eng, 1, z["bf16_ids_0"][:N], z["bf16_topv_0"], z["bf16_topi_0"])
+    assert ex + tie == N and ex >= N - 3
+    ids1, fin1 = eng.read(0)
+    assert fin1 and len(ids1) == N
+    agree = sum(int(a == b) for a, b in zip(ids1, z["bf16_ids_1"][:N]))
+    assert agree >= N - 2, (ids1, z["bf16_ids_1"][:N])
+
+
+def test_small_gqa2_page_crossing_peaked_exact(emu_lib):
+    """2 kv heads, prompt of 70 (3 pages), decode crosses the 96-token page boundary; peaked weights so the
+    free-running greedy ids must be bit-identical to HF's."""
+    z, cfg, w = load_fixture("backbone_small_peaked")
+    S, N, eos = int(z["s_len"]), 30, int(z["eos"])
+    eng = make_engine(cfg, w, emu_lib, max_batch=1)
+    samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
+    eng.prefill([br.synthetic_prompt(cfg, 0, S)], [0], [samp])
+    eng.decode(N - 1)
+    ids, fin = eng.read(0)
+    assert fin and ids == z["bf16_ids_0"][:N].tolist()
+
+
+def test_continuous_batching_ragged_vs_oracle(emu_lib):
+    """More prompts than slots, ragged prompt lengths, EOS stop before max_length, slot recycling:
+    every prompt's ids equal the oracle's single-sequence run (ref:neutts/neutts.py:334-352 is batch 1)."""
+    cfg = br.BackboneConfig.tiny(vocab_size=512, num_layers=1)
+    w = br.make_weights(cfg, 11, peak_sigma=0.5)
+    wd = br.cast_weights(w, torch.bfloat16)
+    lens = [5, 33, 64, 17, 40]
+    prompts = [br.synthetic_prompt(cfg, 10 + i, n) for i, n in enumerate(lens)]
+    # choose an EOS that the model really emits for prompt 3 after a few tokens (and not before)
+    probe = br.generate(cfg, wd, prompts[3], lens[3] + 12, eos_id=cfg.vocab_size - 1, min_new_tokens=0)
+    eos = probe.ids[4]
+    assert eos not in probe.ids[:4]
+    want = [br.generate(cfg, wd, p, len(p) + 10, eos_id=eos, min_new_tokens=3).ids for p in prompts]
+    assert any(len(x) < 10 for x in want), "test should exercise an early EOS stop"
+    eng = make_engine(cfg, w, emu_lib, max_batch=2, max_prefill_tokens=128)
+    samp = [_hip.Sampling(max_length=len(p) + 10, min_new_tokens=3, eos_token_id=eos, do_sample=False) for p in prompts]
+    got = eng.generate(prompts, samp, steps_per_poll=3, prefill_token_budget=70)
+    assert got == want
+
+
+def test_engine_error_paths(emu_lib):
+    cfg = br.BackboneConfig.tiny(vocab_size=256, num_layers=1)
+    w = br.make_weights(cfg, 3)
+    eng = _hip.BackboneEngine(dict(vocab_size=256, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                                   num_layers=1, num_heads=7, num_kv_heads=1, max_context=64, max_batch=2, num_pages=2,
+                                   max_prefill_tokens=64), 0, emu_lib)
+    samp = _hip.Sampling(max_length=64, min_new_tokens=0, eos_token_id=1, do_sample=False)
+    with pytest.raises(_hip.NeuTTSHipError) as ei:      # weights not loaded
+        eng.prefill([[1, 2, 3]], [0], [samp])
+    assert ei.value.code == -4
+    with pytest.raises(_hip.NeuTTSHipError):            # wrong shape
+        eng.load_tensor("model.norm.weight", np.zeros(7, dtype=np.float32))
+    with pytest.raises(_hip.NeuTTSHipError):            # unknown name
+        eng.load_tensor("model.layers.0.nope", np.zeros(7, dtype=np.float32))
+    eng.load_state_dict({k: v.numpy() for k, v in w.items()}, inv_freq=br.rope_inv_freq(cfg).numpy())
+    with pytest.raises(_hip.NeuTTSHipError) as ei:      # sampling mode not implemented -> loud, not silent greedy
+        eng.prefill([[1, 2, 3]], [0], [_hip.Sampling(max_length=64, eos_token_id=1, do_sample=True)])
+    assert ei.value.code == -1
+    with pytest.raises(_hip.NeuTTSHipError):            # token id out of range
+        eng.prefill([[1, 2, 999]], [0], [samp])
+    with pytest.raises(_hip.NeuTTSHipError) as ei:      # 3 pages needed, pool has 2
+        eng.prefill([list(range(1, 35)), list(range(1, 31))], [0, 1], [samp, samp])
+    assert ei.value.code == -3
+    eng.prefill([list(range(1, 30))], [0], [samp])      # pool intact after the failed call
+    with pytest.raises(_hip.NeuTTSHipError) as ei:      # slot busy
+        eng.prefill([[1, 2, 3]], [0], [samp])
+    assert ei.value.code == -4
+    eng.release(0)
+    eng.prefill([[1, 2, 3]], [0], [samp])
+    st, nn = eng.poll()
+    assert st[0] in (1, 2) and nn[0] == 1 and st[1] == 0
