@@ -156,6 +156,46 @@ int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_t iters, fl
 int ntts_backbone_step_bytes(ntts_backbone* e, double* bytes);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Codec engine: NeuCodec decoder, codes -> 24 kHz waveform.  Replaces NeuCodec.decode_code behind  */
+/* ref:neutts/neutts.py:288-291 (FSQ de-index -> Linear -> Conv/ResNet -> 12 x transformer ->       */
+/* ResNet -> LayerNorm -> ISTFT head; hf:models/xcodec2/modeling_xcodec2.py:746-862).                */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct ntts_codec ntts_codec;
+
+typedef struct ntts_codec_config {
+    int32_t hidden_size;        /* 1024 */
+    int32_t intermediate_size;  /* 4096 */
+    int32_t num_layers;         /* 12 */
+    int32_t num_heads;          /* 16 */
+    int32_t head_dim;           /* 64 */
+    int32_t quantization_dim;   /* 2048 */
+    int32_t n_levels;           /* 8 */
+    int32_t levels[8];          /* FSQ levels, 4 each: 65 536 codes */
+    int32_t hop_length;         /* 480 (ref:neutts/neutts.py:86); n_fft = 4 * hop */
+    float rms_eps;              /* 1e-6 */
+    int32_t max_frames;         /* longest utterance, in codec frames */
+    int32_t max_rows;           /* workspace rows: sum over a decode call of (max frames of the call + 6) */
+} ntts_codec_config;
+
+const char* ntts_codec_last_error(const ntts_codec* c);
+int ntts_codec_create(const ntts_codec_config* cfg, int device, ntts_codec** out);
+void ntts_codec_destroy(ntts_codec* c);
+/* `name` = parameter name of transformers' Xcodec2Model: "quantizer.project_out.{weight,bias}",
+ * "decoder.fc.*", "decoder.embed.*", "decoder.{prior_net,post_net}.{0,1}.{norm1,conv1,norm2,conv2}.*",
+ * "decoder.layers.{i}.{input_layernorm,post_attention_layernorm}.weight",
+ * "decoder.layers.{i}.self_attn.{q,k,v,o}_proj.weight", "decoder.layers.{i}.mlp.{fc1,fc2}.weight",
+ * "decoder.norm.*", "decoder.head.linear.*".  Host or device pointer, fp32 or bf16.  Blocking. */
+int ntts_codec_load_tensor(ntts_codec* c, const char* name, const void* data, int dtype, const int64_t* shape,
+                           int ndim, int is_device);
+int ntts_codec_finalize(ntts_codec* c);
+/* Decode `n` utterances: codes packed back to back (HOST int32, utterance i has lens[i] frames) ->
+ * wav_out (HOST float32) row i = hop_length * lens[i] samples at offset i * wav_stride.  Blocking. */
+int ntts_codec_decode(ntts_codec* c, int32_t n, const int32_t* codes, const int32_t* lens, float* wav_out,
+                      int64_t wav_stride);
+/* GPU milliseconds (hipEvents) of the most recent decode call, H2D/D2H excluded. */
+int ntts_codec_last_timing(ntts_codec* c, float* ms);
+
+/* ------------------------------------------------------------------------------------------ */
 /* Kernel-level entry points (used by the parity tests and micro-benchmarks; all pointers are   */
 /* DEVICE pointers, bf16 unless noted, row-major; run on the NULL stream and block).           */
 /* ------------------------------------------------------------------------------------------ */

@@ -40,10 +40,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-           "-I" + CSRC, "-Wno-unused-result", "-Wno-unused-value", "-o", LIB] + _sources()
+           "-I" + CSRC, "-Wno-unused-result", "-Wno-unused-value", "-o", LIB + ".tmp"] + _sources()
     if verbose:
         print("[build]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)      # a failed build never destroys the previous library
     return LIB
 
 
@@ -52,10 +53,11 @@ def build_emu(force: bool = False, verbose: bool = True) -> str:
         return EMU_LIB
     cxx = os.environ.get("EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
     cmd = [cxx, "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-x", "c++", "-I" + EMU_DIR, "-Wno-unused-result",
-           "-Wno-unknown-pragmas", "-Wno-pass-failed", "-o", EMU_LIB, os.path.join(EMU_DIR, "emu.cpp")] + _sources()
+           "-Wno-unknown-pragmas", "-Wno-pass-failed", "-o", EMU_LIB + ".tmp", os.path.join(EMU_DIR, "emu.cpp")] + _sources()
     if verbose:
         print("[build-emu]", " ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    os.replace(EMU_LIB + ".tmp", EMU_LIB)
     return EMU_LIB
 
 

@@ -1,0 +1,431 @@
+// codec.cpp -- NeuCodec decoder engine behind include/neutts_hip.h (ntts_codec_*).
+//
+// Replaces  self.codec.decode_code(codes[1,1,T]) -> wav[1,1,480*T]  (ref:neutts/neutts.py:288-291) for a batch
+// of utterances: one non-autoregressive pass, all Linear/Conv1d/DFT work on the MFMA GEMM (gemm.h), the rest
+// in kernels/codec.h.  Weights keep the parameter names of transformers' Xcodec2Model.
+#include <ntts/dev.h>
+
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/neutts_hip.h"
+#include "kernels/codec.h"
+#include "kernels/gemm.h"
+
+using namespace ntts;
+
+static std::string g_codec_create_err;
+
+struct ResW { float *g1, *b1, *cb1, *g2, *b2, *cb2; bf16_t *w1, *w2; };
+struct CLayerW { float *ln1, *ln2; bf16_t *wqkv, *wo, *fc1, *fc2; };
+
+struct ntts_codec {
+    ntts_codec_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int H = 0, I = 0, nq = 0, n_fft = 0, nb = 0, NS = 0, lds_spec = 0;
+    long K3 = 0, max_rows = 0;
+    bool finalized = false;
+    std::map<std::string, std::vector<float>> host;            // staged fp32 tensors until finalize
+    std::map<std::string, std::vector<int64_t>> shapes;
+    std::vector<void*> allocs;
+    // device weights
+    float *wf = nullptr, *bf = nullptr, *embed_b = nullptr, *fn_w = nullptr, *fn_b = nullptr, *head_b = nullptr, *win2 = nullptr;
+    bf16_t *embed_w = nullptr, *head_w = nullptr, *basis3 = nullptr;
+    ResW res[4]{};
+    std::vector<CLayerW> layers;
+    // workspaces
+    float *h = nullptr, *t1 = nullptr, *spec = nullptr, *frames = nullptr, *wav = nullptr;
+    bf16_t *xa = nullptr, *xb = nullptr, *qkv = nullptr, *act = nullptr, *vt = nullptr, *s3 = nullptr;
+    int* meta = nullptr;
+    size_t meta_cap = 0;
+    size_t wav_cap = 0;
+    hipEvent_t ev[2]{};
+    bool have_time = false;
+};
+
+static int cfail(ntts_codec* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_codec_create_err = buf;
+    return code;
+}
+#define CHIP(c, call)                                                                                  \
+    do {                                                                                               \
+        hipError_t _s = (call);                                                                        \
+        if (_s != hipSuccess) return cfail(c, _s == 2 ? NTTS_ENOMEM : NTTS_EHIP, "%s failed: %s", #call, hipGetErrorString(_s)); \
+    } while (0)
+
+extern "C" const char* ntts_codec_last_error(const ntts_codec* c) { return c ? c->err.c_str() : g_codec_create_err.c_str(); }
+
+template <typename T>
+static int dalloc(ntts_codec* c, T** p, size_t n) {
+    void* v = nullptr;
+    CHIP(c, hipMalloc(&v, n * sizeof(T)));
+    c->allocs.push_back(v);
+    *p = (T*)v;
+    return NTTS_OK;
+}
+
+extern "C" void ntts_codec_destroy(ntts_codec* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    for (void* p : c->allocs) hipFree(p);
+    for (auto& e : c->ev)
+        if (e) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int ntts_codec_create(const ntts_codec_config* cf, int device, ntts_codec** out) {
+    if (!cf || !out) return cfail(nullptr, NTTS_EINVAL, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device || device < 0)
+        return cfail(nullptr, NTTS_ENODEV, "no HIP device %d (found %d): this library has no CPU fallback", device, ndev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return cfail(nullptr, NTTS_ENODEV, "device %d is '%s', kernels are built for gfx950 only", device, prop.gcnArchName);
+    if (cf->head_dim != 64 || cf->num_heads * 64 != cf->hidden_size) return cfail(nullptr, NTTS_EINVAL, "need head_dim 64 and heads*64 == hidden");
+    if (cf->hidden_size % 64 || cf->intermediate_size % 64 || cf->hidden_size > 2048 || (cf->hidden_size / 32) > 256 || 256 % (cf->hidden_size / 32))
+        return cfail(nullptr, NTTS_EINVAL, "unsupported hidden/intermediate size");
+    if (cf->n_levels < 1 || cf->n_levels > 8 || cf->hop_length < 8 || (cf->hop_length % 8)) return cfail(nullptr, NTTS_EINVAL, "bad levels / hop");
+    if (cf->max_frames < 1 || cf->max_rows < cf->max_frames + 2 * kPadRows) return cfail(nullptr, NTTS_EINVAL, "bad max_frames / max_rows");
+    ntts_codec* c = new ntts_codec();
+    c->cfg = *cf;
+    c->device = device;
+    c->H = cf->hidden_size; c->I = cf->intermediate_size; c->nq = cf->n_levels;
+    c->n_fft = cf->hop_length * 4; c->nb = c->n_fft / 2 + 1; c->NS = c->n_fft + 2;
+    c->lds_spec = (c->NS + 3) / 4 * 4;
+    c->K3 = (6L * c->nb + 63) / 64 * 64;
+    c->max_rows = cf->max_rows;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return cfail(nullptr, NTTS_EHIP, "stream creation failed");
+    }
+    hipEventCreate(&c->ev[0]); hipEventCreate(&c->ev[1]);
+    const size_t R = c->max_rows, H = c->H;
+    const int npages_max = (cf->max_frames + kPage - 1) / kPage;
+    const size_t max_utts = R / (1 + 2 * kPadRows) + 1;
+    int rc = NTTS_OK;
+#define A(call) if (rc == NTTS_OK) rc = (call)
+    A(dalloc(c, &c->h, R * H)); A(dalloc(c, &c->t1, R * H)); A(dalloc(c, &c->xa, R * H)); A(dalloc(c, &c->xb, R * H));
+    A(dalloc(c, &c->qkv, R * 3 * H)); A(dalloc(c, &c->act, R * c->I));
+    A(dalloc(c, &c->vt, (R + (size_t)max_utts * kPage) * H));
+    A(dalloc(c, &c->spec, R * c->lds_spec)); A(dalloc(c, &c->s3, R * c->K3)); A(dalloc(c, &c->frames, R * c->n_fft));
+    c->wav_cap = R * cf->hop_length;
+    A(dalloc(c, &c->wav, c->wav_cap));
+    c->meta_cap = R + 2 * max_utts + 64;
+    A(dalloc(c, &c->meta, c->meta_cap));
+    (void)npages_max;
+    if (rc == NTTS_OK) {
+        hipMemset(c->h, 0, R * H * 4); hipMemset(c->t1, 0, R * H * 4);
+        hipMemset(c->xa, 0, R * H * 2); hipMemset(c->xb, 0, R * H * 2);
+        hipMemset(c->qkv, 0, R * 3 * H * 2);
+        hipDeviceSynchronize();
+    } else {
+        g_codec_create_err = c->err;
+        ntts_codec_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return NTTS_OK;
+}
+
+extern "C" int ntts_codec_load_tensor(ntts_codec* c, const char* name, const void* data, int dtype, const int64_t* shape,
+                                      int ndim, int is_device) {
+    if (!c || !name || !data || !shape || ndim < 1 || ndim > 3) return cfail(c, NTTS_EINVAL, "bad argument");
+    if (c->finalized) return cfail(c, NTTS_ESTATE, "weights already finalised");
+    if (dtype != NTTS_DT_F32 && dtype != NTTS_DT_BF16) return cfail(c, NTTS_EINVAL, "tensor '%s': dtype must be f32 or bf16", name);
+    CHIP(c, hipSetDevice(c->device));
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+    const size_t esz = dtype == NTTS_DT_F32 ? 4 : 2;
+    std::vector<unsigned char> raw(n * esz);
+    if (is_device) CHIP(c, hipMemcpy(raw.data(), data, n * esz, hipMemcpyDeviceToHost));
+    else memcpy(raw.data(), data, n * esz);
+    std::vector<float> v(n);
+    if (dtype == NTTS_DT_F32) memcpy(v.data(), raw.data(), n * 4);
+    else
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t u = (uint32_t)((const uint16_t*)raw.data())[i] << 16;
+            memcpy(&v[i], &u, 4);
+        }
+    c->host[name] = std::move(v);
+    c->shapes[name] = std::vector<int64_t>(shape, shape + ndim);
+    return NTTS_OK;
+}
+
+static bf16_t h_f2bf(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+static float h_bf2f(bf16_t b) {
+    const uint32_t u = (uint32_t)b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+struct Finalizer {
+    ntts_codec* c;
+    int rc = NTTS_OK;
+    const std::vector<float>* get(const std::string& name, std::initializer_list<int64_t> shp) {
+        auto it = c->host.find(name);
+        if (it == c->host.end()) { rc = cfail(c, NTTS_ESTATE, "tensor '%s' not loaded", name.c_str()); return nullptr; }
+        const auto& s = c->shapes[name];
+        if (s.size() != shp.size() || !std::equal(s.begin(), s.end(), shp.begin())) {
+            rc = cfail(c, NTTS_EINVAL, "tensor '%s': unexpected shape", name.c_str());
+            return nullptr;
+        }
+        return &it->second;
+    }
+    float* up_f32(const std::vector<float>& v) {
+        float* d = nullptr;
+        if (dalloc(c, &d, v.size()) != NTTS_OK || hipMemcpy(d, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = NTTS_EHIP; return nullptr; }
+        return d;
+    }
+    bf16_t* up_bf16(const std::vector<float>& v) {
+        std::vector<bf16_t> b(v.size());
+        for (size_t i = 0; i < v.size(); ++i) b[i] = h_f2bf(v[i]);
+        bf16_t* d = nullptr;
+        if (dalloc(c, &d, b.size()) != NTTS_OK || hipMemcpy(d, b.data(), b.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { rc = NTTS_EHIP; return nullptr; }
+        return d;
+    }
+    float* vec(const std::string& name, int64_t n) {
+        auto* v = get(name, {n});
+        return v ? up_f32(*v) : nullptr;
+    }
+    bf16_t* mat(const std::string& name, int64_t r, int64_t k) {
+        auto* v = get(name, {r, k});
+        return v ? up_bf16(*v) : nullptr;
+    }
+    // Conv1d weight [Cout][Cin][k] -> GEMM weight [Cout][k][Cin]  (row of the overlapping-rows GEMM = k frames x Cin)
+    bf16_t* conv(const std::string& name, int64_t co, int64_t ci, int64_t k) {
+        auto* v = get(name, {co, ci, k});
+        if (!v) return nullptr;
+        std::vector<float> r((size_t)co * k * ci);
+        for (int64_t o = 0; o < co; ++o)
+            for (int64_t i = 0; i < ci; ++i)
+                for (int64_t t = 0; t < k; ++t) r[((size_t)o * k + t) * ci + i] = (*v)[((size_t)o * ci + i) * k + t];
+        return up_bf16(r);
+    }
+};
+
+extern "C" int ntts_codec_finalize(ntts_codec* c) {
+    if (!c) return NTTS_EINVAL;
+    if (c->finalized) return NTTS_OK;
+    CHIP(c, hipSetDevice(c->device));
+    Finalizer f{c};
+    const int64_t H = c->H, I = c->I, Q = c->cfg.quantization_dim, nq = c->nq, NS = c->NS;
+    // ---- fold quantizer.project_out (nq -> Q) and decoder.fc (Q -> H): no nonlinearity in between
+    {
+        auto* pw = f.get("quantizer.project_out.weight", {Q, nq});
+        auto* pb = f.get("quantizer.project_out.bias", {Q});
+        auto* fw = f.get("decoder.fc.weight", {H, Q});
+        auto* fb = f.get("decoder.fc.bias", {H});
+        if (!pw || !pb || !fw || !fb) return f.rc;
+        std::vector<float> wf((size_t)H * nq), bf(H);
+        for (int64_t o = 0; o < H; ++o) {
+            double b = (*fb)[o];
+            std::vector<double> acc(nq, 0.0);
+            for (int64_t q = 0; q < Q; ++q) {
+                const double w = (*fw)[(size_t)o * Q + q];
+                b += w * (*pb)[q];
+                for (int64_t i = 0; i < nq; ++i) acc[i] += w * (*pw)[(size_t)q * nq + i];
+            }
+            bf[o] = (float)b;
+            for (int64_t i = 0; i < nq; ++i) wf[(size_t)o * nq + i] = (float)acc[i];
+        }
+        c->wf = f.up_f32(wf); c->bf = f.up_f32(bf);
+    }
+    c->embed_w = f.conv("decoder.embed.weight", H, H, 7);
+    c->embed_b = f.vec("decoder.embed.bias", H);
+    const char* nets[2] = {"prior_net", "post_net"};
+    for (int n = 0; n < 2; ++n)
+        for (int b = 0; b < 2; ++b) {
+            const std::string p = std::string("decoder.") + nets[n] + "." + std::to_string(b) + ".";
+            ResW& r = c->res[n * 2 + b];
+            r.g1 = f.vec(p + "norm1.weight", H); r.b1 = f.vec(p + "norm1.bias", H);
+            r.w1 = f.conv(p + "conv1.weight", H, H, 3); r.cb1 = f.vec(p + "conv1.bias", H);
+            r.g2 = f.vec(p + "norm2.weight", H); r.b2 = f.vec(p + "norm2.bias", H);
+            r.w2 = f.conv(p + "conv2.weight", H, H, 3); r.cb2 = f.vec(p + "conv2.bias", H);
+        }
+    c->layers.resize(c->cfg.num_layers);
+    for (int i = 0; i < c->cfg.num_layers && f.rc == NTTS_OK; ++i) {
+        const std::string p = "decoder.layers." + std::to_string(i) + ".";
+        CLayerW& L = c->layers[i];
+        L.ln1 = f.vec(p + "input_layernorm.weight", H);
+        L.ln2 = f.vec(p + "post_attention_layernorm.weight", H);
+        auto* q = f.get(p + "self_attn.q_proj.weight", {H, H});
+        auto* k = f.get(p + "self_attn.k_proj.weight", {H, H});
+        auto* v = f.get(p + "self_attn.v_proj.weight", {H, H});
+        if (!q || !k || !v) return f.rc;
+        std::vector<float> qkv;
+        qkv.reserve((size_t)3 * H * H);
+        qkv.insert(qkv.end(), q->begin(), q->end()); qkv.insert(qkv.end(), k->begin(), k->end()); qkv.insert(qkv.end(), v->begin(), v->end());
+        L.wqkv = f.up_bf16(qkv);
+        L.wo = f.mat(p + "self_attn.o_proj.weight", H, H);
+        L.fc1 = f.mat(p + "mlp.fc1.weight", I, H);
+        L.fc2 = f.mat(p + "mlp.fc2.weight", H, I);
+    }
+    c->fn_w = f.vec("decoder.norm.weight", H); c->fn_b = f.vec("decoder.norm.bias", H);
+    c->head_w = f.mat("decoder.head.linear.weight", NS, H);
+    c->head_b = f.vec("decoder.head.linear.bias", NS);
+    if (f.rc != NTTS_OK) return f.rc;
+    // ---- windowed inverse real DFT as a GEMM operand, split hi/lo so bf16 MFMA reaches ~fp32 accuracy:
+    //      frame[n] = hann[n]/N * ( Re0 + (-1)^n Re_{N/2} + 2 sum_k (Re_k cos(2 pi k n / N) - Im_k sin(2 pi k n / N)) )
+    //      (torch.fft.irfft norm="backward" + window, hf:...modeling_xcodec2.py:776-777); row layout [B_hi | B_hi | B_lo].
+    {
+        const int N = c->n_fft, nb = c->nb;
+        const long K3 = c->K3;
+        std::vector<bf16_t> B((size_t)N * K3, 0);
+        std::vector<float> w2(N);
+        for (int n = 0; n < N; ++n) {
+            const double win = 0.5 - 0.5 * cos(2.0 * M_PI * n / N);   // torch.hann_window (periodic)
+            w2[n] = (float)(win * win);
+            for (int k = 0; k < nb; ++k) {
+                const double ck = (k == 0 || k == N / 2) ? 1.0 : 2.0;
+                const double ang = 2.0 * M_PI * (double)((long)k * n % N) / N;
+                const float cr = (float)(win * ck * cos(ang) / N);
+                const float ci = (k == 0 || k == N / 2) ? 0.f : (float)(-win * ck * sin(ang) / N);
+                const bf16_t crh = h_f2bf(cr), cih = h_f2bf(ci);
+                const bf16_t crl = h_f2bf(cr - h_bf2f(crh)), cil = h_f2bf(ci - h_bf2f(cih));
+                bf16_t* row = &B[(size_t)n * K3];
+                row[k] = crh; row[nb + k] = cih;
+                row[2 * nb + k] = crh; row[3 * nb + k] = cih;
+                row[4 * nb + k] = crl; row[5 * nb + k] = cil;
+            }
+        }
+        if (dalloc(c, &c->basis3, B.size()) != NTTS_OK) return NTTS_ENOMEM;
+        CHIP(c, hipMemcpy(c->basis3, B.data(), B.size() * 2, hipMemcpyHostToDevice));
+        c->win2 = f.up_f32(w2);
+    }
+    if (f.rc != NTTS_OK) return f.rc;
+    c->host.clear();
+    c->finalized = true;
+    return NTTS_OK;
+}
+
+static GemmArgs cg(const bf16_t* X, long ldx, const bf16_t* W, long K, const float* bias, void* out, long ldo, long M, int N,
+                   const float* resid = nullptr, long ldr = 0) {
+    GemmArgs a{};
+    a.X = X; a.ldx = ldx; a.W = W; a.ldw = K; a.bias_f32 = bias; a.out = out; a.ldo = ldo; a.M = (int)M; a.N = N; a.K = (int)K;
+    a.resid = resid; a.ldr = ldr;
+    return a;
+}
+
+static void resnet_block(ntts_codec* c, const ResW& w, const CodecRows& R, long rows) {
+    const int H = c->H;
+    hipStream_t st = c->stream;
+    GroupNormArgs g{};
+    g.x = c->h; g.y = c->xa; g.gamma = w.g1; g.beta = w.b1; g.R = R; g.C = H; g.eps = 1e-6f;
+    NTTS_LAUNCH((groupnorm_silu_kernel), dim3(R.B, 32), dim3(256), st, g);
+    NTTS_GEMM_L(EPI_F32, cg(c->xa, H, w.w1, 3L * H, w.cb1, c->t1 + H, H, rows - 2, H), 1, st);
+    g.x = c->t1; g.y = c->xb; g.gamma = w.g2; g.beta = w.b2;
+    NTTS_LAUNCH((groupnorm_silu_kernel), dim3(R.B, 32), dim3(256), st, g);
+    NTTS_GEMM_L(EPI_F32, cg(c->xb, H, w.w2, 3L * H, w.cb2, c->h + H, H, rows - 2, H, c->h + H, H), 1, st);
+}
+
+extern "C" int ntts_codec_decode(ntts_codec* c, int32_t n, const int32_t* codes, const int32_t* lens, float* wav_out,
+                                 int64_t wav_stride) {
+    if (!c || n < 1 || !codes || !lens || !wav_out) return cfail(c, NTTS_EINVAL, "null/empty argument");
+    if (!c->finalized) return cfail(c, NTTS_ESTATE, "weights not finalised");
+    CHIP(c, hipSetDevice(c->device));
+    const int H = c->H, hop = c->cfg.hop_length;
+    int Tmax = 0;
+    long total = 0;
+    long ncodes = 1;
+    for (int i = 0; i < c->nq; ++i) ncodes *= c->cfg.levels[i];
+    for (int i = 0; i < n; ++i) {
+        if (lens[i] < 1 || lens[i] > c->cfg.max_frames) return cfail(c, NTTS_EINVAL, "utterance %d: %d frames (1..%d)", i, lens[i], c->cfg.max_frames);
+        if (lens[i] > Tmax) Tmax = lens[i];
+        total += lens[i];
+    }
+    for (long i = 0; i < total; ++i)
+        if (codes[i] < 0 || codes[i] >= ncodes) return cfail(c, NTTS_EINVAL, "code %d out of range [0, %ld)", codes[i], ncodes);
+    if (wav_stride < (int64_t)hop * Tmax) return cfail(c, NTTS_EINVAL, "wav_stride %ld < %d samples", (long)wav_stride, hop * Tmax);
+    const int Tp = Tmax + 2 * kPadRows;
+    const long rows = (long)n * Tp;
+    if (rows > c->max_rows) return cfail(c, NTTS_EINVAL, "%ld rows exceed max_rows %ld: decode fewer utterances per call", rows, c->max_rows);
+    const int npages = (Tmax + kPage - 1) / kPage, qtiles = (Tmax + 63) / 64;
+    // ---- meta: [lens n][code_off n][codes total]
+    std::vector<int> m;
+    m.reserve(2 * n + total);
+    m.insert(m.end(), lens, lens + n);
+    long off = 0;
+    for (int i = 0; i < n; ++i) { m.push_back((int)off); off += lens[i]; }
+    m.insert(m.end(), codes, codes + total);
+    if (m.size() > c->meta_cap) return cfail(c, NTTS_EINVAL, "meta block too large");
+    hipStream_t st = c->stream;
+    CHIP(c, hipMemcpyAsync(c->meta, m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice, st));
+    CHIP(c, hipStreamSynchronize(st));
+    CodecRows R{c->meta, n, Tp};
+    CHIP(c, hipEventRecord(c->ev[0], st));
+
+    CodecEmbedArgs ea{};
+    ea.codes = c->meta + 2 * n; ea.code_off = c->meta + n; ea.wf = c->wf; ea.bf = c->bf; ea.out = c->xa; ea.R = R; ea.H = H; ea.nq = c->nq;
+    for (int i = 0; i < 8; ++i) ea.levels[i] = i < c->nq ? c->cfg.levels[i] : 1;
+    NTTS_LAUNCH((codec_embed_kernel), dim3((unsigned)rows), dim3(256), st, ea);
+    // stem Conv1d(k=7, padding 3): window rows r..r+6 -> centre row r+3
+    NTTS_GEMM_L(EPI_F32, cg(c->xa, H, c->embed_w, 7L * H, c->embed_b, c->h + 3L * H, H, rows - 6, H), 1, st);
+    resnet_block(c, c->res[0], R, rows);
+    resnet_block(c, c->res[1], R, rows);
+    for (int i = 0; i < c->cfg.num_layers; ++i) {
+        const CLayerW& L = c->layers[i];
+        RowNormArgs rn{};
+        rn.x = c->h; rn.y = c->xa; rn.w = L.ln1; rn.rows = rows; rn.C = H; rn.eps = c->cfg.rms_eps;
+        rownorm_launch(rn, st);
+        NTTS_GEMM_L(EPI_BF16, cg(c->xa, H, L.wqkv, H, nullptr, c->qkv, 3L * H, rows, 3 * H), 1, st);
+        VTransposeArgs vt{};
+        vt.qkv = c->qkv; vt.vt = c->vt; vt.R = R; vt.C = H; vt.nh = c->cfg.num_heads; vt.npages = npages;
+        NTTS_LAUNCH((v_transpose_kernel), dim3(n * npages, c->cfg.num_heads), dim3(256), st, vt);
+        AttnFullArgs at{};
+        at.qkv = c->qkv; at.vt = c->vt; at.out = c->xb; at.R = R; at.C = H; at.nh = c->cfg.num_heads; at.npages = npages; at.qtiles = qtiles;
+        NTTS_LAUNCH((attn_full_kernel), dim3(n * qtiles, c->cfg.num_heads), dim3(256), st, at);
+        NTTS_GEMM_L(EPI_F32, cg(c->xb, H, L.wo, H, nullptr, c->h, H, rows, H, c->h, H), 1, st);
+        rn.w = L.ln2;
+        rownorm_launch(rn, st);
+        NTTS_GEMM_L(EPI_BF16_SILU, cg(c->xa, H, L.fc1, H, nullptr, c->act, c->I, rows, c->I), 1, st);
+        NTTS_GEMM_L(EPI_F32, cg(c->act, c->I, L.fc2, c->I, nullptr, c->h, H, rows, H, c->h, H), 1, st);
+    }
+    resnet_block(c, c->res[2], R, rows);
+    resnet_block(c, c->res[3], R, rows);
+    RowNormArgs fn{};
+    fn.x = c->h; fn.y = c->xa; fn.w = c->fn_w; fn.bias = c->fn_b; fn.rows = rows; fn.C = H; fn.eps = 1e-6f;
+    rownorm_launch(fn, st);
+    NTTS_GEMM_L(EPI_F32, cg(c->xa, H, c->head_w, H, c->head_b, c->spec, c->lds_spec, rows, c->NS), 1, st);
+    IstftPrepArgs ip{};
+    ip.spec = c->spec; ip.lds = c->lds_spec; ip.s3 = c->s3; ip.K3 = c->K3; ip.rows = rows; ip.nb = c->nb;
+    NTTS_LAUNCH((istft_prep_kernel), dim3((unsigned)rows), dim3(256), st, ip);
+    NTTS_GEMM_L(EPI_F32, cg(c->s3, c->K3, c->basis3, c->K3, nullptr, c->frames, c->n_fft, rows, c->n_fft), 1, st);
+    OlaArgs oa{};
+    oa.frames = c->frames; oa.win2 = c->win2; oa.wav = c->wav; oa.wav_stride = (long)hop * Tmax; oa.R = R; oa.hop = hop; oa.n_fft = c->n_fft;
+    NTTS_LAUNCH((ola_kernel), dim3(n, (unsigned)(((long)hop * Tmax + 255) / 256)), dim3(256), st, oa);
+    CHIP(c, hipEventRecord(c->ev[1], st));
+    c->have_time = true;
+    CHIP(c, hipStreamSynchronize(st));
+    CHIP(c, hipGetLastError());
+    for (int i = 0; i < n; ++i)
+        CHIP(c, hipMemcpy(wav_out + (size_t)i * wav_stride, c->wav + (size_t)i * hop * Tmax, (size_t)hop * lens[i] * sizeof(float), hipMemcpyDeviceToHost));
+    return NTTS_OK;
+}
+
+extern "C" int ntts_codec_last_timing(ntts_codec* c, float* ms) {
+    if (!c || !ms) return NTTS_EINVAL;
+    *ms = 0;
+    if (c->have_time) CHIP(c, hipEventElapsedTime(ms, c->ev[0], c->ev[1]));
+    return NTTS_OK;
+}

@@ -1,0 +1,363 @@
+// codec.h -- NeuCodec decoder kernels (everything that is not a GEMM).
+//
+// Replaces NeuCodec.decode_code (ref:neutts/neutts.py:288-291) as restated by transformers' xcodec2
+// (hf:models/xcodec2/modeling_xcodec2.py): FSQ de-index + project_out + fc (:806-809, :839), Conv1d k7 / k3
+// (as GEMMs over overlapping rows, gemm.h), GroupNorm(32)+SiLU (:650-659), RMSNorm / LayerNorm (:320-325,
+// :862), full (non-causal) attention (:268-308), ISTFT head (:762-796).
+//
+// Row layout ("padded flat rows"): utterance b owns rows [b*Tp, (b+1)*Tp), Tp = Tmax + 2*kPadRows; frame t sits
+// at row b*Tp + kPadRows + t.  Pad rows of every bf16 GEMM-input buffer are ZERO, which is exactly Conv1d's
+// zero padding, so a k-tap convolution is one GEMM with lda = C and K = k*C over overlapping rows.
+// The residual stream is fp32 (the reference codec runs in fp32); only GEMM operands are bf16.
+#pragma once
+#include <ntts/dev.h>
+#include "attn_decode.h"
+
+namespace ntts {
+
+constexpr int kPadRows = 3;  // covers the k=7 stem (padding 3) and the k=3 ResNet convs (padding 1)
+
+struct CodecRows {
+    const int* lens;   // [B] valid frames of each utterance
+    int B, Tp;         // rows = B * Tp
+};
+
+NTTS_D bool codec_row(const CodecRows& R, long r, int& b, int& t) {
+    b = (int)(r / R.Tp);
+    t = (int)(r % R.Tp) - kPadRows;
+    return t >= 0 && t < R.lens[b];
+}
+
+// ---- FSQ de-index + (project_out o fc) folded into one affine  8 -> H --------------------------------
+struct CodecEmbedArgs {
+    const int* codes;      // packed, utterance b starts at code_off[b]
+    const int* code_off;
+    const float* wf;       // [H][nq] folded weight (fp32)
+    const float* bf;       // [H]
+    bf16_t* out;           // [rows][H]
+    CodecRows R;
+    int H, nq;
+    int levels[8];
+};
+NTTS_KERNEL(256) void codec_embed_kernel(CodecEmbedArgs p) {
+    const long r = blockIdx.x;
+    int b, t;
+    const bool ok = codec_row(p.R, r, b, t);
+    float val[8];
+    if (ok) {
+        int code = p.codes[p.code_off[b] + t];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i < p.nq) {
+                const int L = p.levels[i], d = code % L, half = L / 2;   // hf:...modeling_xcodec2.py:680-690
+                code /= L;
+                val[i] = (float)(d - half) / (float)half;
+            } else val[i] = 0.f;
+        }
+    }
+    for (int c = threadIdx.x; c < p.H; c += 256) {
+        float acc = 0.f;
+        if (ok) {
+            acc = p.bf[c];
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (i < p.nq) acc += p.wf[(long)c * p.nq + i] * val[i];
+        }
+        p.out[r * p.H + c] = f2bf(acc);
+    }
+}
+
+// ---- GroupNorm(32 groups, eps) + SiLU : fp32 [rows][C] -> bf16 [rows][C], pad rows zeroed ---------------
+struct GroupNormArgs {
+    const float* x;
+    bf16_t* y;
+    const float* gamma;
+    const float* beta;
+    CodecRows R;
+    int C;
+    float eps;
+};
+// grid (B, 32); block 256 = (256/cg row lanes) x (cg channels)
+NTTS_KERNEL(256) void groupnorm_silu_kernel(GroupNormArgs p) {
+    NTTS_SHARED float red[2][4];
+    const int b = blockIdx.x, grp = blockIdx.y, tid = threadIdx.x;
+    const int cg = p.C / 32, nrl = 256 / cg;
+    const int ch = grp * cg + tid % cg, rl = tid / cg;
+    const int T = p.R.lens[b];
+    const long row0 = (long)b * p.R.Tp + kPadRows;
+    float s = 0.f, ss = 0.f;
+    for (int t = rl; t < T; t += nrl) {
+        const float v = p.x[(row0 + t) * p.C + ch];
+        s += v;
+        ss += v * v;
+    }
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) { s += shfl_xor(s, sh); ss += shfl_xor(ss, sh); }
+    if (lane_id() == 0) { red[0][wave_id()] = s; red[1][wave_id()] = ss; }
+    sync();
+    s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    ss = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const float n = (float)T * (float)cg;
+    const float mean = s / n;
+    float var = ss / n - mean * mean;
+    if (var < 0.f) var = 0.f;
+    const float rstd = frsqrt_exact(var + p.eps);
+    const float ga = p.gamma[ch], be = p.beta[ch];
+    for (int t = rl - kPadRows; t < p.R.Tp - kPadRows; t += nrl) {   // all Tp rows of the utterance
+        float o = 0.f;
+        if (t >= 0 && t < T) {
+            const float v = (p.x[(row0 + t) * p.C + ch] - mean) * rstd * ga + be;
+            o = v / (1.0f + fexp(-v));
+        }
+        p.y[(row0 + t) * p.C + ch] = f2bf(o);
+    }
+}
+
+// ---- RMSNorm / LayerNorm over a row: fp32 -> bf16, one wave per row -------------------------------------
+struct RowNormArgs {
+    const float* x;
+    bf16_t* y;
+    const float* w;
+    const float* bias;  // nullptr -> RMSNorm, else LayerNorm
+    long rows;
+    int C;
+    float eps;
+};
+template <int NV>  // float4 per lane: C <= 256 * NV
+NTTS_KERNEL(256) void rownorm_kernel(RowNormArgs p) {
+    const int lane = lane_id();
+    long row = (long)blockIdx.x * 4 + wave_id();
+    const bool rok = row < p.rows;
+    if (!rok) row = p.rows - 1;
+    const int nvec = p.C >> 2;
+    f32x4 v[NV];
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = lane + 64 * i;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (vi < nvec) v[i] = ld16<f32x4>(p.x + row * p.C + vi * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s += v[i][e]; ss += v[i][e] * v[i][e]; }
+    }
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) { s += shfl_xor(s, sh); ss += shfl_xor(ss, sh); }
+    const float n = (float)p.C;
+    float mean = 0.f, inv;
+    if (p.bias) {
+        mean = s / n;
+        float var = ss / n - mean * mean;
+        if (var < 0.f) var = 0.f;
+        inv = frsqrt_exact(var + p.eps);
+    } else {
+        inv = frsqrt_exact(ss / n + p.eps);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int vi = lane + 64 * i;
+        if (vi < nvec && rok) {
+            const f32x4 w = ld16<f32x4>(p.w + vi * 4);
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float y = (v[i][e] - mean) * inv * w[e];
+                if (p.bias) y += p.bias[vi * 4 + e];
+                o[e] = (short)f2bf(y);
+            }
+            *(bf16x4*)(p.y + row * p.C + vi * 4) = o;
+        }
+    }
+}
+inline void rownorm_launch(const RowNormArgs& p, hipStream_t s) {
+    const dim3 grid((unsigned)((p.rows + 3) / 4)), block(256);
+    if (p.C <= 256) NTTS_LAUNCH((rownorm_kernel<1>), grid, block, s, p);
+    else if (p.C <= 1024) NTTS_LAUNCH((rownorm_kernel<4>), grid, block, s, p);
+    else NTTS_LAUNCH((rownorm_kernel<8>), grid, block, s, p);
+}
+
+// ---- V -> V^T pages: qkv[rows][3C] (v part) -> vt[b][head][page][64 d][32 frames], frames >= T zeroed ------
+struct VTransposeArgs {
+    const bf16_t* qkv;
+    bf16_t* vt;
+    CodecRows R;
+    int C, nh, npages;
+};
+// grid (B * npages, nh)
+NTTS_KERNEL(256) void v_transpose_kernel(VTransposeArgs p) {
+    NTTS_SHARED bf16_t tile[kPage][64 + 2];
+    const int b = blockIdx.x / p.npages, pg = blockIdx.x % p.npages, h = blockIdx.y, tid = threadIdx.x;
+    const int T = p.R.lens[b];
+    const long row0 = (long)b * p.R.Tp + kPadRows + (long)pg * kPage;
+    for (int x = tid; x < kPage * 64; x += 256) {
+        const int tk = x >> 6, d = x & 63;
+        const int t = pg * kPage + tk;
+        tile[tk][d] = (t < T) ? p.qkv[(row0 + tk) * (3L * p.C) + 2 * p.C + h * 64 + d] : (bf16_t)0;
+    }
+    sync();
+    bf16_t* dst = p.vt + (((long)b * p.nh + h) * p.npages + pg) * 64 * kPage;
+    for (int x = tid; x < 64 * kPage; x += 256) {
+        const int d = x >> 5, tk = x & 31;
+        dst[d * kPage + tk] = tile[tk][d];
+    }
+}
+
+// ---- full (non-causal) multi-head attention within each utterance ----------------------------------------
+struct AttnFullArgs {
+    const bf16_t* qkv;   // [rows][3C]: q | k | v
+    const bf16_t* vt;    // from v_transpose_kernel
+    bf16_t* out;         // [rows][C]
+    CodecRows R;
+    int C, nh, npages, qtiles;
+};
+// grid (B * qtiles, nh); 4 waves x 16 queries.  Same matrix-core mapping as attn_prefill.h.
+NTTS_KERNEL(256) void attn_full_kernel(AttnFullArgs p) {
+    const int lane = lane_id(), w = wave_id();
+    const int g = lane >> 4, l15 = lane & 15;
+    const int b = blockIdx.x / p.qtiles, qt = blockIdx.x % p.qtiles, h = blockIdx.y;
+    const int T = p.R.lens[b];
+    const int qw0 = qt * 64 + w * 16;
+    if (qw0 >= T) return;  // wave-uniform, kernel has no barrier
+    const long row0 = (long)b * p.R.Tp + kPadRows;
+    const long ld = 3L * p.C;
+    int qi = qw0 + l15;
+    if (qi > T - 1) qi = T - 1;
+    const bf16_t* qr = p.qkv + (row0 + qi) * ld + h * 64 + g * 16;
+    bf16x8 qB[2];
+    qB[0] = ld16<bf16x8>(qr);
+    qB[1] = ld16<bf16x8>(qr + 8);
+    const int npg = (T + kPage - 1) / kPage;
+
+    auto scores = [&](int pg, float (&s)[8]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int kt = pg * kPage + u * 16 + l15;          // this lane's key row (A-operand row)
+            if (kt > T - 1) kt = T - 1;
+            const bf16_t* kr = p.qkv + (row0 + kt) * ld + p.C + h * 64 + g * 16;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = mfma16(ld16<bf16x8>(kr), qB[0], a);
+            a = mfma16(ld16<bf16x8>(kr + 8), qB[1], a);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = pg * kPage + u * 16 + g * 4 + r;
+                s[u * 4 + r] = key < T ? a[r] * 0.125f : -INFINITY;
+            }
+        }
+    };
+    float m = -INFINITY, sum = 0.f;
+    for (int pg = 0; pg < npg; ++pg) {
+        float s[8];
+        scores(pg, s);
+        float tm = s[0];
+#pragma unroll
+        for (int e = 1; e < 8; ++e) tm = fmaxf(tm, s[e]);
+        const float mn = fmaxf(m, tm);
+        if (mn != -INFINITY) {
+            float add = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) add += fexp(s[e] - mn);
+            sum = sum * fexp(m - mn) + add;
+            m = mn;
+        }
+    }
+#pragma unroll
+    for (int sh = 16; sh <= 32; sh <<= 1) {
+        const float om = shfl_xor(m, sh), os = shfl_xor(sum, sh);
+        const float mn = fmaxf(m, om);
+        if (mn != -INFINITY) {
+            sum = (m == -INFINITY ? 0.f : sum * fexp(m - mn)) + (om == -INFINITY ? 0.f : os * fexp(om - mn));
+            m = mn;
+        }
+    }
+    f32x4 oacc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) oacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float rs = 1.0f / sum;
+    for (int pg = 0; pg < npg; ++pg) {
+        float s[8];
+        scores(pg, s);
+        bf16x8 pA;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pA[e] = (short)f2bf(fexp(s[e] - m) * rs);
+        const bf16_t* vp = p.vt + (((long)b * p.nh + h) * p.npages + pg) * 64 * kPage;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const bf16_t* vr = vp + (nt * 16 + l15) * kPage + g * 4;
+            const bf16x4 v0 = ld16<bf16x4>(vr), v1 = ld16<bf16x4>(vr + 16);
+            bf16x8 vB;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { vB[e] = v0[e]; vB[4 + e] = v1[e]; }
+            oacc[nt] = mfma16(pA, vB, oacc[nt]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int q = qw0 + g * 4 + r;
+        if (q < T) {
+            bf16_t* o = p.out + (row0 + q) * p.C + h * 64 + l15;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) o[nt * 16] = f2bf(oacc[nt][r]);
+        }
+    }
+}
+
+// ---- ISTFT head: spectrum -> hi/lo-split bf16 DFT operand ------------------------------------------------
+// spec fp32 [rows][lds]: log-magnitude bins [0, nb) | phase bins [nb, 2nb), nb = n_fft/2 + 1.
+// s3 bf16 [rows][K3]: [re_hi | im_hi | re_lo | im_lo | re_hi | im_hi | 0...]  (pairs with basis [B_hi | B_hi | B_lo])
+struct IstftPrepArgs {
+    const float* spec;
+    long lds;
+    bf16_t* s3;
+    long K3;
+    long rows;
+    int nb;
+};
+NTTS_KERNEL(256) void istft_prep_kernel(IstftPrepArgs p) {
+    const long r = blockIdx.x;
+    const float* x = p.spec + r * p.lds;
+    bf16_t* o = p.s3 + r * p.K3;
+    for (int k = threadIdx.x; k < p.nb; k += 256) {
+        float mag = fexp(x[k]);
+        if (mag > 100.f) mag = 100.f;              // hf:...modeling_xcodec2.py:771
+        const float ph = x[p.nb + k];
+        const float re = mag * cosf(ph), im = mag * sinf(ph);
+        const bf16_t rh = f2bf(re), ih = f2bf(im);
+        const bf16_t rl = f2bf(re - bf2f(rh)), il = f2bf(im - bf2f(ih));
+        o[k] = rh; o[p.nb + k] = ih;
+        o[2 * p.nb + k] = rl; o[3 * p.nb + k] = il;
+        o[4 * p.nb + k] = rh; o[5 * p.nb + k] = ih;
+    }
+    for (long k = 6L * p.nb + threadIdx.x; k < p.K3; k += 256) o[k] = 0;
+}
+
+// ---- overlap-add of the windowed frames, trim, divide by the window envelope -------------------------------
+struct OlaArgs {
+    const float* frames;   // [rows][n_fft]  (window already folded into the DFT basis)
+    const float* win2;     // [n_fft] window^2
+    float* wav;            // [B][wav_stride]
+    long wav_stride;
+    CodecRows R;
+    int hop, n_fft;
+};
+// grid (B, ceil(hop*Tmax / 256))
+NTTS_KERNEL(256) void ola_kernel(OlaArgs p) {
+    const int b = blockIdx.x;
+    const int T = p.R.lens[b];
+    const long s = (long)blockIdx.y * 256 + threadIdx.x;
+    if (s >= (long)p.hop * T) return;
+    const int pad = (p.n_fft - p.hop) / 2;
+    const long pos = s + pad;                       // index in the untrimmed overlap-add buffer
+    const long row0 = (long)b * p.R.Tp + kPadRows;
+    int f_hi = (int)(pos / p.hop);
+    if (f_hi > T - 1) f_hi = T - 1;
+    float acc = 0.f, env = 0.f;
+    for (int f = f_hi; f >= 0; --f) {
+        const long n = pos - (long)f * p.hop;
+        if (n >= p.n_fft) break;
+        acc += p.frames[(row0 + f) * p.n_fft + n];
+        env += p.win2[n];
+    }
+    if (env < 1e-11f) env = 1e-11f;                 // hf:...modeling_xcodec2.py:793
+    p.wav[(long)b * p.wav_stride + s] = acc / env;
+}
+
+}  // namespace ntts

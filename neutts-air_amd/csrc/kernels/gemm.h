@@ -29,8 +29,8 @@ enum GemmEpi {
     EPI_SILU_MUL = 1,  // W rows packed gate/up (see pack_gate_up); out bf16 [M][N/2] = silu(g)*u, HF rounding
     EPI_SPLITK = 2,    // out fp32 [split][M][N] raw partial sums
     EPI_ARGMAX = 3,    // per-row (max, first index) partials over this wave's 64 columns, logits = bf16(acc)
-    EPI_BF16_SILU = 4, // out bf16 = silu(bf16(acc + bias))   (codec MLP fc1)
-    EPI_F32 = 5        // out fp32 [M][N] = acc + bias (no rounding; codec ISTFT head / DFT)
+    EPI_BF16_SILU = 4, // out bf16 = bf16(silu(acc + bias))   (codec MLP fc1; the codec reference is fp32)
+    EPI_F32 = 5        // out fp32 [M][N] = acc + bias (+ fp32 residual): codec residual stream / ISTFT head / DFT
 };
 
 struct GemmArgs {
@@ -39,6 +39,7 @@ struct GemmArgs {
     const bf16_t* W;
     long ldw;
     const bf16_t* bias;  // [N] or nullptr
+    const float* bias_f32;  // alternative fp32 bias (codec path keeps its affine terms in fp32)
     void* out;
     long ldo;
     int M, N, K;  // K % 64 == 0
@@ -51,6 +52,9 @@ struct GemmArgs {
     const int* mask_eos;   // [M] value e+1 > 0 -> logit[e] = -inf for that row (MinNewTokens processor)
     float* logits;         // optional fp32 [M][ld_logits] dump of the processed logits
     long ld_logits;
+    // EPI_F32
+    const float* resid;    // optional fp32 [M][ldr] added in the epilogue (may alias out)
+    long ldr;
 };
 
 NTTS_D void gemm_tile_coords(int bid, int mblocks, int nblocks, int& mb, int& nb) {
@@ -69,6 +73,7 @@ NTTS_D void gemm_tile_coords(int bid, int mblocks, int nblocks, int& mb, int& nb
 }
 
 NTTS_D float silu_f(float x) { return x / (1.0f + fexp(-x)); }
+NTTS_D float gemm_bias(const GemmArgs& p, int n) { return p.bias_f32 ? p.bias_f32[n] : (p.bias ? bf2f(p.bias[n]) : 0.f); }
 
 template <int WM, int WN, int TM, int EPI>
 NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
@@ -173,8 +178,8 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
                 for (int r = 0; r < 4; ++r) {
                     const int n = nb16 + j * 4 + r;
                     float v = acc[a][j][r];
-                    if (p.bias && n < p.N) v += bf2f(p.bias[n]);
-                    if constexpr (EPI == EPI_BF16_SILU) v = silu_f(rbf(v));
+                    if (n < p.N) v += gemm_bias(p, n);
+                    if constexpr (EPI == EPI_BF16_SILU) v = silu_f(v);
                     o[j * 4 + r] = f2bf(v);
                 }
             if (mok) {
@@ -190,13 +195,31 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         } else if constexpr (EPI == EPI_F32) {
             if (mok) {
                 float* dst = (float*)p.out + (long)m * p.ldo + nb16;
+                const float* rs = p.resid ? p.resid + (long)m * p.ldr + nb16 : nullptr;
+                if (nb16 + 16 <= p.N) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 v = acc[a][j];
+                        if (p.bias || p.bias_f32) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int n = nb16 + j * 4 + r;
-                        if (n < p.N) dst[j * 4 + r] = acc[a][j][r] + (p.bias ? bf2f(p.bias[n]) : 0.f);
+                            for (int r = 0; r < 4; ++r) v[r] += gemm_bias(p, nb16 + j * 4 + r);
+                        }
+                        if (rs) {
+                            const f32x4 q = ld16<f32x4>(rs + j * 4);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += q[r];
+                        }
+                        *(f32x4*)(dst + j * 4) = v;
                     }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int n = nb16 + j * 4 + r;
+                            if (n < p.N) dst[j * 4 + r] = acc[a][j][r] + gemm_bias(p, n) + (rs ? rs[j * 4 + r] : 0.f);
+                        }
+                }
             }
         } else if constexpr (EPI == EPI_SILU_MUL) {
             // packed rows: j = 0,1 -> gate features fb + j*4 + r ; j = 2,3 -> up of the same features

@@ -7,7 +7,7 @@
 
 #define NTTS_HD __host__ __device__ __forceinline__
 #define NTTS_D __device__ __forceinline__
-#define NTTS_KERNEL(threads) __global__ __launch_bounds__(threads)
+#define NTTS_KERNEL(threads) static __global__ __launch_bounds__(threads)
 #define NTTS_SHARED __shared__ __attribute__((aligned(16)))
 
 namespace ntts {

@@ -34,6 +34,13 @@ class BackboneConfigC(C.Structure):
                 ("max_batch", C.c_int32), ("num_pages", C.c_int32), ("max_prefill_tokens", C.c_int32)]
 
 
+class CodecConfigC(C.Structure):
+    _fields_ = [("hidden_size", C.c_int32), ("intermediate_size", C.c_int32), ("num_layers", C.c_int32),
+                ("num_heads", C.c_int32), ("head_dim", C.c_int32), ("quantization_dim", C.c_int32),
+                ("n_levels", C.c_int32), ("levels", C.c_int32 * 8), ("hop_length", C.c_int32), ("rms_eps", C.c_float),
+                ("max_frames", C.c_int32), ("max_rows", C.c_int32)]
+
+
 class SamplingC(C.Structure):
     _fields_ = [("max_length", C.c_int32), ("min_new_tokens", C.c_int32), ("eos_token_id", C.c_int32),
                 ("do_sample", C.c_int32), ("top_k", C.c_int32), ("temperature", C.c_float), ("seed", C.c_uint64)]
@@ -74,6 +81,13 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_backbone_debug_force": (C.c_int, [p, i32, i32]),
         "ntts_backbone_last_timing": (C.c_int, [p, C.POINTER(f32), C.POINTER(f32)]),
         "ntts_backbone_step_bytes": (C.c_int, [p, C.POINTER(C.c_double)]),
+        "ntts_codec_last_error": (C.c_char_p, [p]),
+        "ntts_codec_create": (C.c_int, [C.POINTER(CodecConfigC), C.c_int, C.POINTER(p)]),
+        "ntts_codec_destroy": (None, [p]),
+        "ntts_codec_load_tensor": (C.c_int, [p, C.c_char_p, p, C.c_int, C.POINTER(i64), C.c_int, C.c_int]),
+        "ntts_codec_finalize": (C.c_int, [p]),
+        "ntts_codec_decode": (C.c_int, [p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(f32), i64]),
+        "ntts_codec_last_timing": (C.c_int, [p, C.POINTER(f32)]),
         "ntts_k_gemm_bf16": (C.c_int, [p, i64, p, p, p, i64, i32, i32, i32, i32]),
         "ntts_k_rmsnorm_bf16": (C.c_int, [p, p, p, i32, i32, f32]),
         "ntts_k_membw": (C.c_int, [C.c_size_t, i32, C.POINTER(C.c_double)]),
@@ -286,3 +300,72 @@ class BackboneEngine:
             if owner and any(st[s] == 1 for s in owner):
                 self.decode(steps_per_poll)
         return [r if r is not None else [] for r in results]
+
+
+class CodecEngine:
+    """NeuCodec decoder on one GPU: codes -> 24 kHz waveform (replaces codec.decode_code, ref:neutts/neutts.py:288-291)."""
+
+    def __init__(self, cfg: dict, device: int = 0, lib_path: Optional[str] = None):
+        self.lib = load_library(lib_path)
+        lv = list(cfg.get("levels", [4] * 8))
+        c = CodecConfigC(cfg.get("hidden_size", 1024), cfg.get("intermediate_size", 4096), cfg.get("num_layers", 12),
+                         cfg.get("num_heads", 16), cfg.get("head_dim", 64), cfg.get("quantization_dim", 2048), len(lv),
+                         (C.c_int32 * 8)(*(lv + [1] * (8 - len(lv)))), cfg.get("hop_length", 480), cfg.get("rms_eps", 1e-6),
+                         cfg.get("max_frames", 2048), cfg.get("max_rows", 4096))
+        h = C.c_void_p()
+        rc = self.lib.ntts_codec_create(C.byref(c), device, C.byref(h))
+        if rc != 0:
+            raise NeuTTSHipError(rc, (self.lib.ntts_codec_last_error(None) or b"").decode())
+        self.h = h
+        self.hop_length = c.hop_length
+        self.max_frames, self.max_rows = c.max_frames, c.max_rows
+        self.device = device
+
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise NeuTTSHipError(rc, (self.lib.ntts_codec_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ntts_codec_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_state_dict(self, sd: Dict[str, object]):
+        for k, v in sd.items():
+            ptr, code, shape, is_dev, keep = _tensor_ptr(v)
+            shp = (C.c_int64 * len(shape))(*shape)
+            self._chk(self.lib.ntts_codec_load_tensor(self.h, k.encode(), C.c_void_p(ptr), code, shp, len(shape), is_dev))
+            del keep
+        self._chk(self.lib.ntts_codec_finalize(self.h))
+
+    def decode(self, codes: Sequence[Sequence[int]]) -> List[np.ndarray]:
+        """codes: one int sequence per utterance -> list of float32 waveforms (hop_length * len each)."""
+        out: List[Optional[np.ndarray]] = [None] * len(codes)
+        order = sorted(range(len(codes)), key=lambda i: -len(codes[i]))   # batch similar lengths together
+        i = 0
+        i32p = C.POINTER(C.c_int32)
+        while i < len(order):
+            tmax = len(codes[order[i]])
+            nb = max(1, min(len(order) - i, self.max_rows // (tmax + 6)))
+            grp = order[i:i + nb]
+            lens = np.array([len(codes[j]) for j in grp], dtype=np.int32)
+            flat = np.ascontiguousarray(np.concatenate([np.asarray(codes[j], dtype=np.int32) for j in grp]))
+            stride = int(self.hop_length * tmax)
+            wav = np.empty((len(grp), stride), dtype=np.float32)
+            self._chk(self.lib.ntts_codec_decode(self.h, len(grp), flat.ctypes.data_as(i32p), lens.ctypes.data_as(i32p),
+                                                 wav.ctypes.data_as(C.POINTER(C.c_float)), stride))
+            for r, j in enumerate(grp):
+                out[j] = wav[r, : self.hop_length * len(codes[j])].copy()
+            i += nb
+        return out  # type: ignore[return-value]
+
+    def last_timing(self) -> float:
+        ms = C.c_float()
+        self._chk(self.lib.ntts_codec_last_timing(self.h, C.byref(ms)))
+        return ms.value

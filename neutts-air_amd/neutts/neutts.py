@@ -1,0 +1,416 @@
+"""NeuTTS -- the reference's class surface (ref:neutts/neutts.py:73-465) over the MI355X-native hot path.
+
+Same constructor arguments, public attributes, `infer` / `infer_stream` / `encode_reference` signatures, return
+types and error messages as the reference; the two third-party calls on its hot path are replaced:
+
+    self.backbone.generate(...)      ref:neutts/neutts.py:338-347   ->  _hip.BackboneEngine (HIP, paged KV, batched)
+    self.codec.decode_code(codes)    ref:neutts/neutts.py:288-291   ->  _hip.CodecEngine    (HIP)
+
+and the id -> string -> regex -> id round trip between them (ref :349 -> :276) becomes `code = id - id(<|speech_0|>)`
+with a range mask (ids outside the speech range are dropped, exactly what the regex does).
+
+Differences, all deliberate:
+  * devices: this implementation runs on MI355X only -- "cpu" raises (there is no CPU fallback); defaults are "cuda".
+  * `infer_stream` is implemented for this backend (the reference raises NotImplementedError for torch, :264) with
+    the GGUF path's window / overlap-add semantics (:401-465).
+  * batched entry points (`infer_batch`, `generate_codes`, `decode_codes`) expose what the engine is built for.
+  * GGUF (llama.cpp) backbones and the ONNX codec are other runtimes of the same model and are not provided.
+Optional front/back-end dependencies (phonemizer, librosa, neucodec, perth) are imported lazily, where used.
+"""
+from __future__ import annotations
+
+import re
+import warnings
+from pathlib import Path
+from typing import Dict, Generator, List, Optional, Sequence
+
+import numpy as np
+
+from . import _hip
+
+_SPEECH_RE = re.compile(r"<\|speech_(\d+)\|>")
+
+
+def _linear_overlap_add(frames: List[np.ndarray], stride: int) -> np.ndarray:
+    """Triangular-weight cross-fade of overlapping chunks; behaviour of ref:neutts/neutts.py:46-70."""
+    assert len(frames)
+    dtype = frames[0].dtype
+    total = max(stride * i + f.shape[-1] for i, f in enumerate(frames))
+    weight_sum = np.zeros(total, dtype=dtype)
+    mixed = np.zeros(total, dtype=dtype)
+    for i, f in enumerate(frames):
+        n = f.shape[-1]
+        t = np.linspace(0, 1, n + 2, dtype=dtype)[1:-1]
+        tri = np.abs(0.5 - (t - 0.5))
+        mixed[stride * i: stride * i + n] += tri * f
+        weight_sum[stride * i: stride * i + n] += tri
+    assert weight_sum.min() > 0
+    return mixed / weight_sum
+
+
+def _device_index(device, what: str) -> int:
+    s = str(device)
+    if s in ("gpu", "cuda", "hip"):
+        return 0
+    if s.startswith("cuda:") or s.startswith("hip:"):
+        return int(s.split(":", 1)[1])
+    raise RuntimeError(
+        f"{what}={device!r}: this NeuTTS implementation runs on AMD MI355X (gfx950) only and has no CPU fallback; "
+        "pass 'cuda' / 'cuda:N'.")
+
+
+class _CodecFacade:
+    """What `self.codec` looks like to callers of the reference: `.decode_code(codes[B,1,T]) -> wav[B,1,480*T]`,
+    `.encode_code(audio_or_path=...)` (delegated to the neucodec package when it is installed) and `.device`."""
+
+    def __init__(self, engine: _hip.CodecEngine, encoder=None):
+        self.engine = engine
+        self.encoder = encoder
+        self.device = f"cuda:{engine.device}"
+
+    def decode_code(self, codes):
+        arr = np.asarray(codes.cpu() if hasattr(codes, "cpu") else codes)
+        if arr.ndim != 3 or arr.shape[1] != 1:
+            raise ValueError("codes must have shape [B, 1, T]")
+        wavs = self.engine.decode([arr[b, 0].tolist() for b in range(arr.shape[0])])
+        import torch  # tensor container for API compatibility
+        return torch.from_numpy(np.stack(wavs)[:, None, :])
+
+    def encode_code(self, audio_or_path):
+        if self.encoder is None:
+            raise ImportError("Reference encoding needs the `neucodec` package (encoder half, not part of the "
+                              "synthesis hot path): pip install neucodec, or pre-encode references "
+                              "(ref:examples/encode_reference.py).")
+        return self.encoder.encode_code(audio_or_path=audio_or_path)
+
+
+class NeuTTS:
+
+    def __init__(
+        self,
+        backbone_repo="neuphonic/neutts-nano",
+        backbone_device="cuda",
+        codec_repo="neuphonic/neucodec",
+        codec_device="cuda",
+        *,
+        max_batch: int = 1,
+        lib_path: Optional[str] = None,
+        do_sample: bool = True,
+        seed: int = 0,
+    ):
+        # Consts (ref:neutts/neutts.py:84-91)
+        self.sample_rate = 24_000
+        self.max_context = 2048
+        self.hop_length = 480
+        self.streaming_overlap_frames = 1
+        self.streaming_frames_per_chunk = 25
+        self.streaming_lookforward = 5
+        self.streaming_lookback = 50
+        self.streaming_stride_samples = self.streaming_frames_per_chunk * self.hop_length
+
+        self._is_quantized_model = False
+        self._is_onnx_codec = False
+        self._lib_path = lib_path
+        self._max_batch = max_batch
+        # sampling contract of the reference call (ref:neutts/neutts.py:338-347); do_sample=False = greedy
+        self.do_sample = do_sample
+        self.top_k = 50
+        self.temperature = 1.0
+        self.min_new_tokens = 50
+        self._seed = seed
+
+        self.tokenizer = None
+        self.phonemizer = None       # created on first use: text front-end is off the hot path
+        self._load_backbone(backbone_repo, backbone_device)
+        self._load_codec(codec_repo, codec_device)
+
+        try:  # optional watermarker, as the reference (ref:neutts/neutts.py:110-121)
+            import perth
+            self.watermarker = perth.PerthImplicitWatermarker()
+        except (ImportError, AttributeError) as e:
+            warnings.warn(f"Perth watermarking unavailable: {e}. Audio will not be watermarked. "
+                          "Install with: pip install perth>=0.2.0")
+            self.watermarker = None
+
+    # ------------------------------------------------------------------------------------------ loading
+    def _load_backbone(self, backbone_repo, backbone_device):
+        print(f"Loading backbone from: {backbone_repo if isinstance(backbone_repo, str) else '<in-memory weights>'}"
+              f" on {backbone_device} ...")
+        dev = _device_index(backbone_device, "backbone_device")
+        if isinstance(backbone_repo, dict):
+            # in-memory weights (tests, synthetic benchmarks): {"config", "state_dict", "inv_freq", "tokenizer",
+            # "speech_base", "eos_token_id"}
+            spec = backbone_repo
+            cfg, sd, inv_freq = dict(spec["config"]), spec["state_dict"], spec["inv_freq"]
+            self.tokenizer = spec.get("tokenizer")
+            self._speech_base = spec.get("speech_base")
+            self._eos_id = spec.get("eos_token_id")
+        else:
+            if str(backbone_repo).endswith("gguf"):
+                raise NotImplementedError(
+                    "GGUF backbones run on llama.cpp (another runtime of the same model, quantised numerics); this "
+                    "implementation provides the transformers-path backbone on MI355X only.")
+            from transformers import AutoConfig, AutoModelForCausalLM, AutoTokenizer  # checkpoint readers only
+            self.tokenizer = AutoTokenizer.from_pretrained(backbone_repo)
+            hc = AutoConfig.from_pretrained(backbone_repo)
+            if getattr(hc, "model_type", "") not in ("qwen2",):
+                raise NotImplementedError(f"backbone model_type {hc.model_type!r}: only the Qwen2 architecture "
+                                          "(NeuTTS-Air) is implemented")
+            model = AutoModelForCausalLM.from_pretrained(backbone_repo)
+            sd = {k: v for k, v in model.state_dict().items() if not k.endswith("inv_freq")}
+            inv_freq = model.model.rotary_emb.inv_freq.float().cpu().numpy()
+            cfg = dict(vocab_size=hc.vocab_size, hidden_size=hc.hidden_size, intermediate_size=hc.intermediate_size,
+                       num_layers=hc.num_hidden_layers, num_heads=hc.num_attention_heads,
+                       num_kv_heads=hc.num_key_value_heads, rms_eps=hc.rms_norm_eps,
+                       head_dim=getattr(hc, "head_dim", None) or hc.hidden_size // hc.num_attention_heads)
+            del model
+            self._speech_base = self.tokenizer.convert_tokens_to_ids("<|speech_0|>")
+            self._eos_id = self.tokenizer.convert_tokens_to_ids("<|SPEECH_GENERATION_END|>")
+        cfg.setdefault("max_context", self.max_context)
+        cfg["max_batch"] = self._max_batch
+        cfg.setdefault("max_prefill_tokens", max(2 * self.max_context, 8192))
+        self.backbone = _hip.BackboneEngine(cfg, dev, self._lib_path)
+        self.backbone.load_state_dict(sd, inv_freq=inv_freq)
+        self._vocab_size = cfg["vocab_size"]
+
+    def _load_codec(self, codec_repo, codec_device):
+        print(f"Loading codec from: {codec_repo if isinstance(codec_repo, str) else '<in-memory weights>'} on {codec_device} ...")
+        dev = _device_index(codec_device, "codec_device")
+        encoder = None
+        if isinstance(codec_repo, dict):
+            cfg, sd = dict(codec_repo["config"]), codec_repo["state_dict"]
+        else:
+            match codec_repo:
+                case "neuphonic/neucodec" | "neuphonic/distill-neucodec":
+                    try:
+                        from neucodec import DistillNeuCodec, NeuCodec
+                    except ImportError as e:
+                        raise ImportError(
+                            "Loading the NeuCodec checkpoint needs the `neucodec` package (weights + reference "
+                            "encoder): pip install neucodec") from e
+                    cls = NeuCodec if codec_repo == "neuphonic/neucodec" else DistillNeuCodec
+                    encoder = cls.from_pretrained(codec_repo).eval()
+                    sd = neucodec_to_xcodec2_names(encoder.state_dict())
+                    cfg = {}
+                case "neuphonic/neucodec-onnx-decoder":
+                    raise NotImplementedError("The ONNX decoder is a CPU runtime of the same decoder; use "
+                                              "'neuphonic/neucodec' for the MI355X path.")
+                case _:
+                    raise ValueError(
+                        "Invalid codec repo! Must be one of:"
+                        " 'neuphonic/neucodec', 'neuphonic/distill-neucodec',"
+                        " 'neuphonic/neucodec-onnx-decoder'."
+                    )
+        cfg.setdefault("hop_length", self.hop_length)
+        cfg.setdefault("max_frames", self.max_context)
+        cfg.setdefault("max_rows", max(2 * (self.max_context + 6), self._max_batch * 512))
+        self.hop_length = cfg["hop_length"]
+        self.streaming_stride_samples = self.streaming_frames_per_chunk * self.hop_length
+        engine = _hip.CodecEngine(cfg, dev, self._lib_path)
+        engine.load_state_dict(sd)
+        self.codec = _CodecFacade(engine, encoder)
+
+    # ------------------------------------------------------------------------------------------ public API
+    def infer(self, text: str, ref_codes, ref_text: str) -> np.ndarray:
+        """Generate speech for `text` in the voice of the encoded reference (ref:neutts/neutts.py:216-243)."""
+        prompt_ids = self._apply_chat_template(ref_codes, ref_text, text)
+        new_ids = self.generate_codes([prompt_ids])[0]
+        wav = self._decode_ids(new_ids)
+        return wav if self.watermarker is None else self.watermarker.apply_watermark(wav, sample_rate=24_000)
+
+    def infer_batch(self, texts: Sequence[str], ref_codes, ref_texts) -> List[np.ndarray]:
+        """Many utterances at once: continuous batching over the engine's decode slots, one codec pass."""
+        if not isinstance(ref_texts, (list, tuple)):
+            ref_texts = [ref_texts] * len(texts)
+            ref_codes = [ref_codes] * len(texts)
+        prompts = [self._apply_chat_template(rc, rt, t) for rc, rt, t in zip(ref_codes, ref_texts, texts)]
+        codes = [self._ids_to_codes(ids) for ids in self.generate_codes(prompts)]
+        if any(len(c) == 0 for c in codes):
+            raise ValueError("No valid speech tokens found in the output.")
+        wavs = self.codec.engine.decode(codes)
+        if self.watermarker is not None:
+            wavs = [self.watermarker.apply_watermark(w, sample_rate=24_000) for w in wavs]
+        return wavs
+
+    def infer_stream(self, text: str, ref_codes, ref_text: str) -> Generator[np.ndarray, None, None]:
+        """Streaming synthesis with the reference's window / cross-fade semantics (ref:neutts/neutts.py:373-465)."""
+        prompt_ids = self._apply_chat_template(ref_codes, ref_text, text)
+        return self._infer_stream_hip(prompt_ids, [int(c) for c in _to_list(ref_codes)])
+
+    def encode_reference(self, ref_audio_path: str | Path):
+        """ref:neutts/neutts.py:266-271 -- one-off per speaker, off the hot path: delegated to neucodec's encoder."""
+        import librosa
+        import torch
+        wav, _ = librosa.load(ref_audio_path, sr=16000, mono=True)
+        wav_tensor = torch.from_numpy(wav).float().unsqueeze(0).unsqueeze(0)  # [1, 1, T]
+        with torch.no_grad():
+            ref_codes = self.codec.encode_code(audio_or_path=wav_tensor).squeeze(0).squeeze(0)
+        return ref_codes
+
+    # ------------------------------------------------------------------------------------------ id-level hot path
+    def _sampling(self, prompt_len: int) -> _hip.Sampling:
+        if self._eos_id is None:
+            raise RuntimeError("eos token id unknown: supply 'eos_token_id' with in-memory weights")
+        return _hip.Sampling(max_length=self.max_context, min_new_tokens=self.min_new_tokens, eos_token_id=self._eos_id,
+                             do_sample=self.do_sample, top_k=self.top_k, temperature=self.temperature, seed=self._seed)
+
+    def generate_codes(self, prompts: Sequence[Sequence[int]]) -> List[List[int]]:
+        """Batched equivalent of `_infer_torch` (ref:neutts/neutts.py:334-352): new token ids per prompt."""
+        self._seed += 1
+        return self.backbone.generate(prompts, [self._sampling(len(p)) for p in prompts])
+
+    def _ids_to_codes(self, ids: Sequence[int]) -> List[int]:
+        """ref :349 (tokenizer.decode) + :276 (regex): keep `<|speech_N|>` tokens, N = id - id(<|speech_0|>)."""
+        if self._speech_base is not None:
+            n_codes = 65536
+            return [i - self._speech_base for i in ids if self._speech_base <= i < self._speech_base + n_codes]
+        text = self.tokenizer.decode(list(ids), add_special_tokens=False)
+        return [int(n) for n in _SPEECH_RE.findall(text)]
+
+    def decode_codes(self, codes: Sequence[Sequence[int]]) -> List[np.ndarray]:
+        return self.codec.engine.decode(codes)
+
+    def _decode_ids(self, ids: Sequence[int]) -> np.ndarray:
+        speech_ids = self._ids_to_codes(ids)
+        if len(speech_ids) > 0:
+            return self.codec.engine.decode([speech_ids])[0]
+        raise ValueError("No valid speech tokens found in the output.")
+
+    def _decode(self, codes: str) -> np.ndarray:
+        """String form kept for callers of the reference's private helper (ref:neutts/neutts.py:273-295)."""
+        speech_ids = [int(num) for num in _SPEECH_RE.findall(codes)]
+        if len(speech_ids) > 0:
+            return self.codec.engine.decode([speech_ids])[0]
+        raise ValueError("No valid speech tokens found in the output.")
+
+    # ------------------------------------------------------------------------------------------ text front-end
+    def _to_phones(self, text: str) -> str:
+        if self.phonemizer is None:
+            try:
+                from phonemizer.backend import EspeakBackend
+            except ImportError as e:
+                raise ImportError("Text input needs `phonemizer` + espeak-ng (ref:requirements.txt:4); id-level entry "
+                                  "points (generate_codes / decode_codes) do not.") from e
+            print("Loading phonemizer...")
+            self.phonemizer = EspeakBackend(language="en-us", preserve_punctuation=True, with_stress=True)
+        phones = self.phonemizer.phonemize([text])
+        return " ".join(phones[0].split())
+
+    def _apply_chat_template(self, ref_codes, ref_text: str, input_text: str) -> List[int]:
+        """Prompt ids exactly as ref:neutts/neutts.py:303-332 builds them."""
+        tk = self.tokenizer
+        input_text = self._to_phones(ref_text) + " " + self._to_phones(input_text)
+        speech_replace = tk.convert_tokens_to_ids("<|SPEECH_REPLACE|>")
+        speech_gen_start = tk.convert_tokens_to_ids("<|SPEECH_GENERATION_START|>")
+        text_replace = tk.convert_tokens_to_ids("<|TEXT_REPLACE|>")
+        text_prompt_start = tk.convert_tokens_to_ids("<|TEXT_PROMPT_START|>")
+        text_prompt_end = tk.convert_tokens_to_ids("<|TEXT_PROMPT_END|>")
+        input_ids = tk.encode(input_text, add_special_tokens=False)
+        chat = """user: Convert the text to speech:<|TEXT_REPLACE|>\nassistant:<|SPEECH_REPLACE|>"""
+        ids = tk.encode(chat)
+        i = ids.index(text_replace)
+        ids = ids[:i] + [text_prompt_start] + input_ids + [text_prompt_end] + ids[i + 1:]
+        j = ids.index(speech_replace)
+        codes_str = "".join(f"<|speech_{c}|>" for c in _to_list(ref_codes))
+        codes = tk.encode(codes_str, add_special_tokens=False)
+        return ids[:j] + [speech_gen_start] + list(codes)
+
+    # ------------------------------------------------------------------------------------------ streaming
+    def _infer_stream_hip(self, prompt_ids: List[int], ref_codes: List[int]) -> Generator[np.ndarray, None, None]:
+        eng = self.backbone
+        self._seed += 1
+        eng.prefill([prompt_ids], [0], [self._sampling(len(prompt_ids))])
+        audio_cache: List[np.ndarray] = []
+        token_cache: List[int] = list(ref_codes)          # codec codes (the reference caches "<|speech_N|>" strings)
+        n_decoded_samples = 0
+        n_decoded_tokens = len(ref_codes)
+        n_seen = 0
+        hop = self.hop_length
+        chunk, look_f, look_b, ovl = (self.streaming_frames_per_chunk, self.streaming_lookforward,
+                                      self.streaming_lookback, self.streaming_overlap_frames)
+        try:
+            finished = False
+            while not finished:
+                ids, finished = eng.read(0)
+                new = self._ids_to_codes(ids[n_seen:])
+                n_seen = len(ids)
+                for c in new:
+                    token_cache.append(c)
+                    if len(token_cache) - n_decoded_tokens >= chunk + look_f:
+                        t0 = max(n_decoded_tokens - look_b - ovl, 0)
+                        t1 = n_decoded_tokens + chunk + look_f + ovl
+                        s0 = (n_decoded_tokens - t0) * hop
+                        s1 = s0 + (chunk + 2 * ovl) * hop
+                        recon = self.codec.engine.decode([token_cache[t0:t1]])[0]
+                        if self.watermarker is not None:
+                            recon = self.watermarker.apply_watermark(recon, sample_rate=24_000)
+                        audio_cache.append(recon[s0:s1])
+                        mixed = _linear_overlap_add(audio_cache, stride=self.streaming_stride_samples)
+                        end = len(audio_cache) * self.streaming_stride_samples
+                        out = mixed[n_decoded_samples:end]
+                        n_decoded_samples = end
+                        n_decoded_tokens += chunk
+                        yield out
+                if not finished:
+                    eng.decode(chunk)          # the codec pass above overlaps nothing yet: see DESIGN.md "next"
+            remaining = len(token_cache) - n_decoded_tokens
+            if remaining > 0:
+                t0 = max(len(token_cache) - (look_b + ovl + remaining), 0)
+                s0 = (len(token_cache) - t0 - remaining - ovl) * hop
+                recon = self.codec.engine.decode([token_cache[t0:]])[0]
+                if self.watermarker is not None:
+                    recon = self.watermarker.apply_watermark(recon, sample_rate=24_000)
+                audio_cache.append(recon[s0:])
+                mixed = _linear_overlap_add(audio_cache, stride=self.streaming_stride_samples)
+                yield mixed[n_decoded_samples:]
+        finally:
+            eng.release(0)
+
+
+def _to_list(codes) -> List[int]:
+    if hasattr(codes, "tolist"):
+        return [int(c) for c in np.asarray(codes.cpu() if hasattr(codes, "cpu") else codes).reshape(-1).tolist()]
+    return [int(c) for c in codes]
+
+
+def neucodec_to_xcodec2_names(sd: Dict[str, object]) -> Dict[str, object]:
+    """Original `neucodec` state-dict keys -> the xcodec2 parameter names the codec engine loads (SURVEY.md B.4;
+    written from the survey's recollection of the neucodec layout -- validate against a real checkpoint).
+    Fused `att.c_attn.weight [3H, H]` rows are split q | k | v."""
+    out: Dict[str, object] = {}
+
+    def put(dst, src):
+        if src in sd:
+            out[dst] = sd[src]
+
+    put("quantizer.project_out.weight", "generator.quantizer.project_out.weight")
+    put("quantizer.project_out.bias", "generator.quantizer.project_out.bias")
+    put("decoder.fc.weight", "fc_post_a.weight")
+    put("decoder.fc.bias", "fc_post_a.bias")
+    put("decoder.embed.weight", "generator.backbone.embed.weight")
+    put("decoder.embed.bias", "generator.backbone.embed.bias")
+    for net in ("prior_net", "post_net"):
+        for b in range(2):
+            for part in ("norm1", "conv1", "norm2", "conv2"):
+                for wb in ("weight", "bias"):
+                    put(f"decoder.{net}.{b}.{part}.{wb}", f"generator.backbone.{net}.{b}.{part}.{wb}")
+    i = 0
+    while f"generator.backbone.transformers.{i}.att.c_attn.weight" in sd:
+        p, q = f"generator.backbone.transformers.{i}.", f"decoder.layers.{i}."
+        w = sd[p + "att.c_attn.weight"]
+        h = w.shape[0] // 3
+        out[q + "self_attn.q_proj.weight"], out[q + "self_attn.k_proj.weight"], out[q + "self_attn.v_proj.weight"] = (
+            w[:h], w[h:2 * h], w[2 * h:])
+        put(q + "self_attn.o_proj.weight", p + "att.c_proj.weight")
+        put(q + "input_layernorm.weight", p + "att_norm.weight")
+        put(q + "post_attention_layernorm.weight", p + "ffn_norm.weight")
+        put(q + "mlp.fc1.weight", p + "mlp.fc1.weight")
+        put(q + "mlp.fc2.weight", p + "mlp.fc2.weight")
+        i += 1
+    put("decoder.norm.weight", "generator.backbone.final_layer_norm.weight")
+    put("decoder.norm.bias", "generator.backbone.final_layer_norm.bias")
+    put("decoder.head.linear.weight", "generator.head.out.weight")
+    put("decoder.head.linear.bias", "generator.head.out.bias")
+    if not out:
+        raise ValueError("no NeuCodec decoder tensors found in the state dict")
+    return out

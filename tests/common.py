@@ -67,3 +67,26 @@ def teacher_forced_compare(eng, slot, gold_ids, gold_topv, gold_topi, max_ulps=2
             if k + 1 < n:
                 eng.debug_force(slot, int(gold_ids[k]))
     return n_exact, n_tie
+
+
+# ---------------------------------------------------------------------------------------------- codec
+def load_codec_fixture(name):
+    from oracle import codec_ref as cr
+    z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=True)
+    d = {k: v for k, v in z["cfg"]}
+    d["levels"] = tuple(d["levels"])
+    cfg = cr.CodecConfig(**d)
+    return z, cfg, cr.make_weights(cfg, int(z["seed"]))
+
+
+def make_codec_engine(cfg, w, lib, max_frames=64, max_rows=512):
+    eng = _hip.CodecEngine(dict(hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                                num_layers=cfg.num_layers, num_heads=cfg.num_heads, quantization_dim=cfg.quantization_dim,
+                                levels=list(cfg.levels), hop_length=cfg.hop_length, rms_eps=cfg.rms_eps,
+                                max_frames=max_frames, max_rows=max_rows), 0, lib)
+    eng.load_state_dict({k: v.numpy() for k, v in w.items()})
+    return eng
+
+
+def rms(x):
+    return float(np.sqrt(np.mean(np.square(np.asarray(x, dtype=np.float64)))))

@@ -1,0 +1,51 @@
+"""NeuCodec decoder engine on the CPU SIMT emulator vs the golden waveforms / the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import codec_ref as cr
+from neutts import _hip
+from common import load_codec_fixture, make_codec_engine, rms
+
+
+def test_codec_tiny_vs_golden_ragged_batch(emu_lib):
+    z, cfg, w = load_codec_fixture("codec_tiny")
+    eng = make_codec_engine(cfg, w, emu_lib)
+    codes = [z["codes_0"][0, 0].tolist(), z["codes_1"][0, 0].tolist(), z["codes_0"][1, 0].tolist()]
+    gold = [z["wav_0"][0, 0], z["wav_1"][0, 0], z["wav_0"][1, 0]]
+    wavs = eng.decode(codes)                          # 37-, 5- and 37-frame utterances in ONE call
+    for wv, g in zip(wavs, gold):
+        assert wv.dtype == np.float32 and wv.shape == g.shape and not np.isnan(wv).any()
+        assert rms(wv - g) <= 1e-3, rms(wv - g)       # BASELINE.json: waveform RMS within 1e-3 of the fp32 reference
+        assert rms(wv - g) <= 0.02 * rms(g)
+    # batch invariance: decoding an utterance alone gives the same samples as inside the ragged batch
+    alone = eng.decode([codes[1]])[0]
+    assert np.array_equal(alone, wavs[1])
+
+
+def test_codec_splits_calls_when_rows_exceed_workspace(emu_lib):
+    z, cfg, w = load_codec_fixture("codec_tiny")
+    eng = make_codec_engine(cfg, w, emu_lib, max_frames=40, max_rows=50)   # room for one 37-frame utterance per call
+    codes = [z["codes_0"][0, 0].tolist(), z["codes_0"][1, 0].tolist()]
+    wavs = eng.decode(codes)
+    assert rms(wavs[0] - z["wav_0"][0, 0]) <= 1e-3 and rms(wavs[1] - z["wav_0"][1, 0]) <= 1e-3
+
+
+def test_codec_error_paths(emu_lib):
+    z, cfg, w = load_codec_fixture("codec_tiny")
+    eng = _hip.CodecEngine(dict(hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size, num_layers=cfg.num_layers,
+                                num_heads=cfg.num_heads, quantization_dim=cfg.quantization_dim, levels=list(cfg.levels),
+                                hop_length=cfg.hop_length, max_frames=16, max_rows=64), 0, emu_lib)
+    with pytest.raises(_hip.NeuTTSHipError):             # not finalised
+        eng.decode([[1, 2, 3]])
+    sd = {k: v.numpy() for k, v in w.items()}
+    missing = dict(sd)
+    missing.pop("decoder.norm.bias")
+    with pytest.raises(_hip.NeuTTSHipError):             # a tensor is missing -> finalize fails loudly
+        eng.load_state_dict(missing)
+    eng.load_state_dict(sd)
+    with pytest.raises(_hip.NeuTTSHipError):             # code out of range
+        eng.decode([[1, 2, 10 ** 6]])
+    with pytest.raises(_hip.NeuTTSHipError):             # too many frames
+        eng.decode([list(range(17))])
+    assert eng.decode([[1, 2, 3]])[0].shape == (3 * cfg.hop_length,)

@@ -1,0 +1,173 @@
+"""Drop-in class surface (ref:neutts/neutts.py:73-465) over the emulated engines: the reference's own smoke
+assertions (ref:tests/test_neutts.py:55-58, :78-85) + id-level equivalence with the oracle pipeline."""
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import backbone_ref as br
+from oracle import codec_ref as cr
+from common import engine_cfg, rms
+
+
+class FakeTokenizer:
+    """Minimal stand-in for the HF tokenizer: every special / speech token is one id, text is byte-level."""
+    SPECIALS = ["<|TEXT_REPLACE|>", "<|SPEECH_REPLACE|>", "<|TEXT_PROMPT_START|>", "<|TEXT_PROMPT_END|>",
+                "<|SPEECH_GENERATION_START|>", "<|SPEECH_GENERATION_END|>"]
+
+    def __init__(self, n_codes):
+        self.base_special = 256
+        self.speech_base = self.base_special + len(self.SPECIALS)
+        self.n_codes = n_codes
+        self.vocab_size = self.speech_base + n_codes
+
+    def convert_tokens_to_ids(self, tok):
+        if tok in self.SPECIALS:
+            return self.base_special + self.SPECIALS.index(tok)
+        m = re.fullmatch(r"<\|speech_(\d+)\|>", tok)
+        return self.speech_base + int(m.group(1))
+
+    def encode(self, text, add_special_tokens=True):
+        ids, pos = [], 0
+        pat = re.compile(r"<\|[A-Za-z_0-9]+\|>")
+        for m in pat.finditer(text):
+            ids += list(text[pos:m.start()].encode())
+            ids.append(self.convert_tokens_to_ids(m.group(0)))
+            pos = m.end()
+        return ids + list(text[pos:].encode())
+
+    def decode(self, ids, add_special_tokens=False):
+        out = []
+        for i in ids:
+            if i >= self.speech_base:
+                out.append(f"<|speech_{i - self.speech_base}|>")
+            elif i >= self.base_special:
+                out.append(self.SPECIALS[i - self.base_special])
+            else:
+                out.append(chr(i))
+        return "".join(out)
+
+
+class FakePhonemizer:
+    def phonemize(self, texts):
+        return [t.lower() for t in texts]
+
+
+@pytest.fixture(scope="module")
+def tts(emu_lib):
+    from neutts import NeuTTS
+    ccfg = cr.CodecConfig.tiny()
+    n_codes = int(np.prod(ccfg.levels))
+    tok = FakeTokenizer(n_codes)
+    bcfg = br.BackboneConfig.tiny(vocab_size=tok.vocab_size, num_layers=1)
+    bw = br.make_weights(bcfg, 31, peak_sigma=0.5)
+    # bias the tied embedding towards speech tokens so that greedy decoding emits codec codes
+    bw["model.embed_tokens.weight"][tok.speech_base:] *= 3.0
+    cw = cr.make_weights(ccfg, 2)
+    eos = tok.convert_tokens_to_ids("<|SPEECH_GENERATION_END|>")
+    t = NeuTTS(
+        backbone_repo=dict(config=engine_cfg(bcfg, max_context=256, max_prefill_tokens=512),
+                           state_dict={k: v.numpy() for k, v in bw.items()}, inv_freq=br.rope_inv_freq(bcfg).numpy(),
+                           tokenizer=tok, speech_base=tok.speech_base, eos_token_id=eos),
+        backbone_device="cuda",
+        codec_repo=dict(config=dict(hidden_size=ccfg.hidden_size, intermediate_size=ccfg.intermediate_size,
+                                    num_layers=ccfg.num_layers, num_heads=ccfg.num_heads,
+                                    quantization_dim=ccfg.quantization_dim, levels=list(ccfg.levels),
+                                    hop_length=ccfg.hop_length, max_frames=256, max_rows=1024),
+                        state_dict={k: v.numpy() for k, v in cw.items()}),
+        codec_device="cuda", lib_path=emu_lib, do_sample=False, max_batch=2)
+    t.phonemizer = FakePhonemizer()
+    t.max_context = 120          # keep the emulated run short
+    t.min_new_tokens = 5
+    t._oracle = (bcfg, bw, ccfg, cw, tok, eos)
+    return t
+
+
+def test_surface_matches_reference(tts):
+    for name, val in dict(sample_rate=24000, streaming_overlap_frames=1, streaming_frames_per_chunk=25,
+                          streaming_lookforward=5, streaming_lookback=50).items():
+        assert getattr(tts, name) == val
+    assert tts.streaming_stride_samples == 25 * tts.hop_length
+    for attr in ("tokenizer", "backbone", "codec", "watermarker", "infer", "infer_stream", "encode_reference"):
+        assert hasattr(tts, attr)
+    import neuttsair
+    assert issubclass(neuttsair.NeuTTSAir, type(tts))
+
+
+def test_infer_smoke_and_equivalence(tts):
+    bcfg, bw, ccfg, cw, tok, eos = tts._oracle
+    ref_codes = torch.tensor([3, 77, 200, 5, 18, 9], dtype=torch.int32)
+    audio = tts.infer("Testing.", ref_codes, "So I'm live.")
+    # the reference's smoke assertions (ref:tests/test_neutts.py:55-58)
+    assert isinstance(audio, np.ndarray) and len(audio) > 0 and not np.any(np.isnan(audio))
+    assert audio.dtype in [np.float32, np.float64]
+    # id-level equivalence with the oracle pipeline on the same prompt
+    prompt = tts._apply_chat_template(ref_codes, "So I'm live.", "Testing.")
+    assert prompt[-len(ref_codes):] == [tok.speech_base + int(c) for c in ref_codes]
+    wd = br.cast_weights(bw, torch.bfloat16)
+    want_ids = br.generate(bcfg, wd, prompt, 120, eos, min_new_tokens=5).ids
+    codes = [i - tok.speech_base for i in want_ids if i >= tok.speech_base]
+    assert len(codes) > 0
+    want = cr.decode_code(ccfg, cw, torch.tensor(codes)[None, None, :])[0, 0].numpy()
+    assert audio.shape == want.shape == (len(codes) * tts.hop_length,)
+    assert rms(audio - want) <= 1e-3
+
+
+def test_decode_without_speech_tokens_raises(tts):
+    with pytest.raises(ValueError, match="No valid speech tokens found in the output."):
+        tts._decode("no codes here")
+    with pytest.raises(ValueError, match="No valid speech tokens found in the output."):
+        tts._decode_ids([1, 2, 3])
+
+
+def test_invalid_codec_repo_and_devices(emu_lib):
+    from neutts import NeuTTS
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        NeuTTS(backbone_repo={"config": {}, "state_dict": {}, "inv_freq": None}, backbone_device="cpu", lib_path=emu_lib)
+
+
+def test_infer_stream_matches_reference_windowing(tts):
+    """Chunks are ndarrays, the main-loop chunks are exactly 25 frames, and the concatenation equals what the
+    reference's streaming algorithm (ref:neutts/neutts.py:401-465, restated here with the oracle codec) yields."""
+    bcfg, bw, ccfg, cw, tok, eos = tts._oracle
+    ref_codes = [3, 77, 200, 5, 18, 9, 100, 41]
+    tts.min_new_tokens = 70
+    tts.max_context = 200
+    try:
+        chunks = list(tts.infer_stream("Streaming test.", ref_codes, "So I'm live."))
+    finally:
+        tts.min_new_tokens = 5
+        tts.max_context = 120
+    assert len(chunks) >= 2 and all(isinstance(c, np.ndarray) for c in chunks)
+    hop = tts.hop_length
+    assert all(len(c) == 25 * hop for c in chunks[:-1])
+    # reference algorithm on the same generated tokens, oracle codec
+    prompt = tts._apply_chat_template(ref_codes, "So I'm live.", "Streaming test.")
+    wd = br.cast_weights(bw, torch.bfloat16)
+    ids = br.generate(bcfg, wd, prompt, 200, eos, min_new_tokens=70).ids
+    new_codes = [i - tok.speech_base for i in ids if i >= tok.speech_base]
+
+    def dec(cs):
+        return cr.decode_code(ccfg, cw, torch.tensor(cs)[None, None, :])[0, 0].numpy()
+
+    cache, audio, out = list(ref_codes), [], []
+    n_tok, n_samp = len(ref_codes), 0
+    for c in new_codes:
+        cache.append(c)
+        if len(cache) - n_tok >= 30:
+            t0 = max(n_tok - 51, 0)
+            s0 = (n_tok - t0) * hop
+            audio.append(dec(cache[t0:n_tok + 31])[s0:s0 + 27 * hop])
+            mixed = cr.linear_overlap_add(audio, 25 * hop)
+            out.append(mixed[n_samp:len(audio) * 25 * hop])
+            n_samp = len(audio) * 25 * hop
+            n_tok += 25
+    rem = len(cache) - n_tok
+    if rem > 0:
+        t0 = max(len(cache) - (51 + rem), 0)
+        audio.append(dec(cache[t0:])[(len(cache) - t0 - rem - 1) * hop:])
+        out.append(cr.linear_overlap_add(audio, 25 * hop)[n_samp:])
+    want = np.concatenate(out)
+    got = np.concatenate(chunks)
+    assert got.shape == want.shape and rms(got - want) <= 1e-3
