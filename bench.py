@@ -39,12 +39,16 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(cfg, w, prompt, n_new, eos):
-    """The reference's own CPU path for this hot path: transformers Qwen2ForCausalLM.generate called as in
-    ref:neutts/neutts.py:338-347 (fp32, greedy so the work is fixed) when transformers is importable
-    (kind "reference"); otherwise the oracle restatement (kind "port")."""
+def cpu_baseline(cfg, w, prompt, n_new, eos, codec_cfg, codec_w, max_seconds=45.0):
+    """The reference's own CPU path for this hot path on the box's host cores: transformers
+    Qwen2ForCausalLM.generate called as in ref:neutts/neutts.py:338-347 (fp32, greedy so the work is fixed;
+    kind "reference") followed by the NeuCodec-decoder restatement (oracle/codec_ref.decode_code) on the
+    produced codes.  BOUNDED: generate() gets max_time=max_seconds, so the sample is one utterance or the
+    part of it that fits; falls back to the oracle port when transformers is missing (kind "port")."""
     from oracle import backbone_ref as br
-    cores = os.cpu_count() or 1
+    from oracle import codec_ref as cr
+    # many-core hosts: HF's tiny per-token ops crawl when spread over hundreds of threads
+    cores = min(os.cpu_count() or 1, int(os.environ.get("NTTS_CPU_BASELINE_THREADS", "32")))
     torch.set_num_threads(cores)
     t0 = time.time()
     try:
@@ -52,20 +56,28 @@ def cpu_baseline(cfg, w, prompt, n_new, eos):
         m = hf_backbone(cfg, w, torch.float32)
         t1 = time.time()
         out = m.generate(torch.tensor([prompt]), max_length=len(prompt) + n_new, eos_token_id=eos, pad_token_id=eos,
-                         do_sample=False, use_cache=True, min_new_tokens=n_new)
-        n = out.shape[1] - len(prompt)
+                         do_sample=False, use_cache=True, min_new_tokens=n_new, max_time=max_seconds)
+        ids = out[0, len(prompt):].tolist()
         kind = "reference"
     except Exception as ex:  # transformers missing on this box
         log(f"[cpu_baseline] transformers path unavailable ({type(ex).__name__}: {ex}); timing the oracle port")
         wd = br.cast_weights(w, torch.float32)
         t1 = time.time()
-        n = len(br.generate(cfg, wd, prompt, len(prompt) + n_new, eos, min_new_tokens=n_new).ids)
+        ids = br.generate(cfg, wd, prompt, len(prompt) + min(n_new, 32), eos, min_new_tokens=min(n_new, 32)).ids
         kind = "port"
-    dt = time.time() - t1
+    t2 = time.time()
+    n = len(ids)
+    codes = torch.tensor([i % 65536 for i in ids], dtype=torch.long)[None, None, :]
+    wav = cr.decode_code(codec_cfg, codec_w, codes)
+    t3 = time.time()
+    assert wav.shape[-1] == codec_cfg.hop_length * n
+    dt = t3 - t1
     return {"value": n / dt, "unit": "codec-tokens/s", "cores": cores, "kind": kind,
-            "sample": f"1 utterance, {len(prompt)} prefill + {n} greedy tokens, fp32 torch CPU "
-                      f"({'transformers Qwen2ForCausalLM.generate' if kind == 'reference' else 'oracle/backbone_ref.generate'}), "
-                      f"{dt:.1f}s (+{t1 - t0:.1f}s model build)",
+            "sample": f"1 utterance, {len(prompt)} prefill + {n} greedy tokens "
+                      f"({'transformers Qwen2ForCausalLM.generate' if kind == 'reference' else 'oracle/backbone_ref.generate'}"
+                      f", fp32 torch CPU) {t2 - t1:.1f}s + NeuCodec-decoder restatement on the {n} codes {t3 - t2:.2f}s "
+                      f"(+{t1 - t0:.1f}s model build, untimed); host has {os.cpu_count()} logical cores",
+            "backbone_tokens_per_s": n / (t2 - t1), "codec_frames_per_s": n / (t3 - t2),
             "rtf": dt / (n / 50.0)}
 
 
@@ -81,6 +93,7 @@ def main():
     ap.add_argument("--prefill-chunk", type=int, default=64, help="prompts per prefill call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-codec", action="store_true", help="backbone only (profiling aid; not the headline metric)")
     ap.add_argument("--tiny", action="store_true", help="tiny model geometry (plumbing tests only; not a benchmark)")
     a = ap.parse_args()
     # Plumbing-test hook (tests/test_dist_gloo.py): run the launch / shard / broadcast / timing logic on CPU
@@ -89,6 +102,7 @@ def main():
 
     from neutts import _hip, dist as ndist
     from oracle import backbone_ref as br  # weights/prompt generators + cpu_baseline leg only
+    from oracle import codec_ref as cr     # synthetic codec weights + cpu_baseline leg only
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,19 +129,35 @@ def main():
     lib = emu_lib or bmod.build(verbose=False)
 
     cfg = br.BackboneConfig.tiny(vocab_size=512, num_layers=1) if a.tiny else br.BackboneConfig.neutts_air(a.vocab)
+    ccfg = cr.CodecConfig.tiny() if a.tiny else cr.CodecConfig.neucodec()
+    n_codes = int(np.prod(ccfg.levels))
     B, S, N = a.batch, a.prefill, a.decode
+    dev = 0 if emu_lib else local
     eng = _hip.BackboneEngine(dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
                                    intermediate_size=cfg.intermediate_size, num_layers=cfg.num_layers,
                                    num_heads=cfg.num_heads, num_kv_heads=cfg.num_kv_heads, rms_eps=cfg.rms_eps,
                                    max_context=((S + N + 31) // 32) * 32, max_batch=B,
-                                   max_prefill_tokens=a.prefill_chunk * S), 0 if emu_lib else local, lib)
-    w = None
+                                   max_prefill_tokens=a.prefill_chunk * S), dev, lib)
+    codec = None
+    if not a.no_codec:
+        codec = _hip.CodecEngine(dict(hidden_size=ccfg.hidden_size, intermediate_size=ccfg.intermediate_size,
+                                      num_layers=ccfg.num_layers, num_heads=ccfg.num_heads,
+                                      quantization_dim=ccfg.quantization_dim, levels=list(ccfg.levels),
+                                      hop_length=ccfg.hop_length, rms_eps=ccfg.rms_eps, max_frames=N,
+                                      max_rows=B * (N + 6)), dev, lib)
+    w = cw = None
     t0 = time.time()
     if rank == 0:
         w = br.make_weights(cfg, 0)            # synthetic N(0,1/fan_in) weights at the exact NeuTTS-Air shapes
         eng.load_state_dict({k: v.numpy() for k, v in w.items()}, inv_freq=br.rope_inv_freq(cfg).numpy())
+        cw = cr.make_weights(ccfg, 0)          # synthetic NeuCodec-decoder weights (xcodec2 parameter names)
     if world > 1:
-        ndist.broadcast_weights(eng, src=0, device=torch.device("cpu") if emu_lib else None)  # RCCL over xGMI
+        tdev = torch.device("cpu") if emu_lib else None
+        ndist.broadcast_weights(eng, src=0, device=tdev)  # RCCL over xGMI: packed backbone arena, one broadcast
+        if codec is not None:
+            codec.load_state_dict(ndist.broadcast_state_dict(cw, src=0, device=tdev))
+    elif codec is not None:
+        codec.load_state_dict({k: v.numpy() for k, v in cw.items()})
     log(f"[bench] rank {rank}: weights ready in {time.time() - t0:.1f}s")
 
     eos = cfg.vocab_size - 1
@@ -136,21 +166,31 @@ def main():
     prompts = [br.synthetic_prompt(cfg, lo + i, S) for i in range(B)]   # seed 1234 + utterance index
 
     def one_step(collect=False):
-        pf_ms = 0.0
+        """One pass of the hot path over one batch: prompts -> codec-token ids -> 24 kHz waveforms."""
+        ph = {"prefill": 0.0, "decode": 0.0, "codec": 0.0, "handoff_host": 0.0}
         for c in range(0, B, a.prefill_chunk):
             n = min(a.prefill_chunk, B - c)
             eng.prefill(prompts[c:c + n], list(range(c, c + n)), [samp] * n)
             if collect:
-                pf_ms += eng.last_timing()[0]
+                ph["prefill"] += eng.last_timing()[0]
         eng.decode(N - 1)
         eng.sync()
-        dec_ms = eng.last_timing()[1] if collect else 0.0
-        out = None
         if collect:
-            out = [eng.read(s) for s in (0, B - 1)]
+            ph["decode"] = eng.last_timing()[1]
+        th = time.time()
+        ids, fin = eng.read_all()
+        assert all(len(x) == N for x in ids) and all(fin), "bench run did not produce the expected tokens"
         for s in range(B):
             eng.release(s)
-        return pf_ms, dec_ms, out
+        wavs = None
+        if codec is not None:
+            # SURVEY 8d: random weights do not stay in the speech range -> code = id mod 65536
+            codes = [[t % n_codes for t in x] for x in ids]
+            ph["handoff_host"] = (time.time() - th) * 1e3
+            wavs = codec.decode(codes)
+            ph["codec"] = codec.last_timing()
+            assert len(wavs) == B and all(wv.shape[0] == ccfg.hop_length * N for wv in wavs)
+        return ph, ids, wavs
 
     def barrier():
         if world > 1:
@@ -174,8 +214,9 @@ def main():
         dt = float(t.item())
 
     # ---- untimed extra legs (phase split, roofline of the dominant kernel, CPU baseline)
-    pf_ms, dec_ms, out = one_step(collect=True)
-    assert all(len(ids) == N and fin for ids, fin in out), "bench run did not produce the expected tokens"
+    ph, ids, wavs = one_step(collect=True)
+    if wavs is not None:
+        assert all(np.isfinite(wv).all() for wv in wavs[:4]), "non-finite waveform"
     roof = None
     step_info = None
     if rank == 0 and not a.no_roofline:
@@ -200,7 +241,9 @@ def main():
         ach = nbytes / (ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBPS, "traffic": None, "avg_launch_us": ms * 1e3,
-                "alg_bytes_per_launch": nbytes, "launches_per_step": nl}
+                "alg_bytes_per_launch": nbytes, "launches_per_step": nl,
+                "per_kernel": [{"kernel": r[1], "us": r[2] * 1e3, "launches_per_step": r[4], "alg_bytes": r[3],
+                                "GBps": r[3] / (r[2] * 1e-3) / 1e9} for r in rows]}
         step_info = {"ms": step_ms, "alg_bytes": step_bytes, "achieved_GBps": step_bytes / (step_ms * 1e-3) / 1e9,
                      "frac_of_hbm_peak": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "sum_of_isolated_kernels_ms": sum(r[0] for r in rows)}
@@ -208,11 +251,13 @@ def main():
             eng.release(s)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(cfg, w, prompts[0], N, eos)
+        cpu = cpu_baseline(cfg, w, prompts[0], N, eos, ccfg, cw)
 
     if rank == 0:
         tokens = world * B * N * a.steps
         value = tokens / dt
+        stages = "backbone prefill + decode loop" + (" + NeuCodec decoder to 24 kHz waveform (D2H included)"
+                                                     if codec is not None else " (codec skipped: --no-codec)")
         rec = {
             "metric": "codec-tokens/s", "value": value, "unit": "codec-tokens/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
@@ -220,11 +265,11 @@ def main():
             "config": {"workload": f"NeuTTS-Air bf16 1xMI355X batch={B} synthetic prompts, {S} prefill / {N} decode tokens, "
                                    "greedy, continuous-batching engine + hipGraph decode (BASELINE.json configs[2])",
                        "batch_per_gpu": B, "prefill_tokens": S, "decode_tokens": N, "vocab_size": cfg.vocab_size,
-                       "stages": "backbone prefill + decode loop (NeuCodec decoder not yet in the timed region)",
+                       "stages": stages,
                        "parallelism": f"independent shards x{world}, RCCL weight broadcast only"},
             "tokens_per_s_per_gpu": value / world,
             "rtf": dt / (tokens / 50.0),
-            "phase_ms": {"prefill": pf_ms, "decode": dec_ms},
+            "phase_ms": ph,
             "roofline": roof, "decode_step": step_info, "cpu_baseline": cpu,
         }
         print(json.dumps(rec), flush=True)

@@ -129,6 +129,9 @@ int ntts_backbone_decode(ntts_backbone* e, int32_t n_steps);
  * generate()'s return value. */
 int ntts_backbone_read(ntts_backbone* e, int32_t slot, int32_t* out_ids, int32_t cap, int32_t* n_out,
                        int32_t* finished);
+/* Blocking.  ntts_backbone_read for every slot at once (three device-to-host copies in total): row s of
+ * out_ids (row stride `cap` ints) gets slot s's new ids, n_out[s] / finished[s] as above; free slots report 0. */
+int ntts_backbone_read_all(ntts_backbone* e, int32_t* out_ids, int32_t cap, int32_t* n_out, int32_t* finished);
 /* Blocking.  One int32 per slot: 0 free, 1 running, 2 finished; new-token counts in n_new (may be NULL). */
 int ntts_backbone_poll(ntts_backbone* e, int32_t* state, int32_t* n_new);
 /* Return the slot's KV pages to the pool and mark it free. */

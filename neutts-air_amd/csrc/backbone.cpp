@@ -687,6 +687,24 @@ extern "C" int ntts_backbone_read(ntts_backbone* e, int32_t slot, int32_t* out_i
     return NTTS_OK;
 }
 
+extern "C" int ntts_backbone_read_all(ntts_backbone* e, int32_t* out_ids, int32_t cap, int32_t* n_out, int32_t* finished) {
+    if (!e || !out_ids || !n_out || cap < 1) return fail(e, NTTS_EINVAL, "bad argument");
+    const int B = e->cfg.max_batch;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    std::vector<int> st(B);
+    HIPCHK(e, hipMemcpy(st.data(), e->sl.state, B * sizeof(int), hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(n_out, e->sl.n_new, B * sizeof(int), hipMemcpyDeviceToHost));
+    const int w = cap < e->sl.out_stride ? cap : e->sl.out_stride;
+    HIPCHK(e, hipMemcpy2D(out_ids, (size_t)cap * sizeof(int), e->sl.out_tokens, (size_t)e->sl.out_stride * sizeof(int),
+                          (size_t)w * sizeof(int), B, hipMemcpyDeviceToHost));
+    for (int b = 0; b < B; ++b) {
+        if (e->slots[b].state == SLOT_FREE) { st[b] = SLOT_FREE; n_out[b] = 0; }
+        if (finished) finished[b] = st[b] == SLOT_FINISHED ? 1 : 0;
+    }
+    return NTTS_OK;
+}
+
 extern "C" int ntts_backbone_release(ntts_backbone* e, int32_t slot) {
     if (!e || slot < 0 || slot >= e->cfg.max_batch) return fail(e, NTTS_EINVAL, "bad slot");
     HIPCHK(e, hipSetDevice(e->device));

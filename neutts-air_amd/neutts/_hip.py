@@ -57,6 +57,13 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         raise FileNotFoundError(
             f"{path} not found: build it with `python neutts-air_amd/build.py` (hipcc, gfx950). "
             "There is no CPU fallback for the NeuTTS hot path.")
+    # Load order matters: PyTorch-ROCm bundles its own libamdhip64.so (SONAME libamdhip64.so.7).  If this library
+    # were dlopen'ed first it would pull /opt/rocm's copy in, torch would later load its bundled one, and the process
+    # would hold TWO HIP runtimes (the second one sees no devices).  Importing torch first makes both share one.
+    try:
+        import torch  # noqa: F401  (plumbing only)
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     p, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     sig = {
@@ -73,6 +80,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_backbone_prefill": (C.c_int, [p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(SamplingC)]),
         "ntts_backbone_decode": (C.c_int, [p, i32]),
         "ntts_backbone_read": (C.c_int, [p, i32, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(i32)]),
+        "ntts_backbone_read_all": (C.c_int, [p, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(i32)]),
         "ntts_backbone_poll": (C.c_int, [p, C.POINTER(i32), C.POINTER(i32)]),
         "ntts_backbone_release": (C.c_int, [p, i32]),
         "ntts_backbone_sync": (C.c_int, [p]),
@@ -228,6 +236,16 @@ class BackboneEngine:
         self._chk(self.lib.ntts_backbone_read(self.h, slot, out.ctypes.data_as(C.POINTER(C.c_int32)), len(out),
                                               C.byref(n), C.byref(fin)))
         return out[: n.value].tolist(), bool(fin.value)
+
+    def read_all(self):
+        """Every slot's new ids in one call: ([ids per slot], [finished per slot])."""
+        out = np.empty((self.max_batch, self.max_context), dtype=np.int32)
+        n = np.empty(self.max_batch, dtype=np.int32)
+        fin = np.empty(self.max_batch, dtype=np.int32)
+        i32p = C.POINTER(C.c_int32)
+        self._chk(self.lib.ntts_backbone_read_all(self.h, out.ctypes.data_as(i32p), self.max_context,
+                                                  n.ctypes.data_as(i32p), fin.ctypes.data_as(i32p)))
+        return [out[s, : n[s]].tolist() for s in range(self.max_batch)], [bool(f) for f in fin]
 
     def poll(self):
         st = np.empty(self.max_batch, dtype=np.int32)

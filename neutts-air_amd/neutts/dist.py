@@ -33,6 +33,27 @@ def broadcast_weights(engine, src: int = 0, device=None):
     del buf
 
 
+def broadcast_state_dict(sd, src: int = 0, device=None):
+    """Codec weights (a few hundred MB, many tensors): rank `src` passes its state dict, the others pass None and
+    receive {name: tensor on `device`}.  One metadata broadcast + one tensor broadcast per parameter, start-up only."""
+    import torch
+    import torch.distributed as dist
+
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    meta = [[(k, tuple(v.shape)) for k, v in sd.items()]] if dist.get_rank() == src else [None]
+    dist.broadcast_object_list(meta, src=src)
+    out = {}
+    for name, shape in meta[0]:
+        if dist.get_rank() == src:
+            t = torch.as_tensor(sd[name]).to(device=device, dtype=torch.float32).contiguous()
+        else:
+            t = torch.empty(shape, dtype=torch.float32, device=device)
+        dist.broadcast(t, src=src)
+        out[name] = t
+    return out
+
+
 def gather_results(local: Sequence, world: int) -> List:
     """Host-side gather of per-rank python results to every rank (ids / waveforms leave the GPU as host
     objects anyway)."""

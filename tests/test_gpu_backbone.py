@@ -36,7 +36,7 @@ def test_small_peaked_exact(lib, graph, monkeypatch):
     monkeypatch.setenv("NTTS_NO_GRAPH", "0" if graph else "1")
     z, cfg, w = load_fixture("backbone_small_peaked")
     S, N, eos = int(z["s_len"]), int(z["n_new"]), int(z["eos"])
-    eng = make_engine(cfg, w, lib, max_batch=2, bf16_upload=True)
+    eng = make_engine(cfg, w, lib, max_batch=2, max_context=160, bf16_upload=True)
     samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
     eng.prefill([br.synthetic_prompt(cfg, 0, S), br.synthetic_prompt(cfg, 1, S)], [0, 1], [samp, samp])
     eng.decode(N - 1)

@@ -13,11 +13,11 @@ for leg in $LEGS; do
     smoke) timeout 420 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -5 $OUT/smoke.log;;
     tests) timeout 900 python -m pytest tests -m gpu -q -rA --durations=10 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -45 $OUT/pytest_gpu.log;;
     bench) timeout 600 python bench.py --steps ${BENCH_STEPS:-2} --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -25 $OUT/bench.err;;
-    prof)  rm -rf $OUT/prof; timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $OUT/prof_bench.json 2> $OUT/prof.err; echo "prof rc=$?"
-           f=$(find $OUT/prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -30 "$f"; cat $OUT/prof_bench.json; tail -5 $OUT/prof.err
+    prof)  rm -rf $OUT/prof; timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof -o bench -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $OUT/prof_bench.json 2> $OUT/prof.err; echo "prof rc=$?"
+           python tools/prof_summary.py $OUT/prof > $OUT/prof_summary.txt 2>&1; head -40 $OUT/prof_summary.txt; cat $OUT/prof_bench.json; tail -3 $OUT/prof.err
            find $OUT/prof -name '*kernel_trace.csv' -size +20M -delete;;
-    pmc)   rm -rf $OUT/pmc; timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/pmc -o fetch -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --batch ${PMC_BATCH:-256} > $OUT/pmc_bench.json 2> $OUT/pmc.err; echo "pmc rc=$?"; tail -3 $OUT/pmc.err
-           find $OUT/pmc -name '*.csv' | head; python tools/pmc_summary.py $OUT/pmc > $OUT/pmc_summary.txt 2>&1; cat $OUT/pmc_summary.txt;;
+    pmc)   rm -rf $OUT/pmc; timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/pmc -o fetch -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-codec --batch ${PMC_BATCH:-256} > $OUT/pmc_bench.json 2> $OUT/pmc.err; echo "pmc rc=$?"; tail -3 $OUT/pmc.err
+           python tools/pmc_summary.py $OUT/pmc > $OUT/pmc_summary.txt 2>&1; head -30 $OUT/pmc_summary.txt; find $OUT/pmc -name '*.csv' -size +8M -delete;;
     *) echo "unknown leg $leg";;
   esac
 done
