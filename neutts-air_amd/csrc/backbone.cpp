@@ -73,7 +73,8 @@ struct ntts_backbone {
     int* part_idx = nullptr;
     int n_part = 0;
     float* logits = nullptr;  // debug
-    int ks_o = 1, ks_d = 1;
+    int ks_o = 1, ks_d = 1, ks_qkv = 1;
+    int s_stages = 4, head_stages = 2;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
     bool gu_large = false, head_large = true;
 
     // prefill workspaces
@@ -225,18 +226,23 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     };
     e->ks_o = env_int("NTTS_KSPLIT_O", pick_split(H / 64, c->num_heads * 64 / 64));
     e->ks_d = env_int("NTTS_KSPLIT_D", pick_split(H / 64, F / 64));
+    e->ks_qkv = env_int("NTTS_KSPLIT_QKV", 1);
+    e->s_stages = env_int("NTTS_S_STAGES", 4);
+    e->head_stages = env_int("NTTS_HEAD_STAGES", 2);
     e->gu_large = env_int("NTTS_GU_LARGE", 0) != 0;
     e->head_large = env_int("NTTS_HEAD_LARGE", B > 64 ? 1 : 0) != 0;
     const int max_slabs = 16;
     if (e->ks_o > max_slabs) e->ks_o = max_slabs;
     if (e->ks_d > max_slabs) e->ks_d = max_slabs;
+    if (e->ks_qkv > max_slabs) e->ks_qkv = max_slabs;
+    if (e->ks_qkv < 1) e->ks_qkv = 1;
     e->n_part = e->head_large ? ((V + 127) / 128) * 2 : (V + 63) / 64;
     CR_HIP(hipMalloc((void**)&e->h_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->xn_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->qkv_dec, (size_t)B * e->NQKV * 2));
     CR_HIP(hipMalloc((void**)&e->attn_dec, (size_t)B * c->num_heads * 64 * 2));
     CR_HIP(hipMalloc((void**)&e->act_dec, (size_t)B * F * 2));
-    CR_HIP(hipMalloc((void**)&e->slabs, (size_t)max_slabs * B * H * 4));
+    CR_HIP(hipMalloc((void**)&e->slabs, (size_t)max_slabs * B * (H > e->NQKV ? H : e->NQKV) * 4));
     CR_HIP(hipMalloc((void**)&e->part_val, (size_t)B * e->n_part * 4));
     CR_HIP(hipMalloc((void**)&e->part_idx, (size_t)B * e->n_part * 4));
     CR_HIP(hipMemset(e->h_dec, 0, (size_t)B * H * 2));
@@ -417,47 +423,98 @@ static GemmArgs gemm_args(const bf16_t* X, long ldx, const bf16_t* W, long ldw, 
     return a;
 }
 
-static void lm_head_and_sample(ntts_backbone* e, int phase) {
+// ---- the decode step's launches, one helper per kernel (shared by decode_step and ntts_backbone_time_kernel)
+template <int EPI>
+static void gemm_skinny(ntts_backbone* e, const GemmArgs& a, int ks, hipStream_t st) {
+    switch (e->s_stages) {
+        case 2: gemm_launch<4, 1, 1, EPI, 2>(a, ks, st); break;
+        case 3: gemm_launch<4, 1, 1, EPI, 3>(a, ks, st); break;
+        case 6: gemm_launch<4, 1, 1, EPI, 6>(a, ks, st); break;
+        default: gemm_launch<4, 1, 1, EPI, 4>(a, ks, st); break;
+    }
+}
+
+static void k_lm_head(ntts_backbone* e, bool keep_logits) {
     const int B = e->cfg.max_batch, H = e->H, V = e->cfg.vocab_size;
     GemmArgs a = gemm_args(e->xn_dec, H, e->embed, H, nullptr, nullptr, 0, B, V, H);
     a.part_val = e->part_val; a.part_idx = e->part_idx; a.mask_eos = e->sl.mask_eos;
-    a.logits = e->logits; a.ld_logits = V;
-    if (e->head_large) NTTS_GEMM_L(EPI_ARGMAX, a, 1, e->stream); else NTTS_GEMM_S(EPI_ARGMAX, a, 1, e->stream);
+    a.logits = keep_logits ? e->logits : nullptr; a.ld_logits = V;
+    if (!e->head_large) { gemm_skinny<EPI_ARGMAX>(e, a, 1, e->stream); return; }
+    switch (e->head_stages) {
+        case 3: gemm_launch<2, 2, 4, EPI_ARGMAX, 3>(a, 1, e->stream); break;
+        case 4: gemm_launch<2, 2, 4, EPI_ARGMAX, 4>(a, 1, e->stream); break;
+        default: gemm_launch<2, 2, 4, EPI_ARGMAX, 2>(a, 1, e->stream); break;
+    }
+}
+
+static void lm_head_and_sample(ntts_backbone* e, int phase) {
+    k_lm_head(e, true);
     SampleArgs s{};
     s.part_val = e->part_val; s.part_idx = e->part_idx; s.n_part = e->n_part; s.sl = e->sl; s.phase = phase;
-    NTTS_LAUNCH((sample_greedy_kernel), dim3(B), dim3(256), e->stream, s);
+    NTTS_LAUNCH((sample_greedy_kernel), dim3(e->cfg.max_batch), dim3(256), e->stream, s);
+}
+
+static void k_qkv(ntts_backbone* e, int i) {
+    const int B = e->cfg.max_batch, H = e->H;
+    const LayerW& w = e->layers[i];
+    if (e->ks_qkv > 1)   // fp32 split-K slabs; bias + the nn.Linear rounding happen in the attention prologue
+        gemm_skinny<EPI_SPLITK>(e, gemm_args(e->xn_dec, H, w.wqkv, H, nullptr, e->slabs, e->NQKV, B, e->NQKV, H), e->ks_qkv, e->stream);
+    else
+        gemm_skinny<EPI_BF16>(e, gemm_args(e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H), 1, e->stream);
+}
+
+static void k_attn(ntts_backbone* e, int i) {
+    const ntts_backbone_config& c = e->cfg;
+    AttnDecodeArgs a{};
+    a.qkv = e->qkv_dec; a.ld_qkv = e->NQKV; a.out = e->attn_dec; a.ld_out = c.num_heads * 64;
+    if (e->ks_qkv > 1) {
+        a.qkv_slabs = e->slabs; a.nslab = gemm_nsplit(e->H, e->ks_qkv); a.slab_rows = c.max_batch; a.qkv_bias = e->layers[i].bqkv;
+    }
+    a.kpool = e->kv + (size_t)i * e->layer_stride; a.vpool = a.kpool + e->kv_half;
+    a.block_table = e->block_table; a.max_pages = e->max_pages; a.pos = e->sl.pos; a.state = e->sl.state;
+    a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
+    attn_decode_launch(a, c.max_batch, e->stream);
+}
+
+static void k_o_proj(ntts_backbone* e, int i) {
+    const int B = e->cfg.max_batch, H = e->H, QD = e->cfg.num_heads * 64;
+    gemm_skinny<EPI_SPLITK>(e, gemm_args(e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->slabs, H, B, H, QD), e->ks_o, e->stream);
+}
+
+static void k_gate_up(ntts_backbone* e, int i) {
+    const int B = e->cfg.max_batch, H = e->H, F = e->F;
+    GemmArgs gu = gemm_args(e->xn_dec, H, e->layers[i].wgu, H, nullptr, e->act_dec, F, B, 2 * F, H);
+    if (e->gu_large) NTTS_GEMM_L(EPI_SILU_MUL, gu, 1, e->stream); else gemm_skinny<EPI_SILU_MUL>(e, gu, 1, e->stream);
+}
+
+static void k_down(ntts_backbone* e, int i) {
+    const int B = e->cfg.max_batch, H = e->H, F = e->F;
+    gemm_skinny<EPI_SPLITK>(e, gemm_args(e->act_dec, F, e->layers[i].wd, F, nullptr, e->slabs, H, B, H, F), e->ks_d, e->stream);
+}
+
+// residual += reduce(slabs of a K-deep split-K GEMM); normed = rmsnorm(residual) * norm_w
+static void k_add_norm(ntts_backbone* e, int K, int ks, const bf16_t* norm_w, bf16_t* resid_out, bf16_t* normed_out) {
+    NormArgs n{};
+    n.slabs = e->slabs; n.nslab = gemm_nsplit(K, ks); n.slab_rows = e->cfg.max_batch; n.resid_in = e->h_dec; n.resid_out = resid_out;
+    n.norm_w = norm_w; n.normed_out = normed_out; n.M = e->cfg.max_batch; n.H = e->H; n.eps = e->cfg.rms_eps;
+    add_rmsnorm_launch(n, e->stream);
 }
 
 static void decode_step(ntts_backbone* e) {
     const ntts_backbone_config& c = e->cfg;
     const int B = c.max_batch, H = e->H, F = e->F, QD = c.num_heads * 64;
-    hipStream_t st = e->stream;
     NormArgs n0{};
     n0.gather_ids = e->sl.cur_tok; n0.embed = e->embed; n0.resid_out = e->h_dec; n0.norm_w = e->layers[0].ln1;
     n0.normed_out = e->xn_dec; n0.M = B; n0.H = H; n0.eps = c.rms_eps;
-    add_rmsnorm_launch(n0, st);
+    add_rmsnorm_launch(n0, e->stream);
     for (int i = 0; i < c.num_layers; ++i) {
-        const LayerW& w = e->layers[i];
-        NTTS_GEMM_S(EPI_BF16, gemm_args(e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H), 1, st);
-        AttnDecodeArgs a{};
-        a.qkv = e->qkv_dec; a.ld_qkv = e->NQKV; a.out = e->attn_dec; a.ld_out = QD;
-        a.kpool = e->kv + (size_t)i * e->layer_stride; a.vpool = a.kpool + e->kv_half;
-        a.block_table = e->block_table; a.max_pages = e->max_pages; a.pos = e->sl.pos; a.state = e->sl.state;
-        a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
-        attn_decode_launch(a, B, st);
-        NTTS_GEMM_S(EPI_SPLITK, gemm_args(e->attn_dec, QD, w.wo, QD, nullptr, e->slabs, H, B, H, QD), e->ks_o, st);
-        NormArgs n1{};
-        n1.slabs = e->slabs; n1.nslab = gemm_nsplit(QD, e->ks_o); n1.slab_rows = B; n1.resid_in = e->h_dec; n1.resid_out = e->h_dec;
-        n1.norm_w = w.ln2; n1.normed_out = e->xn_dec; n1.M = B; n1.H = H; n1.eps = c.rms_eps;
-        add_rmsnorm_launch(n1, st);
-        GemmArgs gu = gemm_args(e->xn_dec, H, w.wgu, H, nullptr, e->act_dec, F, B, 2 * F, H);
-        if (e->gu_large) NTTS_GEMM_L(EPI_SILU_MUL, gu, 1, st); else NTTS_GEMM_S(EPI_SILU_MUL, gu, 1, st);
-        NTTS_GEMM_S(EPI_SPLITK, gemm_args(e->act_dec, F, w.wd, F, nullptr, e->slabs, H, B, H, F), e->ks_d, st);
-        NormArgs n2{};
-        n2.slabs = e->slabs; n2.nslab = gemm_nsplit(F, e->ks_d); n2.slab_rows = B; n2.resid_in = e->h_dec; n2.resid_out = e->h_dec;
-        n2.norm_w = (i + 1 < c.num_layers) ? e->layers[i + 1].ln1 : e->final_norm;
-        n2.normed_out = e->xn_dec; n2.M = B; n2.H = H; n2.eps = c.rms_eps;
-        add_rmsnorm_launch(n2, st);
+        k_qkv(e, i);
+        k_attn(e, i);
+        k_o_proj(e, i);
+        k_add_norm(e, QD, e->ks_o, e->layers[i].ln2, e->h_dec, e->xn_dec);
+        k_gate_up(e, i);
+        k_down(e, i);
+        k_add_norm(e, F, e->ks_d, (i + 1 < c.num_layers) ? e->layers[i + 1].ln1 : e->final_norm, e->h_dec, e->xn_dec);
     }
     lm_head_and_sample(e, SLOT_RUNNING);
 }
@@ -805,46 +862,24 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
     double kv_layer = 0;  // bytes one attention launch must read (+ write): K and V of every cached token
     for (int b = 0; b < B; ++b)
         if (sst[b] == SLOT_RUNNING) kv_layer += ((double)pos[b] + 1) * 2 * KD * 2.0;
-    const LayerW& w = e->layers[0];
     const double act = (double)B * 2.0;
     auto run = [&](int k) {
         switch (k) {
-            case 0: {  // paged decode attention (+RoPE, +KV append)
-                AttnDecodeArgs a{};
-                a.qkv = e->qkv_dec; a.ld_qkv = e->NQKV; a.out = e->attn_dec; a.ld_out = QD;
-                a.kpool = e->kv; a.vpool = e->kv + e->kv_half; a.block_table = e->block_table; a.max_pages = e->max_pages;
-                a.pos = e->sl.pos; a.state = e->sl.state; a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
-                a.nh = c.num_heads; a.nkv = c.num_kv_heads;
-                attn_decode_launch(a, B, st);
-                break;
-            }
-            case 1: NTTS_GEMM_S(EPI_BF16, gemm_args(e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H), 1, st); break;
-            case 2: NTTS_GEMM_S(EPI_SPLITK, gemm_args(e->attn_dec, QD, w.wo, QD, nullptr, e->slabs, H, B, H, QD), e->ks_o, st); break;
-            case 3: {
-                GemmArgs gu = gemm_args(e->xn_dec, H, w.wgu, H, nullptr, e->act_dec, F, B, 2 * F, H);
-                if (e->gu_large) NTTS_GEMM_L(EPI_SILU_MUL, gu, 1, st); else NTTS_GEMM_S(EPI_SILU_MUL, gu, 1, st);
-                break;
-            }
-            case 4: NTTS_GEMM_S(EPI_SPLITK, gemm_args(e->act_dec, F, w.wd, F, nullptr, e->slabs, H, B, H, F), e->ks_d, st); break;
-            case 5: {
-                GemmArgs a = gemm_args(e->xn_dec, H, e->embed, H, nullptr, nullptr, 0, B, c.vocab_size, H);
-                a.part_val = e->part_val; a.part_idx = e->part_idx; a.mask_eos = e->sl.mask_eos; a.logits = nullptr; a.ld_logits = c.vocab_size;
-                if (e->head_large) NTTS_GEMM_L(EPI_ARGMAX, a, 1, st); else NTTS_GEMM_S(EPI_ARGMAX, a, 1, st);
-                break;
-            }
-            case 6: {
-                NormArgs n1{};
-                n1.slabs = e->slabs; n1.nslab = gemm_nsplit(QD, e->ks_o); n1.slab_rows = B; n1.resid_in = e->h_dec; n1.resid_out = e->o_pf;
-                n1.norm_w = w.ln2; n1.normed_out = e->xn_pf; n1.M = B; n1.H = H; n1.eps = c.rms_eps;
-                add_rmsnorm_launch(n1, st);
-                break;
-            }
+            case 0: k_attn(e, 0); break;                        // paged decode attention (+RoPE, +KV append)
+            case 1: k_qkv(e, 0); break;
+            case 2: k_o_proj(e, 0); break;
+            case 3: k_gate_up(e, 0); break;
+            case 4: k_down(e, 0); break;
+            case 5: k_lm_head(e, false); break;
+            case 6: k_add_norm(e, QD, e->ks_o, e->layers[0].ln2, e->o_pf, e->xn_pf); break;   // scratch outputs
             default: break;
         }
     };
     switch (which) {
         case 0: *alg_bytes = kv_layer + act * (e->NQKV + QD); *launches_per_step = L; break;
-        case 1: *alg_bytes = ((double)e->NQKV * H + e->NQKV) * 2.0 + act * (H + e->NQKV); *launches_per_step = L; break;
+        case 1: *alg_bytes = ((double)e->NQKV * H + e->NQKV) * 2.0 + act * H +
+                             (e->ks_qkv > 1 ? (double)gemm_nsplit(H, e->ks_qkv) * B * e->NQKV * 4.0 : act * e->NQKV);
+                *launches_per_step = L; break;
         case 2: *alg_bytes = (double)H * QD * 2.0 + act * QD + (double)gemm_nsplit(QD, e->ks_o) * B * H * 4.0; *launches_per_step = L; break;
         case 3: *alg_bytes = (double)2 * F * H * 2.0 + act * (H + F); *launches_per_step = L; break;
         case 4: *alg_bytes = (double)H * F * 2.0 + act * F + (double)gemm_nsplit(F, e->ks_d) * B * H * 4.0; *launches_per_step = L; break;

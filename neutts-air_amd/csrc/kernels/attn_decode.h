@@ -25,6 +25,12 @@ constexpr int kGroupMax = 8;     // query heads per kv head handled by one workg
 struct AttnDecodeArgs {
     const bf16_t* qkv;     // [B][ld_qkv]: q heads | k heads | v heads, bias already added
     long ld_qkv;
+    // alternative input: the QKV GEMM's fp32 split-K slabs [nslab][slab_rows][ld_qkv]; this kernel then adds the
+    // bias and applies the nn.Linear output rounding (one RNE to bf16) itself
+    const float* qkv_slabs;
+    int nslab;
+    long slab_rows;
+    const bf16_t* qkv_bias;
     bf16_t* out;           // [B][nh*64]
     long ld_out;
     bf16_t* kpool;         // this layer
@@ -65,6 +71,13 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
     const int last_page = npages - 1;
     const int* bt = p.block_table + (long)b * p.max_pages;
     const bf16_t* row = p.qkv + (long)b * p.ld_qkv;
+    // element `col` of this sequence's q|k|v row as the bf16 nn.Linear output
+    auto qkv_at = [&](int col) -> bf16_t {
+        if (!p.qkv_slabs) return row[col];
+        float a = 0.f;
+        for (int s = 0; s < p.nslab; ++s) a += p.qkv_slabs[((long)s * p.slab_rows + b) * p.ld_qkv + col];
+        return f2bf(a + bf2f(p.qkv_bias[col]));
+    };
 
     // ---- prologue: RoPE(q), RoPE(k) + append k, v to the cache (and keep them in LDS for this step)
     for (int t = tid; t < (group + 1) * 32; t += 256) {
@@ -72,15 +85,14 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
         const float c = bf2f(p.rope_cos[(long)P * 32 + i]), s = bf2f(p.rope_sin[(long)P * 32 + i]);
         float o1, o2;
         if (hh < group) {
-            const bf16_t* q = row + (kvh * group + hh) * 64;
-            rope_pair(bf2f(q[i]), bf2f(q[i + 32]), c, s, o1, o2);
+            const int q0 = (kvh * group + hh) * 64;
+            rope_pair(bf2f(qkv_at(q0 + i)), bf2f(qkv_at(q0 + i + 32)), c, s, o1, o2);
             qs[hh][i] = f2bf(o1);
             qs[hh][i + 32] = f2bf(o2);
         } else {
-            const bf16_t* k = row + (p.nh + kvh) * 64;
-            const bf16_t* v = row + (p.nh + p.nkv + kvh) * 64;
-            rope_pair(bf2f(k[i]), bf2f(k[i + 32]), c, s, o1, o2);
-            const bf16_t k1 = f2bf(o1), k2 = f2bf(o2), v1 = v[i], v2 = v[i + 32];
+            const int k0 = (p.nh + kvh) * 64, v0 = (p.nh + p.nkv + kvh) * 64;
+            rope_pair(bf2f(qkv_at(k0 + i)), bf2f(qkv_at(k0 + i + 32)), c, s, o1, o2);
+            const bf16_t k1 = f2bf(o1), k2 = f2bf(o2), v1 = qkv_at(v0 + i), v2 = qkv_at(v0 + i + 32);
             knew[i] = k1; knew[i + 32] = k2; vnew[i] = v1; vnew[i + 32] = v2;
             const long pg = bt[P / kPage];
             const int slot = P % kPage;

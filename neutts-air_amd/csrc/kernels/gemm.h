@@ -14,8 +14,10 @@
 //   * K is consumed in tiles of 64 (= one 128-byte line per row).  Tiles are brought in by LDS-DMA
 //     (global_load_lds_dwordx4): 8 rows x 128 B per wave-instruction, destination lane-linear, bank
 //     conflicts removed by swizzling the SOURCE chunk (c ^ ((row>>1)&7)) and applying the same
-//     involution on the ds_read_b128 side (rule 21 of the guide).  Two LDS buffers, one barrier/tile:
-//     the DMA of tile t+1 is in flight under the MFMAs of tile t.
+//     involution on the ds_read_b128 side (rule 21 of the guide).  NS LDS buffers in a ring, one barrier/tile:
+//     the DMAs of tiles t+1 .. t+NS-1 are in flight under the MFMAs of tile t (s_waitcnt vmcnt(N) retires them
+//     in order).  The skinny decode GEMMs (M = batch, <= 1 block per CU) are latency-bound and want NS = 4;
+//     the big prefill / codec GEMMs hide latency with 2 co-resident blocks per CU and keep NS = 2.
 //   * blockIdx -> tile mapping is XCD-aware (8 XCDs, private L2s): each XCD walks a contiguous chunk
 //     of a grouped (8 m-blocks x all n-blocks) order so co-resident blocks share W and X panels in L2.
 //   * split-K (gridDim.y) writes fp32 slabs that the consumer kernel reduces (no in-launch hand-off).
@@ -75,14 +77,15 @@ NTTS_D void gemm_tile_coords(int bid, int mblocks, int nblocks, int& mb, int& nb
 NTTS_D float silu_f(float x) { return x / (1.0f + fexp(-x)); }
 NTTS_D float gemm_bias(const GemmArgs& p, int n) { return p.bias_f32 ? p.bias_f32[n] : (p.bias ? bf2f(p.bias[n]) : 0.f); }
 
-template <int WM, int WN, int TM, int EPI>
+template <int WM, int WN, int TM, int EPI, int NS>
 NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     constexpr int BM = WM * TM * 16, BN = WN * 64, NW = WM * WN;
     constexpr int ROWS = BM + BN;              // LDS rows per buffer, 64 bf16 (128 B) each
     constexpr int NINST = ROWS / 8;            // wave-instructions per K tile
     static_assert(NINST % NW == 0, "loader split");
     constexpr int PER_WAVE = NINST / NW;
-    NTTS_SHARED bf16_t lds[2 * ROWS * 64];
+    static_assert(NS >= 2 && (NS - 2) * PER_WAVE <= 63, "vmcnt range");
+    NTTS_SHARED bf16_t lds[NS * ROWS * 64];
 
     const int lane = lane_id(), wave = wave_id();
     const int wm = wave / WN, wn = wave % WN;
@@ -143,12 +146,18 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         wsw[j] = (rho >> 1) & 7;
     }
 
-    if (nk > 0) stage(0, 0);
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) stage(s, s);
+    int buf = 0;                  // ring slot of tile kt
     for (int kt = 0; kt < nk; ++kt) {
-        wait_vmem();
-        sync();  // tile kt landed for every wave; everyone is done reading the other buffer
-        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-        const bf16_t* base = lds + (kt & 1) * (ROWS * 64);
+        // tile kt must have landed; tiles kt+1 .. kt+NS-2 may stay in flight (none are left to wait on
+        // at the tail, where the plain drain costs nothing extra)
+        if (kt + NS - 2 < nk) wait_vmem_le<(NS - 2) * PER_WAVE>(); else wait_vmem();
+        sync();  // tile kt landed for every wave; everyone is done reading the slot refilled below
+        if (kt + NS - 1 < nk) stage(kt + NS - 1, buf == 0 ? NS - 1 : buf - 1);
+        const bf16_t* base = lds + buf * (ROWS * 64);
+        buf = buf + 1 == NS ? 0 : buf + 1;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int c = ks * 4 + g;
@@ -279,7 +288,7 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 // ------------------------------------------------------------------------------------------------
 struct GemmShape { int BM, BN, WN; };
 
-template <int WM, int WN, int TM, int EPI>
+template <int WM, int WN, int TM, int EPI, int NS = 2>
 inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * 64;
     p.mblocks = (p.M + BM - 1) / BM;
@@ -290,13 +299,13 @@ inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
     p.k_tiles_per_split = (ktiles + ksplit - 1) / ksplit;
     const int nsplit = (ktiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
     if constexpr (EPI == EPI_ARGMAX) p.part_stride = p.nblocks * WN;
-    NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI>), dim3(p.mblocks * p.nblocks, nsplit), dim3(WM * WN * 64), s, p);
+    NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS>), dim3(p.mblocks * p.nblocks, nsplit), dim3(WM * WN * 64), s, p);
 }
 
 // tile families:  L = 128x128 (2x2 waves, 64x64 per wave)  -- prefill, lm_head, gate/up, codec
 //                 S = 64x64   (4x1 waves, 16x64 per wave)  -- decode-batch skinny GEMMs (+ split-K)
-#define NTTS_GEMM_L(EPI, p, ks, s) ::ntts::gemm_launch<2, 2, 4, EPI>(p, ks, s)
-#define NTTS_GEMM_S(EPI, p, ks, s) ::ntts::gemm_launch<4, 1, 1, EPI>(p, ks, s)
+#define NTTS_GEMM_L(EPI, p, ks, s) ::ntts::gemm_launch<2, 2, 4, EPI, 2>(p, ks, s)
+#define NTTS_GEMM_S(EPI, p, ks, s) ::ntts::gemm_launch<4, 1, 1, EPI, 4>(p, ks, s)
 
 // number of split-K slabs gemm_launch will produce for (K, ksplit)
 inline int gemm_nsplit(int K, int ksplit) {

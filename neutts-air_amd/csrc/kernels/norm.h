@@ -55,11 +55,22 @@ NTTS_KERNEL(256) void add_rmsnorm_kernel(NormArgs p) {
         for (int e = 0; e < 8; ++e) o[e] = 0.f;
         if (ok) {
             if (p.slabs) {
-                for (int s = 0; s < p.nslab; ++s) {
-                    const float* sp = p.slabs + ((long)s * p.slab_rows + ri) * p.H + col;
-                    const f32x4 a = ld16<f32x4>(sp), b = ld16<f32x4>(sp + 4);
+                // slabs summed in ascending order; loads issued four slabs at a time so they overlap
+                for (int s0 = 0; s0 < p.nslab; s0 += 4) {
+                    f32x4 a[4], b[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { o[e] += a[e]; o[4 + e] += b[e]; }
+                    for (int u = 0; u < 4; ++u)
+                        if (s0 + u < p.nslab) {
+                            const float* sp = p.slabs + ((long)(s0 + u) * p.slab_rows + ri) * p.H + col;
+                            a[u] = ld16<f32x4>(sp);
+                            b[u] = ld16<f32x4>(sp + 4);
+                        }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (s0 + u < p.nslab) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { o[e] += a[u][e]; o[4 + e] += b[u][e]; }
+                        }
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = rbf(o[e]);

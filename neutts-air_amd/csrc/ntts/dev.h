@@ -52,6 +52,10 @@ NTTS_D void glds16(const void* gsrc, void* lds_wave_base) {
 // all of this wave's outstanding vector-memory ops (incl. LDS-DMA) have landed
 NTTS_D void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// at most N of this wave's vector-memory ops are still outstanding (they retire in issue order)
+template <int N>
+NTTS_D void wait_vmem_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 NTTS_D float fexp(float x) { return expf(x); }
 NTTS_D float frsqrt_exact(float x) { return 1.0f / sqrtf(x); }
 

@@ -133,6 +133,8 @@ inline void glds16(const void* gsrc, void* lds_wave_base) {
     memcpy((char*)d0.l + lane_id() * 16, gsrc, 16);
 }
 inline void wait_vmem() {}
+template <int N>
+inline void wait_vmem_le() {}
 
 inline float fexp(float x) { return expf(x); }
 inline float frsqrt_exact(float x) { return 1.0f / sqrtf(x); }

@@ -25,9 +25,14 @@ def test_tiny_teacher_forced(emu_lib):
     assert agree >= N - 2, (ids1, z["bf16_ids_1"][:N])
 
 
-def test_small_gqa2_page_crossing_peaked_exact(emu_lib):
+@pytest.mark.parametrize("knobs", [{}, {"NTTS_KSPLIT_QKV": "3", "NTTS_S_STAGES": "3"},
+                                   {"NTTS_KSPLIT_QKV": "2", "NTTS_S_STAGES": "6", "NTTS_KSPLIT_O": "2", "NTTS_KSPLIT_D": "5"}])
+def test_small_gqa2_page_crossing_peaked_exact(emu_lib, knobs, monkeypatch):
     """2 kv heads, prompt of 70 (3 pages), decode crosses the 96-token page boundary; peaked weights so the
-    free-running greedy ids must be bit-identical to HF's."""
+    free-running greedy ids must be bit-identical to HF's -- for every tuning of the decode GEMMs (LDS ring depth,
+    split-K of QKV reduced in the attention prologue, split-K of o/down reduced in the norm kernel)."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
     z, cfg, w = load_fixture("backbone_small_peaked")
     S, N, eos = int(z["s_len"]), 30, int(z["eos"])
     eng = make_engine(cfg, w, emu_lib, max_batch=1)
