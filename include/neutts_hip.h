@@ -192,7 +192,8 @@ int ntts_codec_load_tensor(ntts_codec* c, const char* name, const void* data, in
                            int ndim, int is_device);
 int ntts_codec_finalize(ntts_codec* c);
 /* Decode `n` utterances: codes packed back to back (HOST int32, utterance i has lens[i] frames) ->
- * wav_out (HOST float32) row i = hop_length * lens[i] samples at offset i * wav_stride.  Blocking. */
+ * wav_out (HOST float32) row i = hop_length * lens[i] samples at offset i * wav_stride (wav_stride >= hop_length *
+ * max(lens); the tail of a shorter row up to that length is scratch).  One strided D2H copy.  Blocking. */
 int ntts_codec_decode(ntts_codec* c, int32_t n, const int32_t* codes, const int32_t* lens, float* wav_out,
                       int64_t wav_stride);
 /* GPU milliseconds (hipEvents) of the most recent decode call, H2D/D2H excluded. */
@@ -208,6 +209,9 @@ int ntts_k_gemm_bf16(const void* A, int64_t lda, const void* W, const void* bias
                      int32_t M, int32_t N, int32_t K, int32_t variant);
 /* y = rmsnorm(x) * w with Qwen2RMSNorm's rounding (hf:models/qwen2/modeling_qwen2.py:247-252). */
 int ntts_k_rmsnorm_bf16(const void* x, const void* w, void* y, int32_t rows, int32_t cols, float eps);
+/* Micro-benchmark of one GEMM tile configuration on synthetic operands (tools/ubench_gemm.py); see csrc/kapi.cpp. */
+int ntts_k_gemm_probe(int32_t M, int32_t N, int32_t K, int32_t config, int32_t abl, int32_t copies, int32_t iters,
+                      double* us);
 /* Achieved HBM copy bandwidth probe: copies `bytes` device->device `iters` times, returns GB/s. */
 int ntts_k_membw(size_t bytes, int32_t iters, double* gbps);
 /* Diagnostics: writes 3 x 64 x 4 floats describing the MFMA 16x16x32 lane layout (see csrc/kapi.cpp). */

@@ -74,7 +74,8 @@ struct ntts_backbone {
     int n_part = 0;
     float* logits = nullptr;  // debug
     int ks_o = 1, ks_d = 1, ks_qkv = 1;
-    int s_stages = 4, head_stages = 2;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
+    int st_qkv = 4, st_o = 4, st_gu = 3, st_d = 4;   // LDS ring depth of each skinny decode GEMM
+    int head_stages = 2, l_stages = 2;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
     bool gu_large = false, head_large = true;
 
     // prefill workspaces
@@ -227,8 +228,13 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->ks_o = env_int("NTTS_KSPLIT_O", pick_split(H / 64, c->num_heads * 64 / 64));
     e->ks_d = env_int("NTTS_KSPLIT_D", pick_split(H / 64, F / 64));
     e->ks_qkv = env_int("NTTS_KSPLIT_QKV", 1);
-    e->s_stages = env_int("NTTS_S_STAGES", 4);
+    const int s_all = env_int("NTTS_S_STAGES", 0);
+    e->st_qkv = env_int("NTTS_STAGES_QKV", s_all ? s_all : 4);
+    e->st_o = env_int("NTTS_STAGES_O", s_all ? s_all : 4);
+    e->st_gu = env_int("NTTS_STAGES_GU", s_all ? s_all : 3);
+    e->st_d = env_int("NTTS_STAGES_D", s_all ? s_all : 4);
     e->head_stages = env_int("NTTS_HEAD_STAGES", 2);
+    e->l_stages = env_int("NTTS_L_STAGES", 2);
     e->gu_large = env_int("NTTS_GU_LARGE", 0) != 0;
     e->head_large = env_int("NTTS_HEAD_LARGE", B > 64 ? 1 : 0) != 0;
     const int max_slabs = 16;
@@ -425,12 +431,21 @@ static GemmArgs gemm_args(const bf16_t* X, long ldx, const bf16_t* W, long ldw, 
 
 // ---- the decode step's launches, one helper per kernel (shared by decode_step and ntts_backbone_time_kernel)
 template <int EPI>
-static void gemm_skinny(ntts_backbone* e, const GemmArgs& a, int ks, hipStream_t st) {
-    switch (e->s_stages) {
+static void gemm_skinny(int stages, const GemmArgs& a, int ks, hipStream_t st) {
+    switch (stages) {
         case 2: gemm_launch<4, 1, 1, EPI, 2>(a, ks, st); break;
         case 3: gemm_launch<4, 1, 1, EPI, 3>(a, ks, st); break;
         case 6: gemm_launch<4, 1, 1, EPI, 6>(a, ks, st); break;
         default: gemm_launch<4, 1, 1, EPI, 4>(a, ks, st); break;
+    }
+}
+
+template <int EPI>
+static void gemm_large(ntts_backbone* e, const GemmArgs& a, hipStream_t st) {
+    switch (e->l_stages) {
+        case 3: gemm_launch<2, 2, 4, EPI, 3>(a, 1, st); break;
+        case 4: gemm_launch<2, 2, 4, EPI, 4>(a, 1, st); break;
+        default: gemm_launch<2, 2, 4, EPI, 2>(a, 1, st); break;
     }
 }
 
@@ -439,7 +454,7 @@ static void k_lm_head(ntts_backbone* e, bool keep_logits) {
     GemmArgs a = gemm_args(e->xn_dec, H, e->embed, H, nullptr, nullptr, 0, B, V, H);
     a.part_val = e->part_val; a.part_idx = e->part_idx; a.mask_eos = e->sl.mask_eos;
     a.logits = keep_logits ? e->logits : nullptr; a.ld_logits = V;
-    if (!e->head_large) { gemm_skinny<EPI_ARGMAX>(e, a, 1, e->stream); return; }
+    if (!e->head_large) { gemm_skinny<EPI_ARGMAX>(4, a, 1, e->stream); return; }
     switch (e->head_stages) {
         case 3: gemm_launch<2, 2, 4, EPI_ARGMAX, 3>(a, 1, e->stream); break;
         case 4: gemm_launch<2, 2, 4, EPI_ARGMAX, 4>(a, 1, e->stream); break;
@@ -458,9 +473,9 @@ static void k_qkv(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H;
     const LayerW& w = e->layers[i];
     if (e->ks_qkv > 1)   // fp32 split-K slabs; bias + the nn.Linear rounding happen in the attention prologue
-        gemm_skinny<EPI_SPLITK>(e, gemm_args(e->xn_dec, H, w.wqkv, H, nullptr, e->slabs, e->NQKV, B, e->NQKV, H), e->ks_qkv, e->stream);
+        gemm_skinny<EPI_SPLITK>(e->st_qkv, gemm_args(e->xn_dec, H, w.wqkv, H, nullptr, e->slabs, e->NQKV, B, e->NQKV, H), e->ks_qkv, e->stream);
     else
-        gemm_skinny<EPI_BF16>(e, gemm_args(e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H), 1, e->stream);
+        gemm_skinny<EPI_BF16>(e->st_qkv, gemm_args(e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H), 1, e->stream);
 }
 
 static void k_attn(ntts_backbone* e, int i) {
@@ -478,18 +493,18 @@ static void k_attn(ntts_backbone* e, int i) {
 
 static void k_o_proj(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, QD = e->cfg.num_heads * 64;
-    gemm_skinny<EPI_SPLITK>(e, gemm_args(e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->slabs, H, B, H, QD), e->ks_o, e->stream);
+    gemm_skinny<EPI_SPLITK>(e->st_o, gemm_args(e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->slabs, H, B, H, QD), e->ks_o, e->stream);
 }
 
 static void k_gate_up(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, F = e->F;
     GemmArgs gu = gemm_args(e->xn_dec, H, e->layers[i].wgu, H, nullptr, e->act_dec, F, B, 2 * F, H);
-    if (e->gu_large) NTTS_GEMM_L(EPI_SILU_MUL, gu, 1, e->stream); else gemm_skinny<EPI_SILU_MUL>(e, gu, 1, e->stream);
+    if (e->gu_large) gemm_large<EPI_SILU_MUL>(e, gu, e->stream); else gemm_skinny<EPI_SILU_MUL>(e->st_gu, gu, 1, e->stream);
 }
 
 static void k_down(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, F = e->F;
-    gemm_skinny<EPI_SPLITK>(e, gemm_args(e->act_dec, F, e->layers[i].wd, F, nullptr, e->slabs, H, B, H, F), e->ks_d, e->stream);
+    gemm_skinny<EPI_SPLITK>(e->st_d, gemm_args(e->act_dec, F, e->layers[i].wd, F, nullptr, e->slabs, H, B, H, F), e->ks_d, e->stream);
 }
 
 // residual += reduce(slabs of a K-deep split-K GEMM); normed = rmsnorm(residual) * norm_w
@@ -616,7 +631,7 @@ extern "C" int ntts_backbone_prefill(ntts_backbone* e, int32_t n, const int32_t*
     for (int i = 0; i < c.num_layers; ++i) {
         const LayerW& w = e->layers[i];
         const bool last = i + 1 == c.num_layers;
-        NTTS_GEMM_L(EPI_BF16, gemm_args(e->xn_pf, H, w.wqkv, H, w.bqkv, e->qkv_pf, e->NQKV, Ti, e->NQKV, H), 1, st);
+        gemm_large<EPI_BF16>(e, gemm_args(e->xn_pf, H, w.wqkv, H, w.bqkv, e->qkv_pf, e->NQKV, Ti, e->NQKV, H), st);
         RopeWriteArgs r{};
         r.qkv = e->qkv_pf; r.ld_qkv = e->NQKV; r.kpool = e->kv + (size_t)i * e->layer_stride; r.vpool = r.kpool + e->kv_half;
         r.block_table = e->block_table; r.max_pages = e->max_pages; r.meta = meta; r.rope_cos = e->rope_cos; r.rope_sin = e->rope_sin;
@@ -626,13 +641,13 @@ extern "C" int ntts_backbone_prefill(ntts_backbone* e, int32_t n, const int32_t*
         a.qkv = e->qkv_pf; a.ld_qkv = e->NQKV; a.out = e->attn_pf; a.ld_out = QD; a.kpool = r.kpool; a.vpool = r.vpool;
         a.block_table = e->block_table; a.max_pages = e->max_pages; a.meta = meta; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
         NTTS_LAUNCH((attn_prefill_kernel), dim3((unsigned)tile_seq.size(), c.num_heads), dim3(256), st, a);
-        NTTS_GEMM_L(EPI_BF16, gemm_args(e->attn_pf, QD, w.wo, QD, nullptr, e->o_pf, H, Ti, H, QD), 1, st);
+        gemm_large<EPI_BF16>(e, gemm_args(e->attn_pf, QD, w.wo, QD, nullptr, e->o_pf, H, Ti, H, QD), st);
         NormArgs n1{};
         n1.o_bf16 = e->o_pf; n1.resid_in = e->h_pf; n1.resid_out = e->h_pf; n1.norm_w = w.ln2; n1.normed_out = e->xn_pf;
         n1.M = Ti; n1.H = H; n1.eps = c.rms_eps;
         add_rmsnorm_launch(n1, st);
-        NTTS_GEMM_L(EPI_SILU_MUL, gemm_args(e->xn_pf, H, w.wgu, H, nullptr, e->act_pf, F, Ti, 2 * F, H), 1, st);
-        NTTS_GEMM_L(EPI_BF16, gemm_args(e->act_pf, F, w.wd, F, nullptr, e->o_pf, H, Ti, H, F), 1, st);
+        gemm_large<EPI_SILU_MUL>(e, gemm_args(e->xn_pf, H, w.wgu, H, nullptr, e->act_pf, F, Ti, 2 * F, H), st);
+        gemm_large<EPI_BF16>(e, gemm_args(e->act_pf, F, w.wd, F, nullptr, e->o_pf, H, Ti, H, F), st);
         NormArgs n2{};
         n2.o_bf16 = e->o_pf; n2.resid_in = e->h_pf; n2.eps = c.rms_eps; n2.H = H;
         if (!last) {
@@ -765,13 +780,14 @@ extern "C" int ntts_backbone_read_all(ntts_backbone* e, int32_t* out_ids, int32_
 extern "C" int ntts_backbone_release(ntts_backbone* e, int32_t slot) {
     if (!e || slot < 0 || slot >= e->cfg.max_batch) return fail(e, NTTS_EINVAL, "bad slot");
     HIPCHK(e, hipSetDevice(e->device));
-    HIPCHK(e, hipStreamSynchronize(e->stream));
+    // Stream-ordered, no host sync: the slot's pages go back to the pool now, but anything that re-uses them is
+    // enqueued on the same stream behind the work that still reads them.
     HostSlot& s = e->slots[slot];
     for (int pg : s.pages) e->free_pages.push_back(pg);
     s.pages.clear();
     s.state = SLOT_FREE;
-    const int zero = SLOT_FREE;
-    HIPCHK(e, hipMemcpy(e->sl.state + slot, &zero, sizeof(int), hipMemcpyHostToDevice));
+    static_assert(SLOT_FREE == 0, "release writes the state with a memset");
+    HIPCHK(e, hipMemsetAsync(e->sl.state + slot, 0, sizeof(int), e->stream));
     return NTTS_OK;
 }
 

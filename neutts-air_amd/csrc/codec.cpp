@@ -418,8 +418,9 @@ extern "C" int ntts_codec_decode(ntts_codec* c, int32_t n, const int32_t* codes,
     c->have_time = true;
     CHIP(c, hipStreamSynchronize(st));
     CHIP(c, hipGetLastError());
-    for (int i = 0; i < n; ++i)
-        CHIP(c, hipMemcpy(wav_out + (size_t)i * wav_stride, c->wav + (size_t)i * hop * Tmax, (size_t)hop * lens[i] * sizeof(float), hipMemcpyDeviceToHost));
+    // one strided device-to-host copy for the whole batch (rows shorter than Tmax carry don't-care tails)
+    CHIP(c, hipMemcpy2D(wav_out, (size_t)wav_stride * sizeof(float), c->wav, (size_t)hop * Tmax * sizeof(float),
+                        (size_t)hop * Tmax * sizeof(float), n, hipMemcpyDeviceToHost));
     return NTTS_OK;
 }
 

@@ -68,6 +68,70 @@ extern "C" int ntts_k_membw(size_t bytes, int32_t iters, double* gbps) {
     return hipDeviceSynchronize() == hipSuccess ? NTTS_OK : NTTS_EHIP;
 }
 
+// Micro-benchmark of one GEMM tile configuration (tools/ubench_gemm.py): `copies` rotating weight buffers keep W
+// HBM-cold when copies * N * K * 2 B exceeds the 256 MB Infinity Cache.  config: tile family, abl: ablation bits
+// of gemm_kernel.  Returns the average microseconds per launch (back-to-back launches on the NULL stream).
+NTTS_KERNEL(64) void empty_kernel(int* p) { if (p && threadIdx.x == 12345) *p = 0; }
+
+template <int WM, int WN, int TM, int NS>
+static void probe_launch(const GemmArgs& a, int ks, int abl) {
+    constexpr int EPI = EPI_BF16;
+    switch (abl) {
+        case 1: gemm_launch<WM, WN, TM, EPI, NS, 1>(a, ks, 0); break;
+        case 2: gemm_launch<WM, WN, TM, EPI, NS, 2>(a, ks, 0); break;
+        case 3: gemm_launch<WM, WN, TM, EPI, NS, 3>(a, ks, 0); break;
+        case 4: gemm_launch<WM, WN, TM, EPI, NS, 4>(a, ks, 0); break;
+        case 7: gemm_launch<WM, WN, TM, EPI, NS, 7>(a, ks, 0); break;
+        default: gemm_launch<WM, WN, TM, EPI, NS, 0>(a, ks, 0); break;
+    }
+}
+
+extern "C" int ntts_k_gemm_probe(int32_t M, int32_t N, int32_t K, int32_t config, int32_t abl, int32_t copies, int32_t iters,
+                                 double* us) {
+    if (!us || M < 1 || N < 16 || K < 64 || (K % 64) || copies < 1 || iters < 1) return NTTS_EINVAL;
+    bf16_t *X = nullptr, *W = nullptr, *C = nullptr;
+    const size_t wn = (size_t)N * K;
+    if (hipMalloc((void**)&X, (size_t)M * K * 2) != hipSuccess || hipMalloc((void**)&W, wn * 2 * copies) != hipSuccess ||
+        hipMalloc((void**)&C, (size_t)M * N * 2) != hipSuccess)
+        return NTTS_ENOMEM;
+    hipMemset(X, 0x11, (size_t)M * K * 2);
+    hipMemset(W, 0x22, wn * 2 * copies);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    auto run = [&](int i) {
+        GemmArgs a{};
+        a.X = X; a.ldx = K; a.W = W + (size_t)(i % copies) * wn; a.ldw = K; a.out = C; a.ldo = N; a.M = M; a.N = N; a.K = K;
+        switch (config) {
+            case 0: NTTS_LAUNCH((empty_kernel), dim3(256), dim3(64), (hipStream_t)0, (int*)nullptr); break;
+            case 10: probe_launch<4, 1, 1, 2>(a, 1, abl); break;   // 64 x 64, 4 waves
+            case 11: probe_launch<4, 1, 1, 3>(a, 1, abl); break;
+            case 12: probe_launch<4, 1, 1, 4>(a, 1, abl); break;
+            case 13: probe_launch<4, 1, 1, 6>(a, 1, abl); break;
+            case 20: probe_launch<2, 1, 1, 4>(a, 1, abl); break;   // 32 x 64, 2 waves
+            case 21: probe_launch<2, 1, 2, 4>(a, 1, abl); break;   // 64 x 64, 2 waves
+            case 22: probe_launch<1, 1, 4, 4>(a, 1, abl); break;   // 64 x 64, 1 wave
+            case 23: probe_launch<2, 2, 2, 3>(a, 1, abl); break;   // 64 x 128, 4 waves
+            case 24: probe_launch<4, 2, 1, 3>(a, 1, abl); break;   // 64 x 128, 8 waves
+            case 25: probe_launch<8, 1, 1, 3>(a, 1, abl); break;   // 128 x 64, 8 waves
+            case 26: probe_launch<4, 1, 2, 3>(a, 1, abl); break;   // 128 x 64, 4 waves
+            case 30: probe_launch<2, 2, 4, 2>(a, 1, abl); break;   // 128 x 128, 4 waves (prefill tile)
+            case 31: probe_launch<2, 2, 4, 3>(a, 1, abl); break;
+            default: break;
+        }
+    };
+    for (int i = 0; i < copies && i < 8; ++i) run(i);
+    hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i) run(i);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    *us = (double)ms * 1e3 / iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(X); hipFree(W); hipFree(C);
+    return hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess ? NTTS_OK : NTTS_EHIP;
+}
+
 // MFMA lane-layout probe (diagnostics): three products whose results spell out which (row, col) each
 // (lane, reg) of the accumulator holds and whether A and B agree on the k slot.  Expected, under the
 // layout documented in ntts/dev.h:  out[0][l][r] = (l>>4)*4 + r,  out[1][l][r] = l & 15,

@@ -77,7 +77,8 @@ NTTS_D void gemm_tile_coords(int bid, int mblocks, int nblocks, int& mb, int& nb
 NTTS_D float silu_f(float x) { return x / (1.0f + fexp(-x)); }
 NTTS_D float gemm_bias(const GemmArgs& p, int n) { return p.bias_f32 ? p.bias_f32[n] : (p.bias ? bf2f(p.bias[n]) : 0.f); }
 
-template <int WM, int WN, int TM, int EPI, int NS>
+// ABL (micro-benchmark ablation, always 0 in the product): 1 = no LDS reads / MFMA, 2 = no LDS-DMA, 4 = no stores
+template <int WM, int WN, int TM, int EPI, int NS, int ABL = 0>
 NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     constexpr int BM = WM * TM * 16, BN = WN * 64, NW = WM * WN;
     constexpr int ROWS = BM + BN;              // LDS rows per buffer, 64 bf16 (128 B) each
@@ -118,6 +119,7 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         }
     }
     auto stage = [&](int kt, int buf) {
+        if constexpr (ABL & 2) return;
 #pragma unroll
         for (int i = 0; i < PER_WAVE; ++i) {
             const int inst = wave + i * NW;
@@ -154,10 +156,11 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         // tile kt must have landed; tiles kt+1 .. kt+NS-2 may stay in flight (none are left to wait on
         // at the tail, where the plain drain costs nothing extra)
         if (kt + NS - 2 < nk) wait_vmem_le<(NS - 2) * PER_WAVE>(); else wait_vmem();
-        sync();  // tile kt landed for every wave; everyone is done reading the slot refilled below
+        sync_keep_dma();  // tile kt landed for every wave; everyone is done reading the slot refilled below
         if (kt + NS - 1 < nk) stage(kt + NS - 1, buf == 0 ? NS - 1 : buf - 1);
         const bf16_t* base = lds + buf * (ROWS * 64);
         buf = buf + 1 == NS ? 0 : buf + 1;
+        if constexpr (ABL & 1) continue;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int c = ks * 4 + g;
@@ -173,6 +176,9 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         }
     }
 
+    if constexpr (ABL & 4) {
+        if (acc[0][0][0] != 12345.678f) return;   // keeps the accumulators live without storing
+    }
     // ---- epilogue: lane owns token m (per a) x features nb16 .. nb16+15  (acc[a][j][r] <-> nb16 + j*4 + r)
     const int nb16 = n0 + wn * 64 + g * 16;
 #pragma unroll
@@ -288,7 +294,7 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 // ------------------------------------------------------------------------------------------------
 struct GemmShape { int BM, BN, WN; };
 
-template <int WM, int WN, int TM, int EPI, int NS = 2>
+template <int WM, int WN, int TM, int EPI, int NS = 2, int ABL = 0>
 inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * 64;
     p.mblocks = (p.M + BM - 1) / BM;
@@ -299,7 +305,7 @@ inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
     p.k_tiles_per_split = (ktiles + ksplit - 1) / ksplit;
     const int nsplit = (ktiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
     if constexpr (EPI == EPI_ARGMAX) p.part_stride = p.nblocks * WN;
-    NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS>), dim3(p.mblocks * p.nblocks, nsplit), dim3(WM * WN * 64), s, p);
+    NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL>), dim3(p.mblocks * p.nblocks, nsplit), dim3(WM * WN * 64), s, p);
 }
 
 // tile families:  L = 128x128 (2x2 waves, 64x64 per wave)  -- prefill, lm_head, gate/up, codec

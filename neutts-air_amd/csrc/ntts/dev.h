@@ -56,6 +56,11 @@ NTTS_D void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 template <int N>
 NTTS_D void wait_vmem_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+// Workgroup barrier that does NOT drain in-flight LDS-DMA: __syncthreads() carries a vmcnt(0) whenever a
+// global_load_lds is outstanding, which collapses a multi-tile prefetch ring to depth 1.  This one only retires
+// the wave's own LDS reads/writes (lgkmcnt) before the rendezvous; DMA completion is the caller's counted vmcnt.
+NTTS_D void sync_keep_dma() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 NTTS_D float fexp(float x) { return expf(x); }
 NTTS_D float frsqrt_exact(float x) { return 1.0f / sqrtf(x); }
 

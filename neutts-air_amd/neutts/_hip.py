@@ -97,6 +97,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_codec_decode": (C.c_int, [p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(f32), i64]),
         "ntts_codec_last_timing": (C.c_int, [p, C.POINTER(f32)]),
         "ntts_k_gemm_bf16": (C.c_int, [p, i64, p, p, p, i64, i32, i32, i32, i32]),
+        "ntts_k_gemm_probe": (C.c_int, [i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_double)]),
         "ntts_k_rmsnorm_bf16": (C.c_int, [p, p, p, i32, i32, f32]),
         "ntts_k_membw": (C.c_int, [C.c_size_t, i32, C.POINTER(C.c_double)]),
         "ntts_k_mfma_probe": (C.c_int, [p]),
@@ -379,7 +380,7 @@ class CodecEngine:
             self._chk(self.lib.ntts_codec_decode(self.h, len(grp), flat.ctypes.data_as(i32p), lens.ctypes.data_as(i32p),
                                                  wav.ctypes.data_as(C.POINTER(C.c_float)), stride))
             for r, j in enumerate(grp):
-                out[j] = wav[r, : self.hop_length * len(codes[j])].copy()
+                out[j] = wav[r, : self.hop_length * len(codes[j])]     # view into this call's buffer: no second copy
             i += nb
         return out  # type: ignore[return-value]
 

@@ -133,6 +133,7 @@ inline void glds16(const void* gsrc, void* lds_wave_base) {
     memcpy((char*)d0.l + lane_id() * 16, gsrc, 16);
 }
 inline void wait_vmem() {}
+inline void sync_keep_dma() { emu::barrier(); }
 template <int N>
 inline void wait_vmem_le() {}
 

@@ -16,7 +16,7 @@ for leg in $LEGS; do
     prof)  rm -rf $OUT/prof; timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof -o bench -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $OUT/prof_bench.json 2> $OUT/prof.err; echo "prof rc=$?"
            python tools/prof_summary.py $OUT/prof > $OUT/prof_summary.txt 2>&1; head -40 $OUT/prof_summary.txt; cat $OUT/prof_bench.json; tail -3 $OUT/prof.err
            find $OUT/prof -name '*kernel_trace.csv' -size +20M -delete;;
-    pmc)   rm -rf $OUT/pmc; timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/pmc -o fetch -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-codec --batch ${PMC_BATCH:-256} > $OUT/pmc_bench.json 2> $OUT/pmc.err; echo "pmc rc=$?"; tail -3 $OUT/pmc.err
+    pmc)   rm -rf $OUT/pmc; NTTS_NO_GRAPH=1 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/pmc -o fetch -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-codec --decode ${PMC_DECODE:-250} --batch ${PMC_BATCH:-256} > $OUT/pmc_bench.json 2> $OUT/pmc.err; echo "pmc rc=$?"; tail -3 $OUT/pmc.err
            python tools/pmc_summary.py $OUT/pmc > $OUT/pmc_summary.txt 2>&1; head -30 $OUT/pmc_summary.txt; find $OUT/pmc -name '*.csv' -size +8M -delete;;
     *) echo "unknown leg $leg";;
   esac

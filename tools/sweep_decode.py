@@ -54,6 +54,8 @@ def main():
         for c in range(0, B, 64):
             n = min(64, B - c)
             eng.prefill(prompts[c:c + n], list(range(c, c + n)), [samp] * n)
+        eng.sync()
+        pf_ms = eng.last_timing()[0]
         eng.decode(a.mid)
         eng.sync()
         best = 1e9
@@ -67,7 +69,7 @@ def main():
             ms, nb, nl = eng.time_kernel(k, 20)
             kern[name] = round(ms * 1e3, 2)
         eng.close()
-        rec = {"env": env, "step_ms": round(best, 4), "isolated_us": kern, "ids": ids}
+        rec = {"env": env, "step_ms": round(best, 4), "last_prefill_chunk_ms": round(pf_ms, 2), "isolated_us": kern, "ids": ids}
         print(json.dumps(rec), flush=True)
         out.write(json.dumps(rec) + "\n")
         out.flush()

@@ -1,0 +1,41 @@
+#!/usr/bin/env python
+"""GEMM tile micro-benchmark / ablation on one MI355X (through ntts_k_gemm_probe).
+    python tools/ubench_gemm.py          -> gpurun_out/ubench_gemm.txt"""
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "neutts-air_amd")):
+    sys.path.insert(0, p)
+from neutts import _hip  # noqa: E402
+
+lib = _hip.load_library()
+SHAPES = {"qkv": (256, 1152, 896), "o": (256, 896, 896), "gate_up": (256, 9728, 896), "down": (256, 896, 4864)}
+CONFIGS = {10: "64x64 4w NS2", 11: "64x64 4w NS3", 12: "64x64 4w NS4", 13: "64x64 4w NS6", 20: "32x64 2w NS4",
+           21: "64x64 2w NS4", 22: "64x64 1w NS4", 23: "64x128 4w NS3", 24: "64x128 8w NS3", 25: "128x64 8w NS3",
+           26: "128x64 4w NS3", 30: "128x128 4w NS2", 31: "128x128 4w NS3"}
+
+
+def probe(M, N, K, cfg, abl, copies, iters=200):
+    us = C.c_double()
+    rc = lib.ntts_k_gemm_probe(M, N, K, cfg, abl, copies, iters, C.byref(us))
+    return us.value if rc == 0 else float("nan")
+
+
+def main():
+    print(f"empty kernel: {probe(64, 64, 64, 0, 0, 1):.2f} us/launch")
+    for name, (M, N, K) in SHAPES.items():
+        wbytes = N * K * 2
+        cold = max(2, int(400e6 // wbytes))
+        print(f"== {name}  M={M} N={N} K={K}  W={wbytes / 1e6:.2f} MB  cold copies={cold}")
+        print(f"{'config':18s} {'warm':>8s} {'cold':>8s} | cold ablations: {'noMFMA':>8s} {'noDMA':>8s} {'neither':>8s} {'noStore':>8s}")
+        for cfg, label in CONFIGS.items():
+            warm = probe(M, N, K, cfg, 0, 1)
+            c0 = probe(M, N, K, cfg, 0, cold)
+            ab = [probe(M, N, K, cfg, a, cold) for a in (1, 2, 3, 4)]
+            print(f"{label:18s} {warm:8.2f} {c0:8.2f} | {'':16s} {ab[0]:8.2f} {ab[1]:8.2f} {ab[2]:8.2f} {ab[3]:8.2f}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
