@@ -51,3 +51,20 @@ def test_no_cpu_fallback(hip_lib):
 def test_emulator_exports_same_abi(emu_lib):
     lib = ctypes.CDLL(emu_lib)
     assert not [n for n in declared_functions() if not hasattr(lib, n)]
+
+
+def test_product_never_imports_oracle():
+    """The oracle is the checker, never the thing shipped: no file of the product package may import or execute
+    anything under oracle/ (nor the SIMT emulator, nor /root/reference)."""
+    pkg = os.path.join(ROOT, "neutts-air_amd")
+    bad = []
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip")):
+                src = open(os.path.join(base, f), errors="ignore").read()
+                pat = r"^\s*(from|import)\s+oracle\b|/root/reference"
+                if f != "build.py":                          # build.py also holds the recipe of the test-only emulator library
+                    pat += r"|^\s*(#\s*include|from|import)\b.*simt_emu"
+                if re.search(pat, src, flags=re.M):
+                    bad.append(os.path.relpath(os.path.join(base, f), ROOT))
+    assert not bad, f"product files referencing test infrastructure: {bad}"
