@@ -103,10 +103,10 @@ typedef struct ntts_sampling {
     int32_t max_length;      /* total length cap (prompt + new), <= max_context        [2048] */
     int32_t min_new_tokens;  /* EOS logit = -inf while fewer new tokens than this      [50]   */
     int32_t eos_token_id;    /* <|SPEECH_GENERATION_END|>                                      */
-    int32_t do_sample;       /* 0 = greedy argmax (first max wins); 1 = top-k + multinomial [1] */
-    int32_t top_k;           /* [50] */
-    float temperature;       /* [1.0] */
-    uint64_t seed;           /* Philox seed for do_sample=1 */
+    int32_t do_sample;       /* 0 = greedy argmax (first max wins); 1 = temperature, top-k, multinomial [1] */
+    int32_t top_k;           /* [50]  >= 1; logits below the k-th largest are dropped, ties at the k-th kept (<= 512 kept) */
+    float temperature;       /* [1.0] > 0 */
+    uint64_t seed;           /* Philox4x32-10 key for do_sample=1; the draw of step t depends on (seed, t) only: give each request its own seed */
 } ntts_sampling;
 
 /* Prefill `n` prompts (packed back to back in `ids`, prompt i has lens[i] tokens) into the decode

@@ -30,6 +30,7 @@ struct LayerW {
 };
 
 struct HostSlot {
+    bool sampling = false;      // do_sample=1 request (needs the bf16 logits row)
     int state = SLOT_FREE;      // host view: FREE / RUNNING (may already be finished on device)
     int prompt_len = 0, max_len = 0;
     int pos_upper = 0;          // upper bound of the device-side pos
@@ -73,6 +74,10 @@ struct ntts_backbone {
     int* part_idx = nullptr;
     int n_part = 0;
     float* logits = nullptr;  // debug
+    bf16_t* logits_bf16 = nullptr;   // [B][ldl] processed logits for the top-k sampler (allocated on first sampling request)
+    long ldl = 0;
+    int n_sampling = 0;              // running slots with do_sample=1
+    bool graph_has_logits = false;
     int ks_o = 1, ks_d = 1, ks_qkv = 1;
     int st_qkv = 4, st_o = 4, st_gu = 3, st_d = 4;   // LDS ring depth of each skinny decode GEMM
     int head_stages = 2, l_stages = 2;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
@@ -205,13 +210,16 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->slots.resize(B);
 
     // ---- slot state
-    const size_t n_int = (size_t)B * 9 + (size_t)B * c->max_context + (size_t)B * e->max_pages;
+    const size_t n_int = (size_t)B * 13 + (size_t)B * c->max_context + (size_t)B * e->max_pages;
     CR_HIP(hipMalloc((void**)&e->ibuf, n_int * sizeof(int)));
     CR_HIP(hipMemset(e->ibuf, 0, n_int * sizeof(int)));
     int* ip = e->ibuf;
     e->sl.state = ip; ip += B; e->sl.pos = ip; ip += B; e->sl.n_new = ip; ip += B; e->sl.cur_tok = ip; ip += B;
     e->sl.prompt_len = ip; ip += B; e->sl.min_new = ip; ip += B; e->sl.max_len = ip; ip += B; e->sl.eos = ip; ip += B;
     e->sl.mask_eos = ip; ip += B;
+    e->sl.top_k = ip; ip += B;
+    e->sl.temperature = (float*)ip; ip += B;
+    e->sl.seed = (unsigned int*)ip; ip += 2 * B;
     e->sl.out_tokens = ip; ip += (size_t)B * c->max_context;
     e->sl.out_stride = c->max_context;
     e->block_table = ip;
@@ -251,6 +259,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     CR_HIP(hipMalloc((void**)&e->slabs, (size_t)max_slabs * B * (H > e->NQKV ? H : e->NQKV) * 4));
     CR_HIP(hipMalloc((void**)&e->part_val, (size_t)B * e->n_part * 4));
     CR_HIP(hipMalloc((void**)&e->part_idx, (size_t)B * e->n_part * 4));
+    e->ldl = ((long)V + 7) / 8 * 8;
     CR_HIP(hipMemset(e->h_dec, 0, (size_t)B * H * 2));
     CR_HIP(hipMemset(e->xn_dec, 0, (size_t)B * H * 2));
     CR_HIP(hipMemset(e->qkv_dec, 0, (size_t)B * e->NQKV * 2));
@@ -277,7 +286,7 @@ extern "C" void ntts_backbone_destroy(ntts_backbone* e) {
     hipDeviceSynchronize();
     if (e->graph) hipGraphExecDestroy(e->graph);
     void* bufs[] = {e->arena, e->gu_map_gate, e->gu_map_up, e->kv, e->ibuf, e->h_dec, e->xn_dec, e->qkv_dec, e->attn_dec,
-                    e->act_dec, e->slabs, e->part_val, e->part_idx, e->logits, e->h_pf, e->xn_pf, e->qkv_pf, e->attn_pf,
+                    e->act_dec, e->slabs, e->part_val, e->part_idx, e->logits, e->logits_bf16, e->h_pf, e->xn_pf, e->qkv_pf, e->attn_pf,
                     e->o_pf, e->act_pf, e->meta_dev};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -454,6 +463,7 @@ static void k_lm_head(ntts_backbone* e, bool keep_logits) {
     GemmArgs a = gemm_args(e->xn_dec, H, e->embed, H, nullptr, nullptr, 0, B, V, H);
     a.part_val = e->part_val; a.part_idx = e->part_idx; a.mask_eos = e->sl.mask_eos;
     a.logits = keep_logits ? e->logits : nullptr; a.ld_logits = V;
+    a.logits_bf16 = (keep_logits && e->n_sampling > 0) ? e->logits_bf16 : nullptr; a.ld_logits_bf16 = e->ldl;
     if (!e->head_large) { gemm_skinny<EPI_ARGMAX>(4, a, 1, e->stream); return; }
     switch (e->head_stages) {
         case 3: gemm_launch<2, 2, 4, EPI_ARGMAX, 3>(a, 1, e->stream); break;
@@ -466,6 +476,7 @@ static void lm_head_and_sample(ntts_backbone* e, int phase) {
     k_lm_head(e, true);
     SampleArgs s{};
     s.part_val = e->part_val; s.part_idx = e->part_idx; s.n_part = e->n_part; s.sl = e->sl; s.phase = phase;
+    s.logits = e->n_sampling > 0 ? e->logits_bf16 : nullptr; s.ld_logits = e->ldl; s.vocab = e->cfg.vocab_size;
     NTTS_LAUNCH((sample_greedy_kernel), dim3(e->cfg.max_batch), dim3(256), e->stream, s);
 }
 
@@ -560,7 +571,8 @@ extern "C" int ntts_backbone_prefill(ntts_backbone* e, int32_t n, const int32_t*
         if (lens[i] < 1) return fail(e, NTTS_EINVAL, "empty prompt %d", i);
         if (samp[i].max_length > c.max_context || samp[i].max_length <= lens[i])
             return fail(e, NTTS_EINVAL, "prompt %d: need len < max_length <= max_context (%d, %d)", i, lens[i], samp[i].max_length);
-        if (samp[i].do_sample) return fail(e, NTTS_EINVAL, "do_sample=1 (top-k multinomial) is not implemented yet: greedy only");
+        if (samp[i].do_sample && (samp[i].top_k < 1 || !(samp[i].temperature > 0.f)))
+            return fail(e, NTTS_EINVAL, "prompt %d: do_sample needs top_k >= 1 and temperature > 0 (got %d, %g)", i, samp[i].top_k, samp[i].temperature);
         if (samp[i].eos_token_id < 0 || samp[i].eos_token_id >= c.vocab_size) return fail(e, NTTS_EINVAL, "eos id out of range");
         T += lens[i];
     }
@@ -600,6 +612,11 @@ extern "C" int ntts_backbone_prefill(ntts_backbone* e, int32_t n, const int32_t*
     const size_t o_min = m.size();   for (int i = 0; i < n; ++i) m.push_back(samp[i].min_new_tokens);
     const size_t o_max = m.size();   for (int i = 0; i < n; ++i) m.push_back(samp[i].max_length);
     const size_t o_eos = m.size();   for (int i = 0; i < n; ++i) m.push_back(samp[i].eos_token_id);
+    const size_t o_topk = m.size();  for (int i = 0; i < n; ++i) m.push_back(samp[i].do_sample ? samp[i].top_k : 0);
+    const size_t o_temp = m.size();
+    for (int i = 0; i < n; ++i) { int b; const float t = samp[i].do_sample ? samp[i].temperature : 1.0f; memcpy(&b, &t, 4); m.push_back(b); }
+    const size_t o_seed = m.size();
+    for (int i = 0; i < n; ++i) { m.push_back((int)(uint32_t)samp[i].seed); m.push_back((int)(uint32_t)(samp[i].seed >> 32)); }
     const size_t o_last = m.size();
     acc = 0;
     for (int i = 0; i < n; ++i) { acc += lens[i]; m.push_back((int)acc - 1); }
@@ -611,6 +628,17 @@ extern "C" int ntts_backbone_prefill(ntts_backbone* e, int32_t n, const int32_t*
         for (int k = 0; k < e->max_pages; ++k) m.push_back(k < (int)s.pages.size() ? s.pages[k] : 0);
     }
     if (m.size() > e->meta_cap) return fail(e, NTTS_EINVAL, "prefill meta block too large");
+    {   // sampling requests need the bf16 logits rows: allocate on first use; the captured decode step bakes the pointer
+        int add = 0;
+        for (int i = 0; i < n; ++i) add += samp[i].do_sample ? 1 : 0;
+        if (add && !e->logits_bf16) {
+            HIPCHK(e, hipStreamSynchronize(e->stream));
+            HIPCHK(e, hipMalloc((void**)&e->logits_bf16, (size_t)B * e->ldl * sizeof(bf16_t)));
+            HIPCHK(e, hipMemset(e->logits_bf16, 0, (size_t)B * e->ldl * sizeof(bf16_t)));
+        }
+        for (int i = 0; i < n; ++i) e->slots[slots[i]].sampling = samp[i].do_sample != 0;
+        e->n_sampling += add;
+    }
     hipStream_t st = e->stream;
     HIPCHK(e, hipMemcpyAsync(e->meta_dev, m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(e, hipStreamSynchronize(st));  // m is pageable host memory
@@ -620,6 +648,7 @@ extern "C" int ntts_backbone_prefill(ntts_backbone* e, int32_t n, const int32_t*
     HIPCHK(e, hipEventRecord(e->ev[0], st));
     PrefillInit pi{};
     pi.slot = md + o_slot; pi.seq_len = md + o_len; pi.min_new = md + o_min; pi.max_len = md + o_max; pi.eos = md + o_eos;
+    pi.top_k = md + o_topk; pi.temp_bits = md + o_temp; pi.seed = md + o_seed;
     pi.bt_rows = md + o_bt; pi.block_table = e->block_table; pi.max_pages = e->max_pages; pi.n = n; pi.sl = e->sl;
     NTTS_LAUNCH((prefill_init_kernel), dim3(n), dim3(64), st, pi);
 
@@ -702,8 +731,14 @@ extern "C" int ntts_backbone_decode(ntts_backbone* e, int32_t n_steps) {
         const int nt = (int)trip.size() / 3;
         NTTS_LAUNCH((bt_update_kernel), dim3((nt + 63) / 64), dim3(64), st, (const int*)e->meta_dev, nt, e->block_table, e->max_pages);
     }
+    if (e->graph && e->graph_has_logits != (e->n_sampling > 0)) {   // the step's launch arguments changed
+        hipGraphExecDestroy(e->graph);
+        e->graph = nullptr;
+        e->graph_tried = false;
+    }
     if (e->use_graph && !e->graph_tried) {
         e->graph_tried = true;
+        e->graph_has_logits = e->n_sampling > 0;
         hipGraph_t g = nullptr;
         if (hipStreamBeginCapture(st, hipStreamCaptureModeGlobal) == hipSuccess) {
             decode_step(e);
@@ -785,6 +820,7 @@ extern "C" int ntts_backbone_release(ntts_backbone* e, int32_t slot) {
     HostSlot& s = e->slots[slot];
     for (int pg : s.pages) e->free_pages.push_back(pg);
     s.pages.clear();
+    if (s.sampling) { s.sampling = false; e->n_sampling--; }
     s.state = SLOT_FREE;
     static_assert(SLOT_FREE == 0, "release writes the state with a memset");
     HIPCHK(e, hipMemsetAsync(e->sl.state + slot, 0, sizeof(int), e->stream));

@@ -54,6 +54,8 @@ struct GemmArgs {
     const int* mask_eos;   // [M] value e+1 > 0 -> logit[e] = -inf for that row (MinNewTokens processor)
     float* logits;         // optional fp32 [M][ld_logits] dump of the processed logits
     long ld_logits;
+    bf16_t* logits_bf16;   // optional bf16 [M][ld_logits_bf16] processed logits for the top-k sampler
+    long ld_logits_bf16;
     // EPI_F32
     const float* resid;    // optional fp32 [M][ldr] added in the epilogue (may alias out)
     long ldr;
@@ -262,6 +264,7 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
             float best = -INFINITY;
             int bidx = 0x7fffffff;
             const int meos = (mok && p.mask_eos) ? p.mask_eos[m] : 0;   // eos id + 1, or 0
+            alignas(16) bf16_t lo[16];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -269,11 +272,22 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
                     const int n = nb16 + j * 4 + r;
                     float v = rbf(acc[a][j][r]);                  // lm_head output is bf16, then .float()
                     if (n == meos - 1) v = -INFINITY;
+                    lo[j * 4 + r] = f2bf(v);
                     if (n < p.N) {
                         if (mok && p.logits) p.logits[(long)m * p.ld_logits + n] = v;
                         if (v > best) { best = v; bidx = n; }      // ascending n + strict '>' = first max wins
                     }
                 }
+            if (p.logits_bf16 && mok) {
+                bf16_t* dst = p.logits_bf16 + (long)m * p.ld_logits_bf16 + nb16;
+                if (nb16 + 16 <= p.N) {
+                    *(u32x4*)dst = *(u32x4*)&lo[0];
+                    *(u32x4*)(dst + 8) = *(u32x4*)&lo[8];
+                } else {
+                    for (int e = 0; e < 16; ++e)
+                        if (nb16 + e < p.N) dst[e] = lo[e];
+                }
+            }
 #pragma unroll
             for (int sh = 16; sh <= 32; sh <<= 1) {
                 const float ov = shfl_xor(best, sh);

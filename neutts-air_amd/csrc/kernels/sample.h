@@ -2,8 +2,16 @@
 // as a hipGraph: nothing about a step depends on host-side state).
 //
 // Replaces the tail of GenerationMixin._sample (hf:generation/utils.py:2894-2941):
-//   fp32 logits -> MinNewTokensLength (applied in the lm_head epilogue via mask_eos) -> argmax
-//   (first max wins, torch.argmax) -> append -> EosTokenCriteria / MaxLengthCriteria.
+//   fp32 logits -> MinNewTokensLength (applied in the lm_head epilogue via mask_eos) ->
+//     do_sample=0: argmax (first max wins, torch.argmax)
+//     do_sample=1: [TemperatureLogitsWarper: scores / T] -> TopKLogitsWarper (scores < k-th largest -> -inf, ties at the
+//                  k-th value kept; hf:generation/logits_process.py:542-595) -> softmax -> multinomial(1)
+//                  (the reference's own call: do_sample=True, temperature=1.0, top_k=50, ref:neutts/neutts.py:338-347)
+//   -> append -> EosTokenCriteria / MaxLengthCriteria.
+// Sampling reads the row of bf16 logits the lm_head epilogue leaves behind (HF's logits ARE bf16 values cast to fp32, so a
+// 16-bit radix select finds the exact k-th largest), draws its uniform from Philox4x32-10 keyed by the request's seed with
+// the step index as counter: reproducible for a given seed whatever slot / batch the request runs in (callers give each
+// request its own seed); torch's own generator stream is not reproduced.
 #pragma once
 #include <ntts/dev.h>
 
@@ -21,6 +29,9 @@ struct SlotArrays {      // device arrays, one entry per decode slot
     int* max_len;
     int* eos;
     int* mask_eos;       // eos+1 while EOS is masked for the NEXT sampled token (n_new < min_new), else 0
+    int* top_k;          // 0 = greedy (do_sample=0); k >= 1 = sample among the k largest logits
+    float* temperature;  // > 0
+    unsigned int* seed;  // [slots][2] Philox key
     int* out_tokens;     // [slots][out_stride]
     int out_stride;
 };
@@ -29,9 +40,140 @@ struct SampleArgs {
     const float* part_val;   // [rows][n_part] per-row partial maxima from the lm_head epilogue
     const int* part_idx;
     int n_part;
+    const bf16_t* logits;    // [rows][ld_logits] processed bf16 logits (EOS mask applied); null if no slot samples
+    long ld_logits;
+    int vocab;
     SlotArrays sl;
     int phase;               // SLOT_RUNNING: decode step; SLOT_PREFILLED: first token after prefill
 };
+
+constexpr int kSampleCap = 512;   // candidates kept (k plus ties at the k-th value, capped)
+
+// Philox4x32-10 (Salmon et al. 2011), one block: 128-bit counter, 64-bit key -> 4 x 32 random bits
+NTTS_D void philox4x32(unsigned int (&c)[4], unsigned int k0, unsigned int k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+        const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned int)p1;
+        const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned int)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+// order-preserving 16-bit key of a bf16 value (larger value <-> larger key; -inf smallest of the non-NaN keys)
+NTTS_D unsigned int bf16_key(bf16_t v) { return (v & 0x8000u) ? (~(unsigned int)v & 0xFFFFu) : ((unsigned int)v | 0x8000u); }
+
+// top-k + multinomial for one row; all 256 threads of the block take part.  Returns the token in every thread.
+NTTS_D int sample_topk_row(const bf16_t* row, int V, int k, float temperature, unsigned int s0, unsigned int s1,
+                           unsigned int step) {
+    NTTS_SHARED unsigned int hist[256];
+    NTTS_SHARED unsigned int sel[4];          // [0] high byte, [1] elements above that bin, [2] threshold key, [3] list length
+    NTTS_SHARED int cidx[kSampleCap];
+    NTTS_SHARED unsigned short cval[kSampleCap];
+    NTTS_SHARED int sidx[kSampleCap];
+    NTTS_SHARED unsigned short sval[kSampleCap];
+    NTTS_SHARED int result;
+    const int tid = threadIdx.x;
+    if (k > V) k = V;
+    if (k > kSampleCap) k = kSampleCap;
+    const int nvec = V >> 3;                  // 16-byte vectors; the scalar tail is handled by the first threads
+    // ---- pass 1: histogram of the key's high byte
+    hist[tid] = 0;
+    if (tid < 4) sel[tid] = 0;
+    sync();
+    for (int i = tid; i < nvec; i += 256) {
+        const bf16x8 v = ld16<bf16x8>(row + (long)i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) atomic_add_lds(&hist[bf16_key((bf16_t)v[e]) >> 8], 1u);
+    }
+    for (int i = nvec * 8 + tid; i < V; i += 256) atomic_add_lds(&hist[bf16_key(row[i]) >> 8], 1u);
+    sync();
+    if (tid == 0) {
+        unsigned int above = 0;
+        int b = 255;
+        for (; b > 0; --b) {
+            if (above + hist[b] >= (unsigned int)k) break;
+            above += hist[b];
+        }
+        sel[0] = (unsigned int)b;
+        sel[1] = above;
+    }
+    sync();
+    const unsigned int hb = sel[0], above = sel[1];
+    // ---- pass 2: histogram of the low byte inside that bin
+    hist[tid] = 0;
+    sync();
+    for (int i = tid; i < nvec; i += 256) {
+        const bf16x8 v = ld16<bf16x8>(row + (long)i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const unsigned int key = bf16_key((bf16_t)v[e]);
+            if ((key >> 8) == hb) atomic_add_lds(&hist[key & 255u], 1u);
+        }
+    }
+    for (int i = nvec * 8 + tid; i < V; i += 256) {
+        const unsigned int key = bf16_key(row[i]);
+        if ((key >> 8) == hb) atomic_add_lds(&hist[key & 255u], 1u);
+    }
+    sync();
+    if (tid == 0) {
+        unsigned int acc = above;
+        int b = 255;
+        for (; b > 0; --b) {
+            if (acc + hist[b] >= (unsigned int)k) break;
+            acc += hist[b];
+        }
+        sel[2] = (hb << 8) | (unsigned int)b;   // key of the k-th largest logit
+    }
+    sync();
+    const unsigned int thr = sel[2];
+    // ---- pass 3: gather every logit >= the k-th largest (ties kept, like scores < kth -> -inf)
+    auto push = [&](int idx, bf16_t v) {
+        const unsigned int at = atomic_add_lds(&sel[3], 1u);
+        if (at < (unsigned int)kSampleCap) { cidx[at] = idx; cval[at] = v; }
+    };
+    for (int i = tid; i < nvec; i += 256) {
+        const bf16x8 v = ld16<bf16x8>(row + (long)i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (bf16_key((bf16_t)v[e]) >= thr) push(i * 8 + e, (bf16_t)v[e]);
+    }
+    for (int i = nvec * 8 + tid; i < V; i += 256)
+        if (bf16_key(row[i]) >= thr) push(i, row[i]);
+    sync();
+    int n = (int)sel[3];
+    if (n > kSampleCap) n = kSampleCap;
+    // ---- order the candidates by token id (the append order above is not deterministic): rank sort
+    for (int a = tid; a < n; a += 256) {
+        const int ia = cidx[a];
+        int rank = 0;
+        for (int b = 0; b < n; ++b) rank += cidx[b] < ia;
+        sidx[rank] = ia;
+        sval[rank] = cval[a];
+    }
+    sync();
+    // ---- softmax over the survivors + inverse-CDF draw (serial over <= 512 entries)
+    if (tid == 0) {
+        float m = -INFINITY;
+        for (int a = 0; a < n; ++a) m = fmaxf(m, bf2f(sval[a]));
+        const float it = 1.0f / temperature;
+        float total = 0.f;
+        for (int a = 0; a < n; ++a) total += fexp((bf2f(sval[a]) - m) * it);
+        unsigned int c[4] = {step, 0u, 0u, 0u};
+        philox4x32(c, s0, s1);
+        const float u = (float)(c[0] >> 8) * (1.0f / 16777216.0f);   // [0, 1)
+        const float target = u * total;
+        float acc = 0.f;
+        int pick = sidx[n - 1];
+        for (int a = 0; a < n; ++a) {
+            acc += fexp((bf2f(sval[a]) - m) * it);
+            if (acc > target) { pick = sidx[a]; break; }
+        }
+        result = pick;
+    }
+    sync();
+    return result;
+}
 
 NTTS_KERNEL(256) void sample_greedy_kernel(SampleArgs p) {
     NTTS_SHARED float sv[4];
@@ -52,12 +194,20 @@ NTTS_KERNEL(256) void sample_greedy_kernel(SampleArgs p) {
     }
     if (lane_id() == 0) { sv[wave_id()] = best; si[wave_id()] = bidx; }
     sync();
+    const bool live = p.sl.state[b] == p.phase;                     // block-uniform
+    const int k = (live && p.logits) ? p.sl.top_k[b] : 0;
+    int sampled = -1;
+    if (k > 0) {
+        const int step = (p.phase == SLOT_PREFILLED) ? 0 : p.sl.n_new[b];
+        sampled = sample_topk_row(p.logits + (long)b * p.ld_logits, p.vocab, k, p.sl.temperature[b], p.sl.seed[2 * b],
+                                  p.sl.seed[2 * b + 1], (unsigned int)step);
+    }
     if (tid == 0) {
         for (int w = 1; w < 4; ++w)
             if (sv[w] > best || (sv[w] == best && si[w] < bidx)) { best = sv[w]; bidx = si[w]; }
         SlotArrays& s = p.sl;
-        if (s.state[b] == p.phase) {
-            const int tok = bidx;
+        if (live) {
+            const int tok = k > 0 ? sampled : bidx;
             const int n = (p.phase == SLOT_PREFILLED) ? 0 : s.n_new[b];
             s.out_tokens[(long)b * s.out_stride + n] = tok;
             s.n_new[b] = n + 1;
@@ -77,6 +227,9 @@ struct PrefillInit {
     const int* min_new;
     const int* max_len;
     const int* eos;
+    const int* top_k;      // 0 = greedy
+    const int* temp_bits;  // float bits
+    const int* seed;       // [n][2]
     const int* bt_rows;    // [n][max_pages]
     int* block_table;      // [slots][max_pages]
     int max_pages;
@@ -95,6 +248,10 @@ NTTS_KERNEL(64) void prefill_init_kernel(PrefillInit p) {
         p.sl.min_new[s] = p.min_new[i];
         p.sl.max_len[s] = p.max_len[i];
         p.sl.eos[s] = p.eos[i];
+        p.sl.top_k[s] = p.top_k[i];
+        p.sl.temperature[s] = __builtin_bit_cast(float, p.temp_bits[i]);
+        p.sl.seed[2 * s] = (unsigned int)p.seed[2 * i];
+        p.sl.seed[2 * s + 1] = (unsigned int)p.seed[2 * i + 1];
         p.sl.mask_eos[s] = p.min_new[i] > 0 ? p.eos[i] + 1 : 0;
         p.sl.cur_tok[s] = 0;
     }

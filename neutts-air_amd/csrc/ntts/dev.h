@@ -61,6 +61,8 @@ NTTS_D void wait_vmem_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memo
 // the wave's own LDS reads/writes (lgkmcnt) before the rendezvous; DMA completion is the caller's counted vmcnt.
 NTTS_D void sync_keep_dma() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+NTTS_D unsigned int atomic_add_lds(unsigned int* p, unsigned int v) { return atomicAdd(p, v); }
+
 NTTS_D float fexp(float x) { return expf(x); }
 NTTS_D float frsqrt_exact(float x) { return 1.0f / sqrtf(x); }
 

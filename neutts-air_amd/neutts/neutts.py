@@ -248,16 +248,18 @@ class NeuTTS:
         return ref_codes
 
     # ------------------------------------------------------------------------------------------ id-level hot path
-    def _sampling(self, prompt_len: int) -> _hip.Sampling:
+    def _sampling(self, prompt_len: int, index: int = 0) -> _hip.Sampling:
         if self._eos_id is None:
             raise RuntimeError("eos token id unknown: supply 'eos_token_id' with in-memory weights")
+        # one Philox key per request: (call counter, index within the call)
+        seed = (self._seed * 0x9E3779B97F4A7C15 + index * 0xD1B54A32D192ED03 + 1) & 0xFFFFFFFFFFFFFFFF
         return _hip.Sampling(max_length=self.max_context, min_new_tokens=self.min_new_tokens, eos_token_id=self._eos_id,
-                             do_sample=self.do_sample, top_k=self.top_k, temperature=self.temperature, seed=self._seed)
+                             do_sample=self.do_sample, top_k=self.top_k, temperature=self.temperature, seed=seed)
 
     def generate_codes(self, prompts: Sequence[Sequence[int]]) -> List[List[int]]:
         """Batched equivalent of `_infer_torch` (ref:neutts/neutts.py:334-352): new token ids per prompt."""
         self._seed += 1
-        return self.backbone.generate(prompts, [self._sampling(len(p)) for p in prompts])
+        return self.backbone.generate(prompts, [self._sampling(len(p), i) for i, p in enumerate(prompts)])
 
     def _ids_to_codes(self, ids: Sequence[int]) -> List[int]:
         """ref :349 (tokenizer.decode) + :276 (regex): keep `<|speech_N|>` tokens, N = id - id(<|speech_0|>)."""

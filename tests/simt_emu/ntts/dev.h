@@ -132,6 +132,7 @@ inline void glds16(const void* gsrc, void* lds_wave_base) {
     memcpy(&d0, s.b[p][0], sizeof(d0));
     memcpy((char*)d0.l + lane_id() * 16, gsrc, 16);
 }
+inline unsigned int atomic_add_lds(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = o + v; return o; }
 inline void wait_vmem() {}
 inline void sync_keep_dma() { emu::barrier(); }
 template <int N>

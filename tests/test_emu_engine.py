@@ -78,9 +78,11 @@ def test_engine_error_paths(emu_lib):
     with pytest.raises(_hip.NeuTTSHipError):            # unknown name
         eng.load_tensor("model.layers.0.nope", np.zeros(7, dtype=np.float32))
     eng.load_state_dict({k: v.numpy() for k, v in w.items()}, inv_freq=br.rope_inv_freq(cfg).numpy())
-    with pytest.raises(_hip.NeuTTSHipError) as ei:      # sampling mode not implemented -> loud, not silent greedy
-        eng.prefill([[1, 2, 3]], [0], [_hip.Sampling(max_length=64, eos_token_id=1, do_sample=True)])
+    with pytest.raises(_hip.NeuTTSHipError) as ei:      # nonsensical sampling parameters -> loud, not silent greedy
+        eng.prefill([[1, 2, 3]], [0], [_hip.Sampling(max_length=64, eos_token_id=1, do_sample=True, top_k=0)])
     assert ei.value.code == -1
+    with pytest.raises(_hip.NeuTTSHipError):
+        eng.prefill([[1, 2, 3]], [0], [_hip.Sampling(max_length=64, eos_token_id=1, do_sample=True, temperature=0.0)])
     with pytest.raises(_hip.NeuTTSHipError):            # token id out of range
         eng.prefill([[1, 2, 999]], [0], [samp])
     with pytest.raises(_hip.NeuTTSHipError) as ei:      # 3 pages needed, pool has 2

@@ -124,3 +124,48 @@ def test_air_peaked_free_running_exact(lib):
             assert tv[k][0] - tv[k][1] <= 2 * 2.0 ** (np.floor(np.log2(abs(tv[k][0]))) - 7), (u, k, tv[k])
         if u == 1:
             assert k == N
+
+
+def test_air_sampling_topk50_full_vocab(air):
+    """The reference's own call (do_sample=True, temperature=1.0, top_k=50) at NeuTTS-Air geometry, V = 217 488, 256 slots:
+    each sampled token lies in the top-50 set of that step's logits (TopKLogitsWarper semantics, read back through the
+    debug tap), and the first-token frequencies over 1024 independent seeds follow softmax(top-50 logits)."""
+    z, cfg, eng = air
+    S, eos = int(z["s_len"]), int(z["eos"])
+    p = br.synthetic_prompt(cfg, 0, S)
+    eng.set_debug(True)
+    try:
+        counts = {}
+        ref_row = None
+        for rep in range(4):
+            for c in range(0, 256, 16):
+                samp = [_hip.Sampling(max_length=S + 4, min_new_tokens=4, eos_token_id=eos, do_sample=True, top_k=50,
+                                      temperature=1.0, seed=77_000 * rep + c + i) for i in range(16)]
+                eng.prefill([p] * 16, list(range(c, c + 16)), samp)
+            ids, _ = eng.read_all()
+            row = eng.read_logits(0)
+            if ref_row is None:
+                ref_row = row
+            assert np.array_equal(row, ref_row)                       # same prompt -> same logits, every slot / repeat
+            kth = np.sort(row)[-50]
+            for s in range(256):
+                t = ids[s][0]
+                assert row[t] >= kth, (s, t, row[t], kth)
+                counts[t] = counts.get(t, 0) + 1
+            if rep == 0:   # a few decode steps: membership against each step's own logits
+                for step in range(3):
+                    eng.decode(1)
+                    ids2, _ = eng.read_all()
+                    for s in (0, 17, 255):
+                        r = eng.read_logits(s)
+                        assert r[ids2[s][-1]] >= np.sort(r)[-50], (step, s)
+            for s in range(256):
+                eng.release(s)
+        top = np.argsort(ref_row)[-50:]
+        pr = np.exp(ref_row[top] - ref_row[top].max())
+        pr /= pr.sum()
+        got = np.array([counts.get(int(t), 0) for t in top]) / 1024.0
+        assert abs(got.sum() - 1.0) < 1e-9
+        assert np.abs(got - pr).max() < 0.05, (got, pr)
+    finally:
+        eng.set_debug(False)
