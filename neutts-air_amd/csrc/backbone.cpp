@@ -80,8 +80,8 @@ struct ntts_backbone {
     bool graph_has_logits = false;
     int ks_o = 1, ks_d = 1, ks_qkv = 1;
     int st_qkv = 4, st_o = 4, st_gu = 3, st_d = 4;   // LDS ring depth of each skinny decode GEMM
-    int head_stages = 2, l_stages = 2;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
-    bool gu_large = false, head_large = true;
+    int head_stages = 2, l_stages = 2, pf_gh = 7;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
+    bool gu_large = false, head_large = true, pf_attn_simple = false;
 
     // prefill workspaces
     int Tmax = 0;
@@ -244,6 +244,8 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->head_stages = env_int("NTTS_HEAD_STAGES", 2);
     e->l_stages = env_int("NTTS_L_STAGES", 2);
     e->gu_large = env_int("NTTS_GU_LARGE", 0) != 0;
+    e->pf_attn_simple = env_int("NTTS_PREFILL_ATTN_SIMPLE", 0) != 0;
+    e->pf_gh = env_int("NTTS_PF_GH", 7);
     e->head_large = env_int("NTTS_HEAD_LARGE", B > 64 ? 1 : 0) != 0;
     const int max_slabs = 16;
     if (e->ks_o > max_slabs) e->ks_o = max_slabs;
@@ -669,7 +671,8 @@ extern "C" int ntts_backbone_prefill(ntts_backbone* e, int32_t n, const int32_t*
         AttnPrefillArgs a{};
         a.qkv = e->qkv_pf; a.ld_qkv = e->NQKV; a.out = e->attn_pf; a.ld_out = QD; a.kpool = r.kpool; a.vpool = r.vpool;
         a.block_table = e->block_table; a.max_pages = e->max_pages; a.meta = meta; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
-        NTTS_LAUNCH((attn_prefill_kernel), dim3((unsigned)tile_seq.size(), c.num_heads), dim3(256), st, a);
+        if (e->pf_attn_simple) NTTS_LAUNCH((attn_prefill_kernel), dim3((unsigned)tile_seq.size(), c.num_heads), dim3(256), st, a);
+        else attn_prefill_launch(a, (int)tile_seq.size(), st, e->pf_gh);
         gemm_large<EPI_BF16>(e, gemm_args(e->attn_pf, QD, w.wo, QD, nullptr, e->o_pf, H, Ti, H, QD), st);
         NormArgs n1{};
         n1.o_bf16 = e->o_pf; n1.resid_in = e->h_pf; n1.resid_out = e->h_pf; n1.norm_w = w.ln2; n1.normed_out = e->xn_pf;

@@ -194,4 +194,215 @@ NTTS_KERNEL(256) void attn_prefill_kernel(AttnPrefillArgs p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// GQA-shared prefill attention: one workgroup per (64-query tile, kv-head).  The `group` query heads that share
+// a kv-head (7 for NeuTTS-Air) are processed together, so every K / V^T page is brought into LDS ONCE per
+// workgroup (LDS-DMA, double-buffered) and feeds 4 waves x GH heads, instead of being re-read from L2 by every
+// (head, 16-query wave) as in attn_prefill_kernel (kept as the simple reference path: 24x more load-path traffic).
+// Same arithmetic and rounding points as the simple kernel: two sweeps over the keys, P = bf16(softmax) before PV.
+//   LDS images (lane-linear LDS-DMA, swizzled on the SOURCE side):
+//     K   page [32 keys][128 B]: 16-B chunk c of key r stored at chunk c ^ (r & 7)        (ds_read_b128 conflict-free)
+//     V^T page [64 d][64 B]:     16-B unit  u of row d stored at unit  u ^ ((d >> 2) & 3) (ds_read_b64  conflict-free)
+template <int GH>
+NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
+    NTTS_SHARED bf16_t lds[2 * 2 * kPage * 64];   // [buf][K | V^T] 4 KB each
+    const int lane = lane_id(), w = wave_id();
+    const int g = lane >> 4, l15 = lane & 15;
+    const int sq = p.meta.tile_seq[blockIdx.x];
+    const int S = p.meta.seq_len[sq];
+    const int base = p.meta.tok_base[sq];
+    const int kvh = blockIdx.y;
+    const int group = p.nh / p.nkv;
+    const int h0 = kvh * group + blockIdx.z * GH;            // first query head of this pass
+    int nhd = group - blockIdx.z * GH;                        // heads handled here (<= GH)
+    if (nhd > GH) nhd = GH;
+    const int* bt = p.block_table + (long)p.meta.slot[sq] * p.max_pages;
+    const int q0 = p.meta.tile_q0[blockIdx.x];
+    const int qw0 = q0 + w * 16;                              // first query of this wave
+    const bool wave_live = qw0 < S;                           // dead waves still help loading and hit the barriers
+    int qpos = qw0 + l15;
+    if (qpos > S - 1) qpos = S - 1;
+    const int qlast_blk = (q0 + 63 < S ? q0 + 63 : S - 1);
+    const int npages = qlast_blk / kPage + 1;                 // pages the block needs (causal)
+    const int qlast_w = (qw0 + 15 < S ? qw0 + 15 : S - 1);
+    const int npages_w = wave_live ? qlast_w / kPage + 1 : 0; // pages this wave computes on
+
+    // ---- Q fragments of all heads (B operand: column = query l15, k = d g*8.. within each 32-wide half)
+    bf16x8 qB[GH][2];
+#pragma unroll
+    for (int h = 0; h < GH; ++h) {
+        const int hh = h < nhd ? h0 + h : h0;
+        const bf16_t* qr = p.qkv + (long)(base + qpos) * p.ld_qkv + hh * 64 + g * 16;
+        qB[h][0] = ld16<bf16x8>(qr);
+        qB[h][1] = ld16<bf16x8>(qr + 8);
+    }
+
+    // ---- page loader: wave 0/1 bring K (2 KB each), wave 2/3 bring V^T; one LDS-DMA instruction covers 1 KB
+    auto stage = [&](int pg, int buf) {
+        const long page = bt[pg];
+        bf16_t* dst = lds + buf * (2 * kPage * 64);
+        if (w < 2) {
+            const bf16_t* kp = p.kpool + (page * p.nkv + kvh) * kPage * 64;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int inst = w * 2 + i;                    // 8 keys per instruction
+                const int r = inst * 8 + (lane >> 3);
+                const int c = (lane & 7) ^ (r & 7);
+                glds16(kp + r * 64 + c * 8, dst + inst * 512);
+            }
+        } else {
+            const bf16_t* vp = p.vpool + (page * p.nkv + kvh) * 64 * kPage;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int inst = (w - 2) * 2 + i;              // 16 d-rows per instruction (64 B each)
+                const int d = inst * 16 + (lane >> 2);
+                const int u = (lane & 3) ^ ((d >> 2) & 3);
+                glds16(vp + d * kPage + u * 8, dst + kPage * 64 + inst * 512);
+            }
+        }
+    };
+    // K fragments of a page for this lane: key row u*16 + l15, logical chunks 2g, 2g+1
+    auto load_k = [&](const bf16_t* kb, bf16x8 (&kf)[2][2]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = u * 16 + l15;
+            kf[u][0] = ld16<bf16x8>(kb + r * 64 + (((2 * g) ^ (r & 7)) << 3));
+            kf[u][1] = ld16<bf16x8>(kb + r * 64 + (((2 * g + 1) ^ (r & 7)) << 3));
+        }
+    };
+    auto scores = [&](const bf16x8 (&kf)[2][2], int h, int pg, float (&sc)[8]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = mfma16(kf[u][0], qB[h][0], a);
+            a = mfma16(kf[u][1], qB[h][1], a);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = pg * kPage + u * 16 + g * 4 + r;
+                float v = rbf(rbf(a[r]) * 0.125f);
+                if (key > qpos) v = -INFINITY;                 // causal (covers key >= S as qpos <= S-1)
+                sc[u * 4 + r] = v;
+            }
+        }
+    };
+
+    // ---- sweep 1: row max and softmax denominator per head (online, lane-local; merged across key groups after)
+    float m[GH], sum[GH];
+#pragma unroll
+    for (int h = 0; h < GH; ++h) { m[h] = -INFINITY; sum[h] = 0.f; }
+    stage(0, 0);
+    for (int pg = 0; pg < npages; ++pg) {
+        wait_vmem();
+        sync();                                               // page pg landed; everyone done with the other buffer
+        if (pg + 1 < npages) stage(pg + 1, (pg + 1) & 1);
+        if (pg < npages_w) {
+            bf16x8 kf[2][2];
+            load_k(lds + (pg & 1) * (2 * kPage * 64), kf);
+#pragma unroll
+            for (int h = 0; h < GH; ++h) {
+                float sc[8];
+                scores(kf, h, pg, sc);
+                float tm = sc[0];
+#pragma unroll
+                for (int e = 1; e < 8; ++e) tm = fmaxf(tm, sc[e]);
+                const float mn = fmaxf(m[h], tm);
+                if (mn != -INFINITY) {
+                    float add = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) add += fexp(sc[e] - mn);
+                    sum[h] = sum[h] * fexp(m[h] - mn) + add;
+                    m[h] = mn;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < GH; ++h) {
+#pragma unroll
+        for (int sh = 16; sh <= 32; sh <<= 1) {
+            const float om = shfl_xor(m[h], sh), os = shfl_xor(sum[h], sh);
+            const float mn = fmaxf(m[h], om);
+            if (mn != -INFINITY) {
+                sum[h] = (m[h] == -INFINITY ? 0.f : sum[h] * fexp(m[h] - mn)) + (om == -INFINITY ? 0.f : os * fexp(om - mn));
+                m[h] = mn;
+            }
+        }
+    }
+
+    // ---- sweep 2: P = bf16(exp(s - m) / sum), O += P V
+    f32x4 oacc[GH][4];
+#pragma unroll
+    for (int h = 0; h < GH; ++h)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) oacc[h][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    sync();                                                   // sweep 1's last reads are done before buffer 0 is refilled
+    stage(0, 0);
+    for (int pg = 0; pg < npages; ++pg) {
+        wait_vmem();
+        sync();
+        if (pg + 1 < npages) stage(pg + 1, (pg + 1) & 1);
+        if (pg < npages_w) {
+            const bf16_t* kb = lds + (pg & 1) * (2 * kPage * 64);
+            const bf16_t* vb = kb + kPage * 64;
+            bf16x8 kf[2][2];
+            load_k(kb, kf);
+            bf16x8 vB[4];
+            const bool tail = (pg + 1) * kPage > S;            // page holds slots past the prompt: mask them
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int d = nt * 16 + l15;
+                const int sw = (d >> 2) & 3;
+                // keys g*4..g*4+3 live in 16-B unit g>>1 (half g&1); keys 16+g*4.. in unit 2+(g>>1)
+                const bf16x4 v0 = ld16<bf16x4>(vb + d * kPage + ((((g >> 1)) ^ sw) << 3) + (g & 1) * 4);
+                const bf16x4 v1 = ld16<bf16x4>(vb + d * kPage + (((2 + (g >> 1)) ^ sw) << 3) + (g & 1) * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { vB[nt][e] = v0[e]; vB[nt][4 + e] = v1[e]; }
+                if (tail) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int key = pg * kPage + (e < 4 ? g * 4 + e : 16 + g * 4 + e - 4);
+                        if (key >= S) vB[nt][e] = 0;
+                    }
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < GH; ++h) {
+                float sc[8];
+                scores(kf, h, pg, sc);
+                bf16x8 pA;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pA[e] = (short)f2bf(fexp(sc[e] - m[h]) / sum[h]);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) oacc[h][nt] = mfma16(pA, vB[nt], oacc[h][nt]);
+            }
+        }
+    }
+    // D: col = d (l15 of tile nt), row = query qw0 + g*4 + r
+    if (wave_live) {
+#pragma unroll
+        for (int h = 0; h < GH; ++h) {
+            if (h < nhd) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = qw0 + g * 4 + r;
+                    if (q < S) {
+                        bf16_t* o = p.out + (long)(base + q) * p.ld_out + (h0 + h) * 64 + l15;
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) o[nt * 16] = f2bf(oacc[h][nt][r]);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// host launcher: GH = 7 covers NeuTTS-Air's group in one pass; other group sizes run ceil(group / GH) passes
+inline void attn_prefill_launch(const AttnPrefillArgs& p, int n_tiles, hipStream_t s, int heads_per_pass = 7) {
+    const int group = p.nh / p.nkv;
+    if (group <= 4) NTTS_LAUNCH((attn_prefill_gqa_kernel<4>), dim3(n_tiles, p.nkv, 1), dim3(256), s, p);
+    else if (heads_per_pass <= 4) NTTS_LAUNCH((attn_prefill_gqa_kernel<4>), dim3(n_tiles, p.nkv, (group + 3) / 4), dim3(256), s, p);
+    else NTTS_LAUNCH((attn_prefill_gqa_kernel<7>), dim3(n_tiles, p.nkv, (group + 6) / 7), dim3(256), s, p);
+}
+
 }  // namespace ntts
