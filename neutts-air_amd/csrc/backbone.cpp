@@ -80,7 +80,7 @@ struct ntts_backbone {
     bool graph_has_logits = false;
     int ks_o = 1, ks_d = 1, ks_qkv = 1;
     int st_qkv = 4, st_o = 4, st_gu = 3, st_d = 4;   // LDS ring depth of each skinny decode GEMM
-    int head_stages = 2, l_stages = 2, pf_gh = 7;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
+    int head_stages = 2, l_stages = 2, pf_gh = 4, attn_depth = 3;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
     bool gu_large = false, head_large = true, pf_attn_simple = false;
 
     // prefill workspaces
@@ -245,7 +245,8 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->l_stages = env_int("NTTS_L_STAGES", 2);
     e->gu_large = env_int("NTTS_GU_LARGE", 0) != 0;
     e->pf_attn_simple = env_int("NTTS_PREFILL_ATTN_SIMPLE", 0) != 0;
-    e->pf_gh = env_int("NTTS_PF_GH", 7);
+    e->pf_gh = env_int("NTTS_PF_GH", 4);
+    e->attn_depth = env_int("NTTS_ATTN_DEPTH", 3);
     e->head_large = env_int("NTTS_HEAD_LARGE", B > 64 ? 1 : 0) != 0;
     const int max_slabs = 16;
     if (e->ks_o > max_slabs) e->ks_o = max_slabs;
@@ -501,7 +502,7 @@ static void k_attn(ntts_backbone* e, int i) {
     a.kpool = e->kv + (size_t)i * e->layer_stride; a.vpool = a.kpool + e->kv_half;
     a.block_table = e->block_table; a.max_pages = e->max_pages; a.pos = e->sl.pos; a.state = e->sl.state;
     a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
-    attn_decode_launch(a, c.max_batch, e->stream);
+    attn_decode_launch(a, c.max_batch, e->stream, e->attn_depth);
 }
 
 static void k_o_proj(ntts_backbone* e, int i) {

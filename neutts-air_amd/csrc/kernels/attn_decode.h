@@ -21,6 +21,7 @@ namespace ntts {
 constexpr int kPage = 32;        // tokens per KV page  (== NTTS_PAGE_TOKENS)
 constexpr int kAttnLMax = 2048;  // ref:neutts/neutts.py:85 max_context
 constexpr int kGroupMax = 8;     // query heads per kv head handled by one workgroup
+constexpr int kAttnDepthDefault = 3;  // KV pages each wave keeps in flight (register ring)
 
 struct AttnDecodeArgs {
     const bf16_t* qkv;     // [B][ld_qkv]: q heads | k heads | v heads, bias already added
@@ -50,6 +51,7 @@ NTTS_D void rope_pair(float x1, float x2, float c, float s, float& o1, float& o2
     o2 = rbf(rbf(x2 * c) + rbf(x1 * s));
 }
 
+template <int kDepth>
 NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
     NTTS_SHARED bf16_t sc[kGroupMax][kAttnLMax + 16];   // rounded scores, 33 KB; +32 B/row de-aliases the LDS banks
     NTTS_SHARED bf16_t qs[16][64];
@@ -120,36 +122,47 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
             k[u][1] = ld16<bf16x8>(kr + 8);
         }
     };
-    bf16x8 kc[2][2], kn[2][2];
-    if (w < npages) load_k(w, kc);
-    for (int pg = w; pg < npages; pg += 4) {
-        if (pg + 4 < npages) load_k(pg + 4, kn);
-        if (pg == last_page) {  // the token appended this step comes from LDS, not from HBM
+    // Register ring of kDepth pages per wave: HBM latency is hidden by bytes in flight (8 waves/CU x kDepth x 4 KB),
+    // a one-page look-ahead left the kernel latency-bound at ~0.5 of the HBM peak.
+    bf16x8 kq[kDepth][2][2];
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-                if (pg * kPage + u * 16 + l15 == P) {
-                    kc[u][0] = ld16<bf16x8>(&knew[g * 16]);
-                    kc[u][1] = ld16<bf16x8>(&knew[g * 16 + 8]);
+    for (int j = 0; j < kDepth; ++j)
+        if (w + 4 * j < npages) load_k(w + 4 * j, kq[j]);
+    for (int pg0 = w; pg0 < npages; pg0 += 4 * kDepth) {
+#pragma unroll
+        for (int j = 0; j < kDepth; ++j) {
+            const int pg = pg0 + 4 * j;
+            if (pg < npages) {
+                bf16x8 kc[2][2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { kc[u][0] = kq[j][u][0]; kc[u][1] = kq[j][u][1]; }
+                if (pg + 4 * kDepth < npages) load_k(pg + 4 * kDepth, kq[j]);
+                if (pg == last_page) {  // the token appended this step comes from LDS, not from HBM
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        if (pg * kPage + u * 16 + l15 == P) {
+                            kc[u][0] = ld16<bf16x8>(&knew[g * 16]);
+                            kc[u][1] = ld16<bf16x8>(&knew[g * 16 + 8]);
+                        }
                 }
-        }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            a = mfma16(kc[u][0], qB[0], a);
-            a = mfma16(kc[u][1], qB[1], a);
-            const int key0 = pg * kPage + u * 16 + g * 4;
-            bf16x4 sv;
+                for (int u = 0; u < 2; ++u) {
+                    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                    a = mfma16(kc[u][0], qB[0], a);
+                    a = mfma16(kc[u][1], qB[1], a);
+                    const int key0 = pg * kPage + u * 16 + g * 4;
+                    bf16x4 sv;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float s = rbf(rbf(a[r]) * 0.125f);   // matmul out (bf16) * scaling (bf16)
-                if (key0 + r >= L) s = -INFINITY;
-                lmax = fmaxf(lmax, s);
-                sv[r] = (short)f2bf(s);
+                    for (int r = 0; r < 4; ++r) {
+                        float s = rbf(rbf(a[r]) * 0.125f);   // matmul out (bf16) * scaling (bf16)
+                        if (key0 + r >= L) s = -INFINITY;
+                        lmax = fmaxf(lmax, s);
+                        sv[r] = (short)f2bf(s);
+                    }
+                    if (l15 < kGroupMax) *(bf16x4*)&sc[l15][key0] = sv;
+                }
             }
-            if (l15 < kGroupMax) *(bf16x4*)&sc[l15][key0] = sv;
         }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) { kc[u][0] = kn[u][0]; kc[u][1] = kn[u][1]; }
     }
     lmax = fmaxf(lmax, shfl_xor(lmax, 16));
     lmax = fmaxf(lmax, shfl_xor(lmax, 32));
@@ -187,43 +200,52 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
             v[nt][1] = ld16<bf16x4>(vr + 16);
         }
     };
-    bf16x4 vc[4][2], vn[4][2];
-    if (w < npages) load_v(w, vc);
-    for (int pg = w; pg < npages; pg += 4) {
-        if (pg + 4 < npages) load_v(pg + 4, vn);
-        bf16x8 pA;
+    bf16x4 vq[kDepth][4][2];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pA[e] = 0;
-        if (l15 < kGroupMax) {
-            const bf16x4 s0 = *(const bf16x4*)&sc[l15][pg * kPage + g * 4];
-            const bf16x4 s1 = *(const bf16x4*)&sc[l15][pg * kPage + 16 + g * 4];
+    for (int j = 0; j < kDepth; ++j)
+        if (w + 4 * j < npages) load_v(w + 4 * j, vq[j]);
+    for (int pg0 = w; pg0 < npages; pg0 += 4 * kDepth) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                pA[e] = (short)f2bf(fexp(bf2f((bf16_t)s0[e]) - m_l) / sum_l);
-                pA[4 + e] = (short)f2bf(fexp(bf2f((bf16_t)s1[e]) - m_l) / sum_l);
+        for (int j = 0; j < kDepth; ++j) {
+            const int pg = pg0 + 4 * j;
+            if (pg < npages) {
+                bf16x4 vc[4][2];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) { vc[nt][0] = vq[j][nt][0]; vc[nt][1] = vq[j][nt][1]; }
+                if (pg + 4 * kDepth < npages) load_v(pg + 4 * kDepth, vq[j]);
+                bf16x8 pA;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pA[e] = 0;
+                if (l15 < kGroupMax) {
+                    const bf16x4 s0 = *(const bf16x4*)&sc[l15][pg * kPage + g * 4];
+                    const bf16x4 s1 = *(const bf16x4*)&sc[l15][pg * kPage + 16 + g * 4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        pA[e] = (short)f2bf(fexp(bf2f((bf16_t)s0[e]) - m_l) / sum_l);
+                        pA[4 + e] = (short)f2bf(fexp(bf2f((bf16_t)s1[e]) - m_l) / sum_l);
+                    }
+                }
+                if (pg == last_page) {  // new token's V from LDS; nothing beyond it may leak in (0 * garbage)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const int key = pg * kPage + (e < 4 ? g * 4 + e : 16 + g * 4 + e - 4);
+                            short val = e < 4 ? vc[nt][0][e] : vc[nt][1][e - 4];
+                            if (key == P) val = (short)vnew[nt * 16 + l15];
+                            if (key > P) val = 0;
+                            if (e < 4) vc[nt][0][e] = val; else vc[nt][1][e - 4] = val;
+                        }
+                }
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) {
+                    bf16x8 vB;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { vB[e] = vc[nt][0][e]; vB[4 + e] = vc[nt][1][e]; }
+                    oacc[nt] = mfma16(pA, vB, oacc[nt]);
+                }
             }
         }
-        if (pg == last_page) {  // new token's V from LDS; nothing beyond it may leak in (0 * garbage)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int key = pg * kPage + (e < 4 ? g * 4 + e : 16 + g * 4 + e - 4);
-                    short val = e < 4 ? vc[nt][0][e] : vc[nt][1][e - 4];
-                    if (key == P) val = (short)vnew[nt * 16 + l15];
-                    if (key > P) val = 0;
-                    if (e < 4) vc[nt][0][e] = val; else vc[nt][1][e - 4] = val;
-                }
-        }
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            bf16x8 vB;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { vB[e] = vc[nt][0][e]; vB[4 + e] = vc[nt][1][e]; }
-            oacc[nt] = mfma16(pA, vB, oacc[nt]);
-        }
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) { vc[nt][0] = vn[nt][0]; vc[nt][1] = vn[nt][1]; }
     }
     // D: col = d (l15 within tile nt), row = head g*4 + r
     if (g < 2) {
@@ -240,8 +262,15 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
     }
 }
 
-inline void attn_decode_launch(const AttnDecodeArgs& p, int batch, hipStream_t s) {
-    NTTS_LAUNCH((attn_decode_kernel), dim3(batch, p.nkv), dim3(256), s, p);
+inline void attn_decode_launch(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth = kAttnDepthDefault) {
+    const dim3 grid(batch, p.nkv), block(256);
+    switch (depth) {
+        case 1: NTTS_LAUNCH((attn_decode_kernel<1>), grid, block, s, p); break;
+        case 2: NTTS_LAUNCH((attn_decode_kernel<2>), grid, block, s, p); break;
+        case 4: NTTS_LAUNCH((attn_decode_kernel<4>), grid, block, s, p); break;
+        case 6: NTTS_LAUNCH((attn_decode_kernel<6>), grid, block, s, p); break;
+        default: NTTS_LAUNCH((attn_decode_kernel<3>), grid, block, s, p); break;
+    }
 }
 
 }  // namespace ntts

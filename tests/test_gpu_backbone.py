@@ -161,7 +161,7 @@ def test_air_sampling_topk50_full_vocab(air):
                         assert r[ids2[s][-1]] >= np.sort(r)[-50], (step, s)
             for s in range(256):
                 eng.release(s)
-        top = np.argsort(ref_row)[-50:]
+        top = np.where(ref_row >= np.sort(ref_row)[-50])[0]          # bf16 logits tie: everything >= the 50th value is kept
         pr = np.exp(ref_row[top] - ref_row[top].max())
         pr /= pr.sum()
         got = np.array([counts.get(int(t), 0) for t in top]) / 1024.0
