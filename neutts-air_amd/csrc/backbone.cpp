@@ -78,7 +78,7 @@ struct ntts_backbone {
     long ldl = 0;
     int n_sampling = 0;              // running slots with do_sample=1
     bool graph_has_logits = false;
-    int ks_o = 1, ks_d = 1, ks_qkv = 1;
+    int ks_o = 1, ks_d = 1;
     int st_qkv = 4, st_o = 4, st_gu = 3, st_d = 4;   // LDS ring depth of each skinny decode GEMM
     int head_stages = 2, l_stages = 2, pf_gh = 4, attn_depth = 3;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
     bool gu_large = false, head_large = true, pf_attn_simple = false;
@@ -235,7 +235,6 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     };
     e->ks_o = env_int("NTTS_KSPLIT_O", pick_split(H / 64, c->num_heads * 64 / 64));
     e->ks_d = env_int("NTTS_KSPLIT_D", pick_split(H / 64, F / 64));
-    e->ks_qkv = env_int("NTTS_KSPLIT_QKV", 1);
     const int s_all = env_int("NTTS_S_STAGES", 0);
     e->st_qkv = env_int("NTTS_STAGES_QKV", s_all ? s_all : 4);
     e->st_o = env_int("NTTS_STAGES_O", s_all ? s_all : 4);
@@ -251,15 +250,14 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     const int max_slabs = 16;
     if (e->ks_o > max_slabs) e->ks_o = max_slabs;
     if (e->ks_d > max_slabs) e->ks_d = max_slabs;
-    if (e->ks_qkv > max_slabs) e->ks_qkv = max_slabs;
-    if (e->ks_qkv < 1) e->ks_qkv = 1;
+
     e->n_part = e->head_large ? ((V + 127) / 128) * 2 : (V + 63) / 64;
     CR_HIP(hipMalloc((void**)&e->h_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->xn_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->qkv_dec, (size_t)B * e->NQKV * 2));
     CR_HIP(hipMalloc((void**)&e->attn_dec, (size_t)B * c->num_heads * 64 * 2));
     CR_HIP(hipMalloc((void**)&e->act_dec, (size_t)B * F * 2));
-    CR_HIP(hipMalloc((void**)&e->slabs, (size_t)max_slabs * B * (H > e->NQKV ? H : e->NQKV) * 4));
+    CR_HIP(hipMalloc((void**)&e->slabs, (size_t)max_slabs * B * H * 4));
     CR_HIP(hipMalloc((void**)&e->part_val, (size_t)B * e->n_part * 4));
     CR_HIP(hipMalloc((void**)&e->part_idx, (size_t)B * e->n_part * 4));
     e->ldl = ((long)V + 7) / 8 * 8;
@@ -486,19 +484,13 @@ static void lm_head_and_sample(ntts_backbone* e, int phase) {
 static void k_qkv(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H;
     const LayerW& w = e->layers[i];
-    if (e->ks_qkv > 1)   // fp32 split-K slabs; bias + the nn.Linear rounding happen in the attention prologue
-        gemm_skinny<EPI_SPLITK>(e->st_qkv, gemm_args(e->xn_dec, H, w.wqkv, H, nullptr, e->slabs, e->NQKV, B, e->NQKV, H), e->ks_qkv, e->stream);
-    else
-        gemm_skinny<EPI_BF16>(e->st_qkv, gemm_args(e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H), 1, e->stream);
+    gemm_skinny<EPI_BF16>(e->st_qkv, gemm_args(e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H), 1, e->stream);
 }
 
 static void k_attn(ntts_backbone* e, int i) {
     const ntts_backbone_config& c = e->cfg;
     AttnDecodeArgs a{};
     a.qkv = e->qkv_dec; a.ld_qkv = e->NQKV; a.out = e->attn_dec; a.ld_out = c.num_heads * 64;
-    if (e->ks_qkv > 1) {
-        a.qkv_slabs = e->slabs; a.nslab = gemm_nsplit(e->H, e->ks_qkv); a.slab_rows = c.max_batch; a.qkv_bias = e->layers[i].bqkv;
-    }
     a.kpool = e->kv + (size_t)i * e->layer_stride; a.vpool = a.kpool + e->kv_half;
     a.block_table = e->block_table; a.max_pages = e->max_pages; a.pos = e->sl.pos; a.state = e->sl.state;
     a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
@@ -933,9 +925,7 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
     };
     switch (which) {
         case 0: *alg_bytes = kv_layer + act * (e->NQKV + QD); *launches_per_step = L; break;
-        case 1: *alg_bytes = ((double)e->NQKV * H + e->NQKV) * 2.0 + act * H +
-                             (e->ks_qkv > 1 ? (double)gemm_nsplit(H, e->ks_qkv) * B * e->NQKV * 4.0 : act * e->NQKV);
-                *launches_per_step = L; break;
+        case 1: *alg_bytes = ((double)e->NQKV * H + e->NQKV) * 2.0 + act * (H + e->NQKV); *launches_per_step = L; break;
         case 2: *alg_bytes = (double)H * QD * 2.0 + act * QD + (double)gemm_nsplit(QD, e->ks_o) * B * H * 4.0; *launches_per_step = L; break;
         case 3: *alg_bytes = (double)2 * F * H * 2.0 + act * (H + F); *launches_per_step = L; break;
         case 4: *alg_bytes = (double)H * F * 2.0 + act * F + (double)gemm_nsplit(F, e->ks_d) * B * H * 4.0; *launches_per_step = L; break;

@@ -7,7 +7,9 @@
 // One workgroup (4 waves) per (sequence, kv-head): the 7 query heads of a GQA group share every K/V
 // byte that is read, so KV traffic is the algorithmic minimum  L * 2 * 64 * 2 B  per (seq, kv-head, layer).
 // Layout in HBM (per layer):   K  [page][kv_head][32 tokens][64 d]     (a page-head is 4 KB contiguous)
-//                              V^T[page][kv_head][64 d][32 tokens]     (so PV's B-operand is k-contiguous)
+//                              V^T[page][kv_head][64 d][32 token slots] (so PV's B-operand is k-contiguous); token t of
+//                              a page sits at slot v_slot(t), which makes the 8 keys one lane feeds to the PV MFMA
+//                              (t = 4g..4g+3 and 16+4g..16+4g+3) ONE 16-byte load
 // Matrix-core mapping: S^T = K Q^T with A = K tile (16 keys x 32 d), B = Q^T (group heads padded to 16):
 // the accumulator then holds 4 consecutive keys of ONE head per lane, which is already the A-operand
 // shape PV needs (k-slot e<4 -> key g*4+e, e>=4 -> key 16+g*4+e-4 of the 32-key page) -- no cross-lane
@@ -20,18 +22,14 @@ namespace ntts {
 
 constexpr int kPage = 32;        // tokens per KV page  (== NTTS_PAGE_TOKENS)
 constexpr int kAttnLMax = 2048;  // ref:neutts/neutts.py:85 max_context
+// slot of token t (0..31) inside a V^T page row: [0-3,16-19 | 4-7,20-23 | 8-11,24-27 | 12-15,28-31]
+NTTS_HD int v_slot(int t) { return ((t & 15) >> 2) * 8 + (t >> 4) * 4 + (t & 3); }
 constexpr int kGroupMax = 8;     // query heads per kv head handled by one workgroup
 constexpr int kAttnDepthDefault = 3;  // KV pages each wave keeps in flight (register ring)
 
 struct AttnDecodeArgs {
     const bf16_t* qkv;     // [B][ld_qkv]: q heads | k heads | v heads, bias already added
     long ld_qkv;
-    // alternative input: the QKV GEMM's fp32 split-K slabs [nslab][slab_rows][ld_qkv]; this kernel then adds the
-    // bias and applies the nn.Linear output rounding (one RNE to bf16) itself
-    const float* qkv_slabs;
-    int nslab;
-    long slab_rows;
-    const bf16_t* qkv_bias;
     bf16_t* out;           // [B][nh*64]
     long ld_out;
     bf16_t* kpool;         // this layer
@@ -73,13 +71,23 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
     const int last_page = npages - 1;
     const int* bt = p.block_table + (long)b * p.max_pages;
     const bf16_t* row = p.qkv + (long)b * p.ld_qkv;
-    // element `col` of this sequence's q|k|v row as the bf16 nn.Linear output
-    auto qkv_at = [&](int col) -> bf16_t {
-        if (!p.qkv_slabs) return row[col];
-        float a = 0.f;
-        for (int s = 0; s < p.nslab; ++s) a += p.qkv_slabs[((long)s * p.slab_rows + b) * p.ld_qkv + col];
-        return f2bf(a + bf2f(p.qkv_bias[col]));
+    auto qkv_at = [&](int col) -> bf16_t { return row[col]; };
+
+    // ---- K pages do not depend on this step's q/k/v: start streaming them before the RoPE prologue (the slot of the
+    //      token appended below is overridden from LDS, whatever the page held).  Register ring of kDepth pages per wave.
+    auto load_k = [&](int pg, bf16x8 (&k)[2][2]) {
+        const bf16_t* kp = p.kpool + ((long)bt[pg] * p.nkv + kvh) * kPage * 64;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bf16_t* kr = kp + (u * 16 + l15) * 64 + g * 16;
+            k[u][0] = ld16<bf16x8>(kr);
+            k[u][1] = ld16<bf16x8>(kr + 8);
+        }
     };
+    bf16x8 kq[kDepth][2][2];
+#pragma unroll
+    for (int j = 0; j < kDepth; ++j)
+        if (w + 4 * j < npages) load_k(w + 4 * j, kq[j]);
 
     // ---- prologue: RoPE(q), RoPE(k) + append k, v to the cache (and keep them in LDS for this step)
     for (int t = tid; t < (group + 1) * 32; t += 256) {
@@ -100,7 +108,7 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
             const int slot = P % kPage;
             bf16_t* kd = p.kpool + ((pg * p.nkv + kvh) * kPage + slot) * 64;
             kd[i] = k1; kd[i + 32] = k2;
-            bf16_t* vd = p.vpool + (pg * p.nkv + kvh) * 64 * kPage + slot;
+            bf16_t* vd = p.vpool + (pg * p.nkv + kvh) * 64 * kPage + v_slot(slot);
             vd[(long)i * kPage] = v1; vd[(long)(i + 32) * kPage] = v2;
         }
     }
@@ -113,21 +121,6 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
 
     // ---- pass 1: S^T = K Q^T per 16-key sub-tile, bf16-rounded scores -> LDS, running max
     float lmax = -INFINITY;
-    auto load_k = [&](int pg, bf16x8 (&k)[2][2]) {
-        const bf16_t* kp = p.kpool + ((long)bt[pg] * p.nkv + kvh) * kPage * 64;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const bf16_t* kr = kp + (u * 16 + l15) * 64 + g * 16;
-            k[u][0] = ld16<bf16x8>(kr);
-            k[u][1] = ld16<bf16x8>(kr + 8);
-        }
-    };
-    // Register ring of kDepth pages per wave: HBM latency is hidden by bytes in flight (8 waves/CU x kDepth x 4 KB),
-    // a one-page look-ahead left the kernel latency-bound at ~0.5 of the HBM peak.
-    bf16x8 kq[kDepth][2][2];
-#pragma unroll
-    for (int j = 0; j < kDepth; ++j)
-        if (w + 4 * j < npages) load_k(w + 4 * j, kq[j]);
     for (int pg0 = w; pg0 < npages; pg0 += 4 * kDepth) {
 #pragma unroll
         for (int j = 0; j < kDepth; ++j) {
@@ -164,6 +157,17 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
             }
         }
     }
+    // ---- V^T pages are independent of the scores: get the first ones in flight under the softmax reductions
+    auto load_v = [&](int pg, bf16x8 (&v)[4]) {
+        const bf16_t* vp = p.vpool + ((long)bt[pg] * p.nkv + kvh) * 64 * kPage;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) v[nt] = ld16<bf16x8>(vp + (nt * 16 + l15) * kPage + g * 8);
+    };
+    bf16x8 vq[kDepth][4];
+#pragma unroll
+    for (int j = 0; j < kDepth; ++j)
+        if (w + 4 * j < npages) load_v(w + 4 * j, vq[j]);
+
     lmax = fmaxf(lmax, shfl_xor(lmax, 16));
     lmax = fmaxf(lmax, shfl_xor(lmax, 32));
     if (g == 0 && l15 < kGroupMax) wred[w][l15] = lmax;
@@ -191,27 +195,14 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
     for (int nt = 0; nt < 4; ++nt) oacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float m_l = l15 < kGroupMax ? rowmax[l15] : 0.f;
     const float sum_l = l15 < kGroupMax ? rowsum[l15] : 1.f;
-    auto load_v = [&](int pg, bf16x4 (&v)[4][2]) {
-        const bf16_t* vp = p.vpool + ((long)bt[pg] * p.nkv + kvh) * 64 * kPage;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const bf16_t* vr = vp + (nt * 16 + l15) * kPage + g * 4;
-            v[nt][0] = ld16<bf16x4>(vr);
-            v[nt][1] = ld16<bf16x4>(vr + 16);
-        }
-    };
-    bf16x4 vq[kDepth][4][2];
-#pragma unroll
-    for (int j = 0; j < kDepth; ++j)
-        if (w + 4 * j < npages) load_v(w + 4 * j, vq[j]);
     for (int pg0 = w; pg0 < npages; pg0 += 4 * kDepth) {
 #pragma unroll
         for (int j = 0; j < kDepth; ++j) {
             const int pg = pg0 + 4 * j;
             if (pg < npages) {
-                bf16x4 vc[4][2];
+                bf16x8 vc[4];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) { vc[nt][0] = vq[j][nt][0]; vc[nt][1] = vq[j][nt][1]; }
+                for (int nt = 0; nt < 4; ++nt) vc[nt] = vq[j][nt];
                 if (pg + 4 * kDepth < npages) load_v(pg + 4 * kDepth, vq[j]);
                 bf16x8 pA;
 #pragma unroll
@@ -231,19 +222,14 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const int key = pg * kPage + (e < 4 ? g * 4 + e : 16 + g * 4 + e - 4);
-                            short val = e < 4 ? vc[nt][0][e] : vc[nt][1][e - 4];
+                            short val = vc[nt][e];
                             if (key == P) val = (short)vnew[nt * 16 + l15];
                             if (key > P) val = 0;
-                            if (e < 4) vc[nt][0][e] = val; else vc[nt][1][e - 4] = val;
+                            vc[nt][e] = val;
                         }
                 }
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    bf16x8 vB;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { vB[e] = vc[nt][0][e]; vB[4 + e] = vc[nt][1][e]; }
-                    oacc[nt] = mfma16(pA, vB, oacc[nt]);
-                }
+                for (int nt = 0; nt < 4; ++nt) oacc[nt] = mfma16(pA, vc[nt], oacc[nt]);
             }
         }
     }

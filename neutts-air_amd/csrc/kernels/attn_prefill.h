@@ -62,7 +62,7 @@ NTTS_KERNEL(256) void rope_kv_write_kernel(RopeWriteArgs p) {
             kd[i + 32] = f2bf(o2);
         } else {
             const int kvh = hh - p.nh - p.nkv;
-            bf16_t* vd = p.vpool + (pg * p.nkv + kvh) * 64 * kPage + slot;
+            bf16_t* vd = p.vpool + (pg * p.nkv + kvh) * 64 * kPage + v_slot(slot);
             vd[(long)i * kPage] = h[i];
             vd[(long)(i + 32) * kPage] = h[i + 32];
         }
@@ -164,14 +164,7 @@ NTTS_KERNEL(256) void attn_prefill_kernel(AttnPrefillArgs p) {
         const bool tail = (pg + 1) * kPage > S;            // page holds slots past the prompt: mask them
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const bf16_t* vr = vp + (nt * 16 + l15) * kPage + g * 4;
-            const bf16x4 v0 = ld16<bf16x4>(vr), v1 = ld16<bf16x4>(vr + 16);
-            bf16x8 vB;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                vB[e] = v0[e];
-                vB[4 + e] = v1[e];
-            }
+            bf16x8 vB = ld16<bf16x8>(vp + (nt * 16 + l15) * kPage + g * 8);   // slots 8g..8g+7 = keys 4g..+3, 16+4g..+3
             if (tail) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -203,7 +196,7 @@ NTTS_KERNEL(256) void attn_prefill_kernel(AttnPrefillArgs p) {
 // Same arithmetic and rounding points as the simple kernel: two sweeps over the keys, P = bf16(softmax) before PV.
 //   LDS images (lane-linear LDS-DMA, swizzled on the SOURCE side):
 //     K   page [32 keys][128 B]: 16-B chunk c of key r stored at chunk c ^ (r & 7)        (ds_read_b128 conflict-free)
-//     V^T page [64 d][64 B]:     16-B unit  u of row d stored at unit  u ^ ((d >> 2) & 3) (ds_read_b64  conflict-free)
+//     V^T page [64 d][64 B]:     16-B unit  u of row d stored at unit  u ^ ((d >> 2) & 3) (ds_read_b128 conflict-free)
 template <int GH>
 NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
     NTTS_SHARED bf16_t lds[2 * 2 * kPage * 64];   // [buf][K | V^T] 4 KB each
@@ -353,11 +346,7 @@ NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
             for (int nt = 0; nt < 4; ++nt) {
                 const int d = nt * 16 + l15;
                 const int sw = (d >> 2) & 3;
-                // keys g*4..g*4+3 live in 16-B unit g>>1 (half g&1); keys 16+g*4.. in unit 2+(g>>1)
-                const bf16x4 v0 = ld16<bf16x4>(vb + d * kPage + ((((g >> 1)) ^ sw) << 3) + (g & 1) * 4);
-                const bf16x4 v1 = ld16<bf16x4>(vb + d * kPage + (((2 + (g >> 1)) ^ sw) << 3) + (g & 1) * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { vB[nt][e] = v0[e]; vB[nt][4 + e] = v1[e]; }
+                vB[nt] = ld16<bf16x8>(vb + d * kPage + ((g ^ sw) << 3));   // 16-B unit g of the row = keys 4g..+3, 16+4g..+3
                 if (tail) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
