@@ -82,6 +82,8 @@ struct ntts_backbone {
     int st_qkv = 4, st_o = 4, st_gu = 3, st_d = 4;   // LDS ring depth of each skinny decode GEMM
     int head_stages = 2, l_stages = 2, pf_gh = 4, attn_depth = 3;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
     bool gu_large = false, head_large = true, pf_attn_simple = false;
+    bool fused = true;        // decode step: RMSNorm fused into the QKV / gate-up GEMM prologues, residual into o_proj's epilogue
+    int n_cu = 256, xp_stages = 4;
 
     // prefill workspaces
     int Tmax = 0;
@@ -244,6 +246,9 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->l_stages = env_int("NTTS_L_STAGES", 2);
     e->gu_large = env_int("NTTS_GU_LARGE", 0) != 0;
     e->pf_attn_simple = env_int("NTTS_PREFILL_ATTN_SIMPLE", 0) != 0;
+    e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    e->fused = env_int("NTTS_FUSED", 1) != 0 && H <= 64 * kPanelKT && c->num_heads * 64 <= 64 * kPanelKT;
+    e->xp_stages = env_int("NTTS_XP_STAGES", 4);
     e->pf_gh = env_int("NTTS_PF_GH", 4);
     e->attn_depth = env_int("NTTS_ATTN_DEPTH", 3);
     e->head_large = env_int("NTTS_HEAD_LARGE", B > 64 ? 1 : 0) != 0;
@@ -521,7 +526,64 @@ static void k_add_norm(ntts_backbone* e, int K, int ks, const bf16_t* norm_w, bf
     add_rmsnorm_launch(n, e->stream);
 }
 
+template <int EPI, bool NORM>
+static void gemm_xpanel(ntts_backbone* e, const GemmArgs& a) {
+    switch (e->xp_stages) {
+        case 2: gemm_xpanel_launch<EPI, NORM, 2>(a, e->n_cu, e->stream); break;
+        case 3: gemm_xpanel_launch<EPI, NORM, 3>(a, e->n_cu, e->stream); break;
+        case 6: gemm_xpanel_launch<EPI, NORM, 6>(a, e->n_cu, e->stream); break;
+        default: gemm_xpanel_launch<EPI, NORM, 4>(a, e->n_cu, e->stream); break;
+    }
+}
+
+// fused decode-layer GEMMs (gemm_xpanel_kernel): the residual stream h_dec is the only activation that round-trips
+static void kf_qkv(ntts_backbone* e, int i) {       // qkv = Linear(rmsnorm(h) * ln1) + bias
+    const int B = e->cfg.max_batch, H = e->H;
+    const LayerW& w = e->layers[i];
+    GemmArgs a = gemm_args(e->h_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H);
+    a.norm_w = w.ln1; a.norm_eps = e->cfg.rms_eps;
+    gemm_xpanel<EPI_BF16, true>(e, a);
+}
+static void kf_o_proj(ntts_backbone* e, int i) {    // h = h + Linear_o(attn)   (in place)
+    const int B = e->cfg.max_batch, H = e->H, QD = e->cfg.num_heads * 64;
+    GemmArgs a = gemm_args(e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->h_dec, H, B, H, QD);
+    a.resid_bf16 = e->h_dec; a.ldrb = H;
+    gemm_xpanel<EPI_RESID, false>(e, a);
+}
+static void kf_gate_up(ntts_backbone* e, int i) {   // act = silu(gate(n)) * up(n), n = rmsnorm(h) * ln2
+    const int B = e->cfg.max_batch, H = e->H, F = e->F;
+    GemmArgs a = gemm_args(e->h_dec, H, e->layers[i].wgu, H, nullptr, e->act_dec, F, B, 2 * F, H);
+    a.norm_w = e->layers[i].ln2; a.norm_eps = e->cfg.rms_eps;
+    gemm_xpanel<EPI_SILU_MUL, true>(e, a);
+}
+
+static void kf_o_proj_scratch(ntts_backbone* e, int i) {   // timing replay: same work, result into a scratch buffer
+    const int B = e->cfg.max_batch, H = e->H, QD = e->cfg.num_heads * 64;
+    GemmArgs a = gemm_args(e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->o_pf, H, B, H, QD);
+    a.resid_bf16 = e->h_dec; a.ldrb = H;
+    gemm_xpanel<EPI_RESID, false>(e, a);
+}
+
+static void decode_step_fused(ntts_backbone* e) {
+    const ntts_backbone_config& c = e->cfg;
+    const int B = c.max_batch, H = e->H, F = e->F;
+    NormArgs n0{};   // h = embed[cur_tok]
+    n0.gather_ids = e->sl.cur_tok; n0.embed = e->embed; n0.resid_out = e->h_dec; n0.M = B; n0.H = H; n0.eps = c.rms_eps;
+    add_rmsnorm_launch(n0, e->stream);
+    for (int i = 0; i < c.num_layers; ++i) {
+        kf_qkv(e, i);
+        k_attn(e, i);
+        kf_o_proj(e, i);
+        kf_gate_up(e, i);
+        k_down(e, i);
+        const bool last = i + 1 == c.num_layers;   // h += down; only the final norm (lm_head input) is materialised
+        k_add_norm(e, F, e->ks_d, last ? e->final_norm : nullptr, e->h_dec, last ? e->xn_dec : nullptr);
+    }
+    lm_head_and_sample(e, SLOT_RUNNING);
+}
+
 static void decode_step(ntts_backbone* e) {
+    if (e->fused) { decode_step_fused(e); return; }
     const ntts_backbone_config& c = e->cfg;
     const int B = c.max_batch, H = e->H, F = e->F, QD = c.num_heads * 64;
     NormArgs n0{};
@@ -914,23 +976,29 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
     auto run = [&](int k) {
         switch (k) {
             case 0: k_attn(e, 0); break;                        // paged decode attention (+RoPE, +KV append)
-            case 1: k_qkv(e, 0); break;
-            case 2: k_o_proj(e, 0); break;
-            case 3: k_gate_up(e, 0); break;
+            case 1: if (e->fused) kf_qkv(e, 0); else k_qkv(e, 0); break;
+            case 2: if (e->fused) kf_o_proj_scratch(e, 0); else k_o_proj(e, 0); break;
+            case 3: if (e->fused) kf_gate_up(e, 0); else k_gate_up(e, 0); break;
             case 4: k_down(e, 0); break;
             case 5: k_lm_head(e, false); break;
-            case 6: k_add_norm(e, QD, e->ks_o, e->layers[0].ln2, e->o_pf, e->xn_pf); break;   // scratch outputs
+            case 6:   // scratch outputs
+                if (e->fused) k_add_norm(e, F, e->ks_d, nullptr, e->o_pf, nullptr);
+                else k_add_norm(e, QD, e->ks_o, e->layers[0].ln2, e->o_pf, e->xn_pf);
+                break;
             default: break;
         }
     };
     switch (which) {
         case 0: *alg_bytes = kv_layer + act * (e->NQKV + QD); *launches_per_step = L; break;
         case 1: *alg_bytes = ((double)e->NQKV * H + e->NQKV) * 2.0 + act * (H + e->NQKV); *launches_per_step = L; break;
-        case 2: *alg_bytes = (double)H * QD * 2.0 + act * QD + (double)gemm_nsplit(QD, e->ks_o) * B * H * 4.0; *launches_per_step = L; break;
+        case 2: *alg_bytes = (double)H * QD * 2.0 + act * QD +
+                             (e->fused ? act * 2 * H : (double)gemm_nsplit(QD, e->ks_o) * B * H * 4.0);
+                *launches_per_step = L; break;
         case 3: *alg_bytes = (double)2 * F * H * 2.0 + act * (H + F); *launches_per_step = L; break;
         case 4: *alg_bytes = (double)H * F * 2.0 + act * F + (double)gemm_nsplit(F, e->ks_d) * B * H * 4.0; *launches_per_step = L; break;
         case 5: *alg_bytes = (double)c.vocab_size * H * 2.0 + act * H; *launches_per_step = 1; break;
-        case 6: *alg_bytes = (double)gemm_nsplit(QD, e->ks_o) * B * H * 4.0 + act * H * 3; *launches_per_step = 2 * L; break;
+        case 6: *alg_bytes = (double)gemm_nsplit(e->fused ? F : QD, e->fused ? e->ks_d : e->ks_o) * B * H * 4.0 + act * H * (e->fused ? 2 : 3);
+                *launches_per_step = e->fused ? L : 2 * L; break;
         default: return fail(e, NTTS_EINVAL, "unknown kernel id %d", which);
     }
     if (which == 6 && B > e->Tmax) return fail(e, NTTS_EINVAL, "scratch too small");

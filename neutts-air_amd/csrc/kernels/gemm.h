@@ -32,7 +32,8 @@ enum GemmEpi {
     EPI_SPLITK = 2,    // out fp32 [split][M][N] raw partial sums
     EPI_ARGMAX = 3,    // per-row (max, first index) partials over this wave's 64 columns, logits = bf16(acc)
     EPI_BF16_SILU = 4, // out bf16 = bf16(silu(acc + bias))   (codec MLP fc1; the codec reference is fp32)
-    EPI_F32 = 5        // out fp32 [M][N] = acc + bias (+ fp32 residual): codec residual stream / ISTFT head / DFT
+    EPI_F32 = 5,       // out fp32 [M][N] = acc + bias (+ fp32 residual): codec residual stream / ISTFT head / DFT
+    EPI_RESID = 6      // out bf16 [M][N] = bf16(resid_bf16 + bf16(acc + bias)): o_proj + residual add (may be in place)
 };
 
 struct GemmArgs {
@@ -59,6 +60,13 @@ struct GemmArgs {
     // EPI_F32
     const float* resid;    // optional fp32 [M][ldr] added in the epilogue (may alias out)
     long ldr;
+    // EPI_RESID
+    const bf16_t* resid_bf16;   // [M][ldrb]
+    long ldrb;
+    // gemm_xpanel_kernel
+    const bf16_t* norm_w;  // [K] RMSNorm weight applied to X on load (NORM = true)
+    float norm_eps;
+    int ntiles_per_block;  // 64-column tiles each workgroup walks
 };
 
 NTTS_D void gemm_tile_coords(int bid, int mblocks, int nblocks, int& mb, int& nb) {
@@ -78,6 +86,160 @@ NTTS_D void gemm_tile_coords(int bid, int mblocks, int nblocks, int& mb, int& nb
 
 NTTS_D float silu_f(float x) { return x / (1.0f + fexp(-x)); }
 NTTS_D float gemm_bias(const GemmArgs& p, int n) { return p.bias_f32 ? p.bias_f32[n] : (p.bias ? bf2f(p.bias[n]) : 0.f); }
+
+// ---- epilogue shared by the GEMM kernels: lane owns token m (per a) x features nb16 .. nb16+15
+//      (acc[a][j][r] <-> feature nb16 + j*4 + r); mrow0 = first row of this wave's tile, split = split-K slab index
+template <int TM, int EPI, int WN>
+NTTS_D void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][4], int mrow0, int n0, int wn, int nb, int split) {
+    const int lane = lane_id();
+    const int g = lane >> 4, l15 = lane & 15;
+    const int nb16 = n0 + wn * 64 + g * 16;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const int m = mrow0 + a * 16 + l15;
+        const bool mok = m < p.M;
+        if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_SILU) {
+            alignas(16) bf16_t o[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = nb16 + j * 4 + r;
+                    float v = acc[a][j][r];
+                    if (n < p.N) v += gemm_bias(p, n);
+                    if constexpr (EPI == EPI_BF16_SILU) v = silu_f(v);
+                    o[j * 4 + r] = f2bf(v);
+                }
+            if (mok) {
+                bf16_t* dst = (bf16_t*)p.out + (long)m * p.ldo + nb16;
+                if (nb16 + 16 <= p.N) {
+                    *(u32x4*)dst = *(u32x4*)&o[0];
+                    *(u32x4*)(dst + 8) = *(u32x4*)&o[8];
+                } else {
+                    for (int e = 0; e < 16; ++e)
+                        if (nb16 + e < p.N) dst[e] = o[e];
+                }
+            }
+        } else if constexpr (EPI == EPI_RESID) {
+            // o = bf16(acc + bias) (the nn.Linear output), h = bf16(resid + o) (the residual add); in place is fine:
+            // every element is read and written by the one lane that owns it
+            if (mok) {
+                const bf16_t* rs = p.resid_bf16 + (long)m * p.ldrb + nb16;
+                bf16_t* dst = (bf16_t*)p.out + (long)m * p.ldo + nb16;
+                if (nb16 + 16 <= p.N) {
+                    alignas(16) bf16_t rr[16], o[16];
+                    *(u32x4*)&rr[0] = *(const u32x4*)rs;
+                    *(u32x4*)&rr[8] = *(const u32x4*)(rs + 8);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            o[j * 4 + r] = f2bf(bf2f(rr[j * 4 + r]) + rbf(acc[a][j][r] + gemm_bias(p, nb16 + j * 4 + r)));
+                    *(u32x4*)dst = *(u32x4*)&o[0];
+                    *(u32x4*)(dst + 8) = *(u32x4*)&o[8];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int n = nb16 + j * 4 + r;
+                            if (n < p.N) dst[j * 4 + r] = f2bf(bf2f(rs[j * 4 + r]) + rbf(acc[a][j][r] + gemm_bias(p, n)));
+                        }
+                }
+            }
+        } else if constexpr (EPI == EPI_F32) {
+            if (mok) {
+                float* dst = (float*)p.out + (long)m * p.ldo + nb16;
+                const float* rs = p.resid ? p.resid + (long)m * p.ldr + nb16 : nullptr;
+                if (nb16 + 16 <= p.N) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f32x4 v = acc[a][j];
+                        if (p.bias || p.bias_f32) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += gemm_bias(p, nb16 + j * 4 + r);
+                        }
+                        if (rs) {
+                            const f32x4 q = ld16<f32x4>(rs + j * 4);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += q[r];
+                        }
+                        *(f32x4*)(dst + j * 4) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int n = nb16 + j * 4 + r;
+                            if (n < p.N) dst[j * 4 + r] = acc[a][j][r] + gemm_bias(p, n) + (rs ? rs[j * 4 + r] : 0.f);
+                        }
+                }
+            }
+        } else if constexpr (EPI == EPI_SILU_MUL) {
+            // packed rows: j = 0,1 -> gate features fb + j*4 + r ; j = 2,3 -> up of the same features
+            alignas(16) bf16_t o[8];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gt = rbf(acc[a][jj][r]);          // gate_proj output (bf16)
+                    const float up = rbf(acc[a][jj + 2][r]);      // up_proj output (bf16)
+                    const float s = rbf(silu_f(gt));              // act_fn output (bf16)
+                    o[jj * 4 + r] = f2bf(s * up);                 // product (bf16)
+                }
+            if (mok) {
+                const int fb = ((n0 + wn * 64) >> 1) + g * 8;
+                if (fb + 8 <= (p.N >> 1)) *(u32x4*)((bf16_t*)p.out + (long)m * p.ldo + fb) = *(u32x4*)&o[0];
+            }
+        } else if constexpr (EPI == EPI_SPLITK) {
+            if (mok && nb16 + 16 <= p.N) {
+                float* dst = (float*)p.out + ((long)split * p.M + m) * p.ldo + nb16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) *(f32x4*)(dst + j * 4) = acc[a][j];
+            }
+        } else if constexpr (EPI == EPI_ARGMAX) {
+            float best = -INFINITY;
+            int bidx = 0x7fffffff;
+            const int meos = (mok && p.mask_eos) ? p.mask_eos[m] : 0;   // eos id + 1, or 0
+            alignas(16) bf16_t lo[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = nb16 + j * 4 + r;
+                    float v = rbf(acc[a][j][r]);                  // lm_head output is bf16, then .float()
+                    if (n == meos - 1) v = -INFINITY;
+                    lo[j * 4 + r] = f2bf(v);
+                    if (n < p.N) {
+                        if (mok && p.logits) p.logits[(long)m * p.ld_logits + n] = v;
+                        if (v > best) { best = v; bidx = n; }      // ascending n + strict '>' = first max wins
+                    }
+                }
+            if (p.logits_bf16 && mok) {
+                bf16_t* dst = p.logits_bf16 + (long)m * p.ld_logits_bf16 + nb16;
+                if (nb16 + 16 <= p.N) {
+                    *(u32x4*)dst = *(u32x4*)&lo[0];
+                    *(u32x4*)(dst + 8) = *(u32x4*)&lo[8];
+                } else {
+                    for (int e = 0; e < 16; ++e)
+                        if (nb16 + e < p.N) dst[e] = lo[e];
+                }
+            }
+#pragma unroll
+            for (int sh = 16; sh <= 32; sh <<= 1) {
+                const float ov = shfl_xor(best, sh);
+                const int oi = shfl_xor(bidx, sh);
+                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+            }
+            if (mok && g == 0) {
+                const long pi = (long)m * p.part_stride + nb * WN + wn;
+                p.part_val[pi] = best;
+                p.part_idx[pi] = bidx;
+            }
+        }
+    }
+}
 
 // ABL (micro-benchmark ablation, always 0 in the product): 1 = no LDS reads / MFMA, 2 = no LDS-DMA, 4 = no stores
 template <int WM, int WN, int TM, int EPI, int NS, int ABL = 0>
@@ -181,126 +343,158 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     if constexpr (ABL & 4) {
         if (acc[0][0][0] != 12345.678f) return;   // keeps the accumulators live without storing
     }
-    // ---- epilogue: lane owns token m (per a) x features nb16 .. nb16+15  (acc[a][j][r] <-> nb16 + j*4 + r)
-    const int nb16 = n0 + wn * 64 + g * 16;
+    gemm_epilogue<TM, EPI, WN>(p, acc, m0 + wm * TM * 16, n0, wn, nb, blockIdx.y);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// X-panel-resident GEMM for the decode step's K = hidden_size GEMMs (K <= 896, M = batch):
+//     out[M, N] = f(X)[M, K] * W[N, K]^T,   f = identity  or  RMSNorm (NORM: w * bf16(x * rsqrt(mean(x^2) + eps)))
+// A workgroup owns 64 rows of X.  It loads that 64 x K panel ONCE (through registers, so the RMSNorm of
+// hf:models/qwen2/modeling_qwen2.py:247-252 is applied on the way in: no separate norm kernel, no normalised copy of
+// the activations in HBM), keeps it in LDS in the k-tile-major swizzled image the MFMA loop reads, and then walks
+// `ntiles_per_block` 64-column tiles streaming only W through an NS-deep LDS-DMA ring that runs across tile
+// boundaries.  Compared with the 64x64 tile kernel this halves the bytes pulled through LDS per CU (the measured
+// limiter of the skinny decode GEMMs) and removes one launch per fused norm.
+// LDS: 14 panel k-tiles + NS ring slots of 8 KB (64 rows x 128 B), e.g. 144 KB at NS = 4: one workgroup per CU.
+constexpr int kPanelKT = 14;
+template <int EPI, bool NORM, int NS>
+NTTS_KERNEL(256) void gemm_xpanel_kernel(GemmArgs p) {
+    static_assert(NS >= 2 && NS <= 6, "ring depth");
+    NTTS_SHARED bf16_t lds[(kPanelKT + NS) * 4096];
+    const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+    const int g = lane >> 4, l15 = lane & 15;
+    const int KT = p.K >> 6;
+    // grid = mblocks * ngroups; XCD-aware: consecutive logical ids (one XCD) are the m-blocks of one column group
+    const int nblk = gridDim.x;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int qd = nblk >> 3, rm = nblk & 7;
+    const int t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    const int mb = t % p.mblocks, ng = t / p.mblocks;
+    const int m0 = mb * 64;
+    const int nt0 = ng * p.ntiles_per_block;
+    int ntl = p.nblocks - nt0;
+    if (ntl > p.ntiles_per_block) ntl = p.ntiles_per_block;
+    if (ntl <= 0) return;                        // block-uniform
+    const int total = ntl * KT;
+    bf16_t* ring = lds + kPanelKT * 4096;
+
+    // ---- W loader: 8 LDS-DMA instructions per 64 x 64 tile, 2 per wave
+    auto stage = [&](int f, int slot) {
+        const int nt = f / KT, kt = f - nt * KT;
+        const int n0 = (nt0 + nt) * 64;
 #pragma unroll
-    for (int a = 0; a < TM; ++a) {
-        const int m = m0 + wm * TM * 16 + a * 16 + l15;
-        const bool mok = m < p.M;
-        if constexpr (EPI == EPI_BF16 || EPI == EPI_BF16_SILU) {
-            alignas(16) bf16_t o[16];
+        for (int i = 0; i < 2; ++i) {
+            const int inst = wave + 4 * i;
+            const int q = inst * 8 + (lane >> 3);                 // tile-major W row (see gemm_kernel)
+            const int j = (q >> 4) & 3, i16 = q & 15;
+            int n = n0 + (i16 >> 2) * 16 + j * 4 + (i16 & 3);
+            if (n > p.N - 1) n = p.N - 1;
+            const int c = (lane & 7) ^ ((q >> 1) & 7);
+            glds16(p.W + (long)n * p.ldw + kt * 64 + c * 8, ring + slot * 4096 + inst * 512);
+        }
+    };
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < total) stage(s, s);              // W is on its way while the panel is built
+
+    // ---- X panel: thread = (row r, quarter q4); 16-byte chunks q4, q4 + 4, ... of the row
+    {
+        const int r = tid >> 2, q4 = tid & 3;
+        int m = m0 + r;
+        if (m > p.M - 1) m = p.M - 1;
+        const bf16_t* xr = p.X + (long)m * p.ldx;
+        const int nch = p.K >> 3;
+        constexpr int MAXJ = kPanelKT * 8 / 4;   // 28
+        bf16x8 xv[MAXJ];
+        float ss = 0.f;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = nb16 + j * 4 + r;
-                    float v = acc[a][j][r];
-                    if (n < p.N) v += gemm_bias(p, n);
-                    if constexpr (EPI == EPI_BF16_SILU) v = silu_f(v);
-                    o[j * 4 + r] = f2bf(v);
-                }
-            if (mok) {
-                bf16_t* dst = (bf16_t*)p.out + (long)m * p.ldo + nb16;
-                if (nb16 + 16 <= p.N) {
-                    *(u32x4*)dst = *(u32x4*)&o[0];
-                    *(u32x4*)(dst + 8) = *(u32x4*)&o[8];
-                } else {
-                    for (int e = 0; e < 16; ++e)
-                        if (nb16 + e < p.N) dst[e] = o[e];
-                }
-            }
-        } else if constexpr (EPI == EPI_F32) {
-            if (mok) {
-                float* dst = (float*)p.out + (long)m * p.ldo + nb16;
-                const float* rs = p.resid ? p.resid + (long)m * p.ldr + nb16 : nullptr;
-                if (nb16 + 16 <= p.N) {
+        for (int j = 0; j < MAXJ; ++j) {
+            const int c = q4 + 4 * j;
+            if (c < nch) {
+                xv[j] = ld16<bf16x8>(xr + c * 8);
+                if constexpr (NORM) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        f32x4 v = acc[a][j];
-                        if (p.bias || p.bias_f32) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += gemm_bias(p, nb16 + j * 4 + r);
-                        }
-                        if (rs) {
-                            const f32x4 q = ld16<f32x4>(rs + j * 4);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += q[r];
-                        }
-                        *(f32x4*)(dst + j * 4) = v;
-                    }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int n = nb16 + j * 4 + r;
-                            if (n < p.N) dst[j * 4 + r] = acc[a][j][r] + gemm_bias(p, n) + (rs ? rs[j * 4 + r] : 0.f);
-                        }
-                }
-            }
-        } else if constexpr (EPI == EPI_SILU_MUL) {
-            // packed rows: j = 0,1 -> gate features fb + j*4 + r ; j = 2,3 -> up of the same features
-            alignas(16) bf16_t o[8];
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float gt = rbf(acc[a][jj][r]);          // gate_proj output (bf16)
-                    const float up = rbf(acc[a][jj + 2][r]);      // up_proj output (bf16)
-                    const float s = rbf(silu_f(gt));              // act_fn output (bf16)
-                    o[jj * 4 + r] = f2bf(s * up);                 // product (bf16)
-                }
-            if (mok) {
-                const int fb = ((n0 + wn * 64) >> 1) + g * 8;
-                if (fb + 8 <= (p.N >> 1)) *(u32x4*)((bf16_t*)p.out + (long)m * p.ldo + fb) = *(u32x4*)&o[0];
-            }
-        } else if constexpr (EPI == EPI_SPLITK) {
-            if (mok && nb16 + 16 <= p.N) {
-                float* dst = (float*)p.out + ((long)blockIdx.y * p.M + m) * p.ldo + nb16;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) *(f32x4*)(dst + j * 4) = acc[a][j];
-            }
-        } else if constexpr (EPI == EPI_ARGMAX) {
-            float best = -INFINITY;
-            int bidx = 0x7fffffff;
-            const int meos = (mok && p.mask_eos) ? p.mask_eos[m] : 0;   // eos id + 1, or 0
-            alignas(16) bf16_t lo[16];
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int n = nb16 + j * 4 + r;
-                    float v = rbf(acc[a][j][r]);                  // lm_head output is bf16, then .float()
-                    if (n == meos - 1) v = -INFINITY;
-                    lo[j * 4 + r] = f2bf(v);
-                    if (n < p.N) {
-                        if (mok && p.logits) p.logits[(long)m * p.ld_logits + n] = v;
-                        if (v > best) { best = v; bidx = n; }      // ascending n + strict '>' = first max wins
-                    }
-                }
-            if (p.logits_bf16 && mok) {
-                bf16_t* dst = p.logits_bf16 + (long)m * p.ld_logits_bf16 + nb16;
-                if (nb16 + 16 <= p.N) {
-                    *(u32x4*)dst = *(u32x4*)&lo[0];
-                    *(u32x4*)(dst + 8) = *(u32x4*)&lo[8];
-                } else {
-                    for (int e = 0; e < 16; ++e)
-                        if (nb16 + e < p.N) dst[e] = lo[e];
+                    for (int e = 0; e < 8; ++e) { const float f = bf2f((bf16_t)xv[j][e]); ss += f * f; }
                 }
             }
+        }
+        float inv = 1.f;
+        if constexpr (NORM) {
+            ss += shfl_xor(ss, 1);
+            ss += shfl_xor(ss, 2);
+            inv = frsqrt_exact(ss / (float)p.K + p.norm_eps);
+        }
 #pragma unroll
-            for (int sh = 16; sh <= 32; sh <<= 1) {
-                const float ov = shfl_xor(best, sh);
-                const int oi = shfl_xor(bidx, sh);
-                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-            }
-            if (mok && g == 0) {
-                const long pi = (long)m * p.part_stride + nb * WN + wn;
-                p.part_val[pi] = best;
-                p.part_idx[pi] = bidx;
+        for (int j = 0; j < MAXJ; ++j) {
+            const int c = q4 + 4 * j;
+            if (c < nch) {
+                bf16x8 y = xv[j];
+                if constexpr (NORM) {
+                    const bf16x8 wv = ld16<bf16x8>(p.norm_w + c * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        y[e] = (short)f2bf(bf2f((bf16_t)wv[e]) * rbf(bf2f((bf16_t)xv[j][e]) * inv));
+                }
+                const int kt = c >> 3, cc = c & 7;
+                *(bf16x8*)(lds + kt * 4096 + r * 64 + ((cc ^ ((r >> 1) & 7)) << 3)) = y;
             }
         }
     }
+    sync();
+
+    // ---- main loop over the flattened (column tile, k tile) sequence
+    const int xrow = wave * 16 + l15;
+    const int xoff = xrow * 64, xsw = (xrow >> 1) & 7;
+    int woff[4], wsw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = j * 16 + l15;
+        woff[j] = q * 64;
+        wsw[j] = (q >> 1) & 7;
+    }
+    f32x4 acc[1][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int slot = 0, kt = 0, nt = 0;
+    for (int f = 0; f < total; ++f) {
+        // tile f must have landed; up to NS-2 younger tiles (and an epilogue's stores, retired in order) stay in flight
+        if (f + NS - 2 < total) wait_vmem_le<(NS - 2) * 2>(); else wait_vmem();
+        sync_keep_dma();
+        if (f + NS - 1 < total) stage(f + NS - 1, slot == 0 ? NS - 1 : slot - 1);
+        const bf16_t* xb = lds + kt * 4096;
+        const bf16_t* wb = ring + slot * 4096;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int c = ks * 4 + g;
+            const bf16x8 xf = ld16<bf16x8>(xb + xoff + ((c ^ xsw) << 3));
+            bf16x8 wa[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wa[j] = ld16<bf16x8>(wb + woff[j] + ((c ^ wsw[j]) << 3));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[0][j] = mfma16(wa[j], xf, acc[0][j]);
+        }
+        slot = slot + 1 == NS ? 0 : slot + 1;
+        if (++kt == KT) {
+            gemm_epilogue<1, EPI, 1>(p, acc, m0 + wave * 16, (nt0 + nt) * 64, 0, nt0 + nt, 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            kt = 0;
+            ++nt;
+        }
+    }
+}
+
+// blocks_target: how many workgroups to aim for (about the CU count); K <= 64 * kPanelKT
+template <int EPI, bool NORM, int NS>
+inline void gemm_xpanel_launch(GemmArgs p, int blocks_target, hipStream_t s) {
+    p.mblocks = (p.M + 63) / 64;
+    p.nblocks = (p.N + 63) / 64;
+    int tpb = (p.mblocks * p.nblocks + blocks_target - 1) / blocks_target;
+    if (tpb < 1) tpb = 1;
+    p.ntiles_per_block = tpb;
+    const int ngroups = (p.nblocks + tpb - 1) / tpb;
+    NTTS_LAUNCH((gemm_xpanel_kernel<EPI, NORM, NS>), dim3(p.mblocks * ngroups), dim3(256), s, p);
 }
 
 // ------------------------------------------------------------------------------------------------
