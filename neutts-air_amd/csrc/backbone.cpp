@@ -83,7 +83,7 @@ struct ntts_backbone {
     int head_stages = 2, l_stages = 2, pf_gh = 4, attn_depth = 3;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
     bool gu_large = false, head_large = true, pf_attn_simple = false;
     bool fused = true;        // decode step: RMSNorm fused into the QKV / gate-up GEMM prologues, residual into o_proj's epilogue
-    int n_cu = 256, xp_stages = 4;
+    int n_cu = 256, xp_stages = 8;
 
     // prefill workspaces
     int Tmax = 0;
@@ -248,7 +248,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->pf_attn_simple = env_int("NTTS_PREFILL_ATTN_SIMPLE", 0) != 0;
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e->fused = env_int("NTTS_FUSED", 1) != 0 && H <= 64 * kPanelKT && c->num_heads * 64 <= 64 * kPanelKT;
-    e->xp_stages = env_int("NTTS_XP_STAGES", 4);
+    e->xp_stages = env_int("NTTS_XP_STAGES", 8);
     e->pf_gh = env_int("NTTS_PF_GH", 4);
     e->attn_depth = env_int("NTTS_ATTN_DEPTH", 3);
     e->head_large = env_int("NTTS_HEAD_LARGE", B > 64 ? 1 : 0) != 0;
@@ -528,11 +528,11 @@ static void k_add_norm(ntts_backbone* e, int K, int ks, const bf16_t* norm_w, bf
 
 template <int EPI, bool NORM>
 static void gemm_xpanel(ntts_backbone* e, const GemmArgs& a) {
-    switch (e->xp_stages) {
-        case 2: gemm_xpanel_launch<EPI, NORM, 2>(a, e->n_cu, e->stream); break;
-        case 3: gemm_xpanel_launch<EPI, NORM, 3>(a, e->n_cu, e->stream); break;
-        case 6: gemm_xpanel_launch<EPI, NORM, 6>(a, e->n_cu, e->stream); break;
-        default: gemm_xpanel_launch<EPI, NORM, 4>(a, e->n_cu, e->stream); break;
+    switch (e->xp_stages) {   // depth of the per-wave W register ring (k-tiles in flight)
+        case 4: gemm_xpanel_launch<EPI, NORM, 4>(a, e->n_cu, e->stream); break;
+        case 12: gemm_xpanel_launch<EPI, NORM, 12>(a, e->n_cu, e->stream); break;
+        case 16: gemm_xpanel_launch<EPI, NORM, 16>(a, e->n_cu, e->stream); break;
+        default: gemm_xpanel_launch<EPI, NORM, 8>(a, e->n_cu, e->stream); break;
     }
 }
 

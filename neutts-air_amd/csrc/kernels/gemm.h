@@ -352,16 +352,17 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 //     out[M, N] = f(X)[M, K] * W[N, K]^T,   f = identity  or  RMSNorm (NORM: w * bf16(x * rsqrt(mean(x^2) + eps)))
 // A workgroup owns 64 rows of X.  It loads that 64 x K panel ONCE (through registers, so the RMSNorm of
 // hf:models/qwen2/modeling_qwen2.py:247-252 is applied on the way in: no separate norm kernel, no normalised copy of
-// the activations in HBM), keeps it in LDS in the k-tile-major swizzled image the MFMA loop reads, and then walks
-// `ntiles_per_block` 64-column tiles streaming only W through an NS-deep LDS-DMA ring that runs across tile
-// boundaries.  Compared with the 64x64 tile kernel this halves the bytes pulled through LDS per CU (the measured
-// limiter of the skinny decode GEMMs) and removes one launch per fused norm.
-// LDS: 14 panel k-tiles + NS ring slots of 8 KB (64 rows x 128 B), e.g. 144 KB at NS = 4: one workgroup per CU.
+// the activations in HBM) and keeps it in LDS in the k-tile-major swizzled image the MFMA loop reads.  W never
+// touches LDS: wave w of the workgroup owns 16 of the tile's 64 output features, so its W fragments are private
+// and are streamed HBM -> VGPR through a D-deep register ring (8 KB..24 KB in flight per wave; a first version that
+// staged W through an LDS-DMA ring had only 24 KB in flight per CU and ran at a third of this speed).  The main
+// loop has no barrier at all.  A workgroup walks `ntiles_per_block` 64-feature tiles; the ring runs across tiles.
+// D layout (A = W fragment): lane (g, l15) holds features 4g..4g+3 of the wave's 16 for token rt*16 + l15.
+// LDS: 14 panel k-tiles x 8 KB = 112 KB: one workgroup per CU.
 constexpr int kPanelKT = 14;
-template <int EPI, bool NORM, int NS>
+template <int EPI, bool NORM, int D>
 NTTS_KERNEL(256) void gemm_xpanel_kernel(GemmArgs p) {
-    static_assert(NS >= 2 && NS <= 6, "ring depth");
-    NTTS_SHARED bf16_t lds[(kPanelKT + NS) * 4096];
+    NTTS_SHARED bf16_t lds[kPanelKT * 4096];
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const int g = lane >> 4, l15 = lane & 15;
     const int KT = p.K >> 6;
@@ -377,26 +378,26 @@ NTTS_KERNEL(256) void gemm_xpanel_kernel(GemmArgs p) {
     if (ntl > p.ntiles_per_block) ntl = p.ntiles_per_block;
     if (ntl <= 0) return;                        // block-uniform
     const int total = ntl * KT;
-    bf16_t* ring = lds + kPanelKT * 4096;
 
-    // ---- W loader: 8 LDS-DMA instructions per 64 x 64 tile, 2 per wave
-    auto stage = [&](int f, int slot) {
-        const int nt = f / KT, kt = f - nt * KT;
-        const int n0 = (nt0 + nt) * 64;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int inst = wave + 4 * i;
-            const int q = inst * 8 + (lane >> 3);                 // tile-major W row (see gemm_kernel)
-            const int j = (q >> 4) & 3, i16 = q & 15;
-            int n = n0 + (i16 >> 2) * 16 + j * 4 + (i16 & 3);
-            if (n > p.N - 1) n = p.N - 1;
-            const int c = (lane & 7) ^ ((q >> 1) & 7);
-            glds16(p.W + (long)n * p.ldw + kt * 64 + c * 8, ring + slot * 4096 + inst * 512);
+    // ---- W stream of this wave: fragment rows (nt0 + nt) * 64 + wave * 16 + l15, 2 x 16 B per k-tile per lane
+    bf16x8 wq[D][2];
+    const bf16_t* wrow;                          // row of the tile being prefetched
+    int pf_nt = 0, pf_kt = 0;                    // (tile, k-tile) of the next prefetch
+    auto set_row = [&](int nt) {
+        int n = (nt0 + nt) * 64 + wave * 16 + l15;
+        if (n > p.N - 1) n = p.N - 1;
+        wrow = p.W + (long)n * p.ldw + g * 8;
+    };
+    auto prefetch = [&](bf16x8 (&dst)[2]) {      // always issues (a finished stream re-reads its last k-tile)
+        dst[0] = ld16<bf16x8>(wrow + pf_kt * 64);
+        dst[1] = ld16<bf16x8>(wrow + pf_kt * 64 + 32);
+        if (pf_nt * KT + pf_kt + 1 < total) {
+            if (++pf_kt == KT) { pf_kt = 0; set_row(++pf_nt); }
         }
     };
+    set_row(0);
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-        if (s < total) stage(s, s);              // W is on its way while the panel is built
+    for (int j = 0; j < D; ++j) prefetch(wq[j]);  // W is on its way while the panel is built
 
     // ---- X panel: thread = (row r, quarter q4); 16-byte chunks q4, q4 + 4, ... of the row
     {
@@ -443,58 +444,99 @@ NTTS_KERNEL(256) void gemm_xpanel_kernel(GemmArgs p) {
     }
     sync();
 
-    // ---- main loop over the flattened (column tile, k tile) sequence
-    const int xrow = wave * 16 + l15;
-    const int xoff = xrow * 64, xsw = (xrow >> 1) & 7;
-    int woff[4], wsw[4];
+    // ---- main loop over the flattened (feature tile, k tile) sequence: no barrier, the panel is read-only
+    int xoff[4], xsw[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int q = j * 16 + l15;
-        woff[j] = q * 64;
-        wsw[j] = (q >> 1) & 7;
+    for (int rt = 0; rt < 4; ++rt) {
+        const int r = rt * 16 + l15;
+        xoff[rt] = r * 64;
+        xsw[rt] = (r >> 1) & 7;
     }
-    f32x4 acc[1][4];
+    f32x4 acc[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int slot = 0, kt = 0, nt = 0;
-    for (int f = 0; f < total; ++f) {
-        // tile f must have landed; up to NS-2 younger tiles (and an epilogue's stores, retired in order) stay in flight
-        if (f + NS - 2 < total) wait_vmem_le<(NS - 2) * 2>(); else wait_vmem();
-        sync_keep_dma();
-        if (f + NS - 1 < total) stage(f + NS - 1, slot == 0 ? NS - 1 : slot - 1);
-        const bf16_t* xb = lds + kt * 4096;
-        const bf16_t* wb = ring + slot * 4096;
+    for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int kt = 0, nt = 0;
+    for (int f0 = 0; f0 < total; f0 += D) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int c = ks * 4 + g;
-            const bf16x8 xf = ld16<bf16x8>(xb + xoff + ((c ^ xsw) << 3));
-            bf16x8 wa[4];
+        for (int j = 0; j < D; ++j) {
+            if (f0 + j < total) {
+                const bf16x8 w0 = wq[j][0], w1 = wq[j][1];
+                prefetch(wq[j]);
+                const bf16_t* xb = lds + kt * 4096;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wa[j] = ld16<bf16x8>(wb + woff[j] + ((c ^ wsw[j]) << 3));
+                for (int rt = 0; rt < 4; ++rt) {
+                    acc[rt] = mfma16(w0, ld16<bf16x8>(xb + xoff[rt] + ((g ^ xsw[rt]) << 3)), acc[rt]);
+                    acc[rt] = mfma16(w1, ld16<bf16x8>(xb + xoff[rt] + (((4 + g) ^ xsw[rt]) << 3)), acc[rt]);
+                }
+                if (++kt == KT) {
+                    // ---- epilogue of feature tile nt: lane owns features nf..nf+3 of tokens m0 + rt*16 + l15
+                    const int nf = (nt0 + nt) * 64 + wave * 16 + g * 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[0][j] = mfma16(wa[j], xf, acc[0][j]);
-        }
-        slot = slot + 1 == NS ? 0 : slot + 1;
-        if (++kt == KT) {
-            gemm_epilogue<1, EPI, 1>(p, acc, m0 + wave * 16, (nt0 + nt) * 64, 0, nt0 + nt, 0);
+                    for (int rt = 0; rt < 4; ++rt) {
+                        const int m = m0 + rt * 16 + l15;
+                        const bool mok = m < p.M;
+                        if constexpr (EPI == EPI_SILU_MUL) {
+                            // packed rows (backbone.cpp gu_map): lanes g = 0,1 hold gate, g = 2,3 the up of the same features
+                            float up[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[0][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            kt = 0;
-            ++nt;
+                            for (int r = 0; r < 4; ++r) up[r] = shfl_xor(acc[rt][r], 32);
+                            if (g < 2 && mok) {
+                                alignas(8) bf16_t o[4];
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float gt = rbf(acc[rt][r]), u = rbf(up[r]);
+                                    o[r] = f2bf(rbf(silu_f(gt)) * u);
+                                }
+                                const int fb = (nt0 + nt) * 32 + wave * 8 + g * 4;
+                                if (fb + 4 <= (p.N >> 1)) *(u32x2*)((bf16_t*)p.out + (long)m * p.ldo + fb) = *(u32x2*)&o[0];
+                            }
+                        } else {
+                            if (mok) {
+                                alignas(8) bf16_t o[4];
+                                bf16_t* dst = (bf16_t*)p.out + (long)m * p.ldo + nf;
+                                const bf16_t* rs = nullptr;
+                                if constexpr (EPI == EPI_RESID) rs = p.resid_bf16 + (long)m * p.ldrb + nf;
+                                const bool full = nf + 4 <= p.N;
+                                alignas(8) bf16_t rr[4] = {0, 0, 0, 0};
+                                if constexpr (EPI == EPI_RESID) {
+                                    if (full) *(u32x2*)&rr[0] = *(const u32x2*)rs;
+                                    else
+                                        for (int r = 0; r < 4; ++r)
+                                            if (nf + r < p.N) rr[r] = rs[r];
+                                }
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const float lin = acc[rt][r] + (nf + r < p.N ? gemm_bias(p, nf + r) : 0.f);
+                                    if constexpr (EPI == EPI_RESID) o[r] = f2bf(bf2f(rr[r]) + rbf(lin));   // h + bf16(o_proj)
+                                    else o[r] = f2bf(lin);
+                                }
+                                if (full) *(u32x2*)dst = *(u32x2*)&o[0];
+                                else
+                                    for (int r = 0; r < 4; ++r)
+                                        if (nf + r < p.N) dst[r] = o[r];
+                            }
+                        }
+                        acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                    kt = 0;
+                    ++nt;
+                }
+            }
         }
     }
 }
 
 // blocks_target: how many workgroups to aim for (about the CU count); K <= 64 * kPanelKT
-template <int EPI, bool NORM, int NS>
+template <int EPI, bool NORM, int D>
 inline void gemm_xpanel_launch(GemmArgs p, int blocks_target, hipStream_t s) {
+    static_assert(EPI == EPI_BF16 || EPI == EPI_RESID || EPI == EPI_SILU_MUL, "epilogues of the X-panel kernel");
     p.mblocks = (p.M + 63) / 64;
     p.nblocks = (p.N + 63) / 64;
     int tpb = (p.mblocks * p.nblocks + blocks_target - 1) / blocks_target;
     if (tpb < 1) tpb = 1;
     p.ntiles_per_block = tpb;
     const int ngroups = (p.nblocks + tpb - 1) / tpb;
-    NTTS_LAUNCH((gemm_xpanel_kernel<EPI, NORM, NS>), dim3(p.mblocks * ngroups), dim3(256), s, p);
+    NTTS_LAUNCH((gemm_xpanel_kernel<EPI, NORM, D>), dim3(p.mblocks * ngroups), dim3(256), s, p);
 }
 
 // ------------------------------------------------------------------------------------------------
