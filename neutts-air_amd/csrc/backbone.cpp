@@ -83,7 +83,7 @@ struct ntts_backbone {
     int head_stages = 2, l_stages = 2, pf_gh = 4, attn_depth = 3;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
     bool gu_large = false, head_large = true, pf_attn_simple = false;
     bool fused = true;        // decode step: RMSNorm fused into the QKV / gate-up GEMM prologues, residual into o_proj's epilogue
-    int n_cu = 256, xp_stages = 8;
+    int n_cu = 256, xp_bpc = 1;
 
     // prefill workspaces
     int Tmax = 0;
@@ -247,8 +247,8 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->gu_large = env_int("NTTS_GU_LARGE", 0) != 0;
     e->pf_attn_simple = env_int("NTTS_PREFILL_ATTN_SIMPLE", 0) != 0;
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    e->fused = env_int("NTTS_FUSED", 1) != 0 && H <= 64 * kPanelKT && c->num_heads * 64 <= 64 * kPanelKT;
-    e->xp_stages = env_int("NTTS_XP_STAGES", 8);
+    e->fused = env_int("NTTS_FUSED", 1) != 0 && (H == 64 * 14 || H == 64 * 7) && c->num_heads * 64 == H;
+    e->xp_bpc = env_int("NTTS_XP_BPC", 1);
     e->pf_gh = env_int("NTTS_PF_GH", 4);
     e->attn_depth = env_int("NTTS_ATTN_DEPTH", 3);
     e->head_large = env_int("NTTS_HEAD_LARGE", B > 64 ? 1 : 0) != 0;
@@ -527,14 +527,7 @@ static void k_add_norm(ntts_backbone* e, int K, int ks, const bf16_t* norm_w, bf
 }
 
 template <int EPI, bool NORM>
-static void gemm_xpanel(ntts_backbone* e, const GemmArgs& a) {
-    switch (e->xp_stages) {   // depth of the per-wave W register ring (k-tiles in flight)
-        case 4: gemm_xpanel_launch<EPI, NORM, 4>(a, e->n_cu, e->stream); break;
-        case 12: gemm_xpanel_launch<EPI, NORM, 12>(a, e->n_cu, e->stream); break;
-        case 16: gemm_xpanel_launch<EPI, NORM, 16>(a, e->n_cu, e->stream); break;
-        default: gemm_xpanel_launch<EPI, NORM, 8>(a, e->n_cu, e->stream); break;
-    }
-}
+static void gemm_xpanel(ntts_backbone* e, const GemmArgs& a) { gemm_xpanel_launch<EPI, NORM>(a, e->n_cu * e->xp_bpc, e->stream); }
 
 // fused decode-layer GEMMs (gemm_xpanel_kernel): the residual stream h_dec is the only activation that round-trips
 static void kf_qkv(ntts_backbone* e, int i) {       // qkv = Linear(rmsnorm(h) * ln1) + bias

@@ -23,6 +23,7 @@
 //   * split-K (gridDim.y) writes fp32 slabs that the consumer kernel reduces (no in-launch hand-off).
 #pragma once
 #include <ntts/dev.h>
+#include <type_traits>
 
 namespace ntts {
 
@@ -354,18 +355,19 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 // hf:models/qwen2/modeling_qwen2.py:247-252 is applied on the way in: no separate norm kernel, no normalised copy of
 // the activations in HBM) and keeps it in LDS in the k-tile-major swizzled image the MFMA loop reads.  W never
 // touches LDS: wave w of the workgroup owns 16 of the tile's 64 output features, so its W fragments are private
-// and are streamed HBM -> VGPR through a D-deep register ring (8 KB..24 KB in flight per wave; a first version that
-// staged W through an LDS-DMA ring had only 24 KB in flight per CU and ran at a third of this speed).  The main
-// loop has no barrier at all.  A workgroup walks `ntiles_per_block` 64-feature tiles; the ring runs across tiles.
+// and are streamed HBM -> VGPR: the full K extent of the tile (28 KB per wave) is in flight, and the registers a
+// k-step frees are refilled with the next tile's W at once (a first version that staged W through an LDS-DMA ring
+// had only 24 KB in flight per CU and ran at a third of the speed).  The main loop has no barrier at all.
 // D layout (A = W fragment): lane (g, l15) holds features 4g..4g+3 of the wave's 16 for token rt*16 + l15.
 // LDS: 14 panel k-tiles x 8 KB = 112 KB: one workgroup per CU.
 constexpr int kPanelKT = 14;
-template <int EPI, bool NORM, int D>
+constexpr int kXpMaxTiles = 4;     // 64-feature tiles one workgroup may walk (fully unrolled)
+template <int EPI, bool NORM, int KT>
 NTTS_KERNEL(256) void gemm_xpanel_kernel(GemmArgs p) {
-    NTTS_SHARED bf16_t lds[kPanelKT * 4096];
+    static_assert(KT >= 1 && KT <= kPanelKT, "panel size");
+    NTTS_SHARED bf16_t lds[KT * 4096 + KT * 64];   // panel + the RMSNorm weight row
     const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const int g = lane >> 4, l15 = lane & 15;
-    const int KT = p.K >> 6;
     // grid = mblocks * ngroups; XCD-aware: consecutive logical ids (one XCD) are the m-blocks of one column group
     const int nblk = gridDim.x;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -377,27 +379,27 @@ NTTS_KERNEL(256) void gemm_xpanel_kernel(GemmArgs p) {
     int ntl = p.nblocks - nt0;
     if (ntl > p.ntiles_per_block) ntl = p.ntiles_per_block;
     if (ntl <= 0) return;                        // block-uniform
-    const int total = ntl * KT;
 
-    // ---- W stream of this wave: fragment rows (nt0 + nt) * 64 + wave * 16 + l15, 2 x 16 B per k-tile per lane
-    bf16x8 wq[D][2];
-    const bf16_t* wrow;                          // row of the tile being prefetched
-    int pf_nt = 0, pf_kt = 0;                    // (tile, k-tile) of the next prefetch
-    auto set_row = [&](int nt) {
+    // ---- W stream of this wave: the whole K extent of its 16 feature rows lives in registers (KT x 32 B per lane);
+    //      while tile nt is consumed k-tile by k-tile, the freed registers are refilled with tile nt+1
+    bf16x8 wq[2][KT][2];                         // ping-pong register sets, statically indexed
+    auto w_ptr = [&](int nt) {
         int n = (nt0 + nt) * 64 + wave * 16 + l15;
         if (n > p.N - 1) n = p.N - 1;
-        wrow = p.W + (long)n * p.ldw + g * 8;
+        return p.W + (long)n * p.ldw + g * 8;
     };
-    auto prefetch = [&](bf16x8 (&dst)[2]) {      // always issues (a finished stream re-reads its last k-tile)
-        dst[0] = ld16<bf16x8>(wrow + pf_kt * 64);
-        dst[1] = ld16<bf16x8>(wrow + pf_kt * 64 + 32);
-        if (pf_nt * KT + pf_kt + 1 < total) {
-            if (++pf_kt == KT) { pf_kt = 0; set_row(++pf_nt); }
-        }
-    };
-    set_row(0);
+    {
+        const bf16_t* wr = w_ptr(0);
 #pragma unroll
-    for (int j = 0; j < D; ++j) prefetch(wq[j]);  // W is on its way while the panel is built
+        for (int kt = 0; kt < KT; ++kt) {        // W is on its way while the panel is built
+            wq[0][kt][0] = ld16<bf16x8>(wr + kt * 64);
+            wq[0][kt][1] = ld16<bf16x8>(wr + kt * 64 + 32);
+        }
+    }
+    bf16_t* nw_lds = lds + KT * 4096;
+    if constexpr (NORM) {                        // norm weight row -> LDS (read back per chunk without vmem waits)
+        if (tid < KT * 8) *(bf16x8*)(nw_lds + tid * 8) = ld16<bf16x8>(p.norm_w + tid * 8);
+    }
 
     // ---- X panel: thread = (row r, quarter q4); 16-byte chunks q4, q4 + 4, ... of the row
     {
@@ -405,46 +407,39 @@ NTTS_KERNEL(256) void gemm_xpanel_kernel(GemmArgs p) {
         int m = m0 + r;
         if (m > p.M - 1) m = p.M - 1;
         const bf16_t* xr = p.X + (long)m * p.ldx;
-        const int nch = p.K >> 3;
-        constexpr int MAXJ = kPanelKT * 8 / 4;   // 28
-        bf16x8 xv[MAXJ];
+        constexpr int NJ = KT * 2;               // 16-byte chunks per thread
+        bf16x8 xv[NJ];
         float ss = 0.f;
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
-            const int c = q4 + 4 * j;
-            if (c < nch) {
-                xv[j] = ld16<bf16x8>(xr + c * 8);
-                if constexpr (NORM) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) { const float f = bf2f((bf16_t)xv[j][e]); ss += f * f; }
-                }
-            }
-        }
+        for (int j = 0; j < NJ; ++j) xv[j] = ld16<bf16x8>(xr + (q4 + 4 * j) * 8);
         float inv = 1.f;
         if constexpr (NORM) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = bf2f((bf16_t)xv[j][e]); ss += f * f; }
             ss += shfl_xor(ss, 1);
             ss += shfl_xor(ss, 2);
-            inv = frsqrt_exact(ss / (float)p.K + p.norm_eps);
+            inv = frsqrt_exact(ss / (float)(KT * 64) + p.norm_eps);
+            sync();                              // nw_lds visible
         }
 #pragma unroll
-        for (int j = 0; j < MAXJ; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int c = q4 + 4 * j;
-            if (c < nch) {
-                bf16x8 y = xv[j];
-                if constexpr (NORM) {
-                    const bf16x8 wv = ld16<bf16x8>(p.norm_w + c * 8);
+            bf16x8 y = xv[j];
+            if constexpr (NORM) {
+                const bf16x8 wv = ld16<bf16x8>(nw_lds + c * 8);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        y[e] = (short)f2bf(bf2f((bf16_t)wv[e]) * rbf(bf2f((bf16_t)xv[j][e]) * inv));
-                }
-                const int kt = c >> 3, cc = c & 7;
-                *(bf16x8*)(lds + kt * 4096 + r * 64 + ((cc ^ ((r >> 1) & 7)) << 3)) = y;
+                for (int e = 0; e < 8; ++e)
+                    y[e] = (short)f2bf(bf2f((bf16_t)wv[e]) * rbf(bf2f((bf16_t)xv[j][e]) * inv));
             }
+            const int kt = c >> 3, cc = c & 7;
+            *(bf16x8*)(lds + kt * 4096 + r * 64 + ((cc ^ ((r >> 1) & 7)) << 3)) = y;
         }
     }
     sync();
 
-    // ---- main loop over the flattened (feature tile, k tile) sequence: no barrier, the panel is read-only
+    // ---- main loop: no barrier, the panel is read-only
     int xoff[4], xsw[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
@@ -452,91 +447,111 @@ NTTS_KERNEL(256) void gemm_xpanel_kernel(GemmArgs p) {
         xoff[rt] = r * 64;
         xsw[rt] = (r >> 1) & 7;
     }
-    f32x4 acc[4];
+    // One 64-feature tile: consume set `cur` k-step by k-step; with MORE, refill the other set with the next tile.
+    // Tiles are fully unrolled (kXpMaxTiles) so every W register is statically named and hipcc's counted vmcnt
+    // waits keep the whole next tile in flight (a rolled loop made it drain the stream at every back-edge).
+    auto tile = [&](auto cur_c, auto more_c, int nt) {
+        constexpr int CUR = decltype(cur_c)::value;
+        constexpr bool MORE = decltype(more_c)::value;
+        f32x4 acc[4];
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int kt = 0, nt = 0;
-    for (int f0 = 0; f0 < total; f0 += D) {
+        for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bf16_t* wnext = w_ptr(nt + (MORE ? 1 : 0));
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-            if (f0 + j < total) {
-                const bf16x8 w0 = wq[j][0], w1 = wq[j][1];
-                prefetch(wq[j]);
-                const bf16_t* xb = lds + kt * 4096;
+        for (int kt = 0; kt < KT; ++kt) {
+            if constexpr (MORE) {
+                wq[CUR ^ 1][kt][0] = ld16<bf16x8>(wnext + kt * 64);
+                wq[CUR ^ 1][kt][1] = ld16<bf16x8>(wnext + kt * 64 + 32);
+            }
+            const bf16_t* xb = lds + kt * 4096;
 #pragma unroll
-                for (int rt = 0; rt < 4; ++rt) {
-                    acc[rt] = mfma16(w0, ld16<bf16x8>(xb + xoff[rt] + ((g ^ xsw[rt]) << 3)), acc[rt]);
-                    acc[rt] = mfma16(w1, ld16<bf16x8>(xb + xoff[rt] + (((4 + g) ^ xsw[rt]) << 3)), acc[rt]);
-                }
-                if (++kt == KT) {
-                    // ---- epilogue of feature tile nt: lane owns features nf..nf+3 of tokens m0 + rt*16 + l15
-                    const int nf = (nt0 + nt) * 64 + wave * 16 + g * 4;
+            for (int rt = 0; rt < 4; ++rt) {
+                acc[rt] = mfma16(wq[CUR][kt][0], ld16<bf16x8>(xb + xoff[rt] + ((g ^ xsw[rt]) << 3)), acc[rt]);
+                acc[rt] = mfma16(wq[CUR][kt][1], ld16<bf16x8>(xb + xoff[rt] + (((4 + g) ^ xsw[rt]) << 3)), acc[rt]);
+            }
+        }
+        // ---- epilogue of feature tile nt: lane owns features nf..nf+3 of tokens m0 + rt*16 + l15
+        const int nf = (nt0 + nt) * 64 + wave * 16 + g * 4;
+        float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (EPI != EPI_SILU_MUL) {
 #pragma unroll
-                    for (int rt = 0; rt < 4; ++rt) {
-                        const int m = m0 + rt * 16 + l15;
-                        const bool mok = m < p.M;
-                        if constexpr (EPI == EPI_SILU_MUL) {
-                            // packed rows (backbone.cpp gu_map): lanes g = 0,1 hold gate, g = 2,3 the up of the same features
-                            float up[4];
+            for (int r = 0; r < 4; ++r)
+                if (nf + r < p.N) bias4[r] = gemm_bias(p, nf + r);
+        }
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) up[r] = shfl_xor(acc[rt][r], 32);
-                            if (g < 2 && mok) {
-                                alignas(8) bf16_t o[4];
+        for (int rt = 0; rt < 4; ++rt) {
+            const int m = m0 + rt * 16 + l15;
+            const bool mok = m < p.M;
+            if constexpr (EPI == EPI_SILU_MUL) {
+                // packed rows (backbone.cpp gu_map): lanes g = 0,1 hold gate, g = 2,3 the up of the same features
+                float up[4];
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const float gt = rbf(acc[rt][r]), u = rbf(up[r]);
-                                    o[r] = f2bf(rbf(silu_f(gt)) * u);
-                                }
-                                const int fb = (nt0 + nt) * 32 + wave * 8 + g * 4;
-                                if (fb + 4 <= (p.N >> 1)) *(u32x2*)((bf16_t*)p.out + (long)m * p.ldo + fb) = *(u32x2*)&o[0];
-                            }
-                        } else {
-                            if (mok) {
-                                alignas(8) bf16_t o[4];
-                                bf16_t* dst = (bf16_t*)p.out + (long)m * p.ldo + nf;
-                                const bf16_t* rs = nullptr;
-                                if constexpr (EPI == EPI_RESID) rs = p.resid_bf16 + (long)m * p.ldrb + nf;
-                                const bool full = nf + 4 <= p.N;
-                                alignas(8) bf16_t rr[4] = {0, 0, 0, 0};
-                                if constexpr (EPI == EPI_RESID) {
-                                    if (full) *(u32x2*)&rr[0] = *(const u32x2*)rs;
-                                    else
-                                        for (int r = 0; r < 4; ++r)
-                                            if (nf + r < p.N) rr[r] = rs[r];
-                                }
+                for (int r = 0; r < 4; ++r) up[r] = shfl_xor(acc[rt][r], 32);
+                if (g < 2 && mok) {
+                    alignas(8) bf16_t o[4];
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const float lin = acc[rt][r] + (nf + r < p.N ? gemm_bias(p, nf + r) : 0.f);
-                                    if constexpr (EPI == EPI_RESID) o[r] = f2bf(bf2f(rr[r]) + rbf(lin));   // h + bf16(o_proj)
-                                    else o[r] = f2bf(lin);
-                                }
-                                if (full) *(u32x2*)dst = *(u32x2*)&o[0];
-                                else
-                                    for (int r = 0; r < 4; ++r)
-                                        if (nf + r < p.N) dst[r] = o[r];
-                            }
-                        }
-                        acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    for (int r = 0; r < 4; ++r) {
+                        const float gt = rbf(acc[rt][r]), u = rbf(up[r]);
+                        o[r] = f2bf(rbf(silu_f(gt)) * u);
                     }
-                    kt = 0;
-                    ++nt;
+                    const int fb = (nt0 + nt) * 32 + wave * 8 + g * 4;
+                    if (fb + 4 <= (p.N >> 1)) *(u32x2*)((bf16_t*)p.out + (long)m * p.ldo + fb) = *(u32x2*)&o[0];
+                }
+            } else {
+                if (mok) {
+                    alignas(8) bf16_t o[4];
+                    bf16_t* dst = (bf16_t*)p.out + (long)m * p.ldo + nf;
+                    const bool full = nf + 4 <= p.N;
+                    alignas(8) bf16_t rr[4] = {0, 0, 0, 0};
+                    if constexpr (EPI == EPI_RESID) {
+                        const bf16_t* rs = p.resid_bf16 + (long)m * p.ldrb + nf;
+                        if (full) *(u32x2*)&rr[0] = *(const u32x2*)rs;
+                        else
+                            for (int r = 0; r < 4; ++r)
+                                if (nf + r < p.N) rr[r] = rs[r];
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float lin = acc[rt][r] + bias4[r];
+                        if constexpr (EPI == EPI_RESID) o[r] = f2bf(bf2f(rr[r]) + rbf(lin));   // h + bf16(o_proj)
+                        else o[r] = f2bf(lin);
+                    }
+                    if (full) *(u32x2*)dst = *(u32x2*)&o[0];
+                    else
+                        for (int r = 0; r < 4; ++r)
+                            if (nf + r < p.N) dst[r] = o[r];
                 }
             }
         }
-    }
+    };
+    using T0 = std::integral_constant<int, 0>;
+    using T1 = std::integral_constant<int, 1>;
+    using Yes = std::integral_constant<bool, true>;
+    using No = std::integral_constant<bool, false>;
+    static_assert(kXpMaxTiles == 4, "unrolled below");
+    if (ntl > 1) tile(T0{}, Yes{}, 0); else { tile(T0{}, No{}, 0); return; }
+    if (ntl > 2) tile(T1{}, Yes{}, 1); else { tile(T1{}, No{}, 1); return; }
+    if (ntl > 3) tile(T0{}, Yes{}, 2); else { tile(T0{}, No{}, 2); return; }
+    tile(T1{}, No{}, 3);
 }
 
-// blocks_target: how many workgroups to aim for (about the CU count); K <= 64 * kPanelKT
-template <int EPI, bool NORM, int D>
-inline void gemm_xpanel_launch(GemmArgs p, int blocks_target, hipStream_t s) {
+// blocks_target: how many workgroups to aim for (about the CU count).  K must be 64 * 7 or 64 * 14 (the panel is a
+// compile-time size so the W register file is statically indexed); returns false otherwise.
+template <int EPI, bool NORM>
+inline bool gemm_xpanel_launch(GemmArgs p, int blocks_target, hipStream_t s) {
     static_assert(EPI == EPI_BF16 || EPI == EPI_RESID || EPI == EPI_SILU_MUL, "epilogues of the X-panel kernel");
     p.mblocks = (p.M + 63) / 64;
     p.nblocks = (p.N + 63) / 64;
     int tpb = (p.mblocks * p.nblocks + blocks_target - 1) / blocks_target;
     if (tpb < 1) tpb = 1;
+    if (tpb > kXpMaxTiles) tpb = kXpMaxTiles;
     p.ntiles_per_block = tpb;
     const int ngroups = (p.nblocks + tpb - 1) / tpb;
-    NTTS_LAUNCH((gemm_xpanel_kernel<EPI, NORM, D>), dim3(p.mblocks * ngroups), dim3(256), s, p);
+    const dim3 grid(p.mblocks * ngroups), block(256);
+    if (p.K == 64 * 14) NTTS_LAUNCH((gemm_xpanel_kernel<EPI, NORM, 14>), grid, block, s, p);
+    else if (p.K == 64 * 7) NTTS_LAUNCH((gemm_xpanel_kernel<EPI, NORM, 7>), grid, block, s, p);
+    else return false;
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------
