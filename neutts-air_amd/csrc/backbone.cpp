@@ -80,9 +80,12 @@ struct ntts_backbone {
     bool graph_has_logits = false;
     int ks_o = 1, ks_d = 1;
     int st_qkv = 4, st_o = 4, st_gu = 3, st_d = 4;   // LDS ring depth of each skinny decode GEMM
-    int head_stages = 2, l_stages = 2, pf_gh = 4, attn_depth = 3;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
+    int head_stages = 2, l_stages = 2, pf_gh = 4, attn_depth = 1;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
     bool gu_large = false, head_large = true, pf_attn_simple = false;
-    bool fused = true;        // decode step: RMSNorm fused into the QKV / gate-up GEMM prologues, residual into o_proj's epilogue
+    // EXPERIMENTAL (off): RMSNorm fused into the QKV / gate-up GEMM prologues, residual into o_proj's epilogue
+    // (gemm_xpanel_kernel).  Parity-clean but slower on MI355X at batch 256: one 4-wave workgroup per CU cannot
+    // overlap its LDS-read -> MFMA chains (2.33 vs 1.95 ms per step), see DESIGN.md.
+    bool fused = false;
     int n_cu = 256, xp_bpc = 1;
 
     // prefill workspaces
@@ -247,10 +250,10 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->gu_large = env_int("NTTS_GU_LARGE", 0) != 0;
     e->pf_attn_simple = env_int("NTTS_PREFILL_ATTN_SIMPLE", 0) != 0;
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    e->fused = env_int("NTTS_FUSED", 1) != 0 && (H == 64 * 14 || H == 64 * 7) && c->num_heads * 64 == H;
+    e->fused = env_int("NTTS_FUSED", 0) != 0 && (H == 64 * 14 || H == 64 * 7) && c->num_heads * 64 == H;
     e->xp_bpc = env_int("NTTS_XP_BPC", 1);
     e->pf_gh = env_int("NTTS_PF_GH", 4);
-    e->attn_depth = env_int("NTTS_ATTN_DEPTH", 3);
+    e->attn_depth = env_int("NTTS_ATTN_DEPTH", 1);
     e->head_large = env_int("NTTS_HEAD_LARGE", B > 64 ? 1 : 0) != 0;
     const int max_slabs = 16;
     if (e->ks_o > max_slabs) e->ks_o = max_slabs;

@@ -25,7 +25,7 @@ constexpr int kAttnLMax = 2048;  // ref:neutts/neutts.py:85 max_context
 // slot of token t (0..31) inside a V^T page row: [0-3,16-19 | 4-7,20-23 | 8-11,24-27 | 12-15,28-31]
 NTTS_HD int v_slot(int t) { return ((t & 15) >> 2) * 8 + (t >> 4) * 4 + (t & 3); }
 constexpr int kGroupMax = 8;     // query heads per kv head handled by one workgroup
-constexpr int kAttnDepthDefault = 3;  // KV pages each wave keeps in flight (register ring)
+constexpr int kAttnDepthDefault = 1;  // KV pages each wave keeps in flight (register ring)
 
 struct AttnDecodeArgs {
     const bf16_t* qkv;     // [B][ld_qkv]: q heads | k heads | v heads, bias already added

@@ -23,7 +23,24 @@ def probe(M, N, K, cfg, abl, copies, iters=200):
     return us.value if rc == 0 else float("nan")
 
 
+PREFILL = {"pf_qkv": (32000, 1152, 896), "pf_gate_up": (32000, 9728, 896), "pf_down": (32000, 896, 4864),
+           "codec_fc1": (65536, 4096, 1024)}
+
+
+def prefill():
+    for name, (M, N, K) in PREFILL.items():
+        fl = 2.0 * M * N * K
+        print(f"== {name}  M={M} N={N} K={K}  {fl / 1e12:.2f} TFLOP")
+        print(f"{'config':18s} {'us':>9s} {'TF/s':>7s} | ablations us: {'noMFMA':>9s} {'noDMA':>9s} {'neither':>9s} {'noStore':>9s}")
+        for cfg in (30, 31, 23, 24, 25, 26):
+            t = probe(M, N, K, cfg, 0, 1, iters=5)
+            ab = [probe(M, N, K, cfg, a, 1, iters=5) for a in (1, 2, 3, 4)]
+            print(f"{CONFIGS[cfg]:18s} {t:9.1f} {fl / t / 1e6:7.0f} | {'':14s} {ab[0]:9.1f} {ab[1]:9.1f} {ab[2]:9.1f} {ab[3]:9.1f}", flush=True)
+
+
 def main():
+    if "--prefill" in sys.argv:
+        return prefill()
     print(f"empty kernel: {probe(64, 64, 64, 0, 0, 1):.2f} us/launch")
     for name, (M, N, K) in SHAPES.items():
         wbytes = N * K * 2
