@@ -204,7 +204,7 @@ int ntts_codec_last_timing(ntts_codec* c, float* ms);
 /* DEVICE pointers, bf16 unless noted, row-major; run on the NULL stream and block).           */
 /* ------------------------------------------------------------------------------------------ */
 /* C[M,N] = A[M,K] (lda) * W[N,K]^T (+ bias[N]); fp32 accumulate on MFMA, one RNE rounding to bf16.
- * variant: 0 = auto, otherwise a specific tile configuration (see csrc/gemm.h). */
+ * variant: 0 = auto, 1 = 128x128 tile, 2 = 64x64 tile, 3 = 64x64 split-K slabs + reduce, 4 = 256x256 tile. */
 int ntts_k_gemm_bf16(const void* A, int64_t lda, const void* W, const void* bias, void* C, int64_t ldc,
                      int32_t M, int32_t N, int32_t K, int32_t variant);
 /* y = rmsnorm(x) * w with Qwen2RMSNorm's rounding (hf:models/qwen2/modeling_qwen2.py:247-252). */

@@ -81,7 +81,7 @@ struct ntts_backbone {
     int ks_o = 1, ks_d = 1;
     int st_qkv = 4, st_o = 4, st_gu = 3, st_d = 4;   // LDS ring depth of each skinny decode GEMM
     int head_stages = 2, l_stages = 2, pf_gh = 4, attn_depth = 1;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
-    bool gu_large = false, head_large = true, pf_attn_simple = false;
+    bool gu_large = false, head_large = true, pf_attn_simple = false, use_xl = true, head_xl = false;
     // EXPERIMENTAL (off): RMSNorm fused into the QKV / gate-up GEMM prologues, residual into o_proj's epilogue
     // (gemm_xpanel_kernel).  Parity-clean but slower on MI355X at batch 256: one 4-wave workgroup per CU cannot
     // overlap its LDS-read -> MFMA chains (2.33 vs 1.95 ms per step), see DESIGN.md.
@@ -249,6 +249,8 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->l_stages = env_int("NTTS_L_STAGES", 2);
     e->gu_large = env_int("NTTS_GU_LARGE", 0) != 0;
     e->pf_attn_simple = env_int("NTTS_PREFILL_ATTN_SIMPLE", 0) != 0;
+    e->use_xl = env_int("NTTS_XL", 1) != 0;
+    e->head_xl = env_int("NTTS_HEAD_XL", 0) != 0;
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e->fused = env_int("NTTS_FUSED", 0) != 0 && (H == 64 * 14 || H == 64 * 7) && c->num_heads * 64 == H;
     e->xp_bpc = env_int("NTTS_XP_BPC", 1);
@@ -259,7 +261,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     if (e->ks_o > max_slabs) e->ks_o = max_slabs;
     if (e->ks_d > max_slabs) e->ks_d = max_slabs;
 
-    e->n_part = e->head_large ? ((V + 127) / 128) * 2 : (V + 63) / 64;
+    e->n_part = e->head_xl ? ((V + 255) / 256) * 4 : e->head_large ? ((V + 127) / 128) * 2 : (V + 63) / 64;
     CR_HIP(hipMalloc((void**)&e->h_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->xn_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->qkv_dec, (size_t)B * e->NQKV * 2));
@@ -460,6 +462,7 @@ static void gemm_skinny(int stages, const GemmArgs& a, int ks, hipStream_t st) {
 
 template <int EPI>
 static void gemm_large(ntts_backbone* e, const GemmArgs& a, hipStream_t st) {
+    if (e->use_xl && a.M >= 1024 && a.N >= 256) { NTTS_GEMM_XL(EPI, a, 1, st); return; }
     switch (e->l_stages) {
         case 3: gemm_launch<2, 2, 4, EPI, 3>(a, 1, st); break;
         case 4: gemm_launch<2, 2, 4, EPI, 4>(a, 1, st); break;
@@ -474,6 +477,7 @@ static void k_lm_head(ntts_backbone* e, bool keep_logits) {
     a.logits = keep_logits ? e->logits : nullptr; a.ld_logits = V;
     a.logits_bf16 = (keep_logits && e->n_sampling > 0) ? e->logits_bf16 : nullptr; a.ld_logits_bf16 = e->ldl;
     if (!e->head_large) { gemm_skinny<EPI_ARGMAX>(4, a, 1, e->stream); return; }
+    if (e->head_xl) { NTTS_GEMM_XL(EPI_ARGMAX, a, 1, e->stream); return; }
     switch (e->head_stages) {
         case 3: gemm_launch<2, 2, 4, EPI_ARGMAX, 3>(a, 1, e->stream); break;
         case 4: gemm_launch<2, 2, 4, EPI_ARGMAX, 4>(a, 1, e->stream); break;

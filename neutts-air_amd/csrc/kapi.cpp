@@ -17,6 +17,7 @@ extern "C" int ntts_k_gemm_bf16(const void* A, int64_t lda, const void* W, const
     if (variant == 0) variant = M > 64 ? 1 : 2;
     if (variant == 1) NTTS_GEMM_L(EPI_BF16, a, 1, (hipStream_t)0);
     else if (variant == 2) NTTS_GEMM_S(EPI_BF16, a, 1, (hipStream_t)0);
+    else if (variant == 4) NTTS_GEMM_XL(EPI_BF16, a, 1, (hipStream_t)0);
     else if (variant == 3) {  // split-K slabs reduced by the norm kernel (the decode o_proj / down_proj path)
         if (bias || (N % 16) || ldc != N) return NTTS_EINVAL;
         const int ks = 4, ns = gemm_nsplit(K, ks);
@@ -116,6 +117,11 @@ extern "C" int ntts_k_gemm_probe(int32_t M, int32_t N, int32_t K, int32_t config
             case 26: probe_launch<4, 1, 2, 3>(a, 1, abl); break;   // 128 x 64, 4 waves
             case 30: probe_launch<2, 2, 4, 2>(a, 1, abl); break;   // 128 x 128, 4 waves (prefill tile)
             case 31: probe_launch<2, 2, 4, 3>(a, 1, abl); break;
+            case 40: probe_launch<4, 2, 4, 2>(a, 1, abl); break;   // 256 x 128, 8 waves
+            case 41: probe_launch<2, 4, 4, 2>(a, 1, abl); break;   // 128 x 256, 8 waves
+            case 42: probe_launch<4, 4, 4, 2>(a, 1, abl); break;   // 256 x 256, 16 waves
+            case 43: probe_launch<4, 2, 4, 3>(a, 1, abl); break;   // 256 x 128, 8 waves, 3 stages (144 KB)
+            case 44: probe_launch<2, 2, 8, 2>(a, 1, abl); break;   // 256 x 128, 4 waves (128 x 64 per wave)
             default: break;
         }
     };

@@ -573,8 +573,14 @@ inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
     NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL>), dim3(p.mblocks * p.nblocks, nsplit), dim3(WM * WN * 64), s, p);
 }
 
-// tile families:  L = 128x128 (2x2 waves, 64x64 per wave)  -- prefill, lm_head, gate/up, codec
+// tile families:  XL = 256x256 (4x4 waves = 1024 threads, 64x64 per wave, 128 KB LDS) -- big-M GEMMs (prefill, codec):
+//                      half the bytes through LDS per FLOP of the L tile; measured 1.13-1.19 vs 0.89-0.96 PFLOP/s
+//                      (profiles/r01_ubench_prefill.txt), the per-CU LDS-DMA fill rate being the limiter
+//                 L = 128x128 (2x2 waves, 64x64 per wave)  -- medium M, lm_head
 //                 S = 64x64   (4x1 waves, 16x64 per wave)  -- decode-batch skinny GEMMs (+ split-K)
+#define NTTS_GEMM_XL(EPI, p, ks, s) ::ntts::gemm_launch<4, 4, 4, EPI, 2>(p, ks, s)
+// big-M dispatch used by the prefill and codec paths
+#define NTTS_GEMM_BIG(EPI, p, s) do { if ((p).M >= 1024 && (p).N >= 256) NTTS_GEMM_XL(EPI, p, 1, s); else NTTS_GEMM_L(EPI, p, 1, s); } while (0)
 #define NTTS_GEMM_L(EPI, p, ks, s) ::ntts::gemm_launch<2, 2, 4, EPI, 2>(p, ks, s)
 #define NTTS_GEMM_S(EPI, p, ks, s) ::ntts::gemm_launch<4, 1, 1, EPI, 4>(p, ks, s)
 

@@ -31,6 +31,7 @@ GEMM_CASES = [  # (M, N, K, variant, bias)
     (5, 64, 64, 2, True),        # S tile, tiny M
     (100, 176, 256, 2, True),    # S tile, ragged
     (37, 64, 448, 3, False),     # S tile split-K + slab reduce
+    (300, 272, 128, 4, True),    # XL tile (256 x 256, 16 waves), ragged M and N
 ]
 
 

@@ -31,6 +31,8 @@ BIG = [  # the decode-batch and prefill shapes of NeuTTS-Air
     (256, 896, 4864, 3, False),   # down_proj, split-K
     (500, 1152, 896, 1, True),    # prefill QKV, L tile, ragged M
     (1000, 2048, 1024, 1, True),  # codec-like
+    (1500, 1152, 896, 4, True),   # XL tile (256 x 256, 1024 threads): prefill QKV, ragged M
+    (3000, 896, 4864, 4, False),  # XL tile: prefill down_proj, N not a multiple of 256
 ]
 
 

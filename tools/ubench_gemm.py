@@ -14,7 +14,8 @@ lib = _hip.load_library()
 SHAPES = {"qkv": (256, 1152, 896), "o": (256, 896, 896), "gate_up": (256, 9728, 896), "down": (256, 896, 4864)}
 CONFIGS = {10: "64x64 4w NS2", 11: "64x64 4w NS3", 12: "64x64 4w NS4", 13: "64x64 4w NS6", 20: "32x64 2w NS4",
            21: "64x64 2w NS4", 22: "64x64 1w NS4", 23: "64x128 4w NS3", 24: "64x128 8w NS3", 25: "128x64 8w NS3",
-           26: "128x64 4w NS3", 30: "128x128 4w NS2", 31: "128x128 4w NS3"}
+           26: "128x64 4w NS3", 30: "128x128 4w NS2", 31: "128x128 4w NS3", 40: "256x128 8w NS2", 41: "128x256 8w NS2",
+           42: "256x256 16w NS2", 43: "256x128 8w NS3", 44: "256x128 4w NS2"}
 
 
 def probe(M, N, K, cfg, abl, copies, iters=200):
@@ -32,7 +33,7 @@ def prefill():
         fl = 2.0 * M * N * K
         print(f"== {name}  M={M} N={N} K={K}  {fl / 1e12:.2f} TFLOP")
         print(f"{'config':18s} {'us':>9s} {'TF/s':>7s} | ablations us: {'noMFMA':>9s} {'noDMA':>9s} {'neither':>9s} {'noStore':>9s}")
-        for cfg in (30, 31, 23, 24, 25, 26):
+        for cfg in (30, 40, 41, 42, 43, 44):
             t = probe(M, N, K, cfg, 0, 1, iters=5)
             ab = [probe(M, N, K, cfg, a, 1, iters=5) for a in (1, 2, 3, 4)]
             print(f"{CONFIGS[cfg]:18s} {t:9.1f} {fl / t / 1e6:7.0f} | {'':14s} {ab[0]:9.1f} {ab[1]:9.1f} {ab[2]:9.1f} {ab[3]:9.1f}", flush=True)
@@ -48,6 +49,8 @@ def main():
         print(f"== {name}  M={M} N={N} K={K}  W={wbytes / 1e6:.2f} MB  cold copies={cold}")
         print(f"{'config':18s} {'warm':>8s} {'cold':>8s} | cold ablations: {'noMFMA':>8s} {'noDMA':>8s} {'neither':>8s} {'noStore':>8s}")
         for cfg, label in CONFIGS.items():
+            if cfg >= 40:
+                continue
             warm = probe(M, N, K, cfg, 0, 1)
             c0 = probe(M, N, K, cfg, 0, cold)
             ab = [probe(M, N, K, cfg, a, cold) for a in (1, 2, 3, 4)]
