@@ -250,7 +250,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->gu_large = env_int("NTTS_GU_LARGE", 0) != 0;
     e->pf_attn_simple = env_int("NTTS_PREFILL_ATTN_SIMPLE", 0) != 0;
     e->use_xl = env_int("NTTS_XL", 1) != 0;
-    e->head_xl = env_int("NTTS_HEAD_XL", 0) != 0;
+    e->head_xl = env_int("NTTS_HEAD_XL", B > 128 ? 1 : 0) != 0;
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e->fused = env_int("NTTS_FUSED", 0) != 0 && (H == 64 * 14 || H == 64 * 7) && c->num_heads * 64 == H;
     e->xp_bpc = env_int("NTTS_XP_BPC", 1);

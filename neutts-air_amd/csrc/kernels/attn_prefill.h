@@ -9,6 +9,7 @@
 // the rope kernel just wrote (L2/MALL resident), so prefill exercises exactly the layout decode reads.
 #pragma once
 #include <ntts/dev.h>
+#include <type_traits>
 #include "attn_decode.h"
 
 namespace ntts {
@@ -264,7 +265,12 @@ NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
             kf[u][1] = ld16<bf16x8>(kb + r * 64 + (((2 * g + 1) ^ (r & 7)) << 3));
         }
     };
-    auto scores = [&](const bf16x8 (&kf)[2][2], int h, int pg, float (&sc)[8]) {
+    // scores of one head against one page.  bf16(QK^T) * scaling: the product by 2^-3 is exact, one rounding suffices.
+    // MASKED pages (those reaching past the wave's first query) apply the causal mask with a large finite value so the
+    // fast exp never sees an infinity; pages entirely below the diagonal skip the compare/select.
+    constexpr float kMasked = -1.0e30f;
+    auto scores = [&](const bf16x8 (&kf)[2][2], int h, int pg, float (&sc)[8], auto masked_c) {
+        constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
@@ -272,18 +278,36 @@ NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
             a = mfma16(kf[u][1], qB[h][1], a);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int key = pg * kPage + u * 16 + g * 4 + r;
-                float v = rbf(rbf(a[r]) * 0.125f);
-                if (key > qpos) v = -INFINITY;                 // causal (covers key >= S as qpos <= S-1)
+                float v = rbf(a[r]) * 0.125f;
+                if constexpr (MASKED) {
+                    const int key = pg * kPage + u * 16 + g * 4 + r;
+                    if (key > qpos) v = kMasked;               // causal (covers key >= S as qpos <= S-1)
+                }
                 sc[u * 4 + r] = v;
             }
         }
     };
+    using Masked = std::integral_constant<bool, true>;
+    using Clear = std::integral_constant<bool, false>;
 
     // ---- sweep 1: row max and softmax denominator per head (online, lane-local; merged across key groups after)
     float m[GH], sum[GH];
 #pragma unroll
-    for (int h = 0; h < GH; ++h) { m[h] = -INFINITY; sum[h] = 0.f; }
+    for (int h = 0; h < GH; ++h) { m[h] = kMasked; sum[h] = 0.f; }
+    auto sweep1_page = [&](const bf16x8 (&kf)[2][2], int pg, auto masked_c) {
+#pragma unroll
+        for (int h = 0; h < GH; ++h) {
+            float sc[8];
+            scores(kf, h, pg, sc, masked_c);
+            float tm = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7])));
+            const float mn = fmaxf(m[h], tm);
+            float add = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) add += fexp_neg(sc[e] - mn);
+            sum[h] = sum[h] * fexp_neg(m[h] - mn) + add;       // lanes whose keys are all masked carry junk that the
+            m[h] = mn;                                         // merge below wipes out (their m stays at kMasked)
+        }
+    };
     stage(0, 0);
     for (int pg = 0; pg < npages; ++pg) {
         wait_vmem();
@@ -292,35 +316,20 @@ NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
         if (pg < npages_w) {
             bf16x8 kf[2][2];
             load_k(lds + (pg & 1) * (2 * kPage * 64), kf);
-#pragma unroll
-            for (int h = 0; h < GH; ++h) {
-                float sc[8];
-                scores(kf, h, pg, sc);
-                float tm = sc[0];
-#pragma unroll
-                for (int e = 1; e < 8; ++e) tm = fmaxf(tm, sc[e]);
-                const float mn = fmaxf(m[h], tm);
-                if (mn != -INFINITY) {
-                    float add = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) add += fexp(sc[e] - mn);
-                    sum[h] = sum[h] * fexp(m[h] - mn) + add;
-                    m[h] = mn;
-                }
-            }
+            if (pg * kPage + kPage - 1 > qw0) sweep1_page(kf, pg, Masked{}); else sweep1_page(kf, pg, Clear{});
         }
     }
+    float rs[GH];
 #pragma unroll
     for (int h = 0; h < GH; ++h) {
 #pragma unroll
         for (int sh = 16; sh <= 32; sh <<= 1) {
             const float om = shfl_xor(m[h], sh), os = shfl_xor(sum[h], sh);
             const float mn = fmaxf(m[h], om);
-            if (mn != -INFINITY) {
-                sum[h] = (m[h] == -INFINITY ? 0.f : sum[h] * fexp(m[h] - mn)) + (om == -INFINITY ? 0.f : os * fexp(om - mn));
-                m[h] = mn;
-            }
+            sum[h] = sum[h] * fexp_neg(m[h] - mn) + os * fexp_neg(om - mn);
+            m[h] = mn;
         }
+        rs[h] = frcp_refined(sum[h]);
     }
 
     // ---- sweep 2: P = bf16(exp(s - m) / sum), O += P V
@@ -329,6 +338,18 @@ NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
     for (int h = 0; h < GH; ++h)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) oacc[h][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto sweep2_page = [&](const bf16x8 (&kf)[2][2], const bf16x8 (&vB)[4], int pg, auto masked_c) {
+#pragma unroll
+        for (int h = 0; h < GH; ++h) {
+            float sc[8];
+            scores(kf, h, pg, sc, masked_c);
+            bf16x8 pA;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pA[e] = (short)f2bf(fdiv_r(fexp_neg(sc[e] - m[h]), sum[h], rs[h]));
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) oacc[h][nt] = mfma16(pA, vB[nt], oacc[h][nt]);
+        }
+    };
     sync();                                                   // sweep 1's last reads are done before buffer 0 is refilled
     stage(0, 0);
     for (int pg = 0; pg < npages; ++pg) {
@@ -355,16 +376,7 @@ NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
                     }
                 }
             }
-#pragma unroll
-            for (int h = 0; h < GH; ++h) {
-                float sc[8];
-                scores(kf, h, pg, sc);
-                bf16x8 pA;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pA[e] = (short)f2bf(fexp(sc[e] - m[h]) / sum[h]);
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) oacc[h][nt] = mfma16(pA, vB[nt], oacc[h][nt]);
-            }
+            if (pg * kPage + kPage - 1 > qw0) sweep2_page(kf, vB, pg, Masked{}); else sweep2_page(kf, vB, pg, Clear{});
         }
     }
     // D: col = d (l15 of tile nt), row = query qw0 + g*4 + r

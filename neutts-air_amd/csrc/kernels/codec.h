@@ -209,14 +209,21 @@ struct AttnFullArgs {
     CodecRows R;
     int C, nh, npages, qtiles;
 };
-// grid (B * qtiles, nh); 4 waves x 16 queries.  Same matrix-core mapping as attn_prefill.h.
+// grid (B * qtiles, nh); 4 waves x 16 queries.  Same matrix-core mapping as attn_prefill.h: the workgroup's K page
+// (gathered from the qkv rows) and V^T page are staged ONCE in LDS by LDS-DMA (double-buffered) and shared by the 4
+// waves, instead of every wave pulling them through its own load path.  Two sweeps (max / denominator, then PV).
+//   K image [32 keys][128 B], chunk c of key r at c ^ (r & 7);  V^T image [64 d][64 B], 16-B unit u of row d at
+//   u ^ ((d >> 2) & 3)  -- V^T pages come from v_transpose_kernel in plain token order, so a lane's 8 keys are the
+//   two 8-byte halves (units g>>1 and 2 + (g>>1)).
 NTTS_KERNEL(256) void attn_full_kernel(AttnFullArgs p) {
+    NTTS_SHARED bf16_t lds[2 * 2 * kPage * 64];
     const int lane = lane_id(), w = wave_id();
     const int g = lane >> 4, l15 = lane & 15;
     const int b = blockIdx.x / p.qtiles, qt = blockIdx.x % p.qtiles, h = blockIdx.y;
     const int T = p.R.lens[b];
+    if (qt * 64 >= T) return;                                  // block-uniform
     const int qw0 = qt * 64 + w * 16;
-    if (qw0 >= T) return;  // wave-uniform, kernel has no barrier
+    const bool wave_live = qw0 < T;
     const long row0 = (long)b * p.R.Tp + kPadRows;
     const long ld = 3L * p.C;
     int qi = qw0 + l15;
@@ -227,35 +234,59 @@ NTTS_KERNEL(256) void attn_full_kernel(AttnFullArgs p) {
     qB[1] = ld16<bf16x8>(qr + 8);
     const int npg = (T + kPage - 1) / kPage;
 
-    auto scores = [&](int pg, float (&s)[8]) {
+    auto stage = [&](int pg, int buf) {
+        bf16_t* dst = lds + buf * (2 * kPage * 64);
+        if (w < 2) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            int kt = pg * kPage + u * 16 + l15;          // this lane's key row (A-operand row)
-            if (kt > T - 1) kt = T - 1;
-            const bf16_t* kr = p.qkv + (row0 + kt) * ld + p.C + h * 64 + g * 16;
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            a = mfma16(ld16<bf16x8>(kr), qB[0], a);
-            a = mfma16(ld16<bf16x8>(kr + 8), qB[1], a);
+            for (int i = 0; i < 2; ++i) {
+                const int inst = w * 2 + i;                    // 8 keys per instruction
+                const int r = inst * 8 + (lane >> 3);
+                int kt = pg * kPage + r;
+                if (kt > T - 1) kt = T - 1;
+                const int c = (lane & 7) ^ (r & 7);
+                glds16(p.qkv + (row0 + kt) * ld + p.C + h * 64 + c * 8, dst + inst * 512);
+            }
+        } else {
+            const bf16_t* vp = p.vt + (((long)b * p.nh + h) * p.npages + pg) * 64 * kPage;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = pg * kPage + u * 16 + g * 4 + r;
-                s[u * 4 + r] = key < T ? a[r] * 0.125f : -INFINITY;
+            for (int i = 0; i < 2; ++i) {
+                const int inst = (w - 2) * 2 + i;              // 16 d-rows per instruction
+                const int d = inst * 16 + (lane >> 2);
+                const int u = (lane & 3) ^ ((d >> 2) & 3);
+                glds16(vp + d * kPage + u * 8, dst + kPage * 64 + inst * 512);
             }
         }
     };
-    float m = -INFINITY, sum = 0.f;
-    for (int pg = 0; pg < npg; ++pg) {
-        float s[8];
-        scores(pg, s);
-        float tm = s[0];
+    constexpr float kMasked = -1.0e30f;
+    auto scores = [&](const bf16_t* kb, int pg, float (&s)[8]) {
 #pragma unroll
-        for (int e = 1; e < 8; ++e) tm = fmaxf(tm, s[e]);
-        const float mn = fmaxf(m, tm);
-        if (mn != -INFINITY) {
+        for (int u = 0; u < 2; ++u) {
+            const int r = u * 16 + l15;
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = mfma16(ld16<bf16x8>(kb + r * 64 + (((2 * g) ^ (r & 7)) << 3)), qB[0], a);
+            a = mfma16(ld16<bf16x8>(kb + r * 64 + (((2 * g + 1) ^ (r & 7)) << 3)), qB[1], a);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int key = pg * kPage + u * 16 + g * 4 + rr;
+                s[u * 4 + rr] = key < T ? a[rr] * 0.125f : kMasked;
+            }
+        }
+    };
+    float m = kMasked, sum = 0.f;
+    stage(0, 0);
+    for (int pg = 0; pg < npg; ++pg) {
+        wait_vmem();
+        sync();
+        if (pg + 1 < npg) stage(pg + 1, (pg + 1) & 1);
+        if (wave_live) {
+            float s[8];
+            scores(lds + (pg & 1) * (2 * kPage * 64), pg, s);
+            const float tm = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+            const float mn = fmaxf(m, tm);
             float add = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) add += fexp(s[e] - mn);
-            sum = sum * fexp(m - mn) + add;
+            for (int e = 0; e < 8; ++e) add += fexp_neg(s[e] - mn);
+            sum = sum * fexp_neg(m - mn) + add;
             m = mn;
         }
     }
@@ -263,39 +294,49 @@ NTTS_KERNEL(256) void attn_full_kernel(AttnFullArgs p) {
     for (int sh = 16; sh <= 32; sh <<= 1) {
         const float om = shfl_xor(m, sh), os = shfl_xor(sum, sh);
         const float mn = fmaxf(m, om);
-        if (mn != -INFINITY) {
-            sum = (m == -INFINITY ? 0.f : sum * fexp(m - mn)) + (om == -INFINITY ? 0.f : os * fexp(om - mn));
-            m = mn;
-        }
+        sum = sum * fexp_neg(m - mn) + os * fexp_neg(om - mn);
+        m = mn;
     }
     f32x4 oacc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) oacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     const float rs = 1.0f / sum;
+    sync();
+    stage(0, 0);
     for (int pg = 0; pg < npg; ++pg) {
-        float s[8];
-        scores(pg, s);
-        bf16x8 pA;
+        wait_vmem();
+        sync();
+        if (pg + 1 < npg) stage(pg + 1, (pg + 1) & 1);
+        if (wave_live) {
+            const bf16_t* kb = lds + (pg & 1) * (2 * kPage * 64);
+            const bf16_t* vb = kb + kPage * 64;
+            float s[8];
+            scores(kb, pg, s);
+            bf16x8 pA;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pA[e] = (short)f2bf(fexp(s[e] - m) * rs);
-        const bf16_t* vp = p.vt + (((long)b * p.nh + h) * p.npages + pg) * 64 * kPage;
+            for (int e = 0; e < 8; ++e) pA[e] = (short)f2bf(fexp_neg(s[e] - m) * rs);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const bf16_t* vr = vp + (nt * 16 + l15) * kPage + g * 4;
-            const bf16x4 v0 = ld16<bf16x4>(vr), v1 = ld16<bf16x4>(vr + 16);
-            bf16x8 vB;
+            for (int nt = 0; nt < 4; ++nt) {
+                const int d = nt * 16 + l15;
+                const int sw = (d >> 2) & 3;
+                const bf16x4 v0 = ld16<bf16x4>(vb + d * kPage + (((g >> 1) ^ sw) << 3) + (g & 1) * 4);
+                const bf16x4 v1 = ld16<bf16x4>(vb + d * kPage + (((2 + (g >> 1)) ^ sw) << 3) + (g & 1) * 4);
+                bf16x8 vB;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { vB[e] = v0[e]; vB[4 + e] = v1[e]; }
-            oacc[nt] = mfma16(pA, vB, oacc[nt]);
+                for (int e = 0; e < 4; ++e) { vB[e] = v0[e]; vB[4 + e] = v1[e]; }
+                oacc[nt] = mfma16(pA, vB, oacc[nt]);
+            }
         }
     }
+    if (wave_live) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int q = qw0 + g * 4 + r;
-        if (q < T) {
-            bf16_t* o = p.out + (row0 + q) * p.C + h * 64 + l15;
+        for (int r = 0; r < 4; ++r) {
+            const int q = qw0 + g * 4 + r;
+            if (q < T) {
+                bf16_t* o = p.out + (row0 + q) * p.C + h * 64 + l15;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) o[nt * 16] = f2bf(oacc[nt][r]);
+                for (int nt = 0; nt < 4; ++nt) o[nt * 16] = f2bf(oacc[nt][r]);
+            }
         }
     }
 }

@@ -64,6 +64,26 @@ NTTS_D void sync_keep_dma() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" :
 NTTS_D unsigned int atomic_add_lds(unsigned int* p, unsigned int v) { return atomicAdd(p, v); }
 
 NTTS_D float fexp(float x) { return expf(x); }
+// exp(x) for FINITE x <= ~0 (softmax arguments after the max is subtracted; masked scores are -1e30, never -inf):
+// x*log2(e) is split into its rounded product t and the exact remainder r (fma), exp2(t) is one v_exp_f32 and the
+// remainder is a first-order correction.  ~1.5 ulp, 6 instructions, no range checks (libm's expf is ~12 with them).
+NTTS_D float fexp_neg(float x) {
+    const float hi = 1.44269502162933349609375f, lo = 1.925963033500011e-8f;   // log2(e) = hi + lo
+    const float t = x * hi;
+    float r = __builtin_fmaf(x, hi, -t);
+    r = __builtin_fmaf(x, lo, r);
+    const float y = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(y, r * 0.693147180559945309f, y);
+}
+// e / d given r ~ 1/d (v_rcp_f32 refined once): one Newton step on the quotient, within ~0.5 ulp of IEEE division
+NTTS_D float fdiv_r(float e, float d, float r) {
+    const float q = e * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, d, e), r, q);
+}
+NTTS_D float frcp_refined(float d) {
+    float r = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+}
 NTTS_D float frsqrt_exact(float x) { return 1.0f / sqrtf(x); }
 
 template <typename T>

@@ -139,6 +139,22 @@ template <int N>
 inline void wait_vmem_le() {}
 
 inline float fexp(float x) { return expf(x); }
+inline float fexp_neg(float x) {
+    const float hi = 1.44269502162933349609375f, lo = 1.925963033500011e-8f;
+    const float t = x * hi;
+    float r = fmaf(x, hi, -t);
+    r = fmaf(x, lo, r);
+    const float y = exp2f(t);
+    return fmaf(y, r * 0.693147180559945309f, y);
+}
+inline float fdiv_r(float e, float d, float r) {
+    const float q = e * r;
+    return fmaf(fmaf(-q, d, e), r, q);
+}
+inline float frcp_refined(float d) {
+    float r = 1.0f / d;
+    return fmaf(fmaf(-d, r, 1.0f), r, r);
+}
 inline float frsqrt_exact(float x) { return 1.0f / sqrtf(x); }
 
 template <typename T>
