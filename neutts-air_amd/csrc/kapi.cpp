@@ -73,6 +73,12 @@ extern "C" int ntts_k_membw(size_t bytes, int32_t iters, double* gbps) {
 // HBM-cold when copies * N * K * 2 B exceeds the 256 MB Infinity Cache.  config: tile family, abl: ablation bits
 // of gemm_kernel.  Returns the average microseconds per launch (back-to-back launches on the NULL stream).
 NTTS_KERNEL(64) void empty_kernel(int* p) { if (p && threadIdx.x == 12345) *p = 0; }
+// touch `n16` 16-byte words so that they are resident in the memory-side cache (and this XCD's L2) afterwards
+NTTS_KERNEL(256) void prefetch_kernel(const u32x4* src, long n16, int* sink) {
+    unsigned int acc = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256) acc ^= src[i][0];
+    if (acc == 0x12345678u && sink) *sink = 1;
+}
 
 template <int WM, int WN, int TM, int NS>
 static void probe_launch(const GemmArgs& a, int ks, int abl) {
@@ -99,7 +105,10 @@ extern "C" int ntts_k_gemm_probe(int32_t M, int32_t N, int32_t K, int32_t config
     hipMemset(W, 0x22, wn * 2 * copies);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
+    const bool pf = (abl & 8) != 0;
+    abl &= 7;
     auto run = [&](int i) {
+        if (pf) NTTS_LAUNCH((prefetch_kernel), dim3(256), dim3(256), (hipStream_t)0, (const u32x4*)(W + (size_t)((i + 1) % copies) * wn), (long)(wn / 8), (int*)nullptr);
         GemmArgs a{};
         a.X = X; a.ldx = K; a.W = W + (size_t)(i % copies) * wn; a.ldw = K; a.out = C; a.ldo = N; a.M = M; a.N = N; a.K = K;
         switch (config) {

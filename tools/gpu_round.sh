@@ -16,8 +16,12 @@ for leg in $LEGS; do
     prof)  rm -rf $OUT/prof; timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof -o bench -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $OUT/prof_bench.json 2> $OUT/prof.err; echo "prof rc=$?"
            python tools/prof_summary.py $OUT/prof > $OUT/prof_summary.txt 2>&1; head -40 $OUT/prof_summary.txt; cat $OUT/prof_bench.json; tail -3 $OUT/prof.err
            find $OUT/prof -name '*kernel_trace.csv' -size +20M -delete;;
-    pmc)   rm -rf $OUT/pmc; NTTS_NO_GRAPH=1 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/pmc -o fetch -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-codec --decode ${PMC_DECODE:-250} --batch ${PMC_BATCH:-256} > $OUT/pmc_bench.json 2> $OUT/pmc.err; echo "pmc rc=$?"; tail -3 $OUT/pmc.err
-           python tools/pmc_summary.py $OUT/pmc > $OUT/pmc_summary.txt 2>&1; head -30 $OUT/pmc_summary.txt; find $OUT/pmc -name '*.csv' -size +8M -delete;;
+    pmc)   # HBM traffic counters, each in its own pass (FETCH_SIZE and WRITE_SIZE do not fit one pass); hipGraph replay off
+           # (counter collection crashed rocprofv3 under graph replay); --kernel-trace only, as the pool rules require
+           for ctr in FETCH_SIZE WRITE_SIZE; do
+             rm -rf $OUT/pmc_$ctr; NTTS_NO_GRAPH=1 timeout 600 rocprofv3 --kernel-trace --pmc $ctr -f csv -d $OUT/pmc_$ctr -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-codec --decode ${PMC_DECODE:-250} --batch ${PMC_BATCH:-256} > $OUT/pmc_bench.json 2> $OUT/pmc_$ctr.err; echo "pmc $ctr rc=$?"
+             python tools/pmc_summary.py $OUT/pmc_$ctr > $OUT/pmc_${ctr}_summary.txt 2>&1; head -14 $OUT/pmc_${ctr}_summary.txt; find $OUT/pmc_$ctr -name '*.csv' -size +8M -delete
+           done;;
     *) echo "unknown leg $leg";;
   esac
 done

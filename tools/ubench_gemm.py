@@ -39,9 +39,25 @@ def prefill():
             print(f"{CONFIGS[cfg]:18s} {t:9.1f} {fl / t / 1e6:7.0f} | {'':14s} {ab[0]:9.1f} {ab[1]:9.1f} {ab[2]:9.1f} {ab[3]:9.1f}", flush=True)
 
 
+def mall():
+    """Does touching the weights one kernel ahead (Infinity-Cache resident instead of HBM-cold) speed the decode GEMMs up?"""
+    for name, (M, N, K) in SHAPES.items():
+        wbytes = N * K * 2
+        cold = max(2, int(400e6 // wbytes))
+        pf_alone = probe(M, N, K, 0, 8, cold)
+        print(f"== {name}: prefetch kernel alone {pf_alone:.2f} us (incl. one empty launch)")
+        for cfg in (11, 12):
+            c0 = probe(M, N, K, cfg, 0, cold)
+            c1 = probe(M, N, K, cfg, 8, cold)
+            w0 = probe(M, N, K, cfg, 0, 1)
+            print(f"  {CONFIGS[cfg]:16s} cold {c0:7.2f}  warm {w0:7.2f}  [prefetch(next) + gemm] {c1:7.2f}  -> gemm on prefetched ~ {c1 - pf_alone + 2.2:7.2f}", flush=True)
+
+
 def main():
     if "--prefill" in sys.argv:
         return prefill()
+    if "--mall" in sys.argv:
+        return mall()
     print(f"empty kernel: {probe(64, 64, 64, 0, 0, 1):.2f} us/launch")
     for name, (M, N, K) in SHAPES.items():
         wbytes = N * K * 2
