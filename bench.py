@@ -239,8 +239,18 @@ def main():
         rows.sort(reverse=True)
         _, name, ms, nbytes, nl = rows[0]
         ach = nbytes / (ms * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        try:   # HBM bytes per launch from the committed PMC pass (tools/gpu_round.sh pmc -> tools/pmc_to_json.py)
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                pm = json.load(fh)
+            for kname, rec in pm["kernels"].items():
+                if kname.startswith(name):
+                    traffic = rec["fetch_bytes_per_launch"] + rec.get("write_bytes_per_launch_uncorrected", 0.0)
+                    traffic_src = "profiles/r01_pmc_traffic.json: " + pm["source"]
+        except (OSError, KeyError, ValueError):
+            pass
         roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBPS, "traffic": None, "avg_launch_us": ms * 1e3,
+                "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": ms * 1e3,
                 "alg_bytes_per_launch": nbytes, "launches_per_step": nl,
                 "per_kernel": [{"kernel": r[1], "us": r[2] * 1e3, "launches_per_step": r[4], "alg_bytes": r[3],
                                 "GBps": r[3] / (r[2] * 1e-3) / 1e9} for r in rows]}

@@ -27,6 +27,8 @@ def broadcast_weights(engine, src: int = 0, device=None):
     if dist.get_rank() == src:
         engine.arena_copy(buf.data_ptr(), nbytes, to_arena=False)
     dist.broadcast(buf, src=src)
+    if buf.is_cuda:
+        torch.cuda.synchronize()     # the engine copies on its own HIP stream: the collective must have landed
     if dist.get_rank() != src:
         engine.arena_copy(buf.data_ptr(), nbytes, to_arena=True)
         engine.adopt_arena()
@@ -51,6 +53,8 @@ def broadcast_state_dict(sd, src: int = 0, device=None):
             t = torch.empty(shape, dtype=torch.float32, device=device)
         dist.broadcast(t, src=src)
         out[name] = t
+    if device.type == "cuda":
+        torch.cuda.synchronize()
     return out
 
 

@@ -19,7 +19,7 @@ for leg in $LEGS; do
     pmc)   # HBM traffic counters, each in its own pass (FETCH_SIZE and WRITE_SIZE do not fit one pass); hipGraph replay off
            # (counter collection crashed rocprofv3 under graph replay); --kernel-trace only, as the pool rules require
            for ctr in FETCH_SIZE WRITE_SIZE; do
-             rm -rf $OUT/pmc_$ctr; NTTS_NO_GRAPH=1 timeout 240 rocprofv3 --kernel-trace --pmc $ctr -f csv -d $OUT/pmc_$ctr -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-codec --decode ${PMC_DECODE:-24} --batch ${PMC_BATCH:-256} > $OUT/pmc_bench.json 2> $OUT/pmc_$ctr.err; echo "pmc $ctr rc=$?"
+             rm -rf $OUT/pmc_$ctr; NTTS_NO_GRAPH=1 timeout 240 rocprofv3 --kernel-trace --pmc $ctr -f csv -d $OUT/pmc_$ctr -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-codec --prefill ${PMC_PREFILL:-605} --decode ${PMC_DECODE:-40} --batch ${PMC_BATCH:-256} > $OUT/pmc_bench.json 2> $OUT/pmc_$ctr.err; echo "pmc $ctr rc=$?"
              python tools/pmc_summary.py $OUT/pmc_$ctr > $OUT/pmc_${ctr}_summary.txt 2>&1; head -14 $OUT/pmc_${ctr}_summary.txt; find $OUT/pmc_$ctr -name '*.csv' -size +8M -delete
            done;;
     *) echo "unknown leg $leg";;
