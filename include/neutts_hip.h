@@ -196,6 +196,10 @@ int ntts_codec_finalize(ntts_codec* c);
  * max(lens); the tail of a shorter row up to that length is scratch).  One strided D2H copy.  Blocking. */
 int ntts_codec_decode(ntts_codec* c, int32_t n, const int32_t* codes, const int32_t* lens, float* wav_out,
                       int64_t wav_stride);
+/* Page-locked host memory for wav_out: a pinned destination lets the D2H copy run at PCIe speed (pageable memory is
+ * staged by the runtime at a fraction of it).  Plain malloc/free semantics; not tied to an engine. */
+int ntts_host_alloc(size_t bytes, void** out);
+int ntts_host_free(void* p);
 /* GPU milliseconds (hipEvents) of the most recent decode call, H2D/D2H excluded. */
 int ntts_codec_last_timing(ntts_codec* c, float* ms);
 

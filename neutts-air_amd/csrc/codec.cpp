@@ -424,6 +424,12 @@ extern "C" int ntts_codec_decode(ntts_codec* c, int32_t n, const int32_t* codes,
     return NTTS_OK;
 }
 
+extern "C" int ntts_host_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return NTTS_EINVAL;
+    return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? NTTS_OK : NTTS_ENOMEM;
+}
+extern "C" int ntts_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? NTTS_OK : NTTS_EHIP; }
+
 extern "C" int ntts_codec_last_timing(ntts_codec* c, float* ms) {
     if (!c || !ms) return NTTS_EINVAL;
     *ms = 0;

@@ -100,6 +100,12 @@ NTTS_KERNEL(256) void add_rmsnorm_kernel(NormArgs p) {
         }
     }
     if (!p.norm_w) return;  // wave-uniform
+    bf16x8 wv[NCH];         // issued before the cross-lane reduction so their latency hides under it
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ci = lane + 64 * i;
+        wv[i] = ld16<bf16x8>(p.norm_w + (ci < nchunk ? (long)ci * 8 : 0));
+    }
 #pragma unroll
     for (int sh = 1; sh < 64; sh <<= 1) ss += shfl_xor(ss, sh);
     const float inv = frsqrt_exact(ss / (float)p.H + p.eps);
@@ -108,7 +114,7 @@ NTTS_KERNEL(256) void add_rmsnorm_kernel(NormArgs p) {
         const int ci = lane + 64 * i;
         if (ci < nchunk && rok) {
             const long col = (long)ci * 8;
-            const bf16x8 w = ld16<bf16x8>(p.norm_w + col);
+            const bf16x8 w = wv[i];
             bf16x8 t;
 #pragma unroll
             for (int e = 0; e < 8; ++e) t[e] = (short)f2bf(bf2f((bf16_t)w[e]) * rbf(v[i][e] * inv));

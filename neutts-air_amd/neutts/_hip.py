@@ -96,6 +96,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_codec_finalize": (C.c_int, [p]),
         "ntts_codec_decode": (C.c_int, [p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(f32), i64]),
         "ntts_codec_last_timing": (C.c_int, [p, C.POINTER(f32)]),
+        "ntts_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(p)]),
+        "ntts_host_free": (C.c_int, [p]),
         "ntts_k_gemm_bf16": (C.c_int, [p, i64, p, p, p, i64, i32, i32, i32, i32]),
         "ntts_k_gemm_probe": (C.c_int, [i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_double)]),
         "ntts_k_rmsnorm_bf16": (C.c_int, [p, p, p, i32, i32, f32]),
@@ -345,6 +347,9 @@ class CodecEngine:
             raise NeuTTSHipError(rc, (self.lib.ntts_codec_last_error(self.h) or b"").decode())
 
     def close(self):
+        if getattr(self, "_pin_ptr", None):
+            self.lib.ntts_host_free(self._pin_ptr)
+            self._pin_ptr, self._pin_cap = None, 0
         if getattr(self, "h", None):
             self.lib.ntts_codec_destroy(self.h)
             self.h = None
@@ -363,8 +368,21 @@ class CodecEngine:
             del keep
         self._chk(self.lib.ntts_codec_finalize(self.h))
 
-    def decode(self, codes: Sequence[Sequence[int]]) -> List[np.ndarray]:
-        """codes: one int sequence per utterance -> list of float32 waveforms (hop_length * len each)."""
+    def _pinned(self, n_floats: int) -> np.ndarray:
+        """Engine-owned page-locked staging buffer (grown on demand), viewed as a float32 numpy array."""
+        if getattr(self, "_pin_cap", 0) < n_floats:
+            if getattr(self, "_pin_ptr", None):
+                self.lib.ntts_host_free(self._pin_ptr)
+            ptr = C.c_void_p()
+            if self.lib.ntts_host_alloc(n_floats * 4, C.byref(ptr)) != 0:
+                raise MemoryError("pinned host allocation failed")
+            self._pin_ptr, self._pin_cap = ptr, n_floats
+        return np.ctypeslib.as_array((C.c_float * n_floats).from_address(self._pin_ptr.value))
+
+    def decode(self, codes: Sequence[Sequence[int]], reuse_output: bool = False) -> List[np.ndarray]:
+        """codes: one int sequence per utterance -> list of float32 waveforms (hop_length * len each).
+        reuse_output=True returns views into an engine-owned pinned buffer (fast D2H, no copy): they are only valid
+        until the next decode() call on this engine."""
         out: List[Optional[np.ndarray]] = [None] * len(codes)
         order = sorted(range(len(codes)), key=lambda i: -len(codes[i]))   # batch similar lengths together
         i = 0
@@ -376,7 +394,10 @@ class CodecEngine:
             lens = np.array([len(codes[j]) for j in grp], dtype=np.int32)
             flat = np.ascontiguousarray(np.concatenate([np.asarray(codes[j], dtype=np.int32) for j in grp]))
             stride = int(self.hop_length * tmax)
-            wav = np.empty((len(grp), stride), dtype=np.float32)
+            if reuse_output and i == 0 and nb == len(order):      # single call covers the batch: pinned fast path
+                wav = self._pinned(len(grp) * stride).reshape(len(grp), stride)
+            else:
+                wav = np.empty((len(grp), stride), dtype=np.float32)
             self._chk(self.lib.ntts_codec_decode(self.h, len(grp), flat.ctypes.data_as(i32p), lens.ctypes.data_as(i32p),
                                                  wav.ctypes.data_as(C.POINTER(C.c_float)), stride))
             for r, j in enumerate(grp):

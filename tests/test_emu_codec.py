@@ -49,3 +49,15 @@ def test_codec_error_paths(emu_lib):
     with pytest.raises(_hip.NeuTTSHipError):             # too many frames
         eng.decode([list(range(17))])
     assert eng.decode([[1, 2, 3]])[0].shape == (3 * cfg.hop_length,)
+
+
+def test_codec_pinned_output_views(emu_lib):
+    """reuse_output=True: same samples, returned as views into the engine's page-locked staging buffer."""
+    z, cfg, w = load_codec_fixture("codec_tiny")
+    eng = make_codec_engine(cfg, w, emu_lib)
+    codes = [z["codes_0"][0, 0].tolist(), z["codes_1"][0, 0].tolist()]
+    a = eng.decode(codes)
+    b = eng.decode(codes, reuse_output=True)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    assert not b[0].flags["OWNDATA"]

@@ -53,7 +53,17 @@ def mall():
             print(f"  {CONFIGS[cfg]:16s} cold {c0:7.2f}  warm {w0:7.2f}  [prefetch(next) + gemm] {c1:7.2f}  -> gemm on prefetched ~ {c1 - pf_alone + 2.2:7.2f}", flush=True)
 
 
+def head():
+    M, N, K = 256, 217488, 896
+    print(f"== lm_head M={M} N={N} K={K} W=390 MB (always HBM-cold)")
+    for cfg in (30, 31, 40, 41, 42, 43, 12):
+        t = probe(M, N, K, cfg, 0, 1, iters=20)
+        print(f"  {CONFIGS[cfg]:18s} {t:8.1f} us  {N * K * 2 / t / 1e6:6.2f} TB/s", flush=True)
+
+
 def main():
+    if "--head" in sys.argv:
+        return head()
     if "--prefill" in sys.argv:
         return prefill()
     if "--mall" in sys.argv:
