@@ -167,7 +167,7 @@ def main():
 
     def one_step(collect=False):
         """One pass of the hot path over one batch: prompts -> codec-token ids -> 24 kHz waveforms."""
-        ph = {"prefill": 0.0, "decode": 0.0, "codec": 0.0, "handoff_host": 0.0}
+        ph = {"prefill": 0.0, "decode": 0.0, "codec": 0.0, "handoff_host": 0.0, "codec_call_wall": 0.0}
         for c in range(0, B, a.prefill_chunk):
             n = min(a.prefill_chunk, B - c)
             eng.prefill(prompts[c:c + n], list(range(c, c + n)), [samp] * n)
@@ -187,7 +187,9 @@ def main():
             # random weights do not stay in the speech range -> code = id mod 65536
             codes = [[t % n_codes for t in x] for x in ids]
             ph["handoff_host"] = (time.time() - th) * 1e3
+            tc = time.time()
             wavs = codec.decode(codes, reuse_output=True)    # waveforms land in the engine's pinned host buffer
+            ph["codec_call_wall"] = (time.time() - tc) * 1e3
             ph["codec"] = codec.last_timing()
             assert len(wavs) == B and all(wv.shape[0] == ccfg.hop_length * N for wv in wavs)
         return ph, ids, wavs

@@ -419,8 +419,11 @@ extern "C" int ntts_codec_decode(ntts_codec* c, int32_t n, const int32_t* codes,
     CHIP(c, hipStreamSynchronize(st));
     CHIP(c, hipGetLastError());
     // one strided device-to-host copy for the whole batch (rows shorter than Tmax carry don't-care tails)
-    CHIP(c, hipMemcpy2D(wav_out, (size_t)wav_stride * sizeof(float), c->wav, (size_t)hop * Tmax * sizeof(float),
-                        (size_t)hop * Tmax * sizeof(float), n, hipMemcpyDeviceToHost));
+    if (wav_stride == (int64_t)hop * Tmax)   // dense destination: one linear copy (DMA engine at PCIe speed into pinned memory)
+        CHIP(c, hipMemcpy(wav_out, c->wav, (size_t)n * hop * Tmax * sizeof(float), hipMemcpyDeviceToHost));
+    else
+        CHIP(c, hipMemcpy2D(wav_out, (size_t)wav_stride * sizeof(float), c->wav, (size_t)hop * Tmax * sizeof(float),
+                            (size_t)hop * Tmax * sizeof(float), n, hipMemcpyDeviceToHost));
     return NTTS_OK;
 }
 
