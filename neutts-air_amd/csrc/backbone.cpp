@@ -80,7 +80,7 @@ struct ntts_backbone {
     bool graph_has_logits = false;
     int ks_o = 1, ks_d = 1;
     int st_qkv = 4, st_o = 4, st_gu = 3, st_d = 4;   // LDS ring depth of each skinny decode GEMM
-    int head_stages = 2, l_stages = 2, pf_gh = 4, attn_depth = 1;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
+    int head_stages = 2, l_stages = 2, pf_gh = 4, attn_depth = 1, gu_tile = 0;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
     bool gu_large = false, head_large = true, pf_attn_simple = false, use_xl = true, head_xl = false;
     // EXPERIMENTAL (off): RMSNorm fused into the QKV / gate-up GEMM prologues, residual into o_proj's epilogue
     // (gemm_xpanel_kernel).  Parity-clean but slower on MI355X at batch 256: one 4-wave workgroup per CU cannot
@@ -256,6 +256,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->xp_bpc = env_int("NTTS_XP_BPC", 1);
     e->pf_gh = env_int("NTTS_PF_GH", 4);
     e->attn_depth = env_int("NTTS_ATTN_DEPTH", 1);
+    e->gu_tile = env_int("NTTS_GU_TILE", B > 128 ? 1 : 0);   // 128x128 / 8 waves measured -2 % per step at B = 256
     e->head_large = env_int("NTTS_HEAD_LARGE", B > 64 ? 1 : 0) != 0;
     const int max_slabs = 16;
     if (e->ks_o > max_slabs) e->ks_o = max_slabs;
@@ -517,7 +518,10 @@ static void k_o_proj(ntts_backbone* e, int i) {
 static void k_gate_up(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, F = e->F;
     GemmArgs gu = gemm_args(e->xn_dec, H, e->layers[i].wgu, H, nullptr, e->act_dec, F, B, 2 * F, H);
-    if (e->gu_large) gemm_large<EPI_SILU_MUL>(e, gu, e->stream); else gemm_skinny<EPI_SILU_MUL>(e->st_gu, gu, 1, e->stream);
+    if (e->gu_tile == 1) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);        // 128 x 128, 8 waves
+    else if (e->gu_tile == 2) gemm_launch<8, 1, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);   // 256 x 64, 8 waves
+    else if (e->gu_large) gemm_large<EPI_SILU_MUL>(e, gu, e->stream);
+    else gemm_skinny<EPI_SILU_MUL>(e->st_gu, gu, 1, e->stream);
 }
 
 static void k_down(ntts_backbone* e, int i) {

@@ -131,6 +131,11 @@ extern "C" int ntts_k_gemm_probe(int32_t M, int32_t N, int32_t K, int32_t config
             case 42: probe_launch<4, 4, 4, 2>(a, 1, abl); break;   // 256 x 256, 16 waves
             case 43: probe_launch<4, 2, 4, 3>(a, 1, abl); break;   // 256 x 128, 8 waves, 3 stages (144 KB)
             case 44: probe_launch<2, 2, 8, 2>(a, 1, abl); break;   // 256 x 128, 4 waves (128 x 64 per wave)
+            case 50: probe_launch<4, 1, 4, 3>(a, 1, abl); break;   // 256 x 64, 4 waves: all decode rows in one block
+            case 51: probe_launch<8, 1, 2, 3>(a, 1, abl); break;   // 256 x 64, 8 waves
+            case 52: probe_launch<8, 1, 2, 2>(a, 1, abl); break;
+            case 53: probe_launch<8, 2, 2, 2>(a, 1, abl); break;   // 256 x 128, 16 waves
+            case 54: probe_launch<4, 2, 2, 3>(a, 1, abl); break;   // 128 x 128, 8 waves
             default: break;
         }
     };

@@ -15,7 +15,8 @@ SHAPES = {"qkv": (256, 1152, 896), "o": (256, 896, 896), "gate_up": (256, 9728, 
 CONFIGS = {10: "64x64 4w NS2", 11: "64x64 4w NS3", 12: "64x64 4w NS4", 13: "64x64 4w NS6", 20: "32x64 2w NS4",
            21: "64x64 2w NS4", 22: "64x64 1w NS4", 23: "64x128 4w NS3", 24: "64x128 8w NS3", 25: "128x64 8w NS3",
            26: "128x64 4w NS3", 30: "128x128 4w NS2", 31: "128x128 4w NS3", 40: "256x128 8w NS2", 41: "128x256 8w NS2",
-           42: "256x256 16w NS2", 43: "256x128 8w NS3", 44: "256x128 4w NS2"}
+           42: "256x256 16w NS2", 43: "256x128 8w NS3", 44: "256x128 4w NS2", 50: "256x64 4w NS3", 51: "256x64 8w NS3",
+           52: "256x64 8w NS2", 53: "256x128 16w NS2", 54: "128x128 8w NS3"}
 
 
 def probe(M, N, K, cfg, abl, copies, iters=200):
@@ -53,6 +54,16 @@ def mall():
             print(f"  {CONFIGS[cfg]:16s} cold {c0:7.2f}  warm {w0:7.2f}  [prefetch(next) + gemm] {c1:7.2f}  -> gemm on prefetched ~ {c1 - pf_alone + 2.2:7.2f}", flush=True)
 
 
+def tall():
+    """decode shapes with tiles that hold all 256 rows (W passes through LDS once)"""
+    for name, (M, N, K) in SHAPES.items():
+        wbytes = N * K * 2
+        cold = max(2, int(400e6 // wbytes))
+        print(f"== {name}  M={M} N={N} K={K}")
+        for cfg in (11, 12, 50, 51, 52, 53, 54):
+            print(f"  {CONFIGS[cfg]:18s} warm {probe(M, N, K, cfg, 0, 1):7.2f}  cold {probe(M, N, K, cfg, 0, cold):7.2f}", flush=True)
+
+
 def head():
     M, N, K = 256, 217488, 896
     print(f"== lm_head M={M} N={N} K={K} W=390 MB (always HBM-cold)")
@@ -64,6 +75,8 @@ def head():
 def main():
     if "--head" in sys.argv:
         return head()
+    if "--tall" in sys.argv:
+        return tall()
     if "--prefill" in sys.argv:
         return prefill()
     if "--mall" in sys.argv:
