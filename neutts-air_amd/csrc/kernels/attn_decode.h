@@ -56,8 +56,7 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
     NTTS_SHARED bf16_t knew[64];
     NTTS_SHARED bf16_t vnew[64];
     NTTS_SHARED float wred[4][kGroupMax];
-    NTTS_SHARED float rowmax[kGroupMax];
-    NTTS_SHARED float rowsum[kGroupMax];
+    NTTS_SHARED float wsum[4][kGroupMax];
     NTTS_SHARED float ored[4][kGroupMax][64];
 
     const int b = blockIdx.x, kvh = blockIdx.y;
@@ -119,8 +118,11 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
     qB[0] = ld16<bf16x8>(&qs[l15][g * 16]);
     qB[1] = ld16<bf16x8>(&qs[l15][g * 16 + 8]);
 
-    // ---- pass 1: S^T = K Q^T per 16-key sub-tile, bf16-rounded scores -> LDS, running max
-    float lmax = -INFINITY;
+    // ---- pass 1: S^T = K Q^T per 16-key sub-tile, bf16-rounded scores -> LDS, with the softmax statistics carried
+    //      online per lane (running max and sum of exp in fp32), so that one merge after the pass yields the row max
+    //      and denominator: no separate pass over the stored scores.  Masked keys use a large finite score.
+    constexpr float kMasked = -1.0e30f;
+    float lmax = kMasked, lsum = 0.f;
     for (int pg0 = w; pg0 < npages; pg0 += 4 * kDepth) {
 #pragma unroll
         for (int j = 0; j < kDepth; ++j) {
@@ -145,14 +147,19 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
                     a = mfma16(kc[u][1], qB[1], a);
                     const int key0 = pg * kPage + u * 16 + g * 4;
                     bf16x4 sv;
+                    float s4[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float s = rbf(rbf(a[r]) * 0.125f);   // matmul out (bf16) * scaling (bf16)
-                        if (key0 + r >= L) s = -INFINITY;
-                        lmax = fmaxf(lmax, s);
+                        float s = rbf(a[r]) * 0.125f;        // matmul out (bf16) * scaling (bf16): the x 2^-3 is exact
+                        if (key0 + r >= L) s = kMasked;
+                        s4[r] = s;
                         sv[r] = (short)f2bf(s);
                     }
                     if (l15 < kGroupMax) *(bf16x4*)&sc[l15][key0] = sv;
+                    const float mn = fmaxf(lmax, fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s4[3])));
+                    lsum = lsum * fexp_neg(lmax - mn) + fexp_neg(s4[0] - mn) + fexp_neg(s4[1] - mn) + fexp_neg(s4[2] - mn) +
+                           fexp_neg(s4[3] - mn);
+                    lmax = mn;
                 }
             }
         }
@@ -168,33 +175,28 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
     for (int j = 0; j < kDepth; ++j)
         if (w + 4 * j < npages) load_v(w + 4 * j, vq[j]);
 
-    lmax = fmaxf(lmax, shfl_xor(lmax, 16));
-    lmax = fmaxf(lmax, shfl_xor(lmax, 32));
-    if (g == 0 && l15 < kGroupMax) wred[w][l15] = lmax;
-    sync();
-    if (tid < kGroupMax) rowmax[tid] = fmaxf(fmaxf(wred[0][tid], wred[1][tid]), fmaxf(wred[2][tid], wred[3][tid]));
-    sync();
-
-    // ---- softmax denominator in fp32 (32 threads per head)
-    {
-        const int hh = tid >> 5, i = tid & 31;
-        float sum = 0.f;
-        if (hh < kGroupMax) {
-            const float m = rowmax[hh];
-            for (int key = i; key < L; key += 32) sum += fexp(bf2f(sc[hh][key]) - m);
-        }
+    // ---- merge the (max, sum) pairs: across the 4 key groups of a wave, then across the 4 waves (one barrier)
 #pragma unroll
-        for (int sh = 1; sh < 32; sh <<= 1) sum += shfl_xor(sum, sh);
-        if (i == 0 && hh < kGroupMax) rowsum[hh] = sum;
+    for (int sh = 16; sh <= 32; sh <<= 1) {
+        const float om = shfl_xor(lmax, sh), os = shfl_xor(lsum, sh);
+        const float mn = fmaxf(lmax, om);
+        lsum = lsum * fexp_neg(lmax - mn) + os * fexp_neg(om - mn);
+        lmax = mn;
     }
+    if (g == 0 && l15 < kGroupMax) { wred[w][l15] = lmax; wsum[w][l15] = lsum; }
     sync();
+    float m_l = kMasked, sum_l = 1.f;
+    if (l15 < kGroupMax) {
+        m_l = fmaxf(fmaxf(wred[0][l15], wred[1][l15]), fmaxf(wred[2][l15], wred[3][l15]));
+        sum_l = wsum[0][l15] * fexp_neg(wred[0][l15] - m_l) + wsum[1][l15] * fexp_neg(wred[1][l15] - m_l) +
+                wsum[2][l15] * fexp_neg(wred[2][l15] - m_l) + wsum[3][l15] * fexp_neg(wred[3][l15] - m_l);
+    }
+    const float rs_l = frcp_refined(sum_l);
 
     // ---- pass 2: O = P V with P = bf16(exp(s - m) / sum)
     f32x4 oacc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) oacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float m_l = l15 < kGroupMax ? rowmax[l15] : 0.f;
-    const float sum_l = l15 < kGroupMax ? rowsum[l15] : 1.f;
     for (int pg0 = w; pg0 < npages; pg0 += 4 * kDepth) {
 #pragma unroll
         for (int j = 0; j < kDepth; ++j) {
@@ -212,8 +214,8 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
                     const bf16x4 s1 = *(const bf16x4*)&sc[l15][pg * kPage + 16 + g * 4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        pA[e] = (short)f2bf(fexp(bf2f((bf16_t)s0[e]) - m_l) / sum_l);
-                        pA[4 + e] = (short)f2bf(fexp(bf2f((bf16_t)s1[e]) - m_l) / sum_l);
+                        pA[e] = (short)f2bf(fdiv_r(fexp_neg(bf2f((bf16_t)s0[e]) - m_l), sum_l, rs_l));
+                        pA[4 + e] = (short)f2bf(fdiv_r(fexp_neg(bf2f((bf16_t)s1[e]) - m_l), sum_l, rs_l));
                     }
                 }
                 if (pg == last_page) {  // new token's V from LDS; nothing beyond it may leak in (0 * garbage)
