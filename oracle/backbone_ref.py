@@ -297,6 +297,28 @@ def generate(cfg: BackboneConfig, w, prompt_ids: List[int], max_length: int, eos
     return GenResult(out, margins, kept if keep_logits else None)
 
 
+def bf16_ulp(x: float) -> float:
+    x = abs(float(x))
+    return 2.0 ** -133 if x == 0 else 2.0 ** (np.floor(np.log2(x)) - 7)
+
+
+def assert_free_run_matches(got_ids: List[int], ref: GenResult, max_ulps: float = 2.0) -> None:
+    """Free-running greedy ids of an implementation vs a GenResult produced with keep_logits=True: identical, or identical
+    up to the first step where the ORACLE's own top-2 logits are within `max_ulps` bf16 ulps (exact bf16 ties do occur
+    with synthetic weights; which side wins then depends on fp32 summation order -- even between two CPUs running this
+    oracle), in which case the implementation's token must be one of those two."""
+    want = ref.ids
+    k = next((i for i in range(min(len(got_ids), len(want))) if got_ids[i] != want[i]), None)
+    if k is None:
+        assert len(got_ids) == len(want), (len(got_ids), len(want))
+        return
+    top = torch.topk(ref.logits[k], 2)
+    gap = float(top.values[0] - top.values[1])
+    assert gap <= max_ulps * bf16_ulp(float(top.values[0])), \
+        f"step {k}: got {got_ids[k]}, oracle {want[k]}, oracle top-2 gap {gap}"
+    assert got_ids[k] in top.indices.tolist(), (k, got_ids[k], top.indices.tolist())
+
+
 def synthetic_prompt(cfg: BackboneConfig, utt_idx: int, length: int = 500) -> List[int]:
     """randint(0, V) with seed 1234 + utt_idx (numpy PCG64 here so that the
     GPU box, which has no /root/reference and maybe another torch, draws identical prompts)."""

@@ -69,6 +69,9 @@ def teacher_forced_compare(eng, slot, gold_ids, gold_topv, gold_topi, max_ulps=2
     return n_exact, n_tie
 
 
+assert_free_run_matches = br.assert_free_run_matches
+
+
 # ---------------------------------------------------------------------------------------------- codec
 def load_codec_fixture(name):
     from oracle import codec_ref as cr

@@ -7,7 +7,7 @@ import torch
 
 from oracle import backbone_ref as br
 from neutts import _hip
-from common import load_fixture, make_engine, teacher_forced_compare
+from common import assert_free_run_matches, load_fixture, make_engine, teacher_forced_compare
 
 pytestmark = pytest.mark.gpu
 
@@ -53,11 +53,13 @@ def test_continuous_batching_ragged_vs_oracle(lib):
     prompts = [br.synthetic_prompt(cfg, 10 + i, n) for i, n in enumerate(lens)]
     probe = br.generate(cfg, wd, prompts[3], lens[3] + 20, eos_id=cfg.vocab_size - 1, min_new_tokens=0)
     eos = probe.ids[6]
-    want = [br.generate(cfg, wd, p, len(p) + 24, eos_id=eos, min_new_tokens=3).ids for p in prompts]
+    want = [br.generate(cfg, wd, p, len(p) + 24, eos_id=eos, min_new_tokens=3, keep_logits=True) for p in prompts]
     eng = make_engine(cfg, w, lib, max_batch=4, max_context=256, max_prefill_tokens=256)
     samp = [_hip.Sampling(max_length=len(p) + 24, min_new_tokens=3, eos_token_id=eos, do_sample=False) for p in prompts]
     got = eng.generate(prompts, samp, steps_per_poll=5, prefill_token_budget=150)
-    assert got == want
+    for g, ref in zip(got, want):
+        assert_free_run_matches(g, ref)
+    assert sum(int(g == ref.ids) for g, ref in zip(got, want)) >= 8      # exact bf16 ties are the exception
 
 
 @pytest.fixture(scope="module")
