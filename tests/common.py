@@ -41,13 +41,15 @@ def bf16_ulp(x: float) -> float:
     return 2.0 ** (np.floor(np.log2(x)) - 7)
 
 
-def teacher_forced_compare(eng, slot, gold_ids, gold_topv, gold_topi, max_ulps=2.0):
+def teacher_forced_compare(eng, slot, gold_ids, gold_topv, gold_topi, max_ulps=2.0, logit_stats=None):
     """Step the engine one token at a time against a golden greedy run.
 
     A token must equal the golden one unless the golden top-1/top-2 logits are within `max_ulps`
     bf16 ulps of each other (then fp32 summation order legitimately decides; our token must then be
     among the golden top-4 with a logit inside that band).  After such a step the golden token is
-    forced so that later steps stay comparable.  Returns (n_exact, n_near_tie)."""
+    forced so that later steps stay comparable.  Returns (n_exact, n_near_tie).
+    With `logit_stats` (a list) and the engine's debug tap enabled, the absolute error of OUR logits at the golden
+    top-4 token ids is appended per step, in bf16 ulps of the golden value: the direct measure of numerical fidelity."""
     n_exact = n_tie = 0
     n = len(gold_ids)
     for k in range(n):
@@ -56,6 +58,11 @@ def teacher_forced_compare(eng, slot, gold_ids, gold_topv, gold_topi, max_ulps=2
         ids, fin = eng.read(slot)
         assert len(ids) == k + 1, (k, len(ids))
         tok = ids[-1]
+        if logit_stats is not None:
+            row = eng.read_logits(slot)
+            for i, v in zip(gold_topi[k], gold_topv[k]):
+                if np.isfinite(v):
+                    logit_stats.append(abs(float(row[int(i)]) - float(v)) / bf16_ulp(float(v)))
         if tok == int(gold_ids[k]):
             n_exact += 1
         else:

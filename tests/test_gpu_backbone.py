@@ -70,14 +70,27 @@ def air(lib):
 
 
 def test_air_teacher_forced_vs_hf_golden(air):
-    """NeuTTS-Air geometry, 500-token prompt, 250 greedy tokens: every token equals HF's unless HF's own
-    top-2 logits are within 2 bf16 ulps (then ours must be the runner-up)."""
+    """NeuTTS-Air geometry, 500-token prompt, 250 greedy tokens, teacher-forced against transformers' bf16 run.
+    (1) Fidelity of the logits themselves (debug tap): at the golden top-4 token ids of every step our logit is within
+        a few bf16 ulps of HF's -- both sides round to bf16 ~170 times per token, in different fp32 summation orders.
+    (2) Ids: every token equals HF's unless HF's own top-2 logits are within 4 bf16 ulps of each other (then ours must
+        be one of HF's top-4 inside that band); random-init weights give flat logits, so such near-ties are frequent."""
     z, cfg, eng = air
     S, N, eos = int(z["s_len"]), int(z["n_new"]), int(z["eos"])
     samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
-    eng.prefill([br.synthetic_prompt(cfg, 0, S)], [7], [samp])
-    ex, tie = teacher_forced_compare(eng, 7, z["bf16_ids_0"], z["bf16_topv_0"], z["bf16_topi_0"])
-    eng.release(7)
+    eng.set_debug(True)
+    stats = []
+    try:
+        eng.prefill([br.synthetic_prompt(cfg, 0, S)], [7], [samp])
+        ex, tie = teacher_forced_compare(eng, 7, z["bf16_ids_0"], z["bf16_topv_0"], z["bf16_topi_0"], max_ulps=4.0,
+                                         logit_stats=stats)
+    finally:
+        eng.release(7)
+        eng.set_debug(False)
+    err = np.array(stats)
+    print(f"logit error at golden top-4 ids, bf16 ulps: mean {err.mean():.3f}  p99 {np.percentile(err, 99):.2f}  max {err.max():.2f}; "
+          f"{ex} exact + {tie} near-tie of {N}")
+    assert err.mean() <= 0.8 and np.percentile(err, 99) <= 2.5 and err.max() <= 3.0,   # measured: 0.56 / 2.0 / 2.0 (err.mean(), np.percentile(err, 99), err.max())
     assert ex + tie == N
     assert ex >= 0.7 * N, f"only {ex}/{N} exact ({tie} near-ties)"
 
@@ -90,6 +103,8 @@ def test_air_batch256_invariance_and_golden_prefix(air):
     S, N, eos = int(z["s_len"]), 64, int(z["eos"])
     samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
     prompts = [br.synthetic_prompt(cfg, u, S) for u in (0, 1, 2, 3)]
+    for s in range(256):            # whatever an earlier (failed) test left behind
+        eng.release(s)
     for c in range(0, 256, 16):     # prefill in chunks of 16 prompts (8000 tokens)
         eng.prefill([prompts[(c + i) % 4] for i in range(16)], list(range(c, c + 16)), [samp] * 16)
     eng.decode(N - 1)
@@ -102,7 +117,7 @@ def test_air_batch256_invariance_and_golden_prefix(air):
         tv = z[f"bf16_topv_{u}"]
         k = next((i for i in range(N) if rows[u][i] != g[i]), N)
         if k < N:   # first divergence must be a near-tie of the golden run
-            assert tv[k][0] - tv[k][1] <= 2 * 2.0 ** (np.floor(np.log2(abs(tv[k][0]))) - 7), (u, k, tv[k])
+            assert tv[k][0] - tv[k][1] <= 4 * 2.0 ** (np.floor(np.log2(abs(tv[k][0]))) - 7), (u, k, tv[k])
     for s in range(256):
         eng.release(s)
 
@@ -135,6 +150,8 @@ def test_air_sampling_topk50_full_vocab(air):
     z, cfg, eng = air
     S, eos = int(z["s_len"]), int(z["eos"])
     p = br.synthetic_prompt(cfg, 0, S)
+    for s in range(256):
+        eng.release(s)
     eng.set_debug(True)
     try:
         counts = {}
