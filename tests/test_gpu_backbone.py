@@ -90,7 +90,9 @@ def test_air_teacher_forced_vs_hf_golden(air):
     err = np.array(stats)
     print(f"logit error at golden top-4 ids, bf16 ulps: mean {err.mean():.3f}  p99 {np.percentile(err, 99):.2f}  max {err.max():.2f}; "
           f"{ex} exact + {tie} near-tie of {N}")
-    assert err.mean() <= 0.8 and np.percentile(err, 99) <= 2.5 and err.max() <= 3.0,   # measured: 0.56 / 2.0 / 2.0 (err.mean(), np.percentile(err, 99), err.max())
+    # measured on MI355X: mean 0.56 / p99 2.0 / max 2.0 bf16 ulps
+    assert err.mean() <= 0.8 and np.percentile(err, 99) <= 2.5 and err.max() <= 3.0, \
+        (err.mean(), np.percentile(err, 99), err.max())
     assert ex + tie == N
     assert ex >= 0.7 * N, f"only {ex}/{N} exact ({tie} near-ties)"
 
