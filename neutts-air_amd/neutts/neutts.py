@@ -48,6 +48,29 @@ def _linear_overlap_add(frames: List[np.ndarray], stride: int) -> np.ndarray:
     return mixed / weight_sum
 
 
+class _StreamBlender:
+    """Incremental form of the reference's streaming post-process (ref:neutts/neutts.py:441-448, :461-465): the
+    reference re-blends its whole audio cache for every chunk (O(n^2)); frames are `chunk + 2*overlap` hops long at a
+    stride of `chunk` hops, so only the previous frame can touch the samples a new frame releases.  `push` returns
+    exactly `_linear_overlap_add(all frames)[n_decoded_samples:new_end]` (bit-identical: same operands, same order)."""
+
+    def __init__(self, stride: int):
+        self.stride = stride
+        self.prev: Optional[np.ndarray] = None
+
+    def push(self, frame: np.ndarray, last: bool = False) -> np.ndarray:
+        st = self.stride
+        if self.prev is None:
+            mixed = _linear_overlap_add([frame], stride=st)
+            out = mixed if last else mixed[:st]
+        else:
+            assert self.prev.shape[-1] < 2 * st, "frame longer than two strides: more than one frame overlaps"
+            mixed = _linear_overlap_add([self.prev, frame], stride=st)
+            out = mixed[st:] if last else mixed[st:2 * st]
+        self.prev = frame
+        return out
+
+
 def _device_index(device, what: str) -> int:
     s = str(device)
     if s in ("gpu", "cuda", "hip"):
@@ -107,6 +130,7 @@ class NeuTTS:
         self.streaming_lookforward = 5
         self.streaming_lookback = 50
         self.streaming_stride_samples = self.streaming_frames_per_chunk * self.hop_length
+        self.streaming_overlap_compute = True    # backbone decode of chunk k+1 runs beside the codec pass of chunk k
 
         self._is_quantized_model = False
         self._is_onnx_codec = False
@@ -319,21 +343,29 @@ class NeuTTS:
 
     # ------------------------------------------------------------------------------------------ streaming
     def _infer_stream_hip(self, prompt_ids: List[int], ref_codes: List[int]) -> Generator[np.ndarray, None, None]:
+        """Window / cross-fade semantics of ref:neutts/neutts.py:401-465 (Appendix C of SURVEY.md), token by token.
+        The backbone and the codec are separate engines on separate HIP streams: the next `chunk` decode steps are
+        enqueued (asynchronously) BEFORE the codec pass of the chunk that just became decodable, so the codec runs
+        beside the backbone instead of between its bursts; the host only blocks in `read()`."""
         eng = self.backbone
         self._seed += 1
         eng.prefill([prompt_ids], [0], [self._sampling(len(prompt_ids))])
-        audio_cache: List[np.ndarray] = []
         token_cache: List[int] = list(ref_codes)          # codec codes (the reference caches "<|speech_N|>" strings)
-        n_decoded_samples = 0
         n_decoded_tokens = len(ref_codes)
         n_seen = 0
         hop = self.hop_length
+        stride = self.streaming_stride_samples
         chunk, look_f, look_b, ovl = (self.streaming_frames_per_chunk, self.streaming_lookforward,
                                       self.streaming_lookback, self.streaming_overlap_frames)
+
+        blend = _StreamBlender(stride)
+
         try:
             finished = False
             while not finished:
-                ids, finished = eng.read(0)
+                ids, finished = eng.read(0)               # blocks until the steps enqueued so far are done
+                if not finished and self.streaming_overlap_compute:
+                    eng.decode(chunk)                     # async: runs while the codec below decodes the last chunk
                 new = self._ids_to_codes(ids[n_seen:])
                 n_seen = len(ids)
                 for c in new:
@@ -346,15 +378,10 @@ class NeuTTS:
                         recon = self.codec.engine.decode([token_cache[t0:t1]])[0]
                         if self.watermarker is not None:
                             recon = self.watermarker.apply_watermark(recon, sample_rate=24_000)
-                        audio_cache.append(recon[s0:s1])
-                        mixed = _linear_overlap_add(audio_cache, stride=self.streaming_stride_samples)
-                        end = len(audio_cache) * self.streaming_stride_samples
-                        out = mixed[n_decoded_samples:end]
-                        n_decoded_samples = end
                         n_decoded_tokens += chunk
-                        yield out
-                if not finished:
-                    eng.decode(chunk)          # the codec pass above overlaps nothing yet: see DESIGN.md "next"
+                        yield blend.push(np.array(recon[s0:s1]))
+                if not finished and not self.streaming_overlap_compute:
+                    eng.decode(chunk)                     # serial variant (A/B aid): backbone waits for the codec
             remaining = len(token_cache) - n_decoded_tokens
             if remaining > 0:
                 t0 = max(len(token_cache) - (look_b + ovl + remaining), 0)
@@ -362,10 +389,9 @@ class NeuTTS:
                 recon = self.codec.engine.decode([token_cache[t0:]])[0]
                 if self.watermarker is not None:
                     recon = self.watermarker.apply_watermark(recon, sample_rate=24_000)
-                audio_cache.append(recon[s0:])
-                mixed = _linear_overlap_add(audio_cache, stride=self.streaming_stride_samples)
-                yield mixed[n_decoded_samples:]
+                yield blend.push(np.array(recon[s0:]), last=True)
         finally:
+            eng.sync()
             eng.release(0)
 
 

@@ -171,3 +171,27 @@ def test_infer_stream_matches_reference_windowing(tts):
     want = np.concatenate(out)
     got = np.concatenate(chunks)
     assert got.shape == want.shape and rms(got - want) <= 1e-3
+
+
+@pytest.mark.parametrize("n_frames,last_len", [(1, 7), (2, 1), (5, 13), (9, 27), (4, 40)])
+def test_stream_blender_is_bit_identical_to_full_reblend(n_frames, last_len):
+    """The incremental cross-fade equals the reference's per-chunk re-blend of the whole audio cache
+    (ref:neutts/neutts.py:441-448 main loop, :461-465 final chunk), bit for bit."""
+    from neutts.neutts import _StreamBlender, _linear_overlap_add
+    hop, chunk = 16, 25
+    stride = chunk * hop
+    rng = np.random.default_rng(n_frames * 100 + last_len)
+    frames = [rng.standard_normal(27 * hop).astype(np.float32) for _ in range(n_frames - 1)]
+    frames.append(rng.standard_normal(last_len * hop).astype(np.float32))
+    b = _StreamBlender(stride)
+    cache, n_done = [], 0
+    for i, f in enumerate(frames):
+        last = i == len(frames) - 1
+        cache.append(f)
+        full = _linear_overlap_add(cache, stride=stride)          # what the reference recomputes every chunk
+        want = full[n_done:] if last else full[n_done:len(cache) * stride]
+        n_done = len(cache) * stride
+        got = b.push(f, last=last)
+        assert got.dtype == want.dtype and np.array_equal(got, want)
+    # and the oracle's restatement of _linear_overlap_add agrees with the product's
+    assert np.array_equal(cr.linear_overlap_add(frames, stride), _linear_overlap_add(frames, stride=stride))
