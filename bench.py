@@ -11,8 +11,8 @@ wall time of the K timed steps.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W        # one rank per GPU, RCCL weight broadcast, no step collective
 
-Extra legs on rank 0 at N=1: `roofline` (dominant kernel of the decode step, hipEvent-timed in isolation
-at mid-generation slot state) and `cpu_baseline` (the reference's CPU path for this hot path, one
+Extra legs on rank 0 at N=1: `roofline` (dominant kernel of the decode step, hipEvent-timed on the engine stream
+at mid-generation slot state, cycling over the layers so operands are HBM-cold as inside the step) and `cpu_baseline` (the reference's CPU path for this hot path, one
 utterance, on the box's host cores).
 """
 from __future__ import annotations
@@ -234,7 +234,7 @@ def main():
         step_ms = eng.last_timing()[1] / 8
         rows = []
         for k, name in enumerate(_hip.BackboneEngine.KERNELS):
-            ms, nbytes, nl = eng.time_kernel(k, 20)
+            ms, nbytes, nl = eng.time_kernel(k, 48)   # 2 sweeps over the 24 layers: HBM-cold, like the step
             rows.append((ms * nl, name, ms, nbytes, nl))
             log(f"[roofline] {name:24s} {ms * 1e3:8.1f} us/launch x {nl:3d} = {ms * nl:7.3f} ms/step   "
                 f"{nbytes / 1e6:9.2f} MB/launch   {nbytes / (ms * 1e-3) / 1e9:7.0f} GB/s")

@@ -151,7 +151,9 @@ int ntts_backbone_last_timing(ntts_backbone* e, float* prefill_ms, float* decode
 /* Replay ONE kernel of the decode step `iters` times at the current slot state and report its average
  * duration (hipEvents on the engine stream), its algorithmic HBM bytes per launch and how many times a
  * decode step launches it.  which: 0 paged attention (+RoPE/KV append), 1 QKV GEMM, 2 o_proj GEMM,
- * 3 gate/up GEMM (+SiLU*mul), 4 down_proj GEMM, 5 lm_head GEMM (+argmax partials), 6 add+RMSNorm. */
+ * 3 gate/up GEMM (+SiLU*mul), 4 down_proj GEMM, 5 lm_head GEMM (+argmax partials), 6 add+RMSNorm.
+ * Replay k runs on layer (k mod num_layers): consecutive replays touch different weights / KV pools, as
+ * consecutive launches inside a decode step do, so the operands come from HBM and not from the Infinity Cache. */
 int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_t iters, float* avg_ms, double* alg_bytes,
                               int32_t* launches_per_step);
 /* Algorithmic HBM bytes of one decode step at the current slot lengths (SURVEY.md 8d formula:

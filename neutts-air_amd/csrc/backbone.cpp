@@ -977,17 +977,20 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
     for (int b = 0; b < B; ++b)
         if (sst[b] == SLOT_RUNNING) kv_layer += ((double)pos[b] + 1) * 2 * KD * 2.0;
     const double act = (double)B * 2.0;
-    auto run = [&](int k) {
+    // Every replay works on the NEXT layer's weights / KV pool, as consecutive launches of this kernel do inside the
+    // decode step: one layer's operands (84 MB of KV at batch 256) would sit in the 256 MB Infinity Cache when replayed
+    // alone, all layers together (2 GB) do not -- so the timing below is HBM-cold like the in-graph launches.
+    auto run = [&](int k, int i) {
         switch (k) {
-            case 0: k_attn(e, 0); break;                        // paged decode attention (+RoPE, +KV append)
-            case 1: if (e->fused) kf_qkv(e, 0); else k_qkv(e, 0); break;
-            case 2: if (e->fused) kf_o_proj_scratch(e, 0); else k_o_proj(e, 0); break;
-            case 3: if (e->fused) kf_gate_up(e, 0); else k_gate_up(e, 0); break;
-            case 4: k_down(e, 0); break;
+            case 0: k_attn(e, i); break;                        // paged decode attention (+RoPE, +KV append)
+            case 1: if (e->fused) kf_qkv(e, i); else k_qkv(e, i); break;
+            case 2: if (e->fused) kf_o_proj_scratch(e, i); else k_o_proj(e, i); break;
+            case 3: if (e->fused) kf_gate_up(e, i); else k_gate_up(e, i); break;
+            case 4: k_down(e, i); break;
             case 5: k_lm_head(e, false); break;
             case 6:   // scratch outputs
                 if (e->fused) k_add_norm(e, F, e->ks_d, nullptr, e->o_pf, nullptr);
-                else k_add_norm(e, QD, e->ks_o, e->layers[0].ln2, e->o_pf, e->xn_pf);
+                else k_add_norm(e, QD, e->ks_o, e->layers[i].ln2, e->o_pf, e->xn_pf);
                 break;
             default: break;
         }
@@ -1006,9 +1009,9 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
         default: return fail(e, NTTS_EINVAL, "unknown kernel id %d", which);
     }
     if (which == 6 && B > e->Tmax) return fail(e, NTTS_EINVAL, "scratch too small");
-    run(which);  // warm
+    run(which, L - 1);  // warm (code, TLBs); the timed replays start from layer 0
     HIPCHK(e, hipEventRecord(e->ev[2], st));
-    for (int i = 0; i < iters; ++i) run(which);
+    for (int i = 0; i < iters; ++i) run(which, i % L);
     HIPCHK(e, hipEventRecord(e->ev[3], st));
     HIPCHK(e, hipStreamSynchronize(st));
     float ms = 0;
