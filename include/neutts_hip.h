@@ -117,6 +117,24 @@ typedef struct ntts_sampling {
 int ntts_backbone_prefill(ntts_backbone* e, int32_t n, const int32_t* ids, const int32_t* lens,
                           const int32_t* slots, const ntts_sampling* samp);
 
+/* Prefix sharing.  The reference rebuilds, for every utterance of a speaker, a prompt that begins
+ * with the same tokens -- chat header + phonemised reference text (ref:neutts/neutts.py:307,315-325) -- and runs the
+ * whole prompt through the model again (ref:neutts/neutts.py:338-347 via generate()).  Here prompt i may name a donor:
+ * a RUNNING slot, or a prompt given earlier in this same call (by its slot), whose prompt starts with the same
+ * shared_len[i] tokens (checked; NTTS_EINVAL on a mismatch).  The KV pages holding the first
+ * floor(min(shared_len, donor length, lens[i]-1) / NTTS_PAGE_TOKENS) * NTTS_PAGE_TOKENS tokens are then shared
+ * (reference-counted, never written again) and only the remaining tokens of prompt i are computed.  `ids` / `lens`
+ * still describe the FULL prompts; only the computed tokens count against max_prefill_tokens.  donor_slot[i] < 0 = no
+ * sharing for prompt i.  Results are identical to ntts_backbone_prefill: every K/V row and every query sees the same
+ * operands in the same order (tests/test_emu_prefix.py, tests/test_gpu_backbone.py). */
+int ntts_backbone_prefill_shared(ntts_backbone* e, int32_t n, const int32_t* ids, const int32_t* lens,
+                                 const int32_t* slots, const ntts_sampling* samp, const int32_t* donor_slot,
+                                 const int32_t* shared_len);
+/* KV pool occupancy and prompt-token accounting since create: free / total pages, prompt tokens pushed through the
+ * layers and prompt tokens served from shared pages.  Any out pointer may be NULL.  Host state only (no sync). */
+int ntts_backbone_kv_stats(ntts_backbone* e, int32_t* free_pages, int32_t* total_pages, int64_t* prompt_tokens_computed,
+                           int64_t* prompt_tokens_shared);
+
 /* Run `n_steps` decode steps over all `max_batch` rows (one hipGraph replay per step).  Rows whose
  * slot is free or finished are carried along masked: they attend to nothing and emit nothing.
  * KV pages for up to n_steps more tokens per running slot are reserved first (NTTS_ENOMEM if the

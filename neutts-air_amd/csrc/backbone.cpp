@@ -34,7 +34,8 @@ struct HostSlot {
     int state = SLOT_FREE;      // host view: FREE / RUNNING (may already be finished on device)
     int prompt_len = 0, max_len = 0;
     int pos_upper = 0;          // upper bound of the device-side pos
-    std::vector<int> pages;
+    std::vector<int> pages;     // KV pages of positions [32k, 32k+32); the leading ones may be shared (page_ref > 1)
+    std::vector<int> prompt;    // prompt ids (what a later prompt must match to share this slot's prefix pages)
 };
 
 struct ntts_backbone {
@@ -60,6 +61,7 @@ struct ntts_backbone {
     size_t layer_stride = 0, kv_half = 0;  // elements
     int num_pages = 0;
     std::vector<int> free_pages;
+    std::vector<int> page_ref;   // owners per page: 1 private, > 1 a prefix shared by several slots (read-only by construction)
     std::vector<HostSlot> slots;
 
     // device slot state
@@ -98,6 +100,7 @@ struct ntts_backbone {
     bool graph_tried = false, use_graph = true;
     hipEvent_t ev[4]{};
     bool have_pf_time = false, have_dec_time = false;
+    long long pf_tokens_computed = 0, pf_tokens_shared = 0;   // prompt tokens pushed through the layers / served from shared pages
 };
 
 static int fail(ntts_backbone* e, int code, const char* fmt, ...) {
@@ -212,6 +215,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     CR_HIP(hipMemset(e->kv, 0, (size_t)L * e->layer_stride * sizeof(bf16_t)));
     e->free_pages.reserve(e->num_pages);
     for (int p = e->num_pages - 1; p >= 0; --p) e->free_pages.push_back(p);
+    e->page_ref.assign(e->num_pages, 0);
     e->slots.resize(B);
 
     // ---- slot state
@@ -610,20 +614,36 @@ static int alloc_pages(ntts_backbone* e, HostSlot& s, int tokens) {
     const int need = (tokens + kPage - 1) / kPage;
     while ((int)s.pages.size() < need) {
         if (e->free_pages.empty()) return NTTS_ENOMEM;
-        s.pages.push_back(e->free_pages.back());
+        const int pg = e->free_pages.back();
         e->free_pages.pop_back();
+        e->page_ref[pg] = 1;
+        s.pages.push_back(pg);
     }
     return NTTS_OK;
 }
+// give back the slot's pages from index `keep` on; a page returns to the pool when its last owner lets go
+static void drop_pages(ntts_backbone* e, HostSlot& s, size_t keep = 0) {
+    while (s.pages.size() > keep) {
+        const int pg = s.pages.back();
+        s.pages.pop_back();
+        if (--e->page_ref[pg] == 0) e->free_pages.push_back(pg);
+    }
+}
 
-extern "C" int ntts_backbone_prefill(ntts_backbone* e, int32_t n, const int32_t* ids, const int32_t* lens,
-                                     const int32_t* slots, const ntts_sampling* samp) {
+// Prompt pass.  With donor_slot / shared_len (ntts_backbone_prefill_shared): prompt i re-uses the KV pages that hold the
+// first pos0[i] = floor(shared_len[i] / 32) * 32 tokens of its donor's prompt -- only the remaining tokens are packed,
+// embedded and pushed through the layers; their queries attend to the shared pages exactly as they would to their own.
+static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const int32_t* lens, const int32_t* slots,
+                        const ntts_sampling* samp, const int32_t* donor_slot, const int32_t* shared_len) {
     if (!e || n < 1 || !ids || !lens || !slots || !samp) return fail(e, NTTS_EINVAL, "null/empty argument");
+    if ((donor_slot == nullptr) != (shared_len == nullptr)) return fail(e, NTTS_EINVAL, "donor_slot and shared_len go together");
     if (!e->finalized) return fail(e, NTTS_ESTATE, "weights not finalised");
     HIPCHK(e, hipSetDevice(e->device));
     const ntts_backbone_config& c = e->cfg;
     const int B = c.max_batch, H = e->H, F = e->F, QD = c.num_heads * 64;
-    long T = 0;
+    long T = 0, Tfull = 0;
+    std::vector<int> pos0(n, 0), id_off(n, 0);
+    for (int i = 0; i < n; ++i) { id_off[i] = (int)Tfull; Tfull += lens[i] > 0 ? lens[i] : 0; }
     for (int i = 0; i < n; ++i) {
         if (slots[i] < 0 || slots[i] >= B) return fail(e, NTTS_EINVAL, "slot %d out of range", slots[i]);
         if (e->slots[slots[i]].state != SLOT_FREE) return fail(e, NTTS_ESTATE, "slot %d is busy", slots[i]);
@@ -635,21 +655,44 @@ extern "C" int ntts_backbone_prefill(ntts_backbone* e, int32_t n, const int32_t*
         if (samp[i].do_sample && (samp[i].top_k < 1 || !(samp[i].temperature > 0.f)))
             return fail(e, NTTS_EINVAL, "prompt %d: do_sample needs top_k >= 1 and temperature > 0 (got %d, %g)", i, samp[i].top_k, samp[i].temperature);
         if (samp[i].eos_token_id < 0 || samp[i].eos_token_id >= c.vocab_size) return fail(e, NTTS_EINVAL, "eos id out of range");
-        T += lens[i];
+        if (donor_slot && donor_slot[i] >= 0) {
+            // the donor is a running slot, or a prompt given EARLIER in this call (its pages are filled by the same
+            // launches: the rope/KV-write kernel of a layer completes before that layer's attention kernel starts)
+            const int d = donor_slot[i];
+            if (d >= B) return fail(e, NTTS_EINVAL, "prompt %d: donor slot %d out of range", i, d);
+            const int* dp = nullptr;
+            int dlen = 0;
+            for (int j = 0; j < i; ++j)
+                if (slots[j] == d) { dp = ids + id_off[j]; dlen = lens[j]; }
+            if (!dp) {
+                if (e->slots[d].state != SLOT_RUNNING) return fail(e, NTTS_ESTATE, "prompt %d: donor slot %d holds no prompt", i, d);
+                dp = e->slots[d].prompt.data();
+                dlen = (int)e->slots[d].prompt.size();
+            }
+            int sl = shared_len[i];
+            if (sl < 0) return fail(e, NTTS_EINVAL, "prompt %d: negative shared_len", i);
+            if (sl > dlen) sl = dlen;
+            if (sl > lens[i] - 1) sl = lens[i] - 1;          // the last position is always computed (it yields the logits)
+            for (int t = 0; t < sl; ++t)
+                if (dp[t] != ids[id_off[i] + t])
+                    return fail(e, NTTS_EINVAL, "prompt %d does not start with the first %d tokens of slot %d's prompt (token %d differs)", i, sl, d, t);
+            pos0[i] = sl / kPage * kPage;                       // whole pages only: a page is never written by two slots
+        }
+        T += lens[i] - pos0[i];
     }
     if (T > e->Tmax) return fail(e, NTTS_EINVAL, "%ld prompt tokens exceed max_prefill_tokens %d", T, e->Tmax);
-    for (long t = 0; t < T; ++t)
+    for (long t = 0; t < Tfull; ++t)
         if (ids[t] < 0 || ids[t] >= c.vocab_size) return fail(e, NTTS_EINVAL, "token id %d out of range", ids[t]);
 
     // ---- pages (roll back on exhaustion)
     for (int i = 0; i < n; ++i) {
         HostSlot& s = e->slots[slots[i]];
+        if (pos0[i] > 0) {                                      // borrow the donor's leading pages
+            const HostSlot& d = e->slots[donor_slot[i]];
+            for (int k = 0; k < pos0[i] / kPage; ++k) { s.pages.push_back(d.pages[k]); e->page_ref[d.pages[k]]++; }
+        }
         if (alloc_pages(e, s, lens[i]) != NTTS_OK) {
-            for (int j = 0; j <= i; ++j) {
-                HostSlot& r = e->slots[slots[j]];
-                for (int pg : r.pages) e->free_pages.push_back(pg);
-                r.pages.clear();
-            }
+            for (int j = 0; j <= i; ++j) drop_pages(e, e->slots[slots[j]]);
             return fail(e, NTTS_ENOMEM, "KV page pool exhausted (%d pages)", e->num_pages);
         }
     }
@@ -657,18 +700,19 @@ extern "C" int ntts_backbone_prefill(ntts_backbone* e, int32_t n, const int32_t*
     //                  [tile_seq nt][tile_q0 nt][bt_rows n*max_pages]
     std::vector<int> tile_seq, tile_q0;
     std::vector<int> m;
-    m.reserve(2 * T + 8 * n);
-    m.insert(m.end(), ids, ids + T);
+    m.reserve(2 * T + 16 * n);
+    for (int i = 0; i < n; ++i) m.insert(m.end(), ids + id_off[i] + pos0[i], ids + id_off[i] + lens[i]);   // packed: new tokens only
     const size_t o_tok_seq = m.size();
-    for (int i = 0; i < n; ++i) m.insert(m.end(), lens[i], i);
+    for (int i = 0; i < n; ++i) m.insert(m.end(), lens[i] - pos0[i], i);
     const size_t o_base = m.size();
     long acc = 0;
     for (int i = 0; i < n; ++i) {
         m.push_back((int)acc);
-        for (int q = 0; q < lens[i]; q += 64) { tile_seq.push_back(i); tile_q0.push_back(q); }
-        acc += lens[i];
+        for (int q = pos0[i]; q < lens[i]; q += 64) { tile_seq.push_back(i); tile_q0.push_back(q); }
+        acc += lens[i] - pos0[i];
     }
     const size_t o_len = m.size();   m.insert(m.end(), lens, lens + n);
+    const size_t o_pos0 = m.size();  m.insert(m.end(), pos0.begin(), pos0.end());
     const size_t o_slot = m.size();  m.insert(m.end(), slots, slots + n);
     const size_t o_min = m.size();   for (int i = 0; i < n; ++i) m.push_back(samp[i].min_new_tokens);
     const size_t o_max = m.size();   for (int i = 0; i < n; ++i) m.push_back(samp[i].max_length);
@@ -680,7 +724,7 @@ extern "C" int ntts_backbone_prefill(ntts_backbone* e, int32_t n, const int32_t*
     for (int i = 0; i < n; ++i) { m.push_back((int)(uint32_t)samp[i].seed); m.push_back((int)(uint32_t)(samp[i].seed >> 32)); }
     const size_t o_last = m.size();
     acc = 0;
-    for (int i = 0; i < n; ++i) { acc += lens[i]; m.push_back((int)acc - 1); }
+    for (int i = 0; i < n; ++i) { acc += lens[i] - pos0[i]; m.push_back((int)acc - 1); }
     const size_t o_tseq = m.size();  m.insert(m.end(), tile_seq.begin(), tile_seq.end());
     const size_t o_tq0 = m.size();   m.insert(m.end(), tile_q0.begin(), tile_q0.end());
     const size_t o_bt = m.size();
@@ -688,7 +732,10 @@ extern "C" int ntts_backbone_prefill(ntts_backbone* e, int32_t n, const int32_t*
         const HostSlot& s = e->slots[slots[i]];
         for (int k = 0; k < e->max_pages; ++k) m.push_back(k < (int)s.pages.size() ? s.pages[k] : 0);
     }
-    if (m.size() > e->meta_cap) return fail(e, NTTS_EINVAL, "prefill meta block too large");
+    if (m.size() > e->meta_cap) {
+        for (int i = 0; i < n; ++i) drop_pages(e, e->slots[slots[i]]);
+        return fail(e, NTTS_EINVAL, "prefill meta block too large");
+    }
     {   // sampling requests need the bf16 logits rows: allocate on first use; the captured decode step bakes the pointer
         int add = 0;
         for (int i = 0; i < n; ++i) add += samp[i].do_sample ? 1 : 0;
@@ -704,7 +751,7 @@ extern "C" int ntts_backbone_prefill(ntts_backbone* e, int32_t n, const int32_t*
     HIPCHK(e, hipMemcpyAsync(e->meta_dev, m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(e, hipStreamSynchronize(st));  // m is pageable host memory
     const int* md = e->meta_dev;
-    PrefillMeta meta{md + o_base, md + o_len, md + o_slot, md + o_tok_seq, md + o_tseq, md + o_tq0};
+    PrefillMeta meta{md + o_base, md + o_len, md + o_pos0, md + o_slot, md + o_tok_seq, md + o_tseq, md + o_tq0};
 
     HIPCHK(e, hipEventRecord(e->ev[0], st));
     PrefillInit pi{};
@@ -756,7 +803,32 @@ extern "C" int ntts_backbone_prefill(ntts_backbone* e, int32_t n, const int32_t*
     for (int i = 0; i < n; ++i) {
         HostSlot& s = e->slots[slots[i]];
         s.state = SLOT_RUNNING; s.prompt_len = lens[i]; s.max_len = samp[i].max_length; s.pos_upper = lens[i];
+        s.prompt.assign(ids + id_off[i], ids + id_off[i] + lens[i]);
     }
+    e->pf_tokens_computed += T;
+    e->pf_tokens_shared += Tfull - T;
+    return NTTS_OK;
+}
+
+extern "C" int ntts_backbone_prefill(ntts_backbone* e, int32_t n, const int32_t* ids, const int32_t* lens,
+                                     const int32_t* slots, const ntts_sampling* samp) {
+    return prefill_impl(e, n, ids, lens, slots, samp, nullptr, nullptr);
+}
+
+extern "C" int ntts_backbone_prefill_shared(ntts_backbone* e, int32_t n, const int32_t* ids, const int32_t* lens,
+                                            const int32_t* slots, const ntts_sampling* samp, const int32_t* donor_slot,
+                                            const int32_t* shared_len) {
+    if (!donor_slot || !shared_len) return fail(e, NTTS_EINVAL, "null argument");
+    return prefill_impl(e, n, ids, lens, slots, samp, donor_slot, shared_len);
+}
+
+extern "C" int ntts_backbone_kv_stats(ntts_backbone* e, int32_t* free_pages, int32_t* total_pages, int64_t* prompt_tokens_computed,
+                                      int64_t* prompt_tokens_shared) {
+    if (!e) return NTTS_EINVAL;
+    if (free_pages) *free_pages = (int32_t)e->free_pages.size();
+    if (total_pages) *total_pages = e->num_pages;
+    if (prompt_tokens_computed) *prompt_tokens_computed = e->pf_tokens_computed;
+    if (prompt_tokens_shared) *prompt_tokens_shared = e->pf_tokens_shared;
     return NTTS_OK;
 }
 
@@ -776,10 +848,7 @@ extern "C" int ntts_backbone_decode(ntts_backbone* e, int32_t n_steps) {
         const size_t before = s.pages.size();
         if (alloc_pages(e, s, upto) != NTTS_OK) {
             undo.emplace_back(b, before);
-            for (auto& u : undo) {
-                HostSlot& r = e->slots[u.first];
-                while (r.pages.size() > u.second) { e->free_pages.push_back(r.pages.back()); r.pages.pop_back(); }
-            }
+            for (auto& u : undo) drop_pages(e, e->slots[u.first], u.second);
             return fail(e, NTTS_ENOMEM, "KV page pool exhausted (%d pages)", e->num_pages);
         }
         undo.emplace_back(b, before);
@@ -880,8 +949,8 @@ extern "C" int ntts_backbone_release(ntts_backbone* e, int32_t slot) {
     // Stream-ordered, no host sync: the slot's pages go back to the pool now, but anything that re-uses them is
     // enqueued on the same stream behind the work that still reads them.
     HostSlot& s = e->slots[slot];
-    for (int pg : s.pages) e->free_pages.push_back(pg);
-    s.pages.clear();
+    drop_pages(e, s);
+    s.prompt.clear();
     if (s.sampling) { s.sampling = false; e->n_sampling--; }
     s.state = SLOT_FREE;
     static_assert(SLOT_FREE == 0, "release writes the state with a memset");

@@ -16,11 +16,13 @@ namespace ntts {
 
 struct PrefillMeta {           // one entry per prompt of the packed batch (device arrays)
     const int* tok_base;       // [n] first packed row of prompt i
-    const int* seq_len;        // [n]
+    const int* seq_len;        // [n] TOTAL context length after this pass (cached prefix + packed tokens)
+    const int* pos0;           // [n] tokens of the prompt already in its KV pages (shared prefix; multiple of the page
+                               //     size): the packed rows of prompt i are positions pos0[i] .. seq_len[i]-1
     const int* slot;           // [n] decode slot -> block_table row
     const int* tok_seq;        // [T] prompt index of packed row t
     const int* tile_seq;       // [n_tiles] work list of 64-row query tiles
-    const int* tile_q0;        // [n_tiles]
+    const int* tile_q0;        // [n_tiles] ABSOLUTE position of the tile's first query (pos0 + 64 k)
 };
 
 struct RopeWriteArgs {
@@ -39,7 +41,7 @@ struct RopeWriteArgs {
 NTTS_KERNEL(256) void rope_kv_write_kernel(RopeWriteArgs p) {
     const int t = blockIdx.x;
     const int sq = p.meta.tok_seq[t];
-    const int pos = t - p.meta.tok_base[sq];
+    const int pos = p.meta.pos0[sq] + t - p.meta.tok_base[sq];
     const int* bt = p.block_table + (long)p.meta.slot[sq] * p.max_pages;
     const long pg = bt[pos / kPage];
     const int slot = pos % kPage;
@@ -89,7 +91,7 @@ NTTS_KERNEL(256) void attn_prefill_kernel(AttnPrefillArgs p) {
     const int g = lane >> 4, l15 = lane & 15;
     const int sq = p.meta.tile_seq[blockIdx.x];
     const int S = p.meta.seq_len[sq];
-    const int base = p.meta.tok_base[sq];
+    const int base = p.meta.tok_base[sq] - p.meta.pos0[sq];   // packed row of absolute position q is base + q
     const int h = blockIdx.y;
     const int kvh = h / (p.nh / p.nkv);
     const int* bt = p.block_table + (long)p.meta.slot[sq] * p.max_pages;
@@ -205,7 +207,7 @@ NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
     const int g = lane >> 4, l15 = lane & 15;
     const int sq = p.meta.tile_seq[blockIdx.x];
     const int S = p.meta.seq_len[sq];
-    const int base = p.meta.tok_base[sq];
+    const int base = p.meta.tok_base[sq] - p.meta.pos0[sq];   // packed row of absolute position q is base + q
     const int kvh = blockIdx.y;
     const int group = p.nh / p.nkv;
     const int h0 = kvh * group + blockIdx.z * GH;            // first query head of this pass

@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "libneutts_hip.so")
 
 NTTS_DT_F32, NTTS_DT_BF16, NTTS_DT_I32 = 0, 1, 2
+NTTS_PAGE_TOKENS = 32            # include/neutts_hip.h
 PAGE_TOKENS = 32
 ERRORS = {-1: "EINVAL", -2: "ENODEV", -3: "ENOMEM", -4: "ESTATE", -5: "EHIP"}
 
@@ -78,6 +79,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_backbone_arena_copy": (C.c_int, [p, p, C.c_size_t, C.c_int]),
         "ntts_backbone_time_kernel": (C.c_int, [p, i32, i32, C.POINTER(f32), C.POINTER(C.c_double), C.POINTER(i32)]),
         "ntts_backbone_prefill": (C.c_int, [p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(SamplingC)]),
+        "ntts_backbone_prefill_shared": (C.c_int, [p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(SamplingC),
+                                                   C.POINTER(i32), C.POINTER(i32)]),
+        "ntts_backbone_kv_stats": (C.c_int, [p, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64), C.POINTER(i64)]),
         "ntts_backbone_decode": (C.c_int, [p, i32]),
         "ntts_backbone_read": (C.c_int, [p, i32, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(i32)]),
         "ntts_backbone_read_all": (C.c_int, [p, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(i32)]),
@@ -220,15 +224,32 @@ class BackboneEngine:
         self._chk(self.lib.ntts_backbone_adopt_arena(self.h))
 
     # -- requests
-    def prefill(self, prompts: Sequence[Sequence[int]], slots: Sequence[int], sampling: Sequence[Sampling]):
+    def prefill(self, prompts: Sequence[Sequence[int]], slots: Sequence[int], sampling: Sequence[Sampling],
+                donors: Optional[Sequence[Optional[tuple]]] = None):
+        """donors (optional): per prompt None or (donor_slot, shared_len) -- re-use the KV pages of the first
+        `shared_len` tokens (rounded down to whole pages) of a running slot / an earlier prompt of this call whose
+        prompt starts with the same tokens (include/neutts_hip.h: ntts_backbone_prefill_shared)."""
         n = len(prompts)
         lens = np.array([len(p) for p in prompts], dtype=np.int32)
         ids = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.int32) for p in prompts]))
         sl = np.asarray(slots, dtype=np.int32)
         sc = (SamplingC * n)(*[s.to_c() for s in sampling])
         i32p = C.POINTER(C.c_int32)
-        self._chk(self.lib.ntts_backbone_prefill(self.h, n, ids.ctypes.data_as(i32p), lens.ctypes.data_as(i32p),
-                                                 sl.ctypes.data_as(i32p), sc))
+        if donors is None or all(d is None for d in donors):
+            self._chk(self.lib.ntts_backbone_prefill(self.h, n, ids.ctypes.data_as(i32p), lens.ctypes.data_as(i32p),
+                                                     sl.ctypes.data_as(i32p), sc))
+            return
+        ds = np.array([-1 if d is None else d[0] for d in donors], dtype=np.int32)
+        dl = np.array([0 if d is None else d[1] for d in donors], dtype=np.int32)
+        self._chk(self.lib.ntts_backbone_prefill_shared(self.h, n, ids.ctypes.data_as(i32p), lens.ctypes.data_as(i32p),
+                                                        sl.ctypes.data_as(i32p), sc, ds.ctypes.data_as(i32p),
+                                                        dl.ctypes.data_as(i32p)))
+
+    def kv_stats(self) -> dict:
+        fp, tp, tc, ts = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64()
+        self._chk(self.lib.ntts_backbone_kv_stats(self.h, C.byref(fp), C.byref(tp), C.byref(tc), C.byref(ts)))
+        return {"free_pages": fp.value, "total_pages": tp.value, "prompt_tokens_computed": tc.value,
+                "prompt_tokens_shared": ts.value}
 
     def decode(self, n_steps: int = 1):
         self._chk(self.lib.ntts_backbone_decode(self.h, n_steps))
@@ -286,37 +307,63 @@ class BackboneEngine:
 
     # -- continuous batching (host scheduler): keep every slot busy until all prompts are done
     def generate(self, prompts: Sequence[Sequence[int]], sampling, steps_per_poll: int = 16,
-                 prefill_token_budget: Optional[int] = None) -> List[List[int]]:
+                 prefill_token_budget: Optional[int] = None, share_prefix: bool = False) -> List[List[int]]:
         """Batched equivalent of calling ref:neutts/neutts.py:338-351 once per prompt.
-        Returns the NEW ids of each prompt (prompt stripped), in order."""
+        Returns the NEW ids of each prompt (prompt stripped), in order.
+        share_prefix=True: a prompt that starts like one already in flight (same speaker: chat header + reference
+        text, ref:neutts/neutts.py:307,315-325) re-uses that slot's KV pages for the common whole pages."""
         if isinstance(sampling, Sampling):
             sampling = [sampling] * len(prompts)
         budget = prefill_token_budget or self.cfg.get("max_prefill_tokens", 0) or 16384
         results: List[Optional[List[int]]] = [None] * len(prompts)
         free = list(range(self.max_batch))
         owner: Dict[int, int] = {}
+        anchors: List[tuple] = []       # (slot, prompt as int32 array) of live slots that later prompts are compared with
+        arrs = [np.asarray(p, dtype=np.int32) for p in prompts] if share_prefix else None
+
+        def find_donor(i):
+            best = None
+            for slot, arr in anchors:
+                m = min(len(arr), len(arrs[i]) - 1)
+                if m < NTTS_PAGE_TOKENS:
+                    continue
+                neq = np.flatnonzero(arr[:m] != arrs[i][:m])
+                lcp = int(neq[0]) if len(neq) else m
+                if lcp >= NTTS_PAGE_TOKENS and (best is None or lcp > best[1]):
+                    best = (slot, lcp)
+            return best
+
         nxt = 0
         while nxt < len(prompts) or owner:
             # admit as many waiting prompts as slots / prefill workspace allow
             while nxt < len(prompts) and free:
-                batch, used = [], 0
-                while nxt < len(prompts) and free and used + len(prompts[nxt]) <= budget:
+                batch, used, donors = [], 0, []
+                while nxt < len(prompts) and free:
+                    d = find_donor(nxt) if share_prefix else None
+                    cost = len(prompts[nxt]) - (d[1] // NTTS_PAGE_TOKENS * NTTS_PAGE_TOKENS if d else 0)
+                    if used + cost > budget:
+                        break
                     s = free.pop()
                     batch.append((nxt, s))
-                    used += len(prompts[nxt])
+                    donors.append(d)
+                    used += cost
                     owner[s] = nxt
+                    if share_prefix and d is None and len(anchors) < 16:
+                        anchors.append((s, arrs[nxt]))      # a new beginning: later prompts may share it
                     nxt += 1
                 if not batch:
                     if not owner:
                         raise ValueError("prompt longer than max_prefill_tokens")
                     break
-                self.prefill([prompts[i] for i, _ in batch], [s for _, s in batch], [sampling[i] for i, _ in batch])
+                self.prefill([prompts[i] for i, _ in batch], [s for _, s in batch], [sampling[i] for i, _ in batch],
+                             donors if share_prefix else None)
             st, _ = self.poll()
             for s in list(owner):
                 if st[s] == 2:  # finished
                     ids, _ = self.read(s)
                     results[owner.pop(s)] = ids
-                    self.release(s)
+                    self.release(s)                          # shared pages live on until their last user is released
+                    anchors = [a for a in anchors if a[0] != s]
                     free.append(s)
             if owner and any(st[s] == 1 for s in owner):
                 self.decode(steps_per_poll)

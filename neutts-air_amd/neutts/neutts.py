@@ -283,7 +283,10 @@ class NeuTTS:
     def generate_codes(self, prompts: Sequence[Sequence[int]]) -> List[List[int]]:
         """Batched equivalent of `_infer_torch` (ref:neutts/neutts.py:334-352): new token ids per prompt."""
         self._seed += 1
-        return self.backbone.generate(prompts, [self._sampling(len(p), i) for i, p in enumerate(prompts)])
+        # utterances of one speaker start with the same tokens (chat header + reference-text phones, ref :307,:315-325):
+        # the engine keeps one copy of those KV pages and computes only what differs
+        return self.backbone.generate(prompts, [self._sampling(len(p), i) for i, p in enumerate(prompts)],
+                                      share_prefix=len(prompts) > 1)
 
     def _ids_to_codes(self, ids: Sequence[int]) -> List[int]:
         """ref :349 (tokenizer.decode) + :276 (regex): keep `<|speech_N|>` tokens, N = id - id(<|speech_0|>)."""
