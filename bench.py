@@ -11,9 +11,9 @@ wall time of the K timed steps.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W        # one rank per GPU, RCCL weight broadcast, no step collective
 
-Extra legs on rank 0 at N=1: `roofline` (dominant kernel of the decode step, hipEvent-timed on the engine stream
-at mid-generation slot state, cycling over the layers so operands are HBM-cold as inside the step) and `cpu_baseline` (the reference's CPU path for this hot path, one
-utterance, on the box's host cores).
+Extra legs on rank 0 at N=1: `roofline` (dominant kernel of the decode step, hipEvent-timed on the engine
+stream at mid-generation slot state, cycling over the layers so operands are HBM-cold as inside the step) and
+`cpu_baseline` (the reference's CPU path for this hot path, one utterance, on the box's host cores).
 """
 from __future__ import annotations
 
@@ -178,20 +178,21 @@ def main():
         if collect:
             ph["decode"] = eng.last_timing()[1]
         th = time.time()
-        ids, fin = eng.read_all()
-        assert all(len(x) == N for x in ids) and all(fin), "bench run did not produce the expected tokens"
+        ids, n_new, fin = eng.read_all_array()            # [B, max_context] int32; numpy end to end, no Python lists
+        assert (n_new == N).all() and fin.all(), "bench run did not produce the expected tokens"
         for s in range(B):
             eng.release(s)
+        ids = ids[:, :N]
         wavs = None
         if codec is not None:
             # random weights do not stay in the speech range -> code = id mod 65536
-            codes = [[t % n_codes for t in x] for x in ids]
+            codes = ids % n_codes
             ph["handoff_host"] = (time.time() - th) * 1e3
             tc = time.time()
-            wavs = codec.decode(codes, reuse_output=True)    # waveforms land in the engine's pinned host buffer
+            wavs = codec.decode_array(codes, reuse_output=True)   # waveforms land in the engine's pinned host buffer
             ph["codec_call_wall"] = (time.time() - tc) * 1e3
             ph["codec"] = codec.last_timing()
-            assert len(wavs) == B and all(wv.shape[0] == ccfg.hop_length * N for wv in wavs)
+            assert wavs.shape == (B, ccfg.hop_length * N)
         return ph, ids, wavs
 
     def barrier():
@@ -218,7 +219,7 @@ def main():
     # ---- untimed extra legs (phase split, roofline of the dominant kernel, CPU baseline)
     ph, ids, wavs = one_step(collect=True)
     if wavs is not None:
-        assert all(np.isfinite(wv).all() for wv in wavs[:4]), "non-finite waveform"
+        assert np.isfinite(wavs[:4]).all(), "non-finite waveform"
     roof = None
     step_info = None
     if rank == 0 and not a.no_roofline:

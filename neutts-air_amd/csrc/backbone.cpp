@@ -84,6 +84,7 @@ struct ntts_backbone {
     int st_qkv = 4, st_o = 4, st_gu = 3, st_d = 4;   // LDS ring depth of each skinny decode GEMM
     int head_stages = 2, l_stages = 2, pf_gh = 4, attn_depth = 1, gu_tile = 0;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
     bool gu_large = false, head_large = true, pf_attn_simple = false, use_xl = true, head_xl = false;
+    bool pf_prune_last = true;   // prefill, last layer: attention / o_proj / MLP only for each prompt's last position
     // EXPERIMENTAL (off): RMSNorm fused into the QKV / gate-up GEMM prologues, residual into o_proj's epilogue
     // (gemm_xpanel_kernel).  Parity-clean but slower on MI355X at batch 256: one 4-wave workgroup per CU cannot
     // overlap its LDS-read -> MFMA chains (2.33 vs 1.95 ms per step), see DESIGN.md.
@@ -253,6 +254,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->l_stages = env_int("NTTS_L_STAGES", 2);
     e->gu_large = env_int("NTTS_GU_LARGE", 0) != 0;
     e->pf_attn_simple = env_int("NTTS_PREFILL_ATTN_SIMPLE", 0) != 0;
+    e->pf_prune_last = env_int("NTTS_PF_PRUNE_LAST", 1) != 0;
     e->use_xl = env_int("NTTS_XL", 1) != 0;
     e->head_xl = env_int("NTTS_HEAD_XL", B > 128 ? 1 : 0) != 0;
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -289,7 +291,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     CR_HIP(hipMalloc((void**)&e->attn_pf, T * c->num_heads * 64 * 2));
     CR_HIP(hipMalloc((void**)&e->o_pf, T * H * 2));
     CR_HIP(hipMalloc((void**)&e->act_pf, T * F * 2));
-    e->meta_cap = 2 * T + (size_t)B * (8 + e->max_pages) + (T / 64 + B) * 2 + 3 * (size_t)B * e->max_pages + 64;
+    e->meta_cap = 2 * T + (size_t)B * (16 + e->max_pages) + (T / 64 + B) * 2 + 3 * (size_t)B * e->max_pages + 64;
     CR_HIP(hipMalloc((void**)&e->meta_dev, e->meta_cap * sizeof(int)));
     CR_HIP(hipDeviceSynchronize());
     *out = e;
@@ -727,6 +729,9 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
     for (int i = 0; i < n; ++i) { acc += lens[i] - pos0[i]; m.push_back((int)acc - 1); }
     const size_t o_tseq = m.size();  m.insert(m.end(), tile_seq.begin(), tile_seq.end());
     const size_t o_tq0 = m.size();   m.insert(m.end(), tile_q0.begin(), tile_q0.end());
+    // work list of the LAST layer's attention: the one tile per prompt that holds its last position
+    const size_t o_ltseq = m.size(); for (int i = 0; i < n; ++i) m.push_back(i);
+    const size_t o_ltq0 = m.size();  for (int i = 0; i < n; ++i) m.push_back(pos0[i] + (lens[i] - 1 - pos0[i]) / 64 * 64);
     const size_t o_bt = m.size();
     for (int i = 0; i < n; ++i) {
         const HostSlot& s = e->slots[slots[i]];
@@ -777,22 +782,40 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
         AttnPrefillArgs a{};
         a.qkv = e->qkv_pf; a.ld_qkv = e->NQKV; a.out = e->attn_pf; a.ld_out = QD; a.kpool = r.kpool; a.vpool = r.vpool;
         a.block_table = e->block_table; a.max_pages = e->max_pages; a.meta = meta; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
-        if (e->pf_attn_simple) NTTS_LAUNCH((attn_prefill_kernel), dim3((unsigned)tile_seq.size(), c.num_heads), dim3(256), st, a);
-        else attn_prefill_launch(a, (int)tile_seq.size(), st, e->pf_gh);
-        gemm_large<EPI_BF16>(e, gemm_args(e->attn_pf, QD, w.wo, QD, nullptr, e->o_pf, H, Ti, H, QD), st);
+        // Last layer: the KV pages are complete after the rope/KV-write above, and nothing but each prompt's LAST position
+        // is read afterwards (it alone feeds the lm_head).  Attention runs on the one query tile per prompt that holds
+        // it, then that row and its residual row are compacted and o_proj / the MLP run on n rows instead of T.
+        // Row-wise results are unchanged (every GEMM / norm row is computed from that row's operands alone).
+        const bool prune = last && e->pf_prune_last && T >= 4L * n;
+        int n_tiles = (int)tile_seq.size();
+        if (prune) { a.meta.tile_seq = md + o_ltseq; a.meta.tile_q0 = md + o_ltq0; n_tiles = n; }
+        if (e->pf_attn_simple) NTTS_LAUNCH((attn_prefill_kernel), dim3((unsigned)n_tiles, c.num_heads), dim3(256), st, a);
+        else attn_prefill_launch(a, n_tiles, st, e->pf_gh);
+        const int Mi = prune ? n : Ti;                       // rows from here on
+        const bf16_t* attn_in = e->attn_pf;
+        bf16_t* hres = e->h_pf;
+        if (prune) {   // qkv_pf is free once attention has run: T * NQKV >= 4 n * NQKV > n * (QD + H) elements
+            bf16_t* attn_c = e->qkv_pf;
+            bf16_t* h_c = e->qkv_pf + (size_t)n * QD;
+            NTTS_LAUNCH((gather_rows_kernel), dim3(n), dim3(256), st, (const bf16_t*)e->attn_pf, (long)QD, (const int*)(md + o_last), attn_c, (long)QD, QD);
+            NTTS_LAUNCH((gather_rows_kernel), dim3(n), dim3(256), st, (const bf16_t*)e->h_pf, (long)H, (const int*)(md + o_last), h_c, (long)H, H);
+            attn_in = attn_c;
+            hres = h_c;
+        }
+        gemm_large<EPI_BF16>(e, gemm_args(attn_in, QD, w.wo, QD, nullptr, e->o_pf, H, Mi, H, QD), st);
         NormArgs n1{};
-        n1.o_bf16 = e->o_pf; n1.resid_in = e->h_pf; n1.resid_out = e->h_pf; n1.norm_w = w.ln2; n1.normed_out = e->xn_pf;
-        n1.M = Ti; n1.H = H; n1.eps = c.rms_eps;
+        n1.o_bf16 = e->o_pf; n1.resid_in = hres; n1.resid_out = hres; n1.norm_w = w.ln2; n1.normed_out = e->xn_pf;
+        n1.M = Mi; n1.H = H; n1.eps = c.rms_eps;
         add_rmsnorm_launch(n1, st);
-        gemm_large<EPI_SILU_MUL>(e, gemm_args(e->xn_pf, H, w.wgu, H, nullptr, e->act_pf, F, Ti, 2 * F, H), st);
-        gemm_large<EPI_BF16>(e, gemm_args(e->act_pf, F, w.wd, F, nullptr, e->o_pf, H, Ti, H, F), st);
+        gemm_large<EPI_SILU_MUL>(e, gemm_args(e->xn_pf, H, w.wgu, H, nullptr, e->act_pf, F, Mi, 2 * F, H), st);
+        gemm_large<EPI_BF16>(e, gemm_args(e->act_pf, F, w.wd, F, nullptr, e->o_pf, H, Mi, H, F), st);
         NormArgs n2{};
-        n2.o_bf16 = e->o_pf; n2.resid_in = e->h_pf; n2.eps = c.rms_eps; n2.H = H;
+        n2.o_bf16 = e->o_pf; n2.resid_in = hres; n2.eps = c.rms_eps; n2.H = H;
         if (!last) {
             n2.resid_out = e->h_pf; n2.norm_w = e->layers[i + 1].ln1; n2.normed_out = e->xn_pf; n2.M = Ti;
         } else {  // only each prompt's last position feeds the lm_head: gather it into its decode-slot row
             n2.resid_out = e->h_dec; n2.norm_w = e->final_norm; n2.normed_out = e->xn_dec; n2.M = n;
-            n2.in_rows = md + o_last; n2.out_rows = md + o_slot;
+            n2.in_rows = prune ? nullptr : md + o_last; n2.out_rows = md + o_slot;
         }
         add_rmsnorm_launch(n2, st);
     }

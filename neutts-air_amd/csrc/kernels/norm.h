@@ -123,6 +123,15 @@ NTTS_KERNEL(256) void add_rmsnorm_kernel(NormArgs p) {
     }
 }
 
+// dst[r][:] = src[rows[r]][:]  (bf16, 16-byte chunks; cols % 8 == 0) -- prefill's last layer: only each prompt's last position
+// goes on to o_proj / the MLP / the lm_head, so its attention row and residual row are compacted first
+NTTS_KERNEL(256) void gather_rows_kernel(const bf16_t* src, long ld_src, const int* rows, bf16_t* dst, long ld_dst, int cols) {
+    const long r = blockIdx.x;
+    const bf16_t* s = src + (long)rows[r] * ld_src;
+    bf16_t* d = dst + r * ld_dst;
+    for (int c = threadIdx.x * 8; c < cols; c += 256 * 8) *(bf16x8*)(d + c) = ld16<bf16x8>(s + c);
+}
+
 inline void add_rmsnorm_launch(const NormArgs& p, hipStream_t s) {
     const dim3 grid((p.M + 3) / 4), block(256);
     if (p.H <= 512) NTTS_LAUNCH((add_rmsnorm_kernel<1>), grid, block, s, p);

@@ -261,14 +261,20 @@ class BackboneEngine:
                                               C.byref(n), C.byref(fin)))
         return out[: n.value].tolist(), bool(fin.value)
 
-    def read_all(self):
-        """Every slot's new ids in one call: ([ids per slot], [finished per slot])."""
+    def read_all_array(self):
+        """Every slot's new ids in one call, as arrays: (ids [max_batch, max_context] int32 -- row s valid up to n[s]),
+        n [max_batch], finished [max_batch] bool).  The batch hand-off to the codec stays in numpy (no Python lists)."""
         out = np.empty((self.max_batch, self.max_context), dtype=np.int32)
         n = np.empty(self.max_batch, dtype=np.int32)
         fin = np.empty(self.max_batch, dtype=np.int32)
         i32p = C.POINTER(C.c_int32)
         self._chk(self.lib.ntts_backbone_read_all(self.h, out.ctypes.data_as(i32p), self.max_context,
                                                   n.ctypes.data_as(i32p), fin.ctypes.data_as(i32p)))
+        return out, n, fin.astype(bool)
+
+    def read_all(self):
+        """Every slot's new ids in one call: ([ids per slot], [finished per slot])."""
+        out, n, fin = self.read_all_array()
         return [out[s, : n[s]].tolist() for s in range(self.max_batch)], [bool(f) for f in fin]
 
     def poll(self):
@@ -451,6 +457,25 @@ class CodecEngine:
                 out[j] = wav[r, : self.hop_length * len(codes[j])]     # view into this call's buffer: no second copy
             i += nb
         return out  # type: ignore[return-value]
+
+    def decode_array(self, codes: np.ndarray, lens: Optional[np.ndarray] = None, reuse_output: bool = False) -> np.ndarray:
+        """Batch fast path: codes [n, T] int (row i valid up to lens[i]; all T when lens is None) -> waveforms
+        [n, hop_length * T] float32 in ONE engine call (n * (T + 6) must fit max_rows).  reuse_output=True returns a
+        view of the engine's pinned staging buffer, valid until the next decode on this engine."""
+        codes = np.asarray(codes)
+        n, T = codes.shape
+        if lens is None:
+            lens = np.full(n, T, dtype=np.int32)
+            flat = np.ascontiguousarray(codes, dtype=np.int32).reshape(-1)
+        else:
+            lens = np.ascontiguousarray(lens, dtype=np.int32)
+            flat = np.ascontiguousarray(np.concatenate([codes[i, : lens[i]] for i in range(n)]), dtype=np.int32)
+        stride = int(self.hop_length * int(lens.max()))
+        wav = (self._pinned(n * stride) if reuse_output else np.empty(n * stride, dtype=np.float32)).reshape(n, stride)
+        i32p = C.POINTER(C.c_int32)
+        self._chk(self.lib.ntts_codec_decode(self.h, n, flat.ctypes.data_as(i32p), lens.ctypes.data_as(i32p),
+                                             wav.ctypes.data_as(C.POINTER(C.c_float)), stride))
+        return wav
 
     def last_timing(self) -> float:
         ms = C.c_float()

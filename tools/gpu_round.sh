@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call = everything we want from a GPU box, each leg under its own timeout, logs in gpurun_out/.
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_round.sh [legs...]'
-# legs: smoke tests bench prof pmc   (default: smoke tests bench prof)
+# legs: smoke tests bench prof pmc stream sweep   (default: smoke tests bench prof)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -11,7 +11,7 @@ echo "== legs: $LEGS"; rocm-smi --showproductname 2>/dev/null | head -8; nproc
 for leg in $LEGS; do
   case $leg in
     smoke) timeout 420 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -5 $OUT/smoke.log;;
-    tests) timeout 900 python -m pytest tests -m gpu -q -rA --durations=10 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -45 $OUT/pytest_gpu.log;;
+    tests) timeout ${TESTS_TIMEOUT:-900} python -m pytest tests -m gpu -q -rA --durations=10 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -45 $OUT/pytest_gpu.log;;
     bench) timeout 600 python bench.py --steps ${BENCH_STEPS:-2} --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -25 $OUT/bench.err;;
     prof)  rm -rf $OUT/prof; timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof -o bench -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $OUT/prof_bench.json 2> $OUT/prof.err; echo "prof rc=$?"
            python tools/prof_summary.py $OUT/prof > $OUT/prof_summary.txt 2>&1; head -40 $OUT/prof_summary.txt; cat $OUT/prof_bench.json; tail -3 $OUT/prof.err
@@ -22,6 +22,9 @@ for leg in $LEGS; do
              rm -rf $OUT/pmc_$ctr; NTTS_NO_GRAPH=1 timeout 240 rocprofv3 --kernel-trace --pmc $ctr -f csv -d $OUT/pmc_$ctr -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-codec --prefill ${PMC_PREFILL:-605} --decode ${PMC_DECODE:-40} --batch ${PMC_BATCH:-256} > $OUT/pmc_bench.json 2> $OUT/pmc_$ctr.err; echo "pmc $ctr rc=$?"
              python tools/pmc_summary.py $OUT/pmc_$ctr > $OUT/pmc_${ctr}_summary.txt 2>&1; head -14 $OUT/pmc_${ctr}_summary.txt; find $OUT/pmc_$ctr -name '*.csv' -size +8M -delete
            done;;
+    stream) timeout 300 python tools/stream_probe.py > $OUT/stream_probe.jsonl 2> $OUT/stream_probe.err; echo "stream rc=$?"; cat $OUT/stream_probe.jsonl; tail -3 $OUT/stream_probe.err;;
+    sweep)  # SWEEP_KNOBS='[["NTTS_ATTN_DEPTH",[2]]]'
+           timeout ${SWEEP_TIMEOUT:-400} python tools/sweep_decode.py --knobs "${SWEEP_KNOBS:-[[\"NTTS_ATTN_DEPTH\",[2]]]}" > $OUT/sweep.log 2>&1; echo "sweep rc=$?"; grep -v '^\[sweep\] weights' $OUT/sweep.log | tail -12;;
     *) echo "unknown leg $leg";;
   esac
 done
