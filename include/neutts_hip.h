@@ -174,6 +174,11 @@ int ntts_backbone_last_timing(ntts_backbone* e, float* prefill_ms, float* decode
  * consecutive launches inside a decode step do, so the operands come from HBM and not from the Infinity Cache. */
 int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_t iters, float* avg_ms, double* alg_bytes,
                               int32_t* launches_per_step);
+/* Diagnostics: launch the decode attention kernel of `layer` once at the current slot state and return the phase
+ * timestamps it records: out[((slot * num_kv_heads + kv_head) * 4 + wave) * 8 + phase], 100 MHz ticks; phases: 0 kernel
+ * entry, 1 slot state known, 2 RoPE / KV-append prologue done, 3 first K page through the matrix core, 4 scores done,
+ * 5 softmax statistics merged, 6 PV done, 7 exit.  cap = entries available in `out` (>= max_batch * kv_heads * 32). */
+int ntts_backbone_attn_timeline(ntts_backbone* e, int32_t layer, uint64_t* out, int64_t cap);
 /* Algorithmic HBM bytes of one decode step at the current slot lengths (SURVEY.md 8d formula:
  * layer weights + lm_head + sum_b len_b * kv_bytes_per_token + new-token KV writes). */
 int ntts_backbone_step_bytes(ntts_backbone* e, double* bytes);

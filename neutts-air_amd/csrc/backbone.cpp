@@ -82,7 +82,7 @@ struct ntts_backbone {
     bool graph_has_logits = false;
     int ks_o = 1, ks_d = 1;
     int st_qkv = 4, st_o = 4, st_gu = 3, st_d = 4;   // LDS ring depth of each skinny decode GEMM
-    int head_stages = 2, l_stages = 2, pf_gh = 4, attn_depth = 1, gu_tile = 0;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
+    int head_stages = 2, l_stages = 2, pf_gh = 4, attn_depth = 1, attn_var = 1, gu_tile = 0;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
     bool gu_large = false, head_large = true, pf_attn_simple = false, use_xl = true, head_xl = false;
     bool pf_prune_last = true;   // prefill, last layer: attention / o_proj / MLP only for each prompt's last position
     // EXPERIMENTAL (off): RMSNorm fused into the QKV / gate-up GEMM prologues, residual into o_proj's epilogue
@@ -101,6 +101,7 @@ struct ntts_backbone {
     bool graph_tried = false, use_graph = true;
     hipEvent_t ev[4]{};
     bool have_pf_time = false, have_dec_time = false;
+    unsigned long long* attn_tl = nullptr;   // diagnostics (ntts_backbone_attn_timeline)
     long long pf_tokens_computed = 0, pf_tokens_shared = 0;   // prompt tokens pushed through the layers / served from shared pages
 };
 
@@ -262,6 +263,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->xp_bpc = env_int("NTTS_XP_BPC", 1);
     e->pf_gh = env_int("NTTS_PF_GH", 4);
     e->attn_depth = env_int("NTTS_ATTN_DEPTH", 1);
+    e->attn_var = env_int("NTTS_ATTN_VAR", 1);   // 1: prologue operands requested before the K pages (attn_decode.h)
     e->gu_tile = env_int("NTTS_GU_TILE", B > 128 ? 1 : 0);   // 128x128 / 8 waves measured -2 % per step at B = 256
     e->head_large = env_int("NTTS_HEAD_LARGE", B > 64 ? 1 : 0) != 0;
     const int max_slabs = 16;
@@ -513,7 +515,8 @@ static void k_attn(ntts_backbone* e, int i) {
     a.kpool = e->kv + (size_t)i * e->layer_stride; a.vpool = a.kpool + e->kv_half;
     a.block_table = e->block_table; a.max_pages = e->max_pages; a.pos = e->sl.pos; a.state = e->sl.state;
     a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
-    attn_decode_launch(a, c.max_batch, e->stream, e->attn_depth);
+    a.tl = e->attn_tl;
+    attn_decode_launch(a, c.max_batch, e->stream, e->attn_depth, e->attn_var);
 }
 
 static void k_o_proj(ntts_backbone* e, int i) {
@@ -1045,6 +1048,26 @@ extern "C" int ntts_backbone_step_bytes(ntts_backbone* e, double* bytes) {
     for (int b = 0; b < B; ++b)
         if (st[b] == SLOT_RUNNING) kv += (double)pos[b] * kv_tok + kv_tok;  // read L tokens, write 1
     *bytes = w_layers + w_head + kv;
+    return NTTS_OK;
+}
+
+// Diagnostics: one launch of the decode attention kernel of `layer` at the current slot state with its phase
+// timestamps recorded (attn_decode.h `mark`): out[((b * nkv + kvh) * 4 + wave) * 8 + phase], 100 MHz ticks.
+extern "C" int ntts_backbone_attn_timeline(ntts_backbone* e, int32_t layer, uint64_t* out, int64_t cap) {
+    if (!e || !out || layer < 0 || layer >= e->cfg.num_layers) return fail(e, NTTS_EINVAL, "bad argument");
+    const size_t n = (size_t)e->cfg.max_batch * e->cfg.num_kv_heads * 4 * 8;
+    if (cap < (int64_t)n) return fail(e, NTTS_EINVAL, "timeline needs %zu entries", n);
+    HIPCHK(e, hipSetDevice(e->device));
+    unsigned long long* tl = nullptr;
+    HIPCHK(e, hipMalloc((void**)&tl, n * 8));
+    HIPCHK(e, hipMemsetAsync(tl, 0, n * 8, e->stream));
+    k_attn(e, (layer + 1) % e->cfg.num_layers);     // another layer first: this launch is neither the first nor cache-warm
+    e->attn_tl = tl;
+    k_attn(e, layer);
+    e->attn_tl = nullptr;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(out, tl, n * 8, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipFree(tl));
     return NTTS_OK;
 }
 

@@ -18,6 +18,8 @@ extern "C" int ntts_k_gemm_bf16(const void* A, int64_t lda, const void* W, const
     if (variant == 1) NTTS_GEMM_L(EPI_BF16, a, 1, (hipStream_t)0);
     else if (variant == 2) NTTS_GEMM_S(EPI_BF16, a, 1, (hipStream_t)0);
     else if (variant == 4) NTTS_GEMM_XL(EPI_BF16, a, 1, (hipStream_t)0);
+    else if (variant == 5) gemm_launch<4, 4, 4, EPI_BF16, 4, 0, 32>(a, 1, (hipStream_t)0);   // XL tile, 4 ring slots of K = 32
+    else if (variant == 6) gemm_launch<2, 2, 4, EPI_BF16, 3, 0, 32>(a, 1, (hipStream_t)0);   // L tile, 3 ring slots of K = 32
     else if (variant == 3) {  // split-K slabs reduced by the norm kernel (the decode o_proj / down_proj path)
         if (bias || (N % 16) || ldc != N) return NTTS_EINVAL;
         const int ks = 4, ns = gemm_nsplit(K, ks);
@@ -80,16 +82,16 @@ NTTS_KERNEL(256) void prefetch_kernel(const u32x4* src, long n16, int* sink) {
     if (acc == 0x12345678u && sink) *sink = 1;
 }
 
-template <int WM, int WN, int TM, int NS>
+template <int WM, int WN, int TM, int NS, int BK = 64>
 static void probe_launch(const GemmArgs& a, int ks, int abl) {
     constexpr int EPI = EPI_BF16;
     switch (abl) {
-        case 1: gemm_launch<WM, WN, TM, EPI, NS, 1>(a, ks, 0); break;
-        case 2: gemm_launch<WM, WN, TM, EPI, NS, 2>(a, ks, 0); break;
-        case 3: gemm_launch<WM, WN, TM, EPI, NS, 3>(a, ks, 0); break;
-        case 4: gemm_launch<WM, WN, TM, EPI, NS, 4>(a, ks, 0); break;
-        case 7: gemm_launch<WM, WN, TM, EPI, NS, 7>(a, ks, 0); break;
-        default: gemm_launch<WM, WN, TM, EPI, NS, 0>(a, ks, 0); break;
+        case 1: gemm_launch<WM, WN, TM, EPI, NS, 1, BK>(a, ks, 0); break;
+        case 2: gemm_launch<WM, WN, TM, EPI, NS, 2, BK>(a, ks, 0); break;
+        case 3: gemm_launch<WM, WN, TM, EPI, NS, 3, BK>(a, ks, 0); break;
+        case 4: gemm_launch<WM, WN, TM, EPI, NS, 4, BK>(a, ks, 0); break;
+        case 7: gemm_launch<WM, WN, TM, EPI, NS, 7, BK>(a, ks, 0); break;
+        default: gemm_launch<WM, WN, TM, EPI, NS, 0, BK>(a, ks, 0); break;
     }
 }
 
@@ -131,6 +133,11 @@ extern "C" int ntts_k_gemm_probe(int32_t M, int32_t N, int32_t K, int32_t config
             case 42: probe_launch<4, 4, 4, 2>(a, 1, abl); break;   // 256 x 256, 16 waves
             case 43: probe_launch<4, 2, 4, 3>(a, 1, abl); break;   // 256 x 128, 8 waves, 3 stages (144 KB)
             case 44: probe_launch<2, 2, 8, 2>(a, 1, abl); break;   // 256 x 128, 4 waves (128 x 64 per wave)
+            case 45: probe_launch<2, 4, 8, 2>(a, 1, abl); break;   // 256 x 256, 8 waves (128 x 64 per wave)
+            case 46: probe_launch<4, 4, 4, 4, 32>(a, 1, abl); break;   // 256 x 256, 16 waves, 4 slots of K = 32 (128 KB)
+            case 47: probe_launch<4, 4, 4, 3, 32>(a, 1, abl); break;   // ... 3 slots (96 KB)
+            case 48: probe_launch<2, 4, 8, 4, 32>(a, 1, abl); break;   // 256 x 256, 8 waves, 4 slots of K = 32
+            case 49: probe_launch<2, 2, 4, 4, 32>(a, 1, abl); break;   // 128 x 128, 4 waves, 4 slots of K = 32 (64 KB: 2 blocks / CU)
             case 50: probe_launch<4, 1, 4, 3>(a, 1, abl); break;   // 256 x 64, 4 waves: all decode rows in one block
             case 51: probe_launch<8, 1, 2, 3>(a, 1, abl); break;   // 256 x 64, 8 waves
             case 52: probe_launch<8, 1, 2, 2>(a, 1, abl); break;

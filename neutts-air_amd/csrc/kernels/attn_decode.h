@@ -41,6 +41,7 @@ struct AttnDecodeArgs {
     const bf16_t* rope_cos;  // [max_ctx][32] bf16 (cos(emb) rounded to bf16 like HF's cos.to(dtype))
     const bf16_t* rope_sin;
     int nh, nkv;
+    unsigned long long* tl;   // diagnostics: [B][nkv][4 waves][8] phase timestamps (now_ticks), null in the product path
 };
 
 // bf16 RoPE of one (x1 = x[i], x2 = x[i+32]) pair: q*cos + rotate_half(q)*sin, every op rounded
@@ -49,7 +50,14 @@ NTTS_D void rope_pair(float x1, float x2, float c, float s, float& o1, float& o2
     o2 = rbf(rbf(x2 * c) + rbf(x1 * s));
 }
 
-template <int kDepth>
+// kVar: 1 = the prologue's own operands (q/k/v row, RoPE row) are requested BEFORE the first K pages, 0 = after them.
+//   A wave's vector loads return in order, so whatever is requested first is what the RoPE prologue ends up waiting for;
+//   measured on MI355X at batch 256 (profiles/r01e_sweep_attn_variants.jsonl): 1 = -0.6 us per launch, -1.3 % per step.
+//   Also measured there and NOT kept: LDS-only barriers (s_waitcnt lgkmcnt(0) + s_barrier, leaving the K / V^T prefetch in
+//   flight) after the prologue (+3.5 us per launch) or at the softmax merge (+1.1 us), scheduling fences around the K
+//   requests (no effect), deeper register rings (kDepth 2 / 3: +0.2 / +1.2 us), the RoPE row served from a per-slot copy
+//   so that it does not hang off the load of the position (no effect).
+template <int kDepth, bool kTimeline = false, int kVar = 1>
 NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
     NTTS_SHARED bf16_t sc[kGroupMax][kAttnLMax + 16];   // rounded scores, 33 KB; +32 B/row de-aliases the LDS banks
     NTTS_SHARED bf16_t qs[16][64];
@@ -60,22 +68,29 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
     NTTS_SHARED float ored[4][kGroupMax][64];
 
     const int b = blockIdx.x, kvh = blockIdx.y;
-    if (p.state[b] != 1) return;  // block-uniform
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const int g = lane >> 4, l15 = lane & 15;
     const int group = p.nh / p.nkv;
-    const int P = p.pos[b];
-    const int L = P + 1;
-    const int npages = (L + kPage - 1) / kPage;
-    const int last_page = npages - 1;
     const int* bt = p.block_table + (long)b * p.max_pages;
-    const bf16_t* row = p.qkv + (long)b * p.ld_qkv;
-    auto qkv_at = [&](int col) -> bf16_t { return row[col]; };
-
-    // ---- K pages do not depend on this step's q/k/v: start streaming them before the RoPE prologue (the slot of the
-    //      token appended below is overridden from LDS, whatever the page held).  Register ring of kDepth pages per wave.
-    auto load_k = [&](int pg, bf16x8 (&k)[2][2]) {
-        const bf16_t* kp = p.kpool + ((long)bt[pg] * p.nkv + kvh) * kPage * 64;
+    auto mark = [&](int phase) {   // diagnostics instantiation only (ntts_backbone_attn_timeline); compiled out of the product kernel
+        if constexpr (kTimeline) {
+            if (lane == 0) p.tl[(((long)b * p.nkv + kvh) * 4 + w) * 8 + phase] = now_ticks();
+        }
+    };
+    mark(0);
+    // ---- Order of the first requests.  A wave's vector loads return IN ORDER: whatever is requested before the prologue's
+    //      own operands sits on the prologue's critical path.  So (kVar & 1): (1) the block-table entries of the first K
+    //      pages and this token's q/k/v values (needing nothing but the slot index) go first; (2) once the position is known,
+    //      its RoPE row; (3) THEN the K pages, landing while the prologue computes.  Page indices past the context (or of a
+    //      slot that turns out not to run) address some valid page of the pool and are never used: every use below is
+    //      guarded by pg < npages.
+    int bt0[kDepth];
+#pragma unroll
+    for (int j = 0; j < kDepth; ++j) bt0[j] = bt[w + 4 * j < p.max_pages ? w + 4 * j : 0];
+    const int st = p.state[b];
+    const int P = p.pos[b];
+    auto load_k_at = [&](long page, bf16x8 (&k)[2][2]) {
+        const bf16_t* kp = p.kpool + (page * p.nkv + kvh) * kPage * 64;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const bf16_t* kr = kp + (u * 16 + l15) * 64 + g * 16;
@@ -83,36 +98,79 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
             k[u][1] = ld16<bf16x8>(kr + 8);
         }
     };
+    // K pages do not depend on this step's q/k/v: they stream under the RoPE prologue (the slot of the token appended
+    // below is overridden from LDS, whatever the page held).  Register ring of kDepth pages per wave.
     bf16x8 kq[kDepth][2][2];
+    if constexpr (!(kVar & 1)) {
 #pragma unroll
-    for (int j = 0; j < kDepth; ++j)
-        if (w + 4 * j < npages) load_k(w + 4 * j, kq[j]);
+        for (int j = 0; j < kDepth; ++j) load_k_at(bt0[j], kq[j]);
+    }
+    const bf16_t* row = p.qkv + (long)b * p.ld_qkv;
+    // prologue work items: t = head * 32 + pair index; heads 0 .. group-1 are the q heads, item head == group is k (+ v)
+    const int nitems = (group + 1) * 32;
+    bf16_t rx1[2], rx2[2], rv1[2], rv2[2], rc[2], rs[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int t = tid + it * 256;
+        rx1[it] = rx2[it] = rv1[it] = rv2[it] = rc[it] = rs[it] = 0;
+        if (t < nitems) {
+            const int hh = t >> 5, i = t & 31;
+            const int c0 = hh < group ? (kvh * group + hh) * 64 : (p.nh + kvh) * 64;
+            rx1[it] = row[c0 + i];
+            rx2[it] = row[c0 + i + 32];
+            if (hh == group) {
+                const int v0 = (p.nh + p.nkv + kvh) * 64;
+                rv1[it] = row[v0 + i];
+                rv2[it] = row[v0 + i + 32];
+            }
+        }
+    }
+    if (st != 1) return;  // block-uniform
+    mark(1);
+    const int L = P + 1;
+    const int npages = (L + kPage - 1) / kPage;
+    const int last_page = npages - 1;
+    long new_page = 0;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int t = tid + it * 256;
+        if (t < nitems) {
+            rc[it] = p.rope_cos[(long)P * 32 + (t & 31)];
+            rs[it] = p.rope_sin[(long)P * 32 + (t & 31)];
+            if ((t >> 5) == group) new_page = bt[P / kPage];
+        }
+    }
+    auto load_k = [&](int pg, bf16x8 (&k)[2][2]) { load_k_at(bt[pg], k); };
+    if constexpr (kVar & 1) {
+#pragma unroll
+        for (int j = 0; j < kDepth; ++j) load_k_at(bt0[j], kq[j]);
+    }
 
     // ---- prologue: RoPE(q), RoPE(k) + append k, v to the cache (and keep them in LDS for this step)
-    for (int t = tid; t < (group + 1) * 32; t += 256) {
-        const int hh = t >> 5, i = t & 31;
-        const float c = bf2f(p.rope_cos[(long)P * 32 + i]), s = bf2f(p.rope_sin[(long)P * 32 + i]);
-        float o1, o2;
-        if (hh < group) {
-            const int q0 = (kvh * group + hh) * 64;
-            rope_pair(bf2f(qkv_at(q0 + i)), bf2f(qkv_at(q0 + i + 32)), c, s, o1, o2);
-            qs[hh][i] = f2bf(o1);
-            qs[hh][i + 32] = f2bf(o2);
-        } else {
-            const int k0 = (p.nh + kvh) * 64, v0 = (p.nh + p.nkv + kvh) * 64;
-            rope_pair(bf2f(qkv_at(k0 + i)), bf2f(qkv_at(k0 + i + 32)), c, s, o1, o2);
-            const bf16_t k1 = f2bf(o1), k2 = f2bf(o2), v1 = qkv_at(v0 + i), v2 = qkv_at(v0 + i + 32);
-            knew[i] = k1; knew[i + 32] = k2; vnew[i] = v1; vnew[i + 32] = v2;
-            const long pg = bt[P / kPage];
-            const int slot = P % kPage;
-            bf16_t* kd = p.kpool + ((pg * p.nkv + kvh) * kPage + slot) * 64;
-            kd[i] = k1; kd[i + 32] = k2;
-            bf16_t* vd = p.vpool + (pg * p.nkv + kvh) * 64 * kPage + v_slot(slot);
-            vd[(long)i * kPage] = v1; vd[(long)(i + 32) * kPage] = v2;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int t = tid + it * 256;
+        if (t < nitems) {
+            const int hh = t >> 5, i = t & 31;
+            float o1, o2;
+            rope_pair(bf2f(rx1[it]), bf2f(rx2[it]), bf2f(rc[it]), bf2f(rs[it]), o1, o2);
+            if (hh < group) {
+                qs[hh][i] = f2bf(o1);
+                qs[hh][i + 32] = f2bf(o2);
+            } else {
+                const bf16_t k1 = f2bf(o1), k2 = f2bf(o2), v1 = rv1[it], v2 = rv2[it];
+                knew[i] = k1; knew[i + 32] = k2; vnew[i] = v1; vnew[i + 32] = v2;
+                const int slot = P % kPage;
+                bf16_t* kd = p.kpool + ((new_page * p.nkv + kvh) * kPage + slot) * 64;
+                kd[i] = k1; kd[i + 32] = k2;
+                bf16_t* vd = p.vpool + (new_page * p.nkv + kvh) * 64 * kPage + v_slot(slot);
+                vd[(long)i * kPage] = v1; vd[(long)(i + 32) * kPage] = v2;
+            }
         }
     }
     for (int t = tid; t < (16 - group) * 64; t += 256) qs[group + t / 64][t % 64] = 0;
     sync();
+    mark(2);
 
     bf16x8 qB[2];
     qB[0] = ld16<bf16x8>(&qs[l15][g * 16]);
@@ -161,9 +219,11 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
                            fexp_neg(s4[3] - mn);
                     lmax = mn;
                 }
+                if (pg == w) mark(3);   // this wave's first page is through the matrix core
             }
         }
     }
+    mark(4);
     // ---- V^T pages are independent of the scores: get the first ones in flight under the softmax reductions
     auto load_v = [&](int pg, bf16x8 (&v)[4]) {
         const bf16_t* vp = p.vpool + ((long)bt[pg] * p.nkv + kvh) * 64 * kPage;
@@ -192,6 +252,7 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
                 wsum[2][l15] * fexp_neg(wred[2][l15] - m_l) + wsum[3][l15] * fexp_neg(wred[3][l15] - m_l);
     }
     const float rs_l = frcp_refined(sum_l);
+    mark(5);
 
     // ---- pass 2: O = P V with P = bf16(exp(s - m) / sum)
     f32x4 oacc[4];
@@ -235,6 +296,7 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
             }
         }
     }
+    mark(6);
     // D: col = d (l15 within tile nt), row = head g*4 + r
     if (g < 2) {
 #pragma unroll
@@ -248,17 +310,30 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
         const float o = ored[0][hh][d] + ored[1][hh][d] + ored[2][hh][d] + ored[3][hh][d];
         p.out[(long)b * p.ld_out + (kvh * group + hh) * 64 + d] = f2bf(o);
     }
+    mark(7);
 }
 
-inline void attn_decode_launch(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth = kAttnDepthDefault) {
+template <int kVar>
+inline void attn_decode_launch_v(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth) {
     const dim3 grid(batch, p.nkv), block(256);
-    switch (depth) {
-        case 1: NTTS_LAUNCH((attn_decode_kernel<1>), grid, block, s, p); break;
-        case 2: NTTS_LAUNCH((attn_decode_kernel<2>), grid, block, s, p); break;
-        case 4: NTTS_LAUNCH((attn_decode_kernel<4>), grid, block, s, p); break;
-        case 6: NTTS_LAUNCH((attn_decode_kernel<6>), grid, block, s, p); break;
-        default: NTTS_LAUNCH((attn_decode_kernel<3>), grid, block, s, p); break;
+    if (p.tl) {   // diagnostics: the instantiation that records phase timestamps
+        switch (depth) {
+            case 1: NTTS_LAUNCH((attn_decode_kernel<1, true, kVar>), grid, block, s, p); break;
+            case 2: NTTS_LAUNCH((attn_decode_kernel<2, true, kVar>), grid, block, s, p); break;
+            default: NTTS_LAUNCH((attn_decode_kernel<3, true, kVar>), grid, block, s, p); break;
+        }
+        return;
     }
+    switch (depth) {
+        case 1: NTTS_LAUNCH((attn_decode_kernel<1, false, kVar>), grid, block, s, p); break;
+        case 2: NTTS_LAUNCH((attn_decode_kernel<2, false, kVar>), grid, block, s, p); break;
+        case 4: NTTS_LAUNCH((attn_decode_kernel<4, false, kVar>), grid, block, s, p); break;
+        default: NTTS_LAUNCH((attn_decode_kernel<3, false, kVar>), grid, block, s, p); break;
+    }
+}
+inline void attn_decode_launch(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth = kAttnDepthDefault, int var = 1) {
+    if (var & 1) attn_decode_launch_v<1>(p, batch, s, depth);
+    else attn_decode_launch_v<0>(p, batch, s, depth);
 }
 
 }  // namespace ntts

@@ -243,15 +243,27 @@ NTTS_D void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][4], int mrow0, int
 }
 
 // ABL (micro-benchmark ablation, always 0 in the product): 1 = no LDS reads / MFMA, 2 = no LDS-DMA, 4 = no stores
-template <int WM, int WN, int TM, int EPI, int NS, int ABL = 0>
+// BK = K extent of one ring slot (64 or 32).  A 256 x 256 block moves 64 KB per 64-wide K tile and one LDS-DMA round
+// trip takes ~1.25 us whatever else the CU does, so a 2-slot ring of 64-wide tiles (all 128 KB a CU can spare) caps the
+// load path at ~51 GB/s per CU -- below what the MFMAs of the tile need.  With BK = 32 the same 128 KB hold FOUR slots:
+// three slices (96 KB) stay in flight under the MFMAs of the fourth.
+template <int WM, int WN, int TM, int EPI, int NS, int ABL = 0, int BK = 64>
 NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
+    static_assert(BK == 64 || BK == 32, "ring slot K extent");
     constexpr int BM = WM * TM * 16, BN = WN * 64, NW = WM * WN;
-    constexpr int ROWS = BM + BN;              // LDS rows per buffer, 64 bf16 (128 B) each
-    constexpr int NINST = ROWS / 8;            // wave-instructions per K tile
+    constexpr int ROWS = BM + BN;              // LDS rows per buffer, BK bf16 each
+    constexpr int KC = BK / 8;                 // 16-byte chunks per row
+    constexpr int RPI = 64 / KC;               // rows one wave-instruction (64 lanes x 16 B = 1 KB) brings in
+    constexpr int NINST = ROWS / RPI;          // wave-instructions per slot
+    constexpr int SPT = 64 / BK;               // ring slots per 64-wide K tile (GemmArgs counts K in tiles of 64)
     static_assert(NINST % NW == 0, "loader split");
     constexpr int PER_WAVE = NINST / NW;
     static_assert(NS >= 2 && (NS - 2) * PER_WAVE <= 63, "vmcnt range");
-    NTTS_SHARED bf16_t lds[NS * ROWS * 64];
+    NTTS_SHARED bf16_t lds[NS * ROWS * BK];
+    // bank-conflict-free ds_read_b128: 16 lanes read 16 consecutive rows; XOR the 16-byte chunk index with row bits so the
+    // 16 accesses cover the 64 banks once (128-byte rows: bits 1..3; 64-byte rows: bits 2..3); applied on the DMA SOURCE
+    // side (the destination is lane-linear) and again on the read side
+    auto swz = [](int rho) { return BK == 64 ? (rho >> 1) & 7 : (rho >> 2) & 3; };
 
     const int lane = lane_id(), wave = wave_id();
     const int wm = wave / WN, wn = wave % WN;
@@ -260,17 +272,18 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     gemm_tile_coords(blockIdx.x, p.mblocks, p.nblocks, mb, nb);
     const int m0 = mb * BM, n0 = nb * BN;
     const int ktiles = p.K >> 6;
-    const int kt0 = blockIdx.y * p.k_tiles_per_split;
-    int nk = ktiles - kt0;
+    const int kt0 = blockIdx.y * p.k_tiles_per_split * SPT;   // in ring slots from here on
+    int nk = ktiles - blockIdx.y * p.k_tiles_per_split;
     if (nk > p.k_tiles_per_split) nk = p.k_tiles_per_split;
+    nk *= SPT;
 
     // ---- loader set-up: which global row feeds each of this lane's LDS-DMA pieces
     const bf16_t* src[PER_WAVE];
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
         const int inst = wave + i * NW;
-        const int rho = inst * 8 + (lane >> 3);         // LDS row
-        const int c = (lane & 7) ^ ((rho >> 1) & 7);    // logical 16-byte chunk stored at physical lane&7
+        const int rho = inst * RPI + lane / KC;          // LDS row
+        const int c = (lane % KC) ^ swz(rho);            // logical 16-byte chunk stored at physical lane % KC
         if (rho < BM) {
             int m = m0 + rho;
             if (m > p.M - 1) m = p.M - 1;
@@ -288,7 +301,7 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < PER_WAVE; ++i) {
             const int inst = wave + i * NW;
-            glds16(src[i] + (long)(kt0 + kt) * 64, lds + buf * (ROWS * 64) + inst * 512);
+            glds16(src[i] + (long)(kt0 + kt) * BK, lds + buf * (ROWS * BK) + inst * 512);
         }
     };
 
@@ -303,14 +316,14 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
         const int rho = wm * TM * 16 + a * 16 + l15;
-        xoff[a] = rho * 64;
-        xsw[a] = (rho >> 1) & 7;
+        xoff[a] = rho * BK;
+        xsw[a] = swz(rho);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int rho = BM + wn * 64 + j * 16 + l15;
-        woff[j] = rho * 64;
-        wsw[j] = (rho >> 1) & 7;
+        woff[j] = rho * BK;
+        wsw[j] = swz(rho);
     }
 
 #pragma unroll
@@ -323,11 +336,11 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         if (kt + NS - 2 < nk) wait_vmem_le<(NS - 2) * PER_WAVE>(); else wait_vmem();
         sync_keep_dma();  // tile kt landed for every wave; everyone is done reading the slot refilled below
         if (kt + NS - 1 < nk) stage(kt + NS - 1, buf == 0 ? NS - 1 : buf - 1);
-        const bf16_t* base = lds + buf * (ROWS * 64);
+        const bf16_t* base = lds + buf * (ROWS * BK);
         buf = buf + 1 == NS ? 0 : buf + 1;
         if constexpr (ABL & 1) continue;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BK / 32; ++ks) {
             const int c = ks * 4 + g;
             bf16x8 xb[TM], wa[4];
 #pragma unroll
@@ -559,7 +572,7 @@ inline bool gemm_xpanel_launch(GemmArgs p, int blocks_target, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 struct GemmShape { int BM, BN, WN; };
 
-template <int WM, int WN, int TM, int EPI, int NS = 2, int ABL = 0>
+template <int WM, int WN, int TM, int EPI, int NS = 2, int ABL = 0, int BK = 64>
 inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * 64;
     p.mblocks = (p.M + BM - 1) / BM;
@@ -570,7 +583,7 @@ inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
     p.k_tiles_per_split = (ktiles + ksplit - 1) / ksplit;
     const int nsplit = (ktiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
     if constexpr (EPI == EPI_ARGMAX) p.part_stride = p.nblocks * WN;
-    NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL>), dim3(p.mblocks * p.nblocks, nsplit), dim3(WM * WN * 64), s, p);
+    NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK>), dim3(p.mblocks * p.nblocks, nsplit), dim3(WM * WN * 64), s, p);
 }
 
 // tile families:  XL = 256x256 (4x4 waves = 1024 threads, 64x64 per wave, 128 KB LDS) -- big-M GEMMs (prefill, codec):

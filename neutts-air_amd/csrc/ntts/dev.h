@@ -60,8 +60,15 @@ NTTS_D void wait_vmem_le() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memo
 // global_load_lds is outstanding, which collapses a multi-tile prefetch ring to depth 1.  This one only retires
 // the wave's own LDS reads/writes (lgkmcnt) before the rendezvous; DMA completion is the caller's counted vmcnt.
 NTTS_D void sync_keep_dma() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// The same instruction sequence where the point is that ordinary global loads (register prefetch rings) stay in flight:
+// a workgroup barrier that orders LDS traffic only.  Use it when what the barrier publishes lives in LDS.
+NTTS_D void lds_barrier() { sync_keep_dma(); }
+// nothing is scheduled across this point by the compiler (issue order of memory requests matters: in-order returns)
+NTTS_D void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 NTTS_D unsigned int atomic_add_lds(unsigned int* p, unsigned int v) { return atomicAdd(p, v); }
+// constant-rate timestamp (s_memrealtime, 100 MHz): phase timelines of a kernel (diagnostics only)
+NTTS_D unsigned long long now_ticks() { return wall_clock64(); }
 
 NTTS_D float fexp(float x) { return expf(x); }
 // exp(x) for FINITE x <= ~0 (softmax arguments after the max is subtracted; masked scores are -1e30, never -inf):

@@ -93,6 +93,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_backbone_debug_force": (C.c_int, [p, i32, i32]),
         "ntts_backbone_last_timing": (C.c_int, [p, C.POINTER(f32), C.POINTER(f32)]),
         "ntts_backbone_step_bytes": (C.c_int, [p, C.POINTER(C.c_double)]),
+        "ntts_backbone_attn_timeline": (C.c_int, [p, i32, C.POINTER(C.c_uint64), i64]),
         "ntts_codec_last_error": (C.c_char_p, [p]),
         "ntts_codec_create": (C.c_int, [C.POINTER(CodecConfigC), C.c_int, C.POINTER(p)]),
         "ntts_codec_destroy": (None, [p]),
@@ -305,6 +306,13 @@ class BackboneEngine:
         a, b = C.c_float(), C.c_float()
         self._chk(self.lib.ntts_backbone_last_timing(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def attn_timeline(self, layer: int = 0) -> np.ndarray:
+        """Phase timestamps of one decode-attention launch: [max_batch, kv_heads, 4 waves, 8 phases], 100 MHz ticks."""
+        nkv = self.cfg["num_kv_heads"]
+        out = np.zeros((self.max_batch, nkv, 4, 8), dtype=np.uint64)
+        self._chk(self.lib.ntts_backbone_attn_timeline(self.h, layer, out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size))
+        return out
 
     def step_bytes(self) -> float:
         d = C.c_double()

@@ -133,8 +133,11 @@ inline void glds16(const void* gsrc, void* lds_wave_base) {
     memcpy((char*)d0.l + lane_id() * 16, gsrc, 16);
 }
 inline unsigned int atomic_add_lds(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = o + v; return o; }
+NTTS_D unsigned long long now_ticks() { return 0; }   // no clock on the emulator
 inline void wait_vmem() {}
 inline void sync_keep_dma() { emu::barrier(); }
+inline void lds_barrier() { emu::barrier(); }
+inline void sched_fence() {}
 template <int N>
 inline void wait_vmem_le() {}
 

@@ -32,6 +32,9 @@ GEMM_CASES = [  # (M, N, K, variant, bias)
     (100, 176, 256, 2, True),    # S tile, ragged
     (37, 64, 448, 3, False),     # S tile split-K + slab reduce
     (300, 272, 128, 4, True),    # XL tile (256 x 256, 16 waves), ragged M and N
+    (300, 272, 192, 5, True),    # XL tile on the 4-slot ring of 32-wide K slices (64-byte LDS rows, other swizzle)
+    (70, 200, 64, 5, False),     # ... a single 64-wide K tile = 2 slices, fewer than the ring holds
+    (130, 144, 320, 6, True),    # L tile, 3-slot ring of 32-wide slices
 ]
 
 

@@ -33,6 +33,9 @@ BIG = [  # the decode-batch and prefill shapes of NeuTTS-Air
     (1000, 2048, 1024, 1, True),  # codec-like
     (1500, 1152, 896, 4, True),   # XL tile (256 x 256, 1024 threads): prefill QKV, ragged M
     (3000, 896, 4864, 4, False),  # XL tile: prefill down_proj, N not a multiple of 256
+    (1500, 1152, 896, 5, True),   # XL tile on the 4-slot ring of 32-wide K slices: prefill QKV, ragged M
+    (3000, 896, 4864, 5, False),  # ... prefill down_proj (152 slices)
+    (2000, 9728, 896, 5, False),  # ... prefill gate/up width
 ]
 
 
