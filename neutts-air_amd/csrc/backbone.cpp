@@ -80,7 +80,7 @@ struct ntts_backbone {
     long ldl = 0;
     int n_sampling = 0;              // running slots with do_sample=1
     bool graph_has_logits = false;
-    int ks_o = 1, ks_d = 1;
+    int ks_qkv = 1, ks_o = 1, ks_d = 1;
     int st_qkv = 4, st_o = 4, st_gu = 3, st_d = 4;   // LDS ring depth of each skinny decode GEMM
     int head_stages = 2, l_stages = 2, pf_gh = 4, attn_depth = 1, attn_var = 1, gu_tile = 0;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
     bool gu_large = false, head_large = true, pf_attn_simple = false, use_xl = true, head_xl = false;
@@ -244,6 +244,10 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
         if (ks > ktiles) ks = ktiles;
         return ks;
     };
+    // QKV GEMM: 18 x 4 = 72 workgroups at batch 256 leave most CUs idle; split-K 2 with the slabs reduced in the attention
+    // prologue measured -3.4 us on the GEMM, +1.7 us on the attention kernel, -1.8 % per step (profiles/r01e_sweep_qkv_split.jsonl)
+    e->ks_qkv = env_int("NTTS_KSPLIT_QKV", 2);
+    if (e->ks_qkv > kAttnMaxSlabs) e->ks_qkv = kAttnMaxSlabs;
     e->ks_o = env_int("NTTS_KSPLIT_O", pick_split(H / 64, c->num_heads * 64 / 64));
     e->ks_d = env_int("NTTS_KSPLIT_D", pick_split(H / 64, F / 64));
     const int s_all = env_int("NTTS_S_STAGES", 0);
@@ -505,13 +509,19 @@ static void lm_head_and_sample(ntts_backbone* e, int phase) {
 static void k_qkv(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H;
     const LayerW& w = e->layers[i];
-    gemm_skinny<EPI_BF16>(e->st_qkv, gemm_args(e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H), 1, e->stream);
+    if (e->ks_qkv > 1)   // fp32 split-K slabs; the attention prologue sums them, adds the bias and rounds (attn_decode.h)
+        gemm_skinny<EPI_SPLITK>(e->st_qkv, gemm_args(e->xn_dec, H, w.wqkv, H, nullptr, e->slabs, e->NQKV, B, e->NQKV, H), e->ks_qkv, e->stream);
+    else
+        gemm_skinny<EPI_BF16>(e->st_qkv, gemm_args(e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H), 1, e->stream);
 }
 
 static void k_attn(ntts_backbone* e, int i) {
     const ntts_backbone_config& c = e->cfg;
     AttnDecodeArgs a{};
     a.qkv = e->qkv_dec; a.ld_qkv = e->NQKV; a.out = e->attn_dec; a.ld_out = c.num_heads * 64;
+    if (e->ks_qkv > 1 && !e->fused) {
+        a.qkv_slabs = e->slabs; a.nslab = gemm_nsplit(e->H, e->ks_qkv); a.slab_rows = c.max_batch; a.qkv_bias = e->layers[i].bqkv;
+    }
     a.kpool = e->kv + (size_t)i * e->layer_stride; a.vpool = a.kpool + e->kv_half;
     a.block_table = e->block_table; a.max_pages = e->max_pages; a.pos = e->sl.pos; a.state = e->sl.state;
     a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
@@ -1092,6 +1102,7 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
     for (int b = 0; b < B; ++b)
         if (sst[b] == SLOT_RUNNING) kv_layer += ((double)pos[b] + 1) * 2 * KD * 2.0;
     const double act = (double)B * 2.0;
+    const bool qkv_split = e->ks_qkv > 1 && !e->fused;   // QKV leaves fp32 split-K slabs that the attention prologue reduces
     // Every replay works on the NEXT layer's weights / KV pool, as consecutive launches of this kernel do inside the
     // decode step: one layer's operands (84 MB of KV at batch 256) would sit in the 256 MB Infinity Cache when replayed
     // alone, all layers together (2 GB) do not -- so the timing below is HBM-cold like the in-graph launches.
@@ -1111,8 +1122,11 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
         }
     };
     switch (which) {
-        case 0: *alg_bytes = kv_layer + act * (e->NQKV + QD); *launches_per_step = L; break;
-        case 1: *alg_bytes = ((double)e->NQKV * H + e->NQKV) * 2.0 + act * (H + e->NQKV); *launches_per_step = L; break;
+        case 0: *alg_bytes = kv_layer + act * QD + (double)B * e->NQKV * (qkv_split ? 4.0 * gemm_nsplit(H, e->ks_qkv) : 2.0);
+                *launches_per_step = L; break;
+        case 1: *alg_bytes = ((double)e->NQKV * H + e->NQKV) * 2.0 + act * H +
+                             (double)B * e->NQKV * (qkv_split ? 4.0 * gemm_nsplit(H, e->ks_qkv) : 2.0);
+                *launches_per_step = L; break;
         case 2: *alg_bytes = (double)H * QD * 2.0 + act * QD +
                              (e->fused ? act * 2 * H : (double)gemm_nsplit(QD, e->ks_o) * B * H * 4.0);
                 *launches_per_step = L; break;

@@ -25,6 +25,7 @@ constexpr int kAttnLMax = 2048;  // ref:neutts/neutts.py:85 max_context
 // slot of token t (0..31) inside a V^T page row: [0-3,16-19 | 4-7,20-23 | 8-11,24-27 | 12-15,28-31]
 NTTS_HD int v_slot(int t) { return ((t & 15) >> 2) * 8 + (t >> 4) * 4 + (t & 3); }
 constexpr int kGroupMax = 8;     // query heads per kv head handled by one workgroup
+constexpr int kAttnMaxSlabs = 4;      // split-K factor of the QKV GEMM this kernel can reduce in its prologue
 constexpr int kAttnDepthDefault = 1;  // KV pages each wave keeps in flight (register ring)
 
 struct AttnDecodeArgs {
@@ -41,6 +42,12 @@ struct AttnDecodeArgs {
     const bf16_t* rope_cos;  // [max_ctx][32] bf16 (cos(emb) rounded to bf16 like HF's cos.to(dtype))
     const bf16_t* rope_sin;
     int nh, nkv;
+    // alternative input (qkv == null): the QKV GEMM's fp32 split-K slabs [nslab <= kAttnMaxSlabs][slab_rows][ld_qkv]; this
+    // kernel then sums them in slab order, adds the bias and applies the nn.Linear output rounding (one RNE to bf16) itself
+    const float* qkv_slabs;
+    int nslab;
+    long slab_rows;
+    const bf16_t* qkv_bias;
     unsigned long long* tl;   // diagnostics: [B][nkv][4 waves][8] phase timestamps (now_ticks), null in the product path
 };
 
@@ -108,20 +115,34 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
     const bf16_t* row = p.qkv + (long)b * p.ld_qkv;
     // prologue work items: t = head * 32 + pair index; heads 0 .. group-1 are the q heads, item head == group is k (+ v)
     const int nitems = (group + 1) * 32;
-    bf16_t rx1[2], rx2[2], rv1[2], rv2[2], rc[2], rs[2];
+    // element `col` of this sequence's q|k|v row as the bf16 nn.Linear output: read as such, or rebuilt from the QKV GEMM's
+    // split-K slabs (all loads independent; the additions follow the slab order, then + bias, then ONE rounding)
+    auto qkv_at = [&](int col) -> bf16_t {
+        if (!p.qkv_slabs) return row[col];
+        float part[kAttnMaxSlabs];
+#pragma unroll
+        for (int sl = 0; sl < kAttnMaxSlabs; ++sl)
+            part[sl] = sl < p.nslab ? p.qkv_slabs[((long)sl * p.slab_rows + b) * p.ld_qkv + col] : 0.f;
+        const float bias = bf2f(p.qkv_bias[col]);
+        float a = part[0];
+#pragma unroll
+        for (int sl = 1; sl < kAttnMaxSlabs; ++sl) a += part[sl];   // + 0.f for absent slabs: exact
+        return f2bf(a + bias);
+    };
+    bf16_t rx1[2], rx2[2], rv1[2], rv2[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int t = tid + it * 256;
-        rx1[it] = rx2[it] = rv1[it] = rv2[it] = rc[it] = rs[it] = 0;
+        rx1[it] = rx2[it] = rv1[it] = rv2[it] = 0;
         if (t < nitems) {
             const int hh = t >> 5, i = t & 31;
             const int c0 = hh < group ? (kvh * group + hh) * 64 : (p.nh + kvh) * 64;
-            rx1[it] = row[c0 + i];
-            rx2[it] = row[c0 + i + 32];
+            rx1[it] = qkv_at(c0 + i);
+            rx2[it] = qkv_at(c0 + i + 32);
             if (hh == group) {
                 const int v0 = (p.nh + p.nkv + kvh) * 64;
-                rv1[it] = row[v0 + i];
-                rv2[it] = row[v0 + i + 32];
+                rv1[it] = qkv_at(v0 + i);
+                rv2[it] = qkv_at(v0 + i + 32);
             }
         }
     }
@@ -131,9 +152,11 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
     const int npages = (L + kPage - 1) / kPage;
     const int last_page = npages - 1;
     long new_page = 0;
+    bf16_t rc[2], rs[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int t = tid + it * 256;
+        rc[it] = rs[it] = 0;
         if (t < nitems) {
             rc[it] = p.rope_cos[(long)P * 32 + (t & 31)];
             rs[it] = p.rope_sin[(long)P * 32 + (t & 31)];
