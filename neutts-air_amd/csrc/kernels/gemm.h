@@ -42,6 +42,10 @@ struct GemmArgs {
     long ldx;
     const bf16_t* W;
     long ldw;
+    int w_tile_major;    // 0: W is [N][K] row-major (ldw).  1: "tile-major": for each group of 64 rows, the 64 x 64 blocks of
+                         // consecutive K tiles follow each other (block = 64 rows x 128 B = 8 KB contiguous, group = 64 x K
+                         // elements contiguous): a workgroup's weight stream is ONE sequential run of HBM addresses instead
+                         // of 64 row segments of 128 B, 2*K bytes apart, revisited once per K tile (DRAM pages re-opened)
     const bf16_t* bias;  // [N] or nullptr
     const float* bias_f32;  // alternative fp32 bias (codec path keeps its affine terms in fp32)
     void* out;
@@ -293,15 +297,18 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
             const int wq = q >> 6, j = (q >> 4) & 3, i16 = q & 15;
             int n = n0 + wq * 64 + (i16 >> 2) * 16 + j * 4 + (i16 & 3);
             if (n > p.N - 1) n = p.N - 1;
-            src[i] = p.W + (long)n * p.ldw + c * 8;
+            src[i] = p.w_tile_major ? p.W + (long)(n >> 6) * 64 * p.K + (n & 63) * 64 + c * 8 : p.W + (long)n * p.ldw + c * 8;
         }
     }
+    static_assert(BK == 64 || true, "");
+    const long wstep = p.w_tile_major ? 4096 : BK;      // elements between consecutive K tiles of a W row (BK = 64 only)
     auto stage = [&](int kt, int buf) {
         if constexpr (ABL & 2) return;
 #pragma unroll
         for (int i = 0; i < PER_WAVE; ++i) {
             const int inst = wave + i * NW;
-            glds16(src[i] + (long)(kt0 + kt) * BK, lds + buf * (ROWS * BK) + inst * 512);
+            const bool is_w = (inst * RPI) >= BM;          // this instruction's rows are W rows (wave-uniform)
+            glds16(src[i] + (long)(kt0 + kt) * (is_w ? wstep : (long)BK), lds + buf * (ROWS * BK) + inst * 512);
         }
     };
 

@@ -65,16 +65,32 @@ def tall():
 
 
 def head():
-    M, N, K = 256, 217488, 896
-    print(f"== lm_head M={M} N={N} K={K} W=390 MB (always HBM-cold)")
-    for cfg in (30, 31, 40, 41, 42, 43, 12):
+    M, N, K = 256, 217472, 896
+    print(f"== lm_head M={M} N={N} K={K} W=390 MB (always HBM-cold); row-major W vs tile-major W (abl bit 16)")
+    for cfg in (30, 42, 12):
         t = probe(M, N, K, cfg, 0, 1, iters=20)
-        print(f"  {CONFIGS[cfg]:18s} {t:8.1f} us  {N * K * 2 / t / 1e6:6.2f} TB/s", flush=True)
+        t2 = probe(M, N, K, cfg, 16, 1, iters=20)
+        print(f"  {CONFIGS[cfg]:18s} {t:8.1f} us  {N * K * 2 / t / 1e6:6.2f} TB/s | tile-major {t2:8.1f} us  {N * K * 2 / t2 / 1e6:6.2f} TB/s", flush=True)
+
+
+def layout():
+    """decode GEMMs, HBM-cold weights: row-major vs tile-major weight addressing"""
+    for name, (M, N, K) in SHAPES.items():
+        wbytes = N * K * 2
+        cold = max(2, int(400e6 // wbytes))
+        print(f"== {name}  M={M} N={N} K={K}  cold copies={cold}")
+        for cfg in (11, 12, 54):
+            c0 = probe(M, N, K, cfg, 0, cold)
+            c1 = probe(M, N, K, cfg, 16, cold)
+            print(f"  {CONFIGS[cfg]:18s} row-major {c0:7.2f}  tile-major {c1:7.2f}", flush=True)
 
 
 def main():
     if "--head" in sys.argv:
         return head()
+    if "--layout" in sys.argv:
+        head()
+        return layout()
     if "--tall" in sys.argv:
         return tall()
     if "--prefill" in sys.argv:
