@@ -25,7 +25,7 @@ def test_tiny_teacher_forced(emu_lib):
     assert agree >= N - 2, (ids1, z["bf16_ids_1"][:N])
 
 
-@pytest.mark.parametrize("knobs", [{}, {"NTTS_ATTN_DEPTH": "1", "NTTS_S_STAGES": "3", "NTTS_PF_GH": "7", "NTTS_FUSED": "1"},
+@pytest.mark.parametrize("knobs", [{}, {"NTTS_ATTN_DEPTH": "1", "NTTS_S_STAGES": "3", "NTTS_PF_GH": "4", "NTTS_FUSED": "1"},
                                    {"NTTS_ATTN_DEPTH": "4", "NTTS_S_STAGES": "6", "NTTS_KSPLIT_O": "2", "NTTS_KSPLIT_D": "5",
                                     "NTTS_PREFILL_ATTN_SIMPLE": "1", "NTTS_KSPLIT_QKV": "3", "NTTS_ATTN_VAR": "0"}])
 def test_small_gqa2_page_crossing_peaked_exact(emu_lib, knobs, monkeypatch):
