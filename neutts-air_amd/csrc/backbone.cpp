@@ -84,6 +84,7 @@ struct ntts_backbone {
     int st_qkv = 4, st_o = 4, st_gu = 3, st_d = 4;   // LDS ring depth of each skinny decode GEMM
     int head_stages = 2, l_stages = 2, pf_gh = 7, attn_depth = 1, attn_var = 1, gu_tile = 0;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
     bool gu_large = false, head_large = true, pf_attn_simple = false, use_xl = true, head_xl = false;
+    bool norm_wide = true;       // decode add+RMSNorm: one row per workgroup (256 CUs pull) instead of four
     bool pf_prune_last = true;   // prefill, last layer: attention / o_proj / MLP only for each prompt's last position
     // EXPERIMENTAL (off): RMSNorm fused into the QKV / gate-up GEMM prologues, residual into o_proj's epilogue
     // (gemm_xpanel_kernel).  Parity-clean but slower on MI355X at batch 256: one 4-wave workgroup per CU cannot
@@ -260,6 +261,8 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->gu_large = env_int("NTTS_GU_LARGE", 0) != 0;
     e->pf_attn_simple = env_int("NTTS_PREFILL_ATTN_SIMPLE", 0) != 0;
     e->pf_prune_last = env_int("NTTS_PF_PRUNE_LAST", 1) != 0;
+    // one row per workgroup: 256 CUs pull the slabs instead of 64 -- 5.5 -> 4.0 us per launch, -4.4 % per step at batch 256
+    e->norm_wide = env_int("NTTS_NORM_WIDE", 1) != 0;
     e->use_xl = env_int("NTTS_XL", 1) != 0;
     e->head_xl = env_int("NTTS_HEAD_XL", B > 128 ? 1 : 0) != 0;
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -553,7 +556,7 @@ static void k_add_norm(ntts_backbone* e, int K, int ks, const bf16_t* norm_w, bf
     NormArgs n{};
     n.slabs = e->slabs; n.nslab = gemm_nsplit(K, ks); n.slab_rows = e->cfg.max_batch; n.resid_in = e->h_dec; n.resid_out = resid_out;
     n.norm_w = norm_w; n.normed_out = normed_out; n.M = e->cfg.max_batch; n.H = e->H; n.eps = e->cfg.rms_eps;
-    add_rmsnorm_launch(n, e->stream);
+    add_rmsnorm_launch(n, e->stream, e->norm_wide);
 }
 
 template <int EPI, bool NORM>
@@ -612,7 +615,7 @@ static void decode_step(ntts_backbone* e) {
     NormArgs n0{};
     n0.gather_ids = e->sl.cur_tok; n0.embed = e->embed; n0.resid_out = e->h_dec; n0.norm_w = e->layers[0].ln1;
     n0.normed_out = e->xn_dec; n0.M = B; n0.H = H; n0.eps = c.rms_eps;
-    add_rmsnorm_launch(n0, e->stream);
+    add_rmsnorm_launch(n0, e->stream, e->norm_wide);
     for (int i = 0; i < c.num_layers; ++i) {
         k_qkv(e, i);
         k_attn(e, i);

@@ -123,6 +123,90 @@ NTTS_KERNEL(256) void add_rmsnorm_kernel(NormArgs p) {
     }
 }
 
+// Decode-batch variant: ONE ROW PER WORKGROUP (2 waves, one 16-byte chunk per thread, H <= 1024), so that 256 rows occupy
+// 256 CUs instead of 64 and every CU pulls a quarter of the bytes through its load path.  Same arithmetic in the same
+// order as add_rmsnorm_kernel<2>: the sum of squares of lane l runs over chunk l and then chunk l + 64 element by element
+// (wave 1 hands its values to wave 0 through LDS), then the 64-lane butterfly.
+NTTS_KERNEL(128) void add_rmsnorm_row_kernel(NormArgs p) {
+    NTTS_SHARED float hand[64][8];
+    NTTS_SHARED float inv_s;
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int r = blockIdx.x;
+    const long ri = p.in_rows ? p.in_rows[r] : r;
+    const long ro = p.out_rows ? p.out_rows[r] : r;
+    const int nchunk = p.H >> 3;
+    const int ci = tid;                           // wave 0: chunks 0..63, wave 1: chunks 64..127
+    const bool ok = ci < nchunk;
+    const long col = (long)ci * 8;
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = 0.f;
+    bf16x8 wv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ok) {
+        if (p.slabs) {
+            for (int s0 = 0; s0 < p.nslab; s0 += 4) {
+                f32x4 a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (s0 + u < p.nslab) {
+                        const float* sp = p.slabs + ((long)(s0 + u) * p.slab_rows + ri) * p.H + col;
+                        a[u] = ld16<f32x4>(sp);
+                        b[u] = ld16<f32x4>(sp + 4);
+                    }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (s0 + u < p.nslab) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { o[e] += a[u][e]; o[4 + e] += b[u][e]; }
+                    }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rbf(o[e]);
+        } else {
+            const bf16_t* src = p.gather_ids ? p.embed + (long)p.gather_ids[ri] * p.H + col : p.o_bf16 + ri * p.H + col;
+            const bf16x8 t = ld16<bf16x8>(src);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = bf2f((bf16_t)t[e]);
+        }
+        if (p.resid_in) {
+            const bf16x8 t = ld16<bf16x8>(p.resid_in + ri * p.H + col);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = rbf(bf2f((bf16_t)t[e]) + o[e]);
+        }
+        if (p.norm_w) wv = ld16<bf16x8>(p.norm_w + col);
+        if (p.resid_out) {
+            bf16x8 t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (short)f2bf(o[e]);
+            *(bf16x8*)(p.resid_out + ro * p.H + col) = t;
+        }
+    }
+    if (!p.norm_w) return;  // block-uniform
+    if (w == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) hand[lane][e] = o[e];
+    }
+    sync();
+    if (w == 0) {
+        float ss = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += o[e] * o[e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float x = hand[lane][e]; ss += x * x; }   // zeros beyond the row: + 0 is exact
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) ss += shfl_xor(ss, sh);
+        if (lane == 0) inv_s = frsqrt_exact(ss / (float)p.H + p.eps);
+    }
+    sync();
+    const float inv = inv_s;
+    if (ok) {
+        bf16x8 t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = (short)f2bf(bf2f((bf16_t)wv[e]) * rbf(o[e] * inv));
+        *(bf16x8*)(p.normed_out + ro * p.H + col) = t;
+    }
+}
+
 // dst[r][:] = src[rows[r]][:]  (bf16, 16-byte chunks; cols % 8 == 0) -- prefill's last layer: only each prompt's last position
 // goes on to o_proj / the MLP / the lm_head, so its attention row and residual row are compacted first
 NTTS_KERNEL(256) void gather_rows_kernel(const bf16_t* src, long ld_src, const int* rows, bf16_t* dst, long ld_dst, int cols) {
@@ -132,7 +216,11 @@ NTTS_KERNEL(256) void gather_rows_kernel(const bf16_t* src, long ld_src, const i
     for (int c = threadIdx.x * 8; c < cols; c += 256 * 8) *(bf16x8*)(d + c) = ld16<bf16x8>(s + c);
 }
 
-inline void add_rmsnorm_launch(const NormArgs& p, hipStream_t s) {
+inline void add_rmsnorm_launch(const NormArgs& p, hipStream_t s, bool row_per_block = false) {
+    if (row_per_block && p.H > 512 && p.H <= 1024) {     // decode batch: one row per workgroup, all CUs pull
+        NTTS_LAUNCH((add_rmsnorm_row_kernel), dim3(p.M), dim3(128), s, p);
+        return;
+    }
     const dim3 grid((p.M + 3) / 4), block(256);
     if (p.H <= 512) NTTS_LAUNCH((add_rmsnorm_kernel<1>), grid, block, s, p);
     else if (p.H <= 1024) NTTS_LAUNCH((add_rmsnorm_kernel<2>), grid, block, s, p);
