@@ -117,32 +117,46 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
     const int nitems = (group + 1) * 32;
     // element `col` of this sequence's q|k|v row as the bf16 nn.Linear output: read as such, or rebuilt from the QKV GEMM's
     // split-K slabs (all loads independent; the additions follow the slab order, then + bias, then ONE rounding)
-    auto qkv_at = [&](int col) -> bf16_t {
-        if (!p.qkv_slabs) return row[col];
-        float part[kAttnMaxSlabs];
+    // Branch-free on purpose: with a data-dependent slab count in the control flow the compiler waits for each element's
+    // loads before it requests the next element's (a chain of round trips); here every request of the prologue is in
+    // flight at once.  Absent slabs re-read the last present one and are dropped by a select.
+    const bool from_slabs = p.qkv_slabs != nullptr;
+    const float* sbase[kAttnMaxSlabs];
 #pragma unroll
-        for (int sl = 0; sl < kAttnMaxSlabs; ++sl)
-            part[sl] = sl < p.nslab ? p.qkv_slabs[((long)sl * p.slab_rows + b) * p.ld_qkv + col] : 0.f;
-        const float bias = bf2f(p.qkv_bias[col]);
-        float a = part[0];
+    for (int sl = 0; sl < kAttnMaxSlabs; ++sl) {
+        const int su = sl < p.nslab ? sl : (p.nslab > 0 ? p.nslab - 1 : 0);
+        sbase[sl] = from_slabs ? p.qkv_slabs + ((long)su * p.slab_rows + b) * p.ld_qkv : nullptr;
+    }
+    struct QkvReq { float part[kAttnMaxSlabs]; bf16_t bias; bf16_t direct; };
+    auto qkv_request = [&](int col, QkvReq& q) {
+        if (from_slabs) {              // wave-uniform
 #pragma unroll
-        for (int sl = 1; sl < kAttnMaxSlabs; ++sl) a += part[sl];   // + 0.f for absent slabs: exact
-        return f2bf(a + bias);
+            for (int sl = 0; sl < kAttnMaxSlabs; ++sl) q.part[sl] = sbase[sl][col];
+            q.bias = p.qkv_bias[col];
+        } else {
+            q.direct = row[col];
+        }
     };
-    bf16_t rx1[2], rx2[2], rv1[2], rv2[2];
+    auto qkv_value = [&](const QkvReq& q) -> bf16_t {
+        if (!from_slabs) return q.direct;
+        float a = q.part[0];
+#pragma unroll
+        for (int sl = 1; sl < kAttnMaxSlabs; ++sl) a += sl < p.nslab ? q.part[sl] : 0.f;   // + 0.f: exact
+        return f2bf(a + bf2f(q.bias));
+    };
+    QkvReq qx1[2], qx2[2], qv1[2], qv2[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int t = tid + it * 256;
-        rx1[it] = rx2[it] = rv1[it] = rv2[it] = 0;
         if (t < nitems) {
             const int hh = t >> 5, i = t & 31;
             const int c0 = hh < group ? (kvh * group + hh) * 64 : (p.nh + kvh) * 64;
-            rx1[it] = qkv_at(c0 + i);
-            rx2[it] = qkv_at(c0 + i + 32);
+            qkv_request(c0 + i, qx1[it]);
+            qkv_request(c0 + i + 32, qx2[it]);
             if (hh == group) {
                 const int v0 = (p.nh + p.nkv + kvh) * 64;
-                rv1[it] = qkv_at(v0 + i);
-                rv2[it] = qkv_at(v0 + i + 32);
+                qkv_request(v0 + i, qv1[it]);
+                qkv_request(v0 + i + 32, qv2[it]);
             }
         }
     }
@@ -176,12 +190,12 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
         if (t < nitems) {
             const int hh = t >> 5, i = t & 31;
             float o1, o2;
-            rope_pair(bf2f(rx1[it]), bf2f(rx2[it]), bf2f(rc[it]), bf2f(rs[it]), o1, o2);
+            rope_pair(bf2f(qkv_value(qx1[it])), bf2f(qkv_value(qx2[it])), bf2f(rc[it]), bf2f(rs[it]), o1, o2);
             if (hh < group) {
                 qs[hh][i] = f2bf(o1);
                 qs[hh][i + 32] = f2bf(o2);
             } else {
-                const bf16_t k1 = f2bf(o1), k2 = f2bf(o2), v1 = rv1[it], v2 = rv2[it];
+                const bf16_t k1 = f2bf(o1), k2 = f2bf(o2), v1 = qkv_value(qv1[it]), v2 = qkv_value(qv2[it]);
                 knew[i] = k1; knew[i + 32] = k2; vnew[i] = v1; vnew[i + 32] = v2;
                 const int slot = P % kPage;
                 bf16_t* kd = p.kpool + ((new_page * p.nkv + kvh) * kPage + slot) * 64;
