@@ -195,3 +195,24 @@ def test_stream_blender_is_bit_identical_to_full_reblend(n_frames, last_len):
         assert got.dtype == want.dtype and np.array_equal(got, want)
     # and the oracle's restatement of _linear_overlap_add agrees with the product's
     assert np.array_equal(cr.linear_overlap_add(frames, stride), _linear_overlap_add(frames, stride=stride))
+
+
+def test_infer_batch_shares_prompt_beginnings_and_matches_single_inference(tts):
+    """Three utterances of one speaker in one call: the engine shares the KV pages of the common prompt beginning
+    (chat header + reference-text phones, ref:neutts/neutts.py:307,315-325) and every waveform equals what `infer`
+    gives for that utterance alone (greedy: same ids, hence the same codes and samples)."""
+    ref_codes = torch.tensor([3, 77, 200, 5, 18, 9], dtype=torch.int32)
+    ref_text = "So I'm live, and this is the reference sentence that every prompt of the speaker starts with."
+    texts = ["First.", "Second one.", "And a third."]
+    tts.max_context = 200                 # the prompts are ~155 tokens here
+    try:
+        before = tts.backbone.kv_stats()
+        batch = tts.infer_batch(texts, ref_codes, ref_text)
+        after = tts.backbone.kv_stats()
+        assert after["free_pages"] == after["total_pages"]
+        assert after["prompt_tokens_shared"] - before["prompt_tokens_shared"] >= 64, "a 2-slot engine still shares with the running donor"
+        for text, wav in zip(texts, batch):
+            single = tts.infer(text, ref_codes, ref_text)
+            assert wav.shape == single.shape and np.array_equal(wav, single)
+    finally:
+        tts.max_context = 120
