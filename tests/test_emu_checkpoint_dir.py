@@ -62,7 +62,7 @@ def test_checkpoint_dir_through_the_reference_loading_path(ckpt, emu_lib):
         def phonemize(self, texts):
             return [t.lower() for t in texts]
     tts.phonemizer = Phon()
-    tts.max_context, tts.min_new_tokens = 160, 6
+    tts.max_context, tts.min_new_tokens = 160, 6          # lowered to prompt + 24 once the prompt is known
     assert tts._speech_base == tok.convert_tokens_to_ids("<|speech_0|>")
     assert tts._eos_id == tok.convert_tokens_to_ids("<|SPEECH_GENERATION_END|>")
 
@@ -73,12 +73,13 @@ def test_checkpoint_dir_through_the_reference_loading_path(ckpt, emu_lib):
     assert text == ("user: Convert the text to speech:<|TEXT_PROMPT_START|>so i'm live. testing.<|TEXT_PROMPT_END|>"
                     "\nassistant:<|SPEECH_GENERATION_START|>" + "".join(f"<|speech_{int(c)}|>" for c in ref_codes))
 
+    tts.max_context = len(prompt) + 24            # keeps the emulated run short
     # transformers on the same checkpoint, bf16 compute, the reference's generate() call with sampling off
     from transformers import AutoModelForCausalLM
     hf = AutoModelForCausalLM.from_pretrained(d, attn_implementation="eager").to(torch.bfloat16).eval()
     hf.model.rotary_emb.inv_freq = br.rope_inv_freq(cfg)            # keep the fp32 buffer (oracle/backbone_ref.py docstring)
     hf.model.rotary_emb.original_inv_freq = br.rope_inv_freq(cfg)
-    out = hf.generate(torch.tensor([prompt]), max_length=160, eos_token_id=tts._eos_id, pad_token_id=tts._eos_id,
+    out = hf.generate(torch.tensor([prompt]), max_length=tts.max_context, eos_token_id=tts._eos_id, pad_token_id=tts._eos_id,
                       do_sample=False, use_cache=True, min_new_tokens=6)
     want = out[0, len(prompt):].tolist()
     got = tts.generate_codes([prompt])[0]
