@@ -49,6 +49,8 @@ struct ntts_backbone {
     bf16_t* arena = nullptr;
     size_t arena_elems = 0;
     bf16_t *embed = nullptr, *final_norm = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
+    bf16_t* embed_tm = nullptr;   // tile-major copy of the tied embedding = the lm_head's weight stream (w_tile_major)
+    bool w_tile_major = true;     // GEMM weights stored tile-major (gemm.h GemmArgs::w_tile_major)
     std::vector<LayerW> layers;
     std::set<std::string> loaded;
     float inv_freq[64];
@@ -177,6 +179,11 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += align_up(n, 128); return o; };
     const size_t o_embed = take((size_t)V * H);
+    // Weight layout: tile-major by default (each workgroup's weight stream is one sequential run of HBM addresses:
+    // lm_head -8 %, gate/up -3 % on the micro-benchmark, profiles/r01e_ubench_weight_layout.txt).  The embedding gather
+    // needs rows, the lm_head tiles: the tied matrix is kept in both layouts.  The X-panel path reads W rows directly.
+    e->w_tile_major = env_int("NTTS_W_TILE_MAJOR", 1) != 0 && env_int("NTTS_FUSED", 0) == 0 && H % 64 == 0 && F % 64 == 0;
+    const size_t o_embed_tm = e->w_tile_major ? take((size_t)((V + 63) / 64) * 64 * H) : 0;
     struct LO { size_t ln1, wqkv, bqkv, wo, ln2, wgu, wd; };
     std::vector<LO> lo(L);
     for (int i = 0; i < L; ++i) {
@@ -189,6 +196,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     CR_HIP(hipMalloc((void**)&e->arena, off * sizeof(bf16_t)));
     CR_HIP(hipMemset(e->arena, 0, off * sizeof(bf16_t)));
     e->embed = e->arena + o_embed;
+    e->embed_tm = e->w_tile_major ? e->arena + o_embed_tm : nullptr;
     e->layers.resize(L);
     for (int i = 0; i < L; ++i)
         e->layers[i] = LayerW{e->arena + lo[i].ln1, e->arena + lo[i].wqkv, e->arena + lo[i].bqkv, e->arena + lo[i].wo,
@@ -342,6 +350,24 @@ static int put_rows(ntts_backbone* e, const void* data, int dtype, int is_device
     return NTTS_OK;
 }
 
+// a GEMM weight: rows [row0, row0 + rows) of the packed matrix `dst` ([*, cols]), in the engine's weight layout
+static int put_weight(ntts_backbone* e, const void* data, int dtype, int is_device, long rows, long cols, bf16_t* dst, long row0,
+                      const int* dst_rows, int tile_major) {
+    const size_t esz = dtype == NTTS_DT_F32 ? 4 : 2;
+    const void* src = data;
+    void* tmp = nullptr;
+    if (!is_device) {
+        HIPCHK(e, hipMalloc(&tmp, (size_t)rows * cols * esz));
+        HIPCHK(e, hipMemcpy(tmp, data, (size_t)rows * cols * esz, hipMemcpyHostToDevice));
+        src = tmp;
+    }
+    NTTS_LAUNCH((pack_weight_kernel), dim3((unsigned)rows), dim3(256), e->stream, src, dtype == NTTS_DT_F32 ? 1 : 0, dst, dst_rows, row0,
+                cols, tile_major);
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (tmp) HIPCHK(e, hipFree(tmp));
+    return NTTS_OK;
+}
+
 extern "C" int ntts_backbone_load_tensor(ntts_backbone* e, const char* name, const void* data, int dtype,
                                          const int64_t* shape, int ndim, int is_device) {
     if (!e || !name || !data || !shape) return fail(e, NTTS_EINVAL, "null argument");
@@ -368,6 +394,7 @@ extern "C" int ntts_backbone_load_tensor(ntts_backbone* e, const char* name, con
         if (!want(c.vocab_size, H)) return bad_shape();
         if (n == "lm_head.weight" && e->loaded.count("model.embed_tokens.weight")) return NTTS_OK;  // tied: same bytes
         rc = put_rows(e, data, dtype, is_device, c.vocab_size, H, e->embed, nullptr);
+        if (rc == NTTS_OK && e->w_tile_major) rc = put_weight(e, data, dtype, is_device, c.vocab_size, H, e->embed_tm, 0, nullptr, 1);
         if (rc == NTTS_OK) e->loaded.insert("model.embed_tokens.weight");
         return rc;
     }
@@ -383,16 +410,16 @@ extern "C" int ntts_backbone_load_tensor(ntts_backbone* e, const char* name, con
         LayerW& w = e->layers[li];
         if (t == "input_layernorm.weight") { if (!want(H, 0)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, 1, H, w.ln1, nullptr); }
         else if (t == "post_attention_layernorm.weight") { if (!want(H, 0)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, 1, H, w.ln2, nullptr); }
-        else if (t == "self_attn.q_proj.weight") { if (!want(QD, H)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, QD, H, w.wqkv, nullptr); }
-        else if (t == "self_attn.k_proj.weight") { if (!want(KD, H)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, KD, H, w.wqkv + QD * H, nullptr); }
-        else if (t == "self_attn.v_proj.weight") { if (!want(KD, H)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, KD, H, w.wqkv + (QD + KD) * H, nullptr); }
+        else if (t == "self_attn.q_proj.weight") { if (!want(QD, H)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, QD, H, w.wqkv, 0, nullptr, e->w_tile_major ? 1 : 0); }
+        else if (t == "self_attn.k_proj.weight") { if (!want(KD, H)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, KD, H, w.wqkv, QD, nullptr, e->w_tile_major ? 1 : 0); }
+        else if (t == "self_attn.v_proj.weight") { if (!want(KD, H)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, KD, H, w.wqkv, QD + KD, nullptr, e->w_tile_major ? 1 : 0); }
         else if (t == "self_attn.q_proj.bias") { if (!want(QD, 0)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, 1, QD, w.bqkv, nullptr); }
         else if (t == "self_attn.k_proj.bias") { if (!want(KD, 0)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, 1, KD, w.bqkv + QD, nullptr); }
         else if (t == "self_attn.v_proj.bias") { if (!want(KD, 0)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, 1, KD, w.bqkv + QD + KD, nullptr); }
-        else if (t == "self_attn.o_proj.weight") { if (!want(H, QD)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, H, QD, w.wo, nullptr); }
-        else if (t == "mlp.gate_proj.weight") { if (!want(F, H)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, F, H, w.wgu, e->gu_map_gate); }
-        else if (t == "mlp.up_proj.weight") { if (!want(F, H)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, F, H, w.wgu, e->gu_map_up); }
-        else if (t == "mlp.down_proj.weight") { if (!want(H, F)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, H, F, w.wd, nullptr); }
+        else if (t == "self_attn.o_proj.weight") { if (!want(H, QD)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, H, QD, w.wo, 0, nullptr, e->w_tile_major ? 1 : 0); }
+        else if (t == "mlp.gate_proj.weight") { if (!want(F, H)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, F, H, w.wgu, 0, e->gu_map_gate, e->w_tile_major ? 1 : 0); }
+        else if (t == "mlp.up_proj.weight") { if (!want(F, H)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, F, H, w.wgu, 0, e->gu_map_up, e->w_tile_major ? 1 : 0); }
+        else if (t == "mlp.down_proj.weight") { if (!want(H, F)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, H, F, w.wd, 0, nullptr, e->w_tile_major ? 1 : 0); }
         else return fail(e, NTTS_EINVAL, "unknown tensor '%s'", name);
     } else {
         return fail(e, NTTS_EINVAL, "unknown tensor '%s'", name);
@@ -458,9 +485,10 @@ extern "C" int ntts_backbone_adopt_arena(ntts_backbone* e) {
 // ------------------------------------------------------------------------------------------------
 // model passes
 // ------------------------------------------------------------------------------------------------
-static GemmArgs gemm_args(const bf16_t* X, long ldx, const bf16_t* W, long ldw, const bf16_t* bias, void* out, long ldo,
-                          int M, int N, int K) {
+static GemmArgs gemm_args(const ntts_backbone* e, const bf16_t* X, long ldx, const bf16_t* W, long ldw, const bf16_t* bias, void* out,
+                          long ldo, int M, int N, int K) {
     GemmArgs a{};
+    a.w_tile_major = e->w_tile_major ? 1 : 0;   // every W this engine hands to a GEMM is in its weight layout
     a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K;
     return a;
 }
@@ -488,7 +516,7 @@ static void gemm_large(ntts_backbone* e, const GemmArgs& a, hipStream_t st) {
 
 static void k_lm_head(ntts_backbone* e, bool keep_logits) {
     const int B = e->cfg.max_batch, H = e->H, V = e->cfg.vocab_size;
-    GemmArgs a = gemm_args(e->xn_dec, H, e->embed, H, nullptr, nullptr, 0, B, V, H);
+    GemmArgs a = gemm_args(e, e->xn_dec, H, e->w_tile_major ? e->embed_tm : e->embed, H, nullptr, nullptr, 0, B, V, H);
     a.part_val = e->part_val; a.part_idx = e->part_idx; a.mask_eos = e->sl.mask_eos;
     a.logits = keep_logits ? e->logits : nullptr; a.ld_logits = V;
     a.logits_bf16 = (keep_logits && e->n_sampling > 0) ? e->logits_bf16 : nullptr; a.ld_logits_bf16 = e->ldl;
@@ -513,9 +541,9 @@ static void k_qkv(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H;
     const LayerW& w = e->layers[i];
     if (e->ks_qkv > 1)   // fp32 split-K slabs; the attention prologue sums them, adds the bias and rounds (attn_decode.h)
-        gemm_skinny<EPI_SPLITK>(e->st_qkv, gemm_args(e->xn_dec, H, w.wqkv, H, nullptr, e->slabs, e->NQKV, B, e->NQKV, H), e->ks_qkv, e->stream);
+        gemm_skinny<EPI_SPLITK>(e->st_qkv, gemm_args(e, e->xn_dec, H, w.wqkv, H, nullptr, e->slabs, e->NQKV, B, e->NQKV, H), e->ks_qkv, e->stream);
     else
-        gemm_skinny<EPI_BF16>(e->st_qkv, gemm_args(e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H), 1, e->stream);
+        gemm_skinny<EPI_BF16>(e->st_qkv, gemm_args(e, e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H), 1, e->stream);
 }
 
 static void k_attn(ntts_backbone* e, int i) {
@@ -534,12 +562,12 @@ static void k_attn(ntts_backbone* e, int i) {
 
 static void k_o_proj(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, QD = e->cfg.num_heads * 64;
-    gemm_skinny<EPI_SPLITK>(e->st_o, gemm_args(e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->slabs, H, B, H, QD), e->ks_o, e->stream);
+    gemm_skinny<EPI_SPLITK>(e->st_o, gemm_args(e, e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->slabs, H, B, H, QD), e->ks_o, e->stream);
 }
 
 static void k_gate_up(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, F = e->F;
-    GemmArgs gu = gemm_args(e->xn_dec, H, e->layers[i].wgu, H, nullptr, e->act_dec, F, B, 2 * F, H);
+    GemmArgs gu = gemm_args(e, e->xn_dec, H, e->layers[i].wgu, H, nullptr, e->act_dec, F, B, 2 * F, H);
     if (e->gu_tile == 1) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);        // 128 x 128, 8 waves
     else if (e->gu_tile == 2) gemm_launch<8, 1, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);   // 256 x 64, 8 waves
     else if (e->gu_large) gemm_large<EPI_SILU_MUL>(e, gu, e->stream);
@@ -548,7 +576,7 @@ static void k_gate_up(ntts_backbone* e, int i) {
 
 static void k_down(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, F = e->F;
-    gemm_skinny<EPI_SPLITK>(e->st_d, gemm_args(e->act_dec, F, e->layers[i].wd, F, nullptr, e->slabs, H, B, H, F), e->ks_d, e->stream);
+    gemm_skinny<EPI_SPLITK>(e->st_d, gemm_args(e, e->act_dec, F, e->layers[i].wd, F, nullptr, e->slabs, H, B, H, F), e->ks_d, e->stream);
 }
 
 // residual += reduce(slabs of a K-deep split-K GEMM); normed = rmsnorm(residual) * norm_w
@@ -566,26 +594,26 @@ static void gemm_xpanel(ntts_backbone* e, const GemmArgs& a) { gemm_xpanel_launc
 static void kf_qkv(ntts_backbone* e, int i) {       // qkv = Linear(rmsnorm(h) * ln1) + bias
     const int B = e->cfg.max_batch, H = e->H;
     const LayerW& w = e->layers[i];
-    GemmArgs a = gemm_args(e->h_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H);
+    GemmArgs a = gemm_args(e, e->h_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H);
     a.norm_w = w.ln1; a.norm_eps = e->cfg.rms_eps;
     gemm_xpanel<EPI_BF16, true>(e, a);
 }
 static void kf_o_proj(ntts_backbone* e, int i) {    // h = h + Linear_o(attn)   (in place)
     const int B = e->cfg.max_batch, H = e->H, QD = e->cfg.num_heads * 64;
-    GemmArgs a = gemm_args(e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->h_dec, H, B, H, QD);
+    GemmArgs a = gemm_args(e, e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->h_dec, H, B, H, QD);
     a.resid_bf16 = e->h_dec; a.ldrb = H;
     gemm_xpanel<EPI_RESID, false>(e, a);
 }
 static void kf_gate_up(ntts_backbone* e, int i) {   // act = silu(gate(n)) * up(n), n = rmsnorm(h) * ln2
     const int B = e->cfg.max_batch, H = e->H, F = e->F;
-    GemmArgs a = gemm_args(e->h_dec, H, e->layers[i].wgu, H, nullptr, e->act_dec, F, B, 2 * F, H);
+    GemmArgs a = gemm_args(e, e->h_dec, H, e->layers[i].wgu, H, nullptr, e->act_dec, F, B, 2 * F, H);
     a.norm_w = e->layers[i].ln2; a.norm_eps = e->cfg.rms_eps;
     gemm_xpanel<EPI_SILU_MUL, true>(e, a);
 }
 
 static void kf_o_proj_scratch(ntts_backbone* e, int i) {   // timing replay: same work, result into a scratch buffer
     const int B = e->cfg.max_batch, H = e->H, QD = e->cfg.num_heads * 64;
-    GemmArgs a = gemm_args(e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->o_pf, H, B, H, QD);
+    GemmArgs a = gemm_args(e, e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->o_pf, H, B, H, QD);
     a.resid_bf16 = e->h_dec; a.ldrb = H;
     gemm_xpanel<EPI_RESID, false>(e, a);
 }
@@ -789,7 +817,7 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
     for (int i = 0; i < c.num_layers; ++i) {
         const LayerW& w = e->layers[i];
         const bool last = i + 1 == c.num_layers;
-        gemm_large<EPI_BF16>(e, gemm_args(e->xn_pf, H, w.wqkv, H, w.bqkv, e->qkv_pf, e->NQKV, Ti, e->NQKV, H), st);
+        gemm_large<EPI_BF16>(e, gemm_args(e, e->xn_pf, H, w.wqkv, H, w.bqkv, e->qkv_pf, e->NQKV, Ti, e->NQKV, H), st);
         RopeWriteArgs r{};
         r.qkv = e->qkv_pf; r.ld_qkv = e->NQKV; r.kpool = e->kv + (size_t)i * e->layer_stride; r.vpool = r.kpool + e->kv_half;
         r.block_table = e->block_table; r.max_pages = e->max_pages; r.meta = meta; r.rope_cos = e->rope_cos; r.rope_sin = e->rope_sin;
@@ -818,13 +846,13 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
             attn_in = attn_c;
             hres = h_c;
         }
-        gemm_large<EPI_BF16>(e, gemm_args(attn_in, QD, w.wo, QD, nullptr, e->o_pf, H, Mi, H, QD), st);
+        gemm_large<EPI_BF16>(e, gemm_args(e, attn_in, QD, w.wo, QD, nullptr, e->o_pf, H, Mi, H, QD), st);
         NormArgs n1{};
         n1.o_bf16 = e->o_pf; n1.resid_in = hres; n1.resid_out = hres; n1.norm_w = w.ln2; n1.normed_out = e->xn_pf;
         n1.M = Mi; n1.H = H; n1.eps = c.rms_eps;
         add_rmsnorm_launch(n1, st);
-        gemm_large<EPI_SILU_MUL>(e, gemm_args(e->xn_pf, H, w.wgu, H, nullptr, e->act_pf, F, Mi, 2 * F, H), st);
-        gemm_large<EPI_BF16>(e, gemm_args(e->act_pf, F, w.wd, F, nullptr, e->o_pf, H, Mi, H, F), st);
+        gemm_large<EPI_SILU_MUL>(e, gemm_args(e, e->xn_pf, H, w.wgu, H, nullptr, e->act_pf, F, Mi, 2 * F, H), st);
+        gemm_large<EPI_BF16>(e, gemm_args(e, e->act_pf, F, w.wd, F, nullptr, e->o_pf, H, Mi, H, F), st);
         NormArgs n2{};
         n2.o_bf16 = e->o_pf; n2.resid_in = hres; n2.eps = c.rms_eps; n2.H = H;
         if (!last) {

@@ -269,4 +269,18 @@ NTTS_KERNEL(256) void pack_rows_kernel(const void* src, int src_is_f32, bf16_t* 
         dst[dr * cols + c] = src_is_f32 ? f2bf(((const float*)src)[r * cols + c]) : ((const bf16_t*)src)[r * cols + c];
 }
 
+// GEMM weight packing: logical row r of the source lands in row dr = row0 + (dst_rows ? dst_rows[r] : r) of the packed matrix
+// [*, cols]; tile_major = 1 stores it "tile-major" (gemm.h GemmArgs::w_tile_major): groups of 64 rows, inside a group the
+// 64 x 64 blocks of consecutive K tiles follow each other, so a workgroup's weight stream is one sequential run of addresses
+NTTS_KERNEL(256) void pack_weight_kernel(const void* src, int src_is_f32, bf16_t* dst, const int* dst_rows, long row0, long cols,
+                                         int tile_major) {
+    const long r = blockIdx.x;
+    const long dr = row0 + (dst_rows ? dst_rows[r] : r);
+    for (long c = threadIdx.x; c < cols; c += 256) {
+        const bf16_t v = src_is_f32 ? f2bf(((const float*)src)[r * cols + c]) : ((const bf16_t*)src)[r * cols + c];
+        const long at = tile_major ? (dr >> 6) * 64 * cols + (c >> 6) * 4096 + (dr & 63) * 64 + (c & 63) : dr * cols + c;
+        dst[at] = v;
+    }
+}
+
 }  // namespace ntts
