@@ -13,7 +13,8 @@ Differences, all deliberate:
   * devices: this implementation runs on MI355X only -- "cpu" raises (there is no CPU fallback); defaults are "cuda".
   * `infer_stream` is implemented for this backend (the reference raises NotImplementedError for torch, :264) with
     the GGUF path's window / overlap-add semantics (:401-465).
-  * batched entry points (`infer_batch`, `generate_codes`, `decode_codes`) expose what the engine is built for.
+  * batched entry points (`infer_batch`, `infer_stream_batch`, `generate_codes`, `decode_codes`) expose what the engine is
+    built for.
   * GGUF (llama.cpp) backbones and the ONNX codec are other runtimes of the same model and are not provided.
 Optional front/back-end dependencies (phonemizer, librosa, neucodec, perth) are imported lazily, where used.
 """
@@ -261,6 +262,20 @@ class NeuTTS:
         prompt_ids = self._apply_chat_template(ref_codes, ref_text, text)
         return self._infer_stream_hip(prompt_ids, [int(c) for c in _to_list(ref_codes)])
 
+    def infer_stream_batch(self, texts: Sequence[str], ref_codes, ref_texts) -> Generator[tuple, None, None]:
+        """Many utterances streamed at once (BASELINE config 5's shape: a decode batch with the codec on its own stream):
+        yields `(utterance index, chunk)` pairs; the chunks of one utterance, in order, are exactly what `infer_stream`
+        yields for it.  One decode burst serves every running utterance, and all windows that became decodable in a burst
+        go through the codec in ONE batched call, enqueued behind the next burst (the two engines' streams overlap).
+        At most `max_batch` utterances (the engine's decode slots) per call."""
+        if not isinstance(ref_texts, (list, tuple)):
+            ref_texts = [ref_texts] * len(texts)
+            ref_codes = [ref_codes] * len(texts)
+        if len(texts) > self.backbone.max_batch:
+            raise ValueError(f"{len(texts)} utterances exceed the engine's {self.backbone.max_batch} decode slots")
+        prompts = [self._apply_chat_template(rc, rt, t) for rc, rt, t in zip(ref_codes, ref_texts, texts)]
+        return self._infer_stream_batch_hip(prompts, [[int(c) for c in _to_list(rc)] for rc in ref_codes])
+
     def encode_reference(self, ref_audio_path: str | Path):
         """ref:neutts/neutts.py:266-271 -- one-off per speaker, off the hot path: delegated to neucodec's encoder."""
         import librosa
@@ -396,6 +411,61 @@ class NeuTTS:
         finally:
             eng.sync()
             eng.release(0)
+
+
+    def _infer_stream_batch_hip(self, prompts: List[List[int]], ref_codes: List[List[int]]):
+        eng = self.backbone
+        n = len(prompts)
+        self._seed += 1
+        slots = list(range(n))
+        eng.prefill(prompts, slots, [self._sampling(len(p), i) for i, p in enumerate(prompts)])
+        hop, stride = self.hop_length, self.streaming_stride_samples
+        chunk, look_f, look_b, ovl = (self.streaming_frames_per_chunk, self.streaming_lookforward,
+                                      self.streaming_lookback, self.streaming_overlap_frames)
+        cache = [list(rc) for rc in ref_codes]            # per utterance: reference codes + generated codes
+        n_dec = [len(rc) for rc in ref_codes]             # tokens already turned into audio
+        n_seen = [0] * n
+        blend = [_StreamBlender(stride) for _ in range(n)]
+        done = [False] * n                                # final chunk emitted
+        try:
+            while not all(done):
+                ids, n_new, fin = eng.read_all_array()    # blocks until the bursts enqueued so far are done
+                running = [i for i in range(n) if not done[i] and not fin[i]]
+                if running and self.streaming_overlap_compute:
+                    eng.decode(chunk)                     # async: runs beside the codec pass below
+                jobs = []                                 # (utterance, window codes, s0, s1 or None, last)
+                for i in range(n):
+                    if done[i]:
+                        continue
+                    new = self._ids_to_codes(ids[i, n_seen[i]:n_new[i]].tolist())
+                    n_seen[i] = int(n_new[i])
+                    for c in new:
+                        cache[i].append(c)
+                        if len(cache[i]) - n_dec[i] >= chunk + look_f:
+                            t0 = max(n_dec[i] - look_b - ovl, 0)
+                            t1 = n_dec[i] + chunk + look_f + ovl
+                            s0 = (n_dec[i] - t0) * hop
+                            jobs.append((i, cache[i][t0:t1], s0, s0 + (chunk + 2 * ovl) * hop, False))
+                            n_dec[i] += chunk
+                    if fin[i]:
+                        remaining = len(cache[i]) - n_dec[i]
+                        if remaining > 0:
+                            t0 = max(len(cache[i]) - (look_b + ovl + remaining), 0)
+                            s0 = (len(cache[i]) - t0 - remaining - ovl) * hop
+                            jobs.append((i, cache[i][t0:], s0, None, True))
+                        done[i] = True
+                if jobs:
+                    wavs = self.codec.engine.decode([j[1] for j in jobs])     # one batched codec pass
+                    for (i, _, s0, s1, last), recon in zip(jobs, wavs):
+                        if self.watermarker is not None:
+                            recon = self.watermarker.apply_watermark(recon, sample_rate=24_000)
+                        yield i, blend[i].push(np.array(recon[s0:s1]), last=last)
+                if running and not self.streaming_overlap_compute:
+                    eng.decode(chunk)
+        finally:
+            eng.sync()
+            for s in slots:
+                eng.release(s)
 
 
 def _to_list(codes) -> List[int]:

@@ -216,3 +216,26 @@ def test_infer_batch_shares_prompt_beginnings_and_matches_single_inference(tts):
             assert wav.shape == single.shape and np.array_equal(wav, single)
     finally:
         tts.max_context = 120
+
+
+def test_infer_stream_batch_equals_single_streams(tts):
+    """Two utterances streamed together: each one's chunks are exactly those of its own `infer_stream`."""
+    ref_codes = [3, 77, 200, 5, 18, 9, 100, 41]
+    texts = ["Streaming test.", "Another one, a little longer."]
+    tts.min_new_tokens, tts.max_context = 34, 150      # one full window (30 tokens) + a final partial one
+    try:
+        singles = [list(tts.infer_stream(t, ref_codes, "So I'm live.")) for t in texts]
+        got = [[], []]
+        for i, chunk in tts.infer_stream_batch(texts, ref_codes, "So I'm live."):
+            assert isinstance(chunk, np.ndarray)
+            got[i].append(chunk)
+    finally:
+        tts.min_new_tokens, tts.max_context = 5, 120
+    st = tts.backbone.kv_stats()
+    assert st["free_pages"] == st["total_pages"]
+    for i in range(2):
+        assert len(got[i]) == len(singles[i]) >= 2
+        for a, b in zip(got[i], singles[i]):
+            assert a.shape == b.shape and np.array_equal(a, b)
+    with pytest.raises(ValueError, match="decode slots"):
+        next(tts.infer_stream_batch(["a", "b", "c"], ref_codes, "x"))
