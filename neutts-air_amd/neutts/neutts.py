@@ -181,14 +181,27 @@ class NeuTTS:
             if getattr(hc, "model_type", "") not in ("qwen2",):
                 raise NotImplementedError(f"backbone model_type {hc.model_type!r}: only the Qwen2 architecture "
                                           "(NeuTTS-Air) is implemented")
-            model = AutoModelForCausalLM.from_pretrained(backbone_repo)
-            sd = {k: v for k, v in model.state_dict().items() if not k.endswith("inv_freq")}
-            inv_freq = model.model.rotary_emb.inv_freq.float().cpu().numpy()
             cfg = dict(vocab_size=hc.vocab_size, hidden_size=hc.hidden_size, intermediate_size=hc.intermediate_size,
                        num_layers=hc.num_hidden_layers, num_heads=hc.num_attention_heads,
                        num_kv_heads=hc.num_key_value_heads, rms_eps=hc.rms_norm_eps,
                        head_dim=getattr(hc, "head_dim", None) or hc.hidden_size // hc.num_attention_heads)
-            del model
+            sd = inv_freq = None
+            shards = _safetensors_shards(backbone_repo)
+            theta = _default_rope_theta(hc)
+            if shards and theta is not None:
+                # stream the checkpoint tensor by tensor into the engine's arena: no fp32 nn.Module copy of the model
+                # on the host (the reference builds one, ref:neutts/neutts.py:164; only its weights matter here)
+                import torch
+                d = cfg["head_dim"]
+                inv_freq = (1.0 / (theta ** (torch.arange(0, d, 2, dtype=torch.int64).to(dtype=torch.float) / d))).numpy()
+                sd = _SafetensorsStateDict(shards)        # hf:modeling_rope_utils.py _compute_default_rope_parameters
+                self._backbone_loader = "safetensors"
+            else:
+                model = AutoModelForCausalLM.from_pretrained(backbone_repo)
+                sd = {k: v for k, v in model.state_dict().items() if not k.endswith("inv_freq")}
+                inv_freq = model.model.rotary_emb.inv_freq.float().cpu().numpy()
+                del model
+                self._backbone_loader = "transformers"
             self._speech_base = self.tokenizer.convert_tokens_to_ids("<|speech_0|>")
             self._eos_id = self.tokenizer.convert_tokens_to_ids("<|SPEECH_GENERATION_END|>")
         cfg.setdefault("max_context", self.max_context)
@@ -472,6 +485,50 @@ def _to_list(codes) -> List[int]:
     if hasattr(codes, "tolist"):
         return [int(c) for c in np.asarray(codes.cpu() if hasattr(codes, "cpu") else codes).reshape(-1).tolist()]
     return [int(c) for c in codes]
+
+
+def _safetensors_shards(repo) -> List[str]:
+    """*.safetensors files of a checkpoint: a local directory, or a hub repo id resolved through the local HF cache /
+    a download of exactly those files."""
+    import glob
+    import os
+    repo = str(repo)
+    if os.path.isdir(repo):
+        return sorted(glob.glob(os.path.join(repo, "*.safetensors")))
+    try:
+        from huggingface_hub import snapshot_download
+        d = snapshot_download(repo, allow_patterns=["*.safetensors", "*.json"])
+        return sorted(glob.glob(os.path.join(d, "*.safetensors")))
+    except Exception:
+        return []
+
+
+def _default_rope_theta(hc) -> Optional[float]:
+    """rope_theta when the checkpoint uses the default RoPE parametrisation (what NeuTTS-Air / Qwen2.5 do), else None
+    (the caller then lets transformers build the rotary embedding and reads its inv_freq buffer)."""
+    rp = getattr(hc, "rope_parameters", None) or getattr(hc, "rope_scaling", None)
+    if isinstance(rp, dict):
+        if rp.get("rope_type", rp.get("type", "default")) != "default":
+            return None
+        if "rope_theta" in rp:
+            return float(rp["rope_theta"])
+    theta = getattr(hc, "rope_theta", None)
+    return float(theta) if theta is not None else None
+
+
+class _SafetensorsStateDict:
+    """Minimal `.items()` view over safetensors shards: one tensor in host memory at a time."""
+
+    def __init__(self, shards: Sequence[str]):
+        self.shards = list(shards)
+
+    def items(self):
+        from safetensors import safe_open
+        for path in self.shards:
+            with safe_open(path, framework="pt", device="cpu") as f:
+                for k in f.keys():
+                    if not k.endswith("inv_freq"):
+                        yield k, f.get_tensor(k)
 
 
 def neucodec_to_xcodec2_names(sd: Dict[str, object]) -> Dict[str, object]:

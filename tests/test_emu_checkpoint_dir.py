@@ -63,6 +63,7 @@ def test_checkpoint_dir_through_the_reference_loading_path(ckpt, emu_lib):
             return [t.lower() for t in texts]
     tts.phonemizer = Phon()
     tts.max_context, tts.min_new_tokens = 160, 6          # lowered to prompt + 24 once the prompt is known
+    assert tts._backbone_loader == "safetensors"      # tensors streamed from the shards, no nn.Module copy on the host
     assert tts._speech_base == tok.convert_tokens_to_ids("<|speech_0|>")
     assert tts._eos_id == tok.convert_tokens_to_ids("<|SPEECH_GENERATION_END|>")
 
