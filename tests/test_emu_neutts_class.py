@@ -202,9 +202,9 @@ def test_infer_batch_shares_prompt_beginnings_and_matches_single_inference(tts):
     (chat header + reference-text phones, ref:neutts/neutts.py:307,315-325) and every waveform equals what `infer`
     gives for that utterance alone (greedy: same ids, hence the same codes and samples)."""
     ref_codes = torch.tensor([3, 77, 200, 5, 18, 9], dtype=torch.int32)
-    ref_text = "So I'm live, and this is the reference sentence that every prompt of the speaker starts with."
-    texts = ["First.", "Second one.", "And a third."]
-    tts.max_context = 200                 # the prompts are ~155 tokens here
+    ref_text = "So I'm live, and every prompt starts like this."
+    texts = ["First.", "Second one."]
+    tts.max_context = 150                 # the prompts are ~105 tokens here
     try:
         before = tts.backbone.kv_stats()
         batch = tts.infer_batch(texts, ref_codes, ref_text)
