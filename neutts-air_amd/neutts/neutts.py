@@ -431,7 +431,15 @@ class NeuTTS:
         n = len(prompts)
         self._seed += 1
         slots = list(range(n))
-        eng.prefill(prompts, slots, [self._sampling(len(p), i) for i, p in enumerate(prompts)])
+        budget = eng.cfg.get("max_prefill_tokens", 0) or 16384       # the prefill workspace bounds one call
+        i0 = 0
+        while i0 < n:
+            i1, used = i0, 0
+            while i1 < n and (i1 == i0 or used + len(prompts[i1]) <= budget):
+                used += len(prompts[i1])
+                i1 += 1
+            eng.prefill(prompts[i0:i1], slots[i0:i1], [self._sampling(len(prompts[i]), i) for i in range(i0, i1)])
+            i0 = i1
         hop, stride = self.hop_length, self.streaming_stride_samples
         chunk, look_f, look_b, ovl = (self.streaming_frames_per_chunk, self.streaming_lookforward,
                                       self.streaming_lookback, self.streaming_overlap_frames)

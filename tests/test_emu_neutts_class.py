@@ -226,10 +226,13 @@ def test_infer_stream_batch_equals_single_streams(tts):
     try:
         singles = [list(tts.infer_stream(t, ref_codes, "So I'm live.")) for t in texts]
         got = [[], []]
+        budget = tts.backbone.cfg["max_prefill_tokens"]
+        tts.backbone.cfg["max_prefill_tokens"] = 80     # smaller than the two prompts together: prefilled in two calls
         for i, chunk in tts.infer_stream_batch(texts, ref_codes, "So I'm live."):
             assert isinstance(chunk, np.ndarray)
             got[i].append(chunk)
     finally:
+        tts.backbone.cfg["max_prefill_tokens"] = budget
         tts.min_new_tokens, tts.max_context = 5, 120
     st = tts.backbone.kv_stats()
     assert st["free_pages"] == st["total_pages"]
