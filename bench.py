@@ -45,7 +45,7 @@ def cpu_baseline(cfg, w, prompt, n_new, eos, codec_cfg, codec_w, max_seconds=45.
     kind "reference") followed by the NeuCodec-decoder restatement (oracle/codec_ref.decode_code) on the
     produced codes.  BOUNDED: generate() gets max_time=max_seconds, so the sample is one utterance or the
     part of it that fits; falls back to the oracle port when transformers is missing (kind "port")."""
-    from oracle import backbone_ref as br
+    from oracle import backbone_ref as br     # the ONLY place bench.py touches oracle/: the reported CPU baseline
     from oracle import codec_ref as cr
     # many-core hosts: HF's tiny per-token ops crawl when spread over hundreds of threads
     cores = min(os.cpu_count() or 1, int(os.environ.get("NTTS_CPU_BASELINE_THREADS", "32")))
@@ -101,8 +101,7 @@ def main():
     emu_lib = os.environ.get("NTTS_BENCH_EMU_LIB")
 
     from neutts import _hip, dist as ndist
-    from oracle import backbone_ref as br  # weights/prompt generators + cpu_baseline leg only
-    from oracle import codec_ref as cr     # synthetic codec weights + cpu_baseline leg only
+    import synthetic as syn                 # model geometry, seeded random weights and prompts (plain data, not the oracle)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -128,8 +127,8 @@ def main():
     spec.loader.exec_module(bmod)
     lib = emu_lib or bmod.build(verbose=False)
 
-    cfg = br.BackboneConfig.tiny(vocab_size=512, num_layers=1) if a.tiny else br.BackboneConfig.neutts_air(a.vocab)
-    ccfg = cr.CodecConfig.tiny() if a.tiny else cr.CodecConfig.neucodec()
+    cfg = syn.BackboneConfig.tiny(vocab_size=512, num_layers=1) if a.tiny else syn.BackboneConfig.neutts_air(a.vocab)
+    ccfg = syn.CodecConfig.tiny() if a.tiny else syn.CodecConfig.neucodec()
     n_codes = int(np.prod(ccfg.levels))
     B, S, N = a.batch, a.prefill, a.decode
     dev = 0 if emu_lib else local
@@ -148,9 +147,9 @@ def main():
     w = cw = None
     t0 = time.time()
     if rank == 0:
-        w = br.make_weights(cfg, 0)            # synthetic N(0,1/fan_in) weights at the exact NeuTTS-Air shapes
-        eng.load_state_dict({k: v.numpy() for k, v in w.items()}, inv_freq=br.rope_inv_freq(cfg).numpy())
-        cw = cr.make_weights(ccfg, 0)          # synthetic NeuCodec-decoder weights (xcodec2 parameter names)
+        w = syn.make_weights(cfg, 0)           # synthetic N(0,1/fan_in) weights at the exact NeuTTS-Air shapes
+        eng.load_state_dict({k: v.numpy() for k, v in w.items()}, inv_freq=syn.rope_inv_freq(cfg).numpy())
+        cw = syn.make_codec_weights(ccfg, 0)         # synthetic NeuCodec-decoder weights (xcodec2 parameter names)
     if world > 1:
         tdev = torch.device("cpu") if emu_lib else None
         ndist.broadcast_weights(eng, src=0, device=tdev)  # RCCL over xGMI: packed backbone arena, one broadcast
@@ -163,7 +162,7 @@ def main():
     eos = cfg.vocab_size - 1
     samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
     lo = rank * B
-    prompts = [br.synthetic_prompt(cfg, lo + i, S) for i in range(B)]   # seed 1234 + utterance index
+    prompts = [syn.synthetic_prompt(cfg, lo + i, S) for i in range(B)]   # seed 1234 + utterance index
 
     def one_step(collect=False):
         """One pass of the hot path over one batch: prompts -> codec-token ids -> 24 kHz waveforms."""

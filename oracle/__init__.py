@@ -5,6 +5,10 @@ TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is imported by the product
 ``cpu_baseline`` leg of ``bench.py`` may import it, and only as the checker /
 reported baseline -- never as the thing measured or shipped.
 
+Model geometries and the seeded random weights / prompts of the benchmark are plain data and live in `synthetic.py`
+(re-exported by backbone_ref / codec_ref for the tests); `bench.py` and `tools/` take them from there and touch this
+package only in the `cpu_baseline` leg.
+
 Pinning status (see DESIGN.md section "Oracle"):
   * backbone_ref.py  -- pinned: bit-checked against transformers' Qwen2ForCausalLM
     (the un-vendored dependency the reference calls, ref:neutts/neutts.py:164,338-347)

@@ -23,85 +23,8 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-
-@dataclass(frozen=True)
-class BackboneConfig:
-    vocab_size: int = 217488          # 151 936 base + 65 536 speech + specials
-    hidden_size: int = 896
-    intermediate_size: int = 4864
-    num_layers: int = 24
-    num_heads: int = 14
-    num_kv_heads: int = 2
-    head_dim: int = 64
-    rms_eps: float = 1e-6
-    rope_theta: float = 1e6
-
-    @staticmethod
-    def neutts_air(vocab_size: int = 217488) -> "BackboneConfig":
-        return BackboneConfig(vocab_size=vocab_size)
-
-    @staticmethod
-    def tiny(vocab_size: int = 1024, num_layers: int = 2) -> "BackboneConfig":
-        """Same head geometry (GQA 7:1, d=64) at a size the oracle finishes in milliseconds."""
-        return BackboneConfig(vocab_size=vocab_size, hidden_size=448, intermediate_size=1216,
-                              num_layers=num_layers, num_heads=7, num_kv_heads=1, head_dim=64)
-
-    def to_dict(self):
-        return asdict(self)
-
-
-# --------------------------------------------------------------------------------------
-# deterministic synthetic weights (numpy PCG64: stable across machines / torch versions)
-# --------------------------------------------------------------------------------------
-def make_weights(cfg: BackboneConfig, seed: int = 0, init: str = "unit",
-                 peak_sigma: float = 0.0) -> Dict[str, torch.Tensor]:
-    """HF-named fp32 state dict (hf:models/qwen2/modeling_qwen2.py: names of Qwen2ForCausalLM).
-
-    init="hf":   N(0, 0.02) matrices like HF's `_init_weights`.  With tied
-                 embeddings such a model mostly re-predicts its input token -- a weak id test.
-    init="unit": N(0, 1/fan_in) matrices (unit gain), embedding N(0, 0.02): layer outputs
-                 dominate the residual stream, greedy ids are diverse.  Used for parity + bench.
-    peak_sigma:  multiply embedding row j by exp(N(0, peak_sigma)): heavy-tailed logits whose
-                 top-1/top-2 gap is many bf16 ulps -> free-running greedy ids are comparable
-                 bit-for-bit across implementations with different fp32 summation order.
-    Norm weights are 1 + N(0, 0.1) and biases N(0, 0.02) so every multiply/add is exercised.
-    lm_head is tied to embed_tokens (hf:...modeling_qwen2.py:407 `_tied_weights_keys`).
-    """
-    rng = np.random.default_rng(seed)
-
-    def normal(*shape, s=0.02):
-        return torch.from_numpy(rng.standard_normal(shape, dtype=np.float32) * np.float32(s))
-
-    def mat(n_out, n_in):
-        return normal(n_out, n_in, s=0.02 if init == "hf" else float(n_in) ** -0.5)
-
-    H, F_, nh, nkv, d = cfg.hidden_size, cfg.intermediate_size, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim
-    w: Dict[str, torch.Tensor] = {}
-    emb = normal(cfg.vocab_size, H)
-    if peak_sigma > 0:
-        scale = np.exp(rng.standard_normal(cfg.vocab_size, dtype=np.float32) * np.float32(peak_sigma))
-        emb = emb * torch.from_numpy(scale)[:, None]
-    w["model.embed_tokens.weight"] = emb
-    for i in range(cfg.num_layers):
-        p = f"model.layers.{i}."
-        w[p + "input_layernorm.weight"] = 1.0 + normal(H, s=0.1)
-        w[p + "self_attn.q_proj.weight"] = mat(nh * d, H)
-        w[p + "self_attn.q_proj.bias"] = normal(nh * d)
-        w[p + "self_attn.k_proj.weight"] = mat(nkv * d, H)
-        w[p + "self_attn.k_proj.bias"] = normal(nkv * d)
-        w[p + "self_attn.v_proj.weight"] = mat(nkv * d, H)
-        w[p + "self_attn.v_proj.bias"] = normal(nkv * d)
-        w[p + "self_attn.o_proj.weight"] = mat(H, nh * d)
-        w[p + "post_attention_layernorm.weight"] = 1.0 + normal(H, s=0.1)
-        w[p + "mlp.gate_proj.weight"] = mat(F_, H)
-        w[p + "mlp.up_proj.weight"] = mat(F_, H)
-        w[p + "mlp.down_proj.weight"] = mat(H, F_)
-    w["model.norm.weight"] = 1.0 + normal(H, s=0.1)
-    return w
-
-
-def cast_weights(w: Dict[str, torch.Tensor], dtype: torch.dtype) -> Dict[str, torch.Tensor]:
-    return {k: v.to(dtype) for k, v in w.items()}
+# model geometry + seeded synthetic weights / prompts are plain data shared with bench.py and the tools (synthetic.py)
+from synthetic import BackboneConfig, cast_weights, make_weights, rope_inv_freq, synthetic_prompt  # noqa: F401
 
 
 # --------------------------------------------------------------------------------------
@@ -114,12 +37,6 @@ def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
     var = x32.pow(2).mean(-1, keepdim=True)
     x32 = x32 * torch.rsqrt(var + eps)
     return weight * x32.to(dt)
-
-
-def rope_inv_freq(cfg: BackboneConfig) -> torch.Tensor:
-    """compute_default_rope_parameters  hf:models/qwen2/modeling_qwen2.py:70-89."""
-    d = cfg.head_dim
-    return 1.0 / (cfg.rope_theta ** (torch.arange(0, d, 2, dtype=torch.float) / d))
 
 
 def rope_cos_sin(cfg: BackboneConfig, positions: torch.Tensor, dtype: torch.dtype):
@@ -319,8 +236,3 @@ def assert_free_run_matches(got_ids: List[int], ref: GenResult, max_ulps: float 
     assert got_ids[k] in top.indices.tolist(), (k, got_ids[k], top.indices.tolist())
 
 
-def synthetic_prompt(cfg: BackboneConfig, utt_idx: int, length: int = 500) -> List[int]:
-    """randint(0, V) with seed 1234 + utt_idx (numpy PCG64 here so that the
-    GPU box, which has no /root/reference and maybe another torch, draws identical prompts)."""
-    rng = np.random.default_rng(1234 + utt_idx)
-    return rng.integers(0, cfg.vocab_size, size=length, dtype=np.int64).tolist()

@@ -20,82 +20,10 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-
-@dataclass(frozen=True)
-class CodecConfig:
-    hidden_size: int = 1024
-    intermediate_size: int = 4096
-    num_layers: int = 12
-    num_heads: int = 16
-    head_dim: int = 64
-    quantization_dim: int = 2048
-    levels: tuple = (4, 4, 4, 4, 4, 4, 4, 4)
-    hop_length: int = 480           # ref:neutts/neutts.py:86
-    rms_eps: float = 1e-6
-    rope_theta: float = 10000.0
-
-    @property
-    def n_fft(self) -> int:         # hf:models/xcodec2/configuration_xcodec2.py:113-115
-        return self.hop_length * 4
-
-    @staticmethod
-    def neucodec() -> "CodecConfig":
-        return CodecConfig()
-
-    @staticmethod
-    def tiny() -> "CodecConfig":
-        """Same structure at a size the CPU (and the SIMT emulator) handles in seconds."""
-        return CodecConfig(hidden_size=128, intermediate_size=256, num_layers=2, num_heads=2, head_dim=64,
-                           quantization_dim=256, levels=(4, 4, 4, 4), hop_length=24)
-
-    def to_dict(self):
-        d = asdict(self)
-        d["levels"] = list(self.levels)
-        return d
+from synthetic import CodecConfig  # noqa: F401  (geometry + seeded synthetic weights are plain data: synthetic.py)
+from synthetic import make_codec_weights as make_weights  # noqa: F401
 
 
-def make_weights(cfg: CodecConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
-    """fp32 state dict with the parameter names of transformers' Xcodec2Model (quantizer.project_out + decoder.*).
-    Unit-gain matrices (N(0, 1/fan_in)), perturbed norm weights/biases so every affine term is exercised; the
-    ISTFT head is scaled down so exp(magnitude) stays far from the clamp(max=100) except for a few bins."""
-    rng = np.random.default_rng(seed)
-    H, I = cfg.hidden_size, cfg.intermediate_size
-
-    def n(*shape, s):
-        return torch.from_numpy(rng.standard_normal(shape, dtype=np.float32) * np.float32(s))
-
-    w: Dict[str, torch.Tensor] = {}
-    nq = len(cfg.levels)
-    w["quantizer.project_out.weight"] = n(cfg.quantization_dim, nq, s=nq ** -0.5)
-    w["quantizer.project_out.bias"] = n(cfg.quantization_dim, s=0.1)
-    w["decoder.fc.weight"] = n(H, cfg.quantization_dim, s=cfg.quantization_dim ** -0.5)
-    w["decoder.fc.bias"] = n(H, s=0.1)
-    w["decoder.embed.weight"] = n(H, H, 7, s=(7 * H) ** -0.5)
-    w["decoder.embed.bias"] = n(H, s=0.1)
-    for net in ("prior_net", "post_net"):
-        for b in range(2):
-            p = f"decoder.{net}.{b}."
-            for k in (1, 2):
-                w[p + f"norm{k}.weight"] = 1.0 + n(H, s=0.1)
-                w[p + f"norm{k}.bias"] = n(H, s=0.1)
-                w[p + f"conv{k}.weight"] = n(H, H, 3, s=(3 * H) ** -0.5)
-                w[p + f"conv{k}.bias"] = n(H, s=0.1)
-    for i in range(cfg.num_layers):
-        p = f"decoder.layers.{i}."
-        w[p + "input_layernorm.weight"] = 1.0 + n(H, s=0.1)
-        for proj in ("q_proj", "k_proj", "v_proj", "o_proj"):
-            w[p + f"self_attn.{proj}.weight"] = n(H, H, s=H ** -0.5)
-        w[p + "post_attention_layernorm.weight"] = 1.0 + n(H, s=0.1)
-        w[p + "mlp.fc1.weight"] = n(I, H, s=H ** -0.5)
-        w[p + "mlp.fc2.weight"] = n(H, I, s=I ** -0.5)
-    w["decoder.norm.weight"] = 1.0 + n(H, s=0.1)
-    w["decoder.norm.bias"] = n(H, s=0.1)
-    w["decoder.head.linear.weight"] = n(cfg.n_fft + 2, H, s=0.5 * H ** -0.5)
-    w["decoder.head.linear.bias"] = n(cfg.n_fft + 2, s=0.1)
-    return w
-
-
-# ------------------------------------------------------------------------------------------------
 def fsq_codebook(cfg: CodecConfig) -> torch.Tensor:
     """Xcodec2FiniteScalarQuantization._compute_buffers  hf:...modeling_xcodec2.py:676-690: digit d of index i in
     base `levels`, value (d - L//2) / (L//2)."""

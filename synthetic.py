@@ -1,0 +1,181 @@
+"""Synthetic workload generators: model geometries, seeded random weights and prompts.
+
+Neither product nor oracle: plain data for `bench.py`, the tools, the tests and the golden-vector generators
+(there is no network for checkpoints or datasets, so the benchmark runs random-init weights of the exact
+NeuTTS-Air / NeuCodec shapes and `randint` prompts; numpy PCG64 so that every machine draws identical values).
+`oracle/backbone_ref.py` and `oracle/codec_ref.py` re-export these names; nothing here computes a model.
+"""
+from __future__ import annotations
+
+from dataclasses import asdict, dataclass
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+
+@dataclass(frozen=True)
+class BackboneConfig:
+    vocab_size: int = 217488          # 151 936 base + 65 536 speech + specials
+    hidden_size: int = 896
+    intermediate_size: int = 4864
+    num_layers: int = 24
+    num_heads: int = 14
+    num_kv_heads: int = 2
+    head_dim: int = 64
+    rms_eps: float = 1e-6
+    rope_theta: float = 1e6
+
+    @staticmethod
+    def neutts_air(vocab_size: int = 217488) -> "BackboneConfig":
+        return BackboneConfig(vocab_size=vocab_size)
+
+    @staticmethod
+    def tiny(vocab_size: int = 1024, num_layers: int = 2) -> "BackboneConfig":
+        """Same head geometry (GQA 7:1, d=64) at a size the oracle finishes in milliseconds."""
+        return BackboneConfig(vocab_size=vocab_size, hidden_size=448, intermediate_size=1216,
+                              num_layers=num_layers, num_heads=7, num_kv_heads=1, head_dim=64)
+
+    def to_dict(self):
+        return asdict(self)
+
+
+# --------------------------------------------------------------------------------------
+# deterministic synthetic weights (numpy PCG64: stable across machines / torch versions)
+# --------------------------------------------------------------------------------------
+def make_weights(cfg: BackboneConfig, seed: int = 0, init: str = "unit",
+                 peak_sigma: float = 0.0) -> Dict[str, torch.Tensor]:
+    """HF-named fp32 state dict (hf:models/qwen2/modeling_qwen2.py: names of Qwen2ForCausalLM).
+
+    init="hf":   N(0, 0.02) matrices like HF's `_init_weights`.  With tied
+                 embeddings such a model mostly re-predicts its input token -- a weak id test.
+    init="unit": N(0, 1/fan_in) matrices (unit gain), embedding N(0, 0.02): layer outputs
+                 dominate the residual stream, greedy ids are diverse.  Used for parity + bench.
+    peak_sigma:  multiply embedding row j by exp(N(0, peak_sigma)): heavy-tailed logits whose
+                 top-1/top-2 gap is many bf16 ulps -> free-running greedy ids are comparable
+                 bit-for-bit across implementations with different fp32 summation order.
+    Norm weights are 1 + N(0, 0.1) and biases N(0, 0.02) so every multiply/add is exercised.
+    lm_head is tied to embed_tokens (hf:...modeling_qwen2.py:407 `_tied_weights_keys`).
+    """
+    rng = np.random.default_rng(seed)
+
+    def normal(*shape, s=0.02):
+        return torch.from_numpy(rng.standard_normal(shape, dtype=np.float32) * np.float32(s))
+
+    def mat(n_out, n_in):
+        return normal(n_out, n_in, s=0.02 if init == "hf" else float(n_in) ** -0.5)
+
+    H, F_, nh, nkv, d = cfg.hidden_size, cfg.intermediate_size, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim
+    w: Dict[str, torch.Tensor] = {}
+    emb = normal(cfg.vocab_size, H)
+    if peak_sigma > 0:
+        scale = np.exp(rng.standard_normal(cfg.vocab_size, dtype=np.float32) * np.float32(peak_sigma))
+        emb = emb * torch.from_numpy(scale)[:, None]
+    w["model.embed_tokens.weight"] = emb
+    for i in range(cfg.num_layers):
+        p = f"model.layers.{i}."
+        w[p + "input_layernorm.weight"] = 1.0 + normal(H, s=0.1)
+        w[p + "self_attn.q_proj.weight"] = mat(nh * d, H)
+        w[p + "self_attn.q_proj.bias"] = normal(nh * d)
+        w[p + "self_attn.k_proj.weight"] = mat(nkv * d, H)
+        w[p + "self_attn.k_proj.bias"] = normal(nkv * d)
+        w[p + "self_attn.v_proj.weight"] = mat(nkv * d, H)
+        w[p + "self_attn.v_proj.bias"] = normal(nkv * d)
+        w[p + "self_attn.o_proj.weight"] = mat(H, nh * d)
+        w[p + "post_attention_layernorm.weight"] = 1.0 + normal(H, s=0.1)
+        w[p + "mlp.gate_proj.weight"] = mat(F_, H)
+        w[p + "mlp.up_proj.weight"] = mat(F_, H)
+        w[p + "mlp.down_proj.weight"] = mat(H, F_)
+    w["model.norm.weight"] = 1.0 + normal(H, s=0.1)
+    return w
+
+
+def cast_weights(w: Dict[str, torch.Tensor], dtype: torch.dtype) -> Dict[str, torch.Tensor]:
+    return {k: v.to(dtype) for k, v in w.items()}
+
+
+def rope_inv_freq(cfg: BackboneConfig) -> torch.Tensor:
+    """compute_default_rope_parameters  hf:models/qwen2/modeling_qwen2.py:70-89."""
+    d = cfg.head_dim
+    return 1.0 / (cfg.rope_theta ** (torch.arange(0, d, 2, dtype=torch.float) / d))
+
+
+def synthetic_prompt(cfg: BackboneConfig, utt_idx: int, length: int = 500) -> List[int]:
+    """randint(0, V) with seed 1234 + utt_idx (numpy PCG64 here so that the
+    GPU box, which has no /root/reference and maybe another torch, draws identical prompts)."""
+    rng = np.random.default_rng(1234 + utt_idx)
+    return rng.integers(0, cfg.vocab_size, size=length, dtype=np.int64).tolist()
+
+
+@dataclass(frozen=True)
+class CodecConfig:
+    hidden_size: int = 1024
+    intermediate_size: int = 4096
+    num_layers: int = 12
+    num_heads: int = 16
+    head_dim: int = 64
+    quantization_dim: int = 2048
+    levels: tuple = (4, 4, 4, 4, 4, 4, 4, 4)
+    hop_length: int = 480           # ref:neutts/neutts.py:86
+    rms_eps: float = 1e-6
+    rope_theta: float = 10000.0
+
+    @property
+    def n_fft(self) -> int:         # hf:models/xcodec2/configuration_xcodec2.py:113-115
+        return self.hop_length * 4
+
+    @staticmethod
+    def neucodec() -> "CodecConfig":
+        return CodecConfig()
+
+    @staticmethod
+    def tiny() -> "CodecConfig":
+        """Same structure at a size the CPU (and the SIMT emulator) handles in seconds."""
+        return CodecConfig(hidden_size=128, intermediate_size=256, num_layers=2, num_heads=2, head_dim=64,
+                           quantization_dim=256, levels=(4, 4, 4, 4), hop_length=24)
+
+    def to_dict(self):
+        d = asdict(self)
+        d["levels"] = list(self.levels)
+        return d
+
+
+def make_codec_weights(cfg: CodecConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """fp32 state dict with the parameter names of transformers' Xcodec2Model (quantizer.project_out + decoder.*).
+    Unit-gain matrices (N(0, 1/fan_in)), perturbed norm weights/biases so every affine term is exercised; the
+    ISTFT head is scaled down so exp(magnitude) stays far from the clamp(max=100) except for a few bins."""
+    rng = np.random.default_rng(seed)
+    H, I = cfg.hidden_size, cfg.intermediate_size
+
+    def n(*shape, s):
+        return torch.from_numpy(rng.standard_normal(shape, dtype=np.float32) * np.float32(s))
+
+    w: Dict[str, torch.Tensor] = {}
+    nq = len(cfg.levels)
+    w["quantizer.project_out.weight"] = n(cfg.quantization_dim, nq, s=nq ** -0.5)
+    w["quantizer.project_out.bias"] = n(cfg.quantization_dim, s=0.1)
+    w["decoder.fc.weight"] = n(H, cfg.quantization_dim, s=cfg.quantization_dim ** -0.5)
+    w["decoder.fc.bias"] = n(H, s=0.1)
+    w["decoder.embed.weight"] = n(H, H, 7, s=(7 * H) ** -0.5)
+    w["decoder.embed.bias"] = n(H, s=0.1)
+    for net in ("prior_net", "post_net"):
+        for b in range(2):
+            p = f"decoder.{net}.{b}."
+            for k in (1, 2):
+                w[p + f"norm{k}.weight"] = 1.0 + n(H, s=0.1)
+                w[p + f"norm{k}.bias"] = n(H, s=0.1)
+                w[p + f"conv{k}.weight"] = n(H, H, 3, s=(3 * H) ** -0.5)
+                w[p + f"conv{k}.bias"] = n(H, s=0.1)
+    for i in range(cfg.num_layers):
+        p = f"decoder.layers.{i}."
+        w[p + "input_layernorm.weight"] = 1.0 + n(H, s=0.1)
+        for proj in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            w[p + f"self_attn.{proj}.weight"] = n(H, H, s=H ** -0.5)
+        w[p + "post_attention_layernorm.weight"] = 1.0 + n(H, s=0.1)
+        w[p + "mlp.fc1.weight"] = n(I, H, s=H ** -0.5)
+        w[p + "mlp.fc2.weight"] = n(H, I, s=I ** -0.5)
+    w["decoder.norm.weight"] = 1.0 + n(H, s=0.1)
+    w["decoder.norm.bias"] = n(H, s=0.1)
+    w["decoder.head.linear.weight"] = n(cfg.n_fft + 2, H, s=0.5 * H ** -0.5)
+    w["decoder.head.linear.bias"] = n(cfg.n_fft + 2, s=0.1)
+    return w

@@ -11,7 +11,7 @@ for p in (ROOT, os.path.join(ROOT, "neutts-air_amd")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from neutts import _hip  # noqa: E402
-from oracle import backbone_ref as br  # noqa: E402  (synthetic weights / prompts only)
+import synthetic as br  # noqa: E402  (model geometry, seeded random weights / prompts: plain data)
 
 PHASES = ["entry", "state known", "prologue done", "first K page done", "scores done", "softmax merged", "PV done", "exit"]
 

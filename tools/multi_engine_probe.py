@@ -11,7 +11,7 @@ for p in (ROOT, os.path.join(ROOT, "neutts-air_amd")):
     sys.path.insert(0, p)
 import torch  # noqa: E402
 from neutts import _hip  # noqa: E402
-from oracle import backbone_ref as br  # noqa: E402  (synthetic weights / prompts only)
+import synthetic as br  # noqa: E402  (model geometry, seeded random weights / prompts: plain data)
 
 
 def main():

@@ -15,8 +15,8 @@ for p in (ROOT, os.path.join(ROOT, "neutts-air_amd")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from neutts import NeuTTS  # noqa: E402
-from oracle import backbone_ref as br  # noqa: E402  (synthetic weights / prompts only)
-from oracle import codec_ref as cr  # noqa: E402
+import synthetic as br  # noqa: E402  (model geometry, seeded random weights / prompts: plain data)
+import synthetic as cr  # noqa: E402
 
 
 def main():
@@ -29,7 +29,7 @@ def main():
     cfg = br.BackboneConfig.neutts_air()
     ccfg = cr.CodecConfig.neucodec()
     w = br.make_weights(cfg, 0)
-    cw = cr.make_weights(ccfg, 0)
+    cw = cr.make_codec_weights(ccfg, 0)
     eos = cfg.vocab_size - 1
     tts = NeuTTS(
         backbone_repo={"config": dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,

@@ -16,7 +16,7 @@ for p in (ROOT, os.path.join(ROOT, "neutts-air_amd")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 from neutts import _hip  # noqa: E402
-from oracle import backbone_ref as br  # noqa: E402  (synthetic weight / prompt generators only)
+import synthetic as br  # noqa: E402  (model geometry, seeded random weights / prompts: plain data)
 
 
 def main():
