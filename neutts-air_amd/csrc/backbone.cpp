@@ -128,6 +128,12 @@ extern "C" const char* ntts_last_error(const ntts_backbone* e) { return e ? e->e
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// scratch device allocation released on every exit path of its scope (the HIPCHK early returns included)
+struct DevScratch {
+    void* p = nullptr;
+    ~DevScratch() { if (p) (void)hipFree(p); }
+};
+
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v && *v ? atoi(v) : dflt;
@@ -338,15 +344,14 @@ static int put_rows(ntts_backbone* e, const void* data, int dtype, int is_device
                     const int* dst_rows) {
     const size_t esz = dtype == NTTS_DT_F32 ? 4 : 2;
     const void* src = data;
-    void* tmp = nullptr;
+    DevScratch tmp;
     if (!is_device) {
-        HIPCHK(e, hipMalloc(&tmp, (size_t)rows * cols * esz));
-        HIPCHK(e, hipMemcpy(tmp, data, (size_t)rows * cols * esz, hipMemcpyHostToDevice));
-        src = tmp;
+        HIPCHK(e, hipMalloc(&tmp.p, (size_t)rows * cols * esz));
+        HIPCHK(e, hipMemcpy(tmp.p, data, (size_t)rows * cols * esz, hipMemcpyHostToDevice));
+        src = tmp.p;
     }
     NTTS_LAUNCH((pack_rows_kernel), dim3((unsigned)rows), dim3(256), e->stream, src, dtype == NTTS_DT_F32 ? 1 : 0, dst, dst_rows, cols);
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    if (tmp) HIPCHK(e, hipFree(tmp));
     return NTTS_OK;
 }
 
@@ -355,16 +360,15 @@ static int put_weight(ntts_backbone* e, const void* data, int dtype, int is_devi
                       const int* dst_rows, int tile_major) {
     const size_t esz = dtype == NTTS_DT_F32 ? 4 : 2;
     const void* src = data;
-    void* tmp = nullptr;
+    DevScratch tmp;
     if (!is_device) {
-        HIPCHK(e, hipMalloc(&tmp, (size_t)rows * cols * esz));
-        HIPCHK(e, hipMemcpy(tmp, data, (size_t)rows * cols * esz, hipMemcpyHostToDevice));
-        src = tmp;
+        HIPCHK(e, hipMalloc(&tmp.p, (size_t)rows * cols * esz));
+        HIPCHK(e, hipMemcpy(tmp.p, data, (size_t)rows * cols * esz, hipMemcpyHostToDevice));
+        src = tmp.p;
     }
     NTTS_LAUNCH((pack_weight_kernel), dim3((unsigned)rows), dim3(256), e->stream, src, dtype == NTTS_DT_F32 ? 1 : 0, dst, dst_rows, row0,
                 cols, tile_major);
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    if (tmp) HIPCHK(e, hipFree(tmp));
     return NTTS_OK;
 }
 
@@ -1099,8 +1103,9 @@ extern "C" int ntts_backbone_attn_timeline(ntts_backbone* e, int32_t layer, uint
     const size_t n = (size_t)e->cfg.max_batch * e->cfg.num_kv_heads * 4 * 8;
     if (cap < (int64_t)n) return fail(e, NTTS_EINVAL, "timeline needs %zu entries", n);
     HIPCHK(e, hipSetDevice(e->device));
-    unsigned long long* tl = nullptr;
-    HIPCHK(e, hipMalloc((void**)&tl, n * 8));
+    DevScratch buf;
+    HIPCHK(e, hipMalloc(&buf.p, n * 8));
+    unsigned long long* tl = (unsigned long long*)buf.p;
     HIPCHK(e, hipMemsetAsync(tl, 0, n * 8, e->stream));
     k_attn(e, (layer + 1) % e->cfg.num_layers);     // another layer first: this launch is neither the first nor cache-warm
     e->attn_tl = tl;
@@ -1108,7 +1113,6 @@ extern "C" int ntts_backbone_attn_timeline(ntts_backbone* e, int32_t layer, uint
     e->attn_tl = nullptr;
     HIPCHK(e, hipStreamSynchronize(e->stream));
     HIPCHK(e, hipMemcpy(out, tl, n * 8, hipMemcpyDeviceToHost));
-    HIPCHK(e, hipFree(tl));
     return NTTS_OK;
 }
 
