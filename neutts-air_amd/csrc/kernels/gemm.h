@@ -369,6 +369,159 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 
 
 // ------------------------------------------------------------------------------------------------
+// EXPERIMENTAL (not used by default; measured next): persistent variant of gemm_kernel for the big-M GEMMs.
+// Observation (profiles/r01e_ubench_prefill_ring_variants.txt, "noStore" column): a quarter of a 256 x 256 tile's time is its
+// store epilogue -- HBM-write-bound, with every CU storing at the same moment and the matrix cores idle -- plus the
+// un-overlapped round trip of the next tile's first stage.  Here a workgroup walks several tiles, and BEFORE it stores
+// tile i it requests the first NS-1 stages of tile i+1: a wave's vector-memory operations retire in order, so the counted
+// waits of the next main loop (which count the E store instructions issued after those requests) let the stores drain
+// under the MFMAs of the next tile's first K tiles instead of in front of them.
+//   * no split-K, BK = 64;  * grid = min(tiles, n_workgroups) in gridDim.x;  * E is known for FULL tiles of the plain
+//   epilogues (every lane stores: EPI_BF16 / EPI_BF16_SILU 2 x 16 B per 16 rows, EPI_SILU_MUL 1); edge tiles and the
+//   other epilogues fall back to a full drain, which is always correct.
+template <int WM, int WN, int TM, int EPI, int NS>
+NTTS_KERNEL(WM * WN * 64) void gemm_persist_kernel(GemmArgs p) {
+    constexpr int BK = 64;
+    constexpr int BM = WM * TM * 16, BN = WN * 64, NW = WM * WN;
+    constexpr int ROWS = BM + BN, NINST = ROWS / 8;
+    static_assert(NINST % NW == 0, "loader split");
+    constexpr int PER_WAVE = NINST / NW;
+    constexpr int E_FULL = (EPI == EPI_SILU_MUL) ? TM : 2 * TM;     // store instructions a wave issues for a full tile
+    constexpr bool COUNTED = (EPI == EPI_BF16 || EPI == EPI_BF16_SILU || EPI == EPI_SILU_MUL);
+    static_assert(NS >= 2 && (NS - 2) * PER_WAVE + E_FULL <= 63, "vmcnt range");
+    NTTS_SHARED bf16_t lds[NS * ROWS * BK];
+    auto swz = [](int rho) { return (rho >> 1) & 7; };
+
+    const int lane = lane_id(), wave = wave_id();
+    const int wm = wave / WN, wn = wave % WN;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int ntiles = p.mblocks * p.nblocks;
+    const int nk = p.K >> 6;
+    const long wstep = p.w_tile_major ? 4096 : BK;
+
+    int xoff[TM], woff[4], xsw[TM], wsw[4];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const int rho = wm * TM * 16 + a * 16 + l15;
+        xoff[a] = rho * BK;
+        xsw[a] = swz(rho);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rho = BM + wn * 64 + j * 16 + l15;
+        woff[j] = rho * BK;
+        wsw[j] = swz(rho);
+    }
+
+    const bf16_t* src[PER_WAVE];
+    auto setup = [&](int tile, int& m0, int& n0, int& nbv) {   // loader pointers of `tile`
+        int mb, nb;
+        gemm_tile_coords(tile, p.mblocks, p.nblocks, mb, nb);
+        m0 = mb * BM; n0 = nb * BN; nbv = nb;
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int inst = wave + i * NW;
+            const int rho = inst * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ swz(rho);
+            if (rho < BM) {
+                int m = m0 + rho;
+                if (m > p.M - 1) m = p.M - 1;
+                src[i] = p.X + (long)m * p.ldx + c * 8;
+            } else {
+                const int q = rho - BM;
+                const int wq = q >> 6, j = (q >> 4) & 3, i16 = q & 15;
+                int n = n0 + wq * 64 + (i16 >> 2) * 16 + j * 4 + (i16 & 3);
+                if (n > p.N - 1) n = p.N - 1;
+                src[i] = p.w_tile_major ? p.W + (long)(n >> 6) * 64 * p.K + (n & 63) * 64 + c * 8 : p.W + (long)n * p.ldw + c * 8;
+            }
+        }
+    };
+    auto stage = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int inst = wave + i * NW;
+            const bool is_w = (inst * 8) >= BM;
+            glds16(src[i] + (long)kt * (is_w ? wstep : (long)BK), lds + buf * (ROWS * BK) + inst * 512);
+        }
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    int m0, n0, nb;
+    setup(tile, m0, n0, nb);
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) stage(s, s);
+    bool stores_behind = false;            // E_FULL store instructions of the previous tile were issued after this tile's prologue
+    while (true) {
+        f32x4 acc[TM][4];
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            // stage kt must have landed.  Younger operations that may stay in flight: stages kt+1 .. kt+NS-2 and, while
+            // kt <= NS-2, the previous tile's stores (issued after this tile's prologue stages, before stage NS-1)
+            if (kt + NS - 2 < nk) {
+                if (stores_behind && kt <= NS - 2) wait_vmem_le<(NS - 2) * PER_WAVE + E_FULL>();
+                else wait_vmem_le<(NS - 2) * PER_WAVE>();
+            } else {
+                wait_vmem();
+            }
+            sync_keep_dma();
+            if (kt + NS - 1 < nk) stage(kt + NS - 1, buf == 0 ? NS - 1 : buf - 1);
+            const bf16_t* base = lds + buf * (ROWS * BK);
+            buf = buf + 1 == NS ? 0 : buf + 1;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int c = ks * 4 + g;
+                bf16x8 xb[TM], wa[4];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) xb[a] = ld16<bf16x8>(base + xoff[a] + ((c ^ xsw[a]) << 3));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wa[j] = ld16<bf16x8>(base + woff[j] + ((c ^ wsw[j]) << 3));
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[a][j] = mfma16(wa[j], xb[a], acc[a][j]);
+            }
+        }
+        // this tile's operands are consumed (the tail of the loop drained every request).  Request the next tile's first
+        // stages BEFORE storing this one; the barrier makes sure no wave still reads the slots they land in.
+        const int next = tile + gridDim.x;
+        const int cm0 = m0, cn0 = n0, cnb = nb;
+        const bool full = COUNTED && cm0 + BM <= p.M && cn0 + BN <= p.N;
+        if (next < ntiles) {
+            sync_keep_dma();
+            setup(next, m0, n0, nb);
+#pragma unroll
+            for (int s = 0; s < NS - 1; ++s)
+                if (s < nk) stage(s, s);
+            sched_fence();   // the counted waits above assume the stores below are YOUNGER than these requests
+        }
+        gemm_epilogue<TM, EPI, WN>(p, acc, cm0 + wm * TM * 16, cn0, wn, cnb, 0);
+        if (next >= ntiles) break;
+        if (!full) wait_vmem();            // unknown number of store instructions (edge tile / other epilogue): drain
+        stores_behind = full;
+        tile = next;
+    }
+}
+
+template <int WM, int WN, int TM, int EPI, int NS = 2>
+inline void gemm_persist_launch(GemmArgs p, int n_workgroups, hipStream_t s) {
+    constexpr int BM = WM * TM * 16, BN = WN * 64;
+    p.mblocks = (p.M + BM - 1) / BM;
+    p.nblocks = (p.N + BN - 1) / BN;
+    p.k_tiles_per_split = p.K / 64;
+    if constexpr (EPI == EPI_ARGMAX) p.part_stride = p.nblocks * WN;
+    const int ntiles = p.mblocks * p.nblocks;
+    int grid = n_workgroups < ntiles ? n_workgroups : ntiles;
+    if (grid >= 8) grid = grid / 8 * 8;    // tiles keep their XCD (tile % 8) from one round to the next
+    NTTS_LAUNCH((gemm_persist_kernel<WM, WN, TM, EPI, NS>), dim3(grid), dim3(WM * WN * 64), s, p);
+}
+
+// ------------------------------------------------------------------------------------------------
 // X-panel-resident GEMM for the decode step's K = hidden_size GEMMs (K <= 896, M = batch):
 //     out[M, N] = f(X)[M, K] * W[N, K]^T,   f = identity  or  RMSNorm (NORM: w * bf16(x * rsqrt(mean(x^2) + eps)))
 // A workgroup owns 64 rows of X.  It loads that 64 x K panel ONCE (through registers, so the RMSNorm of

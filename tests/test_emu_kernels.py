@@ -35,6 +35,8 @@ GEMM_CASES = [  # (M, N, K, variant, bias)
     (300, 272, 192, 5, True),    # XL tile on the 4-slot ring of 32-wide K slices (64-byte LDS rows, other swizzle)
     (70, 200, 64, 5, False),     # ... a single 64-wide K tile = 2 slices, fewer than the ring holds
     (130, 144, 320, 6, True),    # L tile, 3-slot ring of 32-wide slices
+    (1100, 712, 192, 8, True),   # persistent XL tile: 5 x 3 = 15 tiles walked by 8 workgroups (1 or 2 tiles each), ragged edges
+    (600, 272, 128, 9, False),   # persistent L tile, 3-slot ring: 5 x 3 tiles walked by 3 workgroups (5 tiles each)
 ]
 
 
