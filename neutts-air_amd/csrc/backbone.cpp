@@ -86,6 +86,7 @@ struct ntts_backbone {
     int st_qkv = 4, st_o = 4, st_gu = 3, st_d = 4;   // LDS ring depth of each skinny decode GEMM
     int head_stages = 2, l_stages = 2, pf_gh = 7, attn_depth = 1, attn_var = 1, gu_tile = 0;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
     bool gu_large = false, head_large = true, pf_attn_simple = false, use_xl = true, head_xl = false;
+    bool gemm_persist = false;   // experimental persistent big-GEMM kernel for the prefill GEMMs
     bool norm_wide = true;       // decode add+RMSNorm: one row per workgroup (256 CUs pull) instead of four
     bool pf_prune_last = true;   // prefill, last layer: attention / o_proj / MLP only for each prompt's last position
     // EXPERIMENTAL (off): RMSNorm fused into the QKV / gate-up GEMM prologues, residual into o_proj's epilogue
@@ -282,6 +283,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->pf_prune_last = env_int("NTTS_PF_PRUNE_LAST", 1) != 0;
     // one row per workgroup: 256 CUs pull the slabs instead of 64 -- 5.5 -> 4.0 us per launch, -4.4 % per step at batch 256
     e->norm_wide = env_int("NTTS_NORM_WIDE", 1) != 0;
+    e->gemm_persist = env_int("NTTS_GEMM_PERSIST", 0) != 0;   // prefill GEMMs on gemm_persist_kernel (gemm.h; unmeasured)
     e->use_xl = env_int("NTTS_XL", 1) != 0;
     e->head_xl = env_int("NTTS_HEAD_XL", B > 128 ? 1 : 0) != 0;
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -516,7 +518,11 @@ static void gemm_skinny(int stages, const GemmArgs& a, int ks, hipStream_t st) {
 
 template <int EPI>
 static void gemm_large(ntts_backbone* e, const GemmArgs& a, hipStream_t st) {
-    if (e->use_xl && a.M >= 1024 && a.N >= 256) { NTTS_GEMM_XL(EPI, a, 1, st); return; }
+    if (e->use_xl && a.M >= 1024 && a.N >= 256) {
+        if (e->gemm_persist) gemm_persist_launch<4, 4, 4, EPI, 2>(a, e->n_cu, st);   // experimental, NTTS_GEMM_PERSIST=1
+        else NTTS_GEMM_XL(EPI, a, 1, st);
+        return;
+    }
     switch (e->l_stages) {
         case 3: gemm_launch<2, 2, 4, EPI, 3>(a, 1, st); break;
         case 4: gemm_launch<2, 2, 4, EPI, 4>(a, 1, st); break;

@@ -27,7 +27,7 @@ def test_tiny_teacher_forced(emu_lib):
 
 @pytest.mark.parametrize("knobs", [{}, {"NTTS_ATTN_DEPTH": "1", "NTTS_S_STAGES": "3", "NTTS_PF_GH": "4", "NTTS_FUSED": "1"},
                                    {"NTTS_ATTN_DEPTH": "4", "NTTS_S_STAGES": "6", "NTTS_KSPLIT_O": "2", "NTTS_KSPLIT_D": "5",
-                                    "NTTS_PREFILL_ATTN_SIMPLE": "1", "NTTS_KSPLIT_QKV": "3", "NTTS_ATTN_VAR": "0", "NTTS_NORM_WIDE": "0", "NTTS_W_TILE_MAJOR": "0"}])
+                                    "NTTS_PREFILL_ATTN_SIMPLE": "1", "NTTS_KSPLIT_QKV": "3", "NTTS_ATTN_VAR": "0", "NTTS_NORM_WIDE": "0", "NTTS_W_TILE_MAJOR": "0", "NTTS_GEMM_PERSIST": "1"}])
 def test_small_gqa2_page_crossing_peaked_exact(emu_lib, knobs, monkeypatch):
     """2 kv heads, prompt of 70 (3 pages), decode crosses the 96-token page boundary; peaked weights so the
     free-running greedy ids must be bit-identical to HF's -- for every tuning of the decode GEMMs (LDS ring depth,
