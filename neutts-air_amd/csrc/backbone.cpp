@@ -537,7 +537,11 @@ static void k_lm_head(ntts_backbone* e, bool keep_logits) {
     a.logits = keep_logits ? e->logits : nullptr; a.ld_logits = V;
     a.logits_bf16 = (keep_logits && e->n_sampling > 0) ? e->logits_bf16 : nullptr; a.ld_logits_bf16 = e->ldl;
     if (!e->head_large) { gemm_skinny<EPI_ARGMAX>(4, a, 1, e->stream); return; }
-    if (e->head_xl) { NTTS_GEMM_XL(EPI_ARGMAX, a, 1, e->stream); return; }
+    if (e->head_xl) {
+        if (e->gemm_persist) gemm_persist_launch<4, 4, 4, EPI_ARGMAX, 2>(a, e->n_cu, e->stream);   // experimental
+        else NTTS_GEMM_XL(EPI_ARGMAX, a, 1, e->stream);
+        return;
+    }
     switch (e->head_stages) {
         case 3: gemm_launch<2, 2, 4, EPI_ARGMAX, 3>(a, 1, e->stream); break;
         case 4: gemm_launch<2, 2, 4, EPI_ARGMAX, 4>(a, 1, e->stream); break;

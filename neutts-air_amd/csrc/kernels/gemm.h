@@ -754,6 +754,9 @@ inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
 #define NTTS_GEMM_XL(EPI, p, ks, s) ::ntts::gemm_launch<4, 4, 4, EPI, 2>(p, ks, s)
 // big-M dispatch used by the prefill and codec paths
 #define NTTS_GEMM_BIG(EPI, p, s) do { if ((p).M >= 1024 && (p).N >= 256) NTTS_GEMM_XL(EPI, p, 1, s); else NTTS_GEMM_L(EPI, p, 1, s); } while (0)
+// the same dispatch with the EXPERIMENTAL persistent kernel for the XL case when `persist_wgs` > 0 (workgroups = CUs)
+#define NTTS_GEMM_BIG_P(EPI, p, s, persist_wgs) do { if ((persist_wgs) > 0 && (p).M >= 1024 && (p).N >= 256) \
+        ::ntts::gemm_persist_launch<4, 4, 4, EPI, 2>(p, persist_wgs, s); else NTTS_GEMM_BIG(EPI, p, s); } while (0)
 #define NTTS_GEMM_L(EPI, p, ks, s) ::ntts::gemm_launch<2, 2, 4, EPI, 2>(p, ks, s)
 #define NTTS_GEMM_S(EPI, p, ks, s) ::ntts::gemm_launch<4, 1, 1, EPI, 4>(p, ks, s)
 
