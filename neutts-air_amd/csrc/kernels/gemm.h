@@ -379,6 +379,10 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 //   * no split-K, BK = 64;  * grid = min(tiles, n_workgroups) in gridDim.x;  * E is known for FULL tiles of the plain
 //   epilogues (every lane stores: EPI_BF16 / EPI_BF16_SILU 2 x 16 B per 16 rows, EPI_SILU_MUL 1); edge tiles and the
 //   other epilogues fall back to a full drain, which is always correct.
+//   Known before measuring (from the ISA): with a bias the epilogue's bias loads are younger than the next tile's requests
+//   and the compiler waits vmcnt(0) for them between the store groups, which serialises the stores again -- the bias row
+//   of a tile should be fetched before the next tile's stages are requested; the bias-free GEMMs (o, gate/up, down, the
+//   codec's fc1 / fc2 / qkv / o) are the ones this kernel is expected to help first.
 template <int WM, int WN, int TM, int EPI, int NS>
 NTTS_KERNEL(WM * WN * 64) void gemm_persist_kernel(GemmArgs p) {
     constexpr int BK = 64;
