@@ -39,28 +39,47 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(cfg, w, prompt, n_new, eos, codec_cfg, codec_w, max_seconds=45.0):
+def cpu_baseline(cfg, w, prompt, n_new, eos, codec_cfg, codec_w, max_seconds=30.0):
     """The reference's own CPU path for this hot path on the box's host cores: transformers
     Qwen2ForCausalLM.generate called as in ref:neutts/neutts.py:338-347 (fp32, greedy so the work is fixed;
     kind "reference") followed by the NeuCodec-decoder restatement (oracle/codec_ref.decode_code) on the
-    produced codes.  BOUNDED: generate() gets max_time=max_seconds, so the sample is one utterance or the
-    part of it that fits; falls back to the oracle port when transformers is missing (kind "port")."""
+    produced codes.  Thread count: a short sweep over {8, 16, 32, 64} (bounded probes of the same call) picks the
+    fastest -- HF's tiny per-token ops crawl when spread over hundreds of threads, and crawl on too few -- and the
+    reported sample runs at that count.  BOUNDED: every generate() gets max_time, so the sample is one utterance or
+    the part of it that fits; falls back to the oracle port when transformers is missing (kind "port")."""
     from oracle import backbone_ref as br     # the ONLY place bench.py touches oracle/: the reported CPU baseline
     from oracle import codec_ref as cr
-    # many-core hosts: HF's tiny per-token ops crawl when spread over hundreds of threads
-    cores = min(os.cpu_count() or 1, int(os.environ.get("NTTS_CPU_BASELINE_THREADS", "32")))
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
+    forced = os.environ.get("NTTS_CPU_BASELINE_THREADS")
+    cand = [int(forced)] if forced else sorted({min(c, ncpu) for c in (8, 16, 32, 64)})
     t0 = time.time()
+    sweep = {}
     try:
         from oracle.gen_golden import hf_backbone
         m = hf_backbone(cfg, w, torch.float32)
+        ids_t = torch.tensor([prompt])
+
+        def gen(n, tmax):
+            return m.generate(ids_t, max_length=len(prompt) + n, eos_token_id=eos, pad_token_id=eos, do_sample=False,
+                              use_cache=True, min_new_tokens=n, max_time=tmax)
+        if len(cand) > 1:
+            for c in cand:                      # probe: the prompt pass + 12 decode steps
+                torch.set_num_threads(c)
+                tp = time.time()
+                gen(min(12, n_new), 10.0)
+                sweep[c] = round(time.time() - tp, 3)
+            cores = min(sweep, key=sweep.get)
+        else:
+            cores = cand[0]
+        torch.set_num_threads(cores)
         t1 = time.time()
-        out = m.generate(torch.tensor([prompt]), max_length=len(prompt) + n_new, eos_token_id=eos, pad_token_id=eos,
-                         do_sample=False, use_cache=True, min_new_tokens=n_new, max_time=max_seconds)
+        out = gen(n_new, max_seconds)
         ids = out[0, len(prompt):].tolist()
         kind = "reference"
     except Exception as ex:  # transformers missing on this box
         log(f"[cpu_baseline] transformers path unavailable ({type(ex).__name__}: {ex}); timing the oracle port")
+        cores = min(ncpu, 32)
+        torch.set_num_threads(cores)
         wd = br.cast_weights(w, torch.float32)
         t1 = time.time()
         ids = br.generate(cfg, wd, prompt, len(prompt) + min(n_new, 32), eos, min_new_tokens=min(n_new, 32)).ids
@@ -72,11 +91,18 @@ def cpu_baseline(cfg, w, prompt, n_new, eos, codec_cfg, codec_w, max_seconds=45.
     t3 = time.time()
     assert wav.shape[-1] == codec_cfg.hop_length * n
     dt = t3 - t1
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "")
+    except OSError:
+        pass
     return {"value": n / dt, "unit": "codec-tokens/s", "cores": cores, "kind": kind,
             "sample": f"1 utterance, {len(prompt)} prefill + {n} greedy tokens "
                       f"({'transformers Qwen2ForCausalLM.generate' if kind == 'reference' else 'oracle/backbone_ref.generate'}"
                       f", fp32 torch CPU) {t2 - t1:.1f}s + NeuCodec-decoder restatement on the {n} codes {t3 - t2:.2f}s "
-                      f"(+{t1 - t0:.1f}s model build, untimed); host has {os.cpu_count()} logical cores",
+                      f"(+{t1 - t0:.1f}s model build and thread sweep, untimed); host has {ncpu} logical cores",
+            "thread_sweep_probe_s": sweep, "torch_num_threads": torch.get_num_threads(), "cpu_model": cpu_model,
             "backbone_tokens_per_s": n / (t2 - t1), "codec_frames_per_s": n / (t3 - t2),
             "rtf": dt / (n / 50.0)}
 
@@ -274,8 +300,11 @@ def main():
             "metric": "codec-tokens/s", "value": value, "unit": "codec-tokens/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"NeuTTS-Air bf16 1xMI355X batch={B} synthetic prompts, {S} prefill / {N} decode tokens, "
-                                   "greedy, continuous-batching engine + hipGraph decode (BASELINE.json configs[2])",
+            "config": {"workload": (f"NeuTTS-Air bf16 1xMI355X, batch=1, {S} prefill / {N} decode tokens, greedy "
+                                    "(BASELINE.json configs[1])" if B == 1 and world == 1 else
+                                    f"NeuTTS-Air bf16 {world}xMI355X batch={B} synthetic prompts per GPU, {S} prefill / {N} decode "
+                                    "tokens, greedy, continuous-batching engine + hipGraph decode "
+                                    f"(BASELINE.json configs[{2 if world == 1 else 3}])"),
                        "batch_per_gpu": B, "prefill_tokens": S, "decode_tokens": N, "vocab_size": cfg.vocab_size,
                        "stages": stages,
                        "parallelism": f"independent shards x{world}, RCCL weight broadcast only"},

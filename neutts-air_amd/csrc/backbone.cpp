@@ -87,6 +87,7 @@ struct ntts_backbone {
     int head_stages = 2, l_stages = 2, pf_gh = 7, attn_depth = 1, attn_var = 1, gu_tile = 0;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
     bool gu_large = false, head_large = true, pf_attn_simple = false, use_xl = true, head_xl = false;
     bool gemm_persist = false;   // experimental persistent big-GEMM kernel for the prefill GEMMs
+    bool w_nt = true;            // decode GEMMs: non-temporal policy on the weight stream (NTTS_W_NT)
     bool norm_wide = true;       // decode add+RMSNorm: one row per workgroup (256 CUs pull) instead of four
     bool pf_prune_last = true;   // prefill, last layer: attention / o_proj / MLP only for each prompt's last position
     // EXPERIMENTAL (off): RMSNorm fused into the QKV / gate-up GEMM prologues, residual into o_proj's epilogue
@@ -283,6 +284,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->pf_prune_last = env_int("NTTS_PF_PRUNE_LAST", 1) != 0;
     // one row per workgroup: 256 CUs pull the slabs instead of 64 -- 5.5 -> 4.0 us per launch, -4.4 % per step at batch 256
     e->norm_wide = env_int("NTTS_NORM_WIDE", 1) != 0;
+    e->w_nt = env_int("NTTS_W_NT", 1) != 0;
     e->gemm_persist = env_int("NTTS_GEMM_PERSIST", 0) != 0;   // prefill GEMMs on gemm_persist_kernel (gemm.h; unmeasured)
     e->use_xl = env_int("NTTS_XL", 1) != 0;
     e->head_xl = env_int("NTTS_HEAD_XL", B > 128 ? 1 : 0) != 0;
@@ -506,8 +508,14 @@ static GemmArgs gemm_args(const ntts_backbone* e, const bf16_t* X, long ldx, con
 }
 
 // ---- the decode step's launches, one helper per kernel (shared by decode_step and ntts_backbone_time_kernel)
+// nt: non-temporal policy on the weight stream (decode step only: each weight byte is read once per step)
 template <int EPI>
-static void gemm_skinny(int stages, const GemmArgs& a, int ks, hipStream_t st) {
+static void gemm_skinny(int stages, const GemmArgs& a, int ks, hipStream_t st, bool nt = false) {
+    if (nt) {
+        if (stages == 3) gemm_launch<4, 1, 1, EPI, 3, 0, 64, true>(a, ks, st);
+        else gemm_launch<4, 1, 1, EPI, 4, 0, 64, true>(a, ks, st);
+        return;
+    }
     switch (stages) {
         case 2: gemm_launch<4, 1, 1, EPI, 2>(a, ks, st); break;
         case 3: gemm_launch<4, 1, 1, EPI, 3>(a, ks, st); break;
@@ -536,9 +544,10 @@ static void k_lm_head(ntts_backbone* e, bool keep_logits) {
     a.part_val = e->part_val; a.part_idx = e->part_idx; a.mask_eos = e->sl.mask_eos;
     a.logits = keep_logits ? e->logits : nullptr; a.ld_logits = V;
     a.logits_bf16 = (keep_logits && e->n_sampling > 0) ? e->logits_bf16 : nullptr; a.ld_logits_bf16 = e->ldl;
-    if (!e->head_large) { gemm_skinny<EPI_ARGMAX>(4, a, 1, e->stream); return; }
+    if (!e->head_large) { gemm_skinny<EPI_ARGMAX>(4, a, 1, e->stream, e->w_nt); return; }
     if (e->head_xl) {
         if (e->gemm_persist) gemm_persist_launch<4, 4, 4, EPI_ARGMAX, 2>(a, e->n_cu, e->stream);   // experimental
+        else if (e->w_nt) gemm_launch<4, 4, 4, EPI_ARGMAX, 2, 0, 64, true>(a, 1, e->stream);
         else NTTS_GEMM_XL(EPI_ARGMAX, a, 1, e->stream);
         return;
     }
@@ -561,9 +570,9 @@ static void k_qkv(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H;
     const LayerW& w = e->layers[i];
     if (e->ks_qkv > 1)   // fp32 split-K slabs; the attention prologue sums them, adds the bias and rounds (attn_decode.h)
-        gemm_skinny<EPI_SPLITK>(e->st_qkv, gemm_args(e, e->xn_dec, H, w.wqkv, H, nullptr, e->slabs, e->NQKV, B, e->NQKV, H), e->ks_qkv, e->stream);
+        gemm_skinny<EPI_SPLITK>(e->st_qkv, gemm_args(e, e->xn_dec, H, w.wqkv, H, nullptr, e->slabs, e->NQKV, B, e->NQKV, H), e->ks_qkv, e->stream, e->w_nt);
     else
-        gemm_skinny<EPI_BF16>(e->st_qkv, gemm_args(e, e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H), 1, e->stream);
+        gemm_skinny<EPI_BF16>(e->st_qkv, gemm_args(e, e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H), 1, e->stream, e->w_nt);
 }
 
 static void k_attn(ntts_backbone* e, int i) {
@@ -582,21 +591,22 @@ static void k_attn(ntts_backbone* e, int i) {
 
 static void k_o_proj(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, QD = e->cfg.num_heads * 64;
-    gemm_skinny<EPI_SPLITK>(e->st_o, gemm_args(e, e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->slabs, H, B, H, QD), e->ks_o, e->stream);
+    gemm_skinny<EPI_SPLITK>(e->st_o, gemm_args(e, e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->slabs, H, B, H, QD), e->ks_o, e->stream, e->w_nt);
 }
 
 static void k_gate_up(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, F = e->F;
     GemmArgs gu = gemm_args(e, e->xn_dec, H, e->layers[i].wgu, H, nullptr, e->act_dec, F, B, 2 * F, H);
-    if (e->gu_tile == 1) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);        // 128 x 128, 8 waves
+    if (e->gu_tile == 1 && e->w_nt) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3, 0, 64, true>(gu, 1, e->stream);
+    else if (e->gu_tile == 1) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);        // 128 x 128, 8 waves
     else if (e->gu_tile == 2) gemm_launch<8, 1, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);   // 256 x 64, 8 waves
     else if (e->gu_large) gemm_large<EPI_SILU_MUL>(e, gu, e->stream);
-    else gemm_skinny<EPI_SILU_MUL>(e->st_gu, gu, 1, e->stream);
+    else gemm_skinny<EPI_SILU_MUL>(e->st_gu, gu, 1, e->stream, e->w_nt);
 }
 
 static void k_down(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, F = e->F;
-    gemm_skinny<EPI_SPLITK>(e->st_d, gemm_args(e, e->act_dec, F, e->layers[i].wd, F, nullptr, e->slabs, H, B, H, F), e->ks_d, e->stream);
+    gemm_skinny<EPI_SPLITK>(e->st_d, gemm_args(e, e->act_dec, F, e->layers[i].wd, F, nullptr, e->slabs, H, B, H, F), e->ks_d, e->stream, e->w_nt);
 }
 
 // residual += reduce(slabs of a K-deep split-K GEMM); normed = rmsnorm(residual) * norm_w
@@ -1183,7 +1193,8 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
         }
     };
     switch (which) {
-        case 0: *alg_bytes = kv_layer + act * QD + (double)B * e->NQKV * (qkv_split ? 4.0 * gemm_nsplit(H, e->ks_qkv) : 2.0);
+        case 0: *alg_bytes = kv_layer;   // SURVEY 8(d), strictly: K and V of every cached token (+ the appended one); the q/k/v
+                                         // inputs (bf16 row or the QKV GEMM's fp32 slabs) and the output are the builder's own
                 *launches_per_step = L; break;
         case 1: *alg_bytes = ((double)e->NQKV * H + e->NQKV) * 2.0 + act * H +
                              (double)B * e->NQKV * (qkv_split ? 4.0 * gemm_nsplit(H, e->ks_qkv) : 2.0);

@@ -101,8 +101,8 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const bf16_t* kr = kp + (u * 16 + l15) * 64 + g * 16;
-            k[u][0] = ld16<bf16x8>(kr);
-            k[u][1] = ld16<bf16x8>(kr + 8);
+            if constexpr (kVar & 2) { k[u][0] = ld16_nt<bf16x8>(kr); k[u][1] = ld16_nt<bf16x8>(kr + 8); }
+            else { k[u][0] = ld16<bf16x8>(kr); k[u][1] = ld16<bf16x8>(kr + 8); }
         }
     };
     // K pages do not depend on this step's q/k/v: they stream under the RoPE prologue (the slot of the token appended
@@ -265,7 +265,10 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
     auto load_v = [&](int pg, bf16x8 (&v)[4]) {
         const bf16_t* vp = p.vpool + ((long)bt[pg] * p.nkv + kvh) * 64 * kPage;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) v[nt] = ld16<bf16x8>(vp + (nt * 16 + l15) * kPage + g * 8);
+        for (int nt = 0; nt < 4; ++nt) {
+            if constexpr (kVar & 2) v[nt] = ld16_nt<bf16x8>(vp + (nt * 16 + l15) * kPage + g * 8);   // K/V pages: read once per step
+            else v[nt] = ld16<bf16x8>(vp + (nt * 16 + l15) * kPage + g * 8);
+        }
     };
     bf16x8 vq[kDepth][4];
 #pragma unroll
@@ -369,7 +372,8 @@ inline void attn_decode_launch_v(const AttnDecodeArgs& p, int batch, hipStream_t
     }
 }
 inline void attn_decode_launch(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth = kAttnDepthDefault, int var = 1) {
-    if (var & 1) attn_decode_launch_v<1>(p, batch, s, depth);
+    if ((var & 3) == 3) attn_decode_launch_v<3>(p, batch, s, depth);        // + non-temporal K / V^T page loads
+    else if (var & 1) attn_decode_launch_v<1>(p, batch, s, depth);
     else attn_decode_launch_v<0>(p, batch, s, depth);
 }
 

@@ -251,7 +251,9 @@ NTTS_D void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][4], int mrow0, int
 // trip takes ~1.25 us whatever else the CU does, so a 2-slot ring of 64-wide tiles (all 128 KB a CU can spare) caps the
 // load path at ~51 GB/s per CU -- below what the MFMAs of the tile need.  With BK = 32 the same 128 KB hold FOUR slots:
 // three slices (96 KB) stay in flight under the MFMAs of the fourth.
-template <int WM, int WN, int TM, int EPI, int NS, int ABL = 0, int BK = 64>
+// WNT: the W stream uses the non-temporal cache policy (decode step: every weight byte is read once per step by one
+// workgroup, or by the few m-blocks of one XCD); X keeps the default policy (re-read by every n-block).
+template <int WM, int WN, int TM, int EPI, int NS, int ABL = 0, int BK = 64, bool WNT = false>
 NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     static_assert(BK == 64 || BK == 32, "ring slot K extent");
     constexpr int BM = WM * TM * 16, BN = WN * 64, NW = WM * WN;
@@ -308,7 +310,9 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         for (int i = 0; i < PER_WAVE; ++i) {
             const int inst = wave + i * NW;
             const bool is_w = (inst * RPI) >= BM;          // this instruction's rows are W rows (wave-uniform)
-            glds16(src[i] + (long)(kt0 + kt) * (is_w ? wstep : (long)BK), lds + buf * (ROWS * BK) + inst * 512);
+            const bf16_t* g = src[i] + (long)(kt0 + kt) * (is_w ? wstep : (long)BK);
+            bf16_t* l = lds + buf * (ROWS * BK) + inst * 512;
+            if (WNT && is_w) glds16_nt(g, l); else glds16(g, l);
         }
     };
 
@@ -736,7 +740,7 @@ inline bool gemm_xpanel_launch(GemmArgs p, int blocks_target, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 struct GemmShape { int BM, BN, WN; };
 
-template <int WM, int WN, int TM, int EPI, int NS = 2, int ABL = 0, int BK = 64>
+template <int WM, int WN, int TM, int EPI, int NS = 2, int ABL = 0, int BK = 64, bool WNT = false>
 inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * 64;
     p.mblocks = (p.M + BM - 1) / BM;
@@ -747,7 +751,7 @@ inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
     p.k_tiles_per_split = (ktiles + ksplit - 1) / ksplit;
     const int nsplit = (ktiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
     if constexpr (EPI == EPI_ARGMAX) p.part_stride = p.nblocks * WN;
-    NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK>), dim3(p.mblocks * p.nblocks, nsplit), dim3(WM * WN * 64), s, p);
+    NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT>), dim3(p.mblocks * p.nblocks, nsplit), dim3(WM * WN * 64), s, p);
 }
 
 // tile families:  XL = 256x256 (4x4 waves = 1024 threads, 64x64 per wave, 128 KB LDS) -- big-M GEMMs (prefill, codec):

@@ -49,6 +49,15 @@ NTTS_D void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// the same with the non-temporal cache policy (aux = 2, "nt"): for bytes ONE workgroup reads ONCE (decode-step weight streams);
+// MI355X_MICROARCH.md price list row nt-weights: issued -> landed -18 %, 5-10 % per decode layer.  Never for re-read operands.
+NTTS_D void glds16_nt(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 2);
+}
+// 16-byte global load with the non-temporal policy into registers (streamed-once K/V pages, weight fragments)
+template <typename T>
+NTTS_D T ld16_nt(const void* p) { return __builtin_nontemporal_load(reinterpret_cast<const T*>(p)); }
 // all of this wave's outstanding vector-memory ops (incl. LDS-DMA) have landed
 NTTS_D void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 

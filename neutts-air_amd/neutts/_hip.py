@@ -170,6 +170,17 @@ class BackboneEngine:
         self.max_batch = c.max_batch
         self.max_context = c.max_context
         self.vocab_size = c.vocab_size
+        self._free: List[int] = list(range(self.max_batch - 1, -1, -1))   # host-side pool of decode slots (pop -> slot 0 first)
+
+    # -- decode-slot pool: every path that admits a request (generate, the streaming generators) draws from here, so an
+    #    unfinished stream and a later call can never be handed the same slot
+    def acquire_slot(self) -> int:
+        if not self._free:
+            raise NeuTTSHipError(-4, f"all {self.max_batch} decode slots are in use")
+        return self._free.pop()
+
+    def free_slots(self) -> int:
+        return len(self._free)
 
     # -- plumbing
     def _chk(self, rc: int):
@@ -234,6 +245,13 @@ class BackboneEngine:
         lens = np.array([len(p) for p in prompts], dtype=np.int32)
         ids = np.ascontiguousarray(np.concatenate([np.asarray(p, dtype=np.int32) for p in prompts]))
         sl = np.asarray(slots, dtype=np.int32)
+        try:
+            self._prefill_call(n, ids, lens, sl, sampling, donors)
+        except NeuTTSHipError:
+            raise                      # the engine admitted nothing: slots drawn from the pool stay with the caller to release
+        self._mark_busy(slots)
+
+    def _prefill_call(self, n, ids, lens, sl, sampling, donors):
         sc = (SamplingC * n)(*[s.to_c() for s in sampling])
         i32p = C.POINTER(C.c_int32)
         if donors is None or all(d is None for d in donors):
@@ -287,6 +305,14 @@ class BackboneEngine:
 
     def release(self, slot: int):
         self._chk(self.lib.ntts_backbone_release(self.h, slot))
+        if slot not in self._free:
+            self._free.append(slot)
+
+    def _mark_busy(self, slots: Sequence[int]):
+        """Callers that choose slot numbers themselves (tests, bench): keep the pool consistent."""
+        for s in slots:
+            if s in self._free:
+                self._free.remove(s)
 
     def sync(self):
         self._chk(self.lib.ntts_backbone_sync(self.h))
@@ -329,8 +355,16 @@ class BackboneEngine:
         if isinstance(sampling, Sampling):
             sampling = [sampling] * len(prompts)
         budget = prefill_token_budget or self.cfg.get("max_prefill_tokens", 0) or 16384
+        # validate up front: a request that cannot run must not strand the ones admitted before it
+        for i, (p, sp) in enumerate(zip(prompts, sampling)):
+            if len(p) < 1:
+                raise ValueError(f"prompt {i} is empty")
+            if not (len(p) < sp.max_length <= self.max_context):
+                raise ValueError(f"prompt {i}: need len(prompt) < max_length <= max_context "
+                                 f"({len(p)}, {sp.max_length}, {self.max_context})")
+            if len(p) > budget:
+                raise ValueError(f"prompt {i}: {len(p)} tokens exceed max_prefill_tokens {budget}")
         results: List[Optional[List[int]]] = [None] * len(prompts)
-        free = list(range(self.max_batch))
         owner: Dict[int, int] = {}
         anchors: List[tuple] = []       # (slot, prompt as int32 array) of live slots that later prompts are compared with
         arrs = [np.asarray(p, dtype=np.int32) for p in prompts] if share_prefix else None
@@ -348,39 +382,65 @@ class BackboneEngine:
             return best
 
         nxt = 0
-        while nxt < len(prompts) or owner:
-            # admit as many waiting prompts as slots / prefill workspace allow
-            while nxt < len(prompts) and free:
-                batch, used, donors = [], 0, []
-                while nxt < len(prompts) and free:
-                    d = find_donor(nxt) if share_prefix else None
-                    cost = len(prompts[nxt]) - (d[1] // NTTS_PAGE_TOKENS * NTTS_PAGE_TOKENS if d else 0)
-                    if used + cost > budget:
+        try:
+            while nxt < len(prompts) or owner:
+                # admit as many waiting prompts as slots / prefill workspace allow
+                while nxt < len(prompts) and self._free:
+                    batch, used, donors = [], 0, []
+                    while nxt < len(prompts) and self._free:
+                        d = find_donor(nxt) if share_prefix else None
+                        cost = len(prompts[nxt]) - (d[1] // NTTS_PAGE_TOKENS * NTTS_PAGE_TOKENS if d else 0)
+                        if used + cost > budget:
+                            break
+                        s = self.acquire_slot()
+                        batch.append((nxt, s))
+                        donors.append(d)
+                        used += cost
+                        owner[s] = nxt
+                        if share_prefix and d is None and len(anchors) < 16:
+                            anchors.append((s, arrs[nxt]))      # a new beginning: later prompts may share it
+                        nxt += 1
+                    if not batch:
                         break
-                    s = free.pop()
-                    batch.append((nxt, s))
-                    donors.append(d)
-                    used += cost
-                    owner[s] = nxt
-                    if share_prefix and d is None and len(anchors) < 16:
-                        anchors.append((s, arrs[nxt]))      # a new beginning: later prompts may share it
-                    nxt += 1
-                if not batch:
-                    if not owner:
-                        raise ValueError("prompt longer than max_prefill_tokens")
-                    break
-                self.prefill([prompts[i] for i, _ in batch], [s for _, s in batch], [sampling[i] for i, _ in batch],
-                             donors if share_prefix else None)
-            st, _ = self.poll()
-            for s in list(owner):
-                if st[s] == 2:  # finished
-                    ids, _ = self.read(s)
-                    results[owner.pop(s)] = ids
-                    self.release(s)                          # shared pages live on until their last user is released
-                    anchors = [a for a in anchors if a[0] != s]
-                    free.append(s)
-            if owner and any(st[s] == 1 for s in owner):
-                self.decode(steps_per_poll)
+                    try:
+                        self.prefill([prompts[i] for i, _ in batch], [s for _, s in batch], [sampling[i] for i, _ in batch],
+                                     donors if share_prefix else None)
+                    except NeuTTSHipError as ex:
+                        running = [s for s in owner if s not in [b[1] for b in batch]]
+                        if ex.code != -3 or not running:
+                            raise
+                        # KV page pool exhausted while other requests still run: hand this batch back, let the running
+                        # ones finish and free their pages, then try again
+                        for i, s in reversed(batch):
+                            owner.pop(s)
+                            anchors = [a for a in anchors if a[0] != s]
+                            self._free.append(s)
+                        nxt = batch[0][0]
+                        break
+                if not owner:
+                    raise NeuTTSHipError(-4, "no decode slot is free (held by an unfinished stream?)")
+                st, _ = self.poll()
+                for s in list(owner):
+                    if st[s] == 2:  # finished
+                        ids, _ = self.read(s)
+                        results[owner.pop(s)] = ids
+                        self.release(s)                          # shared pages live on until their last user is released
+                        anchors = [a for a in anchors if a[0] != s]
+                if owner and any(st[s] == 1 for s in owner):
+                    self.decode(steps_per_poll)
+        finally:
+            # an exception (KV pool exhausted, a failed launch, ...) must not leave admitted slots RUNNING with their
+            # pages held: the next call would find them busy
+            if owner:
+                try:
+                    self.sync()
+                except NeuTTSHipError:
+                    pass
+                for s in list(owner):
+                    try:
+                        self.release(s)
+                    except NeuTTSHipError:
+                        pass
         return [r if r is not None else [] for r in results]
 
 

@@ -380,7 +380,12 @@ class NeuTTS:
         beside the backbone instead of between its bursts; the host only blocks in `read()`."""
         eng = self.backbone
         self._seed += 1
-        eng.prefill([prompt_ids], [0], [self._sampling(len(prompt_ids))])
+        slot = eng.acquire_slot()         # from the engine's pool: a stream that is still open never shares its slot
+        try:
+            eng.prefill([prompt_ids], [slot], [self._sampling(len(prompt_ids))])
+        except Exception:
+            eng.release(slot)
+            raise
         token_cache: List[int] = list(ref_codes)          # codec codes (the reference caches "<|speech_N|>" strings)
         n_decoded_tokens = len(ref_codes)
         n_seen = 0
@@ -394,7 +399,7 @@ class NeuTTS:
         try:
             finished = False
             while not finished:
-                ids, finished = eng.read(0)               # blocks until the steps enqueued so far are done
+                ids, finished = eng.read(slot)            # blocks until the steps enqueued so far are done
                 if not finished and self.streaming_overlap_compute:
                     eng.decode(chunk)                     # async: runs while the codec below decodes the last chunk
                 new = self._ids_to_codes(ids[n_seen:])
@@ -423,23 +428,31 @@ class NeuTTS:
                 yield blend.push(np.array(recon[s0:]), last=True)
         finally:
             eng.sync()
-            eng.release(0)
+            eng.release(slot)
 
 
     def _infer_stream_batch_hip(self, prompts: List[List[int]], ref_codes: List[List[int]]):
         eng = self.backbone
         n = len(prompts)
         self._seed += 1
-        slots = list(range(n))
+        if eng.free_slots() < n:
+            raise ValueError(f"{n} utterances exceed the engine's {eng.free_slots()} free decode slots")
+        slots = [eng.acquire_slot() for _ in range(n)]
         budget = eng.cfg.get("max_prefill_tokens", 0) or 16384       # the prefill workspace bounds one call
-        i0 = 0
-        while i0 < n:
-            i1, used = i0, 0
-            while i1 < n and (i1 == i0 or used + len(prompts[i1]) <= budget):
-                used += len(prompts[i1])
-                i1 += 1
-            eng.prefill(prompts[i0:i1], slots[i0:i1], [self._sampling(len(prompts[i]), i) for i in range(i0, i1)])
-            i0 = i1
+        try:
+            i0 = 0
+            while i0 < n:
+                i1, used = i0, 0
+                while i1 < n and (i1 == i0 or used + len(prompts[i1]) <= budget):
+                    used += len(prompts[i1])
+                    i1 += 1
+                eng.prefill(prompts[i0:i1], slots[i0:i1], [self._sampling(len(prompts[i]), i) for i in range(i0, i1)])
+                i0 = i1
+        except Exception:                  # a later group failed: the earlier groups' slots must not stay RUNNING
+            eng.sync()
+            for s in slots:
+                eng.release(s)
+            raise
         hop, stride = self.hop_length, self.streaming_stride_samples
         chunk, look_f, look_b, ovl = (self.streaming_frames_per_chunk, self.streaming_lookforward,
                                       self.streaming_lookback, self.streaming_overlap_frames)
@@ -450,7 +463,8 @@ class NeuTTS:
         done = [False] * n                                # final chunk emitted
         try:
             while not all(done):
-                ids, n_new, fin = eng.read_all_array()    # blocks until the bursts enqueued so far are done
+                ids_all, n_new_all, fin_all = eng.read_all_array()    # blocks until the bursts enqueued so far are done
+                ids, n_new, fin = ids_all[slots], n_new_all[slots], fin_all[slots]     # row i = utterance i
                 running = [i for i in range(n) if not done[i] and not fin[i]]
                 if running and self.streaming_overlap_compute:
                     eng.decode(chunk)                     # async: runs beside the codec pass below
@@ -539,15 +553,25 @@ class _SafetensorsStateDict:
                         yield k, f.get_tensor(k)
 
 
-def neucodec_to_xcodec2_names(sd: Dict[str, object]) -> Dict[str, object]:
-    """Original `neucodec` state-dict keys -> the xcodec2 parameter names the codec engine loads (SURVEY.md B.4;
-    written from the survey's recollection of the neucodec layout -- validate against a real checkpoint).
-    Fused `att.c_attn.weight [3H, H]` rows are split q | k | v."""
+def neucodec_to_xcodec2_names(sd: Dict[str, object], strict: bool = True) -> Dict[str, object]:
+    """Original `neucodec` state-dict keys -> the xcodec2 parameter names the codec engine loads.
+    Fused `att.c_attn.weight [3H, H]` rows are split q | k | v.
+
+    The key layout is the survey's reading of the neucodec package, which cannot be installed offline, so this function
+    does not trust it: with `strict` (the default) EVERY decoder-side tensor the engine needs must be found under its
+    expected source key, and every decoder-side source key (`generator.backbone.*`, `generator.head.*`,
+    `generator.quantizer.project_out.*`, `fc_post_a.*`) must be consumed -- otherwise a ValueError lists the missing and
+    the unrecognised keys, instead of a late 'tensor X not loaded' from the engine or, worse, silently skipped weights."""
     out: Dict[str, object] = {}
+    missing: List[str] = []
+    used = set()
 
     def put(dst, src):
         if src in sd:
             out[dst] = sd[src]
+            used.add(src)
+        else:
+            missing.append(f"{src} (-> {dst})")
 
     put("quantizer.project_out.weight", "generator.quantizer.project_out.weight")
     put("quantizer.project_out.bias", "generator.quantizer.project_out.bias")
@@ -564,6 +588,9 @@ def neucodec_to_xcodec2_names(sd: Dict[str, object]) -> Dict[str, object]:
     while f"generator.backbone.transformers.{i}.att.c_attn.weight" in sd:
         p, q = f"generator.backbone.transformers.{i}.", f"decoder.layers.{i}."
         w = sd[p + "att.c_attn.weight"]
+        used.add(p + "att.c_attn.weight")
+        if w.shape[0] % 3:
+            raise ValueError(f"{p}att.c_attn.weight: {tuple(w.shape)} is not a fused q|k|v matrix")
         h = w.shape[0] // 3
         out[q + "self_attn.q_proj.weight"], out[q + "self_attn.k_proj.weight"], out[q + "self_attn.v_proj.weight"] = (
             w[:h], w[h:2 * h], w[2 * h:])
@@ -573,10 +600,25 @@ def neucodec_to_xcodec2_names(sd: Dict[str, object]) -> Dict[str, object]:
         put(q + "mlp.fc1.weight", p + "mlp.fc1.weight")
         put(q + "mlp.fc2.weight", p + "mlp.fc2.weight")
         i += 1
+    if i == 0:
+        missing.append("generator.backbone.transformers.0.att.c_attn.weight (-> decoder.layers.0.self_attn.{q,k,v}_proj.weight)")
     put("decoder.norm.weight", "generator.backbone.final_layer_norm.weight")
     put("decoder.norm.bias", "generator.backbone.final_layer_norm.bias")
     put("decoder.head.linear.weight", "generator.head.out.weight")
     put("decoder.head.linear.bias", "generator.head.out.bias")
     if not out:
         raise ValueError("no NeuCodec decoder tensors found in the state dict")
+    # decoder-side source keys nobody asked for: buffers that carry no parameters are fine, anything else is a layout
+    # this mapping does not know
+    benign = ("generator.head.istft.window", "rotary", "inv_freq", "freqs_cis", "num_batches_tracked", "codebook",
+              "implicit_codebook", "_levels", "_basis", "scales", "project_in")
+    decoder_side = ("generator.backbone.", "generator.head.", "generator.quantizer.project_out", "fc_post_a.")
+    unknown = sorted(k for k in sd if k.startswith(decoder_side) and k not in used and not any(b in k for b in benign))
+    if strict and (missing or unknown):
+        raise ValueError(
+            "NeuCodec checkpoint does not match the expected decoder layout (SURVEY.md B.4):\n"
+            + (f"  missing source keys ({len(missing)}): " + ", ".join(missing[:12]) + (" ..." if len(missing) > 12 else "") + "\n"
+               if missing else "")
+            + (f"  unrecognised decoder-side keys ({len(unknown)}): " + ", ".join(unknown[:12]) + (" ..." if len(unknown) > 12 else "")
+               if unknown else ""))
     return out

@@ -132,6 +132,7 @@ inline void glds16(const void* gsrc, void* lds_wave_base) {
     memcpy(&d0, s.b[p][0], sizeof(d0));
     memcpy((char*)d0.l + lane_id() * 16, gsrc, 16);
 }
+inline void glds16_nt(const void* gsrc, void* lds_wave_base) { glds16(gsrc, lds_wave_base); }
 inline unsigned int atomic_add_lds(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = o + v; return o; }
 NTTS_D unsigned long long now_ticks() { return 0; }   // no clock on the emulator
 inline void wait_vmem() {}
@@ -166,6 +167,8 @@ inline T ld16(const void* p) {
     memcpy(&v, p, sizeof(T));
     return v;
 }
+template <typename T>
+inline T ld16_nt(const void* p) { return ld16<T>(p); }
 
 }  // namespace ntts
 

@@ -54,20 +54,21 @@ class FakePhonemizer:
         return [t.lower() for t in texts]
 
 
-@pytest.fixture(scope="module")
-def tts(emu_lib):
+def build_tts(lib, bcfg=None, ccfg=None, max_batch=2, max_context=256, max_prefill_tokens=512, seed=31):
+    """A NeuTTS object over in-memory synthetic weights on library `lib` (the SIMT-emulator build here, the real
+    libneutts_hip.so in tests/test_gpu_neutts_class.py) + the oracle-side copies of everything it was built from."""
     from neutts import NeuTTS
-    ccfg = cr.CodecConfig.tiny()
+    ccfg = ccfg or cr.CodecConfig.tiny()
     n_codes = int(np.prod(ccfg.levels))
     tok = FakeTokenizer(n_codes)
-    bcfg = br.BackboneConfig.tiny(vocab_size=tok.vocab_size, num_layers=1)
-    bw = br.make_weights(bcfg, 31, peak_sigma=0.5)
+    bcfg = bcfg(tok.vocab_size) if callable(bcfg) else br.BackboneConfig.tiny(vocab_size=tok.vocab_size, num_layers=1)
+    bw = br.make_weights(bcfg, seed, peak_sigma=0.5)
     # bias the tied embedding towards speech tokens so that greedy decoding emits codec codes
     bw["model.embed_tokens.weight"][tok.speech_base:] *= 3.0
     cw = cr.make_weights(ccfg, 2)
     eos = tok.convert_tokens_to_ids("<|SPEECH_GENERATION_END|>")
     t = NeuTTS(
-        backbone_repo=dict(config=engine_cfg(bcfg, max_context=256, max_prefill_tokens=512),
+        backbone_repo=dict(config=engine_cfg(bcfg, max_context=max_context, max_prefill_tokens=max_prefill_tokens),
                            state_dict={k: v.numpy() for k, v in bw.items()}, inv_freq=br.rope_inv_freq(bcfg).numpy(),
                            tokenizer=tok, speech_base=tok.speech_base, eos_token_id=eos),
         backbone_device="cuda",
@@ -76,12 +77,17 @@ def tts(emu_lib):
                                     quantization_dim=ccfg.quantization_dim, levels=list(ccfg.levels),
                                     hop_length=ccfg.hop_length, max_frames=256, max_rows=1024),
                         state_dict={k: v.numpy() for k, v in cw.items()}),
-        codec_device="cuda", lib_path=emu_lib, do_sample=False, max_batch=2)
+        codec_device="cuda", lib_path=lib, do_sample=False, max_batch=max_batch)
     t.phonemizer = FakePhonemizer()
     t.max_context = 120          # keep the emulated run short
     t.min_new_tokens = 5
     t._oracle = (bcfg, bw, ccfg, cw, tok, eos)
     return t
+
+
+@pytest.fixture(scope="module")
+def tts(emu_lib):
+    return build_tts(emu_lib)
 
 
 def test_surface_matches_reference(tts):
@@ -106,12 +112,17 @@ def test_infer_smoke_and_equivalence(tts):
     prompt = tts._apply_chat_template(ref_codes, "So I'm live.", "Testing.")
     assert prompt[-len(ref_codes):] == [tok.speech_base + int(c) for c in ref_codes]
     wd = br.cast_weights(bw, torch.bfloat16)
-    want_ids = br.generate(bcfg, wd, prompt, 120, eos, min_new_tokens=5).ids
-    codes = [i - tok.speech_base for i in want_ids if i >= tok.speech_base]
+    ref = br.generate(bcfg, wd, prompt, 120, eos, min_new_tokens=5, keep_logits=True)
+    got_ids = tts.generate_codes([prompt])[0]          # greedy: the ids `infer` just turned into audio
+    br.assert_free_run_matches(got_ids, ref)           # identical, or identical up to an exact bf16 tie of the oracle's logits
+    codes = [i - tok.speech_base for i in got_ids if i >= tok.speech_base]
     assert len(codes) > 0
     want = cr.decode_code(ccfg, cw, torch.tensor(codes)[None, None, :])[0, 0].numpy()
     assert audio.shape == want.shape == (len(codes) * tts.hop_length,)
-    assert rms(audio - want) <= 1e-3
+    err = rms(audio - want)
+    print(f"infer(): ids {'==' if got_ids == ref.ids else '~ (bf16 tie)'} oracle ({len(got_ids)} tokens); "
+          f"waveform RMS error {err:.3e} (signal RMS {rms(want):.3e})")
+    assert err <= 1e-3
 
 
 def test_decode_without_speech_tokens_raises(tts):
@@ -145,7 +156,13 @@ def test_infer_stream_matches_reference_windowing(tts):
     # reference algorithm on the same generated tokens, oracle codec
     prompt = tts._apply_chat_template(ref_codes, "So I'm live.", "Streaming test.")
     wd = br.cast_weights(bw, torch.bfloat16)
-    ids = br.generate(bcfg, wd, prompt, 200, eos, min_new_tokens=70).ids
+    ref = br.generate(bcfg, wd, prompt, 200, eos, min_new_tokens=70, keep_logits=True)
+    tts.min_new_tokens, tts.max_context = 70, 200
+    try:
+        ids = tts.generate_codes([prompt])[0]          # greedy: the ids the stream above was cut from
+    finally:
+        tts.min_new_tokens, tts.max_context = 5, 120
+    br.assert_free_run_matches(ids, ref)
     new_codes = [i - tok.speech_base for i in ids if i >= tok.speech_base]
 
     def dec(cs):
@@ -170,7 +187,12 @@ def test_infer_stream_matches_reference_windowing(tts):
         out.append(cr.linear_overlap_add(audio, 25 * hop)[n_samp:])
     want = np.concatenate(out)
     got = np.concatenate(chunks)
-    assert got.shape == want.shape and rms(got - want) <= 1e-3
+    assert got.shape == want.shape
+    # chunk for chunk: every yielded chunk against the reference algorithm's chunk (not only the concatenation)
+    assert [len(c) for c in chunks] == [len(o) for o in out]
+    errs = [rms(c - o) for c, o in zip(chunks, out)]
+    print(f"infer_stream(): {len(chunks)} chunks, per-chunk RMS error max {max(errs):.3e} (signal RMS {rms(want):.3e})")
+    assert max(errs) <= 1e-3 and rms(got - want) <= 1e-3
 
 
 @pytest.mark.parametrize("n_frames,last_len", [(1, 7), (2, 1), (5, 13), (9, 27), (4, 40)])

@@ -90,11 +90,55 @@ def test_air_teacher_forced_vs_hf_golden(air):
     err = np.array(stats)
     print(f"logit error at golden top-4 ids, bf16 ulps: mean {err.mean():.3f}  p99 {np.percentile(err, 99):.2f}  max {err.max():.2f}; "
           f"{ex} exact + {tie} near-tie of {N}")
-    # measured on MI355X: mean 0.56 / p99 2.0 / max 2.0 bf16 ulps
-    assert err.mean() <= 0.8 and np.percentile(err, 99) <= 2.5 and err.max() <= 3.0, \
+    # Both sides' logits are bf16 values, so the error at a golden value is a whole number of that value's bf16 ulps:
+    # measured on MI355X (profiles/r01g_pytest_gpu.log): mean 0.56, p99 2, max 3 -- "<= 3.5" means "at most 3 ulps".
+    assert err.mean() <= 0.8 and np.percentile(err, 99) <= 2.5 and err.max() <= 3.5, \
         (err.mean(), np.percentile(err, 99), err.max())
     assert ex + tie == N
-    assert ex >= 0.7 * N, f"only {ex}/{N} exact ({tie} near-ties)"
+    # The steps where HF's OWN top-2 logits lie within 4 bf16 ulps are a property of the fixture (frozen with it); only
+    # there may our token differ (teacher_forced_compare asserts the band per step).  Measured: 239 exact + 11 near-ties.
+    tv = z["bf16_topv_0"]
+    fixture_near = [k for k in range(N) if tv[k][0] - tv[k][1] <= 4.0 * 2.0 ** (np.floor(np.log2(abs(tv[k][0]))) - 7)]
+    print(f"fixture near-tie steps (golden top-2 gap <= 4 ulps): {len(fixture_near)} of {N}: {fixture_near}")
+    assert tie <= len(fixture_near)
+    assert ex >= 235, f"only {ex}/{N} exact ({tie} near-ties); measured 239"
+
+
+def test_air_batch1_vs_hf_golden(lib):
+    """BASELINE.json configs[1]: NeuTTS-Air bf16, batch 1, 500 prefill / 250 decode, greedy.  A single-slot engine takes
+    the small-batch kernel path (wave-per-16-features GEMMs, context-split attention); same golden run, same bars as
+    the batch-256 engine: logits within 3 bf16 ulps of HF's at its top-4 ids, ids equal except at HF's own near-ties,
+    and the free-running ids follow HF's up to the first such near-tie."""
+    z, cfg, w = load_fixture("backbone_air")
+    S, N, eos = int(z["s_len"]), int(z["n_new"]), int(z["eos"])
+    eng = make_engine(cfg, w, lib, max_batch=1, max_context=1024, max_prefill_tokens=1024)
+    samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
+    prompt = br.synthetic_prompt(cfg, 0, S)
+    eng.set_debug(True)
+    stats = []
+    try:
+        eng.prefill([prompt], [0], [samp])
+        ex, tie = teacher_forced_compare(eng, 0, z["bf16_ids_0"], z["bf16_topv_0"], z["bf16_topi_0"], max_ulps=4.0,
+                                         logit_stats=stats)
+    finally:
+        eng.release(0)
+        eng.set_debug(False)
+    err = np.array(stats)
+    print(f"batch 1: logit error at golden top-4 ids, bf16 ulps: mean {err.mean():.3f}  p99 {np.percentile(err, 99):.2f}  "
+          f"max {err.max():.2f}; {ex} exact + {tie} near-tie of {N}")
+    assert err.mean() <= 0.8 and np.percentile(err, 99) <= 2.5 and err.max() <= 3.5
+    assert ex + tie == N and ex >= 235
+    # free-running (hipGraph replay, no debug tap): follows HF's ids up to the first near-tie of HF's own logits
+    eng.prefill([prompt], [0], [samp])
+    eng.decode(N - 1)
+    ids, fin = eng.read(0)
+    g, tv = z["bf16_ids_0"].tolist(), z["bf16_topv_0"]
+    assert fin and len(ids) == N
+    k = next((i for i in range(N) if ids[i] != g[i]), N)
+    print(f"batch 1 free run: identical to HF's ids for {k} of {N} steps")
+    if k < N:
+        assert tv[k][0] - tv[k][1] <= 4 * 2.0 ** (np.floor(np.log2(abs(tv[k][0]))) - 7), (k, tv[k])
+    eng.close()
 
 
 def test_air_batch256_invariance_and_golden_prefix(air):

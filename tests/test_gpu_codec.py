@@ -10,6 +10,9 @@ from common import load_codec_fixture, make_codec_engine, rms
 
 pytestmark = pytest.mark.gpu
 
+# bf16 GEMM operands against an fp32 reference: measured relative RMS error on MI355X (profiles/r02*_pytest_gpu.log) x 2
+REL_BOUND = 0.03
+
 
 @pytest.fixture(scope="module")
 def lib(hip_lib):
@@ -26,6 +29,7 @@ def test_codec_tiny(lib):
     wavs = eng.decode(codes)
     for wv, g in zip(wavs, gold):
         assert wv.shape == g.shape and not np.isnan(wv).any()
+        print(f"codec_tiny: RMS error {rms(wv - g):.3e}, signal RMS {rms(g):.3e}, relative {rms(wv - g) / rms(g):.3e}")
         assert rms(wv - g) <= 1e-3 and rms(wv - g) <= 0.02 * rms(g), (rms(wv - g), rms(g))
     assert np.array_equal(eng.decode([codes[1]])[0], wavs[1])
 
@@ -46,8 +50,10 @@ def test_neucodec_geometry_vs_golden(neucodec):
         wv = eng.decode([codes])[0]
         g = z[f"wav_{i}"][0, 0]
         assert wv.shape == g.shape == (480 * len(codes),)
-        assert rms(wv - g) <= 1e-3, (i, rms(wv - g), rms(g))
-        assert rms(wv - g) <= 0.03 * rms(g), (i, rms(wv - g), rms(g))
+        err, sig = rms(wv - g), rms(g)
+        print(f"neucodec golden set {i}: {len(codes)} frames, RMS error {err:.3e}, signal RMS {sig:.3e}, relative {err / sig:.3e}")
+        assert err <= 1e-3, (i, err, sig)                 # BASELINE.json: waveform RMS within 1e-3 (fp32 reference)
+        assert err <= REL_BOUND * sig, (i, err, sig)      # and relative to the signal: 2x the error measured on MI355X
 
 
 def test_neucodec_batch256_properties(neucodec):
@@ -63,4 +69,6 @@ def test_neucodec_batch256_properties(neucodec):
         assert np.array_equal(wavs[i], wavs[i % 4]), i
     assert np.array_equal(wavs[255], eng.decode([base[0][:97]])[0])
     ref = cr.decode_code(cfg, w, torch.tensor(base[1], dtype=torch.long)[None, None, :])[0, 0].numpy()
-    assert rms(wavs[1] - ref) <= 1e-3 and rms(wavs[1] - ref) <= 0.03 * rms(ref)
+    err, sig = rms(wavs[1] - ref), rms(ref)
+    print(f"batch-256 row vs oracle: RMS error {err:.3e}, signal RMS {sig:.3e}, relative {err / sig:.3e}")
+    assert err <= 1e-3 and err <= REL_BOUND * sig

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call = everything we want from a GPU box, each leg under its own timeout, logs in gpurun_out/.
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_round.sh [legs...]'
-# legs: smoke tests bench prof pmc stream sweep exp   (default: smoke tests bench prof)
+# legs: smoke tests bench b1 prof pmc stream sweep exp   (default: smoke tests bench prof)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -13,6 +13,7 @@ for leg in $LEGS; do
     smoke) timeout 420 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -5 $OUT/smoke.log;;
     tests) timeout ${TESTS_TIMEOUT:-900} python -m pytest tests -m gpu -q -rA --durations=10 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -45 $OUT/pytest_gpu.log;;
     bench) timeout 600 python bench.py --steps ${BENCH_STEPS:-2} --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -25 $OUT/bench.err;;
+    b1)    timeout 300 python bench.py --batch 1 --steps ${BENCH_STEPS:-3} --warmup 1 --no-cpu-baseline > $OUT/bench_b1.json 2> $OUT/bench_b1.err; echo "bench b1 rc=$?"; cat $OUT/bench_b1.json | cut -c1-1500; tail -12 $OUT/bench_b1.err;;
     prof)  rm -rf $OUT/prof; timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof -o bench -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $OUT/prof_bench.json 2> $OUT/prof.err; echo "prof rc=$?"
            python tools/prof_summary.py $OUT/prof > $OUT/prof_summary.txt 2>&1; head -40 $OUT/prof_summary.txt; cat $OUT/prof_bench.json; tail -3 $OUT/prof.err
            find $OUT/prof -name '*kernel_trace.csv' -size +20M -delete;;
@@ -44,7 +45,7 @@ for M, N, K, variant, has_bias in EXPERIMENTAL_CASES + [(3000, 896, 4864, 8, Fal
     print(f"persistent gemm variant {variant} {M}x{N}x{K}: {bad} elements out of tolerance over 5 runs")
 PY
            timeout 200 python tools/ubench_gemm.py --prefill 2>&1 | tee $OUT/ubench_prefill_persist.txt | tail -16
-           for env in "" "NTTS_GEMM_PERSIST=1" "NTTS_GRAPH_STEPS=4" "NTTS_GRAPH_STEPS=8"; do
+           for env in ${EXP_ENVS:-"NTTS_GEMM_PERSIST=1"}; do
              echo "== bench with: ${env:-defaults}"
              env $env timeout 100 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline 2>/dev/null | cut -c1-160
            done;;
