@@ -18,6 +18,7 @@
 #include "kernels/attn_decode.h"
 #include "kernels/attn_prefill.h"
 #include "kernels/gemm.h"
+#include "kernels/gemv.h"
 #include "kernels/norm.h"
 #include "kernels/sample.h"
 
@@ -86,15 +87,20 @@ struct ntts_backbone {
     int st_qkv = 4, st_o = 4, st_gu = 3, st_d = 4;   // LDS ring depth of each skinny decode GEMM
     int head_stages = 2, l_stages = 2, pf_gh = 7, attn_depth = 1, attn_var = 1, gu_tile = 0;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
     bool gu_large = false, head_large = true, pf_attn_simple = false, use_xl = true, head_xl = false;
-    bool gemm_persist = false;   // experimental persistent big-GEMM kernel for the prefill GEMMs
-    bool w_nt = true;            // decode GEMMs: non-temporal policy on the weight stream (NTTS_W_NT)
+    // non-temporal policy on the lm_head's weight stream (NTTS_W_NT).  Measured at batch 256
+    // (profiles/r02a_sweep_nt_graphsteps.jsonl): lm_head 136.6 -> 132.3 us; on the LDS-DMA rings of the skinny layer GEMMs the
+    // same policy was SLOWER (qkv 5.78 -> 5.96, down 9.95 -> 10.54 us; step 1.679 -> 1.718 ms) and is not offered there
+    int w_nt = 1;
+    // Small-batch decode step (max_batch <= NTTS_SMALL_BATCH, default 8; BASELINE configs[1] = batch 1): wave-per-16-features
+    // GEMV kernels with the slab-reduce + residual + RMSNorm fused into the consumer's prologue (gemv.h) -- 5 launches per
+    // layer instead of 7 -- and 16-wave attention workgroups (attn_decode.h NW).
+    bool small = false;
+    int sks_q = 4, sks_o = 7, sks_d = 10, attn_depth_small = 2;
+    bf16_t* h_alt = nullptr;     // second residual-stream buffer (the fused prologue writes the new stream while others still read the old)
+    float* slabs2 = nullptr;     // down_proj's slabs (read by the next layer's QKV prologue while that kernel writes `slabs`)
     bool norm_wide = true;       // decode add+RMSNorm: one row per workgroup (256 CUs pull) instead of four
     bool pf_prune_last = true;   // prefill, last layer: attention / o_proj / MLP only for each prompt's last position
-    // EXPERIMENTAL (off): RMSNorm fused into the QKV / gate-up GEMM prologues, residual into o_proj's epilogue
-    // (gemm_xpanel_kernel).  Parity-clean but slower on MI355X at batch 256: one 4-wave workgroup per CU cannot
-    // overlap its LDS-read -> MFMA chains (2.33 vs 1.95 ms per step), see DESIGN.md.
-    bool fused = false;
-    int n_cu = 256, xp_bpc = 1;
+    int n_cu = 256;
 
     // prefill workspaces
     int Tmax = 0;
@@ -103,8 +109,6 @@ struct ntts_backbone {
     size_t meta_cap = 0;
 
     hipGraphExec_t graph = nullptr;
-    hipGraphExec_t graph_multi = nullptr;   // graph_steps decode steps in one graph (NTTS_GRAPH_STEPS > 1), else null
-    int graph_steps = 1;
     bool graph_tried = false, use_graph = true;
     hipEvent_t ev[4]{};
     bool have_pf_time = false, have_dec_time = false;
@@ -169,9 +173,6 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->Tmax = c->max_prefill_tokens > 0 ? c->max_prefill_tokens : 16384;
     e->num_pages = c->num_pages > 0 ? c->num_pages : c->max_batch * e->max_pages;
     e->use_graph = env_int("NTTS_NO_GRAPH", 0) == 0;
-    e->graph_steps = env_int("NTTS_GRAPH_STEPS", 1);
-    if (e->graph_steps < 1) e->graph_steps = 1;
-    if (e->graph_steps > 16) e->graph_steps = 16;
     const int B = c->max_batch, H = e->H, F = e->F, L = c->num_layers, V = c->vocab_size;
 
 #define CR_HIP(call)                                                                          \
@@ -195,7 +196,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     // Weight layout: tile-major by default (each workgroup's weight stream is one sequential run of HBM addresses:
     // lm_head -8 %, gate/up -3 % on the micro-benchmark, profiles/r01e_ubench_weight_layout.txt).  The embedding gather
     // needs rows, the lm_head tiles: the tied matrix is kept in both layouts.  The X-panel path reads W rows directly.
-    e->w_tile_major = env_int("NTTS_W_TILE_MAJOR", 1) != 0 && env_int("NTTS_FUSED", 0) == 0 && H % 64 == 0 && F % 64 == 0;
+    e->w_tile_major = env_int("NTTS_W_TILE_MAJOR", 1) != 0 && H % 64 == 0 && F % 64 == 0;
     const size_t o_embed_tm = e->w_tile_major ? take((size_t)((V + 63) / 64) * 64 * H) : 0;
     struct LO { size_t ln1, wqkv, bqkv, wo, ln2, wgu, wd; };
     std::vector<LO> lo(L);
@@ -284,13 +285,10 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->pf_prune_last = env_int("NTTS_PF_PRUNE_LAST", 1) != 0;
     // one row per workgroup: 256 CUs pull the slabs instead of 64 -- 5.5 -> 4.0 us per launch, -4.4 % per step at batch 256
     e->norm_wide = env_int("NTTS_NORM_WIDE", 1) != 0;
-    e->w_nt = env_int("NTTS_W_NT", 1) != 0;
-    e->gemm_persist = env_int("NTTS_GEMM_PERSIST", 0) != 0;   // prefill GEMMs on gemm_persist_kernel (gemm.h; unmeasured)
+    e->w_nt = env_int("NTTS_W_NT", 1);
     e->use_xl = env_int("NTTS_XL", 1) != 0;
     e->head_xl = env_int("NTTS_HEAD_XL", B > 128 ? 1 : 0) != 0;
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    e->fused = env_int("NTTS_FUSED", 0) != 0 && (H == 64 * 14 || H == 64 * 7) && c->num_heads * 64 == H;
-    e->xp_bpc = env_int("NTTS_XP_BPC", 1);
     e->pf_gh = env_int("NTTS_PF_GH", 7);   // all 7 heads of a GQA group in one pass: K/V pages staged once (prefill chunk 35.0 -> 33.4 ms)
     e->attn_depth = env_int("NTTS_ATTN_DEPTH", 1);
     e->attn_var = env_int("NTTS_ATTN_VAR", 1);   // 1: prologue operands requested before the K pages (attn_decode.h)
@@ -300,13 +298,26 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     if (e->ks_o > max_slabs) e->ks_o = max_slabs;
     if (e->ks_d > max_slabs) e->ks_d = max_slabs;
 
-    e->n_part = e->head_xl ? ((V + 255) / 256) * 4 : e->head_large ? ((V + 127) / 128) * 2 : (V + 63) / 64;
+    e->small = B <= env_int("NTTS_SMALL_BATCH", 8) && B <= kGemvRows && H <= 1024 && V % 16 == 0 && e->NQKV % 16 == 0 && F % 32 == 0;
+    e->sks_q = env_int("NTTS_SKS_Q", 4);
+    if (e->sks_q > kAttnMaxSlabs) e->sks_q = kAttnMaxSlabs;
+    e->sks_o = env_int("NTTS_SKS_O", 7);
+    e->sks_d = env_int("NTTS_SKS_D", 10);
+    if (e->sks_o > max_slabs) e->sks_o = max_slabs;
+    if (e->sks_d > max_slabs) e->sks_d = max_slabs;
+    e->attn_depth_small = env_int("NTTS_ATTN_DEPTH_SMALL", 2);
+    e->n_part = e->small ? V / 16 : e->head_xl ? ((V + 255) / 256) * 4 : e->head_large ? ((V + 127) / 128) * 2 : (V + 63) / 64;
     CR_HIP(hipMalloc((void**)&e->h_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->xn_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->qkv_dec, (size_t)B * e->NQKV * 2));
     CR_HIP(hipMalloc((void**)&e->attn_dec, (size_t)B * c->num_heads * 64 * 2));
     CR_HIP(hipMalloc((void**)&e->act_dec, (size_t)B * F * 2));
     CR_HIP(hipMalloc((void**)&e->slabs, (size_t)max_slabs * B * H * 4));
+    if (e->small) {
+        CR_HIP(hipMalloc((void**)&e->slabs2, (size_t)max_slabs * B * H * 4));
+        CR_HIP(hipMalloc((void**)&e->h_alt, (size_t)B * H * 2));
+        CR_HIP(hipMemset(e->h_alt, 0, (size_t)B * H * 2));
+    }
     CR_HIP(hipMalloc((void**)&e->part_val, (size_t)B * e->n_part * 4));
     CR_HIP(hipMalloc((void**)&e->part_idx, (size_t)B * e->n_part * 4));
     e->ldl = ((long)V + 7) / 8 * 8;
@@ -335,9 +346,8 @@ extern "C" void ntts_backbone_destroy(ntts_backbone* e) {
     hipSetDevice(e->device);
     hipDeviceSynchronize();
     if (e->graph) hipGraphExecDestroy(e->graph);
-    if (e->graph_multi) hipGraphExecDestroy(e->graph_multi);
     void* bufs[] = {e->arena, e->gu_map_gate, e->gu_map_up, e->kv, e->ibuf, e->h_dec, e->xn_dec, e->qkv_dec, e->attn_dec,
-                    e->act_dec, e->slabs, e->part_val, e->part_idx, e->logits, e->logits_bf16, e->h_pf, e->xn_pf, e->qkv_pf, e->attn_pf,
+                    e->act_dec, e->slabs, e->slabs2, e->h_alt, e->part_val, e->part_idx, e->logits, e->logits_bf16, e->h_pf, e->xn_pf, e->qkv_pf, e->attn_pf,
                     e->o_pf, e->act_pf, e->meta_dev};
     for (void* b : bufs)
         if (b) hipFree(b);
@@ -508,14 +518,8 @@ static GemmArgs gemm_args(const ntts_backbone* e, const bf16_t* X, long ldx, con
 }
 
 // ---- the decode step's launches, one helper per kernel (shared by decode_step and ntts_backbone_time_kernel)
-// nt: non-temporal policy on the weight stream (decode step only: each weight byte is read once per step)
 template <int EPI>
-static void gemm_skinny(int stages, const GemmArgs& a, int ks, hipStream_t st, bool nt = false) {
-    if (nt) {
-        if (stages == 3) gemm_launch<4, 1, 1, EPI, 3, 0, 64, true>(a, ks, st);
-        else gemm_launch<4, 1, 1, EPI, 4, 0, 64, true>(a, ks, st);
-        return;
-    }
+static void gemm_skinny(int stages, const GemmArgs& a, int ks, hipStream_t st) {
     switch (stages) {
         case 2: gemm_launch<4, 1, 1, EPI, 2>(a, ks, st); break;
         case 3: gemm_launch<4, 1, 1, EPI, 3>(a, ks, st); break;
@@ -527,8 +531,7 @@ static void gemm_skinny(int stages, const GemmArgs& a, int ks, hipStream_t st, b
 template <int EPI>
 static void gemm_large(ntts_backbone* e, const GemmArgs& a, hipStream_t st) {
     if (e->use_xl && a.M >= 1024 && a.N >= 256) {
-        if (e->gemm_persist) gemm_persist_launch<4, 4, 4, EPI, 2>(a, e->n_cu, st);   // experimental, NTTS_GEMM_PERSIST=1
-        else NTTS_GEMM_XL(EPI, a, 1, st);
+        NTTS_GEMM_XL(EPI, a, 1, st);
         return;
     }
     switch (e->l_stages) {
@@ -538,16 +541,17 @@ static void gemm_large(ntts_backbone* e, const GemmArgs& a, hipStream_t st) {
     }
 }
 
+static void ks_lm_head(ntts_backbone* e, bool keep_logits);
 static void k_lm_head(ntts_backbone* e, bool keep_logits) {
+    if (e->small) { ks_lm_head(e, keep_logits); return; }
     const int B = e->cfg.max_batch, H = e->H, V = e->cfg.vocab_size;
     GemmArgs a = gemm_args(e, e->xn_dec, H, e->w_tile_major ? e->embed_tm : e->embed, H, nullptr, nullptr, 0, B, V, H);
     a.part_val = e->part_val; a.part_idx = e->part_idx; a.mask_eos = e->sl.mask_eos;
     a.logits = keep_logits ? e->logits : nullptr; a.ld_logits = V;
     a.logits_bf16 = (keep_logits && e->n_sampling > 0) ? e->logits_bf16 : nullptr; a.ld_logits_bf16 = e->ldl;
-    if (!e->head_large) { gemm_skinny<EPI_ARGMAX>(4, a, 1, e->stream, e->w_nt); return; }
+    if (!e->head_large) { gemm_skinny<EPI_ARGMAX>(4, a, 1, e->stream); return; }
     if (e->head_xl) {
-        if (e->gemm_persist) gemm_persist_launch<4, 4, 4, EPI_ARGMAX, 2>(a, e->n_cu, e->stream);   // experimental
-        else if (e->w_nt) gemm_launch<4, 4, 4, EPI_ARGMAX, 2, 0, 64, true>(a, 1, e->stream);
+        if (e->w_nt & 1) gemm_launch<4, 4, 4, EPI_ARGMAX, 2, 0, 64, true>(a, 1, e->stream);
         else NTTS_GEMM_XL(EPI_ARGMAX, a, 1, e->stream);
         return;
     }
@@ -570,16 +574,16 @@ static void k_qkv(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H;
     const LayerW& w = e->layers[i];
     if (e->ks_qkv > 1)   // fp32 split-K slabs; the attention prologue sums them, adds the bias and rounds (attn_decode.h)
-        gemm_skinny<EPI_SPLITK>(e->st_qkv, gemm_args(e, e->xn_dec, H, w.wqkv, H, nullptr, e->slabs, e->NQKV, B, e->NQKV, H), e->ks_qkv, e->stream, e->w_nt);
+        gemm_skinny<EPI_SPLITK>(e->st_qkv, gemm_args(e, e->xn_dec, H, w.wqkv, H, nullptr, e->slabs, e->NQKV, B, e->NQKV, H), e->ks_qkv, e->stream);
     else
-        gemm_skinny<EPI_BF16>(e->st_qkv, gemm_args(e, e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H), 1, e->stream, e->w_nt);
+        gemm_skinny<EPI_BF16>(e->st_qkv, gemm_args(e, e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H), 1, e->stream);
 }
 
 static void k_attn(ntts_backbone* e, int i) {
     const ntts_backbone_config& c = e->cfg;
     AttnDecodeArgs a{};
     a.qkv = e->qkv_dec; a.ld_qkv = e->NQKV; a.out = e->attn_dec; a.ld_out = c.num_heads * 64;
-    if (e->ks_qkv > 1 && !e->fused) {
+    if (e->ks_qkv > 1) {
         a.qkv_slabs = e->slabs; a.nslab = gemm_nsplit(e->H, e->ks_qkv); a.slab_rows = c.max_batch; a.qkv_bias = e->layers[i].bqkv;
     }
     a.kpool = e->kv + (size_t)i * e->layer_stride; a.vpool = a.kpool + e->kv_half;
@@ -591,22 +595,21 @@ static void k_attn(ntts_backbone* e, int i) {
 
 static void k_o_proj(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, QD = e->cfg.num_heads * 64;
-    gemm_skinny<EPI_SPLITK>(e->st_o, gemm_args(e, e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->slabs, H, B, H, QD), e->ks_o, e->stream, e->w_nt);
+    gemm_skinny<EPI_SPLITK>(e->st_o, gemm_args(e, e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->slabs, H, B, H, QD), e->ks_o, e->stream);
 }
 
 static void k_gate_up(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, F = e->F;
     GemmArgs gu = gemm_args(e, e->xn_dec, H, e->layers[i].wgu, H, nullptr, e->act_dec, F, B, 2 * F, H);
-    if (e->gu_tile == 1 && e->w_nt) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3, 0, 64, true>(gu, 1, e->stream);
-    else if (e->gu_tile == 1) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);        // 128 x 128, 8 waves
+    if (e->gu_tile == 1) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);        // 128 x 128, 8 waves
     else if (e->gu_tile == 2) gemm_launch<8, 1, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);   // 256 x 64, 8 waves
     else if (e->gu_large) gemm_large<EPI_SILU_MUL>(e, gu, e->stream);
-    else gemm_skinny<EPI_SILU_MUL>(e->st_gu, gu, 1, e->stream, e->w_nt);
+    else gemm_skinny<EPI_SILU_MUL>(e->st_gu, gu, 1, e->stream);
 }
 
 static void k_down(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, F = e->F;
-    gemm_skinny<EPI_SPLITK>(e->st_d, gemm_args(e, e->act_dec, F, e->layers[i].wd, F, nullptr, e->slabs, H, B, H, F), e->ks_d, e->stream, e->w_nt);
+    gemm_skinny<EPI_SPLITK>(e->st_d, gemm_args(e, e->act_dec, F, e->layers[i].wd, F, nullptr, e->slabs, H, B, H, F), e->ks_d, e->stream);
 }
 
 // residual += reduce(slabs of a K-deep split-K GEMM); normed = rmsnorm(residual) * norm_w
@@ -617,57 +620,83 @@ static void k_add_norm(ntts_backbone* e, int K, int ks, const bf16_t* norm_w, bf
     add_rmsnorm_launch(n, e->stream, e->norm_wide);
 }
 
-template <int EPI, bool NORM>
-static void gemm_xpanel(ntts_backbone* e, const GemmArgs& a) { gemm_xpanel_launch<EPI, NORM>(a, e->n_cu * e->xp_bpc, e->stream); }
-
-// fused decode-layer GEMMs (gemm_xpanel_kernel): the residual stream h_dec is the only activation that round-trips
-static void kf_qkv(ntts_backbone* e, int i) {       // qkv = Linear(rmsnorm(h) * ln1) + bias
-    const int B = e->cfg.max_batch, H = e->H;
-    const LayerW& w = e->layers[i];
-    GemmArgs a = gemm_args(e, e->h_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H);
-    a.norm_w = w.ln1; a.norm_eps = e->cfg.rms_eps;
-    gemm_xpanel<EPI_BF16, true>(e, a);
+// ---- small-batch step (gemv.h): per layer  [norm -> QKV]  attention  [o_proj]  [norm -> gate/up -> SiLU*mul]  [down]
+static GemvArgs gemv_args(const ntts_backbone* e, const bf16_t* X, long ldx, const bf16_t* W, long ldw, void* out, long ldo, int N, int K) {
+    GemvArgs a{};
+    a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.w_tile_major = e->w_tile_major ? 1 : 0; a.out = out; a.ldo = ldo;
+    a.slab_rows = e->cfg.max_batch; a.M = e->cfg.max_batch; a.N = N; a.K = K;
+    return a;
 }
-static void kf_o_proj(ntts_backbone* e, int i) {    // h = h + Linear_o(attn)   (in place)
-    const int B = e->cfg.max_batch, H = e->H, QD = e->cfg.num_heads * 64;
-    GemmArgs a = gemm_args(e, e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->h_dec, H, B, H, QD);
-    a.resid_bf16 = e->h_dec; a.ldrb = H;
-    gemm_xpanel<EPI_RESID, false>(e, a);
+// the fused prologue of layer i's QKV GEMV: h = (i == 0 ? embed[cur_tok] : h + bf16(sum of the previous down_proj's slabs));
+// x = rmsnorm(h) * ln1.  The residual stream alternates between h_dec and h_alt (block 0 writes, every block reads).
+static NormArgs pro_qkv(ntts_backbone* e, int i) {
+    NormArgs n{};
+    n.M = e->cfg.max_batch; n.H = e->H; n.eps = e->cfg.rms_eps; n.norm_w = e->layers[i].ln1;
+    if (i == 0) { n.gather_ids = e->sl.cur_tok; n.embed = e->embed; }
+    else { n.slabs = e->slabs2; n.nslab = gemv_nsplit(e->F, e->sks_d); n.slab_rows = e->cfg.max_batch; n.resid_in = e->h_dec; }
+    n.resid_out = e->h_alt;
+    return n;
 }
-static void kf_gate_up(ntts_backbone* e, int i) {   // act = silu(gate(n)) * up(n), n = rmsnorm(h) * ln2
-    const int B = e->cfg.max_batch, H = e->H, F = e->F;
-    GemmArgs a = gemm_args(e, e->h_dec, H, e->layers[i].wgu, H, nullptr, e->act_dec, F, B, 2 * F, H);
-    a.norm_w = e->layers[i].ln2; a.norm_eps = e->cfg.rms_eps;
-    gemm_xpanel<EPI_SILU_MUL, true>(e, a);
+static void ks_qkv(ntts_backbone* e, int i) {
+    GemvArgs a = gemv_args(e, nullptr, 0, e->layers[i].wqkv, e->H, e->slabs, e->NQKV, e->NQKV, e->H);
+    a.pro = pro_qkv(e, i);
+    gemv_launch<EPI_SPLITK, true>(a, e->sks_q, e->stream);
 }
-
-static void kf_o_proj_scratch(ntts_backbone* e, int i) {   // timing replay: same work, result into a scratch buffer
-    const int B = e->cfg.max_batch, H = e->H, QD = e->cfg.num_heads * 64;
-    GemmArgs a = gemm_args(e, e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->o_pf, H, B, H, QD);
-    a.resid_bf16 = e->h_dec; a.ldrb = H;
-    gemm_xpanel<EPI_RESID, false>(e, a);
-}
-
-static void decode_step_fused(ntts_backbone* e) {
+static void ks_attn(ntts_backbone* e, int i) {
     const ntts_backbone_config& c = e->cfg;
-    const int B = c.max_batch, H = e->H, F = e->F;
-    NormArgs n0{};   // h = embed[cur_tok]
-    n0.gather_ids = e->sl.cur_tok; n0.embed = e->embed; n0.resid_out = e->h_dec; n0.M = B; n0.H = H; n0.eps = c.rms_eps;
-    add_rmsnorm_launch(n0, e->stream);
-    for (int i = 0; i < c.num_layers; ++i) {
-        kf_qkv(e, i);
-        k_attn(e, i);
-        kf_o_proj(e, i);
-        kf_gate_up(e, i);
-        k_down(e, i);
-        const bool last = i + 1 == c.num_layers;   // h += down; only the final norm (lm_head input) is materialised
-        k_add_norm(e, F, e->ks_d, last ? e->final_norm : nullptr, e->h_dec, last ? e->xn_dec : nullptr);
+    AttnDecodeArgs a{};
+    a.qkv = nullptr; a.ld_qkv = e->NQKV; a.out = e->attn_dec; a.ld_out = c.num_heads * 64;
+    a.qkv_slabs = e->slabs; a.nslab = gemv_nsplit(e->H, e->sks_q); a.slab_rows = c.max_batch; a.qkv_bias = e->layers[i].bqkv;
+    a.kpool = e->kv + (size_t)i * e->layer_stride; a.vpool = a.kpool + e->kv_half;
+    a.block_table = e->block_table; a.max_pages = e->max_pages; a.pos = e->sl.pos; a.state = e->sl.state;
+    a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
+    attn_decode_launch_wide(a, c.max_batch, e->stream, e->attn_depth_small);
+}
+static void ks_o_proj(ntts_backbone* e, int i) {
+    const int QD = e->cfg.num_heads * 64;
+    gemv_launch<EPI_SPLITK, false>(gemv_args(e, e->attn_dec, QD, e->layers[i].wo, QD, e->slabs, e->H, e->H, QD), e->sks_o, e->stream);
+}
+static void ks_gate_up(ntts_backbone* e, int i) {
+    GemvArgs a = gemv_args(e, nullptr, 0, e->layers[i].wgu, e->H, e->act_dec, e->F, 2 * e->F, e->H);
+    NormArgs n{};
+    n.M = e->cfg.max_batch; n.H = e->H; n.eps = e->cfg.rms_eps; n.norm_w = e->layers[i].ln2;
+    n.slabs = e->slabs; n.nslab = gemv_nsplit(e->cfg.num_heads * 64, e->sks_o); n.slab_rows = e->cfg.max_batch;
+    n.resid_in = e->h_alt; n.resid_out = e->h_dec;
+    a.pro = n;
+    gemv_launch<EPI_SILU_MUL, true>(a, 1, e->stream);
+}
+static void ks_down(ntts_backbone* e, int i) {
+    gemv_launch<EPI_SPLITK, false>(gemv_args(e, e->act_dec, e->F, e->layers[i].wd, e->F, e->slabs2, e->H, e->H, e->F), e->sks_d, e->stream);
+}
+static void ks_final_norm(ntts_backbone* e) {   // h += down (last layer); xn = rmsnorm(h) * final_norm  -> the lm_head's input
+    NormArgs n{};
+    n.slabs = e->slabs2; n.nslab = gemv_nsplit(e->F, e->sks_d); n.slab_rows = e->cfg.max_batch; n.resid_in = e->h_dec; n.resid_out = e->h_dec;
+    n.norm_w = e->final_norm; n.normed_out = e->xn_dec; n.M = e->cfg.max_batch; n.H = e->H; n.eps = e->cfg.rms_eps;
+    add_rmsnorm_launch(n, e->stream, e->norm_wide);
+}
+static void ks_lm_head(ntts_backbone* e, bool keep_logits) {
+    const int H = e->H, V = e->cfg.vocab_size;
+    GemvArgs a = gemv_args(e, e->xn_dec, H, e->w_tile_major ? e->embed_tm : e->embed, H, nullptr, 0, V, H);
+    a.part_val = e->part_val; a.part_idx = e->part_idx; a.mask_eos = e->sl.mask_eos;
+    a.logits = keep_logits ? e->logits : nullptr; a.ld_logits = V;
+    a.logits_bf16 = (keep_logits && e->n_sampling > 0) ? e->logits_bf16 : nullptr; a.ld_logits_bf16 = e->ldl;
+    gemv_launch<EPI_ARGMAX, false>(a, 1, e->stream);
+}
+
+static void decode_step_small(ntts_backbone* e) {
+    for (int i = 0; i < e->cfg.num_layers; ++i) {
+        ks_qkv(e, i);
+        ks_attn(e, i);
+        ks_o_proj(e, i);
+        ks_gate_up(e, i);
+        ks_down(e, i);
     }
+    ks_final_norm(e);
     lm_head_and_sample(e, SLOT_RUNNING);
 }
 
 static void decode_step(ntts_backbone* e) {
-    if (e->fused) { decode_step_fused(e); return; }
+    if (e->small) { decode_step_small(e); return; }
     const ntts_backbone_config& c = e->cfg;
     const int B = c.max_batch, H = e->H, F = e->F, QD = c.num_heads * 64;
     NormArgs n0{};
@@ -962,7 +991,6 @@ extern "C" int ntts_backbone_decode(ntts_backbone* e, int32_t n_steps) {
     if (e->graph && e->graph_has_logits != (e->n_sampling > 0)) {   // the step's launch arguments changed
         hipGraphExecDestroy(e->graph);
         e->graph = nullptr;
-        if (e->graph_multi) { hipGraphExecDestroy(e->graph_multi); e->graph_multi = nullptr; }
         e->graph_tried = false;
     }
     if (e->use_graph && !e->graph_tried) {
@@ -979,14 +1007,10 @@ extern "C" int ntts_backbone_decode(ntts_backbone* e, int32_t n_steps) {
             }
             (void)hipGetLastError();
         };
-        capture(1, &e->graph);
-        // several steps per graph (experimental, NTTS_GRAPH_STEPS): saves the ~9 us between graph replays; every step only
-        // reads and writes device-side slot state, so a captured sequence of steps replays like single steps do
-        if (e->graph && e->graph_steps > 1) capture(e->graph_steps, &e->graph_multi);
+        capture(1, &e->graph);   // several steps per graph were measured: -0.3 % per step (profiles/r02a_sweep_nt_graphsteps.jsonl), not kept
     }
     HIPCHK(e, hipEventRecord(e->ev[2], st));
     for (int s = 0; s < n_steps;) {
-        if (e->graph_multi && n_steps - s >= e->graph_steps) { HIPCHK(e, hipGraphLaunch(e->graph_multi, st)); s += e->graph_steps; continue; }
         if (e->graph) HIPCHK(e, hipGraphLaunch(e->graph, st));
         else decode_step(e);
         ++s;
@@ -1076,7 +1100,6 @@ extern "C" int ntts_backbone_set_debug(ntts_backbone* e, int32_t keep_logits) {
         e->logits = nullptr;
     }
     if (e->graph) { hipGraphExecDestroy(e->graph); e->graph = nullptr; }
-    if (e->graph_multi) { hipGraphExecDestroy(e->graph_multi); e->graph_multi = nullptr; }
     e->graph_tried = false;  // the logits pointer is baked into the captured step
     return NTTS_OK;
 }
@@ -1138,6 +1161,7 @@ extern "C" int ntts_backbone_attn_timeline(ntts_backbone* e, int32_t layer, uint
     if (!e || !out || layer < 0 || layer >= e->cfg.num_layers) return fail(e, NTTS_EINVAL, "bad argument");
     const size_t n = (size_t)e->cfg.max_batch * e->cfg.num_kv_heads * 4 * 8;
     if (cap < (int64_t)n) return fail(e, NTTS_EINVAL, "timeline needs %zu entries", n);
+    if (e->small) return fail(e, NTTS_ESTATE, "the phase timeline instruments the 4-wave attention kernel (max_batch > NTTS_SMALL_BATCH)");
     HIPCHK(e, hipSetDevice(e->device));
     DevScratch buf;
     HIPCHK(e, hipMalloc(&buf.p, n * 8));
@@ -1173,40 +1197,51 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
     for (int b = 0; b < B; ++b)
         if (sst[b] == SLOT_RUNNING) kv_layer += ((double)pos[b] + 1) * 2 * KD * 2.0;
     const double act = (double)B * 2.0;
-    const bool qkv_split = e->ks_qkv > 1 && !e->fused;   // QKV leaves fp32 split-K slabs that the attention prologue reduces
+    const bool qkv_split = e->ks_qkv > 1;   // QKV leaves fp32 split-K slabs that the attention prologue reduces
     // Every replay works on the NEXT layer's weights / KV pool, as consecutive launches of this kernel do inside the
     // decode step: one layer's operands (84 MB of KV at batch 256) would sit in the 256 MB Infinity Cache when replayed
     // alone, all layers together (2 GB) do not -- so the timing below is HBM-cold like the in-graph launches.
     auto run = [&](int k, int i) {
+        if (e->small) {
+            switch (k) {
+                case 0: ks_attn(e, i); break;
+                case 1: ks_qkv(e, i); break;         // incl. the fused slab-reduce + residual + RMSNorm prologue
+                case 2: ks_o_proj(e, i); break;
+                case 3: ks_gate_up(e, i); break;     // incl. its fused prologue
+                case 4: ks_down(e, i); break;
+                case 5: k_lm_head(e, false); break;
+                case 6: ks_final_norm(e); break;
+                default: break;
+            }
+            return;
+        }
         switch (k) {
             case 0: k_attn(e, i); break;                        // paged decode attention (+RoPE, +KV append)
-            case 1: if (e->fused) kf_qkv(e, i); else k_qkv(e, i); break;
-            case 2: if (e->fused) kf_o_proj_scratch(e, i); else k_o_proj(e, i); break;
-            case 3: if (e->fused) kf_gate_up(e, i); else k_gate_up(e, i); break;
+            case 1: k_qkv(e, i); break;
+            case 2: k_o_proj(e, i); break;
+            case 3: k_gate_up(e, i); break;
             case 4: k_down(e, i); break;
             case 5: k_lm_head(e, false); break;
-            case 6:   // scratch outputs
-                if (e->fused) k_add_norm(e, F, e->ks_d, nullptr, e->o_pf, nullptr);
-                else k_add_norm(e, QD, e->ks_o, e->layers[i].ln2, e->o_pf, e->xn_pf);
-                break;
+            case 6: k_add_norm(e, QD, e->ks_o, e->layers[i].ln2, e->o_pf, e->xn_pf); break;   // scratch outputs
             default: break;
         }
     };
+    // algorithmic bytes per launch: the weights of the GEMM + its activations in/out; for attention K/V only
+    const int ksq = e->small ? e->sks_q : e->ks_qkv, kso = e->small ? e->sks_o : e->ks_o, ksd = e->small ? e->sks_d : e->ks_d;
     switch (which) {
         case 0: *alg_bytes = kv_layer;   // SURVEY 8(d), strictly: K and V of every cached token (+ the appended one); the q/k/v
                                          // inputs (bf16 row or the QKV GEMM's fp32 slabs) and the output are the builder's own
                 *launches_per_step = L; break;
         case 1: *alg_bytes = ((double)e->NQKV * H + e->NQKV) * 2.0 + act * H +
-                             (double)B * e->NQKV * (qkv_split ? 4.0 * gemm_nsplit(H, e->ks_qkv) : 2.0);
+                             (double)B * e->NQKV * ((qkv_split || e->small) ? 4.0 * gemm_nsplit(H, ksq) : 2.0);
                 *launches_per_step = L; break;
-        case 2: *alg_bytes = (double)H * QD * 2.0 + act * QD +
-                             (e->fused ? act * 2 * H : (double)gemm_nsplit(QD, e->ks_o) * B * H * 4.0);
+        case 2: *alg_bytes = (double)H * QD * 2.0 + act * QD + (double)gemm_nsplit(QD, kso) * B * H * 4.0;
                 *launches_per_step = L; break;
         case 3: *alg_bytes = (double)2 * F * H * 2.0 + act * (H + F); *launches_per_step = L; break;
-        case 4: *alg_bytes = (double)H * F * 2.0 + act * F + (double)gemm_nsplit(F, e->ks_d) * B * H * 4.0; *launches_per_step = L; break;
+        case 4: *alg_bytes = (double)H * F * 2.0 + act * F + (double)gemm_nsplit(F, ksd) * B * H * 4.0; *launches_per_step = L; break;
         case 5: *alg_bytes = (double)c.vocab_size * H * 2.0 + act * H; *launches_per_step = 1; break;
-        case 6: *alg_bytes = (double)gemm_nsplit(e->fused ? F : QD, e->fused ? e->ks_d : e->ks_o) * B * H * 4.0 + act * H * (e->fused ? 2 : 3);
-                *launches_per_step = e->fused ? L : 2 * L; break;
+        case 6: *alg_bytes = (double)gemm_nsplit(e->small ? F : QD, e->small ? ksd : kso) * B * H * 4.0 + act * H * 3;
+                *launches_per_step = e->small ? 1 : 2 * L; break;
         default: return fail(e, NTTS_EINVAL, "unknown kernel id %d", which);
     }
     if (which == 6 && B > e->Tmax) return fail(e, NTTS_EINVAL, "scratch too small");

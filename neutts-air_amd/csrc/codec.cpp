@@ -32,7 +32,6 @@ struct ntts_codec {
     int H = 0, I = 0, nq = 0, n_fft = 0, nb = 0, NS = 0, lds_spec = 0;
     long K3 = 0, max_rows = 0;
     bool finalized = false;
-    int persist_wgs = 0;        // > 0: big GEMMs on the experimental persistent kernel (NTTS_GEMM_PERSIST=1), one workgroup per CU
     std::map<std::string, std::vector<float>> host;            // staged fp32 tensors until finalize
     std::map<std::string, std::vector<int64_t>> shapes;
     std::vector<void*> allocs;
@@ -104,10 +103,6 @@ extern "C" int ntts_codec_create(const ntts_codec_config* cf, int device, ntts_c
     ntts_codec* c = new ntts_codec();
     c->cfg = *cf;
     c->device = device;
-    {   // experimental persistent big-GEMM kernel (gemm.h), off unless NTTS_GEMM_PERSIST=1
-        const char* v = getenv("NTTS_GEMM_PERSIST");
-        if (v && atoi(v) != 0) c->persist_wgs = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
     c->H = cf->hidden_size; c->I = cf->intermediate_size; c->nq = cf->n_levels;
     c->n_fft = cf->hop_length * 4; c->nb = c->n_fft / 2 + 1; c->NS = c->n_fft + 2;
     c->lds_spec = (c->NS + 3) / 4 * 4;
@@ -338,10 +333,10 @@ static void resnet_block(ntts_codec* c, const ResW& w, const CodecRows& R, long 
     GroupNormArgs g{};
     g.x = c->h; g.y = c->xa; g.gamma = w.g1; g.beta = w.b1; g.R = R; g.C = H; g.eps = 1e-6f;
     NTTS_LAUNCH((groupnorm_silu_kernel), dim3(R.B, 32), dim3(256), st, g);
-    { GemmArgs ga_ = cg(c->xa, H, w.w1, 3L * H, w.cb1, c->t1 + H, H, rows - 2, H); NTTS_GEMM_BIG_P(EPI_F32, ga_, st, c->persist_wgs); }
+    { GemmArgs ga_ = cg(c->xa, H, w.w1, 3L * H, w.cb1, c->t1 + H, H, rows - 2, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
     g.x = c->t1; g.y = c->xb; g.gamma = w.g2; g.beta = w.b2;
     NTTS_LAUNCH((groupnorm_silu_kernel), dim3(R.B, 32), dim3(256), st, g);
-    { GemmArgs ga_ = cg(c->xb, H, w.w2, 3L * H, w.cb2, c->h + H, H, rows - 2, H, c->h + H, H); NTTS_GEMM_BIG_P(EPI_F32, ga_, st, c->persist_wgs); }
+    { GemmArgs ga_ = cg(c->xb, H, w.w2, 3L * H, w.cb2, c->h + H, H, rows - 2, H, c->h + H, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
 }
 
 extern "C" int ntts_codec_decode(ntts_codec* c, int32_t n, const int32_t* codes, const int32_t* lens, float* wav_out,
@@ -385,7 +380,7 @@ extern "C" int ntts_codec_decode(ntts_codec* c, int32_t n, const int32_t* codes,
     for (int i = 0; i < 8; ++i) ea.levels[i] = i < c->nq ? c->cfg.levels[i] : 1;
     NTTS_LAUNCH((codec_embed_kernel), dim3((unsigned)rows), dim3(256), st, ea);
     // stem Conv1d(k=7, padding 3): window rows r..r+6 -> centre row r+3
-    { GemmArgs ga_ = cg(c->xa, H, c->embed_w, 7L * H, c->embed_b, c->h + 3L * H, H, rows - 6, H); NTTS_GEMM_BIG_P(EPI_F32, ga_, st, c->persist_wgs); }
+    { GemmArgs ga_ = cg(c->xa, H, c->embed_w, 7L * H, c->embed_b, c->h + 3L * H, H, rows - 6, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
     resnet_block(c, c->res[0], R, rows);
     resnet_block(c, c->res[1], R, rows);
     for (int i = 0; i < c->cfg.num_layers; ++i) {
@@ -393,29 +388,29 @@ extern "C" int ntts_codec_decode(ntts_codec* c, int32_t n, const int32_t* codes,
         RowNormArgs rn{};
         rn.x = c->h; rn.y = c->xa; rn.w = L.ln1; rn.rows = rows; rn.C = H; rn.eps = c->cfg.rms_eps;
         rownorm_launch(rn, st);
-        { GemmArgs ga_ = cg(c->xa, H, L.wqkv, H, nullptr, c->qkv, 3L * H, rows, 3 * H); NTTS_GEMM_BIG_P(EPI_BF16, ga_, st, c->persist_wgs); }
+        { GemmArgs ga_ = cg(c->xa, H, L.wqkv, H, nullptr, c->qkv, 3L * H, rows, 3 * H); NTTS_GEMM_BIG(EPI_BF16, ga_, st); }
         VTransposeArgs vt{};
         vt.qkv = c->qkv; vt.vt = c->vt; vt.R = R; vt.C = H; vt.nh = c->cfg.num_heads; vt.npages = npages;
         NTTS_LAUNCH((v_transpose_kernel), dim3(n * npages, c->cfg.num_heads), dim3(256), st, vt);
         AttnFullArgs at{};
         at.qkv = c->qkv; at.vt = c->vt; at.out = c->xb; at.R = R; at.C = H; at.nh = c->cfg.num_heads; at.npages = npages; at.qtiles = qtiles;
         NTTS_LAUNCH((attn_full_kernel), dim3(n * qtiles, c->cfg.num_heads), dim3(256), st, at);
-        { GemmArgs ga_ = cg(c->xb, H, L.wo, H, nullptr, c->h, H, rows, H, c->h, H); NTTS_GEMM_BIG_P(EPI_F32, ga_, st, c->persist_wgs); }
+        { GemmArgs ga_ = cg(c->xb, H, L.wo, H, nullptr, c->h, H, rows, H, c->h, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
         rn.w = L.ln2;
         rownorm_launch(rn, st);
-        { GemmArgs ga_ = cg(c->xa, H, L.fc1, H, nullptr, c->act, c->I, rows, c->I); NTTS_GEMM_BIG_P(EPI_BF16_SILU, ga_, st, c->persist_wgs); }
-        { GemmArgs ga_ = cg(c->act, c->I, L.fc2, c->I, nullptr, c->h, H, rows, H, c->h, H); NTTS_GEMM_BIG_P(EPI_F32, ga_, st, c->persist_wgs); }
+        { GemmArgs ga_ = cg(c->xa, H, L.fc1, H, nullptr, c->act, c->I, rows, c->I); NTTS_GEMM_BIG(EPI_BF16_SILU, ga_, st); }
+        { GemmArgs ga_ = cg(c->act, c->I, L.fc2, c->I, nullptr, c->h, H, rows, H, c->h, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
     }
     resnet_block(c, c->res[2], R, rows);
     resnet_block(c, c->res[3], R, rows);
     RowNormArgs fn{};
     fn.x = c->h; fn.y = c->xa; fn.w = c->fn_w; fn.bias = c->fn_b; fn.rows = rows; fn.C = H; fn.eps = 1e-6f;
     rownorm_launch(fn, st);
-    { GemmArgs ga_ = cg(c->xa, H, c->head_w, H, c->head_b, c->spec, c->lds_spec, rows, c->NS); NTTS_GEMM_BIG_P(EPI_F32, ga_, st, c->persist_wgs); }
+    { GemmArgs ga_ = cg(c->xa, H, c->head_w, H, c->head_b, c->spec, c->lds_spec, rows, c->NS); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
     IstftPrepArgs ip{};
     ip.spec = c->spec; ip.lds = c->lds_spec; ip.s3 = c->s3; ip.K3 = c->K3; ip.rows = rows; ip.nb = c->nb;
     NTTS_LAUNCH((istft_prep_kernel), dim3((unsigned)rows), dim3(256), st, ip);
-    { GemmArgs ga_ = cg(c->s3, c->K3, c->basis3, c->K3, nullptr, c->frames, c->n_fft, rows, c->n_fft); NTTS_GEMM_BIG_P(EPI_F32, ga_, st, c->persist_wgs); }
+    { GemmArgs ga_ = cg(c->s3, c->K3, c->basis3, c->K3, nullptr, c->frames, c->n_fft, rows, c->n_fft); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
     OlaArgs oa{};
     oa.frames = c->frames; oa.win2 = c->win2; oa.wav = c->wav; oa.wav_stride = (long)hop * Tmax; oa.R = R; oa.hop = hop; oa.n_fft = c->n_fft;
     NTTS_LAUNCH((ola_kernel), dim3(n, (unsigned)(((long)hop * Tmax + 255) / 256)), dim3(256), st, oa);

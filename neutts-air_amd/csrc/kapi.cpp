@@ -20,8 +20,6 @@ extern "C" int ntts_k_gemm_bf16(const void* A, int64_t lda, const void* W, const
     else if (variant == 4) NTTS_GEMM_XL(EPI_BF16, a, 1, (hipStream_t)0);
     else if (variant == 5) gemm_launch<4, 4, 4, EPI_BF16, 4, 0, 32>(a, 1, (hipStream_t)0);   // XL tile, 4 ring slots of K = 32
     else if (variant == 6) gemm_launch<2, 2, 4, EPI_BF16, 3, 0, 32>(a, 1, (hipStream_t)0);   // L tile, 3 ring slots of K = 32
-    else if (variant == 8) gemm_persist_launch<4, 4, 4, EPI_BF16, 2>(a, 8, (hipStream_t)0);   // persistent XL tile, 8 workgroups walk the tiles
-    else if (variant == 9) gemm_persist_launch<2, 2, 4, EPI_BF16, 3>(a, 3, (hipStream_t)0);   // persistent L tile, 3-slot ring, 3 workgroups
     else if (variant == 3) {  // split-K slabs reduced by the norm kernel (the decode o_proj / down_proj path)
         if (bias || (N % 16) || ldc != N) return NTTS_EINVAL;
         const int ks = 4, ns = gemm_nsplit(K, ks);
@@ -142,7 +140,6 @@ extern "C" int ntts_k_gemm_probe(int32_t M, int32_t N, int32_t K, int32_t config
             case 47: probe_launch<4, 4, 4, 3, 32>(a, 1, abl); break;   // ... 3 slots (96 KB)
             case 48: probe_launch<2, 4, 8, 4, 32>(a, 1, abl); break;   // 256 x 256, 8 waves, 4 slots of K = 32
             case 49: probe_launch<2, 2, 4, 4, 32>(a, 1, abl); break;   // 128 x 128, 4 waves, 4 slots of K = 32 (64 KB: 2 blocks / CU)
-            case 60: gemm_persist_launch<4, 4, 4, EPI_BF16, 2>(a, 256, 0); break;   // persistent 256 x 256: next tile's stages requested before the stores
             case 50: probe_launch<4, 1, 4, 3>(a, 1, abl); break;   // 256 x 64, 4 waves: all decode rows in one block
             case 51: probe_launch<8, 1, 2, 3>(a, 1, abl); break;   // 256 x 64, 8 waves
             case 52: probe_launch<8, 1, 2, 2>(a, 1, abl); break;

@@ -64,15 +64,19 @@ NTTS_D void rope_pair(float x1, float x2, float c, float s, float& o1, float& o2
 //   flight) after the prologue (+3.5 us per launch) or at the softmax merge (+1.1 us), scheduling fences around the K
 //   requests (no effect), deeper register rings (kDepth 2 / 3: +0.2 / +1.2 us), the RoPE row served from a per-slot copy
 //   so that it does not hang off the load of the position (no effect).
-template <int kDepth, bool kTimeline = false, int kVar = 1>
-NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
+// NW = waves per workgroup.  4 at large batch (two workgroups per CU, B * kv_heads >= the CU count).  16 at small batch
+//   (BASELINE configs[1], batch 1: only B * kv_heads workgroups exist, so one workgroup must put a whole context's pages in
+//   flight by itself: 16 waves x kDepth pages = the K of 512 x kDepth tokens requested at once instead of 128 x kDepth).
+template <int kDepth, bool kTimeline = false, int kVar = 1, int NW = 4>
+NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
+    constexpr int NT = NW * 64;
     NTTS_SHARED bf16_t sc[kGroupMax][kAttnLMax + 16];   // rounded scores, 33 KB; +32 B/row de-aliases the LDS banks
     NTTS_SHARED bf16_t qs[16][64];
     NTTS_SHARED bf16_t knew[64];
     NTTS_SHARED bf16_t vnew[64];
-    NTTS_SHARED float wred[4][kGroupMax];
-    NTTS_SHARED float wsum[4][kGroupMax];
-    NTTS_SHARED float ored[4][kGroupMax][64];
+    NTTS_SHARED float wred[NW][kGroupMax];
+    NTTS_SHARED float wsum[NW][kGroupMax];
+    NTTS_SHARED float ored[NW][kGroupMax][64];
 
     const int b = blockIdx.x, kvh = blockIdx.y;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
@@ -93,7 +97,7 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
     //      guarded by pg < npages.
     int bt0[kDepth];
 #pragma unroll
-    for (int j = 0; j < kDepth; ++j) bt0[j] = bt[w + 4 * j < p.max_pages ? w + 4 * j : 0];
+    for (int j = 0; j < kDepth; ++j) bt0[j] = bt[w + NW * j < p.max_pages ? w + NW * j : 0];
     const int st = p.state[b];
     const int P = p.pos[b];
     auto load_k_at = [&](long page, bf16x8 (&k)[2][2]) {
@@ -144,10 +148,11 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
         for (int sl = 1; sl < kAttnMaxSlabs; ++sl) a += sl < p.nslab ? q.part[sl] : 0.f;   // + 0.f: exact
         return f2bf(a + bf2f(q.bias));
     };
-    QkvReq qx1[2], qx2[2], qv1[2], qv2[2];
+    constexpr int ITS = ((kGroupMax + 1) * 32 + NT - 1) / NT;   // prologue items per thread
+    QkvReq qx1[ITS], qx2[ITS], qv1[ITS], qv2[ITS];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int t = tid + it * 256;
+    for (int it = 0; it < ITS; ++it) {
+        const int t = tid + it * NT;
         if (t < nitems) {
             const int hh = t >> 5, i = t & 31;
             const int c0 = hh < group ? (kvh * group + hh) * 64 : (p.nh + kvh) * 64;
@@ -166,10 +171,10 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
     const int npages = (L + kPage - 1) / kPage;
     const int last_page = npages - 1;
     long new_page = 0;
-    bf16_t rc[2], rs[2];
+    bf16_t rc[ITS], rs[ITS];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int t = tid + it * 256;
+    for (int it = 0; it < ITS; ++it) {
+        const int t = tid + it * NT;
         rc[it] = rs[it] = 0;
         if (t < nitems) {
             rc[it] = p.rope_cos[(long)P * 32 + (t & 31)];
@@ -185,8 +190,8 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
 
     // ---- prologue: RoPE(q), RoPE(k) + append k, v to the cache (and keep them in LDS for this step)
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int t = tid + it * 256;
+    for (int it = 0; it < ITS; ++it) {
+        const int t = tid + it * NT;
         if (t < nitems) {
             const int hh = t >> 5, i = t & 31;
             float o1, o2;
@@ -205,7 +210,7 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
             }
         }
     }
-    for (int t = tid; t < (16 - group) * 64; t += 256) qs[group + t / 64][t % 64] = 0;
+    for (int t = tid; t < (16 - group) * 64; t += NT) qs[group + t / 64][t % 64] = 0;
     sync();
     mark(2);
 
@@ -218,15 +223,15 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
     //      and denominator: no separate pass over the stored scores.  Masked keys use a large finite score.
     constexpr float kMasked = -1.0e30f;
     float lmax = kMasked, lsum = 0.f;
-    for (int pg0 = w; pg0 < npages; pg0 += 4 * kDepth) {
+    for (int pg0 = w; pg0 < npages; pg0 += NW * kDepth) {
 #pragma unroll
         for (int j = 0; j < kDepth; ++j) {
-            const int pg = pg0 + 4 * j;
+            const int pg = pg0 + NW * j;
             if (pg < npages) {
                 bf16x8 kc[2][2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) { kc[u][0] = kq[j][u][0]; kc[u][1] = kq[j][u][1]; }
-                if (pg + 4 * kDepth < npages) load_k(pg + 4 * kDepth, kq[j]);
+                if (pg + NW * kDepth < npages) load_k(pg + NW * kDepth, kq[j]);
                 if (pg == last_page) {  // the token appended this step comes from LDS, not from HBM
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
@@ -273,7 +278,7 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
     bf16x8 vq[kDepth][4];
 #pragma unroll
     for (int j = 0; j < kDepth; ++j)
-        if (w + 4 * j < npages) load_v(w + 4 * j, vq[j]);
+        if (w + NW * j < npages) load_v(w + NW * j, vq[j]);
 
     // ---- merge the (max, sum) pairs: across the 4 key groups of a wave, then across the 4 waves (one barrier)
 #pragma unroll
@@ -287,9 +292,12 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
     sync();
     float m_l = kMasked, sum_l = 1.f;
     if (l15 < kGroupMax) {
-        m_l = fmaxf(fmaxf(wred[0][l15], wred[1][l15]), fmaxf(wred[2][l15], wred[3][l15]));
-        sum_l = wsum[0][l15] * fexp_neg(wred[0][l15] - m_l) + wsum[1][l15] * fexp_neg(wred[1][l15] - m_l) +
-                wsum[2][l15] * fexp_neg(wred[2][l15] - m_l) + wsum[3][l15] * fexp_neg(wred[3][l15] - m_l);
+        m_l = wred[0][l15];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) m_l = fmaxf(m_l, wred[ww][l15]);
+        sum_l = wsum[0][l15] * fexp_neg(wred[0][l15] - m_l);            // waves in ascending order (fp32 sum order is part of the result)
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) sum_l += wsum[ww][l15] * fexp_neg(wred[ww][l15] - m_l);
     }
     const float rs_l = frcp_refined(sum_l);
     mark(5);
@@ -298,15 +306,15 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
     f32x4 oacc[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) oacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int pg0 = w; pg0 < npages; pg0 += 4 * kDepth) {
+    for (int pg0 = w; pg0 < npages; pg0 += NW * kDepth) {
 #pragma unroll
         for (int j = 0; j < kDepth; ++j) {
-            const int pg = pg0 + 4 * j;
+            const int pg = pg0 + NW * j;
             if (pg < npages) {
                 bf16x8 vc[4];
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) vc[nt] = vq[j][nt];
-                if (pg + 4 * kDepth < npages) load_v(pg + 4 * kDepth, vq[j]);
+                if (pg + NW * kDepth < npages) load_v(pg + NW * kDepth, vq[j]);
                 bf16x8 pA;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pA[e] = 0;
@@ -345,9 +353,11 @@ NTTS_KERNEL(256) void attn_decode_kernel(AttnDecodeArgs p) {
             for (int r = 0; r < 4; ++r) ored[w][g * 4 + r][nt * 16 + l15] = oacc[nt][r];
     }
     sync();
-    for (int t = tid; t < group * 64; t += 256) {
+    for (int t = tid; t < group * 64; t += NT) {
         const int hh = t >> 6, d = t & 63;
-        const float o = ored[0][hh][d] + ored[1][hh][d] + ored[2][hh][d] + ored[3][hh][d];
+        float o = ored[0][hh][d];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) o += ored[ww][hh][d];            // ascending wave order
         p.out[(long)b * p.ld_out + (kvh * group + hh) * 64 + d] = f2bf(o);
     }
     mark(7);
@@ -370,6 +380,12 @@ inline void attn_decode_launch_v(const AttnDecodeArgs& p, int batch, hipStream_t
         case 4: NTTS_LAUNCH((attn_decode_kernel<4, false, kVar>), grid, block, s, p); break;
         default: NTTS_LAUNCH((attn_decode_kernel<3, false, kVar>), grid, block, s, p); break;
     }
+}
+// small-batch variant: 16 waves per workgroup, 1 or 2 pages per wave in flight
+inline void attn_decode_launch_wide(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth) {
+    const dim3 grid(batch, p.nkv), block(16 * 64);
+    if (depth >= 2) NTTS_LAUNCH((attn_decode_kernel<2, false, 3, 16>), grid, block, s, p);
+    else NTTS_LAUNCH((attn_decode_kernel<1, false, 3, 16>), grid, block, s, p);
 }
 inline void attn_decode_launch(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth = kAttnDepthDefault, int var = 1) {
     if ((var & 3) == 3) attn_decode_launch_v<3>(p, batch, s, depth);        // + non-temporal K / V^T page loads

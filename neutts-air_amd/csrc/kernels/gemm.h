@@ -68,10 +68,6 @@ struct GemmArgs {
     // EPI_RESID
     const bf16_t* resid_bf16;   // [M][ldrb]
     long ldrb;
-    // gemm_xpanel_kernel
-    const bf16_t* norm_w;  // [K] RMSNorm weight applied to X on load (NORM = true)
-    float norm_eps;
-    int ntiles_per_block;  // 64-column tiles each workgroup walks
 };
 
 NTTS_D void gemm_tile_coords(int bid, int mblocks, int nblocks, int& mb, int& nb) {
@@ -372,368 +368,11 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// EXPERIMENTAL (not used by default; measured next): persistent variant of gemm_kernel for the big-M GEMMs.
-// Observation (profiles/r01e_ubench_prefill_ring_variants.txt, "noStore" column): a quarter of a 256 x 256 tile's time is its
-// store epilogue -- HBM-write-bound, with every CU storing at the same moment and the matrix cores idle -- plus the
-// un-overlapped round trip of the next tile's first stage.  Here a workgroup walks several tiles, and BEFORE it stores
-// tile i it requests the first NS-1 stages of tile i+1: a wave's vector-memory operations retire in order, so the counted
-// waits of the next main loop (which count the E store instructions issued after those requests) let the stores drain
-// under the MFMAs of the next tile's first K tiles instead of in front of them.
-//   * no split-K, BK = 64;  * grid = min(tiles, n_workgroups) in gridDim.x;  * E is known for FULL tiles of the plain
-//   epilogues (every lane stores: EPI_BF16 / EPI_BF16_SILU 2 x 16 B per 16 rows, EPI_SILU_MUL 1); edge tiles and the
-//   other epilogues fall back to a full drain, which is always correct.
-//   Known before measuring (from the ISA): with a bias the epilogue's bias loads are younger than the next tile's requests
-//   and the compiler waits vmcnt(0) for them between the store groups, which serialises the stores again -- the bias row
-//   of a tile should be fetched before the next tile's stages are requested; the bias-free GEMMs (o, gate/up, down, the
-//   codec's fc1 / fc2 / qkv / o) are the ones this kernel is expected to help first.
-template <int WM, int WN, int TM, int EPI, int NS>
-NTTS_KERNEL(WM * WN * 64) void gemm_persist_kernel(GemmArgs p) {
-    constexpr int BK = 64;
-    constexpr int BM = WM * TM * 16, BN = WN * 64, NW = WM * WN;
-    constexpr int ROWS = BM + BN, NINST = ROWS / 8;
-    static_assert(NINST % NW == 0, "loader split");
-    constexpr int PER_WAVE = NINST / NW;
-    constexpr int E_FULL = (EPI == EPI_SILU_MUL) ? TM : 2 * TM;     // store instructions a wave issues for a full tile
-    constexpr bool COUNTED = (EPI == EPI_BF16 || EPI == EPI_BF16_SILU || EPI == EPI_SILU_MUL);
-    static_assert(NS >= 2 && (NS - 2) * PER_WAVE + E_FULL <= 63, "vmcnt range");
-    NTTS_SHARED bf16_t lds[NS * ROWS * BK];
-    auto swz = [](int rho) { return (rho >> 1) & 7; };
-
-    const int lane = lane_id(), wave = wave_id();
-    const int wm = wave / WN, wn = wave % WN;
-    const int g = lane >> 4, l15 = lane & 15;
-    const int ntiles = p.mblocks * p.nblocks;
-    const int nk = p.K >> 6;
-    const long wstep = p.w_tile_major ? 4096 : BK;
-
-    int xoff[TM], woff[4], xsw[TM], wsw[4];
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-        const int rho = wm * TM * 16 + a * 16 + l15;
-        xoff[a] = rho * BK;
-        xsw[a] = swz(rho);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int rho = BM + wn * 64 + j * 16 + l15;
-        woff[j] = rho * BK;
-        wsw[j] = swz(rho);
-    }
-
-    const bf16_t* src[PER_WAVE];
-    auto setup = [&](int tile, int& m0, int& n0, int& nbv) {   // loader pointers of `tile`
-        int mb, nb;
-        gemm_tile_coords(tile, p.mblocks, p.nblocks, mb, nb);
-        m0 = mb * BM; n0 = nb * BN; nbv = nb;
-#pragma unroll
-        for (int i = 0; i < PER_WAVE; ++i) {
-            const int inst = wave + i * NW;
-            const int rho = inst * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ swz(rho);
-            if (rho < BM) {
-                int m = m0 + rho;
-                if (m > p.M - 1) m = p.M - 1;
-                src[i] = p.X + (long)m * p.ldx + c * 8;
-            } else {
-                const int q = rho - BM;
-                const int wq = q >> 6, j = (q >> 4) & 3, i16 = q & 15;
-                int n = n0 + wq * 64 + (i16 >> 2) * 16 + j * 4 + (i16 & 3);
-                if (n > p.N - 1) n = p.N - 1;
-                src[i] = p.w_tile_major ? p.W + (long)(n >> 6) * 64 * p.K + (n & 63) * 64 + c * 8 : p.W + (long)n * p.ldw + c * 8;
-            }
-        }
-    };
-    auto stage = [&](int kt, int buf) {
-#pragma unroll
-        for (int i = 0; i < PER_WAVE; ++i) {
-            const int inst = wave + i * NW;
-            const bool is_w = (inst * 8) >= BM;
-            glds16(src[i] + (long)kt * (is_w ? wstep : (long)BK), lds + buf * (ROWS * BK) + inst * 512);
-        }
-    };
-
-    int tile = blockIdx.x;
-    if (tile >= ntiles) return;
-    int m0, n0, nb;
-    setup(tile, m0, n0, nb);
-#pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-        if (s < nk) stage(s, s);
-    bool stores_behind = false;            // E_FULL store instructions of the previous tile were issued after this tile's prologue
-    while (true) {
-        f32x4 acc[TM][4];
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        int buf = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            // stage kt must have landed.  Younger operations that may stay in flight: stages kt+1 .. kt+NS-2 and, while
-            // kt <= NS-2, the previous tile's stores (issued after this tile's prologue stages, before stage NS-1)
-            if (kt + NS - 2 < nk) {
-                if (stores_behind && kt <= NS - 2) wait_vmem_le<(NS - 2) * PER_WAVE + E_FULL>();
-                else wait_vmem_le<(NS - 2) * PER_WAVE>();
-            } else {
-                wait_vmem();
-            }
-            sync_keep_dma();
-            if (kt + NS - 1 < nk) stage(kt + NS - 1, buf == 0 ? NS - 1 : buf - 1);
-            const bf16_t* base = lds + buf * (ROWS * BK);
-            buf = buf + 1 == NS ? 0 : buf + 1;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int c = ks * 4 + g;
-                bf16x8 xb[TM], wa[4];
-#pragma unroll
-                for (int a = 0; a < TM; ++a) xb[a] = ld16<bf16x8>(base + xoff[a] + ((c ^ xsw[a]) << 3));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) wa[j] = ld16<bf16x8>(base + woff[j] + ((c ^ wsw[j]) << 3));
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[a][j] = mfma16(wa[j], xb[a], acc[a][j]);
-            }
-        }
-        // this tile's operands are consumed (the tail of the loop drained every request).  Request the next tile's first
-        // stages BEFORE storing this one; the barrier makes sure no wave still reads the slots they land in.
-        const int next = tile + gridDim.x;
-        const int cm0 = m0, cn0 = n0, cnb = nb;
-        const bool full = COUNTED && cm0 + BM <= p.M && cn0 + BN <= p.N;
-        if (next < ntiles) {
-            sync_keep_dma();
-            setup(next, m0, n0, nb);
-#pragma unroll
-            for (int s = 0; s < NS - 1; ++s)
-                if (s < nk) stage(s, s);
-            sched_fence();   // the counted waits above assume the stores below are YOUNGER than these requests
-        }
-        gemm_epilogue<TM, EPI, WN>(p, acc, cm0 + wm * TM * 16, cn0, wn, cnb, 0);
-        if (next >= ntiles) break;
-        if (!full) wait_vmem();            // unknown number of store instructions (edge tile / other epilogue): drain
-        stores_behind = full;
-        tile = next;
-    }
-}
-
-template <int WM, int WN, int TM, int EPI, int NS = 2>
-inline void gemm_persist_launch(GemmArgs p, int n_workgroups, hipStream_t s) {
-    constexpr int BM = WM * TM * 16, BN = WN * 64;
-    p.mblocks = (p.M + BM - 1) / BM;
-    p.nblocks = (p.N + BN - 1) / BN;
-    p.k_tiles_per_split = p.K / 64;
-    if constexpr (EPI == EPI_ARGMAX) p.part_stride = p.nblocks * WN;
-    const int ntiles = p.mblocks * p.nblocks;
-    int grid = n_workgroups < ntiles ? n_workgroups : ntiles;
-    if (grid >= 8) grid = grid / 8 * 8;    // tiles keep their XCD (tile % 8) from one round to the next
-    NTTS_LAUNCH((gemm_persist_kernel<WM, WN, TM, EPI, NS>), dim3(grid), dim3(WM * WN * 64), s, p);
-}
-
-// ------------------------------------------------------------------------------------------------
-// X-panel-resident GEMM for the decode step's K = hidden_size GEMMs (K <= 896, M = batch):
-//     out[M, N] = f(X)[M, K] * W[N, K]^T,   f = identity  or  RMSNorm (NORM: w * bf16(x * rsqrt(mean(x^2) + eps)))
-// A workgroup owns 64 rows of X.  It loads that 64 x K panel ONCE (through registers, so the RMSNorm of
-// hf:models/qwen2/modeling_qwen2.py:247-252 is applied on the way in: no separate norm kernel, no normalised copy of
-// the activations in HBM) and keeps it in LDS in the k-tile-major swizzled image the MFMA loop reads.  W never
-// touches LDS: wave w of the workgroup owns 16 of the tile's 64 output features, so its W fragments are private
-// and are streamed HBM -> VGPR: the full K extent of the tile (28 KB per wave) is in flight, and the registers a
-// k-step frees are refilled with the next tile's W at once (a first version that staged W through an LDS-DMA ring
-// had only 24 KB in flight per CU and ran at a third of the speed).  The main loop has no barrier at all.
-// D layout (A = W fragment): lane (g, l15) holds features 4g..4g+3 of the wave's 16 for token rt*16 + l15.
-// LDS: 14 panel k-tiles x 8 KB = 112 KB: one workgroup per CU.
-constexpr int kPanelKT = 14;
-constexpr int kXpMaxTiles = 4;     // 64-feature tiles one workgroup may walk (fully unrolled)
-template <int EPI, bool NORM, int KT>
-NTTS_KERNEL(256) void gemm_xpanel_kernel(GemmArgs p) {
-    static_assert(KT >= 1 && KT <= kPanelKT, "panel size");
-    NTTS_SHARED bf16_t lds[KT * 4096 + KT * 64];   // panel + the RMSNorm weight row
-    const int tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-    const int g = lane >> 4, l15 = lane & 15;
-    // grid = mblocks * ngroups; XCD-aware: consecutive logical ids (one XCD) are the m-blocks of one column group
-    const int nblk = gridDim.x;
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-    const int qd = nblk >> 3, rm = nblk & 7;
-    const int t = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
-    const int mb = t % p.mblocks, ng = t / p.mblocks;
-    const int m0 = mb * 64;
-    const int nt0 = ng * p.ntiles_per_block;
-    int ntl = p.nblocks - nt0;
-    if (ntl > p.ntiles_per_block) ntl = p.ntiles_per_block;
-    if (ntl <= 0) return;                        // block-uniform
-
-    // ---- W stream of this wave: the whole K extent of its 16 feature rows lives in registers (KT x 32 B per lane);
-    //      while tile nt is consumed k-tile by k-tile, the freed registers are refilled with tile nt+1
-    bf16x8 wq[2][KT][2];                         // ping-pong register sets, statically indexed
-    auto w_ptr = [&](int nt) {
-        int n = (nt0 + nt) * 64 + wave * 16 + l15;
-        if (n > p.N - 1) n = p.N - 1;
-        return p.W + (long)n * p.ldw + g * 8;
-    };
-    {
-        const bf16_t* wr = w_ptr(0);
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {        // W is on its way while the panel is built
-            wq[0][kt][0] = ld16<bf16x8>(wr + kt * 64);
-            wq[0][kt][1] = ld16<bf16x8>(wr + kt * 64 + 32);
-        }
-    }
-    bf16_t* nw_lds = lds + KT * 4096;
-    if constexpr (NORM) {                        // norm weight row -> LDS (read back per chunk without vmem waits)
-        if (tid < KT * 8) *(bf16x8*)(nw_lds + tid * 8) = ld16<bf16x8>(p.norm_w + tid * 8);
-    }
-
-    // ---- X panel: thread = (row r, quarter q4); 16-byte chunks q4, q4 + 4, ... of the row
-    {
-        const int r = tid >> 2, q4 = tid & 3;
-        int m = m0 + r;
-        if (m > p.M - 1) m = p.M - 1;
-        const bf16_t* xr = p.X + (long)m * p.ldx;
-        constexpr int NJ = KT * 2;               // 16-byte chunks per thread
-        bf16x8 xv[NJ];
-        float ss = 0.f;
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) xv[j] = ld16<bf16x8>(xr + (q4 + 4 * j) * 8);
-        float inv = 1.f;
-        if constexpr (NORM) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const float f = bf2f((bf16_t)xv[j][e]); ss += f * f; }
-            ss += shfl_xor(ss, 1);
-            ss += shfl_xor(ss, 2);
-            inv = frsqrt_exact(ss / (float)(KT * 64) + p.norm_eps);
-            sync();                              // nw_lds visible
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int c = q4 + 4 * j;
-            bf16x8 y = xv[j];
-            if constexpr (NORM) {
-                const bf16x8 wv = ld16<bf16x8>(nw_lds + c * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    y[e] = (short)f2bf(bf2f((bf16_t)wv[e]) * rbf(bf2f((bf16_t)xv[j][e]) * inv));
-            }
-            const int kt = c >> 3, cc = c & 7;
-            *(bf16x8*)(lds + kt * 4096 + r * 64 + ((cc ^ ((r >> 1) & 7)) << 3)) = y;
-        }
-    }
-    sync();
-
-    // ---- main loop: no barrier, the panel is read-only
-    int xoff[4], xsw[4];
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
-        const int r = rt * 16 + l15;
-        xoff[rt] = r * 64;
-        xsw[rt] = (r >> 1) & 7;
-    }
-    // One 64-feature tile: consume set `cur` k-step by k-step; with MORE, refill the other set with the next tile.
-    // Tiles are fully unrolled (kXpMaxTiles) so every W register is statically named and hipcc's counted vmcnt
-    // waits keep the whole next tile in flight (a rolled loop made it drain the stream at every back-edge).
-    auto tile = [&](auto cur_c, auto more_c, int nt) {
-        constexpr int CUR = decltype(cur_c)::value;
-        constexpr bool MORE = decltype(more_c)::value;
-        f32x4 acc[4];
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) acc[rt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const bf16_t* wnext = w_ptr(nt + (MORE ? 1 : 0));
-#pragma unroll
-        for (int kt = 0; kt < KT; ++kt) {
-            if constexpr (MORE) {
-                wq[CUR ^ 1][kt][0] = ld16<bf16x8>(wnext + kt * 64);
-                wq[CUR ^ 1][kt][1] = ld16<bf16x8>(wnext + kt * 64 + 32);
-            }
-            const bf16_t* xb = lds + kt * 4096;
-#pragma unroll
-            for (int rt = 0; rt < 4; ++rt) {
-                acc[rt] = mfma16(wq[CUR][kt][0], ld16<bf16x8>(xb + xoff[rt] + ((g ^ xsw[rt]) << 3)), acc[rt]);
-                acc[rt] = mfma16(wq[CUR][kt][1], ld16<bf16x8>(xb + xoff[rt] + (((4 + g) ^ xsw[rt]) << 3)), acc[rt]);
-            }
-        }
-        // ---- epilogue of feature tile nt: lane owns features nf..nf+3 of tokens m0 + rt*16 + l15
-        const int nf = (nt0 + nt) * 64 + wave * 16 + g * 4;
-        float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (EPI != EPI_SILU_MUL) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (nf + r < p.N) bias4[r] = gemm_bias(p, nf + r);
-        }
-#pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
-            const int m = m0 + rt * 16 + l15;
-            const bool mok = m < p.M;
-            if constexpr (EPI == EPI_SILU_MUL) {
-                // packed rows (backbone.cpp gu_map): lanes g = 0,1 hold gate, g = 2,3 the up of the same features
-                float up[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) up[r] = shfl_xor(acc[rt][r], 32);
-                if (g < 2 && mok) {
-                    alignas(8) bf16_t o[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float gt = rbf(acc[rt][r]), u = rbf(up[r]);
-                        o[r] = f2bf(rbf(silu_f(gt)) * u);
-                    }
-                    const int fb = (nt0 + nt) * 32 + wave * 8 + g * 4;
-                    if (fb + 4 <= (p.N >> 1)) *(u32x2*)((bf16_t*)p.out + (long)m * p.ldo + fb) = *(u32x2*)&o[0];
-                }
-            } else {
-                if (mok) {
-                    alignas(8) bf16_t o[4];
-                    bf16_t* dst = (bf16_t*)p.out + (long)m * p.ldo + nf;
-                    const bool full = nf + 4 <= p.N;
-                    alignas(8) bf16_t rr[4] = {0, 0, 0, 0};
-                    if constexpr (EPI == EPI_RESID) {
-                        const bf16_t* rs = p.resid_bf16 + (long)m * p.ldrb + nf;
-                        if (full) *(u32x2*)&rr[0] = *(const u32x2*)rs;
-                        else
-                            for (int r = 0; r < 4; ++r)
-                                if (nf + r < p.N) rr[r] = rs[r];
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float lin = acc[rt][r] + bias4[r];
-                        if constexpr (EPI == EPI_RESID) o[r] = f2bf(bf2f(rr[r]) + rbf(lin));   // h + bf16(o_proj)
-                        else o[r] = f2bf(lin);
-                    }
-                    if (full) *(u32x2*)dst = *(u32x2*)&o[0];
-                    else
-                        for (int r = 0; r < 4; ++r)
-                            if (nf + r < p.N) dst[r] = o[r];
-                }
-            }
-        }
-    };
-    using T0 = std::integral_constant<int, 0>;
-    using T1 = std::integral_constant<int, 1>;
-    using Yes = std::integral_constant<bool, true>;
-    using No = std::integral_constant<bool, false>;
-    static_assert(kXpMaxTiles == 4, "unrolled below");
-    if (ntl > 1) tile(T0{}, Yes{}, 0); else { tile(T0{}, No{}, 0); return; }
-    if (ntl > 2) tile(T1{}, Yes{}, 1); else { tile(T1{}, No{}, 1); return; }
-    if (ntl > 3) tile(T0{}, Yes{}, 2); else { tile(T0{}, No{}, 2); return; }
-    tile(T1{}, No{}, 3);
-}
-
-// blocks_target: how many workgroups to aim for (about the CU count).  K must be 64 * 7 or 64 * 14 (the panel is a
-// compile-time size so the W register file is statically indexed); returns false otherwise.
-template <int EPI, bool NORM>
-inline bool gemm_xpanel_launch(GemmArgs p, int blocks_target, hipStream_t s) {
-    static_assert(EPI == EPI_BF16 || EPI == EPI_RESID || EPI == EPI_SILU_MUL, "epilogues of the X-panel kernel");
-    p.mblocks = (p.M + 63) / 64;
-    p.nblocks = (p.N + 63) / 64;
-    int tpb = (p.mblocks * p.nblocks + blocks_target - 1) / blocks_target;
-    if (tpb < 1) tpb = 1;
-    if (tpb > kXpMaxTiles) tpb = kXpMaxTiles;
-    p.ntiles_per_block = tpb;
-    const int ngroups = (p.nblocks + tpb - 1) / tpb;
-    const dim3 grid(p.mblocks * ngroups), block(256);
-    if (p.K == 64 * 14) NTTS_LAUNCH((gemm_xpanel_kernel<EPI, NORM, 14>), grid, block, s, p);
-    else if (p.K == 64 * 7) NTTS_LAUNCH((gemm_xpanel_kernel<EPI, NORM, 7>), grid, block, s, p);
-    else return false;
-    return true;
-}
+// Measured on MI355X and removed (profiles/r02a_*): a persistent variant of this kernel that requested the next tile's first
+// stages before storing the current tile (prefill / codec GEMMs: 1116-1190 vs 1123-1188 TFLOP/s, no gain: the store tail
+// is not what the counted waits were hiding), and an X-panel-resident variant with the RMSNorm fused into the QKV / gate-up
+// prologues (2.33 vs 1.95 ms per decode step at batch 256: one 4-wave workgroup per CU cannot overlap its LDS-read -> MFMA
+// chains).
 
 // ------------------------------------------------------------------------------------------------
 // host launchers
@@ -762,9 +401,6 @@ inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
 #define NTTS_GEMM_XL(EPI, p, ks, s) ::ntts::gemm_launch<4, 4, 4, EPI, 2>(p, ks, s)
 // big-M dispatch used by the prefill and codec paths
 #define NTTS_GEMM_BIG(EPI, p, s) do { if ((p).M >= 1024 && (p).N >= 256) NTTS_GEMM_XL(EPI, p, 1, s); else NTTS_GEMM_L(EPI, p, 1, s); } while (0)
-// the same dispatch with the EXPERIMENTAL persistent kernel for the XL case when `persist_wgs` > 0 (workgroups = CUs)
-#define NTTS_GEMM_BIG_P(EPI, p, s, persist_wgs) do { if ((persist_wgs) > 0 && (p).M >= 1024 && (p).N >= 256) \
-        ::ntts::gemm_persist_launch<4, 4, 4, EPI, 2>(p, persist_wgs, s); else NTTS_GEMM_BIG(EPI, p, s); } while (0)
 #define NTTS_GEMM_L(EPI, p, ks, s) ::ntts::gemm_launch<2, 2, 4, EPI, 2>(p, ks, s)
 #define NTTS_GEMM_S(EPI, p, ks, s) ::ntts::gemm_launch<4, 1, 1, EPI, 4>(p, ks, s)
 

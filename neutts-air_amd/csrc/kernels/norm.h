@@ -34,12 +34,13 @@ struct NormArgs {
     float eps;
 };
 
+// One wave64 = one row.  `r` = logical row (already clamped into range), `rok` = its outputs are wanted (the clamped
+// duplicates of a ragged last block keep every lane alive for the shuffles), `write_resid` = store the new residual row.
+// `dst` != nullptr: the normalised row goes there (H contiguous bf16, e.g. an LDS panel: gemv.h's fused prologue) instead of
+// p.normed_out.  This is THE arithmetic (and its order) of the residual add + RMSNorm on the path; every caller shares it.
 template <int NCH>  // 16-byte chunks per lane: H <= 512*NCH
-NTTS_KERNEL(256) void add_rmsnorm_kernel(NormArgs p) {
+NTTS_D void rmsnorm_row_wave(const NormArgs& p, int r, bool rok, bool write_resid, bf16_t* dst) {
     const int lane = lane_id();
-    const int row = blockIdx.x * 4 + wave_id();
-    const bool rok = row < p.M;
-    const int r = rok ? row : p.M - 1;           // keep every lane alive for the shuffles
     const long ri = p.in_rows ? p.in_rows[r] : r;
     const long ro = p.out_rows ? p.out_rows[r] : r;
     const int nchunk = p.H >> 3;
@@ -86,7 +87,7 @@ NTTS_KERNEL(256) void add_rmsnorm_kernel(NormArgs p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = rbf(bf2f((bf16_t)t[e]) + o[e]);
             }
-            if (p.resid_out && rok) {
+            if (p.resid_out && rok && write_resid) {
                 bf16x8 t;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) t[e] = (short)f2bf(o[e]);
@@ -118,9 +119,16 @@ NTTS_KERNEL(256) void add_rmsnorm_kernel(NormArgs p) {
             bf16x8 t;
 #pragma unroll
             for (int e = 0; e < 8; ++e) t[e] = (short)f2bf(bf2f((bf16_t)w[e]) * rbf(v[i][e] * inv));
-            *(bf16x8*)(p.normed_out + ro * p.H + col) = t;
+            *(bf16x8*)(dst ? dst + col : p.normed_out + ro * p.H + col) = t;
         }
     }
+}
+
+template <int NCH>
+NTTS_KERNEL(256) void add_rmsnorm_kernel(NormArgs p) {
+    const int row = blockIdx.x * 4 + wave_id();
+    const bool rok = row < p.M;
+    rmsnorm_row_wave<NCH>(p, rok ? row : p.M - 1, rok, true, nullptr);   // clamped duplicates keep every lane alive for the shuffles
 }
 
 // Decode-batch variant: ONE ROW PER WORKGROUP (2 waves, one 16-byte chunk per thread, H <= 1024), so that 256 rows occupy

@@ -25,14 +25,18 @@ def test_tiny_teacher_forced(emu_lib):
     assert agree >= N - 2, (ids1, z["bf16_ids_1"][:N])
 
 
-@pytest.mark.parametrize("knobs", [{}, {"NTTS_ATTN_DEPTH": "1", "NTTS_S_STAGES": "3", "NTTS_PF_GH": "4", "NTTS_FUSED": "1"},
-                                   {"NTTS_ATTN_DEPTH": "4", "NTTS_S_STAGES": "6", "NTTS_KSPLIT_O": "2", "NTTS_KSPLIT_D": "5",
-                                    "NTTS_PREFILL_ATTN_SIMPLE": "1", "NTTS_KSPLIT_QKV": "3", "NTTS_ATTN_VAR": "0", "NTTS_NORM_WIDE": "0", "NTTS_W_TILE_MAJOR": "0", "NTTS_GEMM_PERSIST": "1"}])
+@pytest.mark.parametrize("knobs", [
+    {},                                                                                    # small-batch path (gemv.h), defaults
+    {"NTTS_SKS_Q": "2", "NTTS_SKS_O": "3", "NTTS_SKS_D": "16", "NTTS_ATTN_DEPTH_SMALL": "1", "NTTS_W_TILE_MAJOR": "0"},
+    {"NTTS_SMALL_BATCH": "0", "NTTS_ATTN_DEPTH": "1", "NTTS_S_STAGES": "3", "NTTS_PF_GH": "4"},   # large-batch path (gemm.h tiles)
+    {"NTTS_SMALL_BATCH": "0", "NTTS_ATTN_DEPTH": "4", "NTTS_S_STAGES": "6", "NTTS_KSPLIT_O": "2", "NTTS_KSPLIT_D": "5",
+     "NTTS_PREFILL_ATTN_SIMPLE": "1", "NTTS_KSPLIT_QKV": "3", "NTTS_ATTN_VAR": "2", "NTTS_NORM_WIDE": "0", "NTTS_W_TILE_MAJOR": "0"}])
 def test_small_gqa2_page_crossing_peaked_exact(emu_lib, knobs, monkeypatch):
     """2 kv heads, prompt of 70 (3 pages), decode crosses the 96-token page boundary; peaked weights so the
-    free-running greedy ids must be bit-identical to HF's -- for every tuning of the decode GEMMs (LDS ring depth,
-    attention prefetch depth, split-K of o/down reduced in the norm kernel, split-K of QKV reduced in the attention prologue, either
-    prefill attention kernel)."""
+    free-running greedy ids must be bit-identical to HF's -- on the small-batch decode path (wave-per-16-features GEMVs with
+    the fused norm prologue, 16-wave attention; any split-K factors, either weight layout) and on the large-batch path for
+    every tuning of its GEMMs (LDS ring depth, attention prefetch depth, split-K of o/down reduced in the norm kernel,
+    split-K of QKV reduced in the attention prologue, either prefill attention kernel)."""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     z, cfg, w = load_fixture("backbone_small_peaked")

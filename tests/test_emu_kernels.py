@@ -36,13 +36,9 @@ GEMM_CASES = [  # (M, N, K, variant, bias)
     (70, 200, 64, 5, False),     # ... a single 64-wide K tile = 2 slices, fewer than the ring holds
     (130, 144, 320, 6, True),    # L tile, 3-slot ring of 32-wide slices
 ]
-EXPERIMENTAL_CASES = [  # kernels not used by the product yet: emulator only until they have been measured on the GPU
-    (1100, 712, 192, 8, True),   # persistent XL tile: 5 x 3 = 15 tiles walked by 8 workgroups (1 or 2 tiles each), ragged edges
-    (600, 272, 128, 9, False),   # persistent L tile, 3-slot ring: 5 x 3 tiles walked by 3 workgroups (5 tiles each)
-]
 
 
-@pytest.mark.parametrize("M,N,K,variant,has_bias", GEMM_CASES + EXPERIMENTAL_CASES)
+@pytest.mark.parametrize("M,N,K,variant,has_bias", GEMM_CASES)
 def test_gemm_emu(emu_lib, M, N, K, variant, has_bias):
     lib = _hip.load_library(emu_lib)
     g = torch.Generator().manual_seed(M * 1000 + N)

@@ -263,4 +263,4 @@ def test_infer_stream_batch_equals_single_streams(tts):
         for a, b in zip(got[i], singles[i]):
             assert a.shape == b.shape and np.array_equal(a, b)
     with pytest.raises(ValueError, match="decode slots"):
-        next(tts.infer_stream_batch(["a", "b", "c"], ref_codes, "x"))
+        next(tts.infer_stream_batch(["a"] * (tts.backbone.max_batch + 1), ref_codes, "x"))

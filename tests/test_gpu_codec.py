@@ -10,8 +10,10 @@ from common import load_codec_fixture, make_codec_engine, rms
 
 pytestmark = pytest.mark.gpu
 
-# bf16 GEMM operands against an fp32 reference: measured relative RMS error on MI355X (profiles/r02*_pytest_gpu.log) x 2
-REL_BOUND = 0.03
+# bf16 GEMM operands against an fp32 reference.  Measured on MI355X (profiles/r02a_pytest_gpu.log): NeuCodec geometry
+# RMS error 1.10e-4 .. 1.15e-4 at signal RMS 1.6e-2 (relative 6.9e-3 .. 7.2e-3); the bounds below are 2x what was measured.
+REL_BOUND = 0.015
+ABS_BOUND = 2.5e-4      # BASELINE.json asks for 1e-3
 
 
 @pytest.fixture(scope="module")
@@ -30,7 +32,8 @@ def test_codec_tiny(lib):
     for wv, g in zip(wavs, gold):
         assert wv.shape == g.shape and not np.isnan(wv).any()
         print(f"codec_tiny: RMS error {rms(wv - g):.3e}, signal RMS {rms(g):.3e}, relative {rms(wv - g) / rms(g):.3e}")
-        assert rms(wv - g) <= 1e-3 and rms(wv - g) <= 0.02 * rms(g), (rms(wv - g), rms(g))
+        # measured: 4.5e-4 .. 5.9e-4 at signal RMS 7e-2 .. 8.6e-2 (relative 5.4e-3 .. 8.5e-3)
+        assert rms(wv - g) <= 1e-3 and rms(wv - g) <= 0.017 * rms(g), (rms(wv - g), rms(g))
     assert np.array_equal(eng.decode([codes[1]])[0], wavs[1])
 
 
@@ -52,7 +55,7 @@ def test_neucodec_geometry_vs_golden(neucodec):
         assert wv.shape == g.shape == (480 * len(codes),)
         err, sig = rms(wv - g), rms(g)
         print(f"neucodec golden set {i}: {len(codes)} frames, RMS error {err:.3e}, signal RMS {sig:.3e}, relative {err / sig:.3e}")
-        assert err <= 1e-3, (i, err, sig)                 # BASELINE.json: waveform RMS within 1e-3 (fp32 reference)
+        assert err <= ABS_BOUND, (i, err, sig)            # BASELINE.json: waveform RMS within 1e-3 (fp32 reference)
         assert err <= REL_BOUND * sig, (i, err, sig)      # and relative to the signal: 2x the error measured on MI355X
 
 
@@ -71,4 +74,4 @@ def test_neucodec_batch256_properties(neucodec):
     ref = cr.decode_code(cfg, w, torch.tensor(base[1], dtype=torch.long)[None, None, :])[0, 0].numpy()
     err, sig = rms(wavs[1] - ref), rms(ref)
     print(f"batch-256 row vs oracle: RMS error {err:.3e}, signal RMS {sig:.3e}, relative {err / sig:.3e}")
-    assert err <= 1e-3 and err <= REL_BOUND * sig
+    assert err <= ABS_BOUND and err <= REL_BOUND * sig
