@@ -85,7 +85,7 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
     const int* bt = p.block_table + (long)b * p.max_pages;
     auto mark = [&](int phase) {   // diagnostics instantiation only (ntts_backbone_attn_timeline); compiled out of the product kernel
         if constexpr (kTimeline) {
-            if (lane == 0) p.tl[(((long)b * p.nkv + kvh) * 4 + w) * 8 + phase] = now_ticks();
+            if (lane == 0 && w < 4) p.tl[(((long)b * p.nkv + kvh) * 4 + w) * 8 + phase] = now_ticks();
         }
     };
     mark(0);
@@ -187,6 +187,22 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
 #pragma unroll
         for (int j = 0; j < kDepth; ++j) load_k_at(bt0[j], kq[j]);
     }
+    auto load_v_at = [&](long page, bf16x8 (&v)[4]) {
+        const bf16_t* vp = p.vpool + (page * p.nkv + kvh) * 64 * kPage;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            if constexpr (kVar & 2) v[nt] = ld16_nt<bf16x8>(vp + (nt * 16 + l15) * kPage + g * 8);   // K/V pages: read once per step
+            else v[nt] = ld16<bf16x8>(vp + (nt * 16 + l15) * kPage + g * 8);
+        }
+    };
+    auto load_v = [&](int pg, bf16x8 (&v)[4]) { load_v_at(bt[pg], v); };
+    bf16x8 vq[kDepth][4];
+    // kVar & 4: the first V^T pages are requested right behind the first K pages instead of after the score pass -- at small
+    // batch the kernel is one chain of dependent round trips (block table -> K -> scores -> V -> PV) and this removes one
+    if constexpr (kVar & 4) {
+#pragma unroll
+        for (int j = 0; j < kDepth; ++j) load_v_at(bt0[j], vq[j]);   // (a page index past the context addresses a valid page; unused)
+    }
 
     // ---- prologue: RoPE(q), RoPE(k) + append k, v to the cache (and keep them in LDS for this step)
 #pragma unroll
@@ -266,19 +282,13 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
         }
     }
     mark(4);
-    // ---- V^T pages are independent of the scores: get the first ones in flight under the softmax reductions
-    auto load_v = [&](int pg, bf16x8 (&v)[4]) {
-        const bf16_t* vp = p.vpool + ((long)bt[pg] * p.nkv + kvh) * 64 * kPage;
+    // ---- V^T pages are independent of the scores: (kVar & 4: already requested next to the K pages) else get the first
+    //      ones in flight under the softmax reductions
+    if constexpr (!(kVar & 4)) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            if constexpr (kVar & 2) v[nt] = ld16_nt<bf16x8>(vp + (nt * 16 + l15) * kPage + g * 8);   // K/V pages: read once per step
-            else v[nt] = ld16<bf16x8>(vp + (nt * 16 + l15) * kPage + g * 8);
-        }
-    };
-    bf16x8 vq[kDepth][4];
-#pragma unroll
-    for (int j = 0; j < kDepth; ++j)
-        if (w + NW * j < npages) load_v(w + NW * j, vq[j]);
+        for (int j = 0; j < kDepth; ++j)
+            if (w + NW * j < npages) load_v(w + NW * j, vq[j]);
+    }
 
     // ---- merge the (max, sum) pairs: across the 4 key groups of a wave, then across the 4 waves (one barrier)
 #pragma unroll
@@ -367,28 +377,34 @@ template <int kVar>
 inline void attn_decode_launch_v(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth) {
     const dim3 grid(batch, p.nkv), block(256);
     if (p.tl) {   // diagnostics: the instantiation that records phase timestamps
-        switch (depth) {
-            case 1: NTTS_LAUNCH((attn_decode_kernel<1, true, kVar>), grid, block, s, p); break;
-            case 2: NTTS_LAUNCH((attn_decode_kernel<2, true, kVar>), grid, block, s, p); break;
-            default: NTTS_LAUNCH((attn_decode_kernel<3, true, kVar>), grid, block, s, p); break;
-        }
+        NTTS_LAUNCH((attn_decode_kernel<1, true, kVar>), grid, block, s, p);
         return;
     }
     switch (depth) {
         case 1: NTTS_LAUNCH((attn_decode_kernel<1, false, kVar>), grid, block, s, p); break;
-        case 2: NTTS_LAUNCH((attn_decode_kernel<2, false, kVar>), grid, block, s, p); break;
-        case 4: NTTS_LAUNCH((attn_decode_kernel<4, false, kVar>), grid, block, s, p); break;
-        default: NTTS_LAUNCH((attn_decode_kernel<3, false, kVar>), grid, block, s, p); break;
+        default: NTTS_LAUNCH((attn_decode_kernel<2, false, kVar>), grid, block, s, p); break;   // deeper rings measured slower (r01d)
     }
 }
-// small-batch variant: 16 waves per workgroup, 1 or 2 pages per wave in flight
-inline void attn_decode_launch_wide(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth) {
-    const dim3 grid(batch, p.nkv), block(16 * 64);
-    if (depth >= 2) NTTS_LAUNCH((attn_decode_kernel<2, false, 3, 16>), grid, block, s, p);
-    else NTTS_LAUNCH((attn_decode_kernel<1, false, 3, 16>), grid, block, s, p);
+// small-batch variants: nw = 16 or 4 waves per workgroup, `depth` pages per wave in flight, V^T requested next to K (kVar 7)
+inline void attn_decode_launch_small(const AttnDecodeArgs& p, int batch, hipStream_t s, int nw, int depth) {
+    const dim3 grid(batch, p.nkv);
+    if (p.tl) {   // diagnostics: phase timestamps of waves 0-3
+        if (nw == 16) NTTS_LAUNCH((attn_decode_kernel<2, true, 7, 16>), grid, dim3(1024), s, p);
+        else NTTS_LAUNCH((attn_decode_kernel<2, true, 7, 4>), grid, dim3(256), s, p);
+        return;
+    }
+    if (nw == 16) {
+        if (depth >= 2) NTTS_LAUNCH((attn_decode_kernel<2, false, 7, 16>), grid, dim3(1024), s, p);
+        else NTTS_LAUNCH((attn_decode_kernel<1, false, 7, 16>), grid, dim3(1024), s, p);
+    } else {
+        if (depth >= 4) NTTS_LAUNCH((attn_decode_kernel<4, false, 7, 4>), grid, dim3(256), s, p);
+        else if (depth >= 2) NTTS_LAUNCH((attn_decode_kernel<2, false, 7, 4>), grid, dim3(256), s, p);
+        else NTTS_LAUNCH((attn_decode_kernel<1, false, 7, 4>), grid, dim3(256), s, p);
+    }
 }
 inline void attn_decode_launch(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth = kAttnDepthDefault, int var = 1) {
-    if ((var & 3) == 3) attn_decode_launch_v<3>(p, batch, s, depth);        // + non-temporal K / V^T page loads
+    if ((var & 7) == 7) attn_decode_launch_v<7>(p, batch, s, depth);        // + V^T pages requested next to the K pages
+    else if ((var & 3) == 3) attn_decode_launch_v<3>(p, batch, s, depth);   // + non-temporal K / V^T page loads
     else if (var & 1) attn_decode_launch_v<1>(p, batch, s, depth);
     else attn_decode_launch_v<0>(p, batch, s, depth);
 }

@@ -8,19 +8,24 @@
 // (at batch 1 a layer's weights are 30 MB = 6 us at 5 TB/s, while every launch boundary costs ~2 us).
 //
 // Structure (MI355X_MICROARCH.md / cdna_hip_programming.md "GEMV / M <= 16 decode weights"):
-//   * one WAVE owns 16 output features over a K slice; no LDS staging of W, no barrier in the main loop: the W fragments go
-//     HBM -> VGPR with the non-temporal policy, a whole chunk of k-tiles requested at once (double-buffered chunks), so a
-//     wave has 8-28 KB of its private weight stream in flight.  With the engine's tile-major weight layout a wave's
-//     16 rows x 128 B of one k-tile are 2 KB CONTIGUOUS: two fully coalesced 1 KB wave-loads.
+//   * a workgroup = 4 FEATURE waves + 4 HELPER waves.  A feature wave owns 16 output features over the workgroup's K slice:
+//     no LDS staging of W, no barrier in its main loop; its W fragments go HBM -> VGPR, the WHOLE slice (<= 16 k-tiles =
+//     32 KB per wave) requested at kernel entry, before anything else (default cache policy: the non-temporal one measured
+//     SLOWER here, lm_head 76.5 vs 65.7 us, gate/up 10.2 vs 9.1 -- profiles/r02b_sweep_b1.log).  With the engine's tile-major weight layout a
+//     wave's 16 rows x 128 B of one k-tile are 2 KB CONTIGUOUS: two fully coalesced 1 KB wave-loads.
+//   * the helper waves build the X panel of the slice in LDS meanwhile (so that X costs the feature waves no global loads
+//     and no registers): a plain copy of the bf16 rows, or -- PRO, prologue fusion -- what add_rmsnorm (norm.h) would have
+//     computed: sum the producer's split-K slabs in order, round (the Linear output), add the residual, round, RMSNorm,
+//     times the norm weight; block 0 also writes the new residual stream.  Every workgroup redoes that little piece of
+//     work (at M <= 8 a few KB out of L2), which removes two of a layer's seven launches and the embedding gather of
+//     layer 0.  The arithmetic and its ORDER are add_rmsnorm_kernel<2>'s (norm.h rmsnorm_row_wave).  Because the helpers
+//     are separate waves, their (L2) loads do not queue behind the feature waves' HBM weight stream (a wave's loads
+//     return in order) and their registers cost the feature waves nothing.
 //   * the matrix core is used as a 16 x 16 x 32 dot-product engine: A = W fragment (16 features x 32 k), B = X fragment
-//     (32 k x 16 token rows, rows >= M are clamped duplicates and never stored).  Lane (l15, g) holds k = g*16 .. g*16+15 of
-//     its row for BOTH operands (first MFMA: the low 8, second: the high 8): any k order works as long as A and B agree.
+//     (32 k x 16 token rows; rows >= M hold whatever the LDS held: a B column only feeds its own output column, which is
+//     never stored).  Lane (l15, g) holds k = g*16 .. g*16+15 of its row for BOTH operands (first MFMA: the low 8, second:
+//     the high 8): any k order works as long as A and B agree.
 //   * split-K over gridDim.y writes fp32 slabs [split][slab_rows][N] that the consumer reduces -- same hand-off as gemm.h.
-//   * PRO (prologue fusion): the consumer of a split-K GEMM normally is add_rmsnorm (norm.h); here every workgroup redoes
-//     that little piece of work itself -- sum the slabs in order, round (the Linear output), add the residual, round,
-//     RMSNorm, times the norm weight -- for all M rows into LDS, and block 0 writes the new residual stream.  At M <= 8
-//     that is a few KB per workgroup out of L2, and it removes two of a layer's seven launches (and the embedding
-//     gather of layer 0).  The arithmetic and its ORDER are add_rmsnorm_kernel<2>'s (norm.h rmsnorm_row_wave).
 #pragma once
 #include <ntts/dev.h>
 
@@ -42,8 +47,8 @@ struct GemvArgs {
     void* out;
     long ldo;
     long slab_rows;        // EPI_SPLITK: rows per slab of `out`
-    int M, N, K;           // M <= 16, N % 16 == 0, K % 64 == 0
-    int k_tiles_per_split;
+    int M, N, K;           // M <= 16, N % 16 == 0, K % 64 == 0 (PRO: K = pro.H <= 1024)
+    int k_tiles_per_split; // <= 16
     // EPI_ARGMAX (lm_head)
     float* part_val;
     int* part_idx;
@@ -55,100 +60,68 @@ struct GemvArgs {
     long ld_logits_bf16;
 };
 
-template <int EPI, bool PRO>
-NTTS_KERNEL(256) void gemv_kernel(GemvArgs p) {
-    constexpr int CH = PRO ? 7 : 4;                        // k-tiles per register chunk (two chunks live: W only, or W + X)
-    NTTS_SHARED bf16_t xs[PRO ? kGemvRows * kGemvXld : 8];
+// KT = k-tiles of the workgroup's K slice this instantiation is unrolled for (the slice may be shorter: the surplus loads
+// re-read the last tile and their fragments are masked to zero -- NO per-element branches: a load guarded by a run-time
+// condition makes hipcc wait for each element before it requests the next, cdna_hip_programming.md "three .s-level traps" (c),
+// which is what a first version of this kernel did: 66 s_waitcnt in 770 instructions, slower than the LDS-DMA tiles).
+template <int EPI, bool PRO, int KT>
+NTTS_KERNEL(512) void gemv_kernel(GemvArgs p) {
+    NTTS_SHARED bf16_t xs[kGemvRows * kGemvXld];
     const int lane = lane_id(), w = wave_id();
     const int g = lane >> 4, l15 = lane & 15;
-    const int f0 = (blockIdx.x * 4 + w) * 16;              // this wave's 16 features
     const int ktiles = p.K >> 6;
     const int kt0 = blockIdx.y * p.k_tiles_per_split;
     int nk = ktiles - kt0;
-    if (nk > p.k_tiles_per_split) nk = p.k_tiles_per_split;
-    const bool active = f0 < p.N && nk > 0;                // wave-uniform
+    if (nk > p.k_tiles_per_split) nk = p.k_tiles_per_split;       // <= KT (launcher)
+    const int col0 = PRO ? 0 : kt0 * 64;                          // K index held by panel column 0 (PRO: the panel is the whole row)
 
-    // ---- this wave's weight stream: requested BEFORE the prologue so that it is in flight while the norm is computed
-    const bf16_t* wbase = nullptr;
-    long wstep = 64;
-    if (active) {
-        if (p.w_tile_major) { wbase = p.W + (long)(f0 >> 6) * 64 * p.K + ((f0 & 63) + l15) * 64 + g * 16; wstep = 4096; }
-        else wbase = p.W + (long)(f0 + l15) * p.ldw + g * 16;
-    }
-    bf16x8 wa[2][CH][2], xb[2][PRO ? 1 : CH][2];
-    auto load_w = [&](int c, auto buf_c) {
-        constexpr int BUF = decltype(buf_c)::value;
-#pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const int kt = c * CH + j;
-            const bf16_t* src = wbase + (long)(kt0 + (kt < nk ? kt : nk - 1)) * wstep;   // past the slice: a duplicate, skipped below
-            wa[BUF][j][0] = ld16_nt<bf16x8>(src);
-            wa[BUF][j][1] = ld16_nt<bf16x8>(src + 8);
-        }
-    };
-    const bf16_t* xrow = nullptr;
-    if constexpr (!PRO) {
-        int m = l15 < p.M ? l15 : p.M - 1;
-        xrow = p.X + (long)m * p.ldx + g * 16;
-    }
-    auto load_x = [&](int c, auto buf_c) {
-        constexpr int BUF = decltype(buf_c)::value;
-        if constexpr (!PRO) {
-#pragma unroll
-            for (int j = 0; j < CH; ++j) {
-                const int kt = c * CH + j;
-                const bf16_t* src = xrow + (long)(kt0 + (kt < nk ? kt : nk - 1)) * 64;
-                xb[BUF][j][0] = ld16<bf16x8>(src);
-                xb[BUF][j][1] = ld16<bf16x8>(src + 8);
+    if (w >= 4) {
+        // ---- helper waves: the X panel.  Row m is built by helper (m & 3); rows >= M are left alone.
+        const int hw = w - 4;
+        if constexpr (PRO) {
+            const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
+            for (int m = hw; m < p.M; m += 4) rmsnorm_row_wave<2, 16>(p.pro, m, true, writer, xs + m * kGemvXld);
+        } else {
+            const int nch = nk * 8;                               // 16-byte chunks per row of the slice: <= 128 = 2 per lane
+            for (int m = hw; m < p.M; m += 4) {
+                const bf16_t* src = p.X + (long)m * p.ldx + kt0 * 64;
+                const int c0 = lane, c1 = lane + 64;                // both loads first (clamped addresses), then the guarded stores
+                const bf16x8 t0 = ld16<bf16x8>(src + (c0 < nch ? c0 : 0) * 8);
+                const bf16x8 t1 = ld16<bf16x8>(src + (c1 < nch ? c1 : 0) * 8);
+                if (c0 < nch) *(bf16x8*)(xs + m * kGemvXld + c0 * 8) = t0;
+                if (c1 < nch) *(bf16x8*)(xs + m * kGemvXld + c1 * 8) = t1;
             }
         }
-    };
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
-    const int nchunks = (nk + CH - 1) / CH;
-    if (active) { load_w(0, B0{}); load_x(0, B0{}); }
-
-    if constexpr (PRO) {
-        // rows m = w, w + 4, ...: one wave per row, exactly add_rmsnorm_kernel<2>'s arithmetic; padding rows are zero
-        const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
-        for (int m = w; m < kGemvRows; m += 4) {
-            bf16_t* dst = xs + m * kGemvXld;
-            if (m < p.M) rmsnorm_row_wave<2>(p.pro, m, true, writer, dst);
-            else
-                for (int c = lane; c < (p.K >> 3); c += 64) *(bf16x8*)(dst + c * 8) = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
         sync();
+        return;
     }
+
+    // ---- feature waves: request the whole weight slice (branch-free), then wait for the panel
+    const int f0r = (blockIdx.x * 4 + w) * 16;
+    const bool active = f0r < p.N;                                // wave-uniform
+    const int f0 = active ? f0r : 0;                              // an inactive wave streams (and discards) group 0: no branch around the loads
+    const bf16_t* wbase;
+    long wstep = 64;
+    if (p.w_tile_major) { wbase = p.W + (long)(f0 >> 6) * 64 * p.K + ((f0 & 63) + l15) * 64 + g * 16; wstep = 4096; }
+    else wbase = p.W + (long)(f0 + l15) * p.ldw + g * 16;
+    bf16x8 wa[KT][2];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        const bf16_t* src = wbase + (long)(kt0 + (j < nk ? j : nk - 1)) * wstep;
+        wa[j][0] = ld16<bf16x8>(src);
+        wa[j][1] = ld16<bf16x8>(src + 8);
+    }
+    sync();                                                       // the panel is complete
     if (!active) return;
 
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    auto compute = [&](int c, auto buf_c) {
-        constexpr int BUF = decltype(buf_c)::value;
+    const bf16_t* xrow = xs + l15 * kGemvXld + g * 16 - col0;
 #pragma unroll
-        for (int j = 0; j < CH; ++j) {
-            const int kt = c * CH + j;
-            if (kt < nk) {                                   // wave-uniform
-                bf16x8 x0, x1;
-                if constexpr (PRO) {
-                    const bf16_t* xp = xs + l15 * kGemvXld + (kt0 + kt) * 64 + g * 16;
-                    x0 = ld16<bf16x8>(xp);
-                    x1 = ld16<bf16x8>(xp + 8);
-                } else {
-                    x0 = xb[BUF][j][0];
-                    x1 = xb[BUF][j][1];
-                }
-                acc = mfma16(wa[BUF][j][0], x0, acc);
-                acc = mfma16(wa[BUF][j][1], x1, acc);
-            }
-        }
-    };
-    for (int c = 0; c < nchunks; c += 2) {
-        if (c + 1 < nchunks) { load_w(c + 1, B1{}); load_x(c + 1, B1{}); }
-        compute(c, B0{});
-        if (c + 1 < nchunks) {
-            if (c + 2 < nchunks) { load_w(c + 2, B0{}); load_x(c + 2, B0{}); }
-            compute(c + 1, B1{});
-        }
+    for (int j = 0; j < KT; ++j) {
+        const short keep = j < nk ? (short)-1 : (short)0;         // surplus tiles contribute 0 * x
+        const bf16_t* xp = xrow + (kt0 + (j < nk ? j : nk - 1)) * 64;
+        acc = mfma16(wa[j][0] & keep, ld16<bf16x8>(xp), acc);
+        acc = mfma16(wa[j][1] & keep, ld16<bf16x8>(xp + 8), acc);
     }
 
     // ---- epilogue: lane (g, l15) holds features f0 + g*4 + r (r = 0..3) of token row l15
@@ -203,18 +176,33 @@ NTTS_KERNEL(256) void gemv_kernel(GemvArgs p) {
     }
 }
 
-// number of split-K slabs gemv_launch produces for (K, ksplit)
-inline int gemv_nsplit(int K, int ksplit) { return gemm_nsplit(K, ksplit); }
+
+// the split actually used for (K, requested ksplit): a K slice must fit the LDS panel and the register chunk (<= 16 k-tiles)
+inline int gemv_ksplit(int K, int ksplit) {
+    const int ktiles = K / 64, need = (ktiles + 15) / 16;
+    if (ksplit < need) ksplit = need;
+    if (ksplit > ktiles) ksplit = ktiles;
+    return ksplit < 1 ? 1 : ksplit;
+}
 
 template <int EPI, bool PRO>
 inline void gemv_launch(GemvArgs p, int ksplit, hipStream_t s) {
     const int ktiles = p.K / 64;
-    if (ksplit < 1) ksplit = 1;
-    if (ksplit > ktiles) ksplit = ktiles;
+    ksplit = gemv_ksplit(p.K, ksplit);                            // (PRO: the panel is the whole normalised row, K = H <= 1024)
     p.k_tiles_per_split = (ktiles + ksplit - 1) / ksplit;
     const int nsplit = (ktiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
     if constexpr (EPI == EPI_ARGMAX) p.part_stride = p.N / 16;
-    NTTS_LAUNCH((gemv_kernel<EPI, PRO>), dim3((p.N + 63) / 64, nsplit), dim3(256), s, p);
+    const dim3 grid((p.N + 63) / 64, nsplit), block(512);
+    const int kps = p.k_tiles_per_split;
+    if constexpr (EPI == EPI_SPLITK) {                            // the split-K GEMVs come in every slice length
+        if (kps <= 2) { NTTS_LAUNCH((gemv_kernel<EPI, PRO, 2>), grid, block, s, p); return; }
+        if (kps <= 4) { NTTS_LAUNCH((gemv_kernel<EPI, PRO, 4>), grid, block, s, p); return; }
+        if (kps <= 8) { NTTS_LAUNCH((gemv_kernel<EPI, PRO, 8>), grid, block, s, p); return; }
+    }
+    NTTS_LAUNCH((gemv_kernel<EPI, PRO, 16>), grid, block, s, p);
 }
+
+// number of split-K slabs gemv_launch produces for (K, ksplit)
+inline int gemv_nsplit(int K, int ksplit) { return gemm_nsplit(K, gemv_ksplit(K, ksplit)); }
 
 }  // namespace ntts

@@ -38,7 +38,10 @@ struct NormArgs {
 // duplicates of a ragged last block keep every lane alive for the shuffles), `write_resid` = store the new residual row.
 // `dst` != nullptr: the normalised row goes there (H contiguous bf16, e.g. an LDS panel: gemv.h's fused prologue) instead of
 // p.normed_out.  This is THE arithmetic (and its order) of the residual add + RMSNorm on the path; every caller shares it.
-template <int NCH>  // 16-byte chunks per lane: H <= 512*NCH
+// SG = slabs whose loads are in flight together (the additions always run in ascending slab order): 4 in the stand-alone
+// kernels (register budget of 4 rows per workgroup), 16 = all of them for gemv.h's helper waves, whose whole job is this
+// row and for whom every extra group is one more L2 round trip on the kernel's critical path.
+template <int NCH, int SG = 4>  // NCH = 16-byte chunks per lane: H <= 512*NCH
 NTTS_D void rmsnorm_row_wave(const NormArgs& p, int r, bool rok, bool write_resid, bf16_t* dst) {
     const int lane = lane_id();
     const long ri = p.in_rows ? p.in_rows[r] : r;
@@ -46,6 +49,15 @@ NTTS_D void rmsnorm_row_wave(const NormArgs& p, int r, bool rok, bool write_resi
     const int nchunk = p.H >> 3;
     float v[NCH][8];
     float ss = 0.f;
+    // every operand that does not depend on the slabs is requested first (clamped addresses, no branches): the residual
+    // chunk and the norm weight would otherwise each cost one more round trip AFTER the slab sums
+    bf16x8 rin[NCH], wv[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const long cc = (lane + 64 * i < nchunk) ? (long)(lane + 64 * i) * 8 : 0;
+        if (p.resid_in) rin[i] = ld16<bf16x8>(p.resid_in + ri * p.H + cc);
+        if (p.norm_w) wv[i] = ld16<bf16x8>(p.norm_w + cc);
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int ci = lane + 64 * i;
@@ -57,17 +69,17 @@ NTTS_D void rmsnorm_row_wave(const NormArgs& p, int r, bool rok, bool write_resi
         if (ok) {
             if (p.slabs) {
                 // slabs summed in ascending order; loads issued four slabs at a time so they overlap
-                for (int s0 = 0; s0 < p.nslab; s0 += 4) {
-                    f32x4 a[4], b[4];
+                for (int s0 = 0; s0 < p.nslab; s0 += SG) {
+                    f32x4 a[SG], b[SG];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
+                    for (int u = 0; u < SG; ++u)
                         if (s0 + u < p.nslab) {
                             const float* sp = p.slabs + ((long)(s0 + u) * p.slab_rows + ri) * p.H + col;
                             a[u] = ld16<f32x4>(sp);
                             b[u] = ld16<f32x4>(sp + 4);
                         }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
+                    for (int u = 0; u < SG; ++u)
                         if (s0 + u < p.nslab) {
 #pragma unroll
                             for (int e = 0; e < 4; ++e) { o[e] += a[u][e]; o[4 + e] += b[u][e]; }
@@ -83,7 +95,7 @@ NTTS_D void rmsnorm_row_wave(const NormArgs& p, int r, bool rok, bool write_resi
                 for (int e = 0; e < 8; ++e) o[e] = bf2f((bf16_t)t[e]);
             }
             if (p.resid_in) {
-                const bf16x8 t = ld16<bf16x8>(p.resid_in + ri * p.H + col);
+                const bf16x8 t = rin[i];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = rbf(bf2f((bf16_t)t[e]) + o[e]);
             }
@@ -101,12 +113,6 @@ NTTS_D void rmsnorm_row_wave(const NormArgs& p, int r, bool rok, bool write_resi
         }
     }
     if (!p.norm_w) return;  // wave-uniform
-    bf16x8 wv[NCH];         // issued before the cross-lane reduction so their latency hides under it
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int ci = lane + 64 * i;
-        wv[i] = ld16<bf16x8>(p.norm_w + (ci < nchunk ? (long)ci * 8 : 0));
-    }
 #pragma unroll
     for (int sh = 1; sh < 64; sh <<= 1) ss += shfl_xor(ss, sh);
     const float inv = frsqrt_exact(ss / (float)p.H + p.eps);
@@ -149,7 +155,12 @@ NTTS_KERNEL(128) void add_rmsnorm_row_kernel(NormArgs p) {
     float o[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = 0.f;
-    bf16x8 wv = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 wv = {0, 0, 0, 0, 0, 0, 0, 0}, rin = {0, 0, 0, 0, 0, 0, 0, 0};
+    {   // operands that do not depend on the slabs: requested first (clamped address, no branch), see rmsnorm_row_wave
+        const long cc = ok ? col : 0;
+        if (p.resid_in) rin = ld16<bf16x8>(p.resid_in + ri * p.H + cc);
+        if (p.norm_w) wv = ld16<bf16x8>(p.norm_w + cc);
+    }
     if (ok) {
         if (p.slabs) {
             for (int s0 = 0; s0 < p.nslab; s0 += 4) {
@@ -177,11 +188,9 @@ NTTS_KERNEL(128) void add_rmsnorm_row_kernel(NormArgs p) {
             for (int e = 0; e < 8; ++e) o[e] = bf2f((bf16_t)t[e]);
         }
         if (p.resid_in) {
-            const bf16x8 t = ld16<bf16x8>(p.resid_in + ri * p.H + col);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = rbf(bf2f((bf16_t)t[e]) + o[e]);
+            for (int e = 0; e < 8; ++e) o[e] = rbf(bf2f((bf16_t)rin[e]) + o[e]);
         }
-        if (p.norm_w) wv = ld16<bf16x8>(p.norm_w + col);
         if (p.resid_out) {
             bf16x8 t;
 #pragma unroll

@@ -21,7 +21,7 @@ def main():
     w = br.make_weights(cfg, 0)
     wd = {k: v.to(torch.bfloat16).cuda() for k, v in w.items()}
     del w
-    B, S = 256, 500
+    B, S = int(os.environ.get("TL_BATCH", "256")), 500
     eng = _hip.BackboneEngine(dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
                                    intermediate_size=cfg.intermediate_size, num_layers=cfg.num_layers,
                                    num_heads=cfg.num_heads, num_kv_heads=cfg.num_kv_heads, rms_eps=cfg.rms_eps,
@@ -30,7 +30,8 @@ def main():
     samp = _hip.Sampling(max_length=S + 250, min_new_tokens=250, eos_token_id=cfg.vocab_size - 1, do_sample=False)
     prompts = [br.synthetic_prompt(cfg, i, S) for i in range(B)]
     for c in range(0, B, 64):
-        eng.prefill(prompts[c:c + 64], list(range(c, c + 64)), [samp] * 64)
+        n = min(64, B - c)
+        eng.prefill(prompts[c:c + n], list(range(c, c + n)), [samp] * n)
     eng.decode(125)
     eng.sync()
     for rep in range(3):
