@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NTTS_ABI_VERSION 1
+#define NTTS_ABI_VERSION 2
 
 enum {
     NTTS_OK = 0,
@@ -67,7 +67,15 @@ typedef struct ntts_backbone_config {
     int32_t max_batch;          /* number of decode slots (rows of the decode step) */
     int32_t num_pages;          /* KV pool size in pages of NTTS_PAGE_TOKENS tokens; 0 = max_batch * max_context / page */
     int32_t max_prefill_tokens; /* workspace rows for one packed prefill call; 0 = 16384 */
+    /* ABI 2: architecture / precision switches of the decoder family the reference's AutoModelForCausalLM dispatch covers
+     * (ref:neutts/neutts.py:164: NeuTTS-Air = Qwen2; NeuTTS-Nano ships under the same class surface). */
+    int32_t tie_word_embeddings; /* 1: lm_head = embedding (Qwen2.5-0.5B / NeuTTS-Air); 0: a separate "lm_head.weight" must be loaded */
+    int32_t attention_bias;      /* 1: q/k/v_proj carry a bias (Qwen2); 0: none (Llama-style) */
+    int32_t qk_norm;             /* must be 0 (Qwen3-style per-head q/k RMSNorm is not implemented: create fails) */
+    int32_t weight_dtype;        /* NTTS_W_BF16 | NTTS_W_FP8_E4M3: fp8 weights with per-output-channel scales, fp8 GEMM inputs with
+                                    static per-tensor scales ("*.input_scale" tensors), bf16 residual stream / KV / attention */
 } ntts_backbone_config;
+enum { NTTS_W_BF16 = 0, NTTS_W_FP8_E4M3 = 1 };
 
 #define NTTS_PAGE_TOKENS 32
 
@@ -78,9 +86,14 @@ int ntts_backbone_create(const ntts_backbone_config* cfg, int device, ntts_backb
 void ntts_backbone_destroy(ntts_backbone* e);
 
 /* Weight upload.  `name` is the HF state-dict key of Qwen2ForCausalLM ("model.embed_tokens.weight",
- * "model.layers.{i}.self_attn.q_proj.weight|bias", ..., "model.norm.weight"; "lm_head.weight" is
- * accepted and must alias the embedding) plus "rope.inv_freq" (fp32 [head_dim/2], the buffer
- * hf:models/qwen2/modeling_qwen2.py:86 computes).  `data` may be a host or a device pointer
+ * "model.layers.{i}.self_attn.q_proj.weight|bias", ..., "model.norm.weight"; "lm_head.weight": with tie_word_embeddings
+ * it must hold the embedding's values -- anything else is NTTS_EINVAL, never silently dropped -- without, it is the
+ * separate head matrix) plus "rope.inv_freq" (fp32 [head_dim/2], the buffer hf:models/qwen2/modeling_qwen2.py:86 computes).
+ * NTTS_W_FP8_E4M3: the matrices are quantised on upload (per output channel: scale = max|w| / 448, w_q = e4m3(w / scale)) and
+ * the static activation scales of the four GEMM inputs of a layer and of the head are loaded as fp32 scalars named
+ * "model.layers.{i}.self_attn.q_proj.input_scale" (= k_proj / v_proj), "...self_attn.o_proj.input_scale",
+ * "...mlp.gate_proj.input_scale" (= up_proj), "...mlp.down_proj.input_scale", "lm_head.input_scale" (the naming of
+ * static-fp8 checkpoints).  `data` may be a host or a device pointer
  * (is_device); dtype NTTS_DT_F32 or NTTS_DT_BF16 (fp32 is rounded to bf16 RNE, like `.to(bfloat16)`).
  * The tensor is copied into the engine's packed arena (fused QKV rows, gate/up interleaved in 16-row
  * groups) -- the caller's buffer can be freed on return.  Blocking. */

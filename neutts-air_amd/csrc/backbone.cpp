@@ -28,6 +28,10 @@ static std::string g_create_err;
 
 struct LayerW {
     bf16_t *ln1, *wqkv, *bqkv, *wo, *ln2, *wgu, *wd;
+    // fp8 model (NTTS_W_FP8_E4M3): the four matrices hold e4m3 bytes; per-output-channel weight scales (device fp32, in the
+    // arena) and the static input scales of the four GEMMs (device copy in the arena for the broadcast, host copy for launches)
+    float *sqkv = nullptr, *so = nullptr, *sgu = nullptr, *sd = nullptr, *xs_dev = nullptr;
+    float xs[4] = {1.f, 1.f, 1.f, 1.f};   // input scale of: 0 qkv, 1 o_proj, 2 gate/up, 3 down
 };
 
 struct HostSlot {
@@ -50,8 +54,15 @@ struct ntts_backbone {
     bf16_t* arena = nullptr;
     size_t arena_elems = 0;
     bf16_t *embed = nullptr, *final_norm = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
-    bf16_t* embed_tm = nullptr;   // tile-major copy of the tied embedding = the lm_head's weight stream (w_tile_major)
+    bf16_t* embed_tm = nullptr;   // the lm_head's weight stream: tile-major copy of the tied embedding (w_tile_major), the untied
+                                  // "lm_head.weight", or (fp8) the e4m3 bytes of either; null = the head reads `embed` directly
     bool w_tile_major = true;     // GEMM weights stored tile-major (gemm.h GemmArgs::w_tile_major)
+    bool fp8 = false, tied = true, has_bias = true;
+    float* shead = nullptr;       // fp8: per-vocab-row scales of the head matrix
+    float* xs_head_dev = nullptr;
+    float xs_head = 1.f;          // fp8: input scale of the lm_head
+    bool head_from_embed = false, head_loaded = false;
+    std::set<std::string> needed; // tensor names finalize() insists on
     std::vector<LayerW> layers;
     std::set<std::string> loaded;
     float inv_freq[64];
@@ -162,6 +173,10 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
         return fail(nullptr, NTTS_EINVAL, "hidden/intermediate size must be multiples of 64 (hidden <= 2048)");
     if (c->max_context > kAttnLMax || c->max_context % kPage) return fail(nullptr, NTTS_EINVAL, "max_context must be <= %d and a multiple of %d", kAttnLMax, kPage);
     if (c->max_batch < 1 || c->vocab_size < 2) return fail(nullptr, NTTS_EINVAL, "bad max_batch / vocab_size");
+    if (c->qk_norm) return fail(nullptr, NTTS_EINVAL, "qk_norm (Qwen3-style per-head q/k RMSNorm) is not implemented");
+    if (c->weight_dtype != NTTS_W_BF16 && c->weight_dtype != NTTS_W_FP8_E4M3) return fail(nullptr, NTTS_EINVAL, "unknown weight_dtype %d", c->weight_dtype);
+    if (c->weight_dtype == NTTS_W_FP8_E4M3 && (c->hidden_size % 128 || c->intermediate_size % 128 || (c->num_heads * 64) % 128))
+        return fail(nullptr, NTTS_EINVAL, "fp8 weights need hidden / intermediate / q width to be multiples of 128 (one 128-byte K tile)");
 
     ntts_backbone* e = new ntts_backbone();
     e->cfg = *c;
@@ -173,6 +188,9 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->Tmax = c->max_prefill_tokens > 0 ? c->max_prefill_tokens : 16384;
     e->num_pages = c->num_pages > 0 ? c->num_pages : c->max_batch * e->max_pages;
     e->use_graph = env_int("NTTS_NO_GRAPH", 0) == 0;
+    e->fp8 = c->weight_dtype == NTTS_W_FP8_E4M3;
+    e->tied = c->tie_word_embeddings != 0;
+    e->has_bias = c->attention_bias != 0;
     const int B = c->max_batch, H = e->H, F = e->F, L = c->num_layers, V = c->vocab_size;
 
 #define CR_HIP(call)                                                                          \
@@ -196,25 +214,53 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     // Weight layout: tile-major by default (each workgroup's weight stream is one sequential run of HBM addresses:
     // lm_head -8 %, gate/up -3 % on the micro-benchmark, profiles/r01e_ubench_weight_layout.txt).  The embedding gather
     // needs rows, the lm_head tiles: the tied matrix is kept in both layouts.  The X-panel path reads W rows directly.
-    e->w_tile_major = env_int("NTTS_W_TILE_MAJOR", 1) != 0 && H % 64 == 0 && F % 64 == 0;
-    const size_t o_embed_tm = e->w_tile_major ? take((size_t)((V + 63) / 64) * 64 * H) : 0;
-    struct LO { size_t ln1, wqkv, bqkv, wo, ln2, wgu, wd; };
+    e->w_tile_major = (env_int("NTTS_W_TILE_MAJOR", 1) != 0 || e->fp8) && H % 64 == 0 && F % 64 == 0;
+    // sizes in bf16 elements: a matrix of n weights takes n (bf16) or n / 2 (fp8 bytes); fp32 arrays take 2 per value
+    auto take_w = [&](size_t n) { return take(e->fp8 ? (n + 1) / 2 : n); };
+    auto take_f = [&](size_t n) { return take(2 * n); };
+    const bool own_head = e->w_tile_major || !e->tied || e->fp8;   // the head has its own copy (layout / values / precision differ)
+    const size_t o_embed_tm = own_head ? take_w((size_t)((V + 63) / 64) * 64 * H) : 0;
+    const size_t o_shead = e->fp8 ? take_f((size_t)((V + 63) / 64) * 64) : 0, o_xs_head = e->fp8 ? take_f(4) : 0;
+    struct LO { size_t ln1, wqkv, bqkv, wo, ln2, wgu, wd, sqkv, so, sgu, sd, xs; };
     std::vector<LO> lo(L);
     for (int i = 0; i < L; ++i) {
-        lo[i].ln1 = take(H); lo[i].wqkv = take((size_t)e->NQKV * H); lo[i].bqkv = take(e->NQKV);
-        lo[i].wo = take((size_t)H * c->num_heads * 64); lo[i].ln2 = take(H);
-        lo[i].wgu = take((size_t)2 * F * H); lo[i].wd = take((size_t)H * F);
+        lo[i].ln1 = take(H); lo[i].wqkv = take_w((size_t)e->NQKV * H); lo[i].bqkv = take(e->NQKV);
+        lo[i].wo = take_w((size_t)H * c->num_heads * 64); lo[i].ln2 = take(H);
+        lo[i].wgu = take_w((size_t)2 * F * H); lo[i].wd = take_w((size_t)H * F);
+        if (e->fp8) { lo[i].sqkv = take_f(e->NQKV); lo[i].so = take_f(H); lo[i].sgu = take_f(2 * (size_t)F); lo[i].sd = take_f(H); lo[i].xs = take_f(4); }
     }
     const size_t o_fn = take(H), o_cos = take((size_t)c->max_context * 32), o_sin = take((size_t)c->max_context * 32);
     e->arena_elems = off;
     CR_HIP(hipMalloc((void**)&e->arena, off * sizeof(bf16_t)));
     CR_HIP(hipMemset(e->arena, 0, off * sizeof(bf16_t)));
     e->embed = e->arena + o_embed;
-    e->embed_tm = e->w_tile_major ? e->arena + o_embed_tm : nullptr;
+    e->embed_tm = own_head ? e->arena + o_embed_tm : nullptr;
+    if (e->fp8) { e->shead = (float*)(e->arena + o_shead); e->xs_head_dev = (float*)(e->arena + o_xs_head); }
     e->layers.resize(L);
-    for (int i = 0; i < L; ++i)
-        e->layers[i] = LayerW{e->arena + lo[i].ln1, e->arena + lo[i].wqkv, e->arena + lo[i].bqkv, e->arena + lo[i].wo,
-                              e->arena + lo[i].ln2, e->arena + lo[i].wgu, e->arena + lo[i].wd};
+    for (int i = 0; i < L; ++i) {
+        LayerW& w = e->layers[i];
+        w.ln1 = e->arena + lo[i].ln1; w.wqkv = e->arena + lo[i].wqkv; w.bqkv = e->arena + lo[i].bqkv; w.wo = e->arena + lo[i].wo;
+        w.ln2 = e->arena + lo[i].ln2; w.wgu = e->arena + lo[i].wgu; w.wd = e->arena + lo[i].wd;
+        if (e->fp8) {
+            w.sqkv = (float*)(e->arena + lo[i].sqkv); w.so = (float*)(e->arena + lo[i].so); w.sgu = (float*)(e->arena + lo[i].sgu);
+            w.sd = (float*)(e->arena + lo[i].sd); w.xs_dev = (float*)(e->arena + lo[i].xs);
+        }
+    }
+    // what finalize() will insist on
+    e->needed = {"model.embed_tokens.weight", "model.norm.weight", "rope.inv_freq"};
+    if (!e->tied) e->needed.insert("lm_head.weight");
+    if (e->fp8) e->needed.insert("lm_head.input_scale");
+    for (int i = 0; i < L; ++i) {
+        const std::string pre = "model.layers." + std::to_string(i) + ".";
+        for (const char* t : {"input_layernorm.weight", "post_attention_layernorm.weight", "self_attn.q_proj.weight", "self_attn.k_proj.weight",
+                              "self_attn.v_proj.weight", "self_attn.o_proj.weight", "mlp.gate_proj.weight", "mlp.up_proj.weight", "mlp.down_proj.weight"})
+            e->needed.insert(pre + t);
+        if (e->has_bias)
+            for (const char* t : {"self_attn.q_proj.bias", "self_attn.k_proj.bias", "self_attn.v_proj.bias"}) e->needed.insert(pre + t);
+        if (e->fp8)
+            for (const char* t : {"self_attn.q_proj.input_scale", "self_attn.o_proj.input_scale", "mlp.gate_proj.input_scale", "mlp.down_proj.input_scale"})
+                e->needed.insert(pre + t);
+    }
     e->final_norm = e->arena + o_fn;
     e->rope_cos = e->arena + o_cos;
     e->rope_sin = e->arena + o_sin;
@@ -271,8 +317,9 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     // prologue measured -3.4 us on the GEMM, +1.7 us on the attention kernel, -1.8 % per step (profiles/r01e_sweep_qkv_split.jsonl)
     e->ks_qkv = env_int("NTTS_KSPLIT_QKV", 2);
     if (e->ks_qkv > kAttnMaxSlabs) e->ks_qkv = kAttnMaxSlabs;
-    e->ks_o = env_int("NTTS_KSPLIT_O", pick_split(H / 64, c->num_heads * 64 / 64));
-    e->ks_d = env_int("NTTS_KSPLIT_D", pick_split(H / 64, F / 64));
+    const int ktile = e->fp8 ? 128 : 64;   // K extent of one 128-byte tile
+    e->ks_o = env_int("NTTS_KSPLIT_O", pick_split(H / 64, c->num_heads * 64 / ktile));
+    e->ks_d = env_int("NTTS_KSPLIT_D", pick_split(H / 64, F / ktile));
     const int s_all = env_int("NTTS_S_STAGES", 0);
     e->st_qkv = env_int("NTTS_STAGES_QKV", s_all ? s_all : 4);
     e->st_o = env_int("NTTS_STAGES_O", s_all ? s_all : 4);
@@ -298,7 +345,8 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     if (e->ks_o > max_slabs) e->ks_o = max_slabs;
     if (e->ks_d > max_slabs) e->ks_d = max_slabs;
 
-    e->small = B <= env_int("NTTS_SMALL_BATCH", 8) && B <= kGemvRows && H <= 1024 && V % 16 == 0 && e->NQKV % 16 == 0 && F % 32 == 0;
+    e->small = B <= env_int("NTTS_SMALL_BATCH", 8) && B <= kGemvRows && H <= 1024 && V % 16 == 0 && e->NQKV % 16 == 0 && F % 32 == 0 &&
+               !e->fp8;   // (the small-batch GEMV kernels are bf16 only: the fp8 model takes the tile kernels at every batch)
     e->sks_q = env_int("NTTS_SKS_Q", 4);
     if (e->sks_q > kAttnMaxSlabs) e->sks_q = kAttnMaxSlabs;
     e->sks_o = env_int("NTTS_SKS_O", 7);
@@ -380,7 +428,7 @@ static int put_rows(ntts_backbone* e, const void* data, int dtype, int is_device
 
 // a GEMM weight: rows [row0, row0 + rows) of the packed matrix `dst` ([*, cols]), in the engine's weight layout
 static int put_weight(ntts_backbone* e, const void* data, int dtype, int is_device, long rows, long cols, bf16_t* dst, long row0,
-                      const int* dst_rows, int tile_major) {
+                      const int* dst_rows, int tile_major, float* wscale = nullptr) {
     const size_t esz = dtype == NTTS_DT_F32 ? 4 : 2;
     const void* src = data;
     DevScratch tmp;
@@ -389,8 +437,12 @@ static int put_weight(ntts_backbone* e, const void* data, int dtype, int is_devi
         HIPCHK(e, hipMemcpy(tmp.p, data, (size_t)rows * cols * esz, hipMemcpyHostToDevice));
         src = tmp.p;
     }
-    NTTS_LAUNCH((pack_weight_kernel), dim3((unsigned)rows), dim3(256), e->stream, src, dtype == NTTS_DT_F32 ? 1 : 0, dst, dst_rows, row0,
-                cols, tile_major);
+    if (wscale)   // fp8 model: quantise per output channel on the way in
+        NTTS_LAUNCH((pack_weight_fp8_kernel), dim3((unsigned)rows), dim3(256), e->stream, src, dtype == NTTS_DT_F32 ? 1 : 0, (unsigned char*)dst,
+                    wscale, dst_rows, row0, cols);
+    else
+        NTTS_LAUNCH((pack_weight_kernel), dim3((unsigned)rows), dim3(256), e->stream, src, dtype == NTTS_DT_F32 ? 1 : 0, dst, dst_rows, row0,
+                    cols, tile_major);
     HIPCHK(e, hipStreamSynchronize(e->stream));
     return NTTS_OK;
 }
@@ -415,15 +467,109 @@ extern "C" int ntts_backbone_load_tensor(ntts_backbone* e, const char* name, con
         e->loaded.insert(n);
         return NTTS_OK;
     }
+    // ---- fp8 model: static input scales (fp32 scalars, naming of static-fp8 checkpoints); k_proj / v_proj / up_proj repeat
+    //      the scale of the fused GEMM they belong to and must agree with it
+    if (n.size() > 12 && n.compare(n.size() - 12, 12, ".input_scale") == 0) {
+        if (!e->fp8) return fail(e, NTTS_EINVAL, "tensor '%s': input scales belong to the fp8 model (weight_dtype = NTTS_W_FP8_E4M3)", name);
+        long cnt = 1;
+        for (int d = 0; d < ndim; ++d) cnt *= shape[d];
+        if (dtype != NTTS_DT_F32 || cnt != 1) return fail(e, NTTS_EINVAL, "tensor '%s' must be one fp32 value", name);
+        float v = 0.f;
+        if (is_device) HIPCHK(e, hipMemcpy(&v, data, 4, hipMemcpyDeviceToHost));
+        else memcpy(&v, data, 4);
+        if (!(v > 0.f) || !(v < 3.0e38f)) return fail(e, NTTS_EINVAL, "tensor '%s': scale must be positive and finite", name);
+        float* slot = nullptr;
+        std::string canon = n;
+        if (n == "lm_head.input_scale") slot = &e->xs_head;
+        else if (n.rfind("model.layers.", 0) == 0) {
+            char* endp = nullptr;
+            const long li = strtol(name + 13, &endp, 10);
+            if (endp == name + 13 || *endp != '.' || li < 0 || li >= e->cfg.num_layers) return fail(e, NTTS_EINVAL, "tensor '%s': bad layer index", name);
+            const std::string t(endp + 1), pre = "model.layers." + std::to_string(li) + ".";
+            LayerW& w = e->layers[li];
+            if (t == "self_attn.q_proj.input_scale" || t == "self_attn.k_proj.input_scale" || t == "self_attn.v_proj.input_scale") { slot = &w.xs[0]; canon = pre + "self_attn.q_proj.input_scale"; }
+            else if (t == "self_attn.o_proj.input_scale") slot = &w.xs[1];
+            else if (t == "mlp.gate_proj.input_scale" || t == "mlp.up_proj.input_scale") { slot = &w.xs[2]; canon = pre + "mlp.gate_proj.input_scale"; }
+            else if (t == "mlp.down_proj.input_scale") slot = &w.xs[3];
+        }
+        if (!slot) return fail(e, NTTS_EINVAL, "unknown tensor '%s'", name);
+        if (e->loaded.count(canon) && *slot != v)
+            return fail(e, NTTS_EINVAL, "tensor '%s' = %g disagrees with the scale already loaded for the same fused GEMM input (%g)", name, v, *slot);
+        *slot = v;
+        e->loaded.insert(canon);
+        return NTTS_OK;
+    }
     if (dtype != NTTS_DT_F32 && dtype != NTTS_DT_BF16) return fail(e, NTTS_EINVAL, "tensor '%s': dtype must be f32 or bf16", name);
     int rc = NTTS_EINVAL;
-    if (n == "model.embed_tokens.weight" || n == "lm_head.weight") {
+    const int tm = e->w_tile_major ? 1 : 0;
+    if (n == "model.embed_tokens.weight") {
         if (!want(c.vocab_size, H)) return bad_shape();
-        if (n == "lm_head.weight" && e->loaded.count("model.embed_tokens.weight")) return NTTS_OK;  // tied: same bytes
+        if (e->head_from_embed) {   // a tied "lm_head.weight" arrived first and was taken as the embedding: the two must agree
+            DevScratch cnt, tmp;
+            const void* src = data;
+            const size_t esz = dtype == NTTS_DT_F32 ? 4 : 2;
+            if (!is_device) {
+                HIPCHK(e, hipMalloc(&tmp.p, (size_t)c.vocab_size * H * esz));
+                HIPCHK(e, hipMemcpy(tmp.p, data, (size_t)c.vocab_size * H * esz, hipMemcpyHostToDevice));
+                src = tmp.p;
+            }
+            HIPCHK(e, hipMalloc(&cnt.p, 4));
+            unsigned int* cntp = (unsigned int*)cnt.p;     // (a plain pointer for the launch: the emulator's launch captures by value)
+            const bf16_t* refp = e->embed;
+            HIPCHK(e, hipMemsetAsync(cntp, 0, 4, e->stream));
+            NTTS_LAUNCH((rows_mismatch_kernel), dim3((unsigned)c.vocab_size), dim3(256), e->stream, src, dtype == NTTS_DT_F32 ? 1 : 0,
+                        refp, (long)H, cntp);
+            unsigned int bad = 0;
+            HIPCHK(e, hipMemcpyAsync(&bad, cntp, 4, hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(e, hipStreamSynchronize(e->stream));
+            if (bad) return fail(e, NTTS_EINVAL, "tie_word_embeddings is set but 'lm_head.weight' differs from 'model.embed_tokens.weight' in %u values: "
+                                                 "create the engine with tie_word_embeddings = 0 for an untied head", bad);
+            e->loaded.insert(n);
+            return NTTS_OK;
+        }
         rc = put_rows(e, data, dtype, is_device, c.vocab_size, H, e->embed, nullptr);
-        if (rc == NTTS_OK && e->w_tile_major) rc = put_weight(e, data, dtype, is_device, c.vocab_size, H, e->embed_tm, 0, nullptr, 1);
-        if (rc == NTTS_OK) e->loaded.insert("model.embed_tokens.weight");
+        if (rc == NTTS_OK && e->tied && e->embed_tm)   // the tied head's own copy (tile-major and / or fp8)
+            rc = put_weight(e, data, dtype, is_device, c.vocab_size, H, e->embed_tm, 0, nullptr, tm, e->fp8 ? e->shead : nullptr);
+        if (rc == NTTS_OK) e->loaded.insert(n);
         return rc;
+    }
+    if (n == "lm_head.weight") {
+        if (!want(c.vocab_size, H)) return bad_shape();
+        if (!e->tied) {             // a separate head matrix
+            rc = put_weight(e, data, dtype, is_device, c.vocab_size, H, e->embed_tm, 0, nullptr, tm, e->fp8 ? e->shead : nullptr);
+            if (rc == NTTS_OK) e->loaded.insert(n);
+            return rc;
+        }
+        // tied: the tensor may be present in a checkpoint (safetensors of some exporters keep both names) but it must BE the embedding
+        if (!e->loaded.count("model.embed_tokens.weight")) {
+            rc = put_rows(e, data, dtype, is_device, c.vocab_size, H, e->embed, nullptr);
+            if (rc == NTTS_OK && e->embed_tm) rc = put_weight(e, data, dtype, is_device, c.vocab_size, H, e->embed_tm, 0, nullptr, tm, e->fp8 ? e->shead : nullptr);
+            if (rc == NTTS_OK) { e->head_from_embed = true; e->loaded.insert("lm_head.weight"); }
+            return rc;
+        }
+        {
+            DevScratch cnt, tmp;
+            const void* src = data;
+            const size_t esz = dtype == NTTS_DT_F32 ? 4 : 2;
+            if (!is_device) {
+                HIPCHK(e, hipMalloc(&tmp.p, (size_t)c.vocab_size * H * esz));
+                HIPCHK(e, hipMemcpy(tmp.p, data, (size_t)c.vocab_size * H * esz, hipMemcpyHostToDevice));
+                src = tmp.p;
+            }
+            HIPCHK(e, hipMalloc(&cnt.p, 4));
+            unsigned int* cntp = (unsigned int*)cnt.p;     // (a plain pointer for the launch: the emulator's launch captures by value)
+            const bf16_t* refp = e->embed;
+            HIPCHK(e, hipMemsetAsync(cntp, 0, 4, e->stream));
+            NTTS_LAUNCH((rows_mismatch_kernel), dim3((unsigned)c.vocab_size), dim3(256), e->stream, src, dtype == NTTS_DT_F32 ? 1 : 0,
+                        refp, (long)H, cntp);
+            unsigned int bad = 0;
+            HIPCHK(e, hipMemcpyAsync(&bad, cntp, 4, hipMemcpyDeviceToHost, e->stream));
+            HIPCHK(e, hipStreamSynchronize(e->stream));
+            if (bad) return fail(e, NTTS_EINVAL, "tie_word_embeddings is set but 'lm_head.weight' differs from 'model.embed_tokens.weight' in %u values: "
+                                                 "create the engine with tie_word_embeddings = 0 for an untied head", bad);
+        }
+        e->loaded.insert("lm_head.weight");
+        return NTTS_OK;
     }
     if (n == "model.norm.weight") {
         if (!want(H, 0)) return bad_shape();
@@ -437,16 +583,19 @@ extern "C" int ntts_backbone_load_tensor(ntts_backbone* e, const char* name, con
         LayerW& w = e->layers[li];
         if (t == "input_layernorm.weight") { if (!want(H, 0)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, 1, H, w.ln1, nullptr); }
         else if (t == "post_attention_layernorm.weight") { if (!want(H, 0)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, 1, H, w.ln2, nullptr); }
-        else if (t == "self_attn.q_proj.weight") { if (!want(QD, H)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, QD, H, w.wqkv, 0, nullptr, e->w_tile_major ? 1 : 0); }
-        else if (t == "self_attn.k_proj.weight") { if (!want(KD, H)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, KD, H, w.wqkv, QD, nullptr, e->w_tile_major ? 1 : 0); }
-        else if (t == "self_attn.v_proj.weight") { if (!want(KD, H)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, KD, H, w.wqkv, QD + KD, nullptr, e->w_tile_major ? 1 : 0); }
-        else if (t == "self_attn.q_proj.bias") { if (!want(QD, 0)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, 1, QD, w.bqkv, nullptr); }
-        else if (t == "self_attn.k_proj.bias") { if (!want(KD, 0)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, 1, KD, w.bqkv + QD, nullptr); }
-        else if (t == "self_attn.v_proj.bias") { if (!want(KD, 0)) return bad_shape(); rc = put_rows(e, data, dtype, is_device, 1, KD, w.bqkv + QD + KD, nullptr); }
-        else if (t == "self_attn.o_proj.weight") { if (!want(H, QD)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, H, QD, w.wo, 0, nullptr, e->w_tile_major ? 1 : 0); }
-        else if (t == "mlp.gate_proj.weight") { if (!want(F, H)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, F, H, w.wgu, 0, e->gu_map_gate, e->w_tile_major ? 1 : 0); }
-        else if (t == "mlp.up_proj.weight") { if (!want(F, H)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, F, H, w.wgu, 0, e->gu_map_up, e->w_tile_major ? 1 : 0); }
-        else if (t == "mlp.down_proj.weight") { if (!want(H, F)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, H, F, w.wd, 0, nullptr, e->w_tile_major ? 1 : 0); }
+        else if (t == "self_attn.q_proj.weight") { if (!want(QD, H)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, QD, H, w.wqkv, 0, nullptr, tm, w.sqkv); }
+        else if (t == "self_attn.k_proj.weight") { if (!want(KD, H)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, KD, H, w.wqkv, QD, nullptr, tm, w.sqkv); }
+        else if (t == "self_attn.v_proj.weight") { if (!want(KD, H)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, KD, H, w.wqkv, QD + KD, nullptr, tm, w.sqkv); }
+        else if (t == "self_attn.q_proj.bias" || t == "self_attn.k_proj.bias" || t == "self_attn.v_proj.bias") {
+            if (!e->has_bias) return fail(e, NTTS_EINVAL, "tensor '%s': the engine was created with attention_bias = 0", name);
+            const long rows_n = t[10] == 'q' ? QD : KD, at = t[10] == 'q' ? 0 : (t[10] == 'k' ? QD : QD + KD);
+            if (!want(rows_n, 0)) return bad_shape();
+            rc = put_rows(e, data, dtype, is_device, 1, rows_n, w.bqkv + at, nullptr);
+        }
+        else if (t == "self_attn.o_proj.weight") { if (!want(H, QD)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, H, QD, w.wo, 0, nullptr, tm, w.so); }
+        else if (t == "mlp.gate_proj.weight") { if (!want(F, H)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, F, H, w.wgu, 0, e->gu_map_gate, tm, w.sgu); }
+        else if (t == "mlp.up_proj.weight") { if (!want(F, H)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, F, H, w.wgu, 0, e->gu_map_up, tm, w.sgu); }
+        else if (t == "mlp.down_proj.weight") { if (!want(H, F)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, H, F, w.wd, 0, nullptr, tm, w.sd); }
         else return fail(e, NTTS_EINVAL, "unknown tensor '%s'", name);
     } else {
         return fail(e, NTTS_EINVAL, "unknown tensor '%s'", name);
@@ -477,13 +626,30 @@ static int build_rope(ntts_backbone* e) {
     return NTTS_OK;
 }
 
+static int sync_input_scales(ntts_backbone* e, bool to_device) {   // fp8: host copies <-> the arena's copies (what the broadcast carries)
+    if (!e->fp8) return NTTS_OK;
+    const hipMemcpyKind k = to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost;
+    for (auto& w : e->layers) {
+        if (to_device) HIPCHK(e, hipMemcpy(w.xs_dev, w.xs, 16, k)); else HIPCHK(e, hipMemcpy(w.xs, w.xs_dev, 16, k));
+    }
+    if (to_device) HIPCHK(e, hipMemcpy(e->xs_head_dev, &e->xs_head, 4, k)); else HIPCHK(e, hipMemcpy(&e->xs_head, e->xs_head_dev, 4, k));
+    return NTTS_OK;
+}
+
 extern "C" int ntts_backbone_finalize(ntts_backbone* e) {
     if (!e) return NTTS_EINVAL;
     HIPCHK(e, hipSetDevice(e->device));
-    const size_t need = 3 + (size_t)e->cfg.num_layers * 12;  // embed, norm, inv_freq + 12 per layer
     if (!e->have_inv_freq) return fail(e, NTTS_ESTATE, "rope.inv_freq not loaded");
-    if (e->loaded.size() != need) return fail(e, NTTS_ESTATE, "%zu of %zu tensors loaded", e->loaded.size(), need);
+    std::string missing;
+    int n_missing = 0;
+    for (const auto& name : e->needed)
+        if (!e->loaded.count(name) && !(name == "model.embed_tokens.weight" && e->head_from_embed)) {
+            if (n_missing++ < 6) missing += (missing.empty() ? "" : ", ") + name;
+        }
+    if (n_missing) return fail(e, NTTS_ESTATE, "%d tensors not loaded: %s%s", n_missing, missing.c_str(), n_missing > 6 ? ", ..." : "");
     int rc = build_rope(e);
+    if (rc) return rc;
+    rc = sync_input_scales(e, true);
     if (rc) return rc;
     e->finalized = true;
     return NTTS_OK;
@@ -505,6 +671,9 @@ extern "C" int ntts_backbone_arena_copy(ntts_backbone* e, void* buf, size_t byte
 }
 extern "C" int ntts_backbone_adopt_arena(ntts_backbone* e) {
     if (!e) return NTTS_EINVAL;
+    HIPCHK(e, hipSetDevice(e->device));
+    const int rc = sync_input_scales(e, false);   // fp8: the launches need the input scales on the host
+    if (rc) return rc;
     e->finalized = true;  // arena (incl. the RoPE table) was filled by a broadcast from a finalised engine
     return NTTS_OK;
 }
@@ -512,17 +681,26 @@ extern "C" int ntts_backbone_adopt_arena(ntts_backbone* e) {
 // ------------------------------------------------------------------------------------------------
 // model passes
 // ------------------------------------------------------------------------------------------------
+// fp8 model: X and W hold e4m3 bytes (ldx / ldw / K still count elements), wscale = the matrix's per-row scales, xscale = the
+// static scale its input was quantised with
 static GemmArgs gemm_args(const ntts_backbone* e, const bf16_t* X, long ldx, const bf16_t* W, long ldw, const bf16_t* bias, void* out,
-                          long ldo, int M, int N, int K) {
+                          long ldo, int M, int N, int K, const float* wscale = nullptr, float xscale = 1.f) {
     GemmArgs a{};
     a.w_tile_major = e->w_tile_major ? 1 : 0;   // every W this engine hands to a GEMM is in its weight layout
     a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K;
+    a.wscale = wscale; a.xscale = xscale;
     return a;
 }
+static int ktile_of(const ntts_backbone* e) { return e->fp8 ? 128 : 64; }
 
 // ---- the decode step's launches, one helper per kernel (shared by decode_step and ntts_backbone_time_kernel)
 template <int EPI>
 static void gemm_skinny(int stages, const GemmArgs& a, int ks, hipStream_t st) {
+    if (a.wscale) {   // fp8 operands
+        if (stages == 3) gemm_launch<4, 1, 1, EPI, 3, 0, 64, false, true>(a, ks, st);
+        else gemm_launch<4, 1, 1, EPI, 4, 0, 64, false, true>(a, ks, st);
+        return;
+    }
     switch (stages) {
         case 2: gemm_launch<4, 1, 1, EPI, 2>(a, ks, st); break;
         case 3: gemm_launch<4, 1, 1, EPI, 3>(a, ks, st); break;
@@ -533,6 +711,11 @@ static void gemm_skinny(int stages, const GemmArgs& a, int ks, hipStream_t st) {
 
 template <int EPI>
 static void gemm_large(ntts_backbone* e, const GemmArgs& a, hipStream_t st) {
+    if (e->fp8) {
+        if (e->use_xl && a.M >= 1024 && a.N >= 256) gemm_launch<4, 4, 4, EPI, 2, 0, 64, false, true>(a, 1, st);
+        else gemm_launch<2, 2, 4, EPI, 2, 0, 64, false, true>(a, 1, st);
+        return;
+    }
     if (e->use_xl && a.M >= 1024 && a.N >= 256) {
         NTTS_GEMM_XL(EPI, a, 1, st);
         return;
@@ -548,16 +731,18 @@ static void ks_lm_head(ntts_backbone* e, bool keep_logits);
 static void k_lm_head(ntts_backbone* e, bool keep_logits) {
     if (e->small) { ks_lm_head(e, keep_logits); return; }
     const int B = e->cfg.max_batch, H = e->H, V = e->cfg.vocab_size;
-    GemmArgs a = gemm_args(e, e->xn_dec, H, e->w_tile_major ? e->embed_tm : e->embed, H, nullptr, nullptr, 0, B, V, H);
+    GemmArgs a = gemm_args(e, e->xn_dec, H, e->embed_tm ? e->embed_tm : e->embed, H, nullptr, nullptr, 0, B, V, H, e->shead, e->xs_head);
     a.part_val = e->part_val; a.part_idx = e->part_idx; a.mask_eos = e->sl.mask_eos;
     a.logits = keep_logits ? e->logits : nullptr; a.ld_logits = V;
     a.logits_bf16 = (keep_logits && e->n_sampling > 0) ? e->logits_bf16 : nullptr; a.ld_logits_bf16 = e->ldl;
     if (!e->head_large) { gemm_skinny<EPI_ARGMAX>(4, a, 1, e->stream); return; }
     if (e->head_xl) {
-        if (e->w_nt & 1) gemm_launch<4, 4, 4, EPI_ARGMAX, 2, 0, 64, true>(a, 1, e->stream);
+        if (e->fp8) gemm_launch<4, 4, 4, EPI_ARGMAX, 2, 0, 64, true, true>(a, 1, e->stream);
+        else if (e->w_nt & 1) gemm_launch<4, 4, 4, EPI_ARGMAX, 2, 0, 64, true>(a, 1, e->stream);
         else NTTS_GEMM_XL(EPI_ARGMAX, a, 1, e->stream);
         return;
     }
+    if (e->fp8) { gemm_launch<2, 2, 4, EPI_ARGMAX, 2, 0, 64, false, true>(a, 1, e->stream); return; }
     switch (e->head_stages) {
         case 3: gemm_launch<2, 2, 4, EPI_ARGMAX, 3>(a, 1, e->stream); break;
         case 4: gemm_launch<2, 2, 4, EPI_ARGMAX, 4>(a, 1, e->stream); break;
@@ -577,9 +762,9 @@ static void k_qkv(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H;
     const LayerW& w = e->layers[i];
     if (e->ks_qkv > 1)   // fp32 split-K slabs; the attention prologue sums them, adds the bias and rounds (attn_decode.h)
-        gemm_skinny<EPI_SPLITK>(e->st_qkv, gemm_args(e, e->xn_dec, H, w.wqkv, H, nullptr, e->slabs, e->NQKV, B, e->NQKV, H), e->ks_qkv, e->stream);
+        gemm_skinny<EPI_SPLITK>(e->st_qkv, gemm_args(e, e->xn_dec, H, w.wqkv, H, nullptr, e->slabs, e->NQKV, B, e->NQKV, H, w.sqkv, w.xs[0]), e->ks_qkv, e->stream);
     else
-        gemm_skinny<EPI_BF16>(e->st_qkv, gemm_args(e, e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H), 1, e->stream);
+        gemm_skinny<EPI_BF16>(e->st_qkv, gemm_args(e, e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H, w.sqkv, w.xs[0]), 1, e->stream);
 }
 
 static void k_attn(ntts_backbone* e, int i) {
@@ -587,23 +772,30 @@ static void k_attn(ntts_backbone* e, int i) {
     AttnDecodeArgs a{};
     a.qkv = e->qkv_dec; a.ld_qkv = e->NQKV; a.out = e->attn_dec; a.ld_out = c.num_heads * 64;
     if (e->ks_qkv > 1) {
-        a.qkv_slabs = e->slabs; a.nslab = gemm_nsplit(e->H, e->ks_qkv); a.slab_rows = c.max_batch; a.qkv_bias = e->layers[i].bqkv;
+        a.qkv_slabs = e->slabs; a.nslab = gemm_nsplit(e->H, e->ks_qkv, ktile_of(e)); a.slab_rows = c.max_batch; a.qkv_bias = e->layers[i].bqkv;
     }
     a.kpool = e->kv + (size_t)i * e->layer_stride; a.vpool = a.kpool + e->kv_half;
     a.block_table = e->block_table; a.max_pages = e->max_pages; a.pos = e->sl.pos; a.state = e->sl.state;
     a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
     a.tl = e->attn_tl;
+    if (e->fp8) a.out_fp8_inv = 1.0f / e->layers[i].xs[1];   // attention output = o_proj's input
     attn_decode_launch(a, c.max_batch, e->stream, e->attn_depth, e->attn_var);
 }
 
 static void k_o_proj(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, QD = e->cfg.num_heads * 64;
-    gemm_skinny<EPI_SPLITK>(e->st_o, gemm_args(e, e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->slabs, H, B, H, QD), e->ks_o, e->stream);
+    gemm_skinny<EPI_SPLITK>(e->st_o, gemm_args(e, e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->slabs, H, B, H, QD, e->layers[i].so, e->layers[i].xs[1]), e->ks_o, e->stream);
 }
 
 static void k_gate_up(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, F = e->F;
-    GemmArgs gu = gemm_args(e, e->xn_dec, H, e->layers[i].wgu, H, nullptr, e->act_dec, F, B, 2 * F, H);
+    GemmArgs gu = gemm_args(e, e->xn_dec, H, e->layers[i].wgu, H, nullptr, e->act_dec, F, B, 2 * F, H, e->layers[i].sgu, e->layers[i].xs[2]);
+    if (e->fp8) {
+        gu.out_fp8_inv = 1.0f / e->layers[i].xs[3];            // the activation is down_proj's input
+        if (e->gu_tile == 1) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3, 0, 64, false, true>(gu, 1, e->stream);
+        else gemm_skinny<EPI_SILU_MUL>(e->st_gu, gu, 1, e->stream);
+        return;
+    }
     if (e->gu_tile == 1) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);        // 128 x 128, 8 waves
     else if (e->gu_tile == 2) gemm_launch<8, 1, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);   // 256 x 64, 8 waves
     else if (e->gu_large) gemm_large<EPI_SILU_MUL>(e, gu, e->stream);
@@ -612,14 +804,16 @@ static void k_gate_up(ntts_backbone* e, int i) {
 
 static void k_down(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, F = e->F;
-    gemm_skinny<EPI_SPLITK>(e->st_d, gemm_args(e, e->act_dec, F, e->layers[i].wd, F, nullptr, e->slabs, H, B, H, F), e->ks_d, e->stream);
+    gemm_skinny<EPI_SPLITK>(e->st_d, gemm_args(e, e->act_dec, F, e->layers[i].wd, F, nullptr, e->slabs, H, B, H, F, e->layers[i].sd, e->layers[i].xs[3]), e->ks_d, e->stream);
 }
 
 // residual += reduce(slabs of a K-deep split-K GEMM); normed = rmsnorm(residual) * norm_w
-static void k_add_norm(ntts_backbone* e, int K, int ks, const bf16_t* norm_w, bf16_t* resid_out, bf16_t* normed_out) {
+// next_scale: fp8 model, the static input scale of the GEMM that consumes the normalised rows (0 = bf16 output)
+static void k_add_norm(ntts_backbone* e, int K, int ks, const bf16_t* norm_w, bf16_t* resid_out, bf16_t* normed_out, float next_scale = 0.f) {
     NormArgs n{};
-    n.slabs = e->slabs; n.nslab = gemm_nsplit(K, ks); n.slab_rows = e->cfg.max_batch; n.resid_in = e->h_dec; n.resid_out = resid_out;
+    n.slabs = e->slabs; n.nslab = gemm_nsplit(K, ks, ktile_of(e)); n.slab_rows = e->cfg.max_batch; n.resid_in = e->h_dec; n.resid_out = resid_out;
     n.norm_w = norm_w; n.normed_out = normed_out; n.M = e->cfg.max_batch; n.H = e->H; n.eps = e->cfg.rms_eps;
+    if (e->fp8 && next_scale > 0.f) n.out_fp8_inv = 1.0f / next_scale;
     add_rmsnorm_launch(n, e->stream, e->norm_wide);
 }
 
@@ -706,15 +900,17 @@ static void decode_step(ntts_backbone* e) {
     NormArgs n0{};
     n0.gather_ids = e->sl.cur_tok; n0.embed = e->embed; n0.resid_out = e->h_dec; n0.norm_w = e->layers[0].ln1;
     n0.normed_out = e->xn_dec; n0.M = B; n0.H = H; n0.eps = c.rms_eps;
+    if (e->fp8) n0.out_fp8_inv = 1.0f / e->layers[0].xs[0];
     add_rmsnorm_launch(n0, e->stream, e->norm_wide);
     for (int i = 0; i < c.num_layers; ++i) {
+        const bool last = i + 1 == c.num_layers;
         k_qkv(e, i);
         k_attn(e, i);
         k_o_proj(e, i);
-        k_add_norm(e, QD, e->ks_o, e->layers[i].ln2, e->h_dec, e->xn_dec);
+        k_add_norm(e, QD, e->ks_o, e->layers[i].ln2, e->h_dec, e->xn_dec, e->layers[i].xs[2]);
         k_gate_up(e, i);
         k_down(e, i);
-        k_add_norm(e, F, e->ks_d, (i + 1 < c.num_layers) ? e->layers[i + 1].ln1 : e->final_norm, e->h_dec, e->xn_dec);
+        k_add_norm(e, F, e->ks_d, last ? e->final_norm : e->layers[i + 1].ln1, e->h_dec, e->xn_dec, last ? e->xs_head : e->layers[i + 1].xs[0]);
     }
     lm_head_and_sample(e, SLOT_RUNNING);
 }
@@ -876,11 +1072,12 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
     NormArgs n0{};
     n0.gather_ids = md; n0.embed = e->embed; n0.resid_out = e->h_pf; n0.norm_w = e->layers[0].ln1; n0.normed_out = e->xn_pf;
     n0.M = Ti; n0.H = H; n0.eps = c.rms_eps;
+    if (e->fp8) n0.out_fp8_inv = 1.0f / e->layers[0].xs[0];
     add_rmsnorm_launch(n0, st);
     for (int i = 0; i < c.num_layers; ++i) {
         const LayerW& w = e->layers[i];
         const bool last = i + 1 == c.num_layers;
-        gemm_large<EPI_BF16>(e, gemm_args(e, e->xn_pf, H, w.wqkv, H, w.bqkv, e->qkv_pf, e->NQKV, Ti, e->NQKV, H), st);
+        gemm_large<EPI_BF16>(e, gemm_args(e, e->xn_pf, H, w.wqkv, H, w.bqkv, e->qkv_pf, e->NQKV, Ti, e->NQKV, H, w.sqkv, w.xs[0]), st);
         RopeWriteArgs r{};
         r.qkv = e->qkv_pf; r.ld_qkv = e->NQKV; r.kpool = e->kv + (size_t)i * e->layer_stride; r.vpool = r.kpool + e->kv_half;
         r.block_table = e->block_table; r.max_pages = e->max_pages; r.meta = meta; r.rope_cos = e->rope_cos; r.rope_sin = e->rope_sin;
@@ -889,6 +1086,7 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
         AttnPrefillArgs a{};
         a.qkv = e->qkv_pf; a.ld_qkv = e->NQKV; a.out = e->attn_pf; a.ld_out = QD; a.kpool = r.kpool; a.vpool = r.vpool;
         a.block_table = e->block_table; a.max_pages = e->max_pages; a.meta = meta; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
+        if (e->fp8) a.out_fp8_inv = 1.0f / w.xs[1];     // attn_pf rows hold QD e4m3 BYTES (ld_out counts bytes then)
         // Last layer: the KV pages are complete after the rope/KV-write above, and nothing but each prompt's LAST position
         // is read afterwards (it alone feeds the lm_head).  Attention runs on the one query tile per prompt that holds
         // it, then that row and its residual row are compacted and o_proj / the MLP run on n rows instead of T.
@@ -904,25 +1102,31 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
         if (prune) {   // qkv_pf is free once attention has run: T * NQKV >= 4 n * NQKV > n * (QD + H) elements
             bf16_t* attn_c = e->qkv_pf;
             bf16_t* h_c = e->qkv_pf + (size_t)n * QD;
-            NTTS_LAUNCH((gather_rows_kernel), dim3(n), dim3(256), st, (const bf16_t*)e->attn_pf, (long)QD, (const int*)(md + o_last), attn_c, (long)QD, QD);
+            const int qe = e->fp8 ? QD / 2 : QD;   // attention rows in bf16 units (fp8: QD bytes)
+            NTTS_LAUNCH((gather_rows_kernel), dim3(n), dim3(256), st, (const bf16_t*)e->attn_pf, (long)qe, (const int*)(md + o_last), attn_c, (long)qe, qe);
             NTTS_LAUNCH((gather_rows_kernel), dim3(n), dim3(256), st, (const bf16_t*)e->h_pf, (long)H, (const int*)(md + o_last), h_c, (long)H, H);
             attn_in = attn_c;
             hres = h_c;
         }
-        gemm_large<EPI_BF16>(e, gemm_args(e, attn_in, QD, w.wo, QD, nullptr, e->o_pf, H, Mi, H, QD), st);
+        gemm_large<EPI_BF16>(e, gemm_args(e, attn_in, QD, w.wo, QD, nullptr, e->o_pf, H, Mi, H, QD, w.so, w.xs[1]), st);
         NormArgs n1{};
         n1.o_bf16 = e->o_pf; n1.resid_in = hres; n1.resid_out = hres; n1.norm_w = w.ln2; n1.normed_out = e->xn_pf;
         n1.M = Mi; n1.H = H; n1.eps = c.rms_eps;
+        if (e->fp8) n1.out_fp8_inv = 1.0f / w.xs[2];
         add_rmsnorm_launch(n1, st);
-        gemm_large<EPI_SILU_MUL>(e, gemm_args(e, e->xn_pf, H, w.wgu, H, nullptr, e->act_pf, F, Mi, 2 * F, H), st);
-        gemm_large<EPI_BF16>(e, gemm_args(e, e->act_pf, F, w.wd, F, nullptr, e->o_pf, H, Mi, H, F), st);
+        GemmArgs gu = gemm_args(e, e->xn_pf, H, w.wgu, H, nullptr, e->act_pf, F, Mi, 2 * F, H, w.sgu, w.xs[2]);
+        if (e->fp8) gu.out_fp8_inv = 1.0f / w.xs[3];
+        gemm_large<EPI_SILU_MUL>(e, gu, st);
+        gemm_large<EPI_BF16>(e, gemm_args(e, e->act_pf, F, w.wd, F, nullptr, e->o_pf, H, Mi, H, F, w.sd, w.xs[3]), st);
         NormArgs n2{};
         n2.o_bf16 = e->o_pf; n2.resid_in = hres; n2.eps = c.rms_eps; n2.H = H;
         if (!last) {
             n2.resid_out = e->h_pf; n2.norm_w = e->layers[i + 1].ln1; n2.normed_out = e->xn_pf; n2.M = Ti;
+            if (e->fp8) n2.out_fp8_inv = 1.0f / e->layers[i + 1].xs[0];
         } else {  // only each prompt's last position feeds the lm_head: gather it into its decode-slot row
             n2.resid_out = e->h_dec; n2.norm_w = e->final_norm; n2.normed_out = e->xn_dec; n2.M = n;
             n2.in_rows = prune ? nullptr : md + o_last; n2.out_rows = md + o_slot;
+            if (e->fp8) n2.out_fp8_inv = 1.0f / e->xs_head;
         }
         add_rmsnorm_launch(n2, st);
     }
@@ -1149,8 +1353,11 @@ extern "C" int ntts_backbone_step_bytes(ntts_backbone* e, double* bytes) {
     HIPCHK(e, hipMemcpy(st.data(), e->sl.state, B * sizeof(int), hipMemcpyDeviceToHost));
     HIPCHK(e, hipMemcpy(pos.data(), e->sl.pos, B * sizeof(int), hipMemcpyDeviceToHost));
     const double H = e->H, F = e->F, QD = c.num_heads * 64, KD = c.num_kv_heads * 64;
-    const double per_layer = (QD + 2 * KD) * H + (QD + 2 * KD) + H * QD + 3 * F * H + 2 * H;
-    const double w_layers = (per_layer * c.num_layers + H) * 2.0, w_head = (double)c.vocab_size * H * 2.0;
+    const double wb = e->fp8 ? 1.0 : 2.0;      // bytes per matrix weight (+ 4 per output channel for the fp8 scales)
+    const double mats = (QD + 2 * KD) * H + H * QD + 3 * F * H, small = (QD + 2 * KD) + 2 * H;
+    const double sc = e->fp8 ? ((QD + 2 * KD) + 2 * H + 2 * F) * 4.0 : 0.0;
+    const double w_layers = (mats * wb + small * 2.0 + sc) * c.num_layers + H * 2.0;
+    const double w_head = (double)c.vocab_size * H * wb + (e->fp8 ? c.vocab_size * 4.0 : 0.0);
     const double kv_tok = (double)c.num_layers * 2 * KD * 2.0;  // bytes per cached token (K+V, all layers)
     double kv = 0;
     for (int b = 0; b < B; ++b)
@@ -1200,7 +1407,9 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
     double kv_layer = 0;  // bytes one attention launch must read (+ write): K and V of every cached token
     for (int b = 0; b < B; ++b)
         if (sst[b] == SLOT_RUNNING) kv_layer += ((double)pos[b] + 1) * 2 * KD * 2.0;
-    const double act = (double)B * 2.0;
+    const double wb = e->fp8 ? 1.0 : 2.0;      // bytes per matrix weight / per GEMM-input activation element
+    const double act = (double)B * wb;
+    const int kt_ = ktile_of(e);
     const bool qkv_split = e->ks_qkv > 1;   // QKV leaves fp32 split-K slabs that the attention prologue reduces
     // Every replay works on the NEXT layer's weights / KV pool, as consecutive launches of this kernel do inside the
     // decode step: one layer's operands (84 MB of KV at batch 256) would sit in the 256 MB Infinity Cache when replayed
@@ -1226,7 +1435,7 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
             case 3: k_gate_up(e, i); break;
             case 4: k_down(e, i); break;
             case 5: k_lm_head(e, false); break;
-            case 6: k_add_norm(e, QD, e->ks_o, e->layers[i].ln2, e->o_pf, e->xn_pf); break;   // scratch outputs
+            case 6: k_add_norm(e, QD, e->ks_o, e->layers[i].ln2, e->o_pf, e->xn_pf, e->layers[i].xs[2]); break;   // scratch outputs
             default: break;
         }
     };
@@ -1236,15 +1445,15 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
         case 0: *alg_bytes = kv_layer;   // SURVEY 8(d), strictly: K and V of every cached token (+ the appended one); the q/k/v
                                          // inputs (bf16 row or the QKV GEMM's fp32 slabs) and the output are the builder's own
                 *launches_per_step = L; break;
-        case 1: *alg_bytes = ((double)e->NQKV * H + e->NQKV) * 2.0 + act * H +
-                             (double)B * e->NQKV * ((qkv_split || e->small) ? 4.0 * gemm_nsplit(H, ksq) : 2.0);
+        case 1: *alg_bytes = (double)e->NQKV * H * wb + e->NQKV * 2.0 + act * H +
+                             (double)B * e->NQKV * ((qkv_split || e->small) ? 4.0 * gemm_nsplit(H, ksq, kt_) : 2.0);
                 *launches_per_step = L; break;
-        case 2: *alg_bytes = (double)H * QD * 2.0 + act * QD + (double)gemm_nsplit(QD, kso) * B * H * 4.0;
+        case 2: *alg_bytes = (double)H * QD * wb + act * QD + (double)gemm_nsplit(QD, kso, kt_) * B * H * 4.0;
                 *launches_per_step = L; break;
-        case 3: *alg_bytes = (double)2 * F * H * 2.0 + act * (H + F); *launches_per_step = L; break;
-        case 4: *alg_bytes = (double)H * F * 2.0 + act * F + (double)gemm_nsplit(F, ksd) * B * H * 4.0; *launches_per_step = L; break;
-        case 5: *alg_bytes = (double)c.vocab_size * H * 2.0 + act * H; *launches_per_step = 1; break;
-        case 6: *alg_bytes = (double)gemm_nsplit(e->small ? F : QD, e->small ? ksd : kso) * B * H * 4.0 + act * H * 3;
+        case 3: *alg_bytes = (double)2 * F * H * wb + act * (H + F); *launches_per_step = L; break;
+        case 4: *alg_bytes = (double)H * F * wb + act * F + (double)gemm_nsplit(F, ksd, kt_) * B * H * 4.0; *launches_per_step = L; break;
+        case 5: *alg_bytes = (double)c.vocab_size * H * wb + act * H; *launches_per_step = 1; break;
+        case 6: *alg_bytes = (double)gemm_nsplit(e->small ? F : QD, e->small ? ksd : kso, kt_) * B * H * 4.0 + (double)B * 2.0 * H * 2 + act * H;
                 *launches_per_step = e->small ? 1 : 2 * L; break;
         default: return fail(e, NTTS_EINVAL, "unknown kernel id %d", which);
     }

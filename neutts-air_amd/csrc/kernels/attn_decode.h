@@ -33,6 +33,7 @@ struct AttnDecodeArgs {
     long ld_qkv;
     bf16_t* out;           // [B][nh*64]
     long ld_out;
+    float out_fp8_inv;     // > 0: `out` holds e4m3 BYTES, value = bf16 result * out_fp8_inv (the o_proj input of the fp8 model)
     bf16_t* kpool;         // this layer
     bf16_t* vpool;
     const int* block_table;  // [B][max_pages]
@@ -368,7 +369,8 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
         float o = ored[0][hh][d];
 #pragma unroll
         for (int ww = 1; ww < NW; ++ww) o += ored[ww][hh][d];            // ascending wave order
-        p.out[(long)b * p.ld_out + (kvh * group + hh) * 64 + d] = f2bf(o);
+        if (p.out_fp8_inv > 0.f) ((unsigned char*)p.out)[(long)b * p.ld_out + (kvh * group + hh) * 64 + d] = f2fp8c(rbf(o) * p.out_fp8_inv);
+        else p.out[(long)b * p.ld_out + (kvh * group + hh) * 64 + d] = f2bf(o);
     }
     mark(7);
 }

@@ -77,6 +77,7 @@ struct AttnPrefillArgs {
     long ld_qkv;
     bf16_t* out;               // [T][nh*64]
     long ld_out;
+    float out_fp8_inv;         // > 0: `out` holds e4m3 BYTES, value = bf16 result * out_fp8_inv (the o_proj input of the fp8 model)
     const bf16_t* kpool;
     const bf16_t* vpool;
     const int* block_table;
@@ -183,9 +184,15 @@ NTTS_KERNEL(256) void attn_prefill_kernel(AttnPrefillArgs p) {
     for (int r = 0; r < 4; ++r) {
         const int q = qw0 + g * 4 + r;
         if (q < S) {
-            bf16_t* o = p.out + (long)(base + q) * p.ld_out + h * 64 + l15;
+            if (p.out_fp8_inv > 0.f) {
+                unsigned char* o = (unsigned char*)p.out + (long)(base + q) * p.ld_out + h * 64 + l15;
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) o[nt * 16] = f2bf(oacc[nt][r]);
+                for (int nt = 0; nt < 4; ++nt) o[nt * 16] = f2fp8c(rbf(oacc[nt][r]) * p.out_fp8_inv);
+            } else {
+                bf16_t* o = p.out + (long)(base + q) * p.ld_out + h * 64 + l15;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) o[nt * 16] = f2bf(oacc[nt][r]);
+            }
         }
     }
 }
@@ -390,9 +397,15 @@ NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
                 for (int r = 0; r < 4; ++r) {
                     const int q = qw0 + g * 4 + r;
                     if (q < S) {
-                        bf16_t* o = p.out + (long)(base + q) * p.ld_out + (h0 + h) * 64 + l15;
+                        if (p.out_fp8_inv > 0.f) {
+                            unsigned char* o = (unsigned char*)p.out + (long)(base + q) * p.ld_out + (h0 + h) * 64 + l15;
 #pragma unroll
-                        for (int nt = 0; nt < 4; ++nt) o[nt * 16] = f2bf(oacc[h][nt][r]);
+                            for (int nt = 0; nt < 4; ++nt) o[nt * 16] = f2fp8c(rbf(oacc[h][nt][r]) * p.out_fp8_inv);
+                        } else {
+                            bf16_t* o = p.out + (long)(base + q) * p.ld_out + (h0 + h) * 64 + l15;
+#pragma unroll
+                            for (int nt = 0; nt < 4; ++nt) o[nt * 16] = f2bf(oacc[h][nt][r]);
+                        }
                     }
                 }
             }

@@ -68,6 +68,12 @@ struct GemmArgs {
     // EPI_RESID
     const bf16_t* resid_bf16;   // [M][ldrb]
     long ldrb;
+    // F8 kernels (fp8 e4m3 operands): X and W hold BYTES ([M][ldx] / [N][ldw] or tile-major in 64 x 128-byte blocks), K is a
+    // multiple of 128; out = acc * (xscale * wscale[n]) (+ bias): static per-tensor activation scale, per-output-channel
+    // weight scale.  EPI_SILU_MUL can emit fp8 (the next GEMM's input): out byte = e4m3(value * out_fp8_inv), 0 = bf16 out.
+    const float* wscale;
+    float xscale;
+    float out_fp8_inv;
 };
 
 NTTS_D void gemm_tile_coords(int bid, int mblocks, int nblocks, int& mb, int& nb) {
@@ -90,11 +96,29 @@ NTTS_D float gemm_bias(const GemmArgs& p, int n) { return p.bias_f32 ? p.bias_f3
 
 // ---- epilogue shared by the GEMM kernels: lane owns token m (per a) x features nb16 .. nb16+15
 //      (acc[a][j][r] <-> feature nb16 + j*4 + r); mrow0 = first row of this wave's tile, split = split-K slab index
-template <int TM, int EPI, int WN>
+template <int TM, int EPI, int WN, bool F8 = false>
 NTTS_D void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][4], int mrow0, int n0, int wn, int nb, int split) {
     const int lane = lane_id();
     const int g = lane >> 4, l15 = lane & 15;
     const int nb16 = n0 + wn * 64 + g * 16;
+    float sc[4][4];        // F8: xscale * wscale[n] of this lane's 16 features (one product, then ONE multiply per accumulator)
+    if constexpr (F8) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = nb16 + j * 4 + r;
+                sc[j][r] = p.xscale * p.wscale[n < p.N ? n : p.N - 1];
+            }
+        if constexpr (EPI != EPI_BF16) {   // (EPI_BF16 applies the scale and the bias in one fma, below)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[a][j][r] *= sc[j][r];
+        }
+    }
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
         const int m = mrow0 + a * 16 + l15;
@@ -107,7 +131,8 @@ NTTS_D void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][4], int mrow0, int
                 for (int r = 0; r < 4; ++r) {
                     const int n = nb16 + j * 4 + r;
                     float v = acc[a][j][r];
-                    if (n < p.N) v += gemm_bias(p, n);
+                    if constexpr (F8 && EPI == EPI_BF16) v = __builtin_fmaf(v, sc[j][r], n < p.N ? gemm_bias(p, n) : 0.f);
+                    else if (n < p.N) v += gemm_bias(p, n);
                     if constexpr (EPI == EPI_BF16_SILU) v = silu_f(v);
                     o[j * 4 + r] = f2bf(v);
                 }
@@ -191,7 +216,16 @@ NTTS_D void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][4], int mrow0, int
                 }
             if (mok) {
                 const int fb = ((n0 + wn * 64) >> 1) + g * 8;
-                if (fb + 8 <= (p.N >> 1)) *(u32x4*)((bf16_t*)p.out + (long)m * p.ldo + fb) = *(u32x4*)&o[0];
+                if (fb + 8 <= (p.N >> 1)) {
+                    if (F8 && p.out_fp8_inv > 0.f) {   // the down_proj input of the fp8 model: e4m3(bf16 value / input scale)
+                        alignas(8) unsigned short q[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) q[e] = f2fp8x2(bf2f(o[2 * e]) * p.out_fp8_inv, bf2f(o[2 * e + 1]) * p.out_fp8_inv);
+                        *(u32x2*)((unsigned char*)p.out + (long)m * p.ldo + fb) = *(u32x2*)&q[0];
+                    } else {
+                        *(u32x4*)((bf16_t*)p.out + (long)m * p.ldo + fb) = *(u32x4*)&o[0];
+                    }
+                }
             }
         } else if constexpr (EPI == EPI_SPLITK) {
             if (mok && nb16 + 16 <= p.N) {
@@ -249,9 +283,15 @@ NTTS_D void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][4], int mrow0, int
 // three slices (96 KB) stay in flight under the MFMAs of the fourth.
 // WNT: the W stream uses the non-temporal cache policy (decode step: every weight byte is read once per step by one
 // workgroup, or by the few m-blocks of one XCD); X keeps the default policy (re-read by every n-block).
-template <int WM, int WN, int TM, int EPI, int NS, int ABL = 0, int BK = 64, bool WNT = false>
+// F8: fp8 e4m3 operands on v_mfma_f32_16x16x32_fp8_fp8.  Everything about staging is byte-identical to the bf16 kernel -- an
+// LDS row is still one 128-byte line, now 128 k-values instead of 64 -- so the ring, the DMA pieces and the swizzle are
+// shared; a lane's 16-byte fragment read holds TWO 8-byte MFMA operands (the low and the high 8 of its 16 k-values; A and B
+// use the same split, so the k order is consistent).  Half the weight AND activation bytes through the per-CU load path.
+template <int WM, int WN, int TM, int EPI, int NS, int ABL = 0, int BK = 64, bool WNT = false, bool F8 = false>
 NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     static_assert(BK == 64 || BK == 32, "ring slot K extent");
+    static_assert(!F8 || BK == 64, "fp8: one ring slot = 128-byte rows");
+    constexpr int ESZ = F8 ? 1 : 2;            // bytes per operand element
     constexpr int BM = WM * TM * 16, BN = WN * 64, NW = WM * WN;
     constexpr int ROWS = BM + BN;              // LDS rows per buffer, BK bf16 each
     constexpr int KC = BK / 8;                 // 16-byte chunks per row
@@ -273,14 +313,14 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     int mb, nb;
     gemm_tile_coords(blockIdx.x, p.mblocks, p.nblocks, mb, nb);
     const int m0 = mb * BM, n0 = nb * BN;
-    const int ktiles = p.K >> 6;
+    const int ktiles = F8 ? p.K >> 7 : p.K >> 6;               // 128-byte K tiles
     const int kt0 = blockIdx.y * p.k_tiles_per_split * SPT;   // in ring slots from here on
     int nk = ktiles - blockIdx.y * p.k_tiles_per_split;
     if (nk > p.k_tiles_per_split) nk = p.k_tiles_per_split;
     nk *= SPT;
 
     // ---- loader set-up: which global row feeds each of this lane's LDS-DMA pieces
-    const bf16_t* src[PER_WAVE];
+    const char* src[PER_WAVE];                          // byte addresses (an operand element is ESZ bytes)
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
         const int inst = wave + i * NW;
@@ -289,24 +329,25 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         if (rho < BM) {
             int m = m0 + rho;
             if (m > p.M - 1) m = p.M - 1;
-            src[i] = p.X + (long)m * p.ldx + c * 8;
+            src[i] = (const char*)p.X + (long)m * p.ldx * ESZ + c * 16;
         } else {
             const int q = rho - BM;                      // tile-major W row: q = wq*64 + j*16 + i16
             const int wq = q >> 6, j = (q >> 4) & 3, i16 = q & 15;
             int n = n0 + wq * 64 + (i16 >> 2) * 16 + j * 4 + (i16 & 3);
             if (n > p.N - 1) n = p.N - 1;
-            src[i] = p.w_tile_major ? p.W + (long)(n >> 6) * 64 * p.K + (n & 63) * 64 + c * 8 : p.W + (long)n * p.ldw + c * 8;
+            src[i] = p.w_tile_major ? (const char*)p.W + (long)(n >> 6) * 64 * p.K * ESZ + (n & 63) * 128 + c * 16
+                                    : (const char*)p.W + (long)n * p.ldw * ESZ + c * 16;
         }
     }
-    static_assert(BK == 64 || true, "");
-    const long wstep = p.w_tile_major ? 4096 : BK;      // elements between consecutive K tiles of a W row (BK = 64 only)
+    const long xstep = BK * 2;                           // bytes between consecutive K tiles of a row (128; 64 for BK = 32)
+    const long wstep = p.w_tile_major ? 8192 : xstep;   // tile-major: the next 64 x 128-byte block (BK = 64 only)
     auto stage = [&](int kt, int buf) {
         if constexpr (ABL & 2) return;
 #pragma unroll
         for (int i = 0; i < PER_WAVE; ++i) {
             const int inst = wave + i * NW;
             const bool is_w = (inst * RPI) >= BM;          // this instruction's rows are W rows (wave-uniform)
-            const bf16_t* g = src[i] + (long)(kt0 + kt) * (is_w ? wstep : (long)BK);
+            const char* g = src[i] + (long)(kt0 + kt) * (is_w ? wstep : xstep);
             bf16_t* l = lds + buf * (ROWS * BK) + inst * 512;
             if (WNT && is_w) glds16_nt(g, l); else glds16(g, l);
         }
@@ -357,14 +398,22 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[a][j] = mfma16(wa[j], xb[a], acc[a][j]);
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (F8) {
+                        const i64x2 w2 = __builtin_bit_cast(i64x2, wa[j]), x2 = __builtin_bit_cast(i64x2, xb[a]);
+                        acc[a][j] = mfma16_fp8(w2[0], x2[0], acc[a][j]);
+                        acc[a][j] = mfma16_fp8(w2[1], x2[1], acc[a][j]);
+                    } else {
+                        acc[a][j] = mfma16(wa[j], xb[a], acc[a][j]);
+                    }
+                }
         }
     }
 
     if constexpr (ABL & 4) {
         if (acc[0][0][0] != 12345.678f) return;   // keeps the accumulators live without storing
     }
-    gemm_epilogue<TM, EPI, WN>(p, acc, m0 + wm * TM * 16, n0, wn, nb, blockIdx.y);
+    gemm_epilogue<TM, EPI, WN, F8>(p, acc, m0 + wm * TM * 16, n0, wn, nb, blockIdx.y);
 }
 
 
@@ -379,18 +428,18 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 // ------------------------------------------------------------------------------------------------
 struct GemmShape { int BM, BN, WN; };
 
-template <int WM, int WN, int TM, int EPI, int NS = 2, int ABL = 0, int BK = 64, bool WNT = false>
+template <int WM, int WN, int TM, int EPI, int NS = 2, int ABL = 0, int BK = 64, bool WNT = false, bool F8 = false>
 inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * 64;
     p.mblocks = (p.M + BM - 1) / BM;
     p.nblocks = (p.N + BN - 1) / BN;
-    const int ktiles = p.K / 64;
+    const int ktiles = p.K / (F8 ? 128 : 64);
     if (ksplit < 1) ksplit = 1;
     if (ksplit > ktiles) ksplit = ktiles;
     p.k_tiles_per_split = (ktiles + ksplit - 1) / ksplit;
     const int nsplit = (ktiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
     if constexpr (EPI == EPI_ARGMAX) p.part_stride = p.nblocks * WN;
-    NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT>), dim3(p.mblocks * p.nblocks, nsplit), dim3(WM * WN * 64), s, p);
+    NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT, F8>), dim3(p.mblocks * p.nblocks, nsplit), dim3(WM * WN * 64), s, p);
 }
 
 // tile families:  XL = 256x256 (4x4 waves = 1024 threads, 64x64 per wave, 128 KB LDS) -- big-M GEMMs (prefill, codec):
@@ -404,9 +453,9 @@ inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
 #define NTTS_GEMM_L(EPI, p, ks, s) ::ntts::gemm_launch<2, 2, 4, EPI, 2>(p, ks, s)
 #define NTTS_GEMM_S(EPI, p, ks, s) ::ntts::gemm_launch<4, 1, 1, EPI, 4>(p, ks, s)
 
-// number of split-K slabs gemm_launch will produce for (K, ksplit)
-inline int gemm_nsplit(int K, int ksplit) {
-    const int ktiles = K / 64;
+// number of split-K slabs gemm_launch will produce for (K, ksplit); ktile = K extent of one 128-byte tile (64 bf16, 128 fp8)
+inline int gemm_nsplit(int K, int ksplit, int ktile = 64) {
+    const int ktiles = K / ktile;
     if (ksplit < 1) ksplit = 1;
     if (ksplit > ktiles) ksplit = ktiles;
     const int per = (ktiles + ksplit - 1) / ksplit;

@@ -32,6 +32,7 @@ struct NormArgs {
     const int* out_rows;     // logical row r writes output row out_rows[r] (null: r)
     int M, H;
     float eps;
+    float out_fp8_inv;       // > 0: normed_out holds e4m3 BYTES [*, H], value = bf16 result * out_fp8_inv (GEMM input of the fp8 model)
 };
 
 // One wave64 = one row.  `r` = logical row (already clamped into range), `rok` = its outputs are wanted (the clamped
@@ -125,7 +126,15 @@ NTTS_D void rmsnorm_row_wave(const NormArgs& p, int r, bool rok, bool write_resi
             bf16x8 t;
 #pragma unroll
             for (int e = 0; e < 8; ++e) t[e] = (short)f2bf(bf2f((bf16_t)w[e]) * rbf(v[i][e] * inv));
-            *(bf16x8*)(dst ? dst + col : p.normed_out + ro * p.H + col) = t;
+            if (p.out_fp8_inv > 0.f && !dst) {
+                alignas(8) unsigned short q[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    q[e] = f2fp8x2(bf2f((bf16_t)t[2 * e]) * p.out_fp8_inv, bf2f((bf16_t)t[2 * e + 1]) * p.out_fp8_inv);
+                *(u32x2*)((unsigned char*)p.normed_out + ro * p.H + col) = *(u32x2*)&q[0];
+            } else {
+                *(bf16x8*)(dst ? dst + col : p.normed_out + ro * p.H + col) = t;
+            }
         }
     }
 }
@@ -220,7 +229,15 @@ NTTS_KERNEL(128) void add_rmsnorm_row_kernel(NormArgs p) {
         bf16x8 t;
 #pragma unroll
         for (int e = 0; e < 8; ++e) t[e] = (short)f2bf(bf2f((bf16_t)wv[e]) * rbf(o[e] * inv));
-        *(bf16x8*)(p.normed_out + ro * p.H + col) = t;
+        if (p.out_fp8_inv > 0.f) {
+            alignas(8) unsigned short q[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                q[e] = f2fp8x2(bf2f((bf16_t)t[2 * e]) * p.out_fp8_inv, bf2f((bf16_t)t[2 * e + 1]) * p.out_fp8_inv);
+            *(u32x2*)((unsigned char*)p.normed_out + ro * p.H + col) = *(u32x2*)&q[0];
+        } else {
+            *(bf16x8*)(p.normed_out + ro * p.H + col) = t;
+        }
     }
 }
 

@@ -283,4 +283,37 @@ NTTS_KERNEL(256) void pack_weight_kernel(const void* src, int src_is_f32, bf16_t
     }
 }
 
+// fp8 model: one source row -> e4m3 bytes + its scale.  The row is first rounded to bf16 (what the bf16 checkpoint holds), then
+// scale = max|w| / 448 (1 for an all-zero row), w_q = e4m3(w / scale) -- per output channel, as static-fp8 checkpoints store
+// them.  Layout of the byte matrix: tile-major in 64-row x 128-byte blocks (gemm.h F8).
+NTTS_KERNEL(256) void pack_weight_fp8_kernel(const void* src, int src_is_f32, unsigned char* dst, float* scales, const int* dst_rows,
+                                             long row0, long cols) {
+    NTTS_SHARED float red[4];
+    const long r = blockIdx.x;
+    const long dr = row0 + (dst_rows ? dst_rows[r] : r);
+    auto val = [&](long c) { return src_is_f32 ? rbf(((const float*)src)[r * cols + c]) : bf2f(((const bf16_t*)src)[r * cols + c]); };
+    float am = 0.f;
+    for (long c = threadIdx.x; c < cols; c += 256) am = fmaxf(am, fabsf(val(c)));
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) am = fmaxf(am, shfl_xor(am, sh));
+    if (lane_id() == 0) red[wave_id()] = am;
+    sync();
+    am = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const float scale = am > 0.f ? am / kFp8Max : 1.0f;
+    if (threadIdx.x == 0) scales[dr] = scale;
+    for (long c = threadIdx.x; c < cols; c += 256)
+        dst[(dr >> 6) * 64 * cols + (c >> 7) * 8192 + (dr & 63) * 128 + (c & 127)] = f2fp8c(val(c) / scale);
+}
+
+// number of elements of `src` ([rows][cols], fp32 or bf16) whose bf16 value differs from ref[rows][cols]: the tied-head check
+NTTS_KERNEL(256) void rows_mismatch_kernel(const void* src, int src_is_f32, const bf16_t* ref, long cols, unsigned int* count) {
+    const long r = blockIdx.x;
+    unsigned int bad = 0;
+    for (long c = threadIdx.x; c < cols; c += 256) {
+        const bf16_t v = src_is_f32 ? f2bf(((const float*)src)[r * cols + c]) : ((const bf16_t*)src)[r * cols + c];
+        bad += v != ref[r * cols + c];
+    }
+    if (bad) atomic_add_global(count, bad);
+}
+
 }  // namespace ntts

@@ -36,6 +36,20 @@ NTTS_D f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// ---- fp8 (OCP e4m3fn on gfx950: max 448, no inf) -- weights and GEMM-input activations of the fp8 model variant
+typedef __attribute__((ext_vector_type(2))) long i64x2;   // one 16-byte LDS chunk = two fp8 MFMA fragments (8 fp8 each)
+constexpr float kFp8Max = 448.0f;
+// D = A(16x32) * B(32x16) + C with e4m3 operands: lane l holds A[row l&15][k (l>>4)*8 .. +7] as 8 bytes (same layout as mfma16)
+NTTS_D f32x4 mfma16_fp8(long a, long b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a, b, c, 0, 0, 0); }
+// two floats -> two e4m3 bytes (round-to-nearest-even, clamped to +-448 first: e4m3fn has no inf, an overflow would be NaN)
+NTTS_D unsigned short f2fp8x2(float a, float b) {
+    a = __builtin_fminf(__builtin_fmaxf(a, -kFp8Max), kFp8Max);
+    b = __builtin_fminf(__builtin_fmaxf(b, -kFp8Max), kFp8Max);
+    return (unsigned short)(__builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false) & 0xffff);
+}
+NTTS_D unsigned char f2fp8c(float a) { return (unsigned char)(f2fp8x2(a, 0.f) & 0xff); }
+NTTS_D float fp82f(unsigned char v) { return __builtin_amdgcn_cvt_f32_fp8((int)v, 0); }
+
 NTTS_D float shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 NTTS_D int shfl_xor(int v, int m) { return __shfl_xor(v, m, 64); }
 NTTS_D float shfl(float v, int src) { return __shfl(v, src, 64); }
@@ -75,6 +89,7 @@ NTTS_D void lds_barrier() { sync_keep_dma(); }
 // nothing is scheduled across this point by the compiler (issue order of memory requests matters: in-order returns)
 NTTS_D void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
+NTTS_D unsigned int atomic_add_global(unsigned int* p, unsigned int v) { return atomicAdd(p, v); }
 NTTS_D unsigned int atomic_add_lds(unsigned int* p, unsigned int v) { return atomicAdd(p, v); }
 // constant-rate timestamp (s_memrealtime, 100 MHz): phase timelines of a kernel (diagnostics only)
 NTTS_D unsigned long long now_ticks() { return wall_clock64(); }

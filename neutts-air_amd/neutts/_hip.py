@@ -17,6 +17,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "libneutts_hip.so")
 
 NTTS_DT_F32, NTTS_DT_BF16, NTTS_DT_I32 = 0, 1, 2
+NTTS_W_BF16, NTTS_W_FP8_E4M3 = 0, 1
+ABI_VERSION = 2
 NTTS_PAGE_TOKENS = 32            # include/neutts_hip.h
 PAGE_TOKENS = 32
 ERRORS = {-1: "EINVAL", -2: "ENODEV", -3: "ENOMEM", -4: "ESTATE", -5: "EHIP"}
@@ -32,7 +34,9 @@ class BackboneConfigC(C.Structure):
     _fields_ = [("vocab_size", C.c_int32), ("hidden_size", C.c_int32), ("intermediate_size", C.c_int32),
                 ("num_layers", C.c_int32), ("num_heads", C.c_int32), ("num_kv_heads", C.c_int32),
                 ("head_dim", C.c_int32), ("rms_eps", C.c_float), ("max_context", C.c_int32),
-                ("max_batch", C.c_int32), ("num_pages", C.c_int32), ("max_prefill_tokens", C.c_int32)]
+                ("max_batch", C.c_int32), ("num_pages", C.c_int32), ("max_prefill_tokens", C.c_int32),
+                ("tie_word_embeddings", C.c_int32), ("attention_bias", C.c_int32), ("qk_norm", C.c_int32),
+                ("weight_dtype", C.c_int32)]
 
 
 class CodecConfigC(C.Structure):
@@ -155,13 +159,16 @@ class BackboneEngine:
 
     def __init__(self, cfg: dict, device: int = 0, lib_path: Optional[str] = None):
         self.lib = load_library(lib_path)
-        if self.lib.ntts_abi_version() != 1:
-            raise RuntimeError("libneutts_hip ABI mismatch")
+        if self.lib.ntts_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libneutts_hip ABI mismatch: library {self.lib.ntts_abi_version()}, binding {ABI_VERSION} (rebuild: python neutts-air_amd/build.py)")
         self.cfg = dict(cfg)
         c = BackboneConfigC(cfg["vocab_size"], cfg["hidden_size"], cfg["intermediate_size"], cfg["num_layers"],
                             cfg["num_heads"], cfg["num_kv_heads"], cfg.get("head_dim", 64), cfg.get("rms_eps", 1e-6),
                             cfg.get("max_context", 2048), cfg.get("max_batch", 1), cfg.get("num_pages", 0),
-                            cfg.get("max_prefill_tokens", 0))
+                            cfg.get("max_prefill_tokens", 0), int(cfg.get("tie_word_embeddings", True)),
+                            int(cfg.get("attention_bias", True)), int(cfg.get("qk_norm", False)),
+                            {"bf16": NTTS_W_BF16, "fp8": NTTS_W_FP8_E4M3, "fp8_e4m3": NTTS_W_FP8_E4M3}[str(cfg.get("weight_dtype", "bf16"))])
+        self.fp8 = c.weight_dtype == NTTS_W_FP8_E4M3
         h = C.c_void_p()
         rc = self.lib.ntts_backbone_create(C.byref(c), device, C.byref(h))
         if rc != 0:
@@ -205,12 +212,18 @@ class BackboneEngine:
         self._chk(self.lib.ntts_backbone_load_tensor(self.h, name.encode(), C.c_void_p(ptr), code, shp, len(shape), is_dev))
         del keep
 
-    def load_state_dict(self, sd: Dict[str, object], inv_freq=None):
-        """HF Qwen2ForCausalLM state dict (+ rope.inv_freq; computed like hf:...modeling_qwen2.py:86 if absent)."""
+    def load_state_dict(self, sd: Dict[str, object], inv_freq=None, input_scales: Optional[Dict[str, float]] = None):
+        """HF Qwen2ForCausalLM state dict (+ rope.inv_freq; computed like hf:...modeling_qwen2.py:86 if absent).
+        fp8 engines (weight_dtype="fp8"): the bf16 / fp32 matrices are quantised on upload; the static activation scales come
+        as `*.input_scale` entries of `sd` (static-fp8 checkpoints) or as the `input_scales` dict {tensor name: float}."""
         for k, v in sd.items():
             if k.endswith("rotary_emb.inv_freq"):
                 continue
+            if k.endswith(".input_scale"):
+                v = np.asarray(v.float().cpu() if hasattr(v, "cpu") else v, dtype=np.float32).reshape(1)
             self.load_tensor(k, v)
+        for k, v in (input_scales or {}).items():
+            self.load_tensor(k, np.asarray([v], dtype=np.float32))
         if inv_freq is None:
             raise ValueError("inv_freq (fp32 [head_dim/2]) must be supplied: it is a model buffer, not a constant")
         self.load_tensor("rope.inv_freq", np.asarray(inv_freq, dtype=np.float32))

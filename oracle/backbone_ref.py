@@ -25,6 +25,60 @@ import torch.nn.functional as F
 
 # model geometry + seeded synthetic weights / prompts are plain data shared with bench.py and the tools (synthetic.py)
 from synthetic import BackboneConfig, cast_weights, make_weights, rope_inv_freq, synthetic_prompt  # noqa: F401
+from synthetic import FP8_MAX, default_fp8_input_scales  # noqa: F401
+
+
+# --------------------------------------------------------------------------------------
+# fp8 model variant: e4m3 weights (per-output-channel scale) x e4m3 GEMM inputs (static per-tensor scale), fp32 accumulate,
+# bf16 everywhere else.  There is no third-party reference for this variant on the path (the reference runs bf16 / fp32
+# weights, or llama.cpp's own quantisations): this restatement of the scheme of static-fp8 checkpoints IS the specification
+# the HIP path is checked against -- same quantisation points, same rounding (RNE, clamped to +-448), same scale algebra.
+# --------------------------------------------------------------------------------------
+def fp8_quantize_weights(w: Dict[str, torch.Tensor], input_scales: Dict[str, float]) -> Dict[str, torch.Tensor]:
+    """bf16 state dict -> the same dict with, for every Linear on the path (and the head), three extra entries:
+    name + "::q" (float32 tensor holding the e4m3 VALUES of the quantised weight), name + "::scale" (fp32 [N]) and
+    name + "::in_scale" (python float).  The original tensors stay (embedding gather, biases, norms)."""
+    out = dict(w)
+
+    def quant(name, xs):
+        wt = w[name].to(torch.bfloat16).to(torch.float32)
+        am = wt.abs().amax(dim=1)
+        sc = torch.where(am > 0, am / FP8_MAX, torch.ones_like(am))
+        q = (wt / sc[:, None]).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).to(torch.float32)
+        out[name + "::q"], out[name + "::scale"], out[name + "::in_scale"] = q, sc, float(xs)
+
+    n_layers = 1 + max(int(k.split(".")[2]) for k in w if k.startswith("model.layers."))
+    for i in range(n_layers):
+        p = f"model.layers.{i}."
+        for t, sname in (("self_attn.q_proj", "self_attn.q_proj"), ("self_attn.k_proj", "self_attn.q_proj"), ("self_attn.v_proj", "self_attn.q_proj"),
+                         ("self_attn.o_proj", "self_attn.o_proj"), ("mlp.gate_proj", "mlp.gate_proj"), ("mlp.up_proj", "mlp.gate_proj"),
+                         ("mlp.down_proj", "mlp.down_proj")):
+            quant(p + t + ".weight", input_scales[p + sname + ".input_scale"])
+    head = "lm_head.weight" if "lm_head.weight" in w else "model.embed_tokens.weight"
+    quant(head, input_scales["lm_head.input_scale"])
+    if head != "lm_head.weight":
+        for suf in ("::q", "::scale", "::in_scale"):
+            out["lm_head.weight" + suf] = out.pop(head + suf)
+    return out
+
+
+def fp8_act(x: torch.Tensor, in_scale: float) -> torch.Tensor:
+    """e4m3 VALUES (as fp32) of a GEMM input: e4m3(clamp(x / in_scale)), RNE."""
+    return (x.to(torch.float32) * (1.0 / in_scale)).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).to(torch.float32)
+
+
+def linear(x: torch.Tensor, w: Dict[str, torch.Tensor], name: str, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.Linear in the model dtype (hf:models/qwen2/modeling_qwen2.py:46-48,206-208,233), or -- when `w` carries the fp8
+    entries of `name` -- acc = q(x) @ Wq^T in fp32, y = fma(acc, in_scale * w_scale[n], bias) rounded once to the model dtype."""
+    if name + "::q" not in w:
+        return F.linear(x, w[name], bias)
+    xs = w[name + "::in_scale"]
+    acc = fp8_act(x, xs) @ w[name + "::q"].t()                                   # exact products, fp32 sums
+    sc = (torch.tensor(xs, dtype=torch.float32) * w[name + "::scale"]).to(torch.float64)
+    y = acc.to(torch.float64) * sc
+    if bias is not None:
+        y = y + bias.to(torch.float64)                                           # = one fma per element (fp64 holds the product exactly)
+    return y.to(torch.float32).to(x.dtype)
 
 
 # --------------------------------------------------------------------------------------
@@ -122,21 +176,21 @@ def decoder_layer(cfg, w, i, h, cos, sin, cache: KVCache, taps=None):
     nh, nkv, d = cfg.num_heads, cfg.num_kv_heads, cfg.head_dim
     resid = h
     x = rms_norm(h, w[p + "input_layernorm.weight"], cfg.rms_eps)
-    q = F.linear(x, w[p + "self_attn.q_proj.weight"], w[p + "self_attn.q_proj.bias"]).view(B, S, nh, d).transpose(1, 2)
-    k = F.linear(x, w[p + "self_attn.k_proj.weight"], w[p + "self_attn.k_proj.bias"]).view(B, S, nkv, d).transpose(1, 2)
-    v = F.linear(x, w[p + "self_attn.v_proj.weight"], w[p + "self_attn.v_proj.bias"]).view(B, S, nkv, d).transpose(1, 2)
+    q = linear(x, w, p + "self_attn.q_proj.weight", w.get(p + "self_attn.q_proj.bias")).view(B, S, nh, d).transpose(1, 2)
+    k = linear(x, w, p + "self_attn.k_proj.weight", w.get(p + "self_attn.k_proj.bias")).view(B, S, nkv, d).transpose(1, 2)
+    v = linear(x, w, p + "self_attn.v_proj.weight", w.get(p + "self_attn.v_proj.bias")).view(B, S, nkv, d).transpose(1, 2)
     q, k = apply_rope(q, k, cos, sin)
     kk, vv = cache.update(i, k, v)
     mask = causal_mask(S, kk.shape[-2], h.dtype)
     a = eager_attention(q, kk, vv, mask, d ** -0.5, nh // nkv)
     a = a.reshape(B, S, -1).contiguous()
-    o = F.linear(a, w[p + "self_attn.o_proj.weight"])
+    o = linear(a, w, p + "self_attn.o_proj.weight")
     h = resid + o
     resid = h
     x2 = rms_norm(h, w[p + "post_attention_layernorm.weight"], cfg.rms_eps)
-    g = F.linear(x2, w[p + "mlp.gate_proj.weight"])
-    u = F.linear(x2, w[p + "mlp.up_proj.weight"])
-    m = F.linear(F.silu(g) * u, w[p + "mlp.down_proj.weight"])
+    g = linear(x2, w, p + "mlp.gate_proj.weight")
+    u = linear(x2, w, p + "mlp.up_proj.weight")
+    m = linear(F.silu(g) * u, w, p + "mlp.down_proj.weight")
     out = resid + m
     if taps is not None:
         taps.append(dict(x=x, q=q, k=k, v=v, attn=a, o=o, h_mid=h, x2=x2, act=F.silu(g) * u, mlp=m, h_out=out))
@@ -158,7 +212,9 @@ def model_forward(cfg: BackboneConfig, w, ids: torch.Tensor, cache: KVCache, tap
         if taps is not None:
             taps.append(lt[0])
     h = rms_norm(h, w["model.norm.weight"], cfg.rms_eps)
-    return F.linear(h[:, -1, :], w["model.embed_tokens.weight"])  # tied lm_head
+    if "lm_head.weight::q" in w:
+        return linear(h[:, -1, :], w, "lm_head.weight")
+    return F.linear(h[:, -1, :], w.get("lm_head.weight", w["model.embed_tokens.weight"]))  # tied unless the checkpoint unties it
 
 
 @dataclass

@@ -25,10 +25,21 @@ class BackboneConfig:
     head_dim: int = 64
     rms_eps: float = 1e-6
     rope_theta: float = 1e6
+    attention_bias: bool = True       # Qwen2: q/k/v_proj carry a bias; Llama-style decoders do not
+    tie_word_embeddings: bool = True  # False: a separate lm_head.weight
 
     @staticmethod
     def neutts_air(vocab_size: int = 217488) -> "BackboneConfig":
         return BackboneConfig(vocab_size=vocab_size)
+
+    @staticmethod
+    def neutts_nano_like(vocab_size: int = 142080) -> "BackboneConfig":
+        """A geometry with NeuTTS-Nano's published parameter counts (ref:README.md:44-45: ~120 M active, ~229 M with the
+        embedding).  The checkpoint's config.json cannot be fetched offline, so this is an ASSUMED shape, chosen to satisfy
+        both numbers with the engine's head_dim of 64: hidden 768, 19 layers, 12 query / 4 kv heads, FFN 2048
+        (19 x 6.29 M = 119.6 M) and 142 080 x 768 = 109.1 M tied embedding weights."""
+        return BackboneConfig(vocab_size=vocab_size, hidden_size=768, intermediate_size=2048, num_layers=19, num_heads=12,
+                              num_kv_heads=4, head_dim=64)
 
     @staticmethod
     def tiny(vocab_size: int = 1024, num_layers: int = 2) -> "BackboneConfig":
@@ -76,18 +87,55 @@ def make_weights(cfg: BackboneConfig, seed: int = 0, init: str = "unit",
         p = f"model.layers.{i}."
         w[p + "input_layernorm.weight"] = 1.0 + normal(H, s=0.1)
         w[p + "self_attn.q_proj.weight"] = mat(nh * d, H)
-        w[p + "self_attn.q_proj.bias"] = normal(nh * d)
         w[p + "self_attn.k_proj.weight"] = mat(nkv * d, H)
-        w[p + "self_attn.k_proj.bias"] = normal(nkv * d)
         w[p + "self_attn.v_proj.weight"] = mat(nkv * d, H)
-        w[p + "self_attn.v_proj.bias"] = normal(nkv * d)
+        if cfg.attention_bias:
+            w[p + "self_attn.q_proj.bias"] = normal(nh * d)
+            w[p + "self_attn.k_proj.bias"] = normal(nkv * d)
+            w[p + "self_attn.v_proj.bias"] = normal(nkv * d)
         w[p + "self_attn.o_proj.weight"] = mat(H, nh * d)
         w[p + "post_attention_layernorm.weight"] = 1.0 + normal(H, s=0.1)
         w[p + "mlp.gate_proj.weight"] = mat(F_, H)
         w[p + "mlp.up_proj.weight"] = mat(F_, H)
         w[p + "mlp.down_proj.weight"] = mat(H, F_)
     w["model.norm.weight"] = 1.0 + normal(H, s=0.1)
+    if not cfg.tie_word_embeddings:
+        head = normal(cfg.vocab_size, H)
+        if peak_sigma > 0:
+            head = head * torch.from_numpy(np.exp(rng.standard_normal(cfg.vocab_size, dtype=np.float32) * np.float32(peak_sigma)))[:, None]
+        w["lm_head.weight"] = head
     return w
+
+
+# --------------------------------------------------------------------------------------
+# fp8 model variant (static activation scales): plain data, like the weights
+# --------------------------------------------------------------------------------------
+FP8_MAX = 448.0
+FP8_LINEARS = ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj")
+
+
+def fp8_input_scale_names(cfg: BackboneConfig) -> List[str]:
+    names = ["lm_head.input_scale"]
+    for i in range(cfg.num_layers):
+        names += [f"model.layers.{i}.{t}.input_scale" for t in ("self_attn.q_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.down_proj")]
+    return names
+
+
+def default_fp8_input_scales(cfg: BackboneConfig, norm_out: float = 2.0 ** -5, attn_out: float = 2.0 ** -8,
+                             mlp_act: float = 2.0 ** -6) -> Dict[str, float]:
+    """Static per-tensor activation scales for the SYNTHETIC weights of make_weights(init="unit") (a real static-fp8
+    checkpoint ships calibrated `input_scale` tensors).  e4m3 is a floating-point format -- 3 mantissa bits over
+    [2^-6, 448] x scale -- so a power-of-two scale only has to place the bulk of the distribution inside that window:
+    RMSNorm outputs are O(1) (window 4.9e-4 .. 14), attention outputs of these weights O(0.1) (6e-5 .. 1.75), the
+    SiLU(gate) * up products O(0.1 .. 1) (2.4e-4 .. 7).  tests/test_oracle_fp8.py checks the clipped fraction."""
+    out = {"lm_head.input_scale": norm_out}
+    for i in range(cfg.num_layers):
+        p = f"model.layers.{i}."
+        out[p + "self_attn.q_proj.input_scale"] = norm_out
+        out[p + "self_attn.o_proj.input_scale"] = attn_out
+        out[p + "mlp.gate_proj.input_scale"] = norm_out
+        out[p + "mlp.down_proj.input_scale"] = mlp_act
+    return out
 
 
 def cast_weights(w: Dict[str, torch.Tensor], dtype: torch.dtype) -> Dict[str, torch.Tensor]:

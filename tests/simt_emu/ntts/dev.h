@@ -112,6 +112,65 @@ inline f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return out;
 }
 
+// ---- fp8 e4m3fn (OCP): 1 sign, 4 exponent (bias 7), 3 mantissa bits; 0x7f = NaN, max finite 448, subnormals 2^-9 .. 7 * 2^-9
+typedef __attribute__((ext_vector_type(2))) long i64x2;
+constexpr float kFp8Max = 448.0f;
+inline float fp82f(unsigned char v) {
+    const int s = v >> 7, e = (v >> 3) & 15, m = v & 7;
+    float r;
+    if (e == 15 && m == 7) r = NAN;
+    else if (e == 0) r = ldexpf((float)m, -9);
+    else r = ldexpf(1.0f + m / 8.0f, e - 7);
+    return s ? -r : r;
+}
+inline unsigned char f2fp8(float f) {       // round-to-nearest-even, input clamped to +-448 by the caller
+    if (f != f) return 0x7f;
+    const unsigned char s = signbit(f) ? 0x80 : 0;
+    float a = fabsf(f);
+    if (a > kFp8Max) a = kFp8Max;
+    if (a < ldexpf(1.0f, -6)) {             // subnormal range: multiples of 2^-9
+        const float q = nearbyintf(ldexpf(a, 9));      // default rounding mode = to nearest even
+        return s | (unsigned char)q;        // q == 8 is exactly the smallest normal (e = 1, m = 0) = 0x08
+    }
+    int ex;
+    const float fr = frexpf(a, &ex);        // a = fr * 2^ex, fr in [0.5, 1)
+    float mant = nearbyintf(ldexpf(fr, 4)); // 1.mmm scaled to [8, 16]
+    int e = ex - 1 + 7;
+    if (mant == 16.0f) { mant = 8.0f; e += 1; }
+    if (e > 15 || (e == 15 && mant > 14.0f)) return s | 0x7e;   // 448
+    return s | (unsigned char)((e << 3) | ((int)mant - 8));
+}
+inline unsigned short f2fp8x2(float a, float b) {
+    a = fminf(fmaxf(a, -kFp8Max), kFp8Max);
+    b = fminf(fmaxf(b, -kFp8Max), kFp8Max);
+    return (unsigned short)(f2fp8(a) | (f2fp8(b) << 8));
+}
+inline unsigned char f2fp8c(float a) { return (unsigned char)(f2fp8x2(a, 0.f) & 0xff); }
+// v_mfma_f32_16x16x32_fp8_fp8: same lane layout as mfma16 with 8 e4m3 bytes per lane (k ascending, fp32 accumulate)
+inline f32x4 mfma16_fp8(long a, long b, f32x4 c) {
+    struct Dep { long a, b; };
+    int p = emu::wave_parity();
+    auto& s = emu::wave_slots();
+    Dep d{a, b};
+    memcpy(s.b[p][lane_id()], &d, sizeof(d));
+    emu::wave_sync();
+    int l = lane_id(), col = l & 15, rg = l >> 4;
+    f32x4 out = c;
+    for (int r = 0; r < 4; ++r) {
+        int row = rg * 4 + r;
+        float acc = c[r];
+        for (int kg = 0; kg < 4; ++kg) {
+            Dep da, db;
+            memcpy(&da, s.b[p][row + 16 * kg], sizeof(Dep));
+            memcpy(&db, s.b[p][col + 16 * kg], sizeof(Dep));
+            for (int j = 0; j < 8; ++j)
+                acc += fp82f((unsigned char)(da.a >> (8 * j))) * fp82f((unsigned char)(db.b >> (8 * j)));
+        }
+        out[r] = acc;
+    }
+    return out;
+}
+
 inline float shfl_xor(float v, int m) { return emu_exchange(v, lane_id() ^ m); }
 inline int shfl_xor(int v, int m) { return emu_exchange(v, lane_id() ^ m); }
 inline float shfl(float v, int src) { return emu_exchange(v, src); }
@@ -133,6 +192,7 @@ inline void glds16(const void* gsrc, void* lds_wave_base) {
     memcpy((char*)d0.l + lane_id() * 16, gsrc, 16);
 }
 inline void glds16_nt(const void* gsrc, void* lds_wave_base) { glds16(gsrc, lds_wave_base); }
+inline unsigned int atomic_add_global(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = o + v; return o; }
 inline unsigned int atomic_add_lds(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = o + v; return o; }
 NTTS_D unsigned long long now_ticks() { return 0; }   // no clock on the emulator
 inline void wait_vmem() {}

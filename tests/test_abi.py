@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
 
 def test_binding_covers_header(hip_lib):
     lib = _hip.load_library(hip_lib)   # sets argtypes for every bound symbol; raises on drift
-    assert lib.ntts_abi_version() == 1
+    assert lib.ntts_abi_version() == _hip.ABI_VERSION
 
 
 def test_no_cpu_fallback(hip_lib):
