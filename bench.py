@@ -112,10 +112,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=256, help="utterances per GPU")
+    ap.add_argument("--config", choices=["air-bf16", "nano-fp8", "nano-bf16"], default="air-bf16",
+                    help="air-bf16: NeuTTS-Air bf16 (BASELINE.json configs[1..3], the headline metric); nano-fp8: the assumed NeuTTS-Nano "
+                         "geometry with fp8 weights / GEMM inputs, batch 512 (configs[4])")
+    ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default 256; 512 for --config nano-fp8)")
     ap.add_argument("--prefill", type=int, default=500)
     ap.add_argument("--decode", type=int, default=250)
-    ap.add_argument("--vocab", type=int, default=217488)
+    ap.add_argument("--vocab", type=int, default=None, help="default: 217488 (NeuTTS-Air), 142080 (assumed Nano)")
     ap.add_argument("--prefill-chunk", type=int, default=64, help="prompts per prefill call")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -153,7 +156,17 @@ def main():
     spec.loader.exec_module(bmod)
     lib = emu_lib or bmod.build(verbose=False)
 
-    cfg = syn.BackboneConfig.tiny(vocab_size=512, num_layers=1) if a.tiny else syn.BackboneConfig.neutts_air(a.vocab)
+    nano = a.config.startswith("nano")          # the assumed Nano geometry
+    fp8 = a.config == "nano-fp8"
+    if a.batch is None:
+        a.batch = 512 if nano else 256
+    if a.tiny:
+        cfg = syn.BackboneConfig.tiny(vocab_size=512, num_layers=1)
+    elif nano:
+        cfg = syn.BackboneConfig.neutts_nano_like(a.vocab or 142080)
+    else:
+        cfg = syn.BackboneConfig.neutts_air(a.vocab or 217488)
+    fp8_scales = syn.default_fp8_input_scales(cfg) if fp8 else None
     ccfg = syn.CodecConfig.tiny() if a.tiny else syn.CodecConfig.neucodec()
     n_codes = int(np.prod(ccfg.levels))
     B, S, N = a.batch, a.prefill, a.decode
@@ -162,7 +175,7 @@ def main():
                                    intermediate_size=cfg.intermediate_size, num_layers=cfg.num_layers,
                                    num_heads=cfg.num_heads, num_kv_heads=cfg.num_kv_heads, rms_eps=cfg.rms_eps,
                                    max_context=((S + N + 31) // 32) * 32, max_batch=B,
-                                   max_prefill_tokens=a.prefill_chunk * S), dev, lib)
+                                   max_prefill_tokens=a.prefill_chunk * S, weight_dtype="fp8" if fp8 else "bf16"), dev, lib)
     codec = None
     if not a.no_codec:
         codec = _hip.CodecEngine(dict(hidden_size=ccfg.hidden_size, intermediate_size=ccfg.intermediate_size,
@@ -174,7 +187,7 @@ def main():
     t0 = time.time()
     if rank == 0:
         w = syn.make_weights(cfg, 0)           # synthetic N(0,1/fan_in) weights at the exact NeuTTS-Air shapes
-        eng.load_state_dict({k: v.numpy() for k, v in w.items()}, inv_freq=syn.rope_inv_freq(cfg).numpy())
+        eng.load_state_dict({k: v.numpy() for k, v in w.items()}, inv_freq=syn.rope_inv_freq(cfg).numpy(), input_scales=fp8_scales)
         cw = syn.make_codec_weights(ccfg, 0)         # synthetic NeuCodec-decoder weights (xcodec2 parameter names)
     if world > 1:
         tdev = torch.device("cpu") if emu_lib else None
@@ -268,7 +281,9 @@ def main():
         _, name, ms, nbytes, nl = rows[0]
         ach = nbytes / (ms * 1e-3) / 1e9
         traffic, traffic_src = None, None
-        try:   # HBM bytes per launch from the committed PMC pass (tools/gpu_round.sh pmc -> tools/pmc_to_json.py)
+        try:   # HBM bytes per launch from the committed PMC pass (tools/gpu_round.sh pmc -> tools/pmc_to_json.py): this configuration only
+            if nano or B != 256 or S != 500:
+                raise OSError("no PMC pass for this configuration")
             with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
                 pm = json.load(fh)
             for kname, rec in pm["kernels"].items():
@@ -296,15 +311,21 @@ def main():
         value = tokens / dt
         stages = "backbone prefill + decode loop" + (" + NeuCodec decoder to 24 kHz waveform (D2H included)"
                                                      if codec is not None else " (codec skipped: --no-codec)")
+        if nano:
+            workload = (f"NeuTTS-Nano (ASSUMED geometry: hidden {cfg.hidden_size}, {cfg.num_layers} layers, {cfg.num_heads}:{cfg.num_kv_heads} "
+                        f"heads, FFN {cfg.intermediate_size}, V {cfg.vocab_size}) "
+                        + ("fp8 e4m3 weights + GEMM inputs on the fp8 MFMA, bf16 KV / attention, " if fp8 else "bf16, ")
+                        + f"{world}xMI355X batch={B}, {S} prefill / {N} decode tokens, greedy (BASELINE.json configs[4])")
+        elif B == 1 and world == 1:
+            workload = f"NeuTTS-Air bf16 1xMI355X, batch=1, {S} prefill / {N} decode tokens, greedy (BASELINE.json configs[1])"
+        else:
+            workload = (f"NeuTTS-Air bf16 {world}xMI355X batch={B} synthetic prompts per GPU, {S} prefill / {N} decode tokens, greedy, "
+                        f"continuous-batching engine + hipGraph decode (BASELINE.json configs[{2 if world == 1 else 3}])")
         rec = {
             "metric": "codec-tokens/s", "value": value, "unit": "codec-tokens/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": (f"NeuTTS-Air bf16 1xMI355X, batch=1, {S} prefill / {N} decode tokens, greedy "
-                                    "(BASELINE.json configs[1])" if B == 1 and world == 1 else
-                                    f"NeuTTS-Air bf16 {world}xMI355X batch={B} synthetic prompts per GPU, {S} prefill / {N} decode "
-                                    "tokens, greedy, continuous-batching engine + hipGraph decode "
-                                    f"(BASELINE.json configs[{2 if world == 1 else 3}])"),
+            "vs_baseline": None, "dtype": "fp8" if fp8 else "bf16", "data": "synthetic",
+            "config": {"workload": workload,
                        "batch_per_gpu": B, "prefill_tokens": S, "decode_tokens": N, "vocab_size": cfg.vocab_size,
                        "stages": stages,
                        "parallelism": f"independent shards x{world}, RCCL weight broadcast only"},

@@ -249,6 +249,12 @@ int ntts_codec_last_timing(ntts_codec* c, float* ms);
  * variant: 0 = auto, 1 = 128x128 tile, 2 = 64x64 tile, 3 = 64x64 split-K slabs + reduce, 4 = 256x256 tile. */
 int ntts_k_gemm_bf16(const void* A, int64_t lda, const void* W, const void* bias, void* C, int64_t ldc,
                      int32_t M, int32_t N, int32_t K, int32_t variant);
+/* fp8 probes (tests): out[i] = e4m3(clamp(in[i] * inv_scale, +-448)), round-to-nearest-even -- the conversion every fp8
+ * producer on the path uses; and C[M,N] = bf16(fma(A[M,K] . W[N,K]^T, xscale * wscale[n], bias[n])) with e4m3 BYTE operands
+ * (row-major, K % 128 == 0) on v_mfma_f32_16x16x32_fp8_fp8.  variant: 2 = 64x64 tile, 4 = 256x256, else 128x128. */
+int ntts_k_fp8_quantize(const float* in_dev, void* out_dev, int64_t n, float inv_scale);
+int ntts_k_gemm_fp8(const void* A, const void* W, const float* wscale, float xscale, const void* bias, void* C,
+                    int32_t M, int32_t N, int32_t K, int32_t variant);
 /* y = rmsnorm(x) * w with Qwen2RMSNorm's rounding (hf:models/qwen2/modeling_qwen2.py:247-252). */
 int ntts_k_rmsnorm_bf16(const void* x, const void* w, void* y, int32_t rows, int32_t cols, float eps);
 /* Micro-benchmark of one GEMM tile configuration on synthetic operands (tools/ubench_gemm.py); see csrc/kapi.cpp. */

@@ -37,6 +37,31 @@ extern "C" int ntts_k_gemm_bf16(const void* A, int64_t lda, const void* W, const
     return hipGetLastError() == hipSuccess ? NTTS_OK : NTTS_EHIP;
 }
 
+// ---- fp8 probes: the conversion the producers use, and one fp8 GEMM (row-major e4m3 operands), for tests against torch
+NTTS_KERNEL(256) void fp8_quantize_kernel(const float* in, unsigned char* out, long n, float inv_scale) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i + 1 < n) { const unsigned short q = f2fp8x2(in[i] * inv_scale, in[i + 1] * inv_scale); out[i] = (unsigned char)(q & 0xff); out[i + 1] = (unsigned char)(q >> 8); }
+    else if (i < n) out[i] = f2fp8c(in[i] * inv_scale);
+}
+extern "C" int ntts_k_fp8_quantize(const float* in_dev, void* out_dev, int64_t n, float inv_scale) {
+    if (!in_dev || !out_dev || n < 1) return NTTS_EINVAL;
+    NTTS_LAUNCH((fp8_quantize_kernel), dim3((unsigned)((n + 511) / 512)), dim3(256), (hipStream_t)0, in_dev, (unsigned char*)out_dev, (long)n, inv_scale);
+    if (hipDeviceSynchronize() != hipSuccess) return NTTS_EHIP;
+    return hipGetLastError() == hipSuccess ? NTTS_OK : NTTS_EHIP;
+}
+extern "C" int ntts_k_gemm_fp8(const void* A, const void* W, const float* wscale, float xscale, const void* bias, void* C,
+                               int32_t M, int32_t N, int32_t K, int32_t variant) {
+    if (!A || !W || !wscale || !C || M < 1 || N < 1 || K < 128 || (K % 128) || (N % 8)) return NTTS_EINVAL;
+    GemmArgs a{};
+    a.X = (const bf16_t*)A; a.ldx = K; a.W = (const bf16_t*)W; a.ldw = K; a.bias = (const bf16_t*)bias;
+    a.out = C; a.ldo = N; a.M = M; a.N = N; a.K = K; a.wscale = wscale; a.xscale = xscale;
+    if (variant == 2) gemm_launch<4, 1, 1, EPI_BF16, 4, 0, 64, false, true>(a, 1, (hipStream_t)0);          // 64 x 64
+    else if (variant == 4) gemm_launch<4, 4, 4, EPI_BF16, 2, 0, 64, false, true>(a, 1, (hipStream_t)0);     // 256 x 256
+    else gemm_launch<2, 2, 4, EPI_BF16, 2, 0, 64, false, true>(a, 1, (hipStream_t)0);                       // 128 x 128
+    if (hipDeviceSynchronize() != hipSuccess) return NTTS_EHIP;
+    return hipGetLastError() == hipSuccess ? NTTS_OK : NTTS_EHIP;
+}
+
 extern "C" int ntts_k_rmsnorm_bf16(const void* x, const void* w, void* y, int32_t rows, int32_t cols, float eps) {
     if (!x || !w || !y || rows < 1 || cols < 8 || (cols % 8) || cols > 2048) return NTTS_EINVAL;
     NormArgs n{};

@@ -86,13 +86,10 @@ def make_weights(cfg: BackboneConfig, seed: int = 0, init: str = "unit",
     for i in range(cfg.num_layers):
         p = f"model.layers.{i}."
         w[p + "input_layernorm.weight"] = 1.0 + normal(H, s=0.1)
-        w[p + "self_attn.q_proj.weight"] = mat(nh * d, H)
-        w[p + "self_attn.k_proj.weight"] = mat(nkv * d, H)
-        w[p + "self_attn.v_proj.weight"] = mat(nkv * d, H)
-        if cfg.attention_bias:
-            w[p + "self_attn.q_proj.bias"] = normal(nh * d)
-            w[p + "self_attn.k_proj.bias"] = normal(nkv * d)
-            w[p + "self_attn.v_proj.bias"] = normal(nkv * d)
+        for name, rows in (("q_proj", nh * d), ("k_proj", nkv * d), ("v_proj", nkv * d)):   # (draw order is part of the fixtures)
+            w[p + f"self_attn.{name}.weight"] = mat(rows, H)
+            if cfg.attention_bias:
+                w[p + f"self_attn.{name}.bias"] = normal(rows)
         w[p + "self_attn.o_proj.weight"] = mat(H, nh * d)
         w[p + "post_attention_layernorm.weight"] = 1.0 + normal(H, s=0.1)
         w[p + "mlp.gate_proj.weight"] = mat(F_, H)

@@ -81,3 +81,66 @@ def test_mfma_probe_emu(emu_lib):
     out = torch.zeros(3 * 64 * 4)
     assert lib.ntts_k_mfma_probe(C.c_void_p(out.data_ptr())) == 0
     assert np.array_equal(out.numpy().reshape(3, 64, 4), mfma_probe_expected())
+
+
+# ---------------------------------------------------------------------------------------------- fp8 probes
+def fp8_quantize_case(lib_path):
+    """e4m3 conversion of the fp8 producers vs torch's float8_e4m3fn cast (RNE; inputs clamped to +-448 like the kernels do):
+    every e4m3 value, every midpoint between neighbours (ties), subnormals, overflow, and random values."""
+    import ctypes as C
+    lib = _hip.load_library(lib_path)
+    allv = torch.arange(256, dtype=torch.uint8).view(torch.float8_e4m3fn).to(torch.float32)
+    allv = allv[torch.isfinite(allv)]
+    srt = torch.sort(allv).values
+    mids = (srt[:-1] + srt[1:]) / 2
+    g = torch.Generator().manual_seed(5)
+    rnd = torch.randn(4096, generator=g) * torch.exp(torch.randn(4096, generator=g) * 3)
+    x = torch.cat([allv, mids, mids * (1 + 2.0 ** -20), mids * (1 - 2.0 ** -20), torch.tensor([500.0, -1e9, 464.0, 465.0, 1e-12, -0.0]), rnd])
+    for inv in (1.0, 16.0, 2.0 ** -3):
+        want = (x * inv).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+        dev = "cuda" if torch.cuda.is_available() and "emu" not in lib_path else "cpu"
+        xd = x.to(dev).contiguous()
+        out = torch.empty(x.numel(), dtype=torch.uint8, device=dev)
+        assert lib.ntts_k_fp8_quantize(C.c_void_p(xd.data_ptr()), C.c_void_p(out.data_ptr()), x.numel(), inv) == 0
+        got = out.cpu()
+        same = (got == want) | ((got & 0x7f) == 0) & ((want & 0x7f) == 0)       # +0 / -0 are the same value
+        assert bool(same.all()), [(float(x[i] * inv), int(got[i]), int(want[i])) for i in torch.nonzero(~same)[:8, 0]]
+
+
+def fp8_gemm_case(lib_path, M, N, K, variant, has_bias):
+    """one fp8 GEMM (all three tile shapes) vs torch on the same e4m3 values: acc in fp32, fma(acc, xs * ws[n], bias), bf16."""
+    import ctypes as C
+    lib = _hip.load_library(lib_path)
+    dev = "cuda" if torch.cuda.is_available() and "emu" not in lib_path else "cpu"
+    g = torch.Generator().manual_seed(M * 1000 + N + K)
+    xq = (torch.randn(M, K, generator=g) * 4).clamp(-448, 448).to(torch.float8_e4m3fn)
+    wq = (torch.randn(N, K, generator=g) * 32).clamp(-448, 448).to(torch.float8_e4m3fn)
+    ws = torch.rand(N, generator=g) * 0.01 + 0.001
+    xs = 0.0625
+    b = _bf16(torch.randn(N, generator=g)) if has_bias else None
+    acc = xq.float() @ wq.float().t()
+    ref = acc.double() * (torch.tensor(xs, dtype=torch.float32) * ws).double() + (b.float().double() if b is not None else 0)
+    ref = ref.float().to(torch.bfloat16)
+    xd, wd, sd = xq.view(torch.uint8).to(dev), wq.view(torch.uint8).to(dev), ws.to(dev)
+    bd = b.to(dev) if b is not None else None
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    assert lib.ntts_k_gemm_fp8(C.c_void_p(xd.data_ptr()), C.c_void_p(wd.data_ptr()), C.c_void_p(sd.data_ptr()), xs,
+                               C.c_void_p(bd.data_ptr()) if bd is not None else None, C.c_void_p(out.data_ptr()), M, N, K, variant) == 0
+    got = out.float().cpu()
+    err = (got - ref.float()).abs()
+    # one bf16 ulp of the result + the matrix core's own accumulation error, which is relative to the ADDENDS, not to the
+    # (possibly cancelling) sum: the fp8 MFMA does not accumulate like an fp32 fma chain (measured on MI355X against an fp64
+    # reference: mean 0.26 bf16 ulps = the rounding floor, but up to 10^3 ulps where |sum| << sum of |products|)
+    mag = (xq.float().abs() @ wq.float().abs().t()) * (xs * ws)[None, :]
+    tol = 2.0 ** -7 * ref.float().abs() + 2.0 ** -16 * mag
+    print(f"fp8 gemm {M}x{N}x{K}: max err / addend magnitude {float((err / mag).max()):.2e}, elements beyond one bf16 ulp {int((err > 2.0 ** -7 * ref.float().abs()).sum())}")
+    assert bool((err <= tol).all()), (float(err.max()), int((err > tol).sum()), float((err / mag).max()))
+
+
+def test_fp8_quantize_emu(emu_lib):
+    fp8_quantize_case(emu_lib)
+
+
+@pytest.mark.parametrize("M,N,K,variant,has_bias", [(70, 200, 256, 1, True), (5, 64, 128, 2, False), (300, 272, 384, 4, True)])
+def test_fp8_gemm_emu(emu_lib, M, N, K, variant, has_bias):
+    fp8_gemm_case(emu_lib, M, N, K, variant, has_bias)

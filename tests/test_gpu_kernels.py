@@ -76,3 +76,15 @@ def test_hbm_copy_bandwidth(lib):
     gbps = C.c_double()
     assert lib.ntts_k_membw(1 << 30, 10, C.byref(gbps)) == 0
     assert gbps.value > 2000, f"HBM copy only {gbps.value:.0f} GB/s"
+
+
+def test_fp8_quantize(lib, hip_lib):
+    from test_emu_kernels import fp8_quantize_case
+    fp8_quantize_case(hip_lib)
+
+
+@pytest.mark.parametrize("M,N,K,variant,has_bias", [(70, 200, 256, 1, True), (5, 64, 128, 2, False), (300, 272, 384, 4, True),
+                                                    (256, 1280, 768, 2, True), (2000, 4096, 768, 4, False), (256, 768, 2048, 1, False)])
+def test_fp8_gemm(lib, hip_lib, M, N, K, variant, has_bias):
+    from test_emu_kernels import fp8_gemm_case
+    fp8_gemm_case(hip_lib, M, N, K, variant, has_bias)
