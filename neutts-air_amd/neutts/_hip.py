@@ -379,6 +379,15 @@ class BackboneEngine:
                                  f"({len(p)}, {sp.max_length}, {self.max_context})")
             if len(p) > budget:
                 raise ValueError(f"prompt {i}: {len(p)} tokens exceed max_prefill_tokens {budget}")
+        # KV admission control: a request is admitted only if the pool can hold it up to ITS max_length next to everything
+        # already running (pages are allocated as the sequence grows; without the reservation two admitted requests could
+        # starve each other in the middle of decoding)
+        total_pages = self.kv_stats()["total_pages"]
+        need_pages = [(sp.max_length - 1 + NTTS_PAGE_TOKENS - 1) // NTTS_PAGE_TOKENS for sp in sampling]
+        for i, n in enumerate(need_pages):
+            if n > total_pages:
+                raise NeuTTSHipError(-3, f"prompt {i}: max_length {sampling[i].max_length} needs {n} KV pages, the pool has {total_pages}")
+        committed: Dict[int, int] = {}                      # slot -> pages reserved for it
         results: List[Optional[List[int]]] = [None] * len(prompts)
         owner: Dict[int, int] = {}
         anchors: List[tuple] = []       # (slot, prompt as int32 array) of live slots that later prompts are compared with
@@ -405,9 +414,10 @@ class BackboneEngine:
                     while nxt < len(prompts) and self._free:
                         d = find_donor(nxt) if share_prefix else None
                         cost = len(prompts[nxt]) - (d[1] // NTTS_PAGE_TOKENS * NTTS_PAGE_TOKENS if d else 0)
-                        if used + cost > budget:
+                        if used + cost > budget or sum(committed.values()) + need_pages[nxt] > total_pages:
                             break
                         s = self.acquire_slot()
+                        committed[s] = need_pages[nxt]
                         batch.append((nxt, s))
                         donors.append(d)
                         used += cost
@@ -428,6 +438,7 @@ class BackboneEngine:
                         # ones finish and free their pages, then try again
                         for i, s in reversed(batch):
                             owner.pop(s)
+                            committed.pop(s, None)
                             anchors = [a for a in anchors if a[0] != s]
                             self._free.append(s)
                         nxt = batch[0][0]
@@ -439,6 +450,7 @@ class BackboneEngine:
                     if st[s] == 2:  # finished
                         ids, _ = self.read(s)
                         results[owner.pop(s)] = ids
+                        committed.pop(s, None)
                         self.release(s)                          # shared pages live on until their last user is released
                         anchors = [a for a in anchors if a[0] != s]
                 if owner and any(st[s] == 1 for s in owner):

@@ -167,6 +167,7 @@ class NeuTTS:
             # "speech_base", "eos_token_id"}
             spec = backbone_repo
             cfg, sd, inv_freq = dict(spec["config"]), spec["state_dict"], spec["inv_freq"]
+            input_scales = spec.get("input_scales")          # fp8 model (config["weight_dtype"] = "fp8"): static activation scales
             self.tokenizer = spec.get("tokenizer")
             self._speech_base = spec.get("speech_base")
             self._eos_id = spec.get("eos_token_id")
@@ -178,13 +179,8 @@ class NeuTTS:
             from transformers import AutoConfig, AutoModelForCausalLM, AutoTokenizer  # checkpoint readers only
             self.tokenizer = AutoTokenizer.from_pretrained(backbone_repo)
             hc = AutoConfig.from_pretrained(backbone_repo)
-            if getattr(hc, "model_type", "") not in ("qwen2",):
-                raise NotImplementedError(f"backbone model_type {hc.model_type!r}: only the Qwen2 architecture "
-                                          "(NeuTTS-Air) is implemented")
-            cfg = dict(vocab_size=hc.vocab_size, hidden_size=hc.hidden_size, intermediate_size=hc.intermediate_size,
-                       num_layers=hc.num_hidden_layers, num_heads=hc.num_attention_heads,
-                       num_kv_heads=hc.num_key_value_heads, rms_eps=hc.rms_norm_eps,
-                       head_dim=getattr(hc, "head_dim", None) or hc.hidden_size // hc.num_attention_heads)
+            cfg = _engine_config_from_hf(hc)
+            input_scales = None
             sd = inv_freq = None
             shards = _safetensors_shards(backbone_repo)
             theta = _default_rope_theta(hc)
@@ -208,7 +204,7 @@ class NeuTTS:
         cfg["max_batch"] = self._max_batch
         cfg.setdefault("max_prefill_tokens", max(2 * self.max_context, 8192))
         self.backbone = _hip.BackboneEngine(cfg, dev, self._lib_path)
-        self.backbone.load_state_dict(sd, inv_freq=inv_freq)
+        self.backbone.load_state_dict(sd, inv_freq=inv_freq, input_scales=input_scales)
         self._vocab_size = cfg["vocab_size"]
 
     def _load_codec(self, codec_repo, codec_device):
@@ -501,6 +497,31 @@ class NeuTTS:
             eng.sync()
             for s in slots:
                 eng.release(s)
+
+
+def _engine_config_from_hf(hc) -> Dict[str, object]:
+    """AutoModelForCausalLM's dispatch (ref:neutts/neutts.py:164), restated for the decoder family the engine implements:
+    the pre-norm RoPE / GQA / SwiGLU decoder of Qwen2 (NeuTTS-Air) and Llama-style checkpoints (no q/k/v bias, possibly an
+    untied head).  Everything is read from config.json; what the kernels cannot do fails HERE with the reason, not later
+    with wrong audio."""
+    mt = getattr(hc, "model_type", "")
+    if mt not in ("qwen2", "llama", "mistral", "qwen3"):
+        raise NotImplementedError(f"backbone model_type {mt!r}: the MI355X engine implements the Qwen2 / Llama decoder "
+                                  "family (NeuTTS-Air is 'qwen2')")
+    if mt == "qwen3":
+        raise NotImplementedError("backbone model_type 'qwen3': per-head q/k RMSNorm (qk_norm) is not implemented by the engine")
+    head_dim = getattr(hc, "head_dim", None) or hc.hidden_size // hc.num_attention_heads
+    if head_dim != 64:
+        raise NotImplementedError(f"backbone head_dim {head_dim}: the attention kernels are built for head_dim 64")
+    if getattr(hc, "sliding_window", None) and getattr(hc, "use_sliding_window", False):
+        raise NotImplementedError("sliding-window attention is not implemented")
+    if getattr(hc, "mlp_bias", False):
+        raise NotImplementedError("MLP biases are not implemented")
+    return dict(vocab_size=hc.vocab_size, hidden_size=hc.hidden_size, intermediate_size=hc.intermediate_size,
+                num_layers=hc.num_hidden_layers, num_heads=hc.num_attention_heads,
+                num_kv_heads=getattr(hc, "num_key_value_heads", None) or hc.num_attention_heads, rms_eps=hc.rms_norm_eps,
+                head_dim=head_dim, tie_word_embeddings=bool(getattr(hc, "tie_word_embeddings", True)),
+                attention_bias=bool(getattr(hc, "attention_bias", mt == "qwen2")))
 
 
 def _to_list(codes) -> List[int]:

@@ -92,3 +92,54 @@ def test_checkpoint_dir_through_the_reference_loading_path(ckpt, emu_lib):
     assert tts._ids_to_codes(got) == [int(x) for x in re.findall(r"<\|speech_(\d+)\|>", s)]
     audio = tts.infer("Testing.", ref_codes, "So I'm live.")
     assert isinstance(audio, np.ndarray) and audio.dtype == np.float32 and len(audio) == tts.hop_length * len(tts._ids_to_codes(got))
+
+
+def test_llama_style_checkpoint_dispatch(tmp_path, emu_lib):
+    """The AutoModelForCausalLM dispatch of ref:neutts/neutts.py:164 beyond Qwen2: a Llama checkpoint (no q/k/v bias, UNTIED
+    lm_head -- `model_type: llama`, `tie_word_embeddings: false`, `attention_bias: false` in its config.json) saved by
+    transformers, loaded through `NeuTTS(backbone_repo=dir)`, gives the ids of transformers' own LlamaForCausalLM.generate
+    on that checkpoint (bf16, eager attention, greedy).  A `qwen3` config is refused with the reason."""
+    from transformers import AutoModelForCausalLM, LlamaConfig, LlamaForCausalLM
+    from neutts import NeuTTS
+    from neutts.neutts import _engine_config_from_hf
+    ccfg = cr.CodecConfig.tiny()
+    n_codes = int(np.prod(ccfg.levels))
+    tok = build_tokenizer(n_codes)
+    cfg = br.BackboneConfig(vocab_size=len(tok), hidden_size=448, intermediate_size=1216, num_layers=1, num_heads=7, num_kv_heads=1,
+                            attention_bias=False, tie_word_embeddings=False)
+    w = br.make_weights(cfg, 78, peak_sigma=0.5)
+    base = tok.convert_tokens_to_ids("<|speech_0|>")
+    w["lm_head.weight"][base:] *= 3.0
+    hc = LlamaConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                     num_hidden_layers=cfg.num_layers, num_attention_heads=cfg.num_heads, num_key_value_heads=cfg.num_kv_heads,
+                     head_dim=64, rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta, max_position_embeddings=2048,
+                     tie_word_embeddings=False, attention_bias=False, mlp_bias=False)
+    m = LlamaForCausalLM(hc).eval()
+    missing, unexpected = m.load_state_dict(w, strict=False)
+    assert not unexpected and all("inv_freq" in k for k in missing), (missing, unexpected)
+    d = str(tmp_path)
+    m.save_pretrained(d)
+    tok.save_pretrained(d)
+    cw = cr.make_weights(ccfg, 4)
+    tts = NeuTTS(backbone_repo=d, backbone_device="cuda",
+                 codec_repo=dict(config=dict(hidden_size=ccfg.hidden_size, intermediate_size=ccfg.intermediate_size,
+                                             num_layers=ccfg.num_layers, num_heads=ccfg.num_heads,
+                                             quantization_dim=ccfg.quantization_dim, levels=list(ccfg.levels),
+                                             hop_length=ccfg.hop_length, max_frames=256, max_rows=1024),
+                                 state_dict={k: v.numpy() for k, v in cw.items()}),
+                 codec_device="cuda", lib_path=emu_lib, do_sample=False)
+    assert tts.backbone.cfg["tie_word_embeddings"] is False and tts.backbone.cfg["attention_bias"] is False
+    prompt = [tok.convert_tokens_to_ids("<|SPEECH_GENERATION_START|>")] + [base + c for c in (3, 77, 200, 5, 18, 9)] + list(b"hello")
+    tts.max_context, tts.min_new_tokens = len(prompt) + 20, 6
+    hf = AutoModelForCausalLM.from_pretrained(d, attn_implementation="eager").to(torch.bfloat16).eval()
+    hf.model.rotary_emb.inv_freq = br.rope_inv_freq(cfg)
+    hf.model.rotary_emb.original_inv_freq = br.rope_inv_freq(cfg)
+    out = hf.generate(torch.tensor([prompt]), max_length=tts.max_context, eos_token_id=tts._eos_id, pad_token_id=tts._eos_id,
+                      do_sample=False, use_cache=True, min_new_tokens=6)
+    want = out[0, len(prompt):].tolist()
+    got = tts.generate_codes([prompt])[0]
+    n = min(len(got), len(want))
+    assert n >= 6 and got[:n] == want[:n] and abs(len(got) - len(want)) <= 1
+    from transformers import Qwen3Config
+    with pytest.raises(NotImplementedError, match="qk_norm"):
+        _engine_config_from_hf(Qwen3Config(hidden_size=448, num_attention_heads=7, num_key_value_heads=1, head_dim=64))

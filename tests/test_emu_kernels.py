@@ -129,11 +129,12 @@ def fp8_gemm_case(lib_path, M, N, K, variant, has_bias):
     got = out.float().cpu()
     err = (got - ref.float()).abs()
     # one bf16 ulp of the result + the matrix core's own accumulation error, which is relative to the ADDENDS, not to the
-    # (possibly cancelling) sum: the fp8 MFMA does not accumulate like an fp32 fma chain (measured on MI355X against an fp64
-    # reference: mean 0.26 bf16 ulps = the rounding floor, but up to 10^3 ulps where |sum| << sum of |products|)
+    # (possibly cancelling) sum: v_mfma_f32_16x16x32_fp8_fp8 is not an fp32 fma chain.  Probed on MI355X (tools/fp8_probe.py
+    # notes in DESIGN.md): small-integer operands come out exact, but inside one lane group's 8 products an addend below
+    # ~2^-17 of the largest is dropped (448*448 - 448*448 + 126 x 1*1 gives 120: the six 1's next to the big pair are lost).
     mag = (xq.float().abs() @ wq.float().abs().t()) * (xs * ws)[None, :]
-    tol = 2.0 ** -7 * ref.float().abs() + 2.0 ** -16 * mag
-    print(f"fp8 gemm {M}x{N}x{K}: max err / addend magnitude {float((err / mag).max()):.2e}, elements beyond one bf16 ulp {int((err > 2.0 ** -7 * ref.float().abs()).sum())}")
+    tol = 2.0 ** -7 * ref.float().abs() + 2.0 ** -13 * mag
+    print(f"fp8 gemm {M}x{N}x{K}: elements beyond one bf16 ulp of the result {int((err > 2.0 ** -7 * ref.float().abs()).sum())} of {err.numel()}")
     assert bool((err <= tol).all()), (float(err.max()), int((err > tol).sum()), float((err / mag).max()))
 
 
