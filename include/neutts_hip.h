@@ -106,6 +106,9 @@ int ntts_backbone_finalize(ntts_backbone* e);
  * finalize on the sender; a receiver calls ntts_backbone_adopt_arena() after the broadcast landed. */
 int ntts_backbone_arena(ntts_backbone* e, void** dev_ptr, size_t* bytes);
 int ntts_backbone_adopt_arena(ntts_backbone* e);
+/* The byte range of the arena that is derived from another part of it (the tied lm_head's own tile-major / fp8 copy of the
+ * embedding; *bytes = 0 if there is none): a broadcast may skip it, ntts_backbone_adopt_arena rebuilds it on the receiver. */
+int ntts_backbone_arena_derived(ntts_backbone* e, size_t* off, size_t* bytes);
 /* Device-to-device copy between the arena and a caller buffer of exactly the arena size (the staging
  * tensor torch.distributed broadcasts): to_arena = 0 arena -> buf, 1 buf -> arena.  Blocking. */
 int ntts_backbone_arena_copy(ntts_backbone* e, void* buf, size_t bytes, int to_arena);
@@ -165,6 +168,15 @@ int ntts_backbone_read(ntts_backbone* e, int32_t slot, int32_t* out_ids, int32_t
 int ntts_backbone_read_all(ntts_backbone* e, int32_t* out_ids, int32_t cap, int32_t* n_out, int32_t* finished);
 /* Blocking.  One int32 per slot: 0 free, 1 running, 2 finished; new-token counts in n_new (may be NULL). */
 int ntts_backbone_poll(ntts_backbone* e, int32_t* state, int32_t* n_new);
+/* The id -> code hand-off of ref:neutts/neutts.py:349 (tokenizer.decode) + :276 (regex over "<|speech_N|>") without leaving the
+ * device: for each of the `n` decode slots `slots[i]` (HOST array), the new ids that are speech tokens -- speech_base <= id <
+ * speech_base + n_codes -- are written in order as id - speech_base to codes_dev[i * stride ...] (DEVICE int32, at most `stride`
+ * per slot) and their count to lens_dev[i] (DEVICE).  modulo != 0 (synthetic benchmark only): every id becomes
+ * id mod n_codes.  Enqueued on the engine's stream (ntts_backbone_stream) behind the decode steps issued so far. */
+int ntts_backbone_export_codes(ntts_backbone* e, int32_t n, const int32_t* slots, int32_t speech_base, int32_t n_codes,
+                               int32_t modulo, int32_t* codes_dev, int32_t stride, int32_t* lens_dev);
+/* The engine's HIP stream (a hipStream_t), for a consumer that must order its own work behind the engine's. */
+int ntts_backbone_stream(ntts_backbone* e, void** stream);
 /* Return the slot's KV pages to the pool and mark it free. */
 int ntts_backbone_release(ntts_backbone* e, int32_t slot);
 int ntts_backbone_sync(ntts_backbone* e);
@@ -234,6 +246,14 @@ int ntts_codec_finalize(ntts_codec* c);
  * max(lens); the tail of a shorter row up to that length is scratch).  One strided D2H copy.  Blocking. */
 int ntts_codec_decode(ntts_codec* c, int32_t n, const int32_t* codes, const int32_t* lens, float* wav_out,
                       int64_t wav_stride);
+/* The same pass over codes that are already ON THE DEVICE (ntts_backbone_export_codes): utterance i's codes at
+ * codes_dev + i * codes_stride, lens[i] of them (`lens` is a HOST array: the launch geometry depends on it).  Asynchronous:
+ * the pass is ordered behind `producer_stream` (a hipStream_t, e.g. the backbone's; may be NULL), the waveforms are copied to
+ * wav_out -- a DEVICE buffer (wav_on_device != 0) or page-locked host memory -- on the codec's own stream, and the call
+ * returns once everything is enqueued; ntts_codec_sync() waits for it.  SURVEY.md 8b: device pointers + caller stream. */
+int ntts_codec_decode_dev(ntts_codec* c, int32_t n, const int32_t* codes_dev, int32_t codes_stride, const int32_t* lens,
+                          float* wav_out, int64_t wav_stride, int32_t wav_on_device, void* producer_stream);
+int ntts_codec_sync(ntts_codec* c);
 /* Page-locked host memory for wav_out: a pinned destination lets the D2H copy run at PCIe speed (pageable memory is
  * staged by the runtime at a fraction of it).  Plain malloc/free semantics; not tied to an engine. */
 int ntts_host_alloc(size_t bytes, void** out);

@@ -669,8 +669,27 @@ extern "C" int ntts_backbone_arena_copy(ntts_backbone* e, void* buf, size_t byte
     else HIPCHK(e, hipMemcpy(buf, e->arena, bytes, hipMemcpyDeviceToDevice));
     return NTTS_OK;
 }
+// The part of the arena that is DERIVED from another part: the tied head's own copy of the embedding (tile-major and / or fp8
+// with its scales).  A broadcast can skip [*off, *off + *bytes) and have the receiver rebuild it (ntts_backbone_adopt_arena does).
+extern "C" int ntts_backbone_arena_derived(ntts_backbone* e, size_t* off, size_t* bytes) {
+    if (!e || !off || !bytes) return NTTS_EINVAL;
+    *off = 0; *bytes = 0;
+    if (e->tied && e->embed_tm) {
+        const size_t V64 = (size_t)((e->cfg.vocab_size + 63) / 64) * 64;
+        *off = (size_t)((char*)e->embed_tm - (char*)e->arena);
+        *bytes = e->fp8 ? ((V64 * e->H + 1) / 2) * 2 : V64 * e->H * 2;     // the matrix (its fp8 scales follow and are rebuilt too)
+    }
+    return NTTS_OK;
+}
+
 extern "C" int ntts_backbone_adopt_arena(ntts_backbone* e) {
     if (!e) return NTTS_EINVAL;
+    if (e->tied && e->embed_tm) {   // rebuild the derived head copy from the (received) embedding: it need not travel
+        HIPCHK(e, hipSetDevice(e->device));
+        const int rc0 = put_weight(e, e->embed, NTTS_DT_BF16, 1, e->cfg.vocab_size, e->H, e->embed_tm, 0, nullptr, e->w_tile_major ? 1 : 0,
+                                   e->fp8 ? e->shead : nullptr);
+        if (rc0) return rc0;
+    }
     HIPCHK(e, hipSetDevice(e->device));
     const int rc = sync_input_scales(e, false);   // fp8: the launches need the input scales on the host
     if (rc) return rc;
@@ -1278,6 +1297,30 @@ extern "C" int ntts_backbone_read_all(ntts_backbone* e, int32_t* out_ids, int32_
         if (e->slots[b].state == SLOT_FREE) { st[b] = SLOT_FREE; n_out[b] = 0; }
         if (finished) finished[b] = st[b] == SLOT_FINISHED ? 1 : 0;
     }
+    return NTTS_OK;
+}
+
+extern "C" int ntts_backbone_stream(ntts_backbone* e, void** stream) {
+    if (!e || !stream) return NTTS_EINVAL;
+    *stream = (void*)e->stream;
+    return NTTS_OK;
+}
+
+extern "C" int ntts_backbone_export_codes(ntts_backbone* e, int32_t n, const int32_t* slots, int32_t speech_base, int32_t n_codes,
+                                          int32_t modulo, int32_t* codes_dev, int32_t stride, int32_t* lens_dev) {
+    if (!e || n < 1 || !slots || !codes_dev || !lens_dev || stride < 1 || n_codes < 1) return fail(e, NTTS_EINVAL, "bad argument");
+    if ((size_t)n > e->meta_cap) return fail(e, NTTS_EINVAL, "too many slots");
+    for (int i = 0; i < n; ++i)
+        if (slots[i] < 0 || slots[i] >= e->cfg.max_batch) return fail(e, NTTS_EINVAL, "slot %d out of range", slots[i]);
+    HIPCHK(e, hipSetDevice(e->device));
+    // the slot list travels through the engine's meta block: stream-ordered behind whatever still reads it
+    HIPCHK(e, hipMemcpyAsync(e->meta_dev, slots, (size_t)n * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));   // `slots` is pageable host memory (also: the decode steps before are done)
+    ExportCodesArgs a{};
+    a.slots = e->meta_dev; a.sl = e->sl; a.speech_base = speech_base; a.n_codes = n_codes; a.modulo = modulo;
+    a.codes = codes_dev; a.stride = stride; a.lens = lens_dev;
+    NTTS_LAUNCH((export_codes_kernel), dim3(n), dim3(256), e->stream, a);
+    HIPCHK(e, hipGetLastError());
     return NTTS_OK;
 }
 

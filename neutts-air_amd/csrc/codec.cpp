@@ -47,6 +47,7 @@ struct ntts_codec {
     size_t meta_cap = 0;
     size_t wav_cap = 0;
     hipEvent_t ev[2]{};
+    hipEvent_t ev_in = nullptr;   // orders a pass behind the stream that produced its device-side codes
     bool have_time = false;
 };
 
@@ -83,6 +84,7 @@ extern "C" void ntts_codec_destroy(ntts_codec* c) {
     for (void* p : c->allocs) hipFree(p);
     for (auto& e : c->ev)
         if (e) hipEventDestroy(e);
+    if (c->ev_in) hipEventDestroy(c->ev_in);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -112,7 +114,7 @@ extern "C" int ntts_codec_create(const ntts_codec_config* cf, int device, ntts_c
         delete c;
         return cfail(nullptr, NTTS_EHIP, "stream creation failed");
     }
-    hipEventCreate(&c->ev[0]); hipEventCreate(&c->ev[1]);
+    hipEventCreate(&c->ev[0]); hipEventCreate(&c->ev[1]); hipEventCreate(&c->ev_in);
     const size_t R = c->max_rows, H = c->H;
     const int npages_max = (cf->max_frames + kPage - 1) / kPage;
     const size_t max_utts = R / (1 + 2 * kPadRows) + 1;
@@ -339,9 +341,13 @@ static void resnet_block(ntts_codec* c, const ResW& w, const CodecRows& R, long 
     { GemmArgs ga_ = cg(c->xb, H, w.w2, 3L * H, w.cb2, c->h + H, H, rows - 2, H, c->h + H, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
 }
 
-extern "C" int ntts_codec_decode(ntts_codec* c, int32_t n, const int32_t* codes, const int32_t* lens, float* wav_out,
-                                 int64_t wav_stride) {
-    if (!c || n < 1 || !codes || !lens || !wav_out) return cfail(c, NTTS_EINVAL, "null/empty argument");
+// codes: HOST packed codes (codes_dev == null), or DEVICE codes, utterance i at codes_dev + i * codes_stride (already in range:
+// they come from ntts_backbone_export_codes).  out_kind: 0 = host destination, blocking (the classic entry point);
+// 1 = host destination (pinned), asynchronous; 2 = device destination, asynchronous.  producer: a HIP stream whose work so far
+// must complete before the codes are read (the backbone's stream), or null.
+static int codec_decode_impl(ntts_codec* c, int32_t n, const int32_t* codes, const int32_t* codes_dev, int32_t codes_stride,
+                             const int32_t* lens, float* wav_out, int64_t wav_stride, int out_kind, hipStream_t producer) {
+    if (!c || n < 1 || (!codes && !codes_dev) || !lens || !wav_out) return cfail(c, NTTS_EINVAL, "null/empty argument");
     if (!c->finalized) return cfail(c, NTTS_ESTATE, "weights not finalised");
     CHIP(c, hipSetDevice(c->device));
     const int H = c->H, hop = c->cfg.hop_length;
@@ -354,8 +360,10 @@ extern "C" int ntts_codec_decode(ntts_codec* c, int32_t n, const int32_t* codes,
         if (lens[i] > Tmax) Tmax = lens[i];
         total += lens[i];
     }
-    for (long i = 0; i < total; ++i)
-        if (codes[i] < 0 || codes[i] >= ncodes) return cfail(c, NTTS_EINVAL, "code %d out of range [0, %ld)", codes[i], ncodes);
+    if (codes)
+        for (long i = 0; i < total; ++i)
+            if (codes[i] < 0 || codes[i] >= ncodes) return cfail(c, NTTS_EINVAL, "code %d out of range [0, %ld)", codes[i], ncodes);
+    if (codes_dev && codes_stride < Tmax) return cfail(c, NTTS_EINVAL, "codes_stride %d < longest utterance %d", codes_stride, Tmax);
     if (wav_stride < (int64_t)hop * Tmax) return cfail(c, NTTS_EINVAL, "wav_stride %ld < %d samples", (long)wav_stride, hop * Tmax);
     const int Tp = Tmax + 2 * kPadRows;
     const long rows = (long)n * Tp;
@@ -363,20 +371,24 @@ extern "C" int ntts_codec_decode(ntts_codec* c, int32_t n, const int32_t* codes,
     const int npages = (Tmax + kPage - 1) / kPage, qtiles = (Tmax + 63) / 64;
     // ---- meta: [lens n][code_off n][codes total]
     std::vector<int> m;
-    m.reserve(2 * n + total);
+    m.reserve(2 * n + (codes ? total : 0));
     m.insert(m.end(), lens, lens + n);
     long off = 0;
-    for (int i = 0; i < n; ++i) { m.push_back((int)off); off += lens[i]; }
-    m.insert(m.end(), codes, codes + total);
+    for (int i = 0; i < n; ++i) { m.push_back(codes ? (int)off : i * codes_stride); off += lens[i]; }
+    if (codes) m.insert(m.end(), codes, codes + total);
     if (m.size() > c->meta_cap) return cfail(c, NTTS_EINVAL, "meta block too large");
     hipStream_t st = c->stream;
     CHIP(c, hipMemcpyAsync(c->meta, m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    CHIP(c, hipStreamSynchronize(st));
+    CHIP(c, hipStreamSynchronize(st));   // m is pageable host memory
+    if (producer) {                        // the codes are being written on another stream: order this pass behind it
+        CHIP(c, hipEventRecord(c->ev_in, producer));
+        CHIP(c, hipStreamWaitEvent(st, c->ev_in, 0));
+    }
     CodecRows R{c->meta, n, Tp};
     CHIP(c, hipEventRecord(c->ev[0], st));
 
     CodecEmbedArgs ea{};
-    ea.codes = c->meta + 2 * n; ea.code_off = c->meta + n; ea.wf = c->wf; ea.bf = c->bf; ea.out = c->xa; ea.R = R; ea.H = H; ea.nq = c->nq;
+    ea.codes = codes ? c->meta + 2 * n : codes_dev; ea.code_off = c->meta + n; ea.wf = c->wf; ea.bf = c->bf; ea.out = c->xa; ea.R = R; ea.H = H; ea.nq = c->nq;
     for (int i = 0; i < 8; ++i) ea.levels[i] = i < c->nq ? c->cfg.levels[i] : 1;
     NTTS_LAUNCH((codec_embed_kernel), dim3((unsigned)rows), dim3(256), st, ea);
     // stem Conv1d(k=7, padding 3): window rows r..r+6 -> centre row r+3
@@ -416,14 +428,44 @@ extern "C" int ntts_codec_decode(ntts_codec* c, int32_t n, const int32_t* codes,
     NTTS_LAUNCH((ola_kernel), dim3(n, (unsigned)(((long)hop * Tmax + 255) / 256)), dim3(256), st, oa);
     CHIP(c, hipEventRecord(c->ev[1], st));
     c->have_time = true;
-    CHIP(c, hipStreamSynchronize(st));
-    CHIP(c, hipGetLastError());
-    // one strided device-to-host copy for the whole batch (rows shorter than Tmax carry don't-care tails)
-    if (wav_stride == (int64_t)hop * Tmax)   // dense destination: one linear copy (DMA engine at PCIe speed into pinned memory)
-        CHIP(c, hipMemcpy(wav_out, c->wav, (size_t)n * hop * Tmax * sizeof(float), hipMemcpyDeviceToHost));
+    const hipMemcpyKind kind = out_kind == 2 ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (out_kind == 0) {
+        CHIP(c, hipStreamSynchronize(st));
+        CHIP(c, hipGetLastError());
+        // one strided device-to-host copy for the whole batch (rows shorter than Tmax carry don't-care tails)
+        if (wav_stride == (int64_t)hop * Tmax)   // dense destination: one linear copy (DMA engine at PCIe speed into pinned memory)
+            CHIP(c, hipMemcpy(wav_out, c->wav, (size_t)n * hop * Tmax * sizeof(float), kind));
+        else
+            CHIP(c, hipMemcpy2D(wav_out, (size_t)wav_stride * sizeof(float), c->wav, (size_t)hop * Tmax * sizeof(float),
+                                (size_t)hop * Tmax * sizeof(float), n, kind));
+        return NTTS_OK;
+    }
+    // asynchronous hand-over, stream-ordered behind the pass (ntts_codec_sync waits for it)
+    if (wav_stride == (int64_t)hop * Tmax)
+        CHIP(c, hipMemcpyAsync(wav_out, c->wav, (size_t)n * hop * Tmax * sizeof(float), kind, st));
     else
-        CHIP(c, hipMemcpy2D(wav_out, (size_t)wav_stride * sizeof(float), c->wav, (size_t)hop * Tmax * sizeof(float),
-                            (size_t)hop * Tmax * sizeof(float), n, hipMemcpyDeviceToHost));
+        CHIP(c, hipMemcpy2DAsync(wav_out, (size_t)wav_stride * sizeof(float), c->wav, (size_t)hop * Tmax * sizeof(float),
+                                 (size_t)hop * Tmax * sizeof(float), n, kind, st));
+    return NTTS_OK;
+}
+
+extern "C" int ntts_codec_decode(ntts_codec* c, int32_t n, const int32_t* codes, const int32_t* lens, float* wav_out,
+                                 int64_t wav_stride) {
+    if (!codes) return cfail(c, NTTS_EINVAL, "null/empty argument");
+    return codec_decode_impl(c, n, codes, nullptr, 0, lens, wav_out, wav_stride, 0, nullptr);
+}
+
+extern "C" int ntts_codec_decode_dev(ntts_codec* c, int32_t n, const int32_t* codes_dev, int32_t codes_stride, const int32_t* lens,
+                                     float* wav_out, int64_t wav_stride, int32_t wav_on_device, void* producer_stream) {
+    if (!codes_dev) return cfail(c, NTTS_EINVAL, "null/empty argument");
+    return codec_decode_impl(c, n, nullptr, codes_dev, codes_stride, lens, wav_out, wav_stride, wav_on_device ? 2 : 1, (hipStream_t)producer_stream);
+}
+
+extern "C" int ntts_codec_sync(ntts_codec* c) {
+    if (!c) return NTTS_EINVAL;
+    CHIP(c, hipSetDevice(c->device));
+    CHIP(c, hipStreamSynchronize(c->stream));
+    CHIP(c, hipGetLastError());
     return NTTS_OK;
 }
 

@@ -283,6 +283,47 @@ NTTS_KERNEL(256) void pack_weight_kernel(const void* src, int src_is_f32, bf16_t
     }
 }
 
+// ids -> codec codes on the device (ref:neutts/neutts.py:349 tokenizer.decode + :276 regex, as one pass): of slot s's new ids
+// keep those in [speech_base, speech_base + n_codes), as id - speech_base, in order; `modulo` (synthetic benchmark only: random
+// weights do not stay in the speech range) maps every id to id mod n_codes instead.  One workgroup per utterance.
+struct ExportCodesArgs {
+    const int* slots;       // [n] decode slots
+    SlotArrays sl;
+    int speech_base, n_codes, modulo;
+    int* codes;             // [n][stride]
+    int stride;
+    int* lens;              // [n] number of codes written
+};
+NTTS_KERNEL(256) void export_codes_kernel(ExportCodesArgs p) {
+    NTTS_SHARED int wcount[4];
+    NTTS_SHARED int base_s;
+    const int u = blockIdx.x, s = p.slots[u], tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int n = p.sl.n_new[s];
+    const int* ids = p.sl.out_tokens + (long)s * p.sl.out_stride;
+    if (tid == 0) base_s = 0;
+    sync();
+    for (int t0 = 0; t0 < n; t0 += 256) {      // order-preserving compaction, 256 ids per round
+        const int t = t0 + tid;
+        int code = -1;
+        if (t < n) {
+            const int id = ids[t];
+            if (p.modulo) code = id % p.n_codes;
+            else if (id >= p.speech_base && id < p.speech_base + p.n_codes) code = id - p.speech_base;
+        }
+        const unsigned long long m = ballot(code >= 0);
+        const int before = popc64(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wcount[w] = popc64(m);
+        sync();
+        int off = base_s;
+        for (int k = 0; k < w; ++k) off += wcount[k];
+        if (code >= 0 && off + before < p.stride) p.codes[(long)u * p.stride + off + before] = code;
+        sync();
+        if (tid == 0) base_s += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        sync();
+    }
+    if (tid == 0) p.lens[u] = base_s < p.stride ? base_s : p.stride;
+}
+
 // fp8 model: one source row -> e4m3 bytes + its scale.  The row is first rounded to bf16 (what the bf16 checkpoint holds), then
 // scale = max|w| / 448 (1 for an all-zero row), w_q = e4m3(w / scale) -- per output channel, as static-fp8 checkpoints store
 // them.  Layout of the byte matrix: tile-major in 64-row x 128-byte blocks (gemm.h F8).

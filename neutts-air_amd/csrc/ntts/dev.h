@@ -55,6 +55,9 @@ NTTS_D int shfl_xor(int v, int m) { return __shfl_xor(v, m, 64); }
 NTTS_D float shfl(float v, int src) { return __shfl(v, src, 64); }
 NTTS_D int shfl(int v, int src) { return __shfl(v, src, 64); }
 
+NTTS_D unsigned long long ballot(bool p) { return __ballot(p); }     // bit l = lane l's predicate (wave64)
+NTTS_D int popc64(unsigned long long m) { return __popcll(m); }
+
 NTTS_D void sync() { __syncthreads(); }
 
 // LDS-DMA: every lane supplies its own 16-byte global source; the wave's 64 pieces land at

@@ -80,6 +80,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_backbone_finalize": (C.c_int, [p]),
         "ntts_backbone_arena": (C.c_int, [p, C.POINTER(p), C.POINTER(C.c_size_t)]),
         "ntts_backbone_adopt_arena": (C.c_int, [p]),
+        "ntts_backbone_arena_derived": (C.c_int, [p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
         "ntts_backbone_arena_copy": (C.c_int, [p, p, C.c_size_t, C.c_int]),
         "ntts_backbone_time_kernel": (C.c_int, [p, i32, i32, C.POINTER(f32), C.POINTER(C.c_double), C.POINTER(i32)]),
         "ntts_backbone_prefill": (C.c_int, [p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(SamplingC)]),
@@ -91,6 +92,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_backbone_read_all": (C.c_int, [p, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(i32)]),
         "ntts_backbone_poll": (C.c_int, [p, C.POINTER(i32), C.POINTER(i32)]),
         "ntts_backbone_release": (C.c_int, [p, i32]),
+        "ntts_backbone_export_codes": (C.c_int, [p, i32, C.POINTER(i32), i32, i32, i32, p, i32, p]),
+        "ntts_backbone_stream": (C.c_int, [p, C.POINTER(p)]),
+        "ntts_codec_decode_dev": (C.c_int, [p, i32, p, i32, C.POINTER(i32), p, i64, i32, p]),
+        "ntts_codec_sync": (C.c_int, [p]),
         "ntts_backbone_sync": (C.c_int, [p]),
         "ntts_backbone_set_debug": (C.c_int, [p, i32]),
         "ntts_backbone_read_logits": (C.c_int, [p, i32, C.POINTER(f32), i32]),
@@ -236,6 +241,12 @@ class BackboneEngine:
         self._chk(self.lib.ntts_backbone_arena(self.h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    def arena_derived(self):
+        """(offset, bytes) of the arena range a broadcast may skip (rebuilt by adopt_arena on the receiver)."""
+        o, n = C.c_size_t(), C.c_size_t()
+        self._chk(self.lib.ntts_backbone_arena_derived(self.h, C.byref(o), C.byref(n)))
+        return o.value, n.value
+
     def arena_copy(self, buf_ptr: int, nbytes: int, to_arena: bool):
         self._chk(self.lib.ntts_backbone_arena_copy(self.h, C.c_void_p(buf_ptr), nbytes, int(to_arena)))
 
@@ -317,6 +328,20 @@ class BackboneEngine:
         i32p = C.POINTER(C.c_int32)
         self._chk(self.lib.ntts_backbone_poll(self.h, st.ctypes.data_as(i32p), nn.ctypes.data_as(i32p)))
         return st, nn
+
+    def stream(self) -> int:
+        st = C.c_void_p()
+        self._chk(self.lib.ntts_backbone_stream(self.h, C.byref(st)))
+        return st.value or 0
+
+    def export_codes(self, slots: Sequence[int], speech_base: int, n_codes: int, codes_dev_ptr: int, stride: int,
+                     lens_dev_ptr: int, modulo: bool = False):
+        """Device-side id -> code hand-off (ntts_backbone_export_codes): codes land in a caller-owned DEVICE int32 buffer
+        [len(slots), stride], their counts in a DEVICE int32 buffer [len(slots)]; asynchronous on the engine's stream."""
+        sl = np.ascontiguousarray(slots, dtype=np.int32)
+        self._chk(self.lib.ntts_backbone_export_codes(self.h, len(sl), sl.ctypes.data_as(C.POINTER(C.c_int32)), speech_base,
+                                                      n_codes, int(modulo), C.c_void_p(codes_dev_ptr), stride,
+                                                      C.c_void_p(lens_dev_ptr)))
 
     def release(self, slot: int):
         self._chk(self.lib.ntts_backbone_release(self.h, slot))
@@ -571,6 +596,28 @@ class CodecEngine:
         self._chk(self.lib.ntts_codec_decode(self.h, n, flat.ctypes.data_as(i32p), lens.ctypes.data_as(i32p),
                                              wav.ctypes.data_as(C.POINTER(C.c_float)), stride))
         return wav
+
+    def decode_device(self, codes_dev_ptr: int, codes_stride: int, lens: np.ndarray, producer_stream: int = 0,
+                      wav_dev_ptr: Optional[int] = None, wav_stride: Optional[int] = None, reuse_output: bool = True):
+        """Codes already on the device (BackboneEngine.export_codes) -> waveforms, asynchronously: returns the [n, stride]
+        float32 destination (a view of the engine's pinned host buffer, or None when `wav_dev_ptr` names a device buffer);
+        call sync() before reading it."""
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        n = len(lens)
+        stride = int(wav_stride or self.hop_length * int(lens.max()))
+        wav = None
+        if wav_dev_ptr is None:
+            wav = self._pinned(n * stride).reshape(n, stride)
+            dst, on_dev = wav.ctypes.data, 0
+        else:
+            dst, on_dev = wav_dev_ptr, 1
+        self._chk(self.lib.ntts_codec_decode_dev(self.h, n, C.c_void_p(codes_dev_ptr), codes_stride,
+                                                 lens.ctypes.data_as(C.POINTER(C.c_int32)), C.c_void_p(dst), stride, on_dev,
+                                                 C.c_void_p(producer_stream or None)))
+        return wav
+
+    def sync(self):
+        self._chk(self.lib.ntts_codec_sync(self.h))
 
     def last_timing(self) -> float:
         ms = C.c_float()

@@ -14,47 +14,70 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+class _DeviceBytes:
+    """Zero-copy view of `nbytes` of device memory at `ptr` for torch (the __cuda_array_interface__ protocol)."""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+def alias_bytes(ptr: int, nbytes: int, device):
+    """A torch uint8 tensor that ALIASES [ptr, ptr + nbytes) -- no staging copy: the collective reads / writes the engine's own
+    memory.  `device` cpu = the emulator's "device" memory (host)."""
+    import ctypes
+    import torch
+    if torch.device(device).type == "cpu":
+        return torch.frombuffer((ctypes.c_uint8 * nbytes).from_address(ptr), dtype=torch.uint8)
+    return torch.as_tensor(_DeviceBytes(ptr, nbytes), device=device)
+
+
 def broadcast_weights(engine, src: int = 0, device=None):
-    """Rank `src` holds finalised weights; every other rank receives the packed arena (weights + RoPE
-    table) with one broadcast and adopts it.  A torch uint8 tensor is only the transport container."""
+    """Rank `src` holds finalised weights; every other rank receives the packed arena (weights, scales, RoPE table) IN PLACE:
+    the collective runs on tensors that alias the engines' own arenas (start-up peak memory = one arena, no staging copy),
+    and the part of the arena that is derived from another part -- the tied lm_head's tile-major / fp8 copy of the embedding,
+    a quarter of NeuTTS-Air's arena -- does not travel: the receiver rebuilds it (ntts_backbone_adopt_arena)."""
     import torch
     import torch.distributed as dist
 
-    _, nbytes = engine.arena()
+    ptr, nbytes = engine.arena()
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-    buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    if dist.get_rank() == src:
-        engine.arena_copy(buf.data_ptr(), nbytes, to_arena=False)
-    dist.broadcast(buf, src=src)
-    if buf.is_cuda:
-        torch.cuda.synchronize()     # the engine copies on its own HIP stream: the collective must have landed
+    skip_off, skip_n = engine.arena_derived()
+    parts = [(0, nbytes)] if skip_n == 0 else [(0, skip_off), (skip_off + skip_n, nbytes - skip_off - skip_n)]
+    engine.sync()                                   # uploads ran on the engine's own stream
+    for off, n in parts:
+        if n > 0:
+            dist.broadcast(alias_bytes(ptr + off, n, device), src=src)
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize()                    # the collective must have landed before the engine's stream reads it
     if dist.get_rank() != src:
-        engine.arena_copy(buf.data_ptr(), nbytes, to_arena=True)
         engine.adopt_arena()
-    del buf
 
 
 def broadcast_state_dict(sd, src: int = 0, device=None):
-    """Codec weights (a few hundred MB, many tensors): rank `src` passes its state dict, the others pass None and
-    receive {name: tensor on `device`}.  One metadata broadcast + one tensor broadcast per parameter, start-up only."""
+    """Codec weights: rank `src` passes its state dict, the others pass None and receive {name: fp32 tensor on `device`}.
+    ONE metadata broadcast + ONE tensor broadcast of the packed parameters (the ~150 tensors are views into it), start-up only."""
     import torch
     import torch.distributed as dist
 
     if device is None:
         device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-    meta = [[(k, tuple(v.shape)) for k, v in sd.items()]] if dist.get_rank() == src else [None]
+    meta = [[(k, tuple(torch.as_tensor(v).shape)) for k, v in sd.items()]] if dist.get_rank() == src else [None]
     dist.broadcast_object_list(meta, src=src)
-    out = {}
-    for name, shape in meta[0]:
-        if dist.get_rank() == src:
-            t = torch.as_tensor(sd[name]).to(device=device, dtype=torch.float32).contiguous()
-        else:
-            t = torch.empty(shape, dtype=torch.float32, device=device)
-        dist.broadcast(t, src=src)
-        out[name] = t
-    if device.type == "cuda":
+    sizes = [int(torch.Size(shape).numel()) for _, shape in meta[0]]
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=device)
+    if dist.get_rank() == src:
+        off = 0
+        for (name, _), n in zip(meta[0], sizes):
+            flat[off:off + n] = torch.as_tensor(sd[name]).to(dtype=torch.float32).reshape(-1)
+            off += n
+    dist.broadcast(flat, src=src)
+    if torch.device(device).type == "cuda":
         torch.cuda.synchronize()
+    out, off = {}, 0
+    for (name, shape), n in zip(meta[0], sizes):
+        out[name] = flat[off:off + n].view(shape)
+        off += n
     return out
 
 

@@ -19,14 +19,20 @@ from common import engine_cfg  # noqa: E402
 
 def main():
     lib = sys.argv[1]
-    dist.init_process_group("gloo")
+    backend = sys.argv[2] if len(sys.argv) > 2 else "gloo"     # "nccl" = RCCL: tests/test_gpu_dist.py on a box with >= 2 GPUs
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     cfg = br.BackboneConfig.tiny(vocab_size=512, num_layers=1)
-    eng = _hip.BackboneEngine(engine_cfg(cfg, max_batch=2, max_context=64, max_prefill_tokens=128), 0, lib)
+    eng = _hip.BackboneEngine(engine_cfg(cfg, max_batch=2, max_context=64, max_prefill_tokens=128), local if backend == "nccl" else 0, lib)
     w = br.make_weights(cfg, 17, peak_sigma=0.5)
     if rank == 0:
         eng.load_state_dict({k: v.numpy() for k, v in w.items()}, inv_freq=br.rope_inv_freq(cfg).numpy())
-    ndist.broadcast_weights(eng, src=0, device=torch.device("cpu"))
+    ndist.broadcast_weights(eng, src=0, device=torch.device("cuda", local) if backend == "nccl" else torch.device("cpu"))
     prompts = [br.synthetic_prompt(cfg, 50 + i, 6 + 3 * i) for i in range(5)]
     lo, hi = ndist.shard_range(len(prompts), rank, world)
     eos = cfg.vocab_size - 1

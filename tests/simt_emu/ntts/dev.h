@@ -176,6 +176,18 @@ inline int shfl_xor(int v, int m) { return emu_exchange(v, lane_id() ^ m); }
 inline float shfl(float v, int src) { return emu_exchange(v, src); }
 inline int shfl(int v, int src) { return emu_exchange(v, src); }
 
+inline unsigned long long ballot(bool pr) {
+    int par = emu::wave_parity();
+    auto& s = emu::wave_slots();
+    int v = pr ? 1 : 0;
+    memcpy(s.b[par][lane_id()], &v, 4);
+    emu::wave_sync();
+    unsigned long long m = 0;
+    for (int l = 0; l < emu::wave_lanes(); ++l) { int x; memcpy(&x, s.b[par][l], 4); if (x) m |= 1ull << l; }
+    return m;
+}
+inline int popc64(unsigned long long m) { return __builtin_popcountll(m); }
+
 inline void sync() { emu::barrier(); }
 
 // LDS-DMA: destination = lane 0's base + lane*16, whatever the other lanes passed (hardware
@@ -277,6 +289,10 @@ double emu_now_ms();
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emuEvent{0}; return 0; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = emu_now_ms(); return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
+inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind k, hipStream_t) {
+    return hipMemcpy2D(d, dp, s, sp, w, h, k);
+}
 inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return 0; }
 // graphs: not emulated -- the engine falls back to direct launches when capture is unsupported

@@ -264,3 +264,65 @@ def test_infer_stream_batch_equals_single_streams(tts):
             assert a.shape == b.shape and np.array_equal(a, b)
     with pytest.raises(ValueError, match="decode slots"):
         next(tts.infer_stream_batch(["a"] * (tts.backbone.max_batch + 1), ref_codes, "x"))
+
+
+def _device_i32(tts, shape):
+    """A zeroed int32 buffer in the engines' 'device' memory (host memory on the emulator, HBM on the GPU): (pointer, reader)."""
+    if "emu" in str(tts._lib_path):
+        a = np.zeros(shape, dtype=np.int32)
+        return a.ctypes.data, (lambda: a.copy()), a
+    t = torch.zeros(shape, dtype=torch.int32, device="cuda")
+    return t.data_ptr(), (lambda: t.cpu().numpy()), t
+
+
+def test_device_side_code_handoff(tts):
+    """ids -> codes -> waveform without the host round trip (include/neutts_hip.h ntts_backbone_export_codes +
+    ntts_codec_decode_dev): the device-side selection equals `_ids_to_codes` (= the reference's tokenizer.decode + regex,
+    ref:neutts/neutts.py:349,:276), specials and text ids dropped, and the codec pass fed from the device buffer -- ordered
+    behind the backbone's stream -- returns exactly the waveforms of the host-fed pass."""
+    bcfg, bw, ccfg, cw, tok, eos = tts._oracle
+    eng, cod = tts.backbone, tts.codec.engine
+    n_codes = int(np.prod(ccfg.levels))
+    ref_codes = [3, 77, 200, 5, 18, 9]
+    prompts = [tts._apply_chat_template(ref_codes, "So I'm live.", t) for t in ("Testing.", "A second, longer one.")]
+    slots = [eng.acquire_slot() for _ in prompts]
+    try:
+        samp = [_hip_sampling(len(p) + 40, 12, eos) for p in prompts]
+        eng.prefill(prompts, slots, samp)
+        # a text byte and a special token in the middle of the stream must be dropped by the selection
+        eng.decode(6)
+        eng.debug_force(slots[0], 65)
+        eng.decode(1)
+        eng.debug_force(slots[0], tok.convert_tokens_to_ids("<|TEXT_PROMPT_END|>"))
+        eng.decode(40)
+        ids = [eng.read(s)[0] for s in slots]
+        want = [tts._ids_to_codes(i) for i in ids]
+        assert 65 in ids[0] and len(want[0]) <= len(ids[0]) - 2 and all(len(w) > 0 for w in want)
+        stride = 64
+        cptr, cread, _c = _device_i32(tts, (len(slots), stride))
+        lptr, lread, _l = _device_i32(tts, (len(slots),))
+        eng.export_codes(slots, tok.speech_base, n_codes, cptr, stride, lptr)
+        eng.sync()
+        lens, codes = lread(), cread()
+        assert lens.tolist() == [len(w) for w in want]
+        for u, w in enumerate(want):
+            assert codes[u, :len(w)].tolist() == w
+        wav = cod.decode_device(cptr, stride, lens, producer_stream=eng.stream())
+        cod.sync()
+        host = cod.decode(want)
+        for u, w in enumerate(want):
+            assert np.array_equal(wav[u, :len(w) * cod.hop_length], host[u])
+        # the synthetic-benchmark mapping (id mod n_codes) keeps every id
+        eng.export_codes(slots, 0, n_codes, cptr, stride, lptr, modulo=True)
+        eng.sync()
+        assert lread().tolist() == [min(len(i), stride) for i in ids]
+        assert cread()[1, :len(ids[1])].tolist() == [i % n_codes for i in ids[1]][:stride]
+    finally:
+        eng.sync()
+        for s in slots:
+            eng.release(s)
+
+
+def _hip_sampling(max_length, min_new, eos):
+    from neutts import _hip
+    return _hip.Sampling(max_length=max_length, min_new_tokens=min_new, eos_token_id=eos, do_sample=False)

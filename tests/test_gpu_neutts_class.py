@@ -71,3 +71,4 @@ def test_sampling_default_call_runs_and_stays_in_vocab(tts):
         assert np.isfinite(audio).all()
     finally:
         tts.do_sample = False
+test_device_side_code_handoff = cases.test_device_side_code_handoff
