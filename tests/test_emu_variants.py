@@ -15,8 +15,8 @@ def lib(emu_lib):
     return emu_lib
 
 
-def _engine(cfg, w, lib, max_batch=2, input_scales=None, **kw):
-    eng = _hip.BackboneEngine(engine_cfg(cfg, max_batch=max_batch, max_context=128, max_prefill_tokens=256,
+def _engine(cfg, w, lib, max_batch=2, input_scales=None, max_prefill_tokens=256, **kw):
+    eng = _hip.BackboneEngine(engine_cfg(cfg, max_batch=max_batch, max_context=128, max_prefill_tokens=max_prefill_tokens,
                                          tie_word_embeddings=cfg.tie_word_embeddings, attention_bias=cfg.attention_bias, **kw), 0, lib)
     eng.load_state_dict({k: v.numpy() for k, v in w.items()}, inv_freq=br.rope_inv_freq(cfg).numpy(), input_scales=input_scales)
     return eng
@@ -100,7 +100,8 @@ def check_fp8_model(lib, cfg, prompts, n_new, max_batch):
     scales = br.default_fp8_input_scales(cfg)
     wb = br.cast_weights(w, torch.bfloat16)
     wq = br.fp8_quantize_weights(wb, scales)
-    eng = _engine(cfg, w, lib, max_batch=max_batch, input_scales=scales, weight_dtype="fp8")
+    eng = _engine(cfg, w, lib, max_batch=max_batch, input_scales=scales, weight_dtype="fp8",
+                  max_prefill_tokens=max(256, sum(len(p) for p in prompts)))
     eos = cfg.vocab_size - 1
     samp = [_hip.Sampling(max_length=len(p) + n_new, min_new_tokens=n_new, eos_token_id=eos, do_sample=False) for p in prompts]
     eng.set_debug(True)
