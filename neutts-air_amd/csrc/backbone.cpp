@@ -102,6 +102,11 @@ struct ntts_backbone {
     // (profiles/r02a_sweep_nt_graphsteps.jsonl): lm_head 136.6 -> 132.3 us; on the LDS-DMA rings of the skinny layer GEMMs the
     // same policy was SLOWER (qkv 5.78 -> 5.96, down 9.95 -> 10.54 us; step 1.679 -> 1.718 ms) and is not offered there
     int w_nt = 1;
+    // Split-K decode GEMMs: XCD-aware slice placement (gemm.h GemmArgs::xcd_nsplit; NTTS_XCD_SPLIT bit 0 qkv, 1 o_proj, 2 down).
+    // Measured at batch 256 (profiles/r02f_*): FETCH per skinny-GEMM launch 15.0 -> 6.8 MB (algorithmic 5.3: the 8 private L2s
+    // no longer each pull the whole X panel), down_proj 10.2 -> 10.1 us, qkv unchanged, o_proj 5.3 -> 5.6-5.8 us (K = 896 only
+    // has 14 tiles to split: its X panel is small and the y-grid placement balances better) -- hence qkv + down by default.
+    int xcd_split = 5;
     // Small-batch decode step (max_batch <= NTTS_SMALL_BATCH, default 8; BASELINE configs[1] = batch 1): wave-per-16-features
     // GEMV kernels with the slab-reduce + residual + RMSNorm fused into the consumer's prologue (gemv.h) -- 5 launches per
     // layer instead of 7 -- and 16-wave attention workgroups (attn_decode.h NW).
@@ -333,6 +338,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     // one row per workgroup: 256 CUs pull the slabs instead of 64 -- 5.5 -> 4.0 us per launch, -4.4 % per step at batch 256
     e->norm_wide = env_int("NTTS_NORM_WIDE", 1) != 0;
     e->w_nt = env_int("NTTS_W_NT", 1);
+    e->xcd_split = env_int("NTTS_XCD_SPLIT", 5);
     e->use_xl = env_int("NTTS_XL", 1) != 0;
     e->head_xl = env_int("NTTS_HEAD_XL", B > 128 ? 1 : 0) != 0;
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -781,7 +787,11 @@ static void k_qkv(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H;
     const LayerW& w = e->layers[i];
     if (e->ks_qkv > 1)   // fp32 split-K slabs; the attention prologue sums them, adds the bias and rounds (attn_decode.h)
-        gemm_skinny<EPI_SPLITK>(e->st_qkv, gemm_args(e, e->xn_dec, H, w.wqkv, H, nullptr, e->slabs, e->NQKV, B, e->NQKV, H, w.sqkv, w.xs[0]), e->ks_qkv, e->stream);
+    {
+        GemmArgs a = gemm_args(e, e->xn_dec, H, w.wqkv, H, nullptr, e->slabs, e->NQKV, B, e->NQKV, H, w.sqkv, w.xs[0]);
+        a.xcd_nsplit = (e->xcd_split & 1) ? -1 : 0;
+        gemm_skinny<EPI_SPLITK>(e->st_qkv, a, e->ks_qkv, e->stream);
+    }
     else
         gemm_skinny<EPI_BF16>(e->st_qkv, gemm_args(e, e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H, w.sqkv, w.xs[0]), 1, e->stream);
 }
@@ -803,7 +813,9 @@ static void k_attn(ntts_backbone* e, int i) {
 
 static void k_o_proj(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, QD = e->cfg.num_heads * 64;
-    gemm_skinny<EPI_SPLITK>(e->st_o, gemm_args(e, e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->slabs, H, B, H, QD, e->layers[i].so, e->layers[i].xs[1]), e->ks_o, e->stream);
+    GemmArgs a = gemm_args(e, e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->slabs, H, B, H, QD, e->layers[i].so, e->layers[i].xs[1]);
+    a.xcd_nsplit = (e->xcd_split & 2) ? -1 : 0;
+    gemm_skinny<EPI_SPLITK>(e->st_o, a, e->ks_o, e->stream);
 }
 
 static void k_gate_up(ntts_backbone* e, int i) {
@@ -823,7 +835,9 @@ static void k_gate_up(ntts_backbone* e, int i) {
 
 static void k_down(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, F = e->F;
-    gemm_skinny<EPI_SPLITK>(e->st_d, gemm_args(e, e->act_dec, F, e->layers[i].wd, F, nullptr, e->slabs, H, B, H, F, e->layers[i].sd, e->layers[i].xs[3]), e->ks_d, e->stream);
+    GemmArgs a = gemm_args(e, e->act_dec, F, e->layers[i].wd, F, nullptr, e->slabs, H, B, H, F, e->layers[i].sd, e->layers[i].xs[3]);
+    a.xcd_nsplit = (e->xcd_split & 4) ? -1 : 0;
+    gemm_skinny<EPI_SPLITK>(e->st_d, a, e->ks_d, e->stream);
 }
 
 // residual += reduce(slabs of a K-deep split-K GEMM); normed = rmsnorm(residual) * norm_w

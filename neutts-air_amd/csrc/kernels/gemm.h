@@ -74,7 +74,25 @@ struct GemmArgs {
     const float* wscale;
     float xscale;
     float out_fp8_inv;
+    // split-K placement (gemm_launch sets it): 0 = splits in gridDim.y (every XCD then works on every K slice of its tiles, so
+    // each of the 8 private L2s pulls the WHOLE X panel: measured 2.8x the algorithmic fetch on the skinny decode GEMMs,
+    // profiles/r02e_pmc_fetch_*); n = 2 / 4 / 8: a 1-D grid in which an XCD only ever sees ONE K slice (8 / n XCDs share the
+    // tiles of a slice), so X and W are each fetched into exactly one L2 per slice.  Speed only: block b runs on XCD b % 8
+    // is an observation, not a contract, and nothing depends on it.
+    int xcd_nsplit, xcd_per;
 };
+
+// position t of the grouped tile order (8 m-blocks x all n-blocks per group, m fastest) -> tile coordinates
+NTTS_D void gemm_tile_from_linear(int t, int mblocks, int nblocks, int& mb, int& nb) {
+    const int GM = 8;
+    const int per_group = GM * nblocks;
+    const int g = t / per_group;
+    const int first_m = g * GM;
+    const int gsz = (mblocks - first_m) < GM ? (mblocks - first_m) : GM;
+    const int in = t - g * per_group;
+    mb = first_m + in % gsz;
+    nb = in / gsz;
+}
 
 NTTS_D void gemm_tile_coords(int bid, int mblocks, int nblocks, int& mb, int& nb) {
     const int ntiles = mblocks * nblocks;
@@ -310,12 +328,20 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     const int lane = lane_id(), wave = wave_id();
     const int wm = wave / WN, wn = wave % WN;
     const int g = lane >> 4, l15 = lane & 15;
-    int mb, nb;
-    gemm_tile_coords(blockIdx.x, p.mblocks, p.nblocks, mb, nb);
+    int mb, nb, split = blockIdx.y;
+    if (p.xcd_nsplit) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, xps = 8 / p.xcd_nsplit;   // XCDs per K slice
+        split = xcd / xps;
+        const int t = (xcd % xps) * p.xcd_per + j;
+        if (t >= p.mblocks * p.nblocks) return;                // padding block (block-uniform, before any barrier)
+        gemm_tile_from_linear(t, p.mblocks, p.nblocks, mb, nb);
+    } else {
+        gemm_tile_coords(blockIdx.x, p.mblocks, p.nblocks, mb, nb);
+    }
     const int m0 = mb * BM, n0 = nb * BN;
     const int ktiles = F8 ? p.K >> 7 : p.K >> 6;               // 128-byte K tiles
-    const int kt0 = blockIdx.y * p.k_tiles_per_split * SPT;   // in ring slots from here on
-    int nk = ktiles - blockIdx.y * p.k_tiles_per_split;
+    const int kt0 = split * p.k_tiles_per_split * SPT;        // in ring slots from here on
+    int nk = ktiles - split * p.k_tiles_per_split;
     if (nk > p.k_tiles_per_split) nk = p.k_tiles_per_split;
     nk *= SPT;
 
@@ -413,7 +439,7 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     if constexpr (ABL & 4) {
         if (acc[0][0][0] != 12345.678f) return;   // keeps the accumulators live without storing
     }
-    gemm_epilogue<TM, EPI, WN, F8>(p, acc, m0 + wm * TM * 16, n0, wn, nb, blockIdx.y);
+    gemm_epilogue<TM, EPI, WN, F8>(p, acc, m0 + wm * TM * 16, n0, wn, nb, split);
 }
 
 
@@ -439,6 +465,14 @@ inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
     p.k_tiles_per_split = (ktiles + ksplit - 1) / ksplit;
     const int nsplit = (ktiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
     if constexpr (EPI == EPI_ARGMAX) p.part_stride = p.nblocks * WN;
+    if (EPI == EPI_SPLITK && p.xcd_nsplit == -1 && (nsplit == 2 || nsplit == 4 || nsplit == 8)) {   // XCD-aware split-K placement requested
+        p.xcd_nsplit = nsplit;
+        const int xps = 8 / nsplit, tiles = p.mblocks * p.nblocks;
+        p.xcd_per = (tiles + xps - 1) / xps;
+        NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT, F8>), dim3(8 * p.xcd_per), dim3(WM * WN * 64), s, p);
+        return;
+    }
+    p.xcd_nsplit = 0;
     NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT, F8>), dim3(p.mblocks * p.nblocks, nsplit), dim3(WM * WN * 64), s, p);
 }
 

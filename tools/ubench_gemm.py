@@ -67,7 +67,7 @@ def tall():
 def head():
     M, N, K = 256, 217472, 896
     print(f"== lm_head M={M} N={N} K={K} W=390 MB (always HBM-cold); row-major W vs tile-major W (abl bit 16)")
-    for cfg in (30, 42, 12):
+    for cfg in (30, 42, 12, 46, 47, 43, 53):
         t = probe(M, N, K, cfg, 0, 1, iters=20)
         t2 = probe(M, N, K, cfg, 16, 1, iters=20)
         print(f"  {CONFIGS[cfg]:18s} {t:8.1f} us  {N * K * 2 / t / 1e6:6.2f} TB/s | tile-major {t2:8.1f} us  {N * K * 2 / t2 / 1e6:6.2f} TB/s", flush=True)
