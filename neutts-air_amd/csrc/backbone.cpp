@@ -111,7 +111,7 @@ struct ntts_backbone {
     // GEMV kernels with the slab-reduce + residual + RMSNorm fused into the consumer's prologue (gemv.h) -- 5 launches per
     // layer instead of 7 -- and 16-wave attention workgroups (attn_decode.h NW).
     bool small = false;
-    int sks_q = 4, sks_o = 7, sks_d = 10, attn_depth_small = 2, attn_nw_small = 4;
+    int sks_q = 4, sks_o = 7, sks_d = 10, attn_depth_small = 2;
     bf16_t* h_alt = nullptr;     // second residual-stream buffer (the fused prologue writes the new stream while others still read the old)
     float* slabs2 = nullptr;     // down_proj's slabs (read by the next layer's QKV prologue while that kernel writes `slabs`)
     bool norm_wide = true;       // decode add+RMSNorm: one row per workgroup (256 CUs pull) instead of four
@@ -360,9 +360,6 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     if (e->sks_o > max_slabs) e->sks_o = max_slabs;
     if (e->sks_d > max_slabs) e->sks_d = max_slabs;
     e->attn_depth_small = env_int("NTTS_ATTN_DEPTH_SMALL", 2);
-    // 16 waves per workgroup were measured SLOWER at batch 1 (13.6 vs 12.0 us per launch, profiles/r02c_attn_timeline_b1.txt): the
-    // 12 extra waves' K / V^T requests (192 KB through ONE CU's ~50 GB/s load path) queue ahead of the prologue's RoPE row
-    e->attn_nw_small = env_int("NTTS_ATTN_NW_SMALL", 4);
     e->n_part = e->small ? V / 16 : e->head_xl ? ((V + 255) / 256) * 4 : e->head_large ? ((V + 127) / 128) * 2 : (V + 63) / 64;
     CR_HIP(hipMalloc((void**)&e->h_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->xn_dec, (size_t)B * H * 2));
@@ -881,7 +878,7 @@ static void ks_attn(ntts_backbone* e, int i) {
     a.block_table = e->block_table; a.max_pages = e->max_pages; a.pos = e->sl.pos; a.state = e->sl.state;
     a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
     a.tl = e->attn_tl;
-    attn_decode_launch_small(a, c.max_batch, e->stream, e->attn_nw_small, e->attn_depth_small);
+    attn_decode_launch_small(a, c.max_batch, e->stream, e->attn_depth_small);
 }
 static void ks_o_proj(ntts_backbone* e, int i) {
     const int QD = e->cfg.num_heads * 64;

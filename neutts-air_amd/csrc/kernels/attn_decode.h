@@ -65,9 +65,11 @@ NTTS_D void rope_pair(float x1, float x2, float c, float s, float& o1, float& o2
 //   flight) after the prologue (+3.5 us per launch) or at the softmax merge (+1.1 us), scheduling fences around the K
 //   requests (no effect), deeper register rings (kDepth 2 / 3: +0.2 / +1.2 us), the RoPE row served from a per-slot copy
 //   so that it does not hang off the load of the position (no effect).
-// NW = waves per workgroup.  4 at large batch (two workgroups per CU, B * kv_heads >= the CU count).  16 at small batch
-//   (BASELINE configs[1], batch 1: only B * kv_heads workgroups exist, so one workgroup must put a whole context's pages in
-//   flight by itself: 16 waves x kDepth pages = the K of 512 x kDepth tokens requested at once instead of 128 x kDepth).
+// NW = waves per workgroup: 4.  16-wave workgroups (a whole 600-token context's pages requested at once by the one workgroup
+//   a (sequence, kv-head) gets at batch 1) were measured and are not instantiated: 13.1-13.7 vs 10.5-12.0 us per launch --
+//   the 12 extra waves' 192 KB of page requests queue on the CU's ~50 GB/s load path ahead of the prologue's RoPE row
+//   (prologue 1.9 -> 6.4 us); letting them request only after the prologue moves the wait into the softmax merge
+//   (14.8 us).  profiles/r02c_attn_timeline_b1.txt, r02f_sweep_b1_nw16_late_fw2.log.
 template <int kDepth, bool kTimeline = false, int kVar = 1, int NW = 4>
 NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
     constexpr int NT = NW * 64;
@@ -387,22 +389,12 @@ inline void attn_decode_launch_v(const AttnDecodeArgs& p, int batch, hipStream_t
         default: NTTS_LAUNCH((attn_decode_kernel<2, false, kVar>), grid, block, s, p); break;   // deeper rings measured slower (r01d)
     }
 }
-// small-batch variants: nw = 16 or 4 waves per workgroup, `depth` pages per wave in flight, V^T requested next to K (kVar 7)
-inline void attn_decode_launch_small(const AttnDecodeArgs& p, int batch, hipStream_t s, int nw, int depth) {
+// small-batch variant: `depth` pages per wave in flight, V^T requested next to K (kVar 7)
+inline void attn_decode_launch_small(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth) {
     const dim3 grid(batch, p.nkv);
-    if (p.tl) {   // diagnostics: phase timestamps of waves 0-3
-        if (nw == 16) NTTS_LAUNCH((attn_decode_kernel<2, true, 7, 16>), grid, dim3(1024), s, p);
-        else NTTS_LAUNCH((attn_decode_kernel<2, true, 7, 4>), grid, dim3(256), s, p);
-        return;
-    }
-    if (nw == 16) {
-        if (depth >= 2) NTTS_LAUNCH((attn_decode_kernel<2, false, 7, 16>), grid, dim3(1024), s, p);
-        else NTTS_LAUNCH((attn_decode_kernel<1, false, 7, 16>), grid, dim3(1024), s, p);
-    } else {
-        if (depth >= 4) NTTS_LAUNCH((attn_decode_kernel<4, false, 7, 4>), grid, dim3(256), s, p);
-        else if (depth >= 2) NTTS_LAUNCH((attn_decode_kernel<2, false, 7, 4>), grid, dim3(256), s, p);
-        else NTTS_LAUNCH((attn_decode_kernel<1, false, 7, 4>), grid, dim3(256), s, p);
-    }
+    if (p.tl) { NTTS_LAUNCH((attn_decode_kernel<2, true, 7, 4>), grid, dim3(256), s, p); return; }   // diagnostics: phase timestamps
+    if (depth >= 2) NTTS_LAUNCH((attn_decode_kernel<2, false, 7, 4>), grid, dim3(256), s, p);
+    else NTTS_LAUNCH((attn_decode_kernel<1, false, 7, 4>), grid, dim3(256), s, p);
 }
 inline void attn_decode_launch(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth = kAttnDepthDefault, int var = 1) {
     if ((var & 7) == 7) attn_decode_launch_v<7>(p, batch, s, depth);        // + V^T pages requested next to the K pages

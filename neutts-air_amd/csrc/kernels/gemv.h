@@ -64,8 +64,11 @@ struct GemvArgs {
 // re-read the last tile and their fragments are masked to zero -- NO per-element branches: a load guarded by a run-time
 // condition makes hipcc wait for each element before it requests the next, cdna_hip_programming.md "three .s-level traps" (c),
 // which is what a first version of this kernel did: 66 s_waitcnt in 770 instructions, slower than the LDS-DMA tiles).
-template <int EPI, bool PRO, int KT>
-NTTS_KERNEL(512) void gemv_kernel(GemvArgs p) {
+// FW = feature waves per workgroup, + 4 helper waves.  FW = 2 for gate/up (304 workgroups of 32 features instead of 152 of
+// 64, so that every CU has a weight stream) was measured and is NOT used: 16.1 vs 10.7 us at batch 1 -- twice the
+// prologues, each on its workgroup's critical path (profiles/r02f_sweep_b1_nw16_late_fw2.log).
+template <int EPI, bool PRO, int KT, int FW = 4>
+NTTS_KERNEL((FW + 4) * 64) void gemv_kernel(GemvArgs p) {
     NTTS_SHARED bf16_t xs[kGemvRows * kGemvXld];
     const int lane = lane_id(), w = wave_id();
     const int g = lane >> 4, l15 = lane & 15;
@@ -75,9 +78,9 @@ NTTS_KERNEL(512) void gemv_kernel(GemvArgs p) {
     if (nk > p.k_tiles_per_split) nk = p.k_tiles_per_split;       // <= KT (launcher)
     const int col0 = PRO ? 0 : kt0 * 64;                          // K index held by panel column 0 (PRO: the panel is the whole row)
 
-    if (w >= 4) {
+    if (w >= FW) {
         // ---- helper waves: the X panel.  Row m is built by helper (m & 3); rows >= M are left alone.
-        const int hw = w - 4;
+        const int hw = w - FW;
         if constexpr (PRO) {
             const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
             for (int m = hw; m < p.M; m += 4) rmsnorm_row_wave<2, 16>(p.pro, m, true, writer, xs + m * kGemvXld);
@@ -97,7 +100,7 @@ NTTS_KERNEL(512) void gemv_kernel(GemvArgs p) {
     }
 
     // ---- feature waves: request the whole weight slice (branch-free), then wait for the panel
-    const int f0r = (blockIdx.x * 4 + w) * 16;
+    const int f0r = (blockIdx.x * FW + w) * 16;
     const bool active = f0r < p.N;                                // wave-uniform
     const int f0 = active ? f0r : 0;                              // an inactive wave streams (and discards) group 0: no branch around the loads
     const bf16_t* wbase;
@@ -192,8 +195,8 @@ inline void gemv_launch(GemvArgs p, int ksplit, hipStream_t s) {
     p.k_tiles_per_split = (ktiles + ksplit - 1) / ksplit;
     const int nsplit = (ktiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
     if constexpr (EPI == EPI_ARGMAX) p.part_stride = p.N / 16;
-    const dim3 grid((p.N + 63) / 64, nsplit), block(512);
     const int kps = p.k_tiles_per_split;
+    const dim3 grid((p.N + 63) / 64, nsplit), block(512);
     if constexpr (EPI == EPI_SPLITK) {                            // the split-K GEMVs come in every slice length
         if (kps <= 2) { NTTS_LAUNCH((gemv_kernel<EPI, PRO, 2>), grid, block, s, p); return; }
         if (kps <= 4) { NTTS_LAUNCH((gemv_kernel<EPI, PRO, 4>), grid, block, s, p); return; }

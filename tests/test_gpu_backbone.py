@@ -104,6 +104,41 @@ def test_air_teacher_forced_vs_hf_golden(air):
     assert ex >= 235, f"only {ex}/{N} exact ({tie} near-ties); measured 239"
 
 
+def test_air_logits_vs_fp32_reference(air):
+    """The reference as shipped loads fp32 weights (ref:neutts/neutts.py:164 calls from_pretrained without a dtype); this
+    engine's contract is bf16 (BASELINE.json).  How far apart are they where it matters for sampling?  First-token
+    distribution after the 500-token prompt, engine (bf16) vs the oracle run in fp32: overlap of the top-50 sets (the
+    reference's top_k), KL divergence of the softmax, and the same for the oracle's own bf16 run as the yardstick."""
+    z, cfg, eng = air
+    _, _, w = load_fixture("backbone_air")
+    S, eos = int(z["s_len"]), int(z["eos"])
+    prompt = br.synthetic_prompt(cfg, 0, S)
+    for s in range(256):
+        eng.release(s)
+    eng.set_debug(True)
+    try:
+        eng.prefill([prompt], [3], [_hip.Sampling(max_length=S + 2, min_new_tokens=2, eos_token_id=eos, do_sample=False)])
+        ours = torch.from_numpy(eng.read_logits(3)).double()
+    finally:
+        eng.release(3)
+        eng.set_debug(False)
+    ref32 = br.generate(cfg, w, prompt, S + 1, eos, min_new_tokens=1, keep_logits=True).logits[0].double()
+    ref16 = br.generate(cfg, br.cast_weights(w, torch.bfloat16), prompt, S + 1, eos, min_new_tokens=1, keep_logits=True).logits[0].double()
+    fin = torch.isfinite(ref32)
+
+    def stats(a):
+        p, q = torch.softmax(ref32[fin], 0), torch.softmax(a[fin], 0)
+        kl = float((p * (p.log() - q.log())).sum())
+        top = len(set(torch.topk(ref32[fin], 50).indices.tolist()) & set(torch.topk(a[fin], 50).indices.tolist()))
+        return kl, top, float((a[fin] - ref32[fin]).abs().max())
+    kl_o, top_o, d_o = stats(ours)
+    kl_h, top_h, d_h = stats(ref16)
+    print(f"vs the fp32 run: engine bf16  KL {kl_o:.2e}  top-50 overlap {top_o}/50  max |dlogit| {d_o:.3f};  "
+          f"oracle bf16 (= HF bf16)  KL {kl_h:.2e}  top-50 overlap {top_h}/50  max |dlogit| {d_h:.3f}")
+    # the engine is as close to fp32 as HF's own bf16 model is (it IS that model up to fp32 summation order)
+    assert kl_o <= 2.0 * kl_h + 1e-6 and top_o >= top_h - 3 and kl_o <= 0.05
+
+
 def test_air_batch1_vs_hf_golden(lib):
     """BASELINE.json configs[1]: NeuTTS-Air bf16, batch 1, 500 prefill / 250 decode, greedy.  A single-slot engine takes
     the small-batch kernel path (wave-per-16-features GEMMs, context-split attention); same golden run, same bars as

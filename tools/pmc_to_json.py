@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Turn the rocprofv3 counter-collection csv of the pmc leg into the small record bench.py quotes as roofline.traffic.
 
-    python tools/pmc_to_json.py gpurun_out/pmc_FETCH_SIZE [gpurun_out/pmc_WRITE_SIZE] [--prefill=605 --decode=40] > profiles/r01_pmc_traffic.json
+    python tools/pmc_to_json.py gpurun_out/pmc_FETCH_SIZE [gpurun_out/pmc_WRITE_SIZE] [--prefill=605 --decode=40] > profiles/r02_pmc_traffic.json
 FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE is doubled (gfx950 counts the 128-B requests of wide coalesced reads at
 64 B, MI355X_MICROARCH.md section HBM); WRITE_SIZE is left uncorrected (uncalibrated there)."""
 import csv
