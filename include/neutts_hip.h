@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NTTS_ABI_VERSION 2
+#define NTTS_ABI_VERSION 3
 
 enum {
     NTTS_OK = 0,
@@ -260,6 +260,54 @@ int ntts_host_alloc(size_t bytes, void** out);
 int ntts_host_free(void* p);
 /* GPU milliseconds (hipEvents) of the most recent decode call, H2D/D2H excluded. */
 int ntts_codec_last_timing(ntts_codec* c, float* ms);
+
+/* ------------------------------------------------------------------------------------------ */
+/* NeuCodec ENCODER engine: reference enrolment.  Replaces                                       */
+/*     codec.encode_code(audio_or_path=wav16k[1,1,L]) -> int codes [1,1,T]                       */
+/* (ref:neutts/neutts.py:266-271; neucodec is un-vendored, the architecture is restated from      */
+/* hf:models/xcodec2/modeling_xcodec2.py:974-1049 = zero-pad to a hop multiple -> [kaldi fbank -> */
+/* w2v-BERT 2.0 conformer layers 1..16 -> semantic adapter] || [acoustic conv encoder] -> concat  */
+/* -> Linear -> FSQ).  One-off per speaker, off the synthesis hot path; fp32 throughout.          */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct ntts_encoder ntts_encoder;
+
+typedef struct ntts_encoder_config {
+    int32_t sem_hidden;         /* 1024  w2v-BERT hidden size */
+    int32_t sem_layers;         /* 16    conformer layers run (neucodec reads hidden_states[16]) */
+    int32_t sem_heads;          /* 16 */
+    int32_t sem_ffn;            /* 4096 */
+    int32_t sem_conv_kernel;    /* 31    causal depthwise kernel */
+    int32_t sem_left;           /* 64    relative_key distance clamp */
+    int32_t sem_right;          /* 8 */
+    float sem_ln_eps;           /* 1e-5 */
+    int32_t ac_hidden;          /* 48    acoustic encoder base width */
+    int32_t n_ratios;           /* 5 */
+    int32_t ratios[8];          /* 2,2,4,4,5: 16 kHz -> 50 Hz (hop 320) */
+    int32_t codec_hidden;       /* 1024  acoustic encoder output channels */
+    int32_t n_levels;           /* 8 */
+    int32_t levels[8];          /* FSQ levels, 4 each */
+    int32_t max_samples;        /* longest clip (16 kHz samples) one encode call accepts */
+} ntts_encoder_config;
+
+const char* ntts_encoder_last_error(const ntts_encoder* e);
+int ntts_encoder_create(const ntts_encoder_config* cfg, int device, ntts_encoder** out);
+void ntts_encoder_destroy(ntts_encoder* e);
+/* `name` = parameter name of transformers' Xcodec2Model: "semantic_encoder.feature_projection.*",
+ * "semantic_encoder.encoder.layers.{i}.*", "semantic_adapter.conv{1..4}.*", "acoustic_encoder.*", "fc_encoder.*",
+ * "quantizer.project_in.*".  Host or device pointer, fp32 or bf16 (widened to fp32).  Blocking. */
+int ntts_encoder_load_tensor(ntts_encoder* e, const char* name, const void* data, int dtype, const int64_t* shape,
+                             int ndim, int is_device);
+/* Lists every missing tensor in the error text; repacks Conv1d weights for the implicit GEMM. */
+int ntts_encoder_finalize(ntts_encoder* e);
+/* wav: HOST float32 mono at 16 kHz, n_samples of them -> codes_out (HOST int32, capacity `cap`), *n_codes =
+ * n_samples / hop + 1 (the reference appends one zero, then pads to a hop multiple).  Blocking. */
+int ntts_encoder_encode(ntts_encoder* e, const float* wav, int64_t n_samples, int32_t* codes_out, int32_t cap, int32_t* n_codes);
+/* Stage outputs of the most recent encode call, for the per-stage parity tests: 0 = fbank features [T,160], 1 = semantic
+ * adapter || acoustic encoder [T, sem_hidden + codec_hidden], 2 = fc_encoder output [T, same], 3 = twice-bounded FSQ
+ * latents [T, n_levels].  HOST float32 out of capacity `cap` floats. */
+int ntts_encoder_read_stage(ntts_encoder* e, int32_t stage, float* out, int64_t cap, int32_t* rows, int32_t* cols);
+/* GPU milliseconds (hipEvents) of the most recent encode call, H2D/D2H excluded. */
+int ntts_encoder_last_timing(ntts_encoder* e, float* ms);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Kernel-level entry points (used by the parity tests and micro-benchmarks; all pointers are   */

@@ -97,7 +97,8 @@ struct ntts_backbone {
     int ks_qkv = 1, ks_o = 1, ks_d = 1;
     int st_qkv = 4, st_o = 4, st_gu = 3, st_d = 4;   // LDS ring depth of each skinny decode GEMM
     int head_stages = 2, l_stages = 2, pf_gh = 7, attn_depth = 1, attn_var = 1, gu_tile = 0;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
-    bool gu_large = false, head_large = true, pf_attn_simple = false, use_xl = true, head_xl = false;
+    bool gu_large = false, head_large = true, pf_attn_simple = false, use_xl = true;
+    int head_xl = 0;   // lm_head tile at large batch: 0 = 128 x 128, 1 = 256 x 256 (16 waves), 2 = 128 x 256, 3 = 256 x 128 (8 waves, two per CU)
     // non-temporal policy on the lm_head's weight stream (NTTS_W_NT).  Measured at batch 256
     // (profiles/r02a_sweep_nt_graphsteps.jsonl): lm_head 136.6 -> 132.3 us; on the LDS-DMA rings of the skinny layer GEMMs the
     // same policy was SLOWER (qkv 5.78 -> 5.96, down 9.95 -> 10.54 us; step 1.679 -> 1.718 ms) and is not offered there
@@ -340,7 +341,8 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->w_nt = env_int("NTTS_W_NT", 1);
     e->xcd_split = env_int("NTTS_XCD_SPLIT", 5);
     e->use_xl = env_int("NTTS_XL", 1) != 0;
-    e->head_xl = env_int("NTTS_HEAD_XL", B > 128 ? 1 : 0) != 0;
+    e->head_xl = env_int("NTTS_HEAD_XL", B > 128 ? 1 : 0);
+    if (e->fp8 && e->head_xl > 1) e->head_xl = 1;
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e->pf_gh = env_int("NTTS_PF_GH", 7);   // all 7 heads of a GQA group in one pass: K/V pages staged once (prefill chunk 35.0 -> 33.4 ms)
     e->attn_depth = env_int("NTTS_ATTN_DEPTH", 1);
@@ -360,7 +362,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     if (e->sks_o > max_slabs) e->sks_o = max_slabs;
     if (e->sks_d > max_slabs) e->sks_d = max_slabs;
     e->attn_depth_small = env_int("NTTS_ATTN_DEPTH_SMALL", 2);
-    e->n_part = e->small ? V / 16 : e->head_xl ? ((V + 255) / 256) * 4 : e->head_large ? ((V + 127) / 128) * 2 : (V + 63) / 64;
+    e->n_part = e->small ? V / 16 : (e->head_xl == 1 || e->head_xl == 2) ? ((V + 255) / 256) * 4 : e->head_large ? ((V + 127) / 128) * 2 : (V + 63) / 64;
     CR_HIP(hipMalloc((void**)&e->h_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->xn_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->qkv_dec, (size_t)B * e->NQKV * 2));
@@ -758,6 +760,8 @@ static void k_lm_head(ntts_backbone* e, bool keep_logits) {
     a.logits = keep_logits ? e->logits : nullptr; a.ld_logits = V;
     a.logits_bf16 = (keep_logits && e->n_sampling > 0) ? e->logits_bf16 : nullptr; a.ld_logits_bf16 = e->ldl;
     if (!e->head_large) { gemm_skinny<EPI_ARGMAX>(4, a, 1, e->stream); return; }
+    if (e->head_xl == 2) { gemm_launch<2, 4, 4, EPI_ARGMAX, 2, 0, 64, true>(a, 1, e->stream); return; }
+    if (e->head_xl == 3) { gemm_launch<4, 2, 4, EPI_ARGMAX, 2, 0, 64, true>(a, 1, e->stream); return; }
     if (e->head_xl) {
         if (e->fp8) gemm_launch<4, 4, 4, EPI_ARGMAX, 2, 0, 64, true, true>(a, 1, e->stream);
         else if (e->w_nt & 1) gemm_launch<4, 4, 4, EPI_ARGMAX, 2, 0, 64, true>(a, 1, e->stream);

@@ -36,6 +36,10 @@ NTTS_D f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// fp32 matrix core (v_mfma_f32_16x16x4_f32): D = A(16x4) * B(4x16) + C.  Lane l holds A[row l&15][k l>>4] and
+// B[k l>>4][col l&15] (one float each); D/C as mfma16.  The reference-encoding path (kernels/enc.h) computes in fp32.
+NTTS_D f32x4 mfma16_f32(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
 // ---- fp8 (OCP e4m3fn on gfx950: max 448, no inf) -- weights and GEMM-input activations of the fp8 model variant
 typedef __attribute__((ext_vector_type(2))) long i64x2;   // one 16-byte LDS chunk = two fp8 MFMA fragments (8 fp8 each)
 constexpr float kFp8Max = 448.0f;

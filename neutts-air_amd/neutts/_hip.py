@@ -18,7 +18,7 @@ DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "libneutts_hip.so")
 
 NTTS_DT_F32, NTTS_DT_BF16, NTTS_DT_I32 = 0, 1, 2
 NTTS_W_BF16, NTTS_W_FP8_E4M3 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 NTTS_PAGE_TOKENS = 32            # include/neutts_hip.h
 PAGE_TOKENS = 32
 ERRORS = {-1: "EINVAL", -2: "ENODEV", -3: "ENOMEM", -4: "ESTATE", -5: "EHIP"}
@@ -44,6 +44,13 @@ class CodecConfigC(C.Structure):
                 ("num_heads", C.c_int32), ("head_dim", C.c_int32), ("quantization_dim", C.c_int32),
                 ("n_levels", C.c_int32), ("levels", C.c_int32 * 8), ("hop_length", C.c_int32), ("rms_eps", C.c_float),
                 ("max_frames", C.c_int32), ("max_rows", C.c_int32)]
+
+
+class EncoderConfigC(C.Structure):
+    _fields_ = [("sem_hidden", C.c_int32), ("sem_layers", C.c_int32), ("sem_heads", C.c_int32), ("sem_ffn", C.c_int32),
+                ("sem_conv_kernel", C.c_int32), ("sem_left", C.c_int32), ("sem_right", C.c_int32), ("sem_ln_eps", C.c_float),
+                ("ac_hidden", C.c_int32), ("n_ratios", C.c_int32), ("ratios", C.c_int32 * 8), ("codec_hidden", C.c_int32),
+                ("n_levels", C.c_int32), ("levels", C.c_int32 * 8), ("max_samples", C.c_int32)]
 
 
 class SamplingC(C.Structure):
@@ -110,6 +117,14 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_codec_finalize": (C.c_int, [p]),
         "ntts_codec_decode": (C.c_int, [p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(f32), i64]),
         "ntts_codec_last_timing": (C.c_int, [p, C.POINTER(f32)]),
+        "ntts_encoder_last_error": (C.c_char_p, [p]),
+        "ntts_encoder_create": (C.c_int, [C.POINTER(EncoderConfigC), C.c_int, C.POINTER(p)]),
+        "ntts_encoder_destroy": (None, [p]),
+        "ntts_encoder_load_tensor": (C.c_int, [p, C.c_char_p, p, C.c_int, C.POINTER(i64), C.c_int, C.c_int]),
+        "ntts_encoder_finalize": (C.c_int, [p]),
+        "ntts_encoder_encode": (C.c_int, [p, C.POINTER(f32), i64, C.POINTER(i32), i32, C.POINTER(i32)]),
+        "ntts_encoder_read_stage": (C.c_int, [p, i32, C.POINTER(f32), i64, C.POINTER(i32), C.POINTER(i32)]),
+        "ntts_encoder_last_timing": (C.c_int, [p, C.POINTER(f32)]),
         "ntts_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(p)]),
         "ntts_host_free": (C.c_int, [p]),
         "ntts_k_gemm_bf16": (C.c_int, [p, i64, p, p, p, i64, i32, i32, i32, i32]),
@@ -623,3 +638,84 @@ class CodecEngine:
         ms = C.c_float()
         self._chk(self.lib.ntts_codec_last_timing(self.h, C.byref(ms)))
         return ms.value
+
+
+class EncoderEngine:
+    """NeuCodec encoder on one GPU: 16 kHz mono waveform -> FSQ codes at 50 Hz (replaces codec.encode_code,
+    ref:neutts/neutts.py:266-271).  One clip per call; fp32."""
+
+    STAGES = {"features": 0, "concat": 1, "fc": 2, "latents": 3}
+
+    def __init__(self, cfg: dict, device: int = 0, lib_path: Optional[str] = None):
+        self.lib = load_library(lib_path)
+        ratios = list(cfg.get("ratios", [2, 2, 4, 4, 5]))
+        lv = list(cfg.get("levels", [4] * 8))
+        self.hop = int(np.prod(ratios))
+        self.max_samples = int(cfg.get("max_samples", 30 * 16000))
+        c = EncoderConfigC(cfg.get("sem_hidden", 1024), cfg.get("sem_layers", 16), cfg.get("sem_heads", 16),
+                           cfg.get("sem_ffn", 4096), cfg.get("sem_conv_kernel", 31), cfg.get("sem_left", 64),
+                           cfg.get("sem_right", 8), cfg.get("sem_ln_eps", 1e-5), cfg.get("ac_hidden", 48), len(ratios),
+                           (C.c_int32 * 8)(*(ratios + [1] * (8 - len(ratios)))), cfg.get("codec_hidden", 1024), len(lv),
+                           (C.c_int32 * 8)(*(lv + [1] * (8 - len(lv)))), self.max_samples)
+        h = C.c_void_p()
+        rc = self.lib.ntts_encoder_create(C.byref(c), device, C.byref(h))
+        if rc != 0:
+            raise NeuTTSHipError(rc, (self.lib.ntts_encoder_last_error(None) or b"").decode())
+        self.h = h
+        self.device = device
+
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise NeuTTSHipError(rc, (self.lib.ntts_encoder_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ntts_encoder_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_state_dict(self, sd: Dict[str, object]):
+        """Encoder tensors of an Xcodec2Model-named state dict; decoder / project_out entries are skipped here (they belong
+        to CodecEngine), anything else unknown is an error at finalize only if a needed tensor is missing."""
+        for k, v in sd.items():
+            if k.startswith(("acoustic_decoder.", "decoder.", "quantizer.project_out.")) or k.endswith("masked_spec_embed"):
+                continue
+            ptr, code, shape, is_dev, keep = _tensor_ptr(v)
+            shp = (C.c_int64 * len(shape))(*shape)
+            self._chk(self.lib.ntts_encoder_load_tensor(self.h, k.encode(), C.c_void_p(ptr), code, shp, len(shape), is_dev))
+            del keep
+        self._chk(self.lib.ntts_encoder_finalize(self.h))
+
+    def encode(self, wav: np.ndarray) -> np.ndarray:
+        """wav: float32 mono at 16 kHz, [L] -> int32 codes [L // hop + 1]."""
+        w = np.ascontiguousarray(np.asarray(wav, dtype=np.float32).reshape(-1))
+        if w.size < 1:
+            raise ValueError("empty waveform")
+        if w.size > self.max_samples:
+            raise ValueError(f"clip of {w.size} samples exceeds max_samples {self.max_samples}")
+        cap = w.size // self.hop + 2
+        out = np.empty(cap, dtype=np.int32)
+        n = C.c_int32()
+        self._chk(self.lib.ntts_encoder_encode(self.h, w.ctypes.data_as(C.POINTER(C.c_float)), w.size,
+                                               out.ctypes.data_as(C.POINTER(C.c_int32)), cap, C.byref(n)))
+        return out[: n.value].copy()
+
+    def read_stage(self, name: str) -> np.ndarray:
+        """Intermediate of the last encode() call ('features' | 'concat' | 'fc' | 'latents') as [T, C] float32."""
+        cap = (self.max_samples // self.hop + 2) * 4096
+        buf = np.empty(cap, dtype=np.float32)
+        r, c = C.c_int32(), C.c_int32()
+        self._chk(self.lib.ntts_encoder_read_stage(self.h, self.STAGES[name], buf.ctypes.data_as(C.POINTER(C.c_float)), cap,
+                                                   C.byref(r), C.byref(c)))
+        return buf[: r.value * c.value].reshape(r.value, c.value).copy()
+
+    def last_timing(self) -> float:
+        ms = C.c_float()
+        self._chk(self.lib.ntts_encoder_last_timing(self.h, C.byref(ms)))
+        return ms.value
+

@@ -85,11 +85,14 @@ def _device_index(device, what: str) -> int:
 
 class _CodecFacade:
     """What `self.codec` looks like to callers of the reference: `.decode_code(codes[B,1,T]) -> wav[B,1,480*T]`,
-    `.encode_code(audio_or_path=...)` (delegated to the neucodec package when it is installed) and `.device`."""
+    `.encode_code(audio_or_path=...) -> codes[B,1,T]` and `.device`.  `enc_engine` = the on-device encoder
+    (_hip.EncoderEngine); `encoder` = the neucodec package's torch module, used only when the checkpoint's encoder tensors
+    could not be mapped onto the engine (reference_encoder="neucodec" / "auto")."""
 
-    def __init__(self, engine: _hip.CodecEngine, encoder=None):
+    def __init__(self, engine: _hip.CodecEngine, encoder=None, enc_engine: Optional[_hip.EncoderEngine] = None):
         self.engine = engine
         self.encoder = encoder
+        self.enc_engine = enc_engine
         self.device = f"cuda:{engine.device}"
 
     def decode_code(self, codes):
@@ -101,11 +104,55 @@ class _CodecFacade:
         return torch.from_numpy(np.stack(wavs)[:, None, :])
 
     def encode_code(self, audio_or_path):
+        """neucodec `encode_code`: a path, or a 16 kHz waveform [B, 1, L] (tensor / array) -> int codes [B, 1, T]."""
+        if self.enc_engine is not None:
+            import torch  # tensor container for API compatibility
+            if isinstance(audio_or_path, (str, Path)):
+                wavs = [load_audio_16k(audio_or_path)]
+            else:
+                arr = np.asarray(audio_or_path.detach().cpu() if hasattr(audio_or_path, "detach") else audio_or_path, dtype=np.float32)
+                if arr.ndim == 1:
+                    arr = arr[None, None, :]
+                elif arr.ndim == 2:
+                    arr = arr[:, None, :]
+                if arr.ndim != 3 or arr.shape[1] != 1:
+                    raise ValueError("audio must have shape [B, 1, L] (mono, 16 kHz)")
+                wavs = [arr[b, 0] for b in range(arr.shape[0])]
+            return torch.from_numpy(np.stack([self.enc_engine.encode(w) for w in wavs])[:, None, :].astype(np.int64))
         if self.encoder is None:
-            raise ImportError("Reference encoding needs the `neucodec` package (encoder half, not part of the "
-                              "synthesis hot path): pip install neucodec, or pre-encode references "
-                              "(ref:examples/encode_reference.py).")
+            raise ImportError("Reference encoding needs encoder weights: a codec spec with an 'encoder' entry, or the `neucodec` "
+                              "package (pip install neucodec); or pre-encode references (ref:examples/encode_reference.py).")
         return self.encoder.encode_code(audio_or_path=audio_or_path)
+
+
+def load_audio_16k(path) -> np.ndarray:
+    """`librosa.load(path, sr=16000, mono=True)` (ref:neutts/neutts.py:268) -> float32 [L].  Without librosa, PCM / float WAV
+    files are read with scipy and resampled with a polyphase filter (a front-end detail: the two resamplers are not
+    sample-identical); anything else needs librosa, as in the reference."""
+    try:
+        import librosa
+    except ImportError:
+        librosa = None
+    if librosa is not None:
+        wav, _ = librosa.load(str(path), sr=16000, mono=True)
+        return np.asarray(wav, dtype=np.float32)
+    if not str(path).lower().endswith(".wav"):
+        raise ImportError("Reading this audio format needs librosa (pip install librosa), as in the reference.")
+    from math import gcd
+    from scipy.io import wavfile
+    from scipy.signal import resample_poly
+    sr, x = wavfile.read(str(path))
+    if x.dtype.kind == "i":
+        x = x.astype(np.float32) / float(2 ** (8 * x.dtype.itemsize - 1))
+    elif x.dtype.kind == "u":
+        x = (x.astype(np.float32) - 128.0) / 128.0
+    x = x.astype(np.float32)
+    if x.ndim == 2:
+        x = x.mean(axis=1)
+    if sr != 16000:
+        g = gcd(int(sr), 16000)
+        x = resample_poly(x, 16000 // g, int(sr) // g).astype(np.float32)
+    return x
 
 
 class NeuTTS:
@@ -121,6 +168,7 @@ class NeuTTS:
         lib_path: Optional[str] = None,
         do_sample: bool = True,
         seed: int = 0,
+        reference_encoder: str = "auto",
     ):
         # Consts (ref:neutts/neutts.py:84-91)
         self.sample_rate = 24_000
@@ -137,6 +185,11 @@ class NeuTTS:
         self._is_onnx_codec = False
         self._lib_path = lib_path
         self._max_batch = max_batch
+        # encode_reference: "hip" = the on-device encoder engine or an error, "neucodec" = the neucodec package's torch
+        # module, "auto" = the engine when the checkpoint's encoder tensors map onto it, else the package (with a warning)
+        if reference_encoder not in ("auto", "hip", "neucodec"):
+            raise ValueError("reference_encoder must be 'auto', 'hip' or 'neucodec'")
+        self._reference_encoder = reference_encoder
         # sampling contract of the reference call (ref:neutts/neutts.py:338-347); do_sample=False = greedy
         self.do_sample = do_sample
         self.top_k = 50
@@ -210,9 +263,10 @@ class NeuTTS:
     def _load_codec(self, codec_repo, codec_device):
         print(f"Loading codec from: {codec_repo if isinstance(codec_repo, str) else '<in-memory weights>'} on {codec_device} ...")
         dev = _device_index(codec_device, "codec_device")
-        encoder = None
+        encoder, enc_spec = None, None
         if isinstance(codec_repo, dict):
             cfg, sd = dict(codec_repo["config"]), codec_repo["state_dict"]
+            enc_spec = codec_repo.get("encoder")       # {"config": EncoderConfig fields, "state_dict": Xcodec2Model names}
         else:
             match codec_repo:
                 case "neuphonic/neucodec" | "neuphonic/distill-neucodec":
@@ -224,8 +278,16 @@ class NeuTTS:
                             "encoder): pip install neucodec") from e
                     cls = NeuCodec if codec_repo == "neuphonic/neucodec" else DistillNeuCodec
                     encoder = cls.from_pretrained(codec_repo).eval()
-                    sd = neucodec_to_xcodec2_names(encoder.state_dict())
+                    full_sd = encoder.state_dict()
+                    sd = neucodec_to_xcodec2_names(full_sd)
                     cfg = {}
+                    if self._reference_encoder != "neucodec":
+                        try:
+                            enc_spec = {"config": {}, "state_dict": neucodec_encoder_to_xcodec2_names(full_sd)}
+                        except ValueError as e:
+                            if self._reference_encoder == "hip":
+                                raise
+                            warnings.warn(f"encode_reference stays on the neucodec package's torch encoder: {e}")
                 case "neuphonic/neucodec-onnx-decoder":
                     raise NotImplementedError("The ONNX decoder is a CPU runtime of the same decoder; use "
                                               "'neuphonic/neucodec' for the MI355X path.")
@@ -242,7 +304,15 @@ class NeuTTS:
         self.streaming_stride_samples = self.streaming_frames_per_chunk * self.hop_length
         engine = _hip.CodecEngine(cfg, dev, self._lib_path)
         engine.load_state_dict(sd)
-        self.codec = _CodecFacade(engine, encoder)
+        enc_engine = None
+        if enc_spec is not None and self._reference_encoder != "neucodec":
+            ecfg = dict(enc_spec.get("config", {}))
+            ecfg.setdefault("max_samples", 30 * 16000)       # the context holds ~30 s of audio (ref:README.md:35)
+            enc_engine = _hip.EncoderEngine(ecfg, dev, self._lib_path)
+            enc_engine.load_state_dict(enc_spec["state_dict"])
+        elif self._reference_encoder == "hip":
+            raise ValueError("reference_encoder='hip' needs encoder weights: a codec spec with an 'encoder' entry or a NeuCodec checkpoint")
+        self.codec = _CodecFacade(engine, encoder, enc_engine)
 
     # ------------------------------------------------------------------------------------------ public API
     def infer(self, text: str, ref_codes, ref_text: str) -> np.ndarray:
@@ -286,10 +356,10 @@ class NeuTTS:
         return self._infer_stream_batch_hip(prompts, [[int(c) for c in _to_list(rc)] for rc in ref_codes])
 
     def encode_reference(self, ref_audio_path: str | Path):
-        """ref:neutts/neutts.py:266-271 -- one-off per speaker, off the hot path: delegated to neucodec's encoder."""
-        import librosa
+        """ref:neutts/neutts.py:266-271: 16 kHz mono -> `codec.encode_code` -> 1-D int codes at 50 Hz.  On the encoder engine
+        (kernels/enc.h) when encoder weights are loaded; one-off per speaker, off the synthesis hot path."""
         import torch
-        wav, _ = librosa.load(ref_audio_path, sr=16000, mono=True)
+        wav = load_audio_16k(ref_audio_path)
         wav_tensor = torch.from_numpy(wav).float().unsqueeze(0).unsqueeze(0)  # [1, 1, T]
         with torch.no_grad():
             ref_codes = self.codec.encode_code(audio_or_path=wav_tensor).squeeze(0).squeeze(0)
@@ -643,3 +713,104 @@ def neucodec_to_xcodec2_names(sd: Dict[str, object], strict: bool = True) -> Dic
             + (f"  unrecognised decoder-side keys ({len(unknown)}): " + ", ".join(unknown[:12]) + (" ..." if len(unknown) > 12 else "")
                if unknown else ""))
     return out
+
+
+def neucodec_encoder_to_xcodec2_names(sd: Dict[str, object], n_layers: int = 16) -> Dict[str, object]:
+    """Original `neucodec` ENCODER-side state-dict keys -> the xcodec2 parameter names the encoder engine loads.
+
+    Like the decoder mapping above, the key layout is a reading of the neucodec / xcodec2 sources that cannot be checked
+    offline, so nothing is trusted: the w2v-BERT, adapter, fc and project_in tensors are looked up by name and every one
+    must exist; the acoustic encoder (`CodecEnc.*`, weight-normalised convolutions + SnakeBeta activations inside nested
+    nn.Sequential containers) is mapped by MODULE ORDER and checked by SHAPE -- 1 input conv, per ratio 3 x (snake, conv 7,
+    snake, conv 1) + snake + strided conv, then snake + conv 3 -- with weight norm folded (w = g * v / ||v||).  Any mismatch
+    raises ValueError; the caller then keeps the neucodec package's own encoder."""
+    import torch
+    out: Dict[str, object] = {}
+    missing: List[str] = []
+
+    def put(dst, src):
+        if src in sd:
+            out[dst] = sd[src]
+        else:
+            missing.append(f"{src} (-> {dst})")
+
+    for k in sd:
+        if k.startswith("semantic_model.") and "masked_spec_embed" not in k:
+            parts = k.split(".")
+            if parts[1:3] == ["encoder", "layers"] and int(parts[3]) >= n_layers:
+                continue                                   # neucodec reads hidden_states[16]: layers 17..24 never run
+            if parts[1] in ("feature_projection", "encoder"):
+                out["semantic_encoder." + k[len("semantic_model."):]] = sd[k]
+    if not any(k.startswith("semantic_encoder.encoder.layers.") for k in out):
+        missing.append("semantic_model.encoder.layers.* (w2v-BERT 2.0)")
+    put("semantic_adapter.conv1.weight", "SemanticEncoder_module.initial_conv.weight")
+    put("semantic_adapter.conv2.weight", "SemanticEncoder_module.residual_blocks.1.weight")
+    put("semantic_adapter.conv2.bias", "SemanticEncoder_module.residual_blocks.1.bias")
+    put("semantic_adapter.conv3.weight", "SemanticEncoder_module.residual_blocks.3.weight")
+    put("semantic_adapter.conv3.bias", "SemanticEncoder_module.residual_blocks.3.bias")
+    put("semantic_adapter.conv4.weight", "SemanticEncoder_module.final_conv.weight")
+    put("fc_encoder.weight", "fc_prior.weight")
+    put("fc_encoder.bias", "fc_prior.bias")
+    put("quantizer.project_in.weight", "generator.quantizer.project_in.weight")
+    put("quantizer.project_in.bias", "generator.quantizer.project_in.bias")
+    # acoustic encoder: modules in registration order
+    mods: Dict[str, Dict[str, object]] = {}
+    for k, v in sd.items():
+        if not k.startswith("CodecEnc.") or "filter" in k:
+            continue
+        for suf in ("parametrizations.weight.original0", "parametrizations.weight.original1", "weight_g", "weight_v", "weight",
+                    "bias", "alpha", "beta"):
+            if k.endswith("." + suf):
+                mods.setdefault(k[: -len(suf) - 1], {})[suf] = v
+                break
+        else:
+            missing.append(f"{k} (unrecognised acoustic-encoder tensor)")
+    convs, snakes = [], []
+    for name, t in mods.items():
+        if "alpha" in t and "beta" in t:
+            snakes.append((name, t["alpha"].reshape(-1), t["beta"].reshape(-1)))
+            continue
+        g = t.get("weight_g", t.get("parametrizations.weight.original0"))
+        v = t.get("weight_v", t.get("parametrizations.weight.original1"))
+        if g is not None and v is not None:
+            w = v * (g.reshape(-1, 1, 1) / torch.linalg.vector_norm(v.float(), dim=(1, 2), keepdim=True).to(v.dtype))
+        elif "weight" in t:
+            w = t["weight"]
+        else:
+            missing.append(f"{name} (neither a convolution nor a SnakeBeta)")
+            continue
+        convs.append((name, w, t.get("bias")))
+    n_ratios = (len(convs) - 2) // 7
+    if missing or len(convs) != 2 + 7 * n_ratios or len(snakes) != 1 + 7 * n_ratios or n_ratios < 1:
+        raise ValueError("NeuCodec checkpoint does not match the expected ENCODER layout: "
+                         + (", ".join(missing[:12]) + (" ..." if len(missing) > 12 else "") if missing
+                            else f"{len(convs)} convolutions / {len(snakes)} SnakeBeta activations under CodecEnc.*"))
+    ci, si = iter(convs), iter(snakes)
+
+    def conv(dst, k=None, cin=None):
+        name, w, b = next(ci)
+        if w.dim() != 3 or (k is not None and w.shape[2] != k) or (cin is not None and w.shape[1] != cin) or b is None:
+            raise ValueError(f"acoustic encoder: {name} {tuple(w.shape)} is not the convolution expected at {dst}")
+        out[dst + ".weight"], out[dst + ".bias"] = w, b
+        return w.shape[0]
+
+    def snake(dst, c):
+        name, a, b = next(si)
+        if a.numel() != c or b.numel() != c:
+            raise ValueError(f"acoustic encoder: {name} has {a.numel()} channels, {c} expected at {dst}")
+        out[dst + ".act.alpha"], out[dst + ".act.beta"] = a, b
+
+    ch = conv("acoustic_encoder.conv1", 7, 1)
+    for bi in range(n_ratios):
+        b = f"acoustic_encoder.block.{bi}."
+        for u in (1, 2, 3):
+            snake(f"{b}res_unit{u}.snake1", ch)
+            conv(f"{b}res_unit{u}.conv1", 7, ch)
+            snake(f"{b}res_unit{u}.snake2", ch)
+            conv(f"{b}res_unit{u}.conv2", 1, ch)
+        snake(b + "snake1", ch)
+        ch = conv(b + "conv1", None, ch)
+    snake("acoustic_encoder.snake1", ch)
+    conv("acoustic_encoder.conv2", 3, ch)
+    return out
+

@@ -224,3 +224,139 @@ def make_codec_weights(cfg: CodecConfig, seed: int = 0) -> Dict[str, torch.Tenso
     w["decoder.head.linear.weight"] = n(cfg.n_fft + 2, H, s=0.5 * H ** -0.5)
     w["decoder.head.linear.bias"] = n(cfg.n_fft + 2, s=0.1)
     return w
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# NeuCodec ENCODER (reference enrolment, ref:neutts/neutts.py:266-271): geometry + seeded synthetic weights
+# ------------------------------------------------------------------------------------------------------------------
+@dataclass
+class EncoderConfig:
+    """Geometry of `NeuCodec.encode_code`: w2v-BERT 2.0 conformer (first 16 layers) + semantic adapter + acoustic conv
+    encoder + fc + FSQ.  Parameter names / defaults are transformers' Xcodec2Config + Wav2Vec2BertConfig
+    (hf:models/xcodec2/configuration_xcodec2.py:58-86)."""
+    sem_hidden: int = 1024
+    sem_layers: int = 16
+    sem_heads: int = 16
+    sem_ffn: int = 4096
+    sem_feat_dim: int = 160                 # 80 mel bins x stride 2
+    sem_conv_kernel: int = 31
+    sem_left: int = 64                      # relative_key distance clamp
+    sem_right: int = 8
+    sem_ln_eps: float = 1e-5
+    ac_hidden: int = 48                     # encoder_hidden_size
+    ratios: tuple = (2, 2, 4, 4, 5)         # downsampling_ratios: 16 kHz -> 50 Hz
+    codec_hidden: int = 1024                # acoustic encoder output channels
+    levels: tuple = (4, 4, 4, 4, 4, 4, 4, 4)
+    sample_rate: int = 16000
+
+    @property
+    def hop(self) -> int:
+        return int(np.prod(self.ratios))
+
+    @property
+    def cat_dim(self) -> int:               # fc_encoder / quantizer.project_in width
+        return self.codec_hidden + self.sem_hidden
+
+    @staticmethod
+    def neucodec() -> "EncoderConfig":
+        return EncoderConfig()
+
+    @staticmethod
+    def tiny() -> "EncoderConfig":
+        """Same structure (every ratio, 2 conformer layers, head size 16) at a size the SIMT emulator handles."""
+        return EncoderConfig(sem_hidden=64, sem_layers=2, sem_heads=4, sem_ffn=128, ac_hidden=4, codec_hidden=64)
+
+    def to_dict(self):
+        d = asdict(self)
+        d["ratios"] = list(self.ratios)
+        d["levels"] = list(self.levels)
+        return d
+
+
+def make_encoder_weights(cfg: EncoderConfig, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """fp32 state dict with the parameter names of transformers' Xcodec2Model (semantic_encoder.*, semantic_adapter.*,
+    acoustic_encoder.*, fc_encoder.*, quantizer.project_in.*).  Unit-gain matrices, perturbed norm affine terms, non-zero
+    snake alpha/beta (their init is 0, which would hide the exp())."""
+    rng = np.random.default_rng(seed)
+
+    def n(*shape, s):
+        return torch.from_numpy(rng.standard_normal(shape, dtype=np.float32) * np.float32(s))
+
+    w: Dict[str, torch.Tensor] = {}
+
+    def lin(name, out, inp, bias=True, gain=1.0):
+        w[name + ".weight"] = n(out, inp, s=gain * inp ** -0.5)
+        if bias:
+            w[name + ".bias"] = n(out, s=0.05)
+
+    def conv(name, out, inp, k, bias=True, gain=1.0):
+        w[name + ".weight"] = n(out, inp, k, s=gain * (inp * k) ** -0.5)
+        if bias:
+            w[name + ".bias"] = n(out, s=0.05)
+
+    def ln(name, dim):
+        w[name + ".weight"] = 1.0 + n(dim, s=0.1)
+        w[name + ".bias"] = n(dim, s=0.05)
+
+    H, I = cfg.sem_hidden, cfg.sem_ffn
+    p = "semantic_encoder."
+    ln(p + "feature_projection.layer_norm", cfg.sem_feat_dim)
+    lin(p + "feature_projection.projection", H, cfg.sem_feat_dim)
+    hd = H // cfg.sem_heads
+    for i in range(cfg.sem_layers):
+        q = f"{p}encoder.layers.{i}."
+        ln(q + "ffn1_layer_norm", H)
+        lin(q + "ffn1.intermediate_dense", I, H)
+        lin(q + "ffn1.output_dense", H, I)
+        ln(q + "self_attn_layer_norm", H)
+        for nm in ("linear_q", "linear_k", "linear_v", "linear_out"):
+            lin(q + "self_attn." + nm, H, H)
+        w[q + "self_attn.distance_embedding.weight"] = n(cfg.sem_left + cfg.sem_right + 1, hd, s=0.5)
+        ln(q + "conv_module.layer_norm", H)
+        conv(q + "conv_module.pointwise_conv1", 2 * H, H, 1, bias=False)
+        conv(q + "conv_module.depthwise_conv", H, 1, cfg.sem_conv_kernel, bias=False, gain=2.0)
+        ln(q + "conv_module.depthwise_layer_norm", H)
+        conv(q + "conv_module.pointwise_conv2", H, H, 1, bias=False)
+        ln(q + "ffn2_layer_norm", H)
+        lin(q + "ffn2.intermediate_dense", I, H)
+        lin(q + "ffn2.output_dense", H, I)
+        ln(q + "final_layer_norm", H)
+    conv("semantic_adapter.conv1", H, H, 3, bias=False)
+    conv("semantic_adapter.conv2", H, H, 3)
+    conv("semantic_adapter.conv3", H, H, 3)
+    conv("semantic_adapter.conv4", H, H, 3, bias=False)
+
+    def snake(name, dim):
+        w[name + ".act.alpha"] = n(dim, s=0.3)
+        w[name + ".act.beta"] = n(dim, s=0.3)
+
+    a = "acoustic_encoder."
+    conv(a + "conv1", cfg.ac_hidden, 1, 7, gain=3.0)
+    for bi, stride in enumerate(cfg.ratios):
+        dim = cfg.ac_hidden * 2 ** (bi + 1)
+        b = f"{a}block.{bi}."
+        for u in (1, 2, 3):
+            snake(f"{b}res_unit{u}.snake1", dim // 2)
+            conv(f"{b}res_unit{u}.conv1", dim // 2, dim // 2, 7, gain=0.7)
+            snake(f"{b}res_unit{u}.snake2", dim // 2)
+            conv(f"{b}res_unit{u}.conv2", dim // 2, dim // 2, 1, gain=0.7)
+        snake(b + "snake1", dim // 2)
+        conv(b + "conv1", dim, dim // 2, 2 * stride)
+    d_model = cfg.ac_hidden * 2 ** len(cfg.ratios)
+    snake(a + "snake1", d_model)
+    conv(a + "conv2", cfg.codec_hidden, d_model, 3, gain=0.25)
+    lin("fc_encoder", cfg.cat_dim, cfg.cat_dim)
+    lin("quantizer.project_in", len(cfg.levels), cfg.cat_dim, gain=0.6)    # latents spread over all levels, few saturated
+    return w
+
+
+def synthetic_speech(n_samples: int, seed: int = 0, sample_rate: int = 16000) -> np.ndarray:
+    """A seeded speech-like test signal in [-1, 1]: a few gliding harmonics under a slow envelope + a little noise."""
+    rng = np.random.default_rng(seed)
+    t = np.arange(n_samples) / sample_rate
+    f0 = 110.0 + 40.0 * np.sin(2 * np.pi * 0.7 * t + rng.uniform(0, 6.28))
+    ph = 2 * np.pi * np.cumsum(f0) / sample_rate
+    x = sum(a * np.sin(k * ph + rng.uniform(0, 6.28)) for k, a in ((1, 0.5), (2, 0.3), (3, 0.2), (5, 0.1), (9, 0.05)))
+    env = 0.55 + 0.45 * np.sin(2 * np.pi * 2.3 * t + rng.uniform(0, 6.28))
+    x = x * env + 0.01 * rng.standard_normal(n_samples)
+    return (0.5 * x / np.max(np.abs(x))).astype(np.float32)

@@ -100,3 +100,43 @@ def make_codec_engine(cfg, w, lib, max_frames=64, max_rows=512):
 
 def rms(x):
     return float(np.sqrt(np.mean(np.square(np.asarray(x, dtype=np.float64)))))
+
+
+# ------------------------------------------------------------------------------------------------ reference encoder (f4)
+def load_encoder_fixture(name):
+    import synthetic as syn
+    z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=True)
+    d = {k: v for k, v in z["cfg"]}
+    d["ratios"], d["levels"] = tuple(d["ratios"]), tuple(d["levels"])
+    cfg = syn.EncoderConfig(**d)
+    return z, cfg, syn.make_encoder_weights(cfg, int(z["seed"]))
+
+
+def make_encoder_engine(cfg, w, lib, max_samples=16000):
+    d = cfg.to_dict()
+    d["max_samples"] = max_samples
+    eng = _hip.EncoderEngine(d, 0, lib)
+    eng.load_state_dict({k: v.numpy() for k, v in w.items()})
+    return eng
+
+
+def check_encoder_codes(cfg, got_codes, got_lat, gold_codes, gold_lat, lat_tol, tag=""):
+    """Integer parity of an FSQ index stream computed in floating point: the twice-bounded latents agree within `lat_tol`,
+    every code whose gold latents all sit farther than 2 * lat_tol from a rounding boundary is IDENTICAL, and a code that does
+    differ differs only in digits whose gold latent is that close to a boundary (by one level)."""
+    assert got_codes.shape == gold_codes.shape and got_codes.dtype == np.int32
+    err = np.abs(got_lat - gold_lat).max()
+    dist = np.abs(gold_lat - np.floor(gold_lat) - 0.5)            # distance of each gold latent to the nearest x.5
+    safe = (dist > 2 * lat_tol).all(axis=1)
+    same = got_codes == gold_codes
+    print(f"encoder{tag}: latents max |err| {err:.2e} (bound {lat_tol:.0e}); codes equal {same.sum()}/{same.size}; "
+          f"{(~safe).sum()} frames within {2 * lat_tol:.0e} of a rounding boundary")
+    assert err <= lat_tol, err
+    assert same[safe].all(), np.nonzero(~same & safe)[0]
+    levels = np.array(cfg.levels)
+    basis = np.cumprod(np.concatenate([[1], levels[:-1]]))
+    for t in np.nonzero(~same)[0]:
+        dg, dr = (got_codes[t] // basis) % levels, (gold_codes[t] // basis) % levels
+        bad = np.nonzero(dg != dr)[0]
+        assert (np.abs(dg[bad] - dr[bad]) == 1).all() and (dist[t, bad] <= 2 * lat_tol).all(), (t, dg, dr, dist[t])
+    return err

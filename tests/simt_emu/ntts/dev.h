@@ -112,6 +112,30 @@ inline f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return out;
 }
 
+// v_mfma_f32_16x16x4_f32: lane l holds A[row l&15][k l>>4], B[k l>>4][col l&15]; k ascending, fp32 accumulate
+inline f32x4 mfma16_f32(float a, float b, f32x4 c) {
+    struct Dep { float a, b; };
+    int p = emu::wave_parity();
+    auto& s = emu::wave_slots();
+    Dep d{a, b};
+    memcpy(s.b[p][lane_id()], &d, sizeof(d));
+    emu::wave_sync();
+    int l = lane_id(), col = l & 15, rg = l >> 4;
+    f32x4 out = c;
+    for (int r = 0; r < 4; ++r) {
+        int row = rg * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            Dep da, db;
+            memcpy(&da, s.b[p][row + 16 * k], sizeof(Dep));
+            memcpy(&db, s.b[p][col + 16 * k], sizeof(Dep));
+            acc = fmaf(da.a, db.b, acc);
+        }
+        out[r] = acc;
+    }
+    return out;
+}
+
 // ---- fp8 e4m3fn (OCP): 1 sign, 4 exponent (bias 7), 3 mantissa bits; 0x7f = NaN, max finite 448, subnormals 2^-9 .. 7 * 2^-9
 typedef __attribute__((ext_vector_type(2))) long i64x2;
 constexpr float kFp8Max = 448.0f;

@@ -8,7 +8,8 @@ import torch
 
 from oracle import backbone_ref as br
 from oracle import codec_ref as cr
-from common import engine_cfg, rms
+import synthetic as syn
+from common import check_encoder_codes, engine_cfg, rms
 
 
 class FakeTokenizer:
@@ -66,6 +67,8 @@ def build_tts(lib, bcfg=None, ccfg=None, max_batch=2, max_context=256, max_prefi
     # bias the tied embedding towards speech tokens so that greedy decoding emits codec codes
     bw["model.embed_tokens.weight"][tok.speech_base:] *= 3.0
     cw = cr.make_weights(ccfg, 2)
+    ecfg = syn.EncoderConfig.tiny()      # reference encoder (encode_reference): FSQ levels independent of the tiny decoder's
+    ew = syn.make_encoder_weights(ecfg, 4)
     eos = tok.convert_tokens_to_ids("<|SPEECH_GENERATION_END|>")
     t = NeuTTS(
         backbone_repo=dict(config=engine_cfg(bcfg, max_context=max_context, max_prefill_tokens=max_prefill_tokens),
@@ -76,12 +79,14 @@ def build_tts(lib, bcfg=None, ccfg=None, max_batch=2, max_context=256, max_prefi
                                     num_layers=ccfg.num_layers, num_heads=ccfg.num_heads,
                                     quantization_dim=ccfg.quantization_dim, levels=list(ccfg.levels),
                                     hop_length=ccfg.hop_length, max_frames=256, max_rows=1024),
-                        state_dict={k: v.numpy() for k, v in cw.items()}),
+                        state_dict={k: v.numpy() for k, v in cw.items()},
+                        encoder=dict(config=dict(ecfg.to_dict(), max_samples=20000), state_dict={k: v.numpy() for k, v in ew.items()})),
         codec_device="cuda", lib_path=lib, do_sample=False, max_batch=max_batch)
     t.phonemizer = FakePhonemizer()
     t.max_context = 120          # keep the emulated run short
     t.min_new_tokens = 5
     t._oracle = (bcfg, bw, ccfg, cw, tok, eos)
+    t._oracle_encoder = (ecfg, ew)
     return t
 
 
@@ -326,3 +331,31 @@ def test_device_side_code_handoff(tts):
 def _hip_sampling(max_length, min_new, eos):
     from neutts import _hip
     return _hip.Sampling(max_length=max_length, min_new_tokens=min_new, eos_token_id=eos, do_sample=False)
+
+
+
+def test_encode_reference_on_the_encoder_engine(tts, tmp_path):
+    """ref:neutts/neutts.py:266-271 + ref:tests/test_neutts.py (reference codes are a 1-D integer tensor): a WAV file at
+    another sample rate -> 16 kHz mono -> the encoder engine -> codes equal to the oracle's on the same samples; the
+    `codec.encode_code` facade takes the tensor / array / path forms neucodec's does."""
+    from scipy.io import wavfile
+    from oracle import encoder_ref as er
+    from neutts.neutts import load_audio_16k
+    ecfg, ew = tts._oracle_encoder
+    wav24 = syn.synthetic_speech(9000, 6, sample_rate=24000)
+    path = tmp_path / "ref.wav"
+    wavfile.write(str(path), 24000, (wav24 * 32767).astype(np.int16))
+    wav16 = load_audio_16k(path)
+    assert wav16.dtype == np.float32 and abs(wav16.size - 6000) <= 1
+    codes = tts.encode_reference(path)
+    assert isinstance(codes, torch.Tensor) and codes.dim() == 1 and not codes.is_floating_point()
+    want, parts = er.encode(ecfg, ew, wav16, return_parts=True)
+    # integer parity of a float pipeline: identical except where a latent sits on a rounding boundary (common.py)
+    check_encoder_codes(ecfg, codes.numpy().astype(np.int32), tts.codec.enc_engine.read_stage("latents"), want, parts["latents"], 2e-4,
+                        " class")
+    via_tensor = tts.codec.encode_code(audio_or_path=torch.from_numpy(wav16)[None, None, :])
+    assert via_tensor.shape == (1, 1, want.size) and torch.equal(via_tensor[0, 0], codes)
+    assert torch.equal(tts.codec.encode_code(audio_or_path=str(path))[0, 0], codes)
+    with pytest.raises(ValueError, match="shape"):
+        tts.codec.encode_code(audio_or_path=np.zeros((1, 2, 100), np.float32))
+

@@ -31,6 +31,7 @@ test_infer_stream_matches_reference_windowing = cases.test_infer_stream_matches_
 test_infer_batch_shares_prompt_beginnings_and_matches_single_inference = \
     cases.test_infer_batch_shares_prompt_beginnings_and_matches_single_inference
 test_infer_stream_batch_equals_single_streams = cases.test_infer_stream_batch_equals_single_streams
+test_encode_reference_on_the_encoder_engine = cases.test_encode_reference_on_the_encoder_engine
 
 
 def test_ids_to_codes_and_decode_paths_agree(tts):

@@ -63,6 +63,80 @@ def test_neucodec_key_mapping_round_trip_and_strictness():
         neucodec_to_xcodec2_names({"generator.head.out.weight": torch.zeros(2, 2)})
 
 
+def _neucodec_style_encoder(w, cfg, extra_layers=2, parametrize=False):
+    """The encoder half of a neucodec state dict as the neucodec / xcodec2 sources lay it out (nested nn.Sequential
+    containers, weight-normalised convolutions, the full-depth w2v-BERT), built from xcodec2-named weights."""
+    out = {}
+    for k, v in w.items():
+        if k.startswith("semantic_encoder."):
+            out["semantic_model." + k[len("semantic_encoder."):]] = v
+    last = cfg.sem_layers - 1
+    for k, v in list(out.items()):                       # layers 17..24 of the real model: present, never used
+        if f".layers.{last}." in k:
+            for j in range(extra_layers):
+                out[k.replace(f".layers.{last}.", f".layers.{cfg.sem_layers + j}.")] = v + 1.0
+    out["semantic_model.masked_spec_embed"] = torch.zeros(cfg.sem_hidden)
+    for dst, src in (("initial_conv.weight", "conv1.weight"), ("residual_blocks.1.weight", "conv2.weight"),
+                     ("residual_blocks.1.bias", "conv2.bias"), ("residual_blocks.3.weight", "conv3.weight"),
+                     ("residual_blocks.3.bias", "conv3.bias"), ("final_conv.weight", "conv4.weight")):
+        out["SemanticEncoder_module." + dst] = w["semantic_adapter." + src]
+    out["fc_prior.weight"], out["fc_prior.bias"] = w["fc_encoder.weight"], w["fc_encoder.bias"]
+    out["generator.quantizer.project_in.weight"] = w["quantizer.project_in.weight"]
+    out["generator.quantizer.project_in.bias"] = w["quantizer.project_in.bias"]
+
+    def wn(prefix, name):
+        v = w[name + ".weight"]
+        g = torch.linalg.vector_norm(v, dim=(1, 2), keepdim=True)               # weight norm: w = g * v / ||v||
+        vv = v * 3.0                                                            # any positive scale of the direction tensor
+        gk, vk = ("parametrizations.weight.original0", "parametrizations.weight.original1") if parametrize else ("weight_g", "weight_v")
+        out[f"{prefix}.{gk}"], out[f"{prefix}.{vk}"] = g, vv
+        out[prefix + ".bias"] = w[name + ".bias"]
+
+    def snake(prefix, name):
+        out[prefix + ".act.alpha"], out[prefix + ".act.beta"] = w[name + ".act.alpha"], w[name + ".act.beta"]
+        out[prefix + ".upsample.filter"] = torch.zeros(1, 1, 12)
+        out[prefix + ".downsample.lowpass.filter"] = torch.zeros(1, 1, 12)
+
+    wn("CodecEnc.conv_blocks.0", "acoustic_encoder.conv1")
+    for bi in range(len(cfg.ratios)):
+        b, hb = f"CodecEnc.conv_blocks.{bi + 1}.block", f"acoustic_encoder.block.{bi}."
+        for u in range(3):
+            snake(f"{b}.{u}.block.0", f"{hb}res_unit{u + 1}.snake1")
+            wn(f"{b}.{u}.block.1", f"{hb}res_unit{u + 1}.conv1")
+            snake(f"{b}.{u}.block.2", f"{hb}res_unit{u + 1}.snake2")
+            wn(f"{b}.{u}.block.3", f"{hb}res_unit{u + 1}.conv2")
+        snake(f"{b}.3", hb + "snake1")
+        wn(f"{b}.4", hb + "conv1")
+    snake("CodecEnc.conv_final_block.0", "acoustic_encoder.snake1")
+    wn("CodecEnc.conv_final_block.1", "acoustic_encoder.conv2")
+    return out
+
+
+@pytest.mark.parametrize("parametrize", [False, True])
+def test_neucodec_encoder_key_mapping_round_trip_and_strictness(parametrize):
+    import synthetic as syn
+    from neutts.neutts import neucodec_encoder_to_xcodec2_names
+    cfg = syn.EncoderConfig.tiny()
+    w = syn.make_encoder_weights(cfg, 5)
+    nsd = _neucodec_style_encoder(w, cfg, parametrize=parametrize)
+    back = neucodec_encoder_to_xcodec2_names(nsd, n_layers=cfg.sem_layers)
+    assert set(back) == set(w), (set(back) ^ set(w))
+    for k in w:
+        assert torch.allclose(torch.as_tensor(back[k]).reshape(w[k].shape), w[k], rtol=1e-6, atol=1e-7), k   # weight norm folded
+    broken = dict(nsd)
+    broken.pop("fc_prior.bias")
+    with pytest.raises(ValueError, match=r"fc_prior\.bias"):
+        neucodec_encoder_to_xcodec2_names(broken, n_layers=cfg.sem_layers)
+    broken = {k: v for k, v in nsd.items() if not k.startswith("CodecEnc.conv_blocks.3.block.1.")}   # one residual unit gone
+    with pytest.raises(ValueError, match="ENCODER layout|not the convolution expected|channels"):
+        neucodec_encoder_to_xcodec2_names(broken, n_layers=cfg.sem_layers)
+    swapped = dict(nsd)                                                                            # a conv of the wrong kernel size
+    key = [k for k in nsd if k.startswith("CodecEnc.conv_blocks.2.block.0.block.1.") and k.endswith(("weight_v", "original1"))][0]
+    swapped[key] = nsd[key][:, :, :5]
+    with pytest.raises(ValueError, match="not the convolution expected"):
+        neucodec_encoder_to_xcodec2_names(swapped, n_layers=cfg.sem_layers)
+
+
 def test_hf_config_dispatch():
     from transformers import LlamaConfig, Qwen2Config
     from neutts.neutts import _engine_config_from_hf

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call = everything we want from a GPU box, each leg under its own timeout, logs in gpurun_out/.
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_round.sh [legs...]'
-# legs: smoke tests bench b1 prof pmc stream sweep exp   (default: smoke tests bench prof)
+# legs: smoke tests bench b1 nano prof pmc stream sweep   (default: smoke tests bench prof)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -26,29 +26,7 @@ for leg in $LEGS; do
     stream) timeout 300 python tools/stream_probe.py > $OUT/stream_probe.jsonl 2> $OUT/stream_probe.err; echo "stream rc=$?"; cat $OUT/stream_probe.jsonl; tail -3 $OUT/stream_probe.err;;
     sweep)  # SWEEP_KNOBS='[["NTTS_ATTN_DEPTH",[2]]]'
            timeout ${SWEEP_TIMEOUT:-400} python tools/sweep_decode.py --knobs "${SWEEP_KNOBS:-[[\"NTTS_ATTN_DEPTH\",[2]]]}" > $OUT/sweep.log 2>&1; echo "sweep rc=$?"; grep -v '^\[sweep\] weights' $OUT/sweep.log | tail -12;;
-    exp)   # prepared, still unmeasured experiments: persistent big-GEMM kernel, several steps per graph
-           timeout 120 python - <<'PY' 2>&1 | tail -6
-import sys; sys.path[:0] = ["tests", ".", "neutts-air_amd"]
-import torch
-from neutts import _hip
-from test_emu_kernels import EXPERIMENTAL_CASES, run_gemm, _bf16
-lib = _hip.load_library()
-for M, N, K, variant, has_bias in EXPERIMENTAL_CASES + [(3000, 896, 4864, 8, False), (2000, 9728, 896, 8, True)]:
-    g = torch.Generator().manual_seed(M * 1000 + N)
-    x = _bf16(torch.randn(M, K, generator=g)); w = _bf16(torch.randn(N, K, generator=g) / K ** 0.5)
-    b = _bf16(torch.randn(N, generator=g)) if has_bias else None
-    ref = x.float() @ w.float().t() + (b.float() if b is not None else 0)
-    bad = 0
-    for rep in range(5):   # races come and go: repeat
-        out = run_gemm(lib, x.cuda(), w.cuda(), b.cuda() if b is not None else None, variant).float().cpu()
-        bad += int(((out - _bf16(ref).float()).abs() > 2.0 ** -7 * ref.abs().clamp(min=1e-2)).sum())
-    print(f"persistent gemm variant {variant} {M}x{N}x{K}: {bad} elements out of tolerance over 5 runs")
-PY
-           timeout 200 python tools/ubench_gemm.py --prefill 2>&1 | tee $OUT/ubench_prefill_persist.txt | tail -16
-           for env in ${EXP_ENVS:-"NTTS_GEMM_PERSIST=1"}; do
-             echo "== bench with: ${env:-defaults}"
-             env $env timeout 100 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline 2>/dev/null | cut -c1-160
-           done;;
+    nano)  for cfg in nano-fp8 nano-bf16; do timeout 300 python bench.py --config $cfg --steps ${BENCH_STEPS:-2} --warmup 1 --no-cpu-baseline > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err; echo "bench $cfg rc=$?"; cut -c1-1200 $OUT/bench_$cfg.json; tail -12 $OUT/bench_$cfg.err; done;;
     *) echo "unknown leg $leg";;
   esac
 done
