@@ -98,7 +98,8 @@ struct ntts_backbone {
     int st_qkv = 4, st_o = 4, st_gu = 3, st_d = 4;   // LDS ring depth of each skinny decode GEMM
     int head_stages = 2, l_stages = 2, pf_gh = 7, attn_depth = 1, attn_var = 1, gu_tile = 0;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
     bool gu_large = false, head_large = true, pf_attn_simple = false, use_xl = true;
-    int head_xl = 0;   // lm_head tile at large batch: 0 = 128 x 128, 1 = 256 x 256 (16 waves), 2 = 128 x 256, 3 = 256 x 128 (8 waves, two per CU)
+    bool head_xl = false;   // lm_head tile at large batch: 128 x 128, or 256 x 256 (16 waves).  128 x 256 and 256 x 128 tiles (8 waves,
+                            // two workgroups per CU) were measured: 168 / 158 vs 126 us (profiles/r02g_sweep_head_tiles.log)
     // non-temporal policy on the lm_head's weight stream (NTTS_W_NT).  Measured at batch 256
     // (profiles/r02a_sweep_nt_graphsteps.jsonl): lm_head 136.6 -> 132.3 us; on the LDS-DMA rings of the skinny layer GEMMs the
     // same policy was SLOWER (qkv 5.78 -> 5.96, down 9.95 -> 10.54 us; step 1.679 -> 1.718 ms) and is not offered there
@@ -341,8 +342,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->w_nt = env_int("NTTS_W_NT", 1);
     e->xcd_split = env_int("NTTS_XCD_SPLIT", 5);
     e->use_xl = env_int("NTTS_XL", 1) != 0;
-    e->head_xl = env_int("NTTS_HEAD_XL", B > 128 ? 1 : 0);
-    if (e->fp8 && e->head_xl > 1) e->head_xl = 1;
+    e->head_xl = env_int("NTTS_HEAD_XL", B > 128 ? 1 : 0) != 0;
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e->pf_gh = env_int("NTTS_PF_GH", 7);   // all 7 heads of a GQA group in one pass: K/V pages staged once (prefill chunk 35.0 -> 33.4 ms)
     e->attn_depth = env_int("NTTS_ATTN_DEPTH", 1);
@@ -362,7 +362,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     if (e->sks_o > max_slabs) e->sks_o = max_slabs;
     if (e->sks_d > max_slabs) e->sks_d = max_slabs;
     e->attn_depth_small = env_int("NTTS_ATTN_DEPTH_SMALL", 2);
-    e->n_part = e->small ? V / 16 : (e->head_xl == 1 || e->head_xl == 2) ? ((V + 255) / 256) * 4 : e->head_large ? ((V + 127) / 128) * 2 : (V + 63) / 64;
+    e->n_part = e->small ? V / 16 : e->head_xl ? ((V + 255) / 256) * 4 : e->head_large ? ((V + 127) / 128) * 2 : (V + 63) / 64;
     CR_HIP(hipMalloc((void**)&e->h_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->xn_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->qkv_dec, (size_t)B * e->NQKV * 2));
@@ -760,8 +760,6 @@ static void k_lm_head(ntts_backbone* e, bool keep_logits) {
     a.logits = keep_logits ? e->logits : nullptr; a.ld_logits = V;
     a.logits_bf16 = (keep_logits && e->n_sampling > 0) ? e->logits_bf16 : nullptr; a.ld_logits_bf16 = e->ldl;
     if (!e->head_large) { gemm_skinny<EPI_ARGMAX>(4, a, 1, e->stream); return; }
-    if (e->head_xl == 2) { gemm_launch<2, 4, 4, EPI_ARGMAX, 2, 0, 64, true>(a, 1, e->stream); return; }
-    if (e->head_xl == 3) { gemm_launch<4, 2, 4, EPI_ARGMAX, 2, 0, 64, true>(a, 1, e->stream); return; }
     if (e->head_xl) {
         if (e->fp8) gemm_launch<4, 4, 4, EPI_ARGMAX, 2, 0, 64, true, true>(a, 1, e->stream);
         else if (e->w_nt & 1) gemm_launch<4, 4, 4, EPI_ARGMAX, 2, 0, 64, true>(a, 1, e->stream);
@@ -828,6 +826,8 @@ static void k_gate_up(ntts_backbone* e, int i) {
         else gemm_skinny<EPI_SILU_MUL>(e->st_gu, gu, 1, e->stream);
         return;
     }
+    // (a 4-slot ring on the 128 x 128 tile, 96 KB in flight per CU instead of 64: 13.3 vs 13.4 us -- ring depth is not what
+    //  bounds this kernel; profiles/r02h_sweep_gate_up_ring.log)
     if (e->gu_tile == 1) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);        // 128 x 128, 8 waves
     else if (e->gu_tile == 2) gemm_launch<8, 1, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);   // 256 x 64, 8 waves
     else if (e->gu_large) gemm_large<EPI_SILU_MUL>(e, gu, e->stream);
