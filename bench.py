@@ -107,6 +107,41 @@ def cpu_baseline(cfg, w, prompt, n_new, eos, codec_cfg, codec_w, max_seconds=30.
             "rtf": dt / (n / 50.0)}
 
 
+ROCPROF_SYMBOLS = [   # rocprofv3 symbol prefix -> the step's logical kernels it serves
+    ("attn_decode_kernel<", ["attn_decode_kernel"]),
+    ("gemm_kernel<4, 1, 1, 2, 4,", ["gemm_qkv", "gemm_o_proj_splitk", "gemm_down_splitk"]),
+    ("gemm_kernel<4, 2, 2, 1, 3,", ["gemm_gate_up_silu"]),
+    ("gemm_kernel<4, 4, 4, 3, 2, 0, 64, true", ["gemm_lm_head_argmax"]),
+    ("add_rmsnorm_row_kernel", ["add_rmsnorm_kernel"]),
+]
+
+
+def rocprof_symbols(path, live):
+    """live: logical kernel -> (ms per launch, algorithmic bytes per launch, launches per step) from this run's HIP events."""
+    try:
+        lines = open(path).read().splitlines()
+    except OSError:
+        return None
+    out = []
+    for ln in lines:
+        for prefix, names in ROCPROF_SYMBOLS:
+            if ln.startswith(prefix) and all(n in live for n in names):
+                f = ln.split()
+                calls, total_ms, avg_us, share = int(f[-6]), float(f[-5]), float(f[-4]), float(f[-1])
+                nl = sum(live[n][2] for n in names)
+                alg = sum(live[n][1] * live[n][2] for n in names) / nl
+                live_us = sum(live[n][0] * live[n][2] for n in names) / nl * 1e3
+                out.append({"symbol": prefix.rstrip(",< ") , "serves": names, "calls": calls, "share_pct": share, "avg_us": avg_us,
+                            "launches_per_step": nl, "mean_alg_bytes": alg, "GBps": alg / (avg_us * 1e-6) / 1e9,
+                            "frac_of_hbm_peak": alg / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBPS, "live_avg_us": live_us,
+                            "agree": abs(avg_us - live_us) <= 0.15 * live_us})
+    if not out:
+        return None
+    out.sort(key=lambda r: -r["share_pct"])
+    return {"summary": os.path.relpath(path, ROOT), "command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 0 "
+            "--no-cpu-baseline --no-roofline", "dominant_symbol_by_share": out[0]["symbol"], "symbols": out}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,6 +155,11 @@ def main():
     ap.add_argument("--decode", type=int, default=250)
     ap.add_argument("--vocab", type=int, default=None, help="default: 217488 (NeuTTS-Air), 142080 (assumed Nano)")
     ap.add_argument("--prefill-chunk", type=int, default=64, help="prompts per prefill call")
+    ap.add_argument("--mode", choices=["static", "continuous"], default="static",
+                    help="static (default, BASELINE's shape): one batch of equal-length utterances per step.  continuous: --requests "
+                         "ragged requests (prompts 0.7-1.3 x --prefill, lengths 0.6-1.4 x --decode) through the continuous-batching "
+                         "scheduler -- slots recycled as utterances finish, prefill chunks between decode bursts")
+    ap.add_argument("--requests", type=int, default=None, help="continuous mode: requests per step (default 4 x batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-codec", action="store_true", help="backbone only (profiling aid; not the headline metric)")
@@ -170,19 +210,22 @@ def main():
     ccfg = syn.CodecConfig.tiny() if a.tiny else syn.CodecConfig.neucodec()
     n_codes = int(np.prod(ccfg.levels))
     B, S, N = a.batch, a.prefill, a.decode
+    cont = a.mode == "continuous"
+    R = a.requests or 4 * B
+    S_max, N_max = (int(S * 1.3) + 1, int(N * 1.4) + 1) if cont else (S, N)
     dev = 0 if emu_lib else local
     eng = _hip.BackboneEngine(dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
                                    intermediate_size=cfg.intermediate_size, num_layers=cfg.num_layers,
                                    num_heads=cfg.num_heads, num_kv_heads=cfg.num_kv_heads, rms_eps=cfg.rms_eps,
-                                   max_context=((S + N + 31) // 32) * 32, max_batch=B,
+                                   max_context=((S_max + N_max + 31) // 32) * 32, max_batch=B,
                                    max_prefill_tokens=a.prefill_chunk * S, weight_dtype="fp8" if fp8 else "bf16"), dev, lib)
     codec = None
     if not a.no_codec:
         codec = _hip.CodecEngine(dict(hidden_size=ccfg.hidden_size, intermediate_size=ccfg.intermediate_size,
                                       num_layers=ccfg.num_layers, num_heads=ccfg.num_heads,
                                       quantization_dim=ccfg.quantization_dim, levels=list(ccfg.levels),
-                                      hop_length=ccfg.hop_length, rms_eps=ccfg.rms_eps, max_frames=N,
-                                      max_rows=B * (N + 6)), dev, lib)
+                                      hop_length=ccfg.hop_length, rms_eps=ccfg.rms_eps, max_frames=N_max,
+                                      max_rows=B * (N_max + 6)), dev, lib)
     w = cw = None
     t0 = time.time()
     if rank == 0:
@@ -212,7 +255,38 @@ def main():
         lens_buf = torch.zeros(B, dtype=torch.int32, device=f"cuda:{dev}")
         codes_ptr, lens_ptr = codes_buf.data_ptr(), lens_buf.data_ptr()
 
-    def one_step(collect=False):
+    if cont:   # ragged requests, seeded: prompt lengths 0.7 .. 1.3 x S, generated lengths 0.6 .. 1.4 x N (means S and N)
+        rng = np.random.default_rng(4321 + rank)
+        r_plen = rng.integers(int(S * 0.7), int(S * 1.3) + 1, size=R)
+        r_glen = rng.integers(int(N * 0.6), int(N * 1.4) + 1, size=R)
+        r_prompts = [syn.synthetic_prompt(cfg, lo * 8 + i, int(r_plen[i])) for i in range(R)]
+        r_samp = [_hip.Sampling(max_length=int(r_plen[i] + r_glen[i]), min_new_tokens=int(r_glen[i]), eos_token_id=eos, do_sample=False)
+                  for i in range(R)]
+    cont_tokens = [0]
+
+    def one_step_continuous(collect=False):
+        """One pass over R ragged requests: continuous batching (BackboneEngine.generate: admission by free slots, KV pages
+        and prefill budget; finished slots are read, released and refilled every 16 decode steps), then the codec over the
+        finished utterances in batches of B."""
+        ph = {"generate_wall": 0.0, "codec_wall": 0.0}
+        t1 = time.time()
+        ids = eng.generate(r_prompts, r_samp, steps_per_poll=16, prefill_token_budget=a.prefill_chunk * S)
+        ph["generate_wall"] = (time.time() - t1) * 1e3
+        assert all(len(x) == int(g) for x, g in zip(ids, r_glen)), "continuous run did not produce the expected tokens"
+        cont_tokens[0] = int(sum(len(x) for x in ids))
+        wavs = None
+        if codec is not None:
+            t1 = time.time()
+            order = np.argsort(-r_glen)                          # similar lengths together: fewer padded frames per codec pass
+            for c in range(0, R, B):
+                grp = order[c:c + B]
+                out = codec.decode([(np.asarray(ids[j], dtype=np.int64) % n_codes).astype(np.int32) for j in grp], reuse_output=False)
+                if wavs is None:
+                    wavs = np.concatenate([o[:1000] for o in out[:4]])[None, :]
+            ph["codec_wall"] = (time.time() - t1) * 1e3
+        return ph, None, wavs
+
+    def one_step_static(collect=False):
         """One pass of the hot path over one batch: prompts -> codec-token ids -> 24 kHz waveforms."""
         ph = {"prefill": 0.0, "decode": 0.0, "codec": 0.0, "handoff_host": 0.0, "codec_call_wall": 0.0}
         for c in range(0, B, a.prefill_chunk):
@@ -250,6 +324,8 @@ def main():
         ids = None
         return ph, ids, wavs
 
+    one_step = one_step_continuous if cont else one_step_static
+
     def barrier():
         if world > 1:
             import torch.distributed as dist
@@ -277,7 +353,7 @@ def main():
         assert np.isfinite(wavs[:4]).all(), "non-finite waveform"
     roof = None
     step_info = None
-    if rank == 0 and not a.no_roofline:
+    if rank == 0 and not a.no_roofline and not cont:
         # slot state at mid-generation (mean context S + N/2 ~ 625): prefill everything, decode N/2 steps
         for c in range(0, B, a.prefill_chunk):
             n = min(a.prefill_chunk, B - c)
@@ -309,9 +385,18 @@ def main():
                     traffic_src = "profiles/r02_pmc_traffic.json: " + pm["source"]
         except (OSError, KeyError, ValueError):
             pass
+        # rocprofv3 view of the same command (committed summary of the same configuration): per SYMBOL, since one gemm
+        # template serves three launches per layer.  `agree` = its average duration is within 15 % of this run's HIP events.
+        rocprof = None
+        if not nano and B == 256 and S == 500:
+            rocprof = rocprof_symbols(os.path.join(ROOT, "profiles", "r02g_bench_kernel_stats.txt"),
+                                      {r[1]: (r[2], r[3], r[4]) for r in rows})
         roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": ms * 1e3,
                 "alg_bytes_per_launch": nbytes, "launches_per_step": nl,
+                "dominant_choice": "largest ms/step among the step's logical kernels (HIP events, this run); by rocprofv3 SYMBOL "
+                                   "share the split-K skinny GEMM template (qkv + o + down, 3 launches per layer) comes first: rocprof.symbols",
+                "rocprof": rocprof,
                 "per_kernel": [{"kernel": r[1], "us": r[2] * 1e3, "launches_per_step": r[4], "alg_bytes": r[3],
                                 "GBps": r[3] / (r[2] * 1e-3) / 1e9} for r in rows]}
         step_info = {"ms": step_ms, "alg_bytes": step_bytes, "achieved_GBps": step_bytes / (step_ms * 1e-3) / 1e9,
@@ -324,7 +409,7 @@ def main():
         cpu = cpu_baseline(cfg, w, prompts[0], N, eos, ccfg, cw)
 
     if rank == 0:
-        tokens = world * B * N * a.steps
+        tokens = world * (cont_tokens[0] if cont else B * N) * a.steps
         value = tokens / dt
         stages = "backbone prefill + decode loop" + (" + NeuCodec decoder to 24 kHz waveform (D2H included)"
                                                      if codec is not None else " (codec skipped: --no-codec)")
@@ -338,6 +423,10 @@ def main():
         else:
             workload = (f"NeuTTS-Air bf16 {world}xMI355X batch={B} synthetic prompts per GPU, {S} prefill / {N} decode tokens, greedy, "
                         f"continuous-batching engine + hipGraph decode (BASELINE.json configs[{2 if world == 1 else 3}])")
+        if cont:
+            workload = (f"CONTINUOUS mode (not BASELINE's static shape): {R} ragged requests per GPU through {B} decode slots, prompts "
+                        f"{int(S * 0.7)}-{int(S * 1.3)} tokens, {int(N * 0.6)}-{int(N * 1.4)} generated tokens each, slots recycled as utterances finish; "
+                        + workload)
         rec = {
             "metric": "codec-tokens/s", "value": value, "unit": "codec-tokens/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
