@@ -289,12 +289,15 @@ def main():
     def one_step_static(collect=False):
         """One pass of the hot path over one batch: prompts -> codec-token ids -> 24 kHz waveforms."""
         ph = {"prefill": 0.0, "decode": 0.0, "codec": 0.0, "handoff_host": 0.0, "codec_call_wall": 0.0}
+        tw = [time.time()]                                   # host wall-clock stamps (reported as phase_ms.host_wall_*)
         for c in range(0, B, a.prefill_chunk):
             n = min(a.prefill_chunk, B - c)
             eng.prefill(prompts[c:c + n], list(range(c, c + n)), [samp] * n)
             if collect:
                 ph["prefill"] += eng.last_timing()[0]
+        tw.append(time.time())
         eng.decode(N - 1)
+        tw.append(time.time())
         wavs = None
         if codec is None:
             eng.sync()
@@ -319,8 +322,15 @@ def main():
             ph["codec_call_wall"] = (time.time() - tc) * 1e3
             ph["codec"] = codec.last_timing()
             assert wavs.shape == (B, ccfg.hop_length * N)
+        tw.append(time.time())
         for s in range(B):
             eng.release(s)
+        tw.append(time.time())
+        ph["host_wall_prefill_calls"] = (tw[1] - tw[0]) * 1e3     # host time inside the (asynchronous) prefill calls
+        ph["host_wall_decode_call"] = (tw[2] - tw[1]) * 1e3       # host time enqueueing the decode graphs
+        ph["host_wall_wait_and_codec"] = (tw[3] - tw[2]) * 1e3    # blocking: decode done, codec pass, D2H
+        ph["host_wall_release"] = (tw[4] - tw[3]) * 1e3
+        ph["host_wall_total"] = (tw[4] - tw[0]) * 1e3
         ids = None
         return ph, ids, wavs
 
@@ -337,8 +347,11 @@ def main():
         one_step()
     barrier()
     t0 = time.time()
+    step_wall = []                                   # per-step host wall time (diagnostic; `value` uses the barrier-bracketed total)
     for _ in range(a.steps):
+        ts = time.time()
         one_step()
+        step_wall.append(round((time.time() - ts) * 1e3, 2))
     barrier()
     dt = time.time() - t0
     if world > 1:
@@ -437,7 +450,7 @@ def main():
                        "parallelism": f"independent shards x{world}, RCCL weight broadcast only"},
             "tokens_per_s_per_gpu": value / world,
             "rtf": dt / (tokens / 50.0),
-            "phase_ms": ph,
+            "phase_ms": ph, "step_wall_ms": step_wall,
             "roofline": roof, "decode_step": step_info, "cpu_baseline": cpu,
         }
         print(json.dumps(rec), flush=True)

@@ -85,7 +85,26 @@ def layout():
             print(f"  {CONFIGS[cfg]:18s} row-major {c0:7.2f}  tile-major {c1:7.2f}", flush=True)
 
 
+def wreg():
+    """decode shapes, HBM-cold weights: the tile kernels the engine uses vs the weight-in-registers kernel (gemm_wreg.h)"""
+    for name, (M, N, K) in SHAPES.items():
+        wbytes = N * K * 2
+        cold = max(2, int(400e6 // wbytes))
+        print(f"== {name}  M={M} N={N} K={K}  cold copies={cold}")
+        base = {"qkv": 12, "o": 12, "gate_up": 54, "down": 12}[name]
+        print(f"  tile kernel {CONFIGS[base]:16s} (no split-K)  cold {probe(M, N, K, base, 16, cold):7.2f}")
+        if K <= 896:
+            print(f"  wreg SiLU*mul epilogue (N/2 outputs)       cold {probe(M, N, K, 70, 0, cold):7.2f}")
+        if K <= 896:
+            print("  wreg split-K 1 slice, ablations: " + "  ".join(f"{lab} {probe(M, N, K, 76, a, cold):6.2f}" for lab, a in
+                  (("full", 0), ("noMFMA", 1), ("noDMA", 2), ("noStore", 4), ("noW", 8), ("noMFMA+noDMA", 3), ("noMFMA/DMA/W", 11), ("nothing", 15))), flush=True)
+        for x in range(0, 5):
+            print(f"  wreg split-K, {-(-K // 896) + x:2d} slices                    cold {probe(M, N, K, 71 + x, 0, cold):7.2f}", flush=True)
+
+
 def main():
+    if "--wreg" in sys.argv:
+        return wreg()
     if "--head" in sys.argv:
         return head()
     if "--layout" in sys.argv:
