@@ -4,18 +4,9 @@
 
 #include "../../include/neutts_hip.h"
 #include "kernels/gemm.h"
-#include "kernels/gemm_wreg.h"
 #include "kernels/norm.h"
 
 using namespace ntts;
-
-// row-major W[N][K] -> the engine's tile-major layout (64-row x 64-k blocks, consecutive K tiles of a 64-row group contiguous)
-NTTS_KERNEL(256) void tile_major_kernel(const bf16_t* src, bf16_t* dst, int N, int K) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (long)N * K) return;
-    const long n = i / K, k = i % K;
-    dst[(n >> 6) * 64 * K + (k >> 6) * 4096 + (n & 63) * 64 + (k & 63)] = src[i];
-}
 
 extern "C" int ntts_k_gemm_bf16(const void* A, int64_t lda, const void* W, const void* bias, void* C, int64_t ldc,
                                 int32_t M, int32_t N, int32_t K, int32_t variant) {
@@ -27,6 +18,8 @@ extern "C" int ntts_k_gemm_bf16(const void* A, int64_t lda, const void* W, const
     if (variant == 1) NTTS_GEMM_L(EPI_BF16, a, 1, (hipStream_t)0);
     else if (variant == 2) NTTS_GEMM_S(EPI_BF16, a, 1, (hipStream_t)0);
     else if (variant == 4) NTTS_GEMM_XL(EPI_BF16, a, 1, (hipStream_t)0);
+    else if (variant == 7) gemm_asym_launch<4, 4, 4, EPI_BF16, true>(a, (hipStream_t)0);    // XL tile, asymmetric ring: W deep
+    else if (variant == 8) gemm_asym_launch<4, 4, 4, EPI_BF16, false>(a, (hipStream_t)0);   // XL tile, asymmetric ring: X deep
     else if (variant == 5) gemm_launch<4, 4, 4, EPI_BF16, 4, 0, 32>(a, 1, (hipStream_t)0);   // XL tile, 4 ring slots of K = 32
     else if (variant == 6) gemm_launch<2, 2, 4, EPI_BF16, 3, 0, 32>(a, 1, (hipStream_t)0);   // L tile, 3 ring slots of K = 32
     else if (variant == 3) {  // split-K slabs reduced by the norm kernel (the decode o_proj / down_proj path)
@@ -41,35 +34,6 @@ extern "C" int ntts_k_gemm_bf16(const void* A, int64_t lda, const void* W, const
         add_rmsnorm_launch(n, (hipStream_t)0);
         if (hipDeviceSynchronize() != hipSuccess) { hipFree(slabs); return NTTS_EHIP; }
         hipFree(slabs);
-    } else if (variant == 7 || variant == 8) {
-        // weight-in-registers decode kernel (gemm_wreg.h) on a tile-major copy of W.  7: split-K slabs + reduce (the down_proj
-        // path; K slices of <= 896).  8: W = gate/up packed in 16-row groups (8 gate + 8 up rows of the same 8 features), C = the
-        // [M][N/2] SiLU(gate)*up activations (ldc = N/2), K <= 896.
-        if (bias || (N % 16) || ldc != (variant == 7 ? N : N / 2) || (variant == 8 && K > 64 * kWregKT)) return NTTS_EINVAL;
-        const long npad = (N + 63) / 64 * 64;
-        bf16_t* wt = nullptr;
-        if (hipMalloc((void**)&wt, (size_t)npad * K * 2) != hipSuccess) return NTTS_ENOMEM;
-        hipMemset(wt, 0, (size_t)npad * K * 2);
-        NTTS_LAUNCH((tile_major_kernel), dim3((unsigned)(((long)N * K + 255) / 256)), dim3(256), (hipStream_t)0, (const bf16_t*)W, wt, N, K);
-        a.W = wt; a.w_tile_major = 1;
-        int rc = NTTS_OK;
-        if (variant == 7) {
-            const int ks = (K / 64 + kWregKT - 1) / kWregKT < 2 ? 2 : (K / 64 + kWregKT - 1) / kWregKT, ns = gemm_nsplit(K, ks);
-            float* slabs = nullptr;
-            if (hipMalloc((void**)&slabs, (size_t)ns * M * N * sizeof(float)) != hipSuccess) { hipFree(wt); return NTTS_ENOMEM; }
-            a.out = slabs; a.ldo = N;
-            if (!gemm_wreg_launch<EPI_SPLITK>(a, ks, (hipStream_t)0)) rc = NTTS_EINVAL;
-            NormArgs n{};
-            n.slabs = slabs; n.nslab = ns; n.slab_rows = M; n.resid_out = (bf16_t*)C; n.M = M; n.H = N;
-            if (rc == NTTS_OK) add_rmsnorm_launch(n, (hipStream_t)0);
-            if (hipDeviceSynchronize() != hipSuccess) rc = NTTS_EHIP;
-            hipFree(slabs);
-        } else {
-            if (!gemm_wreg_launch<EPI_SILU_MUL>(a, 1, (hipStream_t)0)) rc = NTTS_EINVAL;
-            if (hipDeviceSynchronize() != hipSuccess) rc = NTTS_EHIP;
-        }
-        hipFree(wt);
-        if (rc != NTTS_OK) return rc;
     } else return NTTS_EINVAL;
     if (hipDeviceSynchronize() != hipSuccess) return NTTS_EHIP;
     return hipGetLastError() == hipSuccess ? NTTS_OK : NTTS_EHIP;
@@ -164,16 +128,15 @@ extern "C" int ntts_k_gemm_probe(int32_t M, int32_t N, int32_t K, int32_t config
     bf16_t *X = nullptr, *W = nullptr, *C = nullptr;
     const size_t wn = (size_t)N * K;
     if (hipMalloc((void**)&X, (size_t)M * K * 2) != hipSuccess || hipMalloc((void**)&W, wn * 2 * copies) != hipSuccess ||
-        hipMalloc((void**)&C, (size_t)M * N * (config >= 70 ? 4 * 16 : 2)) != hipSuccess)   // 7x: up to 16 fp32 split-K slabs
+        hipMalloc((void**)&C, (size_t)M * N * 2) != hipSuccess)
         return NTTS_ENOMEM;
     hipMemset(X, 0x11, (size_t)M * K * 2);
     hipMemset(W, 0x22, wn * 2 * copies);
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    const bool pf = (abl & 8) != 0 && config != 76;   // (config 76 reads bit 3 as an ablation of its own)
+    const bool pf = (abl & 8) != 0;
     const int tile_major = (abl & 16) ? 1 : 0;     // weights addressed tile-major (same bytes, sequential per workgroup)
-    const int abl_full = abl & 15;                  // config 76 (gemm_wreg ablations) uses bit 3 as "no weight loads"
-    if (config != 76) abl &= 7; else abl = 0;
+    abl &= 7;
     auto run = [&](int i) {
         if (pf) NTTS_LAUNCH((prefetch_kernel), dim3(256), dim3(256), (hipStream_t)0, (const u32x4*)(W + (size_t)((i + 1) % copies) * wn), (long)(wn / 8), (int*)nullptr);
         GemmArgs a{};
@@ -209,26 +172,9 @@ extern "C" int ntts_k_gemm_probe(int32_t M, int32_t N, int32_t K, int32_t config
             case 52: probe_launch<8, 1, 2, 2>(a, 1, abl); break;
             case 53: probe_launch<8, 2, 2, 2>(a, 1, abl); break;   // 256 x 128, 16 waves
             case 54: probe_launch<4, 2, 2, 3>(a, 1, abl); break;   // 128 x 128, 8 waves
-            // weight-in-registers kernel (gemm_wreg.h), tile-major addressing: 70 = SiLU*mul epilogue (K <= 896);
-            // 71 + x = split-K slabs with x more slices than the minimum ceil(K / 896)
-            case 70: a.w_tile_major = 1; a.ldo = N / 2; gemm_wreg_launch<EPI_SILU_MUL>(a, 1, (hipStream_t)0); break;
-            case 71: case 72: case 73: case 74: case 75:
-                a.w_tile_major = 1; gemm_wreg_launch<EPI_SPLITK>(a, (K / 64 + kWregKT - 1) / kWregKT + (config - 71), (hipStream_t)0); break;
-            case 76: {   // 71 with ablations (abl: 1 no MFMA, 2 no DMA, 4 no stores, 8 no weight loads; 15 = all)
-                a.w_tile_major = 1; a.k_tiles_per_split = K / 64 > kWregKT ? kWregKT : K / 64;
-                const dim3 grid((N + 63) / 64, (K / 64 + a.k_tiles_per_split - 1) / a.k_tiles_per_split, (M + 255) / 256);
-                switch (abl_full) {
-                    case 0: NTTS_LAUNCH((gemm_wreg_kernel<EPI_SPLITK, 16, 4, 0>), grid, dim3(512), (hipStream_t)0, a); break;
-                    case 1: NTTS_LAUNCH((gemm_wreg_kernel<EPI_SPLITK, 16, 4, 1>), grid, dim3(512), (hipStream_t)0, a); break;
-                    case 2: NTTS_LAUNCH((gemm_wreg_kernel<EPI_SPLITK, 16, 4, 2>), grid, dim3(512), (hipStream_t)0, a); break;
-                    case 4: NTTS_LAUNCH((gemm_wreg_kernel<EPI_SPLITK, 16, 4, 4>), grid, dim3(512), (hipStream_t)0, a); break;
-                    case 8: NTTS_LAUNCH((gemm_wreg_kernel<EPI_SPLITK, 16, 4, 8>), grid, dim3(512), (hipStream_t)0, a); break;
-                    case 3: NTTS_LAUNCH((gemm_wreg_kernel<EPI_SPLITK, 16, 4, 3>), grid, dim3(512), (hipStream_t)0, a); break;
-                    case 11: NTTS_LAUNCH((gemm_wreg_kernel<EPI_SPLITK, 16, 4, 11>), grid, dim3(512), (hipStream_t)0, a); break;
-                    default: NTTS_LAUNCH((gemm_wreg_kernel<EPI_SPLITK, 16, 4, 15>), grid, dim3(512), (hipStream_t)0, a); break;
-                }
-                break;
-            }
+            case 61: gemm_asym_launch<4, 4, 4, EPI_BF16, true>(a, (hipStream_t)0); break;          // 256 x 256, asymmetric ring, W deep
+            case 62: gemm_asym_launch<4, 4, 4, EPI_BF16, false>(a, (hipStream_t)0); break;         // ... X deep
+            case 63: gemm_asym_launch<4, 4, 4, EPI_BF16, true, true>(a, (hipStream_t)0); break;    // W deep, non-temporal W stream
             default: break;
         }
     };

@@ -35,47 +35,11 @@ GEMM_CASES = [  # (M, N, K, variant, bias)
     (300, 272, 192, 5, True),    # XL tile on the 4-slot ring of 32-wide K slices (64-byte LDS rows, other swizzle)
     (70, 200, 64, 5, False),     # ... a single 64-wide K tile = 2 slices, fewer than the ring holds
     (130, 144, 320, 6, True),    # L tile, 3-slot ring of 32-wide slices
-    (37, 64, 448, 7, False),     # weight-in-registers kernel (gemm_wreg.h): split-K slabs + reduce, BM = 128, short slices
-    (150, 176, 1024, 7, False),  # ... BM = 256 with ragged M, N not a multiple of 64 (an inactive feature wave), 2 slices of 8 tiles
+    (300, 272, 320, 7, True),    # XL tile, asymmetric ring (gemm_asym_kernel): W keeps two k-tiles in flight, X one
+    (300, 272, 320, 8, True),    # ... X deep
+    (70, 200, 64, 7, False),     # ... a single k-tile
+    (70, 200, 128, 8, False),    # ... two
 ]
-
-
-def run_gate_up(lib, x, wg, wu):
-    """SiLU(x Wg^T) * (x Wu^T) through the weight-in-registers kernel (kapi variant 8): gate/up rows packed in 16-row groups."""
-    M, K = x.shape
-    F = wg.shape[0]
-    assert F % 8 == 0
-    packed = torch.stack([wg.view(F // 8, 8, K), wu.view(F // 8, 8, K)], dim=1).reshape(2 * F, K).contiguous()
-    out = torch.zeros(M, F, dtype=torch.bfloat16, device=x.device)
-    rc = lib.ntts_k_gemm_bf16(C.c_void_p(x.data_ptr()), K, C.c_void_p(packed.data_ptr()), None,
-                              C.c_void_p(out.data_ptr()), F, M, 2 * F, K, 8)
-    assert rc == 0
-    return out
-
-
-def gate_up_reference(x, wg, wu):
-    """hf:models/qwen2/modeling_qwen2.py:46-48 in bf16: act_fn(gate_proj(x)) * up_proj(x), every op rounded"""
-    gt = _bf16(x.float() @ wg.float().t()).float()
-    up = _bf16(x.float() @ wu.float().t()).float()
-    return _bf16(_bf16(torch.nn.functional.silu(gt)).float() * up).float()
-
-
-def check_gate_up(lib, M, F, K, dev="cpu"):
-    g = torch.Generator().manual_seed(M * 7 + F)
-    x = _bf16(torch.randn(M, K, generator=g))
-    wg = _bf16(torch.randn(F, K, generator=g) / K ** 0.5)
-    wu = _bf16(torch.randn(F, K, generator=g) / K ** 0.5)
-    out = run_gate_up(lib, x.to(dev), wg.to(dev), wu.to(dev)).float().cpu()
-    ref = gate_up_reference(x, wg, wu)
-    err = (out - ref).abs()
-    tol = 2.0 ** -6 * ref.abs().clamp(min=1e-2)    # a 1-ulp difference in gate or up moves the product by up to ~2 ulps
-    assert bool((err <= tol).all()), f"max err {err.max()} at {err.argmax()}"
-    assert (out != ref).float().mean() < 0.03
-
-
-@pytest.mark.parametrize("M,F,K", [(20, 40, 128), (150, 72, 896)])
-def test_gate_up_wreg_emu(emu_lib, M, F, K):
-    check_gate_up(_hip.load_library(emu_lib), M, F, K)
 
 
 @pytest.mark.parametrize("M,N,K,variant,has_bias", GEMM_CASES)

@@ -36,17 +36,10 @@ BIG = [  # the decode-batch and prefill shapes of NeuTTS-Air
     (1500, 1152, 896, 5, True),   # XL tile on the 4-slot ring of 32-wide K slices: prefill QKV, ragged M
     (3000, 896, 4864, 5, False),  # ... prefill down_proj (152 slices)
     (2000, 9728, 896, 5, False),  # ... prefill gate/up width
-    (256, 896, 4864, 7, False),   # down_proj, weight-in-registers kernel (gemm_wreg.h): 6 K slices of <= 13 tiles + reduce
-    (256, 896, 896, 7, False),    # o_proj shape on the same kernel (2 slices of 7 tiles)
-    (512, 896, 1536, 7, False),   # two m-blocks of 256 rows
-    (64, 1152, 896, 7, False),    # BM = 128 instantiation
+    (256, 4096, 896, 7, True),    # XL tile, asymmetric ring, W deep: the lm_head's shape (a slice of the vocabulary)
+    (3000, 896, 4864, 8, False),  # ... X deep: prefill down_proj
+    (1500, 1152, 896, 8, True),   # ... prefill QKV, ragged M
 ]
-
-
-@pytest.mark.parametrize("M,F,K", [(256, 4864, 896), (100, 4864, 896), (512, 1536, 576)])
-def test_gate_up_wreg(lib, M, F, K):
-    from test_emu_kernels import check_gate_up
-    check_gate_up(lib, M, F, K, dev="cuda")
 
 
 @pytest.mark.parametrize("M,N,K,variant,has_bias", GEMM_CASES + BIG)
