@@ -104,9 +104,6 @@ struct ntts_backbone {
     // (profiles/r02a_sweep_nt_graphsteps.jsonl): lm_head 136.6 -> 132.3 us; on the LDS-DMA rings of the skinny layer GEMMs the
     // same policy was SLOWER (qkv 5.78 -> 5.96, down 9.95 -> 10.54 us; step 1.679 -> 1.718 ms) and is not offered there
     int w_nt = 1;
-    int asym = 3;           // asymmetric-ring 256 x 256 tile (gemm_asym_kernel): bit 0 = decode lm_head (W deep), bit 1 = prefill
-                            // gate/up (W deep) and down_proj (X deep).  Measured (profiles/r02i_ubench_*_asym.txt): lm_head 136.8 ->
-                            // 117.8 us, prefill down 230 -> 210 us, gate/up 502 -> 491 us; QKV / o_proj unchanged and left alone
     // Split-K decode GEMMs: XCD-aware slice placement (gemm.h GemmArgs::xcd_nsplit; NTTS_XCD_SPLIT bit 0 qkv, 1 o_proj, 2 down).
     // Measured at batch 256 (profiles/r02f_*): FETCH per skinny-GEMM launch 15.0 -> 6.8 MB (algorithmic 5.3: the 8 private L2s
     // no longer each pull the whole X panel), down_proj 10.2 -> 10.1 us, qkv unchanged, o_proj 5.3 -> 5.6-5.8 us (K = 896 only
@@ -343,7 +340,6 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     // one row per workgroup: 256 CUs pull the slabs instead of 64 -- 5.5 -> 4.0 us per launch, -4.4 % per step at batch 256
     e->norm_wide = env_int("NTTS_NORM_WIDE", 1) != 0;
     e->w_nt = env_int("NTTS_W_NT", 1);
-    e->asym = env_int("NTTS_ASYM", 3);
     e->xcd_split = env_int("NTTS_XCD_SPLIT", 5);
     e->use_xl = env_int("NTTS_XL", 1) != 0;
     e->head_xl = env_int("NTTS_HEAD_XL", B > 128 ? 1 : 0) != 0;
@@ -737,14 +733,8 @@ static void gemm_skinny(int stages, const GemmArgs& a, int ks, hipStream_t st) {
     }
 }
 
-// deep: 0 = symmetric ring, 1 = W is the HBM-side operand, 2 = X is (gemm_asym_kernel; bf16 engines, 256 x 256 tile only)
 template <int EPI>
-static void gemm_large(ntts_backbone* e, const GemmArgs& a, hipStream_t st, int deep = 0) {
-    if (!e->fp8 && deep && (e->asym & 2) && e->use_xl && a.M >= 1024 && a.N >= 256) {
-        if (deep == 1) gemm_asym_launch<4, 4, 4, EPI, true>(a, st);
-        else gemm_asym_launch<4, 4, 4, EPI, false>(a, st);
-        return;
-    }
+static void gemm_large(ntts_backbone* e, const GemmArgs& a, hipStream_t st) {
     if (e->fp8) {
         if (e->use_xl && a.M >= 1024 && a.N >= 256) gemm_launch<4, 4, 4, EPI, 2, 0, 64, false, true>(a, 1, st);
         else gemm_launch<2, 2, 4, EPI, 2, 0, 64, false, true>(a, 1, st);
@@ -772,7 +762,6 @@ static void k_lm_head(ntts_backbone* e, bool keep_logits) {
     if (!e->head_large) { gemm_skinny<EPI_ARGMAX>(4, a, 1, e->stream); return; }
     if (e->head_xl) {
         if (e->fp8) gemm_launch<4, 4, 4, EPI_ARGMAX, 2, 0, 64, true, true>(a, 1, e->stream);
-        else if ((e->asym & 1) && (e->w_nt & 1)) gemm_asym_launch<4, 4, 4, EPI_ARGMAX, true, true>(a, e->stream);
         else if (e->w_nt & 1) gemm_launch<4, 4, 4, EPI_ARGMAX, 2, 0, 64, true>(a, 1, e->stream);
         else NTTS_GEMM_XL(EPI_ARGMAX, a, 1, e->stream);
         return;
@@ -1161,8 +1150,8 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
         add_rmsnorm_launch(n1, st);
         GemmArgs gu = gemm_args(e, e->xn_pf, H, w.wgu, H, nullptr, e->act_pf, F, Mi, 2 * F, H, w.sgu, w.xs[2]);
         if (e->fp8) gu.out_fp8_inv = 1.0f / w.xs[3];
-        gemm_large<EPI_SILU_MUL>(e, gu, st, 1);
-        gemm_large<EPI_BF16>(e, gemm_args(e, e->act_pf, F, w.wd, F, nullptr, e->o_pf, H, Mi, H, F, w.sd, w.xs[3]), st, 2);
+        gemm_large<EPI_SILU_MUL>(e, gu, st);
+        gemm_large<EPI_BF16>(e, gemm_args(e, e->act_pf, F, w.wd, F, nullptr, e->o_pf, H, Mi, H, F, w.sd, w.xs[3]), st);
         NormArgs n2{};
         n2.o_bf16 = e->o_pf; n2.resid_in = hres; n2.eps = c.rms_eps; n2.H = H;
         if (!last) {

@@ -18,8 +18,6 @@ extern "C" int ntts_k_gemm_bf16(const void* A, int64_t lda, const void* W, const
     if (variant == 1) NTTS_GEMM_L(EPI_BF16, a, 1, (hipStream_t)0);
     else if (variant == 2) NTTS_GEMM_S(EPI_BF16, a, 1, (hipStream_t)0);
     else if (variant == 4) NTTS_GEMM_XL(EPI_BF16, a, 1, (hipStream_t)0);
-    else if (variant == 7) gemm_asym_launch<4, 4, 4, EPI_BF16, true>(a, (hipStream_t)0);    // XL tile, asymmetric ring: W deep
-    else if (variant == 8) gemm_asym_launch<4, 4, 4, EPI_BF16, false>(a, (hipStream_t)0);   // XL tile, asymmetric ring: X deep
     else if (variant == 5) gemm_launch<4, 4, 4, EPI_BF16, 4, 0, 32>(a, 1, (hipStream_t)0);   // XL tile, 4 ring slots of K = 32
     else if (variant == 6) gemm_launch<2, 2, 4, EPI_BF16, 3, 0, 32>(a, 1, (hipStream_t)0);   // L tile, 3 ring slots of K = 32
     else if (variant == 3) {  // split-K slabs reduced by the norm kernel (the decode o_proj / down_proj path)
@@ -172,9 +170,6 @@ extern "C" int ntts_k_gemm_probe(int32_t M, int32_t N, int32_t K, int32_t config
             case 52: probe_launch<8, 1, 2, 2>(a, 1, abl); break;
             case 53: probe_launch<8, 2, 2, 2>(a, 1, abl); break;   // 256 x 128, 16 waves
             case 54: probe_launch<4, 2, 2, 3>(a, 1, abl); break;   // 128 x 128, 8 waves
-            case 61: gemm_asym_launch<4, 4, 4, EPI_BF16, true>(a, (hipStream_t)0); break;          // 256 x 256, asymmetric ring, W deep
-            case 62: gemm_asym_launch<4, 4, 4, EPI_BF16, false>(a, (hipStream_t)0); break;         // ... X deep
-            case 63: gemm_asym_launch<4, 4, 4, EPI_BF16, true, true>(a, (hipStream_t)0); break;    // W deep, non-temporal W stream
             default: break;
         }
     };

@@ -443,135 +443,13 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// The same tile with an ASYMMETRIC ring: the operand that comes from HBM keeps TWO k-tiles in flight, the L2-resident one
-// ONE.  In gemm_kernel a ring slot holds both operands' tile and every k-step ends at a barrier that waits for the slowest
-// request of the next tile -- an HBM miss (~1 us) whenever one operand is HBM-cold -- with a single tile in flight (two slots
-// of 64 KB are all the LDS a 256 x 256 block has): the lm_head (390 MB of weights, read once) streams at 3 TB/s, half of what
-// the same number of CUs pull with 32-64 KB continuously in flight each (tools/ubench/loadpath.hip).  Splitting the ring
-// gives the cold operand a third slot inside the same 160 KB:  deep operand 3 x 32 KB + shallow operand 2 x 32 KB = 163,840 B.
-//   DW = true : W is the deep operand (decode lm_head: weights HBM-cold, the batch's activations L2-resident)
-//   DW = false: X is the deep operand (prefill / codec: activations stream from HBM / Infinity Cache, weights L2-resident)
-// Per k-step a wave issues the shallow operand's tile kt+1, then the deep operand's tile kt+2; both tiles of step kt+1 were
-// requested before the deep tile kt+2, so ONE counted wait (the deep tile's instructions may stay outstanding) covers both.
-template <int WM, int WN, int TM, int EPI, bool DW, bool WNT = false, bool F8 = false>
-NTTS_KERNEL(WM * WN * 64) void gemm_asym_kernel(GemmArgs p) {
-    constexpr int BK = 64, KC = 8, RPI = 8;
-    constexpr int BM = WM * TM * 16, BN = WN * 64, NW = WM * WN;
-    constexpr int XI = BM / RPI / NW, WI = BN / RPI / NW;       // wave-instructions per wave per tile
-    static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "loader split");
-    constexpr int NSX = DW ? 2 : 3, NSW = DW ? 3 : 2;
-    constexpr int DI = DW ? WI : XI;                              // the deep operand's instructions per tile
-    NTTS_SHARED bf16_t lds[(NSX * BM + NSW * BN) * BK];
-    bf16_t* const xl = lds;
-    bf16_t* const wl = lds + NSX * BM * BK;
-    auto swz = [](int rho) { return (rho >> 1) & 7; };
-
-    const int lane = lane_id(), wave = wave_id();
-    const int wm = wave / WN, wn = wave % WN;
-    const int g = lane >> 4, l15 = lane & 15;
-    int mb, nb;
-    gemm_tile_coords(blockIdx.x, p.mblocks, p.nblocks, mb, nb);
-    const int m0 = mb * BM, n0 = nb * BN;
-    const int nk = F8 ? p.K >> 7 : p.K >> 6;                     // 128-byte K tiles
-    constexpr int ESZ = F8 ? 1 : 2;
-
-    const char* srcx[XI];
-    const char* srcw[WI];
-#pragma unroll
-    for (int i = 0; i < XI; ++i) {
-        const int rho = (wave + i * NW) * RPI + lane / KC;
-        const int c = (lane % KC) ^ swz(rho);
-        int m = m0 + rho;
-        if (m > p.M - 1) m = p.M - 1;
-        srcx[i] = (const char*)p.X + (long)m * p.ldx * ESZ + c * 16;
-    }
-#pragma unroll
-    for (int i = 0; i < WI; ++i) {
-        const int q = (wave + i * NW) * RPI + lane / KC;          // tile-major W row: q = wq*64 + j*16 + i16
-        const int c = (lane % KC) ^ swz(q);
-        const int wq = q >> 6, j = (q >> 4) & 3, i16 = q & 15;
-        int n = n0 + wq * 64 + (i16 >> 2) * 16 + j * 4 + (i16 & 3);
-        if (n > p.N - 1) n = p.N - 1;
-        srcw[i] = p.w_tile_major ? (const char*)p.W + (long)(n >> 6) * 64 * p.K * ESZ + (n & 63) * 128 + c * 16
-                                 : (const char*)p.W + (long)n * p.ldw * ESZ + c * 16;
-    }
-    const long wstep = p.w_tile_major ? 8192 : 128;
-    auto stage_x = [&](int kt, int slot) {
-#pragma unroll
-        for (int i = 0; i < XI; ++i) glds16(srcx[i] + (long)kt * 128, xl + slot * (BM * BK) + (wave + i * NW) * 512);
-    };
-    auto stage_w = [&](int kt, int slot) {
-#pragma unroll
-        for (int i = 0; i < WI; ++i) {
-            const char* gsrc = srcw[i] + (long)kt * wstep;
-            bf16_t* l = wl + slot * (BN * BK) + (wave + i * NW) * 512;
-            if (WNT) glds16_nt(gsrc, l); else glds16(gsrc, l);
-        }
-    };
-
-    f32x4 acc[TM][4];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    int xoff[TM], woff[4], xsw[TM], wsw[4];
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-        const int rho = wm * TM * 16 + a * 16 + l15;
-        xoff[a] = rho * BK;
-        xsw[a] = swz(rho);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int rho = wn * 64 + j * 16 + l15;
-        woff[j] = rho * BK;
-        wsw[j] = swz(rho);
-    }
-
-    // issue order (it is what the single counted wait relies on): shallow(0), deep(0), deep(1) | shallow(1), deep(2) | ...
-    if constexpr (DW) { stage_x(0, 0); stage_w(0, 0); if (nk > 1) stage_w(1, 1); }
-    else              { stage_w(0, 0); stage_x(0, 0); if (nk > 1) stage_x(1, 1); }
-    int sx = 0, sw_ = 0;          // ring slots of tile kt
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) wait_vmem_le<DI>(); else wait_vmem();     // both tiles of step kt have landed; deep(kt+1) may be in flight
-        sync_keep_dma();          // ... for every wave, and everyone is done reading the slots refilled below (step kt-1's)
-        const int sx1 = sx + 1 == NSX ? 0 : sx + 1, sw1 = sw_ + 1 == NSW ? 0 : sw_ + 1;
-        if constexpr (DW) {
-            if (kt + 1 < nk) stage_x(kt + 1, sx1);
-            if (kt + 2 < nk) stage_w(kt + 2, sw1 + 1 == NSW ? 0 : sw1 + 1);
-        } else {
-            if (kt + 1 < nk) stage_w(kt + 1, sw1);
-            if (kt + 2 < nk) stage_x(kt + 2, sx1 + 1 == NSX ? 0 : sx1 + 1);
-        }
-        const bf16_t* xb_ = xl + sx * (BM * BK);
-        const bf16_t* wb_ = wl + sw_ * (BN * BK);
-        sx = sx1; sw_ = sw1;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int c = ks * 4 + g;
-            bf16x8 xb[TM], wa[4];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) xb[a] = ld16<bf16x8>(xb_ + xoff[a] + ((c ^ xsw[a]) << 3));
-#pragma unroll
-            for (int j = 0; j < 4; ++j) wa[j] = ld16<bf16x8>(wb_ + woff[j] + ((c ^ wsw[j]) << 3));
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if constexpr (F8) {
-                        const i64x2 w2 = __builtin_bit_cast(i64x2, wa[j]), x2 = __builtin_bit_cast(i64x2, xb[a]);
-                        acc[a][j] = mfma16_fp8(w2[0], x2[0], acc[a][j]);
-                        acc[a][j] = mfma16_fp8(w2[1], x2[1], acc[a][j]);
-                    } else {
-                        acc[a][j] = mfma16(wa[j], xb[a], acc[a][j]);
-                    }
-                }
-        }
-    }
-    gemm_epilogue<TM, EPI, WN, F8>(p, acc, m0 + wm * TM * 16, n0, wn, nb, 0);
-}
-
+// Measured on MI355X and removed (profiles/r02i_*): (a) an asymmetric ring for the 256 x 256 tile -- the HBM-side operand with
+// three 32 KB slots (two k-tiles in flight), the L2-resident one with two, 160 KB in all: on constant-filled probe operands the
+// lm_head went 136.8 -> 117.8 us and the prefill down_proj 230 -> 210 us, on the engine's random weights nothing moved (lm_head
+// 132.2 vs 131.8-134.0 us, prefill 136.3 vs 137.2 ms, A/B in one process); (b) a decode GEMM with the weight slice of a feature
+// wave requested into registers at kernel entry and the batch rows in an LDS ring (gemm_wreg.h in the history): bit-correct,
+// gate/up 17.6 vs 13.6 us -- one CU needs 4.2 us to receive its 114 KB of HBM-cold weights however early they are requested,
+// and the X ring then costs what the tile kernel's whole k-loop costs.
 // Measured on MI355X and removed (profiles/r02a_*): a persistent variant of this kernel that requested the next tile's first
 // stages before storing the current tile (prefill / codec GEMMs: 1116-1190 vs 1123-1188 TFLOP/s, no gain: the store tail
 // is not what the counted waits were hiding), and an X-panel-resident variant with the RMSNorm fused into the QKV / gate-up
@@ -603,16 +481,6 @@ inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
     }
     p.xcd_nsplit = 0;
     NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT, F8>), dim3(p.mblocks * p.nblocks, nsplit), dim3(WM * WN * 64), s, p);
-}
-
-template <int WM, int WN, int TM, int EPI, bool DW, bool WNT = false, bool F8 = false>
-inline void gemm_asym_launch(GemmArgs p, hipStream_t s) {
-    constexpr int BM = WM * TM * 16, BN = WN * 64;
-    p.mblocks = (p.M + BM - 1) / BM;
-    p.nblocks = (p.N + BN - 1) / BN;
-    p.xcd_nsplit = 0;
-    if constexpr (EPI == EPI_ARGMAX) p.part_stride = p.nblocks * WN;
-    NTTS_LAUNCH((gemm_asym_kernel<WM, WN, TM, EPI, DW, WNT, F8>), dim3(p.mblocks * p.nblocks), dim3(WM * WN * 64), s, p);
 }
 
 // tile families:  XL = 256x256 (4x4 waves = 1024 threads, 64x64 per wave, 128 KB LDS) -- big-M GEMMs (prefill, codec):

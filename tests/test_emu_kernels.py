@@ -35,10 +35,6 @@ GEMM_CASES = [  # (M, N, K, variant, bias)
     (300, 272, 192, 5, True),    # XL tile on the 4-slot ring of 32-wide K slices (64-byte LDS rows, other swizzle)
     (70, 200, 64, 5, False),     # ... a single 64-wide K tile = 2 slices, fewer than the ring holds
     (130, 144, 320, 6, True),    # L tile, 3-slot ring of 32-wide slices
-    (300, 272, 320, 7, True),    # XL tile, asymmetric ring (gemm_asym_kernel): W keeps two k-tiles in flight, X one
-    (300, 272, 320, 8, True),    # ... X deep
-    (70, 200, 64, 7, False),     # ... a single k-tile
-    (70, 200, 128, 8, False),    # ... two
 ]
 
 

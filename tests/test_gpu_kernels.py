@@ -36,9 +36,6 @@ BIG = [  # the decode-batch and prefill shapes of NeuTTS-Air
     (1500, 1152, 896, 5, True),   # XL tile on the 4-slot ring of 32-wide K slices: prefill QKV, ragged M
     (3000, 896, 4864, 5, False),  # ... prefill down_proj (152 slices)
     (2000, 9728, 896, 5, False),  # ... prefill gate/up width
-    (256, 4096, 896, 7, True),    # XL tile, asymmetric ring, W deep: the lm_head's shape (a slice of the vocabulary)
-    (3000, 896, 4864, 8, False),  # ... X deep: prefill down_proj
-    (1500, 1152, 896, 8, True),   # ... prefill QKV, ragged M
 ]
 
 

@@ -15,7 +15,7 @@ SHAPES = {"qkv": (256, 1152, 896), "o": (256, 896, 896), "gate_up": (256, 9728, 
 CONFIGS = {10: "64x64 4w NS2", 11: "64x64 4w NS3", 12: "64x64 4w NS4", 13: "64x64 4w NS6", 20: "32x64 2w NS4",
            21: "64x64 2w NS4", 22: "64x64 1w NS4", 23: "64x128 4w NS3", 24: "64x128 8w NS3", 25: "128x64 8w NS3",
            26: "128x64 4w NS3", 30: "128x128 4w NS2", 31: "128x128 4w NS3", 40: "256x128 8w NS2", 41: "128x256 8w NS2",
-           42: "256x256 16w NS2", 43: "256x128 8w NS3", 44: "256x128 4w NS2", 45: "256x256 8w NS2", 46: "256x256 16w 4xK32", 47: "256x256 16w 3xK32", 48: "256x256 8w 4xK32", 49: "128x128 4w 4xK32", 61: "256x256 asym W-deep", 62: "256x256 asym X-deep", 63: "256x256 asym W-deep nt", 50: "256x64 4w NS3", 51: "256x64 8w NS3",
+           42: "256x256 16w NS2", 43: "256x128 8w NS3", 44: "256x128 4w NS2", 45: "256x256 8w NS2", 46: "256x256 16w 4xK32", 47: "256x256 16w 3xK32", 48: "256x256 8w 4xK32", 49: "128x128 4w 4xK32", 60: "256x256 16w persist", 50: "256x64 4w NS3", 51: "256x64 8w NS3",
            52: "256x64 8w NS2", 53: "256x128 16w NS2", 54: "128x128 8w NS3"}
 
 
@@ -34,9 +34,10 @@ def prefill():
         fl = 2.0 * M * N * K
         print(f"== {name}  M={M} N={N} K={K}  {fl / 1e12:.2f} TFLOP")
         print(f"{'config':18s} {'us':>9s} {'TF/s':>7s} | ablations us: {'noMFMA':>9s} {'noDMA':>9s} {'neither':>9s} {'noStore':>9s}")
-        for cfg in (30, 42, 61, 62):
-            t = probe(M, N, K, cfg, 16, 1, iters=5)
-            print(f"{CONFIGS[cfg]:22s} {t:9.1f} {fl / t / 1e6:7.0f}", flush=True)
+        for cfg in (30, 42):
+            t = probe(M, N, K, cfg, 0, 1, iters=5)
+            ab = [probe(M, N, K, cfg, a, 1, iters=5) for a in (1, 2, 3, 4)]
+            print(f"{CONFIGS[cfg]:18s} {t:9.1f} {fl / t / 1e6:7.0f} | {'':14s} {ab[0]:9.1f} {ab[1]:9.1f} {ab[2]:9.1f} {ab[3]:9.1f}", flush=True)
 
 
 def mall():
@@ -66,7 +67,7 @@ def tall():
 def head():
     M, N, K = 256, 217472, 896
     print(f"== lm_head M={M} N={N} K={K} W=390 MB (always HBM-cold); row-major W vs tile-major W (abl bit 16)")
-    for cfg in (42, 61, 63, 62, 30):
+    for cfg in (30, 42, 12, 46, 47, 43, 53):
         t = probe(M, N, K, cfg, 0, 1, iters=20)
         t2 = probe(M, N, K, cfg, 16, 1, iters=20)
         print(f"  {CONFIGS[cfg]:18s} {t:8.1f} us  {N * K * 2 / t / 1e6:6.2f} TB/s | tile-major {t2:8.1f} us  {N * K * 2 / t2 / 1e6:6.2f} TB/s", flush=True)
