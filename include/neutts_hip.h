@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NTTS_ABI_VERSION 3
+#define NTTS_ABI_VERSION 4
 
 enum {
     NTTS_OK = 0,
@@ -177,6 +177,13 @@ int ntts_backbone_export_codes(ntts_backbone* e, int32_t n, const int32_t* slots
                                int32_t modulo, int32_t* codes_dev, int32_t stride, int32_t* lens_dev);
 /* The engine's HIP stream (a hipStream_t), for a consumer that must order its own work behind the engine's. */
 int ntts_backbone_stream(ntts_backbone* e, void** stream);
+/* Serving-side scheduling knob (no reference counterpart: ref:neutts/neutts.py runs one utterance at a time): run this engine's
+ * prompt passes (ntts_backbone_prefill*) on a side stream restricted to the compute units whose bits are set in `mask` (n_words
+ * 32-bit words, bit i of word w = CU 32 w + i; hipExtStreamCreateWithCUMask), ordered behind and before the engine's own stream.
+ * A prefill is compute-bound and its 1024-thread workgroups occupy whole CUs; confined to a subset it leaves the rest of the GPU
+ * to another engine's decode steps, which are latency-bound (bench.py pipelines consecutive batches this way).  n_words = 0
+ * restores the default (prompt pass on the engine's stream, all CUs).  Blocking (drains the engine's streams). */
+int ntts_backbone_set_prefill_cu_mask(ntts_backbone* e, const uint32_t* mask, int32_t n_words);
 /* Return the slot's KV pages to the pool and mark it free. */
 int ntts_backbone_release(ntts_backbone* e, int32_t slot);
 int ntts_backbone_sync(ntts_backbone* e);
@@ -254,6 +261,8 @@ int ntts_codec_decode(ntts_codec* c, int32_t n, const int32_t* codes, const int3
 int ntts_codec_decode_dev(ntts_codec* c, int32_t n, const int32_t* codes_dev, int32_t codes_stride, const int32_t* lens,
                           float* wav_out, int64_t wav_stride, int32_t wav_on_device, void* producer_stream);
 int ntts_codec_sync(ntts_codec* c);
+/* The same knob for the codec engine: re-create its stream restricted to the CUs of `mask` (n_words = 0: unrestricted).  Blocking. */
+int ntts_codec_set_cu_mask(ntts_codec* c, const uint32_t* mask, int32_t n_words);
 /* Page-locked host memory for wav_out: a pinned destination lets the D2H copy run at PCIe speed (pageable memory is
  * staged by the runtime at a fraction of it).  Plain malloc/free semantics; not tied to an engine. */
 int ntts_host_alloc(size_t bytes, void** out);

@@ -129,6 +129,11 @@ struct ntts_backbone {
     hipGraphExec_t graph = nullptr;
     bool graph_tried = false, use_graph = true;
     hipEvent_t ev[4]{};
+    // optional side stream for the prompt pass, restricted to a subset of the CUs (ntts_backbone_set_prefill_cu_mask): a prefill
+    // on it leaves the other CUs to whatever else runs on the GPU -- another engine's decode steps, which are launch- and
+    // latency-bound and lose little on fewer CUs, while an unrestricted prefill's 1024-thread workgroups would take every CU
+    hipStream_t pf_stream = nullptr;
+    hipEvent_t pf_ev[2]{};
     bool have_pf_time = false, have_dec_time = false;
     unsigned long long* attn_tl = nullptr;   // diagnostics (ntts_backbone_attn_timeline)
     long long pf_tokens_computed = 0, pf_tokens_shared = 0;   // prompt tokens pushed through the layers / served from shared pages
@@ -409,6 +414,7 @@ extern "C" void ntts_backbone_destroy(ntts_backbone* e) {
         if (b) hipFree(b);
     for (auto& ev : e->ev)
         if (ev) hipEventDestroy(ev);
+    if (e->pf_stream) { hipStreamDestroy(e->pf_stream); hipEventDestroy(e->pf_ev[0]); hipEventDestroy(e->pf_ev[1]); }
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1089,6 +1095,23 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
         for (int i = 0; i < n; ++i) e->slots[slots[i]].sampling = samp[i].do_sample != 0;
         e->n_sampling += add;
     }
+    // With a side stream the whole pass (meta upload included) runs there, ordered behind the work already on the engine's
+    // stream and followed by that stream; every launch helper reads e->stream, so it is swapped for the duration of the call.
+    struct SideStream {
+        ntts_backbone* e; hipStream_t main;
+        explicit SideStream(ntts_backbone* e_) : e(e_), main(e_->stream) {
+            if (!e->pf_stream) return;
+            hipEventRecord(e->pf_ev[0], main);
+            hipStreamWaitEvent(e->pf_stream, e->pf_ev[0], 0);
+            e->stream = e->pf_stream;
+        }
+        ~SideStream() {
+            if (!e->pf_stream) return;
+            hipEventRecord(e->pf_ev[1], e->pf_stream);
+            hipStreamWaitEvent(main, e->pf_ev[1], 0);
+            e->stream = main;
+        }
+    } side(e);
     hipStream_t st = e->stream;
     HIPCHK(e, hipMemcpyAsync(e->meta_dev, m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice, st));
     HIPCHK(e, hipStreamSynchronize(st));  // m is pageable host memory
@@ -1240,7 +1263,7 @@ extern "C" int ntts_backbone_decode(ntts_backbone* e, int32_t n_steps) {
         e->graph_has_logits = e->n_sampling > 0;
         auto capture = [&](int steps, hipGraphExec_t* out) {
             hipGraph_t g = nullptr;
-            if (hipStreamBeginCapture(st, hipStreamCaptureModeGlobal) == hipSuccess) {
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                 for (int k = 0; k < steps; ++k) decode_step(e);
                 if (hipStreamEndCapture(st, &g) == hipSuccess && g) {
                     if (hipGraphInstantiate(out, g, nullptr, nullptr, 0) != hipSuccess) *out = nullptr;
@@ -1318,6 +1341,25 @@ extern "C" int ntts_backbone_read_all(ntts_backbone* e, int32_t* out_ids, int32_
 extern "C" int ntts_backbone_stream(ntts_backbone* e, void** stream) {
     if (!e || !stream) return NTTS_EINVAL;
     *stream = (void*)e->stream;
+    return NTTS_OK;
+}
+
+extern "C" int ntts_backbone_set_prefill_cu_mask(ntts_backbone* e, const uint32_t* mask, int32_t n_words) {
+    if (!e || n_words < 0 || (n_words > 0 && !mask)) return fail(e, NTTS_EINVAL, "bad CU mask");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (e->pf_stream) {
+        HIPCHK(e, hipStreamSynchronize(e->pf_stream));
+        hipStreamDestroy(e->pf_stream); hipEventDestroy(e->pf_ev[0]); hipEventDestroy(e->pf_ev[1]);
+        e->pf_stream = nullptr;
+    }
+    if (n_words == 0) return NTTS_OK;
+    long bits = 0;
+    for (int i = 0; i < n_words; ++i) bits += __builtin_popcount(mask[i]);
+    if (bits < 1) return fail(e, NTTS_EINVAL, "empty CU mask");
+    HIPCHK(e, hipExtStreamCreateWithCUMask(&e->pf_stream, (uint32_t)n_words, mask));
+    HIPCHK(e, hipEventCreateWithFlags(&e->pf_ev[0], hipEventDisableTiming));
+    HIPCHK(e, hipEventCreateWithFlags(&e->pf_ev[1], hipEventDisableTiming));
     return NTTS_OK;
 }
 

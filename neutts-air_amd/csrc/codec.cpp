@@ -461,6 +461,18 @@ extern "C" int ntts_codec_decode_dev(ntts_codec* c, int32_t n, const int32_t* co
     return codec_decode_impl(c, n, nullptr, codes_dev, codes_stride, lens, wav_out, wav_stride, wav_on_device ? 2 : 1, (hipStream_t)producer_stream);
 }
 
+extern "C" int ntts_codec_set_cu_mask(ntts_codec* c, const uint32_t* mask, int32_t n_words) {
+    if (!c || n_words < 0 || (n_words > 0 && !mask)) return cfail(c, NTTS_EINVAL, "bad CU mask");
+    CHIP(c, hipSetDevice(c->device));
+    CHIP(c, hipStreamSynchronize(c->stream));
+    hipStream_t ns = nullptr;
+    if (n_words == 0) CHIP(c, hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
+    else CHIP(c, hipExtStreamCreateWithCUMask(&ns, (uint32_t)n_words, mask));
+    hipStreamDestroy(c->stream);
+    c->stream = ns;
+    return NTTS_OK;
+}
+
 extern "C" int ntts_codec_sync(ntts_codec* c) {
     if (!c) return NTTS_EINVAL;
     CHIP(c, hipSetDevice(c->device));

@@ -18,7 +18,7 @@ DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "libneutts_hip.so")
 
 NTTS_DT_F32, NTTS_DT_BF16, NTTS_DT_I32 = 0, 1, 2
 NTTS_W_BF16, NTTS_W_FP8_E4M3 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 NTTS_PAGE_TOKENS = 32            # include/neutts_hip.h
 PAGE_TOKENS = 32
 ERRORS = {-1: "EINVAL", -2: "ENODEV", -3: "ENOMEM", -4: "ESTATE", -5: "EHIP"}
@@ -103,6 +103,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_backbone_stream": (C.c_int, [p, C.POINTER(p)]),
         "ntts_codec_decode_dev": (C.c_int, [p, i32, p, i32, C.POINTER(i32), p, i64, i32, p]),
         "ntts_codec_sync": (C.c_int, [p]),
+        "ntts_codec_set_cu_mask": (C.c_int, [p, C.POINTER(C.c_uint32), i32]),
+        "ntts_backbone_set_prefill_cu_mask": (C.c_int, [p, C.POINTER(C.c_uint32), i32]),
         "ntts_backbone_sync": (C.c_int, [p]),
         "ntts_backbone_set_debug": (C.c_int, [p, i32]),
         "ntts_backbone_read_logits": (C.c_int, [p, i32, C.POINTER(f32), i32]),
@@ -343,6 +345,13 @@ class BackboneEngine:
         i32p = C.POINTER(C.c_int32)
         self._chk(self.lib.ntts_backbone_poll(self.h, st.ctypes.data_as(i32p), nn.ctypes.data_as(i32p)))
         return st, nn
+
+    def set_prefill_cu_mask(self, mask_words: Optional[Sequence[int]]):
+        """Run this engine's prompt passes on a side stream restricted to the CUs of `mask_words` (32-bit words, bit i of word w =
+        CU 32 w + i); None / empty = default.  See include/neutts_hip.h: ntts_backbone_set_prefill_cu_mask."""
+        words = list(mask_words or [])
+        arr = (C.c_uint32 * max(1, len(words)))(*words)
+        self._chk(self.lib.ntts_backbone_set_prefill_cu_mask(self.h, arr, len(words)))
 
     def stream(self) -> int:
         st = C.c_void_p()
@@ -611,6 +620,12 @@ class CodecEngine:
         self._chk(self.lib.ntts_codec_decode(self.h, n, flat.ctypes.data_as(i32p), lens.ctypes.data_as(i32p),
                                              wav.ctypes.data_as(C.POINTER(C.c_float)), stride))
         return wav
+
+    def set_cu_mask(self, mask_words: Optional[Sequence[int]]):
+        """Restrict the codec engine's stream to the CUs of `mask_words` (None / empty = all); ntts_codec_set_cu_mask."""
+        words = list(mask_words or [])
+        arr = (C.c_uint32 * max(1, len(words)))(*words)
+        self._chk(self.lib.ntts_codec_set_cu_mask(self.h, arr, len(words)))
 
     def decode_device(self, codes_dev_ptr: int, codes_stride: int, lens: np.ndarray, producer_stream: int = 0,
                       wav_dev_ptr: Optional[int] = None, wav_stride: Optional[int] = None, reuse_output: bool = True):

@@ -281,7 +281,7 @@ typedef void* hipGraph_t;
 typedef void* hipGraphExec_t;
 enum { hipSuccess = 0, hipErrorNotSupported = 801 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
-enum { hipStreamCaptureModeGlobal = 0, hipStreamNonBlocking = 1 };
+enum { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamNonBlocking = 1 };
 struct hipDeviceProp_t { char gcnArchName[64]; int multiProcessorCount; size_t totalGlobalMem; };
 
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }
@@ -305,6 +305,7 @@ inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind
 inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }
+inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, uint32_t, const uint32_t*) { *s = nullptr; return 0; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 inline hipError_t hipDeviceSynchronize() { return 0; }
@@ -312,6 +313,8 @@ inline hipError_t hipGetLastError() { return 0; }
 double emu_now_ms();
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emuEvent{0}; return 0; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
+constexpr unsigned hipEventDisableTiming = 2;
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new emuEvent{0}; return 0; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = emu_now_ms(); return 0; }
 inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 inline hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t w, size_t h, hipMemcpyKind k, hipStream_t) {

@@ -45,6 +45,24 @@ def test_small_peaked_exact(lib, graph, monkeypatch):
         assert fin and ids == z[f"bf16_ids_{u}"].tolist(), (u, ids, z[f"bf16_ids_{u}"].tolist())
 
 
+def test_prefill_on_cu_masked_side_stream(lib):
+    """ntts_backbone_set_prefill_cu_mask: the prompt pass on a side stream restricted to 64 of the 256 CUs (ordered before and
+    behind the engine's own stream) and the decode steps that follow give HF's ids; two prefills in a row, mask removed again."""
+    z, cfg, w = load_fixture("backbone_small_peaked")
+    S, N, eos = int(z["s_len"]), int(z["n_new"]), int(z["eos"])
+    eng = make_engine(cfg, w, lib, max_batch=2, max_context=160, bf16_upload=True)
+    samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
+    for mask in ([0xffffffff, 0xffffffff], None, [0x0000ffff] * 8):
+        eng.set_prefill_cu_mask(mask)
+        eng.prefill([br.synthetic_prompt(cfg, 0, S)], [0], [samp])
+        eng.prefill([br.synthetic_prompt(cfg, 1, S)], [1], [samp])
+        eng.decode(N - 1)
+        for u in (0, 1):
+            ids, fin = eng.read(u)
+            assert fin and ids == z[f"bf16_ids_{u}"].tolist(), (mask, u, ids)
+            eng.release(u)
+
+
 def test_continuous_batching_ragged_vs_oracle(lib):
     cfg = br.BackboneConfig(vocab_size=3000, hidden_size=896, intermediate_size=1216, num_layers=3)
     w = br.make_weights(cfg, 21, peak_sigma=0.5)
