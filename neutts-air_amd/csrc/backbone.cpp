@@ -104,6 +104,7 @@ struct ntts_backbone {
     // (profiles/r02a_sweep_nt_graphsteps.jsonl): lm_head 136.6 -> 132.3 us; on the LDS-DMA rings of the skinny layer GEMMs the
     // same policy was SLOWER (qkv 5.78 -> 5.96, down 9.95 -> 10.54 us; step 1.679 -> 1.718 ms) and is not offered there
     int w_nt = 1;
+    bool pf_resid = true;   // prefill: residual add in the o_proj / down_proj epilogue (EPI_RESID) instead of in the norm pass
     // Split-K decode GEMMs: XCD-aware slice placement (gemm.h GemmArgs::xcd_nsplit; NTTS_XCD_SPLIT bit 0 qkv, 1 o_proj, 2 down).
     // Measured at batch 256 (profiles/r02f_*): FETCH per skinny-GEMM launch 15.0 -> 6.8 MB (algorithmic 5.3: the 8 private L2s
     // no longer each pull the whole X panel), down_proj 10.2 -> 10.1 us, qkv unchanged, o_proj 5.3 -> 5.6-5.8 us (K = 896 only
@@ -345,6 +346,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     // one row per workgroup: 256 CUs pull the slabs instead of 64 -- 5.5 -> 4.0 us per launch, -4.4 % per step at batch 256
     e->norm_wide = env_int("NTTS_NORM_WIDE", 1) != 0;
     e->w_nt = env_int("NTTS_W_NT", 1);
+    e->pf_resid = env_int("NTTS_PF_RESID", 1) != 0;
     e->xcd_split = env_int("NTTS_XCD_SPLIT", 5);
     e->use_xl = env_int("NTTS_XL", 1) != 0;
     e->head_xl = env_int("NTTS_HEAD_XL", B > 128 ? 1 : 0) != 0;
@@ -1165,20 +1167,39 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
             attn_in = attn_c;
             hres = h_c;
         }
-        gemm_large<EPI_BF16>(e, gemm_args(e, attn_in, QD, w.wo, QD, nullptr, e->o_pf, H, Mi, H, QD, w.so, w.xs[1]), st);
+        // pf_resid: the residual add rides in the o_proj / down_proj epilogue (EPI_RESID: h = bf16(h + bf16(acc)), in place --
+        // the same two roundings the norm kernel applied), so the norm pass reads one row stream instead of two and writes one
         NormArgs n1{};
-        n1.o_bf16 = e->o_pf; n1.resid_in = hres; n1.resid_out = hres; n1.norm_w = w.ln2; n1.normed_out = e->xn_pf;
+        if (e->pf_resid) {
+            GemmArgs ao = gemm_args(e, attn_in, QD, w.wo, QD, nullptr, hres, H, Mi, H, QD, w.so, w.xs[1]);
+            ao.resid_bf16 = hres; ao.ldrb = H;
+            gemm_large<EPI_RESID>(e, ao, st);
+            n1.o_bf16 = hres;
+        } else {
+            gemm_large<EPI_BF16>(e, gemm_args(e, attn_in, QD, w.wo, QD, nullptr, e->o_pf, H, Mi, H, QD, w.so, w.xs[1]), st);
+            n1.o_bf16 = e->o_pf; n1.resid_in = hres; n1.resid_out = hres;
+        }
+        n1.norm_w = w.ln2; n1.normed_out = e->xn_pf;
         n1.M = Mi; n1.H = H; n1.eps = c.rms_eps;
         if (e->fp8) n1.out_fp8_inv = 1.0f / w.xs[2];
         add_rmsnorm_launch(n1, st);
         GemmArgs gu = gemm_args(e, e->xn_pf, H, w.wgu, H, nullptr, e->act_pf, F, Mi, 2 * F, H, w.sgu, w.xs[2]);
         if (e->fp8) gu.out_fp8_inv = 1.0f / w.xs[3];
         gemm_large<EPI_SILU_MUL>(e, gu, st);
-        gemm_large<EPI_BF16>(e, gemm_args(e, e->act_pf, F, w.wd, F, nullptr, e->o_pf, H, Mi, H, F, w.sd, w.xs[3]), st);
         NormArgs n2{};
-        n2.o_bf16 = e->o_pf; n2.resid_in = hres; n2.eps = c.rms_eps; n2.H = H;
+        if (e->pf_resid) {
+            GemmArgs ad = gemm_args(e, e->act_pf, F, w.wd, F, nullptr, hres, H, Mi, H, F, w.sd, w.xs[3]);
+            ad.resid_bf16 = hres; ad.ldrb = H;
+            gemm_large<EPI_RESID>(e, ad, st);
+            n2.o_bf16 = hres;
+        } else {
+            gemm_large<EPI_BF16>(e, gemm_args(e, e->act_pf, F, w.wd, F, nullptr, e->o_pf, H, Mi, H, F, w.sd, w.xs[3]), st);
+            n2.o_bf16 = e->o_pf; n2.resid_in = hres;
+        }
+        n2.eps = c.rms_eps; n2.H = H;
         if (!last) {
-            n2.resid_out = e->h_pf; n2.norm_w = e->layers[i + 1].ln1; n2.normed_out = e->xn_pf; n2.M = Ti;
+            if (!e->pf_resid) n2.resid_out = e->h_pf;
+            n2.norm_w = e->layers[i + 1].ln1; n2.normed_out = e->xn_pf; n2.M = Ti;
             if (e->fp8) n2.out_fp8_inv = 1.0f / e->layers[i + 1].xs[0];
         } else {  // only each prompt's last position feeds the lm_head: gather it into its decode-slot row
             n2.resid_out = e->h_dec; n2.norm_w = e->final_norm; n2.normed_out = e->xn_dec; n2.M = n;
