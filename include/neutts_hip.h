@@ -341,6 +341,10 @@ int ntts_k_gemm_probe(int32_t M, int32_t N, int32_t K, int32_t config, int32_t a
 int ntts_k_membw(size_t bytes, int32_t iters, double* gbps);
 /* Diagnostics: writes 3 x 64 x 4 floats describing the MFMA 16x16x32 lane layout (see csrc/kapi.cpp). */
 int ntts_k_mfma_probe(float* out_dev_768);
+/* SiLU as the GEMM epilogues compute it (hf:activations.py SiLUActivation), elementwise on DEVICE bf16 values: out[i] =
+ * bf16(silu(in[i])).  variant 0 = x / (1 + expf(-x)), 1 = the epilogues' fast form (gemm.h silu_fast); the parity tests run
+ * every bf16 bit pattern through both and compare with torch. */
+int ntts_k_silu_probe(const void* in_bf16_dev, void* out_bf16_dev, int64_t n, int32_t variant);
 
 #ifdef __cplusplus
 }

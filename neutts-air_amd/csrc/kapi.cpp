@@ -208,6 +208,17 @@ NTTS_KERNEL(64) void mfma_probe_kernel(float* out) {
     }
 }
 
+NTTS_KERNEL(256) void silu_probe_kernel(const bf16_t* in, bf16_t* out, long n, int variant) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = f2bf(variant ? silu_fast(bf2f(in[i])) : silu_f(bf2f(in[i])));
+}
+extern "C" int ntts_k_silu_probe(const void* in_bf16_dev, void* out_bf16_dev, int64_t n, int32_t variant) {
+    if (!in_bf16_dev || !out_bf16_dev || n < 1) return NTTS_EINVAL;
+    NTTS_LAUNCH((silu_probe_kernel), dim3((unsigned)((n + 255) / 256)), dim3(256), (hipStream_t)0, (const bf16_t*)in_bf16_dev,
+                (bf16_t*)out_bf16_dev, (long)n, (int)variant);
+    return hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess ? NTTS_OK : NTTS_EHIP;
+}
+
 extern "C" int ntts_k_mfma_probe(float* out_dev_768) {
     if (!out_dev_768) return NTTS_EINVAL;
     NTTS_LAUNCH((mfma_probe_kernel), dim3(1), dim3(64), (hipStream_t)0, out_dev_768);

@@ -143,7 +143,7 @@ NTTS_KERNEL((FW + 4) * 64) void gemv_kernel(GemvArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float gt = rbf(acc[r]), u = rbf(up[r]);      // gate_proj / up_proj outputs (bf16)
-                o[r] = f2bf(rbf(silu_f(gt)) * u);                  // act_fn output (bf16), product (bf16)
+                o[r] = f2bf(rbf(silu_fast(gt)) * u);               // act_fn output (bf16), product (bf16)
             }
             const int fb = (f0 >> 6) * 32 + ((f0 & 63) >> 4) * 8 + g * 4;
             *(u32x2*)((bf16_t*)p.out + (long)m * p.ldo + fb) = *(u32x2*)&o[0];

@@ -136,6 +136,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_k_gemm_fp8": (C.c_int, [p, p, p, f32, p, p, i32, i32, i32, i32]),
         "ntts_k_membw": (C.c_int, [C.c_size_t, i32, C.POINTER(C.c_double)]),
         "ntts_k_mfma_probe": (C.c_int, [p]),
+        "ntts_k_silu_probe": (C.c_int, [p, p, i64, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here == header/library drift: fail loudly

@@ -145,3 +145,24 @@ def test_fp8_quantize_emu(emu_lib):
 @pytest.mark.parametrize("M,N,K,variant,has_bias", [(70, 200, 256, 1, True), (5, 64, 128, 2, False), (300, 272, 384, 4, True)])
 def test_fp8_gemm_emu(emu_lib, M, N, K, variant, has_bias):
     fp8_gemm_case(emu_lib, M, N, K, variant, has_bias)
+
+
+def silu_all_bf16(lib, dev, variant):
+    """every bf16 bit pattern through the library's SiLU -> (inputs as float, outputs as bf16 tensor, torch's bf16 SiLU)"""
+    bits = torch.arange(0, 65536, dtype=torch.int32).to(torch.int16)
+    x = bits.view(torch.bfloat16)
+    xd = x.to(dev)
+    out = torch.zeros_like(xd)
+    assert lib.ntts_k_silu_probe(C.c_void_p(xd.data_ptr()), C.c_void_p(out.data_ptr()), 65536, variant) == 0
+    return x, out.cpu(), torch.nn.functional.silu(x)
+
+
+def test_silu_emu(emu_lib):
+    """host libm stands in for the device's v_exp_f32 here: equality on nearly all inputs, 1 bf16 ulp at most (the GPU test is exact)"""
+    lib = _hip.load_library(emu_lib)
+    for variant in (0, 1):
+        x, got, ref = silu_all_bf16(lib, "cpu", variant)
+        fin = torch.isfinite(x.float()) & (x.float().abs() < 80)     # (host exp2f keeps the subnormals v_exp_f32 flushes)
+        g, r = got.float()[fin], ref.float()[fin]
+        assert bool(((g - r).abs() <= 2.0 ** -7 * r.abs() + 1e-38).all())
+        assert (g != r).float().mean() < 1e-3

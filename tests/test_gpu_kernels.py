@@ -88,3 +88,15 @@ def test_fp8_quantize(lib, hip_lib):
 def test_fp8_gemm(lib, hip_lib, M, N, K, variant, has_bias):
     from test_emu_kernels import fp8_gemm_case
     fp8_gemm_case(hip_lib, M, N, K, variant, has_bias)
+
+
+def test_silu_all_bf16_inputs(lib):
+    """The SiLU of the gate/up epilogues on EVERY bf16 input: both forms (division by 1 + expf(-x); the fast form the kernels
+    use) round to exactly torch's bf16 SiLU for every finite input, so swapping one for the other cannot move a token."""
+    from test_emu_kernels import silu_all_bf16
+    for variant in (0, 1):
+        x, got, ref = silu_all_bf16(lib, "cuda", variant)
+        fin = torch.isfinite(x.float())
+        bad = (got.view(torch.int16)[fin] != ref.view(torch.int16)[fin])
+        # -0.0 vs +0.0 for tiny negative inputs would show up here too: the bit patterns must agree
+        assert int(bad.sum()) == 0, (variant, int(bad.sum()), x[fin][bad][:8], got[fin][bad][:8], ref[fin][bad][:8])
