@@ -341,6 +341,11 @@ int ntts_k_gemm_probe(int32_t M, int32_t N, int32_t K, int32_t config, int32_t a
 int ntts_k_membw(size_t bytes, int32_t iters, double* gbps);
 /* Diagnostics: writes 3 x 64 x 4 floats describing the MFMA 16x16x32 lane layout (see csrc/kapi.cpp). */
 int ntts_k_mfma_probe(float* out_dev_768);
+/* Launch-chain floor (diagnostics): captures `n_kernels` dependent launches of a kernel that only reads 4 bytes per workgroup
+ * (`grid` workgroups of 256 threads; block = 256) into one hipGraph, replays it `iters` times and returns the microseconds per
+ * replay -- what a decode step of that many launches costs before any kernel moves a byte.  block = -256: every thread of every
+ * launch also loads 16 HBM-cold bytes and stores 16 (the least a kernel of the step does: one dependent round trip + a store). */
+int ntts_k_launch_chain_probe(int32_t n_kernels, int32_t grid, int32_t block, int32_t iters, double* us_per_chain);
 /* SiLU as the GEMM epilogues compute it (hf:activations.py SiLUActivation), elementwise on DEVICE bf16 values: out[i] =
  * bf16(silu(in[i])).  variant 0 = x / (1 + expf(-x)), 1 = the epilogues' fast form (gemm.h silu_fast); the parity tests run
  * every bf16 bit pattern through both and compare with torch. */

@@ -208,6 +208,83 @@ NTTS_KERNEL(64) void mfma_probe_kernel(float* out) {
     }
 }
 
+// ---- launch-chain floor: n dependent launches of a kernel that does (almost) nothing, replayed from one hipGraph like the
+//      decode step.  What a chain of n kernels costs before any of them moves a byte.
+NTTS_KERNEL(256) void chain_probe_kernel(int* sink) {
+    if (threadIdx.x == 0 && sink[blockIdx.x & 1023] == 0x7fffffff) sink[0] = 1;   // one 4-byte load per workgroup, never stores
+}
+// the smallest kernel that does what every decode kernel must: one HBM-cold 16-byte load per thread, then one 16-byte store
+NTTS_KERNEL(256) void chain_touch_kernel(const u32x4* src, u32x4* dst) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    u32x4 v = src[i];
+    v[0] += 1;
+    dst[i] = v;
+}
+extern "C" int ntts_k_launch_chain_probe(int32_t n_kernels, int32_t grid, int32_t block, int32_t iters, double* us_per_chain) {
+    if (!us_per_chain || n_kernels < 1 || n_kernels > 4096 || grid < 1 || (block != 256 && block != -256) || iters < 1) return NTTS_EINVAL;
+    const bool touch = block < 0;      // block = -256: chain_touch_kernel, every launch of a replay on its own (cold) 16 B x grid x 256 region
+    block = 256;
+    if (touch) {
+        u32x4 *src = nullptr, *dst = nullptr;
+        const size_t per = (size_t)grid * 256, total = per * n_kernels;
+        hipStream_t st = nullptr; hipGraph_t g = nullptr; hipGraphExec_t ge = nullptr;
+        if (hipMalloc((void**)&src, total * 16) != hipSuccess || hipMalloc((void**)&dst, per * 16) != hipSuccess) { hipFree(src); return NTTS_ENOMEM; }
+        hipMemset(src, 1, total * 16);
+        int rc = NTTS_EHIP;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            for (int i = 0; i < n_kernels; ++i) NTTS_LAUNCH((chain_touch_kernel), dim3(grid), dim3(256), st, (const u32x4*)(src + per * i), dst);
+            if (hipStreamEndCapture(st, &g) == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess) {
+                hipEvent_t e0, e1;
+                hipEventCreate(&e0); hipEventCreate(&e1);
+                for (int i = 0; i < 3; ++i) hipGraphLaunch(ge, st);
+                hipEventRecord(e0, st);
+                for (int i = 0; i < iters; ++i) hipGraphLaunch(ge, st);
+                hipEventRecord(e1, st);
+                if (hipEventSynchronize(e1) == hipSuccess) { float ms = 0; hipEventElapsedTime(&ms, e0, e1); *us_per_chain = (double)ms * 1e3 / iters; rc = NTTS_OK; }
+                hipEventDestroy(e0); hipEventDestroy(e1);
+            }
+        }
+        if (ge) hipGraphExecDestroy(ge);
+        if (g) hipGraphDestroy(g);
+        if (st) hipStreamDestroy(st);
+        hipFree(src); hipFree(dst);
+        (void)hipGetLastError();
+        return rc;
+    }
+    int* sink = nullptr;
+    hipStream_t st = nullptr;
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    if (hipMalloc((void**)&sink, 4096) != hipSuccess) return NTTS_ENOMEM;
+    hipMemset(sink, 0, 4096);
+    int rc = NTTS_EHIP;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess &&
+        hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        for (int i = 0; i < n_kernels; ++i) NTTS_LAUNCH((chain_probe_kernel), dim3(grid), dim3(block), st, sink);
+        if (hipStreamEndCapture(st, &g) == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess) {
+            hipEvent_t e0, e1;
+            hipEventCreate(&e0); hipEventCreate(&e1);
+            for (int i = 0; i < 3; ++i) hipGraphLaunch(ge, st);
+            hipEventRecord(e0, st);
+            for (int i = 0; i < iters; ++i) hipGraphLaunch(ge, st);
+            hipEventRecord(e1, st);
+            if (hipEventSynchronize(e1) == hipSuccess) {
+                float ms = 0;
+                hipEventElapsedTime(&ms, e0, e1);
+                *us_per_chain = (double)ms * 1e3 / iters;
+                rc = NTTS_OK;
+            }
+            hipEventDestroy(e0); hipEventDestroy(e1);
+        }
+    }
+    if (ge) hipGraphExecDestroy(ge);
+    if (g) hipGraphDestroy(g);
+    if (st) hipStreamDestroy(st);
+    hipFree(sink);
+    (void)hipGetLastError();
+    return rc;
+}
+
 NTTS_KERNEL(256) void silu_probe_kernel(const bf16_t* in, bf16_t* out, long n, int variant) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = f2bf(variant ? silu_fast(bf2f(in[i])) : silu_f(bf2f(in[i])));

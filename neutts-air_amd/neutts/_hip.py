@@ -137,6 +137,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_k_membw": (C.c_int, [C.c_size_t, i32, C.POINTER(C.c_double)]),
         "ntts_k_mfma_probe": (C.c_int, [p]),
         "ntts_k_silu_probe": (C.c_int, [p, p, i64, i32]),
+        "ntts_k_launch_chain_probe": (C.c_int, [i32, i32, i32, i32, C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)  # AttributeError here == header/library drift: fail loudly
