@@ -104,6 +104,7 @@ struct ntts_backbone {
     // (profiles/r02a_sweep_nt_graphsteps.jsonl): lm_head 136.6 -> 132.3 us; on the LDS-DMA rings of the skinny layer GEMMs the
     // same policy was SLOWER (qkv 5.78 -> 5.96, down 9.95 -> 10.54 us; step 1.679 -> 1.718 ms) and is not offered there
     int w_nt = 1;
+    bool pf_rope_vec = true;   // prefill RoPE + KV write with 16-byte accesses (rope_kv_write_vec_kernel)
     bool pf_resid = true;   // prefill: residual add in the o_proj / down_proj epilogue (EPI_RESID) instead of in the norm pass
     // Split-K decode GEMMs: XCD-aware slice placement (gemm.h GemmArgs::xcd_nsplit; NTTS_XCD_SPLIT bit 0 qkv, 1 o_proj, 2 down).
     // Measured at batch 256 (profiles/r02f_*): FETCH per skinny-GEMM launch 15.0 -> 6.8 MB (algorithmic 5.3: the 8 private L2s
@@ -347,6 +348,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->norm_wide = env_int("NTTS_NORM_WIDE", 1) != 0;
     e->w_nt = env_int("NTTS_W_NT", 1);
     e->pf_resid = env_int("NTTS_PF_RESID", 1) != 0;
+    e->pf_rope_vec = env_int("NTTS_PF_ROPE_VEC", 1) != 0;
     e->xcd_split = env_int("NTTS_XCD_SPLIT", 5);
     e->use_xl = env_int("NTTS_XL", 1) != 0;
     e->head_xl = env_int("NTTS_HEAD_XL", B > 128 ? 1 : 0) != 0;
@@ -1141,7 +1143,8 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
         r.qkv = e->qkv_pf; r.ld_qkv = e->NQKV; r.kpool = e->kv + (size_t)i * e->layer_stride; r.vpool = r.kpool + e->kv_half;
         r.block_table = e->block_table; r.max_pages = e->max_pages; r.meta = meta; r.rope_cos = e->rope_cos; r.rope_sin = e->rope_sin;
         r.nh = c.num_heads; r.nkv = c.num_kv_heads; r.T = Ti;
-        NTTS_LAUNCH((rope_kv_write_kernel), dim3(Ti), dim3(256), st, r);
+        if (e->pf_rope_vec && e->NQKV % 8 == 0) NTTS_LAUNCH((rope_kv_write_vec_kernel), dim3((Ti + kRopeTokPerBlock - 1) / kRopeTokPerBlock), dim3(256), st, r);
+        else NTTS_LAUNCH((rope_kv_write_kernel), dim3(Ti), dim3(256), st, r);
         AttnPrefillArgs a{};
         a.qkv = e->qkv_pf; a.ld_qkv = e->NQKV; a.out = e->attn_pf; a.ld_out = QD; a.kpool = r.kpool; a.vpool = r.vpool;
         a.block_table = e->block_table; a.max_pages = e->max_pages; a.meta = meta; a.nh = c.num_heads; a.nkv = c.num_kv_heads;

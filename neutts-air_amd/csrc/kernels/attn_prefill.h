@@ -72,6 +72,56 @@ NTTS_KERNEL(256) void rope_kv_write_kernel(RopeWriteArgs p) {
     }
 }
 
+// The same pass with 16-byte accesses: a work item = (token, head, 8 consecutive pairs) loads x[i0..i0+7], x[i0+32..i0+39] and
+// the 8 cos / sin of its position as four 16-byte loads and stores the rotated halves as two (q in place, k into its page
+// row); 4 tokens per workgroup.  Only the V^T scatter (a token's 64 values go to 64 rows of its page) stays element-wise.
+// Same arithmetic per element (rope_pair), so the results are bit-identical to rope_kv_write_kernel; 58 -> 30 us per launch
+// at 32 000 tokens.  (ld_qkv % 8 == 0: the engine's QKV width is a multiple of 64.)
+constexpr int kRopeTokPerBlock = 4;
+NTTS_KERNEL(256) void rope_kv_write_vec_kernel(RopeWriteArgs p) {
+    const int nheads = p.nh + 2 * p.nkv;
+    const int per_tok = nheads * 4;                              // work items per token
+    const int t0 = blockIdx.x * kRopeTokPerBlock;
+    for (int x = threadIdx.x; x < per_tok * kRopeTokPerBlock; x += 256) {
+        const int tt = x / per_tok, y = x - tt * per_tok;
+        const int t = t0 + tt;
+        if (t >= p.T) break;
+        const int hh = y >> 2, i0 = (y & 3) * 8;
+        const int sq = p.meta.tok_seq[t];
+        const int pos = p.meta.pos0[sq] + t - p.meta.tok_base[sq];
+        bf16_t* h = p.qkv + (long)t * p.ld_qkv + hh * 64;
+        const bf16x8 x1 = ld16<bf16x8>(h + i0), x2 = ld16<bf16x8>(h + i0 + 32);
+        if (hh < p.nh + p.nkv) {
+            const bf16x8 cv = ld16<bf16x8>(p.rope_cos + (long)pos * 32 + i0), sv = ld16<bf16x8>(p.rope_sin + (long)pos * 32 + i0);
+            bf16x8 r1, r2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float o1, o2;
+                rope_pair(bf2f((bf16_t)x1[e]), bf2f((bf16_t)x2[e]), bf2f((bf16_t)cv[e]), bf2f((bf16_t)sv[e]), o1, o2);
+                r1[e] = (short)f2bf(o1);
+                r2[e] = (short)f2bf(o2);
+            }
+            bf16_t* dst = h;
+            if (hh >= p.nh) {
+                const int* bt = p.block_table + (long)p.meta.slot[sq] * p.max_pages;
+                const long pg = bt[pos / kPage];
+                dst = p.kpool + ((pg * p.nkv + (hh - p.nh)) * kPage + pos % kPage) * 64;
+            }
+            *(bf16x8*)(dst + i0) = r1;
+            *(bf16x8*)(dst + i0 + 32) = r2;
+        } else {
+            const int* bt = p.block_table + (long)p.meta.slot[sq] * p.max_pages;
+            const long pg = bt[pos / kPage];
+            bf16_t* vd = p.vpool + (pg * p.nkv + (hh - p.nh - p.nkv)) * 64 * kPage + v_slot(pos % kPage);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                vd[(long)(i0 + e) * kPage] = (bf16_t)x1[e];
+                vd[(long)(i0 + 32 + e) * kPage] = (bf16_t)x2[e];
+            }
+        }
+    }
+}
+
 struct AttnPrefillArgs {
     const bf16_t* qkv;         // q already rotated
     long ld_qkv;
