@@ -239,6 +239,8 @@ def main():
             codec.load_state_dict(ndist.broadcast_state_dict(cw, src=0, device=tdev))
     elif codec is not None:
         codec.load_state_dict({k: v.numpy() for k, v in cw.items()})
+    if os.environ.get("NTTS_BENCH_PRIME", "1") != "0" and not cont:
+        eng.warm_up(int(os.environ.get("NTTS_BENCH_PRIME_STEPS", "2")))   # start-up: graph capture + runtime pools, before any request
     log(f"[bench] rank {rank}: weights ready in {time.time() - t0:.1f}s")
 
     eos = cfg.vocab_size - 1
@@ -290,11 +292,15 @@ def main():
         """One pass of the hot path over one batch: prompts -> codec-token ids -> 24 kHz waveforms."""
         ph = {"prefill": 0.0, "decode": 0.0, "codec": 0.0, "handoff_host": 0.0, "codec_call_wall": 0.0}
         tw = [time.time()]                                   # host wall-clock stamps (reported as phase_ms.host_wall_*)
+        each = []
         for c in range(0, B, a.prefill_chunk):
             n = min(a.prefill_chunk, B - c)
+            tc0 = time.time()
             eng.prefill(prompts[c:c + n], list(range(c, c + n)), [samp] * n)
+            each.append(round((time.time() - tc0) * 1e3, 1))
             if collect:
                 ph["prefill"] += eng.last_timing()[0]
+        ph["host_wall_prefill_each"] = each
         tw.append(time.time())
         eng.decode(N - 1)
         tw.append(time.time())
@@ -348,10 +354,14 @@ def main():
     barrier()
     t0 = time.time()
     step_wall = []                                   # per-step host wall time (diagnostic; `value` uses the barrier-bracketed total)
+    step_host = []                                   # static mode: host wall of [prefill calls, decode enqueue, wait + codec] per step
     for _ in range(a.steps):
         ts = time.time()
-        one_step()
+        ph_t = one_step(collect=bool(os.environ.get("NTTS_BENCH_STEP_PHASES")))[0]   # (diagnostic: per-step GPU phases add syncs)
         step_wall.append(round((time.time() - ts) * 1e3, 2))
+        if "host_wall_prefill_calls" in ph_t:
+            step_host.append([ph_t["host_wall_prefill_each"]] + [round(ph_t[k], 1) for k in ("host_wall_prefill_calls", "host_wall_decode_call", "host_wall_wait_and_codec")]
+                             + ([round(ph_t[k], 1) for k in ("prefill", "decode", "codec")] if os.environ.get("NTTS_BENCH_STEP_PHASES") else []))
     barrier()
     dt = time.time() - t0
     if world > 1:
@@ -450,7 +460,7 @@ def main():
                        "parallelism": f"independent shards x{world}, RCCL weight broadcast only"},
             "tokens_per_s_per_gpu": value / world,
             "rtf": dt / (tokens / 50.0),
-            "phase_ms": ph, "step_wall_ms": step_wall,
+            "phase_ms": ph, "step_wall_ms": step_wall, "step_host_wall_ms": step_host,
             "roofline": roof, "decode_step": step_info, "cpu_baseline": cpu,
         }
         print(json.dumps(rec), flush=True)

@@ -348,6 +348,17 @@ class BackboneEngine:
         self._chk(self.lib.ntts_backbone_poll(self.h, st.ctypes.data_as(i32p), nn.ctypes.data_as(i32p)))
         return st, nn
 
+    def warm_up(self, decode_steps: int = 2):
+        """One throw-away request through slot 0 (a 1-token prompt, `decode_steps` greedy steps): captures and instantiates the
+        decode-step hipGraph and lets the HIP runtime size its command pools, so that the first real request does not pay for
+        either.  Serving start-up hygiene; the engine must be finalised and slot 0 free."""
+        sp = Sampling(max_length=2 + decode_steps, min_new_tokens=1 + decode_steps, eos_token_id=0, do_sample=False)
+        self.prefill([[1 % self.vocab_size]], [0], [sp])
+        self.decode(decode_steps)
+        self.sync()
+        self.release(0)
+        self.sync()
+
     def set_prefill_cu_mask(self, mask_words: Optional[Sequence[int]]):
         """Run this engine's prompt passes on a side stream restricted to the CUs of `mask_words` (32-bit words, bit i of word w =
         CU 32 w + i); None / empty = default.  See include/neutts_hip.h: ntts_backbone_set_prefill_cu_mask."""
