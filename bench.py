@@ -412,7 +412,7 @@ def main():
         # template serves three launches per layer.  `agree` = its average duration is within 15 % of this run's HIP events.
         rocprof = None
         if not nano and B == 256 and S == 500:
-            rocprof = rocprof_symbols(os.path.join(ROOT, "profiles", "r02g_bench_kernel_stats.txt"),
+            rocprof = rocprof_symbols(os.path.join(ROOT, "profiles", "r02j_bench_kernel_stats.txt"),
                                       {r[1]: (r[2], r[3], r[4]) for r in rows})
         roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": ms * 1e3,
