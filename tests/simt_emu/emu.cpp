@@ -68,6 +68,10 @@ static void fiber_main() {
     g_fib[g_cur].done = true;
     --g_alive;
     ++g_progress;
+    if (g_bar_arrived > 0 && g_bar_arrived == g_alive) {   // a workgroup barrier counts the threads still alive (as s_barrier does
+        g_bar_arrived = 0;                                 // with terminated waves): the last exit may be what completes it
+        ++g_bar_gen;
+    }
     yield();
     abort();
 }
