@@ -68,6 +68,8 @@ NTTS_D void rope_pair(float x1, float x2, float c, float s, float& o1, float& o2
 //   registers (one coalesced load + lane broadcasts instead of a dependent global load per page): 20.5-21.1 vs 20.8-21.0 us,
 //   step 1.683 vs 1.685 ms (profiles/r02i_sweep_attn_bt_in_registers.log) -- the K and V^T passes are HBM-bound as they are
 //   (83 MB between 1 us and 14 us after entry = 6.4 TB/s), what is left is the launch gap, the first microsecond and the exit skew.
+//   8-wave workgroups at batch 256: 20.2-20.4 vs 20.6-20.9 us isolated, step 1.657-1.659 vs 1.660-1.661 ms (r02i_sweep_attn_8waves.log):
+//   inside the noise, not instantiated.
 // NW = waves per workgroup: 4.  16-wave workgroups (a whole 600-token context's pages requested at once by the one workgroup
 //   a (sequence, kv-head) gets at batch 1) were measured and are not instantiated: 13.1-13.7 vs 10.5-12.0 us per launch --
 //   the 12 extra waves' 192 KB of page requests queue on the CU's ~50 GB/s load path ahead of the prologue's RoPE row
