@@ -105,3 +105,21 @@ def test_engine_error_paths(emu_lib):
     eng.prefill([[1, 2, 3]], [0], [samp])
     st, nn = eng.poll()
     assert st[0] in (1, 2) and nn[0] == 1 and st[1] == 0
+
+
+def test_warm_up_and_side_stream_prefill(emu_lib):
+    """Start-up hygiene and the serving knobs leave results alone: warm_up() (one throw-away request through slot 0), then the
+    prompt pass routed through the side-stream code path (ntts_backbone_set_prefill_cu_mask; the emulator has one queue, the
+    point here is the stream swap, its ordering calls and the restore on every exit), then the golden teacher-forced run."""
+    z, cfg, w = load_fixture("backbone_tiny")
+    S, N, mn, eos = int(z["s_len"]), 8, int(z["min_new"]), int(z["eos"])
+    eng = make_engine(cfg, w, emu_lib, max_batch=3)
+    eng.warm_up()
+    eng.set_prefill_cu_mask([0xffff])
+    samp = _hip.Sampling(max_length=S + N, min_new_tokens=mn, eos_token_id=eos, do_sample=False)
+    with pytest.raises(_hip.NeuTTSHipError):                     # an error inside the swapped region must restore the engine's stream
+        eng.prefill([br.synthetic_prompt(cfg, 0, S)], [7], [samp])
+    eng.prefill([br.synthetic_prompt(cfg, u, S) for u in (0, 1, 2)], [2, 0, 1], [samp] * 3)
+    eng.set_prefill_cu_mask(None)
+    ex, tie = teacher_forced_compare(eng, 2, z["bf16_ids_0"][:N], z["bf16_topv_0"], z["bf16_topi_0"])
+    assert ex + tie == N and ex >= N - 2
