@@ -268,11 +268,12 @@ def main():
 
     def one_step_continuous(collect=False):
         """One pass over R ragged requests: continuous batching (BackboneEngine.generate: admission by free slots, KV pages
-        and prefill budget; finished slots are read, released and refilled every 16 decode steps), then the codec over the
+        and prefill budget; finished slots are read, released and refilled every 8 decode steps, new prompts admitted 16 at a time), then the codec over the
         finished utterances in batches of B."""
         ph = {"generate_wall": 0.0, "codec_wall": 0.0}
         t1 = time.time()
-        ids = eng.generate(r_prompts, r_samp, steps_per_poll=16, prefill_token_budget=a.prefill_chunk * S)
+        ids = eng.generate(r_prompts, r_samp, steps_per_poll=int(os.environ.get("NTTS_BENCH_POLL", "8")), prefill_token_budget=a.prefill_chunk * S,
+                           min_admit=int(os.environ.get("NTTS_BENCH_MIN_ADMIT", "16")))
         ph["generate_wall"] = (time.time() - t1) * 1e3
         assert all(len(x) == int(g) for x, g in zip(ids, r_glen)), "continuous run did not produce the expected tokens"
         cont_tokens[0] = int(sum(len(x) for x in ids))

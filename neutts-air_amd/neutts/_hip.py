@@ -424,11 +424,14 @@ class BackboneEngine:
 
     # -- continuous batching (host scheduler): keep every slot busy until all prompts are done
     def generate(self, prompts: Sequence[Sequence[int]], sampling, steps_per_poll: int = 16,
-                 prefill_token_budget: Optional[int] = None, share_prefix: bool = False) -> List[List[int]]:
+                 prefill_token_budget: Optional[int] = None, share_prefix: bool = False, min_admit: int = 1) -> List[List[int]]:
         """Batched equivalent of calling ref:neutts/neutts.py:338-351 once per prompt.
         Returns the NEW ids of each prompt (prompt stripped), in order.
         share_prefix=True: a prompt that starts like one already in flight (same speaker: chat header + reference
-        text, ref:neutts/neutts.py:307,315-325) re-uses that slot's KV pages for the common whole pages."""
+        text, ref:neutts/neutts.py:307,315-325) re-uses that slot's KV pages for the common whole pages.
+        min_admit: waiting prompts are admitted only once that many slots are free (or nothing is running): a prompt pass over
+        a handful of prompts runs the big GEMM tiles nearly empty, so under load it pays to let a few slots idle for some steps
+        and prefill them together."""
         if isinstance(sampling, Sampling):
             sampling = [sampling] * len(prompts)
         budget = prefill_token_budget or self.cfg.get("max_prefill_tokens", 0) or 16384
@@ -471,7 +474,7 @@ class BackboneEngine:
         try:
             while nxt < len(prompts) or owner:
                 # admit as many waiting prompts as slots / prefill workspace allow
-                while nxt < len(prompts) and self._free:
+                while nxt < len(prompts) and self._free and (not owner or len(self._free) >= min(min_admit, len(prompts) - nxt)):
                     batch, used, donors = [], 0, []
                     while nxt < len(prompts) and self._free:
                         d = find_donor(nxt) if share_prefix else None
