@@ -1,8 +1,5 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; mkdir -p gpurun_out
-for cfgs in "16 1" "16 8" "16 16" "16 32" "32 16" "32 32" "8 16"; do set -- $cfgs
-NTTS_BENCH_POLL=$1 NTTS_BENCH_MIN_ADMIT=$2 timeout 300 python bench.py --mode continuous --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_cont.json 2> gpurun_out/bench_cont.err; echo "poll=$1 min_admit=$2 rc=$?"
-python - <<PY
-import json
-d=json.load(open("gpurun_out/bench_cont.json")); print(round(d["value"]), round(d["ms_per_step"],1), {k:round(v,1) for k,v in d["phase_ms"].items()})
-PY
-done
+rm -rf gpurun_out/pmc_mfma
+NTTS_NO_GRAPH=1 timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 -f csv -d gpurun_out/pmc_mfma -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --prefill 605 --decode 40 > gpurun_out/pmc_mfma.json 2> gpurun_out/pmc_mfma.err; echo "rc=$?"
+python tools/mfma_util_summary.py gpurun_out/pmc_mfma | tee gpurun_out/mfma_util_summary.txt
+find gpurun_out/pmc_mfma -name '*.csv' -size +8M -delete
