@@ -460,6 +460,10 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 }
 
 
+// Measured on MI355X and removed (profiles/r02i_ab_staged_epilogue.jsonl): the bf16-output epilogues of the 256 x 256 tile staged
+// through the idle ring (swizzled 128 KB tile, then whole-row stores: every 128-byte line written once, in full, instead of
+// 16-byte pieces 4 per line): prefill 122.2 -> 123.4 ms, A/B in one process -- the L2 merges the pieces as they are, and
+// the LDS round trip with its two barriers costs more than the wider stores save.
 // Measured on MI355X and removed (profiles/r02i_*): (a) an asymmetric ring for the 256 x 256 tile -- the HBM-side operand with
 // three 32 KB slots (two k-tiles in flight), the L2-resident one with two, 160 KB in all: on constant-filled probe operands the
 // lm_head went 136.8 -> 117.8 us and the prefill down_proj 230 -> 210 us, on the engine's random weights nothing moved (lm_head
