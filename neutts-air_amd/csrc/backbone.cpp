@@ -117,6 +117,13 @@ struct ntts_backbone {
     bool small = false;
     int sks_q = 4, sks_o = 7, sks_d = 10, attn_depth_small = 2;
     bf16_t* h_alt = nullptr;     // second residual-stream buffer (the fused prologue writes the new stream while others still read the old)
+    int attn_split = 8;          // small-batch path: context-split attention over this many workgroups per (sequence, kv-head), used
+    int attn_split_ctx = 896;    //   once the longest running context reaches attn_split_ctx tokens (0 chunks = never).  Measured at batch 1
+                                 //   (profiles/r02i_sweep_split_*): context 625: 0.987 -> 1.025 ms per step (one more launch per layer, the
+                                 //   o_proj prologue sums 8 slabs); context 1850: 1.257 -> 1.093 ms (attention 23.3 -> 13.4 us); break-even ~870
+    bf16_t* as_scores = nullptr;  // [B * nkv][8][max_context + 16]
+    float* as_stats = nullptr;    // [B * nkv][attn_split][8][2]
+    float* as_oslabs = nullptr;   // [attn_split][B][nh * 64]
     float* slabs2 = nullptr;     // down_proj's slabs (read by the next layer's QKV prologue while that kernel writes `slabs`)
     bool norm_wide = true;       // decode add+RMSNorm: one row per workgroup (256 CUs pull) instead of four
     bool pf_prune_last = true;   // prefill, last layer: attention / o_proj / MLP only for each prompt's last position
@@ -129,6 +136,8 @@ struct ntts_backbone {
     size_t meta_cap = 0;
 
     hipGraphExec_t graph = nullptr;
+    hipGraphExec_t graph_split = nullptr;   // the small-batch step with context-split attention (long contexts)
+    bool graph_split_tried = false, split_active = false;
     bool graph_tried = false, use_graph = true;
     hipEvent_t ev[4]{};
     // optional side stream for the prompt pass, restricted to a subset of the CUs (ntts_backbone_set_prefill_cu_mask): a prefill
@@ -380,6 +389,16 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     CR_HIP(hipMalloc((void**)&e->slabs, (size_t)max_slabs * B * H * 4));
     if (e->small) {
         CR_HIP(hipMalloc((void**)&e->slabs2, (size_t)max_slabs * B * H * 4));
+        e->attn_split = env_int("NTTS_ATTN_SPLIT", 8);
+        e->attn_split_ctx = env_int("NTTS_ATTN_SPLIT_CTX", 896);
+        if (e->attn_split < 2 || e->attn_split > 32) e->attn_split = 0;
+        if (e->attn_split) {
+            const size_t n_sc = (size_t)B * c->num_kv_heads * kGroupMax * (c->max_context + 16), n_st = (size_t)B * c->num_kv_heads * e->attn_split * kGroupMax * 2,
+                         n_os = (size_t)e->attn_split * B * c->num_heads * 64;
+            CR_HIP(hipMalloc((void**)&e->as_scores, n_sc * 2)); CR_HIP(hipMemset(e->as_scores, 0, n_sc * 2));
+            CR_HIP(hipMalloc((void**)&e->as_stats, n_st * 4)); CR_HIP(hipMemset(e->as_stats, 0, n_st * 4));
+            CR_HIP(hipMalloc((void**)&e->as_oslabs, n_os * 4)); CR_HIP(hipMemset(e->as_oslabs, 0, n_os * 4));
+        }
         CR_HIP(hipMalloc((void**)&e->h_alt, (size_t)B * H * 2));
         CR_HIP(hipMemset(e->h_alt, 0, (size_t)B * H * 2));
     }
@@ -411,9 +430,10 @@ extern "C" void ntts_backbone_destroy(ntts_backbone* e) {
     hipSetDevice(e->device);
     hipDeviceSynchronize();
     if (e->graph) hipGraphExecDestroy(e->graph);
+    if (e->graph_split) hipGraphExecDestroy(e->graph_split);
     void* bufs[] = {e->arena, e->gu_map_gate, e->gu_map_up, e->kv, e->ibuf, e->h_dec, e->xn_dec, e->qkv_dec, e->attn_dec,
                     e->act_dec, e->slabs, e->slabs2, e->h_alt, e->part_val, e->part_idx, e->logits, e->logits_bf16, e->h_pf, e->xn_pf, e->qkv_pf, e->attn_pf,
-                    e->o_pf, e->act_pf, e->meta_dev};
+                    e->o_pf, e->act_pf, e->meta_dev, e->as_scores, e->as_stats, e->as_oslabs};
     for (void* b : bufs)
         if (b) hipFree(b);
     for (auto& ev : e->ev)
@@ -892,11 +912,19 @@ static void ks_attn(ntts_backbone* e, int i) {
     a.block_table = e->block_table; a.max_pages = e->max_pages; a.pos = e->sl.pos; a.state = e->sl.state;
     a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
     a.tl = e->attn_tl;
+    if (e->split_active && !e->attn_tl) {
+        AttnSplitArgs q{};
+        q.a = a; q.scores = e->as_scores; q.ld_scores = c.max_context + 16; q.stats = e->as_stats; q.oslabs = e->as_oslabs; q.nsplit = e->attn_split;
+        attn_split_launch(q, c.max_batch, e->stream);
+        return;
+    }
     attn_decode_launch_small(a, c.max_batch, e->stream, e->attn_depth_small);
 }
 static void ks_o_proj(ntts_backbone* e, int i) {
     const int QD = e->cfg.num_heads * 64;
-    gemv_launch<EPI_SPLITK, false>(gemv_args(e, e->attn_dec, QD, e->layers[i].wo, QD, e->slabs, e->H, e->H, QD), e->sks_o, e->stream);
+    GemvArgs a = gemv_args(e, e->attn_dec, QD, e->layers[i].wo, QD, e->slabs, e->H, e->H, QD);
+    if (e->split_active && !e->attn_tl) { a.xslabs = e->as_oslabs; a.n_xslab = e->attn_split; }   // context-split attention: chunk outputs summed here
+    gemv_launch<EPI_SPLITK, false>(a, e->sks_o, e->stream);
 }
 static void ks_gate_up(ntts_backbone* e, int i) {
     GemvArgs a = gemv_args(e, nullptr, 0, e->layers[i].wgu, e->H, e->act_dec, e->F, 2 * e->F, e->H);
@@ -1255,9 +1283,11 @@ extern "C" int ntts_backbone_decode(ntts_backbone* e, int32_t n_steps) {
     // ---- reserve KV pages for the positions these steps can write (pos <= max_len - 2)
     std::vector<int> trip;
     std::vector<std::pair<int, size_t>> undo;
+    int ctx_now = 0;                                             // longest context a running slot may have at the first of these steps
     for (int b = 0; b < e->cfg.max_batch; ++b) {
         HostSlot& s = e->slots[b];
         if (s.state != SLOT_RUNNING) continue;
+        if (s.pos_upper > ctx_now) ctx_now = s.pos_upper;
         int upto = s.pos_upper + n_steps;
         if (upto > s.max_len - 1) upto = s.max_len - 1;
         const size_t before = s.pages.size();
@@ -1281,27 +1311,41 @@ extern "C" int ntts_backbone_decode(ntts_backbone* e, int32_t n_steps) {
         hipGraphExecDestroy(e->graph);
         e->graph = nullptr;
         e->graph_tried = false;
+        if (e->graph_split) { hipGraphExecDestroy(e->graph_split); e->graph_split = nullptr; }
+        e->graph_split_tried = false;
+    }
+    // small-batch path: steps whose longest context has reached attn_split_ctx run the context-split attention (its own graph)
+    const bool can_split = e->small && e->attn_split > 0 && !e->attn_tl;
+    auto wants_split = [&](int step) { return can_split && ctx_now + step >= e->attn_split_ctx; };
+    auto capture = [&](int steps, hipGraphExec_t* out) {
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            for (int k = 0; k < steps; ++k) decode_step(e);
+            if (hipStreamEndCapture(st, &g) == hipSuccess && g) {
+                if (hipGraphInstantiate(out, g, nullptr, nullptr, 0) != hipSuccess) *out = nullptr;
+                hipGraphDestroy(g);
+            }
+        }
+        (void)hipGetLastError();
+    };
+    if (e->use_graph && can_split && wants_split(n_steps - 1) && !e->graph_split_tried) {
+        e->graph_split_tried = true;
+        e->graph_has_logits = e->n_sampling > 0;
+        e->split_active = true;
+        capture(1, &e->graph_split);
+        e->split_active = false;
     }
     if (e->use_graph && !e->graph_tried) {
         e->graph_tried = true;
         e->graph_has_logits = e->n_sampling > 0;
-        auto capture = [&](int steps, hipGraphExec_t* out) {
-            hipGraph_t g = nullptr;
-            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                for (int k = 0; k < steps; ++k) decode_step(e);
-                if (hipStreamEndCapture(st, &g) == hipSuccess && g) {
-                    if (hipGraphInstantiate(out, g, nullptr, nullptr, 0) != hipSuccess) *out = nullptr;
-                    hipGraphDestroy(g);
-                }
-            }
-            (void)hipGetLastError();
-        };
         capture(1, &e->graph);   // several steps per graph were measured: -0.3 % per step (profiles/r02a_sweep_nt_graphsteps.jsonl), not kept
     }
     HIPCHK(e, hipEventRecord(e->ev[2], st));
     for (int s = 0; s < n_steps;) {
-        if (e->graph) HIPCHK(e, hipGraphLaunch(e->graph, st));
-        else decode_step(e);
+        const bool sp = wants_split(s);
+        hipGraphExec_t gx = sp ? e->graph_split : e->graph;
+        if (gx) HIPCHK(e, hipGraphLaunch(gx, st));
+        else { e->split_active = sp; decode_step(e); e->split_active = false; }
         ++s;
     }
     HIPCHK(e, hipEventRecord(e->ev[3], st));
@@ -1432,7 +1476,8 @@ extern "C" int ntts_backbone_set_debug(ntts_backbone* e, int32_t keep_logits) {
         e->logits = nullptr;
     }
     if (e->graph) { hipGraphExecDestroy(e->graph); e->graph = nullptr; }
-    e->graph_tried = false;  // the logits pointer is baked into the captured step
+    if (e->graph_split) { hipGraphExecDestroy(e->graph_split); e->graph_split = nullptr; }
+    e->graph_tried = e->graph_split_tried = false;  // the logits pointer is baked into the captured step
     return NTTS_OK;
 }
 

@@ -382,6 +382,257 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
     mark(7);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Context-split ("split-L") decode attention for SMALL batches: at batch 1 the
+// kernel above is two workgroups, each pulling a whole context through one CU.  Here a (sequence, kv-head) is spread over
+// NSPLIT workgroups, each owning a contiguous range of KV pages.  The eager contract rounds P = bf16(exp(s - m) / sum) with
+// the GLOBAL row maximum and denominator, so the work is two launches with the softmax statistics in between:
+//   attn_split_scores_kernel : prologue as above (slab reduce, RoPE, KV append by chunk 0), bf16 scores of the chunk's pages to a
+//                              global scratch [B][nkv][8 heads][L], (max, sum of exp) per head and chunk
+//   attn_split_pv_kernel     : merges the chunks' statistics in chunk order (every workgroup does, identically), P of its pages,
+//                              P V into an fp32 partial output slab [chunk][B][nh * 64]
+// and the o_proj GEMV's helper waves sum the chunk slabs in order and round ONCE to bf16 (gemv.h xslabs) -- the attention
+// output's rounding point.  Same arithmetic per element as the single-workgroup kernel; the fp32 additions of the softmax
+// denominator and of the output run in another order (chunk partials), which is the freedom the parity bars already allow.
+struct AttnSplitArgs {
+    AttnDecodeArgs a;        // a.out unused
+    bf16_t* scores;          // [B * nkv][kGroupMax][ld_scores]
+    long ld_scores;
+    float* stats;            // [B * nkv][nsplit][kGroupMax][2]  (max, sum of exp)
+    float* oslabs;           // [nsplit][B][nh * 64] fp32 partial outputs
+    int nsplit;
+};
+
+NTTS_KERNEL(256) void attn_split_scores_kernel(AttnSplitArgs q) {
+    constexpr int NW = 4, NT = 256;
+    const AttnDecodeArgs& p = q.a;
+    NTTS_SHARED bf16_t qs[16][64];
+    NTTS_SHARED bf16_t knew[64];
+    NTTS_SHARED float wred[NW][kGroupMax];
+    NTTS_SHARED float wsum[NW][kGroupMax];
+    const int b = blockIdx.x, kvh = blockIdx.y, ch = blockIdx.z;
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int g = lane >> 4, l15 = lane & 15;
+    const int group = p.nh / p.nkv;
+    const int* bt = p.block_table + (long)b * p.max_pages;
+    const int st = p.state[b];
+    const int P = p.pos[b];
+    // ---- prologue operands (every chunk rebuilds q; all of them need the new k for the page that holds position P)
+    const int nitems = (group + 1) * 32;
+    const float* sbase[kAttnMaxSlabs];
+#pragma unroll
+    for (int sl = 0; sl < kAttnMaxSlabs; ++sl) {
+        const int su = sl < p.nslab ? sl : (p.nslab > 0 ? p.nslab - 1 : 0);
+        sbase[sl] = p.qkv_slabs + ((long)su * p.slab_rows + b) * p.ld_qkv;
+    }
+    auto qkv_value = [&](int col) -> bf16_t {
+        float part[kAttnMaxSlabs];
+#pragma unroll
+        for (int sl = 0; sl < kAttnMaxSlabs; ++sl) part[sl] = sbase[sl][col];
+        float a = part[0];
+#pragma unroll
+        for (int sl = 1; sl < kAttnMaxSlabs; ++sl) a += sl < p.nslab ? part[sl] : 0.f;
+        return f2bf(a + bf2f(p.qkv_bias[col]));
+    };
+    constexpr int ITS = ((kGroupMax + 1) * 32 + NT - 1) / NT;
+    bf16_t x1[ITS], x2[ITS], v1[ITS], v2[ITS];
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+        const int t = tid + it * NT;
+        x1[it] = x2[it] = v1[it] = v2[it] = 0;
+        if (t < nitems) {
+            const int hh = t >> 5, i = t & 31;
+            const int c0 = hh < group ? (kvh * group + hh) * 64 : (p.nh + kvh) * 64;
+            x1[it] = qkv_value(c0 + i);
+            x2[it] = qkv_value(c0 + i + 32);
+            if (hh == group && ch == 0) {
+                const int v0 = (p.nh + p.nkv + kvh) * 64;
+                v1[it] = qkv_value(v0 + i);
+                v2[it] = qkv_value(v0 + i + 32);
+            }
+        }
+    }
+    if (st != 1) return;  // block-uniform
+    const int L = P + 1;
+    const int npages = (L + kPage - 1) / kPage;
+    const int last_page = npages - 1;
+    const int ppc = (npages + q.nsplit - 1) / q.nsplit;          // pages per chunk
+    const int pg_lo = ch * ppc, pg_hi = (pg_lo + ppc < npages) ? pg_lo + ppc : npages;
+#pragma unroll
+    for (int it = 0; it < ITS; ++it) {
+        const int t = tid + it * NT;
+        if (t < nitems) {
+            const int hh = t >> 5, i = t & 31;
+            const float c = bf2f(p.rope_cos[(long)P * 32 + i]), sn = bf2f(p.rope_sin[(long)P * 32 + i]);
+            float o1, o2;
+            rope_pair(bf2f(x1[it]), bf2f(x2[it]), c, sn, o1, o2);
+            if (hh < group) {
+                qs[hh][i] = f2bf(o1);
+                qs[hh][i + 32] = f2bf(o2);
+            } else {
+                const bf16_t k1 = f2bf(o1), k2 = f2bf(o2);
+                knew[i] = k1; knew[i + 32] = k2;
+                if (ch == 0) {                                     // chunk 0 appends the token to the cache
+                    const long new_page = bt[P / kPage];
+                    const int slot = P % kPage;
+                    bf16_t* kd = p.kpool + ((new_page * p.nkv + kvh) * kPage + slot) * 64;
+                    kd[i] = k1; kd[i + 32] = k2;
+                    bf16_t* vd = p.vpool + (new_page * p.nkv + kvh) * 64 * kPage + v_slot(slot);
+                    vd[(long)i * kPage] = v1[it]; vd[(long)(i + 32) * kPage] = v2[it];
+                }
+            }
+        }
+    }
+    for (int t = tid; t < (16 - group) * 64; t += NT) qs[group + t / 64][t % 64] = 0;
+    sync();
+    bf16x8 qB[2];
+    qB[0] = ld16<bf16x8>(&qs[l15][g * 16]);
+    qB[1] = ld16<bf16x8>(&qs[l15][g * 16 + 8]);
+    constexpr float kMasked = -1.0e30f;
+    float lmax = kMasked, lsum = 0.f;
+    bf16_t* srow = q.scores + ((long)(b * p.nkv + kvh) * kGroupMax + (l15 < kGroupMax ? l15 : 0)) * q.ld_scores;
+    for (int pg = pg_lo + w; pg < pg_hi; pg += NW) {
+        const bf16_t* kp = p.kpool + ((long)bt[pg] * p.nkv + kvh) * kPage * 64;
+        bf16x8 kc[2][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bf16_t* kr = kp + (u * 16 + l15) * 64 + g * 16;
+            kc[u][0] = ld16<bf16x8>(kr);
+            kc[u][1] = ld16<bf16x8>(kr + 8);
+        }
+        if (pg == last_page) {  // the token appended this step comes from LDS (chunk 0's store may not have landed)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (pg * kPage + u * 16 + l15 == P) {
+                    kc[u][0] = ld16<bf16x8>(&knew[g * 16]);
+                    kc[u][1] = ld16<bf16x8>(&knew[g * 16 + 8]);
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+            a = mfma16(kc[u][0], qB[0], a);
+            a = mfma16(kc[u][1], qB[1], a);
+            const int key0 = pg * kPage + u * 16 + g * 4;
+            bf16x4 sv;
+            float s4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float sc_ = rbf(a[r]) * 0.125f;
+                if (key0 + r >= L) sc_ = kMasked;
+                s4[r] = sc_;
+                sv[r] = (short)f2bf(sc_);
+            }
+            if (l15 < kGroupMax) *(bf16x4*)(srow + key0) = sv;
+            const float mn = fmaxf(lmax, fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s4[3])));
+            lsum = lsum * fexp_neg(lmax - mn) + fexp_neg(s4[0] - mn) + fexp_neg(s4[1] - mn) + fexp_neg(s4[2] - mn) + fexp_neg(s4[3] - mn);
+            lmax = mn;
+        }
+    }
+#pragma unroll
+    for (int sh = 16; sh <= 32; sh <<= 1) {
+        const float om = shfl_xor(lmax, sh), os = shfl_xor(lsum, sh);
+        const float mn = fmaxf(lmax, om);
+        lsum = lsum * fexp_neg(lmax - mn) + os * fexp_neg(om - mn);
+        lmax = mn;
+    }
+    if (g == 0 && l15 < kGroupMax) { wred[w][l15] = lmax; wsum[w][l15] = lsum; }
+    sync();
+    if (w == 0 && g == 0 && l15 < kGroupMax) {
+        float m_l = wred[0][l15];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) m_l = fmaxf(m_l, wred[ww][l15]);
+        float sum_l = wsum[0][l15] * fexp_neg(wred[0][l15] - m_l);
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) sum_l += wsum[ww][l15] * fexp_neg(wred[ww][l15] - m_l);
+        float* sd = q.stats + (((long)(b * p.nkv + kvh) * q.nsplit + ch) * kGroupMax + l15) * 2;
+        sd[0] = m_l;
+        sd[1] = sum_l;
+    }
+}
+
+NTTS_KERNEL(256) void attn_split_pv_kernel(AttnSplitArgs q) {
+    constexpr int NW = 4, NT = 256;
+    const AttnDecodeArgs& p = q.a;
+    NTTS_SHARED float ored[NW][kGroupMax][64];
+    const int b = blockIdx.x, kvh = blockIdx.y, ch = blockIdx.z;
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int g = lane >> 4, l15 = lane & 15;
+    const int group = p.nh / p.nkv;
+    const int* bt = p.block_table + (long)b * p.max_pages;
+    if (p.state[b] != 1) return;  // block-uniform
+    const int P = p.pos[b];
+    const int L = P + 1;
+    const int npages = (L + kPage - 1) / kPage;
+    const int ppc = (npages + q.nsplit - 1) / q.nsplit;
+    const int pg_lo = ch * ppc, pg_hi = (pg_lo + ppc < npages) ? pg_lo + ppc : npages;
+    // ---- global softmax statistics: the chunks' (max, sum) merged in chunk order (chunks past the context wrote nothing: skipped)
+    constexpr float kMasked = -1.0e30f;
+    float m_l = kMasked, sum_l = 1.f;
+    if (l15 < kGroupMax) {
+        const float* sd = q.stats + ((long)(b * p.nkv + kvh) * q.nsplit * kGroupMax + l15) * 2;
+        const int nch = (npages + ppc - 1) / ppc;                   // chunks that own pages
+        for (int c = 0; c < nch; ++c) m_l = fmaxf(m_l, sd[(long)c * kGroupMax * 2]);
+        sum_l = 0.f;
+        for (int c = 0; c < nch; ++c) sum_l += sd[(long)c * kGroupMax * 2 + 1] * fexp_neg(sd[(long)c * kGroupMax * 2] - m_l);
+    }
+    const float rs_l = frcp_refined(sum_l);
+    f32x4 oacc[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) oacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16_t* srow = q.scores + ((long)(b * p.nkv + kvh) * kGroupMax + (l15 < kGroupMax ? l15 : 0)) * q.ld_scores;
+    for (int pg = pg_lo + w; pg < pg_hi; pg += NW) {
+        const bf16_t* vp = p.vpool + ((long)bt[pg] * p.nkv + kvh) * 64 * kPage;
+        bf16x8 vc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) vc[nt] = ld16<bf16x8>(vp + (nt * 16 + l15) * kPage + g * 8);
+        bf16x8 pA;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pA[e] = 0;
+        if (l15 < kGroupMax) {
+            const bf16x4 s0 = *(const bf16x4*)(srow + pg * kPage + g * 4);
+            const bf16x4 s1 = *(const bf16x4*)(srow + pg * kPage + 16 + g * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                pA[e] = (short)f2bf(fdiv_r(fexp_neg(bf2f((bf16_t)s0[e]) - m_l), sum_l, rs_l));
+                pA[4 + e] = (short)f2bf(fdiv_r(fexp_neg(bf2f((bf16_t)s1[e]) - m_l), sum_l, rs_l));
+            }
+        }
+        if (pg == npages - 1) {   // the last page: nothing beyond position P may leak in (0 * garbage); P itself was appended by the scores kernel
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int key = pg * kPage + (e < 4 ? g * 4 + e : 16 + g * 4 + e - 4);
+                    if (key > P) vc[nt][e] = 0;
+                }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) oacc[nt] = mfma16(pA, vc[nt], oacc[nt]);
+    }
+    if (g < 2) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ored[w][g * 4 + r][nt * 16 + l15] = oacc[nt][r];
+    }
+    sync();
+    float* os = q.oslabs + ((long)ch * p.slab_rows + b) * p.ld_out;
+    for (int t = tid; t < group * 64; t += NT) {
+        const int hh = t >> 6, d = t & 63;
+        float o = ored[0][hh][d];
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) o += ored[ww][hh][d];
+        os[(kvh * group + hh) * 64 + d] = o;
+    }
+}
+
+inline void attn_split_launch(const AttnSplitArgs& q, int batch, hipStream_t s) {
+    const dim3 grid(batch, q.a.nkv, q.nsplit), block(256);
+    NTTS_LAUNCH((attn_split_scores_kernel), grid, block, s, q);
+    NTTS_LAUNCH((attn_split_pv_kernel), grid, block, s, q);
+}
+
 template <int kVar>
 inline void attn_decode_launch_v(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth) {
     const dim3 grid(batch, p.nkv), block(256);

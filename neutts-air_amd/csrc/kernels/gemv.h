@@ -40,6 +40,8 @@ constexpr int kGemvXld = 1024 + 8;     // LDS row stride of the prologue's X pan
 struct GemvArgs {
     const bf16_t* X;       // [M][ldx] bf16 (PRO = false)
     long ldx;
+    const float* xslabs;   // PRO = false alternative to X: [n_xslab][slab_rows][ldx] fp32 partials (the context-split attention's
+    int n_xslab;           //   chunk outputs, attn_decode.h): X = bf16(sum over the slabs, in order) -- one rounding, the attention output's
     NormArgs pro;          // PRO = true: what add_rmsnorm would have been given (slabs | o_bf16 | gather) + resid_in/out + norm_w
     const bf16_t* W;
     long ldw;
@@ -87,8 +89,26 @@ NTTS_KERNEL((FW + 4) * 64) void gemv_kernel(GemvArgs p) {
         } else {
             const int nch = nk * 8;                               // 16-byte chunks per row of the slice: <= 128 = 2 per lane
             for (int m = hw; m < p.M; m += 4) {
-                const bf16_t* src = p.X + (long)m * p.ldx + kt0 * 64;
                 const int c0 = lane, c1 = lane + 64;                // both loads first (clamped addresses), then the guarded stores
+                if (p.xslabs) {                                     // (wave-uniform) sum the fp32 slabs in order, round once
+                    float a0[8], a1[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.f;
+                    for (int sl = 0; sl < p.n_xslab; ++sl) {
+                        const float* src = p.xslabs + ((long)sl * p.slab_rows + m) * p.ldx + kt0 * 64;
+                        const f32x4 u0 = ld16<f32x4>(src + (c0 < nch ? c0 : 0) * 8), u1 = ld16<f32x4>(src + (c0 < nch ? c0 : 0) * 8 + 4);
+                        const f32x4 w0 = ld16<f32x4>(src + (c1 < nch ? c1 : 0) * 8), w1 = ld16<f32x4>(src + (c1 < nch ? c1 : 0) * 8 + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { a0[e] += u0[e]; a0[4 + e] += u1[e]; a1[e] += w0[e]; a1[4 + e] += w1[e]; }
+                    }
+                    bf16x8 t0, t1;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { t0[e] = (short)f2bf(a0[e]); t1[e] = (short)f2bf(a1[e]); }
+                    if (c0 < nch) *(bf16x8*)(xs + m * kGemvXld + c0 * 8) = t0;
+                    if (c1 < nch) *(bf16x8*)(xs + m * kGemvXld + c1 * 8) = t1;
+                    continue;
+                }
+                const bf16_t* src = p.X + (long)m * p.ldx + kt0 * 64;
                 const bf16x8 t0 = ld16<bf16x8>(src + (c0 < nch ? c0 : 0) * 8);
                 const bf16x8 t1 = ld16<bf16x8>(src + (c1 < nch ? c1 : 0) * 8);
                 if (c0 < nch) *(bf16x8*)(xs + m * kGemvXld + c0 * 8) = t0;

@@ -63,6 +63,33 @@ def test_prefill_on_cu_masked_side_stream(lib):
             eng.release(u)
 
 
+def test_long_context_switches_to_split_attention(lib, monkeypatch):
+    """Small-batch path, a context that grows past attn_split_ctx (896) mid-generation: the steps before run the single-workgroup
+    attention, the steps after the context-split one (second hipGraph, o_proj prologue summing the chunk slabs).  Free-running
+    greedy ids on peaked weights: identical to the oracle's, and identical with the split disabled."""
+    cfg = br.BackboneConfig(vocab_size=3000, hidden_size=896, intermediate_size=1216, num_layers=3)
+    w = br.make_weights(cfg, 33, peak_sigma=0.5)
+    wd = br.cast_weights(w, torch.bfloat16)
+    S, N = 872, 48                                              # positions 872 .. 919: the switch is at 896
+    prompt = br.synthetic_prompt(cfg, 5, S)
+    eos = cfg.vocab_size - 1
+    want = br.generate(cfg, wd, prompt, S + N, eos_id=eos, min_new_tokens=N, keep_logits=True)
+    got = {}
+    for split in ("8", "0"):
+        monkeypatch.setenv("NTTS_ATTN_SPLIT", split)
+        eng = make_engine(cfg, w, lib, max_batch=2, max_context=1024, max_prefill_tokens=1024, bf16_upload=True)
+        samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
+        eng.prefill([prompt], [1], [samp])
+        eng.decode(10)                                          # two calls: the second one starts below and ends above the switch
+        eng.decode(N - 1 - 10)
+        ids, fin = eng.read(1)
+        assert fin and len(ids) == N
+        got[split] = ids
+        eng.close()
+    assert_free_run_matches(got["8"], want)
+    assert got["8"] == got["0"], (got["8"], got["0"])
+
+
 def test_continuous_batching_ragged_vs_oracle(lib):
     cfg = br.BackboneConfig(vocab_size=3000, hidden_size=896, intermediate_size=1216, num_layers=3)
     w = br.make_weights(cfg, 21, peak_sigma=0.5)

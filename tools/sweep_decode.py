@@ -48,7 +48,7 @@ def main():
         eng = _hip.BackboneEngine(dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
                                        intermediate_size=cfg.intermediate_size, num_layers=cfg.num_layers,
                                        num_heads=cfg.num_heads, num_kv_heads=cfg.num_kv_heads, rms_eps=cfg.rms_eps,
-                                       max_context=768, max_batch=B, max_prefill_tokens=64 * S), 0)
+                                       max_context=((S + 250 + 31) // 32) * 32 if S > 500 else 768, max_batch=B, max_prefill_tokens=64 * S), 0)
         eng.load_state_dict(wd, inv_freq=inv)
         samp = _hip.Sampling(max_length=S + 250, min_new_tokens=250, eos_token_id=cfg.vocab_size - 1, do_sample=False)
         for c in range(0, B, 64):
