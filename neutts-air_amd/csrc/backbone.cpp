@@ -389,9 +389,13 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     CR_HIP(hipMalloc((void**)&e->slabs, (size_t)max_slabs * B * H * 4));
     if (e->small) {
         CR_HIP(hipMalloc((void**)&e->slabs2, (size_t)max_slabs * B * H * 4));
+    }
+    {
+        // context-split attention (small-batch path; tile path below 2 workgroups per CU with split-K QKV slabs, bf16 engines)
         e->attn_split = env_int("NTTS_ATTN_SPLIT", 8);
         e->attn_split_ctx = env_int("NTTS_ATTN_SPLIT_CTX", 896);
         if (e->attn_split < 2 || e->attn_split > 32) e->attn_split = 0;
+        if (!e->small && (e->fp8 || e->ks_qkv < 2 || B * c->num_kv_heads >= 512)) e->attn_split = 0;
         if (e->attn_split) {
             const size_t n_sc = (size_t)B * c->num_kv_heads * kGroupMax * (c->max_context + 16), n_st = (size_t)B * c->num_kv_heads * e->attn_split * kGroupMax * 2,
                          n_os = (size_t)e->attn_split * B * c->num_heads * 64;
@@ -837,6 +841,12 @@ static void k_attn(ntts_backbone* e, int i) {
     a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
     a.tl = e->attn_tl;
     if (e->fp8) a.out_fp8_inv = 1.0f / e->layers[i].xs[1];   // attention output = o_proj's input
+    if (e->split_active && !e->attn_tl && a.qkv_slabs) {       // long contexts below 2 workgroups per CU: context-split attention + combine
+        AttnSplitArgs q{};
+        q.a = a; q.scores = e->as_scores; q.ld_scores = c.max_context + 16; q.stats = e->as_stats; q.oslabs = e->as_oslabs; q.nsplit = e->attn_split;
+        attn_split_launch(q, c.max_batch, e->stream, true);
+        return;
+    }
     attn_decode_launch(a, c.max_batch, e->stream, e->attn_depth, e->attn_var);
 }
 
@@ -1315,7 +1325,7 @@ extern "C" int ntts_backbone_decode(ntts_backbone* e, int32_t n_steps) {
         e->graph_split_tried = false;
     }
     // small-batch path: steps whose longest context has reached attn_split_ctx run the context-split attention (its own graph)
-    const bool can_split = e->small && e->attn_split > 0 && !e->attn_tl;
+    const bool can_split = e->attn_split > 0 && !e->attn_tl;
     auto wants_split = [&](int step) { return can_split && ctx_now + step >= e->attn_split_ctx; };
     auto capture = [&](int steps, hipGraphExec_t* out) {
         hipGraph_t g = nullptr;

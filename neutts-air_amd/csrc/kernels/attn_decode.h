@@ -627,10 +627,33 @@ NTTS_KERNEL(256) void attn_split_pv_kernel(AttnSplitArgs q) {
     }
 }
 
-inline void attn_split_launch(const AttnSplitArgs& q, int batch, hipStream_t s) {
+// the tile path's o_proj reads bf16 rows (LDS-DMA): there the chunk slabs are summed (in order, one rounding) by this pass
+NTTS_KERNEL(256) void attn_split_combine_kernel(AttnSplitArgs q) {
+    const AttnDecodeArgs& p = q.a;
+    const int b = blockIdx.x;
+    if (p.state[b] != 1) return;
+    for (int c8 = threadIdx.x; c8 * 8 < p.ld_out; c8 += 256) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int ch = 0; ch < q.nsplit; ++ch) {
+            const float* src = q.oslabs + ((long)ch * p.slab_rows + b) * p.ld_out + c8 * 8;
+            const f32x4 u0 = ld16<f32x4>(src), u1 = ld16<f32x4>(src + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[e] += u0[e]; acc[4 + e] += u1[e]; }
+        }
+        bf16x8 t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = (short)f2bf(acc[e]);
+        *(bf16x8*)(p.out + (long)b * p.ld_out + c8 * 8) = t;
+    }
+}
+
+inline void attn_split_launch(const AttnSplitArgs& q, int batch, hipStream_t s, bool combine = false) {
     const dim3 grid(batch, q.a.nkv, q.nsplit), block(256);
     NTTS_LAUNCH((attn_split_scores_kernel), grid, block, s, q);
     NTTS_LAUNCH((attn_split_pv_kernel), grid, block, s, q);
+    if (combine) NTTS_LAUNCH((attn_split_combine_kernel), dim3(batch), block, s, q);
 }
 
 template <int kVar>

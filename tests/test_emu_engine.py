@@ -29,7 +29,8 @@ def test_tiny_teacher_forced(emu_lib):
     {},                                                                                    # small-batch path (gemv.h), defaults
     {"NTTS_SKS_Q": "2", "NTTS_SKS_O": "3", "NTTS_SKS_D": "16", "NTTS_ATTN_DEPTH_SMALL": "1", "NTTS_W_TILE_MAJOR": "0"},
     {"NTTS_ATTN_SPLIT": "3", "NTTS_ATTN_SPLIT_CTX": "40"},                                                               # small-batch path, context-split attention from context 40 on (3 chunks: ragged page ranges, an empty chunk early on; the run crosses the switch)
-    {"NTTS_SMALL_BATCH": "0", "NTTS_ATTN_DEPTH": "1", "NTTS_S_STAGES": "3", "NTTS_PF_GH": "4", "NTTS_HEAD_LARGE": "1", "NTTS_HEAD_XL": "1"},   # large-batch path (gemm.h tiles)
+    {"NTTS_SMALL_BATCH": "0", "NTTS_ATTN_DEPTH": "1", "NTTS_S_STAGES": "3", "NTTS_PF_GH": "4", "NTTS_HEAD_LARGE": "1", "NTTS_HEAD_XL": "1",
+     "NTTS_ATTN_SPLIT": "2", "NTTS_ATTN_SPLIT_CTX": "45"},   # large-batch path (gemm.h tiles), context-split attention + combine pass from context 45 on
     {"NTTS_SMALL_BATCH": "0", "NTTS_ATTN_DEPTH": "4", "NTTS_S_STAGES": "6", "NTTS_KSPLIT_O": "2", "NTTS_KSPLIT_D": "5",
      "NTTS_PREFILL_ATTN_SIMPLE": "1", "NTTS_KSPLIT_QKV": "3", "NTTS_ATTN_VAR": "2", "NTTS_NORM_WIDE": "0", "NTTS_W_TILE_MAJOR": "0", "NTTS_HEAD_LARGE": "1"}])
 def test_small_gqa2_page_crossing_peaked_exact(emu_lib, knobs, monkeypatch):

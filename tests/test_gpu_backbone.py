@@ -63,7 +63,8 @@ def test_prefill_on_cu_masked_side_stream(lib):
             eng.release(u)
 
 
-def test_long_context_switches_to_split_attention(lib, monkeypatch):
+@pytest.mark.parametrize("max_batch", [2, 16])     # small-batch path (o_proj prologue sums the chunk slabs) / tile path (combine pass)
+def test_long_context_switches_to_split_attention(lib, monkeypatch, max_batch):
     """Small-batch path, a context that grows past attn_split_ctx (896) mid-generation: the steps before run the single-workgroup
     attention, the steps after the context-split one (second hipGraph, o_proj prologue summing the chunk slabs).  Free-running
     greedy ids on peaked weights: identical to the oracle's, and identical with the split disabled."""
@@ -77,7 +78,7 @@ def test_long_context_switches_to_split_attention(lib, monkeypatch):
     got = {}
     for split in ("8", "0"):
         monkeypatch.setenv("NTTS_ATTN_SPLIT", split)
-        eng = make_engine(cfg, w, lib, max_batch=2, max_context=1024, max_prefill_tokens=1024, bf16_upload=True)
+        eng = make_engine(cfg, w, lib, max_batch=max_batch, max_context=1024, max_prefill_tokens=1024, bf16_upload=True)
         samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
         eng.prefill([prompt], [1], [samp])
         eng.decode(10)                                          # two calls: the second one starts below and ends above the switch
