@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <set>
 #include <string>
 #include <vector>
@@ -98,13 +99,16 @@ struct ntts_backbone {
     int st_qkv = 4, st_o = 4, st_gu = 3, st_d = 4;   // LDS ring depth of each skinny decode GEMM
     int head_stages = 2, l_stages = 2, pf_gh = 7, attn_depth = 1, attn_var = 1, gu_tile = 0;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
     bool gu_large = false, head_large = true, pf_attn_simple = false, use_xl = true;
-    bool head_xl = false;   // lm_head tile at large batch: 128 x 128, or 256 x 256 (16 waves).  128 x 256 and 256 x 128 tiles (8 waves,
-                            // two workgroups per CU) were measured: 168 / 158 vs 126 us (profiles/r02g_sweep_head_tiles.log)
+    int head_xl = 0;        // lm_head tile at large batch: 0 = 128 x 128, 1 = 256 x 256 (16 waves); 4 / 5 / 6 = the natural-order tiles
+                            // that cover the vocabulary in THREE rounds of the 256 CUs instead of 3.32 (gemm.h TN): 256 x 288 with 12
+                            // waves, 256 x 320 with 8, 256 x 288 with 8.  128 x 256 and 256 x 128 tiles (8 waves, two workgroups per
+                            // CU) were measured: 168 / 158 vs 126 us (profiles/r02g_sweep_head_tiles.log)
     // non-temporal policy on the lm_head's weight stream (NTTS_W_NT).  Measured at batch 256
     // (profiles/r02a_sweep_nt_graphsteps.jsonl): lm_head 136.6 -> 132.3 us; on the LDS-DMA rings of the skinny layer GEMMs the
     // same policy was SLOWER (qkv 5.78 -> 5.96, down 9.95 -> 10.54 us; step 1.679 -> 1.718 ms) and is not offered there
     int w_nt = 1;
     bool pf_rope_vec = true;   // prefill RoPE + KV write with 16-byte accesses (rope_kv_write_vec_kernel)
+    bool pf_lpt = true;        // prefill attention work list sorted by descending causal depth (longest tiles dispatched first)
     bool pf_resid = true;   // prefill: residual add in the o_proj / down_proj epilogue (EPI_RESID) instead of in the norm pass
     // Split-K decode GEMMs: XCD-aware slice placement (gemm.h GemmArgs::xcd_nsplit; NTTS_XCD_SPLIT bit 0 qkv, 1 o_proj, 2 down).
     // Measured at batch 256 (profiles/r02f_*): FETCH per skinny-GEMM launch 15.0 -> 6.8 MB (algorithmic 5.3: the 8 private L2s
@@ -358,9 +362,11 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->w_nt = env_int("NTTS_W_NT", 1);
     e->pf_resid = env_int("NTTS_PF_RESID", 1) != 0;
     e->pf_rope_vec = env_int("NTTS_PF_ROPE_VEC", 1) != 0;
+    e->pf_lpt = env_int("NTTS_PF_LPT", 1) != 0;
     e->xcd_split = env_int("NTTS_XCD_SPLIT", 5);
     e->use_xl = env_int("NTTS_XL", 1) != 0;
-    e->head_xl = env_int("NTTS_HEAD_XL", B > 128 ? 1 : 0) != 0;
+    e->head_xl = env_int("NTTS_HEAD_XL", B > 128 ? 1 : 0);
+    if (e->fp8 && e->head_xl > 1) e->head_xl = 1;          // (the natural-order tiles are bf16 only)
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e->pf_gh = env_int("NTTS_PF_GH", 7);   // all 7 heads of a GQA group in one pass: K/V pages staged once (prefill chunk 35.0 -> 33.4 ms)
     e->attn_depth = env_int("NTTS_ATTN_DEPTH", 1);
@@ -380,7 +386,8 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     if (e->sks_o > max_slabs) e->sks_o = max_slabs;
     if (e->sks_d > max_slabs) e->sks_d = max_slabs;
     e->attn_depth_small = env_int("NTTS_ATTN_DEPTH_SMALL", 2);
-    e->n_part = e->small ? V / 16 : e->head_xl ? ((V + 255) / 256) * 4 : e->head_large ? ((V + 127) / 128) * 2 : (V + 63) / 64;
+    e->n_part = e->small ? V / 16 : !e->head_large ? (V + 63) / 64 : e->head_xl == 4 ? ((V + 287) / 288) * 3 : e->head_xl == 5 ? ((V + 319) / 320) * 4 :
+                e->head_xl == 6 ? ((V + 287) / 288) * 2 : e->head_xl ? ((V + 255) / 256) * 4 : ((V + 127) / 128) * 2;
     CR_HIP(hipMalloc((void**)&e->h_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->xn_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->qkv_dec, (size_t)B * e->NQKV * 2));
@@ -794,6 +801,13 @@ static void k_lm_head(ntts_backbone* e, bool keep_logits) {
     a.logits = keep_logits ? e->logits : nullptr; a.ld_logits = V;
     a.logits_bf16 = (keep_logits && e->n_sampling > 0) ? e->logits_bf16 : nullptr; a.ld_logits_bf16 = e->ldl;
     if (!e->head_large) { gemm_skinny<EPI_ARGMAX>(4, a, 1, e->stream); return; }
+    if (e->head_xl >= 4) {   // natural-order tiles (bf16): three rounds of the CUs
+        const bool nt = (e->w_nt & 1) != 0;
+        if (e->head_xl == 4) { if (nt) gemm_launch<4, 3, 4, EPI_ARGMAX, 2, 0, 64, true, false, 6>(a, 1, e->stream); else gemm_launch<4, 3, 4, EPI_ARGMAX, 2, 0, 64, false, false, 6>(a, 1, e->stream); }
+        else if (e->head_xl == 5) { if (nt) gemm_launch<2, 4, 8, EPI_ARGMAX, 2, 0, 64, true, false, 5>(a, 1, e->stream); else gemm_launch<2, 4, 8, EPI_ARGMAX, 2, 0, 64, false, false, 5>(a, 1, e->stream); }
+        else { if (nt) gemm_launch<4, 2, 4, EPI_ARGMAX, 2, 0, 64, true, false, 9>(a, 1, e->stream); else gemm_launch<4, 2, 4, EPI_ARGMAX, 2, 0, 64, false, false, 9>(a, 1, e->stream); }
+        return;
+    }
     if (e->head_xl) {
         if (e->fp8) gemm_launch<4, 4, 4, EPI_ARGMAX, 2, 0, 64, true, true>(a, 1, e->stream);
         else if (e->w_nt & 1) gemm_launch<4, 4, 4, EPI_ARGMAX, 2, 0, 64, true>(a, 1, e->stream);
@@ -868,7 +882,10 @@ static void k_gate_up(ntts_backbone* e, int i) {
     }
     // (a 4-slot ring on the 128 x 128 tile, 96 KB in flight per CU instead of 64: 13.3 vs 13.4 us -- ring depth is not what
     //  bounds this kernel; profiles/r02h_sweep_gate_up_ring.log)
-    if (e->gu_tile == 1) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);        // 128 x 128, 8 waves
+    if (e->gu_tile == 3) gemm_launch<4, 1, 2, EPI_SILU_MUL, 3, 0, 64, false, false, 5>(gu, 1, e->stream);        // 128 x 80, 4 waves: 244 workgroups
+    else if (e->gu_tile == 4) gemm_launch<8, 1, 1, EPI_SILU_MUL, 3, 0, 64, false, false, 5>(gu, 1, e->stream);   // 128 x 80, 8 waves
+    else if (e->gu_tile == 5) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3, 0, 64, false, false, 3>(gu, 1, e->stream);   // 128 x 96, 8 waves: 204 workgroups
+    else if (e->gu_tile == 1) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);        // 128 x 128, 8 waves
     else if (e->gu_tile == 2) gemm_launch<8, 1, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);   // 256 x 64, 8 waves
     else if (e->gu_large) gemm_large<EPI_SILU_MUL>(e, gu, e->stream);
     else gemm_skinny<EPI_SILU_MUL>(e->st_gu, gu, 1, e->stream);
@@ -1097,6 +1114,17 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
         m.push_back((int)acc);
         for (int q = pos0[i]; q < lens[i]; q += 64) { tile_seq.push_back(i); tile_q0.push_back(q); }
         acc += lens[i] - pos0[i];
+    }
+    if (e->pf_lpt) {
+        // Causal attention: a 64-query tile that starts at position q0 sweeps (q0 + 64) / 32 KV pages, 2 .. 16 for a 500-token
+        // prompt.  In prompt order the LAST workgroups dispatched are the deepest tiles of the last prompt and the pass ends on
+        // them; sorted by descending depth (stable: ties keep prompt order) the shallow tiles fill the tail instead.
+        std::vector<int> ord(tile_seq.size());
+        for (size_t k = 0; k < ord.size(); ++k) ord[k] = (int)k;
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return tile_q0[a] > tile_q0[b]; });
+        std::vector<int> ts(ord.size()), tq(ord.size());
+        for (size_t k = 0; k < ord.size(); ++k) { ts[k] = tile_seq[ord[k]]; tq[k] = tile_q0[ord[k]]; }
+        tile_seq.swap(ts); tile_q0.swap(tq);
     }
     const size_t o_len = m.size();   m.insert(m.end(), lens, lens + n);
     const size_t o_pos0 = m.size();  m.insert(m.end(), pos0.begin(), pos0.end());

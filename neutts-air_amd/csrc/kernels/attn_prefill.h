@@ -262,16 +262,19 @@ NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
     NTTS_SHARED bf16_t lds[2 * 2 * kPage * 64];   // [buf][K | V^T] 4 KB each
     const int lane = lane_id(), w = wave_id();
     const int g = lane >> 4, l15 = lane & 15;
-    const int sq = p.meta.tile_seq[blockIdx.x];
+    // grid = (kv-head, tile, pass): the kv-head is the FAST index, so that with the work list sorted by descending causal
+    // depth (prefill_impl) the dispatch order is longest-first over all (tile, kv-head) pairs and the short tiles fill the tail
+    const int tile = blockIdx.y;
+    const int sq = p.meta.tile_seq[tile];
     const int S = p.meta.seq_len[sq];
     const int base = p.meta.tok_base[sq] - p.meta.pos0[sq];   // packed row of absolute position q is base + q
-    const int kvh = blockIdx.y;
+    const int kvh = blockIdx.x;
     const int group = p.nh / p.nkv;
     const int h0 = kvh * group + blockIdx.z * GH;            // first query head of this pass
     int nhd = group - blockIdx.z * GH;                        // heads handled here (<= GH)
     if (nhd > GH) nhd = GH;
     const int* bt = p.block_table + (long)p.meta.slot[sq] * p.max_pages;
-    const int q0 = p.meta.tile_q0[blockIdx.x];
+    const int q0 = p.meta.tile_q0[tile];
     const int qw0 = q0 + w * 16;                              // first query of this wave
     const bool wave_live = qw0 < S;                           // dead waves still help loading and hit the barriers
     int qpos = qw0 + l15;
@@ -466,9 +469,9 @@ NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
 // host launcher: GH = 7 covers NeuTTS-Air's group in one pass; other group sizes run ceil(group / GH) passes
 inline void attn_prefill_launch(const AttnPrefillArgs& p, int n_tiles, hipStream_t s, int heads_per_pass = 7) {
     const int group = p.nh / p.nkv;
-    if (group <= 4) NTTS_LAUNCH((attn_prefill_gqa_kernel<4>), dim3(n_tiles, p.nkv, 1), dim3(256), s, p);
-    else if (heads_per_pass <= 4) NTTS_LAUNCH((attn_prefill_gqa_kernel<4>), dim3(n_tiles, p.nkv, (group + 3) / 4), dim3(256), s, p);
-    else NTTS_LAUNCH((attn_prefill_gqa_kernel<7>), dim3(n_tiles, p.nkv, (group + 6) / 7), dim3(256), s, p);
+    if (group <= 4) NTTS_LAUNCH((attn_prefill_gqa_kernel<4>), dim3(p.nkv, n_tiles, 1), dim3(256), s, p);
+    else if (heads_per_pass <= 4) NTTS_LAUNCH((attn_prefill_gqa_kernel<4>), dim3(p.nkv, n_tiles, (group + 3) / 4), dim3(256), s, p);
+    else NTTS_LAUNCH((attn_prefill_gqa_kernel<7>), dim3(p.nkv, n_tiles, (group + 6) / 7), dim3(256), s, p);
 }
 
 }  // namespace ntts

@@ -311,6 +311,77 @@ NTTS_D void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][4], int mrow0, int
     }
 }
 
+// ---- epilogue of the natural-order tiles (TN != 4): the wave's W rows are features nw0 .. nw0 + TN*16 - 1 in order, so
+//      acc[a][j][r] <-> token mrow0 + a*16 + l15, feature nw0 + j*16 + g*4 + r  (MFMA D: column = l15, rows = g*4 + r)
+template <int TM, int TN, int EPI, int WN>
+NTTS_D void gemm_epilogue_nat(const GemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0, int nw0, int wn, int nb) {
+    const int lane = lane_id();
+    const int g = lane >> 4, l15 = lane & 15;
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const int m = mrow0 + a * 16 + l15;
+        const bool mok = m < p.M;
+        if constexpr (EPI == EPI_SILU_MUL) {
+            // packed rows (backbone.cpp gu_map): every 16-row group = 8 gate rows, then the 8 up rows of the same features:
+            // lanes g = 0, 1 hold gate rows 0-3 / 4-7 of block j, lanes g = 2, 3 the matching up rows (as in gemv.h)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                float up[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) up[r] = shfl_xor(acc[a][j][r], 32);
+                const int n16 = nw0 + j * 16;                       // first packed row of this 16-row group
+                if (g < 2 && mok && n16 + 16 <= p.N) {
+                    alignas(8) bf16_t o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float gt = rbf(acc[a][j][r]), u = rbf(up[r]);   // gate_proj / up_proj outputs (bf16)
+                        o[r] = f2bf(rbf(silu_fast(gt)) * u);                 // act_fn output (bf16), product (bf16)
+                    }
+                    *(u32x2*)((bf16_t*)p.out + (long)m * p.ldo + (n16 >> 1) + g * 4) = *(u32x2*)&o[0];
+                }
+            }
+        } else if constexpr (EPI == EPI_ARGMAX) {
+            float best = -INFINITY;
+            int bidx = 0x7fffffff;
+            const int meos = (mok && p.mask_eos) ? p.mask_eos[m] : 0;   // eos id + 1, or 0
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                alignas(8) bf16_t lo[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = nw0 + j * 16 + g * 4 + r;
+                    float v = rbf(acc[a][j][r]);                  // lm_head output is bf16, then .float()
+                    if (n == meos - 1) v = -INFINITY;
+                    lo[r] = f2bf(v);
+                    if (n < p.N) {
+                        if (mok && p.logits) p.logits[(long)m * p.ld_logits + n] = v;
+                        if (v > best) { best = v; bidx = n; }      // ascending n + strict '>' = first max wins
+                    }
+                }
+                if (p.logits_bf16 && mok) {
+                    const int n4 = nw0 + j * 16 + g * 4;
+                    bf16_t* dst = p.logits_bf16 + (long)m * p.ld_logits_bf16 + n4;
+                    if (n4 + 4 <= p.N) *(u32x2*)dst = *(u32x2*)&lo[0];
+                    else for (int e = 0; e < 4; ++e) if (n4 + e < p.N) dst[e] = lo[e];
+                }
+            }
+#pragma unroll
+            for (int sh = 16; sh <= 32; sh <<= 1) {
+                const float ov = shfl_xor(best, sh);
+                const int oi = shfl_xor(bidx, sh);
+                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+            }
+            if (mok && g == 0) {
+                const long pi = (long)m * p.part_stride + nb * WN + wn;
+                p.part_val[pi] = best;
+                p.part_idx[pi] = bidx;
+            }
+        } else {
+            static_assert(EPI == EPI_ARGMAX || EPI == EPI_SILU_MUL, "epilogues of the natural-order tiles");
+        }
+    }
+}
+
 // ABL (micro-benchmark ablation, always 0 in the product): 1 = no LDS reads / MFMA, 2 = no LDS-DMA, 4 = no stores
 // BK = K extent of one ring slot (64 or 32).  A 256 x 256 block moves 64 KB per 64-wide K tile and one LDS-DMA round
 // trip takes ~1.25 us whatever else the CU does, so a 2-slot ring of 64-wide tiles (all 128 KB a CU can spare) caps the
@@ -322,19 +393,30 @@ NTTS_D void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][4], int mrow0, int
 // LDS row is still one 128-byte line, now 128 k-values instead of 64 -- so the ring, the DMA pieces and the swizzle are
 // shared; a lane's 16-byte fragment read holds TWO 8-byte MFMA operands (the low and the high 8 of its 16 k-values; A and B
 // use the same split, so the k order is consistent).  Half the weight AND activation bytes through the per-CU load path.
-template <int WM, int WN, int TM, int EPI, int NS, int ABL = 0, int BK = 64, bool WNT = false, bool F8 = false>
+// TN: 16-column MFMA blocks per wave (the wave tile is TM*16 rows x TN*16 columns).  TN = 4 is the family described above
+// (a lane owns 16 consecutive output features).  TN != 4 exists for the two decode GEMMs whose GRID, not whose tile, was the
+// problem (EPI_ARGMAX / EPI_SILU_MUL only; gemm_epilogue_nat): the lm_head's 850 tiles of 256 x 256 are 3.32 rounds of the 256
+// CUs -- the fourth round runs 82 tiles on an otherwise idle chip -- while 756 tiles of 256 x 288 are 2.95; gate/up's 152 tiles
+// of 128 x 128 leave 104 CUs idle, 244 tiles of 128 x 80 do not and pull 19 % fewer bytes through each CU's load path.  Their
+// W rows sit in LDS in natural order (LDS row q <-> feature n0 + q), the loader may be uneven (NINST % NW != 0: the surplus
+// instruction slots of the last waves are skipped, and the counted waits use each wave's own count).
+template <int WM, int WN, int TM, int EPI, int NS, int ABL = 0, int BK = 64, bool WNT = false, bool F8 = false, int TN = 4>
 NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     static_assert(BK == 64 || BK == 32, "ring slot K extent");
     static_assert(!F8 || BK == 64, "fp8: one ring slot = 128-byte rows");
+    static_assert(TN == 4 || ((EPI == EPI_ARGMAX || EPI == EPI_SILU_MUL) && !F8 && BK == 64), "natural-order tiles: lm_head / gate-up, bf16");
     constexpr int ESZ = F8 ? 1 : 2;            // bytes per operand element
-    constexpr int BM = WM * TM * 16, BN = WN * 64, NW = WM * WN;
+    constexpr int CW = TN * 16;                // output columns per wave
+    constexpr int BM = WM * TM * 16, BN = WN * CW, NW = WM * WN;
     constexpr int ROWS = BM + BN;              // LDS rows per buffer, BK bf16 each
     constexpr int KC = BK / 8;                 // 16-byte chunks per row
     constexpr int RPI = 64 / KC;               // rows one wave-instruction (64 lanes x 16 B = 1 KB) brings in
+    static_assert(ROWS % RPI == 0, "whole loader instructions");
     constexpr int NINST = ROWS / RPI;          // wave-instructions per slot
     constexpr int SPT = 64 / BK;               // ring slots per 64-wide K tile (GemmArgs counts K in tiles of 64)
-    static_assert(NINST % NW == 0, "loader split");
-    constexpr int PER_WAVE = NINST / NW;
+    static_assert(TN != 4 || NINST % NW == 0, "loader split");
+    constexpr int PER_WAVE = (NINST + NW - 1) / NW;
+    constexpr bool EVEN = NINST % NW == 0;     // every wave issues PER_WAVE instructions per slot (else the last waves issue one fewer)
     static_assert(NS >= 2 && (NS - 2) * PER_WAVE <= 63, "vmcnt range");
     NTTS_SHARED bf16_t lds[NS * ROWS * BK];
     // bank-conflict-free ds_read_b128: 16 lanes read 16 consecutive rows; XOR the 16-byte chunk index with row bits so the
@@ -366,7 +448,7 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     const char* src[PER_WAVE];                          // byte addresses (an operand element is ESZ bytes)
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
-        const int inst = wave + i * NW;
+        const int inst = (EVEN || wave + i * NW < NINST) ? wave + i * NW : 0;   // (a surplus slot's address is never used)
         const int rho = inst * RPI + lane / KC;          // LDS row
         const int c = (lane % KC) ^ swz(rho);            // logical 16-byte chunk stored at physical lane % KC
         if (rho < BM) {
@@ -376,7 +458,7 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         } else {
             const int q = rho - BM;                      // tile-major W row: q = wq*64 + j*16 + i16
             const int wq = q >> 6, j = (q >> 4) & 3, i16 = q & 15;
-            int n = n0 + wq * 64 + (i16 >> 2) * 16 + j * 4 + (i16 & 3);
+            int n = TN == 4 ? n0 + wq * 64 + (i16 >> 2) * 16 + j * 4 + (i16 & 3) : n0 + q;   // (TN != 4: natural order)
             if (n > p.N - 1) n = p.N - 1;
             src[i] = p.w_tile_major ? (const char*)p.W + (long)(n >> 6) * 64 * p.K * ESZ + (n & 63) * 128 + c * 16
                                     : (const char*)p.W + (long)n * p.ldw * ESZ + c * 16;
@@ -389,6 +471,7 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int i = 0; i < PER_WAVE; ++i) {
             const int inst = wave + i * NW;
+            if (!EVEN && inst >= NINST) continue;          // (wave-uniform) surplus slot of an uneven split
             const bool is_w = (inst * RPI) >= BM;          // this instruction's rows are W rows (wave-uniform)
             const char* g = src[i] + (long)(kt0 + kt) * (is_w ? wstep : xstep);
             bf16_t* l = lds + buf * (ROWS * BK) + inst * 512;
@@ -396,14 +479,14 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         }
     };
 
-    f32x4 acc[TM][4];
+    f32x4 acc[TM][TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TN; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // ---- fragment read offsets (elements), swizzle involution on the read side
-    int xoff[TM], woff[4], xsw[TM], wsw[4];
+    int xoff[TM], woff[TN], xsw[TM], wsw[TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
         const int rho = wm * TM * 16 + a * 16 + l15;
@@ -411,11 +494,13 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         xsw[a] = swz(rho);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int rho = BM + wn * 64 + j * 16 + l15;
+    for (int j = 0; j < TN; ++j) {
+        const int rho = BM + wn * CW + j * 16 + l15;
         woff[j] = rho * BK;
         wsw[j] = swz(rho);
     }
+    // this wave's LDS-DMA instructions per slot (wave-uniform): the counted waits retire a wave's OWN requests
+    const bool full_share = EVEN || wave + (PER_WAVE - 1) * NW < NINST;
 
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
@@ -424,7 +509,9 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt must have landed; tiles kt+1 .. kt+NS-2 may stay in flight (none are left to wait on
         // at the tail, where the plain drain costs nothing extra)
-        if (kt + NS - 2 < nk) wait_vmem_le<(NS - 2) * PER_WAVE>(); else wait_vmem();
+        if (kt + NS - 2 < nk) {
+            if (full_share) wait_vmem_le<(NS - 2) * PER_WAVE>(); else wait_vmem_le<(NS - 2) * (PER_WAVE - 1)>();
+        } else wait_vmem();
         sync_keep_dma();  // tile kt landed for every wave; everyone is done reading the slot refilled below
         if (kt + NS - 1 < nk) stage(kt + NS - 1, buf == 0 ? NS - 1 : buf - 1);
         const bf16_t* base = lds + buf * (ROWS * BK);
@@ -433,15 +520,15 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             const int c = ks * 4 + g;
-            bf16x8 xb[TM], wa[4];
+            bf16x8 xb[TM], wa[TN];
 #pragma unroll
             for (int a = 0; a < TM; ++a) xb[a] = ld16<bf16x8>(base + xoff[a] + ((c ^ xsw[a]) << 3));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wa[j] = ld16<bf16x8>(base + woff[j] + ((c ^ wsw[j]) << 3));
+            for (int j = 0; j < TN; ++j) wa[j] = ld16<bf16x8>(base + woff[j] + ((c ^ wsw[j]) << 3));
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < TN; ++j) {
                     if constexpr (F8) {
                         const i64x2 w2 = __builtin_bit_cast(i64x2, wa[j]), x2 = __builtin_bit_cast(i64x2, xb[a]);
                         acc[a][j] = mfma16_fp8(w2[0], x2[0], acc[a][j]);
@@ -456,7 +543,8 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     if constexpr (ABL & 4) {
         if (acc[0][0][0] != 12345.678f) return;   // keeps the accumulators live without storing
     }
-    gemm_epilogue<TM, EPI, WN, F8>(p, acc, m0 + wm * TM * 16, n0, wn, nb, split);
+    if constexpr (TN == 4) gemm_epilogue<TM, EPI, WN, F8>(p, acc, m0 + wm * TM * 16, n0, wn, nb, split);
+    else gemm_epilogue_nat<TM, TN, EPI, WN>(p, acc, m0 + wm * TM * 16, n0 + wn * CW, wn, nb);
 }
 
 
@@ -482,9 +570,9 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 // ------------------------------------------------------------------------------------------------
 struct GemmShape { int BM, BN, WN; };
 
-template <int WM, int WN, int TM, int EPI, int NS = 2, int ABL = 0, int BK = 64, bool WNT = false, bool F8 = false>
+template <int WM, int WN, int TM, int EPI, int NS = 2, int ABL = 0, int BK = 64, bool WNT = false, bool F8 = false, int TN = 4>
 inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
-    constexpr int BM = WM * TM * 16, BN = WN * 64;
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     p.mblocks = (p.M + BM - 1) / BM;
     p.nblocks = (p.N + BN - 1) / BN;
     const int ktiles = p.K / (F8 ? 128 : 64);
@@ -497,11 +585,11 @@ inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
         p.xcd_nsplit = nsplit;
         const int xps = 8 / nsplit, tiles = p.mblocks * p.nblocks;
         p.xcd_per = (tiles + xps - 1) / xps;
-        NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT, F8>), dim3(8 * p.xcd_per), dim3(WM * WN * 64), s, p);
+        NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT, F8, TN>), dim3(8 * p.xcd_per), dim3(WM * WN * 64), s, p);
         return;
     }
     p.xcd_nsplit = 0;
-    NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT, F8>), dim3(p.mblocks * p.nblocks, nsplit), dim3(WM * WN * 64), s, p);
+    NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT, F8, TN>), dim3(p.mblocks * p.nblocks, nsplit), dim3(WM * WN * 64), s, p);
 }
 
 // tile families:  XL = 256x256 (4x4 waves = 1024 threads, 64x64 per wave, 128 KB LDS) -- big-M GEMMs (prefill, codec):

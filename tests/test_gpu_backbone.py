@@ -45,6 +45,30 @@ def test_small_peaked_exact(lib, graph, monkeypatch):
         assert fin and ids == z[f"bf16_ids_{u}"].tolist(), (u, ids, z[f"bf16_ids_{u}"].tolist())
 
 
+@pytest.mark.parametrize("knobs", [
+    {"NTTS_HEAD_XL": "1", "NTTS_GU_TILE": "1", "NTTS_PF_LPT": "0"},      # the TN = 4 tiles (256 x 256 lm_head, 128 x 128 gate/up), prompt-order attention tiles
+    {"NTTS_HEAD_XL": "4", "NTTS_GU_TILE": "3"},                          # natural-order tiles: 256 x 288 / 12 waves, 128 x 80 / 4 waves
+    {"NTTS_HEAD_XL": "5", "NTTS_GU_TILE": "4", "NTTS_W_NT": "0"},        # 256 x 320 / 8 waves, 128 x 80 / 8 waves
+    {"NTTS_HEAD_XL": "6", "NTTS_GU_TILE": "5", "NTTS_W_TILE_MAJOR": "0"}])   # 256 x 288 / 8 waves, 128 x 96 / 8 waves, row-major weights
+def test_small_peaked_exact_tile_variants(lib, knobs, monkeypatch):
+    """Every lm_head / gate-up tile the large-batch decode path can be switched to (gemm.h: TN = 4 and the natural-order
+    tiles with their uneven loader splits and partial last tiles), forced on at batch 2: free-running greedy ids bit-identical to HF's."""
+    monkeypatch.setenv("NTTS_SMALL_BATCH", "0")
+    monkeypatch.setenv("NTTS_HEAD_LARGE", "1")
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    z, cfg, w = load_fixture("backbone_small_peaked")
+    S, N, eos = int(z["s_len"]), int(z["n_new"]), int(z["eos"])
+    eng = make_engine(cfg, w, lib, max_batch=2, max_context=160, bf16_upload=True)
+    samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
+    eng.prefill([br.synthetic_prompt(cfg, 0, S), br.synthetic_prompt(cfg, 1, S)], [0, 1], [samp, samp])
+    eng.decode(N - 1)
+    for u in (0, 1):
+        ids, fin = eng.read(u)
+        assert fin and ids == z[f"bf16_ids_{u}"].tolist(), (knobs, u, ids, z[f"bf16_ids_{u}"].tolist())
+    eng.close()
+
+
 def test_prefill_on_cu_masked_side_stream(lib):
     """ntts_backbone_set_prefill_cu_mask: the prompt pass on a side stream restricted to 64 of the 256 CUs (ordered before and
     behind the engine's own stream) and the decode steps that follow give HF's ids; two prefills in a row, mask removed again."""
