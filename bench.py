@@ -111,7 +111,8 @@ ROCPROF_SYMBOLS = [   # rocprofv3 symbol prefix -> the step's logical kernels it
     ("attn_decode_kernel<", ["attn_decode_kernel"]),
     ("gemm_kernel<4, 1, 1, 2, 4,", ["gemm_qkv", "gemm_o_proj_splitk", "gemm_down_splitk"]),
     ("gemm_kernel<4, 2, 2, 1, 3,", ["gemm_gate_up_silu"]),
-    ("gemm_kernel<4, 4, 4, 3, 2, 0, 64, true", ["gemm_lm_head_argmax"]),
+    ("gemm_kernel<4, 3, 4, 3, 2, 0, 64, true", ["gemm_lm_head_argmax"]),     # 256 x 288 natural-order tile (NTTS_HEAD_XL=4, the default)
+    ("gemm_kernel<4, 4, 4, 3, 2, 0, 64, true", ["gemm_lm_head_argmax"]),     # 256 x 256 tile (NTTS_HEAD_XL=1)
     ("add_rmsnorm_row_kernel", ["add_rmsnorm_kernel"]),
 ]
 

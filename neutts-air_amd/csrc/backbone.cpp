@@ -99,15 +99,17 @@ struct ntts_backbone {
     int st_qkv = 4, st_o = 4, st_gu = 3, st_d = 4;   // LDS ring depth of each skinny decode GEMM
     int head_stages = 2, l_stages = 2, pf_gh = 7, attn_depth = 1, attn_var = 1, gu_tile = 0;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
     bool gu_large = false, head_large = true, pf_attn_simple = false, use_xl = true;
-    int head_xl = 0;        // lm_head tile at large batch: 0 = 128 x 128, 1 = 256 x 256 (16 waves); 4 / 5 / 6 = the natural-order tiles
-                            // that cover the vocabulary in THREE rounds of the 256 CUs instead of 3.32 (gemm.h TN): 256 x 288 with 12
-                            // waves, 256 x 320 with 8, 256 x 288 with 8.  128 x 256 and 256 x 128 tiles (8 waves, two workgroups per
-                            // CU) were measured: 168 / 158 vs 126 us (profiles/r02g_sweep_head_tiles.log)
+    int head_xl = 0;        // lm_head tile at large batch: 0 = 128 x 128, 1 = 256 x 256 (16 waves), 4 = 256 x 288 (12 waves, natural-order
+                            // tile, gemm.h TN): 756 tiles = 2.95 rounds of the 256 CUs instead of 850 = 3.32 (the fourth round ran 82 tiles
+                            // on an otherwise idle chip): 129.5 -> 118.7-123.8 us (profiles/r02k_sweep_lpt_head_gu_tiles.log; 256 x 320 with 8
+                            // waves: 138.6, 256 x 288 with 8 waves: 130.5 -- measured and removed).  128 x 256 and 256 x 128 tiles (8 waves, two
+                            // workgroups per CU) were measured earlier: 168 / 158 vs 126 us (profiles/r02g_sweep_head_tiles.log)
     // non-temporal policy on the lm_head's weight stream (NTTS_W_NT).  Measured at batch 256
     // (profiles/r02a_sweep_nt_graphsteps.jsonl): lm_head 136.6 -> 132.3 us; on the LDS-DMA rings of the skinny layer GEMMs the
     // same policy was SLOWER (qkv 5.78 -> 5.96, down 9.95 -> 10.54 us; step 1.679 -> 1.718 ms) and is not offered there
     int w_nt = 1;
     bool pf_rope_vec = true;   // prefill RoPE + KV write with 16-byte accesses (rope_kv_write_vec_kernel)
+    bool pf_qkv_nat = true;    // prefill QKV on the natural-order 256 x 288 tile when N is a multiple of 288 but not of 256
     bool pf_lpt = true;        // prefill attention work list sorted by descending causal depth (longest tiles dispatched first)
     bool pf_resid = true;   // prefill: residual add in the o_proj / down_proj epilogue (EPI_RESID) instead of in the norm pass
     // Split-K decode GEMMs: XCD-aware slice placement (gemm.h GemmArgs::xcd_nsplit; NTTS_XCD_SPLIT bit 0 qkv, 1 o_proj, 2 down).
@@ -363,10 +365,12 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->pf_resid = env_int("NTTS_PF_RESID", 1) != 0;
     e->pf_rope_vec = env_int("NTTS_PF_ROPE_VEC", 1) != 0;
     e->pf_lpt = env_int("NTTS_PF_LPT", 1) != 0;
+    e->pf_qkv_nat = env_int("NTTS_PF_QKV_NAT", 1) != 0;
     e->xcd_split = env_int("NTTS_XCD_SPLIT", 5);
     e->use_xl = env_int("NTTS_XL", 1) != 0;
-    e->head_xl = env_int("NTTS_HEAD_XL", B > 128 ? 1 : 0);
-    if (e->fp8 && e->head_xl > 1) e->head_xl = 1;          // (the natural-order tiles are bf16 only)
+    e->head_xl = env_int("NTTS_HEAD_XL", B > 128 ? (e->fp8 ? 1 : 4) : 0);
+    if (e->head_xl != 0 && e->head_xl != 4) e->head_xl = 1;
+    if (e->fp8 && e->head_xl == 4) e->head_xl = 1;          // (the natural-order tile is bf16 only)
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e->pf_gh = env_int("NTTS_PF_GH", 7);   // all 7 heads of a GQA group in one pass: K/V pages staged once (prefill chunk 35.0 -> 33.4 ms)
     e->attn_depth = env_int("NTTS_ATTN_DEPTH", 1);
@@ -386,8 +390,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     if (e->sks_o > max_slabs) e->sks_o = max_slabs;
     if (e->sks_d > max_slabs) e->sks_d = max_slabs;
     e->attn_depth_small = env_int("NTTS_ATTN_DEPTH_SMALL", 2);
-    e->n_part = e->small ? V / 16 : !e->head_large ? (V + 63) / 64 : e->head_xl == 4 ? ((V + 287) / 288) * 3 : e->head_xl == 5 ? ((V + 319) / 320) * 4 :
-                e->head_xl == 6 ? ((V + 287) / 288) * 2 : e->head_xl ? ((V + 255) / 256) * 4 : ((V + 127) / 128) * 2;
+    e->n_part = e->small ? V / 16 : !e->head_large ? (V + 63) / 64 : e->head_xl == 4 ? ((V + 287) / 288) * 3 : e->head_xl ? ((V + 255) / 256) * 4 : ((V + 127) / 128) * 2;
     CR_HIP(hipMalloc((void**)&e->h_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->xn_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->qkv_dec, (size_t)B * e->NQKV * 2));
@@ -782,6 +785,11 @@ static void gemm_large(ntts_backbone* e, const GemmArgs& a, hipStream_t st) {
         return;
     }
     if (e->use_xl && a.M >= 1024 && a.N >= 256) {
+        // prefill QKV (N = 1152 = 4.5 x 256): the 256 x 256 tile needs 5 column blocks, the last one half empty -- 625 tiles
+        // = 2.44 rounds of the CUs per 32 000-token chunk; the natural-order 256 x 288 tile needs 4: 500 tiles = 1.95 rounds
+        if constexpr (EPI == EPI_BF16) {
+            if (e->pf_qkv_nat && a.N % 288 == 0 && a.N % 256 != 0) { gemm_launch<4, 3, 4, EPI_BF16, 2, 0, 64, false, false, 6>(a, 1, st); return; }
+        }
         NTTS_GEMM_XL(EPI, a, 1, st);
         return;
     }
@@ -801,11 +809,9 @@ static void k_lm_head(ntts_backbone* e, bool keep_logits) {
     a.logits = keep_logits ? e->logits : nullptr; a.ld_logits = V;
     a.logits_bf16 = (keep_logits && e->n_sampling > 0) ? e->logits_bf16 : nullptr; a.ld_logits_bf16 = e->ldl;
     if (!e->head_large) { gemm_skinny<EPI_ARGMAX>(4, a, 1, e->stream); return; }
-    if (e->head_xl >= 4) {   // natural-order tiles (bf16): three rounds of the CUs
-        const bool nt = (e->w_nt & 1) != 0;
-        if (e->head_xl == 4) { if (nt) gemm_launch<4, 3, 4, EPI_ARGMAX, 2, 0, 64, true, false, 6>(a, 1, e->stream); else gemm_launch<4, 3, 4, EPI_ARGMAX, 2, 0, 64, false, false, 6>(a, 1, e->stream); }
-        else if (e->head_xl == 5) { if (nt) gemm_launch<2, 4, 8, EPI_ARGMAX, 2, 0, 64, true, false, 5>(a, 1, e->stream); else gemm_launch<2, 4, 8, EPI_ARGMAX, 2, 0, 64, false, false, 5>(a, 1, e->stream); }
-        else { if (nt) gemm_launch<4, 2, 4, EPI_ARGMAX, 2, 0, 64, true, false, 9>(a, 1, e->stream); else gemm_launch<4, 2, 4, EPI_ARGMAX, 2, 0, 64, false, false, 9>(a, 1, e->stream); }
+    if (e->head_xl == 4) {   // natural-order 256 x 288 tile (bf16): three rounds of the CUs
+        if (e->w_nt & 1) gemm_launch<4, 3, 4, EPI_ARGMAX, 2, 0, 64, true, false, 6>(a, 1, e->stream);
+        else gemm_launch<4, 3, 4, EPI_ARGMAX, 2, 0, 64, false, false, 6>(a, 1, e->stream);
         return;
     }
     if (e->head_xl) {
@@ -882,10 +888,9 @@ static void k_gate_up(ntts_backbone* e, int i) {
     }
     // (a 4-slot ring on the 128 x 128 tile, 96 KB in flight per CU instead of 64: 13.3 vs 13.4 us -- ring depth is not what
     //  bounds this kernel; profiles/r02h_sweep_gate_up_ring.log)
-    if (e->gu_tile == 3) gemm_launch<4, 1, 2, EPI_SILU_MUL, 3, 0, 64, false, false, 5>(gu, 1, e->stream);        // 128 x 80, 4 waves: 244 workgroups
-    else if (e->gu_tile == 4) gemm_launch<8, 1, 1, EPI_SILU_MUL, 3, 0, 64, false, false, 5>(gu, 1, e->stream);   // 128 x 80, 8 waves
-    else if (e->gu_tile == 5) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3, 0, 64, false, false, 3>(gu, 1, e->stream);   // 128 x 96, 8 waves: 204 workgroups
-    else if (e->gu_tile == 1) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);        // 128 x 128, 8 waves
+    // (natural-order gate/up tiles that use more CUs -- 128 x 80 as 244 workgroups of 4 or 8 waves, 128 x 96 as 204 -- measured
+    //  15.5 / 13.7 / 14.1 vs 13.5 us and were removed: profiles/r02k_sweep_lpt_head_gu_tiles.log)
+    if (e->gu_tile == 1) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);        // 128 x 128, 8 waves
     else if (e->gu_tile == 2) gemm_launch<8, 1, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);   // 256 x 64, 8 waves
     else if (e->gu_large) gemm_large<EPI_SILU_MUL>(e, gu, e->stream);
     else gemm_skinny<EPI_SILU_MUL>(e->st_gu, gu, 1, e->stream);

@@ -20,6 +20,7 @@ extern "C" int ntts_k_gemm_bf16(const void* A, int64_t lda, const void* W, const
     else if (variant == 4) NTTS_GEMM_XL(EPI_BF16, a, 1, (hipStream_t)0);
     else if (variant == 5) gemm_launch<4, 4, 4, EPI_BF16, 4, 0, 32>(a, 1, (hipStream_t)0);   // XL tile, 4 ring slots of K = 32
     else if (variant == 6) gemm_launch<2, 2, 4, EPI_BF16, 3, 0, 32>(a, 1, (hipStream_t)0);   // L tile, 3 ring slots of K = 32
+    else if (variant == 7) gemm_launch<4, 3, 4, EPI_BF16, 2, 0, 64, false, false, 6>(a, 1, (hipStream_t)0);   // natural-order 256 x 288 tile, 12 waves (prefill QKV)
     else if (variant == 3) {  // split-K slabs reduced by the norm kernel (the decode o_proj / down_proj path)
         if (bias || (N % 16) || ldc != N) return NTTS_EINVAL;
         const int ks = 4, ns = gemm_nsplit(K, ks);

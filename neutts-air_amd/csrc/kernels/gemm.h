@@ -321,23 +321,17 @@ NTTS_D void gemm_epilogue_nat(const GemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0
     for (int a = 0; a < TM; ++a) {
         const int m = mrow0 + a * 16 + l15;
         const bool mok = m < p.M;
-        if constexpr (EPI == EPI_SILU_MUL) {
-            // packed rows (backbone.cpp gu_map): every 16-row group = 8 gate rows, then the 8 up rows of the same features:
-            // lanes g = 0, 1 hold gate rows 0-3 / 4-7 of block j, lanes g = 2, 3 the matching up rows (as in gemv.h)
+        if constexpr (EPI == EPI_BF16) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                float up[4];
+                const int n4 = nw0 + j * 16 + g * 4;
+                alignas(8) bf16_t o[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) up[r] = shfl_xor(acc[a][j][r], 32);
-                const int n16 = nw0 + j * 16;                       // first packed row of this 16-row group
-                if (g < 2 && mok && n16 + 16 <= p.N) {
-                    alignas(8) bf16_t o[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float gt = rbf(acc[a][j][r]), u = rbf(up[r]);   // gate_proj / up_proj outputs (bf16)
-                        o[r] = f2bf(rbf(silu_fast(gt)) * u);                 // act_fn output (bf16), product (bf16)
-                    }
-                    *(u32x2*)((bf16_t*)p.out + (long)m * p.ldo + (n16 >> 1) + g * 4) = *(u32x2*)&o[0];
+                for (int r = 0; r < 4; ++r) o[r] = f2bf(acc[a][j][r] + (n4 + r < p.N ? gemm_bias(p, n4 + r) : 0.f));
+                if (mok) {
+                    bf16_t* dst = (bf16_t*)p.out + (long)m * p.ldo + n4;
+                    if (n4 + 4 <= p.N) *(u32x2*)dst = *(u32x2*)&o[0];
+                    else for (int e = 0; e < 4; ++e) if (n4 + e < p.N) dst[e] = o[e];
                 }
             }
         } else if constexpr (EPI == EPI_ARGMAX) {
@@ -377,7 +371,7 @@ NTTS_D void gemm_epilogue_nat(const GemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0
                 p.part_idx[pi] = bidx;
             }
         } else {
-            static_assert(EPI == EPI_ARGMAX || EPI == EPI_SILU_MUL, "epilogues of the natural-order tiles");
+            static_assert(EPI == EPI_ARGMAX || EPI == EPI_BF16, "epilogues of the natural-order tile");
         }
     }
 }
@@ -394,17 +388,20 @@ NTTS_D void gemm_epilogue_nat(const GemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0
 // shared; a lane's 16-byte fragment read holds TWO 8-byte MFMA operands (the low and the high 8 of its 16 k-values; A and B
 // use the same split, so the k order is consistent).  Half the weight AND activation bytes through the per-CU load path.
 // TN: 16-column MFMA blocks per wave (the wave tile is TM*16 rows x TN*16 columns).  TN = 4 is the family described above
-// (a lane owns 16 consecutive output features).  TN != 4 exists for the two decode GEMMs whose GRID, not whose tile, was the
-// problem (EPI_ARGMAX / EPI_SILU_MUL only; gemm_epilogue_nat): the lm_head's 850 tiles of 256 x 256 are 3.32 rounds of the 256
-// CUs -- the fourth round runs 82 tiles on an otherwise idle chip -- while 756 tiles of 256 x 288 are 2.95; gate/up's 152 tiles
-// of 128 x 128 leave 104 CUs idle, 244 tiles of 128 x 80 do not and pull 19 % fewer bytes through each CU's load path.  Their
-// W rows sit in LDS in natural order (LDS row q <-> feature n0 + q), the loader may be uneven (NINST % NW != 0: the surplus
-// instruction slots of the last waves are skipped, and the counted waits use each wave's own count).
+// (a lane owns 16 consecutive output features).  TN != 4 exists for the decode lm_head, whose GRID, not whose tile, was the
+// problem (EPI_ARGMAX only; gemm_epilogue_nat): 850 tiles of 256 x 256 are 3.32 rounds of the 256 CUs -- the fourth round runs
+// 82 tiles on an otherwise idle chip -- while 756 tiles of 256 x 288 (WN = 3, TN = 6, 12 waves) are 2.95: 129.5 -> 118.7-123.8 us.
+// Not the 3 / 4 the round count promises: a tile's time follows its LDS-DMA bytes (X re-read from L2 + W from HBM come to
+// 6.1 TB/s chip-wide = 24 GB/s per CU for either tile), so the 288-column tile costs 40 us where the 256-column one cost 32.
+// The W rows sit in LDS in natural order (LDS row q <-> feature n0 + q), the loader may be uneven (NINST % NW != 0: the surplus
+// instruction slots of the last waves are skipped, and the counted waits use each wave's own count).  The same machinery on the
+// decode gate/up GEMM (128 x 80 as 244 workgroups instead of 128 x 128 as 152; 128 x 96 as 204) measured 13.7-15.5 vs 13.5 us
+// and was removed again (profiles/r02k_sweep_lpt_head_gu_tiles.log).
 template <int WM, int WN, int TM, int EPI, int NS, int ABL = 0, int BK = 64, bool WNT = false, bool F8 = false, int TN = 4>
 NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     static_assert(BK == 64 || BK == 32, "ring slot K extent");
     static_assert(!F8 || BK == 64, "fp8: one ring slot = 128-byte rows");
-    static_assert(TN == 4 || ((EPI == EPI_ARGMAX || EPI == EPI_SILU_MUL) && !F8 && BK == 64), "natural-order tiles: lm_head / gate-up, bf16");
+    static_assert(TN == 4 || ((EPI == EPI_ARGMAX || EPI == EPI_BF16) && !F8 && BK == 64), "natural-order tile: lm_head / prefill QKV, bf16");
     constexpr int ESZ = F8 ? 1 : 2;            // bytes per operand element
     constexpr int CW = TN * 16;                // output columns per wave
     constexpr int BM = WM * TM * 16, BN = WN * CW, NW = WM * WN;

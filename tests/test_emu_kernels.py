@@ -35,6 +35,7 @@ GEMM_CASES = [  # (M, N, K, variant, bias)
     (300, 272, 192, 5, True),    # XL tile on the 4-slot ring of 32-wide K slices (64-byte LDS rows, other swizzle)
     (70, 200, 64, 5, False),     # ... a single 64-wide K tile = 2 slices, fewer than the ring holds
     (130, 144, 320, 6, True),    # L tile, 3-slot ring of 32-wide slices
+    (300, 328, 192, 7, True),    # natural-order 256 x 288 tile (12 waves, uneven loader split), ragged M, N = 1 tile + 40 columns
 ]
 
 

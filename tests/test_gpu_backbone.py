@@ -46,13 +46,12 @@ def test_small_peaked_exact(lib, graph, monkeypatch):
 
 
 @pytest.mark.parametrize("knobs", [
-    {"NTTS_HEAD_XL": "1", "NTTS_GU_TILE": "1", "NTTS_PF_LPT": "0"},      # the TN = 4 tiles (256 x 256 lm_head, 128 x 128 gate/up), prompt-order attention tiles
-    {"NTTS_HEAD_XL": "4", "NTTS_GU_TILE": "3"},                          # natural-order tiles: 256 x 288 / 12 waves, 128 x 80 / 4 waves
-    {"NTTS_HEAD_XL": "5", "NTTS_GU_TILE": "4", "NTTS_W_NT": "0"},        # 256 x 320 / 8 waves, 128 x 80 / 8 waves
-    {"NTTS_HEAD_XL": "6", "NTTS_GU_TILE": "5", "NTTS_W_TILE_MAJOR": "0"}])   # 256 x 288 / 8 waves, 128 x 96 / 8 waves, row-major weights
+    {"NTTS_HEAD_XL": "1", "NTTS_PF_LPT": "0"},                            # the 256 x 256 lm_head tile, prompt-order attention tiles
+    {"NTTS_HEAD_XL": "4"},                                               # natural-order 256 x 288 tile, 12 waves (the batch-256 default)
+    {"NTTS_HEAD_XL": "4", "NTTS_W_NT": "0", "NTTS_W_TILE_MAJOR": "0"}])  # ... default cache policy, row-major weights
 def test_small_peaked_exact_tile_variants(lib, knobs, monkeypatch):
-    """Every lm_head / gate-up tile the large-batch decode path can be switched to (gemm.h: TN = 4 and the natural-order
-    tiles with their uneven loader splits and partial last tiles), forced on at batch 2: free-running greedy ids bit-identical to HF's."""
+    """Every lm_head tile the large-batch decode path can be switched to (gemm.h: TN = 4 and the natural-order tile with its
+    uneven loader split and partial last tile), forced on at batch 2: free-running greedy ids bit-identical to HF's."""
     monkeypatch.setenv("NTTS_SMALL_BATCH", "0")
     monkeypatch.setenv("NTTS_HEAD_LARGE", "1")
     for k, v in knobs.items():
