@@ -257,6 +257,10 @@ NTTS_KERNEL(256) void attn_prefill_kernel(AttnPrefillArgs p) {
 //   LDS images (lane-linear LDS-DMA, swizzled on the SOURCE side):
 //     K   page [32 keys][128 B]: 16-B chunk c of key r stored at chunk c ^ (r & 7)        (ds_read_b128 conflict-free)
 //     V^T page [64 d][64 B]:     16-B unit  u of row d stored at unit  u ^ ((d >> 2) & 3) (ds_read_b128 conflict-free)
+// Measured on MI355X and removed (profiles/r02k_sweep_pf_attn_8waves.log): the 7 heads split 4 + 3 over the two halves of an
+// 8-wave workgroup (231 VGPRs, two waves per SIMD instead of one at 256 + 138 AGPRs; pages still staged once): prefill chunk
+// 28.23-28.29 vs 28.31-28.42 ms -- the kernel is bound by the softmax arithmetic itself (two exp per score: the eager contract
+// needs the global denominator before P is rounded), not by what one wave per SIMD cannot hide.
 template <int GH>
 NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
     NTTS_SHARED bf16_t lds[2 * 2 * kPage * 64];   // [buf][K | V^T] 4 KB each
