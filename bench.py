@@ -241,7 +241,7 @@ def main():
     elif codec is not None:
         codec.load_state_dict({k: v.numpy() for k, v in cw.items()})
     if os.environ.get("NTTS_BENCH_PRIME", "1") != "0" and not cont:
-        eng.warm_up(int(os.environ.get("NTTS_BENCH_PRIME_STEPS", "2")))   # start-up: graph capture + runtime pools, before any request
+        eng.warm_up(int(os.environ.get("NTTS_BENCH_PRIME_STEPS", str(max(2, N - 1)))))   # start-up: graph capture + runtime pools (sized by one decode call of real length), before any request
     log(f"[bench] rank {rank}: weights ready in {time.time() - t0:.1f}s")
 
     eos = cfg.vocab_size - 1

@@ -358,6 +358,14 @@ class BackboneEngine:
         self.sync()
         self.release(0)
         self.sync()
+        # The runtime sizes its pools by the number of graph replays that were ever queued before a synchronisation: the first
+        # call AFTER the first long decode call pays for it once (43 ms on the host, measured in bench.py's step walls).  With
+        # `decode_steps` as long as a real decode call, a second throw-away prompt pass absorbs that too.
+        if decode_steps > 8:
+            self.prefill([[1 % self.vocab_size]], [0], [Sampling(max_length=3, min_new_tokens=1, eos_token_id=0, do_sample=False)])
+            self.sync()
+            self.release(0)
+            self.sync()
 
     def set_prefill_cu_mask(self, mask_words: Optional[Sequence[int]]):
         """Run this engine's prompt passes on a side stream restricted to the CUs of `mask_words` (32-bit words, bit i of word w =
