@@ -109,6 +109,7 @@ struct ntts_backbone {
     // same policy was SLOWER (qkv 5.78 -> 5.96, down 9.95 -> 10.54 us; step 1.679 -> 1.718 ms) and is not offered there
     int w_nt = 1;
     bool pf_rope_vec = true;   // prefill RoPE + KV write with 16-byte accesses (rope_kv_write_vec_kernel)
+    int xl_min_m = 1024;       // rows from which the big-M GEMMs take the 256-row tiles (tests lower it: NTTS_XL_MIN_M)
     bool pf_qkv_nat = true;    // prefill QKV on the natural-order 256 x 288 tile when N is a multiple of 288 but not of 256
     bool pf_lpt = true;        // prefill attention work list sorted by descending causal depth (longest tiles dispatched first)
     bool pf_resid = true;   // prefill: residual add in the o_proj / down_proj epilogue (EPI_RESID) instead of in the norm pass
@@ -366,6 +367,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->pf_rope_vec = env_int("NTTS_PF_ROPE_VEC", 1) != 0;
     e->pf_lpt = env_int("NTTS_PF_LPT", 1) != 0;
     e->pf_qkv_nat = env_int("NTTS_PF_QKV_NAT", 1) != 0;
+    e->xl_min_m = env_int("NTTS_XL_MIN_M", 1024);
     e->xcd_split = env_int("NTTS_XCD_SPLIT", 5);
     e->use_xl = env_int("NTTS_XL", 1) != 0;
     e->head_xl = env_int("NTTS_HEAD_XL", B > 128 ? (e->fp8 ? 1 : 4) : 0);
@@ -780,11 +782,11 @@ static void gemm_skinny(int stages, const GemmArgs& a, int ks, hipStream_t st) {
 template <int EPI>
 static void gemm_large(ntts_backbone* e, const GemmArgs& a, hipStream_t st) {
     if (e->fp8) {
-        if (e->use_xl && a.M >= 1024 && a.N >= 256) gemm_launch<4, 4, 4, EPI, 2, 0, 64, false, true>(a, 1, st);
+        if (e->use_xl && a.M >= e->xl_min_m && a.N >= 256) gemm_launch<4, 4, 4, EPI, 2, 0, 64, false, true>(a, 1, st);
         else gemm_launch<2, 2, 4, EPI, 2, 0, 64, false, true>(a, 1, st);
         return;
     }
-    if (e->use_xl && a.M >= 1024 && a.N >= 256) {
+    if (e->use_xl && a.M >= e->xl_min_m && a.N >= 256) {
         // prefill QKV (N = 1152 = 4.5 x 256): the 256 x 256 tile needs 5 column blocks, the last one half empty -- 625 tiles
         // = 2.44 rounds of the CUs per 32 000-token chunk; the natural-order 256 x 288 tile needs 4: 500 tiles = 1.95 rounds
         if constexpr (EPI == EPI_BF16) {

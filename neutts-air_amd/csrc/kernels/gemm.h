@@ -396,7 +396,11 @@ NTTS_D void gemm_epilogue_nat(const GemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0
 // The W rows sit in LDS in natural order (LDS row q <-> feature n0 + q), the loader may be uneven (NINST % NW != 0: the surplus
 // instruction slots of the last waves are skipped, and the counted waits use each wave's own count).  The same machinery on the
 // decode gate/up GEMM (128 x 80 as 244 workgroups instead of 128 x 128 as 152; 128 x 96 as 204) measured 13.7-15.5 vs 13.5 us
-// and was removed again (profiles/r02k_sweep_lpt_head_gu_tiles.log).
+// and was removed again (profiles/r02k_sweep_lpt_head_gu_tiles.log), and so was the prefill gate/up GEMM on the 256 x 288 tile
+// (34 column blocks instead of 38: 16.6 rounds instead of 18.55 per chunk, but the prompt pass got 12 % SLOWER, 32.4 vs 29.0 ms
+// per chunk: in natural order the SiLU * up epilogue runs on half the lanes -- gate rows in lanes g < 2, their up rows in g >= 2
+// -- and stores 8-byte pieces; profiles/r02k_sweep_pf_gu_nat.log).  The prefill QKV GEMM keeps it (N = 1152 = 4 x 288: 500 tiles
+// instead of 625 with every fifth half empty; 133 -> 98 us per launch).
 template <int WM, int WN, int TM, int EPI, int NS, int ABL = 0, int BK = 64, bool WNT = false, bool F8 = false, int TN = 4>
 NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     static_assert(BK == 64 || BK == 32, "ring slot K extent");

@@ -32,6 +32,8 @@ def _run(eng, cfg, prompts, n_new):
 def test_untied_head_and_no_bias_match_oracle(lib, small_batch, monkeypatch):
     """tie_word_embeddings = 0 (a separate lm_head.weight) and attention_bias = 0, on both decode paths."""
     monkeypatch.setenv("NTTS_SMALL_BATCH", small_batch)
+    if small_batch == "0":   # ... and the prompt pass on the 256-row tiles: QKV (576 = 2 x 288 columns) and gate/up on the natural-order tile
+        monkeypatch.setenv("NTTS_XL_MIN_M", "16")
     cfg = br.BackboneConfig(vocab_size=640, hidden_size=448, intermediate_size=1216, num_layers=2, num_heads=7, num_kv_heads=1,
                             attention_bias=False, tie_word_embeddings=False)
     w = br.make_weights(cfg, 17, peak_sigma=0.5)
