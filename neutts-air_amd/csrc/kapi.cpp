@@ -108,6 +108,15 @@ NTTS_KERNEL(256) void prefetch_kernel(const u32x4* src, long n16, int* sink) {
     if (acc == 0x12345678u && sink) *sink = 1;
 }
 
+NTTS_KERNEL(256) void random_fill_kernel(bf16_t* dst, long n, unsigned int seed) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        unsigned int h = (unsigned int)i * 0x9e3779b1u + seed;
+        h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12; h *= 0x297a2d39u; h ^= h >> 15;
+        // sign + exponent 120 .. 127 (|v| in [2^-7, 2)) + 7 random mantissa bits: a wide spread of magnitudes, no inf / nan
+        dst[i] = (bf16_t)(((h & 1u) << 15) | ((120u + ((h >> 1) & 7u)) << 7) | ((h >> 4) & 0x7fu));
+    }
+}
+
 template <int WM, int WN, int TM, int NS, int BK = 64>
 static void probe_launch(const GemmArgs& a, int ks, int abl) {
     constexpr int EPI = EPI_BF16;
@@ -131,11 +140,16 @@ extern "C" int ntts_k_gemm_probe(int32_t M, int32_t N, int32_t K, int32_t config
         return NTTS_ENOMEM;
     hipMemset(X, 0x11, (size_t)M * K * 2);
     hipMemset(W, 0x22, wn * 2 * copies);
+    if (abl & 32) {   // operands with the statistics of real activations / weights (hashed bf16 values in (-2, 2)) instead of one constant:
+                      // the matrix cores' power draw -- and with it the clock the chip sustains -- depends on how many bits toggle
+        NTTS_LAUNCH((random_fill_kernel), dim3(2048), dim3(256), (hipStream_t)0, X, (long)M * K, 0x9e3779b9u);
+        NTTS_LAUNCH((random_fill_kernel), dim3(2048), dim3(256), (hipStream_t)0, W, (long)(wn * copies), 0x85ebca6bu);
+    }
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const bool pf = (abl & 8) != 0;
     const int tile_major = (abl & 16) ? 1 : 0;     // weights addressed tile-major (same bytes, sequential per workgroup)
-    abl &= 7;
+    abl &= 7;   // (bits 8, 16, 32 are handled here)
     auto run = [&](int i) {
         if (pf) NTTS_LAUNCH((prefetch_kernel), dim3(256), dim3(256), (hipStream_t)0, (const u32x4*)(W + (size_t)((i + 1) % copies) * wn), (long)(wn / 8), (int*)nullptr);
         GemmArgs a{};

@@ -40,6 +40,32 @@ def prefill():
             print(f"{CONFIGS[cfg]:18s} {t:9.1f} {fl / t / 1e6:7.0f} | {'':14s} {ab[0]:9.1f} {ab[1]:9.1f} {ab[2]:9.1f} {ab[3]:9.1f}", flush=True)
 
 
+def power():
+    """The same prefill / codec GEMMs on constant-filled operands (hipMemset) and on operands with the bit statistics of real
+    data: how much of the distance to the 2.5 PFLOP/s matrix-core peak is the clock the chip sustains under real toggling."""
+    for name, (M, N, K) in PREFILL.items():
+        fl = 2.0 * M * N * K
+        print(f"== {name}  M={M} N={N} K={K}  {fl / 1e12:.2f} TFLOP   (256x256 16w NS2)")
+        for label, extra in (("constant operands", 0), ("random operands", 32)):
+            t = [probe(M, N, K, 42, extra, 1, iters=it) for it in (5, 50)]           # 5 launches: cold chip; 50: sustained
+            t2 = probe(M, N, K, 42, extra | 2, 1, iters=20)                         # no LDS-DMA: matrix cores + LDS reads + epilogue
+            print(f"  {label:18s} {t[0]:8.1f} us ({fl / t[0] / 1e6:5.0f} TF/s) over 5 launches, {t[1]:8.1f} us ({fl / t[1] / 1e6:5.0f} TF/s) over 50;"
+                  f"  loads ablated: {t2:8.1f} us ({fl / t2 / 1e6:5.0f} TF/s)", flush=True)
+
+
+def power_tiles():
+    """Ranking of the big-M tile variants at the board's power limit (random operands, sustained): with real data the prefill GEMMs
+    run against the 1400 W cap (tools/clock_probe.py), so the variant that moves the fewest bytes per FLOP may win where it lost on
+    constant operands."""
+    for name, (M, N, K) in PREFILL.items():
+        fl = 2.0 * M * N * K
+        print(f"== {name}  M={M} N={N} K={K}  {fl / 1e12:.2f} TFLOP, random operands, 300 launches each (constant operands, 50 launches, in brackets)")
+        for cfg in (30, 40, 41, 42, 43, 44, 45, 46, 53):
+            t = probe(M, N, K, cfg, 32, 1, iters=300)
+            t0 = probe(M, N, K, cfg, 0, 1, iters=50)
+            print(f"  {CONFIGS[cfg]:20s} {t:8.1f} us {fl / t / 1e6:6.0f} TF/s   [{t0:8.1f} us {fl / t0 / 1e6:6.0f} TF/s]", flush=True)
+
+
 def mall():
     """Does touching the weights one kernel ahead (Infinity-Cache resident instead of HBM-cold) speed the decode GEMMs up?"""
     for name, (M, N, K) in SHAPES.items():
@@ -97,6 +123,10 @@ def main():
         return prefill()
     if "--mall" in sys.argv:
         return mall()
+    if "--power" in sys.argv:
+        return power()
+    if "--power-tiles" in sys.argv:
+        return power_tiles()
     print(f"empty kernel: {probe(64, 64, 64, 0, 0, 1):.2f} us/launch")
     for name, (M, N, K) in SHAPES.items():
         wbytes = N * K * 2
