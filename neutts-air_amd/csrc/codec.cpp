@@ -49,6 +49,7 @@ struct ntts_codec {
     hipEvent_t ev[2]{};
     hipEvent_t ev_in = nullptr;   // orders a pass behind the stream that produced its device-side codes
     bool have_time = false;
+    bool attn_resident = true;   // utterances of up to 256 frames: attn_full_resident_kernel (NTTS_CODEC_ATTN_RESIDENT=0: the two-sweep paged kernel)
 };
 
 static int cfail(ntts_codec* c, int code, const char* fmt, ...) {
@@ -110,6 +111,7 @@ extern "C" int ntts_codec_create(const ntts_codec_config* cf, int device, ntts_c
     c->lds_spec = (c->NS + 3) / 4 * 4;
     c->K3 = (6L * c->nb + 63) / 64 * 64;
     c->max_rows = cf->max_rows;
+    { const char* ev = getenv("NTTS_CODEC_ATTN_RESIDENT"); if (ev && ev[0] == '0') c->attn_resident = false; }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return cfail(nullptr, NTTS_EHIP, "stream creation failed");
@@ -401,12 +403,16 @@ static int codec_decode_impl(ntts_codec* c, int32_t n, const int32_t* codes, con
         rn.x = c->h; rn.y = c->xa; rn.w = L.ln1; rn.rows = rows; rn.C = H; rn.eps = c->cfg.rms_eps;
         rownorm_launch(rn, st);
         { GemmArgs ga_ = cg(c->xa, H, L.wqkv, H, nullptr, c->qkv, 3L * H, rows, 3 * H); NTTS_GEMM_BIG(EPI_BF16, ga_, st); }
-        VTransposeArgs vt{};
-        vt.qkv = c->qkv; vt.vt = c->vt; vt.R = R; vt.C = H; vt.nh = c->cfg.num_heads; vt.npages = npages;
-        NTTS_LAUNCH((v_transpose_kernel), dim3(n * npages, c->cfg.num_heads), dim3(256), st, vt);
         AttnFullArgs at{};
         at.qkv = c->qkv; at.vt = c->vt; at.out = c->xb; at.R = R; at.C = H; at.nh = c->cfg.num_heads; at.npages = npages; at.qtiles = qtiles;
-        NTTS_LAUNCH((attn_full_kernel), dim3(n * qtiles, c->cfg.num_heads), dim3(256), st, at);
+        if (c->attn_resident && npages <= kAttnResPages) {   // up to 256 frames: K / V^T resident in LDS, one sweep, no V^T pass
+            NTTS_LAUNCH((attn_full_resident_kernel), dim3(n, c->cfg.num_heads), dim3(256), st, at);
+        } else {
+            VTransposeArgs vt{};
+            vt.qkv = c->qkv; vt.vt = c->vt; vt.R = R; vt.C = H; vt.nh = c->cfg.num_heads; vt.npages = npages;
+            NTTS_LAUNCH((v_transpose_kernel), dim3(n * npages, c->cfg.num_heads), dim3(256), st, vt);
+            NTTS_LAUNCH((attn_full_kernel), dim3(n * qtiles, c->cfg.num_heads), dim3(256), st, at);
+        }
         { GemmArgs ga_ = cg(c->xb, H, L.wo, H, nullptr, c->h, H, rows, H, c->h, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
         rn.w = L.ln2;
         rownorm_launch(rn, st);

@@ -341,6 +341,133 @@ NTTS_KERNEL(256) void attn_full_kernel(AttnFullArgs p) {
     }
 }
 
+// ---- the same attention for utterances of up to 256 frames (5 s of audio; the benchmark's 250), with K and V^T RESIDENT ----------
+// grid (B, nh): one workgroup per (utterance, head) stages that head's whole K (LDS-DMA, 8 pages) and V^T (transposed on the
+// way in: no v_transpose_kernel pass, no V^T round trip through HBM) ONCE -- 64 KB -- and its 4 waves then walk the 16-query
+// tiles with no barrier in the loop.  ONE sweep over the keys (online softmax: running maximum m, P = bf16(exp(s - m)) unnormalised,
+// accumulator and denominator rescaled by exp(m_old - m_new) per page, one division at the end) instead of two: QK^T is
+// computed once and every score costs one exp instead of two.  Allowed here because the codec's reference is fp32 with a
+// waveform tolerance -- the backbone's eager contract (P rounded AFTER the global normalisation) is not.
+// The rounding of P to bf16 before the PV product is the same 2^-9 relative perturbation as in attn_full_kernel.
+// Replaces hf:models/xcodec2/modeling_xcodec2.py:242-331 (Xcodec2Attention, non-causal) like attn_full_kernel.
+constexpr int kAttnResPages = 8;   // resident pages: 256 frames
+NTTS_KERNEL(256) void attn_full_resident_kernel(AttnFullArgs p) {
+    NTTS_SHARED bf16_t kres[kAttnResPages * kPage * 64];    // [page][32 keys][128 B], chunk c of key r at c ^ (r & 7)
+    NTTS_SHARED bf16_t vres[kAttnResPages * 64 * kPage];    // [page][64 d][64 B], 16-B unit u of row d at u ^ ((d >> 2) & 3)
+    const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int b = blockIdx.x, h = blockIdx.y;
+    const int T = p.R.lens[b];
+    if (T < 1) return;                                         // block-uniform
+    const long row0 = (long)b * p.R.Tp + kPadRows;
+    const long ld = 3L * p.C;
+    const int npg = (T + kPage - 1) / kPage;                  // <= kAttnResPages (launcher)
+    // ---- K: LDS-DMA, all pages requested at once (frames past T re-read the last one; masked below)
+    for (int inst = w; inst < npg * 4; inst += 4) {           // one instruction = 8 keys x 128 B
+        const int pg = inst >> 2, r = (inst & 3) * 8 + (lane >> 3);
+        int kt = pg * kPage + r;
+        if (kt > T - 1) kt = T - 1;
+        const int c = (lane & 7) ^ (r & 7);
+        glds16(p.qkv + (row0 + kt) * ld + p.C + h * 64 + c * 8, kres + pg * (kPage * 64) + (inst & 3) * 512);
+    }
+    // ---- V -> V^T: a work item = (frame, 8 d); consecutive lanes = consecutive frames, so the 2-byte LDS stores of a wave
+    //      fall on consecutive addresses of one V^T row
+    for (int x = tid; x < npg * kPage * 8; x += 256) {
+        const int t = x % (npg * kPage), dc = x / (npg * kPage);          // frame, d chunk (8 values)
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0;
+        if (t < T) v = ld16<bf16x8>(p.qkv + (row0 + t) * ld + 2 * p.C + h * 64 + dc * 8);
+        const int pg = t >> 5, tk = t & 31;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int d = dc * 8 + e;
+            vres[pg * (64 * kPage) + d * kPage + (((tk >> 3) ^ ((d >> 2) & 3)) << 3) + (tk & 7)] = (bf16_t)v[e];
+        }
+    }
+    wait_vmem();
+    sync();
+
+    constexpr float kMasked = -1.0e30f;
+    const int ntile = (T + 15) >> 4;
+    for (int qt = w; qt < ntile; qt += 4) {                    // wave-uniform: no barrier below
+        const int qw0 = qt * 16;
+        int qi = qw0 + l15;
+        if (qi > T - 1) qi = T - 1;
+        const bf16_t* qr = p.qkv + (row0 + qi) * ld + h * 64 + g * 16;
+        bf16x8 qB[2];
+        qB[0] = ld16<bf16x8>(qr);
+        qB[1] = ld16<bf16x8>(qr + 8);
+        float m = kMasked, lsum = 0.f;                          // running maximum of query l15 (same in its 4 lanes), lane-partial denominator
+        f32x4 oacc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) oacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int pg = 0; pg < npg; ++pg) {
+            const bf16_t* kb = kres + pg * (kPage * 64);
+            const bf16_t* vb = vres + pg * (64 * kPage);
+            float s[8];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = u * 16 + l15;
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                a = mfma16(ld16<bf16x8>(kb + r * 64 + (((2 * g) ^ (r & 7)) << 3)), qB[0], a);
+                a = mfma16(ld16<bf16x8>(kb + r * 64 + (((2 * g + 1) ^ (r & 7)) << 3)), qB[1], a);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const int key = pg * kPage + u * 16 + g * 4 + rr;
+                    s[u * 4 + rr] = key < T ? a[rr] * 0.125f : kMasked;
+                }
+            }
+            float tm = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
+            tm = fmaxf(tm, shfl_xor(tm, 16));
+            tm = fmaxf(tm, shfl_xor(tm, 32));                  // this page's maximum for query l15
+            const float mn = fmaxf(m, tm);
+            const float alpha = fexp_neg(m - mn);               // first page: exp(-1e30 - mn) = 0 on zeroed accumulators
+            m = mn;
+            bf16x8 pA;
+            float add = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float pe = fexp_neg(s[e] - mn);
+                add += pe;
+                pA[e] = (short)f2bf(pe);
+            }
+            lsum = lsum * alpha + add;
+            // accumulator rows are queries g*4 + r: their factors live in the lanes whose l15 is that query
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ar = shfl(alpha, g * 4 + r);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) oacc[nt][r] *= ar;
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int d = nt * 16 + l15;
+                const int sw = (d >> 2) & 3;
+                const bf16x4 v0 = ld16<bf16x4>(vb + d * kPage + (((g >> 1) ^ sw) << 3) + (g & 1) * 4);
+                const bf16x4 v1 = ld16<bf16x4>(vb + d * kPage + (((2 + (g >> 1)) ^ sw) << 3) + (g & 1) * 4);
+                bf16x8 vB;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { vB[e] = v0[e]; vB[4 + e] = v1[e]; }
+                oacc[nt] = mfma16(pA, vB, oacc[nt]);
+            }
+        }
+        lsum += shfl_xor(lsum, 16);
+        lsum += shfl_xor(lsum, 32);                            // denominator of query l15
+        const float rl = 1.0f / lsum;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float rr = shfl(rl, g * 4 + r);
+            const int q = qw0 + g * 4 + r;
+            if (q < T) {
+                bf16_t* o = p.out + (row0 + q) * p.C + h * 64 + l15;
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) o[nt * 16] = f2bf(oacc[nt][r] * rr);
+            }
+        }
+    }
+}
+
 // ---- ISTFT head: spectrum -> hi/lo-split bf16 DFT operand ------------------------------------------------
 // spec fp32 [rows][lds]: log-magnitude bins [0, nb) | phase bins [nb, 2nb), nb = n_fft/2 + 1.
 // s3 bf16 [rows][K3]: [re_hi | im_hi | re_lo | im_lo | re_hi | im_hi | 0...]  (pairs with basis [B_hi | B_hi | B_lo])

@@ -8,7 +8,11 @@ from neutts import _hip
 from common import load_codec_fixture, make_codec_engine, rms
 
 
-def test_codec_tiny_vs_golden_ragged_batch(emu_lib):
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_codec_tiny_vs_golden_ragged_batch(emu_lib, resident, monkeypatch):
+    """Both attention kernels of the decoder layers: K / V^T resident in LDS with ONE online-softmax sweep (utterances of up to
+    256 frames: the default), and the paged two-sweep kernel behind the V^T transpose pass (longer utterances; forced here)."""
+    monkeypatch.setenv("NTTS_CODEC_ATTN_RESIDENT", resident)
     z, cfg, w = load_codec_fixture("codec_tiny")
     eng = make_codec_engine(cfg, w, emu_lib)
     codes = [z["codes_0"][0, 0].tolist(), z["codes_1"][0, 0].tolist(), z["codes_0"][1, 0].tolist()]
@@ -61,3 +65,24 @@ def test_codec_pinned_output_views(emu_lib):
     for x, y in zip(a, b):
         assert np.array_equal(x, y)
     assert not b[0].flags["OWNDATA"]
+
+
+def check_long_utterance(lib):
+    """300 frames (> 256: the paged attention kernel even with the resident one enabled) next to a 200-frame one (resident kernel
+    when decoded alone, paged inside this batch: the longest utterance of a call picks the kernel) against the oracle."""
+    z, cfg, w = load_codec_fixture("codec_tiny")
+    eng = make_codec_engine(cfg, w, lib, max_frames=320, max_rows=700)
+    rng = np.random.default_rng(11)
+    n_codes = int(np.prod(cfg.levels))
+    codes = [rng.integers(0, n_codes, size=300).tolist(), rng.integers(0, n_codes, size=200).tolist()]
+    wavs = eng.decode(codes)
+    alone = eng.decode([codes[1]])[0]
+    for c, wv in zip(codes, wavs):
+        ref = cr.decode_code(cfg, w, torch.tensor(c, dtype=torch.long)[None, None, :])[0, 0].numpy()
+        assert wv.shape == ref.shape and rms(wv - ref) <= 1e-3 and rms(wv - ref) <= 0.02 * rms(ref), (len(c), rms(wv - ref), rms(ref))
+    ref1 = cr.decode_code(cfg, w, torch.tensor(codes[1], dtype=torch.long)[None, None, :])[0, 0].numpy()
+    assert rms(alone - ref1) <= 1e-3 and rms(alone - wavs[1]) <= 1e-3      # two kernels, one answer within the bound (not bit-identical)
+
+
+def test_codec_long_utterance_paged_attention(emu_lib):
+    check_long_utterance(emu_lib)

@@ -23,7 +23,9 @@ def lib(hip_lib):
     return hip_lib
 
 
-def test_codec_tiny(lib):
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_codec_tiny(lib, resident, monkeypatch):
+    monkeypatch.setenv("NTTS_CODEC_ATTN_RESIDENT", resident)   # resident single-sweep attention kernel (default) / paged two-sweep kernel
     z, cfg, w = load_codec_fixture("codec_tiny")
     eng = make_codec_engine(cfg, w, lib)
     codes = [z["codes_0"][0, 0].tolist(), z["codes_1"][0, 0].tolist(), z["codes_0"][1, 0].tolist()]
@@ -75,3 +77,8 @@ def test_neucodec_batch256_properties(neucodec):
     err, sig = rms(wavs[1] - ref), rms(ref)
     print(f"batch-256 row vs oracle: RMS error {err:.3e}, signal RMS {sig:.3e}, relative {err / sig:.3e}")
     assert err <= ABS_BOUND and err <= REL_BOUND * sig
+
+
+def test_codec_long_utterance_paged_attention(lib):
+    import test_emu_codec
+    test_emu_codec.check_long_utterance(lib)
