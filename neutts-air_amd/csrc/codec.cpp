@@ -49,6 +49,7 @@ struct ntts_codec {
     hipEvent_t ev[2]{};
     hipEvent_t ev_in = nullptr;   // orders a pass behind the stream that produced its device-side codes
     bool have_time = false;
+    bool gn_reg = true;          // GroupNorm with the utterance slice in registers when it fits (NTTS_CODEC_GN_REG=0: the two-pass kernel)
     bool attn_resident = true;   // utterances of up to 256 frames: attn_full_resident_kernel (NTTS_CODEC_ATTN_RESIDENT=0: the two-sweep paged kernel)
 };
 
@@ -112,6 +113,7 @@ extern "C" int ntts_codec_create(const ntts_codec_config* cf, int device, ntts_c
     c->K3 = (6L * c->nb + 63) / 64 * 64;
     c->max_rows = cf->max_rows;
     { const char* ev = getenv("NTTS_CODEC_ATTN_RESIDENT"); if (ev && ev[0] == '0') c->attn_resident = false; }
+    { const char* ev = getenv("NTTS_CODEC_GN_REG"); if (ev && ev[0] == '0') c->gn_reg = false; }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return cfail(nullptr, NTTS_EHIP, "stream creation failed");
@@ -336,10 +338,10 @@ static void resnet_block(ntts_codec* c, const ResW& w, const CodecRows& R, long 
     hipStream_t st = c->stream;
     GroupNormArgs g{};
     g.x = c->h; g.y = c->xa; g.gamma = w.g1; g.beta = w.b1; g.R = R; g.C = H; g.eps = 1e-6f;
-    NTTS_LAUNCH((groupnorm_silu_kernel), dim3(R.B, 32), dim3(256), st, g);
+    groupnorm_silu_launch(g, c->gn_reg ? R.Tp - 2 * kPadRows : (1 << 30), st);
     { GemmArgs ga_ = cg(c->xa, H, w.w1, 3L * H, w.cb1, c->t1 + H, H, rows - 2, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
     g.x = c->t1; g.y = c->xb; g.gamma = w.g2; g.beta = w.b2;
-    NTTS_LAUNCH((groupnorm_silu_kernel), dim3(R.B, 32), dim3(256), st, g);
+    groupnorm_silu_launch(g, c->gn_reg ? R.Tp - 2 * kPadRows : (1 << 30), st);
     { GemmArgs ga_ = cg(c->xb, H, w.w2, 3L * H, w.cb2, c->h + H, H, rows - 2, H, c->h + H, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
 }
 
@@ -392,7 +394,7 @@ static int codec_decode_impl(ntts_codec* c, int32_t n, const int32_t* codes, con
     CodecEmbedArgs ea{};
     ea.codes = codes ? c->meta + 2 * n : codes_dev; ea.code_off = c->meta + n; ea.wf = c->wf; ea.bf = c->bf; ea.out = c->xa; ea.R = R; ea.H = H; ea.nq = c->nq;
     for (int i = 0; i < 8; ++i) ea.levels[i] = i < c->nq ? c->cfg.levels[i] : 1;
-    NTTS_LAUNCH((codec_embed_kernel), dim3((unsigned)rows), dim3(256), st, ea);
+    NTTS_LAUNCH((codec_embed_kernel), dim3((unsigned)((rows + kEmbedRows - 1) / kEmbedRows)), dim3(256), st, ea);
     // stem Conv1d(k=7, padding 3): window rows r..r+6 -> centre row r+3
     { GemmArgs ga_ = cg(c->xa, H, c->embed_w, 7L * H, c->embed_b, c->h + 3L * H, H, rows - 6, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
     resnet_block(c, c->res[0], R, rows);

@@ -13,6 +13,7 @@ def test_codec_tiny_vs_golden_ragged_batch(emu_lib, resident, monkeypatch):
     """Both attention kernels of the decoder layers: K / V^T resident in LDS with ONE online-softmax sweep (utterances of up to
     256 frames: the default), and the paged two-sweep kernel behind the V^T transpose pass (longer utterances; forced here)."""
     monkeypatch.setenv("NTTS_CODEC_ATTN_RESIDENT", resident)
+    monkeypatch.setenv("NTTS_CODEC_GN_REG", resident)          # likewise GroupNorm: utterance slice in registers / two-pass kernel
     z, cfg, w = load_codec_fixture("codec_tiny")
     eng = make_codec_engine(cfg, w, emu_lib)
     codes = [z["codes_0"][0, 0].tolist(), z["codes_1"][0, 0].tolist(), z["codes_0"][1, 0].tolist()]

@@ -25,7 +25,8 @@ def lib(hip_lib):
 
 @pytest.mark.parametrize("resident", ["1", "0"])
 def test_codec_tiny(lib, resident, monkeypatch):
-    monkeypatch.setenv("NTTS_CODEC_ATTN_RESIDENT", resident)   # resident single-sweep attention kernel (default) / paged two-sweep kernel
+    monkeypatch.setenv("NTTS_CODEC_ATTN_RESIDENT", resident)
+    monkeypatch.setenv("NTTS_CODEC_GN_REG", resident)          # likewise GroupNorm: utterance slice in registers / two-pass kernel   # resident single-sweep attention kernel (default) / paged two-sweep kernel
     z, cfg, w = load_codec_fixture("codec_tiny")
     eng = make_codec_engine(cfg, w, lib)
     codes = [z["codes_0"][0, 0].tolist(), z["codes_1"][0, 0].tolist(), z["codes_0"][1, 0].tolist()]
