@@ -33,9 +33,8 @@ def test_tiny_teacher_forced(emu_lib):
      "NTTS_ATTN_SPLIT": "2", "NTTS_ATTN_SPLIT_CTX": "45"},   # large-batch path (gemm.h tiles), context-split attention + combine pass from context 45 on
     {"NTTS_SMALL_BATCH": "0", "NTTS_ATTN_DEPTH": "4", "NTTS_S_STAGES": "6", "NTTS_KSPLIT_O": "2", "NTTS_KSPLIT_D": "5",
      "NTTS_PREFILL_ATTN_SIMPLE": "1", "NTTS_KSPLIT_QKV": "3", "NTTS_ATTN_VAR": "2", "NTTS_NORM_WIDE": "0", "NTTS_W_TILE_MAJOR": "0", "NTTS_HEAD_LARGE": "1"},
-    # the lm_head's natural-order tile (gemm.h TN = 6: 256 x 288, 12 waves, uneven LDS-DMA loader split, partial last tile), tile-major and row-major weights
-    {"NTTS_SMALL_BATCH": "0", "NTTS_HEAD_LARGE": "1", "NTTS_HEAD_XL": "4", "NTTS_PF_LPT": "0"},
-    {"NTTS_SMALL_BATCH": "0", "NTTS_HEAD_LARGE": "1", "NTTS_HEAD_XL": "4", "NTTS_W_NT": "0", "NTTS_W_TILE_MAJOR": "0"}])
+    # the lm_head's natural-order tile (gemm.h TN = 6: 256 x 288, 12 waves, uneven LDS-DMA loader split, partial last tile), row-major weights, prompt-order attention tiles (the tile-major default runs in tests/test_gpu_backbone.py)
+    {"NTTS_SMALL_BATCH": "0", "NTTS_HEAD_LARGE": "1", "NTTS_HEAD_XL": "4", "NTTS_PF_LPT": "0", "NTTS_W_TILE_MAJOR": "0"}])
 def test_small_gqa2_page_crossing_peaked_exact(emu_lib, knobs, monkeypatch):
     """2 kv heads, prompt of 70 (3 pages), decode crosses the 96-token page boundary; peaked weights so the
     free-running greedy ids must be bit-identical to HF's -- on the small-batch decode path (wave-per-16-features GEMVs with

@@ -16,3 +16,11 @@ def test_broadcast_and_sharded_generate_world2_rccl(hip_lib):
         pytest.skip(f"{torch.cuda.device_count()} GPU visible: the RCCL test needs 2")
     r = _torchrun(2, [os.path.join(ROOT, "tests", "_dist_worker.py"), hip_lib, "nccl"], {"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     assert r.returncode == 0 and "DIST_OK 2" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_rccl_path_world1(hip_lib):
+    """The same worker at world size 1 on the one GPU of the test box: process-group start-up over RCCL, the torch tensor that
+    ALIASES the engine's hipMalloc'ed arena (__cuda_array_interface__, no staging copy) accepted by the collective, the sharded
+    generate and the host-side gather -- everything of the N > 1 path except a second rank."""
+    r = _torchrun(1, [os.path.join(ROOT, "tests", "_dist_worker.py"), hip_lib, "nccl"], {"HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert r.returncode == 0 and "DIST_OK 1" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
