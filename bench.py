@@ -147,7 +147,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=["air-bf16", "nano-fp8", "nano-bf16"], default="air-bf16",
                     help="air-bf16: NeuTTS-Air bf16 (BASELINE.json configs[1..3], the headline metric); nano-fp8: the assumed NeuTTS-Nano "
                          "geometry with fp8 weights / GEMM inputs, batch 512 (configs[4])")
@@ -414,7 +414,7 @@ def main():
         # template serves three launches per layer.  `agree` = its average duration is within 15 % of this run's HIP events.
         rocprof = None
         if not nano and B == 256 and S == 500:
-            rocprof = rocprof_symbols(os.path.join(ROOT, "profiles", "r02j_bench_kernel_stats.txt"),
+            rocprof = rocprof_symbols(os.path.join(ROOT, "profiles", "r02k_bench_kernel_stats.txt"),
                                       {r[1]: (r[2], r[3], r[4]) for r in rows})
         roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": ms * 1e3,

@@ -12,15 +12,15 @@ for leg in $LEGS; do
   case $leg in
     smoke) timeout 420 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -5 $OUT/smoke.log;;
     tests) timeout ${TESTS_TIMEOUT:-900} python -m pytest tests -m gpu -q -rA --durations=10 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -45 $OUT/pytest_gpu.log;;
-    bench) timeout 600 python bench.py --steps ${BENCH_STEPS:-2} --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -25 $OUT/bench.err;;
+    bench) timeout 600 python bench.py --steps ${BENCH_STEPS:-2} --warmup 2 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -25 $OUT/bench.err;;
     b1)    timeout 300 python bench.py --batch 1 --steps ${BENCH_STEPS:-3} --warmup 1 --no-cpu-baseline > $OUT/bench_b1.json 2> $OUT/bench_b1.err; echo "bench b1 rc=$?"; cat $OUT/bench_b1.json | cut -c1-1500; tail -12 $OUT/bench_b1.err;;
     prof)  rm -rf $OUT/prof; NTTS_BENCH_PRIME_STEPS=2 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof -o bench -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $OUT/prof_bench.json 2> $OUT/prof.err; echo "prof rc=$?"
            python tools/prof_summary.py $OUT/prof > $OUT/prof_summary.txt 2>&1; head -40 $OUT/prof_summary.txt; cat $OUT/prof_bench.json; tail -3 $OUT/prof.err
            find $OUT/prof -name '*kernel_trace.csv' -size +20M -delete;;
     pmc)   # HBM traffic counters, each in its own pass (FETCH_SIZE and WRITE_SIZE do not fit one pass); hipGraph replay off
            # (counter collection crashed rocprofv3 under graph replay); --kernel-trace only, as the pool rules require
-           for ctr in FETCH_SIZE WRITE_SIZE; do
-             rm -rf $OUT/pmc_$ctr; NTTS_NO_GRAPH=1 timeout 240 rocprofv3 --kernel-trace --pmc $ctr -f csv -d $OUT/pmc_$ctr -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-codec --prefill ${PMC_PREFILL:-605} --decode ${PMC_DECODE:-40} --batch ${PMC_BATCH:-256} > $OUT/pmc_bench.json 2> $OUT/pmc_$ctr.err; echo "pmc $ctr rc=$?"
+           for ctr in FETCH_SIZE WRITE_SIZE; do export NTTS_BENCH_PRIME_STEPS=2
+             rm -rf $OUT/pmc_$ctr; NTTS_NO_GRAPH=1 timeout 400 rocprofv3 --kernel-trace --pmc $ctr -f csv -d $OUT/pmc_$ctr -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-codec --prefill ${PMC_PREFILL:-605} --decode ${PMC_DECODE:-40} --batch ${PMC_BATCH:-256} > $OUT/pmc_bench.json 2> $OUT/pmc_$ctr.err; echo "pmc $ctr rc=$?"
              python tools/pmc_summary.py $OUT/pmc_$ctr > $OUT/pmc_${ctr}_summary.txt 2>&1; head -14 $OUT/pmc_${ctr}_summary.txt; find $OUT/pmc_$ctr -name '*.csv' -size +8M -delete
            done;;
     stream) timeout 300 python tools/stream_probe.py > $OUT/stream_probe.jsonl 2> $OUT/stream_probe.err; echo "stream rc=$?"; cat $OUT/stream_probe.jsonl; tail -3 $OUT/stream_probe.err;;
