@@ -109,6 +109,9 @@ struct ntts_backbone {
     // same policy was SLOWER (qkv 5.78 -> 5.96, down 9.95 -> 10.54 us; step 1.679 -> 1.718 ms) and is not offered there
     int w_nt = 1;
     bool pf_rope_vec = true;   // prefill RoPE + KV write with 16-byte accesses (rope_kv_write_vec_kernel)
+    int xcd_affine = 0;        // row-block placement per XCD group (gemm.h xcd_maffine; NTTS_XCD_AFFINE): bit 0: o_proj + the norm behind it, bit 1: down_proj + the
+                               // norm behind it, bit 2: QKV GEMM + attention.  Batch 256 (profiles/r02k_sweep_xcd_affine*.log): 7 -> step 1.630 -> 1.615 ms
+    int xcd_xps = 0;           // XCDs per 64-row m-block of the decode batch (8 / (max_batch / 64)); 0 = the batch does not split that way
     int xl_min_m = 1024;       // rows from which the big-M GEMMs take the 256-row tiles (tests lower it: NTTS_XL_MIN_M)
     bool pf_qkv_nat = true;    // prefill QKV on the natural-order 256 x 288 tile when N is a multiple of 288 but not of 256
     bool pf_lpt = true;        // prefill attention work list sorted by descending causal depth (longest tiles dispatched first)
@@ -368,6 +371,8 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->pf_lpt = env_int("NTTS_PF_LPT", 1) != 0;
     e->pf_qkv_nat = env_int("NTTS_PF_QKV_NAT", 1) != 0;
     e->xl_min_m = env_int("NTTS_XL_MIN_M", 1024);
+    e->xcd_xps = (B == 64 || B == 128 || B == 256 || B == 512) ? 8 / (B / 64) : 0;
+    e->xcd_affine = env_int("NTTS_XCD_AFFINE", B > 128 ? 7 : 0);
     e->xcd_split = env_int("NTTS_XCD_SPLIT", 5);
     e->use_xl = env_int("NTTS_XL", 1) != 0;
     e->head_xl = env_int("NTTS_HEAD_XL", B > 128 ? (e->fp8 ? 1 : 4) : 0);
@@ -845,6 +850,7 @@ static void k_qkv(ntts_backbone* e, int i) {
     {
         GemmArgs a = gemm_args(e, e->xn_dec, H, w.wqkv, H, nullptr, e->slabs, e->NQKV, B, e->NQKV, H, w.sqkv, w.xs[0]);
         a.xcd_nsplit = (e->xcd_split & 1) ? -1 : 0;
+        if ((e->xcd_affine & 4) && e->xcd_xps) a.xcd_maffine = -1;
         gemm_skinny<EPI_SPLITK>(e->st_qkv, a, e->ks_qkv, e->stream);
     }
     else
@@ -862,6 +868,7 @@ static void k_attn(ntts_backbone* e, int i) {
     a.block_table = e->block_table; a.max_pages = e->max_pages; a.pos = e->sl.pos; a.state = e->sl.state;
     a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
     a.tl = e->attn_tl;
+    a.xcd_rows = ((e->xcd_affine & 4) && !e->attn_tl) ? e->xcd_xps : 0;
     if (e->fp8) a.out_fp8_inv = 1.0f / e->layers[i].xs[1];   // attention output = o_proj's input
     if (e->split_active && !e->attn_tl && a.qkv_slabs) {       // long contexts below 2 workgroups per CU: context-split attention + combine
         AttnSplitArgs q{};
@@ -876,6 +883,7 @@ static void k_o_proj(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, QD = e->cfg.num_heads * 64;
     GemmArgs a = gemm_args(e, e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->slabs, H, B, H, QD, e->layers[i].so, e->layers[i].xs[1]);
     a.xcd_nsplit = (e->xcd_split & 2) ? -1 : 0;
+    if ((e->xcd_affine & 1) && e->xcd_xps) a.xcd_maffine = -1;
     gemm_skinny<EPI_SPLITK>(e->st_o, a, e->ks_o, e->stream);
 }
 
@@ -902,13 +910,15 @@ static void k_down(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, F = e->F;
     GemmArgs a = gemm_args(e, e->act_dec, F, e->layers[i].wd, F, nullptr, e->slabs, H, B, H, F, e->layers[i].sd, e->layers[i].xs[3]);
     a.xcd_nsplit = (e->xcd_split & 4) ? -1 : 0;
+    if ((e->xcd_affine & 2) && e->xcd_xps) a.xcd_maffine = -1;
     gemm_skinny<EPI_SPLITK>(e->st_d, a, e->ks_d, e->stream);
 }
 
 // residual += reduce(slabs of a K-deep split-K GEMM); normed = rmsnorm(residual) * norm_w
 // next_scale: fp8 model, the static input scale of the GEMM that consumes the normalised rows (0 = bf16 output)
-static void k_add_norm(ntts_backbone* e, int K, int ks, const bf16_t* norm_w, bf16_t* resid_out, bf16_t* normed_out, float next_scale = 0.f) {
+static void k_add_norm(ntts_backbone* e, int K, int ks, const bf16_t* norm_w, bf16_t* resid_out, bf16_t* normed_out, float next_scale = 0.f, int affine_bit = 0) {
     NormArgs n{};
+    n.xcd_rows = ((e->xcd_affine & affine_bit) && e->norm_wide) ? e->xcd_xps : 0;
     n.slabs = e->slabs; n.nslab = gemm_nsplit(K, ks, ktile_of(e)); n.slab_rows = e->cfg.max_batch; n.resid_in = e->h_dec; n.resid_out = resid_out;
     n.norm_w = norm_w; n.normed_out = normed_out; n.M = e->cfg.max_batch; n.H = e->H; n.eps = e->cfg.rms_eps;
     if (e->fp8 && next_scale > 0.f) n.out_fp8_inv = 1.0f / next_scale;
@@ -1013,10 +1023,10 @@ static void decode_step(ntts_backbone* e) {
         k_qkv(e, i);
         k_attn(e, i);
         k_o_proj(e, i);
-        k_add_norm(e, QD, e->ks_o, e->layers[i].ln2, e->h_dec, e->xn_dec, e->layers[i].xs[2]);
+        k_add_norm(e, QD, e->ks_o, e->layers[i].ln2, e->h_dec, e->xn_dec, e->layers[i].xs[2], 1);
         k_gate_up(e, i);
         k_down(e, i);
-        k_add_norm(e, F, e->ks_d, last ? e->final_norm : e->layers[i + 1].ln1, e->h_dec, e->xn_dec, last ? e->xs_head : e->layers[i + 1].xs[0]);
+        k_add_norm(e, F, e->ks_d, last ? e->final_norm : e->layers[i + 1].ln1, e->h_dec, e->xn_dec, last ? e->xs_head : e->layers[i + 1].xs[0], 2);
     }
     lm_head_and_sample(e, SLOT_RUNNING);
 }

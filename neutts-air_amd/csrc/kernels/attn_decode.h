@@ -17,6 +17,7 @@
 // Scores are rounded to bf16 (the eager contract) and parked in LDS, so K is streamed exactly once.
 #pragma once
 #include <ntts/dev.h>
+#include "norm.h"
 
 namespace ntts {
 
@@ -50,6 +51,8 @@ struct AttnDecodeArgs {
     long slab_rows;
     const bf16_t* qkv_bias;
     unsigned long long* tl;   // diagnostics: [B][nkv][4 waves][8] phase timestamps (now_ticks), null in the product path
+    int xcd_rows;             // xps = 8 / (batch / 64), 0 = off: workgroup x takes sequence xcd_row(x, xps) (norm.h) -- the rows of m-block p on XCD group p,
+                              // where the QKV GEMM left their split-K slabs and the o_proj GEMM will read their outputs (gemm.h xcd_maffine); speed only
 };
 
 // bf16 RoPE of one (x1 = x[i], x2 = x[i+32]) pair: q*cos + rotate_half(q)*sin, every op rounded
@@ -86,7 +89,8 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
     NTTS_SHARED float wsum[NW][kGroupMax];
     NTTS_SHARED float ored[NW][kGroupMax][64];
 
-    const int b = blockIdx.x, kvh = blockIdx.y;
+    const int b = p.xcd_rows ? xcd_row((int)blockIdx.x, p.xcd_rows) : (int)blockIdx.x;
+    const int kvh = blockIdx.y;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
     const int g = lane >> 4, l15 = lane & 15;
     const int group = p.nh / p.nkv;

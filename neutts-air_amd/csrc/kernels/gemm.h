@@ -80,6 +80,12 @@ struct GemmArgs {
     // tiles of a slice), so X and W are each fetched into exactly one L2 per slice.  Speed only: block b runs on XCD b % 8
     // is an observation, not a contract, and nothing depends on it.
     int xcd_nsplit, xcd_per;
+    // row-block placement (gemm_launch sets both from a request of xcd_maffine = -1; 1 / 2 / 4 / 8 m-blocks): the xcd_xps = 8 / mblocks XCDs
+    // of group p work on m-block p alone -- all its n-blocks and K slices -- so that the 64 batch rows of an m-block are produced,
+    // reduced (norm.h xcd_rows), attended (attn_decode.h xcd_rows) and consumed inside one group of L2s instead of crossing the fabric
+    // at every kernel boundary; xcd_maffine = number of K slices.  Every group then streams the whole W (fetched from HBM once, from the
+    // memory-side cache by the other groups).  Speed only, like xcd_nsplit: block b on XCD b % 8 is an observation, not a contract.
+    int xcd_maffine, xcd_xps;
 };
 
 // position t of the grouped tile order (8 m-blocks x all n-blocks per group, m fastest) -> tile coordinates
@@ -429,7 +435,14 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     const int wm = wave / WN, wn = wave % WN;
     const int g = lane >> 4, l15 = lane & 15;
     int mb, nb, split = blockIdx.y;
-    if (p.xcd_nsplit) {
+    if (p.xcd_maffine > 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int wi = (xcd % p.xcd_xps) + p.xcd_xps * j;      // work item of m-block xcd / xps: (n-block, K slice)
+        if (wi >= p.nblocks * p.xcd_maffine) return;           // padding block (block-uniform, before any barrier)
+        mb = xcd / p.xcd_xps;
+        nb = wi % p.nblocks;
+        split = wi / p.nblocks;
+    } else if (p.xcd_nsplit) {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, xps = 8 / p.xcd_nsplit;   // XCDs per K slice
         split = xcd / xps;
         const int t = (xcd % xps) * p.xcd_per + j;
@@ -582,6 +595,15 @@ inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
     p.k_tiles_per_split = (ktiles + ksplit - 1) / ksplit;
     const int nsplit = (ktiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
     if constexpr (EPI == EPI_ARGMAX) p.part_stride = p.nblocks * WN;
+    if (EPI == EPI_SPLITK && p.xcd_maffine == -1 && (p.mblocks == 1 || p.mblocks == 2 || p.mblocks == 4 || p.mblocks == 8)) {   // row-block placement requested
+        p.xcd_maffine = nsplit;
+        p.xcd_xps = 8 / p.mblocks;
+        p.xcd_nsplit = 0;
+        const int per_xcd = (p.nblocks * nsplit + p.xcd_xps - 1) / p.xcd_xps;
+        NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT, F8, TN>), dim3(8 * per_xcd), dim3(WM * WN * 64), s, p);
+        return;
+    }
+    p.xcd_maffine = 0;
     if (EPI == EPI_SPLITK && p.xcd_nsplit == -1 && (nsplit == 2 || nsplit == 4 || nsplit == 8)) {   // XCD-aware split-K placement requested
         p.xcd_nsplit = nsplit;
         const int xps = 8 / nsplit, tiles = p.mblocks * p.nblocks;

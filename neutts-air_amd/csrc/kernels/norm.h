@@ -13,6 +13,13 @@
 
 namespace ntts {
 
+// batch row handled by workgroup `bid` of a one-row-per-workgroup grid of 64 * (8 / xps) rows when the rows of m-block p (64 rows)
+// belong on the xps XCDs of group p (workgroup b runs on XCD b % 8 -- an observation, used for speed only): bijective
+NTTS_HD int xcd_row(int bid, int xps) {
+    const int x = bid & 7, j = bid >> 3;
+    return (x / xps) * 64 + (x % xps) * (64 / xps) + j;
+}
+
 struct NormArgs {
     // --- the branch input "o" (exactly one of the three):
     const float* slabs;      // [nslab][slab_rows][H] fp32 split-K partials
@@ -32,6 +39,8 @@ struct NormArgs {
     const int* out_rows;     // logical row r writes output row out_rows[r] (null: r)
     int M, H;
     float eps;
+    int xcd_rows;            // add_rmsnorm_row_kernel, M = 64 * mblocks: xps = 8 / mblocks (0 = off): workgroup b takes row xcd_row(b, xps), i.e. the
+                             // rows of m-block p are normalised on XCD group p (whose L2s hold that m-block's split-K slabs: gemm.h xcd_maffine)
     float out_fp8_inv;       // > 0: normed_out holds e4m3 BYTES [*, H], value = bf16 result * out_fp8_inv (GEMM input of the fp8 model)
 };
 
@@ -154,7 +163,7 @@ NTTS_KERNEL(128) void add_rmsnorm_row_kernel(NormArgs p) {
     NTTS_SHARED float hand[64][8];
     NTTS_SHARED float inv_s;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
-    const int r = blockIdx.x;
+    const int r = p.xcd_rows ? xcd_row((int)blockIdx.x, p.xcd_rows) : (int)blockIdx.x;
     const long ri = p.in_rows ? p.in_rows[r] : r;
     const long ro = p.out_rows ? p.out_rows[r] : r;
     const int nchunk = p.H >> 3;

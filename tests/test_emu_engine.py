@@ -53,6 +53,24 @@ def test_small_gqa2_page_crossing_peaked_exact(emu_lib, knobs, monkeypatch):
     assert fin and ids == z["bf16_ids_0"][:N].tolist()
 
 
+def test_xcd_row_block_placement(emu_lib, monkeypatch):
+    """NTTS_XCD_AFFINE=7 (the default above batch 128): split-K GEMMs, the norms behind them and decode attention place the rows of a
+    64-row m-block on one group of XCDs (gemm.h xcd_maffine, norm.h xcd_row).  A pure permutation of which workgroup does what:
+    at batch 64 (one m-block spread over all 8 XCDs, padding workgroups in the GEMM grids) two sequences in far-apart slots still
+    give HF's ids bit for bit."""
+    for k, v in {"NTTS_SMALL_BATCH": "0", "NTTS_XCD_AFFINE": "7", "NTTS_HEAD_LARGE": "0"}.items():
+        monkeypatch.setenv(k, v)
+    z, cfg, w = load_fixture("backbone_small_peaked")
+    S, N, eos = int(z["s_len"]), 20, int(z["eos"])
+    eng = make_engine(cfg, w, emu_lib, max_batch=64)
+    samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
+    eng.prefill([br.synthetic_prompt(cfg, 0, S), br.synthetic_prompt(cfg, 1, S)], [5, 40], [samp, samp])
+    eng.decode(N - 1)
+    for slot, u in ((5, 0), (40, 1)):
+        ids, fin = eng.read(slot)
+        assert fin and ids == z[f"bf16_ids_{u}"][:N].tolist(), (slot, ids)
+
+
 def test_continuous_batching_ragged_vs_oracle(emu_lib):
     """More prompts than slots, ragged prompt lengths, EOS stop before max_length, slot recycling:
     every prompt's ids equal the oracle's single-sequence run (ref:neutts/neutts.py:334-352 is batch 1)."""

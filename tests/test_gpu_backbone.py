@@ -68,6 +68,31 @@ def test_small_peaked_exact_tile_variants(lib, knobs, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("max_batch", [64, 128, 256, 512])
+def test_xcd_row_block_placement(lib, max_batch, monkeypatch):
+    """NTTS_XCD_AFFINE=7 at every batch size it applies to (8 / 4 / 2 / 1 XCDs per 64-row m-block): the split-K GEMMs, the norms
+    behind them and decode attention place an m-block's rows on one group of XCDs -- a permutation of which workgroup does what.
+    Sequences in scattered slots (first, middle and last m-block) give the oracle's free-running ids."""
+    monkeypatch.setenv("NTTS_XCD_AFFINE", "7")
+    monkeypatch.setenv("NTTS_SMALL_BATCH", "0")
+    cfg = br.BackboneConfig(vocab_size=3000, hidden_size=896, intermediate_size=1216, num_layers=2)
+    w = br.make_weights(cfg, 29, peak_sigma=0.5)
+    wd = br.cast_weights(w, torch.bfloat16)
+    slots = [3, max_batch // 2 + 5, max_batch - 1]
+    prompts = [br.synthetic_prompt(cfg, 70 + i, 30 + 7 * i) for i in range(3)]
+    eos = cfg.vocab_size - 1
+    N = 12
+    eng = make_engine(cfg, w, lib, max_batch=max_batch, max_context=128, max_prefill_tokens=256, bf16_upload=True)
+    samp = [_hip.Sampling(max_length=len(p) + N, min_new_tokens=N, eos_token_id=eos, do_sample=False) for p in prompts]
+    eng.prefill(prompts, slots, samp)
+    eng.decode(N - 1)
+    for sl, p in zip(slots, prompts):
+        ids, fin = eng.read(sl)
+        assert fin and len(ids) == N
+        assert_free_run_matches(ids, br.generate(cfg, wd, p, len(p) + N, eos_id=eos, min_new_tokens=N, keep_logits=True))
+    eng.close()
+
+
 def test_prefill_on_cu_masked_side_stream(lib):
     """ntts_backbone_set_prefill_cu_mask: the prompt pass on a side stream restricted to 64 of the 256 CUs (ordered before and
     behind the engine's own stream) and the decode steps that follow give HF's ids; two prefills in a row, mask removed again."""
