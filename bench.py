@@ -402,12 +402,12 @@ def main():
         try:   # HBM bytes per launch from the committed PMC pass (tools/gpu_round.sh pmc -> tools/pmc_to_json.py): this configuration only
             if nano or B != 256 or S != 500:
                 raise OSError("no PMC pass for this configuration")
-            with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r02k_pmc_traffic.json")) as fh:
                 pm = json.load(fh)
             for kname, rec in pm["kernels"].items():
                 if kname.startswith(name):
                     traffic = rec["fetch_bytes_per_launch"] + rec.get("write_bytes_per_launch_uncorrected", 0.0)
-                    traffic_src = "profiles/r02_pmc_traffic.json: " + pm["source"]
+                    traffic_src = "profiles/r02k_pmc_traffic.json: " + pm["source"]
         except (OSError, KeyError, ValueError):
             pass
         # rocprofv3 view of the same command (committed summary of the same configuration): per SYMBOL, since one gemm
