@@ -144,6 +144,13 @@ struct ntts_backbone {
     bf16_t *h_pf = nullptr, *xn_pf = nullptr, *qkv_pf = nullptr, *attn_pf = nullptr, *o_pf = nullptr, *act_pf = nullptr;
     int* meta_dev = nullptr;
     size_t meta_cap = 0;
+    // page-locked staging ring of the meta block: a host-to-device copy from pageable memory forced a stream synchronisation into
+    // every prompt pass / decode call / code export (the host sat out the previous prompt pass before it could enqueue the next)
+    static constexpr int kMetaStages = 4;
+    int* meta_host[kMetaStages] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t meta_ev[kMetaStages] = {nullptr, nullptr, nullptr, nullptr};
+    bool meta_used[kMetaStages] = {false, false, false, false};
+    int meta_next = 0;
 
     hipGraphExec_t graph = nullptr;
     hipGraphExec_t graph_split = nullptr;   // the small-batch step with context-split attention (long contexts)
@@ -441,6 +448,10 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     CR_HIP(hipMalloc((void**)&e->act_pf, T * F * 2));
     e->meta_cap = 2 * T + (size_t)B * (16 + e->max_pages) + (T / 64 + B) * 2 + 3 * (size_t)B * e->max_pages + 64;
     CR_HIP(hipMalloc((void**)&e->meta_dev, e->meta_cap * sizeof(int)));
+    for (int i = 0; i < ntts_backbone::kMetaStages; ++i) {
+        CR_HIP(hipHostMalloc((void**)&e->meta_host[i], e->meta_cap * sizeof(int), hipHostMallocDefault));
+        CR_HIP(hipEventCreateWithFlags(&e->meta_ev[i], hipEventDisableTiming));
+    }
     CR_HIP(hipDeviceSynchronize());
     *out = e;
     return NTTS_OK;
@@ -459,6 +470,10 @@ extern "C" void ntts_backbone_destroy(ntts_backbone* e) {
         if (b) hipFree(b);
     for (auto& ev : e->ev)
         if (ev) hipEventDestroy(ev);
+    for (int i = 0; i < ntts_backbone::kMetaStages; ++i) {
+        if (e->meta_host[i]) hipHostFree(e->meta_host[i]);
+        if (e->meta_ev[i]) hipEventDestroy(e->meta_ev[i]);
+    }
     if (e->pf_stream) { hipStreamDestroy(e->pf_stream); hipEventDestroy(e->pf_ev[0]); hipEventDestroy(e->pf_ev[1]); }
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
@@ -1051,6 +1066,19 @@ static void drop_pages(ntts_backbone* e, HostSlot& s, size_t keep = 0) {
     }
 }
 
+// meta block -> device, asynchronously on `st`: through the next slot of the page-locked ring (waits only if the copy that last
+// used that slot -- four uploads ago -- has not executed yet)
+static hipError_t upload_meta(ntts_backbone* e, const int* src, size_t n, hipStream_t st) {
+    const int k = e->meta_next;
+    e->meta_next = (k + 1) % ntts_backbone::kMetaStages;
+    if (e->meta_used[k]) { const hipError_t rc = hipEventSynchronize(e->meta_ev[k]); if (rc != hipSuccess) return rc; }
+    memcpy(e->meta_host[k], src, n * sizeof(int));
+    hipError_t rc = hipMemcpyAsync(e->meta_dev, e->meta_host[k], n * sizeof(int), hipMemcpyHostToDevice, st);
+    if (rc != hipSuccess) return rc;
+    e->meta_used[k] = true;
+    return hipEventRecord(e->meta_ev[k], st);
+}
+
 // Prompt pass.  With donor_slot / shared_len (ntts_backbone_prefill_shared): prompt i re-uses the KV pages that hold the
 // first pos0[i] = floor(shared_len[i] / 32) * 32 tokens of its donor's prompt -- only the remaining tokens are packed,
 // embedded and pushed through the layers; their queries attend to the shared pages exactly as they would to their own.
@@ -1200,8 +1228,7 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
         }
     } side(e);
     hipStream_t st = e->stream;
-    HIPCHK(e, hipMemcpyAsync(e->meta_dev, m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    HIPCHK(e, hipStreamSynchronize(st));  // m is pageable host memory
+    HIPCHK(e, upload_meta(e, m.data(), m.size(), st));
     const int* md = e->meta_dev;
     PrefillMeta meta{md + o_base, md + o_len, md + o_pos0, md + o_slot, md + o_tok_seq, md + o_tseq, md + o_tq0};
 
@@ -1357,8 +1384,7 @@ extern "C" int ntts_backbone_decode(ntts_backbone* e, int32_t n_steps) {
     }
     if (!trip.empty()) {
         if (trip.size() > e->meta_cap) return fail(e, NTTS_EINVAL, "block-table update too large");
-        HIPCHK(e, hipMemcpyAsync(e->meta_dev, trip.data(), trip.size() * sizeof(int), hipMemcpyHostToDevice, st));
-        HIPCHK(e, hipStreamSynchronize(st));
+        HIPCHK(e, upload_meta(e, trip.data(), trip.size(), st));
         const int nt = (int)trip.size() / 3;
         NTTS_LAUNCH((bt_update_kernel), dim3((nt + 63) / 64), dim3(64), st, (const int*)e->meta_dev, nt, e->block_table, e->max_pages);
     }
@@ -1494,8 +1520,7 @@ extern "C" int ntts_backbone_export_codes(ntts_backbone* e, int32_t n, const int
         if (slots[i] < 0 || slots[i] >= e->cfg.max_batch) return fail(e, NTTS_EINVAL, "slot %d out of range", slots[i]);
     HIPCHK(e, hipSetDevice(e->device));
     // the slot list travels through the engine's meta block: stream-ordered behind whatever still reads it
-    HIPCHK(e, hipMemcpyAsync(e->meta_dev, slots, (size_t)n * sizeof(int), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipStreamSynchronize(e->stream));   // `slots` is pageable host memory (also: the decode steps before are done)
+    HIPCHK(e, upload_meta(e, slots, (size_t)n, e->stream));
     ExportCodesArgs a{};
     a.slots = e->meta_dev; a.sl = e->sl; a.speech_base = speech_base; a.n_codes = n_codes; a.modulo = modulo;
     a.codes = codes_dev; a.stride = stride; a.lens = lens_dev;
