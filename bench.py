@@ -293,6 +293,16 @@ def main():
     pending = {"codec": False}
     async_codec = os.environ.get("NTTS_BENCH_ASYNC_CODEC", "1") != "0"
 
+    def finish_pending():
+        """Wait for the codec pass enqueued by the previous step (it is ordered behind that step's decode loop and code export, so
+        those are done too) and check that every utterance produced its N tokens: export_codes wrote the counts next to the codes."""
+        if codec is None or not pending["codec"]:
+            return
+        codec.sync()
+        pending["codec"] = False
+        got = lens_buf if emu_lib else lens_buf.cpu().numpy()
+        assert (np.asarray(got) == N).all(), "bench run did not produce the expected tokens"
+
     def one_step_static(collect=False):
         """One pass of the hot path over one batch: prompts -> codec-token ids -> 24 kHz waveforms."""
         ph = {"prefill": 0.0, "decode": 0.0, "codec": 0.0, "handoff_host": 0.0, "codec_call_wall": 0.0}
@@ -320,15 +330,18 @@ def main():
             # id -> code hand-off on the device (random weights do not stay in the speech range -> code = id mod 65536),
             # enqueued behind the decode steps; the codec pass is ordered behind it on its own stream; only the waveforms
             # (into the codec engine's pinned buffer) and 2 x B counters cross PCIe
-            if pending["codec"]:                               # the previous batch's codec pass reads codes_buf and fills the pinned output:
-                codec.sync()                                    # it finished ~0.4 s ago; formally ordered before both are reused
-                pending["codec"] = False
+            finish_pending()                                    # the previous batch's codec pass reads codes_buf / lens_buf and fills the pinned
+                                                                # output: it finished ~0.4 s ago; formally ordered before they are reused
             eng.export_codes(list(range(B)), 0, n_codes, codes_ptr, N, lens_ptr, modulo=True)
             th = time.time()
             st, n_new = eng.poll()                              # blocking: decode + export done
             if collect:
                 ph["decode"] = eng.last_timing()[1]
             assert (n_new == N).all() and (st == 2).all(), "bench run did not produce the expected tokens"
+            # (Measured and not kept, profiles/r02k_ab_bench_async_modes.txt: with the poll dropped too -- export, codec pass, slot
+            #  releases and the next batch's prompt pass are all stream-ordered behind the decode steps, so the host can enqueue a whole
+            #  batch ahead -- the step got SLOWER, 583 vs 573 ms: the launching thread then runs into a full hardware queue (its fourth
+            #  prompt-pass call blocks 165 ms) and the decode loop behind it loses 10 ms.)
             ph["handoff_host"] = (time.time() - th) * 1e3
             tc = time.time()
             wavs = codec.decode_device(codes_ptr, N, np.full(B, N, dtype=np.int32), producer_stream=eng.stream())
@@ -357,9 +370,7 @@ def main():
     one_step = one_step_continuous if cont else one_step_static
 
     def barrier():
-        if codec is not None and pending["codec"]:
-            codec.sync()
-            pending["codec"] = False
+        finish_pending()
         if world > 1:
             import torch.distributed as dist
             dist.barrier()
