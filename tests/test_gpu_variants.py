@@ -27,13 +27,15 @@ test_fp8_model_matches_fp8_oracle = cases.test_fp8_model_matches_fp8_oracle
 test_fp8_needs_its_input_scales = cases.test_fp8_needs_its_input_scales
 
 
-def test_fp8_nano_width_batch64_vs_oracle(lib):
+@pytest.mark.parametrize("batch", [64, 256])
+def test_fp8_nano_width_batch64_vs_oracle(lib, batch):
     """hidden 768 / 12:4 heads / FFN 2048 (the assumed Nano widths), 2 layers, vocabulary 8192, batch 64 (the large-batch tile
-    path incl. the 128 x 128 gate/up tile and the 256-wide lm_head tile), 70-token prompts, 24 greedy tokens: first-token
+    path incl. the 128 x 128 gate/up tile and the 256-wide lm_head tile) and batch 256 (XCD row-block placement of the fp8
+    split-K GEMMs / norms / attention on, as at the benchmark's batch 512), 70-token prompts, 24 greedy tokens: first-token
     logits against the fp8 oracle (bar: cases.check_fp8_model) and identical rows for identical prompts (batch invariance)."""
     cfg = br.BackboneConfig(vocab_size=8192, hidden_size=768, intermediate_size=2048, num_layers=2, num_heads=12, num_kv_heads=4)
     base = [br.synthetic_prompt(cfg, i, 70) for i in range(4)]
-    prompts = [base[i % 4] for i in range(64)]
-    rows, worst = cases.check_fp8_model(lib, cfg, prompts, 24, max_batch=64)
-    for s in range(64):
+    prompts = [base[i % 4] for i in range(batch)]
+    rows, worst = cases.check_fp8_model(lib, cfg, prompts, 24, max_batch=batch)
+    for s in range(batch):
         assert rows[s] == rows[s % 4], s
