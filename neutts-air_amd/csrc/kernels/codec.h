@@ -429,7 +429,7 @@ NTTS_KERNEL(256) void attn_full_kernel(AttnFullArgs p) {
 
 // ---- the same attention for utterances of up to 256 frames (5 s of audio; the benchmark's 250), with K and V^T RESIDENT ----------
 // grid (B, nh): one workgroup per (utterance, head) stages that head's whole K (LDS-DMA, 8 pages) and V^T (transposed on the
-// way in: no v_transpose_kernel pass, no V^T round trip through HBM) ONCE -- 64 KB -- and its 4 waves then walk the 16-query
+// way in: no v_transpose_kernel pass, no V^T round trip through HBM) ONCE -- 64 KB -- and its 8 waves then walk the 16-query
 // tiles with no barrier in the loop.  ONE sweep over the keys (online softmax: running maximum m, P = bf16(exp(s - m)) unnormalised,
 // accumulator and denominator rescaled by exp(m_old - m_new) per page, one division at the end) instead of two: QK^T is
 // computed once and every score costs one exp instead of two.  Allowed here because the codec's reference is fp32 with a
@@ -437,7 +437,10 @@ NTTS_KERNEL(256) void attn_full_kernel(AttnFullArgs p) {
 // The rounding of P to bf16 before the PV product is the same 2^-9 relative perturbation as in attn_full_kernel.
 // Replaces hf:models/xcodec2/modeling_xcodec2.py:242-331 (Xcodec2Attention, non-causal) like attn_full_kernel.
 constexpr int kAttnResPages = 8;   // resident pages: 256 frames
-NTTS_KERNEL(256) void attn_full_resident_kernel(AttnFullArgs p) {
+// 8 waves: the per-page chain K-MFMA -> row maximum (two cross-lane steps) -> exp -> PV-MFMA is serial inside a wave, and the 64 KB of
+// LDS allow two workgroups per CU -- with 4 waves each that was 2 waves per SIMD and the kernel ran at the latency of that chain
+// (289 us per launch; trimming its arithmetic changed nothing); 8 waves halve the query tiles per wave and double the waves per SIMD.
+NTTS_KERNEL(512) void attn_full_resident_kernel(AttnFullArgs p) {
     NTTS_SHARED bf16_t kres[kAttnResPages * kPage * 64];    // [page][32 keys][128 B], chunk c of key r at c ^ (r & 7)
     NTTS_SHARED bf16_t vres[kAttnResPages * 64 * kPage];    // [page][64 d][64 B], 16-B unit u of row d at u ^ ((d >> 2) & 3)
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
@@ -449,7 +452,7 @@ NTTS_KERNEL(256) void attn_full_resident_kernel(AttnFullArgs p) {
     const long ld = 3L * p.C;
     const int npg = (T + kPage - 1) / kPage;                  // <= kAttnResPages (launcher)
     // ---- K: LDS-DMA, all pages requested at once (frames past T re-read the last one; masked below)
-    for (int inst = w; inst < npg * 4; inst += 4) {           // one instruction = 8 keys x 128 B
+    for (int inst = w; inst < npg * 4; inst += 8) {           // one instruction = 8 keys x 128 B
         const int pg = inst >> 2, r = (inst & 3) * 8 + (lane >> 3);
         int kt = pg * kPage + r;
         if (kt > T - 1) kt = T - 1;
@@ -458,7 +461,7 @@ NTTS_KERNEL(256) void attn_full_resident_kernel(AttnFullArgs p) {
     }
     // ---- V -> V^T: a work item = (frame, 8 d); consecutive lanes = consecutive frames, so the 2-byte LDS stores of a wave
     //      fall on consecutive addresses of one V^T row
-    for (int x = tid; x < npg * kPage * 8; x += 256) {
+    for (int x = tid; x < npg * kPage * 8; x += 512) {
         const int t = x % (npg * kPage), dc = x / (npg * kPage);          // frame, d chunk (8 values)
         bf16x8 v;
 #pragma unroll
@@ -476,7 +479,7 @@ NTTS_KERNEL(256) void attn_full_resident_kernel(AttnFullArgs p) {
 
     constexpr float kMasked = -1.0e30f;
     const int ntile = (T + 15) >> 4;
-    for (int qt = w; qt < ntile; qt += 4) {                    // wave-uniform: no barrier below
+    for (int qt = w; qt < ntile; qt += 8) {                    // wave-uniform: no barrier below
         const int qw0 = qt * 16;
         int qi = qw0 + l15;
         if (qi > T - 1) qi = T - 1;
@@ -498,23 +501,31 @@ NTTS_KERNEL(256) void attn_full_resident_kernel(AttnFullArgs p) {
                 f32x4 a = {0.f, 0.f, 0.f, 0.f};
                 a = mfma16(ld16<bf16x8>(kb + r * 64 + (((2 * g) ^ (r & 7)) << 3)), qB[0], a);
                 a = mfma16(ld16<bf16x8>(kb + r * 64 + (((2 * g + 1) ^ (r & 7)) << 3)), qB[1], a);
+                // scores stay in RAW units (q.k, not yet times 1/8): the scale rides in the exponent's constant below.  Only the
+                // last page can hold frames past T (wave-uniform test: full pages skip the compare / select)
+                if (pg + 1 == npg) {
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const int key = pg * kPage + u * 16 + g * 4 + rr;
-                    s[u * 4 + rr] = key < T ? a[rr] * 0.125f : kMasked;
+                    for (int rr = 0; rr < 4; ++rr) s[u * 4 + rr] = pg * kPage + u * 16 + g * 4 + rr < T ? a[rr] : kMasked;
+                } else {
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) s[u * 4 + rr] = a[rr];
                 }
             }
             float tm = fmaxf(fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3])), fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7])));
             tm = fmaxf(tm, shfl_xor(tm, 16));
             tm = fmaxf(tm, shfl_xor(tm, 32));                  // this page's maximum for query l15
             const float mn = fmaxf(m, tm);
-            const float alpha = fexp_neg(m - mn);               // first page: exp(-1e30 - mn) = 0 on zeroed accumulators
+            // exp((s - m) / 8) = exp2((s - m) * log2(e) / 8): one subtract, one multiply, one v_exp_f32 per score (~2e-6 relative:
+            // the result is rounded to bf16 for the PV product, and the codec's bar is a waveform tolerance against an fp32
+            // reference -- the backbone's attention keeps the ~1.5-ulp fexp_neg)
+            constexpr float kC = 0.125f * 1.44269504088896340736f;
+            const float alpha = fexp2((m - mn) * kC);   // first page: exp2(-huge) = 0 on zeroed accumulators
             m = mn;
             bf16x8 pA;
             float add = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float pe = fexp_neg(s[e] - mn);
+                const float pe = fexp2((s[e] - mn) * kC);
                 add += pe;
                 pA[e] = (short)f2bf(pe);
             }

@@ -102,6 +102,8 @@ NTTS_D unsigned int atomic_add_lds(unsigned int* p, unsigned int v) { return ato
 NTTS_D unsigned long long now_ticks() { return wall_clock64(); }
 
 NTTS_D float fexp(float x) { return expf(x); }
+// 2^x as one v_exp_f32 (~1 ulp; flushes to 0 for very negative x): callers whose bar is a tolerance, not a rounding contract
+NTTS_D float fexp2(float x) { return __builtin_amdgcn_exp2f(x); }
 // exp(x) for FINITE x <= ~0 (softmax arguments after the max is subtracted; masked scores are -1e30, never -inf):
 // x*log2(e) is split into its rounded product t and the exact remainder r (fma), exp2(t) is one v_exp_f32 and the
 // remainder is a first-order correction.  ~1.5 ulp, 6 instructions, no range checks (libm's expf is ~12 with them).

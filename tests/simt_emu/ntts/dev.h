@@ -239,6 +239,7 @@ template <int N>
 inline void wait_vmem_le() {}
 
 inline float fexp(float x) { return expf(x); }
+inline float fexp2(float x) { return exp2f(x); }
 inline float fexp_neg(float x) {
     const float hi = 1.44269502162933349609375f, lo = 1.925963033500011e-8f;
     const float t = x * hi;
