@@ -111,6 +111,7 @@ struct ntts_backbone {
     bool pf_rope_vec = true;   // prefill RoPE + KV write with 16-byte accesses (rope_kv_write_vec_kernel)
     int xcd_affine = 0;        // row-block placement per XCD group (gemm.h xcd_maffine; NTTS_XCD_AFFINE): bit 0: o_proj + the norm behind it, bit 1: down_proj + the
                                // norm behind it, bit 2: QKV GEMM + attention.  Batch 256 (profiles/r02k_sweep_xcd_affine*.log): 7 -> step 1.630 -> 1.615 ms
+    bool attn_lmax_small = true;   // decode attention: the 1024-context instantiation when max_context allows (NTTS_ATTN_LMAX_SMALL)
     int xcd_xps = 0;           // XCDs per 64-row m-block of the decode batch (8 / (max_batch / 64)); 0 = the batch does not split that way
     int xl_min_m = 1024;       // rows from which the big-M GEMMs take the 256-row tiles (tests lower it: NTTS_XL_MIN_M)
     bool pf_qkv_nat = true;    // prefill QKV on the natural-order 256 x 288 tile when N is a multiple of 288 but not of 256
@@ -378,6 +379,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->pf_lpt = env_int("NTTS_PF_LPT", 1) != 0;
     e->pf_qkv_nat = env_int("NTTS_PF_QKV_NAT", 1) != 0;
     e->xl_min_m = env_int("NTTS_XL_MIN_M", 1024);
+    e->attn_lmax_small = env_int("NTTS_ATTN_LMAX_SMALL", 1) != 0;
     e->xcd_xps = (B == 64 || B == 128 || B == 256 || B == 512) ? 8 / (B / 64) : 0;
     e->xcd_affine = env_int("NTTS_XCD_AFFINE", B > 128 ? 7 : 0);
     e->xcd_split = env_int("NTTS_XCD_SPLIT", 5);
@@ -891,7 +893,7 @@ static void k_attn(ntts_backbone* e, int i) {
         attn_split_launch(q, c.max_batch, e->stream, true);
         return;
     }
-    attn_decode_launch(a, c.max_batch, e->stream, e->attn_depth, e->attn_var);
+    attn_decode_launch(a, c.max_batch, e->stream, e->attn_depth, e->attn_var, e->attn_lmax_small ? c.max_context : kAttnLMax);
 }
 
 static void k_o_proj(ntts_backbone* e, int i) {

@@ -78,10 +78,13 @@ NTTS_D void rope_pair(float x1, float x2, float c, float s, float& o1, float& o2
 //   the 12 extra waves' 192 KB of page requests queue on the CU's ~50 GB/s load path ahead of the prologue's RoPE row
 //   (prologue 1.9 -> 6.4 us); letting them request only after the prologue moves the wait into the softmax merge
 //   (14.8 us).  profiles/r02c_attn_timeline_b1.txt, r02f_sweep_b1_nw16_late_fw2.log.
-template <int kDepth, bool kTimeline = false, int kVar = 1, int NW = 4>
+// LMAX = longest context the instantiation can hold scores for: the score rows are most of the kernel's LDS (33 KB of 43 at 2048:
+//   three workgroups per CU).  Engines created with max_context <= 1024 take the 1024 instantiation (16.6 KB of 27: the register
+//   budget -- 102 -- then allows four), which matters where the grid is many rounds deep: batch 512 x 4 kv-heads = 2048 workgroups.
+template <int kDepth, bool kTimeline = false, int kVar = 1, int NW = 4, int LMAX = kAttnLMax>
 NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
     constexpr int NT = NW * 64;
-    NTTS_SHARED bf16_t sc[kGroupMax][kAttnLMax + 16];   // rounded scores, 33 KB; +32 B/row de-aliases the LDS banks
+    NTTS_SHARED bf16_t sc[kGroupMax][LMAX + 16];        // rounded scores, 33 KB at 2048; +32 B/row de-aliases the LDS banks
     NTTS_SHARED bf16_t qs[16][64];
     NTTS_SHARED bf16_t knew[64];
     NTTS_SHARED bf16_t vnew[64];
@@ -661,12 +664,13 @@ inline void attn_split_launch(const AttnSplitArgs& q, int batch, hipStream_t s, 
 }
 
 template <int kVar>
-inline void attn_decode_launch_v(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth) {
+inline void attn_decode_launch_v(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth, int max_ctx) {
     const dim3 grid(batch, p.nkv), block(256);
     if (p.tl) {   // diagnostics: the instantiation that records phase timestamps
         NTTS_LAUNCH((attn_decode_kernel<1, true, kVar>), grid, block, s, p);
         return;
     }
+    if (depth == 1 && max_ctx <= 1024) { NTTS_LAUNCH((attn_decode_kernel<1, false, kVar, 4, 1024>), grid, block, s, p); return; }
     switch (depth) {
         case 1: NTTS_LAUNCH((attn_decode_kernel<1, false, kVar>), grid, block, s, p); break;
         default: NTTS_LAUNCH((attn_decode_kernel<2, false, kVar>), grid, block, s, p); break;   // deeper rings measured slower (r01d)
@@ -679,11 +683,11 @@ inline void attn_decode_launch_small(const AttnDecodeArgs& p, int batch, hipStre
     if (depth >= 2) NTTS_LAUNCH((attn_decode_kernel<2, false, 7, 4>), grid, dim3(256), s, p);
     else NTTS_LAUNCH((attn_decode_kernel<1, false, 7, 4>), grid, dim3(256), s, p);
 }
-inline void attn_decode_launch(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth = kAttnDepthDefault, int var = 1) {
-    if ((var & 7) == 7) attn_decode_launch_v<7>(p, batch, s, depth);        // + V^T pages requested next to the K pages
-    else if ((var & 3) == 3) attn_decode_launch_v<3>(p, batch, s, depth);   // + non-temporal K / V^T page loads
-    else if (var & 1) attn_decode_launch_v<1>(p, batch, s, depth);
-    else attn_decode_launch_v<0>(p, batch, s, depth);
+inline void attn_decode_launch(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth = kAttnDepthDefault, int var = 1, int max_ctx = kAttnLMax) {
+    if ((var & 7) == 7) attn_decode_launch_v<7>(p, batch, s, depth, max_ctx);        // + V^T pages requested next to the K pages
+    else if ((var & 3) == 3) attn_decode_launch_v<3>(p, batch, s, depth, max_ctx);   // + non-temporal K / V^T page loads
+    else if (var & 1) attn_decode_launch_v<1>(p, batch, s, depth, max_ctx);
+    else attn_decode_launch_v<0>(p, batch, s, depth, max_ctx);
 }
 
 }  // namespace ntts
