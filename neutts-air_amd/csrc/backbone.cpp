@@ -114,6 +114,7 @@ struct ntts_backbone {
     bool attn_lmax_small = true;   // decode attention: the 1024-context instantiation when max_context allows (NTTS_ATTN_LMAX_SMALL)
     int xcd_xps = 0;           // XCDs per 64-row m-block of the decode batch (8 / (max_batch / 64)); 0 = the batch does not split that way
     int xl_min_m = 1024;       // rows from which the big-M GEMMs take the 256-row tiles (tests lower it: NTTS_XL_MIN_M)
+    bool pf_rope_q_fused = true;   // prefill: RoPE of the q heads inside the attention kernel's Q load (NTTS_PF_ROPE_Q_FUSED)
     bool pf_qkv_nat = true;    // prefill QKV on the natural-order 256 x 288 tile when N is a multiple of 288 but not of 256
     bool pf_lpt = true;        // prefill attention work list sorted by descending causal depth (longest tiles dispatched first)
     bool pf_resid = true;   // prefill: residual add in the o_proj / down_proj epilogue (EPI_RESID) instead of in the norm pass
@@ -378,6 +379,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->pf_rope_vec = env_int("NTTS_PF_ROPE_VEC", 1) != 0;
     e->pf_lpt = env_int("NTTS_PF_LPT", 1) != 0;
     e->pf_qkv_nat = env_int("NTTS_PF_QKV_NAT", 1) != 0;
+    e->pf_rope_q_fused = env_int("NTTS_PF_ROPE_Q_FUSED", 1) != 0;
     e->xl_min_m = env_int("NTTS_XL_MIN_M", 1024);
     e->attn_lmax_small = env_int("NTTS_ATTN_LMAX_SMALL", 1) != 0;
     e->xcd_xps = (B == 64 || B == 128 || B == 256 || B == 512) ? 8 / (B / 64) : 0;
@@ -1255,12 +1257,16 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
         r.qkv = e->qkv_pf; r.ld_qkv = e->NQKV; r.kpool = e->kv + (size_t)i * e->layer_stride; r.vpool = r.kpool + e->kv_half;
         r.block_table = e->block_table; r.max_pages = e->max_pages; r.meta = meta; r.rope_cos = e->rope_cos; r.rope_sin = e->rope_sin;
         r.nh = c.num_heads; r.nkv = c.num_kv_heads; r.T = Ti;
+        // the q heads are rotated by the attention kernel as it loads them (one read + one write of T x 896 values less per layer)
+        const bool rope_q_fused = e->pf_rope_q_fused && e->pf_rope_vec && e->NQKV % 8 == 0 && !e->pf_attn_simple;
+        r.skip_q = rope_q_fused ? 1 : 0;
         if (e->pf_rope_vec && e->NQKV % 8 == 0) NTTS_LAUNCH((rope_kv_write_vec_kernel), dim3((Ti + kRopeTokPerBlock - 1) / kRopeTokPerBlock), dim3(256), st, r);
         else NTTS_LAUNCH((rope_kv_write_kernel), dim3(Ti), dim3(256), st, r);
         AttnPrefillArgs a{};
         a.qkv = e->qkv_pf; a.ld_qkv = e->NQKV; a.out = e->attn_pf; a.ld_out = QD; a.kpool = r.kpool; a.vpool = r.vpool;
         a.block_table = e->block_table; a.max_pages = e->max_pages; a.meta = meta; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
         if (e->fp8) a.out_fp8_inv = 1.0f / w.xs[1];     // attn_pf rows hold QD e4m3 BYTES (ld_out counts bytes then)
+        if (rope_q_fused) { a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; }
         // Last layer: the KV pages are complete after the rope/KV-write above, and nothing but each prompt's LAST position
         // is read afterwards (it alone feeds the lm_head).  Attention runs on the one query tile per prompt that holds
         // it, then that row and its residual row are compacted and o_proj / the MLP run on n rows instead of T.

@@ -36,6 +36,7 @@ struct RopeWriteArgs {
     const bf16_t* rope_cos;
     const bf16_t* rope_sin;
     int nh, nkv, T;
+    int skip_q;                // rope_kv_write_vec_kernel: leave the q heads alone (attn_prefill_gqa_kernel rotates them as it loads them)
 };
 
 NTTS_KERNEL(256) void rope_kv_write_kernel(RopeWriteArgs p) {
@@ -79,14 +80,15 @@ NTTS_KERNEL(256) void rope_kv_write_kernel(RopeWriteArgs p) {
 // at 32 000 tokens.  (ld_qkv % 8 == 0: the engine's QKV width is a multiple of 64.)
 constexpr int kRopeTokPerBlock = 4;
 NTTS_KERNEL(256) void rope_kv_write_vec_kernel(RopeWriteArgs p) {
-    const int nheads = p.nh + 2 * p.nkv;
+    const int h_first = p.skip_q ? p.nh : 0;                     // skip_q: only the k and v heads have work here
+    const int nheads = p.nh + 2 * p.nkv - h_first;
     const int per_tok = nheads * 4;                              // work items per token
     const int t0 = blockIdx.x * kRopeTokPerBlock;
     for (int x = threadIdx.x; x < per_tok * kRopeTokPerBlock; x += 256) {
         const int tt = x / per_tok, y = x - tt * per_tok;
         const int t = t0 + tt;
         if (t >= p.T) break;
-        const int hh = y >> 2, i0 = (y & 3) * 8;
+        const int hh = h_first + (y >> 2), i0 = (y & 3) * 8;
         const int sq = p.meta.tok_seq[t];
         const int pos = p.meta.pos0[sq] + t - p.meta.tok_base[sq];
         bf16_t* h = p.qkv + (long)t * p.ld_qkv + hh * 64;
@@ -134,6 +136,8 @@ struct AttnPrefillArgs {
     int max_pages;
     PrefillMeta meta;
     int nh, nkv;
+    const bf16_t* rope_cos;    // attn_prefill_gqa_kernel: non-null = `qkv` holds the q heads as the QKV GEMM left them and the kernel applies
+    const bf16_t* rope_sin;    // RoPE while it loads its Q fragments (rope_kv_write_vec_kernel then only handles k and v: skip_q)
 };
 
 // grid (n_tiles, nh); 4 waves x 16 query rows
@@ -296,6 +300,34 @@ NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
         const bf16_t* qr = p.qkv + (long)(base + qpos) * p.ld_qkv + hh * 64 + g * 16;
         qB[h][0] = ld16<bf16x8>(qr);
         qB[h][1] = ld16<bf16x8>(qr + 8);
+    }
+    if (p.rope_cos) {
+        // RoPE of the queries on the way in (hf:models/qwen2/modeling_qwen2.py:113-135, the same rope_pair arithmetic the rope kernel
+        // applies: bit-identical q): lane (g, l15) holds d = 16 g .. 16 g + 15 of query qpos; the pair partner d +- 32 sits in lane g ^ 2
+        const bf16_t* cr = p.rope_cos + (long)qpos * 32 + (g & 1) * 16;
+        const bf16_t* sr = p.rope_sin + (long)qpos * 32 + (g & 1) * 16;
+        bf16x8 cv[2], sv[2];
+        cv[0] = ld16<bf16x8>(cr); cv[1] = ld16<bf16x8>(cr + 8);
+        sv[0] = ld16<bf16x8>(sr); sv[1] = ld16<bf16x8>(sr + 8);
+#pragma unroll
+        for (int h = 0; h < GH; ++h)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const u32x4 own = __builtin_bit_cast(u32x4, qB[h][f]);
+                u32x4 oth;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) oth[k] = (unsigned int)shfl_xor((int)own[k], 32);
+                const bf16x8 other = __builtin_bit_cast(bf16x8, oth);
+                bf16x8 r;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float mine = bf2f((bf16_t)qB[h][f][e]), theirs = bf2f((bf16_t)other[e]);
+                    float o1, o2;
+                    rope_pair(g < 2 ? mine : theirs, g < 2 ? theirs : mine, bf2f((bf16_t)cv[f][e]), bf2f((bf16_t)sv[f][e]), o1, o2);
+                    r[e] = (short)f2bf(g < 2 ? o1 : o2);
+                }
+                qB[h][f] = r;
+            }
     }
 
     // ---- page loader: wave 0/1 bring K (2 KB each), wave 2/3 bring V^T; one LDS-DMA instruction covers 1 KB
