@@ -406,7 +406,7 @@ NTTS_D void gemm_epilogue_nat(const GemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0
 // (34 column blocks instead of 38: 16.6 rounds instead of 18.55 per chunk, but the prompt pass got 12 % SLOWER, 32.4 vs 29.0 ms
 // per chunk: in natural order the SiLU * up epilogue runs on half the lanes -- gate rows in lanes g < 2, their up rows in g >= 2
 // -- and stores 8-byte pieces; profiles/r02k_sweep_pf_gu_nat.log).  The prefill QKV GEMM keeps it (N = 1152 = 4 x 288: 500 tiles
-// instead of 625 with every fifth half empty; 133 -> 98 us per launch).
+// instead of 625 with every fifth half empty; prompt pass -0.8 %).
 template <int WM, int WN, int TM, int EPI, int NS, int ABL = 0, int BK = 64, bool WNT = false, bool F8 = false, int TN = 4>
 NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     static_assert(BK == 64 || BK == 32, "ring slot K extent");
