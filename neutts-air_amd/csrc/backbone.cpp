@@ -21,6 +21,7 @@
 #include "kernels/gemm.h"
 #include "kernels/gemv.h"
 #include "kernels/norm.h"
+#include "kernels/qkv_rope.h"
 #include "kernels/sample.h"
 
 using namespace ntts;
@@ -96,6 +97,12 @@ struct ntts_backbone {
     int n_sampling = 0;              // running slots with do_sample=1
     bool graph_has_logits = false;
     int ks_qkv = 1, ks_o = 1, ks_d = 1;
+    // Tile path: the QKV projection with bias, rounding, RoPE and the KV append in its epilogue (qkv_rope.h); the attention kernel
+    // then has no prologue.  step_meta / rope_rows: the per-step row records that kernel reads (step_meta_kernel, once per step).
+    bool qkv_fused = false;
+    int st_qkvf = 3, ks_qkvf = 2;   // ring depth / K slices per workgroup of the fused QKV kernel
+    int* step_meta = nullptr;
+    bf16_t* rope_rows = nullptr;
     int st_qkv = 4, st_o = 4, st_gu = 3, st_d = 4;   // LDS ring depth of each skinny decode GEMM
     int head_stages = 2, l_stages = 2, pf_gh = 7, attn_depth = 1, attn_var = 1, gu_tile = 0;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
     bool gu_large = false, head_large = true, pf_attn_simple = false, use_xl = true;
@@ -358,6 +365,8 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     // QKV GEMM: 18 x 4 = 72 workgroups at batch 256 leave most CUs idle; split-K 2 with the slabs reduced in the attention
     // prologue measured -3.4 us on the GEMM, +1.7 us on the attention kernel, -1.8 % per step (profiles/r01e_sweep_qkv_split.jsonl)
     e->ks_qkv = env_int("NTTS_KSPLIT_QKV", 2);
+    e->st_qkvf = env_int("NTTS_STAGES_QKVF", 3);
+    e->ks_qkvf = env_int("NTTS_KS_QKVF", 2);
     if (e->ks_qkv > kAttnMaxSlabs) e->ks_qkv = kAttnMaxSlabs;
     const int ktile = e->fp8 ? 128 : 64;   // K extent of one 128-byte tile
     e->ks_o = env_int("NTTS_KSPLIT_O", pick_split(H / 64, c->num_heads * 64 / ktile));
@@ -408,6 +417,13 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     if (e->sks_o > max_slabs) e->sks_o = max_slabs;
     if (e->sks_d > max_slabs) e->sks_d = max_slabs;
     e->attn_depth_small = env_int("NTTS_ATTN_DEPTH_SMALL", 2);
+    e->qkv_fused = !e->small && e->w_tile_major && env_int("NTTS_QKV_FUSED", 1) != 0;
+    if (e->qkv_fused) {
+        CR_HIP(hipMalloc((void**)&e->step_meta, (size_t)B * 4 * sizeof(int)));
+        CR_HIP(hipMemset(e->step_meta, 0, (size_t)B * 4 * sizeof(int)));
+        CR_HIP(hipMalloc((void**)&e->rope_rows, (size_t)B * 64 * 2));
+        CR_HIP(hipMemset(e->rope_rows, 0, (size_t)B * 64 * 2));
+    }
     e->n_part = e->small ? V / 16 : !e->head_large ? (V + 63) / 64 : e->head_xl == 4 ? ((V + 287) / 288) * 3 : e->head_xl ? ((V + 255) / 256) * 4 : ((V + 127) / 128) * 2;
     CR_HIP(hipMalloc((void**)&e->h_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->xn_dec, (size_t)B * H * 2));
@@ -423,7 +439,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
         e->attn_split = env_int("NTTS_ATTN_SPLIT", 8);
         e->attn_split_ctx = env_int("NTTS_ATTN_SPLIT_CTX", 896);
         if (e->attn_split < 2 || e->attn_split > 32) e->attn_split = 0;
-        if (!e->small && (e->fp8 || e->ks_qkv < 2 || B * c->num_kv_heads >= 512)) e->attn_split = 0;
+        if (!e->small && (e->fp8 || (e->ks_qkv < 2 && !e->qkv_fused) || B * c->num_kv_heads >= 512)) e->attn_split = 0;
         if (e->attn_split) {
             const size_t n_sc = (size_t)B * c->num_kv_heads * kGroupMax * (c->max_context + 16), n_st = (size_t)B * c->num_kv_heads * e->attn_split * kGroupMax * 2,
                          n_os = (size_t)e->attn_split * B * c->num_heads * 64;
@@ -469,7 +485,7 @@ extern "C" void ntts_backbone_destroy(ntts_backbone* e) {
     if (e->graph_split) hipGraphExecDestroy(e->graph_split);
     void* bufs[] = {e->arena, e->gu_map_gate, e->gu_map_up, e->kv, e->ibuf, e->h_dec, e->xn_dec, e->qkv_dec, e->attn_dec,
                     e->act_dec, e->slabs, e->slabs2, e->h_alt, e->part_val, e->part_idx, e->logits, e->logits_bf16, e->h_pf, e->xn_pf, e->qkv_pf, e->attn_pf,
-                    e->o_pf, e->act_pf, e->meta_dev, e->as_scores, e->as_stats, e->as_oslabs};
+                    e->o_pf, e->act_pf, e->meta_dev, e->as_scores, e->as_stats, e->as_oslabs, e->step_meta, e->rope_rows};
     for (void* b : bufs)
         if (b) hipFree(b);
     for (auto& ev : e->ev)
@@ -862,9 +878,27 @@ static void lm_head_and_sample(ntts_backbone* e, int phase) {
     NTTS_LAUNCH((sample_greedy_kernel), dim3(e->cfg.max_batch), dim3(256), e->stream, s);
 }
 
+static void k_step_meta(ntts_backbone* e) {   // once per decode step, before the first fused QKV kernel
+    StepMetaArgs m{};
+    m.pos = e->sl.pos; m.state = e->sl.state; m.block_table = e->block_table; m.max_pages = e->max_pages; m.max_ctx = e->cfg.max_context;
+    m.M = e->cfg.max_batch; m.rope_cos = e->rope_cos; m.rope_sin = e->rope_sin; m.meta = e->step_meta; m.rope_rows = e->rope_rows;
+    NTTS_LAUNCH((step_meta_kernel), dim3((e->cfg.max_batch + 3) / 4), dim3(256), e->stream, m);
+}
+
 static void k_qkv(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H;
     const LayerW& w = e->layers[i];
+    if (e->qkv_fused) {
+        QkvRopeArgs a{};
+        a.X = e->xn_dec; a.ldx = H; a.W = w.wqkv; a.bias = w.bqkv; a.wscale = w.sqkv; a.xscale = w.xs[0];
+        a.M = B; a.N = e->NQKV; a.K = H; a.meta = e->step_meta; a.rope_rows = e->rope_rows;
+        a.q_out = e->qkv_dec; a.ld_q = e->NQKV; a.kpool = e->kv + (size_t)i * e->layer_stride;
+        a.nh = e->cfg.num_heads; a.nkv = e->cfg.num_kv_heads;
+        const bool place = (e->xcd_affine & 4) && e->xcd_xps;
+        if (e->fp8) qkv_rope_launch<true>(a, e->st_qkvf, e->ks_qkvf, place, e->stream);
+        else qkv_rope_launch<false>(a, e->st_qkvf, e->ks_qkvf, place, e->stream);
+        return;
+    }
     if (e->ks_qkv > 1)   // fp32 split-K slabs; the attention prologue sums them, adds the bias and rounds (attn_decode.h)
     {
         GemmArgs a = gemm_args(e, e->xn_dec, H, w.wqkv, H, nullptr, e->slabs, e->NQKV, B, e->NQKV, H, w.sqkv, w.xs[0]);
@@ -880,7 +914,7 @@ static void k_attn(ntts_backbone* e, int i) {
     const ntts_backbone_config& c = e->cfg;
     AttnDecodeArgs a{};
     a.qkv = e->qkv_dec; a.ld_qkv = e->NQKV; a.out = e->attn_dec; a.ld_out = c.num_heads * 64;
-    if (e->ks_qkv > 1) {
+    if (!e->qkv_fused && e->ks_qkv > 1) {
         a.qkv_slabs = e->slabs; a.nslab = gemm_nsplit(e->H, e->ks_qkv, ktile_of(e)); a.slab_rows = c.max_batch; a.qkv_bias = e->layers[i].bqkv;
     }
     a.kpool = e->kv + (size_t)i * e->layer_stride; a.vpool = a.kpool + e->kv_half;
@@ -889,12 +923,14 @@ static void k_attn(ntts_backbone* e, int i) {
     a.tl = e->attn_tl;
     a.xcd_rows = ((e->xcd_affine & 4) && !e->attn_tl) ? e->xcd_xps : 0;
     if (e->fp8) a.out_fp8_inv = 1.0f / e->layers[i].xs[1];   // attention output = o_proj's input
-    if (e->split_active && !e->attn_tl && a.qkv_slabs) {       // long contexts below 2 workgroups per CU: context-split attention + combine
+    if (e->split_active && !e->attn_tl && (a.qkv_slabs || e->qkv_fused)) {       // long contexts below 2 workgroups per CU: context-split attention + combine
         AttnSplitArgs q{};
         q.a = a; q.scores = e->as_scores; q.ld_scores = c.max_context + 16; q.stats = e->as_stats; q.oslabs = e->as_oslabs; q.nsplit = e->attn_split;
-        attn_split_launch(q, c.max_batch, e->stream, true);
+        q.a.slab_rows = c.max_batch;
+        attn_split_launch(q, c.max_batch, e->stream, true, e->qkv_fused);
         return;
     }
+    if (e->qkv_fused) { attn_decode_launch_pre(a, c.max_batch, e->stream, e->attn_depth, e->attn_var, e->attn_lmax_small ? c.max_context : kAttnLMax); return; }
     attn_decode_launch(a, c.max_batch, e->stream, e->attn_depth, e->attn_var, e->attn_lmax_small ? c.max_context : kAttnLMax);
 }
 
@@ -1037,6 +1073,7 @@ static void decode_step(ntts_backbone* e) {
     n0.normed_out = e->xn_dec; n0.M = B; n0.H = H; n0.eps = c.rms_eps;
     if (e->fp8) n0.out_fp8_inv = 1.0f / e->layers[0].xs[0];
     add_rmsnorm_launch(n0, e->stream, e->norm_wide);
+    if (e->qkv_fused) k_step_meta(e);
     for (int i = 0; i < c.num_layers; ++i) {
         const bool last = i + 1 == c.num_layers;
         k_qkv(e, i);
@@ -1635,6 +1672,7 @@ extern "C" int ntts_backbone_attn_timeline(ntts_backbone* e, int32_t layer, uint
     unsigned long long* tl = (unsigned long long*)buf.p;
     HIPCHK(e, hipMemsetAsync(tl, 0, n * 8, e->stream));
     auto attn = [&](int i) { if (e->small) ks_attn(e, i); else k_attn(e, i); };
+    if (e->qkv_fused) k_step_meta(e);
     attn((layer + 1) % e->cfg.num_layers);     // another layer first: this launch is neither the first nor cache-warm
     e->attn_tl = tl;
     attn(layer);
@@ -1667,7 +1705,7 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
     const double wb = e->fp8 ? 1.0 : 2.0;      // bytes per matrix weight / per GEMM-input activation element
     const double act = (double)B * wb;
     const int kt_ = ktile_of(e);
-    const bool qkv_split = e->ks_qkv > 1;   // QKV leaves fp32 split-K slabs that the attention prologue reduces
+    const bool qkv_split = e->ks_qkv > 1 && !e->qkv_fused;   // QKV leaves fp32 split-K slabs that the attention prologue reduces
     // Every replay works on the NEXT layer's weights / KV pool, as consecutive launches of this kernel do inside the
     // decode step: one layer's operands (84 MB of KV at batch 256) would sit in the 256 MB Infinity Cache when replayed
     // alone, all layers together (2 GB) do not -- so the timing below is HBM-cold like the in-graph launches.
@@ -1715,6 +1753,7 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
         default: return fail(e, NTTS_EINVAL, "unknown kernel id %d", which);
     }
     if (which == 6 && B > e->Tmax) return fail(e, NTTS_EINVAL, "scratch too small");
+    if (e->qkv_fused) k_step_meta(e);   // the fused QKV kernel appends at the CURRENT position (not yet written), like the step it replays
     run(which, L - 1);  // warm (code, TLBs); the timed replays start from layer 0
     HIPCHK(e, hipEventRecord(e->ev[2], st));
     for (int i = 0; i < iters; ++i) run(which, i % L);

@@ -81,7 +81,10 @@ NTTS_D void rope_pair(float x1, float x2, float c, float s, float& o1, float& o2
 // LMAX = longest context the instantiation can hold scores for: the score rows are most of the kernel's LDS (33 KB of 43 at 2048:
 //   three workgroups per CU).  Engines created with max_context <= 1024 take the 1024 instantiation (16.6 KB of 27: the register
 //   budget -- 102 -- then allows four), which matters where the grid is many rounds deep: batch 512 x 4 kv-heads = 2048 workgroups.
-template <int kDepth, bool kTimeline = false, int kVar = 1, int NW = 4, int LMAX = kAttnLMax>
+// kPre: the q heads arrive rotated and this step's K entry is already in its page -- the fused QKV kernel of the tile path did both
+//   (qkv_rope.h): no prologue, the K pages are the kernel's first large requests.  The v row arrives as bf16 and is placed into the
+//   transposed page here (64 two-byte stores per workgroup, off the critical path; pass 2 takes it from LDS).
+template <int kDepth, bool kTimeline = false, int kVar = 1, int NW = 4, int LMAX = kAttnLMax, bool kPre = false>
 NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
     constexpr int NT = NW * 64;
     NTTS_SHARED bf16_t sc[kGroupMax][LMAX + 16];        // rounded scores, 33 KB at 2048; +32 B/row de-aliases the LDS banks
@@ -124,9 +127,53 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
             else { k[u][0] = ld16<bf16x8>(kr); k[u][1] = ld16<bf16x8>(kr + 8); }
         }
     };
+    auto load_v_at = [&](long page, bf16x8 (&v)[4]) {
+        const bf16_t* vp = p.vpool + (page * p.nkv + kvh) * 64 * kPage;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            if constexpr (kVar & 2) v[nt] = ld16_nt<bf16x8>(vp + (nt * 16 + l15) * kPage + g * 8);   // K/V pages: read once per step
+            else v[nt] = ld16<bf16x8>(vp + (nt * 16 + l15) * kPage + g * 8);
+        }
+    };
+    auto load_k = [&](int pg, bf16x8 (&k)[2][2]) { load_k_at(bt[pg], k); };
+    auto load_v = [&](int pg, bf16x8 (&v)[4]) { load_v_at(bt[pg], v); };
     // K pages do not depend on this step's q/k/v: they stream under the RoPE prologue (the slot of the token appended
     // below is overridden from LDS, whatever the page held).  Register ring of kDepth pages per wave.
     bf16x8 kq[kDepth][2][2];
+    bf16x8 vq[kDepth][4];
+    bf16x8 qB[2];
+    bf16_t vrow_new = 0;       // kPre: element tid of this step's v row / the page of position P (threads 0..63)
+    long vpage_new = 0;
+    const int L = P + 1;
+    const int npages = (L + kPage - 1) / kPage;
+    const int last_page = npages - 1;
+  if constexpr (kPre) {
+    // ---- no prologue: the rotated q heads are one bf16 row (requested while the block-table entries are on their way), the
+    //      K pages follow as soon as those entries are known
+    {
+        const bf16_t* qrow = p.qkv + (long)b * p.ld_qkv + (long)(kvh * group + (l15 < group ? l15 : 0)) * 64 + g * 16;
+        qB[0] = ld16<bf16x8>(qrow);
+        qB[1] = ld16<bf16x8>(qrow + 8);
+    }
+    // this step's v row (bf16, from the fused QKV kernel) and the page it belongs in: requested BEFORE the K pages (a wave's loads
+    // return in order), used only after pass 1 -- a wave that had to wait for them first would issue its next K page a whole memory
+    // latency late and hold the other three up at the merge barrier (measured: +1 us per launch)
+    if (tid < 64) vrow_new = p.qkv[(long)b * p.ld_qkv + (long)(p.nh + p.nkv + kvh) * 64 + tid];
+    if (st != 1) return;  // block-uniform
+    mark(1);
+    if (tid < 64) vpage_new = bt[P / kPage];
+#pragma unroll
+    for (int j = 0; j < kDepth; ++j) load_k_at(bt0[j], kq[j]);
+    if constexpr (kVar & 4) {
+#pragma unroll
+        for (int j = 0; j < kDepth; ++j) load_v_at(bt0[j], vq[j]);
+    }
+    if (l15 >= group) {   // heads beyond the GQA group: zero columns of Q^T
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { qB[0][e] = 0; qB[1][e] = 0; }
+    }
+    mark(2);
+  } else {
     if constexpr (!(kVar & 1)) {
 #pragma unroll
         for (int j = 0; j < kDepth; ++j) load_k_at(bt0[j], kq[j]);
@@ -182,9 +229,6 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
     }
     if (st != 1) return;  // block-uniform
     mark(1);
-    const int L = P + 1;
-    const int npages = (L + kPage - 1) / kPage;
-    const int last_page = npages - 1;
     long new_page = 0;
     bf16_t rc[ITS], rs[ITS];
 #pragma unroll
@@ -197,21 +241,10 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
             if ((t >> 5) == group) new_page = bt[P / kPage];
         }
     }
-    auto load_k = [&](int pg, bf16x8 (&k)[2][2]) { load_k_at(bt[pg], k); };
     if constexpr (kVar & 1) {
 #pragma unroll
         for (int j = 0; j < kDepth; ++j) load_k_at(bt0[j], kq[j]);
     }
-    auto load_v_at = [&](long page, bf16x8 (&v)[4]) {
-        const bf16_t* vp = p.vpool + (page * p.nkv + kvh) * 64 * kPage;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            if constexpr (kVar & 2) v[nt] = ld16_nt<bf16x8>(vp + (nt * 16 + l15) * kPage + g * 8);   // K/V pages: read once per step
-            else v[nt] = ld16<bf16x8>(vp + (nt * 16 + l15) * kPage + g * 8);
-        }
-    };
-    auto load_v = [&](int pg, bf16x8 (&v)[4]) { load_v_at(bt[pg], v); };
-    bf16x8 vq[kDepth][4];
     // kVar & 4: the first V^T pages are requested right behind the first K pages instead of after the score pass -- at small
     // batch the kernel is one chain of dependent round trips (block table -> K -> scores -> V -> PV) and this removes one
     if constexpr (kVar & 4) {
@@ -245,9 +278,10 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
     sync();
     mark(2);
 
-    bf16x8 qB[2];
     qB[0] = ld16<bf16x8>(&qs[l15][g * 16]);
     qB[1] = ld16<bf16x8>(&qs[l15][g * 16 + 8]);
+
+  }
 
     // ---- pass 1: S^T = K Q^T per 16-key sub-tile, bf16-rounded scores -> LDS, with the softmax statistics carried
     //      online per lane (running max and sum of exp in fp32), so that one merge after the pass yields the row max
@@ -263,13 +297,15 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) { kc[u][0] = kq[j][u][0]; kc[u][1] = kq[j][u][1]; }
                 if (pg + NW * kDepth < npages) load_k(pg + NW * kDepth, kq[j]);
-                if (pg == last_page) {  // the token appended this step comes from LDS, not from HBM
+                if constexpr (!kPre) {
+                    if (pg == last_page) {  // the token appended this step comes from LDS, not from HBM
 #pragma unroll
-                    for (int u = 0; u < 2; ++u)
-                        if (pg * kPage + u * 16 + l15 == P) {
-                            kc[u][0] = ld16<bf16x8>(&knew[g * 16]);
-                            kc[u][1] = ld16<bf16x8>(&knew[g * 16 + 8]);
-                        }
+                        for (int u = 0; u < 2; ++u)
+                            if (pg * kPage + u * 16 + l15 == P) {
+                                kc[u][0] = ld16<bf16x8>(&knew[g * 16]);
+                                kc[u][1] = ld16<bf16x8>(&knew[g * 16 + 8]);
+                            }
+                    }
                 }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
@@ -297,6 +333,12 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
         }
     }
     mark(4);
+    if constexpr (kPre) {
+        if (tid < 64) {   // v row -> its slot of the transposed page, and LDS (pass 2 reads it there, behind the merge barrier)
+            vnew[tid] = vrow_new;
+            p.vpool[(vpage_new * p.nkv + kvh) * 64 * kPage + (long)tid * kPage + v_slot(P % kPage)] = vrow_new;
+        }
+    }
     // ---- V^T pages are independent of the scores: (kVar & 4: already requested next to the K pages) else get the first
     //      ones in flight under the softmax reductions
     if constexpr (!(kVar & 4)) {
@@ -410,6 +452,7 @@ struct AttnSplitArgs {
     int nsplit;
 };
 
+template <bool kPre>
 NTTS_KERNEL(256) void attn_split_scores_kernel(AttnSplitArgs q) {
     constexpr int NW = 4, NT = 256;
     const AttnDecodeArgs& p = q.a;
@@ -424,6 +467,27 @@ NTTS_KERNEL(256) void attn_split_scores_kernel(AttnSplitArgs q) {
     const int* bt = p.block_table + (long)b * p.max_pages;
     const int st = p.state[b];
     const int P = p.pos[b];
+    const int L = P + 1;
+    const int npages = (L + kPage - 1) / kPage;
+    const int last_page = npages - 1;
+    const int ppc = (npages + q.nsplit - 1) / q.nsplit;          // pages per chunk
+    const int pg_lo = ch * ppc, pg_hi = (pg_lo + ppc < npages) ? pg_lo + ppc : npages;
+    bf16x8 qB[2];
+  if constexpr (kPre) {   // rotated q rows + an appended K / V^T entry from the fused QKV kernel (qkv_rope.h)
+    const bf16_t* qrow = p.qkv + (long)b * p.ld_qkv + (long)(kvh * group + (l15 < group ? l15 : 0)) * 64 + g * 16;
+    qB[0] = ld16<bf16x8>(qrow);
+    qB[1] = ld16<bf16x8>(qrow + 8);
+    if (st != 1) return;  // block-uniform
+    if (l15 >= group) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { qB[0][e] = 0; qB[1][e] = 0; }
+    }
+    if (ch == 0 && tid < 64) {   // chunk 0 places this step's v row into its slot of the transposed page (read by the PV launch)
+        const bf16_t v = p.qkv[(long)b * p.ld_qkv + (long)(p.nh + p.nkv + kvh) * 64 + tid];
+        const long new_page = bt[P / kPage];
+        p.vpool[(new_page * p.nkv + kvh) * 64 * kPage + (long)tid * kPage + v_slot(P % kPage)] = v;
+    }
+  } else {
     // ---- prologue operands (every chunk rebuilds q; all of them need the new k for the page that holds position P)
     const int nitems = (group + 1) * 32;
     const float* sbase[kAttnMaxSlabs];
@@ -460,11 +524,6 @@ NTTS_KERNEL(256) void attn_split_scores_kernel(AttnSplitArgs q) {
         }
     }
     if (st != 1) return;  // block-uniform
-    const int L = P + 1;
-    const int npages = (L + kPage - 1) / kPage;
-    const int last_page = npages - 1;
-    const int ppc = (npages + q.nsplit - 1) / q.nsplit;          // pages per chunk
-    const int pg_lo = ch * ppc, pg_hi = (pg_lo + ppc < npages) ? pg_lo + ppc : npages;
 #pragma unroll
     for (int it = 0; it < ITS; ++it) {
         const int t = tid + it * NT;
@@ -492,9 +551,9 @@ NTTS_KERNEL(256) void attn_split_scores_kernel(AttnSplitArgs q) {
     }
     for (int t = tid; t < (16 - group) * 64; t += NT) qs[group + t / 64][t % 64] = 0;
     sync();
-    bf16x8 qB[2];
     qB[0] = ld16<bf16x8>(&qs[l15][g * 16]);
     qB[1] = ld16<bf16x8>(&qs[l15][g * 16 + 8]);
+  }
     constexpr float kMasked = -1.0e30f;
     float lmax = kMasked, lsum = 0.f;
     bf16_t* srow = q.scores + ((long)(b * p.nkv + kvh) * kGroupMax + (l15 < kGroupMax ? l15 : 0)) * q.ld_scores;
@@ -507,13 +566,15 @@ NTTS_KERNEL(256) void attn_split_scores_kernel(AttnSplitArgs q) {
             kc[u][0] = ld16<bf16x8>(kr);
             kc[u][1] = ld16<bf16x8>(kr + 8);
         }
-        if (pg == last_page) {  // the token appended this step comes from LDS (chunk 0's store may not have landed)
+        if constexpr (!kPre) {
+            if (pg == last_page) {  // the token appended this step comes from LDS (chunk 0's store may not have landed)
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-                if (pg * kPage + u * 16 + l15 == P) {
-                    kc[u][0] = ld16<bf16x8>(&knew[g * 16]);
-                    kc[u][1] = ld16<bf16x8>(&knew[g * 16 + 8]);
-                }
+                for (int u = 0; u < 2; ++u)
+                    if (pg * kPage + u * 16 + l15 == P) {
+                        kc[u][0] = ld16<bf16x8>(&knew[g * 16]);
+                        kc[u][1] = ld16<bf16x8>(&knew[g * 16 + 8]);
+                    }
+            }
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -656,25 +717,31 @@ NTTS_KERNEL(256) void attn_split_combine_kernel(AttnSplitArgs q) {
     }
 }
 
-inline void attn_split_launch(const AttnSplitArgs& q, int batch, hipStream_t s, bool combine = false) {
+inline void attn_split_launch(const AttnSplitArgs& q, int batch, hipStream_t s, bool combine = false, bool pre = false) {
     const dim3 grid(batch, q.a.nkv, q.nsplit), block(256);
-    NTTS_LAUNCH((attn_split_scores_kernel), grid, block, s, q);
+    if (pre) NTTS_LAUNCH((attn_split_scores_kernel<true>), grid, block, s, q);
+    else NTTS_LAUNCH((attn_split_scores_kernel<false>), grid, block, s, q);
     NTTS_LAUNCH((attn_split_pv_kernel), grid, block, s, q);
     if (combine) NTTS_LAUNCH((attn_split_combine_kernel), dim3(batch), block, s, q);
 }
 
-template <int kVar>
+template <int kVar, bool kPre = false>
 inline void attn_decode_launch_v(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth, int max_ctx) {
     const dim3 grid(batch, p.nkv), block(256);
     if (p.tl) {   // diagnostics: the instantiation that records phase timestamps
-        NTTS_LAUNCH((attn_decode_kernel<1, true, kVar>), grid, block, s, p);
+        NTTS_LAUNCH((attn_decode_kernel<1, true, kVar, 4, kAttnLMax, kPre>), grid, block, s, p);
         return;
     }
-    if (depth == 1 && max_ctx <= 1024) { NTTS_LAUNCH((attn_decode_kernel<1, false, kVar, 4, 1024>), grid, block, s, p); return; }
+    if (depth == 1 && max_ctx <= 1024) { NTTS_LAUNCH((attn_decode_kernel<1, false, kVar, 4, 1024, kPre>), grid, block, s, p); return; }
     switch (depth) {
-        case 1: NTTS_LAUNCH((attn_decode_kernel<1, false, kVar>), grid, block, s, p); break;
-        default: NTTS_LAUNCH((attn_decode_kernel<2, false, kVar>), grid, block, s, p); break;   // deeper rings measured slower (r01d)
+        case 1: NTTS_LAUNCH((attn_decode_kernel<1, false, kVar, 4, kAttnLMax, kPre>), grid, block, s, p); break;
+        default: NTTS_LAUNCH((attn_decode_kernel<2, false, kVar, 4, kAttnLMax, kPre>), grid, block, s, p); break;   // deeper rings measured slower (r01d)
     }
+}
+// tile path behind the fused QKV kernel (qkv_rope.h): q rows rotated, the new K / V^T entry already in its page
+inline void attn_decode_launch_pre(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth, int var, int max_ctx) {
+    if (var & 4) attn_decode_launch_v<5, true>(p, batch, s, depth, max_ctx);        // V^T pages requested next to the K pages
+    else attn_decode_launch_v<1, true>(p, batch, s, depth, max_ctx);
 }
 // small-batch variant: `depth` pages per wave in flight, V^T requested next to K (kVar 7)
 inline void attn_decode_launch_small(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth) {

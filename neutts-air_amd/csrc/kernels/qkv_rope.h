@@ -1,0 +1,280 @@
+// qkv_rope.h -- the decode step's QKV projection with everything between the GEMM and the attention scores fused in:
+//   q/k/v = nn.Linear(x) (+ bias, ONE rounding to bf16)          hf:models/qwen2/modeling_qwen2.py:206-208
+//   q, k  = apply_rotary_pos_emb(q, k, cos, sin)                  hf:models/qwen2/modeling_qwen2.py:113-135,211
+//   cache.update(k, v)                                            hf:models/qwen2/modeling_qwen2.py:214, hf:cache_utils.py:127-146
+// The rotated q heads and the v heads leave as one bf16 row per sequence; the rotated k head goes straight into the sequence's
+// K page ([page][kv_head][32][64], attn_decode.h).  The attention kernel behind it then starts with its K pages instead of a
+// prologue (it used to sum this GEMM's fp32 split-K slabs, add the bias, round, rotate and append -- ~3 us during which none of
+// its 512 workgroups streamed a byte); it still places its own v row into the transposed V^T page, off its critical path.
+//
+// Tile: 32 batch rows x 64 output columns (= ONE head: the RoPE partner of feature i is feature i + 32 of the same head, held by
+// lane ^ 32 of the same wave) per workgroup of 2 row halves x KS K SLICES.  The K split lives inside the workgroup: every
+// slice's tiles stream through the same LDS ring, each wave pair multiplies its own slice, and the fp32 partial sums meet in LDS
+// (slice order; at KS = 2 that is the order the two split-K slabs were summed in, so the bits are those of the two-slab path this
+// replaces) -- no slab round trip through HBM.  8 x 18 = 144 workgroups at batch 256.
+#pragma once
+#include <ntts/dev.h>
+#include "attn_decode.h"
+
+namespace ntts {
+
+// ---- per-step row record: what the fused epilogue needs about each sequence, gathered ONCE per decode step (the 24 layers
+//      share it) so that no layer's QKV kernel has a dependent load chain (position -> RoPE row / block-table entry)
+struct StepMetaArgs {
+    const int* pos;          // [M]
+    const int* state;        // [M]
+    const int* block_table;  // [M][max_pages]
+    int max_pages, max_ctx, M;
+    const bf16_t* rope_cos;  // [max_ctx][32]
+    const bf16_t* rope_sin;
+    int* meta;               // [M][4] = {state, pos, page of pos, slot of pos in its page}
+    bf16_t* rope_rows;       // [M][64] = cos[pos][0..31] | sin[pos][0..31]
+};
+NTTS_KERNEL(256) void step_meta_kernel(StepMetaArgs p) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), i = threadIdx.x & 63;
+    if (row >= p.M) return;
+    int P = p.pos[row];
+    if (P < 0) P = 0;
+    if (P > p.max_ctx - 1) P = p.max_ctx - 1;      // (free slots hold stale positions: any valid row will do, nothing uses it)
+    p.rope_rows[(long)row * 64 + i] = i < 32 ? p.rope_cos[(long)P * 32 + i] : p.rope_sin[(long)P * 32 + i - 32];
+    if (i == 0) {
+        int* m = p.meta + (long)row * 4;
+        m[0] = p.state[row];
+        m[1] = P;
+        m[2] = p.block_table[(long)row * p.max_pages + P / kPage];
+        m[3] = P % kPage;
+    }
+}
+
+struct QkvRopeArgs {
+    const bf16_t* X;         // [M][K] normalised rows (bf16; fp8 model: e4m3 bytes)
+    long ldx;
+    const bf16_t* W;         // [N][K] tile-major (gemm.h GemmArgs::w_tile_major), rows q heads | k heads | v heads
+    const bf16_t* bias;      // [N] (zeros for a model without attention bias)
+    const float* wscale;     // fp8 model: per-output-channel weight scales, xscale = the static input scale
+    float xscale;
+    int M, N, K;
+    int kps;                 // 128-byte K tiles per half (the launcher sets it)
+    const int* meta;         // [M][4] step_meta_kernel
+    const bf16_t* rope_rows; // [M][64]
+    bf16_t* q_out;           // [M][ld_q] q|k|v row: the rotated q heads and the v heads (bf16); the k columns stay unwritten
+    long ld_q;
+    bf16_t* kpool;           // this layer's K pages
+    int nh, nkv;
+    int xcd_mpx;             // > 0: XCD x (workgroup b runs on XCD b % 8 -- an observation, speed only) takes the xcd_mpx 32-row blocks
+                             // that hold batch rows [x * M / 8, (x + 1) * M / 8): the rows the attention workgroups of that XCD read
+                             // (attn_decode.h xcd_rows) and whose o_proj tiles run there (gemm.h xcd_maffine)
+};
+
+// KS = K slices inside the workgroup (2 or 4): the workgroup is 2 row halves x KS slices = 2 * KS waves, a k-step brings in one
+//   128-byte tile of EVERY slice (KS x 12 KB), so K = 896 is 7 steps at KS = 2 and 4 at KS = 4 (slices 4 + 4 + 3 + 3 tiles).
+//   The partial sums meet in LDS and are added in slice order.
+template <int NS, bool F8, int KS>
+NTTS_KERNEL(KS * 128) void qkv_rope_kernel(QkvRopeArgs p) {
+    constexpr int ESZ = F8 ? 1 : 2;
+    constexpr int BM = 32, BN = 64, ROWS = BM + BN;      // LDS rows (128 bytes each) per ring slot and K slice
+    constexpr int NINST = ROWS / 8;                       // wave-instructions (8 rows x 128 B) per slot and slice: 12
+    constexpr int PER_WAVE = NINST / 2;                   // the two waves of a K slice split them
+    static_assert(KS == 2 || KS == 4, "K slices per workgroup");
+    static_assert(NS >= 2 && (NS - 1) * PER_WAVE + 13 <= 63, "vmcnt range (ring + the epilogue operands requested at entry)");
+    NTTS_SHARED bf16_t lds[NS * KS * ROWS * 64];
+    static_assert(sizeof(f32x4) * KS * 2 * 4 * 64 <= sizeof(bf16_t) * NS * KS * ROWS * 64, "exchange area fits the ring");
+    typedef f32x4 (*XchT)[2][4][64];
+    XchT xch = (XchT)lds;                                 // [slice][row half][j][lane] partial sums (the ring, once everybody is done with it)
+    auto swz = [](int rho) { return (rho >> 1) & 7; };
+
+    const int lane = lane_id(), wave = wave_id();
+    const int wm = wave & 1, kh = wave >> 1;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int nblocks = p.N >> 6;
+    int mb, nb;
+    if (p.xcd_mpx > 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        mb = xcd * p.xcd_mpx + j % p.xcd_mpx;             // m fastest: co-resident workgroups share a W tile
+        nb = j / p.xcd_mpx;
+    } else {
+        const int mblocks = (p.M + BM - 1) / BM;
+        mb = blockIdx.x % mblocks;
+        nb = blockIdx.x / mblocks;
+    }
+    if (nb >= nblocks) return;                            // (block-uniform, before any barrier)
+    const int m0 = mb * BM, n0 = nb * BN;
+    const int ktiles = F8 ? p.K >> 7 : p.K >> 6;
+    int nk = ktiles - kh * p.kps;                         // this slice's k-tiles (the later slices may be shorter, even empty)
+    if (nk > p.kps) nk = p.kps;
+    if (nk < 0) nk = 0;
+
+    // ---- epilogue operands: requested before anything else, so they are the oldest entries of the in-order vector-memory counter
+    //      and every later counted wait covers them.  The epilogue is shared out: wave (wm, kh) finishes NJ = 4 / KS of the four
+    //      4-feature groups j of its row half -- features nb16 + e0 .. + 4 NJ - 1 of token m in lane (g, l15)
+    constexpr int NJ = 4 / KS;
+    const int m = m0 + wm * 16 + l15;
+    const int mc = m < p.M ? m : p.M - 1;
+    const int e0 = kh * NJ * 4;
+    const int nb16 = n0 + g * 16, nb16p = n0 + (g ^ 2) * 16;             // own features / their RoPE partners (i <-> i + 32)
+    const u32x4 meta = ld16<u32x4>(p.meta + (long)mc * 4);
+    bf16x4 cs[NJ], sn[NJ], bs[NJ], bsp[NJ];
+    f32x4 wsc[NJ], wscp[NJ];
+    {
+        const bf16_t* rr = p.rope_rows + (long)mc * 64 + (g & 1) * 16 + e0;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            cs[jj] = *(const bf16x4*)(rr + jj * 4);
+            sn[jj] = *(const bf16x4*)(rr + 32 + jj * 4);
+            bs[jj] = *(const bf16x4*)(p.bias + nb16 + e0 + jj * 4);
+            bsp[jj] = *(const bf16x4*)(p.bias + nb16p + e0 + jj * 4);
+            if constexpr (F8) {
+                wsc[jj] = ld16<f32x4>(p.wscale + nb16 + e0 + jj * 4);
+                wscp[jj] = ld16<f32x4>(p.wscale + nb16p + e0 + jj * 4);
+            }
+        }
+    }
+
+    // ---- loader: the waves of K slice kh bring in that slice's tiles
+    const char* src[PER_WAVE];
+    bool is_w[PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+        const int inst = wm + 2 * i;
+        const int rho = inst * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ swz(rho);
+        is_w[i] = inst * 8 >= BM;
+        if (rho < BM) {
+            int mr = m0 + rho;
+            if (mr > p.M - 1) mr = p.M - 1;
+            src[i] = (const char*)p.X + (long)mr * p.ldx * ESZ + c * 16;
+        } else {
+            const int q = rho - BM;                       // LDS row j*16 + i16  <->  feature (i16>>2)*16 + j*4 + (i16&3) (gemm.h)
+            const int j = (q >> 4) & 3, i16 = q & 15;
+            const int n = n0 + (i16 >> 2) * 16 + j * 4 + (i16 & 3);
+            src[i] = (const char*)p.W + (long)(n >> 6) * 64 * p.K * ESZ + (n & 63) * 128 + c * 16;
+        }
+    }
+    const int kt0 = kh * p.kps;
+    auto stage = [&](int kt, int slot) {
+#pragma unroll
+        for (int i = 0; i < PER_WAVE; ++i) {
+            const int inst = wm + 2 * i;
+            const char* gp = src[i] + (long)(kt0 + kt) * (is_w[i] ? 8192 : 128);
+            glds16(gp, lds + ((slot * KS + kh) * ROWS) * 64 + inst * 512);
+        }
+    };
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int xrho = wm * 16 + l15;
+    const int xoff = xrho * 64, xsw = swz(xrho);
+    int woff[4], wsw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rho = BM + j * 16 + l15;
+        woff[j] = rho * 64;
+        wsw[j] = swz(rho);
+    }
+
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) stage(s, s);
+    int buf = 0;
+    for (int kt = 0; kt < p.kps; ++kt) {                  // (every slice runs kps rounds of the barrier)
+        if (kt < nk) {
+            if (kt + NS - 2 < nk) wait_vmem_le<(NS - 2) * PER_WAVE>(); else wait_vmem();
+        }
+        sync_keep_dma();
+        if (kt + NS - 1 < nk) stage(kt + NS - 1, buf == 0 ? NS - 1 : buf - 1);
+        const bf16_t* base = lds + ((buf * KS + kh) * ROWS) * 64;
+        buf = buf + 1 == NS ? 0 : buf + 1;
+        if (kt >= nk) continue;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int c = ks * 4 + g;
+            const bf16x8 xb = ld16<bf16x8>(base + xoff + ((c ^ xsw) << 3));
+            bf16x8 wa[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wa[j] = ld16<bf16x8>(base + woff[j] + ((c ^ wsw[j]) << 3));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (F8) {
+                    const i64x2 w2 = __builtin_bit_cast(i64x2, wa[j]), x2 = __builtin_bit_cast(i64x2, xb);
+                    acc[j] = mfma16_fp8(w2[0], x2[0], acc[j]);
+                    acc[j] = mfma16_fp8(w2[1], x2[1], acc[j]);
+                } else {
+                    acc[j] = mfma16(wa[j], xb, acc[j]);
+                }
+            }
+        }
+    }
+
+    // ---- the K slices meet in LDS (every wave parks its partial sums; the ring is free once everybody is past the k-loop), and
+    //      every wave finishes its share: sums in slice order + bias -> ONE rounding (the nn.Linear output), then RoPE against the
+    //      partner feature i +- 32, which sits in the same table at lane ^ 32 -- no shuffles
+    sync();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xch[kh][wm][j][lane] = acc[j];
+    sync();
+    const int hd = n0 >> 6;                               // which head this workgroup's 64 columns are
+    const int st = (int)meta[0], page = (int)meta[2], slot = (int)meta[3];
+    const bool mok = m < p.M, run = mok && st == 1;
+    const bool rot = hd < p.nh + p.nkv;                   // a q or k head: rotate (rope_pair: every op rounded to bf16)
+    alignas(16) bf16_t out[NJ * 4];
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+        const int j = kh * NJ + jj;
+        f32x4 so = xch[0][wm][j][lane], sp = xch[0][wm][j][lane ^ 32];
+        if constexpr (F8) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { so[r] *= p.xscale * wsc[jj][r]; sp[r] *= p.xscale * wscp[jj][r]; }
+        }
+#pragma unroll
+        for (int q = 1; q < KS; ++q) {
+            const f32x4 o = xch[q][wm][j][lane], op = xch[q][wm][j][lane ^ 32];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (F8) { so[r] += o[r] * (p.xscale * wsc[jj][r]); sp[r] += op[r] * (p.xscale * wscp[jj][r]); }
+                else { so[r] += o[r]; sp[r] += op[r]; }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bf16_t vo = f2bf(so[r] + bf2f((bf16_t)bs[jj][r])), vp = f2bf(sp[r] + bf2f((bf16_t)bsp[jj][r]));
+            const float xo = bf2f(vo), xp = bf2f(vp), c = bf2f((bf16_t)cs[jj][r]), sv = bf2f((bf16_t)sn[jj][r]);
+            // g < 2: o1 = x1*c - x2*s with x1 = own, x2 = partner;  g >= 2: o2 = x2*c + x1*s with x2 = own, x1 = partner
+            out[jj * 4 + r] = rot ? f2bf(rbf(xo * c) + (g < 2 ? rbf(-xp * sv) : rbf(xp * sv))) : vo;
+        }
+    }
+    // q heads and v heads leave as bf16 columns of the q|k|v row; the k head goes into its page.  The v head's page is TRANSPOSED
+    // (64 rows of 2 bytes per token): that scatter costs nothing when each attention workgroup does it for its own (sequence,
+    // kv-head) off its critical path, while here it would be 2048 two-byte stores from each of the few workgroups that own a v head
+    bf16_t* dst = nullptr;
+    if (hd < p.nh || hd >= p.nh + p.nkv) { if (mok) dst = p.q_out + (long)m * p.ld_q + nb16 + e0; }
+    else if (run) dst = p.kpool + (((long)page * p.nkv + (hd - p.nh)) * kPage + slot) * 64 + g * 16 + e0;
+    if (dst) {
+        if constexpr (NJ == 2) *(u32x4*)dst = *(u32x4*)&out[0];
+        else *(u32x2*)dst = *(u32x2*)&out[0];
+    }
+}
+
+template <bool F8>
+inline void qkv_rope_launch(QkvRopeArgs p, int stages, int kslices, bool xcd_place, hipStream_t s) {
+    const int ktiles = p.K / (F8 ? 128 : 64);
+    if (kslices != 4) kslices = 2;
+    p.kps = (ktiles + kslices - 1) / kslices;
+    const int mblocks = (p.M + 31) / 32, nblocks = p.N / 64;
+    int grid = mblocks * nblocks;
+    p.xcd_mpx = 0;
+    if (xcd_place && p.M % 256 == 0) {                    // whole 32-row blocks per XCD
+        p.xcd_mpx = p.M / 256;
+        grid = 8 * p.xcd_mpx * nblocks;
+    }
+    if (kslices == 4) {
+        if (stages >= 3) NTTS_LAUNCH((qkv_rope_kernel<3, F8, 4>), dim3(grid), dim3(512), s, p);
+        else NTTS_LAUNCH((qkv_rope_kernel<2, F8, 4>), dim3(grid), dim3(512), s, p);
+        return;
+    }
+    if (stages >= 6) NTTS_LAUNCH((qkv_rope_kernel<6, F8, 2>), dim3(grid), dim3(256), s, p);
+    else if (stages == 3) NTTS_LAUNCH((qkv_rope_kernel<3, F8, 2>), dim3(grid), dim3(256), s, p);
+    else NTTS_LAUNCH((qkv_rope_kernel<4, F8, 2>), dim3(grid), dim3(256), s, p);
+}
+
+}  // namespace ntts
