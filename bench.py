@@ -156,10 +156,16 @@ def main():
     ap.add_argument("--decode", type=int, default=250)
     ap.add_argument("--vocab", type=int, default=None, help="default: 217488 (NeuTTS-Air), 142080 (assumed Nano)")
     ap.add_argument("--prefill-chunk", type=int, default=64, help="prompts per prefill call")
-    ap.add_argument("--mode", choices=["static", "continuous"], default="static",
+    ap.add_argument("--mode", choices=["static", "continuous", "stream"], default="static",
                     help="static (default, BASELINE's shape): one batch of equal-length utterances per step.  continuous: --requests "
                          "ragged requests (prompts 0.7-1.3 x --prefill, lengths 0.6-1.4 x --decode) through the continuous-batching "
-                         "scheduler -- slots recycled as utterances finish, prefill chunks between decode bursts")
+                         "scheduler -- slots recycled as utterances finish, prefill chunks between decode bursts.  stream: the batch as "
+                         "concurrent NeuTTS.infer_stream utterances (ref:neutts/neutts.py:373-465 windows, 0.5 s chunks): the codec pass "
+                         "of chunk k on the codec engine's stream beside the decode graph of chunk k + 1 (BASELINE.json configs[4]); "
+                         "reports time to first audio and chunk cadence next to tokens/s")
+    ap.add_argument("--sample", action="store_true",
+                    help="the reference's own sampling call (ref:neutts/neutts.py:338-347: do_sample=True, top_k=50, temperature=1.0; seeded) "
+                         "instead of greedy: radix select + Philox multinomial on the bf16 logits rows")
     ap.add_argument("--requests", type=int, default=None, help="continuous mode: requests per step (default 4 x batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -195,7 +201,36 @@ def main():
     spec = importlib.util.spec_from_file_location("ntts_build", os.path.join(PKG, "build.py"))
     bmod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bmod)
-    lib = emu_lib or bmod.build(verbose=False)
+    # start-up timeline per rank (read on the first real multi-GPU run): [rank r] stage: seconds since process start
+    t_proc = time.time()
+
+    def stage(what):
+        log(f"[bench] rank {rank}/{world} +{time.time() - t_proc:6.1f}s  {what}")
+
+    # ONE process per node builds (a stale .so on a fresh box must not start 8 hipcc runs on one output file); the others wait
+    if emu_lib:
+        lib = emu_lib
+    else:
+        if local == 0:
+            lib = bmod.build(verbose=False)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        if local != 0:
+            lib = bmod.LIB
+    stage("library ready")
+    # the launching thread of each rank on its own share of the host cores (8 ranks x torch's default thread pools otherwise
+    # oversubscribe rank 0's weight synthesis and every rank's launch loop)
+    if world > 1 and hasattr(os, "sched_setaffinity") and os.environ.get("NTTS_BENCH_AFFINITY", "1") != "0":
+        cpus = sorted(os.sched_getaffinity(0))
+        nloc = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        per = max(1, len(cpus) // nloc)
+        mine = cpus[local * per:(local + 1) * per] or cpus
+        try:
+            os.sched_setaffinity(0, mine)
+            torch.set_num_threads(max(1, min(len(mine), 32)))
+        except OSError:
+            pass
 
     nano = a.config.startswith("nano")          # the assumed Nano geometry
     fp8 = a.config == "nano-fp8"
@@ -212,40 +247,79 @@ def main():
     n_codes = int(np.prod(ccfg.levels))
     B, S, N = a.batch, a.prefill, a.decode
     cont = a.mode == "continuous"
+    strm = a.mode == "stream"
     R = a.requests or 4 * B
     S_max, N_max = (int(S * 1.3) + 1, int(N * 1.4) + 1) if cont else (S, N)
     dev = 0 if emu_lib else local
-    eng = _hip.BackboneEngine(dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
+    eos = cfg.vocab_size - 1
+    tts = None
+    if strm:
+        # Streaming goes through the product's own streaming code (NeuTTS._infer_stream_batch_hip: window / cross-fade semantics of
+        # ref:neutts/neutts.py:401-465 for every utterance of the batch, ONE batched codec pass per 25-token chunk on the codec
+        # engine's stream while the backbone's next 25 graph replays are already enqueued).  Every rank synthesises its own weights
+        # here (a single-GPU configuration: no broadcast leg).
+        from neutts import NeuTTS
+        w = syn.make_weights(cfg, 0)
+        cw = syn.make_codec_weights(ccfg, 0)
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):     # (the class prints its loading messages like the reference; stdout carries the ONE JSON line)
+          tts = NeuTTS(
+            backbone_repo={"config": dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                                          num_layers=cfg.num_layers, num_heads=cfg.num_heads, num_kv_heads=cfg.num_kv_heads, rms_eps=cfg.rms_eps,
+                                          max_context=((S + N + 31) // 32) * 32, max_prefill_tokens=a.prefill_chunk * S,
+                                          weight_dtype="fp8" if fp8 else "bf16"),
+                           "state_dict": {k: v.numpy() for k, v in w.items()}, "inv_freq": syn.rope_inv_freq(cfg).numpy(),
+                           "input_scales": fp8_scales, "tokenizer": None, "speech_base": 0, "eos_token_id": eos},
+            backbone_device=f"cuda:{dev}",
+            codec_repo={"config": dict(hidden_size=ccfg.hidden_size, intermediate_size=ccfg.intermediate_size, num_layers=ccfg.num_layers,
+                                       num_heads=ccfg.num_heads, quantization_dim=ccfg.quantization_dim, levels=list(ccfg.levels),
+                                       hop_length=ccfg.hop_length, rms_eps=ccfg.rms_eps, max_frames=128, max_rows=B * 96),
+                        "state_dict": {k: v.numpy() for k, v in cw.items()}},
+            codec_device=f"cuda:{dev}", do_sample=a.sample, max_batch=B, lib_path=lib)
+        tts.watermarker = None
+        tts._ids_to_codes = lambda ids: [int(i) % n_codes for i in ids]     # random weights do not stay in the speech range
+        tts._ids_to_codes_array = lambda ids: (np.asarray(ids, dtype=np.int64) % n_codes).astype(np.int32)
+        tts.min_new_tokens, tts.max_context = N, S + N
+    eng = tts.backbone if strm else _hip.BackboneEngine(dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
                                    intermediate_size=cfg.intermediate_size, num_layers=cfg.num_layers,
                                    num_heads=cfg.num_heads, num_kv_heads=cfg.num_kv_heads, rms_eps=cfg.rms_eps,
                                    max_context=((S_max + N_max + 31) // 32) * 32, max_batch=B,
                                    max_prefill_tokens=a.prefill_chunk * S, weight_dtype="fp8" if fp8 else "bf16"), dev, lib)
-    codec = None
-    if not a.no_codec:
+    codec = tts.codec.engine if strm else None
+    if not a.no_codec and not strm:
         codec = _hip.CodecEngine(dict(hidden_size=ccfg.hidden_size, intermediate_size=ccfg.intermediate_size,
                                       num_layers=ccfg.num_layers, num_heads=ccfg.num_heads,
                                       quantization_dim=ccfg.quantization_dim, levels=list(ccfg.levels),
                                       hop_length=ccfg.hop_length, rms_eps=ccfg.rms_eps, max_frames=N_max,
                                       max_rows=B * (N_max + 6)), dev, lib)
-    w = cw = None
+    if not strm:
+        w = cw = None
     t0 = time.time()
-    if rank == 0:
+    stage("engines created")
+    if rank == 0 and not strm:
         w = syn.make_weights(cfg, 0)           # synthetic N(0,1/fan_in) weights at the exact NeuTTS-Air shapes
         eng.load_state_dict({k: v.numpy() for k, v in w.items()}, inv_freq=syn.rope_inv_freq(cfg).numpy(), input_scales=fp8_scales)
         cw = syn.make_codec_weights(ccfg, 0)         # synthetic NeuCodec-decoder weights (xcodec2 parameter names)
-    if world > 1:
+    if rank == 0:
+        stage("weights synthesised and uploaded (rank 0)")
+    if strm:
+        pass
+    elif world > 1:
         tdev = torch.device("cpu") if emu_lib else None
         ndist.broadcast_weights(eng, src=0, device=tdev)  # RCCL over xGMI: packed backbone arena, one broadcast
         if codec is not None:
             codec.load_state_dict(ndist.broadcast_state_dict(cw, src=0, device=tdev))
+        stage("weights received (one arena broadcast + one packed codec buffer)")
     elif codec is not None:
         codec.load_state_dict({k: v.numpy() for k, v in cw.items()})
     if os.environ.get("NTTS_BENCH_PRIME", "1") != "0" and not cont:
         eng.warm_up(int(os.environ.get("NTTS_BENCH_PRIME_STEPS", str(max(2, N - 1)))))   # start-up: graph capture + runtime pools (sized by one decode call of real length), before any request
-    log(f"[bench] rank {rank}: weights ready in {time.time() - t0:.1f}s")
+    stage(f"warm-up done (weights ready in {time.time() - t0:.1f}s)")
 
-    eos = cfg.vocab_size - 1
-    samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
+    # --sample: the reference's own call (ref:neutts/neutts.py:338-347): top-k 50, temperature 1.0, one Philox key per utterance
+    samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=a.sample, top_k=50, temperature=1.0, seed=20260930)
+    samps = [_hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=a.sample, top_k=50, temperature=1.0,
+                           seed=20260930 + 7919 * (rank * B + i)) for i in range(B)] if a.sample else None
     lo = rank * B
     prompts = [syn.synthetic_prompt(cfg, lo + i, S) for i in range(B)]   # seed 1234 + utterance index
 
@@ -311,7 +385,7 @@ def main():
         for c in range(0, B, a.prefill_chunk):
             n = min(a.prefill_chunk, B - c)
             tc0 = time.time()
-            eng.prefill(prompts[c:c + n], list(range(c, c + n)), [samp] * n)
+            eng.prefill(prompts[c:c + n], list(range(c, c + n)), samps[c:c + n] if samps else [samp] * n)
             each.append(round((time.time() - tc0) * 1e3, 1))
             if collect:
                 ph["prefill"] += eng.last_timing()[0]
@@ -367,7 +441,34 @@ def main():
         ids = None
         return ph, ids, wavs
 
-    one_step = one_step_continuous if cont else one_step_static
+    stream_stats = {}
+
+    def one_step_stream(collect=False):
+        """One pass over the batch as B concurrent streams: time to first audio per utterance, the times at which utterance 0's
+        0.5 s chunks arrive (every utterance of the batch gets its chunk in the same burst), all waveform samples received."""
+        refs = [[int(t) % n_codes for t in p[-372:]] for p in prompts]      # reference codes as long as ref:samples/dave.pt (372)
+        if not emu_lib:
+            torch.cuda.synchronize()
+        t1 = time.time()
+        first, burst, n_samp = {}, [], 0
+        for i, chunk in tts._infer_stream_batch_hip([list(p) for p in prompts], refs):
+            now = (time.time() - t1) * 1e3
+            first.setdefault(i, now)
+            if i == 0:
+                burst.append(now)
+            n_samp += len(chunk)
+        total = (time.time() - t1) * 1e3
+        # (the reference's windows carry one overlap frame past the last chunk: N or N + 1 frames of audio per utterance)
+        assert B * N * ccfg.hop_length <= n_samp <= B * (N + 2) * ccfg.hop_length, (n_samp, B * N * ccfg.hop_length)
+        tt = np.array(sorted(first.values()))
+        ph = {"ttfa_ms_first": float(tt[0]), "ttfa_ms_median": float(np.median(tt)), "ttfa_ms_last": float(tt[-1]), "total_ms": total,
+              "chunks_per_utterance": len(burst), "chunk_arrival_ms_utt0": [round(x, 1) for x in burst],
+              "mean_chunk_period_ms": (burst[-2] - burst[0]) / max(len(burst) - 2, 1) if len(burst) > 2 else None,
+              "audio_s_per_utterance": n_samp / B / (50.0 * ccfg.hop_length)}
+        stream_stats.update(ph)
+        return ph, None, None
+
+    one_step = one_step_stream if strm else one_step_continuous if cont else one_step_static
 
     def barrier():
         finish_pending()
@@ -404,11 +505,11 @@ def main():
         assert np.isfinite(wavs[:4]).all(), "non-finite waveform"
     roof = None
     step_info = None
-    if rank == 0 and not a.no_roofline and not cont:
+    if rank == 0 and not a.no_roofline and not cont and not strm:
         # slot state at mid-generation (mean context S + N/2 ~ 625): prefill everything, decode N/2 steps
         for c in range(0, B, a.prefill_chunk):
             n = min(a.prefill_chunk, B - c)
-            eng.prefill(prompts[c:c + n], list(range(c, c + n)), [samp] * n)
+            eng.prefill(prompts[c:c + n], list(range(c, c + n)), samps[c:c + n] if samps else [samp] * n)
         eng.decode(N // 2)
         eng.sync()
         step_bytes = eng.step_bytes()
@@ -468,12 +569,18 @@ def main():
             workload = (f"NeuTTS-Nano (ASSUMED geometry: hidden {cfg.hidden_size}, {cfg.num_layers} layers, {cfg.num_heads}:{cfg.num_kv_heads} "
                         f"heads, FFN {cfg.intermediate_size}, V {cfg.vocab_size}) "
                         + ("fp8 e4m3 weights + GEMM inputs on the fp8 MFMA, bf16 KV / attention, " if fp8 else "bf16, ")
-                        + f"{world}xMI355X batch={B}, {S} prefill / {N} decode tokens, greedy (BASELINE.json configs[4])")
+                        + f"{world}xMI355X batch={B}, {S} prefill / {N} decode tokens (BASELINE.json configs[4])")
         elif B == 1 and world == 1:
-            workload = f"NeuTTS-Air bf16 1xMI355X, batch=1, {S} prefill / {N} decode tokens, greedy (BASELINE.json configs[1])"
+            workload = f"NeuTTS-Air bf16 1xMI355X, batch=1, {S} prefill / {N} decode tokens (BASELINE.json configs[1])"
         else:
-            workload = (f"NeuTTS-Air bf16 {world}xMI355X batch={B} synthetic prompts per GPU, {S} prefill / {N} decode tokens, greedy, "
-                        f"continuous-batching engine + hipGraph decode (BASELINE.json configs[{2 if world == 1 else 3}])")
+            workload = (f"NeuTTS-Air bf16 {world}xMI355X batch={B} synthetic prompts per GPU, {S} prefill / {N} decode tokens, "
+                        f"STATIC batch (all {B} slots of the continuous-batching engine filled at once, every utterance {N} tokens; the ragged "
+                        f"scheduler line is --mode continuous) + hipGraph decode (BASELINE.json configs[{2 if world == 1 else 3}])")
+        workload += ", sampling as the reference calls generate (do_sample, top_k=50, temperature=1.0, seeded)" if a.sample else ", greedy"
+        if strm:
+            workload = (f"STREAM mode: {B} concurrent infer_stream utterances per GPU (27-frame windows every 25 tokens, 0.5 s chunks, "
+                        f"ref:neutts/neutts.py:401-465), codec pass of chunk k on the codec engine's stream beside the decode graph of chunk k + 1; "
+                        + workload)
         if cont:
             workload = (f"CONTINUOUS mode (not BASELINE's static shape): {R} ragged requests per GPU through {B} decode slots, prompts "
                         f"{int(S * 0.7)}-{int(S * 1.3)} tokens, {int(N * 0.6)}-{int(N * 1.4)} generated tokens each, slots recycled as utterances finish; "
@@ -490,7 +597,10 @@ def main():
             "rtf": dt / (tokens / 50.0),
             "phase_ms": ph, "step_wall_ms": step_wall, "step_host_wall_ms": step_host,
             "roofline": roof, "decode_step": step_info, "cpu_baseline": cpu,
+            "timed_region": "warm_up() before timing, codec pass + D2H of batch k asynchronous under the prompt pass of batch k + 1 (static mode)",
         }
+        if strm:
+            rec["stream"] = stream_stats
         print(json.dumps(rec), flush=True)
     if world > 1:
         import torch.distributed as dist

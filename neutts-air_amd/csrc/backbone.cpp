@@ -56,9 +56,8 @@ struct ntts_backbone {
     bf16_t* arena = nullptr;
     size_t arena_elems = 0;
     bf16_t *embed = nullptr, *final_norm = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
-    bf16_t* embed_tm = nullptr;   // the lm_head's weight stream: tile-major copy of the tied embedding (w_tile_major), the untied
-                                  // "lm_head.weight", or (fp8) the e4m3 bytes of either; null = the head reads `embed` directly
-    bool w_tile_major = true;     // GEMM weights stored tile-major (gemm.h GemmArgs::w_tile_major)
+    bf16_t* embed_tm = nullptr;   // the lm_head's weight stream: tile-major copy of the tied embedding, the untied
+                                  // "lm_head.weight", or (fp8) the e4m3 bytes of either
     bool fp8 = false, tied = true, has_bias = true;
     float* shead = nullptr;       // fp8: per-vocab-row scales of the head matrix
     float* xs_head_dev = nullptr;
@@ -96,56 +95,38 @@ struct ntts_backbone {
     long ldl = 0;
     int n_sampling = 0;              // running slots with do_sample=1
     bool graph_has_logits = false;
-    int ks_qkv = 1, ks_o = 1, ks_d = 1;
-    // Tile path: the QKV projection with bias, rounding, RoPE and the KV append in its epilogue (qkv_rope.h); the attention kernel
+    // ---- decode-step shape, fixed at create() from the batch size (every constant below was swept on MI355X; the losing variants and
+    //      their knobs are gone -- DESIGN.md section 4 keeps the numbers, the git history the code)
+    int ks_o = 1, ks_d = 1;          // split-K of o_proj / down_proj (fp32 slabs reduced by the norm kernel behind them)
+    // Tile path: the QKV projection with bias, rounding, RoPE and the K append in its epilogue (qkv_rope.h); the attention kernel
     // then has no prologue.  step_meta / rope_rows: the per-step row records that kernel reads (step_meta_kernel, once per step).
-    bool qkv_fused = false;
-    int st_qkvf = 3, ks_qkvf = 2;   // ring depth / K slices per workgroup of the fused QKV kernel
     int* step_meta = nullptr;
     bf16_t* rope_rows = nullptr;
-    int st_qkv = 4, st_o = 4, st_gu = 3, st_d = 4;   // LDS ring depth of each skinny decode GEMM
-    int head_stages = 2, l_stages = 2, pf_gh = 7, attn_depth = 1, attn_var = 1, gu_tile = 0;   // LDS ring depth of the skinny (decode) tile / of the lm_head tile
-    bool gu_large = false, head_large = true, pf_attn_simple = false, use_xl = true;
-    int head_xl = 0;        // lm_head tile at large batch: 0 = 128 x 128, 1 = 256 x 256 (16 waves), 4 = 256 x 288 (12 waves, natural-order
-                            // tile, gemm.h TN): 756 tiles = 2.95 rounds of the 256 CUs instead of 850 = 3.32 (the fourth round ran 82 tiles
-                            // on an otherwise idle chip): 129.5 -> 118.7-123.8 us (profiles/r02k_sweep_lpt_head_gu_tiles.log; 256 x 320 with 8
-                            // waves: 138.6, 256 x 288 with 8 waves: 130.5 -- measured and removed).  128 x 256 and 256 x 128 tiles (8 waves, two
-                            // workgroups per CU) were measured earlier: 168 / 158 vs 126 us (profiles/r02g_sweep_head_tiles.log)
-    // non-temporal policy on the lm_head's weight stream (NTTS_W_NT).  Measured at batch 256
-    // (profiles/r02a_sweep_nt_graphsteps.jsonl): lm_head 136.6 -> 132.3 us; on the LDS-DMA rings of the skinny layer GEMMs the
-    // same policy was SLOWER (qkv 5.78 -> 5.96, down 9.95 -> 10.54 us; step 1.679 -> 1.718 ms) and is not offered there
-    int w_nt = 1;
-    bool pf_rope_vec = true;   // prefill RoPE + KV write with 16-byte accesses (rope_kv_write_vec_kernel)
+    int head_tile = 0;      // lm_head tile (NTTS_HEAD_TILE): 0 = 64 x 64 skinny (batch <= 64), 1 = 128 x 128, 2 = 256 x 256 (16 waves; the fp8 model
+                            // above batch 128), 4 = 256 x 288 natural-order tile, 12 waves (bf16 above batch 128: 756 tiles = 2.95 rounds of the 256 CUs
+                            // instead of 850 = 3.32: 129.5 -> 118.7-123.8 us, profiles/r02k_sweep_lpt_head_gu_tiles.log).  Its weight stream uses the
+                            // non-temporal policy (136.6 -> 132.3 us, profiles/r02a_sweep_nt_graphsteps.jsonl; slower on the skinny layer GEMMs)
+    bool gu_128 = false;    // gate/up on the 128 x 128 / 8-wave tile (above batch 128: -2 % per step) instead of the 64 x 64 skinny tile
     int xcd_affine = 0;        // row-block placement per XCD group (gemm.h xcd_maffine; NTTS_XCD_AFFINE): bit 0: o_proj + the norm behind it, bit 1: down_proj + the
                                // norm behind it, bit 2: QKV GEMM + attention.  Batch 256 (profiles/r02k_sweep_xcd_affine*.log): 7 -> step 1.630 -> 1.615 ms
-    bool attn_lmax_small = true;   // decode attention: the 1024-context instantiation when max_context allows (NTTS_ATTN_LMAX_SMALL)
     int xcd_xps = 0;           // XCDs per 64-row m-block of the decode batch (8 / (max_batch / 64)); 0 = the batch does not split that way
     int xl_min_m = 1024;       // rows from which the big-M GEMMs take the 256-row tiles (tests lower it: NTTS_XL_MIN_M)
-    bool pf_rope_q_fused = true;   // prefill: RoPE of the q heads inside the attention kernel's Q load (NTTS_PF_ROPE_Q_FUSED)
-    bool pf_qkv_nat = true;    // prefill QKV on the natural-order 256 x 288 tile when N is a multiple of 288 but not of 256
-    bool pf_lpt = true;        // prefill attention work list sorted by descending causal depth (longest tiles dispatched first)
-    bool pf_resid = true;   // prefill: residual add in the o_proj / down_proj epilogue (EPI_RESID) instead of in the norm pass
-    // Split-K decode GEMMs: XCD-aware slice placement (gemm.h GemmArgs::xcd_nsplit; NTTS_XCD_SPLIT bit 0 qkv, 1 o_proj, 2 down).
-    // Measured at batch 256 (profiles/r02f_*): FETCH per skinny-GEMM launch 15.0 -> 6.8 MB (algorithmic 5.3: the 8 private L2s
-    // no longer each pull the whole X panel), down_proj 10.2 -> 10.1 us, qkv unchanged, o_proj 5.3 -> 5.6-5.8 us (K = 896 only
-    // has 14 tiles to split: its X panel is small and the y-grid placement balances better) -- hence qkv + down by default.
-    int xcd_split = 5;
+    // Split-K decode GEMMs below batch 129: XCD-aware slice placement of o_proj (gemm.h GemmArgs::xcd_nsplit): FETCH per skinny-GEMM launch
+    // 15.0 -> 6.8 MB (profiles/r02f_*); above it the row-block placement (xcd_affine) takes over
     // Small-batch decode step (max_batch <= NTTS_SMALL_BATCH, default 8; BASELINE configs[1] = batch 1): wave-per-16-features
     // GEMV kernels with the slab-reduce + residual + RMSNorm fused into the consumer's prologue (gemv.h) -- 5 launches per
-    // layer instead of 7 -- and 16-wave attention workgroups (attn_decode.h NW).
+    // layer instead of 7.  Split-K factors 4 / 7 / 10 (QKV / o_proj / down_proj), two KV pages per wave in flight.
     bool small = false;
-    int sks_q = 4, sks_o = 7, sks_d = 10, attn_depth_small = 2;
+    static constexpr int kSksQ = 4, kSksO = 7, kSksD = 10;
     bf16_t* h_alt = nullptr;     // second residual-stream buffer (the fused prologue writes the new stream while others still read the old)
-    int attn_split = 8;          // small-batch path: context-split attention over this many workgroups per (sequence, kv-head), used
-    int attn_split_ctx = 896;    //   once the longest running context reaches attn_split_ctx tokens (0 chunks = never).  Measured at batch 1
+    int attn_split = 8;          // context-split attention over this many workgroups per (sequence, kv-head) (NTTS_ATTN_SPLIT), used
+    int attn_split_ctx = 896;    //   once the longest running context reaches attn_split_ctx tokens (NTTS_ATTN_SPLIT_CTX).  Measured at batch 1
                                  //   (profiles/r02i_sweep_split_*): context 625: 0.987 -> 1.025 ms per step (one more launch per layer, the
                                  //   o_proj prologue sums 8 slabs); context 1850: 1.257 -> 1.093 ms (attention 23.3 -> 13.4 us); break-even ~870
     bf16_t* as_scores = nullptr;  // [B * nkv][8][max_context + 16]
     float* as_stats = nullptr;    // [B * nkv][attn_split][8][2]
     float* as_oslabs = nullptr;   // [attn_split][B][nh * 64]
     float* slabs2 = nullptr;     // down_proj's slabs (read by the next layer's QKV prologue while that kernel writes `slabs`)
-    bool norm_wide = true;       // decode add+RMSNorm: one row per workgroup (256 CUs pull) instead of four
-    bool pf_prune_last = true;   // prefill, last layer: attention / o_proj / MLP only for each prompt's last position
     int n_cu = 256;
 
     // prefill workspaces
@@ -260,15 +241,13 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += align_up(n, 128); return o; };
     const size_t o_embed = take((size_t)V * H);
-    // Weight layout: tile-major by default (each workgroup's weight stream is one sequential run of HBM addresses:
-    // lm_head -8 %, gate/up -3 % on the micro-benchmark, profiles/r01e_ubench_weight_layout.txt).  The embedding gather
-    // needs rows, the lm_head tiles: the tied matrix is kept in both layouts.  The X-panel path reads W rows directly.
-    e->w_tile_major = (env_int("NTTS_W_TILE_MAJOR", 1) != 0 || e->fp8) && H % 64 == 0 && F % 64 == 0;
+    // Weight layout: tile-major (gemm.h GemmArgs::w_tile_major: each workgroup's weight stream is one sequential run of HBM
+    // addresses: lm_head -8 %, gate/up -3 % on the micro-benchmark, profiles/r01e_ubench_weight_layout.txt; neutral end to end,
+    // r01g_ab_weight_layout.jsonl).  The embedding gather needs rows, the lm_head tiles: the tied matrix is kept in both layouts.
     // sizes in bf16 elements: a matrix of n weights takes n (bf16) or n / 2 (fp8 bytes); fp32 arrays take 2 per value
     auto take_w = [&](size_t n) { return take(e->fp8 ? (n + 1) / 2 : n); };
     auto take_f = [&](size_t n) { return take(2 * n); };
-    const bool own_head = e->w_tile_major || !e->tied || e->fp8;   // the head has its own copy (layout / values / precision differ)
-    const size_t o_embed_tm = own_head ? take_w((size_t)((V + 63) / 64) * 64 * H) : 0;
+    const size_t o_embed_tm = take_w((size_t)((V + 63) / 64) * 64 * H);   // the head's own copy (layout / values / precision differ)
     const size_t o_shead = e->fp8 ? take_f((size_t)((V + 63) / 64) * 64) : 0, o_xs_head = e->fp8 ? take_f(4) : 0;
     struct LO { size_t ln1, wqkv, bqkv, wo, ln2, wgu, wd, sqkv, so, sgu, sd, xs; };
     std::vector<LO> lo(L);
@@ -283,7 +262,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     CR_HIP(hipMalloc((void**)&e->arena, off * sizeof(bf16_t)));
     CR_HIP(hipMemset(e->arena, 0, off * sizeof(bf16_t)));
     e->embed = e->arena + o_embed;
-    e->embed_tm = own_head ? e->arena + o_embed_tm : nullptr;
+    e->embed_tm = e->arena + o_embed_tm;
     if (e->fp8) { e->shead = (float*)(e->arena + o_shead); e->xs_head_dev = (float*)(e->arena + o_xs_head); }
     e->layers.resize(L);
     for (int i = 0; i < L; ++i) {
@@ -362,69 +341,29 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
         if (ks > ktiles) ks = ktiles;
         return ks;
     };
-    // QKV GEMM: 18 x 4 = 72 workgroups at batch 256 leave most CUs idle; split-K 2 with the slabs reduced in the attention
-    // prologue measured -3.4 us on the GEMM, +1.7 us on the attention kernel, -1.8 % per step (profiles/r01e_sweep_qkv_split.jsonl)
-    e->ks_qkv = env_int("NTTS_KSPLIT_QKV", 2);
-    e->st_qkvf = env_int("NTTS_STAGES_QKVF", 3);
-    e->ks_qkvf = env_int("NTTS_KS_QKVF", 2);
-    if (e->ks_qkv > kAttnMaxSlabs) e->ks_qkv = kAttnMaxSlabs;
     const int ktile = e->fp8 ? 128 : 64;   // K extent of one 128-byte tile
-    e->ks_o = env_int("NTTS_KSPLIT_O", pick_split(H / 64, c->num_heads * 64 / ktile));
-    e->ks_d = env_int("NTTS_KSPLIT_D", pick_split(H / 64, F / ktile));
-    const int s_all = env_int("NTTS_S_STAGES", 0);
-    e->st_qkv = env_int("NTTS_STAGES_QKV", s_all ? s_all : 4);
-    e->st_o = env_int("NTTS_STAGES_O", s_all ? s_all : 4);
-    e->st_gu = env_int("NTTS_STAGES_GU", s_all ? s_all : 3);
-    e->st_d = env_int("NTTS_STAGES_D", s_all ? s_all : 4);
-    e->head_stages = env_int("NTTS_HEAD_STAGES", 2);
-    e->l_stages = env_int("NTTS_L_STAGES", 2);
-    e->gu_large = env_int("NTTS_GU_LARGE", 0) != 0;
-    e->pf_attn_simple = env_int("NTTS_PREFILL_ATTN_SIMPLE", 0) != 0;
-    e->pf_prune_last = env_int("NTTS_PF_PRUNE_LAST", 1) != 0;
-    // one row per workgroup: 256 CUs pull the slabs instead of 64 -- 5.5 -> 4.0 us per launch, -4.4 % per step at batch 256
-    e->norm_wide = env_int("NTTS_NORM_WIDE", 1) != 0;
-    e->w_nt = env_int("NTTS_W_NT", 1);
-    e->pf_resid = env_int("NTTS_PF_RESID", 1) != 0;
-    e->pf_rope_vec = env_int("NTTS_PF_ROPE_VEC", 1) != 0;
-    e->pf_lpt = env_int("NTTS_PF_LPT", 1) != 0;
-    e->pf_qkv_nat = env_int("NTTS_PF_QKV_NAT", 1) != 0;
-    e->pf_rope_q_fused = env_int("NTTS_PF_ROPE_Q_FUSED", 1) != 0;
+    const int max_slabs = 16;
+    e->ks_o = std::min(max_slabs, pick_split(H / 64, c->num_heads * 64 / ktile));
+    e->ks_d = std::min(max_slabs, pick_split(H / 64, F / ktile));
     e->xl_min_m = env_int("NTTS_XL_MIN_M", 1024);
-    e->attn_lmax_small = env_int("NTTS_ATTN_LMAX_SMALL", 1) != 0;
     e->xcd_xps = (B == 64 || B == 128 || B == 256 || B == 512) ? 8 / (B / 64) : 0;
     e->xcd_affine = env_int("NTTS_XCD_AFFINE", B > 128 ? 7 : 0);
-    e->xcd_split = env_int("NTTS_XCD_SPLIT", 5);
-    e->use_xl = env_int("NTTS_XL", 1) != 0;
-    e->head_xl = env_int("NTTS_HEAD_XL", B > 128 ? (e->fp8 ? 1 : 4) : 0);
-    if (e->head_xl != 0 && e->head_xl != 4) e->head_xl = 1;
-    if (e->fp8 && e->head_xl == 4) e->head_xl = 1;          // (the natural-order tile is bf16 only)
+    e->head_tile = env_int("NTTS_HEAD_TILE", B > 128 ? (e->fp8 ? 2 : 4) : B > 64 ? 1 : 0);
+    if (e->head_tile != 0 && e->head_tile != 1 && e->head_tile != 2 && e->head_tile != 4) e->head_tile = 1;
+    if (e->fp8 && e->head_tile == 4) e->head_tile = 2;          // (the natural-order tile is bf16 only)
+    e->gu_128 = B > 128;
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    e->pf_gh = env_int("NTTS_PF_GH", 7);   // all 7 heads of a GQA group in one pass: K/V pages staged once (prefill chunk 35.0 -> 33.4 ms)
-    e->attn_depth = env_int("NTTS_ATTN_DEPTH", 1);
-    e->attn_var = env_int("NTTS_ATTN_VAR", 1);   // 1: prologue operands requested before the K pages (attn_decode.h)
-    e->gu_tile = env_int("NTTS_GU_TILE", B > 128 ? 1 : 0);   // 128x128 / 8 waves measured -2 % per step at B = 256
-    e->head_large = env_int("NTTS_HEAD_LARGE", B > 64 ? 1 : 0) != 0;
-    const int max_slabs = 16;
-    if (e->ks_o > max_slabs) e->ks_o = max_slabs;
-    if (e->ks_d > max_slabs) e->ks_d = max_slabs;
 
     e->small = B <= env_int("NTTS_SMALL_BATCH", 8) && B <= kGemvRows && H <= 1024 && V % 16 == 0 && e->NQKV % 16 == 0 && F % 32 == 0 &&
                !e->fp8;   // (the small-batch GEMV kernels are bf16 only: the fp8 model takes the tile kernels at every batch)
-    e->sks_q = env_int("NTTS_SKS_Q", 4);
-    if (e->sks_q > kAttnMaxSlabs) e->sks_q = kAttnMaxSlabs;
-    e->sks_o = env_int("NTTS_SKS_O", 7);
-    e->sks_d = env_int("NTTS_SKS_D", 10);
-    if (e->sks_o > max_slabs) e->sks_o = max_slabs;
-    if (e->sks_d > max_slabs) e->sks_d = max_slabs;
-    e->attn_depth_small = env_int("NTTS_ATTN_DEPTH_SMALL", 2);
-    e->qkv_fused = !e->small && e->w_tile_major && env_int("NTTS_QKV_FUSED", 1) != 0;
-    if (e->qkv_fused) {
+    static_assert(ntts_backbone::kSksQ <= kAttnMaxSlabs && ntts_backbone::kSksO <= 16 && ntts_backbone::kSksD <= 16, "slab counts");
+    if (!e->small) {
         CR_HIP(hipMalloc((void**)&e->step_meta, (size_t)B * 4 * sizeof(int)));
         CR_HIP(hipMemset(e->step_meta, 0, (size_t)B * 4 * sizeof(int)));
         CR_HIP(hipMalloc((void**)&e->rope_rows, (size_t)B * 64 * 2));
         CR_HIP(hipMemset(e->rope_rows, 0, (size_t)B * 64 * 2));
     }
-    e->n_part = e->small ? V / 16 : !e->head_large ? (V + 63) / 64 : e->head_xl == 4 ? ((V + 287) / 288) * 3 : e->head_xl ? ((V + 255) / 256) * 4 : ((V + 127) / 128) * 2;
+    e->n_part = e->small ? V / 16 : e->head_tile == 0 ? (V + 63) / 64 : e->head_tile == 4 ? ((V + 287) / 288) * 3 : e->head_tile == 2 ? ((V + 255) / 256) * 4 : ((V + 127) / 128) * 2;
     CR_HIP(hipMalloc((void**)&e->h_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->xn_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->qkv_dec, (size_t)B * e->NQKV * 2));
@@ -439,7 +378,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
         e->attn_split = env_int("NTTS_ATTN_SPLIT", 8);
         e->attn_split_ctx = env_int("NTTS_ATTN_SPLIT_CTX", 896);
         if (e->attn_split < 2 || e->attn_split > 32) e->attn_split = 0;
-        if (!e->small && (e->fp8 || (e->ks_qkv < 2 && !e->qkv_fused) || B * c->num_kv_heads >= 512)) e->attn_split = 0;
+        if (!e->small && (e->fp8 || B * c->num_kv_heads >= 512)) e->attn_split = 0;   // (fp8: the combine pass writes bf16 rows)
         if (e->attn_split) {
             const size_t n_sc = (size_t)B * c->num_kv_heads * kGroupMax * (c->max_context + 16), n_st = (size_t)B * c->num_kv_heads * e->attn_split * kGroupMax * 2,
                          n_os = (size_t)e->attn_split * B * c->num_heads * 64;
@@ -592,7 +531,7 @@ extern "C" int ntts_backbone_load_tensor(ntts_backbone* e, const char* name, con
     }
     if (dtype != NTTS_DT_F32 && dtype != NTTS_DT_BF16) return fail(e, NTTS_EINVAL, "tensor '%s': dtype must be f32 or bf16", name);
     int rc = NTTS_EINVAL;
-    const int tm = e->w_tile_major ? 1 : 0;
+    const int tm = 1;   // GEMM weights are stored tile-major
     if (n == "model.embed_tokens.weight") {
         if (!want(c.vocab_size, H)) return bad_shape();
         if (e->head_from_embed) {   // a tied "lm_head.weight" arrived first and was taken as the embedding: the two must agree
@@ -619,7 +558,7 @@ extern "C" int ntts_backbone_load_tensor(ntts_backbone* e, const char* name, con
             return NTTS_OK;
         }
         rc = put_rows(e, data, dtype, is_device, c.vocab_size, H, e->embed, nullptr);
-        if (rc == NTTS_OK && e->tied && e->embed_tm)   // the tied head's own copy (tile-major and / or fp8)
+        if (rc == NTTS_OK && e->tied)   // the tied head's own copy (tile-major and / or fp8)
             rc = put_weight(e, data, dtype, is_device, c.vocab_size, H, e->embed_tm, 0, nullptr, tm, e->fp8 ? e->shead : nullptr);
         if (rc == NTTS_OK) e->loaded.insert(n);
         return rc;
@@ -634,7 +573,7 @@ extern "C" int ntts_backbone_load_tensor(ntts_backbone* e, const char* name, con
         // tied: the tensor may be present in a checkpoint (safetensors of some exporters keep both names) but it must BE the embedding
         if (!e->loaded.count("model.embed_tokens.weight")) {
             rc = put_rows(e, data, dtype, is_device, c.vocab_size, H, e->embed, nullptr);
-            if (rc == NTTS_OK && e->embed_tm) rc = put_weight(e, data, dtype, is_device, c.vocab_size, H, e->embed_tm, 0, nullptr, tm, e->fp8 ? e->shead : nullptr);
+            if (rc == NTTS_OK) rc = put_weight(e, data, dtype, is_device, c.vocab_size, H, e->embed_tm, 0, nullptr, tm, e->fp8 ? e->shead : nullptr);
             if (rc == NTTS_OK) { e->head_from_embed = true; e->loaded.insert("lm_head.weight"); }
             return rc;
         }
@@ -765,7 +704,7 @@ extern "C" int ntts_backbone_arena_copy(ntts_backbone* e, void* buf, size_t byte
 extern "C" int ntts_backbone_arena_derived(ntts_backbone* e, size_t* off, size_t* bytes) {
     if (!e || !off || !bytes) return NTTS_EINVAL;
     *off = 0; *bytes = 0;
-    if (e->tied && e->embed_tm) {
+    if (e->tied) {
         const size_t V64 = (size_t)((e->cfg.vocab_size + 63) / 64) * 64;
         *off = (size_t)((char*)e->embed_tm - (char*)e->arena);
         *bytes = e->fp8 ? ((V64 * e->H + 1) / 2) * 2 : V64 * e->H * 2;     // the matrix (its fp8 scales follow and are rebuilt too)
@@ -775,9 +714,9 @@ extern "C" int ntts_backbone_arena_derived(ntts_backbone* e, size_t* off, size_t
 
 extern "C" int ntts_backbone_adopt_arena(ntts_backbone* e) {
     if (!e) return NTTS_EINVAL;
-    if (e->tied && e->embed_tm) {   // rebuild the derived head copy from the (received) embedding: it need not travel
+    if (e->tied) {   // rebuild the derived head copy from the (received) embedding: it need not travel
         HIPCHK(e, hipSetDevice(e->device));
-        const int rc0 = put_weight(e, e->embed, NTTS_DT_BF16, 1, e->cfg.vocab_size, e->H, e->embed_tm, 0, nullptr, e->w_tile_major ? 1 : 0,
+        const int rc0 = put_weight(e, e->embed, NTTS_DT_BF16, 1, e->cfg.vocab_size, e->H, e->embed_tm, 0, nullptr, 1,
                                    e->fp8 ? e->shead : nullptr);
         if (rc0) return rc0;
     }
@@ -796,7 +735,7 @@ extern "C" int ntts_backbone_adopt_arena(ntts_backbone* e) {
 static GemmArgs gemm_args(const ntts_backbone* e, const bf16_t* X, long ldx, const bf16_t* W, long ldw, const bf16_t* bias, void* out,
                           long ldo, int M, int N, int K, const float* wscale = nullptr, float xscale = 1.f) {
     GemmArgs a{};
-    a.w_tile_major = e->w_tile_major ? 1 : 0;   // every W this engine hands to a GEMM is in its weight layout
+    a.w_tile_major = 1;   // every W this engine hands to a GEMM is in its weight layout
     a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K;
     a.wscale = wscale; a.xscale = xscale;
     return a;
@@ -804,69 +743,51 @@ static GemmArgs gemm_args(const ntts_backbone* e, const bf16_t* X, long ldx, con
 static int ktile_of(const ntts_backbone* e) { return e->fp8 ? 128 : 64; }
 
 // ---- the decode step's launches, one helper per kernel (shared by decode_step and ntts_backbone_time_kernel)
-template <int EPI>
-static void gemm_skinny(int stages, const GemmArgs& a, int ks, hipStream_t st) {
-    if (a.wscale) {   // fp8 operands
-        if (stages == 3) gemm_launch<4, 1, 1, EPI, 3, 0, 64, false, true>(a, ks, st);
-        else gemm_launch<4, 1, 1, EPI, 4, 0, 64, false, true>(a, ks, st);
-        return;
-    }
-    switch (stages) {
-        case 2: gemm_launch<4, 1, 1, EPI, 2>(a, ks, st); break;
-        case 3: gemm_launch<4, 1, 1, EPI, 3>(a, ks, st); break;
-        case 6: gemm_launch<4, 1, 1, EPI, 6>(a, ks, st); break;
-        default: gemm_launch<4, 1, 1, EPI, 4>(a, ks, st); break;
-    }
+// 64 x 64 tile, 4 waves; LDS ring of 4 slots (3 for gate/up): latency-bound kernels, <= 1 block per CU (profiles/r01_sweep_decode.jsonl)
+template <int EPI, int NS = 4>
+static void gemm_skinny(const GemmArgs& a, int ks, hipStream_t st) {
+    if (a.wscale) gemm_launch<4, 1, 1, EPI, NS, 0, 64, false, true>(a, ks, st);   // fp8 operands
+    else gemm_launch<4, 1, 1, EPI, NS>(a, ks, st);
 }
 
 template <int EPI>
 static void gemm_large(ntts_backbone* e, const GemmArgs& a, hipStream_t st) {
+    const bool xl = a.M >= e->xl_min_m && a.N >= 256;    // 256 x 256 / 16 waves, else 128 x 128 / 4 waves
     if (e->fp8) {
-        if (e->use_xl && a.M >= e->xl_min_m && a.N >= 256) gemm_launch<4, 4, 4, EPI, 2, 0, 64, false, true>(a, 1, st);
+        if (xl) gemm_launch<4, 4, 4, EPI, 2, 0, 64, false, true>(a, 1, st);
         else gemm_launch<2, 2, 4, EPI, 2, 0, 64, false, true>(a, 1, st);
         return;
     }
-    if (e->use_xl && a.M >= e->xl_min_m && a.N >= 256) {
+    if (xl) {
         // prefill QKV (N = 1152 = 4.5 x 256): the 256 x 256 tile needs 5 column blocks, the last one half empty -- 625 tiles
         // = 2.44 rounds of the CUs per 32 000-token chunk; the natural-order 256 x 288 tile needs 4: 500 tiles = 1.95 rounds
         if constexpr (EPI == EPI_BF16) {
-            if (e->pf_qkv_nat && a.N % 288 == 0 && a.N % 256 != 0) { gemm_launch<4, 3, 4, EPI_BF16, 2, 0, 64, false, false, 6>(a, 1, st); return; }
+            if (a.N % 288 == 0 && a.N % 256 != 0) { gemm_launch<4, 3, 4, EPI_BF16, 2, 0, 64, false, false, 6>(a, 1, st); return; }
         }
         NTTS_GEMM_XL(EPI, a, 1, st);
         return;
     }
-    switch (e->l_stages) {
-        case 3: gemm_launch<2, 2, 4, EPI, 3>(a, 1, st); break;
-        case 4: gemm_launch<2, 2, 4, EPI, 4>(a, 1, st); break;
-        default: gemm_launch<2, 2, 4, EPI, 2>(a, 1, st); break;
-    }
+    gemm_launch<2, 2, 4, EPI, 2>(a, 1, st);
 }
 
 static void ks_lm_head(ntts_backbone* e, bool keep_logits);
 static void k_lm_head(ntts_backbone* e, bool keep_logits) {
     if (e->small) { ks_lm_head(e, keep_logits); return; }
     const int B = e->cfg.max_batch, H = e->H, V = e->cfg.vocab_size;
-    GemmArgs a = gemm_args(e, e->xn_dec, H, e->embed_tm ? e->embed_tm : e->embed, H, nullptr, nullptr, 0, B, V, H, e->shead, e->xs_head);
+    GemmArgs a = gemm_args(e, e->xn_dec, H, e->embed_tm, H, nullptr, nullptr, 0, B, V, H, e->shead, e->xs_head);
     a.part_val = e->part_val; a.part_idx = e->part_idx; a.mask_eos = e->sl.mask_eos;
     a.logits = keep_logits ? e->logits : nullptr; a.ld_logits = V;
     a.logits_bf16 = (keep_logits && e->n_sampling > 0) ? e->logits_bf16 : nullptr; a.ld_logits_bf16 = e->ldl;
-    if (!e->head_large) { gemm_skinny<EPI_ARGMAX>(4, a, 1, e->stream); return; }
-    if (e->head_xl == 4) {   // natural-order 256 x 288 tile (bf16): three rounds of the CUs
-        if (e->w_nt & 1) gemm_launch<4, 3, 4, EPI_ARGMAX, 2, 0, 64, true, false, 6>(a, 1, e->stream);
-        else gemm_launch<4, 3, 4, EPI_ARGMAX, 2, 0, 64, false, false, 6>(a, 1, e->stream);
-        return;
-    }
-    if (e->head_xl) {
-        if (e->fp8) gemm_launch<4, 4, 4, EPI_ARGMAX, 2, 0, 64, true, true>(a, 1, e->stream);
-        else if (e->w_nt & 1) gemm_launch<4, 4, 4, EPI_ARGMAX, 2, 0, 64, true>(a, 1, e->stream);
-        else NTTS_GEMM_XL(EPI_ARGMAX, a, 1, e->stream);
-        return;
-    }
-    if (e->fp8) { gemm_launch<2, 2, 4, EPI_ARGMAX, 2, 0, 64, false, true>(a, 1, e->stream); return; }
-    switch (e->head_stages) {
-        case 3: gemm_launch<2, 2, 4, EPI_ARGMAX, 3>(a, 1, e->stream); break;
-        case 4: gemm_launch<2, 2, 4, EPI_ARGMAX, 4>(a, 1, e->stream); break;
-        default: gemm_launch<2, 2, 4, EPI_ARGMAX, 2>(a, 1, e->stream); break;
+    switch (e->head_tile) {     // (the 256-row tiles stream W with the non-temporal policy: read once per step)
+        case 0: gemm_skinny<EPI_ARGMAX>(a, 1, e->stream); break;
+        case 4: gemm_launch<4, 3, 4, EPI_ARGMAX, 2, 0, 64, true, false, 6>(a, 1, e->stream); break;   // natural-order 256 x 288 (bf16)
+        case 2:
+            if (e->fp8) gemm_launch<4, 4, 4, EPI_ARGMAX, 2, 0, 64, true, true>(a, 1, e->stream);
+            else gemm_launch<4, 4, 4, EPI_ARGMAX, 2, 0, 64, true>(a, 1, e->stream);
+            break;
+        default:
+            if (e->fp8) gemm_launch<2, 2, 4, EPI_ARGMAX, 2, 0, 64, false, true>(a, 1, e->stream);
+            else gemm_launch<2, 2, 4, EPI_ARGMAX, 2>(a, 1, e->stream);
     }
 }
 
@@ -885,105 +806,85 @@ static void k_step_meta(ntts_backbone* e) {   // once per decode step, before th
     NTTS_LAUNCH((step_meta_kernel), dim3((e->cfg.max_batch + 3) / 4), dim3(256), e->stream, m);
 }
 
+// QKV projection + bias + rounding + RoPE + K append (qkv_rope.h); 3 ring slots, 2 K slices per workgroup (swept: 4 slices / 4 and
+// 6 slots are equal or slower, profiles/r03a_sweep_qkv_fused.log)
 static void k_qkv(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H;
     const LayerW& w = e->layers[i];
-    if (e->qkv_fused) {
-        QkvRopeArgs a{};
-        a.X = e->xn_dec; a.ldx = H; a.W = w.wqkv; a.bias = w.bqkv; a.wscale = w.sqkv; a.xscale = w.xs[0];
-        a.M = B; a.N = e->NQKV; a.K = H; a.meta = e->step_meta; a.rope_rows = e->rope_rows;
-        a.q_out = e->qkv_dec; a.ld_q = e->NQKV; a.kpool = e->kv + (size_t)i * e->layer_stride;
-        a.nh = e->cfg.num_heads; a.nkv = e->cfg.num_kv_heads;
-        const bool place = (e->xcd_affine & 4) && e->xcd_xps;
-        if (e->fp8) qkv_rope_launch<true>(a, e->st_qkvf, e->ks_qkvf, place, e->stream);
-        else qkv_rope_launch<false>(a, e->st_qkvf, e->ks_qkvf, place, e->stream);
-        return;
-    }
-    if (e->ks_qkv > 1)   // fp32 split-K slabs; the attention prologue sums them, adds the bias and rounds (attn_decode.h)
-    {
-        GemmArgs a = gemm_args(e, e->xn_dec, H, w.wqkv, H, nullptr, e->slabs, e->NQKV, B, e->NQKV, H, w.sqkv, w.xs[0]);
-        a.xcd_nsplit = (e->xcd_split & 1) ? -1 : 0;
-        if ((e->xcd_affine & 4) && e->xcd_xps) a.xcd_maffine = -1;
-        gemm_skinny<EPI_SPLITK>(e->st_qkv, a, e->ks_qkv, e->stream);
-    }
-    else
-        gemm_skinny<EPI_BF16>(e->st_qkv, gemm_args(e, e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H, w.sqkv, w.xs[0]), 1, e->stream);
+    QkvRopeArgs a{};
+    a.X = e->xn_dec; a.ldx = H; a.W = w.wqkv; a.bias = w.bqkv; a.wscale = w.sqkv; a.xscale = w.xs[0];
+    a.M = B; a.N = e->NQKV; a.K = H; a.meta = e->step_meta; a.rope_rows = e->rope_rows;
+    a.q_out = e->qkv_dec; a.ld_q = e->NQKV; a.kpool = e->kv + (size_t)i * e->layer_stride;
+    a.nh = e->cfg.num_heads; a.nkv = e->cfg.num_kv_heads;
+    const bool place = (e->xcd_affine & 4) && e->xcd_xps;
+    if (e->fp8) qkv_rope_launch<true>(a, place, e->stream);
+    else qkv_rope_launch<false>(a, place, e->stream);
 }
 
 static void k_attn(ntts_backbone* e, int i) {
     const ntts_backbone_config& c = e->cfg;
     AttnDecodeArgs a{};
     a.qkv = e->qkv_dec; a.ld_qkv = e->NQKV; a.out = e->attn_dec; a.ld_out = c.num_heads * 64;
-    if (!e->qkv_fused && e->ks_qkv > 1) {
-        a.qkv_slabs = e->slabs; a.nslab = gemm_nsplit(e->H, e->ks_qkv, ktile_of(e)); a.slab_rows = c.max_batch; a.qkv_bias = e->layers[i].bqkv;
-    }
     a.kpool = e->kv + (size_t)i * e->layer_stride; a.vpool = a.kpool + e->kv_half;
     a.block_table = e->block_table; a.max_pages = e->max_pages; a.pos = e->sl.pos; a.state = e->sl.state;
     a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
     a.tl = e->attn_tl;
     a.xcd_rows = ((e->xcd_affine & 4) && !e->attn_tl) ? e->xcd_xps : 0;
     if (e->fp8) a.out_fp8_inv = 1.0f / e->layers[i].xs[1];   // attention output = o_proj's input
-    if (e->split_active && !e->attn_tl && (a.qkv_slabs || e->qkv_fused)) {       // long contexts below 2 workgroups per CU: context-split attention + combine
+    if (e->split_active && !e->attn_tl) {       // long contexts below 2 workgroups per CU: context-split attention + combine
         AttnSplitArgs q{};
         q.a = a; q.scores = e->as_scores; q.ld_scores = c.max_context + 16; q.stats = e->as_stats; q.oslabs = e->as_oslabs; q.nsplit = e->attn_split;
         q.a.slab_rows = c.max_batch;
-        attn_split_launch(q, c.max_batch, e->stream, true, e->qkv_fused);
+        attn_split_launch(q, c.max_batch, e->stream, true, true);
         return;
     }
-    if (e->qkv_fused) { attn_decode_launch_pre(a, c.max_batch, e->stream, e->attn_depth, e->attn_var, e->attn_lmax_small ? c.max_context : kAttnLMax); return; }
-    attn_decode_launch(a, c.max_batch, e->stream, e->attn_depth, e->attn_var, e->attn_lmax_small ? c.max_context : kAttnLMax);
+    attn_decode_launch_pre(a, c.max_batch, e->stream, c.max_context);
 }
 
 static void k_o_proj(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, QD = e->cfg.num_heads * 64;
     GemmArgs a = gemm_args(e, e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->slabs, H, B, H, QD, e->layers[i].so, e->layers[i].xs[1]);
-    a.xcd_nsplit = (e->xcd_split & 2) ? -1 : 0;
     if ((e->xcd_affine & 1) && e->xcd_xps) a.xcd_maffine = -1;
-    gemm_skinny<EPI_SPLITK>(e->st_o, a, e->ks_o, e->stream);
+    gemm_skinny<EPI_SPLITK>(a, e->ks_o, e->stream);
 }
 
 static void k_gate_up(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, F = e->F;
     GemmArgs gu = gemm_args(e, e->xn_dec, H, e->layers[i].wgu, H, nullptr, e->act_dec, F, B, 2 * F, H, e->layers[i].sgu, e->layers[i].xs[2]);
-    if (e->fp8) {
-        gu.out_fp8_inv = 1.0f / e->layers[i].xs[3];            // the activation is down_proj's input
-        if (e->gu_tile == 1) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3, 0, 64, false, true>(gu, 1, e->stream);
-        else gemm_skinny<EPI_SILU_MUL>(e->st_gu, gu, 1, e->stream);
-        return;
-    }
+    if (e->fp8) gu.out_fp8_inv = 1.0f / e->layers[i].xs[3];            // the activation is down_proj's input
     // (a 4-slot ring on the 128 x 128 tile, 96 KB in flight per CU instead of 64: 13.3 vs 13.4 us -- ring depth is not what
     //  bounds this kernel; profiles/r02h_sweep_gate_up_ring.log)
     // (natural-order gate/up tiles that use more CUs -- 128 x 80 as 244 workgroups of 4 or 8 waves, 128 x 96 as 204 -- measured
     //  15.5 / 13.7 / 14.1 vs 13.5 us and were removed: profiles/r02k_sweep_lpt_head_gu_tiles.log)
-    if (e->gu_tile == 1) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);        // 128 x 128, 8 waves
-    else if (e->gu_tile == 2) gemm_launch<8, 1, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);   // 256 x 64, 8 waves
-    else if (e->gu_large) gemm_large<EPI_SILU_MUL>(e, gu, e->stream);
-    else gemm_skinny<EPI_SILU_MUL>(e->st_gu, gu, 1, e->stream);
+    if (e->gu_128) {   // 128 x 128, 8 waves
+        if (e->fp8) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3, 0, 64, false, true>(gu, 1, e->stream);
+        else gemm_launch<4, 2, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);
+    } else gemm_skinny<EPI_SILU_MUL, 3>(gu, 1, e->stream);
 }
 
 static void k_down(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, F = e->F;
     GemmArgs a = gemm_args(e, e->act_dec, F, e->layers[i].wd, F, nullptr, e->slabs, H, B, H, F, e->layers[i].sd, e->layers[i].xs[3]);
-    a.xcd_nsplit = (e->xcd_split & 4) ? -1 : 0;
+    a.xcd_nsplit = -1;   // one K slice per XCD (pair) unless the row-block placement below applies (FETCH 15.0 -> 6.8 MB per launch, profiles/r02f_*)
     if ((e->xcd_affine & 2) && e->xcd_xps) a.xcd_maffine = -1;
-    gemm_skinny<EPI_SPLITK>(e->st_d, a, e->ks_d, e->stream);
+    gemm_skinny<EPI_SPLITK>(a, e->ks_d, e->stream);
 }
 
 // residual += reduce(slabs of a K-deep split-K GEMM); normed = rmsnorm(residual) * norm_w
 // next_scale: fp8 model, the static input scale of the GEMM that consumes the normalised rows (0 = bf16 output)
 static void k_add_norm(ntts_backbone* e, int K, int ks, const bf16_t* norm_w, bf16_t* resid_out, bf16_t* normed_out, float next_scale = 0.f, int affine_bit = 0) {
     NormArgs n{};
-    n.xcd_rows = ((e->xcd_affine & affine_bit) && e->norm_wide) ? e->xcd_xps : 0;
+    n.xcd_rows = (e->xcd_affine & affine_bit) ? e->xcd_xps : 0;
     n.slabs = e->slabs; n.nslab = gemm_nsplit(K, ks, ktile_of(e)); n.slab_rows = e->cfg.max_batch; n.resid_in = e->h_dec; n.resid_out = resid_out;
     n.norm_w = norm_w; n.normed_out = normed_out; n.M = e->cfg.max_batch; n.H = e->H; n.eps = e->cfg.rms_eps;
     if (e->fp8 && next_scale > 0.f) n.out_fp8_inv = 1.0f / next_scale;
-    add_rmsnorm_launch(n, e->stream, e->norm_wide);
+    add_rmsnorm_launch(n, e->stream, true);   // one row per workgroup: 256 CUs pull the slabs instead of 64 (5.5 -> 4.0 us per launch)
 }
 
 // ---- small-batch step (gemv.h): per layer  [norm -> QKV]  attention  [o_proj]  [norm -> gate/up -> SiLU*mul]  [down]
 static GemvArgs gemv_args(const ntts_backbone* e, const bf16_t* X, long ldx, const bf16_t* W, long ldw, void* out, long ldo, int N, int K) {
     GemvArgs a{};
-    a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.w_tile_major = e->w_tile_major ? 1 : 0; a.out = out; a.ldo = ldo;
+    a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.w_tile_major = 1; a.out = out; a.ldo = ldo;
     a.slab_rows = e->cfg.max_batch; a.M = e->cfg.max_batch; a.N = N; a.K = K;
     return a;
 }
@@ -993,20 +894,20 @@ static NormArgs pro_qkv(ntts_backbone* e, int i) {
     NormArgs n{};
     n.M = e->cfg.max_batch; n.H = e->H; n.eps = e->cfg.rms_eps; n.norm_w = e->layers[i].ln1;
     if (i == 0) { n.gather_ids = e->sl.cur_tok; n.embed = e->embed; }
-    else { n.slabs = e->slabs2; n.nslab = gemv_nsplit(e->F, e->sks_d); n.slab_rows = e->cfg.max_batch; n.resid_in = e->h_dec; }
+    else { n.slabs = e->slabs2; n.nslab = gemv_nsplit(e->F, ntts_backbone::kSksD); n.slab_rows = e->cfg.max_batch; n.resid_in = e->h_dec; }
     n.resid_out = e->h_alt;
     return n;
 }
 static void ks_qkv(ntts_backbone* e, int i) {
     GemvArgs a = gemv_args(e, nullptr, 0, e->layers[i].wqkv, e->H, e->slabs, e->NQKV, e->NQKV, e->H);
     a.pro = pro_qkv(e, i);
-    gemv_launch<EPI_SPLITK, true>(a, e->sks_q, e->stream);
+    gemv_launch<EPI_SPLITK, true>(a, ntts_backbone::kSksQ, e->stream);
 }
 static void ks_attn(ntts_backbone* e, int i) {
     const ntts_backbone_config& c = e->cfg;
     AttnDecodeArgs a{};
     a.qkv = nullptr; a.ld_qkv = e->NQKV; a.out = e->attn_dec; a.ld_out = c.num_heads * 64;
-    a.qkv_slabs = e->slabs; a.nslab = gemv_nsplit(e->H, e->sks_q); a.slab_rows = c.max_batch; a.qkv_bias = e->layers[i].bqkv;
+    a.qkv_slabs = e->slabs; a.nslab = gemv_nsplit(e->H, ntts_backbone::kSksQ); a.slab_rows = c.max_batch; a.qkv_bias = e->layers[i].bqkv;
     a.kpool = e->kv + (size_t)i * e->layer_stride; a.vpool = a.kpool + e->kv_half;
     a.block_table = e->block_table; a.max_pages = e->max_pages; a.pos = e->sl.pos; a.state = e->sl.state;
     a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
@@ -1017,35 +918,35 @@ static void ks_attn(ntts_backbone* e, int i) {
         attn_split_launch(q, c.max_batch, e->stream);
         return;
     }
-    attn_decode_launch_small(a, c.max_batch, e->stream, e->attn_depth_small);
+    attn_decode_launch_small(a, c.max_batch, e->stream);
 }
 static void ks_o_proj(ntts_backbone* e, int i) {
     const int QD = e->cfg.num_heads * 64;
     GemvArgs a = gemv_args(e, e->attn_dec, QD, e->layers[i].wo, QD, e->slabs, e->H, e->H, QD);
     if (e->split_active && !e->attn_tl) { a.xslabs = e->as_oslabs; a.n_xslab = e->attn_split; }   // context-split attention: chunk outputs summed here
-    gemv_launch<EPI_SPLITK, false>(a, e->sks_o, e->stream);
+    gemv_launch<EPI_SPLITK, false>(a, ntts_backbone::kSksO, e->stream);
 }
 static void ks_gate_up(ntts_backbone* e, int i) {
     GemvArgs a = gemv_args(e, nullptr, 0, e->layers[i].wgu, e->H, e->act_dec, e->F, 2 * e->F, e->H);
     NormArgs n{};
     n.M = e->cfg.max_batch; n.H = e->H; n.eps = e->cfg.rms_eps; n.norm_w = e->layers[i].ln2;
-    n.slabs = e->slabs; n.nslab = gemv_nsplit(e->cfg.num_heads * 64, e->sks_o); n.slab_rows = e->cfg.max_batch;
+    n.slabs = e->slabs; n.nslab = gemv_nsplit(e->cfg.num_heads * 64, ntts_backbone::kSksO); n.slab_rows = e->cfg.max_batch;
     n.resid_in = e->h_alt; n.resid_out = e->h_dec;
     a.pro = n;
     gemv_launch<EPI_SILU_MUL, true>(a, 1, e->stream);
 }
 static void ks_down(ntts_backbone* e, int i) {
-    gemv_launch<EPI_SPLITK, false>(gemv_args(e, e->act_dec, e->F, e->layers[i].wd, e->F, e->slabs2, e->H, e->H, e->F), e->sks_d, e->stream);
+    gemv_launch<EPI_SPLITK, false>(gemv_args(e, e->act_dec, e->F, e->layers[i].wd, e->F, e->slabs2, e->H, e->H, e->F), ntts_backbone::kSksD, e->stream);
 }
 static void ks_final_norm(ntts_backbone* e) {   // h += down (last layer); xn = rmsnorm(h) * final_norm  -> the lm_head's input
     NormArgs n{};
-    n.slabs = e->slabs2; n.nslab = gemv_nsplit(e->F, e->sks_d); n.slab_rows = e->cfg.max_batch; n.resid_in = e->h_dec; n.resid_out = e->h_dec;
+    n.slabs = e->slabs2; n.nslab = gemv_nsplit(e->F, ntts_backbone::kSksD); n.slab_rows = e->cfg.max_batch; n.resid_in = e->h_dec; n.resid_out = e->h_dec;
     n.norm_w = e->final_norm; n.normed_out = e->xn_dec; n.M = e->cfg.max_batch; n.H = e->H; n.eps = e->cfg.rms_eps;
-    add_rmsnorm_launch(n, e->stream, e->norm_wide);
+    add_rmsnorm_launch(n, e->stream, true);
 }
 static void ks_lm_head(ntts_backbone* e, bool keep_logits) {
     const int H = e->H, V = e->cfg.vocab_size;
-    GemvArgs a = gemv_args(e, e->xn_dec, H, e->w_tile_major ? e->embed_tm : e->embed, H, nullptr, 0, V, H);
+    GemvArgs a = gemv_args(e, e->xn_dec, H, e->embed_tm, H, nullptr, 0, V, H);
     a.part_val = e->part_val; a.part_idx = e->part_idx; a.mask_eos = e->sl.mask_eos;
     a.logits = keep_logits ? e->logits : nullptr; a.ld_logits = V;
     a.logits_bf16 = (keep_logits && e->n_sampling > 0) ? e->logits_bf16 : nullptr; a.ld_logits_bf16 = e->ldl;
@@ -1072,8 +973,8 @@ static void decode_step(ntts_backbone* e) {
     n0.gather_ids = e->sl.cur_tok; n0.embed = e->embed; n0.resid_out = e->h_dec; n0.norm_w = e->layers[0].ln1;
     n0.normed_out = e->xn_dec; n0.M = B; n0.H = H; n0.eps = c.rms_eps;
     if (e->fp8) n0.out_fp8_inv = 1.0f / e->layers[0].xs[0];
-    add_rmsnorm_launch(n0, e->stream, e->norm_wide);
-    if (e->qkv_fused) k_step_meta(e);
+    add_rmsnorm_launch(n0, e->stream, true);
+    k_step_meta(e);
     for (int i = 0; i < c.num_layers; ++i) {
         const bool last = i + 1 == c.num_layers;
         k_qkv(e, i);
@@ -1110,6 +1011,7 @@ static void drop_pages(ntts_backbone* e, HostSlot& s, size_t keep = 0) {
 // meta block -> device, asynchronously on `st`: through the next slot of the page-locked ring (waits only if the copy that last
 // used that slot -- four uploads ago -- has not executed yet)
 static hipError_t upload_meta(ntts_backbone* e, const int* src, size_t n, hipStream_t st) {
+    if (n > e->meta_cap) return hipErrorInvalidValue;   // (every caller checks first; the ring slots hold meta_cap ints)
     const int k = e->meta_next;
     e->meta_next = (k + 1) % ntts_backbone::kMetaStages;
     if (e->meta_used[k]) { const hipError_t rc = hipEventSynchronize(e->meta_ev[k]); if (rc != hipSuccess) return rc; }
@@ -1201,7 +1103,7 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
         for (int q = pos0[i]; q < lens[i]; q += 64) { tile_seq.push_back(i); tile_q0.push_back(q); }
         acc += lens[i] - pos0[i];
     }
-    if (e->pf_lpt) {
+    {
         // Causal attention: a 64-query tile that starts at position q0 sweeps (q0 + 64) / 32 KV pages, 2 .. 16 for a 500-token
         // prompt.  In prompt order the LAST workgroups dispatched are the deepest tiles of the last prompt and the pass ends on
         // them; sorted by descending depth (stable: ties keep prompt order) the shallow tiles fill the tail instead.
@@ -1253,18 +1155,25 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
     }
     // With a side stream the whole pass (meta upload included) runs there, ordered behind the work already on the engine's
     // stream and followed by that stream; every launch helper reads e->stream, so it is swapped for the duration of the call.
+    // If the ordering events cannot be recorded the pass stays on the engine's own stream (correct, merely not CU-masked);
+    // if the closing event fails the side stream is drained on the host before the engine's stream goes on.
     struct SideStream {
-        ntts_backbone* e; hipStream_t main;
+        ntts_backbone* e; hipStream_t main; bool on = false;
         explicit SideStream(ntts_backbone* e_) : e(e_), main(e_->stream) {
-            if (!e->pf_stream) return;
-            hipEventRecord(e->pf_ev[0], main);
-            hipStreamWaitEvent(e->pf_stream, e->pf_ev[0], 0);
+            if (!e->pf_stream || !e->pf_ev[0] || !e->pf_ev[1]) return;
+            if (hipEventRecord(e->pf_ev[0], main) != hipSuccess || hipStreamWaitEvent(e->pf_stream, e->pf_ev[0], 0) != hipSuccess) {
+                (void)hipGetLastError();
+                return;
+            }
             e->stream = e->pf_stream;
+            on = true;
         }
         ~SideStream() {
-            if (!e->pf_stream) return;
-            hipEventRecord(e->pf_ev[1], e->pf_stream);
-            hipStreamWaitEvent(main, e->pf_ev[1], 0);
+            if (!on) return;
+            if (hipEventRecord(e->pf_ev[1], e->pf_stream) != hipSuccess || hipStreamWaitEvent(main, e->pf_ev[1], 0) != hipSuccess) {
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize(e->pf_stream);
+            }
             e->stream = main;
         }
     } side(e);
@@ -1294,25 +1203,23 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
         r.qkv = e->qkv_pf; r.ld_qkv = e->NQKV; r.kpool = e->kv + (size_t)i * e->layer_stride; r.vpool = r.kpool + e->kv_half;
         r.block_table = e->block_table; r.max_pages = e->max_pages; r.meta = meta; r.rope_cos = e->rope_cos; r.rope_sin = e->rope_sin;
         r.nh = c.num_heads; r.nkv = c.num_kv_heads; r.T = Ti;
-        // the q heads are rotated by the attention kernel as it loads them (one read + one write of T x 896 values less per layer)
-        const bool rope_q_fused = e->pf_rope_q_fused && e->pf_rope_vec && e->NQKV % 8 == 0 && !e->pf_attn_simple;
-        r.skip_q = rope_q_fused ? 1 : 0;
-        if (e->pf_rope_vec && e->NQKV % 8 == 0) NTTS_LAUNCH((rope_kv_write_vec_kernel), dim3((Ti + kRopeTokPerBlock - 1) / kRopeTokPerBlock), dim3(256), st, r);
-        else NTTS_LAUNCH((rope_kv_write_kernel), dim3(Ti), dim3(256), st, r);
+        // the q heads are rotated by the attention kernel as it loads them (one read + one write of T x 896 values less per layer:
+        // prompt pass 28.16 -> 27.94 ms per chunk, profiles/r02k_sweep_pf_rope_q_fused.log); this kernel rotates k and scatters v
+        r.skip_q = 1;
+        NTTS_LAUNCH((rope_kv_write_vec_kernel), dim3((Ti + kRopeTokPerBlock - 1) / kRopeTokPerBlock), dim3(256), st, r);
         AttnPrefillArgs a{};
         a.qkv = e->qkv_pf; a.ld_qkv = e->NQKV; a.out = e->attn_pf; a.ld_out = QD; a.kpool = r.kpool; a.vpool = r.vpool;
         a.block_table = e->block_table; a.max_pages = e->max_pages; a.meta = meta; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
         if (e->fp8) a.out_fp8_inv = 1.0f / w.xs[1];     // attn_pf rows hold QD e4m3 BYTES (ld_out counts bytes then)
-        if (rope_q_fused) { a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; }
+        a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
         // Last layer: the KV pages are complete after the rope/KV-write above, and nothing but each prompt's LAST position
         // is read afterwards (it alone feeds the lm_head).  Attention runs on the one query tile per prompt that holds
         // it, then that row and its residual row are compacted and o_proj / the MLP run on n rows instead of T.
         // Row-wise results are unchanged (every GEMM / norm row is computed from that row's operands alone).
-        const bool prune = last && e->pf_prune_last && T >= 4L * n;
+        const bool prune = last && T >= 4L * n;
         int n_tiles = (int)tile_seq.size();
         if (prune) { a.meta.tile_seq = md + o_ltseq; a.meta.tile_q0 = md + o_ltq0; n_tiles = n; }
-        if (e->pf_attn_simple) NTTS_LAUNCH((attn_prefill_kernel), dim3((unsigned)n_tiles, c.num_heads), dim3(256), st, a);
-        else attn_prefill_launch(a, n_tiles, st, e->pf_gh);
+        attn_prefill_launch(a, n_tiles, st);
         const int Mi = prune ? n : Ti;                       // rows from here on
         const bf16_t* attn_in = e->attn_pf;
         bf16_t* hres = e->h_pf;
@@ -1325,17 +1232,15 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
             attn_in = attn_c;
             hres = h_c;
         }
-        // pf_resid: the residual add rides in the o_proj / down_proj epilogue (EPI_RESID: h = bf16(h + bf16(acc)), in place --
-        // the same two roundings the norm kernel applied), so the norm pass reads one row stream instead of two and writes one
+        // the residual add rides in the o_proj / down_proj epilogue (EPI_RESID: h = bf16(h + bf16(acc)), in place -- the same two
+        // roundings the norm kernel applied), so the norm pass reads one row stream instead of two and writes one
+        // (131.8 -> 128.3 ms per batch, profiles/r02i_ab_prefill_resid_epilogue.jsonl)
         NormArgs n1{};
-        if (e->pf_resid) {
+        {
             GemmArgs ao = gemm_args(e, attn_in, QD, w.wo, QD, nullptr, hres, H, Mi, H, QD, w.so, w.xs[1]);
             ao.resid_bf16 = hres; ao.ldrb = H;
             gemm_large<EPI_RESID>(e, ao, st);
             n1.o_bf16 = hres;
-        } else {
-            gemm_large<EPI_BF16>(e, gemm_args(e, attn_in, QD, w.wo, QD, nullptr, e->o_pf, H, Mi, H, QD, w.so, w.xs[1]), st);
-            n1.o_bf16 = e->o_pf; n1.resid_in = hres; n1.resid_out = hres;
         }
         n1.norm_w = w.ln2; n1.normed_out = e->xn_pf;
         n1.M = Mi; n1.H = H; n1.eps = c.rms_eps;
@@ -1345,18 +1250,14 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
         if (e->fp8) gu.out_fp8_inv = 1.0f / w.xs[3];
         gemm_large<EPI_SILU_MUL>(e, gu, st);
         NormArgs n2{};
-        if (e->pf_resid) {
+        {
             GemmArgs ad = gemm_args(e, e->act_pf, F, w.wd, F, nullptr, hres, H, Mi, H, F, w.sd, w.xs[3]);
             ad.resid_bf16 = hres; ad.ldrb = H;
             gemm_large<EPI_RESID>(e, ad, st);
             n2.o_bf16 = hres;
-        } else {
-            gemm_large<EPI_BF16>(e, gemm_args(e, e->act_pf, F, w.wd, F, nullptr, e->o_pf, H, Mi, H, F, w.sd, w.xs[3]), st);
-            n2.o_bf16 = e->o_pf; n2.resid_in = hres;
         }
         n2.eps = c.rms_eps; n2.H = H;
         if (!last) {
-            if (!e->pf_resid) n2.resid_out = e->h_pf;
             n2.norm_w = e->layers[i + 1].ln1; n2.normed_out = e->xn_pf; n2.M = Ti;
             if (e->fp8) n2.out_fp8_inv = 1.0f / e->layers[i + 1].xs[0];
         } else {  // only each prompt's last position feeds the lm_head: gather it into its decode-slot row
@@ -1433,12 +1334,10 @@ extern "C" int ntts_backbone_decode(ntts_backbone* e, int32_t n_steps) {
         const int nt = (int)trip.size() / 3;
         NTTS_LAUNCH((bt_update_kernel), dim3((nt + 63) / 64), dim3(64), st, (const int*)e->meta_dev, nt, e->block_table, e->max_pages);
     }
-    if (e->graph && e->graph_has_logits != (e->n_sampling > 0)) {   // the step's launch arguments changed
-        hipGraphExecDestroy(e->graph);
-        e->graph = nullptr;
-        e->graph_tried = false;
+    if ((e->graph || e->graph_split) && e->graph_has_logits != (e->n_sampling > 0)) {   // the step's launch arguments changed: both captures are stale
+        if (e->graph) { hipGraphExecDestroy(e->graph); e->graph = nullptr; }
         if (e->graph_split) { hipGraphExecDestroy(e->graph_split); e->graph_split = nullptr; }
-        e->graph_split_tried = false;
+        e->graph_tried = e->graph_split_tried = false;
     }
     // small-batch path: steps whose longest context has reached attn_split_ctx run the context-split attention (its own graph)
     const bool can_split = e->attn_split > 0 && !e->attn_tl;
@@ -1552,17 +1451,30 @@ extern "C" int ntts_backbone_set_prefill_cu_mask(ntts_backbone* e, const uint32_
     for (int i = 0; i < n_words; ++i) bits += __builtin_popcount(mask[i]);
     if (bits < 1) return fail(e, NTTS_EINVAL, "empty CU mask");
     HIPCHK(e, hipExtStreamCreateWithCUMask(&e->pf_stream, (uint32_t)n_words, mask));
-    HIPCHK(e, hipEventCreateWithFlags(&e->pf_ev[0], hipEventDisableTiming));
-    HIPCHK(e, hipEventCreateWithFlags(&e->pf_ev[1], hipEventDisableTiming));
+    e->pf_ev[0] = e->pf_ev[1] = nullptr;
+    if (hipEventCreateWithFlags(&e->pf_ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&e->pf_ev[1], hipEventDisableTiming) != hipSuccess) {   // no ordering events, no side stream
+        if (e->pf_ev[0]) hipEventDestroy(e->pf_ev[0]);
+        if (e->pf_ev[1]) hipEventDestroy(e->pf_ev[1]);
+        e->pf_ev[0] = e->pf_ev[1] = nullptr;
+        hipStreamDestroy(e->pf_stream);
+        e->pf_stream = nullptr;
+        return fail(e, NTTS_EHIP, "could not create the side stream's ordering events");
+    }
     return NTTS_OK;
 }
 
 extern "C" int ntts_backbone_export_codes(ntts_backbone* e, int32_t n, const int32_t* slots, int32_t speech_base, int32_t n_codes,
                                           int32_t modulo, int32_t* codes_dev, int32_t stride, int32_t* lens_dev) {
     if (!e || n < 1 || !slots || !codes_dev || !lens_dev || stride < 1 || n_codes < 1) return fail(e, NTTS_EINVAL, "bad argument");
-    if ((size_t)n > e->meta_cap) return fail(e, NTTS_EINVAL, "too many slots");
-    for (int i = 0; i < n; ++i)
-        if (slots[i] < 0 || slots[i] >= e->cfg.max_batch) return fail(e, NTTS_EINVAL, "slot %d out of range", slots[i]);
+    if (n > e->cfg.max_batch || (size_t)n > e->meta_cap) return fail(e, NTTS_EINVAL, "%d slots given, the engine has %d", n, e->cfg.max_batch);
+    {
+        std::vector<char> seen(e->cfg.max_batch, 0);
+        for (int i = 0; i < n; ++i) {
+            if (slots[i] < 0 || slots[i] >= e->cfg.max_batch) return fail(e, NTTS_EINVAL, "slot %d out of range", slots[i]);
+            if (seen[slots[i]]++) return fail(e, NTTS_EINVAL, "slot %d given twice", slots[i]);
+        }
+    }
     HIPCHK(e, hipSetDevice(e->device));
     // the slot list travels through the engine's meta block: stream-ordered behind whatever still reads it
     HIPCHK(e, upload_meta(e, slots, (size_t)n, e->stream));
@@ -1672,7 +1584,7 @@ extern "C" int ntts_backbone_attn_timeline(ntts_backbone* e, int32_t layer, uint
     unsigned long long* tl = (unsigned long long*)buf.p;
     HIPCHK(e, hipMemsetAsync(tl, 0, n * 8, e->stream));
     auto attn = [&](int i) { if (e->small) ks_attn(e, i); else k_attn(e, i); };
-    if (e->qkv_fused) k_step_meta(e);
+    if (!e->small) k_step_meta(e);
     attn((layer + 1) % e->cfg.num_layers);     // another layer first: this launch is neither the first nor cache-warm
     e->attn_tl = tl;
     attn(layer);
@@ -1705,7 +1617,6 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
     const double wb = e->fp8 ? 1.0 : 2.0;      // bytes per matrix weight / per GEMM-input activation element
     const double act = (double)B * wb;
     const int kt_ = ktile_of(e);
-    const bool qkv_split = e->ks_qkv > 1 && !e->qkv_fused;   // QKV leaves fp32 split-K slabs that the attention prologue reduces
     // Every replay works on the NEXT layer's weights / KV pool, as consecutive launches of this kernel do inside the
     // decode step: one layer's operands (84 MB of KV at batch 256) would sit in the 256 MB Infinity Cache when replayed
     // alone, all layers together (2 GB) do not -- so the timing below is HBM-cold like the in-graph launches.
@@ -1735,13 +1646,13 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
         }
     };
     // algorithmic bytes per launch: the weights of the GEMM + its activations in/out; for attention K/V only
-    const int ksq = e->small ? e->sks_q : e->ks_qkv, kso = e->small ? e->sks_o : e->ks_o, ksd = e->small ? e->sks_d : e->ks_d;
+    const int ksq = ntts_backbone::kSksQ, kso = e->small ? ntts_backbone::kSksO : e->ks_o, ksd = e->small ? ntts_backbone::kSksD : e->ks_d;
     switch (which) {
         case 0: *alg_bytes = kv_layer;   // SURVEY 8(d), strictly: K and V of every cached token (+ the appended one); the q/k/v
                                          // inputs (bf16 row or the QKV GEMM's fp32 slabs) and the output are the builder's own
                 *launches_per_step = L; break;
         case 1: *alg_bytes = (double)e->NQKV * H * wb + e->NQKV * 2.0 + act * H +
-                             (double)B * e->NQKV * ((qkv_split || e->small) ? 4.0 * gemm_nsplit(H, ksq, kt_) : 2.0);
+                             (double)B * e->NQKV * (e->small ? 4.0 * gemm_nsplit(H, ksq, kt_) : 2.0);   // small: fp32 slabs; tile path: bf16 q|v rows + the K entry
                 *launches_per_step = L; break;
         case 2: *alg_bytes = (double)H * QD * wb + act * QD + (double)gemm_nsplit(QD, kso, kt_) * B * H * 4.0;
                 *launches_per_step = L; break;
@@ -1753,7 +1664,7 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
         default: return fail(e, NTTS_EINVAL, "unknown kernel id %d", which);
     }
     if (which == 6 && B > e->Tmax) return fail(e, NTTS_EINVAL, "scratch too small");
-    if (e->qkv_fused) k_step_meta(e);   // the fused QKV kernel appends at the CURRENT position (not yet written), like the step it replays
+    if (!e->small) k_step_meta(e);   // the fused QKV kernel appends at the CURRENT position (not yet written), like the step it replays
     run(which, L - 1);  // warm (code, TLBs); the timed replays start from layer 0
     HIPCHK(e, hipEventRecord(e->ev[2], st));
     for (int i = 0; i < iters; ++i) run(which, i % L);

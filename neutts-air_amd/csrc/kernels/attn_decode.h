@@ -30,7 +30,7 @@ constexpr int kAttnMaxSlabs = 4;      // split-K factor of the QKV GEMM this ker
 constexpr int kAttnDepthDefault = 1;  // KV pages each wave keeps in flight (register ring)
 
 struct AttnDecodeArgs {
-    const bf16_t* qkv;     // [B][ld_qkv]: q heads | k heads | v heads, bias already added
+    const bf16_t* qkv;     // kPre (tile path): [B][ld_qkv] q heads (rotated) | k heads (unused) | v heads, bf16, from qkv_rope.h
     long ld_qkv;
     bf16_t* out;           // [B][nh*64]
     long ld_out;
@@ -44,8 +44,8 @@ struct AttnDecodeArgs {
     const bf16_t* rope_cos;  // [max_ctx][32] bf16 (cos(emb) rounded to bf16 like HF's cos.to(dtype))
     const bf16_t* rope_sin;
     int nh, nkv;
-    // alternative input (qkv == null): the QKV GEMM's fp32 split-K slabs [nslab <= kAttnMaxSlabs][slab_rows][ld_qkv]; this
-    // kernel then sums them in slab order, adds the bias and applies the nn.Linear output rounding (one RNE to bf16) itself
+    // small-batch path (!kPre): the QKV GEMV's fp32 split-K slabs [nslab <= kAttnMaxSlabs][slab_rows][ld_qkv]; the kernel sums
+    // them in slab order, adds the bias and applies the nn.Linear output rounding (one RNE to bf16), RoPE and the KV append itself
     const float* qkv_slabs;
     int nslab;
     long slab_rows;
@@ -178,33 +178,26 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
 #pragma unroll
         for (int j = 0; j < kDepth; ++j) load_k_at(bt0[j], kq[j]);
     }
-    const bf16_t* row = p.qkv + (long)b * p.ld_qkv;
     // prologue work items: t = head * 32 + pair index; heads 0 .. group-1 are the q heads, item head == group is k (+ v)
     const int nitems = (group + 1) * 32;
-    // element `col` of this sequence's q|k|v row as the bf16 nn.Linear output: read as such, or rebuilt from the QKV GEMM's
-    // split-K slabs (all loads independent; the additions follow the slab order, then + bias, then ONE rounding)
+    // element `col` of this sequence's q|k|v row as the bf16 nn.Linear output, rebuilt from the QKV GEMV's split-K slabs (all
+    // loads independent; the additions follow the slab order, then + bias, then ONE rounding)
     // Branch-free on purpose: with a data-dependent slab count in the control flow the compiler waits for each element's
     // loads before it requests the next element's (a chain of round trips); here every request of the prologue is in
     // flight at once.  Absent slabs re-read the last present one and are dropped by a select.
-    const bool from_slabs = p.qkv_slabs != nullptr;
     const float* sbase[kAttnMaxSlabs];
 #pragma unroll
     for (int sl = 0; sl < kAttnMaxSlabs; ++sl) {
         const int su = sl < p.nslab ? sl : (p.nslab > 0 ? p.nslab - 1 : 0);
-        sbase[sl] = from_slabs ? p.qkv_slabs + ((long)su * p.slab_rows + b) * p.ld_qkv : nullptr;
+        sbase[sl] = p.qkv_slabs + ((long)su * p.slab_rows + b) * p.ld_qkv;
     }
-    struct QkvReq { float part[kAttnMaxSlabs]; bf16_t bias; bf16_t direct; };
+    struct QkvReq { float part[kAttnMaxSlabs]; bf16_t bias; };
     auto qkv_request = [&](int col, QkvReq& q) {
-        if (from_slabs) {              // wave-uniform
 #pragma unroll
-            for (int sl = 0; sl < kAttnMaxSlabs; ++sl) q.part[sl] = sbase[sl][col];
-            q.bias = p.qkv_bias[col];
-        } else {
-            q.direct = row[col];
-        }
+        for (int sl = 0; sl < kAttnMaxSlabs; ++sl) q.part[sl] = sbase[sl][col];
+        q.bias = p.qkv_bias[col];
     };
     auto qkv_value = [&](const QkvReq& q) -> bf16_t {
-        if (!from_slabs) return q.direct;
         float a = q.part[0];
 #pragma unroll
         for (int sl = 1; sl < kAttnMaxSlabs; ++sl) a += sl < p.nslab ? q.part[sl] : 0.f;   // + 0.f: exact
@@ -725,36 +718,21 @@ inline void attn_split_launch(const AttnSplitArgs& q, int batch, hipStream_t s, 
     if (combine) NTTS_LAUNCH((attn_split_combine_kernel), dim3(batch), block, s, q);
 }
 
-template <int kVar, bool kPre = false>
-inline void attn_decode_launch_v(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth, int max_ctx) {
+// tile path, behind the fused QKV kernel (qkv_rope.h): q rows rotated, the new K entry already in its page.  One KV page per wave
+// in flight (deeper register rings: +0.2 / +1.2 us, r01d), V^T pages requested after the score pass (next to the K pages: 19.3 ->
+// 20.0 us, profiles/r03a_sweep_qkv_fused.log); engines with max_context <= 1024 take the instantiation with half the score rows.
+inline void attn_decode_launch_pre(const AttnDecodeArgs& p, int batch, hipStream_t s, int max_ctx) {
     const dim3 grid(batch, p.nkv), block(256);
-    if (p.tl) {   // diagnostics: the instantiation that records phase timestamps
-        NTTS_LAUNCH((attn_decode_kernel<1, true, kVar, 4, kAttnLMax, kPre>), grid, block, s, p);
-        return;
-    }
-    if (depth == 1 && max_ctx <= 1024) { NTTS_LAUNCH((attn_decode_kernel<1, false, kVar, 4, 1024, kPre>), grid, block, s, p); return; }
-    switch (depth) {
-        case 1: NTTS_LAUNCH((attn_decode_kernel<1, false, kVar, 4, kAttnLMax, kPre>), grid, block, s, p); break;
-        default: NTTS_LAUNCH((attn_decode_kernel<2, false, kVar, 4, kAttnLMax, kPre>), grid, block, s, p); break;   // deeper rings measured slower (r01d)
-    }
+    if (p.tl) NTTS_LAUNCH((attn_decode_kernel<1, true, 1, 4, kAttnLMax, true>), grid, block, s, p);   // diagnostics: phase timestamps
+    else if (max_ctx <= 1024) NTTS_LAUNCH((attn_decode_kernel<1, false, 1, 4, 1024, true>), grid, block, s, p);
+    else NTTS_LAUNCH((attn_decode_kernel<1, false, 1, 4, kAttnLMax, true>), grid, block, s, p);
 }
-// tile path behind the fused QKV kernel (qkv_rope.h): q rows rotated, the new K / V^T entry already in its page
-inline void attn_decode_launch_pre(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth, int var, int max_ctx) {
-    if (var & 4) attn_decode_launch_v<5, true>(p, batch, s, depth, max_ctx);        // V^T pages requested next to the K pages
-    else attn_decode_launch_v<1, true>(p, batch, s, depth, max_ctx);
-}
-// small-batch variant: `depth` pages per wave in flight, V^T requested next to K (kVar 7)
-inline void attn_decode_launch_small(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth) {
+// small-batch path (gemv.h): the QKV GEMV's fp32 split-K slabs are reduced, rotated and appended in this kernel's prologue; two pages
+// per wave in flight, V^T requested next to K (kVar 7): at batch 1 the kernel is one chain of dependent round trips
+inline void attn_decode_launch_small(const AttnDecodeArgs& p, int batch, hipStream_t s) {
     const dim3 grid(batch, p.nkv);
-    if (p.tl) { NTTS_LAUNCH((attn_decode_kernel<2, true, 7, 4>), grid, dim3(256), s, p); return; }   // diagnostics: phase timestamps
-    if (depth >= 2) NTTS_LAUNCH((attn_decode_kernel<2, false, 7, 4>), grid, dim3(256), s, p);
-    else NTTS_LAUNCH((attn_decode_kernel<1, false, 7, 4>), grid, dim3(256), s, p);
-}
-inline void attn_decode_launch(const AttnDecodeArgs& p, int batch, hipStream_t s, int depth = kAttnDepthDefault, int var = 1, int max_ctx = kAttnLMax) {
-    if ((var & 7) == 7) attn_decode_launch_v<7>(p, batch, s, depth, max_ctx);        // + V^T pages requested next to the K pages
-    else if ((var & 3) == 3) attn_decode_launch_v<3>(p, batch, s, depth, max_ctx);   // + non-temporal K / V^T page loads
-    else if (var & 1) attn_decode_launch_v<1>(p, batch, s, depth, max_ctx);
-    else attn_decode_launch_v<0>(p, batch, s, depth, max_ctx);
+    if (p.tl) NTTS_LAUNCH((attn_decode_kernel<2, true, 7, 4>), grid, dim3(256), s, p);   // diagnostics: phase timestamps
+    else NTTS_LAUNCH((attn_decode_kernel<2, false, 7, 4>), grid, dim3(256), s, p);
 }
 
 }  // namespace ntts

@@ -39,44 +39,10 @@ struct RopeWriteArgs {
     int skip_q;                // rope_kv_write_vec_kernel: leave the q heads alone (attn_prefill_gqa_kernel rotates them as it loads them)
 };
 
-NTTS_KERNEL(256) void rope_kv_write_kernel(RopeWriteArgs p) {
-    const int t = blockIdx.x;
-    const int sq = p.meta.tok_seq[t];
-    const int pos = p.meta.pos0[sq] + t - p.meta.tok_base[sq];
-    const int* bt = p.block_table + (long)p.meta.slot[sq] * p.max_pages;
-    const long pg = bt[pos / kPage];
-    const int slot = pos % kPage;
-    bf16_t* row = p.qkv + (long)t * p.ld_qkv;
-    const int npairs = (p.nh + 2 * p.nkv) * 32;
-    for (int x = threadIdx.x; x < npairs; x += 256) {
-        const int hh = x >> 5, i = x & 31;
-        const float c = bf2f(p.rope_cos[(long)pos * 32 + i]), s = bf2f(p.rope_sin[(long)pos * 32 + i]);
-        bf16_t* h = row + hh * 64;
-        if (hh < p.nh) {
-            float o1, o2;
-            rope_pair(bf2f(h[i]), bf2f(h[i + 32]), c, s, o1, o2);
-            h[i] = f2bf(o1);
-            h[i + 32] = f2bf(o2);
-        } else if (hh < p.nh + p.nkv) {
-            const int kvh = hh - p.nh;
-            float o1, o2;
-            rope_pair(bf2f(h[i]), bf2f(h[i + 32]), c, s, o1, o2);
-            bf16_t* kd = p.kpool + ((pg * p.nkv + kvh) * kPage + slot) * 64;
-            kd[i] = f2bf(o1);
-            kd[i + 32] = f2bf(o2);
-        } else {
-            const int kvh = hh - p.nh - p.nkv;
-            bf16_t* vd = p.vpool + (pg * p.nkv + kvh) * 64 * kPage + v_slot(slot);
-            vd[(long)i * kPage] = h[i];
-            vd[(long)(i + 32) * kPage] = h[i + 32];
-        }
-    }
-}
-
-// The same pass with 16-byte accesses: a work item = (token, head, 8 consecutive pairs) loads x[i0..i0+7], x[i0+32..i0+39] and
+// 16-byte accesses: a work item = (token, head, 8 consecutive pairs) loads x[i0..i0+7], x[i0+32..i0+39] and
 // the 8 cos / sin of its position as four 16-byte loads and stores the rotated halves as two (q in place, k into its page
 // row); 4 tokens per workgroup.  Only the V^T scatter (a token's 64 values go to 64 rows of its page) stays element-wise.
-// Same arithmetic per element (rope_pair), so the results are bit-identical to rope_kv_write_kernel; 58 -> 30 us per launch
+// Same arithmetic per element (rope_pair) as the element-wise kernel it replaced (bit-identical results); 58 -> 30 us per launch
 // at 32 000 tokens.  (ld_qkv % 8 == 0: the engine's QKV width is a multiple of 64.)
 constexpr int kRopeTokPerBlock = 4;
 NTTS_KERNEL(256) void rope_kv_write_vec_kernel(RopeWriteArgs p) {
@@ -140,124 +106,12 @@ struct AttnPrefillArgs {
     const bf16_t* rope_sin;    // RoPE while it loads its Q fragments (rope_kv_write_vec_kernel then only handles k and v: skip_q)
 };
 
-// grid (n_tiles, nh); 4 waves x 16 query rows
-NTTS_KERNEL(256) void attn_prefill_kernel(AttnPrefillArgs p) {
-    const int lane = lane_id(), w = wave_id();
-    const int g = lane >> 4, l15 = lane & 15;
-    const int sq = p.meta.tile_seq[blockIdx.x];
-    const int S = p.meta.seq_len[sq];
-    const int base = p.meta.tok_base[sq] - p.meta.pos0[sq];   // packed row of absolute position q is base + q
-    const int h = blockIdx.y;
-    const int kvh = h / (p.nh / p.nkv);
-    const int* bt = p.block_table + (long)p.meta.slot[sq] * p.max_pages;
-    const int qw0 = p.meta.tile_q0[blockIdx.x] + w * 16;   // first query position of this wave
-    if (qw0 >= S) return;                                  // wave-uniform; no barriers in this kernel
-    int qpos = qw0 + l15;                                  // this lane's query (B-operand column)
-    const bool qok = qpos < S;
-    if (!qok) qpos = S - 1;
-    const int qlast = (qw0 + 15 < S ? qw0 + 15 : S - 1);
-    const int npages = qlast / kPage + 1;
-
-    const bf16_t* qr = p.qkv + (long)(base + qpos) * p.ld_qkv + h * 64 + g * 16;
-    bf16x8 qB[2];
-    qB[0] = ld16<bf16x8>(qr);
-    qB[1] = ld16<bf16x8>(qr + 8);
-
-    auto scores = [&](int pg, float (&s)[8]) {
-        const bf16_t* kp = p.kpool + ((long)bt[pg] * p.nkv + kvh) * kPage * 64;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const bf16_t* kr = kp + (u * 16 + l15) * 64 + g * 16;
-            f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            a = mfma16(ld16<bf16x8>(kr), qB[0], a);
-            a = mfma16(ld16<bf16x8>(kr + 8), qB[1], a);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = pg * kPage + u * 16 + g * 4 + r;
-                float v = rbf(rbf(a[r]) * 0.125f);
-                if (key > qpos) v = -INFINITY;            // causal (covers key >= S as qpos <= S-1)
-                s[u * 4 + r] = v;
-            }
-        }
-    };
-
-    // ---- sweep 1: row max and softmax denominator (online), lane-local then across the 4 key groups
-    float m = -INFINITY, sum = 0.f;
-    for (int pg = 0; pg < npages; ++pg) {
-        float s[8];
-        scores(pg, s);
-        float tm = s[0];
-#pragma unroll
-        for (int e = 1; e < 8; ++e) tm = fmaxf(tm, s[e]);
-        const float mn = fmaxf(m, tm);
-        if (mn != -INFINITY) {
-            float add = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) add += fexp(s[e] - mn);
-            sum = sum * fexp(m - mn) + add;
-            m = mn;
-        }
-    }
-#pragma unroll
-    for (int sh = 16; sh <= 32; sh <<= 1) {
-        const float om = shfl_xor(m, sh), os = shfl_xor(sum, sh);
-        const float mn = fmaxf(m, om);
-        if (mn != -INFINITY) {
-            sum = (m == -INFINITY ? 0.f : sum * fexp(m - mn)) + (om == -INFINITY ? 0.f : os * fexp(om - mn));
-            m = mn;
-        }
-    }
-
-    // ---- sweep 2: P = bf16(exp(s - m) / sum), O += P V
-    f32x4 oacc[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) oacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int pg = 0; pg < npages; ++pg) {
-        float s[8];
-        scores(pg, s);
-        bf16x8 pA;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) pA[e] = (short)f2bf(fexp(s[e] - m) / sum);
-        const bf16_t* vp = p.vpool + ((long)bt[pg] * p.nkv + kvh) * 64 * kPage;
-        const bool tail = (pg + 1) * kPage > S;            // page holds slots past the prompt: mask them
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            bf16x8 vB = ld16<bf16x8>(vp + (nt * 16 + l15) * kPage + g * 8);   // slots 8g..8g+7 = keys 4g..+3, 16+4g..+3
-            if (tail) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const int key = pg * kPage + (e < 4 ? g * 4 + e : 16 + g * 4 + e - 4);
-                    if (key >= S) vB[e] = 0;
-                }
-            }
-            oacc[nt] = mfma16(pA, vB, oacc[nt]);
-        }
-    }
-    // D: col = d (l15 of tile nt), row = query qw0 + g*4 + r
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int q = qw0 + g * 4 + r;
-        if (q < S) {
-            if (p.out_fp8_inv > 0.f) {
-                unsigned char* o = (unsigned char*)p.out + (long)(base + q) * p.ld_out + h * 64 + l15;
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) o[nt * 16] = f2fp8c(rbf(oacc[nt][r]) * p.out_fp8_inv);
-            } else {
-                bf16_t* o = p.out + (long)(base + q) * p.ld_out + h * 64 + l15;
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) o[nt * 16] = f2bf(oacc[nt][r]);
-            }
-        }
-    }
-}
-
-
 // ------------------------------------------------------------------------------------------------
 // GQA-shared prefill attention: one workgroup per (64-query tile, kv-head).  The `group` query heads that share
 // a kv-head (7 for NeuTTS-Air) are processed together, so every K / V^T page is brought into LDS ONCE per
 // workgroup (LDS-DMA, double-buffered) and feeds 4 waves x GH heads, instead of being re-read from L2 by every
-// (head, 16-query wave) as in attn_prefill_kernel (kept as the simple reference path: 24x more load-path traffic).
-// Same arithmetic and rounding points as the simple kernel: two sweeps over the keys, P = bf16(softmax) before PV.
+// (head, 16-query wave) (24x less load-path traffic than the first, per-head kernel).
+// Eager contract: two sweeps over the keys, P = bf16(softmax) before PV.
 //   LDS images (lane-linear LDS-DMA, swizzled on the SOURCE side):
 //     K   page [32 keys][128 B]: 16-B chunk c of key r stored at chunk c ^ (r & 7)        (ds_read_b128 conflict-free)
 //     V^T page [64 d][64 B]:     16-B unit  u of row d stored at unit  u ^ ((d >> 2) & 3) (ds_read_b128 conflict-free)
@@ -503,10 +357,9 @@ NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
 }
 
 // host launcher: GH = 7 covers NeuTTS-Air's group in one pass; other group sizes run ceil(group / GH) passes
-inline void attn_prefill_launch(const AttnPrefillArgs& p, int n_tiles, hipStream_t s, int heads_per_pass = 7) {
+inline void attn_prefill_launch(const AttnPrefillArgs& p, int n_tiles, hipStream_t s) {
     const int group = p.nh / p.nkv;
     if (group <= 4) NTTS_LAUNCH((attn_prefill_gqa_kernel<4>), dim3(p.nkv, n_tiles, 1), dim3(256), s, p);
-    else if (heads_per_pass <= 4) NTTS_LAUNCH((attn_prefill_gqa_kernel<4>), dim3(p.nkv, n_tiles, (group + 3) / 4), dim3(256), s, p);
     else NTTS_LAUNCH((attn_prefill_gqa_kernel<7>), dim3(p.nkv, n_tiles, (group + 6) / 7), dim3(256), s, p);
 }
 

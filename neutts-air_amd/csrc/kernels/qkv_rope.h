@@ -255,11 +255,13 @@ NTTS_KERNEL(KS * 128) void qkv_rope_kernel(QkvRopeArgs p) {
     }
 }
 
+// 3 ring slots, 2 K slices per workgroup (MI355X, batch 256: 4 slices 6.56 vs 6.41 us, 2 slots 7.5, 4 / 6 slots 6.4-8.3:
+// profiles/r03a_sweep_qkv_fused*.log; KS = 2 also keeps the summation order of the two-slab path this kernel replaced)
 template <bool F8>
-inline void qkv_rope_launch(QkvRopeArgs p, int stages, int kslices, bool xcd_place, hipStream_t s) {
+inline void qkv_rope_launch(QkvRopeArgs p, bool xcd_place, hipStream_t s) {
+    constexpr int KS = 2, NS = 3;
     const int ktiles = p.K / (F8 ? 128 : 64);
-    if (kslices != 4) kslices = 2;
-    p.kps = (ktiles + kslices - 1) / kslices;
+    p.kps = (ktiles + KS - 1) / KS;
     const int mblocks = (p.M + 31) / 32, nblocks = p.N / 64;
     int grid = mblocks * nblocks;
     p.xcd_mpx = 0;
@@ -267,14 +269,7 @@ inline void qkv_rope_launch(QkvRopeArgs p, int stages, int kslices, bool xcd_pla
         p.xcd_mpx = p.M / 256;
         grid = 8 * p.xcd_mpx * nblocks;
     }
-    if (kslices == 4) {
-        if (stages >= 3) NTTS_LAUNCH((qkv_rope_kernel<3, F8, 4>), dim3(grid), dim3(512), s, p);
-        else NTTS_LAUNCH((qkv_rope_kernel<2, F8, 4>), dim3(grid), dim3(512), s, p);
-        return;
-    }
-    if (stages >= 6) NTTS_LAUNCH((qkv_rope_kernel<6, F8, 2>), dim3(grid), dim3(256), s, p);
-    else if (stages == 3) NTTS_LAUNCH((qkv_rope_kernel<3, F8, 2>), dim3(grid), dim3(256), s, p);
-    else NTTS_LAUNCH((qkv_rope_kernel<4, F8, 2>), dim3(grid), dim3(256), s, p);
+    NTTS_LAUNCH((qkv_rope_kernel<NS, F8, KS>), dim3(grid), dim3(KS * 128), s, p);
 }
 
 }  // namespace ntts

@@ -86,12 +86,10 @@ def _device_index(device, what: str) -> int:
 class _CodecFacade:
     """What `self.codec` looks like to callers of the reference: `.decode_code(codes[B,1,T]) -> wav[B,1,480*T]`,
     `.encode_code(audio_or_path=...) -> codes[B,1,T]` and `.device`.  `enc_engine` = the on-device encoder
-    (_hip.EncoderEngine); `encoder` = the neucodec package's torch module, used only when the checkpoint's encoder tensors
-    could not be mapped onto the engine (reference_encoder="neucodec" / "auto")."""
+    (_hip.EncoderEngine), the only encoder there is: no torch module is kept beside it."""
 
-    def __init__(self, engine: _hip.CodecEngine, encoder=None, enc_engine: Optional[_hip.EncoderEngine] = None):
+    def __init__(self, engine: _hip.CodecEngine, enc_engine: Optional[_hip.EncoderEngine] = None):
         self.engine = engine
-        self.encoder = encoder
         self.enc_engine = enc_engine
         self.device = f"cuda:{engine.device}"
 
@@ -105,24 +103,22 @@ class _CodecFacade:
 
     def encode_code(self, audio_or_path):
         """neucodec `encode_code`: a path, or a 16 kHz waveform [B, 1, L] (tensor / array) -> int codes [B, 1, T]."""
-        if self.enc_engine is not None:
-            import torch  # tensor container for API compatibility
-            if isinstance(audio_or_path, (str, Path)):
-                wavs = [load_audio_16k(audio_or_path)]
-            else:
-                arr = np.asarray(audio_or_path.detach().cpu() if hasattr(audio_or_path, "detach") else audio_or_path, dtype=np.float32)
-                if arr.ndim == 1:
-                    arr = arr[None, None, :]
-                elif arr.ndim == 2:
-                    arr = arr[:, None, :]
-                if arr.ndim != 3 or arr.shape[1] != 1:
-                    raise ValueError("audio must have shape [B, 1, L] (mono, 16 kHz)")
-                wavs = [arr[b, 0] for b in range(arr.shape[0])]
-            return torch.from_numpy(np.stack([self.enc_engine.encode(w) for w in wavs])[:, None, :].astype(np.int64))
-        if self.encoder is None:
-            raise ImportError("Reference encoding needs encoder weights: a codec spec with an 'encoder' entry, or the `neucodec` "
-                              "package (pip install neucodec); or pre-encode references (ref:examples/encode_reference.py).")
-        return self.encoder.encode_code(audio_or_path=audio_or_path)
+        if self.enc_engine is None:
+            raise RuntimeError("Reference encoding needs encoder weights on the encoder engine: a codec spec with an 'encoder' entry "
+                               "or a NeuCodec checkpoint; or pre-encode references (ref:examples/encode_reference.py).")
+        import torch  # tensor container for API compatibility
+        if isinstance(audio_or_path, (str, Path)):
+            wavs = [load_audio_16k(audio_or_path)]
+        else:
+            arr = np.asarray(audio_or_path.detach().cpu() if hasattr(audio_or_path, "detach") else audio_or_path, dtype=np.float32)
+            if arr.ndim == 1:
+                arr = arr[None, None, :]
+            elif arr.ndim == 2:
+                arr = arr[:, None, :]
+            if arr.ndim != 3 or arr.shape[1] != 1:
+                raise ValueError("audio must have shape [B, 1, L] (mono, 16 kHz)")
+            wavs = [arr[b, 0] for b in range(arr.shape[0])]
+        return torch.from_numpy(np.stack([self.enc_engine.encode(w) for w in wavs])[:, None, :].astype(np.int64))
 
 
 def load_audio_16k(path) -> np.ndarray:
@@ -168,7 +164,6 @@ class NeuTTS:
         lib_path: Optional[str] = None,
         do_sample: bool = True,
         seed: int = 0,
-        reference_encoder: str = "auto",
     ):
         # Consts (ref:neutts/neutts.py:84-91)
         self.sample_rate = 24_000
@@ -185,11 +180,6 @@ class NeuTTS:
         self._is_onnx_codec = False
         self._lib_path = lib_path
         self._max_batch = max_batch
-        # encode_reference: "hip" = the on-device encoder engine or an error, "neucodec" = the neucodec package's torch
-        # module, "auto" = the engine when the checkpoint's encoder tensors map onto it, else the package (with a warning)
-        if reference_encoder not in ("auto", "hip", "neucodec"):
-            raise ValueError("reference_encoder must be 'auto', 'hip' or 'neucodec'")
-        self._reference_encoder = reference_encoder
         # sampling contract of the reference call (ref:neutts/neutts.py:338-347); do_sample=False = greedy
         self.do_sample = do_sample
         self.top_k = 50
@@ -263,7 +253,7 @@ class NeuTTS:
     def _load_codec(self, codec_repo, codec_device):
         print(f"Loading codec from: {codec_repo if isinstance(codec_repo, str) else '<in-memory weights>'} on {codec_device} ...")
         dev = _device_index(codec_device, "codec_device")
-        encoder, enc_spec = None, None
+        enc_spec = None
         if isinstance(codec_repo, dict):
             cfg, sd = dict(codec_repo["config"]), codec_repo["state_dict"]
             enc_spec = codec_repo.get("encoder")       # {"config": EncoderConfig fields, "state_dict": Xcodec2Model names}
@@ -277,17 +267,12 @@ class NeuTTS:
                             "Loading the NeuCodec checkpoint needs the `neucodec` package (weights + reference "
                             "encoder): pip install neucodec") from e
                     cls = NeuCodec if codec_repo == "neuphonic/neucodec" else DistillNeuCodec
-                    encoder = cls.from_pretrained(codec_repo).eval()
-                    full_sd = encoder.state_dict()
+                    # the package is the checkpoint READER only (its state dict is re-keyed and uploaded; the module is dropped):
+                    # a tensor that does not map onto the engines is an error that lists the keys -- there is no torch fallback
+                    full_sd = cls.from_pretrained(codec_repo).state_dict()
                     sd = neucodec_to_xcodec2_names(full_sd)
                     cfg = {}
-                    if self._reference_encoder != "neucodec":
-                        try:
-                            enc_spec = {"config": {}, "state_dict": neucodec_encoder_to_xcodec2_names(full_sd)}
-                        except ValueError as e:
-                            if self._reference_encoder == "hip":
-                                raise
-                            warnings.warn(f"encode_reference stays on the neucodec package's torch encoder: {e}")
+                    enc_spec = {"config": {}, "state_dict": neucodec_encoder_to_xcodec2_names(full_sd)}
                 case "neuphonic/neucodec-onnx-decoder":
                     raise NotImplementedError("The ONNX decoder is a CPU runtime of the same decoder; use "
                                               "'neuphonic/neucodec' for the MI355X path.")
@@ -305,14 +290,12 @@ class NeuTTS:
         engine = _hip.CodecEngine(cfg, dev, self._lib_path)
         engine.load_state_dict(sd)
         enc_engine = None
-        if enc_spec is not None and self._reference_encoder != "neucodec":
+        if enc_spec is not None:
             ecfg = dict(enc_spec.get("config", {}))
             ecfg.setdefault("max_samples", 30 * 16000)       # the context holds ~30 s of audio (ref:README.md:35)
             enc_engine = _hip.EncoderEngine(ecfg, dev, self._lib_path)
             enc_engine.load_state_dict(enc_spec["state_dict"])
-        elif self._reference_encoder == "hip":
-            raise ValueError("reference_encoder='hip' needs encoder weights: a codec spec with an 'encoder' entry or a NeuCodec checkpoint")
-        self.codec = _CodecFacade(engine, encoder, enc_engine)
+        self.codec = _CodecFacade(engine, enc_engine)
 
     # ------------------------------------------------------------------------------------------ public API
     def infer(self, text: str, ref_codes, ref_text: str) -> np.ndarray:
@@ -389,6 +372,14 @@ class NeuTTS:
             return [i - self._speech_base for i in ids if self._speech_base <= i < self._speech_base + n_codes]
         text = self.tokenizer.decode(list(ids), add_special_tokens=False)
         return [int(n) for n in _SPEECH_RE.findall(text)]
+
+    def _ids_to_codes_array(self, ids: np.ndarray) -> np.ndarray:
+        """`_ids_to_codes` on an id array (the batched stream's per-burst hand-off): the range test of the regex, vectorised, when
+        the speech-token base is known and `_ids_to_codes` has not been replaced on the instance."""
+        if self._speech_base is not None and "_ids_to_codes" not in self.__dict__:
+            x = np.asarray(ids, dtype=np.int64) - self._speech_base
+            return x[(x >= 0) & (x < 65536)].astype(np.int32)
+        return np.asarray(self._ids_to_codes(np.asarray(ids).tolist()), dtype=np.int32)
 
     def decode_codes(self, codes: Sequence[Sequence[int]]) -> List[np.ndarray]:
         return self.codec.engine.decode(codes)
@@ -522,11 +513,18 @@ class NeuTTS:
         hop, stride = self.hop_length, self.streaming_stride_samples
         chunk, look_f, look_b, ovl = (self.streaming_frames_per_chunk, self.streaming_lookforward,
                                       self.streaming_lookback, self.streaming_overlap_frames)
-        cache = [list(rc) for rc in ref_codes]            # per utterance: reference codes + generated codes
-        n_dec = [len(rc) for rc in ref_codes]             # tokens already turned into audio
+        # per utterance: reference codes + generated codes, in one int32 row (the reference caches "<|speech_N|>" strings)
+        cap = max(len(rc) for rc in ref_codes) + int(eng.cfg["max_context"]) + 1
+        cache = np.zeros((n, cap), dtype=np.int32)
+        clen = np.zeros(n, dtype=np.int64)                # tokens in cache[i]
+        for i, rc in enumerate(ref_codes):
+            cache[i, :len(rc)] = rc
+            clen[i] = len(rc)
+        n_dec = clen.copy()                               # tokens already turned into audio
         n_seen = [0] * n
         blend = [_StreamBlender(stride) for _ in range(n)]
         done = [False] * n                                # final chunk emitted
+        need = chunk + look_f                             # undecoded tokens that make a window decodable (ref :401-404)
         try:
             while not all(done):
                 ids_all, n_new_all, fin_all = eng.read_all_array()    # blocks until the bursts enqueued so far are done
@@ -538,26 +536,30 @@ class NeuTTS:
                 for i in range(n):
                     if done[i]:
                         continue
-                    new = self._ids_to_codes(ids[i, n_seen[i]:n_new[i]].tolist())
-                    n_seen[i] = int(n_new[i])
-                    for c in new:
-                        cache[i].append(c)
-                        if len(cache[i]) - n_dec[i] >= chunk + look_f:
-                            t0 = max(n_dec[i] - look_b - ovl, 0)
-                            t1 = n_dec[i] + chunk + look_f + ovl
-                            s0 = (n_dec[i] - t0) * hop
-                            jobs.append((i, cache[i][t0:t1], s0, s0 + (chunk + 2 * ovl) * hop, False))
-                            n_dec[i] += chunk
+                    if n_new[i] > n_seen[i]:
+                        new = self._ids_to_codes_array(ids[i, n_seen[i]:n_new[i]])
+                        cache[i, clen[i]:clen[i] + len(new)] = new
+                        clen[i] += len(new)
+                        n_seen[i] = int(n_new[i])
+                    # The reference checks after EVERY appended token and slices `token_cache[start : n_dec + 31]` at the moment the
+                    # 30th undecoded token arrives -- the slice then ends at n_dec + 30, whatever arrives later.  Same windows here
+                    # without the per-token loop: as many as the tokens of this burst complete, each ending at its own n_dec + 30.
+                    while clen[i] - n_dec[i] >= need:
+                        t0 = max(int(n_dec[i]) - look_b - ovl, 0)
+                        t1 = int(n_dec[i]) + need
+                        s0 = (int(n_dec[i]) - t0) * hop
+                        jobs.append((i, cache[i, t0:t1], s0, s0 + (chunk + 2 * ovl) * hop, False))
+                        n_dec[i] += chunk
                     if fin[i]:
-                        remaining = len(cache[i]) - n_dec[i]
+                        remaining = int(clen[i] - n_dec[i])
                         if remaining > 0:
-                            t0 = max(len(cache[i]) - (look_b + ovl + remaining), 0)
-                            s0 = (len(cache[i]) - t0 - remaining - ovl) * hop
-                            jobs.append((i, cache[i][t0:], s0, None, True))
+                            t0 = max(int(clen[i]) - (look_b + ovl + remaining), 0)
+                            s0 = (int(clen[i]) - t0 - remaining - ovl) * hop
+                            jobs.append((i, cache[i, t0:clen[i]], s0, None, True))
                         done[i] = True
                 if jobs:
-                    wavs = self.codec.engine.decode([j[1] for j in jobs])     # one batched codec pass
-                    for (i, _, s0, s1, last), recon in zip(jobs, wavs):
+                    wavs = self.codec.engine.decode([j[1] for j in jobs], reuse_output=True)     # one batched codec pass; views of the
+                    for (i, _, s0, s1, last), recon in zip(jobs, wavs):                           # engine's pinned buffer, copied below
                         if self.watermarker is not None:
                             recon = self.watermarker.apply_watermark(recon, sample_rate=24_000)
                         yield i, blend[i].push(np.array(recon[s0:s1]), last=last)
@@ -723,7 +725,7 @@ def neucodec_encoder_to_xcodec2_names(sd: Dict[str, object], n_layers: int = 16)
     must exist; the acoustic encoder (`CodecEnc.*`, weight-normalised convolutions + SnakeBeta activations inside nested
     nn.Sequential containers) is mapped by MODULE ORDER and checked by SHAPE -- 1 input conv, per ratio 3 x (snake, conv 7,
     snake, conv 1) + snake + strided conv, then snake + conv 3 -- with weight norm folded (w = g * v / ||v||).  Any mismatch
-    raises ValueError; the caller then keeps the neucodec package's own encoder."""
+    raises ValueError that lists the keys (there is no other encoder to fall back to)."""
     import torch
     out: Dict[str, object] = {}
     missing: List[str] = []

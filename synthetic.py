@@ -7,6 +7,7 @@ NeuTTS-Air / NeuCodec shapes and `randint` prompts; numpy PCG64 so that every ma
 """
 from __future__ import annotations
 
+import re
 from dataclasses import asdict, dataclass
 from typing import Dict, List
 
@@ -360,3 +361,52 @@ def synthetic_speech(n_samples: int, seed: int = 0, sample_rate: int = 16000) ->
     env = 0.55 + 0.45 * np.sin(2 * np.pi * 2.3 * t + rng.uniform(0, 6.28))
     x = x * env + 0.01 * rng.standard_normal(n_samples)
     return (0.5 * x / np.max(np.abs(x))).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------
+# text front-end stand-ins (class-level tests, golden generators)
+# --------------------------------------------------------------------------------------
+class ByteTokenizer:
+    """Minimal stand-in for the HF tokenizer of a NeuTTS checkpoint (none is reachable offline): every special / `<|speech_N|>`
+    token is one id, text is byte-level.  Used by the class-level tests and the golden-vector generators."""
+    SPECIALS = ["<|TEXT_REPLACE|>", "<|SPEECH_REPLACE|>", "<|TEXT_PROMPT_START|>", "<|TEXT_PROMPT_END|>",
+                "<|SPEECH_GENERATION_START|>", "<|SPEECH_GENERATION_END|>"]
+
+    def __init__(self, n_codes):
+        self.base_special = 256
+        self.speech_base = self.base_special + len(self.SPECIALS)
+        self.n_codes = n_codes
+        self.vocab_size = self.speech_base + n_codes
+
+    def convert_tokens_to_ids(self, tok):
+        if tok in self.SPECIALS:
+            return self.base_special + self.SPECIALS.index(tok)
+        m = re.fullmatch(r"<\|speech_(\d+)\|>", tok)
+        return self.speech_base + int(m.group(1))
+
+    def encode(self, text, add_special_tokens=True):
+        ids, pos = [], 0
+        pat = re.compile(r"<\|[A-Za-z_0-9]+\|>")
+        for m in pat.finditer(text):
+            ids += list(text[pos:m.start()].encode())
+            ids.append(self.convert_tokens_to_ids(m.group(0)))
+            pos = m.end()
+        return ids + list(text[pos:].encode())
+
+    def decode(self, ids, add_special_tokens=False):
+        out = []
+        for i in ids:
+            if i >= self.speech_base:
+                out.append(f"<|speech_{i - self.speech_base}|>")
+            elif i >= self.base_special:
+                out.append(self.SPECIALS[i - self.base_special])
+            else:
+                out.append(chr(i))
+        return "".join(out)
+
+
+class LowercasePhonemizer:
+    """Stand-in for the espeak phonemizer (not installed here; the text front-end is off the hot path)."""
+
+    def phonemize(self, texts):
+        return [t.lower() for t in texts]

@@ -280,7 +280,7 @@ typedef void* hipStream_t;
 typedef struct emuEvent { double t; }* hipEvent_t;
 typedef void* hipGraph_t;
 typedef void* hipGraphExec_t;
-enum { hipSuccess = 0, hipErrorNotSupported = 801 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNotSupported = 801 };
 enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum { hipStreamCaptureModeGlobal = 0, hipStreamCaptureModeThreadLocal = 1, hipStreamNonBlocking = 1 };
 struct hipDeviceProp_t { char gcnArchName[64]; int multiProcessorCount; size_t totalGlobalMem; };

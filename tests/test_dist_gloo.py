@@ -56,3 +56,22 @@ def test_bench_contract_world2(emu_lib):
         assert k in rec
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     assert abs(rec["value"] - 2 * 2 * 4 / (rec["ms_per_step"] / 1e3)) < 1e-6 * rec["value"] + 1e-9
+
+
+def test_bench_contract_world8(emu_lib):
+    """The launch the driver uses on an 8-GPU node (`torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8`), on CPU ranks
+    over gloo against the emulator build: rank-0-only library step + barrier, rank-local CPU affinity, weight synthesis on rank 0
+    -> ONE arena broadcast + one packed codec buffer -> 8 contiguous shards with no collective in the step, max-over-ranks
+    timing, exactly one JSON line -- and every rank's start-up timeline on stderr."""
+    r = _torchrun(8, [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--tiny", "--batch", "2",
+                      "--prefill", "12", "--decode", "4", "--prefill-chunk", "2", "--no-roofline"],
+                  {"NTTS_BENCH_EMU_LIB": emu_lib}, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["scaling"] == "weak" and rec["cpu_baseline"] is None
+    assert abs(rec["value"] - 8 * 2 * 4 / (rec["ms_per_step"] / 1e3)) < 1e-6 * rec["value"] + 1e-9
+    for rank in range(8):          # the per-rank start-up timeline (library, engines, weights received, warm-up)
+        assert f"rank {rank}/8" in r.stderr and "warm-up done" in r.stderr
+    assert r.stderr.count("weights received") == 8 and r.stderr.count("weights synthesised and uploaded (rank 0)") == 1

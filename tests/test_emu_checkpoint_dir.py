@@ -1,145 +1,18 @@
-"""The reference's loading path (ref:neutts/neutts.py:163-166): `NeuTTS(backbone_repo=<HF checkpoint>)` reads the
-tokenizer and the Qwen2 weights with `transformers`.  Here a tiny Qwen2 checkpoint + a real `tokenizers` tokenizer
-(with the NeuTTS special / `<|speech_N|>` tokens) are written with `save_pretrained`, loaded through that path onto
-the emulated engine, and the class's prompt construction + greedy ids are compared with transformers' own
-`generate` on the very same checkpoint, called as the reference calls it (ref:neutts/neutts.py:338-347)."""
-import numpy as np
+"""The reference's loading path (ref:neutts/neutts.py:163-166) on the CPU SIMT emulator: bodies in tests/ckpt_dir_cases.py
+(shared with the MI355X twin tests/test_gpu_checkpoint_dir.py)."""
 import pytest
-import torch
 
-from oracle import backbone_ref as br
-from oracle import codec_ref as cr
-from oracle.gen_golden import hf_backbone
-
-SPECIALS = ["<|TEXT_REPLACE|>", "<|SPEECH_REPLACE|>", "<|TEXT_PROMPT_START|>", "<|TEXT_PROMPT_END|>",
-            "<|SPEECH_GENERATION_START|>", "<|SPEECH_GENERATION_END|>"]
-
-
-def build_tokenizer(n_codes):
-    """Byte-level BPE without merges (one token per byte) in Qwen2's tokenizer format -- AutoTokenizer resolves a
-    `model_type: qwen2` checkpoint to Qwen2Tokenizer, which assumes the ByteLevel alphabet -- plus the NeuTTS tokens."""
-    from tokenizers import Tokenizer, decoders, models, pre_tokenizers
-    from transformers import PreTrainedTokenizerFast
-    vocab = {c: i for i, c in enumerate(sorted(pre_tokenizers.ByteLevel.alphabet()))}
-    tk = Tokenizer(models.BPE(vocab=vocab, merges=[]))
-    tk.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False, use_regex=False)
-    tk.decoder = decoders.ByteLevel()
-    fast = PreTrainedTokenizerFast(tokenizer_object=tk)
-    fast.add_special_tokens({"additional_special_tokens": SPECIALS})
-    fast.add_tokens([f"<|speech_{i}|>" for i in range(n_codes)], special_tokens=True)
-    return fast
+import ckpt_dir_cases as cases
 
 
 @pytest.fixture(scope="module")
 def ckpt(tmp_path_factory):
-    d = tmp_path_factory.mktemp("neutts_tiny_ckpt")
-    ccfg = cr.CodecConfig.tiny()
-    n_codes = int(np.prod(ccfg.levels))
-    tok = build_tokenizer(n_codes)
-    cfg = br.BackboneConfig.tiny(vocab_size=len(tok), num_layers=1)
-    w = br.make_weights(cfg, 77, peak_sigma=0.5)
-    base = tok.convert_tokens_to_ids("<|speech_0|>")
-    w["model.embed_tokens.weight"][base:] *= 3.0      # greedy decoding then stays in the speech range
-    m = hf_backbone(cfg, w, torch.float32)             # the reference loads fp32 weights (ref :164)
-    m.save_pretrained(str(d))
-    tok.save_pretrained(str(d))
-    return str(d), cfg, w, tok, ccfg
+    return cases.make_ckpt(tmp_path_factory.mktemp("neutts_tiny_ckpt"))
 
 
 def test_checkpoint_dir_through_the_reference_loading_path(ckpt, emu_lib):
-    from neutts import NeuTTS
-    d, cfg, w, tok, ccfg = ckpt
-    cw = cr.make_weights(ccfg, 4)
-    tts = NeuTTS(backbone_repo=d, backbone_device="cuda",
-                 codec_repo=dict(config=dict(hidden_size=ccfg.hidden_size, intermediate_size=ccfg.intermediate_size,
-                                             num_layers=ccfg.num_layers, num_heads=ccfg.num_heads,
-                                             quantization_dim=ccfg.quantization_dim, levels=list(ccfg.levels),
-                                             hop_length=ccfg.hop_length, max_frames=256, max_rows=1024),
-                                 state_dict={k: v.numpy() for k, v in cw.items()}),
-                 codec_device="cuda", lib_path=emu_lib, do_sample=False)
-
-    class Phon:   # espeak is not installed here; the text front-end is off the hot path
-        def phonemize(self, texts):
-            return [t.lower() for t in texts]
-    tts.phonemizer = Phon()
-    tts.max_context, tts.min_new_tokens = 160, 6          # lowered to prompt + 24 once the prompt is known
-    assert tts._backbone_loader == "safetensors"      # tensors streamed from the shards, no nn.Module copy on the host
-    assert tts._speech_base == tok.convert_tokens_to_ids("<|speech_0|>")
-    assert tts._eos_id == tok.convert_tokens_to_ids("<|SPEECH_GENERATION_END|>")
-
-    ref_codes = torch.tensor([3, 77, 200, 5, 18, 9], dtype=torch.int32)
-    prompt = tts._apply_chat_template(ref_codes, "So I'm live.", "Testing.")
-    # prompt layout of ref:neutts/neutts.py:303-332, checked through the tokenizer's own decode
-    text = tts.tokenizer.decode(prompt, skip_special_tokens=False)
-    assert text == ("user: Convert the text to speech:<|TEXT_PROMPT_START|>so i'm live. testing.<|TEXT_PROMPT_END|>"
-                    "\nassistant:<|SPEECH_GENERATION_START|>" + "".join(f"<|speech_{int(c)}|>" for c in ref_codes))
-
-    tts.max_context = len(prompt) + 24            # keeps the emulated run short
-    # transformers on the same checkpoint, bf16 compute, the reference's generate() call with sampling off
-    from transformers import AutoModelForCausalLM
-    hf = AutoModelForCausalLM.from_pretrained(d, attn_implementation="eager").to(torch.bfloat16).eval()
-    hf.model.rotary_emb.inv_freq = br.rope_inv_freq(cfg)            # keep the fp32 buffer (oracle/backbone_ref.py docstring)
-    hf.model.rotary_emb.original_inv_freq = br.rope_inv_freq(cfg)
-    out = hf.generate(torch.tensor([prompt]), max_length=tts.max_context, eos_token_id=tts._eos_id, pad_token_id=tts._eos_id,
-                      do_sample=False, use_cache=True, min_new_tokens=6)
-    want = out[0, len(prompt):].tolist()
-    got = tts.generate_codes([prompt])[0]
-    n = min(len(got), len(want))
-    assert n >= 6 and got[:n] == want[:n] and abs(len(got) - len(want)) <= 1   # HF may or may not append the EOS it stopped on
-    # id -> code hand-off = tokenizer.decode + regex of the reference (ref :349, :276)
-    import re
-    s = tok.decode(got, skip_special_tokens=False)
-    assert tts._ids_to_codes(got) == [int(x) for x in re.findall(r"<\|speech_(\d+)\|>", s)]
-    audio = tts.infer("Testing.", ref_codes, "So I'm live.")
-    assert isinstance(audio, np.ndarray) and audio.dtype == np.float32 and len(audio) == tts.hop_length * len(tts._ids_to_codes(got))
+    cases.run_checkpoint_dir_case(ckpt, emu_lib)
 
 
 def test_llama_style_checkpoint_dispatch(tmp_path, emu_lib):
-    """The AutoModelForCausalLM dispatch of ref:neutts/neutts.py:164 beyond Qwen2: a Llama checkpoint (no q/k/v bias, UNTIED
-    lm_head -- `model_type: llama`, `tie_word_embeddings: false`, `attention_bias: false` in its config.json) saved by
-    transformers, loaded through `NeuTTS(backbone_repo=dir)`, gives the ids of transformers' own LlamaForCausalLM.generate
-    on that checkpoint (bf16, eager attention, greedy).  A `qwen3` config is refused with the reason."""
-    from transformers import AutoModelForCausalLM, LlamaConfig, LlamaForCausalLM
-    from neutts import NeuTTS
-    from neutts.neutts import _engine_config_from_hf
-    ccfg = cr.CodecConfig.tiny()
-    n_codes = int(np.prod(ccfg.levels))
-    tok = build_tokenizer(n_codes)
-    cfg = br.BackboneConfig(vocab_size=len(tok), hidden_size=448, intermediate_size=1216, num_layers=1, num_heads=7, num_kv_heads=1,
-                            attention_bias=False, tie_word_embeddings=False)
-    w = br.make_weights(cfg, 78, peak_sigma=0.5)
-    base = tok.convert_tokens_to_ids("<|speech_0|>")
-    w["lm_head.weight"][base:] *= 3.0
-    hc = LlamaConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
-                     num_hidden_layers=cfg.num_layers, num_attention_heads=cfg.num_heads, num_key_value_heads=cfg.num_kv_heads,
-                     head_dim=64, rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta, max_position_embeddings=2048,
-                     tie_word_embeddings=False, attention_bias=False, mlp_bias=False)
-    m = LlamaForCausalLM(hc).eval()
-    missing, unexpected = m.load_state_dict(w, strict=False)
-    assert not unexpected and all("inv_freq" in k for k in missing), (missing, unexpected)
-    d = str(tmp_path)
-    m.save_pretrained(d)
-    tok.save_pretrained(d)
-    cw = cr.make_weights(ccfg, 4)
-    tts = NeuTTS(backbone_repo=d, backbone_device="cuda",
-                 codec_repo=dict(config=dict(hidden_size=ccfg.hidden_size, intermediate_size=ccfg.intermediate_size,
-                                             num_layers=ccfg.num_layers, num_heads=ccfg.num_heads,
-                                             quantization_dim=ccfg.quantization_dim, levels=list(ccfg.levels),
-                                             hop_length=ccfg.hop_length, max_frames=256, max_rows=1024),
-                                 state_dict={k: v.numpy() for k, v in cw.items()}),
-                 codec_device="cuda", lib_path=emu_lib, do_sample=False)
-    assert tts.backbone.cfg["tie_word_embeddings"] is False and tts.backbone.cfg["attention_bias"] is False
-    prompt = [tok.convert_tokens_to_ids("<|SPEECH_GENERATION_START|>")] + [base + c for c in (3, 77, 200, 5, 18, 9)] + list(b"hello")
-    tts.max_context, tts.min_new_tokens = len(prompt) + 20, 6
-    hf = AutoModelForCausalLM.from_pretrained(d, attn_implementation="eager").to(torch.bfloat16).eval()
-    hf.model.rotary_emb.inv_freq = br.rope_inv_freq(cfg)
-    hf.model.rotary_emb.original_inv_freq = br.rope_inv_freq(cfg)
-    out = hf.generate(torch.tensor([prompt]), max_length=tts.max_context, eos_token_id=tts._eos_id, pad_token_id=tts._eos_id,
-                      do_sample=False, use_cache=True, min_new_tokens=6)
-    want = out[0, len(prompt):].tolist()
-    got = tts.generate_codes([prompt])[0]
-    n = min(len(got), len(want))
-    assert n >= 6 and got[:n] == want[:n] and abs(len(got) - len(want)) <= 1
-    from transformers import Qwen3Config
-    with pytest.raises(NotImplementedError, match="qk_norm"):
-        _engine_config_from_hf(Qwen3Config(hidden_size=448, num_attention_heads=7, num_key_value_heads=1, head_dim=64))
+    cases.run_llama_dispatch_case(tmp_path, emu_lib)

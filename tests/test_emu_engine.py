@@ -26,21 +26,18 @@ def test_tiny_teacher_forced(emu_lib):
 
 
 @pytest.mark.parametrize("knobs", [
-    {},                                                                                    # small-batch path (gemv.h), defaults
-    {"NTTS_SKS_Q": "2", "NTTS_SKS_O": "3", "NTTS_SKS_D": "16", "NTTS_ATTN_DEPTH_SMALL": "1", "NTTS_W_TILE_MAJOR": "0"},
+    {},                                                                                    # small-batch path (gemv.h)
     {"NTTS_ATTN_SPLIT": "3", "NTTS_ATTN_SPLIT_CTX": "40"},                                                               # small-batch path, context-split attention from context 40 on (3 chunks: ragged page ranges, an empty chunk early on; the run crosses the switch)
-    {"NTTS_SMALL_BATCH": "0", "NTTS_ATTN_DEPTH": "1", "NTTS_S_STAGES": "3", "NTTS_PF_GH": "4", "NTTS_HEAD_LARGE": "1", "NTTS_HEAD_XL": "1",
-     "NTTS_ATTN_SPLIT": "2", "NTTS_ATTN_SPLIT_CTX": "45"},   # large-batch path (gemm.h tiles), context-split attention + combine pass from context 45 on
-    {"NTTS_SMALL_BATCH": "0", "NTTS_ATTN_DEPTH": "4", "NTTS_S_STAGES": "6", "NTTS_KSPLIT_O": "2", "NTTS_KSPLIT_D": "5",
-     "NTTS_PREFILL_ATTN_SIMPLE": "1", "NTTS_KSPLIT_QKV": "3", "NTTS_ATTN_VAR": "2", "NTTS_NORM_WIDE": "0", "NTTS_W_TILE_MAJOR": "0", "NTTS_HEAD_LARGE": "1"},
-    # the lm_head's natural-order tile (gemm.h TN = 6: 256 x 288, 12 waves, uneven LDS-DMA loader split, partial last tile), row-major weights, prompt-order attention tiles (the tile-major default runs in tests/test_gpu_backbone.py)
-    {"NTTS_SMALL_BATCH": "0", "NTTS_HEAD_LARGE": "1", "NTTS_HEAD_XL": "4", "NTTS_PF_LPT": "0", "NTTS_W_TILE_MAJOR": "0"}])
+    {"NTTS_SMALL_BATCH": "0", "NTTS_HEAD_TILE": "2",
+     "NTTS_ATTN_SPLIT": "2", "NTTS_ATTN_SPLIT_CTX": "45"},   # large-batch path (gemm.h tiles, fused QKV + RoPE + K append), 256 x 256 lm_head tile, context-split attention + combine pass from context 45 on
+    {"NTTS_SMALL_BATCH": "0", "NTTS_HEAD_TILE": "1"},        # ... 128 x 128 lm_head tile
+    # the lm_head's natural-order tile (gemm.h TN = 6: 256 x 288, 12 waves, uneven LDS-DMA loader split, partial last tile)
+    {"NTTS_SMALL_BATCH": "0", "NTTS_HEAD_TILE": "4"}])
 def test_small_gqa2_page_crossing_peaked_exact(emu_lib, knobs, monkeypatch):
     """2 kv heads, prompt of 70 (3 pages), decode crosses the 96-token page boundary; peaked weights so the
     free-running greedy ids must be bit-identical to HF's -- on the small-batch decode path (wave-per-16-features GEMVs with
-    the fused norm prologue, 16-wave attention; any split-K factors, either weight layout) and on the large-batch path for
-    every tuning of its GEMMs (LDS ring depth, attention prefetch depth, split-K of o/down reduced in the norm kernel,
-    split-K of QKV reduced in the attention prologue, either prefill attention kernel)."""
+    the fused norm prologue, slabs reduced in the attention prologue) and on the large-batch path (QKV with RoPE and the K append in
+    its epilogue, attention without a prologue, split-K of o/down reduced in the norm kernel) with every lm_head tile."""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     z, cfg, w = load_fixture("backbone_small_peaked")
@@ -58,7 +55,7 @@ def test_xcd_row_block_placement(emu_lib, monkeypatch):
     64-row m-block on one group of XCDs (gemm.h xcd_maffine, norm.h xcd_row).  A pure permutation of which workgroup does what:
     at batch 64 (one m-block spread over all 8 XCDs, padding workgroups in the GEMM grids) two sequences in far-apart slots still
     give HF's ids bit for bit."""
-    for k, v in {"NTTS_SMALL_BATCH": "0", "NTTS_XCD_AFFINE": "7", "NTTS_HEAD_LARGE": "0"}.items():
+    for k, v in {"NTTS_SMALL_BATCH": "0", "NTTS_XCD_AFFINE": "7"}.items():
         monkeypatch.setenv(k, v)
     z, cfg, w = load_fixture("backbone_small_peaked")
     S, N, eos = int(z["s_len"]), 20, int(z["eos"])

@@ -12,47 +12,7 @@ import synthetic as syn
 from common import check_encoder_codes, engine_cfg, rms
 
 
-class FakeTokenizer:
-    """Minimal stand-in for the HF tokenizer: every special / speech token is one id, text is byte-level."""
-    SPECIALS = ["<|TEXT_REPLACE|>", "<|SPEECH_REPLACE|>", "<|TEXT_PROMPT_START|>", "<|TEXT_PROMPT_END|>",
-                "<|SPEECH_GENERATION_START|>", "<|SPEECH_GENERATION_END|>"]
-
-    def __init__(self, n_codes):
-        self.base_special = 256
-        self.speech_base = self.base_special + len(self.SPECIALS)
-        self.n_codes = n_codes
-        self.vocab_size = self.speech_base + n_codes
-
-    def convert_tokens_to_ids(self, tok):
-        if tok in self.SPECIALS:
-            return self.base_special + self.SPECIALS.index(tok)
-        m = re.fullmatch(r"<\|speech_(\d+)\|>", tok)
-        return self.speech_base + int(m.group(1))
-
-    def encode(self, text, add_special_tokens=True):
-        ids, pos = [], 0
-        pat = re.compile(r"<\|[A-Za-z_0-9]+\|>")
-        for m in pat.finditer(text):
-            ids += list(text[pos:m.start()].encode())
-            ids.append(self.convert_tokens_to_ids(m.group(0)))
-            pos = m.end()
-        return ids + list(text[pos:].encode())
-
-    def decode(self, ids, add_special_tokens=False):
-        out = []
-        for i in ids:
-            if i >= self.speech_base:
-                out.append(f"<|speech_{i - self.speech_base}|>")
-            elif i >= self.base_special:
-                out.append(self.SPECIALS[i - self.base_special])
-            else:
-                out.append(chr(i))
-        return "".join(out)
-
-
-class FakePhonemizer:
-    def phonemize(self, texts):
-        return [t.lower() for t in texts]
+FakeTokenizer, FakePhonemizer = syn.ByteTokenizer, syn.LowercasePhonemizer   # stand-ins for the HF tokenizer / espeak (synthetic.py)
 
 
 def build_tts(lib, bcfg=None, ccfg=None, max_batch=2, max_context=256, max_prefill_tokens=512, seed=31):

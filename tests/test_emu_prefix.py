@@ -37,10 +37,7 @@ def _run(eng, prompts, donors, n_new, eos):
     return logits, ids
 
 
-@pytest.mark.parametrize("knobs", [{}, {"NTTS_PREFILL_ATTN_SIMPLE": "1"}, {"NTTS_PF_GH": "4"}])
-def test_shared_prefill_is_bit_identical_to_plain_prefill(emu_lib, knobs, monkeypatch):
-    for k, v in knobs.items():
-        monkeypatch.setenv(k, v)
+def test_shared_prefill_is_bit_identical_to_plain_prefill(emu_lib):
     cfg = br.BackboneConfig.tiny(vocab_size=512, num_layers=2)
     w = br.make_weights(cfg, 21, peak_sigma=0.5)
     prefix, prompts = _prompts(cfg)

@@ -88,7 +88,7 @@ def fp8_distance(eng_logits, want8, want16):
             float(np.corrcoef(eng_logits[fin], want8[fin])[0, 1]))
 
 
-def check_fp8_model(lib, cfg, prompts, n_new, max_batch):
+def check_fp8_model(lib, cfg, prompts, n_new, max_batch, bar=0.10, corr_bar=0.995):
     """The fp8 engine against the oracle's restatement of the same quantisation scheme.  What can be asked of it: an fp8
     GEMM INPUT has 3 mantissa bits, so wherever two correct implementations differ by one bf16 rounding (fp32 summation
     order; the matrix core's own accumulation of e4m3 products, which is NOT an fp32 fma chain) a few per cent of the
@@ -121,7 +121,7 @@ def check_fp8_model(lib, cfg, prompts, n_new, max_batch):
         d_impl, d_quant, corr = fp8_distance(row, ref8, ref16)
         top2 = np.sort(ref8[np.isfinite(ref8)])[-2:]
         print(f"fp8 slot {s}: engine vs fp8 oracle rel. RMS {d_impl:.4f} (corr {corr:.5f}); fp8 oracle vs bf16 oracle {d_quant:.4f}")
-        assert d_impl <= 0.10 and d_impl < d_quant and corr >= 0.995, (s, d_impl, d_quant, corr)
+        assert d_impl <= bar and d_impl < d_quant and corr >= corr_bar, (s, d_impl, d_quant, corr)
         if top2[1] - top2[0] > 0.25 * float(np.std(ref8[np.isfinite(ref8)])):
             assert int(np.argmax(row)) == int(np.argmax(ref8)), s
         worst = max(worst, d_impl)
@@ -129,7 +129,7 @@ def check_fp8_model(lib, cfg, prompts, n_new, max_batch):
     eng.decode(n_new - 1)
     rows = [eng.read(s)[0] for s in range(len(prompts))]
     agree = [sum(int(a == b) for a, b in zip(rows[s], want8[tuple(p)].ids)) for s, p in enumerate(prompts)]
-    print(f"fp8 free-running ids equal to the fp8 oracle's: {agree} of {n_new} each")
+    print(f"fp8 free-running ids equal to the fp8 oracle's: {agree[:len(distinct)]} of {n_new} each (the {len(distinct)} distinct prompts)")
     assert all(len(r) == n_new for r in rows)
     eng.close()
     return rows, worst

@@ -46,14 +46,14 @@ def test_small_peaked_exact(lib, graph, monkeypatch):
 
 
 @pytest.mark.parametrize("knobs", [
-    {"NTTS_HEAD_XL": "1", "NTTS_PF_LPT": "0"},                            # the 256 x 256 lm_head tile, prompt-order attention tiles
-    {"NTTS_HEAD_XL": "4"},                                               # natural-order 256 x 288 tile, 12 waves (the batch-256 default)
-    {"NTTS_HEAD_XL": "4", "NTTS_W_NT": "0", "NTTS_W_TILE_MAJOR": "0"}])  # ... default cache policy, row-major weights
+    {"NTTS_HEAD_TILE": "0"},                                             # 64 x 64 skinny tile (the default up to batch 64)
+    {"NTTS_HEAD_TILE": "1"},                                             # 128 x 128
+    {"NTTS_HEAD_TILE": "2"},                                             # 256 x 256, 16 waves
+    {"NTTS_HEAD_TILE": "4"}])                                            # natural-order 256 x 288 tile, 12 waves (the batch-256 default)
 def test_small_peaked_exact_tile_variants(lib, knobs, monkeypatch):
     """Every lm_head tile the large-batch decode path can be switched to (gemm.h: TN = 4 and the natural-order tile with its
     uneven loader split and partial last tile), forced on at batch 2: free-running greedy ids bit-identical to HF's."""
     monkeypatch.setenv("NTTS_SMALL_BATCH", "0")
-    monkeypatch.setenv("NTTS_HEAD_LARGE", "1")
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
     z, cfg, w = load_fixture("backbone_small_peaked")
@@ -316,6 +316,39 @@ def test_air_peaked_free_running_exact(lib):
             assert tv[k][0] - tv[k][1] <= 2 * 2.0 ** (np.floor(np.log2(abs(tv[k][0]))) - 7), (u, k, tv[k])
         if u == 1:
             assert k == N
+
+
+def test_air_peaked8_free_running_in_a_full_batch256_engine(lib):
+    """the batch-256 tile path (fused QKV + RoPE + K append, prologue-free attention, 256 x 288 lm_head tile, XCD
+    row-block placement) producing 250 FREE-RUNNING tokens that are compared with transformers' bf16 run end to end -- 8 distinct
+    500-token utterances of the `backbone_air_peaked8` fixture (oracle/gen_golden.py recipe, utterances 0..7, peak_sigma 0.5)
+    spread over all four 64-row m-blocks of a FULL engine (slot s runs utterance s % 8), one prefill pass + 249 graph replays.
+    Per utterance: every id equals HF's up to the end, or up to the first step where HF's own top-2 logits are within 2 bf16
+    ulps (there our token must be one of those two; afterwards the two runs legitimately differ).  Batch / slot invariance: the
+    32 slots of an utterance hold identical rows."""
+    z, cfg, w = load_fixture("backbone_air_peaked8")
+    S, N, eos = int(z["s_len"]), int(z["n_new"]), int(z["eos"])
+    eng = make_engine(cfg, w, lib, max_batch=256, max_context=768, max_prefill_tokens=64 * S, bf16_upload=True)
+    samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
+    prompts = [br.synthetic_prompt(cfg, u, S) for u in range(8)]
+    for c in range(0, 256, 64):
+        eng.prefill([prompts[s % 8] for s in range(c, c + 64)], list(range(c, c + 64)), [samp] * 64)
+    eng.decode(N - 1)
+    rows = [eng.read(s)[0] for s in range(256)]
+    matched = []
+    for u in range(8):
+        ids, g, tv, ti = rows[u], z[f"bf16_ids_{u}"].tolist(), z[f"bf16_topv_{u}"], z[f"bf16_topi_{u}"]
+        assert len(ids) == N
+        k = next((i for i in range(N) if ids[i] != g[i]), N)
+        matched.append(k)
+        if k < N:
+            band = 2.0 * 2.0 ** (np.floor(np.log2(abs(tv[k][0]))) - 7)
+            assert tv[k][0] - tv[k][1] <= band and ids[k] in ti[k][:2].tolist(), (u, k, ids[k], g[k], tv[k], ti[k])
+        for s in range(u, 256, 8):       # slots 8 j + u: m-blocks 0..3, every XCD group
+            assert rows[s] == ids, (u, s)
+    print(f"free-running ids equal to transformers' for {matched} of {N} steps per utterance (N = to the end; else up to a <= 2-ulp tie of HF's own logits); "
+          f"distinct ids per utterance: {[len(set(rows[u])) for u in range(8)]}")
+    eng.close()
 
 
 def test_air_prefix_sharing_identical_to_plain_prefill(air):

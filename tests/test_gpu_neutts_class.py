@@ -73,3 +73,35 @@ def test_sampling_default_call_runs_and_stays_in_vocab(tts):
     finally:
         tts.do_sample = False
 test_device_side_code_handoff = cases.test_device_side_code_handoff
+
+
+def test_infer_at_air_geometry_with_the_dave_reference_voice(hip_lib):
+    """BASELINE.json configs[0]'s workload on the GPU: one utterance, reference voice ref:samples/dave.pt
+    (372 codes), greedy, through `_apply_chat_template` -> `generate_codes` -> `infer()` at NeuTTS-Air's layer geometry (24
+    layers) and NeuCodec's decoder geometry -- against tests/golden/infer_air_dave.npz, which oracle/gen_golden_infer.py made
+    with transformers' generate and the codec restatement from the reference's own lines.  Prompt ids identical; generated ids
+    identical (or up to a <= 2-ulp tie of transformers' own logits); waveform within BASELINE's 1e-3 RMS of the fp32 oracle's."""
+    import os
+    from common import GOLD, rms
+    z = np.load(os.path.join(GOLD, "infer_air_dave.npz"), allow_pickle=True)
+    t = cases.build_tts(hip_lib, bcfg=lambda v: br.BackboneConfig(vocab_size=v), ccfg=cr.CodecConfig.neucodec(), max_batch=1,
+                        max_context=1024, max_prefill_tokens=1024, seed=int(z["seed_backbone"]))
+    dave = torch.tensor(z["dave_codes"])
+    prompt = t._apply_chat_template(dave, str(z["ref_text"]), str(z["text"]))
+    assert prompt == z["prompt"].tolist()
+    t.max_context, t.min_new_tokens = len(prompt) + int(z["n_new"]), int(z["min_new"])
+    got, want, tv, ti = t.generate_codes([prompt])[0], z["ids"].tolist(), z["topv"], z["topi"]
+    n = min(len(got), len(want))
+    k = next((i for i in range(n) if got[i] != want[i]), None)
+    if k is not None:
+        band = 2.0 * 2.0 ** (np.floor(np.log2(abs(tv[k][0]))) - 7)
+        assert tv[k][0] - tv[k][1] <= band and got[k] in ti[k][:2].tolist(), (k, got[k], want[k], tv[k], ti[k])
+        pytest.skip(f"ids equal up to a tie of transformers' own logits at step {k}: the waveform comparison needs equal codes")
+    assert abs(len(got) - len(want)) <= 1 and n >= int(z["min_new"])      # HF may or may not append the EOS it stopped on
+    assert t._ids_to_codes(got) == z["codes"].tolist()[:len(t._ids_to_codes(got))]
+    audio = t.infer(str(z["text"]), dave, str(z["ref_text"]))
+    ref = z["wav"][:len(audio)]
+    assert audio.dtype == np.float32 and len(audio) == t.hop_length * len(t._ids_to_codes(got)) and abs(len(audio) - len(z["wav"])) <= t.hop_length
+    err, sig = rms(audio - ref), rms(ref)
+    print(f"infer() at Air geometry, dave reference: {len(got)} ids identical to transformers', waveform RMS error {err:.3e} at signal RMS {sig:.3e}")
+    assert err <= 1e-3 and err <= 2e-2 * sig

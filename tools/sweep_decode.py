@@ -75,14 +75,8 @@ def main():
         out.flush()
         return best
 
-    plan = json.loads(a.knobs) if a.knobs else [
-        ["NTTS_S_STAGES", [2, 3, 4, 6]],
-        ["NTTS_KSPLIT_QKV", [1, 2, 4]],
-        ["NTTS_KSPLIT_O", [1, 2, 4, 7]],
-        ["NTTS_KSPLIT_D", [2, 4, 8, 16]],
-        ["NTTS_GU_LARGE", [0, 1]],
-        ["NTTS_HEAD_STAGES", [2, 3, 4]],
-    ]
+    # the engine keeps few environment knobs; an experiment adds its own temporary one and names it here
+    plan = json.loads(a.knobs) if a.knobs else [["NTTS_HEAD_TILE", [2, 4]], ["NTTS_XCD_AFFINE", [0, 7]]]
     cur = {}
     base = measure(cur)
     for name, values in plan:
