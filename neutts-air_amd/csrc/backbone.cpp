@@ -115,9 +115,9 @@ struct ntts_backbone {
     // 15.0 -> 6.8 MB (profiles/r02f_*); above it the row-block placement (xcd_affine) takes over
     // Small-batch decode step (max_batch <= NTTS_SMALL_BATCH, default 8; BASELINE configs[1] = batch 1): wave-per-16-features
     // GEMV kernels with the slab-reduce + residual + RMSNorm fused into the consumer's prologue (gemv.h) -- 5 launches per
-    // layer instead of 7.  Split-K factors 4 / 7 / 10 (QKV / o_proj / down_proj), two KV pages per wave in flight.
+    // layer instead of 7.  Split-K factors 7 / 10 (o_proj / down_proj slabs, reduced in the next GEMV's prologue); QKV splits K inside its workgroups.
     bool small = false;
-    static constexpr int kSksQ = 4, kSksO = 7, kSksD = 10;
+    static constexpr int kSksO = 7, kSksD = 10;
     bf16_t* h_alt = nullptr;     // second residual-stream buffer (the fused prologue writes the new stream while others still read the old)
     int attn_split = 8;          // context-split attention over this many workgroups per (sequence, kv-head) (NTTS_ATTN_SPLIT), used
     int attn_split_ctx = 896;    //   once the longest running context reaches attn_split_ctx tokens (NTTS_ATTN_SPLIT_CTX).  Measured at batch 1
@@ -356,8 +356,8 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
 
     e->small = B <= env_int("NTTS_SMALL_BATCH", 8) && B <= kGemvRows && H <= 1024 && V % 16 == 0 && e->NQKV % 16 == 0 && F % 32 == 0 &&
                !e->fp8;   // (the small-batch GEMV kernels are bf16 only: the fp8 model takes the tile kernels at every batch)
-    static_assert(ntts_backbone::kSksQ <= kAttnMaxSlabs && ntts_backbone::kSksO <= 16 && ntts_backbone::kSksD <= 16, "slab counts");
-    if (!e->small) {
+    static_assert(ntts_backbone::kSksO <= 16 && ntts_backbone::kSksD <= 16, "slab counts");
+    {
         CR_HIP(hipMalloc((void**)&e->step_meta, (size_t)B * 4 * sizeof(int)));
         CR_HIP(hipMemset(e->step_meta, 0, (size_t)B * 4 * sizeof(int)));
         CR_HIP(hipMalloc((void**)&e->rope_rows, (size_t)B * 64 * 2));
@@ -835,10 +835,10 @@ static void k_attn(ntts_backbone* e, int i) {
         AttnSplitArgs q{};
         q.a = a; q.scores = e->as_scores; q.ld_scores = c.max_context + 16; q.stats = e->as_stats; q.oslabs = e->as_oslabs; q.nsplit = e->attn_split;
         q.a.slab_rows = c.max_batch;
-        attn_split_launch(q, c.max_batch, e->stream, true, true);
+        attn_split_launch(q, c.max_batch, e->stream, true);
         return;
     }
-    attn_decode_launch_pre(a, c.max_batch, e->stream, c.max_context);
+    attn_decode_launch(a, c.max_batch, e->stream, c.max_context);
 }
 
 static void k_o_proj(ntts_backbone* e, int i) {
@@ -898,16 +898,20 @@ static NormArgs pro_qkv(ntts_backbone* e, int i) {
     n.resid_out = e->h_alt;
     return n;
 }
+// QKV + bias + rounding + RoPE + K append in one GEMV launch (qkv_rope.h gemv_qkv_rope_kernel): batch 1 step 1.003 -> 0.962 ms together
+// with the 8-wave prologue-free attention (profiles/r03c_sweep_b1_fused_qkv_attn_waves.log)
 static void ks_qkv(ntts_backbone* e, int i) {
-    GemvArgs a = gemv_args(e, nullptr, 0, e->layers[i].wqkv, e->H, e->slabs, e->NQKV, e->NQKV, e->H);
-    a.pro = pro_qkv(e, i);
-    gemv_launch<EPI_SPLITK, true>(a, ntts_backbone::kSksQ, e->stream);
+    GemvQkvArgs a{};
+    a.pro = pro_qkv(e, i); a.W = e->layers[i].wqkv; a.bias = e->layers[i].bqkv; a.M = e->cfg.max_batch; a.N = e->NQKV; a.K = e->H;
+    a.meta = e->step_meta; a.rope_rows = e->rope_rows; a.q_out = e->qkv_dec; a.ld_q = e->NQKV;
+    a.kpool = e->kv + (size_t)i * e->layer_stride; a.nh = e->cfg.num_heads; a.nkv = e->cfg.num_kv_heads;
+    gemv_qkv_rope_launch(a, e->stream);
 }
 static void ks_attn(ntts_backbone* e, int i) {
     const ntts_backbone_config& c = e->cfg;
     AttnDecodeArgs a{};
-    a.qkv = nullptr; a.ld_qkv = e->NQKV; a.out = e->attn_dec; a.ld_out = c.num_heads * 64;
-    a.qkv_slabs = e->slabs; a.nslab = gemv_nsplit(e->H, ntts_backbone::kSksQ); a.slab_rows = c.max_batch; a.qkv_bias = e->layers[i].bqkv;
+    a.qkv = e->qkv_dec; a.ld_qkv = e->NQKV; a.out = e->attn_dec; a.ld_out = c.num_heads * 64;
+    a.slab_rows = c.max_batch;
     a.kpool = e->kv + (size_t)i * e->layer_stride; a.vpool = a.kpool + e->kv_half;
     a.block_table = e->block_table; a.max_pages = e->max_pages; a.pos = e->sl.pos; a.state = e->sl.state;
     a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
@@ -954,6 +958,7 @@ static void ks_lm_head(ntts_backbone* e, bool keep_logits) {
 }
 
 static void decode_step_small(ntts_backbone* e) {
+    k_step_meta(e);
     for (int i = 0; i < e->cfg.num_layers; ++i) {
         ks_qkv(e, i);
         ks_attn(e, i);
@@ -1584,7 +1589,7 @@ extern "C" int ntts_backbone_attn_timeline(ntts_backbone* e, int32_t layer, uint
     unsigned long long* tl = (unsigned long long*)buf.p;
     HIPCHK(e, hipMemsetAsync(tl, 0, n * 8, e->stream));
     auto attn = [&](int i) { if (e->small) ks_attn(e, i); else k_attn(e, i); };
-    if (!e->small) k_step_meta(e);
+    k_step_meta(e);
     attn((layer + 1) % e->cfg.num_layers);     // another layer first: this launch is neither the first nor cache-warm
     e->attn_tl = tl;
     attn(layer);
@@ -1646,13 +1651,13 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
         }
     };
     // algorithmic bytes per launch: the weights of the GEMM + its activations in/out; for attention K/V only
-    const int ksq = ntts_backbone::kSksQ, kso = e->small ? ntts_backbone::kSksO : e->ks_o, ksd = e->small ? ntts_backbone::kSksD : e->ks_d;
+    const int kso = e->small ? ntts_backbone::kSksO : e->ks_o, ksd = e->small ? ntts_backbone::kSksD : e->ks_d;
     switch (which) {
         case 0: *alg_bytes = kv_layer;   // SURVEY 8(d), strictly: K and V of every cached token (+ the appended one); the q/k/v
                                          // inputs (bf16 row or the QKV GEMM's fp32 slabs) and the output are the builder's own
                 *launches_per_step = L; break;
         case 1: *alg_bytes = (double)e->NQKV * H * wb + e->NQKV * 2.0 + act * H +
-                             (double)B * e->NQKV * (e->small ? 4.0 * gemm_nsplit(H, ksq, kt_) : 2.0);   // small: fp32 slabs; tile path: bf16 q|v rows + the K entry
+                             (double)B * e->NQKV * 2.0;   // bf16 q | v rows + the K entry
                 *launches_per_step = L; break;
         case 2: *alg_bytes = (double)H * QD * wb + act * QD + (double)gemm_nsplit(QD, kso, kt_) * B * H * 4.0;
                 *launches_per_step = L; break;
@@ -1664,7 +1669,7 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
         default: return fail(e, NTTS_EINVAL, "unknown kernel id %d", which);
     }
     if (which == 6 && B > e->Tmax) return fail(e, NTTS_EINVAL, "scratch too small");
-    if (!e->small) k_step_meta(e);   // the fused QKV kernel appends at the CURRENT position (not yet written), like the step it replays
+    k_step_meta(e);   // the fused QKV kernel appends at the CURRENT position (not yet written), like the step it replays
     run(which, L - 1);  // warm (code, TLBs); the timed replays start from layer 0
     HIPCHK(e, hipEventRecord(e->ev[2], st));
     for (int i = 0; i < iters; ++i) run(which, i % L);

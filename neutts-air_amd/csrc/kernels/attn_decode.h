@@ -1,8 +1,9 @@
-// attn_decode.h -- one decode step of GQA attention over the paged KV cache, RoPE + cache append fused.
+// attn_decode.h -- one decode step of GQA attention over the paged KV cache.
 //
 // Replaces, for q_len = 1 (hf:models/qwen2/modeling_qwen2.py):
-//   apply_rotary_pos_emb :113-135   DynamicCache.update hf:cache_utils.py:127-146
 //   eager_attention_forward :150-172  (bf16(QK^T) * scaling -> softmax fp32 -> bf16 -> PV, bf16 out)
+//   the V half of DynamicCache.update hf:cache_utils.py:127-146 (the transposed V^T page; RoPE and the K append ride in the
+//   QKV projection's epilogue, qkv_rope.h, which hands over rotated q heads and the v head as one bf16 row per sequence)
 //
 // One workgroup (4 waves) per (sequence, kv-head): the 7 query heads of a GQA group share every K/V
 // byte that is read, so KV traffic is the algorithmic minimum  L * 2 * 64 * 2 B  per (seq, kv-head, layer).
@@ -26,11 +27,9 @@ constexpr int kAttnLMax = 2048;  // ref:neutts/neutts.py:85 max_context
 // slot of token t (0..31) inside a V^T page row: [0-3,16-19 | 4-7,20-23 | 8-11,24-27 | 12-15,28-31]
 NTTS_HD int v_slot(int t) { return ((t & 15) >> 2) * 8 + (t >> 4) * 4 + (t & 3); }
 constexpr int kGroupMax = 8;     // query heads per kv head handled by one workgroup
-constexpr int kAttnMaxSlabs = 4;      // split-K factor of the QKV GEMM this kernel can reduce in its prologue
-constexpr int kAttnDepthDefault = 1;  // KV pages each wave keeps in flight (register ring)
 
 struct AttnDecodeArgs {
-    const bf16_t* qkv;     // kPre (tile path): [B][ld_qkv] q heads (rotated) | k heads (unused) | v heads, bf16, from qkv_rope.h
+    const bf16_t* qkv;     // [B][ld_qkv] q heads (rotated) | k heads (unused: already in their pages) | v heads, bf16, from qkv_rope.h
     long ld_qkv;
     bf16_t* out;           // [B][nh*64]
     long ld_out;
@@ -44,12 +43,7 @@ struct AttnDecodeArgs {
     const bf16_t* rope_cos;  // [max_ctx][32] bf16 (cos(emb) rounded to bf16 like HF's cos.to(dtype))
     const bf16_t* rope_sin;
     int nh, nkv;
-    // small-batch path (!kPre): the QKV GEMV's fp32 split-K slabs [nslab <= kAttnMaxSlabs][slab_rows][ld_qkv]; the kernel sums
-    // them in slab order, adds the bias and applies the nn.Linear output rounding (one RNE to bf16), RoPE and the KV append itself
-    const float* qkv_slabs;
-    int nslab;
-    long slab_rows;
-    const bf16_t* qkv_bias;
+    long slab_rows;        // context-split form: rows per chunk slab of the partial outputs (AttnSplitArgs::oslabs)
     unsigned long long* tl;   // diagnostics: [B][nkv][4 waves][8] phase timestamps (now_ticks), null in the product path
     int xcd_rows;             // xps = 8 / (batch / 64), 0 = off: workgroup x takes sequence xcd_row(x, xps) (norm.h) -- the rows of m-block p on XCD group p,
                               // where the QKV GEMM left their split-K slabs and the o_proj GEMM will read their outputs (gemm.h xcd_maffine); speed only
@@ -61,35 +55,27 @@ NTTS_D void rope_pair(float x1, float x2, float c, float s, float& o1, float& o2
     o2 = rbf(rbf(x2 * c) + rbf(x1 * s));
 }
 
-// kVar: 1 = the prologue's own operands (q/k/v row, RoPE row) are requested BEFORE the first K pages, 0 = after them.
-//   A wave's vector loads return in order, so whatever is requested first is what the RoPE prologue ends up waiting for;
-//   measured on MI355X at batch 256 (profiles/r01e_sweep_attn_variants.jsonl): 1 = -0.6 us per launch, -1.3 % per step.
-//   Also measured there and NOT kept: LDS-only barriers (s_waitcnt lgkmcnt(0) + s_barrier, leaving the K / V^T prefetch in
-//   flight) after the prologue (+3.5 us per launch) or at the softmax merge (+1.1 us), scheduling fences around the K
-//   requests (no effect), deeper register rings (kDepth 2 / 3: +0.2 / +1.2 us), the RoPE row served from a per-slot copy
-//   so that it does not hang off the load of the position (no effect).  Round 2: the wave's block-table entries held in
-//   registers (one coalesced load + lane broadcasts instead of a dependent global load per page): 20.5-21.1 vs 20.8-21.0 us,
-//   step 1.683 vs 1.685 ms (profiles/r02i_sweep_attn_bt_in_registers.log) -- the K and V^T passes are HBM-bound as they are
-//   (83 MB between 1 us and 14 us after entry = 6.4 TB/s), what is left is the launch gap, the first microsecond and the exit skew.
-//   8-wave workgroups at batch 256: 20.2-20.4 vs 20.6-20.9 us isolated, step 1.657-1.659 vs 1.660-1.661 ms (r02i_sweep_attn_8waves.log):
-//   inside the noise, not instantiated.
-// NW = waves per workgroup: 4.  16-wave workgroups (a whole 600-token context's pages requested at once by the one workgroup
-//   a (sequence, kv-head) gets at batch 1) were measured and are not instantiated: 13.1-13.7 vs 10.5-12.0 us per launch --
-//   the 12 extra waves' 192 KB of page requests queue on the CU's ~50 GB/s load path ahead of the prologue's RoPE row
-//   (prologue 1.9 -> 6.4 us); letting them request only after the prologue moves the wait into the softmax merge
-//   (14.8 us).  profiles/r02c_attn_timeline_b1.txt, r02f_sweep_b1_nw16_late_fw2.log.
+// No prologue: the rotated q heads are one bf16 row (qkv_rope.h), this step's K entry is already in its page, so the K pages are
+// the kernel's first large requests.  The v row arrives as bf16 and is placed into the transposed page here (64 two-byte stores
+// per workgroup, off the critical path; pass 2 takes it from LDS).  History of this kernel's prologue (sum the QKV GEMM's split-K
+// slabs + bias + rounding + RoPE + KV append, ~3 us during which no workgroup streamed): DESIGN.md section 4a, git history.
+// kVar & 4: the first V^T pages are requested right behind the first K pages instead of after the score pass (small batch: the
+//   kernel is one chain of dependent round trips, this removes one; at batch 256 it costs 0.7 us).  kVar & 2: non-temporal page loads
+//   (no gain).  Measured and not kept at batch 256: LDS-only barriers at the softmax merge (+1.1 us), deeper register rings for K
+//   and V^T or V^T alone (kDepth 2 / 3: +0.2 / +1.2 us; V^T 2 / 3: +0.0 / +0.6, profiles/r03b_sweep_slab_store_policy_attn_vdepth.log),
+//   block-table entries in registers (no effect), 8-wave workgroups (noise).  The K and V^T passes are HBM-bound as they are
+//   (83 MB between 1 us and 14 us after entry = 6.4 TB/s); what is left is the launch gap, the first round trip, the 1.4 us merge
+//   and ~2.5 us of exit skew between the 512 workgroups.
+// NW = waves per workgroup: 4 at large batch; 8 with one page per wave in flight at small batch, where ONE workgroup pulls a whole
+//   context through one CU's load path (batch 1, context 625: 4 waves x 2 pages 12.0 us, 8 x 2 11.1, 8 x 1 9.8, 16 x 2 12.5;
+//   profiles/r03c_sweep_b1_fused_qkv_attn_waves.log).
 // LMAX = longest context the instantiation can hold scores for: the score rows are most of the kernel's LDS (33 KB of 43 at 2048:
 //   three workgroups per CU).  Engines created with max_context <= 1024 take the 1024 instantiation (16.6 KB of 27: the register
 //   budget -- 102 -- then allows four), which matters where the grid is many rounds deep: batch 512 x 4 kv-heads = 2048 workgroups.
-// kPre: the q heads arrive rotated and this step's K entry is already in its page -- the fused QKV kernel of the tile path did both
-//   (qkv_rope.h): no prologue, the K pages are the kernel's first large requests.  The v row arrives as bf16 and is placed into the
-//   transposed page here (64 two-byte stores per workgroup, off the critical path; pass 2 takes it from LDS).
-template <int kDepth, bool kTimeline = false, int kVar = 1, int NW = 4, int LMAX = kAttnLMax, bool kPre = false>
+template <int kDepth, bool kTimeline = false, int kVar = 1, int NW = 4, int LMAX = kAttnLMax>
 NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
     constexpr int NT = NW * 64;
     NTTS_SHARED bf16_t sc[kGroupMax][LMAX + 16];        // rounded scores, 33 KB at 2048; +32 B/row de-aliases the LDS banks
-    NTTS_SHARED bf16_t qs[16][64];
-    NTTS_SHARED bf16_t knew[64];
     NTTS_SHARED bf16_t vnew[64];
     NTTS_SHARED float wred[NW][kGroupMax];
     NTTS_SHARED float wsum[NW][kGroupMax];
@@ -107,12 +93,9 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
         }
     };
     mark(0);
-    // ---- Order of the first requests.  A wave's vector loads return IN ORDER: whatever is requested before the prologue's
-    //      own operands sits on the prologue's critical path.  So (kVar & 1): (1) the block-table entries of the first K
-    //      pages and this token's q/k/v values (needing nothing but the slot index) go first; (2) once the position is known,
-    //      its RoPE row; (3) THEN the K pages, landing while the prologue computes.  Page indices past the context (or of a
-    //      slot that turns out not to run) address some valid page of the pool and are never used: every use below is
-    //      guarded by pg < npages.
+    // ---- Order of the first requests (a wave's vector loads return IN ORDER): the block-table entries of the first K pages, the
+    //      slot's state and position, the q row and the v row; then the K pages.  Page indices past the context (or of a slot that
+    //      turns out not to run) address some valid page of the pool and are never used: every use below is guarded by pg < npages.
     int bt0[kDepth];
 #pragma unroll
     for (int j = 0; j < kDepth; ++j) bt0[j] = bt[w + NW * j < p.max_pages ? w + NW * j : 0];
@@ -137,19 +120,14 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
     };
     auto load_k = [&](int pg, bf16x8 (&k)[2][2]) { load_k_at(bt[pg], k); };
     auto load_v = [&](int pg, bf16x8 (&v)[4]) { load_v_at(bt[pg], v); };
-    // K pages do not depend on this step's q/k/v: they stream under the RoPE prologue (the slot of the token appended
-    // below is overridden from LDS, whatever the page held).  Register ring of kDepth pages per wave.
-    bf16x8 kq[kDepth][2][2];
+    bf16x8 kq[kDepth][2][2];   // register rings of kDepth pages per wave
     bf16x8 vq[kDepth][4];
     bf16x8 qB[2];
-    bf16_t vrow_new = 0;       // kPre: element tid of this step's v row / the page of position P (threads 0..63)
+    bf16_t vrow_new = 0;       // element tid of this step's v row / the page of position P (threads 0..63)
     long vpage_new = 0;
     const int L = P + 1;
     const int npages = (L + kPage - 1) / kPage;
     const int last_page = npages - 1;
-  if constexpr (kPre) {
-    // ---- no prologue: the rotated q heads are one bf16 row (requested while the block-table entries are on their way), the
-    //      K pages follow as soon as those entries are known
     {
         const bf16_t* qrow = p.qkv + (long)b * p.ld_qkv + (long)(kvh * group + (l15 < group ? l15 : 0)) * 64 + g * 16;
         qB[0] = ld16<bf16x8>(qrow);
@@ -173,109 +151,6 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
         for (int e = 0; e < 8; ++e) { qB[0][e] = 0; qB[1][e] = 0; }
     }
     mark(2);
-  } else {
-    if constexpr (!(kVar & 1)) {
-#pragma unroll
-        for (int j = 0; j < kDepth; ++j) load_k_at(bt0[j], kq[j]);
-    }
-    // prologue work items: t = head * 32 + pair index; heads 0 .. group-1 are the q heads, item head == group is k (+ v)
-    const int nitems = (group + 1) * 32;
-    // element `col` of this sequence's q|k|v row as the bf16 nn.Linear output, rebuilt from the QKV GEMV's split-K slabs (all
-    // loads independent; the additions follow the slab order, then + bias, then ONE rounding)
-    // Branch-free on purpose: with a data-dependent slab count in the control flow the compiler waits for each element's
-    // loads before it requests the next element's (a chain of round trips); here every request of the prologue is in
-    // flight at once.  Absent slabs re-read the last present one and are dropped by a select.
-    const float* sbase[kAttnMaxSlabs];
-#pragma unroll
-    for (int sl = 0; sl < kAttnMaxSlabs; ++sl) {
-        const int su = sl < p.nslab ? sl : (p.nslab > 0 ? p.nslab - 1 : 0);
-        sbase[sl] = p.qkv_slabs + ((long)su * p.slab_rows + b) * p.ld_qkv;
-    }
-    struct QkvReq { float part[kAttnMaxSlabs]; bf16_t bias; };
-    auto qkv_request = [&](int col, QkvReq& q) {
-#pragma unroll
-        for (int sl = 0; sl < kAttnMaxSlabs; ++sl) q.part[sl] = sbase[sl][col];
-        q.bias = p.qkv_bias[col];
-    };
-    auto qkv_value = [&](const QkvReq& q) -> bf16_t {
-        float a = q.part[0];
-#pragma unroll
-        for (int sl = 1; sl < kAttnMaxSlabs; ++sl) a += sl < p.nslab ? q.part[sl] : 0.f;   // + 0.f: exact
-        return f2bf(a + bf2f(q.bias));
-    };
-    constexpr int ITS = ((kGroupMax + 1) * 32 + NT - 1) / NT;   // prologue items per thread
-    QkvReq qx1[ITS], qx2[ITS], qv1[ITS], qv2[ITS];
-#pragma unroll
-    for (int it = 0; it < ITS; ++it) {
-        const int t = tid + it * NT;
-        if (t < nitems) {
-            const int hh = t >> 5, i = t & 31;
-            const int c0 = hh < group ? (kvh * group + hh) * 64 : (p.nh + kvh) * 64;
-            qkv_request(c0 + i, qx1[it]);
-            qkv_request(c0 + i + 32, qx2[it]);
-            if (hh == group) {
-                const int v0 = (p.nh + p.nkv + kvh) * 64;
-                qkv_request(v0 + i, qv1[it]);
-                qkv_request(v0 + i + 32, qv2[it]);
-            }
-        }
-    }
-    if (st != 1) return;  // block-uniform
-    mark(1);
-    long new_page = 0;
-    bf16_t rc[ITS], rs[ITS];
-#pragma unroll
-    for (int it = 0; it < ITS; ++it) {
-        const int t = tid + it * NT;
-        rc[it] = rs[it] = 0;
-        if (t < nitems) {
-            rc[it] = p.rope_cos[(long)P * 32 + (t & 31)];
-            rs[it] = p.rope_sin[(long)P * 32 + (t & 31)];
-            if ((t >> 5) == group) new_page = bt[P / kPage];
-        }
-    }
-    if constexpr (kVar & 1) {
-#pragma unroll
-        for (int j = 0; j < kDepth; ++j) load_k_at(bt0[j], kq[j]);
-    }
-    // kVar & 4: the first V^T pages are requested right behind the first K pages instead of after the score pass -- at small
-    // batch the kernel is one chain of dependent round trips (block table -> K -> scores -> V -> PV) and this removes one
-    if constexpr (kVar & 4) {
-#pragma unroll
-        for (int j = 0; j < kDepth; ++j) load_v_at(bt0[j], vq[j]);   // (a page index past the context addresses a valid page; unused)
-    }
-
-    // ---- prologue: RoPE(q), RoPE(k) + append k, v to the cache (and keep them in LDS for this step)
-#pragma unroll
-    for (int it = 0; it < ITS; ++it) {
-        const int t = tid + it * NT;
-        if (t < nitems) {
-            const int hh = t >> 5, i = t & 31;
-            float o1, o2;
-            rope_pair(bf2f(qkv_value(qx1[it])), bf2f(qkv_value(qx2[it])), bf2f(rc[it]), bf2f(rs[it]), o1, o2);
-            if (hh < group) {
-                qs[hh][i] = f2bf(o1);
-                qs[hh][i + 32] = f2bf(o2);
-            } else {
-                const bf16_t k1 = f2bf(o1), k2 = f2bf(o2), v1 = qkv_value(qv1[it]), v2 = qkv_value(qv2[it]);
-                knew[i] = k1; knew[i + 32] = k2; vnew[i] = v1; vnew[i + 32] = v2;
-                const int slot = P % kPage;
-                bf16_t* kd = p.kpool + ((new_page * p.nkv + kvh) * kPage + slot) * 64;
-                kd[i] = k1; kd[i + 32] = k2;
-                bf16_t* vd = p.vpool + (new_page * p.nkv + kvh) * 64 * kPage + v_slot(slot);
-                vd[(long)i * kPage] = v1; vd[(long)(i + 32) * kPage] = v2;
-            }
-        }
-    }
-    for (int t = tid; t < (16 - group) * 64; t += NT) qs[group + t / 64][t % 64] = 0;
-    sync();
-    mark(2);
-
-    qB[0] = ld16<bf16x8>(&qs[l15][g * 16]);
-    qB[1] = ld16<bf16x8>(&qs[l15][g * 16 + 8]);
-
-  }
-
     // ---- pass 1: S^T = K Q^T per 16-key sub-tile, bf16-rounded scores -> LDS, with the softmax statistics carried
     //      online per lane (running max and sum of exp in fp32), so that one merge after the pass yields the row max
     //      and denominator: no separate pass over the stored scores.  Masked keys use a large finite score.
@@ -290,16 +165,6 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) { kc[u][0] = kq[j][u][0]; kc[u][1] = kq[j][u][1]; }
                 if (pg + NW * kDepth < npages) load_k(pg + NW * kDepth, kq[j]);
-                if constexpr (!kPre) {
-                    if (pg == last_page) {  // the token appended this step comes from LDS, not from HBM
-#pragma unroll
-                        for (int u = 0; u < 2; ++u)
-                            if (pg * kPage + u * 16 + l15 == P) {
-                                kc[u][0] = ld16<bf16x8>(&knew[g * 16]);
-                                kc[u][1] = ld16<bf16x8>(&knew[g * 16 + 8]);
-                            }
-                    }
-                }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     f32x4 a = {0.f, 0.f, 0.f, 0.f};
@@ -326,11 +191,9 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
         }
     }
     mark(4);
-    if constexpr (kPre) {
-        if (tid < 64) {   // v row -> its slot of the transposed page, and LDS (pass 2 reads it there, behind the merge barrier)
-            vnew[tid] = vrow_new;
-            p.vpool[(vpage_new * p.nkv + kvh) * 64 * kPage + (long)tid * kPage + v_slot(P % kPage)] = vrow_new;
-        }
+    if (tid < 64) {   // v row -> its slot of the transposed page, and LDS (pass 2 reads it there, behind the merge barrier)
+        vnew[tid] = vrow_new;
+        p.vpool[(vpage_new * p.nkv + kvh) * 64 * kPage + (long)tid * kPage + v_slot(P % kPage)] = vrow_new;
     }
     // ---- V^T pages are independent of the scores: (kVar & 4: already requested next to the K pages) else get the first
     //      ones in flight under the softmax reductions
@@ -445,12 +308,9 @@ struct AttnSplitArgs {
     int nsplit;
 };
 
-template <bool kPre>
 NTTS_KERNEL(256) void attn_split_scores_kernel(AttnSplitArgs q) {
-    constexpr int NW = 4, NT = 256;
+    constexpr int NW = 4;
     const AttnDecodeArgs& p = q.a;
-    NTTS_SHARED bf16_t qs[16][64];
-    NTTS_SHARED bf16_t knew[64];
     NTTS_SHARED float wred[NW][kGroupMax];
     NTTS_SHARED float wsum[NW][kGroupMax];
     const int b = blockIdx.x, kvh = blockIdx.y, ch = blockIdx.z;
@@ -462,11 +322,10 @@ NTTS_KERNEL(256) void attn_split_scores_kernel(AttnSplitArgs q) {
     const int P = p.pos[b];
     const int L = P + 1;
     const int npages = (L + kPage - 1) / kPage;
-    const int last_page = npages - 1;
     const int ppc = (npages + q.nsplit - 1) / q.nsplit;          // pages per chunk
     const int pg_lo = ch * ppc, pg_hi = (pg_lo + ppc < npages) ? pg_lo + ppc : npages;
+    // rotated q rows + an appended K entry from the fused QKV kernel (qkv_rope.h)
     bf16x8 qB[2];
-  if constexpr (kPre) {   // rotated q rows + an appended K / V^T entry from the fused QKV kernel (qkv_rope.h)
     const bf16_t* qrow = p.qkv + (long)b * p.ld_qkv + (long)(kvh * group + (l15 < group ? l15 : 0)) * 64 + g * 16;
     qB[0] = ld16<bf16x8>(qrow);
     qB[1] = ld16<bf16x8>(qrow + 8);
@@ -480,73 +339,6 @@ NTTS_KERNEL(256) void attn_split_scores_kernel(AttnSplitArgs q) {
         const long new_page = bt[P / kPage];
         p.vpool[(new_page * p.nkv + kvh) * 64 * kPage + (long)tid * kPage + v_slot(P % kPage)] = v;
     }
-  } else {
-    // ---- prologue operands (every chunk rebuilds q; all of them need the new k for the page that holds position P)
-    const int nitems = (group + 1) * 32;
-    const float* sbase[kAttnMaxSlabs];
-#pragma unroll
-    for (int sl = 0; sl < kAttnMaxSlabs; ++sl) {
-        const int su = sl < p.nslab ? sl : (p.nslab > 0 ? p.nslab - 1 : 0);
-        sbase[sl] = p.qkv_slabs + ((long)su * p.slab_rows + b) * p.ld_qkv;
-    }
-    auto qkv_value = [&](int col) -> bf16_t {
-        float part[kAttnMaxSlabs];
-#pragma unroll
-        for (int sl = 0; sl < kAttnMaxSlabs; ++sl) part[sl] = sbase[sl][col];
-        float a = part[0];
-#pragma unroll
-        for (int sl = 1; sl < kAttnMaxSlabs; ++sl) a += sl < p.nslab ? part[sl] : 0.f;
-        return f2bf(a + bf2f(p.qkv_bias[col]));
-    };
-    constexpr int ITS = ((kGroupMax + 1) * 32 + NT - 1) / NT;
-    bf16_t x1[ITS], x2[ITS], v1[ITS], v2[ITS];
-#pragma unroll
-    for (int it = 0; it < ITS; ++it) {
-        const int t = tid + it * NT;
-        x1[it] = x2[it] = v1[it] = v2[it] = 0;
-        if (t < nitems) {
-            const int hh = t >> 5, i = t & 31;
-            const int c0 = hh < group ? (kvh * group + hh) * 64 : (p.nh + kvh) * 64;
-            x1[it] = qkv_value(c0 + i);
-            x2[it] = qkv_value(c0 + i + 32);
-            if (hh == group && ch == 0) {
-                const int v0 = (p.nh + p.nkv + kvh) * 64;
-                v1[it] = qkv_value(v0 + i);
-                v2[it] = qkv_value(v0 + i + 32);
-            }
-        }
-    }
-    if (st != 1) return;  // block-uniform
-#pragma unroll
-    for (int it = 0; it < ITS; ++it) {
-        const int t = tid + it * NT;
-        if (t < nitems) {
-            const int hh = t >> 5, i = t & 31;
-            const float c = bf2f(p.rope_cos[(long)P * 32 + i]), sn = bf2f(p.rope_sin[(long)P * 32 + i]);
-            float o1, o2;
-            rope_pair(bf2f(x1[it]), bf2f(x2[it]), c, sn, o1, o2);
-            if (hh < group) {
-                qs[hh][i] = f2bf(o1);
-                qs[hh][i + 32] = f2bf(o2);
-            } else {
-                const bf16_t k1 = f2bf(o1), k2 = f2bf(o2);
-                knew[i] = k1; knew[i + 32] = k2;
-                if (ch == 0) {                                     // chunk 0 appends the token to the cache
-                    const long new_page = bt[P / kPage];
-                    const int slot = P % kPage;
-                    bf16_t* kd = p.kpool + ((new_page * p.nkv + kvh) * kPage + slot) * 64;
-                    kd[i] = k1; kd[i + 32] = k2;
-                    bf16_t* vd = p.vpool + (new_page * p.nkv + kvh) * 64 * kPage + v_slot(slot);
-                    vd[(long)i * kPage] = v1[it]; vd[(long)(i + 32) * kPage] = v2[it];
-                }
-            }
-        }
-    }
-    for (int t = tid; t < (16 - group) * 64; t += NT) qs[group + t / 64][t % 64] = 0;
-    sync();
-    qB[0] = ld16<bf16x8>(&qs[l15][g * 16]);
-    qB[1] = ld16<bf16x8>(&qs[l15][g * 16 + 8]);
-  }
     constexpr float kMasked = -1.0e30f;
     float lmax = kMasked, lsum = 0.f;
     bf16_t* srow = q.scores + ((long)(b * p.nkv + kvh) * kGroupMax + (l15 < kGroupMax ? l15 : 0)) * q.ld_scores;
@@ -558,16 +350,6 @@ NTTS_KERNEL(256) void attn_split_scores_kernel(AttnSplitArgs q) {
             const bf16_t* kr = kp + (u * 16 + l15) * 64 + g * 16;
             kc[u][0] = ld16<bf16x8>(kr);
             kc[u][1] = ld16<bf16x8>(kr + 8);
-        }
-        if constexpr (!kPre) {
-            if (pg == last_page) {  // the token appended this step comes from LDS (chunk 0's store may not have landed)
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    if (pg * kPage + u * 16 + l15 == P) {
-                        kc[u][0] = ld16<bf16x8>(&knew[g * 16]);
-                        kc[u][1] = ld16<bf16x8>(&knew[g * 16 + 8]);
-                    }
-            }
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -710,29 +492,27 @@ NTTS_KERNEL(256) void attn_split_combine_kernel(AttnSplitArgs q) {
     }
 }
 
-inline void attn_split_launch(const AttnSplitArgs& q, int batch, hipStream_t s, bool combine = false, bool pre = false) {
+inline void attn_split_launch(const AttnSplitArgs& q, int batch, hipStream_t s, bool combine = false) {
     const dim3 grid(batch, q.a.nkv, q.nsplit), block(256);
-    if (pre) NTTS_LAUNCH((attn_split_scores_kernel<true>), grid, block, s, q);
-    else NTTS_LAUNCH((attn_split_scores_kernel<false>), grid, block, s, q);
+    NTTS_LAUNCH((attn_split_scores_kernel), grid, block, s, q);
     NTTS_LAUNCH((attn_split_pv_kernel), grid, block, s, q);
     if (combine) NTTS_LAUNCH((attn_split_combine_kernel), dim3(batch), block, s, q);
 }
 
-// tile path, behind the fused QKV kernel (qkv_rope.h): q rows rotated, the new K entry already in its page.  One KV page per wave
-// in flight (deeper register rings: +0.2 / +1.2 us, r01d), V^T pages requested after the score pass (next to the K pages: 19.3 ->
-// 20.0 us, profiles/r03a_sweep_qkv_fused.log); engines with max_context <= 1024 take the instantiation with half the score rows.
-inline void attn_decode_launch_pre(const AttnDecodeArgs& p, int batch, hipStream_t s, int max_ctx) {
+// large batch (tile path): one KV page per wave in flight, V^T pages requested after the score pass; engines with
+// max_context <= 1024 take the instantiation with half the score rows
+inline void attn_decode_launch(const AttnDecodeArgs& p, int batch, hipStream_t s, int max_ctx) {
     const dim3 grid(batch, p.nkv), block(256);
-    if (p.tl) NTTS_LAUNCH((attn_decode_kernel<1, true, 1, 4, kAttnLMax, true>), grid, block, s, p);   // diagnostics: phase timestamps
-    else if (max_ctx <= 1024) NTTS_LAUNCH((attn_decode_kernel<1, false, 1, 4, 1024, true>), grid, block, s, p);
-    else NTTS_LAUNCH((attn_decode_kernel<1, false, 1, 4, kAttnLMax, true>), grid, block, s, p);
+    if (p.tl) NTTS_LAUNCH((attn_decode_kernel<1, true, 1, 4, kAttnLMax>), grid, block, s, p);   // diagnostics: phase timestamps
+    else if (max_ctx <= 1024) NTTS_LAUNCH((attn_decode_kernel<1, false, 1, 4, 1024>), grid, block, s, p);
+    else NTTS_LAUNCH((attn_decode_kernel<1, false, 1, 4, kAttnLMax>), grid, block, s, p);
 }
-// small-batch path (gemv.h): the QKV GEMV's fp32 split-K slabs are reduced, rotated and appended in this kernel's prologue; two pages
-// per wave in flight, V^T requested next to K (kVar 7): at batch 1 the kernel is one chain of dependent round trips
+// small batch (gemv.h path): 8 waves, one page each in flight, V^T requested next to K (kVar 5): at batch 1 the kernel is one
+// chain of dependent round trips through ONE CU's load path
 inline void attn_decode_launch_small(const AttnDecodeArgs& p, int batch, hipStream_t s) {
     const dim3 grid(batch, p.nkv);
-    if (p.tl) NTTS_LAUNCH((attn_decode_kernel<2, true, 7, 4>), grid, dim3(256), s, p);   // diagnostics: phase timestamps
-    else NTTS_LAUNCH((attn_decode_kernel<2, false, 7, 4>), grid, dim3(256), s, p);
+    if (p.tl) NTTS_LAUNCH((attn_decode_kernel<1, true, 5, 8>), grid, dim3(512), s, p);   // diagnostics: phase timestamps (waves 0..3)
+    else NTTS_LAUNCH((attn_decode_kernel<1, false, 5, 8>), grid, dim3(512), s, p);
 }
 
 }  // namespace ntts

@@ -18,7 +18,7 @@
 //     computed: sum the producer's split-K slabs in order, round (the Linear output), add the residual, round, RMSNorm,
 //     times the norm weight; block 0 also writes the new residual stream.  Every workgroup redoes that little piece of
 //     work (at M <= 8 a few KB out of L2), which removes two of a layer's seven launches and the embedding gather of
-//     layer 0.  The arithmetic and its ORDER are add_rmsnorm_kernel<2>'s (norm.h rmsnorm_row_wave).  Because the helpers
+//     layer 0 (the QKV projection's own kernel, qkv_rope.h gemv_qkv_rope_kernel, shares this prologue).  The arithmetic and its ORDER are add_rmsnorm_kernel<2>'s (norm.h rmsnorm_row_wave).  Because the helpers
 //     are separate waves, their (L2) loads do not queue behind the feature waves' HBM weight stream (a wave's loads
 //     return in order) and their registers cost the feature waves nothing.
 //   * the matrix core is used as a 16 x 16 x 32 dot-product engine: A = W fragment (16 features x 32 k), B = X fragment

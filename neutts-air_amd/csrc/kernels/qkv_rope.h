@@ -15,6 +15,7 @@
 #pragma once
 #include <ntts/dev.h>
 #include "attn_decode.h"
+#include "gemv.h"
 
 namespace ntts {
 
@@ -270,6 +271,124 @@ inline void qkv_rope_launch(QkvRopeArgs p, bool xcd_place, hipStream_t s) {
         grid = 8 * p.xcd_mpx * nblocks;
     }
     NTTS_LAUNCH((qkv_rope_kernel<NS, F8, KS>), dim3(grid), dim3(KS * 128), s, p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same fusion for the SMALL-batch step (M <= 16 rows; gemv.h's regime): nothing is tiled, the point is that as many CUs as
+// possible each stream a short, private piece of W once.  A workgroup owns 16 output features -- 8 RoPE pairs of one head,
+// features {8q .. 8q+7} and {32+8q .. 32+8q+7} -- over the WHOLE K: its 4 feature waves each take a K slice (their weight
+// fragments go HBM -> VGPR, all requested at entry, as in gemv.h), the 4 helper waves build the normalised X panel in LDS
+// meanwhile (gemv.h's fused prologue: sum the previous down_proj's split-K slabs + residual + RMSNorm), the four partial sums
+// meet in LDS in slice order (the order the attention prologue used to add the four slabs in: same bits), and wave 0 finishes:
+// bias, ONE rounding, RoPE against the partner rows (lane ^ 32), q / v columns to the bf16 row, the k pair into its page.
+// 72 workgroups at N = 1152 -- as many as the split-K GEMV it replaces had -- and no fp32 slabs for the attention kernel to reduce.
+struct GemvQkvArgs {
+    NormArgs pro;            // the fused prologue's operands (gemv.h PRO)
+    const bf16_t* W;         // [N][K] tile-major
+    const bf16_t* bias;      // [N]
+    int M, N, K;
+    int kps;                 // k-tiles per K slice (launcher)
+    const int* meta;         // [M][4] step_meta_kernel
+    const bf16_t* rope_rows; // [M][64]
+    bf16_t* q_out;           // [M][ld_q] q|k|v row (q rotated, k columns unwritten, v as is)
+    long ld_q;
+    bf16_t* kpool;
+    int nh, nkv;
+};
+
+template <int KT>
+NTTS_KERNEL(512) void gemv_qkv_rope_kernel(GemvQkvArgs p) {
+    NTTS_SHARED bf16_t xs[kGemvRows * kGemvXld];
+    NTTS_SHARED f32x4 red[4][64];
+    const int lane = lane_id(), w = wave_id();
+    const int g = lane >> 4, l15 = lane & 15;
+    if (w >= 4) {            // helper waves: the normalised X panel (block 0 also writes the new residual stream)
+        for (int m = w - 4; m < p.M; m += 4) rmsnorm_row_wave<2, 16>(p.pro, m, true, blockIdx.x == 0, xs + m * kGemvXld);
+        sync();
+        sync();
+        return;
+    }
+    const int hd = blockIdx.x >> 2, q = blockIdx.x & 3;
+    const int m = l15, mc = m < p.M ? m : p.M - 1;
+    // wave 0's epilogue operands first (tiny; a wave's loads return in order)
+    const int i0 = q * 8 + (g & 1) * 4;                            // RoPE index of this lane's 4 features
+    const int n0 = hd * 64 + (g >= 2 ? 32 : 0) + i0;               // their columns
+    u32x4 meta = {0, 0, 0, 0};
+    bf16x4 cs = {0, 0, 0, 0}, sn = {0, 0, 0, 0}, bs = {0, 0, 0, 0};
+    if (w == 0) {
+        meta = ld16<u32x4>(p.meta + (long)mc * 4);
+        cs = *(const bf16x4*)(p.rope_rows + (long)mc * 64 + i0);
+        sn = *(const bf16x4*)(p.rope_rows + (long)mc * 64 + 32 + i0);
+        bs = *(const bf16x4*)(p.bias + n0);
+    }
+    // this wave's K slice of the workgroup's 16 weight rows: MFMA row l15 <-> feature 8q + l15 (l15 < 8) / 32 + 8q + l15 - 8
+    const int ktiles = p.K >> 6;
+    const int kt0 = w * p.kps;
+    int nk = ktiles - kt0;
+    if (nk > p.kps) nk = p.kps;
+    if (nk < 0) nk = 0;
+    const int frow = l15 < 8 ? q * 8 + l15 : 32 + q * 8 + (l15 - 8);
+    const bf16_t* wbase = p.W + (long)hd * 64 * p.K + frow * 64 + g * 16;
+    bf16x8 wa[KT][2];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        const int jj = j < nk ? j : (nk > 0 ? nk - 1 : 0);
+        const int kt = kt0 + jj < ktiles ? kt0 + jj : ktiles - 1;
+        const bf16_t* src = wbase + (long)kt * 4096;
+        wa[j][0] = ld16<bf16x8>(src);
+        wa[j][1] = ld16<bf16x8>(src + 8);
+    }
+    sync();                                                       // the panel is complete
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const bf16_t* xrow = xs + l15 * kGemvXld + g * 16;
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        const short keep = j < nk ? (short)-1 : (short)0;         // surplus tiles contribute 0 * x
+        const int jj = j < nk ? j : (nk > 0 ? nk - 1 : 0);
+        const int kt = kt0 + jj < ktiles ? kt0 + jj : ktiles - 1;
+        const bf16_t* xp = xrow + kt * 64;
+        acc = mfma16(wa[j][0] & keep, ld16<bf16x8>(xp), acc);
+        acc = mfma16(wa[j][1] & keep, ld16<bf16x8>(xp + 8), acc);
+    }
+    red[w][lane] = acc;
+    sync();
+    if (w != 0) return;
+    // lane (g, m): rows g*4 + r of the 16 = features n0 + r of token m; slices added in order
+    f32x4 sum = red[0][lane];
+#pragma unroll
+    for (int sl = 1; sl < 4; ++sl) {
+        const f32x4 o = red[sl][lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum[r] += o[r];
+    }
+    alignas(8) bf16_t val[4], out[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) val[r] = f2bf(sum[r] + bf2f((bf16_t)bs[r]));      // the nn.Linear output: one rounding
+    const bool rot = hd < p.nh + p.nkv;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+        const int own = (int)val[2 * k2] | ((int)val[2 * k2 + 1] << 16);
+        const int par = shfl_xor(own, 32);                         // lanes g < 2 hold x[i], lanes g >= 2 hold x[i + 32]
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int r = 2 * k2 + h;
+            const float xo = bf2f((bf16_t)((own >> (16 * h)) & 0xffff)), xp = bf2f((bf16_t)((par >> (16 * h)) & 0xffff));
+            const float c = bf2f((bf16_t)cs[r]), sv = bf2f((bf16_t)sn[r]);
+            out[r] = rot ? f2bf(rbf(xo * c) + (g < 2 ? rbf(-xp * sv) : rbf(xp * sv))) : val[r];
+        }
+    }
+    const int st = (int)meta[0], page = (int)meta[2], slot = (int)meta[3];
+    const bool mok = m < p.M;
+    bf16_t* dst = nullptr;
+    if (hd < p.nh || hd >= p.nh + p.nkv) { if (mok) dst = p.q_out + (long)m * p.ld_q + n0; }
+    else if (mok && st == 1) dst = p.kpool + (((long)page * p.nkv + (hd - p.nh)) * kPage + slot) * 64 + (n0 & 63);
+    if (dst) *(u32x2*)dst = *(u32x2*)&out[0];
+}
+
+inline void gemv_qkv_rope_launch(GemvQkvArgs p, hipStream_t s) {
+    const int ktiles = p.K / 64;
+    p.kps = (ktiles + 3) / 4;                                     // <= 4 for K <= 1024
+    NTTS_LAUNCH((gemv_qkv_rope_kernel<4>), dim3(p.N / 16), dim3(512), s, p);
 }
 
 }  // namespace ntts

@@ -50,6 +50,27 @@ def test_small_gqa2_page_crossing_peaked_exact(emu_lib, knobs, monkeypatch):
     assert fin and ids == z["bf16_ids_0"][:N].tolist()
 
 
+@pytest.mark.parametrize("small_batch", ["8", "0"])
+def test_short_sequence_beside_a_long_one_across_the_split_switch(emu_lib, monkeypatch, small_batch):
+    """ADVICE r2 (see the GPU twin in tests/test_gpu_backbone.py): the split switch follows the longest context of the batch; a
+    one-page sequence beside a long one runs the split kernels with empty chunks -- each row must still match the oracle's solo run."""
+    for k, v in {"NTTS_SMALL_BATCH": small_batch, "NTTS_ATTN_SPLIT": "3", "NTTS_ATTN_SPLIT_CTX": "40"}.items():
+        monkeypatch.setenv(k, v)
+    z, cfg, w = load_fixture("backbone_small_peaked")
+    wd = br.cast_weights(w, torch.bfloat16)
+    N, eos = 8, int(z["eos"])
+    prompts = [br.synthetic_prompt(cfg, 3, 6), br.synthetic_prompt(cfg, 0, 70)]
+    want = [br.generate(cfg, wd, p, len(p) + N, eos_id=eos, min_new_tokens=N, keep_logits=True) for p in prompts]
+    eng = make_engine(cfg, w, emu_lib, max_batch=2)
+    samp = [_hip.Sampling(max_length=len(p) + N, min_new_tokens=N, eos_token_id=eos, do_sample=False) for p in prompts]
+    eng.prefill(prompts, [0, 1], samp)
+    eng.decode(N - 1)
+    for s in (0, 1):
+        ids, fin = eng.read(s)
+        assert fin and len(ids) == N
+        assert_free_run_matches(ids, want[s])
+
+
 def test_xcd_row_block_placement(emu_lib, monkeypatch):
     """NTTS_XCD_AFFINE=7 (the default above batch 128): split-K GEMMs, the norms behind them and decode attention place the rows of a
     64-row m-block on one group of XCDs (gemm.h xcd_maffine, norm.h xcd_row).  A pure permutation of which workgroup does what:

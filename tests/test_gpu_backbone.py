@@ -139,6 +139,30 @@ def test_long_context_switches_to_split_attention(lib, monkeypatch, max_batch):
     assert got["8"] == got["0"], (got["8"], got["0"])
 
 
+@pytest.mark.parametrize("max_batch", [2, 16])
+def test_short_sequence_beside_a_long_one_across_the_split_switch(lib, max_batch):
+    """the choice between the single-workgroup attention and the context-split one follows the LONGEST running context
+    of the batch, so a short sequence (one page: fewer pages than chunks, most of its chunks empty) runs the split kernels
+    whenever a long one shares its batch.  The two forms add the softmax denominator and P V in different fp32 orders, i.e. a
+    sequence's ids may depend on its batch mates within the summation-order freedom the parity bars allow -- what must hold is
+    that EACH row still matches the oracle's run of that sequence alone (identical, or up to a tie of the oracle's own top-2)."""
+    cfg = br.BackboneConfig(vocab_size=3000, hidden_size=896, intermediate_size=1216, num_layers=3)
+    w = br.make_weights(cfg, 33, peak_sigma=0.5)
+    wd = br.cast_weights(w, torch.bfloat16)
+    N, eos = 24, cfg.vocab_size - 1
+    prompts = [br.synthetic_prompt(cfg, 6, 10), br.synthetic_prompt(cfg, 5, 900)]       # contexts 10.. and 900.. (switch at 896)
+    want = [br.generate(cfg, wd, p, len(p) + N, eos_id=eos, min_new_tokens=N, keep_logits=True) for p in prompts]
+    eng = make_engine(cfg, w, lib, max_batch=max_batch, max_context=1024, max_prefill_tokens=1024, bf16_upload=True)
+    samp = [_hip.Sampling(max_length=len(p) + N, min_new_tokens=N, eos_token_id=eos, do_sample=False) for p in prompts]
+    eng.prefill(prompts, [0, 1], samp)
+    eng.decode(N - 1)
+    for s in (0, 1):
+        ids, fin = eng.read(s)
+        assert fin and len(ids) == N
+        assert_free_run_matches(ids, want[s])
+    eng.close()
+
+
 def test_continuous_batching_ragged_vs_oracle(lib):
     cfg = br.BackboneConfig(vocab_size=3000, hidden_size=896, intermediate_size=1216, num_layers=3)
     w = br.make_weights(cfg, 21, peak_sigma=0.5)

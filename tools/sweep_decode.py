@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--vocab", type=int, default=217488)
     ap.add_argument("--knobs", type=str, default="", help="JSON list of [name, [values...]] overriding the default plan")
+    ap.add_argument("--base", type=str, default="{}", help="JSON dict of settings every measurement starts from")
     a = ap.parse_args()
     cfg = br.BackboneConfig.neutts_air(a.vocab)
     t0 = time.time()
@@ -77,7 +78,7 @@ def main():
 
     # the engine keeps few environment knobs; an experiment adds its own temporary one and names it here
     plan = json.loads(a.knobs) if a.knobs else [["NTTS_HEAD_TILE", [2, 4]], ["NTTS_XCD_AFFINE", [0, 7]]]
-    cur = {}
+    cur = json.loads(a.base)
     base = measure(cur)
     for name, values in plan:
         best_v, best_t = None, base
