@@ -146,7 +146,7 @@ def rocprof_symbols(path, live):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", choices=["air-bf16", "nano-fp8", "nano-bf16"], default="air-bf16",
                     help="air-bf16: NeuTTS-Air bf16 (BASELINE.json configs[1..3], the headline metric); nano-fp8: the assumed NeuTTS-Nano "
@@ -167,6 +167,9 @@ def main():
                     help="the reference's own sampling call (ref:neutts/neutts.py:338-347: do_sample=True, top_k=50, temperature=1.0; seeded) "
                          "instead of greedy: radix select + Philox multinomial on the bf16 logits rows")
     ap.add_argument("--requests", type=int, default=None, help="continuous mode: requests per step (default 4 x batch)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="static mode: ONE backbone engine, batches strictly one after the other (round-2 shape).  Default: two engines, "
+                         "batch k + 1's prompt pass enqueued before batch k's decode graphs, so the GPU runs them side by side")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-codec", action="store_true", help="backbone only (profiling aid; not the headline metric)")
@@ -312,7 +315,17 @@ def main():
         stage("weights received (one arena broadcast + one packed codec buffer)")
     elif codec is not None:
         codec.load_state_dict({k: v.numpy() for k, v in cw.items()})
+    # static mode: a TWIN engine (same configuration, its own KV pool and slot state, the arena copied device to device) so that
+    # consecutive batches can overlap on the GPU: while engine A replays batch k's decode graphs, engine B runs batch k + 1's prompt pass
+    pipe = (not cont) and (not strm) and (not a.no_pipeline) and B > 1
+    engs = [eng]
+    if pipe:
+        eng2 = eng.twin()
+        engs.append(eng2)
+        stage("twin engine ready (arena copied on the device)")
     if os.environ.get("NTTS_BENCH_PRIME", "1") != "0" and not cont:
+        for e2 in engs[1:]:
+            e2.warm_up(int(os.environ.get("NTTS_BENCH_PRIME_STEPS", str(max(2, N - 1)))))
         eng.warm_up(int(os.environ.get("NTTS_BENCH_PRIME_STEPS", str(max(2, N - 1)))))   # start-up: graph capture + runtime pools (sized by one decode call of real length), before any request
     stage(f"warm-up done (weights ready in {time.time() - t0:.1f}s)")
 
@@ -324,13 +337,18 @@ def main():
     prompts = [syn.synthetic_prompt(cfg, lo + i, S) for i in range(B)]   # seed 1234 + utterance index
 
     # device buffers of the id -> code hand-off (torch = tensor container only; the emulator's "device" is host memory)
-    if emu_lib:
-        codes_buf, lens_buf = np.zeros((B, N), dtype=np.int32), np.zeros(B, dtype=np.int32)
-        codes_ptr, lens_ptr = codes_buf.ctypes.data, lens_buf.ctypes.data
-    else:
-        codes_buf = torch.zeros((B, N), dtype=torch.int32, device=f"cuda:{dev}")
-        lens_buf = torch.zeros(B, dtype=torch.int32, device=f"cuda:{dev}")
-        codes_ptr, lens_ptr = codes_buf.data_ptr(), lens_buf.data_ptr()
+    # (one pair per engine: batch k's codec pass reads its pair while batch k + 1's export fills the other)
+    codes_bufs, lens_bufs, codes_ptrs, lens_ptrs = [], [], [], []
+    for _ in engs:
+        if emu_lib:
+            cb, lb = np.zeros((B, N), dtype=np.int32), np.zeros(B, dtype=np.int32)
+            codes_ptrs.append(cb.ctypes.data); lens_ptrs.append(lb.ctypes.data)
+        else:
+            cb = torch.zeros((B, N), dtype=torch.int32, device=f"cuda:{dev}")
+            lb = torch.zeros(B, dtype=torch.int32, device=f"cuda:{dev}")
+            codes_ptrs.append(cb.data_ptr()); lens_ptrs.append(lb.data_ptr())
+        codes_bufs.append(cb); lens_bufs.append(lb)
+    codes_buf, lens_buf, codes_ptr, lens_ptr = codes_bufs[0], lens_bufs[0], codes_ptrs[0], lens_ptrs[0]
 
     if cont:   # ragged requests, seeded: prompt lengths 0.7 .. 1.3 x S, generated lengths 0.6 .. 1.4 x N (means S and N)
         rng = np.random.default_rng(4321 + rank)
@@ -341,7 +359,7 @@ def main():
                   for i in range(R)]
     cont_tokens = [0]
 
-    def one_step_continuous(collect=False):
+    def one_step_continuous(collect=False, last=False):
         """One pass over R ragged requests: continuous batching (BackboneEngine.generate: admission by free slots, KV pages
         and prefill budget; finished slots are read, released and refilled every 8 decode steps, new prompts admitted 16 at a time), then the codec over the
         finished utterances in batches of B."""
@@ -364,7 +382,8 @@ def main():
             ph["codec_wall"] = (time.time() - t1) * 1e3
         return ph, None, wavs
 
-    pending = {"codec": False}
+    pending = {"codec": False, "lens": None}
+    pstate = {"cur": 0, "ready": [False] * len(engs)}     # pipelined static mode: whose turn it is, which engine holds a prefilled batch
     async_codec = os.environ.get("NTTS_BENCH_ASYNC_CODEC", "1") != "0"
 
     def finish_pending():
@@ -374,11 +393,75 @@ def main():
             return
         codec.sync()
         pending["codec"] = False
-        got = lens_buf if emu_lib else lens_buf.cpu().numpy()
+        lb = pending["lens"] if pending["lens"] is not None else lens_buf
+        got = lb if emu_lib else lb.cpu().numpy()
         assert (np.asarray(got) == N).all(), "bench run did not produce the expected tokens"
 
-    def one_step_static(collect=False):
+    def prefill_all(e):
+        each = []
+        for c in range(0, B, a.prefill_chunk):
+            n = min(a.prefill_chunk, B - c)
+            tc0 = time.time()
+            e.prefill(prompts[c:c + n], list(range(c, c + n)), samps[c:c + n] if samps else [samp] * n)
+            each.append(round((time.time() - tc0) * 1e3, 1))
+        return each
+
+    def one_step_pipelined(last=False):
+        """One batch through the two-engine pipeline: prompts -> codec-token ids -> 24 kHz waveforms.  The launching thread enqueues
+        the NEXT batch's prompt pass on the other engine's stream before this batch's 249 decode graphs, and this batch's codec pass
+        (codec engine's stream) before the next iteration: the GPU runs decode (latency-bound, ~a quarter of the HBM peak) beside
+        the matrix-core-bound passes.  A timed region is self-contained: its first step runs its own prompt pass un-overlapped
+        (nothing is ready), its last step starts no further batch -- K steps hold K prompt passes, K decode loops, K codec passes."""
+        i = pstate["cur"]
+        cur, other = engs[i], engs[1 - i]
+        ph = {}
+        tw = [time.time()]
+        each = []
+        if not pstate["ready"][i]:
+            each += prefill_all(cur)                               # pipeline ramp
+        if not last:
+            each += prefill_all(other)                             # batch k + 1, asynchronous, the other engine's stream
+            pstate["ready"][1 - i] = True
+        ph["host_wall_prefill_each"] = each
+        tw.append(time.time())
+        cur.decode(N - 1)
+        tw.append(time.time())
+        wavs = None
+        if codec is not None:
+            cur.export_codes(list(range(B)), 0, n_codes, codes_ptrs[i], N, lens_ptrs[i], modulo=True)
+        st, n_new = cur.poll()                                      # blocking: batch k's decode (+ export) done
+        assert (n_new == N).all() and (st == 2).all(), "bench run did not produce the expected tokens"
+        if codec is not None:
+            finish_pending()                                        # batch k - 1's waveforms have left the codec engine's pinned buffer
+            wavs = codec.decode_device(codes_ptrs[i], N, np.full(B, N, dtype=np.int32), producer_stream=cur.stream())
+            pending["codec"], pending["lens"] = True, lens_bufs[i]
+            assert wavs.shape == (B, ccfg.hop_length * N)
+        tw.append(time.time())
+        for s_ in range(B):
+            cur.release(s_)
+        pstate["ready"][i] = False
+        pstate["cur"] = 1 - i
+        tw.append(time.time())
+        ph["host_wall_prefill_calls"] = (tw[1] - tw[0]) * 1e3
+        ph["host_wall_decode_call"] = (tw[2] - tw[1]) * 1e3
+        ph["host_wall_wait_and_codec"] = (tw[3] - tw[2]) * 1e3
+        ph["host_wall_release"] = (tw[4] - tw[3]) * 1e3
+        ph["host_wall_total"] = (tw[4] - tw[0]) * 1e3
+        return ph, None, wavs
+
+    def one_step_static(collect=False, last=False):
         """One pass of the hot path over one batch: prompts -> codec-token ids -> 24 kHz waveforms."""
+        if pipe and not collect:
+            return one_step_pipelined(last)
+        if pipe:                                                     # the untimed phase split runs serially on engine 0: drain the pipeline first
+            finish_pending()
+            for j, e2 in enumerate(engs):
+                if pstate["ready"][j]:
+                    e2.sync()
+                    for s_ in range(B):
+                        e2.release(s_)
+                    pstate["ready"][j] = False
+            pstate["cur"] = 0
         ph = {"prefill": 0.0, "decode": 0.0, "codec": 0.0, "handoff_host": 0.0, "codec_call_wall": 0.0}
         tw = [time.time()]                                   # host wall-clock stamps (reported as phase_ms.host_wall_*)
         each = []
@@ -443,7 +526,7 @@ def main():
 
     stream_stats = {}
 
-    def one_step_stream(collect=False):
+    def one_step_stream(collect=False, last=False):
         """One pass over the batch as B concurrent streams: time to first audio per utterance, the times at which utterance 0's
         0.5 s chunks arrive (every utterance of the batch gets its chunk in the same burst), all waveform samples received."""
         refs = [[int(t) % n_codes for t in p[-372:]] for p in prompts]      # reference codes as long as ref:samples/dave.pt (372)
@@ -478,15 +561,15 @@ def main():
         if not emu_lib:
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        one_step()
+    for k in range(a.warmup):
+        one_step(last=(k == a.warmup - 1))
     barrier()
     t0 = time.time()
     step_wall = []                                   # per-step host wall time (diagnostic; `value` uses the barrier-bracketed total)
     step_host = []                                   # static mode: host wall of [prefill calls, decode enqueue, wait + codec] per step
-    for _ in range(a.steps):
+    for k in range(a.steps):
         ts = time.time()
-        ph_t = one_step(collect=bool(os.environ.get("NTTS_BENCH_STEP_PHASES")))[0]   # (diagnostic: per-step GPU phases add syncs)
+        ph_t = one_step(collect=bool(os.environ.get("NTTS_BENCH_STEP_PHASES")), last=(k == a.steps - 1))[0]   # (diagnostic: per-step GPU phases add syncs)
         step_wall.append(round((time.time() - ts) * 1e3, 2))
         if "host_wall_prefill_calls" in ph_t:
             step_host.append([ph_t["host_wall_prefill_each"]] + [round(ph_t[k], 1) for k in ("host_wall_prefill_calls", "host_wall_decode_call", "host_wall_wait_and_codec")]
@@ -575,7 +658,7 @@ def main():
         else:
             workload = (f"NeuTTS-Air bf16 {world}xMI355X batch={B} synthetic prompts per GPU, {S} prefill / {N} decode tokens, "
                         f"STATIC batch (all {B} slots of the continuous-batching engine filled at once, every utterance {N} tokens; the ragged "
-                        f"scheduler line is --mode continuous) + hipGraph decode (BASELINE.json configs[{2 if world == 1 else 3}])")
+                        f"scheduler line is --mode continuous)" + (", consecutive batches pipelined over two engines" if pipe else "") + f" + hipGraph decode (BASELINE.json configs[{2 if world == 1 else 3}])")
         workload += ", sampling as the reference calls generate (do_sample, top_k=50, temperature=1.0, seeded)" if a.sample else ", greedy"
         if strm:
             workload = (f"STREAM mode: {B} concurrent infer_stream utterances per GPU (27-frame windows every 25 tokens, 0.5 s chunks, "
@@ -597,7 +680,13 @@ def main():
             "rtf": dt / (tokens / 50.0),
             "phase_ms": ph, "step_wall_ms": step_wall, "step_host_wall_ms": step_host,
             "roofline": roof, "decode_step": step_info, "cpu_baseline": cpu,
-            "timed_region": "warm_up() before timing, codec pass + D2H of batch k asynchronous under the prompt pass of batch k + 1 (static mode)",
+            "timed_region": ("warm_up() before timing; TWO backbone engines, one launching thread: batch k + 1's prompt pass (engine B's stream) is enqueued "
+                             "before batch k's decode graphs (engine A's stream), batch k's codec pass + D2H run on the codec engine's stream under "
+                             "batch k + 1's decode; the timed region is self-contained (first step un-overlapped prompt pass, last step starts no "
+                             "further batch: K prompt passes, K decode loops, K codec passes, every waveform landed before the clock stops); "
+                             "phase_ms is a separate serial pass" if pipe else
+                             "warm_up() before timing, codec pass + D2H of batch k asynchronous under the prompt pass of batch k + 1 (static mode, one engine)"),
+            "pipeline": {"engines": len(engs), "overlap": "prefill(k+1) | decode(k) | codec(k-1)"} if pipe else None,
         }
         if strm:
             rec["stream"] = stream_stats

@@ -188,6 +188,7 @@ class BackboneEngine:
         if self.lib.ntts_abi_version() != ABI_VERSION:
             raise RuntimeError(f"libneutts_hip ABI mismatch: library {self.lib.ntts_abi_version()}, binding {ABI_VERSION} (rebuild: python neutts-air_amd/build.py)")
         self.cfg = dict(cfg)
+        self._device, self._lib_path = device, lib_path
         c = BackboneConfigC(cfg["vocab_size"], cfg["hidden_size"], cfg["intermediate_size"], cfg["num_layers"],
                             cfg["num_heads"], cfg["num_kv_heads"], cfg.get("head_dim", 64), cfg.get("rms_eps", 1e-6),
                             cfg.get("max_context", 2048), cfg.get("max_batch", 1), cfg.get("num_pages", 0),
@@ -279,6 +280,17 @@ class BackboneEngine:
 
     def adopt_arena(self):
         self._chk(self.lib.ntts_backbone_adopt_arena(self.h))
+
+    def twin(self) -> "BackboneEngine":
+        """A second engine with this one's configuration and weights -- its own KV pool, slot state and stream -- filled by ONE
+        device-to-device copy of the finalised arena (no second upload, no re-quantisation).  What cross-batch pipelining needs:
+        while this engine replays batch k's decode graphs, the twin runs batch k + 1's prompt pass (bench.py static mode)."""
+        ptr, nbytes = self.arena()
+        self.sync()
+        t = BackboneEngine(self.cfg, self._device, self._lib_path)
+        t.arena_copy(ptr, nbytes, True)
+        t.adopt_arena()
+        return t
 
     # -- requests
     def prefill(self, prompts: Sequence[Sequence[int]], slots: Sequence[int], sampling: Sequence[Sampling],

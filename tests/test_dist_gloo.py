@@ -44,7 +44,7 @@ def test_broadcast_and_sharded_generate_world2(emu_lib):
 
 
 def test_bench_contract_world2(emu_lib):
-    r = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--tiny", "--batch", "2",
+    r = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--tiny", "--batch", "2",
                       "--prefill", "12", "--decode", "4", "--prefill-chunk", "2", "--no-roofline"],
                   {"NTTS_BENCH_EMU_LIB": emu_lib})
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
@@ -56,6 +56,9 @@ def test_bench_contract_world2(emu_lib):
         assert k in rec
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     assert abs(rec["value"] - 2 * 2 * 4 / (rec["ms_per_step"] / 1e3)) < 1e-6 * rec["value"] + 1e-9
+    # static mode pipelines consecutive batches over two engines (prompt pass of batch k + 1 beside the decode of batch k); every
+    # step asserts its token counts from the device-exported lengths, so three steps = both engines, both hand-off buffer pairs
+    assert rec["pipeline"]["engines"] == 2 and rec["steps"] == 3
 
 
 def test_bench_contract_world8(emu_lib):

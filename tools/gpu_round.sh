@@ -12,7 +12,7 @@ for leg in $LEGS; do
   case $leg in
     smoke) timeout 420 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -5 $OUT/smoke.log;;
     tests) timeout ${TESTS_TIMEOUT:-900} python -m pytest tests -m gpu -q -rA --durations=10 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -45 $OUT/pytest_gpu.log;;
-    bench) timeout 600 python bench.py --steps ${BENCH_STEPS:-2} --warmup 2 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -25 $OUT/bench.err;;
+    bench) timeout 600 python bench.py --steps ${BENCH_STEPS:-10} --warmup 2 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -25 $OUT/bench.err;;
     b1)    timeout 300 python bench.py --batch 1 --steps ${BENCH_STEPS:-3} --warmup 1 --no-cpu-baseline > $OUT/bench_b1.json 2> $OUT/bench_b1.err; echo "bench b1 rc=$?"; cat $OUT/bench_b1.json | cut -c1-1500; tail -12 $OUT/bench_b1.err;;
     prof)  rm -rf $OUT/prof; NTTS_BENCH_PRIME_STEPS=2 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof -o bench -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $OUT/prof_bench.json 2> $OUT/prof.err; echo "prof rc=$?"
            python tools/prof_summary.py $OUT/prof > $OUT/prof_summary.txt 2>&1; head -40 $OUT/prof_summary.txt; cat $OUT/prof_bench.json; tail -3 $OUT/prof.err
