@@ -359,27 +359,69 @@ def main():
                   for i in range(R)]
     cont_tokens = [0]
 
+    # continuous mode: finished utterances leave through the device-side hand-off as they finish (on_finished hook: export_codes
+    # into a staging buffer before the slot is released); every B of them go through ONE codec pass on the codec engine's stream
+    # while the backbone keeps decoding the others
+    if cont and codec is not None and not emu_lib:
+        stage_codes = [torch.zeros((B, N_max), dtype=torch.int32, device=f"cuda:{dev}") for _ in range(2)]
+        stage_lens = [torch.zeros(B, dtype=torch.int32, device=f"cuda:{dev}") for _ in range(2)]
+    elif cont and codec is not None:
+        stage_codes = [np.zeros((B, N_max), dtype=np.int32) for _ in range(2)]
+        stage_lens = [np.zeros(B, dtype=np.int32) for _ in range(2)]
+
     def one_step_continuous(collect=False, last=False):
-        """One pass over R ragged requests: continuous batching (BackboneEngine.generate: admission by free slots, KV pages
-        and prefill budget; finished slots are read, released and refilled every 8 decode steps, new prompts admitted 16 at a time), then the codec over the
-        finished utterances in batches of B."""
-        ph = {"generate_wall": 0.0, "codec_wall": 0.0}
+        """One pass over R ragged requests: continuous batching (BackboneEngine.generate: admission by free slots, KV pages and
+        prefill budget; ONE burst of decode steps always queued ahead of the host's bookkeeping; finished slots exported on the
+        device, released and refilled, new prompts admitted 16 at a time), the codec over every B finished utterances on its own
+        stream beside the decode steps of the others."""
+        ph = {"generate_wall": 0.0, "codec_tail_wall": 0.0, "codec_passes": 0}
+        c0 = dict(eng.counters)
         t1 = time.time()
-        ids = eng.generate(r_prompts, r_samp, steps_per_poll=int(os.environ.get("NTTS_BENCH_POLL", "8")), prefill_token_budget=a.prefill_chunk * S,
-                           min_admit=int(os.environ.get("NTTS_BENCH_MIN_ADMIT", "16")))
+        st8 = {"n": 0, "buf": 0, "tokens": 0, "lens": np.zeros(B, dtype=np.int32), "wavs": None, "busy": False}
+
+        def ptr(x, row):
+            return x[row:row + 1].ctypes.data if emu_lib else x[row:row + 1].data_ptr()
+
+        def flush(nrows):
+            if st8["busy"]:
+                codec.sync()                                  # the previous pass has left the codec engine's pinned output buffer
+            cb = stage_codes[st8["buf"]]
+            wv = codec.decode_device(cb.ctypes.data if emu_lib else cb.data_ptr(), N_max, st8["lens"][:nrows].copy(), producer_stream=eng.stream())
+            st8["busy"], st8["wavs"] = True, wv
+            ph["codec_passes"] += 1
+            st8["buf"] ^= 1
+            st8["n"] = 0
+
+        def hook(i, slot, n_new):
+            assert n_new == int(r_glen[i]), "continuous run did not produce the expected tokens"
+            st8["tokens"] += n_new
+            if codec is None:
+                return
+            row = st8["n"]
+            eng.export_codes([slot], 0, n_codes, ptr(stage_codes[st8["buf"]], row), N_max, ptr(stage_lens[st8["buf"]], row), modulo=True)
+            st8["lens"][row] = n_new
+            st8["n"] = row + 1
+            if st8["n"] == B:
+                flush(B)
+
+        eng.generate(r_prompts, r_samp, steps_per_poll=int(os.environ.get("NTTS_BENCH_POLL", "4")), prefill_token_budget=a.prefill_chunk * S,
+                     min_admit=int(os.environ.get("NTTS_BENCH_MIN_ADMIT", "24")), on_finished=hook,
+                     run_ahead=os.environ.get("NTTS_BENCH_RUN_AHEAD", "1") != "0")
         ph["generate_wall"] = (time.time() - t1) * 1e3
-        assert all(len(x) == int(g) for x, g in zip(ids, r_glen)), "continuous run did not produce the expected tokens"
-        cont_tokens[0] = int(sum(len(x) for x in ids))
+        t1 = time.time()
         wavs = None
         if codec is not None:
-            t1 = time.time()
-            order = np.argsort(-r_glen)                          # similar lengths together: fewer padded frames per codec pass
-            for c in range(0, R, B):
-                grp = order[c:c + B]
-                out = codec.decode([(np.asarray(ids[j], dtype=np.int64) % n_codes).astype(np.int32) for j in grp], reuse_output=False)
-                if wavs is None:
-                    wavs = np.concatenate([o[:1000] for o in out[:4]])[None, :]
-            ph["codec_wall"] = (time.time() - t1) * 1e3
+            if st8["n"]:
+                flush(st8["n"])
+            codec.sync()
+            wavs = st8["wavs"][:1, :4000].copy() if st8["wavs"] is not None else None
+        else:
+            eng.sync()
+        ph["codec_tail_wall"] = (time.time() - t1) * 1e3
+        cont_tokens[0] = st8["tokens"]
+        assert st8["tokens"] == int(r_glen.sum())
+        ph.update({k: eng.counters[k] - c0[k] for k in c0})       # scheduler diagnostics: decode steps issued, prompt passes and their sizes
+        ph["slot_occupancy"] = st8["tokens"] / max(1, ph["decode_steps"] * B)
         return ph, None, wavs
 
     pending = {"codec": False, "lens": None}

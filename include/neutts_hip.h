@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NTTS_ABI_VERSION 4
+#define NTTS_ABI_VERSION 5
 
 enum {
     NTTS_OK = 0,
@@ -168,6 +168,17 @@ int ntts_backbone_read(ntts_backbone* e, int32_t slot, int32_t* out_ids, int32_t
 int ntts_backbone_read_all(ntts_backbone* e, int32_t* out_ids, int32_t cap, int32_t* n_out, int32_t* finished);
 /* Blocking.  One int32 per slot: 0 free, 1 running, 2 finished; new-token counts in n_new (may be NULL). */
 int ntts_backbone_poll(ntts_backbone* e, int32_t* state, int32_t* n_new);
+/* ABI 5.  The same poll WITHOUT stopping the stream, for a scheduler that keeps one burst of decode steps queued ahead of its own
+ * bookkeeping (the stopping criteria of hf:generation/utils.py:2783-2973 are evaluated on the device every step; the host only
+ * has to notice finished rows some steps later).  _begin enqueues a copy of every slot's state / new-token count into page-locked
+ * memory behind the work issued so far and returns; _end waits for THAT copy only -- not for anything enqueued after _begin -- and
+ * hands the values out (n_new may be NULL).  One snapshot may be open at a time (NTTS_ESTATE otherwise). */
+int ntts_backbone_poll_begin(ntts_backbone* e);
+int ntts_backbone_poll_end(ntts_backbone* e, int32_t* state, int32_t* n_new);
+/* ABI 5.  ntts_backbone_read for a slot that the last completed snapshot (poll_begin / poll_end) showed FINISHED and that has not
+ * been released since: its ids are final, so the copy runs on a side stream past the decode steps still queued on the engine's
+ * stream (ntts_backbone_read would wait for all of them).  NTTS_ESTATE if the slot was not finished in that snapshot. */
+int ntts_backbone_read_finished(ntts_backbone* e, int32_t slot, int32_t* out_ids, int32_t cap, int32_t* n_out);
 /* The id -> code hand-off of ref:neutts/neutts.py:349 (tokenizer.decode) + :276 (regex over "<|speech_N|>") without leaving the
  * device: for each of the `n` decode slots `slots[i]` (HOST array), the new ids that are speech tokens -- speech_base <= id <
  * speech_base + n_codes -- are written in order as id - speech_base to codes_dev[i * stride ...] (DEVICE int32, at most `stride`

@@ -139,6 +139,12 @@ struct ntts_backbone {
     static constexpr int kMetaStages = 4;
     int* meta_host[kMetaStages] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t meta_ev[kMetaStages] = {nullptr, nullptr, nullptr, nullptr};
+    // asynchronous slot snapshot (ntts_backbone_poll_begin / _end): state | n_new of every slot as of a point of the stream, in
+    // page-locked memory; the copy stream carries the reads of finished slots' ids past the decode steps still queued
+    int* snap_host = nullptr;          // [2 * max_batch]
+    hipEvent_t snap_ev = nullptr;
+    bool snap_open = false, snap_valid = false;
+    hipStream_t copy_stream = nullptr;
     bool meta_used[kMetaStages] = {false, false, false, false};
     int meta_next = 0;
 
@@ -411,6 +417,9 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
         CR_HIP(hipHostMalloc((void**)&e->meta_host[i], e->meta_cap * sizeof(int), hipHostMallocDefault));
         CR_HIP(hipEventCreateWithFlags(&e->meta_ev[i], hipEventDisableTiming));
     }
+    CR_HIP(hipHostMalloc((void**)&e->snap_host, 2 * (size_t)B * sizeof(int), hipHostMallocDefault));
+    CR_HIP(hipEventCreateWithFlags(&e->snap_ev, hipEventDisableTiming));
+    CR_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
     CR_HIP(hipDeviceSynchronize());
     *out = e;
     return NTTS_OK;
@@ -433,6 +442,9 @@ extern "C" void ntts_backbone_destroy(ntts_backbone* e) {
         if (e->meta_host[i]) hipHostFree(e->meta_host[i]);
         if (e->meta_ev[i]) hipEventDestroy(e->meta_ev[i]);
     }
+    if (e->snap_host) hipHostFree(e->snap_host);
+    if (e->snap_ev) hipEventDestroy(e->snap_ev);
+    if (e->copy_stream) hipStreamDestroy(e->copy_stream);
     if (e->pf_stream) { hipStreamDestroy(e->pf_stream); hipEventDestroy(e->pf_ev[0]); hipEventDestroy(e->pf_ev[1]); }
     if (e->stream) hipStreamDestroy(e->stream);
     delete e;
@@ -1398,6 +1410,52 @@ extern "C" int ntts_backbone_poll(ntts_backbone* e, int32_t* state, int32_t* n_n
     HIPCHK(e, hipStreamSynchronize(e->stream));
     HIPCHK(e, hipMemcpy(state, e->sl.state, B * sizeof(int), hipMemcpyDeviceToHost));
     if (n_new) HIPCHK(e, hipMemcpy(n_new, e->sl.n_new, B * sizeof(int), hipMemcpyDeviceToHost));
+    return NTTS_OK;
+}
+
+// ---- the same poll without stopping the stream: the scheduler enqueues the NEXT burst of decode steps, then looks at the slot
+//      states as they were BEFORE that burst -- the GPU never waits for the host to read, release and refill
+extern "C" int ntts_backbone_poll_begin(ntts_backbone* e) {
+    if (!e) return NTTS_EINVAL;
+    if (e->snap_open) return fail(e, NTTS_ESTATE, "a snapshot is already open (ntts_backbone_poll_end first)");
+    const int B = e->cfg.max_batch;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipMemcpyAsync(e->snap_host, e->sl.state, B * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->snap_host + B, e->sl.n_new, B * sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(e, hipEventRecord(e->snap_ev, e->stream));
+    e->snap_open = true;
+    e->snap_valid = false;
+    return NTTS_OK;
+}
+
+extern "C" int ntts_backbone_poll_end(ntts_backbone* e, int32_t* state, int32_t* n_new) {
+    if (!e || !state) return NTTS_EINVAL;
+    if (!e->snap_open) return fail(e, NTTS_ESTATE, "no snapshot is open (ntts_backbone_poll_begin first)");
+    const int B = e->cfg.max_batch;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipEventSynchronize(e->snap_ev));     // waits for the work enqueued BEFORE poll_begin only
+    memcpy(state, e->snap_host, B * sizeof(int));
+    if (n_new) memcpy(n_new, e->snap_host + B, B * sizeof(int));
+    e->snap_open = false;
+    e->snap_valid = true;
+    return NTTS_OK;
+}
+
+extern "C" int ntts_backbone_read_finished(ntts_backbone* e, int32_t slot, int32_t* out_ids, int32_t cap, int32_t* n_out) {
+    if (!e || slot < 0 || slot >= e->cfg.max_batch || !n_out) return fail(e, NTTS_EINVAL, "bad argument");
+    const int B = e->cfg.max_batch;
+    if (!e->snap_valid || e->snap_host[slot] != SLOT_FINISHED || e->slots[slot].state == SLOT_FREE)
+        return fail(e, NTTS_ESTATE, "slot %d was not finished in the last completed snapshot", slot);
+    HIPCHK(e, hipSetDevice(e->device));
+    // A finished slot's ids do not change until it is released, and the snapshot that showed it finished has completed: the
+    // copy needs no ordering against the decode steps still queued on the engine's stream, so it goes around them
+    const int nn = e->snap_host[B + slot];
+    const int k = nn < cap ? nn : cap;
+    if (out_ids && k > 0) {
+        HIPCHK(e, hipMemcpyAsync(out_ids, e->sl.out_tokens + (size_t)slot * e->sl.out_stride, k * sizeof(int), hipMemcpyDeviceToHost, e->copy_stream));
+        HIPCHK(e, hipStreamSynchronize(e->copy_stream));
+    }
+    *n_out = nn;
     return NTTS_OK;
 }
 

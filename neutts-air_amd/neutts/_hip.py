@@ -18,7 +18,7 @@ DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "libneutts_hip.so")
 
 NTTS_DT_F32, NTTS_DT_BF16, NTTS_DT_I32 = 0, 1, 2
 NTTS_W_BF16, NTTS_W_FP8_E4M3 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 NTTS_PAGE_TOKENS = 32            # include/neutts_hip.h
 PAGE_TOKENS = 32
 ERRORS = {-1: "EINVAL", -2: "ENODEV", -3: "ENOMEM", -4: "ESTATE", -5: "EHIP"}
@@ -98,6 +98,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_backbone_read": (C.c_int, [p, i32, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(i32)]),
         "ntts_backbone_read_all": (C.c_int, [p, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(i32)]),
         "ntts_backbone_poll": (C.c_int, [p, C.POINTER(i32), C.POINTER(i32)]),
+        "ntts_backbone_poll_begin": (C.c_int, [p]),
+        "ntts_backbone_poll_end": (C.c_int, [p, C.POINTER(i32), C.POINTER(i32)]),
+        "ntts_backbone_read_finished": (C.c_int, [p, i32, C.POINTER(i32), i32, C.POINTER(i32)]),
         "ntts_backbone_release": (C.c_int, [p, i32]),
         "ntts_backbone_export_codes": (C.c_int, [p, i32, C.POINTER(i32), i32, i32, i32, p, i32, p]),
         "ntts_backbone_stream": (C.c_int, [p, C.POINTER(p)]),
@@ -205,6 +208,7 @@ class BackboneEngine:
         self.max_context = c.max_context
         self.vocab_size = c.vocab_size
         self._free: List[int] = list(range(self.max_batch - 1, -1, -1))   # host-side pool of decode slots (pop -> slot 0 first)
+        self.counters = {"decode_steps": 0, "prefill_calls": 0, "prefill_prompts": 0, "prefill_tokens": 0}   # diagnostics (bench.py)
 
     # -- decode-slot pool: every path that admits a request (generate, the streaming generators) draws from here, so an
     #    unfinished stream and a later call can never be handed the same slot
@@ -307,6 +311,9 @@ class BackboneEngine:
         except NeuTTSHipError:
             raise                      # the engine admitted nothing: slots drawn from the pool stay with the caller to release
         self._mark_busy(slots)
+        self.counters["prefill_calls"] += 1
+        self.counters["prefill_prompts"] += n
+        self.counters["prefill_tokens"] += int(lens.sum())
 
     def _prefill_call(self, n, ids, lens, sl, sampling, donors):
         sc = (SamplingC * n)(*[s.to_c() for s in sampling])
@@ -329,6 +336,7 @@ class BackboneEngine:
 
     def decode(self, n_steps: int = 1):
         self._chk(self.lib.ntts_backbone_decode(self.h, n_steps))
+        self.counters["decode_steps"] += n_steps
 
     def read(self, slot: int):
         out = np.empty(self.max_context, dtype=np.int32)
@@ -336,6 +344,25 @@ class BackboneEngine:
         self._chk(self.lib.ntts_backbone_read(self.h, slot, out.ctypes.data_as(C.POINTER(C.c_int32)), len(out),
                                               C.byref(n), C.byref(fin)))
         return out[: n.value].tolist(), bool(fin.value)
+
+    def poll_begin(self):
+        """Asynchronous poll: snapshot every slot's state / new-token count behind the work enqueued so far (no host wait)."""
+        self._chk(self.lib.ntts_backbone_poll_begin(self.h))
+
+    def poll_end(self):
+        """(state, n_new) of the snapshot opened by poll_begin; waits for that copy only, not for work enqueued after it."""
+        st = np.empty(self.max_batch, dtype=np.int32)
+        nn = np.empty(self.max_batch, dtype=np.int32)
+        i32p = C.POINTER(C.c_int32)
+        self._chk(self.lib.ntts_backbone_poll_end(self.h, st.ctypes.data_as(i32p), nn.ctypes.data_as(i32p)))
+        return st, nn
+
+    def read_finished(self, slot: int) -> List[int]:
+        """The ids of a slot the last completed snapshot showed finished -- copied past the decode steps still queued."""
+        out = np.empty(self.max_context, dtype=np.int32)
+        n = C.c_int32()
+        self._chk(self.lib.ntts_backbone_read_finished(self.h, slot, out.ctypes.data_as(C.POINTER(C.c_int32)), len(out), C.byref(n)))
+        return out[: n.value].tolist()
 
     def read_all_array(self):
         """Every slot's new ids in one call, as arrays: (ids [max_batch, max_context] int32 -- row s valid up to n[s]),
@@ -444,14 +471,23 @@ class BackboneEngine:
 
     # -- continuous batching (host scheduler): keep every slot busy until all prompts are done
     def generate(self, prompts: Sequence[Sequence[int]], sampling, steps_per_poll: int = 16,
-                 prefill_token_budget: Optional[int] = None, share_prefix: bool = False, min_admit: int = 1) -> List[List[int]]:
+                 prefill_token_budget: Optional[int] = None, share_prefix: bool = False, min_admit: int = 1,
+                 on_finished=None, run_ahead: bool = True) -> List[List[int]]:
         """Batched equivalent of calling ref:neutts/neutts.py:338-351 once per prompt.
         Returns the NEW ids of each prompt (prompt stripped), in order.
         share_prefix=True: a prompt that starts like one already in flight (same speaker: chat header + reference
         text, ref:neutts/neutts.py:307,315-325) re-uses that slot's KV pages for the common whole pages.
         min_admit: waiting prompts are admitted only once that many slots are free (or nothing is running): a prompt pass over
         a handful of prompts runs the big GEMM tiles nearly empty, so under load it pays to let a few slots idle for some steps
-        and prefill them together."""
+        and prefill them together.
+        run_ahead (default): the scheduler keeps ONE burst of `steps_per_poll` decode steps queued ahead of its own bookkeeping --
+        it enqueues burst k + 1 and only then reads the slot states as they were after burst k (ntts_backbone_poll_begin / _end),
+        so the GPU never idles while the host reads finished rows, releases slots and packs the next prompt pass.  The price is
+        that a finished row is noticed up to one burst later (it is carried along masked meanwhile: stopping is decided on the
+        device, the ids cannot differ).
+        on_finished(request_index, slot, n_new): called for every finished request BEFORE its slot is released, INSTEAD of
+        copying its ids to the host (that request's entry of the result is then []): the hook of a device-side hand-off
+        (ntts_backbone_export_codes enqueued from it is ordered before the slot's re-use)."""
         if isinstance(sampling, Sampling):
             sampling = [sampling] * len(prompts)
         budget = prefill_token_budget or self.cfg.get("max_prefill_tokens", 0) or 16384
@@ -477,6 +513,11 @@ class BackboneEngine:
         owner: Dict[int, int] = {}
         anchors: List[tuple] = []       # (slot, prompt as int32 array) of live slots that later prompts are compared with
         arrs = [np.asarray(p, dtype=np.int32) for p in prompts] if share_prefix else None
+        # run-ahead bookkeeping: snapshots are numbered in stream order; a slot's entry in snapshot q describes the request that
+        # owns it now only if the slot was (re)filled before snapshot q was enqueued
+        snap_seq = 0                    # number of the next snapshot to be enqueued
+        valid_from: Dict[int, int] = {}  # slot -> first snapshot number that describes its current request
+        open_snap: Optional[int] = None  # number of the snapshot opened by poll_begin and not read yet
 
         def find_donor(i):
             best = None
@@ -507,6 +548,7 @@ class BackboneEngine:
                         donors.append(d)
                         used += cost
                         owner[s] = nxt
+                        valid_from[s] = snap_seq
                         if share_prefix and d is None and len(anchors) < 16:
                             anchors.append((s, arrs[nxt]))      # a new beginning: later prompts may share it
                         nxt += 1
@@ -530,19 +572,45 @@ class BackboneEngine:
                         break
                 if not owner:
                     raise NeuTTSHipError(-4, "no decode slot is free (held by an unfinished stream?)")
-                st, _ = self.poll()
-                for s in list(owner):
-                    if st[s] == 2:  # finished
-                        ids, _ = self.read(s)
-                        results[owner.pop(s)] = ids
+                if run_ahead:
+                    # keep the GPU fed: this burst goes in BEFORE the host looks at the previous burst's outcome.  Stream order per
+                    # iteration j: [prompt pass j] [burst j] [exports / releases j] [snapshot j]; the host waits for snapshot j - 1
+                    # only, with burst j queued behind it
+                    self.decode(steps_per_poll)
+                    if open_snap is None:
+                        st = nn = None
+                    else:
+                        st, nn = self.poll_end()
+                        q, open_snap = open_snap, None
+                else:
+                    st, nn = self.poll()
+                    q = snap_seq                                  # a blocking poll describes everything enqueued so far
+                if st is not None:
+                    for s in [s for s in list(owner) if valid_from.get(s, 0) <= q and st[s] == 2]:
+                        i = owner.pop(s)
+                        if on_finished is not None:
+                            on_finished(i, s, int(nn[s]))
+                            results[i] = []
+                        else:
+                            results[i] = self.read_finished(s) if run_ahead else self.read(s)[0]
                         committed.pop(s, None)
                         self.release(s)                          # shared pages live on until their last user is released
+                        valid_from.pop(s, None)
                         anchors = [a for a in anchors if a[0] != s]
-                if owner and any(st[s] == 1 for s in owner):
+                if run_ahead:
+                    self.poll_begin()
+                    open_snap = snap_seq
+                    snap_seq += 1
+                elif owner and any(st[s] == 1 for s in owner):
                     self.decode(steps_per_poll)
         finally:
             # an exception (KV pool exhausted, a failed launch, ...) must not leave admitted slots RUNNING with their
             # pages held: the next call would find them busy
+            if open_snap is not None:
+                try:
+                    self.poll_end()
+                except NeuTTSHipError:
+                    pass
             if owner:
                 try:
                     self.sync()

@@ -78,3 +78,18 @@ def test_bench_contract_world8(emu_lib):
     for rank in range(8):          # the per-rank start-up timeline (library, engines, weights received, warm-up)
         assert f"rank {rank}/8" in r.stderr and "warm-up done" in r.stderr
     assert r.stderr.count("weights received") == 8 and r.stderr.count("weights synthesised and uploaded (rank 0)") == 1
+
+
+def test_bench_continuous_mode_emulator(emu_lib):
+    """`bench.py --mode continuous` end to end on the emulator build: ragged requests through the run-ahead scheduler, every finished
+    utterance exported on the "device" from the on_finished hook, one codec pass per `batch` finished utterances + the ragged tail,
+    token counts asserted per request inside the step."""
+    import subprocess
+    import sys
+    env = dict(os.environ, NTTS_BENCH_EMU_LIB=emu_lib)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--tiny", "--mode", "continuous", "--batch", "2", "--requests", "7",
+                        "--prefill", "12", "--decode", "6", "--prefill-chunk", "2", "--steps", "1", "--warmup", "0", "--no-roofline",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["value"] > 0 and rec["phase_ms"]["codec_passes"] == 4      # 7 utterances = 3 full codec batches of 2 + the tail

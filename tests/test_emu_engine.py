@@ -110,6 +110,22 @@ def test_continuous_batching_ragged_vs_oracle(emu_lib):
     for g, r in zip(got, want_r):
         assert_free_run_matches(g, r)
     assert sum(int(g == x) for g, x in zip(got, want)) >= len(want) - 1
+    # the scheduler runs one burst ahead of its bookkeeping by default (poll_begin / poll_end / read_finished): the ids cannot depend
+    # on WHEN the host notices a finished row -- same result with the blocking poll, and with a device-side hand-off hook
+    assert eng.generate(prompts, samp, steps_per_poll=3, prefill_token_budget=70, run_ahead=False) == got
+    assert eng.generate(prompts, samp, steps_per_poll=1, prefill_token_budget=70) == got
+    seen = {}
+    codes = np.zeros((len(prompts), 16), dtype=np.int32)
+    lens_out = np.zeros(len(prompts), dtype=np.int32)
+
+    def hook(i, slot, n_new):          # before the slot is released: export its ids on the "device" (the emulator's is host memory)
+        seen[i] = n_new
+        eng.export_codes([slot], 0, cfg.vocab_size, codes[i:i + 1].ctypes.data, 16, lens_out[i:i + 1].ctypes.data)
+    assert eng.generate(prompts, samp, steps_per_poll=3, prefill_token_budget=70, on_finished=hook) == [[] for _ in prompts]
+    eng.sync()
+    assert seen == {i: len(g) for i, g in enumerate(got)}
+    for i, g in enumerate(got):
+        assert lens_out[i] == len(g) and codes[i, :len(g)].tolist() == g
 
 
 def test_engine_error_paths(emu_lib):

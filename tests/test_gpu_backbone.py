@@ -178,6 +178,23 @@ def test_continuous_batching_ragged_vs_oracle(lib):
     for g, ref in zip(got, want):
         assert_free_run_matches(g, ref)
     assert sum(int(g == ref.ids) for g, ref in zip(got, want)) >= 8      # exact bf16 ties are the exception
+    # run-ahead scheduling (the default: one burst queued ahead of the host's bookkeeping, asynchronous snapshots, finished ids read
+    # on the copy stream past the queued decode steps) against the blocking poll, and a device-side hand-off from the on_finished hook
+    assert eng.generate(prompts, samp, steps_per_poll=5, prefill_token_budget=150, run_ahead=False) == got
+    assert eng.generate(prompts, samp, steps_per_poll=2, prefill_token_budget=150) == got
+    codes = torch.zeros((len(prompts), 32), dtype=torch.int32, device="cuda")
+    lens_out = torch.zeros(len(prompts), dtype=torch.int32, device="cuda")
+    seen = {}
+
+    def hook(i, slot, n_new):
+        seen[i] = n_new
+        eng.export_codes([slot], 0, cfg.vocab_size, codes[i:i + 1].data_ptr(), 32, lens_out[i:i + 1].data_ptr())
+    assert eng.generate(prompts, samp, steps_per_poll=5, prefill_token_budget=150, on_finished=hook) == [[] for _ in prompts]
+    eng.sync()
+    assert seen == {i: len(g) for i, g in enumerate(got)}
+    ch, lh = codes.cpu().numpy(), lens_out.cpu().numpy()
+    for i, g in enumerate(got):
+        assert lh[i] == len(g) and ch[i, :len(g)].tolist() == g
 
 
 @pytest.fixture(scope="module")
