@@ -109,7 +109,8 @@ def cpu_baseline(cfg, w, prompt, n_new, eos, codec_cfg, codec_w, max_seconds=30.
 
 ROCPROF_SYMBOLS = [   # rocprofv3 symbol prefix -> the step's logical kernels it serves
     ("attn_decode_kernel<", ["attn_decode_kernel"]),
-    ("gemm_kernel<4, 1, 1, 2, 4,", ["gemm_qkv", "gemm_o_proj_splitk", "gemm_down_splitk"]),
+    ("qkv_rope_kernel<", ["gemm_qkv"]),                                         # QKV projection + bias + RoPE + K append (qkv_rope.h)
+    ("gemm_kernel<4, 1, 1, 2, 4,", ["gemm_o_proj_splitk", "gemm_down_splitk"]),
     ("gemm_kernel<4, 2, 2, 1, 3,", ["gemm_gate_up_silu"]),
     ("gemm_kernel<4, 3, 4, 3, 2, 0, 64, true", ["gemm_lm_head_argmax"]),     # 256 x 288 natural-order tile (NTTS_HEAD_XL=4, the default)
     ("gemm_kernel<4, 4, 4, 3, 2, 0, 64, true", ["gemm_lm_head_argmax"]),     # 256 x 256 tile (NTTS_HEAD_XL=1)
@@ -139,7 +140,7 @@ def rocprof_symbols(path, live):
     if not out:
         return None
     out.sort(key=lambda r: -r["share_pct"])
-    return {"summary": os.path.relpath(path, ROOT), "command": "rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 0 "
+    return {"summary": os.path.relpath(path, ROOT), "command": "NTTS_BENCH_PRIME_STEPS=2 rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 0 "
             "--no-cpu-baseline --no-roofline", "dominant_symbol_by_share": out[0]["symbol"], "symbols": out}
 
 
@@ -654,19 +655,19 @@ def main():
         try:   # HBM bytes per launch from the committed PMC pass (tools/gpu_round.sh pmc -> tools/pmc_to_json.py): this configuration only
             if nano or B != 256 or S != 500:
                 raise OSError("no PMC pass for this configuration")
-            with open(os.path.join(ROOT, "profiles", "r02k_pmc_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r03f_pmc_traffic.json")) as fh:
                 pm = json.load(fh)
             for kname, rec in pm["kernels"].items():
                 if kname.startswith(name):
                     traffic = rec["fetch_bytes_per_launch"] + rec.get("write_bytes_per_launch_uncorrected", 0.0)
-                    traffic_src = "profiles/r02k_pmc_traffic.json: " + pm["source"]
+                    traffic_src = "profiles/r03f_pmc_traffic.json: " + pm["source"]
         except (OSError, KeyError, ValueError):
             pass
         # rocprofv3 view of the same command (committed summary of the same configuration): per SYMBOL, since one gemm
         # template serves three launches per layer.  `agree` = its average duration is within 15 % of this run's HIP events.
         rocprof = None
         if not nano and B == 256 and S == 500:
-            rocprof = rocprof_symbols(os.path.join(ROOT, "profiles", "r02k_bench_kernel_stats.txt"),
+            rocprof = rocprof_symbols(os.path.join(ROOT, "profiles", "r03f_bench_kernel_stats.txt"),
                                       {r[1]: (r[2], r[3], r[4]) for r in rows})
         roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": ms * 1e3,
