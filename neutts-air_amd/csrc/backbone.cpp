@@ -160,6 +160,7 @@ struct ntts_backbone {
     hipEvent_t pf_ev[2]{};
     bool have_pf_time = false, have_dec_time = false;
     unsigned long long* attn_tl = nullptr;   // diagnostics (ntts_backbone_attn_timeline)
+    unsigned long long* gemv_tl = nullptr;   // diagnostics (ntts_backbone_gemv_timeline)
     long long pf_tokens_computed = 0, pf_tokens_shared = 0;   // prompt tokens pushed through the layers / served from shared pages
 };
 
@@ -898,6 +899,7 @@ static GemvArgs gemv_args(const ntts_backbone* e, const bf16_t* X, long ldx, con
     GemvArgs a{};
     a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.w_tile_major = 1; a.out = out; a.ldo = ldo;
     a.slab_rows = e->cfg.max_batch; a.M = e->cfg.max_batch; a.N = N; a.K = K;
+    a.tl = e->gemv_tl;
     return a;
 }
 // the fused prologue of layer i's QKV GEMV: h = (i == 0 ? embed[cur_tok] : h + bf16(sum of the previous down_proj's slabs));
@@ -949,7 +951,7 @@ static void ks_gate_up(ntts_backbone* e, int i) {
     n.slabs = e->slabs; n.nslab = gemv_nsplit(e->cfg.num_heads * 64, ntts_backbone::kSksO); n.slab_rows = e->cfg.max_batch;
     n.resid_in = e->h_alt; n.resid_out = e->h_dec;
     a.pro = n;
-    gemv_launch<EPI_SILU_MUL, true>(a, 1, e->stream);
+    gemv_launch<EPI_SILU_MUL, true, 3>(a, 1, e->stream);   // 3 feature waves: 203 workgroups, every CU streams <= 86 KB of weights (gemv.h)
 }
 static void ks_down(ntts_backbone* e, int i) {
     gemv_launch<EPI_SPLITK, false>(gemv_args(e, e->act_dec, e->F, e->layers[i].wd, e->F, e->slabs2, e->H, e->H, e->F), ntts_backbone::kSksD, e->stream);
@@ -1654,6 +1656,31 @@ extern "C" int ntts_backbone_attn_timeline(ntts_backbone* e, int32_t layer, uint
     e->attn_tl = nullptr;
     HIPCHK(e, hipStreamSynchronize(e->stream));
     HIPCHK(e, hipMemcpy(out, tl, n * 8, hipMemcpyDeviceToHost));
+    return NTTS_OK;
+}
+
+// Phase timestamps of one small-batch GEMV launch at the current slot state (tools/gemv_timeline.py): which = 2 o_proj, 3 gate/up,
+// 4 down_proj of `layer`; out[workgroup][16] (gemv.h GemvArgs::tl), *n_wg = workgroups of the launch.
+extern "C" int ntts_backbone_gemv_timeline(ntts_backbone* e, int32_t which, int32_t layer, uint64_t* out, int64_t cap, int32_t* n_wg) {
+    if (!e || !out || !n_wg || layer < 0 || layer >= e->cfg.num_layers || which < 2 || which > 4) return fail(e, NTTS_EINVAL, "bad argument");
+    if (!e->small) return fail(e, NTTS_ESTATE, "the engine is not on the small-batch path");
+    const size_t n = 4096 * 16;
+    if (cap < (int64_t)n) return fail(e, NTTS_EINVAL, "timeline needs %zu entries", n);
+    HIPCHK(e, hipSetDevice(e->device));
+    DevScratch buf;
+    HIPCHK(e, hipMalloc(&buf.p, n * 8));
+    unsigned long long* tl = (unsigned long long*)buf.p;
+    HIPCHK(e, hipMemsetAsync(tl, 0, n * 8, e->stream));
+    auto run = [&](int i) { if (which == 2) ks_o_proj(e, i); else if (which == 3) ks_gate_up(e, i); else ks_down(e, i); };
+    run((layer + 1) % e->cfg.num_layers);      // another layer first: this launch is neither the first nor cache-warm
+    e->gemv_tl = tl;
+    run(layer);
+    e->gemv_tl = nullptr;
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(out, tl, n * 8, hipMemcpyDeviceToHost));
+    int wg = 0;
+    for (size_t i = 0; i < 4096; ++i) if (out[i * 16] || out[i * 16 + 8]) wg = (int)i + 1;
+    *n_wg = wg;
     return NTTS_OK;
 }
 

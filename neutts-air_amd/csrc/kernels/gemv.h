@@ -60,15 +60,18 @@ struct GemvArgs {
     long ld_logits;
     bf16_t* logits_bf16;
     long ld_logits_bf16;
+    unsigned long long* tl;   // diagnostics (ntts_backbone_gemv_timeline): [workgroups][16] phase timestamps -- slots 0..7 feature wave 0,
+                              // 8..15 helper wave 0; null in the product path.  With it set the feature wave also WAITS for its whole weight
+                              // slice before the barrier (so that "weights landed" has a timestamp), which the product path never does
 };
 
 // KT = k-tiles of the workgroup's K slice this instantiation is unrolled for (the slice may be shorter: the surplus loads
 // re-read the last tile and their fragments are masked to zero -- NO per-element branches: a load guarded by a run-time
 // condition makes hipcc wait for each element before it requests the next, cdna_hip_programming.md "three .s-level traps" (c),
 // which is what a first version of this kernel did: 66 s_waitcnt in 770 instructions, slower than the LDS-DMA tiles).
-// FW = feature waves per workgroup, + 4 helper waves.  FW = 2 for gate/up (304 workgroups of 32 features instead of 152 of
-// 64, so that every CU has a weight stream) was measured and is NOT used: 16.1 vs 10.7 us at batch 1 -- twice the
-// prologues, each on its workgroup's critical path (profiles/r02f_sweep_b1_nw16_late_fw2.log).
+// FW = feature waves per workgroup, + 4 helper waves.  gate/up takes FW = 3 (203 workgroups of 48 features instead of 152 of 64: 86 instead
+// of 114 KB of weights per CU; 10.8 -> 10.0 us at batch 1, round 3); FW = 2 (304 workgroups -- more than CUs, two rounds) costs 16.1-16.4 us
+// (profiles/r02f_sweep_b1_nw16_late_fw2.log, r03g_sweep_b1_gemv_prologue.log).
 template <int EPI, bool PRO, int KT, int FW = 4>
 NTTS_KERNEL((FW + 4) * 64) void gemv_kernel(GemvArgs p) {
     NTTS_SHARED bf16_t xs[kGemvRows * kGemvXld];
@@ -80,12 +83,15 @@ NTTS_KERNEL((FW + 4) * 64) void gemv_kernel(GemvArgs p) {
     if (nk > p.k_tiles_per_split) nk = p.k_tiles_per_split;       // <= KT (launcher)
     const int col0 = PRO ? 0 : kt0 * 64;                          // K index held by panel column 0 (PRO: the panel is the whole row)
 
+    const long tlb = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 16;
+    auto mark = [&](int slot) { if (p.tl && lane == 0) p.tl[tlb + slot] = now_ticks(); };
     if (w >= FW) {
         // ---- helper waves: the X panel.  Row m is built by helper (m & 3); rows >= M are left alone.
         const int hw = w - FW;
+        if (hw == 0) mark(8);
         if constexpr (PRO) {
             const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
-            for (int m = hw; m < p.M; m += 4) rmsnorm_row_wave<2, 16>(p.pro, m, true, writer, xs + m * kGemvXld);
+            for (int m = hw; m < p.M; m += 4) rmsnorm_row_wave<2, 8, true>(p.pro, m, true, writer, xs + m * kGemvXld);
         } else {
             const int nch = nk * 8;                               // 16-byte chunks per row of the slice: <= 128 = 2 per lane
             for (int m = hw; m < p.M; m += 4) {
@@ -115,11 +121,14 @@ NTTS_KERNEL((FW + 4) * 64) void gemv_kernel(GemvArgs p) {
                 if (c1 < nch) *(bf16x8*)(xs + m * kGemvXld + c1 * 8) = t1;
             }
         }
+        if (hw == 0) mark(9);
         sync();
+        if (hw == 0) mark(10);
         return;
     }
 
     // ---- feature waves: request the whole weight slice (branch-free), then wait for the panel
+    if (w == 0) mark(0);
     const int f0r = (blockIdx.x * FW + w) * 16;
     const bool active = f0r < p.N;                                // wave-uniform
     const int f0 = active ? f0r : 0;                              // an inactive wave streams (and discards) group 0: no branch around the loads
@@ -134,19 +143,41 @@ NTTS_KERNEL((FW + 4) * 64) void gemv_kernel(GemvArgs p) {
         wa[j][0] = ld16<bf16x8>(src);
         wa[j][1] = ld16<bf16x8>(src + 8);
     }
+    if (w == 0) mark(1);
+    if (p.tl) { wait_vmem(); if (w == 0) mark(2); }
     sync();                                                       // the panel is complete
+    if (w == 0) mark(3);
     if (!active) return;
 
+    // One accumulator chain (the fp32 order of the K sum is part of the result), so the chain's length is what this loop costs:
+    // the X fragments are read from LDS kXPf k-tiles AHEAD of the matrix-core instructions that use them -- left to itself hipcc
+    // issues each tile's two ds_reads only after the previous tile's MFMAs (no registers to spare for hoisting them next to 128
+    // VGPRs of weights): 16 x (LDS latency + 2 MFMAs) = 1.57 us at K = 896 (tools/gemv_timeline.py), with the ring the MFMAs alone
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const bf16_t* xrow = xs + l15 * kGemvXld + g * 16 - col0;
+    // (not for the lm_head: 13.6 k workgroups stream 390 MB and what matters there is how fast a CU turns workgroups over -- with the
+    //  ring, 182 instead of 142 VGPRs and the pinned order, it went 70 -> 90 us; profiles/r03g_sweep_b1_gemv_prologue.log)
+    constexpr int kXPf = EPI == EPI_ARGMAX ? 1 : KT < 4 ? KT : 4;
+    bf16x8 xq[kXPf][2];
+    auto xload = [&](int j, bf16x8 (&d)[2]) {
+        const bf16_t* xp = xrow + (kt0 + (j < nk ? j : nk - 1)) * 64;
+        d[0] = ld16<bf16x8>(xp);
+        d[1] = ld16<bf16x8>(xp + 8);
+    };
+#pragma unroll
+    for (int j = 0; j < kXPf; ++j) xload(j, xq[j]);
+    if constexpr (kXPf > 1) sched_fence();
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
         const short keep = j < nk ? (short)-1 : (short)0;         // surplus tiles contribute 0 * x
-        const bf16_t* xp = xrow + (kt0 + (j < nk ? j : nk - 1)) * 64;
-        acc = mfma16(wa[j][0] & keep, ld16<bf16x8>(xp), acc);
-        acc = mfma16(wa[j][1] & keep, ld16<bf16x8>(xp + 8), acc);
+        const bf16x8 x0 = xq[j % kXPf][0], x1 = xq[j % kXPf][1];
+        if (j + kXPf < KT) xload(j + kXPf, xq[j % kXPf]);
+        if constexpr (kXPf > 1) sched_fence();                    // (hipcc sinks the reads back next to their MFMAs otherwise)
+        acc = mfma16(wa[j][0] & keep, x0, acc);
+        acc = mfma16(wa[j][1] & keep, x1, acc);
     }
 
+    if (p.tl && w == 0 && lane == 0) p.tl[tlb + 4] = now_ticks() + (acc[0] == 1.2345e30f ? 1 : 0);   // (after the matrix-core chain)
     // ---- epilogue: lane (g, l15) holds features f0 + g*4 + r (r = 0..3) of token row l15
     const int m = l15;
     const bool mok = m < p.M;
@@ -197,6 +228,7 @@ NTTS_KERNEL((FW + 4) * 64) void gemv_kernel(GemvArgs p) {
     } else {
         static_assert(EPI == EPI_SPLITK || EPI == EPI_SILU_MUL || EPI == EPI_ARGMAX, "epilogues of the small-batch kernel");
     }
+    if (p.tl) { wait_vmem(); if (w == 0) mark(5); }
 }
 
 
@@ -208,7 +240,7 @@ inline int gemv_ksplit(int K, int ksplit) {
     return ksplit < 1 ? 1 : ksplit;
 }
 
-template <int EPI, bool PRO>
+template <int EPI, bool PRO, int FW = 4>
 inline void gemv_launch(GemvArgs p, int ksplit, hipStream_t s) {
     const int ktiles = p.K / 64;
     ksplit = gemv_ksplit(p.K, ksplit);                            // (PRO: the panel is the whole normalised row, K = H <= 1024)
@@ -216,7 +248,7 @@ inline void gemv_launch(GemvArgs p, int ksplit, hipStream_t s) {
     const int nsplit = (ktiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
     if constexpr (EPI == EPI_ARGMAX) p.part_stride = p.N / 16;
     const int kps = p.k_tiles_per_split;
-    const dim3 grid((p.N + 63) / 64, nsplit), block(512);
+    const dim3 grid((p.N + 16 * FW - 1) / (16 * FW), nsplit), block((FW + 4) * 64);
     if constexpr (EPI == EPI_SPLITK) {                            // the split-K GEMVs come in every slice length
         if (kps <= 2) { NTTS_LAUNCH((gemv_kernel<EPI, PRO, 2>), grid, block, s, p); return; }
         if (kps <= 4) { NTTS_LAUNCH((gemv_kernel<EPI, PRO, 4>), grid, block, s, p); return; }
@@ -224,7 +256,7 @@ inline void gemv_launch(GemvArgs p, int ksplit, hipStream_t s) {
     }
     // (K = 896 is 14 k-tiles: a 14-tile instantiation without the two surplus requests per wave -- re-reads of the wave's last tile -- measured
     //  the same, 0.9658-0.9726 ms per step either way at batch 1: the surplus requests hit in the cache; not instantiated)
-    NTTS_LAUNCH((gemv_kernel<EPI, PRO, 16>), grid, block, s, p);
+    NTTS_LAUNCH((gemv_kernel<EPI, PRO, 16, FW>), grid, block, s, p);
 }
 
 // number of split-K slabs gemv_launch produces for (K, ksplit)

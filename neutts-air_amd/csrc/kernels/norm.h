@@ -51,7 +51,12 @@ struct NormArgs {
 // SG = slabs whose loads are in flight together (the additions always run in ascending slab order): 4 in the stand-alone
 // kernels (register budget of 4 rows per workgroup), 16 = all of them for gemv.h's helper waves, whose whole job is this
 // row and for whom every extra group is one more L2 round trip on the kernel's critical path.
-template <int NCH, int SG = 4>  // NCH = 16-byte chunks per lane: H <= 512*NCH
+// WIDE (gemv.h's helper waves, whose whole job is this row and for whom every memory round trip is on the kernel's critical path): the
+//   slab loads of ALL the lane's chunks are requested together, branch-free (clamped addresses; a slab past nslab re-reads the last one
+//   and is not added), SG slabs per group -- up to 8 slabs are ONE round trip.  The plain form walks chunk by chunk, and hipcc does not
+//   hoist chunk 1's requests above chunk 0's sums (they sit behind its guards): two dependent round trips of ~1.4 us each, measured
+//   with the phase timestamps of tools/gemv_timeline.py (profiles/r03g_gemv_timeline_*.txt).  Same additions in the same order.
+template <int NCH, int SG = 4, bool WIDE = false>  // NCH = 16-byte chunks per lane: H <= 512*NCH
 NTTS_D void rmsnorm_row_wave(const NormArgs& p, int r, bool rok, bool write_resid, bf16_t* dst) {
     const int lane = lane_id();
     const long ri = p.in_rows ? p.in_rows[r] : r;
@@ -68,6 +73,44 @@ NTTS_D void rmsnorm_row_wave(const NormArgs& p, int r, bool rok, bool write_resi
         if (p.resid_in) rin[i] = ld16<bf16x8>(p.resid_in + ri * p.H + cc);
         if (p.norm_w) wv[i] = ld16<bf16x8>(p.norm_w + cc);
     }
+    float ow[NCH][8];          // WIDE: the rounded slab sums of every chunk
+    if constexpr (WIDE) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ow[i][e] = 0.f;
+        if (p.slabs) {           // (wave-uniform)
+            for (int s0 = 0; s0 < p.nslab; s0 += SG) {
+                f32x4 a[NCH][SG], b[NCH][SG];
+#pragma unroll
+                for (int u = 0; u < SG; ++u) {
+                    const int su = s0 + u < p.nslab ? s0 + u : p.nslab - 1;
+#pragma unroll
+                    for (int i = 0; i < NCH; ++i) {
+                        const long cc = (lane + 64 * i < nchunk) ? (long)(lane + 64 * i) * 8 : 0;
+                        const float* sp = p.slabs + ((long)su * p.slab_rows + ri) * p.H + cc;
+                        a[i][u] = ld16<f32x4>(sp);
+                        b[i][u] = ld16<f32x4>(sp + 4);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SG; ++u) {
+                    const bool use = s0 + u < p.nslab;                  // ascending slab order, as in the plain form
+#pragma unroll
+                    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            ow[i][e] = use ? ow[i][e] + a[i][u][e] : ow[i][e];
+                            ow[i][4 + e] = use ? ow[i][4 + e] + b[i][u][e] : ow[i][4 + e];
+                        }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ow[i][e] = rbf(ow[i][e]);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int ci = lane + 64 * i;
@@ -77,7 +120,10 @@ NTTS_D void rmsnorm_row_wave(const NormArgs& p, int r, bool rok, bool write_resi
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = 0.f;
         if (ok) {
-            if (p.slabs) {
+            if (p.slabs && WIDE) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = ow[i][e];
+            } else if (p.slabs) {
                 // slabs summed in ascending order; loads issued four slabs at a time so they overlap
                 for (int s0 = 0; s0 < p.nslab; s0 += SG) {
                     f32x4 a[SG], b[SG];

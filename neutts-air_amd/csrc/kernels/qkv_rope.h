@@ -303,7 +303,7 @@ NTTS_KERNEL(512) void gemv_qkv_rope_kernel(GemvQkvArgs p) {
     const int lane = lane_id(), w = wave_id();
     const int g = lane >> 4, l15 = lane & 15;
     if (w >= 4) {            // helper waves: the normalised X panel (block 0 also writes the new residual stream)
-        for (int m = w - 4; m < p.M; m += 4) rmsnorm_row_wave<2, 16>(p.pro, m, true, blockIdx.x == 0, xs + m * kGemvXld);
+        for (int m = w - 4; m < p.M; m += 4) rmsnorm_row_wave<2, 8, true>(p.pro, m, true, blockIdx.x == 0, xs + m * kGemvXld);
         sync();
         sync();
         return;
@@ -341,14 +341,21 @@ NTTS_KERNEL(512) void gemv_qkv_rope_kernel(GemvQkvArgs p) {
     sync();                                                       // the panel is complete
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const bf16_t* xrow = xs + l15 * kGemvXld + g * 16;
+    bf16x8 xq[KT][2];                                             // the slice's X fragments, all read before the matrix-core chain (gemv.h)
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
-        const short keep = j < nk ? (short)-1 : (short)0;         // surplus tiles contribute 0 * x
         const int jj = j < nk ? j : (nk > 0 ? nk - 1 : 0);
         const int kt = kt0 + jj < ktiles ? kt0 + jj : ktiles - 1;
         const bf16_t* xp = xrow + kt * 64;
-        acc = mfma16(wa[j][0] & keep, ld16<bf16x8>(xp), acc);
-        acc = mfma16(wa[j][1] & keep, ld16<bf16x8>(xp + 8), acc);
+        xq[j][0] = ld16<bf16x8>(xp);
+        xq[j][1] = ld16<bf16x8>(xp + 8);
+    }
+    sched_fence();
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        const short keep = j < nk ? (short)-1 : (short)0;         // surplus tiles contribute 0 * x
+        acc = mfma16(wa[j][0] & keep, xq[j][0], acc);
+        acc = mfma16(wa[j][1] & keep, xq[j][1], acc);
     }
     red[w][lane] = acc;
     sync();

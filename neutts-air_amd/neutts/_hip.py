@@ -115,6 +115,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_backbone_last_timing": (C.c_int, [p, C.POINTER(f32), C.POINTER(f32)]),
         "ntts_backbone_step_bytes": (C.c_int, [p, C.POINTER(C.c_double)]),
         "ntts_backbone_attn_timeline": (C.c_int, [p, i32, C.POINTER(C.c_uint64), i64]),
+        "ntts_backbone_gemv_timeline": (C.c_int, [p, i32, i32, C.POINTER(C.c_uint64), i64, C.POINTER(i32)]),
         "ntts_codec_last_error": (C.c_char_p, [p]),
         "ntts_codec_create": (C.c_int, [C.POINTER(CodecConfigC), C.c_int, C.POINTER(p)]),
         "ntts_codec_destroy": (None, [p]),
@@ -456,6 +457,13 @@ class BackboneEngine:
         a, b = C.c_float(), C.c_float()
         self._chk(self.lib.ntts_backbone_last_timing(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def gemv_timeline(self, which: int, layer: int = 0) -> np.ndarray:
+        """[workgroups, 16] phase timestamps (100 MHz ticks) of one small-batch GEMV launch: which = 2 o_proj, 3 gate/up, 4 down_proj."""
+        out = np.zeros((4096, 16), dtype=np.uint64)
+        n = C.c_int32()
+        self._chk(self.lib.ntts_backbone_gemv_timeline(self.h, which, layer, out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size, C.byref(n)))
+        return out[: n.value]
 
     def attn_timeline(self, layer: int = 0) -> np.ndarray:
         """Phase timestamps of one decode-attention launch: [max_batch, kv_heads, 4 waves, 8 phases], 100 MHz ticks."""
