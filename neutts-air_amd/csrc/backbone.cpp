@@ -919,6 +919,7 @@ static void ks_qkv(ntts_backbone* e, int i) {
     a.pro = pro_qkv(e, i); a.W = e->layers[i].wqkv; a.bias = e->layers[i].bqkv; a.M = e->cfg.max_batch; a.N = e->NQKV; a.K = e->H;
     a.meta = e->step_meta; a.rope_rows = e->rope_rows; a.q_out = e->qkv_dec; a.ld_q = e->NQKV;
     a.kpool = e->kv + (size_t)i * e->layer_stride; a.nh = e->cfg.num_heads; a.nkv = e->cfg.num_kv_heads;
+    a.tl = e->gemv_tl;
     gemv_qkv_rope_launch(a, e->stream);
 }
 static void ks_attn(ntts_backbone* e, int i) {
@@ -1659,10 +1660,10 @@ extern "C" int ntts_backbone_attn_timeline(ntts_backbone* e, int32_t layer, uint
     return NTTS_OK;
 }
 
-// Phase timestamps of one small-batch GEMV launch at the current slot state (tools/gemv_timeline.py): which = 2 o_proj, 3 gate/up,
+// Phase timestamps of one small-batch GEMV launch at the current slot state (tools/gemv_timeline.py): which = 1 QKV (+ RoPE + K append), 2 o_proj, 3 gate/up,
 // 4 down_proj of `layer`; out[workgroup][16] (gemv.h GemvArgs::tl), *n_wg = workgroups of the launch.
 extern "C" int ntts_backbone_gemv_timeline(ntts_backbone* e, int32_t which, int32_t layer, uint64_t* out, int64_t cap, int32_t* n_wg) {
-    if (!e || !out || !n_wg || layer < 0 || layer >= e->cfg.num_layers || which < 2 || which > 4) return fail(e, NTTS_EINVAL, "bad argument");
+    if (!e || !out || !n_wg || layer < 0 || layer >= e->cfg.num_layers || which < 1 || which > 4) return fail(e, NTTS_EINVAL, "bad argument");
     if (!e->small) return fail(e, NTTS_ESTATE, "the engine is not on the small-batch path");
     const size_t n = 4096 * 16;
     if (cap < (int64_t)n) return fail(e, NTTS_EINVAL, "timeline needs %zu entries", n);
@@ -1671,7 +1672,8 @@ extern "C" int ntts_backbone_gemv_timeline(ntts_backbone* e, int32_t which, int3
     HIPCHK(e, hipMalloc(&buf.p, n * 8));
     unsigned long long* tl = (unsigned long long*)buf.p;
     HIPCHK(e, hipMemsetAsync(tl, 0, n * 8, e->stream));
-    auto run = [&](int i) { if (which == 2) ks_o_proj(e, i); else if (which == 3) ks_gate_up(e, i); else ks_down(e, i); };
+    auto run = [&](int i) { if (which == 1) ks_qkv(e, i); else if (which == 2) ks_o_proj(e, i); else if (which == 3) ks_gate_up(e, i); else ks_down(e, i); };
+    if (which == 1) k_step_meta(e);
     run((layer + 1) % e->cfg.num_layers);      // another layer first: this launch is neither the first nor cache-warm
     e->gemv_tl = tl;
     run(layer);

@@ -56,6 +56,9 @@ struct NormArgs {
 //   and is not added), SG slabs per group -- up to 8 slabs are ONE round trip.  The plain form walks chunk by chunk, and hipcc does not
 //   hoist chunk 1's requests above chunk 0's sums (they sit behind its guards): two dependent round trips of ~1.4 us each, measured
 //   with the phase timestamps of tools/gemv_timeline.py (profiles/r03g_gemv_timeline_*.txt).  Same additions in the same order.
+//   (Measured and not kept: the row's "slab sum + residual" by all four helper waves with fully coalesced one-load-per-slab accesses, an
+//   extra barrier, then this wave normalising from LDS -- batch 1 0.895 -> 0.890 ms, but batch 4 / 8 0.971 -> 1.011 / 1.143 -> 1.219: with
+//   several rows the helpers already work side by side, one row each; profiles/r03g_ab_two_stage_prologue.txt.)
 template <int NCH, int SG = 4, bool WIDE = false>  // NCH = 16-byte chunks per lane: H <= 512*NCH
 NTTS_D void rmsnorm_row_wave(const NormArgs& p, int r, bool rok, bool write_resid, bf16_t* dst) {
     const int lane = lane_id();

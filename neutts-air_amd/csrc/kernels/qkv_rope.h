@@ -294,6 +294,8 @@ struct GemvQkvArgs {
     long ld_q;
     bf16_t* kpool;
     int nh, nkv;
+    unsigned long long* tl;  // diagnostics (ntts_backbone_gemv_timeline, which = 1): [workgroups][16] phase timestamps as in gemv.h; slot 5 =
+                             // the K slices have met in LDS, slot 6 = wave 0's stores done
 };
 
 template <int KT>
@@ -302,12 +304,18 @@ NTTS_KERNEL(512) void gemv_qkv_rope_kernel(GemvQkvArgs p) {
     NTTS_SHARED f32x4 red[4][64];
     const int lane = lane_id(), w = wave_id();
     const int g = lane >> 4, l15 = lane & 15;
-    if (w >= 4) {            // helper waves: the normalised X panel (block 0 also writes the new residual stream)
-        for (int m = w - 4; m < p.M; m += 4) rmsnorm_row_wave<2, 8, true>(p.pro, m, true, blockIdx.x == 0, xs + m * kGemvXld);
+    const long tlb = (long)blockIdx.x * 16;
+    auto mark = [&](int slot) { if (p.tl && lane == 0) p.tl[tlb + slot] = now_ticks(); };
+    if (w >= 4) {            // helper waves: the normalised X panel (block 0 also writes the new residual stream); SG = 10: the ten
+        if (w == 4) mark(8);  // down_proj slabs are ONE round trip (with 8 + 2 the panel was ready 0.7 us later: profiles/r03g_gemv_timeline_b1.txt)
+        for (int m = w - 4; m < p.M; m += 4) rmsnorm_row_wave<2, 10, true>(p.pro, m, true, blockIdx.x == 0, xs + m * kGemvXld);
+        if (w == 4) mark(9);
         sync();
+        if (w == 4) mark(10);
         sync();
         return;
     }
+    if (w == 0) mark(0);
     const int hd = blockIdx.x >> 2, q = blockIdx.x & 3;
     const int m = l15, mc = m < p.M ? m : p.M - 1;
     // wave 0's epilogue operands first (tiny; a wave's loads return in order)
@@ -338,7 +346,10 @@ NTTS_KERNEL(512) void gemv_qkv_rope_kernel(GemvQkvArgs p) {
         wa[j][0] = ld16<bf16x8>(src);
         wa[j][1] = ld16<bf16x8>(src + 8);
     }
+    if (w == 0) mark(1);
+    if (p.tl) { wait_vmem(); if (w == 0) mark(2); }
     sync();                                                       // the panel is complete
+    if (w == 0) mark(3);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const bf16_t* xrow = xs + l15 * kGemvXld + g * 16;
     bf16x8 xq[KT][2];                                             // the slice's X fragments, all read before the matrix-core chain (gemv.h)
@@ -357,9 +368,11 @@ NTTS_KERNEL(512) void gemv_qkv_rope_kernel(GemvQkvArgs p) {
         acc = mfma16(wa[j][0] & keep, xq[j][0], acc);
         acc = mfma16(wa[j][1] & keep, xq[j][1], acc);
     }
+    if (p.tl && w == 0 && lane == 0) p.tl[tlb + 4] = now_ticks() + (acc[0] == 1.2345e30f ? 1 : 0);
     red[w][lane] = acc;
     sync();
     if (w != 0) return;
+    mark(5);
     // lane (g, m): rows g*4 + r of the 16 = features n0 + r of token m; slices added in order
     f32x4 sum = red[0][lane];
 #pragma unroll
@@ -390,6 +403,7 @@ NTTS_KERNEL(512) void gemv_qkv_rope_kernel(GemvQkvArgs p) {
     if (hd < p.nh || hd >= p.nh + p.nkv) { if (mok) dst = p.q_out + (long)m * p.ld_q + n0; }
     else if (mok && st == 1) dst = p.kpool + (((long)page * p.nkv + (hd - p.nh)) * kPage + slot) * 64 + (n0 & 63);
     if (dst) *(u32x2*)dst = *(u32x2*)&out[0];
+    if (p.tl) { wait_vmem(); mark(6); }
 }
 
 inline void gemv_qkv_rope_launch(GemvQkvArgs p, hipStream_t s) {

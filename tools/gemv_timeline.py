@@ -13,7 +13,7 @@ import torch  # noqa: E402
 from neutts import _hip  # noqa: E402
 import synthetic as br  # noqa: E402  (model geometry, seeded random weights / prompts: plain data)
 
-F = ["entry", "weights requested", "weights landed", "X panel complete", "MFMA chain done", "stores done"]
+F = ["entry", "weights requested", "weights landed", "X panel complete", "MFMA chain done", "stores done / K slices met", "(qkv) stores done"]
 H = ["helper entry", "panel written", "past the barrier"]
 
 
@@ -31,7 +31,7 @@ def main():
     eng.prefill([br.synthetic_prompt(cfg, i, S) for i in range(B)], list(range(B)), [samp] * B)
     eng.decode(125)
     eng.sync()
-    for which, name in [(3, "gate/up")] if os.environ.get("TL_ONLY_GU") else ((2, "o_proj"), (3, "gate/up"), (4, "down_proj")):
+    for which, name in [(3, "gate/up")] if os.environ.get("TL_ONLY_GU") else ((1, "qkv + rope"), (2, "o_proj"), (3, "gate/up"), (4, "down_proj")):
         for rep in range(2):
             t = eng.gemv_timeline(which, 3 + rep).astype(np.float64)
             t[t == 0] = np.nan
