@@ -225,7 +225,9 @@ int ntts_backbone_attn_timeline(ntts_backbone* e, int32_t layer, uint64_t* out, 
 /* Diagnostics (tools/gemv_timeline.py): phase timestamps (100 MHz ticks) of ONE small-batch GEMV launch at the current slot state --
  * which = 1 QKV (+ RoPE + K append; slot 5 = K slices met in LDS, slot 6 = stores done), 2 o_proj, 3 gate/up, 4 down_proj of `layer`.  out[workgroup][16]: slots 0..5 of a workgroup's first feature wave (entry,
  * weights requested, weights landed, X panel complete, matrix-core chain done, stores done), slots 8..10 of its first helper wave (entry,
- * panel written, past the barrier).  cap >= 4096 * 16; *n_wg = workgroups that reported.  Small-batch engines only (NTTS_ESTATE).
+ * panel written, past the barrier).  cap >= 4096 * 16; *n_wg = workgroups that reported.  On a large-batch engine the same call times the tile kernels
+ * (gemm.h / qkv_rope.h): slots 0..5 of wave 0 = entry, first ring slots requested, first tile landed, k-loop done, epilogue issued (qkv: K slices
+ * met in LDS), stores drained.
  * which = 1 rewrites the residual ping-pong buffer out of sequence: do not continue generating from this slot state. */
 int ntts_backbone_gemv_timeline(ntts_backbone* e, int32_t which, int32_t layer, uint64_t* out, int64_t cap, int32_t* n_wg);
 /* Algorithmic HBM bytes of one decode step at the current slot lengths (SURVEY.md 8d formula:

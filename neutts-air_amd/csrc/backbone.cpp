@@ -751,6 +751,7 @@ static GemmArgs gemm_args(const ntts_backbone* e, const bf16_t* X, long ldx, con
     a.w_tile_major = 1;   // every W this engine hands to a GEMM is in its weight layout
     a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K;
     a.wscale = wscale; a.xscale = xscale;
+    a.tl = e->gemv_tl;
     return a;
 }
 static int ktile_of(const ntts_backbone* e) { return e->fp8 ? 128 : 64; }
@@ -829,6 +830,7 @@ static void k_qkv(ntts_backbone* e, int i) {
     a.M = B; a.N = e->NQKV; a.K = H; a.meta = e->step_meta; a.rope_rows = e->rope_rows;
     a.q_out = e->qkv_dec; a.ld_q = e->NQKV; a.kpool = e->kv + (size_t)i * e->layer_stride;
     a.nh = e->cfg.num_heads; a.nkv = e->cfg.num_kv_heads;
+    a.tl = e->gemv_tl;
     const bool place = (e->xcd_affine & 4) && e->xcd_xps;
     if (e->fp8) qkv_rope_launch<true>(a, place, e->stream);
     else qkv_rope_launch<false>(a, place, e->stream);
@@ -1664,7 +1666,6 @@ extern "C" int ntts_backbone_attn_timeline(ntts_backbone* e, int32_t layer, uint
 // 4 down_proj of `layer`; out[workgroup][16] (gemv.h GemvArgs::tl), *n_wg = workgroups of the launch.
 extern "C" int ntts_backbone_gemv_timeline(ntts_backbone* e, int32_t which, int32_t layer, uint64_t* out, int64_t cap, int32_t* n_wg) {
     if (!e || !out || !n_wg || layer < 0 || layer >= e->cfg.num_layers || which < 1 || which > 4) return fail(e, NTTS_EINVAL, "bad argument");
-    if (!e->small) return fail(e, NTTS_ESTATE, "the engine is not on the small-batch path");
     const size_t n = 4096 * 16;
     if (cap < (int64_t)n) return fail(e, NTTS_EINVAL, "timeline needs %zu entries", n);
     HIPCHK(e, hipSetDevice(e->device));
@@ -1672,7 +1673,10 @@ extern "C" int ntts_backbone_gemv_timeline(ntts_backbone* e, int32_t which, int3
     HIPCHK(e, hipMalloc(&buf.p, n * 8));
     unsigned long long* tl = (unsigned long long*)buf.p;
     HIPCHK(e, hipMemsetAsync(tl, 0, n * 8, e->stream));
-    auto run = [&](int i) { if (which == 1) ks_qkv(e, i); else if (which == 2) ks_o_proj(e, i); else if (which == 3) ks_gate_up(e, i); else ks_down(e, i); };
+    auto run = [&](int i) {
+        if (e->small) { if (which == 1) ks_qkv(e, i); else if (which == 2) ks_o_proj(e, i); else if (which == 3) ks_gate_up(e, i); else ks_down(e, i); }
+        else { if (which == 1) k_qkv(e, i); else if (which == 2) k_o_proj(e, i); else if (which == 3) k_gate_up(e, i); else k_down(e, i); }
+    };
     if (which == 1) k_step_meta(e);
     run((layer + 1) % e->cfg.num_layers);      // another layer first: this launch is neither the first nor cache-warm
     e->gemv_tl = tl;

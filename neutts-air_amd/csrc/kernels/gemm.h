@@ -86,6 +86,8 @@ struct GemmArgs {
     // at every kernel boundary; xcd_maffine = number of K slices.  Every group then streams the whole W (fetched from HBM once, from the
     // memory-side cache by the other groups).  Speed only, like xcd_nsplit: block b on XCD b % 8 is an observation, not a contract.
     int xcd_maffine, xcd_xps;
+    unsigned long long* tl;   // diagnostics (ntts_backbone_gemv_timeline on a large-batch engine): [workgroups][16] timestamps of wave 0 -- 0 entry,
+                              // 1 first ring slots requested, 2 first tile landed (past the first barrier), 3 k-loop done, 4 epilogue issued, 5 stores drained
 };
 
 // position t of the grouped tile order (8 m-blocks x all n-blocks per group, m fastest) -> tile coordinates
@@ -451,6 +453,9 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     } else {
         gemm_tile_coords(blockIdx.x, p.mblocks, p.nblocks, mb, nb);
     }
+    const long tlb = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 16;
+    auto mark = [&](int slot) { if (p.tl && wave == 0 && lane == 0) p.tl[tlb + slot] = now_ticks(); };
+    mark(0);
     const int m0 = mb * BM, n0 = nb * BN;
     const int ktiles = F8 ? p.K >> 7 : p.K >> 6;               // 128-byte K tiles
     const int kt0 = split * p.k_tiles_per_split * SPT;        // in ring slots from here on
@@ -519,6 +524,7 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) stage(s, s);
+    mark(1);
     int buf = 0;                  // ring slot of tile kt
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt must have landed; tiles kt+1 .. kt+NS-2 may stay in flight (none are left to wait on
@@ -527,6 +533,7 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
             if (full_share) wait_vmem_le<(NS - 2) * PER_WAVE>(); else wait_vmem_le<(NS - 2) * (PER_WAVE - 1)>();
         } else wait_vmem();
         sync_keep_dma();  // tile kt landed for every wave; everyone is done reading the slot refilled below
+        if (kt == 0) mark(2);
         if (kt + NS - 1 < nk) stage(kt + NS - 1, buf == 0 ? NS - 1 : buf - 1);
         const bf16_t* base = lds + buf * (ROWS * BK);
         buf = buf + 1 == NS ? 0 : buf + 1;
@@ -557,8 +564,10 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     if constexpr (ABL & 4) {
         if (acc[0][0][0] != 12345.678f) return;   // keeps the accumulators live without storing
     }
+    if (p.tl && wave == 0 && lane == 0) p.tl[tlb + 3] = now_ticks() + (acc[0][0][0] == 1.2345e30f ? 1 : 0);   // (after the k-loop's last MFMA)
     if constexpr (TN == 4) gemm_epilogue<TM, EPI, WN, F8>(p, acc, m0 + wm * TM * 16, n0, wn, nb, split);
     else gemm_epilogue_nat<TM, TN, EPI, WN>(p, acc, m0 + wm * TM * 16, n0 + wn * CW, wn, nb);
+    if (p.tl) { mark(4); wait_vmem(); mark(5); }
 }
 
 

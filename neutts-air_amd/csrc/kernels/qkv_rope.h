@@ -62,6 +62,7 @@ struct QkvRopeArgs {
     long ld_q;
     bf16_t* kpool;           // this layer's K pages
     int nh, nkv;
+    unsigned long long* tl;  // diagnostics: [workgroups][16] timestamps of wave 0 (slots as gemm.h GemmArgs::tl; 3 = k-loop done, 4 = K slices met in LDS)
     int xcd_mpx;             // > 0: XCD x (workgroup b runs on XCD b % 8 -- an observation, speed only) takes the xcd_mpx 32-row blocks
                              // that hold batch rows [x * M / 8, (x + 1) * M / 8): the rows the attention workgroups of that XCD read
                              // (attn_decode.h xcd_rows) and whose o_proj tiles run there (gemm.h xcd_maffine)
@@ -99,6 +100,9 @@ NTTS_KERNEL(KS * 128) void qkv_rope_kernel(QkvRopeArgs p) {
         nb = blockIdx.x / mblocks;
     }
     if (nb >= nblocks) return;                            // (block-uniform, before any barrier)
+    const long tlb = (long)blockIdx.x * 16;
+    auto mark = [&](int slot) { if (p.tl && wave == 0 && lane == 0) p.tl[tlb + slot] = now_ticks(); };
+    mark(0);
     const int m0 = mb * BM, n0 = nb * BN;
     const int ktiles = F8 ? p.K >> 7 : p.K >> 6;
     int nk = ktiles - kh * p.kps;                         // this slice's k-tiles (the later slices may be shorter, even empty)
@@ -177,12 +181,14 @@ NTTS_KERNEL(KS * 128) void qkv_rope_kernel(QkvRopeArgs p) {
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) stage(s, s);
+    mark(1);
     int buf = 0;
     for (int kt = 0; kt < p.kps; ++kt) {                  // (every slice runs kps rounds of the barrier)
         if (kt < nk) {
             if (kt + NS - 2 < nk) wait_vmem_le<(NS - 2) * PER_WAVE>(); else wait_vmem();
         }
         sync_keep_dma();
+        if (kt == 0) mark(2);
         if (kt + NS - 1 < nk) stage(kt + NS - 1, buf == 0 ? NS - 1 : buf - 1);
         const bf16_t* base = lds + ((buf * KS + kh) * ROWS) * 64;
         buf = buf + 1 == NS ? 0 : buf + 1;
@@ -210,10 +216,12 @@ NTTS_KERNEL(KS * 128) void qkv_rope_kernel(QkvRopeArgs p) {
     // ---- the K slices meet in LDS (every wave parks its partial sums; the ring is free once everybody is past the k-loop), and
     //      every wave finishes its share: sums in slice order + bias -> ONE rounding (the nn.Linear output), then RoPE against the
     //      partner feature i +- 32, which sits in the same table at lane ^ 32 -- no shuffles
+    if (p.tl && wave == 0 && lane == 0) p.tl[tlb + 3] = now_ticks() + (acc[0][0] == 1.2345e30f ? 1 : 0);
     sync();
 #pragma unroll
     for (int j = 0; j < 4; ++j) xch[kh][wm][j][lane] = acc[j];
     sync();
+    mark(4);
     const int hd = n0 >> 6;                               // which head this workgroup's 64 columns are
     const int st = (int)meta[0], page = (int)meta[2], slot = (int)meta[3];
     const bool mok = m < p.M, run = mok && st == 1;
@@ -254,6 +262,7 @@ NTTS_KERNEL(KS * 128) void qkv_rope_kernel(QkvRopeArgs p) {
         if constexpr (NJ == 2) *(u32x4*)dst = *(u32x4*)&out[0];
         else *(u32x2*)dst = *(u32x2*)&out[0];
     }
+    if (p.tl) { wait_vmem(); mark(5); }
 }
 
 // 3 ring slots, 2 K slices per workgroup (MI355X, batch 256: 4 slices 6.56 vs 6.41 us, 2 slots 7.5, 4 / 6 slots 6.4-8.3:

@@ -15,6 +15,7 @@ import synthetic as br  # noqa: E402  (model geometry, seeded random weights / p
 
 F = ["entry", "weights requested", "weights landed", "X panel complete", "MFMA chain done", "stores done / K slices met", "(qkv) stores done"]
 H = ["helper entry", "panel written", "past the barrier"]
+T = ["entry", "first ring slots requested", "first tile landed", "k-loop done", "epilogue issued / K slices met", "stores drained"]   # tile kernels (batch > 8)
 
 
 def main():
@@ -28,7 +29,10 @@ def main():
                                    max_context=768, max_batch=B, max_prefill_tokens=64 * S), 0)
     eng.load_state_dict(wd, inv_freq=br.rope_inv_freq(cfg).numpy())
     samp = _hip.Sampling(max_length=S + 250, min_new_tokens=250, eos_token_id=cfg.vocab_size - 1, do_sample=False)
-    eng.prefill([br.synthetic_prompt(cfg, i, S) for i in range(B)], list(range(B)), [samp] * B)
+    prompts = [br.synthetic_prompt(cfg, i, S) for i in range(B)]
+    for c in range(0, B, 64):
+        n = min(64, B - c)
+        eng.prefill(prompts[c:c + n], list(range(c, c + n)), [samp] * n)
     eng.decode(125)
     eng.sync()
     for which, name in [(3, "gate/up")] if os.environ.get("TL_ONLY_GU") else ((1, "qkv + rope"), (2, "o_proj"), (3, "gate/up"), (4, "down_proj")):
@@ -38,7 +42,8 @@ def main():
             t0 = np.nanmin(t)
             rel = (t - t0) * 0.01                                  # us
             print(f"-- {name} launch {rep}: {len(t)} workgroups; us since the earliest wave entered the kernel (min / median / max)")
-            for k, nm in list(enumerate(F)) + [(8 + k, nm) for k, nm in enumerate(H)]:
+            names = list(enumerate(F)) + [(8 + k, nm) for k, nm in enumerate(H)] if B <= 8 else list(enumerate(T))
+            for k, nm in names:
                 x = rel[:, k]
                 print(f"   {nm:20s} {np.nanmin(x):7.2f} {np.nanmedian(x):7.2f} {np.nanmax(x):7.2f}")
         ms, nb, nl = eng.time_kernel(which, 48)
