@@ -91,7 +91,9 @@ NTTS_KERNEL((FW + 4) * 64) void gemv_kernel(GemvArgs p) {
         if (hw == 0) mark(8);
         if constexpr (PRO) {
             const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
-            for (int m = hw; m < p.M; m += 4) rmsnorm_row_wave<2, 8, true>(p.pro, m, true, writer, xs + m * kGemvXld);
+            bool first = true;                                    // the issue barrier (norm.h): once per wave, behind its first row's requests
+            for (int m = hw; m < p.M; m += 4) { rmsnorm_row_wave<2, 8, true>(p.pro, m, true, writer, xs + m * kGemvXld, first); first = false; }
+            if (first) sync_keep_dma();                           // (a helper without a row)
         } else {
             const int nch = nk * 8;                               // 16-byte chunks per row of the slice: <= 128 = 2 per lane
             for (int m = hw; m < p.M; m += 4) {
@@ -137,6 +139,7 @@ NTTS_KERNEL((FW + 4) * 64) void gemv_kernel(GemvArgs p) {
     if (p.w_tile_major) { wbase = p.W + (long)(f0 >> 6) * 64 * p.K + ((f0 & 63) + l15) * 64 + g * 16; wstep = 4096; }
     else wbase = p.W + (long)(f0 + l15) * p.ldw + g * 16;
     bf16x8 wa[KT][2];
+    if constexpr (PRO) sync_keep_dma();                           // the helpers' requests go first (norm.h issue_barrier)
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
         const bf16_t* src = wbase + (long)(kt0 + (j < nk ? j : nk - 1)) * wstep;

@@ -59,8 +59,12 @@ struct NormArgs {
 //   (Measured and not kept: the row's "slab sum + residual" by all four helper waves with fully coalesced one-load-per-slab accesses, an
 //   extra barrier, then this wave normalising from LDS -- batch 1 0.895 -> 0.890 ms, but batch 4 / 8 0.971 -> 1.011 / 1.143 -> 1.219: with
 //   several rows the helpers already work side by side, one row each; profiles/r03g_ab_two_stage_prologue.txt.)
+// issue_barrier (WIDE callers only): a workgroup barrier that does not wait for loads (sync_keep_dma) right after this row's requests are
+//   out.  The GEMV kernels hold their feature waves at the matching barrier, so that the prologue's 36 KB go through the CU's load path
+//   AHEAD of the 86-114 KB of weights instead of interleaved with them: a CU accepts HBM-cold requests at ~40 GB/s, in issue order, and
+//   the row used to land when the weights did (3.7 us; 1.9 with the head start -- tools/gemv_timeline.py, profiles/r03g_*).
 template <int NCH, int SG = 4, bool WIDE = false>  // NCH = 16-byte chunks per lane: H <= 512*NCH
-NTTS_D void rmsnorm_row_wave(const NormArgs& p, int r, bool rok, bool write_resid, bf16_t* dst) {
+NTTS_D void rmsnorm_row_wave(const NormArgs& p, int r, bool rok, bool write_resid, bf16_t* dst, bool issue_barrier = false) {
     const int lane = lane_id();
     const long ri = p.in_rows ? p.in_rows[r] : r;
     const long ro = p.out_rows ? p.out_rows[r] : r;
@@ -96,6 +100,7 @@ NTTS_D void rmsnorm_row_wave(const NormArgs& p, int r, bool rok, bool write_resi
                         b[i][u] = ld16<f32x4>(sp + 4);
                     }
                 }
+                if (issue_barrier && s0 == 0) sync_keep_dma();          // (wave-uniform) the first group's requests are out
 #pragma unroll
                 for (int u = 0; u < SG; ++u) {
                     const bool use = s0 + u < p.nslab;                  // ascending slab order, as in the plain form
@@ -112,7 +117,7 @@ NTTS_D void rmsnorm_row_wave(const NormArgs& p, int r, bool rok, bool write_resi
             for (int i = 0; i < NCH; ++i)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) ow[i][e] = rbf(ow[i][e]);
-        }
+        } else if (issue_barrier) sync_keep_dma();                      // (embedding-gather / bf16-input rows: their few requests follow)
     }
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {

@@ -317,7 +317,9 @@ NTTS_KERNEL(512) void gemv_qkv_rope_kernel(GemvQkvArgs p) {
     auto mark = [&](int slot) { if (p.tl && lane == 0) p.tl[tlb + slot] = now_ticks(); };
     if (w >= 4) {            // helper waves: the normalised X panel (block 0 also writes the new residual stream); SG = 10: the ten
         if (w == 4) mark(8);  // down_proj slabs are ONE round trip (with 8 + 2 the panel was ready 0.7 us later: profiles/r03g_gemv_timeline_b1.txt)
-        for (int m = w - 4; m < p.M; m += 4) rmsnorm_row_wave<2, 10, true>(p.pro, m, true, blockIdx.x == 0, xs + m * kGemvXld);
+        bool first = true;    // (the issue barrier of norm.h / gemv.h: the prologue's requests ahead of the weights)
+        for (int m = w - 4; m < p.M; m += 4) { rmsnorm_row_wave<2, 10, true>(p.pro, m, true, blockIdx.x == 0, xs + m * kGemvXld, first); first = false; }
+        if (first) sync_keep_dma();
         if (w == 4) mark(9);
         sync();
         if (w == 4) mark(10);
@@ -347,6 +349,7 @@ NTTS_KERNEL(512) void gemv_qkv_rope_kernel(GemvQkvArgs p) {
     const int frow = l15 < 8 ? q * 8 + l15 : 32 + q * 8 + (l15 - 8);
     const bf16_t* wbase = p.W + (long)hd * 64 * p.K + frow * 64 + g * 16;
     bf16x8 wa[KT][2];
+    sync_keep_dma();                                              // the helpers' requests go first
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
         const int jj = j < nk ? j : (nk > 0 ? nk - 1 : 0);

@@ -179,3 +179,37 @@ def test_warm_up_and_side_stream_prefill(emu_lib):
     eng.set_prefill_cu_mask(None)
     ex, tie = teacher_forced_compare(eng, 2, z["bf16_ids_0"][:N], z["bf16_topv_0"], z["bf16_topi_0"])
     assert ex + tie == N and ex >= N - 2
+
+
+def test_twin_engine_and_async_snapshots(emu_lib):
+    """BackboneEngine.twin(): a second engine filled by ONE device-to-device copy of the finalised arena (what bench.py's two-engine pipeline
+    runs on) generates the same ids as the engine it was cloned from; and the asynchronous snapshot calls (poll_begin / poll_end /
+    read_finished, ABI 5) report what the blocking poll / read report, refuse to be opened twice and refuse rows that were not finished."""
+    z, cfg, w = load_fixture("backbone_tiny")
+    S, N, mn, eos = int(z["s_len"]), 8, int(z["min_new"]), int(z["eos"])
+    eng = make_engine(cfg, w, emu_lib, max_batch=2)
+    tw = eng.twin()
+    samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
+    prompts = [br.synthetic_prompt(cfg, u, S) for u in (0, 1)]
+    got = []
+    for e in (eng, tw):
+        e.prefill(prompts, [0, 1], [samp] * 2)
+        e.decode(3)
+        e.poll_begin()
+        with pytest.raises(_hip.NeuTTSHipError):
+            e.poll_begin()                                   # one snapshot at a time
+        e.decode(N)                                          # enqueued behind the snapshot: must not show in it
+        st, nn = e.poll_end()
+        assert st.tolist() == [1, 1] and nn.tolist() == [4, 4]      # the prompt pass's token + 3 steps
+        with pytest.raises(_hip.NeuTTSHipError):
+            e.read_finished(0)                               # running in that snapshot
+        e.poll_begin()
+        st, nn = e.poll_end()
+        assert st.tolist() == [2, 2] and nn.tolist() == [N, N]
+        ids = [e.read_finished(s) for s in (0, 1)]
+        assert ids == [e.read(s)[0] for s in (0, 1)]
+        got.append(ids)
+        for s in (0, 1):
+            e.release(s)
+    assert got[0] == got[1]
+    assert got[0][0] == z["bf16_ids_0"][:N].tolist() or sum(a == b for a, b in zip(got[0][0], z["bf16_ids_0"][:N].tolist())) >= N - 2
