@@ -171,6 +171,9 @@ def main():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="static mode: ONE backbone engine, batches strictly one after the other (round-2 shape).  Default: two engines, "
                          "batch k + 1's prompt pass enqueued before batch k's decode graphs, so the GPU runs them side by side")
+    ap.add_argument("--pipe-head", type=int, default=100,
+                    help="pipelined static mode: decode steps of batch k enqueued BEFORE batch k + 1's prompt pass (0 = prompt pass first); "
+                         "the prompt pass then runs beside the later, longer-context steps (profiles/r03i_sweep_pipeline_schedule.txt)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-codec", action="store_true", help="backbone only (profiling aid; not the headline metric)")
@@ -451,7 +454,7 @@ def main():
 
     def one_step_pipelined(last=False):
         """One batch through the two-engine pipeline: prompts -> codec-token ids -> 24 kHz waveforms.  The launching thread enqueues
-        the NEXT batch's prompt pass on the other engine's stream before this batch's 249 decode graphs, and this batch's codec pass
+        the NEXT batch's prompt pass on the other engine's stream between this batch's decode graphs (after --pipe-head of the 249), and this batch's codec pass
         (codec engine's stream) before the next iteration: the GPU runs decode (latency-bound, ~a quarter of the HBM peak) beside
         the matrix-core-bound passes.  A timed region is self-contained: its first step runs its own prompt pass un-overlapped
         (nothing is ready), its last step starts no further batch -- K steps hold K prompt passes, K decode loops, K codec passes."""
@@ -462,12 +465,17 @@ def main():
         each = []
         if not pstate["ready"][i]:
             each += prefill_all(cur)                               # pipeline ramp
-        if not last:
-            each += prefill_all(other)                             # batch k + 1, asynchronous, the other engine's stream
-            pstate["ready"][1 - i] = True
+        nd = N - 1
+        head = min(max(a.pipe_head, 0), nd) if not last else nd
         ph["host_wall_prefill_each"] = each
         tw.append(time.time())
-        cur.decode(N - 1)
+        if head > 0:
+            cur.decode(head)                                       # batch k: a head start of `head` decode steps ...
+        if not last:
+            prefill_all(other)                                     # ... then batch k + 1's prompt pass (the other engine's stream) ...
+            pstate["ready"][1 - i] = True
+            if nd > head:
+                cur.decode(nd - head)                              # ... beside the rest of batch k's decode steps
         tw.append(time.time())
         wavs = None
         if codec is not None:
@@ -480,8 +488,7 @@ def main():
             pending["codec"], pending["lens"] = True, lens_bufs[i]
             assert wavs.shape == (B, ccfg.hop_length * N)
         tw.append(time.time())
-        for s_ in range(B):
-            cur.release(s_)
+        cur.release_many(list(range(B)))
         pstate["ready"][i] = False
         pstate["cur"] = 1 - i
         tw.append(time.time())
@@ -556,8 +563,7 @@ def main():
             ph["codec_call_wall"] = (time.time() - tc) * 1e3
             assert wavs.shape == (B, ccfg.hop_length * N)
         tw.append(time.time())
-        for s in range(B):
-            eng.release(s)
+        eng.release_many(list(range(B)))
         tw.append(time.time())
         ph["host_wall_prefill_calls"] = (tw[1] - tw[0]) * 1e3     # host time inside the (asynchronous) prefill calls
         ph["host_wall_decode_call"] = (tw[2] - tw[1]) * 1e3       # host time enqueueing the decode graphs

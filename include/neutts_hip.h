@@ -197,6 +197,9 @@ int ntts_backbone_stream(ntts_backbone* e, void** stream);
 int ntts_backbone_set_prefill_cu_mask(ntts_backbone* e, const uint32_t* mask, int32_t n_words);
 /* Return the slot's KV pages to the pool and mark it free. */
 int ntts_backbone_release(ntts_backbone* e, int32_t slot);
+/* ntts_backbone_release for `n` distinct slots with ONE stream operation (a server frees a whole batch at once); nothing is released if a
+ * slot is invalid or repeated. */
+int ntts_backbone_release_many(ntts_backbone* e, int32_t n, const int32_t* slots);
 int ntts_backbone_sync(ntts_backbone* e);
 
 /* Test / profiling taps (blocking).  Last-step fp32 logits are only materialised when

@@ -1554,18 +1554,48 @@ extern "C" int ntts_backbone_export_codes(ntts_backbone* e, int32_t n, const int
     return NTTS_OK;
 }
 
-extern "C" int ntts_backbone_release(ntts_backbone* e, int32_t slot) {
-    if (!e || slot < 0 || slot >= e->cfg.max_batch) return fail(e, NTTS_EINVAL, "bad slot");
-    HIPCHK(e, hipSetDevice(e->device));
-    // Stream-ordered, no host sync: the slot's pages go back to the pool now, but anything that re-uses them is
-    // enqueued on the same stream behind the work that still reads them.
+static int release_host(ntts_backbone* e, int32_t slot) {   // host half of a release: pages back to the pool, slot FREE
     HostSlot& s = e->slots[slot];
     drop_pages(e, s);
     s.prompt.clear();
     if (s.sampling) { s.sampling = false; e->n_sampling--; }
     s.state = SLOT_FREE;
+    return NTTS_OK;
+}
+
+extern "C" int ntts_backbone_release(ntts_backbone* e, int32_t slot) {
+    if (!e || slot < 0 || slot >= e->cfg.max_batch) return fail(e, NTTS_EINVAL, "bad slot");
+    HIPCHK(e, hipSetDevice(e->device));
+    // Stream-ordered, no host sync: the slot's pages go back to the pool now, but anything that re-uses them is
+    // enqueued on the same stream behind the work that still reads them.
+    release_host(e, slot);
     static_assert(SLOT_FREE == 0, "release writes the state with a memset");
     HIPCHK(e, hipMemsetAsync(e->sl.state + slot, 0, sizeof(int), e->stream));
+    return NTTS_OK;
+}
+
+// ntts_backbone_release for `n` slots at once: ONE stream operation instead of n (a batch server frees a whole batch -- 256 one-int
+// fills were 256 launches on the engine's stream between two batches).  Slots must be distinct and valid; nothing is released if one is not.
+extern "C" int ntts_backbone_release_many(ntts_backbone* e, int32_t n, const int32_t* slots) {
+    if (!e || n < 1 || !slots) return fail(e, NTTS_EINVAL, "bad argument");
+    if ((size_t)n > e->meta_cap) return fail(e, NTTS_EINVAL, "too many slots");
+    std::vector<char> seen(e->cfg.max_batch, 0);
+    int lo = e->cfg.max_batch, hi = -1;
+    for (int i = 0; i < n; ++i) {
+        const int s = slots[i];
+        if (s < 0 || s >= e->cfg.max_batch || seen[s]) return fail(e, NTTS_EINVAL, "bad or repeated slot %d", s);
+        seen[s] = 1;
+        if (s < lo) lo = s;
+        if (s > hi) hi = s;
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    for (int i = 0; i < n; ++i) release_host(e, slots[i]);
+    if (hi - lo + 1 == n) {                                   // a contiguous range (the usual case): one fill
+        HIPCHK(e, hipMemsetAsync(e->sl.state + lo, 0, (size_t)n * sizeof(int), e->stream));
+    } else {
+        HIPCHK(e, upload_meta(e, slots, (size_t)n, e->stream));
+        NTTS_LAUNCH((zero_slots_kernel), dim3((n + 63) / 64), dim3(64), e->stream, (const int*)e->meta_dev, n, e->sl.state);
+    }
     return NTTS_OK;
 }
 

@@ -271,6 +271,10 @@ NTTS_KERNEL(64) void prefill_init_kernel(PrefillInit p) {
         p.sl.cur_tok[s] = 0;
     }
 }
+NTTS_KERNEL(64) void zero_slots_kernel(const int* slots, int n, int* state) {   // ntts_backbone_release_many: state[slots[i]] = FREE
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < n) state[slots[i]] = 0;
+}
 NTTS_KERNEL(64) void bt_update_kernel(const int* trip, int n, int* block_table, int max_pages) {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i < n) block_table[(long)trip[3 * i] * max_pages + trip[3 * i + 1]] = trip[3 * i + 2];

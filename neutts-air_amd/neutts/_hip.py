@@ -102,6 +102,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_backbone_poll_end": (C.c_int, [p, C.POINTER(i32), C.POINTER(i32)]),
         "ntts_backbone_read_finished": (C.c_int, [p, i32, C.POINTER(i32), i32, C.POINTER(i32)]),
         "ntts_backbone_release": (C.c_int, [p, i32]),
+        "ntts_backbone_release_many": (C.c_int, [p, i32, C.POINTER(i32)]),
         "ntts_backbone_export_codes": (C.c_int, [p, i32, C.POINTER(i32), i32, i32, i32, p, i32, p]),
         "ntts_backbone_stream": (C.c_int, [p, C.POINTER(p)]),
         "ntts_codec_decode_dev": (C.c_int, [p, i32, p, i32, C.POINTER(i32), p, i64, i32, p]),
@@ -432,6 +433,14 @@ class BackboneEngine:
         self._chk(self.lib.ntts_backbone_release(self.h, slot))
         if slot not in self._free:
             self._free.append(slot)
+
+    def release_many(self, slots: Sequence[int]):
+        """release() for a whole set of slots with one stream operation."""
+        sl = np.ascontiguousarray(slots, dtype=np.int32)
+        self._chk(self.lib.ntts_backbone_release_many(self.h, len(sl), sl.ctypes.data_as(C.POINTER(C.c_int32))))
+        for s in sl.tolist():
+            if s not in self._free:
+                self._free.append(s)
 
     def _mark_busy(self, slots: Sequence[int]):
         """Callers that choose slot numbers themselves (tests, bench): keep the pool consistent."""

@@ -209,7 +209,10 @@ def test_twin_engine_and_async_snapshots(emu_lib):
         ids = [e.read_finished(s) for s in (0, 1)]
         assert ids == [e.read(s)[0] for s in (0, 1)]
         got.append(ids)
-        for s in (0, 1):
-            e.release(s)
+        with pytest.raises(_hip.NeuTTSHipError):
+            e.release_many([0, 0])                           # repeated slot: nothing is released
+        e.release_many([1, 0])                               # one stream operation for the whole set
+        st, _ = e.poll()
+        assert st.tolist() == [0, 0] and e.free_slots() == 2
     assert got[0] == got[1]
     assert got[0][0] == z["bf16_ids_0"][:N].tolist() or sum(a == b for a, b in zip(got[0][0], z["bf16_ids_0"][:N].tolist())) >= N - 2
