@@ -735,7 +735,7 @@ def main():
                              "further batch: K prompt passes, K decode loops, K codec passes, every waveform landed before the clock stops); "
                              "phase_ms is a separate serial pass" if pipe else
                              "warm_up() before timing, codec pass + D2H of batch k asynchronous under the prompt pass of batch k + 1 (static mode, one engine)"),
-            "pipeline": {"engines": len(engs), "overlap": "prefill(k+1) | decode(k) | codec(k-1)"} if pipe else None,
+            "pipeline": {"engines": len(engs), "overlap": "prefill(k+1) | decode(k) | codec(k-1)", "decode_head_start_steps": a.pipe_head} if pipe else None,
         }
         if strm:
             rec["stream"] = stream_stats

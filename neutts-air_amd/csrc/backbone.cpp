@@ -813,11 +813,14 @@ static void lm_head_and_sample(ntts_backbone* e, int phase) {
     NTTS_LAUNCH((sample_greedy_kernel), dim3(e->cfg.max_batch), dim3(256), e->stream, s);
 }
 
-static void k_step_meta(ntts_backbone* e) {   // once per decode step, before the first fused QKV kernel
+static StepMetaArgs step_meta_args(ntts_backbone* e) {
     StepMetaArgs m{};
     m.pos = e->sl.pos; m.state = e->sl.state; m.block_table = e->block_table; m.max_pages = e->max_pages; m.max_ctx = e->cfg.max_context;
     m.M = e->cfg.max_batch; m.rope_cos = e->rope_cos; m.rope_sin = e->rope_sin; m.meta = e->step_meta; m.rope_rows = e->rope_rows;
-    NTTS_LAUNCH((step_meta_kernel), dim3((e->cfg.max_batch + 3) / 4), dim3(256), e->stream, m);
+    return m;
+}
+static void k_step_meta(ntts_backbone* e) {   // once per decode step, before the first fused QKV kernel
+    NTTS_LAUNCH((step_meta_kernel), dim3((e->cfg.max_batch + 3) / 4), dim3(256), e->stream, step_meta_args(e));
 }
 
 // QKV projection + bias + rounding + RoPE + K append (qkv_rope.h); 3 ring slots, 2 K slices per workgroup (swept: 4 slices / 4 and
@@ -995,8 +998,12 @@ static void decode_step(ntts_backbone* e) {
     n0.gather_ids = e->sl.cur_tok; n0.embed = e->embed; n0.resid_out = e->h_dec; n0.norm_w = e->layers[0].ln1;
     n0.normed_out = e->xn_dec; n0.M = B; n0.H = H; n0.eps = c.rms_eps;
     if (e->fp8) n0.out_fp8_inv = 1.0f / e->layers[0].xs[0];
-    add_rmsnorm_launch(n0, e->stream, true);
-    k_step_meta(e);
+    if (H > 512 && H <= 1024) {   // (the geometry add_rmsnorm_launch gives one row per workgroup) the step record rides in the same launch
+        NTTS_LAUNCH((embed_norm_meta_kernel), dim3(B), dim3(128), e->stream, n0, step_meta_args(e));
+    } else {
+        add_rmsnorm_launch(n0, e->stream, true);
+        k_step_meta(e);
+    }
     for (int i = 0; i < c.num_layers; ++i) {
         const bool last = i + 1 == c.num_layers;
         k_qkv(e, i);

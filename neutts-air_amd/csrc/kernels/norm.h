@@ -213,7 +213,7 @@ NTTS_KERNEL(256) void add_rmsnorm_kernel(NormArgs p) {
 // 256 CUs instead of 64 and every CU pulls a quarter of the bytes through its load path.  Same arithmetic in the same
 // order as add_rmsnorm_kernel<2>: the sum of squares of lane l runs over chunk l and then chunk l + 64 element by element
 // (wave 1 hands its values to wave 0 through LDS), then the 64-lane butterfly.
-NTTS_KERNEL(128) void add_rmsnorm_row_kernel(NormArgs p) {
+NTTS_D void add_rmsnorm_row_body(const NormArgs& p) {   // the whole kernel: also the second half of qkv_rope.h embed_norm_meta_kernel
     NTTS_SHARED float hand[64][8];
     NTTS_SHARED float inv_s;
     const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
@@ -303,6 +303,8 @@ NTTS_KERNEL(128) void add_rmsnorm_row_kernel(NormArgs p) {
         }
     }
 }
+
+NTTS_KERNEL(128) void add_rmsnorm_row_kernel(NormArgs p) { add_rmsnorm_row_body(p); }
 
 // dst[r][:] = src[rows[r]][:]  (bf16, 16-byte chunks; cols % 8 == 0) -- prefill's last layer: only each prompt's last position
 // goes on to o_proj / the MLP / the lm_head, so its attention row and residual row are compacted first

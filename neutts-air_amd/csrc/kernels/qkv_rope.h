@@ -31,9 +31,7 @@ struct StepMetaArgs {
     int* meta;               // [M][4] = {state, pos, page of pos, slot of pos in its page}
     bf16_t* rope_rows;       // [M][64] = cos[pos][0..31] | sin[pos][0..31]
 };
-NTTS_KERNEL(256) void step_meta_kernel(StepMetaArgs p) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), i = threadIdx.x & 63;
-    if (row >= p.M) return;
+NTTS_D void step_meta_row(const StepMetaArgs& p, int row, int i) {   // one wave64 per batch row; i = lane
     int P = p.pos[row];
     if (P < 0) P = 0;
     if (P > p.max_ctx - 1) P = p.max_ctx - 1;      // (free slots hold stale positions: any valid row will do, nothing uses it)
@@ -45,6 +43,17 @@ NTTS_KERNEL(256) void step_meta_kernel(StepMetaArgs p) {
         m[2] = p.block_table[(long)row * p.max_pages + P / kPage];
         m[3] = P % kPage;
     }
+}
+NTTS_KERNEL(256) void step_meta_kernel(StepMetaArgs p) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), i = threadIdx.x & 63;
+    if (row >= p.M) return;
+    step_meta_row(p, row, i);
+}
+// The large-batch decode step's first launch: row b's step record (wave 0) next to its embedding gather + RMSNorm (norm.h, one row per
+// workgroup) -- two per-row jobs that both wait for the previous step's sample kernel, one launch instead of two (171 per step).
+NTTS_KERNEL(128) void embed_norm_meta_kernel(NormArgs p, StepMetaArgs m) {
+    if (threadIdx.x < 64 && (int)blockIdx.x < m.M) step_meta_row(m, (int)blockIdx.x, (int)threadIdx.x);
+    add_rmsnorm_row_body(p);
 }
 
 struct QkvRopeArgs {
