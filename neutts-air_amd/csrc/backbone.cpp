@@ -809,6 +809,7 @@ static void lm_head_and_sample(ntts_backbone* e, int phase) {
     k_lm_head(e, true);
     SampleArgs s{};
     s.part_val = e->part_val; s.part_idx = e->part_idx; s.n_part = e->n_part; s.sl = e->sl; s.phase = phase;
+    s.part_width = e->small ? 16 : e->head_tile == 4 ? 96 : 64;
     s.logits = e->n_sampling > 0 ? e->logits_bf16 : nullptr; s.ld_logits = e->ldl; s.vocab = e->cfg.vocab_size;
     NTTS_LAUNCH((sample_greedy_kernel), dim3(e->cfg.max_batch), dim3(256), e->stream, s);
 }

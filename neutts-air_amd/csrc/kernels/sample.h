@@ -40,6 +40,7 @@ struct SampleArgs {
     const float* part_val;   // [rows][n_part] per-row partial maxima from the lm_head epilogue
     const int* part_idx;
     int n_part;
+    int part_width;          // columns per partial (consecutive: partial i covers columns [i * part_width, (i + 1) * part_width)); 0 = unknown
     const bf16_t* logits;    // [rows][ld_logits] processed bf16 logits (EOS mask applied); null if no slot samples
     long ld_logits;
     int vocab;
@@ -64,82 +65,110 @@ NTTS_D void philox4x32(unsigned int (&c)[4], unsigned int k0, unsigned int k1) {
 NTTS_D unsigned int bf16_key(bf16_t v) { return (v & 0x8000u) ? (~(unsigned int)v & 0xFFFFu) : ((unsigned int)v | 0x8000u); }
 
 // top-k + multinomial for one row; all 256 threads of the block take part.  Returns the token in every thread.
+// The lm_head epilogue leaves one maximum per group of `gw` consecutive columns (pv[0 .. n_part-1]; SampleArgs::part_val).  The k-th
+// largest of those maxima, T, is a lower bound of the k-th largest logit (k groups hold an element >= T), and a group whose maximum is
+// below T holds no element >= T: only the groups with maximum >= T -- k of them plus ties, ~50 x 96 columns of the 217 488 -- are
+// scanned for the exact threshold and the survivors.  Same result as three sweeps over the whole row (the fallback when a row has more
+// than kGroupCap such groups, e.g. constant logits, or when there are fewer groups than k), 1/45 of the bytes and LDS atomics.
+constexpr int kGroupCap = 1024;
 NTTS_D int sample_topk_row(const bf16_t* row, int V, int k, float temperature, unsigned int s0, unsigned int s1,
-                           unsigned int step) {
+                           unsigned int step, const float* pv, int n_part, int gw) {
     NTTS_SHARED unsigned int hist[256];
-    NTTS_SHARED unsigned int sel[4];          // [0] high byte, [1] elements above that bin, [2] threshold key, [3] list length
+    NTTS_SHARED unsigned int sel[6];          // [0] high byte, [1] elements above that bin, [2] threshold key, [3] list length, [4] group threshold key, [5] groups kept
     NTTS_SHARED int cidx[kSampleCap];
     NTTS_SHARED unsigned short cval[kSampleCap];
     NTTS_SHARED int sidx[kSampleCap];
     NTTS_SHARED unsigned short sval[kSampleCap];
+    NTTS_SHARED int glist[kGroupCap];
     NTTS_SHARED int result;
     const int tid = threadIdx.x;
     if (k > V) k = V;
     if (k > kSampleCap) k = kSampleCap;
-    const int nvec = V >> 3;                  // 16-byte vectors; the scalar tail is handled by the first threads
-    // ---- pass 1: histogram of the key's high byte
-    hist[tid] = 0;
-    if (tid < 4) sel[tid] = 0;
-    sync();
-    for (int i = tid; i < nvec; i += 256) {
-        const bf16x8 v = ld16<bf16x8>(row + (long)i * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) atomic_add_lds(&hist[bf16_key((bf16_t)v[e]) >> 8], 1u);
-    }
-    for (int i = nvec * 8 + tid; i < V; i += 256) atomic_add_lds(&hist[bf16_key(row[i]) >> 8], 1u);
-    sync();
-    if (tid == 0) {
-        unsigned int above = 0;
-        int b = 255;
-        for (; b > 0; --b) {
-            if (above + hist[b] >= (unsigned int)k) break;
-            above += hist[b];
+    // the k-th largest of `count` keys (two histogram passes over 16-bit keys): key_at(i) = key of element i or 0x10000 to skip it;
+    // lo_bound: only keys >= lo_bound are counted.  Leaves the key in sel[out]
+    auto kth_key = [&](auto&& for_each_key, int out) {
+        hist[tid] = 0;
+        sync();
+        for_each_key([&](unsigned int key) { atomic_add_lds(&hist[key >> 8], 1u); });
+        sync();
+        if (tid == 0) {
+            unsigned int above = 0;
+            int b = 255;
+            for (; b > 0; --b) {
+                if (above + hist[b] >= (unsigned int)k) break;
+                above += hist[b];
+            }
+            sel[0] = (unsigned int)b;
+            sel[1] = above;
         }
-        sel[0] = (unsigned int)b;
-        sel[1] = above;
-    }
-    sync();
-    const unsigned int hb = sel[0], above = sel[1];
-    // ---- pass 2: histogram of the low byte inside that bin
-    hist[tid] = 0;
-    sync();
-    for (int i = tid; i < nvec; i += 256) {
-        const bf16x8 v = ld16<bf16x8>(row + (long)i * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const unsigned int key = bf16_key((bf16_t)v[e]);
-            if ((key >> 8) == hb) atomic_add_lds(&hist[key & 255u], 1u);
+        sync();
+        const unsigned int hb = sel[0], above = sel[1];
+        hist[tid] = 0;
+        sync();
+        for_each_key([&](unsigned int key) { if ((key >> 8) == hb) atomic_add_lds(&hist[key & 255u], 1u); });
+        sync();
+        if (tid == 0) {
+            unsigned int acc = above;
+            int b = 255;
+            for (; b > 0; --b) {
+                if (acc + hist[b] >= (unsigned int)k) break;
+                acc += hist[b];
+            }
+            sel[out] = (hb << 8) | (unsigned int)b;
         }
-    }
-    for (int i = nvec * 8 + tid; i < V; i += 256) {
-        const unsigned int key = bf16_key(row[i]);
-        if ((key >> 8) == hb) atomic_add_lds(&hist[key & 255u], 1u);
-    }
-    sync();
-    if (tid == 0) {
-        unsigned int acc = above;
-        int b = 255;
-        for (; b > 0; --b) {
-            if (acc + hist[b] >= (unsigned int)k) break;
-            acc += hist[b];
-        }
-        sel[2] = (hb << 8) | (unsigned int)b;   // key of the k-th largest logit
-    }
-    sync();
-    const unsigned int thr = sel[2];
-    // ---- pass 3: gather every logit >= the k-th largest (ties kept, like scores < kth -> -inf)
-    auto push = [&](int idx, bf16_t v) {
-        const unsigned int at = atomic_add_lds(&sel[3], 1u);
-        if (at < (unsigned int)kSampleCap) { cidx[at] = idx; cval[at] = v; }
+        sync();
     };
-    for (int i = tid; i < nvec; i += 256) {
-        const bf16x8 v = ld16<bf16x8>(row + (long)i * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            if (bf16_key((bf16_t)v[e]) >= thr) push(i * 8 + e, (bf16_t)v[e]);
+    if (tid < 6) sel[tid] = 0;
+    sync();
+    // ---- which column groups can hold one of the k largest logits
+    bool grouped = pv != nullptr && gw >= 8 && (gw & 7) == 0 && n_part >= k;
+    if (grouped) {
+        kth_key([&](auto&& f) { for (int i = tid; i < n_part; i += 256) f(bf16_key(f2bf(pv[i]))); }, 4);
+        const unsigned int gthr = sel[4];
+        for (int i = tid; i < n_part; i += 256)
+            if (bf16_key(f2bf(pv[i])) >= gthr) {
+                const unsigned int at = atomic_add_lds(&sel[5], 1u);
+                if (at < (unsigned int)kGroupCap) glist[at] = i;
+            }
+        sync();
+        if (sel[5] > (unsigned int)kGroupCap) grouped = false;      // (block-uniform)
     }
-    for (int i = nvec * 8 + tid; i < V; i += 256)
-        if (bf16_key(row[i]) >= thr) push(i, row[i]);
+    const int ng = grouped ? (int)sel[5] : 0;
+    const unsigned int floor_key = grouped ? sel[4] : 0u;            // elements below the group threshold cannot be among the k largest
+    const int vpg = gw >> 3;                                         // 16-byte vectors per group
+    const int nvec = V >> 3;                                         // full row: 16-byte vectors; the scalar tail is handled by the first threads
+    // every element (index, value) that can matter: the listed groups, or the whole row
+    auto for_each_elem = [&](auto&& f) {
+        if (grouped) {
+            for (int i = tid; i < ng * vpg; i += 256) {
+                const int c0 = glist[i / vpg] * gw + (i % vpg) * 8;
+                if (c0 + 8 <= V) {
+                    const bf16x8 v = ld16<bf16x8>(row + c0);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f(c0 + e, (bf16_t)v[e]);
+                } else {
+                    for (int e = 0; e < 8 && c0 + e < V; ++e) f(c0 + e, row[c0 + e]);
+                }
+            }
+        } else {
+            for (int i = tid; i < nvec; i += 256) {
+                const bf16x8 v = ld16<bf16x8>(row + (long)i * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f(i * 8 + e, (bf16_t)v[e]);
+            }
+            for (int i = nvec * 8 + tid; i < V; i += 256) f(i, row[i]);
+        }
+    };
+    // ---- the exact k-th largest logit (16-bit radix select: HF's logits ARE bf16 values)
+    kth_key([&](auto&& f) { for_each_elem([&](int, bf16_t v) { const unsigned int key = bf16_key(v); if (key >= floor_key) f(key); }); }, 2);
+    const unsigned int thr = sel[2];
+    // ---- gather every logit >= the k-th largest (ties kept, like scores < kth -> -inf)
+    for_each_elem([&](int idx, bf16_t v) {
+        if (bf16_key(v) >= thr) {
+            const unsigned int at = atomic_add_lds(&sel[3], 1u);
+            if (at < (unsigned int)kSampleCap) { cidx[at] = idx; cval[at] = v; }
+        }
+    });
     sync();
     int n = (int)sel[3];
     if (n > kSampleCap) n = kSampleCap;
@@ -215,7 +244,7 @@ NTTS_KERNEL(256) void sample_greedy_kernel(SampleArgs p) {
     if (k > 0) {
         const int step = (p.phase == SLOT_PREFILLED) ? 0 : p.sl.n_new[b];
         sampled = sample_topk_row(p.logits + (long)b * p.ld_logits, p.vocab, k, p.sl.temperature[b], p.sl.seed[2 * b],
-                                  p.sl.seed[2 * b + 1], (unsigned int)step);
+                                  p.sl.seed[2 * b + 1], (unsigned int)step, pv, p.n_part, p.part_width);
     }
     if (tid == 0) {
         for (int w = 1; w < 4; ++w)
