@@ -80,10 +80,32 @@ NTTS_D int sample_topk_row(const bf16_t* row, int V, int k, float temperature, u
     NTTS_SHARED int sidx[kSampleCap];
     NTTS_SHARED unsigned short sval[kSampleCap];
     NTTS_SHARED int glist[kGroupCap];
+    NTTS_SHARED unsigned int wsum[4];
+    NTTS_SHARED float ev[kSampleCap];
+    NTTS_SHARED float wmax[4];
     NTTS_SHARED int result;
     const int tid = threadIdx.x;
     if (k > V) k = V;
     if (k > kSampleCap) k = kSampleCap;
+    // Walking the 256 bins from the top, the bin at which the running count (starting from `base`) first reaches k, and the count above
+    // it -> sel[0], sel[1].  All threads call it; thread t owns bin t: suffix sums by wave shuffles instead of one thread's 256 dependent
+    // LDS reads (the two serial walks of a select were ~8 us of a 62 us kernel).  Bin 0 takes the row if no higher bin reaches k.
+    auto find_bin = [&](unsigned int base) {
+        const int lane = lane_id(), w = wave_id();
+        const unsigned int h = hist[tid];
+        int incl = (int)h;                                 // bins tid .. end of this wave's 64
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = shfl(incl, (lane + d) & 63);
+            if (lane + d < 64) incl += o;
+        }
+        if (lane == 0) wsum[w] = (unsigned int)incl;
+        sync();
+        unsigned int excl = base + (unsigned int)incl - h;  // count strictly above bin tid
+        for (int ww = w + 1; ww < 4; ++ww) excl += wsum[ww];
+        if (tid == 0 ? excl < (unsigned int)k : (excl < (unsigned int)k && excl + h >= (unsigned int)k)) { sel[0] = (unsigned int)tid; sel[1] = excl; }
+        sync();
+    };
     // the k-th largest of `count` keys (two histogram passes over 16-bit keys): key_at(i) = key of element i or 0x10000 to skip it;
     // lo_bound: only keys >= lo_bound are counted.  Leaves the key in sel[out]
     auto kth_key = [&](auto&& for_each_key, int out) {
@@ -91,31 +113,14 @@ NTTS_D int sample_topk_row(const bf16_t* row, int V, int k, float temperature, u
         sync();
         for_each_key([&](unsigned int key) { atomic_add_lds(&hist[key >> 8], 1u); });
         sync();
-        if (tid == 0) {
-            unsigned int above = 0;
-            int b = 255;
-            for (; b > 0; --b) {
-                if (above + hist[b] >= (unsigned int)k) break;
-                above += hist[b];
-            }
-            sel[0] = (unsigned int)b;
-            sel[1] = above;
-        }
-        sync();
+        find_bin(0u);
         const unsigned int hb = sel[0], above = sel[1];
         hist[tid] = 0;
         sync();
         for_each_key([&](unsigned int key) { if ((key >> 8) == hb) atomic_add_lds(&hist[key & 255u], 1u); });
         sync();
-        if (tid == 0) {
-            unsigned int acc = above;
-            int b = 255;
-            for (; b > 0; --b) {
-                if (acc + hist[b] >= (unsigned int)k) break;
-                acc += hist[b];
-            }
-            sel[out] = (hb << 8) | (unsigned int)b;
-        }
+        find_bin(above);
+        if (tid == 0) sel[out] = (hb << 8) | sel[0];
         sync();
     };
     if (tid < 6) sel[tid] = 0;
@@ -181,13 +186,21 @@ NTTS_D int sample_topk_row(const bf16_t* row, int V, int k, float temperature, u
         sval[rank] = cval[a];
     }
     sync();
-    // ---- softmax over the survivors + inverse-CDF draw (serial over <= 512 entries)
+    // ---- softmax over the survivors + inverse-CDF draw: maximum and exponentials in parallel, the two running sums by one thread in
+    //      token order (the draw depends on the order of those additions: kept)
+    float mx = -INFINITY;
+    for (int a = tid; a < n; a += 256) mx = fmaxf(mx, bf2f(sval[a]));
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) mx = fmaxf(mx, shfl_xor(mx, sh));
+    if (lane_id() == 0) wmax[wave_id()] = mx;
+    sync();
+    const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    const float it = 1.0f / temperature;
+    for (int a = tid; a < n; a += 256) ev[a] = fexp((bf2f(sval[a]) - m) * it);
+    sync();
     if (tid == 0) {
-        float m = -INFINITY;
-        for (int a = 0; a < n; ++a) m = fmaxf(m, bf2f(sval[a]));
-        const float it = 1.0f / temperature;
         float total = 0.f;
-        for (int a = 0; a < n; ++a) total += fexp((bf2f(sval[a]) - m) * it);
+        for (int a = 0; a < n; ++a) total += ev[a];
         unsigned int c[4] = {step, 0u, 0u, 0u};
         philox4x32(c, s0, s1);
         const float u = (float)(c[0] >> 8) * (1.0f / 16777216.0f);   // [0, 1)
@@ -195,7 +208,7 @@ NTTS_D int sample_topk_row(const bf16_t* row, int V, int k, float temperature, u
         float acc = 0.f;
         int pick = sidx[n - 1];
         for (int a = 0; a < n; ++a) {
-            acc += fexp((bf2f(sval[a]) - m) * it);
+            acc += ev[a];
             if (acc > target) { pick = sidx[a]; break; }
         }
         result = pick;
