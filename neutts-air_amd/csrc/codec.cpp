@@ -130,7 +130,7 @@ extern "C" int ntts_codec_create(const ntts_codec_config* cf, int device, ntts_c
     A(dalloc(c, &c->spec, R * c->lds_spec)); A(dalloc(c, &c->s3, R * c->K3)); A(dalloc(c, &c->frames, R * c->n_fft));
     c->wav_cap = R * cf->hop_length;
     A(dalloc(c, &c->wav, c->wav_cap));
-    c->meta_cap = R + 2 * max_utts + 64;
+    c->meta_cap = R + 3 * max_utts + 64;
     A(dalloc(c, &c->meta, c->meta_cap));
     (void)npages_max;
     if (rc == NTTS_OK) {
@@ -370,15 +370,23 @@ static int codec_decode_impl(ntts_codec* c, int32_t n, const int32_t* codes, con
     if (codes_dev && codes_stride < Tmax) return cfail(c, NTTS_EINVAL, "codes_stride %d < longest utterance %d", codes_stride, Tmax);
     if (wav_stride < (int64_t)hop * Tmax) return cfail(c, NTTS_EINVAL, "wav_stride %ld < %d samples", (long)wav_stride, hop * Tmax);
     const int Tp = Tmax + 2 * kPadRows;
-    const long rows = (long)n * Tp;
+    const long rows = total + 2L * kPadRows * n;          // packed: every utterance brings its own frames + pad rows (codec.h)
     if (rows > c->max_rows) return cfail(c, NTTS_EINVAL, "%ld rows exceed max_rows %ld: decode fewer utterances per call", rows, c->max_rows);
     const int npages = (Tmax + kPage - 1) / kPage, qtiles = (Tmax + 63) / 64;
-    // ---- meta: [lens n][code_off n][codes total]
+    // the waveform staging buffer holds n rows of the LONGEST utterance's samples (workspace rows x hop samples in all)
+    if ((long)n * Tmax > c->max_rows) return cfail(c, NTTS_EINVAL, "%d utterances x %d frames exceed max_rows %ld: decode fewer utterances per call", n, Tmax, c->max_rows);
+    // the V^T pages of the paged attention path are laid out per utterance x the LONGEST utterance's pages (not packed)
+    if (!(c->attn_resident && npages <= kAttnResPages) && (long)n * npages * kPage > c->max_rows + (c->max_rows / (1 + 2 * kPadRows) + 1) * kPage)
+        return cfail(c, NTTS_EINVAL, "%d utterances x %d pages exceed the V^T workspace: decode fewer utterances per call", n, npages);
+    // ---- meta: [lens n][code_off n][row_off n + 1][codes total]
     std::vector<int> m;
-    m.reserve(2 * n + (codes ? total : 0));
+    m.reserve(3 * n + 1 + (codes ? total : 0));
     m.insert(m.end(), lens, lens + n);
     long off = 0;
     for (int i = 0; i < n; ++i) { m.push_back(codes ? (int)off : i * codes_stride); off += lens[i]; }
+    long roff = 0;
+    for (int i = 0; i < n; ++i) { m.push_back((int)roff); roff += lens[i] + 2 * kPadRows; }
+    m.push_back((int)roff);
     if (codes) m.insert(m.end(), codes, codes + total);
     if (m.size() > c->meta_cap) return cfail(c, NTTS_EINVAL, "meta block too large");
     hipStream_t st = c->stream;
@@ -388,11 +396,11 @@ static int codec_decode_impl(ntts_codec* c, int32_t n, const int32_t* codes, con
         CHIP(c, hipEventRecord(c->ev_in, producer));
         CHIP(c, hipStreamWaitEvent(st, c->ev_in, 0));
     }
-    CodecRows R{c->meta, n, Tp};
+    CodecRows R{c->meta, c->meta + 2 * n, n, Tp, rows};
     CHIP(c, hipEventRecord(c->ev[0], st));
 
     CodecEmbedArgs ea{};
-    ea.codes = codes ? c->meta + 2 * n : codes_dev; ea.code_off = c->meta + n; ea.wf = c->wf; ea.bf = c->bf; ea.out = c->xa; ea.R = R; ea.H = H; ea.nq = c->nq;
+    ea.codes = codes ? c->meta + 3 * n + 1 : codes_dev; ea.code_off = c->meta + n; ea.wf = c->wf; ea.bf = c->bf; ea.out = c->xa; ea.R = R; ea.H = H; ea.nq = c->nq;
     for (int i = 0; i < 8; ++i) ea.levels[i] = i < c->nq ? c->cfg.levels[i] : 1;
     NTTS_LAUNCH((codec_embed_kernel), dim3((unsigned)((rows + kEmbedRows - 1) / kEmbedRows)), dim3(256), st, ea);
     // stem Conv1d(k=7, padding 3): window rows r..r+6 -> centre row r+3

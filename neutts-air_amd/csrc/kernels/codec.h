@@ -5,9 +5,11 @@
 // (as GEMMs over overlapping rows, gemm.h), GroupNorm(32)+SiLU (:650-659), RMSNorm / LayerNorm (:320-325,
 // :862), full (non-causal) attention (:268-308), ISTFT head (:762-796).
 //
-// Row layout ("padded flat rows"): utterance b owns rows [b*Tp, (b+1)*Tp), Tp = Tmax + 2*kPadRows; frame t sits
-// at row b*Tp + kPadRows + t.  Pad rows of every bf16 GEMM-input buffer are ZERO, which is exactly Conv1d's
-// zero padding, so a k-tap convolution is one GEMM with lda = C and K = k*C over overlapping rows.
+// Row layout ("packed padded rows"): utterance b owns rows [off[b], off[b+1]) = its lens[b] frames between kPadRows pad rows on
+// either side; frame t sits at row off[b] + kPadRows + t.  A ragged batch therefore costs its OWN frames, not B x the longest
+// utterance (150-350-frame batches: 1.4x fewer GEMM rows); equal lengths give the layout b * (T + 2 kPadRows) of the earlier rounds.
+// Pad rows of every bf16 GEMM-input buffer are ZERO, which is exactly Conv1d's zero padding (6 zero rows between two utterances),
+// so a k-tap convolution is one GEMM with lda = C and K = k*C over overlapping rows.
 // The residual stream is fp32 (the reference codec runs in fp32); only GEMM operands are bf16.
 #pragma once
 #include <ntts/dev.h>
@@ -19,12 +21,20 @@ constexpr int kPadRows = 3;  // covers the k=7 stem (padding 3) and the k=3 ResN
 
 struct CodecRows {
     const int* lens;   // [B] valid frames of each utterance
-    int B, Tp;         // rows = B * Tp
+    const int* off;    // [B + 1] first row of utterance b (its leading pad rows); off[B] = rows
+    int B, Tp;         // Tp = longest utterance + 2 * kPadRows (grid sizing only)
+    long rows;         // off[B]
 };
+NTTS_D long codec_row0(const CodecRows& R, int b) { return (long)R.off[b] + kPadRows; }   // row of frame 0 of utterance b
 
-NTTS_D bool codec_row(const CodecRows& R, long r, int& b, int& t) {
-    b = (int)(r / R.Tp);
-    t = (int)(r % R.Tp) - kPadRows;
+NTTS_D bool codec_row(const CodecRows& R, long r, int& b, int& t) {   // which (utterance, frame) is row r: binary search in off[]
+    int lo = 0, hi = R.B - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((long)R.off[mid] <= r) lo = mid; else hi = mid - 1;
+    }
+    b = lo;
+    t = (int)(r - R.off[lo]) - kPadRows;
     return t >= 0 && t < R.lens[b];
 }
 
@@ -45,7 +55,7 @@ struct CodecEmbedArgs {
 constexpr int kEmbedRows = 16, kEmbedChMax = 8;   // channels per thread held in registers: H <= 2048
 NTTS_KERNEL(256) void codec_embed_kernel(CodecEmbedArgs p) {
     const long r0 = (long)blockIdx.x * kEmbedRows;
-    const long rows = (long)p.R.B * p.R.Tp;
+    const long rows = p.R.rows;
     float wreg[kEmbedChMax][8], breg[kEmbedChMax];
 #pragma unroll
     for (int j = 0; j < kEmbedChMax; ++j) {
@@ -107,7 +117,7 @@ NTTS_KERNEL(256) void groupnorm_silu_kernel(GroupNormArgs p) {
     const int cg = p.C / 32, nrl = 256 / cg;
     const int ch = grp * cg + tid % cg, rl = tid / cg;
     const int T = p.R.lens[b];
-    const long row0 = (long)b * p.R.Tp + kPadRows;
+    const long row0 = codec_row0(p.R, b);
     float s = 0.f, ss = 0.f;
     for (int t = rl; t < T; t += nrl) {
         const float v = p.x[(row0 + t) * p.C + ch];
@@ -126,7 +136,7 @@ NTTS_KERNEL(256) void groupnorm_silu_kernel(GroupNormArgs p) {
     if (var < 0.f) var = 0.f;
     const float rstd = frsqrt_exact(var + p.eps);
     const float ga = p.gamma[ch], be = p.beta[ch];
-    for (int t = rl - kPadRows; t < p.R.Tp - kPadRows; t += nrl) {   // all Tp rows of the utterance
+    for (int t = rl - kPadRows; t < T + kPadRows; t += nrl) {   // all rows of the utterance, pads included
         float o = 0.f;
         if (t >= 0 && t < T) {
             const float v = (p.x[(row0 + t) * p.C + ch] - mean) * rstd * ga + be;
@@ -148,7 +158,7 @@ NTTS_KERNEL(256) void groupnorm_silu_reg_kernel(GroupNormArgs p) {
     const int cg = p.C / 32, vl = cg >> 2, nrl = 256 / vl;
     const int ch = grp * cg + (tid % vl) * 4, rl = tid / vl;
     const int T = p.R.lens[b];
-    const long row0 = (long)b * p.R.Tp + kPadRows;
+    const long row0 = codec_row0(p.R, b);
     f32x4 v[kGnRegIters];
     float s = 0.f, ss = 0.f;
 #pragma unroll
@@ -188,9 +198,9 @@ NTTS_KERNEL(256) void groupnorm_silu_reg_kernel(GroupNormArgs p) {
             *(bf16x4*)(p.y + (row0 + t) * p.C + ch) = o;
         }
     }
-    // pad rows of the utterance (and frames past T): zero, as the Conv1d padding wants them
+    // pad rows of the utterance: zero, as the Conv1d padding wants them
     const bf16x4 z = {0, 0, 0, 0};
-    for (int t = rl - kPadRows; t < p.R.Tp - kPadRows; t += nrl)
+    for (int t = rl - kPadRows; t < T + kPadRows; t += nrl)
         if (t < 0 || t >= T) *(bf16x4*)(p.y + (row0 + t) * p.C + ch) = z;
 }
 inline void groupnorm_silu_launch(const GroupNormArgs& p, int Tmax, hipStream_t s) {
@@ -273,7 +283,7 @@ NTTS_KERNEL(256) void v_transpose_kernel(VTransposeArgs p) {
     NTTS_SHARED bf16_t tile[kPage][64 + 2];
     const int b = blockIdx.x / p.npages, pg = blockIdx.x % p.npages, h = blockIdx.y, tid = threadIdx.x;
     const int T = p.R.lens[b];
-    const long row0 = (long)b * p.R.Tp + kPadRows + (long)pg * kPage;
+    const long row0 = codec_row0(p.R, b) + (long)pg * kPage;
     for (int x = tid; x < kPage * 64; x += 256) {
         const int tk = x >> 6, d = x & 63;
         const int t = pg * kPage + tk;
@@ -310,7 +320,7 @@ NTTS_KERNEL(256) void attn_full_kernel(AttnFullArgs p) {
     if (qt * 64 >= T) return;                                  // block-uniform
     const int qw0 = qt * 64 + w * 16;
     const bool wave_live = qw0 < T;
-    const long row0 = (long)b * p.R.Tp + kPadRows;
+    const long row0 = codec_row0(p.R, b);
     const long ld = 3L * p.C;
     int qi = qw0 + l15;
     if (qi > T - 1) qi = T - 1;
@@ -448,7 +458,7 @@ NTTS_KERNEL(512) void attn_full_resident_kernel(AttnFullArgs p) {
     const int b = blockIdx.x, h = blockIdx.y;
     const int T = p.R.lens[b];
     if (T < 1) return;                                         // block-uniform
-    const long row0 = (long)b * p.R.Tp + kPadRows;
+    const long row0 = codec_row0(p.R, b);
     const long ld = 3L * p.C;
     const int npg = (T + kPage - 1) / kPage;                  // <= kAttnResPages (launcher)
     // ---- K: LDS-DMA, all pages requested at once (frames past T re-read the last one; masked below)
@@ -611,7 +621,7 @@ NTTS_KERNEL(256) void ola_kernel(OlaArgs p) {
     if (s >= (long)p.hop * T) return;
     const int pad = (p.n_fft - p.hop) / 2;
     const long pos = s + pad;                       // index in the untrimmed overlap-add buffer
-    const long row0 = (long)b * p.R.Tp + kPadRows;
+    const long row0 = codec_row0(p.R, b);
     int f_hi = (int)(pos / p.hop);
     if (f_hi > T - 1) f_hi = T - 1;
     float acc = 0.f, env = 0.f;
