@@ -110,7 +110,7 @@ struct ntts_backbone {
     int xcd_affine = 0;        // row-block placement per XCD group (gemm.h xcd_maffine; NTTS_XCD_AFFINE): bit 0: o_proj + the norm behind it, bit 1: down_proj + the
                                // norm behind it, bit 2: QKV GEMM + attention.  Batch 256 (profiles/r02k_sweep_xcd_affine*.log): 7 -> step 1.630 -> 1.615 ms
     int xcd_xps = 0;           // XCDs per 64-row m-block of the decode batch (8 / (max_batch / 64)); 0 = the batch does not split that way
-    int xl_min_m = 1024;       // rows from which the big-M GEMMs take the 256-row tiles (tests lower it: NTTS_XL_MIN_M)
+    int xl_min_m = 0;          // > 0 (NTTS_XL_MIN_M, tests): rows from which the big-M GEMMs take the 256-row tiles; 0 = by tile count (gemm_large)
     // Split-K decode GEMMs below batch 129: XCD-aware slice placement of o_proj (gemm.h GemmArgs::xcd_nsplit): FETCH per skinny-GEMM launch
     // 15.0 -> 6.8 MB (profiles/r02f_*); above it the row-block placement (xcd_affine) takes over
     // Small-batch decode step (max_batch <= NTTS_SMALL_BATCH, default 8; BASELINE configs[1] = batch 1): wave-per-16-features
@@ -352,7 +352,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     const int max_slabs = 16;
     e->ks_o = std::min(max_slabs, pick_split(H / 64, c->num_heads * 64 / ktile));
     e->ks_d = std::min(max_slabs, pick_split(H / 64, F / ktile));
-    e->xl_min_m = env_int("NTTS_XL_MIN_M", 1024);
+    e->xl_min_m = env_int("NTTS_XL_MIN_M", 0);
     e->xcd_xps = (B == 64 || B == 128 || B == 256 || B == 512) ? 8 / (B / 64) : 0;
     e->xcd_affine = env_int("NTTS_XCD_AFFINE", B > 128 ? 7 : 0);
     e->head_tile = env_int("NTTS_HEAD_TILE", B > 128 ? (e->fp8 ? 2 : 4) : B > 64 ? 1 : 0);
@@ -766,7 +766,14 @@ static void gemm_skinny(const GemmArgs& a, int ks, hipStream_t st) {
 
 template <int EPI>
 static void gemm_large(ntts_backbone* e, const GemmArgs& a, hipStream_t st) {
-    const bool xl = a.M >= e->xl_min_m && a.N >= 256;    // 256 x 256 / 16 waves, else 128 x 128 / 4 waves
+    // Tile by how many tiles the GEMM has, per GEMM (a prompt pass of P x 500 rows; profiles/r03i_sweep_prefill_tiles.txt): 256 x 256 / 16 waves
+    // once that grid has >= 140 tiles (gate/up from ~1 000 rows, the N = 896 GEMMs from ~9 000), else 128 x 128 / 4 waves once THAT grid has
+    // >= 240, else the decode step's 64 x 64 skinny tile -- a 500-row pass is 28 tiles of 128 x 128 on 256 CUs, 112 of 64 x 64: one prompt
+    // 5.36 -> 3.72 ms, 4 prompts 6.12 -> 5.06, 16 prompts 9.99 -> 9.13; from 20 prompts on nothing changes.  Same k order per output element
+    // on every tile: same bits.  NTTS_XL_MIN_M > 0 (tests): the 256-row tiles from that many rows on, whatever the tile count.
+    const long tiles_xl = (long)((a.M + 255) / 256) * ((a.N + 255) / 256), tiles_l = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    const bool xl = a.N >= 256 && (e->xl_min_m > 0 ? a.M >= e->xl_min_m : tiles_xl >= 140);
+    if (!xl && tiles_l < 240 && e->xl_min_m == 0) { gemm_skinny<EPI, 4>(a, 1, st); return; }   // (bf16 and fp8 alike)
     if (e->fp8) {
         if (xl) gemm_launch<4, 4, 4, EPI, 2, 0, 64, false, true>(a, 1, st);
         else gemm_launch<2, 2, 4, EPI, 2, 0, 64, false, true>(a, 1, st);

@@ -631,7 +631,11 @@ inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
 //                 S = 64x64   (4x1 waves, 16x64 per wave)  -- decode-batch skinny GEMMs (+ split-K)
 #define NTTS_GEMM_XL(EPI, p, ks, s) ::ntts::gemm_launch<4, 4, 4, EPI, 2>(p, ks, s)
 // big-M dispatch used by the prefill and codec paths
-#define NTTS_GEMM_BIG(EPI, p, s) do { if ((p).M >= 1024 && (p).N >= 256) NTTS_GEMM_XL(EPI, p, 1, s); else NTTS_GEMM_L(EPI, p, 1, s); } while (0)
+// by how many tiles the GEMM has (the measurements behind the thresholds: backbone.cpp gemm_large): 256 x 256 from 140 of those tiles, else
+// 128 x 128 from 240 of THOSE, else the 64 x 64 skinny tile with its 4-slot ring (streaming codec passes, short batches: few rows)
+#define NTTS_GEMM_BIG(EPI, p, s) do { \
+    const long txl_ = (long)(((p).M + 255) / 256) * (((p).N + 255) / 256), tl_ = (long)(((p).M + 127) / 128) * (((p).N + 127) / 128); \
+    if ((p).N >= 256 && txl_ >= 140) NTTS_GEMM_XL(EPI, p, 1, s); else if (tl_ >= 240) NTTS_GEMM_L(EPI, p, 1, s); else NTTS_GEMM_S(EPI, p, 1, s); } while (0)
 #define NTTS_GEMM_L(EPI, p, ks, s) ::ntts::gemm_launch<2, 2, 4, EPI, 2>(p, ks, s)
 #define NTTS_GEMM_S(EPI, p, ks, s) ::ntts::gemm_launch<4, 1, 1, EPI, 4>(p, ks, s)
 
