@@ -661,19 +661,19 @@ def main():
         try:   # HBM bytes per launch from the committed PMC pass (tools/gpu_round.sh pmc -> tools/pmc_to_json.py): this configuration only
             if nano or B != 256 or S != 500:
                 raise OSError("no PMC pass for this configuration")
-            with open(os.path.join(ROOT, "profiles", "r03f_pmc_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r03i_pmc_traffic.json")) as fh:
                 pm = json.load(fh)
             for kname, rec in pm["kernels"].items():
                 if kname.startswith(name):
                     traffic = rec["fetch_bytes_per_launch"] + rec.get("write_bytes_per_launch_uncorrected", 0.0)
-                    traffic_src = "profiles/r03f_pmc_traffic.json: " + pm["source"]
+                    traffic_src = "profiles/r03i_pmc_traffic.json: " + pm["source"]
         except (OSError, KeyError, ValueError):
             pass
         # rocprofv3 view of the same command (committed summary of the same configuration): per SYMBOL, since one gemm
         # template serves three launches per layer.  `agree` = its average duration is within 15 % of this run's HIP events.
         rocprof = None
         if not nano and B == 256 and S == 500:
-            rocprof = rocprof_symbols(os.path.join(ROOT, "profiles", "r03f_bench_kernel_stats.txt"),
+            rocprof = rocprof_symbols(os.path.join(ROOT, "profiles", "r03i_bench_kernel_stats.txt"),
                                       {r[1]: (r[2], r[3], r[4]) for r in rows})
         roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": ms * 1e3,
