@@ -84,3 +84,42 @@ def test_first_token_distribution(emu_lib, model):
         n += B
     got = np.array([counts[int(i)] for i in top.indices]) / n
     assert np.abs(got - want).max() < 0.07, (got, want)
+
+
+def test_philox_known_answers():
+    """The draw's generator against the published known-answer vectors of philox4x32-10 (Random123 kat_vectors)."""
+    from oracle.sampling_ref import philox4x32_10
+    assert philox4x32_10([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert philox4x32_10([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert philox4x32_10([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+@pytest.mark.parametrize("max_batch", [2, 16])     # GEMV path (16-column groups) / tile path (64-column groups)
+def test_every_draw_equals_the_specification(emu_lib, model, max_batch, monkeypatch):
+    """Token for token: the kernel's draw at every step equals oracle/sampling_ref.sample_topk on that step's processed logits (read
+    back through the debug tap) with the request's seed and step -- the candidate-group scan, the radix select, the tie handling,
+    the token-id ordering, the Philox draw and the inverse CDF all have to agree.  (A draw whose uniform lands within 1e-5 of a
+    cumulative-sum boundary may differ by the last bit of an exp: none of the ones below does.)"""
+    from oracle.sampling_ref import sample_topk
+    cfg, w, wd = model
+    eng = make_engine(cfg, w, emu_lib, max_batch=max_batch)
+    eos, N = cfg.vocab_size - 1, 10
+    eng.set_debug(True)
+    try:
+        for slot, (K, T, seed) in enumerate([(8, 1.5, 77), (50, 1.0, (5 << 32) | 12345)]):
+            p = br.synthetic_prompt(cfg, 30 + slot, 18)
+            eng.prefill([p], [slot], [_hip.Sampling(max_length=64, min_new_tokens=N, eos_token_id=eos, do_sample=True, top_k=K,
+                                                    temperature=T, seed=seed)])
+            checked = 0
+            for step in range(N):
+                if step:
+                    eng.decode(1)
+                ids, _ = eng.read(slot)
+                want, margin = sample_topk(eng.read_logits(slot), K, T, seed, step)
+                if margin > 1e-5:
+                    assert ids[step] == want, (slot, step, ids[step], want, margin)
+                    checked += 1
+            assert checked >= N - 1
+            eng.release(slot)
+    finally:
+        eng.set_debug(False)

@@ -449,8 +449,10 @@ def test_air_sampling_topk50_full_vocab(air):
         eng.release(s)
     eng.set_debug(True)
     try:
+        from oracle.sampling_ref import sample_topk
         counts = {}
         ref_row = None
+        exact = 0
         for rep in range(4):
             for c in range(0, 256, 16):
                 samp = [_hip.Sampling(max_length=S + 4, min_new_tokens=4, eos_token_id=eos, do_sample=True, top_k=50,
@@ -466,6 +468,12 @@ def test_air_sampling_topk50_full_vocab(air):
                 t = ids[s][0]
                 assert row[t] >= kth, (s, t, row[t], kth)
                 counts[t] = counts.get(t, 0) + 1
+                # token for token against the draw's specification (oracle/sampling_ref.py): candidate-group scan over the 2 268 lm_head
+                # maxima, radix select, tie handling, token order, Philox draw, inverse CDF
+                want, margin = sample_topk(row, 50, 1.0, 77_000 * rep + s, 0)
+                if margin > 1e-5:
+                    assert t == want, (rep, s, t, want, margin)
+                    exact += 1
             if rep == 0:   # a few decode steps: membership against each step's own logits
                 for step in range(3):
                     eng.decode(1)
@@ -473,6 +481,8 @@ def test_air_sampling_topk50_full_vocab(air):
                     for s in (0, 17, 255):
                         r = eng.read_logits(s)
                         assert r[ids2[s][-1]] >= np.sort(r)[-50], (step, s)
+                        want, margin = sample_topk(r, 50, 1.0, s, len(ids2[s]) - 1)
+                        assert margin <= 1e-5 or ids2[s][-1] == want, (step, s, ids2[s][-1], want, margin)
             for s in range(256):
                 eng.release(s)
         top = np.where(ref_row >= np.sort(ref_row)[-50])[0]          # bf16 logits tie: everything >= the 50th value is kept
@@ -481,6 +491,7 @@ def test_air_sampling_topk50_full_vocab(air):
         got = np.array([counts.get(int(t), 0) for t in top]) / 1024.0
         assert abs(got.sum() - 1.0) < 1e-9
         assert np.abs(got - pr).max() < 0.05, (got, pr)
+        assert exact >= 1000, exact                                  # (of 1024 draws; the rest sat within 1e-5 of a boundary)
     finally:
         eng.set_debug(False)
 
