@@ -14,6 +14,7 @@
 #pragma once
 #include <ntts/dev.h>
 #include "attn_decode.h"
+#include "gemm.h"   // silu_fast
 
 namespace ntts {
 
@@ -140,7 +141,7 @@ NTTS_KERNEL(256) void groupnorm_silu_kernel(GroupNormArgs p) {
         float o = 0.f;
         if (t >= 0 && t < T) {
             const float v = (p.x[(row0 + t) * p.C + ch] - mean) * rstd * ga + be;
-            o = v / (1.0f + fexp(-v));
+            o = silu_fast(v);
         }
         p.y[(row0 + t) * p.C + ch] = f2bf(o);
     }
@@ -193,7 +194,7 @@ NTTS_KERNEL(256) void groupnorm_silu_reg_kernel(GroupNormArgs p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float y = (v[i][e] - mean) * rstd * ga[e] + be[e];
-                o[e] = (short)f2bf(y / (1.0f + fexp(-y)));
+                o[e] = (short)f2bf(silu_fast(y));
             }
             *(bf16x4*)(p.y + (row0 + t) * p.C + ch) = o;
         }
