@@ -361,8 +361,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->gu_128 = B > 128;
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
-    e->small = B <= env_int("NTTS_SMALL_BATCH", 8) && B <= kGemvRows && H <= 1024 && V % 16 == 0 && e->NQKV % 16 == 0 && F % 32 == 0 &&
-               !e->fp8;   // (the small-batch GEMV kernels are bf16 only: the fp8 model takes the tile kernels at every batch)
+    e->small = B <= env_int("NTTS_SMALL_BATCH", 8) && B <= kGemvRows && H <= 1024 && V % 16 == 0 && e->NQKV % 16 == 0 && F % 32 == 0;   // (bf16 and fp8 models alike: gemv.h / qkv_rope.h F8 instantiations)
     static_assert(ntts_backbone::kSksO <= 16 && ntts_backbone::kSksD <= 16, "slab counts");
     {
         CR_HIP(hipMalloc((void**)&e->step_meta, (size_t)B * 4 * sizeof(int)));
@@ -385,7 +384,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
         e->attn_split = env_int("NTTS_ATTN_SPLIT", 8);
         e->attn_split_ctx = env_int("NTTS_ATTN_SPLIT_CTX", 896);
         if (e->attn_split < 2 || e->attn_split > 32) e->attn_split = 0;
-        if (!e->small && (e->fp8 || B * c->num_kv_heads >= 512)) e->attn_split = 0;   // (fp8: the combine pass writes bf16 rows)
+        if (e->fp8 || (!e->small && B * c->num_kv_heads >= 512)) e->attn_split = 0;   // (fp8: the combine pass writes bf16 rows / fp32 chunk slabs)
         if (e->attn_split) {
             const size_t n_sc = (size_t)B * c->num_kv_heads * kGroupMax * (c->max_context + 16), n_st = (size_t)B * c->num_kv_heads * e->attn_split * kGroupMax * 2,
                          n_os = (size_t)e->attn_split * B * c->num_heads * 64;
@@ -908,8 +907,10 @@ static void k_add_norm(ntts_backbone* e, int K, int ks, const bf16_t* norm_w, bf
 }
 
 // ---- small-batch step (gemv.h): per layer  [norm -> QKV]  attention  [o_proj]  [norm -> gate/up -> SiLU*mul]  [down]
-static GemvArgs gemv_args(const ntts_backbone* e, const bf16_t* X, long ldx, const bf16_t* W, long ldw, void* out, long ldo, int N, int K) {
+static GemvArgs gemv_args(const ntts_backbone* e, const bf16_t* X, long ldx, const bf16_t* W, long ldw, void* out, long ldo, int N, int K,
+                          const float* wscale = nullptr, float xscale = 1.f) {
     GemvArgs a{};
+    a.wscale = wscale; a.xscale = xscale;
     a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.w_tile_major = 1; a.out = out; a.ldo = ldo;
     a.slab_rows = e->cfg.max_batch; a.M = e->cfg.max_batch; a.N = N; a.K = K;
     a.tl = e->gemv_tl;
@@ -921,8 +922,9 @@ static NormArgs pro_qkv(ntts_backbone* e, int i) {
     NormArgs n{};
     n.M = e->cfg.max_batch; n.H = e->H; n.eps = e->cfg.rms_eps; n.norm_w = e->layers[i].ln1;
     if (i == 0) { n.gather_ids = e->sl.cur_tok; n.embed = e->embed; }
-    else { n.slabs = e->slabs2; n.nslab = gemv_nsplit(e->F, ntts_backbone::kSksD); n.slab_rows = e->cfg.max_batch; n.resid_in = e->h_dec; }
+    else { n.slabs = e->slabs2; n.nslab = gemv_nsplit(e->F, ntts_backbone::kSksD, e->fp8); n.slab_rows = e->cfg.max_batch; n.resid_in = e->h_dec; }
     n.resid_out = e->h_alt;
+    if (e->fp8) n.out_fp8_inv = 1.0f / e->layers[i].xs[0];       // the panel holds the QKV GEMV's e4m3 input
     return n;
 }
 // QKV + bias + rounding + RoPE + K append in one GEMV launch (qkv_rope.h gemv_qkv_rope_kernel): batch 1 step 1.003 -> 0.962 ms together
@@ -930,6 +932,7 @@ static NormArgs pro_qkv(ntts_backbone* e, int i) {
 static void ks_qkv(ntts_backbone* e, int i) {
     GemvQkvArgs a{};
     a.pro = pro_qkv(e, i); a.W = e->layers[i].wqkv; a.bias = e->layers[i].bqkv; a.M = e->cfg.max_batch; a.N = e->NQKV; a.K = e->H;
+    if (e->fp8) { a.wscale = e->layers[i].sqkv; a.xscale = e->layers[i].xs[0]; }
     a.meta = e->step_meta; a.rope_rows = e->rope_rows; a.q_out = e->qkv_dec; a.ld_q = e->NQKV;
     a.kpool = e->kv + (size_t)i * e->layer_stride; a.nh = e->cfg.num_heads; a.nkv = e->cfg.num_kv_heads;
     a.tl = e->gemv_tl;
@@ -944,6 +947,7 @@ static void ks_attn(ntts_backbone* e, int i) {
     a.block_table = e->block_table; a.max_pages = e->max_pages; a.pos = e->sl.pos; a.state = e->sl.state;
     a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
     a.tl = e->attn_tl;
+    if (e->fp8) a.out_fp8_inv = 1.0f / e->layers[i].xs[1];       // attention output = o_proj's e4m3 input
     if (e->split_active && !e->attn_tl) {
         AttnSplitArgs q{};
         q.a = a; q.scores = e->as_scores; q.ld_scores = c.max_context + 16; q.stats = e->as_stats; q.oslabs = e->as_oslabs; q.nsplit = e->attn_split;
@@ -954,34 +958,41 @@ static void ks_attn(ntts_backbone* e, int i) {
 }
 static void ks_o_proj(ntts_backbone* e, int i) {
     const int QD = e->cfg.num_heads * 64;
-    GemvArgs a = gemv_args(e, e->attn_dec, QD, e->layers[i].wo, QD, e->slabs, e->H, e->H, QD);
+    GemvArgs a = gemv_args(e, e->attn_dec, QD, e->layers[i].wo, QD, e->slabs, e->H, e->H, QD, e->layers[i].so, e->layers[i].xs[1]);
     if (e->split_active && !e->attn_tl) { a.xslabs = e->as_oslabs; a.n_xslab = e->attn_split; }   // context-split attention: chunk outputs summed here
-    gemv_launch<EPI_SPLITK, false>(a, ntts_backbone::kSksO, e->stream);
+    if (e->fp8) gemv_launch<EPI_SPLITK, false, 4, true>(a, ntts_backbone::kSksO, e->stream);
+    else gemv_launch<EPI_SPLITK, false>(a, ntts_backbone::kSksO, e->stream);
 }
 static void ks_gate_up(ntts_backbone* e, int i) {
-    GemvArgs a = gemv_args(e, nullptr, 0, e->layers[i].wgu, e->H, e->act_dec, e->F, 2 * e->F, e->H);
+    GemvArgs a = gemv_args(e, nullptr, 0, e->layers[i].wgu, e->H, e->act_dec, e->F, 2 * e->F, e->H, e->layers[i].sgu, e->layers[i].xs[2]);
     NormArgs n{};
     n.M = e->cfg.max_batch; n.H = e->H; n.eps = e->cfg.rms_eps; n.norm_w = e->layers[i].ln2;
-    n.slabs = e->slabs; n.nslab = gemv_nsplit(e->cfg.num_heads * 64, ntts_backbone::kSksO); n.slab_rows = e->cfg.max_batch;
+    n.slabs = e->slabs; n.nslab = gemv_nsplit(e->cfg.num_heads * 64, ntts_backbone::kSksO, e->fp8); n.slab_rows = e->cfg.max_batch;
     n.resid_in = e->h_alt; n.resid_out = e->h_dec;
+    if (e->fp8) { n.out_fp8_inv = 1.0f / e->layers[i].xs[2]; a.out_fp8_inv = 1.0f / e->layers[i].xs[3]; }   // e4m3 panel in, e4m3 activation out (down_proj's input)
     a.pro = n;
+    if (e->fp8) { gemv_launch<EPI_SILU_MUL, true, 3, true>(a, 1, e->stream); return; }
     gemv_launch<EPI_SILU_MUL, true, 3>(a, 1, e->stream);   // 3 feature waves: 203 workgroups, every CU streams <= 86 KB of weights (gemv.h)
 }
 static void ks_down(ntts_backbone* e, int i) {
-    gemv_launch<EPI_SPLITK, false>(gemv_args(e, e->act_dec, e->F, e->layers[i].wd, e->F, e->slabs2, e->H, e->H, e->F), ntts_backbone::kSksD, e->stream);
+    const GemvArgs a = gemv_args(e, e->act_dec, e->F, e->layers[i].wd, e->F, e->slabs2, e->H, e->H, e->F, e->layers[i].sd, e->layers[i].xs[3]);
+    if (e->fp8) gemv_launch<EPI_SPLITK, false, 4, true>(a, ntts_backbone::kSksD, e->stream);
+    else gemv_launch<EPI_SPLITK, false>(a, ntts_backbone::kSksD, e->stream);
 }
 static void ks_final_norm(ntts_backbone* e) {   // h += down (last layer); xn = rmsnorm(h) * final_norm  -> the lm_head's input
     NormArgs n{};
-    n.slabs = e->slabs2; n.nslab = gemv_nsplit(e->F, ntts_backbone::kSksD); n.slab_rows = e->cfg.max_batch; n.resid_in = e->h_dec; n.resid_out = e->h_dec;
+    n.slabs = e->slabs2; n.nslab = gemv_nsplit(e->F, ntts_backbone::kSksD, e->fp8); n.slab_rows = e->cfg.max_batch; n.resid_in = e->h_dec; n.resid_out = e->h_dec;
     n.norm_w = e->final_norm; n.normed_out = e->xn_dec; n.M = e->cfg.max_batch; n.H = e->H; n.eps = e->cfg.rms_eps;
+    if (e->fp8) n.out_fp8_inv = 1.0f / e->xs_head;
     add_rmsnorm_launch(n, e->stream, true);
 }
 static void ks_lm_head(ntts_backbone* e, bool keep_logits) {
     const int H = e->H, V = e->cfg.vocab_size;
-    GemvArgs a = gemv_args(e, e->xn_dec, H, e->embed_tm, H, nullptr, 0, V, H);
+    GemvArgs a = gemv_args(e, e->xn_dec, H, e->embed_tm, H, nullptr, 0, V, H, e->shead, e->xs_head);
     a.part_val = e->part_val; a.part_idx = e->part_idx; a.mask_eos = e->sl.mask_eos;
     a.logits = keep_logits ? e->logits : nullptr; a.ld_logits = V;
     a.logits_bf16 = (keep_logits && e->n_sampling > 0) ? e->logits_bf16 : nullptr; a.ld_logits_bf16 = e->ldl;
+    if (e->fp8) { gemv_launch<EPI_ARGMAX, false, 4, true>(a, 1, e->stream); return; }
     gemv_launch<EPI_ARGMAX, false>(a, 1, e->stream);
 }
 

@@ -60,6 +60,12 @@ struct GemvArgs {
     long ld_logits;
     bf16_t* logits_bf16;
     long ld_logits_bf16;
+    // F8 kernels (fp8 model, gemm.h GemmArgs): X and W hold e4m3 BYTES (ldx / K count elements = bytes; a 128-byte k-tile is 128 k-values, K % 128 == 0),
+    // the panel in LDS holds bytes (PRO: pro.out_fp8_inv quantises the normalised rows), out = acc * (xscale * wscale[n]); EPI_SILU_MUL emits e4m3
+    // bytes when out_fp8_inv > 0 (down_proj's input).  Byte for byte the staging is the bf16 kernel's: a lane's 32 bytes per k-tile are 32 k-values
+    // instead of 16 and feed four fp8 MFMAs instead of two bf16 ones.
+    const float* wscale;
+    float xscale, out_fp8_inv;
     unsigned long long* tl;   // diagnostics (ntts_backbone_gemv_timeline): [workgroups][16] phase timestamps -- slots 0..7 feature wave 0,
                               // 8..15 helper wave 0; null in the product path.  With it set the feature wave also WAITS for its whole weight
                               // slice before the barrier (so that "weights landed" has a timestamp), which the product path never does
@@ -72,12 +78,13 @@ struct GemvArgs {
 // FW = feature waves per workgroup, + 4 helper waves.  gate/up takes FW = 3 (203 workgroups of 48 features instead of 152 of 64: 86 instead
 // of 114 KB of weights per CU; 10.8 -> 10.0 us at batch 1, round 3); FW = 2 (304 workgroups -- more than CUs, two rounds) costs 16.1-16.4 us
 // (profiles/r02f_sweep_b1_nw16_late_fw2.log, r03g_sweep_b1_gemv_prologue.log).
-template <int EPI, bool PRO, int KT, int FW = 4>
+template <int EPI, bool PRO, int KT, int FW = 4, bool F8 = false>
 NTTS_KERNEL((FW + 4) * 64) void gemv_kernel(GemvArgs p) {
     NTTS_SHARED bf16_t xs[kGemvRows * kGemvXld];
+    constexpr int ESZ = F8 ? 1 : 2;                               // bytes per operand element
     const int lane = lane_id(), w = wave_id();
     const int g = lane >> 4, l15 = lane & 15;
-    const int ktiles = p.K >> 6;
+    const int ktiles = F8 ? p.K >> 7 : p.K >> 6;                  // 128-byte k-tiles
     const int kt0 = blockIdx.y * p.k_tiles_per_split;
     int nk = ktiles - kt0;
     if (nk > p.k_tiles_per_split) nk = p.k_tiles_per_split;       // <= KT (launcher)
@@ -98,7 +105,7 @@ NTTS_KERNEL((FW + 4) * 64) void gemv_kernel(GemvArgs p) {
             const int nch = nk * 8;                               // 16-byte chunks per row of the slice: <= 128 = 2 per lane
             for (int m = hw; m < p.M; m += 4) {
                 const int c0 = lane, c1 = lane + 64;                // both loads first (clamped addresses), then the guarded stores
-                if (p.xslabs) {                                     // (wave-uniform) sum the fp32 slabs in order, round once
+                if (!F8 && p.xslabs) {                              // (wave-uniform) sum the fp32 slabs in order, round once (bf16 model only)
                     float a0[8], a1[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) a0[e] = a1[e] = 0.f;
@@ -116,7 +123,7 @@ NTTS_KERNEL((FW + 4) * 64) void gemv_kernel(GemvArgs p) {
                     if (c1 < nch) *(bf16x8*)(xs + m * kGemvXld + c1 * 8) = t1;
                     continue;
                 }
-                const bf16_t* src = p.X + (long)m * p.ldx + kt0 * 64;
+                const bf16_t* src = (const bf16_t*)((const char*)p.X + ((long)m * p.ldx) * ESZ) + kt0 * 64;   // (a k-tile is 128 bytes either way)
                 const bf16x8 t0 = ld16<bf16x8>(src + (c0 < nch ? c0 : 0) * 8);
                 const bf16x8 t1 = ld16<bf16x8>(src + (c1 < nch ? c1 : 0) * 8);
                 if (c0 < nch) *(bf16x8*)(xs + m * kGemvXld + c0 * 8) = t0;
@@ -136,8 +143,8 @@ NTTS_KERNEL((FW + 4) * 64) void gemv_kernel(GemvArgs p) {
     const int f0 = active ? f0r : 0;                              // an inactive wave streams (and discards) group 0: no branch around the loads
     const bf16_t* wbase;
     long wstep = 64;
-    if (p.w_tile_major) { wbase = p.W + (long)(f0 >> 6) * 64 * p.K + ((f0 & 63) + l15) * 64 + g * 16; wstep = 4096; }
-    else wbase = p.W + (long)(f0 + l15) * p.ldw + g * 16;
+    if (p.w_tile_major) { wbase = (const bf16_t*)((const char*)p.W + (long)(f0 >> 6) * 64 * p.K * ESZ) + ((f0 & 63) + l15) * 64 + g * 16; wstep = 4096; }
+    else wbase = (const bf16_t*)((const char*)p.W + (long)(f0 + l15) * p.ldw * ESZ) + g * 16;
     bf16x8 wa[KT][2];
     if constexpr (PRO) sync_keep_dma();                           // the helpers' requests go first (norm.h issue_barrier)
 #pragma unroll
@@ -176,8 +183,17 @@ NTTS_KERNEL((FW + 4) * 64) void gemv_kernel(GemvArgs p) {
         const bf16x8 x0 = xq[j % kXPf][0], x1 = xq[j % kXPf][1];
         if (j + kXPf < KT) xload(j + kXPf, xq[j % kXPf]);
         if constexpr (kXPf > 1) sched_fence();                    // (hipcc sinks the reads back next to their MFMAs otherwise)
-        acc = mfma16(wa[j][0] & keep, x0, acc);
-        acc = mfma16(wa[j][1] & keep, x1, acc);
+        if constexpr (F8) {
+            const i64x2 a0 = __builtin_bit_cast(i64x2, wa[j][0] & keep), a1 = __builtin_bit_cast(i64x2, wa[j][1] & keep);
+            const i64x2 b0 = __builtin_bit_cast(i64x2, x0), b1 = __builtin_bit_cast(i64x2, x1);
+            acc = mfma16_fp8(a0[0], b0[0], acc);
+            acc = mfma16_fp8(a0[1], b0[1], acc);
+            acc = mfma16_fp8(a1[0], b1[0], acc);
+            acc = mfma16_fp8(a1[1], b1[1], acc);
+        } else {
+            acc = mfma16(wa[j][0] & keep, x0, acc);
+            acc = mfma16(wa[j][1] & keep, x1, acc);
+        }
     }
 
     if (p.tl && w == 0 && lane == 0) p.tl[tlb + 4] = now_ticks() + (acc[0] == 1.2345e30f ? 1 : 0);   // (after the matrix-core chain)
@@ -185,6 +201,11 @@ NTTS_KERNEL((FW + 4) * 64) void gemv_kernel(GemvArgs p) {
     const int m = l15;
     const bool mok = m < p.M;
     const int nf = f0 + g * 4;
+    if constexpr (F8) {                                           // static input scale x per-output-channel weight scale (W row nf + r)
+        const f32x4 ws = ld16<f32x4>(p.wscale + nf);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] *= p.xscale * ws[r];
+    }
     if constexpr (EPI == EPI_SPLITK) {
         if (mok) *(f32x4*)((float*)p.out + ((long)blockIdx.y * p.slab_rows + m) * p.ldo + nf) = acc;
     } else if constexpr (EPI == EPI_SILU_MUL) {
@@ -200,7 +221,12 @@ NTTS_KERNEL((FW + 4) * 64) void gemv_kernel(GemvArgs p) {
                 o[r] = f2bf(rbf(silu_fast(gt)) * u);               // act_fn output (bf16), product (bf16)
             }
             const int fb = (f0 >> 6) * 32 + ((f0 & 63) >> 4) * 8 + g * 4;
-            *(u32x2*)((bf16_t*)p.out + (long)m * p.ldo + fb) = *(u32x2*)&o[0];
+            if (F8 && p.out_fp8_inv > 0.f) {                       // down_proj's input of the fp8 model: e4m3(bf16 value / input scale)
+                alignas(4) unsigned short q2[2];
+                q2[0] = f2fp8x2(bf2f(o[0]) * p.out_fp8_inv, bf2f(o[1]) * p.out_fp8_inv);
+                q2[1] = f2fp8x2(bf2f(o[2]) * p.out_fp8_inv, bf2f(o[3]) * p.out_fp8_inv);
+                *(unsigned int*)((unsigned char*)p.out + (long)m * p.ldo + fb) = *(unsigned int*)&q2[0];
+            } else *(u32x2*)((bf16_t*)p.out + (long)m * p.ldo + fb) = *(u32x2*)&o[0];
         }
     } else if constexpr (EPI == EPI_ARGMAX) {
         float best = -INFINITY;
@@ -243,26 +269,29 @@ inline int gemv_ksplit(int K, int ksplit) {
     return ksplit < 1 ? 1 : ksplit;
 }
 
-template <int EPI, bool PRO, int FW = 4>
+template <int EPI, bool PRO, int FW = 4, bool F8 = false>
 inline void gemv_launch(GemvArgs p, int ksplit, hipStream_t s) {
-    const int ktiles = p.K / 64;
-    ksplit = gemv_ksplit(p.K, ksplit);                            // (PRO: the panel is the whole normalised row, K = H <= 1024)
+    const int ktiles = p.K / (F8 ? 128 : 64);
+    ksplit = gemv_ksplit(p.K / (F8 ? 2 : 1), ksplit);             // (PRO: the panel is the whole normalised row, K = H <= 1024; fp8: 128 k-values per k-tile)
     p.k_tiles_per_split = (ktiles + ksplit - 1) / ksplit;
     const int nsplit = (ktiles + p.k_tiles_per_split - 1) / p.k_tiles_per_split;
     if constexpr (EPI == EPI_ARGMAX) p.part_stride = p.N / 16;
     const int kps = p.k_tiles_per_split;
     const dim3 grid((p.N + 16 * FW - 1) / (16 * FW), nsplit), block((FW + 4) * 64);
     if constexpr (EPI == EPI_SPLITK) {                            // the split-K GEMVs come in every slice length
-        if (kps <= 2) { NTTS_LAUNCH((gemv_kernel<EPI, PRO, 2>), grid, block, s, p); return; }
-        if (kps <= 4) { NTTS_LAUNCH((gemv_kernel<EPI, PRO, 4>), grid, block, s, p); return; }
-        if (kps <= 8) { NTTS_LAUNCH((gemv_kernel<EPI, PRO, 8>), grid, block, s, p); return; }
+        if (kps <= 2) { NTTS_LAUNCH((gemv_kernel<EPI, PRO, 2, 4, F8>), grid, block, s, p); return; }
+        if (kps <= 4) { NTTS_LAUNCH((gemv_kernel<EPI, PRO, 4, 4, F8>), grid, block, s, p); return; }
+        if (kps <= 8) { NTTS_LAUNCH((gemv_kernel<EPI, PRO, 8, 4, F8>), grid, block, s, p); return; }
     }
     // (K = 896 is 14 k-tiles: a 14-tile instantiation without the two surplus requests per wave -- re-reads of the wave's last tile -- measured
     //  the same, 0.9658-0.9726 ms per step either way at batch 1: the surplus requests hit in the cache; not instantiated)
-    NTTS_LAUNCH((gemv_kernel<EPI, PRO, 16, FW>), grid, block, s, p);
+    if constexpr (F8 && EPI != EPI_SPLITK) {                        // (fp8: K = H <= 1024 is at most 8 k-tiles)
+        if (kps <= 8) { NTTS_LAUNCH((gemv_kernel<EPI, PRO, 8, FW, F8>), grid, block, s, p); return; }
+    }
+    NTTS_LAUNCH((gemv_kernel<EPI, PRO, 16, FW, F8>), grid, block, s, p);
 }
 
 // number of split-K slabs gemv_launch produces for (K, ksplit)
-inline int gemv_nsplit(int K, int ksplit) { return gemm_nsplit(K, gemv_ksplit(K, ksplit)); }
+inline int gemv_nsplit(int K, int ksplit, bool f8 = false) { return gemm_nsplit(K, gemv_ksplit(f8 ? K / 2 : K, ksplit), f8 ? 128 : 64); }
 
 }  // namespace ntts

@@ -189,12 +189,12 @@ NTTS_D void rmsnorm_row_wave(const NormArgs& p, int r, bool rok, bool write_resi
             bf16x8 t;
 #pragma unroll
             for (int e = 0; e < 8; ++e) t[e] = (short)f2bf(bf2f((bf16_t)w[e]) * rbf(v[i][e] * inv));
-            if (p.out_fp8_inv > 0.f && !dst) {
+            if (p.out_fp8_inv > 0.f) {   // fp8 model: e4m3 BYTES, into the global row or (dst: gemv.h's panel of the fp8 GEMV kernels) at byte col of dst's row
                 alignas(8) unsigned short q[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     q[e] = f2fp8x2(bf2f((bf16_t)t[2 * e]) * p.out_fp8_inv, bf2f((bf16_t)t[2 * e + 1]) * p.out_fp8_inv);
-                *(u32x2*)((unsigned char*)p.normed_out + ro * p.H + col) = *(u32x2*)&q[0];
+                *(u32x2*)(dst ? (unsigned char*)dst + col : (unsigned char*)p.normed_out + ro * p.H + col) = *(u32x2*)&q[0];
             } else {
                 *(bf16x8*)(dst ? dst + col : p.normed_out + ro * p.H + col) = t;
             }

@@ -312,12 +312,15 @@ struct GemvQkvArgs {
     long ld_q;
     bf16_t* kpool;
     int nh, nkv;
+    const float* wscale;     // F8 kernel (fp8 model; gemv.h GemvArgs): per-output-channel weight scales, xscale = the static input scale;
+    float xscale;            //   pro.out_fp8_inv quantises the panel
     unsigned long long* tl;  // diagnostics (ntts_backbone_gemv_timeline, which = 1): [workgroups][16] phase timestamps as in gemv.h; slot 5 =
                              // the K slices have met in LDS, slot 6 = wave 0's stores done
 };
 
-template <int KT>
+template <int KT, bool F8 = false>
 NTTS_KERNEL(512) void gemv_qkv_rope_kernel(GemvQkvArgs p) {
+    constexpr int ESZ = F8 ? 1 : 2;
     NTTS_SHARED bf16_t xs[kGemvRows * kGemvXld];
     NTTS_SHARED f32x4 red[4][64];
     const int lane = lane_id(), w = wave_id();
@@ -350,13 +353,13 @@ NTTS_KERNEL(512) void gemv_qkv_rope_kernel(GemvQkvArgs p) {
         bs = *(const bf16x4*)(p.bias + n0);
     }
     // this wave's K slice of the workgroup's 16 weight rows: MFMA row l15 <-> feature 8q + l15 (l15 < 8) / 32 + 8q + l15 - 8
-    const int ktiles = p.K >> 6;
+    const int ktiles = F8 ? p.K >> 7 : p.K >> 6;                  // 128-byte k-tiles
     const int kt0 = w * p.kps;
     int nk = ktiles - kt0;
     if (nk > p.kps) nk = p.kps;
     if (nk < 0) nk = 0;
     const int frow = l15 < 8 ? q * 8 + l15 : 32 + q * 8 + (l15 - 8);
-    const bf16_t* wbase = p.W + (long)hd * 64 * p.K + frow * 64 + g * 16;
+    const bf16_t* wbase = (const bf16_t*)((const char*)p.W + (long)hd * 64 * p.K * ESZ) + frow * 64 + g * 16;
     bf16x8 wa[KT][2];
     sync_keep_dma();                                              // the helpers' requests go first
 #pragma unroll
@@ -386,8 +389,17 @@ NTTS_KERNEL(512) void gemv_qkv_rope_kernel(GemvQkvArgs p) {
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
         const short keep = j < nk ? (short)-1 : (short)0;         // surplus tiles contribute 0 * x
-        acc = mfma16(wa[j][0] & keep, xq[j][0], acc);
-        acc = mfma16(wa[j][1] & keep, xq[j][1], acc);
+        if constexpr (F8) {
+            const i64x2 a0 = __builtin_bit_cast(i64x2, wa[j][0] & keep), a1 = __builtin_bit_cast(i64x2, wa[j][1] & keep);
+            const i64x2 b0 = __builtin_bit_cast(i64x2, xq[j][0]), b1 = __builtin_bit_cast(i64x2, xq[j][1]);
+            acc = mfma16_fp8(a0[0], b0[0], acc);
+            acc = mfma16_fp8(a0[1], b0[1], acc);
+            acc = mfma16_fp8(a1[0], b1[0], acc);
+            acc = mfma16_fp8(a1[1], b1[1], acc);
+        } else {
+            acc = mfma16(wa[j][0] & keep, xq[j][0], acc);
+            acc = mfma16(wa[j][1] & keep, xq[j][1], acc);
+        }
     }
     if (p.tl && w == 0 && lane == 0) p.tl[tlb + 4] = now_ticks() + (acc[0] == 1.2345e30f ? 1 : 0);
     red[w][lane] = acc;
@@ -396,11 +408,19 @@ NTTS_KERNEL(512) void gemv_qkv_rope_kernel(GemvQkvArgs p) {
     mark(5);
     // lane (g, m): rows g*4 + r of the 16 = features n0 + r of token m; slices added in order
     f32x4 sum = red[0][lane];
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f};
+    if constexpr (F8) {                                           // every slice's partial sum times (input scale x weight scale of column n0 + r), as qkv_rope_kernel<F8>
+        const f32x4 ws = ld16<f32x4>(p.wscale + n0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { sc[r] = p.xscale * ws[r]; sum[r] *= sc[r]; }
+    }
 #pragma unroll
     for (int sl = 1; sl < 4; ++sl) {
         const f32x4 o = red[sl][lane];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sum[r] += o[r];
+        for (int r = 0; r < 4; ++r) {
+            if constexpr (F8) sum[r] += o[r] * sc[r]; else sum[r] += o[r];
+        }
     }
     alignas(8) bf16_t val[4], out[4];
 #pragma unroll
@@ -428,6 +448,11 @@ NTTS_KERNEL(512) void gemv_qkv_rope_kernel(GemvQkvArgs p) {
 }
 
 inline void gemv_qkv_rope_launch(GemvQkvArgs p, hipStream_t s) {
+    if (p.wscale) {                                               // fp8 model: 128 k-values per k-tile, <= 2 per slice for K <= 1024
+        p.kps = (p.K / 128 + 3) / 4;
+        NTTS_LAUNCH((gemv_qkv_rope_kernel<2, true>), dim3(p.N / 16), dim3(512), s, p);
+        return;
+    }
     const int ktiles = p.K / 64;
     p.kps = (ktiles + 3) / 4;                                     // <= 4 for K <= 1024
     NTTS_LAUNCH((gemv_qkv_rope_kernel<4>), dim3(p.N / 16), dim3(512), s, p);

@@ -131,6 +131,8 @@ def check_fp8_model(lib, cfg, prompts, n_new, max_batch, bar=0.10, corr_bar=0.99
     agree = [sum(int(a == b) for a, b in zip(rows[s], want8[tuple(p)].ids)) for s, p in enumerate(prompts)]
     print(f"fp8 free-running ids equal to the fp8 oracle's: {agree[:len(distinct)]} of {n_new} each (the {len(distinct)} distinct prompts)")
     assert all(len(r) == n_new for r in rows)
+    if "emu" in lib:      # exact arithmetic there (see above): the decode steps -- GEMV kernels up to batch 8, tile kernels above -- give the oracle's ids
+        assert agree[:len(distinct)] == [n_new] * len(distinct), agree
     eng.close()
     return rows, worst
 
@@ -142,6 +144,35 @@ def test_fp8_model_matches_fp8_oracle(lib):
     rows, worst = check_fp8_model(lib, cfg, prompts, 10, max_batch=3)
     if "emu" in lib:      # the emulator's matrix core is an fp32 fma chain like the oracle's matmul: there the match is exact
         assert worst <= 2e-3
+
+
+@pytest.mark.parametrize("small", ["8", "0"])
+def test_fp8_decode_step_logits_small_and_tile_path(lib, small, monkeypatch):
+    """The fp8 model's DECODE step on both paths (NTTS_SMALL_BATCH=8: gemv.h / qkv_rope.h F8 kernels with the e4m3 panel built by the fused
+    norm prologue; 0: the tile kernels): logits of the 6th generated token, teacher-forced on the engine's own ids, against the fp8 oracle."""
+    monkeypatch.setenv("NTTS_SMALL_BATCH", small)
+    cfg = fp8_cfg()
+    w = br.make_weights(cfg, 23, peak_sigma=0.5)
+    scales = br.default_fp8_input_scales(cfg)
+    wb = br.cast_weights(w, torch.bfloat16)
+    wq = br.fp8_quantize_weights(wb, scales)
+    eng = _engine(cfg, w, lib, max_batch=4, input_scales=scales, weight_dtype="fp8")
+    eos, N = cfg.vocab_size - 1, 6
+    prompts = [br.synthetic_prompt(cfg, 5, 33), br.synthetic_prompt(cfg, 6, 64)]
+    eng.set_debug(True)
+    eng.prefill(prompts, [1, 3], [_hip.Sampling(max_length=len(p) + N, min_new_tokens=N, eos_token_id=eos, do_sample=False) for p in prompts])
+    eng.decode(N - 1)
+    for slot, p in zip((1, 3), prompts):
+        ids = eng.read(slot)[0]
+        assert len(ids) == N
+        ref8 = br.generate(cfg, wq, p, len(p) + N, eos, min_new_tokens=N, force_ids=ids, keep_logits=True).logits[N - 1].numpy()
+        ref16 = br.generate(cfg, wb, p, len(p) + N, eos, min_new_tokens=N, force_ids=ids, keep_logits=True).logits[N - 1].numpy()
+        d_impl, d_quant, corr = fp8_distance(eng.read_logits(slot), ref8, ref16)
+        print(f"fp8 decode step (NTTS_SMALL_BATCH={small}) slot {slot}: engine vs fp8 oracle rel. RMS {d_impl:.4f} (corr {corr:.5f}); quantisation {d_quant:.4f}")
+        assert d_impl <= 0.10 and d_impl < d_quant and corr >= 0.995, (slot, d_impl, d_quant, corr)
+        if "emu" in lib:
+            assert d_impl <= 2e-3
+    eng.close()
 
 
 def test_fp8_needs_its_input_scales(lib):

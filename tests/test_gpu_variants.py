@@ -25,6 +25,7 @@ test_untied_head_and_no_bias_match_oracle = cases.test_untied_head_and_no_bias_m
 test_tied_head_must_equal_embedding = cases.test_tied_head_must_equal_embedding
 test_fp8_model_matches_fp8_oracle = cases.test_fp8_model_matches_fp8_oracle
 test_fp8_needs_its_input_scales = cases.test_fp8_needs_its_input_scales
+test_fp8_decode_step_logits_small_and_tile_path = cases.test_fp8_decode_step_logits_small_and_tile_path
 
 
 @pytest.mark.parametrize("batch", [64, 256])
