@@ -72,9 +72,16 @@ NTTS_D void rope_pair(float x1, float x2, float c, float s, float& o1, float& o2
 // LMAX = longest context the instantiation can hold scores for: the score rows are most of the kernel's LDS (33 KB of 43 at 2048:
 //   three workgroups per CU).  Engines created with max_context <= 1024 take the 1024 instantiation (16.6 KB of 27: the register
 //   budget -- 102 -- then allows four), which matters where the grid is many rounds deep: batch 512 x 4 kv-heads = 2048 workgroups.
-template <int kDepth, bool kTimeline = false, int kVar = 1, int NW = 4, int LMAX = kAttnLMax>
+// DS = 4 (small batch; grid z = 4): the workgroup computes the scores and the softmax of ALL keys like DS = 1 but only 16 of the 64 output
+//   dimensions -- V^T rows 16 z .. 16 z + 15, a quarter of the V^T bytes, one PV tile per page instead of four.  At batch 1 a (sequence, kv-head)
+//   is then four workgroups of 100 KB each instead of one pulling 160 KB through a single CU's load path; P, and with it every output element,
+//   is computed exactly as before (the other three quarters of the K stream are L2 hits).  No cross-workgroup exchange.
+template <int kDepth, bool kTimeline = false, int kVar = 1, int NW = 4, int LMAX = kAttnLMax, int DS = 1>
 NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
+    static_assert(DS == 1 || DS == 4, "output-dimension split");
     constexpr int NT = NW * 64;
+    constexpr int NTL = DS == 1 ? 4 : 1;                // PV tiles (16 output dimensions each) this workgroup computes
+    const int nt0 = DS == 1 ? 0 : (int)blockIdx.z;      // ... starting at tile nt0
     NTTS_SHARED bf16_t sc[kGroupMax][LMAX + 16];        // rounded scores, 33 KB at 2048; +32 B/row de-aliases the LDS banks
     NTTS_SHARED bf16_t vnew[64];
     NTTS_SHARED float wred[NW][kGroupMax];
@@ -110,18 +117,18 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
             else { k[u][0] = ld16<bf16x8>(kr); k[u][1] = ld16<bf16x8>(kr + 8); }
         }
     };
-    auto load_v_at = [&](long page, bf16x8 (&v)[4]) {
+    auto load_v_at = [&](long page, bf16x8 (&v)[NTL]) {
         const bf16_t* vp = p.vpool + (page * p.nkv + kvh) * 64 * kPage;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            if constexpr (kVar & 2) v[nt] = ld16_nt<bf16x8>(vp + (nt * 16 + l15) * kPage + g * 8);   // K/V pages: read once per step
-            else v[nt] = ld16<bf16x8>(vp + (nt * 16 + l15) * kPage + g * 8);
+        for (int nt = 0; nt < NTL; ++nt) {
+            if constexpr (kVar & 2) v[nt] = ld16_nt<bf16x8>(vp + ((nt0 + nt) * 16 + l15) * kPage + g * 8);   // K/V pages: read once per step
+            else v[nt] = ld16<bf16x8>(vp + ((nt0 + nt) * 16 + l15) * kPage + g * 8);
         }
     };
     auto load_k = [&](int pg, bf16x8 (&k)[2][2]) { load_k_at(bt[pg], k); };
-    auto load_v = [&](int pg, bf16x8 (&v)[4]) { load_v_at(bt[pg], v); };
+    auto load_v = [&](int pg, bf16x8 (&v)[NTL]) { load_v_at(bt[pg], v); };
     bf16x8 kq[kDepth][2][2];   // register rings of kDepth pages per wave
-    bf16x8 vq[kDepth][4];
+    bf16x8 vq[kDepth][NTL];
     bf16x8 qB[2];
     bf16_t vrow_new = 0;       // element tid of this step's v row / the page of position P (threads 0..63)
     long vpage_new = 0;
@@ -193,7 +200,8 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
     mark(4);
     if (tid < 64) {   // v row -> its slot of the transposed page, and LDS (pass 2 reads it there, behind the merge barrier)
         vnew[tid] = vrow_new;
-        p.vpool[(vpage_new * p.nkv + kvh) * 64 * kPage + (long)tid * kPage + v_slot(P % kPage)] = vrow_new;
+        if (nt0 == 0)           // (DS = 4: one of the four workgroups appends; the others take the row from their own LDS copy like this one)
+            p.vpool[(vpage_new * p.nkv + kvh) * 64 * kPage + (long)tid * kPage + v_slot(P % kPage)] = vrow_new;
     }
     // ---- V^T pages are independent of the scores: (kVar & 4: already requested next to the K pages) else get the first
     //      ones in flight under the softmax reductions
@@ -226,17 +234,17 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
     mark(5);
 
     // ---- pass 2: O = P V with P = bf16(exp(s - m) / sum)
-    f32x4 oacc[4];
+    f32x4 oacc[NTL];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) oacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NTL; ++nt) oacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int pg0 = w; pg0 < npages; pg0 += NW * kDepth) {
 #pragma unroll
         for (int j = 0; j < kDepth; ++j) {
             const int pg = pg0 + NW * j;
             if (pg < npages) {
-                bf16x8 vc[4];
+                bf16x8 vc[NTL];
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) vc[nt] = vq[j][nt];
+                for (int nt = 0; nt < NTL; ++nt) vc[nt] = vq[j][nt];
                 if (pg + NW * kDepth < npages) load_v(pg + NW * kDepth, vq[j]);
                 bf16x8 pA;
 #pragma unroll
@@ -252,18 +260,18 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
                 }
                 if (pg == last_page) {  // new token's V from LDS; nothing beyond it may leak in (0 * garbage)
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
+                    for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             const int key = pg * kPage + (e < 4 ? g * 4 + e : 16 + g * 4 + e - 4);
                             short val = vc[nt][e];
-                            if (key == P) val = (short)vnew[nt * 16 + l15];
+                            if (key == P) val = (short)vnew[(nt0 + nt) * 16 + l15];
                             if (key > P) val = 0;
                             vc[nt][e] = val;
                         }
                 }
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) oacc[nt] = mfma16(pA, vc[nt], oacc[nt]);
+                for (int nt = 0; nt < NTL; ++nt) oacc[nt] = mfma16(pA, vc[nt], oacc[nt]);
             }
         }
     }
@@ -271,13 +279,13 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
     // D: col = d (l15 within tile nt), row = head g*4 + r
     if (g < 2) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) ored[w][g * 4 + r][nt * 16 + l15] = oacc[nt][r];
+            for (int r = 0; r < 4; ++r) ored[w][g * 4 + r][(nt0 + nt) * 16 + l15] = oacc[nt][r];
     }
     sync();
-    for (int t = tid; t < group * 64; t += NT) {
-        const int hh = t >> 6, d = t & 63;
+    for (int t = tid; t < group * 16 * NTL; t += NT) {
+        const int hh = t / (16 * NTL), d = nt0 * 16 + t % (16 * NTL);
         float o = ored[0][hh][d];
 #pragma unroll
         for (int ww = 1; ww < NW; ++ww) o += ored[ww][hh][d];            // ascending wave order
@@ -512,7 +520,7 @@ inline void attn_decode_launch(const AttnDecodeArgs& p, int batch, hipStream_t s
 inline void attn_decode_launch_small(const AttnDecodeArgs& p, int batch, hipStream_t s) {
     const dim3 grid(batch, p.nkv);
     if (p.tl) NTTS_LAUNCH((attn_decode_kernel<1, true, 5, 8>), grid, dim3(512), s, p);   // diagnostics: phase timestamps (waves 0..3)
-    else NTTS_LAUNCH((attn_decode_kernel<1, false, 5, 8>), grid, dim3(512), s, p);
+    else NTTS_LAUNCH((attn_decode_kernel<1, false, 5, 8, kAttnLMax, 4>), dim3(batch, p.nkv, 4), dim3(512), s, p);   // four workgroups per (sequence, kv-head): 16 output dimensions each
 }
 
 }  // namespace ntts
