@@ -511,6 +511,13 @@ inline void attn_split_launch(const AttnSplitArgs& q, int batch, hipStream_t s, 
 // max_context <= 1024 take the instantiation with half the score rows
 inline void attn_decode_launch(const AttnDecodeArgs& p, int batch, hipStream_t s, int max_ctx) {
     const dim3 grid(batch, p.nkv), block(256);
+    // Few sequences (at most 256 workgroups after the split: batch 9 .. 32 with 2 kv-heads): the small-batch form -- 8 waves, V^T requested next to K,
+    // four workgroups per (sequence, kv-head) with 16 output dimensions each (DS = 4).  Batch 16 / 32: 11.5 / 11.8 -> 8.1 / 8.4 us per launch, step
+    // 1.212 / 1.259 -> 1.129 / 1.177 ms; from 512 workgroups on (batch 64) it is equal, at batch 128 twice as slow (one sweep, one box).
+    if (!p.tl && batch * p.nkv * 4 <= 256) {
+        NTTS_LAUNCH((attn_decode_kernel<1, false, 5, 8, kAttnLMax, 4>), dim3(batch, p.nkv, 4), dim3(512), s, p);
+        return;
+    }
     if (p.tl) NTTS_LAUNCH((attn_decode_kernel<1, true, 1, 4, kAttnLMax>), grid, block, s, p);   // diagnostics: phase timestamps
     else if (max_ctx <= 1024) NTTS_LAUNCH((attn_decode_kernel<1, false, 1, 4, 1024>), grid, block, s, p);
     else NTTS_LAUNCH((attn_decode_kernel<1, false, 1, 4, kAttnLMax>), grid, block, s, p);
