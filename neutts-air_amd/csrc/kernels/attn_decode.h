@@ -78,10 +78,10 @@ NTTS_D void rope_pair(float x1, float x2, float c, float s, float& o1, float& o2
 //   is computed exactly as before (the other three quarters of the K stream are L2 hits).  No cross-workgroup exchange.
 template <int kDepth, bool kTimeline = false, int kVar = 1, int NW = 4, int LMAX = kAttnLMax, int DS = 1>
 NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
-    static_assert(DS == 1 || DS == 4, "output-dimension split");
+    static_assert(DS == 1 || DS == 2 || DS == 4, "output-dimension split");
     constexpr int NT = NW * 64;
-    constexpr int NTL = DS == 1 ? 4 : 1;                // PV tiles (16 output dimensions each) this workgroup computes
-    const int nt0 = DS == 1 ? 0 : (int)blockIdx.z;      // ... starting at tile nt0
+    constexpr int NTL = 4 / DS;                         // PV tiles (16 output dimensions each) this workgroup computes
+    const int nt0 = DS == 1 ? 0 : (int)blockIdx.z * NTL;   // ... starting at tile nt0
     NTTS_SHARED bf16_t sc[kGroupMax][LMAX + 16];        // rounded scores, 33 KB at 2048; +32 B/row de-aliases the LDS banks
     NTTS_SHARED bf16_t vnew[64];
     NTTS_SHARED float wred[NW][kGroupMax];
@@ -517,6 +517,10 @@ inline void attn_decode_launch(const AttnDecodeArgs& p, int batch, hipStream_t s
     if (!p.tl && batch * p.nkv * 4 <= 256) {
         NTTS_LAUNCH((attn_decode_kernel<1, false, 5, 8, kAttnLMax, 4>), dim3(batch, p.nkv, 4), dim3(512), s, p);
         return;
+    }
+    if (!p.tl && batch * p.nkv * 2 <= 256) {           // up to 256 workgroups with TWO per (sequence, kv-head), 32 dimensions each: batch 40 / 48 / 64
+        NTTS_LAUNCH((attn_decode_kernel<1, false, 5, 8, kAttnLMax, 2>), dim3(batch, p.nkv, 2), dim3(512), s, p);   // step 1.263 / 1.277 / 1.304 -> 1.191 / 1.203 / 1.236 ms;
+        return;                                                                                                 // batch 96 (384 workgroups): no gain, not used
     }
     if (p.tl) NTTS_LAUNCH((attn_decode_kernel<1, true, 1, 4, kAttnLMax>), grid, block, s, p);   // diagnostics: phase timestamps
     else if (max_ctx <= 1024) NTTS_LAUNCH((attn_decode_kernel<1, false, 1, 4, 1024>), grid, block, s, p);
