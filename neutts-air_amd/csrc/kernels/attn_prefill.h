@@ -357,8 +357,14 @@ NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
 }
 
 // host launcher: GH = 7 covers NeuTTS-Air's group in one pass; other group sizes run ceil(group / GH) passes
+// A SHORT pass (one to a few prompts) is a handful of (tile, kv-head) pairs: a 500-token prompt is 16 workgroups, each walking its pages for all 7
+// heads -- 54 us per launch, a third of the batch-1 prompt pass.  The heads of a group are independent, so while the grid stays within the CUs they are
+// spread over more workgroups (GH = 1 or 2 heads each, grid z = passes over the group; every pass stages the pages again, from L2): same arithmetic per head.
 inline void attn_prefill_launch(const AttnPrefillArgs& p, int n_tiles, hipStream_t s) {
     const int group = p.nh / p.nkv;
+    const long pairs = (long)p.nkv * n_tiles;
+    if (pairs * group <= 256) { NTTS_LAUNCH((attn_prefill_gqa_kernel<1>), dim3(p.nkv, n_tiles, group), dim3(256), s, p); return; }
+    if (pairs * ((group + 1) / 2) <= 256 && group > 2) { NTTS_LAUNCH((attn_prefill_gqa_kernel<2>), dim3(p.nkv, n_tiles, (group + 1) / 2), dim3(256), s, p); return; }
     if (group <= 4) NTTS_LAUNCH((attn_prefill_gqa_kernel<4>), dim3(p.nkv, n_tiles, 1), dim3(256), s, p);
     else NTTS_LAUNCH((attn_prefill_gqa_kernel<7>), dim3(p.nkv, n_tiles, (group + 6) / 7), dim3(256), s, p);
 }
