@@ -119,10 +119,14 @@ struct ntts_backbone {
     bool small = false;
     static constexpr int kSksO = 7, kSksD = 10;
     bf16_t* h_alt = nullptr;     // second residual-stream buffer (the fused prologue writes the new stream while others still read the old)
-    int attn_split = 8;          // context-split attention over this many workgroups per (sequence, kv-head) (NTTS_ATTN_SPLIT), used
-    int attn_split_ctx = 896;    //   once the longest running context reaches attn_split_ctx tokens (NTTS_ATTN_SPLIT_CTX).  Measured at batch 1
-                                 //   (profiles/r02i_sweep_split_*): context 625: 0.987 -> 1.025 ms per step (one more launch per layer, the
-                                 //   o_proj prologue sums 8 slabs); context 1850: 1.257 -> 1.093 ms (attention 23.3 -> 13.4 us); break-even ~870
+    int attn_split = 0;          // context-split attention over this many workgroups per (sequence, kv-head) (NTTS_ATTN_SPLIT; 0 = off, the default
+    int attn_split_ctx = 896;    //   since round 3), used once the longest running context reaches attn_split_ctx tokens (NTTS_ATTN_SPLIT_CTX).  Round 2, batch 1
+                                 //   (profiles/r02i_sweep_split_*): context 1850: 1.257 -> 1.093 ms, break-even ~870 -- against an attention kernel that spent 3 us in
+                                 //   a prologue and pulled a whole context through one CU.  Against the prologue-free kernel with the output dimensions split over
+                                 //   workgroups (attn_decode.h DS) the two-launch form LOSES at every batch and context it was used for (round 3, one box, split 8 vs
+                                 //   off, ms per step): batch 1 0.961 / 0.980 / 0.994 vs 0.871 / 0.917 / 0.972 at context 1010 / 1410 / 1810; batch 16 1.322 vs 1.184,
+                                 //   batch 64 1.526 vs 1.287, batch 128 1.833 vs 1.482 at context 1010 (1.383 / 1.637 / 1.998 vs 1.252 / 1.374 / 1.684 at 1610).  The
+                                 //   path stays available (and tested) behind the knob.
     bf16_t* as_scores = nullptr;  // [B * nkv][8][max_context + 16]
     float* as_stats = nullptr;    // [B * nkv][attn_split][8][2]
     float* as_oslabs = nullptr;   // [attn_split][B][nh * 64]
@@ -381,7 +385,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     }
     {
         // context-split attention (small-batch path; tile path below 2 workgroups per CU with split-K QKV slabs, bf16 engines)
-        e->attn_split = env_int("NTTS_ATTN_SPLIT", 8);
+        e->attn_split = env_int("NTTS_ATTN_SPLIT", 0);
         e->attn_split_ctx = env_int("NTTS_ATTN_SPLIT_CTX", 896);
         if (e->attn_split < 2 || e->attn_split > 32) e->attn_split = 0;
         if (e->fp8 || (!e->small && B * c->num_kv_heads >= 512)) e->attn_split = 0;   // (fp8: the combine pass writes bf16 rows / fp32 chunk slabs)
