@@ -416,7 +416,9 @@ static int codec_decode_impl(ntts_codec* c, int32_t n, const int32_t* codes, con
         AttnFullArgs at{};
         at.qkv = c->qkv; at.vt = c->vt; at.out = c->xb; at.R = R; at.C = H; at.nh = c->cfg.num_heads; at.npages = npages; at.qtiles = qtiles;
         if (c->attn_resident && npages <= kAttnResPages) {   // up to 256 frames: K / V^T resident in LDS, one sweep, no V^T pass
-            NTTS_LAUNCH((attn_full_resident_kernel), dim3(n, c->cfg.num_heads), dim3(512), st, at);
+            if (npages <= 8) NTTS_LAUNCH((attn_full_resident_kernel<8>), dim3(n, c->cfg.num_heads), dim3(512), st, at);
+            else if (npages <= 12) NTTS_LAUNCH((attn_full_resident_kernel<12>), dim3(n, c->cfg.num_heads), dim3(512), st, at);
+            else NTTS_LAUNCH((attn_full_resident_kernel<16>), dim3(n, c->cfg.num_heads), dim3(512), st, at);
         } else {
             VTransposeArgs vt{};
             vt.qkv = c->qkv; vt.vt = c->vt; vt.R = R; vt.C = H; vt.nh = c->cfg.num_heads; vt.npages = npages;

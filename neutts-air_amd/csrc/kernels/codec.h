@@ -447,13 +447,16 @@ NTTS_KERNEL(256) void attn_full_kernel(AttnFullArgs p) {
 // waveform tolerance -- the backbone's eager contract (P rounded AFTER the global normalisation) is not.
 // The rounding of P to bf16 before the PV product is the same 2^-9 relative perturbation as in attn_full_kernel.
 // Replaces hf:models/xcodec2/modeling_xcodec2.py:242-331 (Xcodec2Attention, non-causal) like attn_full_kernel.
-constexpr int kAttnResPages = 8;   // resident pages: 256 frames
+constexpr int kAttnResPages = 16;  // resident pages at most: 512 frames (NP = 8 / 12 / 16 instantiations: 64 / 96 / 128 KB of LDS)
 // 8 waves: the per-page chain K-MFMA -> row maximum (two cross-lane steps) -> exp -> PV-MFMA is serial inside a wave, and the 64 KB of
 // LDS allow two workgroups per CU -- with 4 waves each that was 2 waves per SIMD and the kernel ran at the latency of that chain
 // (289 us per launch; trimming its arithmetic changed nothing); 8 waves halve the query tiles per wave and double the waves per SIMD.
+// NP = pages the instantiation can hold (the launcher picks the smallest that fits the batch's longest utterance): 8 pages = 64 KB, two workgroups
+// per CU; 12 / 16 pages (384 / 512 frames: a ragged batch of 150-350-frame utterances used to fall to the paged two-sweep kernel as a whole) one.
+template <int NP>
 NTTS_KERNEL(512) void attn_full_resident_kernel(AttnFullArgs p) {
-    NTTS_SHARED bf16_t kres[kAttnResPages * kPage * 64];    // [page][32 keys][128 B], chunk c of key r at c ^ (r & 7)
-    NTTS_SHARED bf16_t vres[kAttnResPages * 64 * kPage];    // [page][64 d][64 B], 16-B unit u of row d at u ^ ((d >> 2) & 3)
+    NTTS_SHARED bf16_t kres[NP * kPage * 64];    // [page][32 keys][128 B], chunk c of key r at c ^ (r & 7)
+    NTTS_SHARED bf16_t vres[NP * 64 * kPage];    // [page][64 d][64 B], 16-B unit u of row d at u ^ ((d >> 2) & 3)
     const int lane = lane_id(), w = wave_id(), tid = threadIdx.x;
     const int g = lane >> 4, l15 = lane & 15;
     const int b = blockIdx.x, h = blockIdx.y;
@@ -461,7 +464,7 @@ NTTS_KERNEL(512) void attn_full_resident_kernel(AttnFullArgs p) {
     if (T < 1) return;                                         // block-uniform
     const long row0 = codec_row0(p.R, b);
     const long ld = 3L * p.C;
-    const int npg = (T + kPage - 1) / kPage;                  // <= kAttnResPages (launcher)
+    const int npg = (T + kPage - 1) / kPage;                  // <= NP (launcher)
     // ---- K: LDS-DMA, all pages requested at once (frames past T re-read the last one; masked below)
     for (int inst = w; inst < npg * 4; inst += 8) {           // one instruction = 8 keys x 128 B
         const int pg = inst >> 2, r = (inst & 3) * 8 + (lane >> 3);
