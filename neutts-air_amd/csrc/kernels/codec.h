@@ -152,7 +152,8 @@ NTTS_KERNEL(256) void groupnorm_silu_kernel(GroupNormArgs p) {
 // kernel above reads each value twice, 4 bytes at a time, one dependent iteration after the other: 205 us per launch at
 // 256 x 250 frames against ~70 us of bytes).  Same arithmetic per element; the sums run in another order.
 // grid (B, 32); block 256 = (256 / (cg/4) row lanes) x (cg/4 float4 lanes); needs cg % 4 == 0, 256 % (cg/4) == 0, T <= 8 * row lanes
-constexpr int kGnRegIters = 8;
+// kGnRegIters = row iterations per thread the instantiation holds in registers: 8 (256 frames at 32 row lanes) or 16 (512 frames)
+template <int kGnRegIters>
 NTTS_KERNEL(256) void groupnorm_silu_reg_kernel(GroupNormArgs p) {
     NTTS_SHARED float red[2][4];
     const int b = blockIdx.x, grp = blockIdx.y, tid = threadIdx.x;
@@ -206,7 +207,8 @@ NTTS_KERNEL(256) void groupnorm_silu_reg_kernel(GroupNormArgs p) {
 }
 inline void groupnorm_silu_launch(const GroupNormArgs& p, int Tmax, hipStream_t s) {
     const int cg = p.C / 32, vl = cg / 4;
-    if (cg % 4 == 0 && vl >= 1 && 256 % vl == 0 && Tmax <= kGnRegIters * (256 / vl)) NTTS_LAUNCH((groupnorm_silu_reg_kernel), dim3(p.R.B, 32), dim3(256), s, p);
+    if (cg % 4 == 0 && vl >= 1 && 256 % vl == 0 && Tmax <= 8 * (256 / vl)) NTTS_LAUNCH((groupnorm_silu_reg_kernel<8>), dim3(p.R.B, 32), dim3(256), s, p);
+    else if (cg % 4 == 0 && vl >= 1 && 256 % vl == 0 && Tmax <= 16 * (256 / vl)) NTTS_LAUNCH((groupnorm_silu_reg_kernel<16>), dim3(p.R.B, 32), dim3(256), s, p);
     else NTTS_LAUNCH((groupnorm_silu_kernel), dim3(p.R.B, 32), dim3(256), s, p);
 }
 
