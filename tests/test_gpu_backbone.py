@@ -68,11 +68,13 @@ def test_small_peaked_exact_tile_variants(lib, knobs, monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("max_batch", [64, 128, 256, 512])
+@pytest.mark.parametrize("max_batch", [16, 40, 64, 128, 256, 512])
 def test_xcd_row_block_placement(lib, max_batch, monkeypatch):
     """NTTS_XCD_AFFINE=7 at every batch size it applies to (8 / 4 / 2 / 1 XCDs per 64-row m-block): the split-K GEMMs, the norms
     behind them and decode attention place an m-block's rows on one group of XCDs -- a permutation of which workgroup does what.
-    Sequences in scattered slots (first, middle and last m-block) give the oracle's free-running ids."""
+    Sequences in scattered slots (first, middle and last m-block) give the oracle's free-running ids.  Batch 16 / 40 (no placement
+    there) and 64 also run the tile path's attention with the output dimensions split over four / two / two workgroups per
+    (sequence, kv-head) (attn_decode.h DS)."""
     monkeypatch.setenv("NTTS_XCD_AFFINE", "7")
     monkeypatch.setenv("NTTS_SMALL_BATCH", "0")
     cfg = br.BackboneConfig(vocab_size=3000, hidden_size=896, intermediate_size=1216, num_layers=2)
