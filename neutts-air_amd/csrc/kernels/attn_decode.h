@@ -522,6 +522,10 @@ inline void attn_decode_launch(const AttnDecodeArgs& p, int batch, hipStream_t s
         NTTS_LAUNCH((attn_decode_kernel<1, false, 5, 8, kAttnLMax, 2>), dim3(batch, p.nkv, 2), dim3(512), s, p);   // step 1.263 / 1.277 / 1.304 -> 1.191 / 1.203 / 1.236 ms;
         return;                                                                                                 // batch 96 (384 workgroups): no gain, not used
     }
+    if (!p.tl && batch * p.nkv <= 256) {               // at most one workgroup per CU: 8 waves (batch 96 / 128: 13.1 / 14.0 -> 10.3 / 11.6 us, step 1.322 / 1.384 ->
+        NTTS_LAUNCH((attn_decode_kernel<1, false, 1, 8, kAttnLMax, 1>), grid, dim3(512), s, p);   // 1.269 / 1.345 ms; batch 192 / 256, two per CU: equal or slower)
+        return;
+    }
     if (p.tl) NTTS_LAUNCH((attn_decode_kernel<1, true, 1, 4, kAttnLMax>), grid, block, s, p);   // diagnostics: phase timestamps
     else if (max_ctx <= 1024) NTTS_LAUNCH((attn_decode_kernel<1, false, 1, 4, 1024>), grid, block, s, p);
     else NTTS_LAUNCH((attn_decode_kernel<1, false, 1, 4, kAttnLMax>), grid, block, s, p);
