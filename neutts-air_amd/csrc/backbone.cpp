@@ -132,6 +132,7 @@ struct ntts_backbone {
     float* as_oslabs = nullptr;   // [attn_split][B][nh * 64]
     float* slabs2 = nullptr;     // down_proj's slabs (read by the next layer's QKV prologue while that kernel writes `slabs`)
     int n_cu = 256;
+    int x_gu_tile = 0, x_down_tile = 0;   // EXPERIMENT knobs (round 4 pricing of M = 768 steps; removed with the experiment)
 
     // prefill workspaces
     int Tmax = 0;
@@ -363,6 +364,9 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     if (e->head_tile != 0 && e->head_tile != 1 && e->head_tile != 2 && e->head_tile != 4) e->head_tile = 1;
     if (e->fp8 && e->head_tile == 4) e->head_tile = 2;          // (the natural-order tile is bf16 only)
     e->gu_128 = B > 128;
+    e->x_gu_tile = env_int("NTTS_X_GU_TILE", 0); e->x_down_tile = env_int("NTTS_X_DOWN_TILE", 0);
+    if (env_int("NTTS_X_KS_D", 0) > 0) e->ks_d = env_int("NTTS_X_KS_D", 0);
+    if (env_int("NTTS_X_KS_O", 0) > 0) e->ks_o = env_int("NTTS_X_KS_O", 0);
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
     e->small = B <= env_int("NTTS_SMALL_BATCH", 8) && B <= kGemvRows && H <= 1024 && V % 16 == 0 && e->NQKV % 16 == 0 && F % 32 == 0;   // (bf16 and fp8 models alike: gemv.h / qkv_rope.h F8 instantiations)
@@ -885,6 +889,9 @@ static void k_gate_up(ntts_backbone* e, int i) {
     //  bounds this kernel; profiles/r02h_sweep_gate_up_ring.log)
     // (natural-order gate/up tiles that use more CUs -- 128 x 80 as 244 workgroups of 4 or 8 waves, 128 x 96 as 204 -- measured
     //  15.5 / 13.7 / 14.1 vs 13.5 us and were removed: profiles/r02k_sweep_lpt_head_gu_tiles.log)
+    if (e->x_gu_tile == 1 && !e->fp8) { gemm_launch<4, 2, 4, EPI_SILU_MUL, 3>(gu, 1, e->stream); return; }   // EXPERIMENT (round 4 pricing): 256 x 128, 8 waves, 3 slots
+    if (e->x_gu_tile == 2 && !e->fp8) { gemm_launch<4, 2, 4, EPI_SILU_MUL, 2>(gu, 1, e->stream); return; }
+    if (e->x_gu_tile == 3 && !e->fp8) { gemm_launch<2, 2, 4, EPI_SILU_MUL, 2>(gu, 1, e->stream); return; }   // 128 x 128, 4 waves
     if (e->gu_128) {   // 128 x 128, 8 waves
         if (e->fp8) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3, 0, 64, false, true>(gu, 1, e->stream);
         else gemm_launch<4, 2, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);
@@ -896,6 +903,8 @@ static void k_down(ntts_backbone* e, int i) {
     GemmArgs a = gemm_args(e, e->act_dec, F, e->layers[i].wd, F, nullptr, e->slabs, H, B, H, F, e->layers[i].sd, e->layers[i].xs[3]);
     a.xcd_nsplit = -1;   // one K slice per XCD (pair) unless the row-block placement below applies (FETCH 15.0 -> 6.8 MB per launch, profiles/r02f_*)
     if ((e->xcd_affine & 2) && e->xcd_xps) a.xcd_maffine = -1;
+    if (e->x_down_tile == 1 && !e->fp8) { a.xcd_nsplit = 0; gemm_launch<4, 2, 1, EPI_SPLITK, 3>(a, e->ks_d, e->stream); return; }   // EXPERIMENT: 64 x 128, 8 waves
+    if (e->x_down_tile == 2 && !e->fp8) { a.xcd_nsplit = 0; gemm_launch<4, 2, 2, EPI_SPLITK, 3>(a, e->ks_d, e->stream); return; }   // 128 x 128, 8 waves
     gemm_skinny<EPI_SPLITK>(a, e->ks_d, e->stream);
 }
 

@@ -147,6 +147,8 @@ extern "C" int ntts_k_gemm_probe(int32_t M, int32_t N, int32_t K, int32_t config
     }
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
+    const int ks = config >= 1000 ? config / 1000 : 1;   // config = 1000 * ksplit + tile: the K split in gridDim.y (timing only: every split stores the same bf16 tile)
+    config %= 1000;
     const bool pf = (abl & 8) != 0;
     const int tile_major = (abl & 16) ? 1 : 0;     // weights addressed tile-major (same bytes, sequential per workgroup)
     abl &= 7;   // (bits 8, 16, 32 are handled here)
@@ -157,34 +159,34 @@ extern "C" int ntts_k_gemm_probe(int32_t M, int32_t N, int32_t K, int32_t config
         a.w_tile_major = tile_major;
         switch (config) {
             case 0: NTTS_LAUNCH((empty_kernel), dim3(256), dim3(64), (hipStream_t)0, (int*)nullptr); break;
-            case 10: probe_launch<4, 1, 1, 2>(a, 1, abl); break;   // 64 x 64, 4 waves
-            case 11: probe_launch<4, 1, 1, 3>(a, 1, abl); break;
-            case 12: probe_launch<4, 1, 1, 4>(a, 1, abl); break;
-            case 13: probe_launch<4, 1, 1, 6>(a, 1, abl); break;
-            case 20: probe_launch<2, 1, 1, 4>(a, 1, abl); break;   // 32 x 64, 2 waves
-            case 21: probe_launch<2, 1, 2, 4>(a, 1, abl); break;   // 64 x 64, 2 waves
-            case 22: probe_launch<1, 1, 4, 4>(a, 1, abl); break;   // 64 x 64, 1 wave
-            case 23: probe_launch<2, 2, 2, 3>(a, 1, abl); break;   // 64 x 128, 4 waves
-            case 24: probe_launch<4, 2, 1, 3>(a, 1, abl); break;   // 64 x 128, 8 waves
-            case 25: probe_launch<8, 1, 1, 3>(a, 1, abl); break;   // 128 x 64, 8 waves
-            case 26: probe_launch<4, 1, 2, 3>(a, 1, abl); break;   // 128 x 64, 4 waves
-            case 30: probe_launch<2, 2, 4, 2>(a, 1, abl); break;   // 128 x 128, 4 waves (prefill tile)
-            case 31: probe_launch<2, 2, 4, 3>(a, 1, abl); break;
-            case 40: probe_launch<4, 2, 4, 2>(a, 1, abl); break;   // 256 x 128, 8 waves
-            case 41: probe_launch<2, 4, 4, 2>(a, 1, abl); break;   // 128 x 256, 8 waves
-            case 42: probe_launch<4, 4, 4, 2>(a, 1, abl); break;   // 256 x 256, 16 waves
-            case 43: probe_launch<4, 2, 4, 3>(a, 1, abl); break;   // 256 x 128, 8 waves, 3 stages (144 KB)
-            case 44: probe_launch<2, 2, 8, 2>(a, 1, abl); break;   // 256 x 128, 4 waves (128 x 64 per wave)
-            case 45: probe_launch<2, 4, 8, 2>(a, 1, abl); break;   // 256 x 256, 8 waves (128 x 64 per wave)
-            case 46: probe_launch<4, 4, 4, 4, 32>(a, 1, abl); break;   // 256 x 256, 16 waves, 4 slots of K = 32 (128 KB)
-            case 47: probe_launch<4, 4, 4, 3, 32>(a, 1, abl); break;   // ... 3 slots (96 KB)
-            case 48: probe_launch<2, 4, 8, 4, 32>(a, 1, abl); break;   // 256 x 256, 8 waves, 4 slots of K = 32
-            case 49: probe_launch<2, 2, 4, 4, 32>(a, 1, abl); break;   // 128 x 128, 4 waves, 4 slots of K = 32 (64 KB: 2 blocks / CU)
-            case 50: probe_launch<4, 1, 4, 3>(a, 1, abl); break;   // 256 x 64, 4 waves: all decode rows in one block
-            case 51: probe_launch<8, 1, 2, 3>(a, 1, abl); break;   // 256 x 64, 8 waves
-            case 52: probe_launch<8, 1, 2, 2>(a, 1, abl); break;
-            case 53: probe_launch<8, 2, 2, 2>(a, 1, abl); break;   // 256 x 128, 16 waves
-            case 54: probe_launch<4, 2, 2, 3>(a, 1, abl); break;   // 128 x 128, 8 waves
+            case 10: probe_launch<4, 1, 1, 2>(a, ks, abl); break;   // 64 x 64, 4 waves
+            case 11: probe_launch<4, 1, 1, 3>(a, ks, abl); break;
+            case 12: probe_launch<4, 1, 1, 4>(a, ks, abl); break;
+            case 13: probe_launch<4, 1, 1, 6>(a, ks, abl); break;
+            case 20: probe_launch<2, 1, 1, 4>(a, ks, abl); break;   // 32 x 64, 2 waves
+            case 21: probe_launch<2, 1, 2, 4>(a, ks, abl); break;   // 64 x 64, 2 waves
+            case 22: probe_launch<1, 1, 4, 4>(a, ks, abl); break;   // 64 x 64, 1 wave
+            case 23: probe_launch<2, 2, 2, 3>(a, ks, abl); break;   // 64 x 128, 4 waves
+            case 24: probe_launch<4, 2, 1, 3>(a, ks, abl); break;   // 64 x 128, 8 waves
+            case 25: probe_launch<8, 1, 1, 3>(a, ks, abl); break;   // 128 x 64, 8 waves
+            case 26: probe_launch<4, 1, 2, 3>(a, ks, abl); break;   // 128 x 64, 4 waves
+            case 30: probe_launch<2, 2, 4, 2>(a, ks, abl); break;   // 128 x 128, 4 waves (prefill tile)
+            case 31: probe_launch<2, 2, 4, 3>(a, ks, abl); break;
+            case 40: probe_launch<4, 2, 4, 2>(a, ks, abl); break;   // 256 x 128, 8 waves
+            case 41: probe_launch<2, 4, 4, 2>(a, ks, abl); break;   // 128 x 256, 8 waves
+            case 42: probe_launch<4, 4, 4, 2>(a, ks, abl); break;   // 256 x 256, 16 waves
+            case 43: probe_launch<4, 2, 4, 3>(a, ks, abl); break;   // 256 x 128, 8 waves, 3 stages (144 KB)
+            case 44: probe_launch<2, 2, 8, 2>(a, ks, abl); break;   // 256 x 128, 4 waves (128 x 64 per wave)
+            case 45: probe_launch<2, 4, 8, 2>(a, ks, abl); break;   // 256 x 256, 8 waves (128 x 64 per wave)
+            case 46: probe_launch<4, 4, 4, 4, 32>(a, ks, abl); break;   // 256 x 256, 16 waves, 4 slots of K = 32 (128 KB)
+            case 47: probe_launch<4, 4, 4, 3, 32>(a, ks, abl); break;   // ... 3 slots (96 KB)
+            case 48: probe_launch<2, 4, 8, 4, 32>(a, ks, abl); break;   // 256 x 256, 8 waves, 4 slots of K = 32
+            case 49: probe_launch<2, 2, 4, 4, 32>(a, ks, abl); break;   // 128 x 128, 4 waves, 4 slots of K = 32 (64 KB: 2 blocks / CU)
+            case 50: probe_launch<4, 1, 4, 3>(a, ks, abl); break;   // 256 x 64, 4 waves: all decode rows in one block
+            case 51: probe_launch<8, 1, 2, 3>(a, ks, abl); break;   // 256 x 64, 8 waves
+            case 52: probe_launch<8, 1, 2, 2>(a, ks, abl); break;
+            case 53: probe_launch<8, 2, 2, 2>(a, ks, abl); break;   // 256 x 128, 16 waves
+            case 54: probe_launch<4, 2, 2, 3>(a, ks, abl); break;   // 128 x 128, 8 waves
             default: break;
         }
     };
