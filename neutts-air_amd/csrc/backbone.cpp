@@ -43,6 +43,7 @@ struct HostSlot {
     int pos_upper = 0;          // upper bound of the device-side pos
     std::vector<int> pages;     // KV pages of positions [32k, 32k+32); the leading ones may be shared (page_ref > 1)
     std::vector<int> prompt;    // prompt ids (what a later prompt must match to share this slot's prefix pages)
+    unsigned gen = 0;           // bumped whenever the slot changes hands (release, prefill): a snapshot entry only speaks for the occupant it saw
 };
 
 struct ntts_backbone {
@@ -132,7 +133,6 @@ struct ntts_backbone {
     float* as_oslabs = nullptr;   // [attn_split][B][nh * 64]
     float* slabs2 = nullptr;     // down_proj's slabs (read by the next layer's QKV prologue while that kernel writes `slabs`)
     int n_cu = 256;
-    int x_gu_tile = 0, x_down_tile = 0;   // EXPERIMENT knobs (round 4 pricing of M = 768 steps; removed with the experiment)
 
     // prefill workspaces
     int Tmax = 0;
@@ -147,6 +147,7 @@ struct ntts_backbone {
     // asynchronous slot snapshot (ntts_backbone_poll_begin / _end): state | n_new of every slot as of a point of the stream, in
     // page-locked memory; the copy stream carries the reads of finished slots' ids past the decode steps still queued
     int* snap_host = nullptr;          // [2 * max_batch]
+    std::vector<unsigned> snap_gen;    // HostSlot::gen of every slot when the open / last completed snapshot was enqueued
     hipEvent_t snap_ev = nullptr;
     bool snap_open = false, snap_valid = false;
     hipStream_t copy_stream = nullptr;
@@ -364,9 +365,6 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     if (e->head_tile != 0 && e->head_tile != 1 && e->head_tile != 2 && e->head_tile != 4) e->head_tile = 1;
     if (e->fp8 && e->head_tile == 4) e->head_tile = 2;          // (the natural-order tile is bf16 only)
     e->gu_128 = B > 128;
-    e->x_gu_tile = env_int("NTTS_X_GU_TILE", 0); e->x_down_tile = env_int("NTTS_X_DOWN_TILE", 0);
-    if (env_int("NTTS_X_KS_D", 0) > 0) e->ks_d = env_int("NTTS_X_KS_D", 0);
-    if (env_int("NTTS_X_KS_O", 0) > 0) e->ks_o = env_int("NTTS_X_KS_O", 0);
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
     e->small = B <= env_int("NTTS_SMALL_BATCH", 8) && B <= kGemvRows && H <= 1024 && V % 16 == 0 && e->NQKV % 16 == 0 && F % 32 == 0;   // (bf16 and fp8 models alike: gemv.h / qkv_rope.h F8 instantiations)
@@ -889,9 +887,6 @@ static void k_gate_up(ntts_backbone* e, int i) {
     //  bounds this kernel; profiles/r02h_sweep_gate_up_ring.log)
     // (natural-order gate/up tiles that use more CUs -- 128 x 80 as 244 workgroups of 4 or 8 waves, 128 x 96 as 204 -- measured
     //  15.5 / 13.7 / 14.1 vs 13.5 us and were removed: profiles/r02k_sweep_lpt_head_gu_tiles.log)
-    if (e->x_gu_tile == 1 && !e->fp8) { gemm_launch<4, 2, 4, EPI_SILU_MUL, 3>(gu, 1, e->stream); return; }   // EXPERIMENT (round 4 pricing): 256 x 128, 8 waves, 3 slots
-    if (e->x_gu_tile == 2 && !e->fp8) { gemm_launch<4, 2, 4, EPI_SILU_MUL, 2>(gu, 1, e->stream); return; }
-    if (e->x_gu_tile == 3 && !e->fp8) { gemm_launch<2, 2, 4, EPI_SILU_MUL, 2>(gu, 1, e->stream); return; }   // 128 x 128, 4 waves
     if (e->gu_128) {   // 128 x 128, 8 waves
         if (e->fp8) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3, 0, 64, false, true>(gu, 1, e->stream);
         else gemm_launch<4, 2, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);
@@ -903,8 +898,6 @@ static void k_down(ntts_backbone* e, int i) {
     GemmArgs a = gemm_args(e, e->act_dec, F, e->layers[i].wd, F, nullptr, e->slabs, H, B, H, F, e->layers[i].sd, e->layers[i].xs[3]);
     a.xcd_nsplit = -1;   // one K slice per XCD (pair) unless the row-block placement below applies (FETCH 15.0 -> 6.8 MB per launch, profiles/r02f_*)
     if ((e->xcd_affine & 2) && e->xcd_xps) a.xcd_maffine = -1;
-    if (e->x_down_tile == 1 && !e->fp8) { a.xcd_nsplit = 0; gemm_launch<4, 2, 1, EPI_SPLITK, 3>(a, e->ks_d, e->stream); return; }   // EXPERIMENT: 64 x 128, 8 waves
-    if (e->x_down_tile == 2 && !e->fp8) { a.xcd_nsplit = 0; gemm_launch<4, 2, 2, EPI_SPLITK, 3>(a, e->ks_d, e->stream); return; }   // 128 x 128, 8 waves
     gemm_skinny<EPI_SPLITK>(a, e->ks_d, e->stream);
 }
 
@@ -1335,6 +1328,7 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
     for (int i = 0; i < n; ++i) {
         HostSlot& s = e->slots[slots[i]];
         s.state = SLOT_RUNNING; s.prompt_len = lens[i]; s.max_len = samp[i].max_length; s.pos_upper = lens[i];
+        s.gen++;
         s.prompt.assign(ids + id_off[i], ids + id_off[i] + lens[i]);
     }
     e->pf_tokens_computed += T;
@@ -1467,6 +1461,8 @@ extern "C" int ntts_backbone_poll_begin(ntts_backbone* e) {
     HIPCHK(e, hipMemcpyAsync(e->snap_host, e->sl.state, B * sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipMemcpyAsync(e->snap_host + B, e->sl.n_new, B * sizeof(int), hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipEventRecord(e->snap_ev, e->stream));
+    e->snap_gen.resize(B);
+    for (int b = 0; b < B; ++b) e->snap_gen[b] = e->slots[b].gen;
     e->snap_open = true;
     e->snap_valid = false;
     return NTTS_OK;
@@ -1488,8 +1484,10 @@ extern "C" int ntts_backbone_poll_end(ntts_backbone* e, int32_t* state, int32_t*
 extern "C" int ntts_backbone_read_finished(ntts_backbone* e, int32_t slot, int32_t* out_ids, int32_t cap, int32_t* n_out) {
     if (!e || slot < 0 || slot >= e->cfg.max_batch || !n_out) return fail(e, NTTS_EINVAL, "bad argument");
     const int B = e->cfg.max_batch;
-    if (!e->snap_valid || e->snap_host[slot] != SLOT_FINISHED || e->slots[slot].state == SLOT_FREE)
-        return fail(e, NTTS_ESTATE, "slot %d was not finished in the last completed snapshot", slot);
+    // The snapshot entry speaks for the request that occupied the slot when poll_begin was enqueued: a release (+ a new prefill) since
+    // then -- before or after poll_end -- makes it stale, and the rows it points at are being overwritten by the new occupant
+    if (!e->snap_valid || e->snap_host[slot] != SLOT_FINISHED || e->slots[slot].state == SLOT_FREE || e->snap_gen[slot] != e->slots[slot].gen)
+        return fail(e, NTTS_ESTATE, "slot %d was not finished in the last completed snapshot (or was released / refilled since it was taken)", slot);
     HIPCHK(e, hipSetDevice(e->device));
     // A finished slot's ids do not change until it is released, and the snapshot that showed it finished has completed: the
     // copy needs no ordering against the decode steps still queued on the engine's stream, so it goes around them
@@ -1599,6 +1597,7 @@ static int release_host(ntts_backbone* e, int32_t slot) {   // host half of a re
     s.prompt.clear();
     if (s.sampling) { s.sampling = false; e->n_sampling--; }
     s.state = SLOT_FREE;
+    s.gen++;
     return NTTS_OK;
 }
 
@@ -1721,7 +1720,11 @@ extern "C" int ntts_backbone_attn_timeline(ntts_backbone* e, int32_t layer, uint
     unsigned long long* tl = (unsigned long long*)buf.p;
     HIPCHK(e, hipMemsetAsync(tl, 0, n * 8, e->stream));
     auto attn = [&](int i) { if (e->small) ks_attn(e, i); else k_attn(e, i); };
+    auto qkv = [&](int i) { if (e->small) ks_qkv(e, i); else k_qkv(e, i); };
     k_step_meta(e);
+    // the fused QKV kernel writes this step's K entry and the q | v row the attention kernel reads (the real step runs it first, too)
+    qkv((layer + 1) % e->cfg.num_layers);
+    qkv(layer);
     attn((layer + 1) % e->cfg.num_layers);     // another layer first: this launch is neither the first nor cache-warm
     e->attn_tl = tl;
     attn(layer);
@@ -1761,8 +1764,11 @@ extern "C" int ntts_backbone_gemv_timeline(ntts_backbone* e, int32_t which, int3
 
 // ------------------------------------------------------------------------------------------------
 // per-kernel timing at the CURRENT slot state (bench.py roofline leg).  Every kernel of the decode
-// step is idempotent with respect to the slot state (the attention kernel re-writes the same K/V
-// entry), so replaying one in isolation does not disturb generation.
+// step is idempotent with respect to the slot state (the fused QKV kernel re-writes the K entry of the
+// current position, the attention kernel its V^T entry), so replaying one in isolation does not disturb
+// generation.  The K entry of the current position is written by the QKV kernel, not by attention: the
+// attention replays below are preceded by ONE untimed QKV pass over every layer, as in the real step --
+// otherwise they would read a page slot no kernel has written yet (stale data of the page's last owner).
 // ------------------------------------------------------------------------------------------------
 extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_t iters, float* avg_ms, double* alg_bytes,
                                          int32_t* launches_per_step) {
@@ -1830,6 +1836,8 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
     }
     if (which == 6 && B > e->Tmax) return fail(e, NTTS_EINVAL, "scratch too small");
     k_step_meta(e);   // the fused QKV kernel appends at the CURRENT position (not yet written), like the step it replays
+    if (which == 0)
+        for (int i = 0; i < L; ++i) run(1, i);   // every layer's K entry + q | v row for the attention replays (untimed)
     run(which, L - 1);  // warm (code, TLBs); the timed replays start from layer 0
     HIPCHK(e, hipEventRecord(e->ev[2], st));
     for (int i = 0; i < iters; ++i) run(which, i % L);

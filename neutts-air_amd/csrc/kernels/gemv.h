@@ -271,6 +271,7 @@ inline int gemv_ksplit(int K, int ksplit) {
 
 template <int EPI, bool PRO, int FW = 4, bool F8 = false>
 inline void gemv_launch(GemvArgs p, int ksplit, hipStream_t s) {
+    static_assert(EPI != EPI_SPLITK || FW == 4, "the split-K instantiations below are written for 4 feature waves (grid, block and the helper barrier)");
     const int ktiles = p.K / (F8 ? 128 : 64);
     ksplit = gemv_ksplit(p.K / (F8 ? 2 : 1), ksplit);             // (PRO: the panel is the whole normalised row, K = H <= 1024; fp8: 128 k-values per k-tile)
     p.k_tiles_per_split = (ktiles + ksplit - 1) / ksplit;

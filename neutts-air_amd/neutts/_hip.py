@@ -534,6 +534,7 @@ class BackboneEngine:
         # owns it now only if the slot was (re)filled before snapshot q was enqueued
         snap_seq = 0                    # number of the next snapshot to be enqueued
         valid_from: Dict[int, int] = {}  # slot -> first snapshot number that describes its current request
+        steps_left: Dict[int, int] = {}  # slot -> decode steps its request can still take before max_length stops it (run-ahead: upper bound)
         open_snap: Optional[int] = None  # number of the snapshot opened by poll_begin and not read yet
 
         def find_donor(i):
@@ -566,6 +567,7 @@ class BackboneEngine:
                         used += cost
                         owner[s] = nxt
                         valid_from[s] = snap_seq
+                        steps_left[s] = sampling[nxt].max_length - len(prompts[nxt]) - 1
                         if share_prefix and d is None and len(anchors) < 16:
                             anchors.append((s, arrs[nxt]))      # a new beginning: later prompts may share it
                         nxt += 1
@@ -582,6 +584,7 @@ class BackboneEngine:
                         # ones finish and free their pages, then try again
                         for i, s in reversed(batch):
                             owner.pop(s)
+                            steps_left.pop(s, None)
                             committed.pop(s, None)
                             anchors = [a for a in anchors if a[0] != s]
                             self._free.append(s)
@@ -592,10 +595,29 @@ class BackboneEngine:
                 if run_ahead:
                     # keep the GPU fed: this burst goes in BEFORE the host looks at the previous burst's outcome.  Stream order per
                     # iteration j: [prompt pass j] [burst j] [exports / releases j] [snapshot j]; the host waits for snapshot j - 1
-                    # only, with burst j queued behind it
-                    self.decode(steps_per_poll)
+                    # only, with burst j queued behind it.  No burst when every owner has certainly stopped already (each has been
+                    # given the decode steps its max_length allows: the snapshots in flight will show them finished).
+                    burst_failed = None
+                    if any(steps_left.get(s, 1) > 0 for s in owner):
+                        try:
+                            self.decode(steps_per_poll)
+                            for s in owner:
+                                steps_left[s] = steps_left.get(s, 0) - steps_per_poll
+                        except NeuTTSHipError as ex:
+                            # Running one burst ahead, rows that have finished on the device still count as running on the host and
+                            # ntts_backbone_decode reserves KV pages for them (up to one page per slot): with a tightly sized pool that
+                            # can fail where the blocking scheduler succeeds.  Nothing was enqueued: drain the snapshot in flight,
+                            # release what has finished, and try again on the next iteration.
+                            if ex.code != -3:
+                                raise
+                            burst_failed = ex
                     if open_snap is None:
                         st = nn = None
+                        if burst_failed is not None:
+                            st, nn = self.poll()                      # blocking: everything enqueued so far
+                            q = snap_seq
+                            if not any(st[s] == 2 for s in owner):
+                                raise burst_failed                    # nothing to drain: the pool really is too small
                     else:
                         st, nn = self.poll_end()
                         q, open_snap = open_snap, None
@@ -613,6 +635,7 @@ class BackboneEngine:
                         committed.pop(s, None)
                         self.release(s)                          # shared pages live on until their last user is released
                         valid_from.pop(s, None)
+                        steps_left.pop(s, None)
                         anchors = [a for a in anchors if a[0] != s]
                 if run_ahead:
                     self.poll_begin()

@@ -559,10 +559,14 @@ class NeuTTS:
                         done[i] = True
                 if jobs:
                     wavs = self.codec.engine.decode([j[1] for j in jobs], reuse_output=True)     # one batched codec pass; views of the
-                    for (i, _, s0, s1, last), recon in zip(jobs, wavs):                           # engine's pinned buffer, copied below
-                        if self.watermarker is not None:
-                            recon = self.watermarker.apply_watermark(recon, sample_rate=24_000)
-                        yield i, blend[i].push(np.array(recon[s0:s1]), last=last)
+                    pieces = []                                                                   # engine's pinned buffer: EVERY job's slice is
+                    for (i, _, s0, s1, last), recon in zip(jobs, wavs):                           # copied out before the first yield -- while the
+                        if self.watermarker is not None:                                         # generator is suspended another decode on this
+                            recon = self.watermarker.apply_watermark(recon, sample_rate=24_000)   # codec engine may overwrite that buffer
+                        pieces.append((i, np.array(recon[s0:s1]), last))
+                    del wavs
+                    for i, piece, last in pieces:
+                        yield i, blend[i].push(piece, last=last)
                 if running and not self.streaming_overlap_compute:
                     eng.decode(chunk)
         finally:

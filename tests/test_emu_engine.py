@@ -216,3 +216,46 @@ def test_twin_engine_and_async_snapshots(emu_lib):
         assert st.tolist() == [0, 0] and e.free_slots() == 2
     assert got[0] == got[1]
     assert got[0][0] == z["bf16_ids_0"][:N].tolist() or sum(a == b for a, b in zip(got[0][0], z["bf16_ids_0"][:N].tolist())) >= N - 2
+
+
+def test_read_finished_refuses_a_stale_snapshot(emu_lib):
+    """a snapshot entry speaks for the request that occupied the slot when poll_begin was enqueued.  Both sequences
+    an external scheduler could run -- (a) poll_begin -> release -> prefill -> poll_end -> read_finished, (b) a completed snapshot that
+    showed the slot FINISHED, then release + prefill, then read_finished -- must fail with ESTATE instead of handing out the OLD count
+    together with rows the new request is overwriting; a fresh snapshot of the new occupant works again."""
+    z, cfg, w = load_fixture("backbone_tiny")
+    S, N, eos = int(z["s_len"]), 4, int(z["eos"])
+    eng = make_engine(cfg, w, emu_lib, max_batch=2)
+    samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
+    p0, p1 = br.synthetic_prompt(cfg, 0, S), br.synthetic_prompt(cfg, 1, S)
+    eng.prefill([p0], [0], [samp])
+    eng.decode(N)                                            # slot 0 is finished on the device
+    first = eng.read(0)[0]
+    # (a) the slot changes hands while the snapshot is open
+    eng.poll_begin()
+    eng.release(0)
+    eng.prefill([p1], [0], [samp])
+    st, nn = eng.poll_end()
+    assert st[0] == 2 and nn[0] == N                          # the snapshot itself still shows the OLD occupant, finished
+    with pytest.raises(_hip.NeuTTSHipError) as ei:
+        eng.read_finished(0)
+    assert ei.value.code == -4
+    # (b) the snapshot completed while the old occupant was there; the slot is refilled afterwards
+    eng.decode(N)
+    eng.poll_begin()
+    st, nn = eng.poll_end()
+    assert st[0] == 2
+    second = eng.read_finished(0)                            # valid: same occupant as in the snapshot
+    assert second == eng.read(0)[0] and second != first
+    eng.release(0)
+    with pytest.raises(_hip.NeuTTSHipError):
+        eng.read_finished(0)                                 # released: free
+    eng.prefill([p0], [0], [samp])
+    with pytest.raises(_hip.NeuTTSHipError) as ei:
+        eng.read_finished(0)                                 # refilled: the last completed snapshot is about somebody else
+    assert ei.value.code == -4
+    eng.decode(N)
+    eng.poll_begin()
+    eng.poll_end()
+    assert eng.read_finished(0) == first                     # a fresh snapshot of the new occupant
+    eng.close()
