@@ -118,6 +118,13 @@ ROCPROF_SYMBOLS = [   # rocprofv3 symbol prefix -> the step's logical kernels it
 ]
 
 
+def latest_profile(suffix):
+    """The newest committed profiles/rNN*<suffix> (files are named per round and session: r03i_..., r04b_...)."""
+    import glob
+    c = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]*" + suffix)))
+    return c[-1] if c else os.path.join(ROOT, "profiles", "missing" + suffix)
+
+
 def rocprof_symbols(path, live):
     """live: logical kernel -> (ms per launch, algorithmic bytes per launch, launches per step) from this run's HIP events."""
     try:
@@ -655,34 +662,55 @@ def main():
             log(f"[roofline] {name:24s} {ms * 1e3:8.1f} us/launch x {nl:3d} = {ms * nl:7.3f} ms/step   "
                 f"{nbytes / 1e6:9.2f} MB/launch   {nbytes / (ms * 1e-3) / 1e9:7.0f} GB/s")
         rows.sort(reverse=True)
-        _, name, ms, nbytes, nl = rows[0]
-        ach = nbytes / (ms * 1e-3) / 1e9
-        traffic, traffic_src = None, None
-        try:   # HBM bytes per launch from the committed PMC pass (tools/gpu_round.sh pmc -> tools/pmc_to_json.py): this configuration only
-            if nano or B != 256 or S != 500:
-                raise OSError("no PMC pass for this configuration")
-            with open(os.path.join(ROOT, "profiles", "r03i_pmc_traffic.json")) as fh:
-                pm = json.load(fh)
-            for kname, rec in pm["kernels"].items():
-                if kname.startswith(name):
-                    traffic = rec["fetch_bytes_per_launch"] + rec.get("write_bytes_per_launch_uncorrected", 0.0)
-                    traffic_src = "profiles/r03i_pmc_traffic.json: " + pm["source"]
-        except (OSError, KeyError, ValueError):
-            pass
+        live = {r[1]: (r[2], r[3], r[4]) for r in rows}
+        std_cfg = not nano and B == 256 and S == 500          # the configuration the committed rocprofv3 / PMC passes were taken on
         # rocprofv3 view of the same command (committed summary of the same configuration): per SYMBOL, since one gemm
-        # template serves three launches per layer.  `agree` = its average duration is within 15 % of this run's HIP events.
-        rocprof = None
-        if not nano and B == 256 and S == 500:
-            rocprof = rocprof_symbols(os.path.join(ROOT, "profiles", "r03i_bench_kernel_stats.txt"),
-                                      {r[1]: (r[2], r[3], r[4]) for r in rows})
+        # template serves two launches per layer.  `agree` = its average duration is within 15 % of this run's HIP events.
+        rocprof = rocprof_symbols(latest_profile("_bench_kernel_stats.txt"), live) if std_cfg else None
+        # HBM bytes per launch from the committed PMC passes (tools/gpu_round.sh pmc -> tools/pmc_to_json.py), per logical kernel, and
+        # the over-fetch ratio traffic / algorithmic bytes (> 1: re-reads through the fabric -- the first thing to fix where it costs time)
+        pmc, pmc_src = {}, None
+        try:
+            if not std_cfg:
+                raise OSError("no PMC pass for this configuration")
+            pm_path = latest_profile("_pmc_traffic.json")
+            with open(pm_path) as fh:
+                pm = json.load(fh)
+            pmc_src = os.path.relpath(pm_path, ROOT) + ": " + pm["source"]
+            for prefix, names in ROCPROF_SYMBOLS:
+                for kname, rec in pm["kernels"].items():
+                    if kname.startswith(prefix.rstrip(", ")) and all(n in live for n in names):
+                        tr = rec["fetch_bytes_per_launch"] + rec.get("write_bytes_per_launch_uncorrected", 0.0)
+                        nl_ = sum(live[n][2] for n in names)
+                        alg = sum(live[n][1] * live[n][2] for n in names) / nl_
+                        pmc["+".join(names)] = {"traffic_bytes_per_launch": tr, "alg_bytes_per_launch": alg, "overfetch": tr / alg}
+        except (OSError, KeyError, ValueError, TypeError):
+            pass
+        # The dominant kernel: by rocprofv3 SYMBOL share of the same command when the committed summary covers this configuration
+        # (VERDICT r3 item 5), else by this run's ms per step.  A symbol that serves several logical kernels (the split-K template:
+        # o_proj + down_proj) is reported as their launch-weighted mean.
+        names = [rows[0][1]]
+        choice = "largest ms/step among the step's logical kernels (HIP events, this run)"
+        if rocprof:
+            names = rocprof["symbols"][0]["serves"]
+            choice = f"largest rocprofv3 symbol share of the same command ({rocprof['summary']}: {rocprof['symbols'][0]['symbol']} {rocprof['symbols'][0]['share_pct']} %)"
+        nl = sum(live[n][2] for n in names)
+        ms = sum(live[n][0] * live[n][2] for n in names) / nl
+        nbytes = sum(live[n][1] * live[n][2] for n in names) / nl
+        name = "+".join(names)
+        ach = nbytes / (ms * 1e-3) / 1e9
+        traffic = pmc.get(name, {}).get("traffic_bytes_per_launch")
+        step_frac = step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
         roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": ms * 1e3,
+                "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": pmc_src if traffic is not None else None, "avg_launch_us": ms * 1e3,
                 "alg_bytes_per_launch": nbytes, "launches_per_step": nl,
-                "dominant_choice": "largest ms/step among the step's logical kernels (HIP events, this run); by rocprofv3 SYMBOL "
-                                   "share the split-K skinny GEMM template (qkv + o + down, 3 launches per layer) comes first: rocprof.symbols",
+                # the quantity BASELINE's target is stated on ("decode step at >= 60 % of the HBM roofline"): the WHOLE step, not its best kernel
+                "step_frac": step_frac, "step_ms": step_ms, "step_alg_bytes": step_bytes,
+                "dominant_choice": choice,
+                "pmc_per_kernel": pmc or None,
                 "rocprof": rocprof,
                 "per_kernel": [{"kernel": r[1], "us": r[2] * 1e3, "launches_per_step": r[4], "alg_bytes": r[3],
-                                "GBps": r[3] / (r[2] * 1e-3) / 1e9} for r in rows]}
+                                "GBps": r[3] / (r[2] * 1e-3) / 1e9, "frac": r[3] / (r[2] * 1e-3) / 1e9 / HBM_PEAK_GBPS} for r in rows]}
         step_info = {"ms": step_ms, "alg_bytes": step_bytes, "achieved_GBps": step_bytes / (step_ms * 1e-3) / 1e9,
                      "frac_of_hbm_peak": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "sum_of_isolated_kernels_ms": sum(r[0] for r in rows)}

@@ -2,6 +2,7 @@
 
 Run in the build container (needs `transformers`; nothing here runs on the GPU box):
     python -m oracle.gen_golden [--full] [--codec]
+    python -m oracle.gen_golden --walk          # the free-running fixtures (permutation-walk weights): small + NeuTTS-Air size
 
 Backbone: transformers.Qwen2ForCausalLM driven exactly like ref:neutts/neutts.py:338-347
 (`generate(..., use_cache=True, min_new_tokens=...)`, greedy so the result is reproducible),
@@ -61,19 +62,21 @@ def run_hf(m, prompt, n_new, eos, min_new):
     return ids, tv, ti
 
 
-def backbone_fixture(name, cfg, seed, utts, s_len, n_new, min_new, dtypes, init="unit", peak_sigma=0.0):
-    w = br.make_weights(cfg, seed, init=init, peak_sigma=peak_sigma)
+def backbone_fixture(name, cfg, seed, utts, s_len, n_new, min_new, dtypes, init="unit", peak_sigma=0.0, walk_gain=0.0, walk_scale=4.0):
+    w = br.make_weights(cfg, seed, init=init, peak_sigma=peak_sigma, walk_gain=walk_gain, walk_scale=walk_scale)
     eos = cfg.vocab_size - 1
     rec = dict(cfg=np.array(list(cfg.to_dict().items()), dtype=object), seed=seed, eos=eos, s_len=s_len,
-               n_new=n_new, min_new=min_new, utts=np.array(utts), init=init, peak_sigma=np.float32(peak_sigma))
+               n_new=n_new, min_new=min_new, utts=np.array(utts), init=init, peak_sigma=np.float32(peak_sigma),
+               walk_gain=np.float32(walk_gain), walk_scale=np.float32(walk_scale))
     for dtype, tag in dtypes:
         m = hf_backbone(cfg, w, dtype)
         for u in utts:
             prompt = br.synthetic_prompt(cfg, u, s_len)
             t = time.time()
             ids, tv, ti = run_hf(m, prompt, n_new, eos, min_new)
-            print(f"[{name}] {tag} utt {u}: {len(ids)} ids in {time.time() - t:.1f}s, "
-                  f"min top1-top2 margin {float((tv[:, 0] - tv[:, 1]).min()):.4g}")
+            ulps = (tv[:, 0] - tv[:, 1]) / 2.0 ** (np.floor(np.log2(np.abs(tv[:, 0]))) - 7)
+            print(f"[{name}] {tag} utt {u}: {len(ids)} ids ({len(set(ids))} distinct) in {time.time() - t:.1f}s, "
+                  f"min top1-top2 margin {float((tv[:, 0] - tv[:, 1]).min()):.4g} = {float(ulps.min()):.1f} bf16 ulps of the top logit")
             rec[f"{tag}_ids_{u}"] = np.array(ids, dtype=np.int64)
             rec[f"{tag}_topv_{u}"] = tv.astype(np.float32)
             rec[f"{tag}_topi_{u}"] = ti.astype(np.int64)
@@ -86,19 +89,25 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also the NeuTTS-Air-size fixture (minutes, ~6 GB RAM)")
     ap.add_argument("--codec", action="store_true", help="codec-decoder fixtures (xcodec2 @ hop 480)")
+    ap.add_argument("--walk", action="store_true", help="ONLY the permutation-walk fixtures (VERDICT r3 item 2): small + NeuTTS-Air size, 8 utterances")
     a = ap.parse_args()
+    if a.walk:
+        # greedy decoding walks a seeded permutation of the vocabulary (synthetic._make_walk): 250 DIFFERENT ids per utterance, every
+        # top-1 / top-2 margin tens of bf16 ulps wide -> free-running ids comparable id for id, no tie clause
+        cfgw = br.BackboneConfig(vocab_size=2048, hidden_size=896, intermediate_size=1216, num_layers=2)
+        backbone_fixture("backbone_small_walk", cfgw, 1, [0, 1], 70, 60, 60, [(torch.bfloat16, "bf16")], walk_gain=4.0, walk_scale=4.0)
+        backbone_fixture("backbone_air_walk8", br.BackboneConfig.neutts_air(), 0, list(range(8)), 500, 250, 250, [(torch.bfloat16, "bf16")],
+                         walk_gain=8.0, walk_scale=8.0)
+        return
     torch.manual_seed(0)
     both = [(torch.float32, "fp32"), (torch.bfloat16, "bf16")]
     backbone_fixture("backbone_tiny", br.BackboneConfig.tiny(), 0, [0, 1, 2], 37, 40, 10, both)
     # GQA with 2 kv heads + odd prompt lengths crossing a KV page boundary
     cfg2 = br.BackboneConfig(vocab_size=2048, hidden_size=896, intermediate_size=1216, num_layers=2)
     backbone_fixture("backbone_small", cfg2, 1, [0, 1], 70, 30, 30, both)
-    backbone_fixture("backbone_small_peaked", cfg2, 1, [0, 1], 70, 60, 60, both, peak_sigma=0.5)
     if a.full:
         bf = [(torch.bfloat16, "bf16")]
         backbone_fixture("backbone_air", br.BackboneConfig.neutts_air(), 0, [0, 1, 2, 3], 500, 250, 250, bf)
-        backbone_fixture("backbone_air_peaked", br.BackboneConfig.neutts_air(), 0, [0, 1], 500, 250, 250, bf,
-                         peak_sigma=0.5)
     if a.codec:
         from oracle import gen_golden_codec
         gen_golden_codec.main()

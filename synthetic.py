@@ -56,7 +56,7 @@ class BackboneConfig:
 # deterministic synthetic weights (numpy PCG64: stable across machines / torch versions)
 # --------------------------------------------------------------------------------------
 def make_weights(cfg: BackboneConfig, seed: int = 0, init: str = "unit",
-                 peak_sigma: float = 0.0) -> Dict[str, torch.Tensor]:
+                 peak_sigma: float = 0.0, walk_gain: float = 0.0, walk_scale: float = 4.0, walk_range=None) -> Dict[str, torch.Tensor]:
     """HF-named fp32 state dict (hf:models/qwen2/modeling_qwen2.py: names of Qwen2ForCausalLM).
 
     init="hf":   N(0, 0.02) matrices like HF's `_init_weights`.  With tied
@@ -66,6 +66,8 @@ def make_weights(cfg: BackboneConfig, seed: int = 0, init: str = "unit",
     peak_sigma:  multiply embedding row j by exp(N(0, peak_sigma)): heavy-tailed logits whose
                  top-1/top-2 gap is many bf16 ulps -> free-running greedy ids are comparable
                  bit-for-bit across implementations with different fp32 summation order.
+    walk_gain:   > 0: greedy decoding walks a seeded permutation of the vocabulary -- or of the ids in walk_range = (lo, hi), e.g. the
+                 speech tokens of a TTS tokenizer -- with wide margins (_make_walk below).
     Norm weights are 1 + N(0, 0.1) and biases N(0, 0.02) so every multiply/add is exercised.
     lm_head is tied to embed_tokens (hf:...modeling_qwen2.py:407 `_tied_weights_keys`).
     """
@@ -102,7 +104,73 @@ def make_weights(cfg: BackboneConfig, seed: int = 0, init: str = "unit",
         if peak_sigma > 0:
             head = head * torch.from_numpy(np.exp(rng.standard_normal(cfg.vocab_size, dtype=np.float32) * np.float32(peak_sigma)))[:, None]
         w["lm_head.weight"] = head
+    if walk_gain > 0:
+        _make_walk(cfg, w, seed, walk_scale, walk_gain, walk_range)
     return w
+
+
+def walk_permutation(cfg: BackboneConfig, seed: int, walk_range=None) -> np.ndarray:
+    """The successor table of make_weights(..., walk_gain > 0): nxt[j] = the token a greedy step emits after token j when nothing but
+    the construction speaks: ONE cycle through the ids of walk_range = (lo, hi) -- default: every id except the last one, which the
+    fixtures use as EOS; every id outside the range is its own successor."""
+    V = cfg.vocab_size
+    lo, hi = walk_range if walk_range is not None else (0, V - 1)
+    order = lo + np.random.default_rng(seed + 7919).permutation(hi - lo)
+    nxt = np.arange(V, dtype=np.int64)
+    nxt[order] = np.roll(order, -1)
+    return nxt
+
+
+def _make_walk(cfg: BackboneConfig, w: Dict[str, torch.Tensor], seed: int, scale: float, gain: float, walk_range=None) -> None:
+    """Re-shape the TIED embedding and the LAST layer's MLP of a unit-gain model so that greedy decoding walks a seeded permutation of
+    the vocabulary with top-1 / top-2 margins of tens of per cent of the top logit (hundreds of bf16 ulps) -- a free-running fixture
+    whose 250 ids are all DIFFERENT and cannot hinge on fp32 summation order (random-init logits are flat, 111 of
+    250 steps are near-ties; the `peak_sigma` fixtures collapse into fixed points).  Everything else stays what make_weights drew:
+    24 layers of attention and MLPs run on every token and perturb the logits; they just cannot overturn the construction.
+
+      hidden dims: A = [0, Hc)   B = [Hc, 2 Hc)   const = H - 1            (Hc = (H - 2) // 2)
+      embedding (tied head): E[k] = scale * [ c_k | c_{prev(k)} | 0 | kappa ]     c_j ~ N(0, 1)^Hc, prev = inverse permutation
+      last layer MLP, features r < Hc: gate_r = e_const, up_r = e_{A,r}, down[B_r][r] = beta; every other entry of those rows / that
+        column is zero.  With x = RMSNorm(h): silu(x_const) ~ x_const (it is ~ kappa >= 8), so the layer adds beta x_const x_A to the
+        B half of the residual stream: a copy of the CURRENT token's code c_j, `gain` times larger than the embedding's own entries.
+      logits: <norm(h), E[k]> ~ [ scale c_j . c_k ] + [ gain scale c_j . c_{prev(k)} ] + const: the second term peaks at
+        prev(k) = j, i.e. k = next(j), with Hc * gain against Hc for the token itself and ~ 4.5 sqrt(Hc) for any other id.
+    The features r >= Hc of the last MLP keep their random weights (the layer's arithmetic stays exercised)."""
+    V, H, F_ = cfg.vocab_size, cfg.hidden_size, cfg.intermediate_size
+    Hc = (H - 2) // 2
+    if F_ < Hc or Hc < 64:
+        raise ValueError("walk weights need hidden >= 130 and intermediate >= hidden / 2")
+    kappa = 8.0
+    rng = np.random.default_rng(seed + 104729)
+    codes = rng.standard_normal((V, Hc), dtype=np.float32)
+    nxt = walk_permutation(cfg, seed, walk_range)
+    prev = np.empty(V, dtype=np.int64)
+    prev[nxt] = np.arange(V)
+    emb = np.zeros((V, H), dtype=np.float32)
+    emb[:, :Hc] = codes
+    emb[:, Hc:2 * Hc] = codes[prev]
+    emb[:, H - 1] = kappa
+    emb *= np.float32(scale)
+    if not cfg.tie_word_embeddings:
+        # an untied head: the two matrices take DIFFERENT halves of the construction (reading the logits off the embedding instead of
+        # the head would make every step repeat its input token): embedding [ c_k | noise | 0 | kappa ], head [ noise | c_prev(k) | 0 | 0 ]
+        head = emb.copy()
+        head[:, :Hc] = rng.standard_normal((V, Hc), dtype=np.float32) * np.float32(0.25 * scale)
+        head[:, H - 1] = 0.0
+        emb[:, Hc:2 * Hc] = rng.standard_normal((V, Hc), dtype=np.float32) * np.float32(0.25 * scale)
+        w["lm_head.weight"] = torch.from_numpy(head)
+    w["model.embed_tokens.weight"] = torch.from_numpy(emb)
+    p = f"model.layers.{cfg.num_layers - 1}.mlp."
+    gate, up, down = w[p + "gate_proj.weight"], w[p + "up_proj.weight"], w[p + "down_proj.weight"]
+    gate[:Hc] = 0.0
+    gate[:Hc, H - 1] = 1.0
+    up[:Hc] = 0.0
+    up[torch.arange(Hc), torch.arange(Hc)] = 1.0
+    down[:, :Hc] = 0.0
+    # x_const ~ kappa * scale / rms(h) and rms(h) ~ scale * sqrt((2 Hc + kappa^2) / H) when the embedding dominates the stream:
+    # beta * x_const * x_A = gain * scale * c  (x_A ~ c / that same ratio)  =>  beta = gain * scale * ratio^2 / kappa
+    ratio2 = (2.0 * Hc + kappa * kappa) / H
+    down[Hc + torch.arange(Hc), torch.arange(Hc)] = float(gain * scale * ratio2 / kappa)
 
 
 # --------------------------------------------------------------------------------------

@@ -29,7 +29,7 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     cfg = br.BackboneConfig.tiny(vocab_size=512, num_layers=1)
     eng = _hip.BackboneEngine(engine_cfg(cfg, max_batch=2, max_context=64, max_prefill_tokens=128), local if backend == "nccl" else 0, lib)
-    w = br.make_weights(cfg, 17, peak_sigma=0.5)
+    w = br.make_weights(cfg, 17, walk_gain=4.0)
     if rank == 0:
         eng.load_state_dict({k: v.numpy() for k, v in w.items()}, inv_freq=br.rope_inv_freq(cfg).numpy())
     ndist.broadcast_weights(eng, src=0, device=torch.device("cuda", local) if backend == "nccl" else torch.device("cpu"))

@@ -15,7 +15,8 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def load_fixture(name):
     z = np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=True)
     cfg = br.BackboneConfig(**{k: v for k, v in z["cfg"]})
-    w = br.make_weights(cfg, int(z["seed"]), init=str(z["init"]), peak_sigma=float(z["peak_sigma"]))
+    walk = dict(walk_gain=float(z["walk_gain"]), walk_scale=float(z["walk_scale"])) if "walk_gain" in z.files else {}
+    w = br.make_weights(cfg, int(z["seed"]), init=str(z["init"]), peak_sigma=float(z["peak_sigma"]), **walk)
     return z, cfg, w
 
 
@@ -77,6 +78,19 @@ def teacher_forced_compare(eng, slot, gold_ids, gold_topv, gold_topi, max_ulps=2
 
 
 assert_free_run_matches = br.assert_free_run_matches
+
+
+def assert_varied(ids, frac=0.8):
+    """A free-running comparison only says something if the run is not a fixed point: `peak_sigma` weights collapse into 1-12
+    distinct ids per 250 steps; the walk weights (synthetic._make_walk) emit a new id every step."""
+    assert len(set(ids)) >= max(2, int(frac * len(ids))), f"degenerate run: {len(set(ids))} distinct ids in {len(ids)} steps"
+
+
+def assert_walk_exact(got, want):
+    """Walk weights: every top-1 / top-2 margin is tens of bf16 ulps wide, so free-running ids are compared id for id -- no tie clause."""
+    got, want = list(got), list(want)
+    assert got == want, f"first difference at step {next((i for i, (a, b) in enumerate(zip(got, want)) if a != b), min(len(got), len(want)))} of {len(want)}"
+    assert_varied(got)
 
 
 # ---------------------------------------------------------------------------------------------- codec

@@ -7,7 +7,7 @@ import torch
 
 from oracle import backbone_ref as br
 from neutts import _hip
-from common import assert_free_run_matches, load_fixture, make_engine, teacher_forced_compare
+from common import load_fixture, make_engine, teacher_forced_compare
 
 
 def test_tiny_teacher_forced(emu_lib):
@@ -33,14 +33,14 @@ def test_tiny_teacher_forced(emu_lib):
     {"NTTS_SMALL_BATCH": "0", "NTTS_HEAD_TILE": "1"},        # ... 128 x 128 lm_head tile
     # the lm_head's natural-order tile (gemm.h TN = 6: 256 x 288, 12 waves, uneven LDS-DMA loader split, partial last tile)
     {"NTTS_SMALL_BATCH": "0", "NTTS_HEAD_TILE": "4"}])
-def test_small_gqa2_page_crossing_peaked_exact(emu_lib, knobs, monkeypatch):
-    """2 kv heads, prompt of 70 (3 pages), decode crosses the 96-token page boundary; peaked weights so the
+def test_small_gqa2_page_crossing_walk_exact(emu_lib, knobs, monkeypatch):
+    """2 kv heads, prompt of 70 (3 pages), decode crosses the 96-token page boundary; walk weights (wide margins, a new id every step) so the
     free-running greedy ids must be bit-identical to HF's -- on the small-batch decode path (wave-per-16-features GEMVs with
     the fused norm prologue, slabs reduced in the attention prologue) and on the large-batch path (QKV with RoPE and the K append in
     its epilogue, attention without a prologue, split-K of o/down reduced in the norm kernel) with every lm_head tile."""
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
-    z, cfg, w = load_fixture("backbone_small_peaked")
+    z, cfg, w = load_fixture("backbone_small_walk")
     S, N, eos = int(z["s_len"]), (30 if not knobs else 27), int(z["eos"])   # 70 + 27 tokens cross the 96-token page boundary
     eng = make_engine(cfg, w, emu_lib, max_batch=1)
     samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
@@ -56,7 +56,7 @@ def test_short_sequence_beside_a_long_one_across_the_split_switch(emu_lib, monke
     one-page sequence beside a long one runs the split kernels with empty chunks -- each row must still match the oracle's solo run."""
     for k, v in {"NTTS_SMALL_BATCH": small_batch, "NTTS_ATTN_SPLIT": "3", "NTTS_ATTN_SPLIT_CTX": "40"}.items():
         monkeypatch.setenv(k, v)
-    z, cfg, w = load_fixture("backbone_small_peaked")
+    z, cfg, w = load_fixture("backbone_small_walk")
     wd = br.cast_weights(w, torch.bfloat16)
     N, eos = 8, int(z["eos"])
     prompts = [br.synthetic_prompt(cfg, 3, 6), br.synthetic_prompt(cfg, 0, 70)]
@@ -67,8 +67,7 @@ def test_short_sequence_beside_a_long_one_across_the_split_switch(emu_lib, monke
     eng.decode(N - 1)
     for s in (0, 1):
         ids, fin = eng.read(s)
-        assert fin and len(ids) == N
-        assert_free_run_matches(ids, want[s])
+        assert fin and ids == want[s].ids, (s, ids, want[s].ids)
 
 
 def test_xcd_row_block_placement(emu_lib, monkeypatch):
@@ -78,7 +77,7 @@ def test_xcd_row_block_placement(emu_lib, monkeypatch):
     give HF's ids bit for bit."""
     for k, v in {"NTTS_SMALL_BATCH": "0", "NTTS_XCD_AFFINE": "7"}.items():
         monkeypatch.setenv(k, v)
-    z, cfg, w = load_fixture("backbone_small_peaked")
+    z, cfg, w = load_fixture("backbone_small_walk")
     S, N, eos = int(z["s_len"]), 20, int(z["eos"])
     eng = make_engine(cfg, w, emu_lib, max_batch=64)
     samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
@@ -93,7 +92,7 @@ def test_continuous_batching_ragged_vs_oracle(emu_lib):
     """More prompts than slots, ragged prompt lengths, EOS stop before max_length, slot recycling:
     every prompt's ids equal the oracle's single-sequence run (ref:neutts/neutts.py:334-352 is batch 1)."""
     cfg = br.BackboneConfig.tiny(vocab_size=512, num_layers=1)
-    w = br.make_weights(cfg, 11, peak_sigma=0.5)
+    w = br.make_weights(cfg, 11, walk_gain=4.0)
     wd = br.cast_weights(w, torch.bfloat16)
     lens = [5, 33, 64, 17, 40]
     prompts = [br.synthetic_prompt(cfg, 10 + i, n) for i, n in enumerate(lens)]
@@ -107,9 +106,7 @@ def test_continuous_batching_ragged_vs_oracle(emu_lib):
     eng = make_engine(cfg, w, emu_lib, max_batch=2, max_prefill_tokens=128)
     samp = [_hip.Sampling(max_length=len(p) + 10, min_new_tokens=3, eos_token_id=eos, do_sample=False) for p in prompts]
     got = eng.generate(prompts, samp, steps_per_poll=3, prefill_token_budget=70)
-    for g, r in zip(got, want_r):
-        assert_free_run_matches(g, r)
-    assert sum(int(g == x) for g, x in zip(got, want)) >= len(want) - 1
+    assert got == want                                    # walk weights: wide margins, id for id
     # the scheduler runs one burst ahead of its bookkeeping by default (poll_begin / poll_end / read_finished): the ids cannot depend
     # on WHEN the host notices a finished row -- same result with the blocking poll, and with a device-side hand-off hook
     assert eng.generate(prompts, samp, steps_per_poll=3, prefill_token_budget=70, run_ahead=False) == got

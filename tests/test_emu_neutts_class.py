@@ -23,9 +23,8 @@ def build_tts(lib, bcfg=None, ccfg=None, max_batch=2, max_context=256, max_prefi
     n_codes = int(np.prod(ccfg.levels))
     tok = FakeTokenizer(n_codes)
     bcfg = bcfg(tok.vocab_size) if callable(bcfg) else br.BackboneConfig.tiny(vocab_size=tok.vocab_size, num_layers=1)
-    bw = br.make_weights(bcfg, seed, peak_sigma=0.5)
-    # bias the tied embedding towards speech tokens so that greedy decoding emits codec codes
-    bw["model.embed_tokens.weight"][tok.speech_base:] *= 3.0
+    # greedy decoding walks a permutation of the SPEECH tokens (synthetic._make_walk): it emits codec codes, a new one every step
+    bw = br.make_weights(bcfg, seed, walk_gain=4.0, walk_range=(tok.speech_base, tok.speech_base + n_codes))
     cw = cr.make_weights(ccfg, 2)
     ecfg = syn.EncoderConfig.tiny()      # reference encoder (encode_reference): FSQ levels independent of the tiny decoder's
     ew = syn.make_encoder_weights(ecfg, 4)

@@ -39,7 +39,7 @@ def _run(eng, prompts, donors, n_new, eos):
 
 def test_shared_prefill_is_bit_identical_to_plain_prefill(emu_lib):
     cfg = br.BackboneConfig.tiny(vocab_size=512, num_layers=2)
-    w = br.make_weights(cfg, 21, peak_sigma=0.5)
+    w = br.make_weights(cfg, 21, walk_gain=4.0)
     prefix, prompts = _prompts(cfg)
     eos = cfg.vocab_size - 1
     eng = make_engine(cfg, w, emu_lib, max_batch=6, max_context=160, max_prefill_tokens=512)
@@ -64,7 +64,7 @@ def test_donor_from_an_earlier_call_and_released_first(emu_lib):
     """The donor was prefilled earlier and has already decoded; it is released while its sharers still run: the shared
     pages stay alive (reference counts) and the sharers' results do not change."""
     cfg = br.BackboneConfig.tiny(vocab_size=512, num_layers=1)
-    w = br.make_weights(cfg, 22, peak_sigma=0.5)
+    w = br.make_weights(cfg, 22, walk_gain=4.0)
     prefix, prompts = _prompts(cfg)
     a, b, c = prompts[0], prompts[1], prompts[2]
     eos = cfg.vocab_size - 1
@@ -124,7 +124,7 @@ def test_shared_prefill_error_paths(emu_lib):
 def test_generate_with_share_prefix_equals_without(emu_lib):
     """Continuous batching (more prompts than slots) over two 'speakers': same ids with and without sharing."""
     cfg = br.BackboneConfig.tiny(vocab_size=512, num_layers=1)
-    w = br.make_weights(cfg, 24, peak_sigma=0.5)
+    w = br.make_weights(cfg, 24, walk_gain=4.0)
     rng = np.random.default_rng(9)
     tok = lambda n: rng.integers(0, cfg.vocab_size - 1, n).tolist()   # noqa: E731
     spk = [tok(70), tok(45)]

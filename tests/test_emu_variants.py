@@ -36,14 +36,14 @@ def test_untied_head_and_no_bias_match_oracle(lib, small_batch, monkeypatch):
         monkeypatch.setenv("NTTS_XL_MIN_M", "16")
     cfg = br.BackboneConfig(vocab_size=640, hidden_size=448, intermediate_size=1216, num_layers=2, num_heads=7, num_kv_heads=1,
                             attention_bias=False, tie_word_embeddings=False)
-    w = br.make_weights(cfg, 17, peak_sigma=0.5)
+    w = br.make_weights(cfg, 17, walk_gain=4.0)
     assert "lm_head.weight" in w and not any(k.endswith(".bias") for k in w)
     wd = br.cast_weights(w, torch.bfloat16)
     prompts = [br.synthetic_prompt(cfg, i, n) for i, n in enumerate((33, 7))]
     eng = _engine(cfg, w, lib)
     got = _run(eng, cfg, prompts, 8)
     for g, p in zip(got, prompts):
-        assert_free_run_matches(g, br.generate(cfg, wd, p, len(p) + 8, cfg.vocab_size - 1, min_new_tokens=8, keep_logits=True))
+        assert g == br.generate(cfg, wd, p, len(p) + 8, cfg.vocab_size - 1, min_new_tokens=8).ids and len(set(g)) == 8
     # the head really is the separate matrix: with the embedding in its place the ids change
     w2 = dict(w)
     w2["lm_head.weight"] = w["model.embed_tokens.weight"]

@@ -161,7 +161,7 @@ def test_engine_slot_pool_and_generate_cleanup(emu_lib):
     from neutts import _hip
     from common import engine_cfg
     cfg = br.BackboneConfig.tiny(vocab_size=256, num_layers=1)
-    w = br.make_weights(cfg, 2, peak_sigma=0.5)
+    w = br.make_weights(cfg, 2, walk_gain=4.0)
     eng = _hip.BackboneEngine(engine_cfg(cfg, max_batch=2, max_context=64, max_prefill_tokens=96, num_pages=3), 0, emu_lib)
     eng.load_state_dict({k: v.numpy() for k, v in w.items()}, inv_freq=br.rope_inv_freq(cfg).numpy())
     eos = cfg.vocab_size - 1

@@ -8,7 +8,7 @@ from oracle import backbone_ref as br
 from common import load_fixture
 
 CASES = [("backbone_tiny", "fp32"), ("backbone_tiny", "bf16"), ("backbone_small", "fp32"), ("backbone_small", "bf16"),
-         ("backbone_small_peaked", "bf16")]
+         ("backbone_small_walk", "bf16")]
 
 
 @pytest.mark.parametrize("name,tag", CASES)
