@@ -292,6 +292,8 @@ def main():
             codec_device=f"cuda:{dev}", do_sample=a.sample, max_batch=B, lib_path=lib)
         tts.watermarker = None
         tts._ids_to_codes = lambda ids: [int(i) % n_codes for i in ids]     # random weights do not stay in the speech range
+        tts._stream_modulo = n_codes                                         # ... the same rule for the device-side streaming path
+        tts.stream_on_device = not os.environ.get("NTTS_STREAM_HOST")        # (A/B aid: the round-3 host path)
         tts._ids_to_codes_array = lambda ids: (np.asarray(ids, dtype=np.int64) % n_codes).astype(np.int32)
         tts.min_new_tokens, tts.max_context = N, S + N
     eng = tts.backbone if strm else _hip.BackboneEngine(dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NTTS_ABI_VERSION 5
+#define NTTS_ABI_VERSION 6
 
 enum {
     NTTS_OK = 0,
@@ -186,6 +186,13 @@ int ntts_backbone_read_finished(ntts_backbone* e, int32_t slot, int32_t* out_ids
  * id mod n_codes.  Enqueued on the engine's stream (ntts_backbone_stream) behind the decode steps issued so far. */
 int ntts_backbone_export_codes(ntts_backbone* e, int32_t n, const int32_t* slots, int32_t speech_base, int32_t n_codes,
                                int32_t modulo, int32_t* codes_dev, int32_t stride, int32_t* lens_dev);
+/* ABI 6.  The same hand-off for STREAMS (ref:neutts/neutts.py:390-404 appends every generated "<|speech_N|>" token to the stream's token
+ * cache as it arrives): for stream i (decode slot slots[i], HOST array) the ids generated since the previous call -- counted by seen_dev[i] --
+ * are filtered / mapped like ntts_backbone_export_codes does and APPENDED to cache_dev[i * stride + clen_dev[i] ...]; clen_dev[i] and
+ * seen_dev[i] advance, fin_dev[i] = 1 once the slot has finished (EOS / max_length), else 0.  All four are DEVICE int32 arrays owned by the
+ * caller (ntts_streams_* below is the in-tree user).  Enqueued on the engine's stream behind the decode steps issued so far. */
+int ntts_backbone_append_codes(ntts_backbone* e, int32_t n, const int32_t* slots, int32_t speech_base, int32_t n_codes, int32_t modulo,
+                               int32_t* cache_dev, int32_t stride, int32_t* clen_dev, int32_t* seen_dev, int32_t* fin_dev);
 /* The engine's HIP stream (a hipStream_t), for a consumer that must order its own work behind the engine's. */
 int ntts_backbone_stream(ntts_backbone* e, void** stream);
 /* Serving-side scheduling knob (no reference counterpart: ref:neutts/neutts.py runs one utterance at a time): run this engine's
@@ -283,6 +290,10 @@ int ntts_codec_decode(ntts_codec* c, int32_t n, const int32_t* codes, const int3
 int ntts_codec_decode_dev(ntts_codec* c, int32_t n, const int32_t* codes_dev, int32_t codes_stride, const int32_t* lens,
                           float* wav_out, int64_t wav_stride, int32_t wav_on_device, void* producer_stream);
 int ntts_codec_sync(ntts_codec* c);
+/* ABI 6.  The codec engine's HIP stream (a hipStream_t) and its workspace limits (config fields max_frames / max_rows as created), for a
+ * consumer that puts its own kernels before / behind a decode pass (ntts_streams_*). */
+int ntts_codec_stream(ntts_codec* c, void** stream);
+int ntts_codec_limits(ntts_codec* c, int32_t* max_frames, int64_t* max_rows);
 /* The same knob for the codec engine: re-create its stream restricted to the CUs of `mask` (n_words = 0: unrestricted).  Blocking. */
 int ntts_codec_set_cu_mask(ntts_codec* c, const uint32_t* mask, int32_t n_words);
 /* Page-locked host memory for wav_out: a pinned destination lets the D2H copy run at PCIe speed (pageable memory is
@@ -291,6 +302,47 @@ int ntts_host_alloc(size_t bytes, void** out);
 int ntts_host_free(void* p);
 /* GPU milliseconds (hipEvents) of the most recent decode call, H2D/D2H excluded. */
 int ntts_codec_last_timing(ntts_codec* c, float* ms);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Device-side streaming (ABI 6): the per-chunk post-process of infer_stream for `n` concurrent    */
+/* utterances -- token cache, window assembly, the 27-frame slice and the triangular cross-fade    */
+/* with the previous chunk (ref:neutts/neutts.py:46-70, :385-388, :401-465) -- without the codes   */
+/* or the decoded windows visiting the host: per burst only a few integers per stream travel up    */
+/* and each stream's NEW samples come back.  Watermarking (ref :422-425, host library) is not      */
+/* part of it: a caller with a watermarker keeps the host path.                                    */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct ntts_streams ntts_streams;
+typedef struct ntts_stream_params {
+    int32_t chunk;          /* streaming_frames_per_chunk  25   ref:neutts/neutts.py:88 */
+    int32_t lookforward;    /* streaming_lookforward        5   ref :89 */
+    int32_t lookback;       /* streaming_lookback          50   ref :90 */
+    int32_t overlap;        /* streaming_overlap_frames     1   ref :87 */
+    int32_t hop_length;     /* 480                              ref :86 */
+    int32_t speech_base;    /* token id of "<|speech_0|>" */
+    int32_t n_codes;        /* 65 536 */
+    int32_t modulo;         /* != 0: every id becomes id mod n_codes (synthetic benchmark only, as ntts_backbone_export_codes) */
+} ntts_stream_params;
+const char* ntts_streams_last_error(const ntts_streams* s);
+/* Stream i runs in decode slot slots[i] of `e` (already prefilled); its token cache starts with its ref_lens[i] reference codes (packed
+ * back to back in ref_codes, HOST) -- ref :385-387 -- and can take max_new_tokens generated ones.  Windows are decoded by `c`. */
+int ntts_streams_create(ntts_backbone* e, ntts_codec* c, const ntts_stream_params* prm, int32_t device, int32_t n, const int32_t* slots,
+                        const int32_t* ref_codes, const int32_t* ref_lens, int32_t max_new_tokens, ntts_streams** out);
+void ntts_streams_destroy(ntts_streams* s);
+/* After a burst of decode steps has been ENQUEUED on the backbone: append the new codes to the caches and snapshot every stream's cache
+ * length / finished flag behind that burst (asynchronous; the caller may enqueue the NEXT burst right away -- it runs beside pump_end). */
+int ntts_streams_pump_begin(ntts_streams* s);
+/* Optional: wait for that snapshot alone and report how many streams were still generating in it -- what a caller needs to know before
+ * it enqueues the next burst (which then runs beside pump_end's codec passes). */
+int ntts_streams_pump_wait(ntts_streams* s, int32_t* n_running);
+/* Wait for that snapshot, decode every window it completes (one regular window per stream and round; a finished stream's final window
+ * once no regular one is left), cross-fade, and hand out the new samples: chunk k belongs to stream chunk_stream[k], has
+ * chunk_samples[k] samples at (*chunks) + k * (*row_stride) (page-locked memory owned by the set, valid until the next pump_end) and is
+ * the stream's last one if chunk_last[k].  cap >= 2 n entries in the three HOST arrays.  *n_running = streams still generating;
+ * *more = 1: further windows are already complete -- call pump_end again (without pump_begin) to get them.  Blocking. */
+int ntts_streams_pump_end(ntts_streams* s, int32_t cap, int32_t* n_chunks, int32_t* chunk_stream, int32_t* chunk_samples, int32_t* chunk_last,
+                          const float** chunks, int64_t* row_stride, int32_t* n_running, int32_t* more);
+/* Streams that have emitted their last chunk. */
+int ntts_streams_done(ntts_streams* s, int32_t* n_done);
 
 /* ------------------------------------------------------------------------------------------ */
 /* NeuCodec ENCODER engine: reference enrolment.  Replaces                                       */

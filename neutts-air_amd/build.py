@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["backbone.cpp", "kapi.cpp", "codec.cpp", "encoder.cpp"]
+SOURCES = ["backbone.cpp", "kapi.cpp", "codec.cpp", "encoder.cpp", "stream.cpp"]
 LIB = os.path.join(HERE, "libneutts_hip.so")
 EMU_DIR = os.path.join(ROOT, "tests", "simt_emu")
 EMU_LIB = os.path.join(EMU_DIR, "libneutts_emu.so")

@@ -1591,6 +1591,27 @@ extern "C" int ntts_backbone_export_codes(ntts_backbone* e, int32_t n, const int
     return NTTS_OK;
 }
 
+extern "C" int ntts_backbone_append_codes(ntts_backbone* e, int32_t n, const int32_t* slots, int32_t speech_base, int32_t n_codes, int32_t modulo,
+                                          int32_t* cache_dev, int32_t stride, int32_t* clen_dev, int32_t* seen_dev, int32_t* fin_dev) {
+    if (!e || n < 1 || !slots || !cache_dev || !clen_dev || !seen_dev || !fin_dev || stride < 1 || n_codes < 1) return fail(e, NTTS_EINVAL, "bad argument");
+    if (n > e->cfg.max_batch || (size_t)n > e->meta_cap) return fail(e, NTTS_EINVAL, "%d slots given, the engine has %d", n, e->cfg.max_batch);
+    {
+        std::vector<char> seen(e->cfg.max_batch, 0);
+        for (int i = 0; i < n; ++i) {
+            if (slots[i] < 0 || slots[i] >= e->cfg.max_batch) return fail(e, NTTS_EINVAL, "slot %d out of range", slots[i]);
+            if (seen[slots[i]]++) return fail(e, NTTS_EINVAL, "slot %d given twice", slots[i]);
+        }
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, upload_meta(e, slots, (size_t)n, e->stream));     // (stream-ordered behind whatever still reads the meta block)
+    AppendCodesArgs a{};
+    a.slots = e->meta_dev; a.sl = e->sl; a.speech_base = speech_base; a.n_codes = n_codes; a.modulo = modulo;
+    a.cache = cache_dev; a.stride = stride; a.clen = clen_dev; a.seen = seen_dev; a.fin = fin_dev;
+    NTTS_LAUNCH((append_codes_kernel), dim3(n), dim3(256), e->stream, a);
+    HIPCHK(e, hipGetLastError());
+    return NTTS_OK;
+}
+
 static int release_host(ntts_backbone* e, int32_t slot) {   // host half of a release: pages back to the pool, slot FREE
     HostSlot& s = e->slots[slot];
     drop_pages(e, s);

@@ -499,6 +499,18 @@ extern "C" int ntts_codec_sync(ntts_codec* c) {
     return NTTS_OK;
 }
 
+extern "C" int ntts_codec_stream(ntts_codec* c, void** stream) {
+    if (!c || !stream) return NTTS_EINVAL;
+    *stream = (void*)c->stream;
+    return NTTS_OK;
+}
+extern "C" int ntts_codec_limits(ntts_codec* c, int32_t* max_frames, int64_t* max_rows) {
+    if (!c || !max_frames || !max_rows) return NTTS_EINVAL;
+    *max_frames = c->cfg.max_frames;
+    *max_rows = c->max_rows;
+    return NTTS_OK;
+}
+
 extern "C" int ntts_host_alloc(size_t bytes, void** out) {
     if (!out || bytes == 0) return NTTS_EINVAL;
     return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? NTTS_OK : NTTS_ENOMEM;

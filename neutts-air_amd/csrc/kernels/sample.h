@@ -385,6 +385,55 @@ NTTS_KERNEL(256) void export_codes_kernel(ExportCodesArgs p) {
     if (tid == 0) p.lens[u] = base_s < p.stride ? base_s : p.stride;
 }
 
+// The same hand-off for STREAMS (ref:neutts/neutts.py:390-404: every generated "<|speech_N|>" token is appended to the stream's token
+// cache as it arrives): of slot s's ids generated since the previous call (seen[u]), the speech codes are appended to the stream's
+// device-side code cache behind its clen[u] entries; seen / clen are advanced and the slot's state is reported.  One workgroup per stream.
+struct AppendCodesArgs {
+    const int* slots;       // [n] decode slots
+    SlotArrays sl;
+    int speech_base, n_codes, modulo;
+    int* cache;             // [n][stride] reference codes + generated codes so far
+    int stride;
+    int* clen;              // [n] codes in cache[u]
+    int* seen;              // [n] generated ids already looked at
+    int* fin;               // [n] out: 1 once the slot has finished (EOS / max_length) -- with everything it generated appended
+};
+NTTS_KERNEL(256) void append_codes_kernel(AppendCodesArgs p) {
+    NTTS_SHARED int wcount[4];
+    NTTS_SHARED int base_s;
+    const int u = blockIdx.x, s = p.slots[u], tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int st = p.sl.state[s];
+    const int n = (st == SLOT_RUNNING || st == SLOT_FINISHED) ? p.sl.n_new[s] : 0;
+    const int from = p.seen[u];
+    const int* ids = p.sl.out_tokens + (long)s * p.sl.out_stride;
+    if (tid == 0) base_s = p.clen[u];
+    sync();
+    for (int t0 = from; t0 < n; t0 += 256) {      // order-preserving compaction, 256 ids per round (export_codes_kernel)
+        const int t = t0 + tid;
+        int code = -1;
+        if (t < n) {
+            const int id = ids[t];
+            if (p.modulo) code = id % p.n_codes;
+            else if (id >= p.speech_base && id < p.speech_base + p.n_codes) code = id - p.speech_base;
+        }
+        const unsigned long long m = ballot(code >= 0);
+        const int before = popc64(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wcount[w] = popc64(m);
+        sync();
+        int off = base_s;
+        for (int k = 0; k < w; ++k) off += wcount[k];
+        if (code >= 0 && off + before < p.stride) p.cache[(long)u * p.stride + off + before] = code;
+        sync();
+        if (tid == 0) base_s += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        sync();
+    }
+    if (tid == 0) {
+        p.clen[u] = base_s < p.stride ? base_s : p.stride;
+        p.seen[u] = n > from ? n : from;
+        p.fin[u] = st == SLOT_FINISHED ? 1 : 0;
+    }
+}
+
 // fp8 model: one source row -> e4m3 bytes + its scale.  The row is first rounded to bf16 (what the bf16 checkpoint holds), then
 // scale = max|w| / 448 (1 for an all-zero row), w_q = e4m3(w / scale) -- per output channel, as static-fp8 checkpoints store
 // them.  Layout of the byte matrix: tile-major in 64-row x 128-byte blocks (gemm.h F8).

@@ -18,7 +18,7 @@ DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "libneutts_hip.so")
 
 NTTS_DT_F32, NTTS_DT_BF16, NTTS_DT_I32 = 0, 1, 2
 NTTS_W_BF16, NTTS_W_FP8_E4M3 = 0, 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 NTTS_PAGE_TOKENS = 32            # include/neutts_hip.h
 PAGE_TOKENS = 32
 ERRORS = {-1: "EINVAL", -2: "ENODEV", -3: "ENOMEM", -4: "ESTATE", -5: "EHIP"}
@@ -51,6 +51,11 @@ class EncoderConfigC(C.Structure):
                 ("sem_conv_kernel", C.c_int32), ("sem_left", C.c_int32), ("sem_right", C.c_int32), ("sem_ln_eps", C.c_float),
                 ("ac_hidden", C.c_int32), ("n_ratios", C.c_int32), ("ratios", C.c_int32 * 8), ("codec_hidden", C.c_int32),
                 ("n_levels", C.c_int32), ("levels", C.c_int32 * 8), ("max_samples", C.c_int32)]
+
+
+class StreamParamsC(C.Structure):
+    _fields_ = [("chunk", C.c_int32), ("lookforward", C.c_int32), ("lookback", C.c_int32), ("overlap", C.c_int32),
+                ("hop_length", C.c_int32), ("speech_base", C.c_int32), ("n_codes", C.c_int32), ("modulo", C.c_int32)]
 
 
 class SamplingC(C.Structure):
@@ -105,6 +110,17 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_backbone_release_many": (C.c_int, [p, i32, C.POINTER(i32)]),
         "ntts_backbone_export_codes": (C.c_int, [p, i32, C.POINTER(i32), i32, i32, i32, p, i32, p]),
         "ntts_backbone_stream": (C.c_int, [p, C.POINTER(p)]),
+        "ntts_backbone_append_codes": (C.c_int, [p, i32, C.POINTER(i32), i32, i32, i32, p, i32, p, p, p]),
+        "ntts_codec_stream": (C.c_int, [p, C.POINTER(p)]),
+        "ntts_codec_limits": (C.c_int, [p, C.POINTER(i32), C.POINTER(i64)]),
+        "ntts_streams_last_error": (C.c_char_p, [p]),
+        "ntts_streams_create": (C.c_int, [p, p, C.POINTER(StreamParamsC), i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32, C.POINTER(p)]),
+        "ntts_streams_destroy": (None, [p]),
+        "ntts_streams_pump_begin": (C.c_int, [p]),
+        "ntts_streams_pump_wait": (C.c_int, [p, C.POINTER(i32)]),
+        "ntts_streams_pump_end": (C.c_int, [p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(C.POINTER(f32)),
+                                            C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]),
+        "ntts_streams_done": (C.c_int, [p, C.POINTER(i32)]),
         "ntts_codec_decode_dev": (C.c_int, [p, i32, p, i32, C.POINTER(i32), p, i64, i32, p]),
         "ntts_codec_sync": (C.c_int, [p]),
         "ntts_codec_set_cu_mask": (C.c_int, [p, C.POINTER(C.c_uint32), i32]),
@@ -797,6 +813,75 @@ class CodecEngine:
         ms = C.c_float()
         self._chk(self.lib.ntts_codec_last_timing(self.h, C.byref(ms)))
         return ms.value
+
+
+class StreamSet:
+    """Device-side streaming state of `n` concurrent infer_stream utterances (ntts_streams_*, ABI 6): token caches, window assembly,
+    the 27-frame slice and the cross-fade with the previous chunk (ref:neutts/neutts.py:385-388, :401-465) run on the device; per burst
+    the host sees a few integers per stream and receives each stream's new samples."""
+
+    def __init__(self, backbone: "BackboneEngine", codec: "CodecEngine", slots: Sequence[int], ref_codes: Sequence[Sequence[int]],
+                 max_new_tokens: int, chunk: int, lookforward: int, lookback: int, overlap: int, hop_length: int, speech_base: int,
+                 n_codes: int, modulo: bool = False):
+        self.lib = backbone.lib
+        self.n = len(slots)
+        prm = StreamParamsC(chunk, lookforward, lookback, overlap, hop_length, speech_base, n_codes, int(bool(modulo)))
+        sl = np.ascontiguousarray(slots, dtype=np.int32)
+        lens = np.array([len(r) for r in ref_codes], dtype=np.int32)
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(r, dtype=np.int32) for r in ref_codes]) if lens.sum() else np.zeros(1, np.int32))
+        i32p = C.POINTER(C.c_int32)
+        h = C.c_void_p()
+        rc = self.lib.ntts_streams_create(backbone.h, codec.h, C.byref(prm), backbone._device, self.n, sl.ctypes.data_as(i32p),
+                                          flat.ctypes.data_as(i32p), lens.ctypes.data_as(i32p), int(max_new_tokens), C.byref(h))
+        if rc != 0:
+            raise NeuTTSHipError(rc, (self.lib.ntts_streams_last_error(None) or b"").decode())
+        self.h = h
+        self._keep = (backbone, codec)                                   # the set borrows both engines
+        cap = 2 * self.n
+        self._cs, self._cn, self._cl = (np.zeros(cap, dtype=np.int32) for _ in range(3))
+
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise NeuTTSHipError(rc, (self.lib.ntts_streams_last_error(self.h) or b"").decode())
+
+    def pump_begin(self):
+        """Append the ids generated so far to the caches and snapshot the streams behind the decode steps enqueued so far (async)."""
+        self._chk(self.lib.ntts_streams_pump_begin(self.h))
+
+    def pump_wait(self) -> int:
+        """Wait for the snapshot of pump_begin alone; returns the number of streams still generating in it."""
+        run = C.c_int32()
+        self._chk(self.lib.ntts_streams_pump_wait(self.h, C.byref(run)))
+        return run.value
+
+    def pump_end(self):
+        """-> (chunks, n_running, more): chunks = [(stream, samples (view of pinned memory, valid until the next pump_end), last)]."""
+        i32p = C.POINTER(C.c_int32)
+        n, run, more = C.c_int32(), C.c_int32(), C.c_int32()
+        ptr, stride = C.POINTER(C.c_float)(), C.c_int64()
+        self._chk(self.lib.ntts_streams_pump_end(self.h, len(self._cs), C.byref(n), self._cs.ctypes.data_as(i32p), self._cn.ctypes.data_as(i32p),
+                                                 self._cl.ctypes.data_as(i32p), C.byref(ptr), C.byref(stride), C.byref(run), C.byref(more)))
+        out = []
+        if n.value:
+            buf = np.ctypeslib.as_array(ptr, shape=(n.value, stride.value))
+            out = [(int(self._cs[k]), buf[k, : int(self._cn[k])], bool(self._cl[k])) for k in range(n.value)]
+        return out, run.value, bool(more.value)
+
+    def done(self) -> int:
+        d = C.c_int32()
+        self._chk(self.lib.ntts_streams_done(self.h, C.byref(d)))
+        return d.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ntts_streams_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class EncoderEngine:

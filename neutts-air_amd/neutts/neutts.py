@@ -488,6 +488,47 @@ class NeuTTS:
             eng.release(slot)
 
 
+    # ---- device-side streaming (csrc/stream.cpp, ABI 6)
+    def _stream_on_device(self, ref_codes) -> bool:
+        # the device path covers what the class does by default: ids -> codes by the speech-token range (or the synthetic benchmark's
+        # modulo rule), no watermarker (Perth runs on the host, ref:neutts/neutts.py:422-425), every stream opened by >= overlap codes
+        if self.watermarker is not None or not getattr(self, "stream_on_device", True):
+            return False
+        if not getattr(self, "_stream_modulo", 0) and (self._speech_base is None or "_ids_to_codes" in self.__dict__):
+            return False
+        return min(len(rc) for rc in ref_codes) >= self.streaming_overlap_frames
+
+    def _stream_batch_device(self, slots, ref_codes):
+        """The loop of _infer_stream_batch_hip with the token caches, the window assembly, the 27-frame slice and the cross-fade on the
+        device (ntts_streams_*): per burst the host waits for a snapshot of 2 n integers, enqueues the next burst, and receives each
+        stream's new samples.  Same windows, same arithmetic (kernels/stream.h restates numpy's operations one by one): the chunks are
+        bit-identical to the host path's."""
+        eng = self.backbone
+        chunk, look_f = self.streaming_frames_per_chunk, self.streaming_lookforward
+        mod = int(getattr(self, "_stream_modulo", 0))
+        ss = _hip.StreamSet(eng, self.codec.engine, slots, ref_codes, int(eng.cfg["max_context"]), chunk, look_f, self.streaming_lookback,
+                            self.streaming_overlap_frames, self.hop_length, 0 if mod else int(self._speech_base), mod or 65536, bool(mod))
+        try:
+            # the first window is complete once chunk + lookforward tokens exist (ref :401-404) and the prompt pass produced one of them
+            steps = chunk + look_f - 1
+            while True:
+                ss.pump_begin()                           # behind everything enqueued so far
+                running = ss.pump_wait()
+                if running and self.streaming_overlap_compute:
+                    eng.decode(steps)                     # async: runs beside the codec passes of pump_end
+                more = True
+                while more:
+                    chunks, _, more = ss.pump_end()
+                    for i, samples, _last in chunks:
+                        yield i, np.array(samples)        # (the pinned buffer is reused by the next pump)
+                if running and not self.streaming_overlap_compute:
+                    eng.decode(steps)
+                if not running:
+                    break
+                steps = chunk
+        finally:
+            ss.close()
+
     def _infer_stream_batch_hip(self, prompts: List[List[int]], ref_codes: List[List[int]]):
         eng = self.backbone
         n = len(prompts)
@@ -513,7 +554,16 @@ class NeuTTS:
         hop, stride = self.hop_length, self.streaming_stride_samples
         chunk, look_f, look_b, ovl = (self.streaming_frames_per_chunk, self.streaming_lookforward,
                                       self.streaming_lookback, self.streaming_overlap_frames)
-        # per utterance: reference codes + generated codes, in one int32 row (the reference caches "<|speech_N|>" strings)
+        if self._stream_on_device(ref_codes):
+            try:
+                yield from self._stream_batch_device(slots, ref_codes)
+            finally:
+                eng.sync()
+                for s in slots:
+                    eng.release(s)
+            return
+        # ---- host path (a watermarker is a host library; an id -> code rule other than the speech-token range): per utterance the
+        #      reference codes + generated codes in one int32 row (the reference caches "<|speech_N|>" strings)
         cap = max(len(rc) for rc in ref_codes) + int(eng.cfg["max_context"]) + 1
         cache = np.zeros((n, cap), dtype=np.int32)
         clen = np.zeros(n, dtype=np.int64)                # tokens in cache[i]

@@ -42,10 +42,10 @@ def backbone_config(vocab):
     return br.BackboneConfig(vocab_size=vocab)          # NeuTTS-Air's layer geometry; the vocabulary is the stand-in tokenizer's
 
 
-def make_backbone_weights(cfg, speech_base):
-    w = br.make_weights(cfg, SEED_BACKBONE, peak_sigma=0.5)
-    w["model.embed_tokens.weight"][speech_base:] *= 3.0       # greedy decoding stays in the speech range (as the class tests do)
-    return w
+def make_backbone_weights(cfg, speech_base, n_codes):
+    # greedy decoding walks a permutation of the speech tokens with wide margins (synthetic._make_walk; the recipe of
+    # tests/test_emu_neutts_class.py build_tts at 24 layers): 120 different codec codes, ids comparable id for id
+    return br.make_weights(cfg, SEED_BACKBONE, walk_gain=8.0, walk_scale=8.0, walk_range=(speech_base, speech_base + n_codes))
 
 
 def apply_chat_template(tok, phon, ref_codes, ref_text, input_text):
@@ -74,7 +74,7 @@ def main():
     ccfg = cr.CodecConfig.neucodec()
     tok = FakeTokenizer(int(np.prod(ccfg.levels)))
     cfg = backbone_config(tok.vocab_size)
-    w = make_backbone_weights(cfg, tok.speech_base)
+    w = make_backbone_weights(cfg, tok.speech_base, int(np.prod(ccfg.levels)))
     eos = tok.convert_tokens_to_ids("<|SPEECH_GENERATION_END|>")
     prompt = apply_chat_template(tok, FakePhonemizer(), dave, REF_TEXT, TEXT)
     m = hf_backbone(cfg, w, torch.bfloat16)

@@ -24,7 +24,8 @@ def build_tts(lib, bcfg=None, ccfg=None, max_batch=2, max_context=256, max_prefi
     tok = FakeTokenizer(n_codes)
     bcfg = bcfg(tok.vocab_size) if callable(bcfg) else br.BackboneConfig.tiny(vocab_size=tok.vocab_size, num_layers=1)
     # greedy decoding walks a permutation of the SPEECH tokens (synthetic._make_walk): it emits codec codes, a new one every step
-    bw = br.make_weights(bcfg, seed, walk_gain=4.0, walk_range=(tok.speech_base, tok.speech_base + n_codes))
+    deep = dict(walk_gain=8.0, walk_scale=8.0) if bcfg.num_layers > 8 else dict(walk_gain=4.0)     # (24 layers add more to the stream: oracle/gen_golden_infer.py)
+    bw = br.make_weights(bcfg, seed, walk_range=(tok.speech_base, tok.speech_base + n_codes), **deep)
     cw = cr.make_weights(ccfg, 2)
     ecfg = syn.EncoderConfig.tiny()      # reference encoder (encode_reference): FSQ levels independent of the tiny decoder's
     ew = syn.make_encoder_weights(ecfg, 4)
@@ -205,7 +206,8 @@ def test_infer_batch_shares_prompt_beginnings_and_matches_single_inference(tts):
 
 
 def test_infer_stream_batch_equals_single_streams(tts):
-    """Two utterances streamed together: each one's chunks are exactly those of its own `infer_stream`."""
+    """Two utterances streamed together: each one's chunks are exactly those of its own `infer_stream` -- the batch runs the DEVICE-side
+    stream path (ntts_streams_*: append_codes / gather / codec / cross-fade kernels), the single streams the host loop: bit for bit."""
     ref_codes = [3, 77, 200, 5, 18, 9, 100, 41]
     texts = ["Streaming test.", "Another one, a little longer."]
     tts.min_new_tokens, tts.max_context = 34, 150      # one full window (30 tokens) + a final partial one
@@ -214,12 +216,20 @@ def test_infer_stream_batch_equals_single_streams(tts):
         got = [[], []]
         budget = tts.backbone.cfg["max_prefill_tokens"]
         tts.backbone.cfg["max_prefill_tokens"] = 80     # smaller than the two prompts together: prefilled in two calls
+        assert tts._stream_on_device([ref_codes, ref_codes])          # token caches, windows and the cross-fade on the device (csrc/stream.cpp)
         for i, chunk in tts.infer_stream_batch(texts, ref_codes, "So I'm live."):
             assert isinstance(chunk, np.ndarray)
             got[i].append(chunk)
+        host = [[], []]
+        tts.stream_on_device = False                                    # the same batch through the host loop (numpy windows + _StreamBlender)
+        for i, chunk in tts.infer_stream_batch(texts, ref_codes, "So I'm live."):
+            host[i].append(chunk)
     finally:
+        tts.stream_on_device = True
         tts.backbone.cfg["max_prefill_tokens"] = budget
         tts.min_new_tokens, tts.max_context = 5, 120
+    for i in range(2):
+        assert len(host[i]) == len(got[i]) and all(np.array_equal(a, b) for a, b in zip(host[i], got[i]))
     st = tts.backbone.kv_stats()
     assert st["free_pages"] == st["total_pages"]
     for i in range(2):
