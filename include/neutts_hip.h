@@ -290,6 +290,11 @@ int ntts_codec_decode(ntts_codec* c, int32_t n, const int32_t* codes, const int3
 int ntts_codec_decode_dev(ntts_codec* c, int32_t n, const int32_t* codes_dev, int32_t codes_stride, const int32_t* lens,
                           float* wav_out, int64_t wav_stride, int32_t wav_on_device, void* producer_stream);
 int ntts_codec_sync(ntts_codec* c);
+/* ABI 6.  Test taps (blocking), like ntts_encoder_read_stage: with keep_stages != 0 every decode call keeps the fp32 residual stream after
+ * the stages of hf:models/xcodec2/modeling_xcodec2.py:838-862 -- 0 embed (fc + k = 7 conv :839-841), 1 prior_net (:845), 2 the transformer
+ * layers (:855-856), 3 post_net (:859); read_stage copies utterance `utt`'s rows of the most recent call: HOST float32 [rows = frames][cols = hidden]. */
+int ntts_codec_set_debug(ntts_codec* c, int32_t keep_stages);
+int ntts_codec_read_stage(ntts_codec* c, int32_t stage, int32_t utt, float* out, int64_t cap, int32_t* rows, int32_t* cols);
 /* ABI 6.  The codec engine's HIP stream (a hipStream_t) and its workspace limits (config fields max_frames / max_rows as created), for a
  * consumer that puts its own kernels before / behind a decode pass (ntts_streams_*). */
 int ntts_codec_stream(ntts_codec* c, void** stream);

@@ -50,6 +50,9 @@ struct ntts_codec {
     hipEvent_t ev_in = nullptr;   // orders a pass behind the stream that produced its device-side codes
     bool have_time = false;
     bool gn_reg = true;          // GroupNorm with the utterance slice in registers when it fits (NTTS_CODEC_GN_REG=0: the two-pass kernel)
+    // per-stage taps of the residual stream (ntts_codec_set_debug / ntts_codec_read_stage: the error-budget tests): fp32 [4][max_rows][H]
+    float* tap = nullptr;
+    std::vector<int> tap_off, tap_len;   // row offset / frames of every utterance of the most recent decode call
     bool attn_resident = true;   // utterances of up to 256 frames: attn_full_resident_kernel (NTTS_CODEC_ATTN_RESIDENT=0: the two-sweep paged kernel)
 };
 
@@ -84,6 +87,7 @@ extern "C" void ntts_codec_destroy(ntts_codec* c) {
     hipSetDevice(c->device);
     hipDeviceSynchronize();
     for (void* p : c->allocs) hipFree(p);
+    if (c->tap) hipFree(c->tap);
     for (auto& e : c->ev)
         if (e) hipEventDestroy(e);
     if (c->ev_in) hipEventDestroy(c->ev_in);
@@ -405,8 +409,19 @@ static int codec_decode_impl(ntts_codec* c, int32_t n, const int32_t* codes, con
     NTTS_LAUNCH((codec_embed_kernel), dim3((unsigned)((rows + kEmbedRows - 1) / kEmbedRows)), dim3(256), st, ea);
     // stem Conv1d(k=7, padding 3): window rows r..r+6 -> centre row r+3
     { GemmArgs ga_ = cg(c->xa, H, c->embed_w, 7L * H, c->embed_b, c->h + 3L * H, H, rows - 6, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
+    auto tap = [&](int stage) -> hipError_t {   // debug only: the residual stream after a stage (hf:models/xcodec2/modeling_xcodec2.py:841-859)
+        if (!c->tap) return hipSuccess;
+        return hipMemcpyAsync(c->tap + (size_t)stage * c->max_rows * H, c->h, (size_t)rows * H * sizeof(float), hipMemcpyDeviceToDevice, st);
+    };
+    if (c->tap) {
+        c->tap_off.assign(n, 0); c->tap_len.assign(lens, lens + n);
+        long ro = 0;
+        for (int i = 0; i < n; ++i) { c->tap_off[i] = (int)ro; ro += lens[i] + 2 * kPadRows; }
+    }
+    CHIP(c, tap(0));
     resnet_block(c, c->res[0], R, rows);
     resnet_block(c, c->res[1], R, rows);
+    CHIP(c, tap(1));
     for (int i = 0; i < c->cfg.num_layers; ++i) {
         const CLayerW& L = c->layers[i];
         RowNormArgs rn{};
@@ -431,8 +446,10 @@ static int codec_decode_impl(ntts_codec* c, int32_t n, const int32_t* codes, con
         { GemmArgs ga_ = cg(c->xa, H, L.fc1, H, nullptr, c->act, c->I, rows, c->I); NTTS_GEMM_BIG(EPI_BF16_SILU, ga_, st); }
         { GemmArgs ga_ = cg(c->act, c->I, L.fc2, c->I, nullptr, c->h, H, rows, H, c->h, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
     }
+    CHIP(c, tap(2));
     resnet_block(c, c->res[2], R, rows);
     resnet_block(c, c->res[3], R, rows);
+    CHIP(c, tap(3));
     RowNormArgs fn{};
     fn.x = c->h; fn.y = c->xa; fn.w = c->fn_w; fn.bias = c->fn_b; fn.rows = rows; fn.C = H; fn.eps = 1e-6f;
     rownorm_launch(fn, st);
@@ -496,6 +513,35 @@ extern "C" int ntts_codec_sync(ntts_codec* c) {
     CHIP(c, hipSetDevice(c->device));
     CHIP(c, hipStreamSynchronize(c->stream));
     CHIP(c, hipGetLastError());
+    return NTTS_OK;
+}
+
+// Test tap: keep the fp32 residual stream after the four stages of hf:models/xcodec2/modeling_xcodec2.py:838-862 -- 0 embed (fc + k = 7 conv),
+// 1 prior_net (2 ResNet blocks), 2 the transformer layers, 3 post_net (2 ResNet blocks) -- of the most recent decode call.
+extern "C" int ntts_codec_set_debug(ntts_codec* c, int32_t keep_stages) {
+    if (!c) return NTTS_EINVAL;
+    CHIP(c, hipSetDevice(c->device));
+    CHIP(c, hipStreamSynchronize(c->stream));
+    if (keep_stages && !c->tap) {
+        CHIP(c, hipMalloc((void**)&c->tap, 4 * (size_t)c->max_rows * c->H * sizeof(float)));
+        CHIP(c, hipMemset(c->tap, 0, 4 * (size_t)c->max_rows * c->H * sizeof(float)));
+    } else if (!keep_stages && c->tap) {
+        CHIP(c, hipFree(c->tap));
+        c->tap = nullptr;
+    }
+    c->tap_off.clear(); c->tap_len.clear();
+    return NTTS_OK;
+}
+extern "C" int ntts_codec_read_stage(ntts_codec* c, int32_t stage, int32_t utt, float* out, int64_t cap, int32_t* rows, int32_t* cols) {
+    if (!c || !out || !rows || !cols || stage < 0 || stage > 3) return cfail(c, NTTS_EINVAL, "bad argument");
+    if (!c->tap || utt < 0 || utt >= (int)c->tap_len.size()) return cfail(c, NTTS_ESTATE, "no stage outputs kept for utterance %d: ntts_codec_set_debug(c, 1), then decode", utt);
+    const long need = (long)c->tap_len[utt] * c->H;
+    if (cap < need) return cfail(c, NTTS_EINVAL, "stage output needs %ld floats", need);
+    CHIP(c, hipSetDevice(c->device));
+    CHIP(c, hipStreamSynchronize(c->stream));
+    CHIP(c, hipMemcpy(out, c->tap + ((size_t)stage * c->max_rows + c->tap_off[utt] + kPadRows) * c->H, (size_t)need * sizeof(float), hipMemcpyDeviceToHost));
+    *rows = c->tap_len[utt];
+    *cols = c->H;
     return NTTS_OK;
 }
 

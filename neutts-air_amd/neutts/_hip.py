@@ -112,6 +112,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_backbone_stream": (C.c_int, [p, C.POINTER(p)]),
         "ntts_backbone_append_codes": (C.c_int, [p, i32, C.POINTER(i32), i32, i32, i32, p, i32, p, p, p]),
         "ntts_codec_stream": (C.c_int, [p, C.POINTER(p)]),
+        "ntts_codec_set_debug": (C.c_int, [p, i32]),
+        "ntts_codec_read_stage": (C.c_int, [p, i32, i32, C.POINTER(f32), i64, C.POINTER(i32), C.POINTER(i32)]),
         "ntts_codec_limits": (C.c_int, [p, C.POINTER(i32), C.POINTER(i64)]),
         "ntts_streams_last_error": (C.c_char_p, [p]),
         "ntts_streams_create": (C.c_int, [p, p, C.POINTER(StreamParamsC), i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), i32, C.POINTER(p)]),
@@ -780,6 +782,18 @@ class CodecEngine:
         self._chk(self.lib.ntts_codec_decode(self.h, n, flat.ctypes.data_as(i32p), lens.ctypes.data_as(i32p),
                                              wav.ctypes.data_as(C.POINTER(C.c_float)), stride))
         return wav
+
+    def set_debug(self, keep_stages: bool):
+        self._chk(self.lib.ntts_codec_set_debug(self.h, int(keep_stages)))
+
+    STAGES = ["embed", "prior", "layers", "post"]            # the tap names of oracle/codec_ref.py decode_code(taps=...)
+
+    def read_stage(self, stage: int, utt: int = 0) -> np.ndarray:
+        """fp32 residual stream [frames, hidden] of utterance `utt` after stage `stage` of the most recent decode call (set_debug(True) first)."""
+        buf = np.empty(self.max_frames * 4096, dtype=np.float32)
+        r, c_ = C.c_int32(), C.c_int32()
+        self._chk(self.lib.ntts_codec_read_stage(self.h, stage, utt, buf.ctypes.data_as(C.POINTER(C.c_float)), buf.size, C.byref(r), C.byref(c_)))
+        return buf[: r.value * c_.value].reshape(r.value, c_.value).copy()
 
     def set_cu_mask(self, mask_words: Optional[Sequence[int]]):
         """Restrict the codec engine's stream to the CUs of `mask_words` (None / empty = all); ntts_codec_set_cu_mask."""

@@ -83,3 +83,54 @@ def test_neucodec_batch256_properties(neucodec):
 def test_codec_long_utterance_paged_attention(lib):
     import test_emu_codec
     test_emu_codec.check_long_utterance(lib)
+
+
+def test_neucodec_error_budget_by_stage_and_at_realistic_amplitude(neucodec):
+    """WHERE the waveform error comes from, and what it is at the amplitude of a real voice.
+    (1) Stage taps (ntts_codec_read_stage, ABI 6) against the oracle's taps (oracle/codec_ref.py decode_code(taps=...)): relative RMS
+        error of the fp32 residual stream after the stem, the prior ResNet blocks, the 12 transformer layers and the post ResNet
+        blocks.  Every GEMM runs bf16 operands (weights AND activations rounded to 8 bits of mantissa, fp32 accumulation) against a
+        reference that is fp32 throughout: ~1.1e-3 relative per rounded operand, accumulating over ~60 GEMMs in series.  A CPU
+        simulation that rounds exactly those operands in the oracle reproduces the total (7.05e-3) and attributes it -- stem 2.6e-3,
+        prior 2.3e-3, layers 5.0e-3, post 0.8e-3, head 2.7e-3, in quadrature: 71 % of the squared error is made
+        inside the transformer layers, i.e. inside 88 % of the pass's FLOPs -- it cannot be bought down without doubling the pass.
+    (2) The bound is RELATIVE (weak 2): the same codes with the magnitude bias of the ISTFT head raised by ln 6 -- every STFT magnitude,
+        hence every sample, exactly 6x larger in the reference -- give signal RMS ~0.1 like a real voice: relative error unchanged,
+        absolute error 6x, still inside BASELINE's 1e-3."""
+    z, cfg, w, eng = neucodec
+    codes = z["codes_1"][0, 0].tolist()                      # ref:samples/dave.pt[:100]
+    eng.set_debug(True)
+    try:
+        wv = eng.decode([codes])[0]
+        got = [eng.read_stage(k) for k in range(4)]
+    finally:
+        eng.set_debug(False)
+    taps = {}
+    ref = cr.decode_code(cfg, w, torch.tensor(codes, dtype=torch.long)[None, None, :], taps=taps)[0, 0].numpy()
+    rel = []
+    for k, name in enumerate(_hip.CodecEngine.STAGES):
+        want = taps[name][0].numpy()
+        assert got[k].shape == want.shape, (name, got[k].shape, want.shape)
+        rel.append(rms(got[k] - want) / rms(want))
+    err, sig = rms(wv - ref), rms(ref)
+    print("codec error budget, relative RMS of the residual stream vs the fp32 oracle: "
+          + ", ".join(f"{n} {r:.2e}" for n, r in zip(_hip.CodecEngine.STAGES, rel)) + f"; waveform {err / sig:.2e} (RMS error {err:.2e} at signal RMS {sig:.2e})")
+    # measured on MI355X (profiles/r04d_pytest_gpu_codec.log); bars at ~1.5x
+    assert rel[0] <= 3.5e-3 and rel[1] <= 6e-3 and rel[2] <= 8e-3 and rel[3] <= 8e-3, rel   # measured 2.29e-3, 3.84e-3, 5.49e-3, 5.60e-3
+    assert err <= REL_BOUND * sig
+    # ---- the same utterance at the amplitude of a real voice
+    w6 = dict(w)
+    b = w["decoder.head.linear.bias"].clone()
+    b[: b.numel() // 2] += float(np.log(6.0))               # magnitude half of the head's output (hf:models/xcodec2/modeling_xcodec2.py:771-773)
+    w6["decoder.head.linear.bias"] = b
+    eng6 = make_codec_engine(cfg, w6, neucodec_lib(eng), max_frames=128, max_rows=512)
+    wv6 = eng6.decode([codes])[0]
+    ref6 = cr.decode_code(cfg, w6, torch.tensor(codes, dtype=torch.long)[None, None, :])[0, 0].numpy()
+    err6, sig6 = rms(wv6 - ref6), rms(ref6)
+    print(f"the same codes 6x louder: RMS error {err6:.2e} at signal RMS {sig6:.2e}, relative {err6 / sig6:.2e}")
+    assert 0.08 <= sig6 <= 0.13 and err6 <= 1e-3 and err6 <= REL_BOUND * sig6
+    eng6.close()
+
+
+def neucodec_lib(eng):
+    return eng.lib._name
