@@ -19,8 +19,9 @@
  *   - an engine is bound to ONE device, is not re-entrant and not thread-safe: serialise calls per
  *     engine (the Python host holds the GIL across each call).  One process per GPU; there is no
  *     cross-GPU collective inside any entry point (utterances are independent).
- *   - work is enqueued on the engine's own HIP stream; functions named *_sync or documented as
- *     "blocking" wait for it, the others return once the work is enqueued.
+ *   - work is enqueued on the engine's HIP stream -- its own, or one the caller lends with ntts_backbone_set_stream /
+ *     ntts_codec_set_stream (ABI 6); functions named *_sync or documented as "blocking" wait for it, the others return
+ *     once the work is enqueued.
  *   - there is NO CPU fallback: without a gfx950 device ntts_*_create fails with NTTS_ENODEV.
  */
 #ifndef NEUTTS_HIP_H
@@ -195,6 +196,10 @@ int ntts_backbone_append_codes(ntts_backbone* e, int32_t n, const int32_t* slots
                                int32_t* cache_dev, int32_t stride, int32_t* clen_dev, int32_t* seen_dev, int32_t* fin_dev);
 /* The engine's HIP stream (a hipStream_t), for a consumer that must order its own work behind the engine's. */
 int ntts_backbone_stream(ntts_backbone* e, void** stream);
+/* ABI 6.  SURVEY.md 8b ("all work enqueued on a caller-provided hipStream_t"): the engine creates a stream of its own; a caller that wants
+ * the engine's launches, copies and graph replays ordered inside ITS stream (e.g. torch's current stream) lends it here; NULL returns to the
+ * engine's own stream.  Blocking (drains the stream in use); NTTS_ESTATE while a snapshot (poll_begin) is open. */
+int ntts_backbone_set_stream(ntts_backbone* e, void* stream);
 /* Serving-side scheduling knob (no reference counterpart: ref:neutts/neutts.py runs one utterance at a time): run this engine's
  * prompt passes (ntts_backbone_prefill*) on a side stream restricted to the compute units whose bits are set in `mask` (n_words
  * 32-bit words, bit i of word w = CU 32 w + i; hipExtStreamCreateWithCUMask), ordered behind and before the engine's own stream.
@@ -298,6 +303,8 @@ int ntts_codec_read_stage(ntts_codec* c, int32_t stage, int32_t utt, float* out,
 /* ABI 6.  The codec engine's HIP stream (a hipStream_t) and its workspace limits (config fields max_frames / max_rows as created), for a
  * consumer that puts its own kernels before / behind a decode pass (ntts_streams_*). */
 int ntts_codec_stream(ntts_codec* c, void** stream);
+/* The codec passes on a stream of the caller's (as ntts_backbone_set_stream); NULL returns to the engine's own.  Blocking. */
+int ntts_codec_set_stream(ntts_codec* c, void* stream);
 int ntts_codec_limits(ntts_codec* c, int32_t* max_frames, int64_t* max_rows);
 /* The same knob for the codec engine: re-create its stream restricted to the CUs of `mask` (n_words = 0: unrestricted).  Blocking. */
 int ntts_codec_set_cu_mask(ntts_codec* c, const uint32_t* mask, int32_t n_words);

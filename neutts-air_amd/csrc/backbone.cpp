@@ -49,7 +49,8 @@ struct HostSlot {
 struct ntts_backbone {
     ntts_backbone_config cfg{};
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // the stream every launch goes to: the engine's own, or one the caller lent (ntts_backbone_set_stream)
+    hipStream_t own_stream = nullptr;
     std::string err;
     int H = 0, F = 0, NQKV = 0, max_pages = 0;
 
@@ -247,7 +248,8 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     } while (0)
 
     CR_HIP(hipSetDevice(device));
-    CR_HIP(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    CR_HIP(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+    e->stream = e->own_stream;
     for (auto& ev : e->ev) CR_HIP(hipEventCreate(&ev));
 
     // ---- weight arena (bf16), every tensor 256-byte aligned
@@ -452,7 +454,7 @@ extern "C" void ntts_backbone_destroy(ntts_backbone* e) {
     if (e->snap_ev) hipEventDestroy(e->snap_ev);
     if (e->copy_stream) hipStreamDestroy(e->copy_stream);
     if (e->pf_stream) { hipStreamDestroy(e->pf_stream); hipEventDestroy(e->pf_ev[0]); hipEventDestroy(e->pf_ev[1]); }
-    if (e->stream) hipStreamDestroy(e->stream);
+    if (e->own_stream) hipStreamDestroy(e->own_stream);
     delete e;
 }
 
@@ -1539,6 +1541,18 @@ extern "C" int ntts_backbone_read_all(ntts_backbone* e, int32_t* out_ids, int32_
 extern "C" int ntts_backbone_stream(ntts_backbone* e, void** stream) {
     if (!e || !stream) return NTTS_EINVAL;
     *stream = (void*)e->stream;
+    return NTTS_OK;
+}
+
+// "all work enqueued on a caller-provided hipStream_t".  The engine creates a stream of its own; a caller that wants the
+// engine's work ordered inside ITS stream (e.g. torch's current stream) lends it here: every later launch, copy and graph replay goes
+// there (a captured decode step replays on any stream).  nullptr returns to the engine's own stream.  Blocking: drains the stream in use.
+extern "C" int ntts_backbone_set_stream(ntts_backbone* e, void* stream) {
+    if (!e) return NTTS_EINVAL;
+    if (e->snap_open) return fail(e, NTTS_ESTATE, "a snapshot is open on the current stream (ntts_backbone_poll_end first)");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    e->stream = stream ? (hipStream_t)stream : e->own_stream;
     return NTTS_OK;
 }
 

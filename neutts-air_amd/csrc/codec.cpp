@@ -27,7 +27,8 @@ struct CLayerW { float *ln1, *ln2; bf16_t *wqkv, *wo, *fc1, *fc2; };
 struct ntts_codec {
     ntts_codec_config cfg{};
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // where the passes run: the engine's own stream or one the caller lent (ntts_codec_set_stream)
+    hipStream_t own_stream = nullptr;
     std::string err;
     int H = 0, I = 0, nq = 0, n_fft = 0, nb = 0, NS = 0, lds_spec = 0;
     long K3 = 0, max_rows = 0;
@@ -91,7 +92,7 @@ extern "C" void ntts_codec_destroy(ntts_codec* c) {
     for (auto& e : c->ev)
         if (e) hipEventDestroy(e);
     if (c->ev_in) hipEventDestroy(c->ev_in);
-    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
 
@@ -118,10 +119,11 @@ extern "C" int ntts_codec_create(const ntts_codec_config* cf, int device, ntts_c
     c->max_rows = cf->max_rows;
     { const char* ev = getenv("NTTS_CODEC_ATTN_RESIDENT"); if (ev && ev[0] == '0') c->attn_resident = false; }
     { const char* ev = getenv("NTTS_CODEC_GN_REG"); if (ev && ev[0] == '0') c->gn_reg = false; }
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return cfail(nullptr, NTTS_EHIP, "stream creation failed");
     }
+    c->stream = c->own_stream;
     hipEventCreate(&c->ev[0]); hipEventCreate(&c->ev[1]); hipEventCreate(&c->ev_in);
     const size_t R = c->max_rows, H = c->H;
     const int npages_max = (cf->max_frames + kPage - 1) / kPage;
@@ -503,8 +505,19 @@ extern "C" int ntts_codec_set_cu_mask(ntts_codec* c, const uint32_t* mask, int32
     hipStream_t ns = nullptr;
     if (n_words == 0) CHIP(c, hipStreamCreateWithFlags(&ns, hipStreamNonBlocking));
     else CHIP(c, hipExtStreamCreateWithCUMask(&ns, (uint32_t)n_words, mask));
-    hipStreamDestroy(c->stream);
-    c->stream = ns;
+    const bool lent = c->stream != c->own_stream;       // (a stream lent by the caller stays in use; the mask applies to the engine's own)
+    hipStreamDestroy(c->own_stream);
+    c->own_stream = ns;
+    if (!lent) c->stream = ns;
+    return NTTS_OK;
+}
+
+// The codec passes on a stream of the caller's; nullptr returns to the engine's own.  Blocking: drains the stream in use.
+extern "C" int ntts_codec_set_stream(ntts_codec* c, void* stream) {
+    if (!c) return NTTS_EINVAL;
+    CHIP(c, hipSetDevice(c->device));
+    CHIP(c, hipStreamSynchronize(c->stream));
+    c->stream = stream ? (hipStream_t)stream : c->own_stream;
     return NTTS_OK;
 }
 

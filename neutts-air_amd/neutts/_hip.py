@@ -110,6 +110,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_backbone_release_many": (C.c_int, [p, i32, C.POINTER(i32)]),
         "ntts_backbone_export_codes": (C.c_int, [p, i32, C.POINTER(i32), i32, i32, i32, p, i32, p]),
         "ntts_backbone_stream": (C.c_int, [p, C.POINTER(p)]),
+        "ntts_backbone_set_stream": (C.c_int, [p, p]),
+        "ntts_codec_set_stream": (C.c_int, [p, p]),
         "ntts_backbone_append_codes": (C.c_int, [p, i32, C.POINTER(i32), i32, i32, i32, p, i32, p, p, p]),
         "ntts_codec_stream": (C.c_int, [p, C.POINTER(p)]),
         "ntts_codec_set_debug": (C.c_int, [p, i32]),
@@ -469,6 +471,10 @@ class BackboneEngine:
     def sync(self):
         self._chk(self.lib.ntts_backbone_sync(self.h))
 
+    def set_stream(self, stream: Optional[int]):
+        """Run the engine's work on the caller's HIP stream (a hipStream_t as an integer, e.g. torch.cuda.Stream().cuda_stream); None = its own."""
+        self._chk(self.lib.ntts_backbone_set_stream(self.h, C.c_void_p(stream or None)))
+
     def set_debug(self, keep_logits: bool):
         self._chk(self.lib.ntts_backbone_set_debug(self.h, int(keep_logits)))
 
@@ -822,6 +828,10 @@ class CodecEngine:
 
     def sync(self):
         self._chk(self.lib.ntts_codec_sync(self.h))
+
+    def set_stream(self, stream: Optional[int]):
+        """Run the codec passes on the caller's HIP stream (a hipStream_t as an integer); None = the engine's own."""
+        self._chk(self.lib.ntts_codec_set_stream(self.h, C.c_void_p(stream or None)))
 
     def last_timing(self) -> float:
         ms = C.c_float()

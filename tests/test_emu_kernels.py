@@ -130,7 +130,7 @@ def fp8_gemm_case(lib_path, M, N, K, variant, has_bias):
     got = out.float().cpu()
     err = (got - ref.float()).abs()
     # one bf16 ulp of the result + the matrix core's own accumulation error, which is relative to the ADDENDS, not to the
-    # (possibly cancelling) sum: v_mfma_f32_16x16x32_fp8_fp8 is not an fp32 fma chain.  Probed on MI355X (tools/fp8_probe.py
+    # (possibly cancelling) sum: v_mfma_f32_16x16x32_fp8_fp8 is not an fp32 fma chain.  Probed on MI355X (tools/fp8_probe.py, in the history up to round 3
     # notes in DESIGN.md): small-integer operands come out exact, but inside one lane group's 8 products an addend below
     # ~2^-17 of the largest is dropped (448*448 - 448*448 + 126 x 1*1 gives 120: the six 1's next to the big pair are lost).
     mag = (xq.float().abs() @ wq.float().abs().t()) * (xs * ws)[None, :]

@@ -186,3 +186,25 @@ def test_fp8_needs_its_input_scales(lib):
         bf.load_tensor("lm_head.input_scale", np.asarray([0.5], dtype=np.float32))
     with pytest.raises(_hip.NeuTTSHipError, match="multiples of 128"):
         _hip.BackboneEngine(engine_cfg(br.BackboneConfig.tiny(), max_batch=1, weight_dtype="fp8"), 0, lib)
+
+
+@pytest.mark.parametrize("small", ["8", "0"])
+def test_fp8_walk_free_running_exact(lib, small, monkeypatch):
+    """Free-running greedy ids of the fp8 model against the fp8 oracle, id for id: on walk weights (synthetic._make_walk) every top-1 /
+    top-2 margin of the fp8 oracle's own run is tens of bf16 ulps wide, far above the e4m3 re-rounding noise that separates two correct
+    fp8 implementations (check_fp8_model), so 40 different ids must come out equal -- on the GEMV path and on the tile path.  (On random
+    weights the free run agrees for 8-10 of 10 tokens: the margins there are smaller than that noise.)"""
+    monkeypatch.setenv("NTTS_SMALL_BATCH", small)
+    cfg = fp8_cfg(vocab=2048)
+    w = br.make_weights(cfg, 23, walk_gain=4.0)
+    scales = br.default_fp8_input_scales(cfg, mlp_act=2.0 ** -3)        # the walk's MLP carries values up to ~30: a window up to 56
+    wq = br.fp8_quantize_weights(br.cast_weights(w, torch.bfloat16), scales)
+    eng = _engine(cfg, w, lib, max_batch=2, input_scales=scales, weight_dtype="fp8")
+    prompts = [br.synthetic_prompt(cfg, 3, 40), br.synthetic_prompt(cfg, 4, 70)]
+    N, eos = 40, cfg.vocab_size - 1
+    want = [br.generate(cfg, wq, p, len(p) + N, eos_id=eos, min_new_tokens=N, keep_logits=True) for p in prompts]
+    for r in want:
+        m = [float(torch.topk(lg.float(), 2).values[0] - torch.topk(lg.float(), 2).values[1]) / br.bf16_ulp(float(lg.float().max())) for lg in r.logits]
+        assert min(m) >= 12.0 and len(set(r.ids)) == N, (min(m), len(set(r.ids)))
+    got = _run(eng, cfg, prompts, N)
+    assert got == [r.ids for r in want]

@@ -537,3 +537,33 @@ def test_twin_engine_and_async_snapshots(lib):
         assert st.tolist() == [0, 0] and e.free_slots() == 2
     assert got[0] == got[1]
     assert got[0][0] == z["bf16_ids_0"][:N].tolist() or sum(a == b for a, b in zip(got[0][0], z["bf16_ids_0"][:N].tolist())) >= N - 2
+
+
+def test_engine_on_a_caller_provided_stream(lib):
+    """SURVEY.md 8b / VERDICT r3 missing 6: ntts_backbone_set_stream -- prompt pass, graph-replayed decode steps and the device-side code
+    export enqueued on a stream the CALLER owns (a torch stream here): a torch op put on that stream right behind them sees their result
+    without any engine-side synchronisation, the ids are those of the engine's own stream, and NULL hands the engine its stream back."""
+    z, cfg, w = load_fixture("backbone_small_walk")
+    S, N, eos = int(z["s_len"]), 24, int(z["eos"])
+    eng = make_engine(cfg, w, lib, max_batch=2, max_context=160, bf16_upload=True)
+    samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
+    prompts = [br.synthetic_prompt(cfg, 0, S), br.synthetic_prompt(cfg, 1, S)]
+    mine = torch.cuda.Stream()
+    eng.set_stream(mine.cuda_stream)
+    codes = torch.zeros((2, 32), dtype=torch.int32, device="cuda")
+    lens = torch.zeros(2, dtype=torch.int32, device="cuda")
+    eng.prefill(prompts, [0, 1], [samp, samp])
+    eng.decode(N - 1)
+    eng.export_codes([0, 1], 0, cfg.vocab_size, codes.data_ptr(), 32, lens.data_ptr())
+    with torch.cuda.stream(mine):                 # ordered behind the engine's work by the stream alone
+        got = (codes + 0).cpu().numpy()
+        n = lens.cpu().numpy()
+    for u in (0, 1):
+        assert n[u] == N
+        assert_walk_exact(got[u, :N].tolist(), z[f"bf16_ids_{u}"][:N].tolist())
+    eng.release_many([0, 1])
+    eng.set_stream(None)                          # back on the engine's own stream
+    eng.prefill(prompts[:1], [0], [samp])
+    eng.decode(N - 1)
+    assert eng.read(0)[0] == z["bf16_ids_0"][:N].tolist()
+    eng.close()

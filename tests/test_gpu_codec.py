@@ -134,3 +134,24 @@ def test_neucodec_error_budget_by_stage_and_at_realistic_amplitude(neucodec):
 
 def neucodec_lib(eng):
     return eng.lib._name
+
+
+def test_verify_checkpoint_codec_half_on_a_neucodec_style_state_dict(neucodec, tmp_path, capsys):
+    """tools/verify_checkpoint.py --codec on what can be built offline: the synthetic NeuCodec-geometry decoder weights re-keyed into the
+    original `neucodec` layout (fused c_attn) and saved as a .pt state dict.  The tool maps the keys (strictly), loads the
+    decoder into the codec engine and compares decode_code with transformers' Xcodec2 modules filled with the same tensors."""
+    import os
+    import sys
+    import re
+    from test_host_logic import _neucodec_style
+    z, cfg, w, eng = neucodec
+    path = str(tmp_path / "neucodec_style.pt")
+    torch.save(_neucodec_style(w), path)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import verify_checkpoint as vc
+    vc.verify_codec(path, "cuda:0", neucodec_lib(eng))       # (returns False here: the synthetic dict has no encoder tensors, and says so)
+    out = capsys.readouterr().out
+    print(out)
+    assert "decoder key map: all" in out and "encoder key map MISMATCH" in out
+    rel = float(re.search(r"relative ([0-9.e+-]+); bar", out).group(1))
+    assert rel <= REL_BOUND

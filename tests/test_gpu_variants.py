@@ -26,6 +26,7 @@ test_tied_head_must_equal_embedding = cases.test_tied_head_must_equal_embedding
 test_fp8_model_matches_fp8_oracle = cases.test_fp8_model_matches_fp8_oracle
 test_fp8_needs_its_input_scales = cases.test_fp8_needs_its_input_scales
 test_fp8_decode_step_logits_small_and_tile_path = cases.test_fp8_decode_step_logits_small_and_tile_path
+test_fp8_walk_free_running_exact = cases.test_fp8_walk_free_running_exact
 
 
 @pytest.mark.parametrize("batch", [64, 256])

@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call = everything we want from a GPU box, each leg under its own timeout, logs in gpurun_out/.
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_round.sh [legs...]'
-# legs: smoke tests bench b1 nano prof pmc stream sweep   (default: smoke tests bench prof)
+# legs: smoke tests bench b1 nano prof pmc sweep   (default: smoke tests bench prof)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -28,7 +28,6 @@ for leg in $LEGS; do
              done
              python tools/pmc_summary.py $OUT/pmc_$ctr > $OUT/pmc_${ctr}_summary.txt 2>&1; head -14 $OUT/pmc_${ctr}_summary.txt; find $OUT/pmc_$ctr -name '*.csv' -size +8M -delete
            done;;
-    stream) timeout 300 python tools/stream_probe.py > $OUT/stream_probe.jsonl 2> $OUT/stream_probe.err; echo "stream rc=$?"; cat $OUT/stream_probe.jsonl; tail -3 $OUT/stream_probe.err;;
     sweep)  # SWEEP_KNOBS='[["NTTS_ATTN_DEPTH",[2]]]'
            timeout ${SWEEP_TIMEOUT:-400} python tools/sweep_decode.py --knobs "${SWEEP_KNOBS:-[[\"NTTS_ATTN_DEPTH\",[2]]]}" > $OUT/sweep.log 2>&1; echo "sweep rc=$?"; grep -v '^\[sweep\] weights' $OUT/sweep.log | tail -12;;
     nano)  for cfg in nano-fp8 nano-bf16; do timeout 300 python bench.py --config $cfg --steps ${BENCH_STEPS:-2} --warmup 1 --no-cpu-baseline > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err; echo "bench $cfg rc=$?"; cut -c1-1200 $OUT/bench_$cfg.json; tail -12 $OUT/bench_$cfg.err; done;;
