@@ -22,7 +22,6 @@
 #include "kernels/gemv.h"
 #include "kernels/norm.h"
 #include "kernels/qkv_rope.h"
-#include "kernels/qkv_attn.h"
 #include "kernels/sample.h"
 
 using namespace ntts;
@@ -105,13 +104,6 @@ struct ntts_backbone {
     // then has no prologue.  step_meta / rope_rows: the per-step row records that kernel reads (step_meta_kernel, once per step).
     int* step_meta = nullptr;
     bf16_t* rope_rows = nullptr;
-    // QKV projection and attention in ONE launch with an in-launch hand-over of q | k | v (qkv_attn.h, round 4): the attention workgroups
-    // request their K pages while the QKV tiles are still computing.  Large-batch bf16 / fp8 tile path, at least two attention workgroups
-    // per CU (DS = 1 regime), contexts up to 1024 (NTTS_FUSED_QKV_ATTN=0: the two launches).
-    bool fused_qa = false;
-    unsigned long long* hand = nullptr;      // [max_batch][NQKV / 2] granules
-    unsigned int* step_ctr = nullptr;        // [0] steps taken (tag base), [1] hand-over time-out flag, [2 ..] CU bitmap of the fused launch
-
     int head_tile = 0;      // lm_head tile (NTTS_HEAD_TILE): 0 = 64 x 64 skinny (batch <= 64), 1 = 128 x 128, 2 = 256 x 256 (16 waves; the fp8 model
                             // above batch 128), 4 = 256 x 288 natural-order tile, 12 waves (bf16 above batch 128: 756 tiles = 2.95 rounds of the 256 CUs
                             // instead of 850 = 3.32: 129.5 -> 118.7-123.8 us, profiles/r02k_sweep_lpt_head_gu_tiles.log).  Its weight stream uses the
@@ -384,15 +376,6 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
         CR_HIP(hipMemset(e->step_meta, 0, (size_t)B * 4 * sizeof(int)));
         CR_HIP(hipMalloc((void**)&e->rope_rows, (size_t)B * 64 * 2));
         CR_HIP(hipMemset(e->rope_rows, 0, (size_t)B * 64 * 2));
-        CR_HIP(hipMalloc((void**)&e->step_ctr, (2 + 128) * sizeof(unsigned int)));
-        CR_HIP(hipMemset(e->step_ctr, 0, (2 + 128) * sizeof(unsigned int)));
-        const int fq = env_int("NTTS_FUSED_QKV_ATTN", 1);      // 0 = the two launches, 1 = by batch (default), 2 = whenever the kernel applies (tests)
-        e->fused_qa = !e->small && fq != 0 && ((long)B * c->num_kv_heads >= 2L * 256 || fq == 2) && c->max_context <= 1024 &&
-                      c->num_heads / c->num_kv_heads <= kGroupMax;
-        if (e->fused_qa) {
-            CR_HIP(hipMalloc((void**)&e->hand, (size_t)B * (e->NQKV / 2) * sizeof(unsigned long long)));
-            CR_HIP(hipMemset(e->hand, 0, (size_t)B * (e->NQKV / 2) * sizeof(unsigned long long)));
-        }
     }
     e->n_part = e->small ? V / 16 : e->head_tile == 0 ? (V + 63) / 64 : e->head_tile == 4 ? ((V + 287) / 288) * 3 : e->head_tile == 2 ? ((V + 255) / 256) * 4 : ((V + 127) / 128) * 2;
     CR_HIP(hipMalloc((void**)&e->h_dec, (size_t)B * H * 2));
@@ -458,7 +441,7 @@ extern "C" void ntts_backbone_destroy(ntts_backbone* e) {
     if (e->graph_split) hipGraphExecDestroy(e->graph_split);
     void* bufs[] = {e->arena, e->gu_map_gate, e->gu_map_up, e->kv, e->ibuf, e->h_dec, e->xn_dec, e->qkv_dec, e->attn_dec,
                     e->act_dec, e->slabs, e->slabs2, e->h_alt, e->part_val, e->part_idx, e->logits, e->logits_bf16, e->h_pf, e->xn_pf, e->qkv_pf, e->attn_pf,
-                    e->o_pf, e->act_pf, e->meta_dev, e->as_scores, e->as_stats, e->as_oslabs, e->step_meta, e->rope_rows, e->hand, e->step_ctr};
+                    e->o_pf, e->act_pf, e->meta_dev, e->as_scores, e->as_stats, e->as_oslabs, e->step_meta, e->rope_rows};
     for (void* b : bufs)
         if (b) hipFree(b);
     for (auto& ev : e->ev)
@@ -849,7 +832,6 @@ static StepMetaArgs step_meta_args(ntts_backbone* e) {
     StepMetaArgs m{};
     m.pos = e->sl.pos; m.state = e->sl.state; m.block_table = e->block_table; m.max_pages = e->max_pages; m.max_ctx = e->cfg.max_context;
     m.M = e->cfg.max_batch; m.rope_cos = e->rope_cos; m.rope_sin = e->rope_sin; m.meta = e->step_meta; m.rope_rows = e->rope_rows;
-    m.step_ctr = e->step_ctr;
     return m;
 }
 static void k_step_meta(ntts_backbone* e) {   // once per decode step, before the first fused QKV kernel
@@ -890,35 +872,6 @@ static void k_attn(ntts_backbone* e, int i) {
         return;
     }
     attn_decode_launch(a, c.max_batch, e->stream, c.max_context);
-}
-
-// the two kernels above as ONE launch (qkv_attn.h): QKV tiles first, attention workgroups behind them, q | k | v handed over in the launch
-static bool fused_qa_now(const ntts_backbone* e) { return e->fused_qa && !e->split_active && !e->attn_tl && !e->gemv_tl; }
-static unsigned long long* g_x_qa_tl = nullptr;   // EXPERIMENT: timeline buffer of the fused launch
-static void k_qkv_attn(ntts_backbone* e, int i) {
-    const ntts_backbone_config& c = e->cfg;
-    const int B = c.max_batch, H = e->H;
-    const LayerW& w = e->layers[i];
-    QkvAttnArgs A{};
-    QkvRopeArgs& q = A.q;
-    q.X = e->xn_dec; q.ldx = H; q.W = w.wqkv; q.bias = w.bqkv; q.wscale = w.sqkv; q.xscale = w.xs[0];
-    q.M = B; q.N = e->NQKV; q.K = H; q.meta = e->step_meta; q.rope_rows = e->rope_rows;
-    q.q_out = nullptr; q.ld_q = e->NQKV; q.kpool = e->kv + (size_t)i * e->layer_stride;
-    q.nh = c.num_heads; q.nkv = c.num_kv_heads;
-    AttnDecodeArgs& a = A.a;
-    a.out = e->attn_dec; a.ld_out = c.num_heads * 64;
-    a.kpool = q.kpool; a.vpool = a.kpool + e->kv_half;
-    a.block_table = e->block_table; a.max_pages = e->max_pages; a.pos = e->sl.pos; a.state = e->sl.state;
-    a.nh = c.num_heads; a.nkv = c.num_kv_heads;
-    a.xcd_rows = (e->xcd_affine & 4) ? e->xcd_xps : 0;
-    if (e->fp8) a.out_fp8_inv = 1.0f / w.xs[1];
-    A.x_sleep = env_int("NTTS_X_SLEEP", 0); A.x_defer = env_int("NTTS_X_DEFER", 0);
-    A.tl = g_x_qa_tl;
-    A.cu_busy = env_int("NTTS_X_CUBUSY", 1) ? e->step_ctr + 2 : nullptr;
-    A.hand = e->hand; A.step_ctr = e->step_ctr; A.err = e->step_ctr + 1; A.layer = i; A.batch = B;
-    const bool place = (e->xcd_affine & 4) && e->xcd_xps;
-    if (e->fp8) qkv_attn_launch<true>(A, place, c.max_context, e->stream);
-    else qkv_attn_launch<false>(A, place, c.max_context, e->stream);
 }
 
 static void k_o_proj(ntts_backbone* e, int i) {
@@ -1080,8 +1033,8 @@ static void decode_step(ntts_backbone* e) {
     }
     for (int i = 0; i < c.num_layers; ++i) {
         const bool last = i + 1 == c.num_layers;
-        if (fused_qa_now(e)) k_qkv_attn(e, i);
-        else { k_qkv(e, i); k_attn(e, i); }
+        k_qkv(e, i);
+        k_attn(e, i);
         k_o_proj(e, i);
         k_add_norm(e, QD, e->ks_o, e->layers[i].ln2, e->h_dec, e->xn_dec, e->layers[i].xs[2], 1);
         k_gate_up(e, i);
@@ -1819,8 +1772,7 @@ extern "C" int ntts_backbone_attn_timeline(ntts_backbone* e, int32_t layer, uint
 // Phase timestamps of one small-batch GEMV launch at the current slot state (tools/gemv_timeline.py): which = 1 QKV (+ RoPE + K append), 2 o_proj, 3 gate/up,
 // 4 down_proj of `layer`; out[workgroup][16] (gemv.h GemvArgs::tl), *n_wg = workgroups of the launch.
 extern "C" int ntts_backbone_gemv_timeline(ntts_backbone* e, int32_t which, int32_t layer, uint64_t* out, int64_t cap, int32_t* n_wg) {
-    if (!e || !out || !n_wg || layer < 0 || layer >= e->cfg.num_layers || which < 1 || which > 5) return fail(e, NTTS_EINVAL, "bad argument");
-    if (which == 5 && !e->fused_qa) return fail(e, NTTS_ESTATE, "the engine does not run the fused QKV + attention launch");
+    if (!e || !out || !n_wg || layer < 0 || layer >= e->cfg.num_layers || which < 1 || which > 4) return fail(e, NTTS_EINVAL, "bad argument");
     const size_t n = 4096 * 16;
     if (cap < (int64_t)n) return fail(e, NTTS_EINVAL, "timeline needs %zu entries", n);
     HIPCHK(e, hipSetDevice(e->device));
@@ -1832,19 +1784,11 @@ extern "C" int ntts_backbone_gemv_timeline(ntts_backbone* e, int32_t which, int3
         if (e->small) { if (which == 1) ks_qkv(e, i); else if (which == 2) ks_o_proj(e, i); else if (which == 3) ks_gate_up(e, i); else ks_down(e, i); }
         else { if (which == 1) k_qkv(e, i); else if (which == 2) k_o_proj(e, i); else if (which == 3) k_gate_up(e, i); else k_down(e, i); }
     };
-    if (which == 5) {                           // the fused QKV + attention launch (qkv_attn.h): slots in its header
-        k_step_meta(e);
-        k_qkv_attn(e, (layer + 1) % e->cfg.num_layers);
-        g_x_qa_tl = tl;
-        k_qkv_attn(e, layer);
-        g_x_qa_tl = nullptr;
-    } else {
     if (which == 1) k_step_meta(e);
     run((layer + 1) % e->cfg.num_layers);      // another layer first: this launch is neither the first nor cache-warm
     e->gemv_tl = tl;
     run(layer);
     e->gemv_tl = nullptr;
-    }
     HIPCHK(e, hipStreamSynchronize(e->stream));
     HIPCHK(e, hipMemcpy(out, tl, n * 8, hipMemcpyDeviceToHost));
     int wg = 0;

@@ -30,14 +30,12 @@ struct StepMetaArgs {
     const bf16_t* rope_sin;
     int* meta;               // [M][4] = {state, pos, page of pos, slot of pos in its page}
     bf16_t* rope_rows;       // [M][64] = cos[pos][0..31] | sin[pos][0..31]
-    unsigned int* step_ctr;  // bumped once per step (row 0): the tag base of the in-launch hand-over of qkv_attn.h; may be null
 };
 NTTS_D void step_meta_row(const StepMetaArgs& p, int row, int i) {   // one wave64 per batch row; i = lane
     int P = p.pos[row];
     if (P < 0) P = 0;
     if (P > p.max_ctx - 1) P = p.max_ctx - 1;      // (free slots hold stale positions: any valid row will do, nothing uses it)
     p.rope_rows[(long)row * 64 + i] = i < 32 ? p.rope_cos[(long)P * 32 + i] : p.rope_sin[(long)P * 32 + i - 32];
-    if (i == 0 && row == 0 && p.step_ctr) *p.step_ctr = *p.step_ctr + 1u;
     if (i == 0) {
         int* m = p.meta + (long)row * 4;
         m[0] = p.state[row];

@@ -8,7 +8,6 @@
 #define NTTS_HD __host__ __device__ __forceinline__
 #define NTTS_D __device__ __forceinline__
 #define NTTS_KERNEL(threads) static __global__ __launch_bounds__(threads)
-#define NTTS_KERNEL2(threads, waves) static __global__ __launch_bounds__(threads, waves)   // waves = minimum waves per SIMD (register budget)
 #define NTTS_SHARED __shared__ __attribute__((aligned(16)))
 
 namespace ntts {
@@ -96,23 +95,6 @@ NTTS_D void sync_keep_dma() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" :
 NTTS_D void lds_barrier() { sync_keep_dma(); }
 // nothing is scheduled across this point by the compiler (issue order of memory requests matters: in-order returns)
 NTTS_D void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
-
-// ---- in-launch hand-over between workgroups (cdna_hip_programming.md Guideline 16, recipe R2): an 8-byte {tag, data} GRANULE written by
-//      ONE write-through (sc1) store and read by ONE relaxed agent-scope load -- the data is the flag: no fence, no separate flag word.
-//      Global address space on purpose (never flat).  spin_pause: between two sweeps of a polling wave.
-typedef __attribute__((address_space(1))) unsigned long long gu64_t;
-NTTS_D void granule_store(unsigned long long* p, unsigned long long v) { __hip_atomic_store((gu64_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-NTTS_D unsigned long long granule_load(const unsigned long long* p) { return __hip_atomic_load((gu64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-NTTS_D void spin_pause() { __builtin_amdgcn_s_sleep(4); }
-// which CU this wave runs on: XCC id (HW_REG_XCC_ID, bits 3:0) | SE / SH / CU id (HW_REG_HW_ID bits 15:8) -- a key < 4096; speed hints only
-NTTS_D int cu_key() {
-    const unsigned int hw = __builtin_amdgcn_s_getreg((8 - 1) << 11 | 8 << 6 | 4);      // HW_ID[15:8]
-    const unsigned int xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);    // XCC_ID[3:0]
-    return (int)((xcc & 15u) << 8 | (hw & 255u));
-}
-NTTS_D void atomic_or_global(unsigned int* p, unsigned int v) { atomicOr(p, v); }
-NTTS_D void atomic_and_global(unsigned int* p, unsigned int v) { atomicAnd(p, v); }
-NTTS_D unsigned int relaxed_load_u32(const unsigned int* p) { return __hip_atomic_load((__attribute__((address_space(1))) unsigned int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 NTTS_D unsigned int atomic_add_global(unsigned int* p, unsigned int v) { return atomicAdd(p, v); }
 NTTS_D unsigned int atomic_add_lds(unsigned int* p, unsigned int v) { return atomicAdd(p, v); }

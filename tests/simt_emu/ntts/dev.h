@@ -25,7 +25,6 @@
 #define NTTS_HD inline
 #define NTTS_D inline
 #define NTTS_KERNEL(threads) static
-#define NTTS_KERNEL2(threads, waves) static
 #define NTTS_SHARED static __attribute__((aligned(16)))
 
 struct dim3 {
@@ -230,15 +229,6 @@ inline void glds16(const void* gsrc, void* lds_wave_base) {
 }
 inline void glds16_nt(const void* gsrc, void* lds_wave_base) { glds16(gsrc, lds_wave_base); }
 inline unsigned int atomic_add_global(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = o + v; return o; }
-// in-launch hand-over granules (product dev.h): the emulator runs the workgroups of a launch one after the other in block order, so a
-// producer (lower block id) has always finished before its consumer sweeps -- plain memory operations
-inline void granule_store(unsigned long long* p, unsigned long long v) { *p = v; }
-inline unsigned long long granule_load(const unsigned long long* p) { return *p; }
-inline void spin_pause() {}
-inline int cu_key() { return 0; }
-inline void atomic_or_global(unsigned int* p, unsigned int v) { *p |= v; }
-inline void atomic_and_global(unsigned int* p, unsigned int v) { *p &= v; }
-inline unsigned int relaxed_load_u32(const unsigned int* p) { return *p; }
 inline unsigned int atomic_add_lds(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = o + v; return o; }
 NTTS_D unsigned long long now_ticks() { return 0; }   // no clock on the emulator
 inline void wait_vmem() {}
