@@ -45,7 +45,7 @@ enum {
     NTTS_EHIP = -5      /* a HIP runtime call failed; see ntts_last_error */
 };
 
-enum { NTTS_DT_F32 = 0, NTTS_DT_BF16 = 1, NTTS_DT_I32 = 2 };
+enum { NTTS_DT_F32 = 0, NTTS_DT_BF16 = 1, NTTS_DT_I32 = 2, NTTS_DT_FP8_E4M3 = 3 /* ABI 6: pre-quantised matrices of an fp8 checkpoint (bytes) */ };
 
 /* ------------------------------------------------------------------------------------------ */
 /* Backbone engine: Qwen2-style decoder, paged KV cache, continuous batching over `max_batch`   */
@@ -94,7 +94,11 @@ void ntts_backbone_destroy(ntts_backbone* e);
  * the static activation scales of the four GEMM inputs of a layer and of the head are loaded as fp32 scalars named
  * "model.layers.{i}.self_attn.q_proj.input_scale" (= k_proj / v_proj), "...self_attn.o_proj.input_scale",
  * "...mlp.gate_proj.input_scale" (= up_proj), "...mlp.down_proj.input_scale", "lm_head.input_scale" (the naming of
- * static-fp8 checkpoints).  `data` may be a host or a device pointer
+ * static-fp8 checkpoints).  ABI 6, PRE-QUANTISED fp8 checkpoints: a matrix may arrive as NTTS_DT_FP8_E4M3 bytes ([N][K] row-major e4m3fn) together with
+ * its "<module>.weight_scale" tensor (fp32: one value per output channel, [N] or [N, 1], or ONE value for the whole matrix) -- in either order; it is
+ * then stored as it is, not re-quantised (finalize insists on the scale; a scale for a matrix that was quantised on upload is NTTS_EINVAL).  The
+ * embedding stays bf16 / fp32 (it is gathered, not multiplied); with tie_word_embeddings the head's fp8 copy is derived from it.
+ * `data` may be a host or a device pointer
  * (is_device); dtype NTTS_DT_F32 or NTTS_DT_BF16 (fp32 is rounded to bf16 RNE, like `.to(bfloat16)`).
  * The tensor is copied into the engine's packed arena (fused QKV rows, gate/up interleaved in 16-row
  * groups) -- the caller's buffer can be freed on return.  Blocking. */

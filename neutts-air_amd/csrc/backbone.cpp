@@ -68,6 +68,7 @@ struct ntts_backbone {
     std::set<std::string> needed; // tensor names finalize() insists on
     std::vector<LayerW> layers;
     std::set<std::string> loaded;
+    std::set<std::string> quantised_here;   // fp8 model: matrices that came in bf16 / fp32 and were quantised on upload (no weight_scale may follow)
     float inv_freq[64];
     bool have_inv_freq = false, finalized = false;
     int* gu_map_gate = nullptr;  // device row maps for the gate/up packing
@@ -479,6 +480,19 @@ static int put_rows(ntts_backbone* e, const void* data, int dtype, int is_device
 // a GEMM weight: rows [row0, row0 + rows) of the packed matrix `dst` ([*, cols]), in the engine's weight layout
 static int put_weight(ntts_backbone* e, const void* data, int dtype, int is_device, long rows, long cols, bf16_t* dst, long row0,
                       const int* dst_rows, int tile_major, float* wscale = nullptr) {
+    if (dtype == NTTS_DT_FP8_E4M3) {      // a pre-quantised matrix: the bytes as they are (its scales come as "<module>.weight_scale")
+        if (!wscale) return fail(e, NTTS_EINVAL, "fp8 bytes for an engine created with weight_dtype = NTTS_W_BF16");
+        const void* srcb = data;
+        DevScratch tmpb;
+        if (!is_device) {
+            HIPCHK(e, hipMalloc(&tmpb.p, (size_t)rows * cols));
+            HIPCHK(e, hipMemcpy(tmpb.p, data, (size_t)rows * cols, hipMemcpyHostToDevice));
+            srcb = tmpb.p;
+        }
+        NTTS_LAUNCH((pack_weight_fp8_raw_kernel), dim3((unsigned)rows), dim3(256), e->stream, (const unsigned char*)srcb, (unsigned char*)dst, dst_rows, row0, cols);
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        return NTTS_OK;
+    }
     const size_t esz = dtype == NTTS_DT_F32 ? 4 : 2;
     const void* src = data;
     DevScratch tmp;
@@ -549,7 +563,57 @@ extern "C" int ntts_backbone_load_tensor(ntts_backbone* e, const char* name, con
         e->loaded.insert(canon);
         return NTTS_OK;
     }
-    if (dtype != NTTS_DT_F32 && dtype != NTTS_DT_BF16) return fail(e, NTTS_EINVAL, "tensor '%s': dtype must be f32 or bf16", name);
+    // ---- pre-quantised fp8 checkpoints: "<module>.weight_scale" (fp32; one value per output channel or one per matrix)
+    if (n.size() > 13 && n.compare(n.size() - 13, 13, ".weight_scale") == 0) {
+        if (!e->fp8) return fail(e, NTTS_EINVAL, "tensor '%s': weight scales belong to the fp8 model (weight_dtype = NTTS_W_FP8_E4M3)", name);
+        if (dtype != NTTS_DT_F32) return fail(e, NTTS_EINVAL, "tensor '%s' must be fp32", name);
+        long cnt = 1;
+        for (int d = 0; d < ndim; ++d) cnt *= shape[d];
+        const std::string mod = n.substr(0, n.size() - 13), wname = mod + ".weight";
+        if (e->quantised_here.count(wname)) return fail(e, NTTS_EINVAL, "tensor '%s': the matrix was given in bf16 / fp32 and quantised on upload; it has its scales", name);
+        float* dst = nullptr; const int* rows_map = nullptr; long row0 = 0, rows_n = 0;
+        if (mod == "lm_head" || mod == "model.embed_tokens") {
+            if (mod == "model.embed_tokens" || e->tied) return fail(e, NTTS_EINVAL, "tensor '%s': the embedding stays bf16 (with tie_word_embeddings the head's fp8 copy is derived from it)", name);
+            dst = e->shead; rows_n = c.vocab_size;
+        } else if (mod.rfind("model.layers.", 0) == 0) {
+            char* endp = nullptr;
+            const long li = strtol(name + 13, &endp, 10);
+            if (endp == name + 13 || *endp != '.' || li < 0 || li >= c.num_layers) return fail(e, NTTS_EINVAL, "tensor '%s': bad layer index", name);
+            const std::string t(endp + 1, strlen(endp + 1) - 13);
+            LayerW& w = e->layers[li];
+            if (t == "self_attn.q_proj") { dst = w.sqkv; rows_n = QD; }
+            else if (t == "self_attn.k_proj") { dst = w.sqkv; row0 = QD; rows_n = KD; }
+            else if (t == "self_attn.v_proj") { dst = w.sqkv; row0 = QD + KD; rows_n = KD; }
+            else if (t == "self_attn.o_proj") { dst = w.so; rows_n = H; }
+            else if (t == "mlp.gate_proj") { dst = w.sgu; rows_map = e->gu_map_gate; rows_n = F; }
+            else if (t == "mlp.up_proj") { dst = w.sgu; rows_map = e->gu_map_up; rows_n = F; }
+            else if (t == "mlp.down_proj") { dst = w.sd; rows_n = H; }
+        }
+        if (!dst) return fail(e, NTTS_EINVAL, "unknown tensor '%s'", name);
+        if (cnt != 1 && cnt != rows_n) return fail(e, NTTS_EINVAL, "tensor '%s': %ld values, expected 1 or %ld (one per output channel)", name, cnt, rows_n);
+        DevScratch tmp;
+        const float* src = (const float*)data;
+        if (!is_device) {
+            HIPCHK(e, hipMalloc(&tmp.p, (size_t)cnt * 4));
+            HIPCHK(e, hipMemcpy(tmp.p, data, (size_t)cnt * 4, hipMemcpyHostToDevice));
+            src = (const float*)tmp.p;
+        }
+        NTTS_LAUNCH((scatter_scales_kernel), dim3((unsigned)((rows_n + 255) / 256)), dim3(256), e->stream, src, cnt == 1 ? 1 : 0, dst, rows_map, row0, rows_n);
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        e->loaded.insert(n);
+        return NTTS_OK;
+    }
+    if (dtype == NTTS_DT_FP8_E4M3) {
+        if (!e->fp8) return fail(e, NTTS_EINVAL, "tensor '%s': fp8 bytes for an engine created with weight_dtype = NTTS_W_BF16", name);
+        const bool is_matrix = n.size() > 7 && n.compare(n.size() - 7, 7, ".weight") == 0 && (n.find("_proj.weight") != std::string::npos || (n == "lm_head.weight" && !e->tied));
+        if (!is_matrix) return fail(e, NTTS_EINVAL, "tensor '%s': only the projection matrices (and an untied lm_head) can be pre-quantised", name);
+        e->needed.insert(n.substr(0, n.size() - 7) + ".weight_scale");     // finalize insists on its scales
+    } else if (dtype != NTTS_DT_F32 && dtype != NTTS_DT_BF16) return fail(e, NTTS_EINVAL, "tensor '%s': dtype must be f32, bf16 or (fp8 model) e4m3 bytes", name);
+    else if (e->fp8 && n.size() > 7 && n.compare(n.size() - 7, 7, ".weight") == 0) {
+        if (e->loaded.count(n.substr(0, n.size() - 7) + ".weight_scale"))
+            return fail(e, NTTS_EINVAL, "tensor '%s': its weight_scale was loaded, so the matrix must come as e4m3 bytes (NTTS_DT_FP8_E4M3)", name);
+        e->quantised_here.insert(n);
+    }
     int rc = NTTS_EINVAL;
     const int tm = 1;   // GEMM weights are stored tile-major
     if (n == "model.embed_tokens.weight") {

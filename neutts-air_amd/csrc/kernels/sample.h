@@ -456,6 +456,19 @@ NTTS_KERNEL(256) void pack_weight_fp8_kernel(const void* src, int src_is_f32, un
         dst[(dr >> 6) * 64 * cols + (c >> 7) * 8192 + (dr & 63) * 128 + (c & 127)] = f2fp8c(val(c) / scale);
 }
 
+// pre-quantised fp8 checkpoints: the matrix arrives as e4m3 bytes [rows][cols] and is stored as it is (same layout as above);
+// its per-output-channel scales arrive separately (one fp32 per row, or one for the whole matrix: `broadcast`)
+NTTS_KERNEL(256) void pack_weight_fp8_raw_kernel(const unsigned char* src, unsigned char* dst, const int* dst_rows, long row0, long cols) {
+    const long r = blockIdx.x;
+    const long dr = row0 + (dst_rows ? dst_rows[r] : r);
+    for (long c = threadIdx.x; c < cols; c += 256)
+        dst[(dr >> 6) * 64 * cols + (c >> 7) * 8192 + (dr & 63) * 128 + (c & 127)] = src[r * cols + c];
+}
+NTTS_KERNEL(256) void scatter_scales_kernel(const float* src, int broadcast, float* dst, const int* dst_rows, long row0, long n) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r < n) dst[row0 + (dst_rows ? dst_rows[r] : r)] = src[broadcast ? 0 : r];
+}
+
 // number of elements of `src` ([rows][cols], fp32 or bf16) whose bf16 value differs from ref[rows][cols]: the tied-head check
 NTTS_KERNEL(256) void rows_mismatch_kernel(const void* src, int src_is_f32, const bf16_t* ref, long cols, unsigned int* count) {
     const long r = blockIdx.x;

@@ -16,7 +16,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "libneutts_hip.so")
 
-NTTS_DT_F32, NTTS_DT_BF16, NTTS_DT_I32 = 0, 1, 2
+NTTS_DT_F32, NTTS_DT_BF16, NTTS_DT_I32, NTTS_DT_FP8_E4M3 = 0, 1, 2, 3
 NTTS_W_BF16, NTTS_W_FP8_E4M3 = 0, 1
 ABI_VERSION = 6
 NTTS_PAGE_TOKENS = 32            # include/neutts_hip.h
@@ -180,6 +180,8 @@ def _tensor_ptr(t):
     import torch  # plumbing only: tensor containers
     if isinstance(t, torch.Tensor):
         tt = t.detach().contiguous()
+        if tt.dtype == getattr(torch, "float8_e4m3fn", None):      # a pre-quantised matrix of an fp8 checkpoint: its bytes
+            return tt.data_ptr(), NTTS_DT_FP8_E4M3, tuple(tt.shape), int(tt.is_cuda), tt
         if tt.dtype == torch.bfloat16:
             code = NTTS_DT_BF16
         else:
@@ -267,13 +269,16 @@ class BackboneEngine:
 
     def load_state_dict(self, sd: Dict[str, object], inv_freq=None, input_scales: Optional[Dict[str, float]] = None):
         """HF Qwen2ForCausalLM state dict (+ rope.inv_freq; computed like hf:...modeling_qwen2.py:86 if absent).
-        fp8 engines (weight_dtype="fp8"): the bf16 / fp32 matrices are quantised on upload; the static activation scales come
-        as `*.input_scale` entries of `sd` (static-fp8 checkpoints) or as the `input_scales` dict {tensor name: float}."""
+        fp8 engines (weight_dtype="fp8"): bf16 / fp32 matrices are quantised on upload; matrices that are ALREADY torch.float8_e4m3fn
+        (a pre-quantised checkpoint) are stored as they are and need their `<module>.weight_scale` entry; the static activation scales
+        come as `*.input_scale` entries of `sd` (static-fp8 checkpoints) or as the `input_scales` dict {tensor name: float}."""
         for k, v in sd.items():
             if k.endswith("rotary_emb.inv_freq"):
                 continue
             if k.endswith(".input_scale"):
                 v = np.asarray(v.float().cpu() if hasattr(v, "cpu") else v, dtype=np.float32).reshape(1)
+            elif k.endswith(".weight_scale"):       # pre-quantised fp8 checkpoint: per-output-channel (or per-matrix) scales, fp32 on the way in
+                v = np.ascontiguousarray(np.asarray(v.float().cpu() if hasattr(v, "cpu") else v, dtype=np.float32))
             self.load_tensor(k, v)
         for k, v in (input_scales or {}).items():
             self.load_tensor(k, np.asarray([v], dtype=np.float32))

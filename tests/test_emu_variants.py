@@ -208,3 +208,56 @@ def test_fp8_walk_free_running_exact(lib, small, monkeypatch):
         assert min(m) >= 12.0 and len(set(r.ids)) == N, (min(m), len(set(r.ids)))
     got = _run(eng, cfg, prompts, N)
     assert got == [r.ids for r in want]
+
+
+def test_fp8_prequantised_checkpoint_equals_quantise_on_upload(lib):
+    """A PRE-QUANTISED fp8 checkpoint (ABI 6: NTTS_DT_FP8_E4M3 bytes + `<module>.weight_scale`, the layout of static-fp8 exports): the seven
+    projection matrices of every layer arrive as torch.float8_e4m3fn tensors with their per-output-channel scales ([N, 1], or ONE value for a
+    matrix quantised per tensor) -- in either order relative to their matrix -- and are stored as they are.  Quantising the same bf16 weights the
+    same way on the host (oracle/backbone_ref.fp8_quantize_weights) must give the engine the state it builds itself when it quantises on
+    upload: bit-identical logits.  Error paths: a scale for a matrix that was quantised on upload, fp8 bytes for a bf16 engine, a missing scale."""
+    cfg = fp8_cfg()
+    w = br.make_weights(cfg, 23, walk_gain=4.0)
+    scales = br.default_fp8_input_scales(cfg, mlp_act=2.0 ** -3)
+    wb = br.cast_weights(w, torch.bfloat16)
+    wq = br.fp8_quantize_weights(wb, scales)
+    pre = {}
+    for k, v in wb.items():
+        if k.endswith("_proj.weight"):
+            pre[k] = wq[k + "::q"].to(torch.float8_e4m3fn)              # exact: the values ARE e4m3
+            pre[k[:-7] + ".weight_scale"] = wq[k + "::scale"].reshape(-1, 1)
+        else:
+            pre[k] = v
+    order = sorted(pre, key=lambda k: (not k.endswith(".weight_scale"), k))   # every scale BEFORE its matrix
+    prompt = br.synthetic_prompt(cfg, 3, 40)
+    eos = cfg.vocab_size - 1
+    samp = [_hip.Sampling(max_length=48, min_new_tokens=8, eos_token_id=eos, do_sample=False)]
+    outs = []
+    for sd in ({k: v for k, v in wb.items()}, pre, {k: pre[k] for k in order}):
+        eng = _hip.BackboneEngine(engine_cfg(cfg, max_batch=2, max_context=128, max_prefill_tokens=256, weight_dtype="fp8"), 0, lib)
+        eng.load_state_dict(sd, inv_freq=br.rope_inv_freq(cfg).numpy(), input_scales=scales)
+        eng.set_debug(True)
+        eng.prefill([prompt], [0], samp)
+        logits = eng.read_logits(0).copy()
+        eng.decode(7)
+        outs.append((logits, eng.read(0)[0]))
+        eng.close()
+    for lg, ids in outs[1:]:
+        assert np.array_equal(lg, outs[0][0]) and ids == outs[0][1]
+    assert len(set(outs[0][1])) == 8
+    # error paths
+    eng = _hip.BackboneEngine(engine_cfg(cfg, max_batch=2, max_context=128, max_prefill_tokens=256, weight_dtype="fp8"), 0, lib)
+    k = "model.layers.0.self_attn.o_proj.weight"
+    eng.load_tensor(k, wb[k])                                               # quantised on upload ...
+    with pytest.raises(_hip.NeuTTSHipError):
+        eng.load_tensor(k[:-7] + ".weight_scale", np.ones((cfg.hidden_size, 1), dtype=np.float32))   # ... so it has its scales
+    k2 = "model.layers.0.mlp.down_proj.weight"
+    eng.load_tensor(k2, pre[k2])                                            # pre-quantised, scale never given
+    sd = {kk: vv for kk, vv in wb.items() if kk not in (k, k2)}
+    with pytest.raises(_hip.NeuTTSHipError, match="weight_scale"):
+        eng.load_state_dict(sd, inv_freq=br.rope_inv_freq(cfg).numpy(), input_scales=scales)
+    eng.close()
+    eng = _hip.BackboneEngine(engine_cfg(cfg, max_batch=2, max_context=128, max_prefill_tokens=256), 0, lib)
+    with pytest.raises(_hip.NeuTTSHipError):
+        eng.load_tensor(k2, pre[k2])                                        # fp8 bytes for a bf16 engine
+    eng.close()

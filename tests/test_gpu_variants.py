@@ -27,6 +27,7 @@ test_fp8_model_matches_fp8_oracle = cases.test_fp8_model_matches_fp8_oracle
 test_fp8_needs_its_input_scales = cases.test_fp8_needs_its_input_scales
 test_fp8_decode_step_logits_small_and_tile_path = cases.test_fp8_decode_step_logits_small_and_tile_path
 test_fp8_walk_free_running_exact = cases.test_fp8_walk_free_running_exact
+test_fp8_prequantised_checkpoint_equals_quantise_on_upload = cases.test_fp8_prequantised_checkpoint_equals_quantise_on_upload
 
 
 @pytest.mark.parametrize("batch", [64, 256])
