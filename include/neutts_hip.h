@@ -357,7 +357,7 @@ int ntts_streams_pump_wait(ntts_streams* s, int32_t* n_running);
  * *more = 1: further windows are already complete -- call pump_end again (without pump_begin) to get them.  Blocking. */
 int ntts_streams_pump_end(ntts_streams* s, int32_t cap, int32_t* n_chunks, int32_t* chunk_stream, int32_t* chunk_samples, int32_t* chunk_last,
                           const float** chunks, int64_t* row_stride, int32_t* n_running, int32_t* more);
-/* Streams that have emitted their last chunk. */
+/* Streams that have emitted their last chunk.  (After a failed pump the set's bookkeeping is ahead of what was emitted: destroy it.) */
 int ntts_streams_done(ntts_streams* s, int32_t* n_done);
 
 /* ------------------------------------------------------------------------------------------ */

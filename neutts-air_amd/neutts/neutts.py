@@ -322,7 +322,10 @@ class NeuTTS:
     def infer_stream(self, text: str, ref_codes, ref_text: str) -> Generator[np.ndarray, None, None]:
         """Streaming synthesis with the reference's window / cross-fade semantics (ref:neutts/neutts.py:373-465)."""
         prompt_ids = self._apply_chat_template(ref_codes, ref_text, text)
-        return self._infer_stream_hip(prompt_ids, [int(c) for c in _to_list(ref_codes)])
+        ref = [int(c) for c in _to_list(ref_codes)]
+        if self._stream_on_device([ref]):       # token cache, windows, codec pass and cross-fade on the device (csrc/stream.cpp): a set of one stream
+            return (chunk for _, chunk in self._infer_stream_batch_hip([prompt_ids], [ref]))
+        return self._infer_stream_hip(prompt_ids, ref)        # host loop: a watermarker (a host library) sits between the codec and the slice
 
     def infer_stream_batch(self, texts: Sequence[str], ref_codes, ref_texts) -> Generator[tuple, None, None]:
         """Many utterances streamed at once (BASELINE config 5's shape: a decode batch with the codec on its own stream):
