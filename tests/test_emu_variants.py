@@ -192,7 +192,7 @@ def test_fp8_needs_its_input_scales(lib):
 def test_fp8_walk_free_running_exact(lib, small, monkeypatch):
     """Free-running greedy ids of the fp8 model against the fp8 oracle, id for id: on walk weights (synthetic._make_walk) every top-1 /
     top-2 margin of the fp8 oracle's own run is tens of bf16 ulps wide, far above the e4m3 re-rounding noise that separates two correct
-    fp8 implementations (check_fp8_model), so 40 different ids must come out equal -- on the GEMV path and on the tile path.  (On random
+    fp8 implementations (check_fp8_model), so every id (40 of them on the GPU, 14 on the emulator) must come out equal -- on the GEMV path and on the tile path.  (On random
     weights the free run agrees for 8-10 of 10 tokens: the margins there are smaller than that noise.)"""
     monkeypatch.setenv("NTTS_SMALL_BATCH", small)
     cfg = fp8_cfg(vocab=2048)
@@ -200,8 +200,9 @@ def test_fp8_walk_free_running_exact(lib, small, monkeypatch):
     scales = br.default_fp8_input_scales(cfg, mlp_act=2.0 ** -3)        # the walk's MLP carries values up to ~30: a window up to 56
     wq = br.fp8_quantize_weights(br.cast_weights(w, torch.bfloat16), scales)
     eng = _engine(cfg, w, lib, max_batch=2, input_scales=scales, weight_dtype="fp8")
-    prompts = [br.synthetic_prompt(cfg, 3, 40), br.synthetic_prompt(cfg, 4, 70)]
-    N, eos = 40, cfg.vocab_size - 1
+    on_emu = "emu" in str(lib)
+    prompts = [br.synthetic_prompt(cfg, 3, 20 if on_emu else 40), br.synthetic_prompt(cfg, 4, 33 if on_emu else 70)]
+    N, eos = (14 if on_emu else 40), cfg.vocab_size - 1          # (the emulator runs the same kernels ~10^4 x slower: a shorter run there)
     want = [br.generate(cfg, wq, p, len(p) + N, eos_id=eos, min_new_tokens=N, keep_logits=True) for p in prompts]
     for r in want:
         m = [float(torch.topk(lg.float(), 2).values[0] - torch.topk(lg.float(), 2).values[1]) / br.bf16_ulp(float(lg.float().max())) for lg in r.logits]
