@@ -21,7 +21,6 @@ extern "C" int ntts_k_gemm_bf16(const void* A, int64_t lda, const void* W, const
     else if (variant == 5) gemm_launch<4, 4, 4, EPI_BF16, 4, 0, 32>(a, 1, (hipStream_t)0);   // XL tile, 4 ring slots of K = 32
     else if (variant == 6) gemm_launch<2, 2, 4, EPI_BF16, 3, 0, 32>(a, 1, (hipStream_t)0);   // L tile, 3 ring slots of K = 32
     else if (variant == 7) gemm_launch<4, 3, 4, EPI_BF16, 2, 0, 64, false, false, 6>(a, 1, (hipStream_t)0);   // natural-order 256 x 288 tile, 12 waves (prefill QKV)
-    else if (variant == 8) gemm_launch<2, 4, 8, EPI_BF16, 4, 0, 32, false, false, 4, true>(a, 1, (hipStream_t)0);   // 256 x 256, 8 waves of 128 x 64, two staggered wave groups
     else if (variant == 3) {  // split-K slabs reduced by the norm kernel (the decode o_proj / down_proj path)
         if (bias || (N % 16) || ldc != N) return NTTS_EINVAL;
         const int ks = 4, ns = gemm_nsplit(K, ks);
@@ -188,11 +187,6 @@ extern "C" int ntts_k_gemm_probe(int32_t M, int32_t N, int32_t K, int32_t config
             case 52: probe_launch<8, 1, 2, 2>(a, ks, abl); break;
             case 53: probe_launch<8, 2, 2, 2>(a, ks, abl); break;   // 256 x 128, 16 waves
             case 54: probe_launch<4, 2, 2, 3>(a, ks, abl); break;   // 128 x 128, 8 waves
-            case 60: gemm_launch<2, 4, 8, EPI_BF16, 4, 0, 32, false, false, 4, true>(a, ks, 0); break;   // 256 x 256, 8 waves of 128 x 64, 4 slots of K = 32, staggered groups
-            case 61: gemm_launch<2, 4, 8, EPI_BF16, 3, 0, 32, false, false, 4, true>(a, ks, 0); break;   // ... 3 slots
-            case 62: gemm_launch<2, 4, 8, EPI_BF16, 4, 0, 32>(a, ks, 0); break;                          // the same tile and ring, unstaggered (= 48)
-            case 63: gemm_launch<4, 4, 4, EPI_BF16, 4, 0, 32, false, false, 4, true>(a, ks, 0); break;   // 256 x 256, 16 waves of 64 x 64, staggered
-            case 64: gemm_launch<4, 2, 4, EPI_BF16, 4, 0, 32, false, false, 4, true>(a, ks, 0); break;   // 256 x 128, 8 waves of 64 x 64, staggered
             default: break;
         }
     };

@@ -411,17 +411,9 @@ NTTS_D void gemm_epilogue_nat(const GemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0
 // per chunk: in natural order the SiLU * up epilogue runs on half the lanes -- gate rows in lanes g < 2, their up rows in g >= 2
 // -- and stores 8-byte pieces; profiles/r02k_sweep_pf_gu_nat.log).  The prefill QKV GEMM keeps it (N = 1152 = 4 x 288: 500 tiles
 // instead of 625 with every fifth half empty; prompt pass -0.8 %).
-// STAG (round 4): the workgroup's waves run as TWO GROUPS staggered by half a k-step -- two barriers per ring slot, group 1 one barrier behind
-//   group 0 -- so that one group's LDS fragment reads (and its LDS-DMA issue) run under the other group's MFMAs instead of everybody reading,
-//   then everybody multiplying (cdna_hip_programming.md: the phase-interleaved 256 x 256 template's "{load-issuing vs MFMA-entering} wave
-//   split").  Hazards, with g = global barrier count, group 0 at A0(kt) = g 2 kt, B0(kt) = g 2 kt + 1, group 1 at A1(kt) = g 2 kt + 1, B1(kt) =
-//   g 2 kt + 2: RAW -- every wave has waited for its OWN loads of tile kt before g 2 kt (group 0 right before A0(kt), group 1 before B1(kt - 1));
-//   WAR -- the slot of tile kt - 1 is refilled after g 2 kt (group 0) / g 2 kt + 1 (group 1), and every wave's reads of tile kt - 1 were retired
-//   (lgkmcnt(0)) before g 2 kt.  Same k order per output element as the unstaggered loop: same bits.
-template <int WM, int WN, int TM, int EPI, int NS, int ABL = 0, int BK = 64, bool WNT = false, bool F8 = false, int TN = 4, bool STAG = false>
+template <int WM, int WN, int TM, int EPI, int NS, int ABL = 0, int BK = 64, bool WNT = false, bool F8 = false, int TN = 4>
 NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     static_assert(BK == 64 || BK == 32, "ring slot K extent");
-    static_assert(!STAG || (WM % 2 == 0 && NS >= 3 && TN == 4), "staggered groups: the row halves of the tile, a ring of at least three slots");
     static_assert(!F8 || BK == 64, "fp8: one ring slot = 128-byte rows");
     static_assert(TN == 4 || ((EPI == EPI_ARGMAX || EPI == EPI_BF16) && !F8 && BK == 64), "natural-order tile: lm_head / prefill QKV, bf16");
     constexpr int ESZ = F8 ? 1 : 2;            // bytes per operand element
@@ -536,51 +528,6 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         if (s < nk) stage(s, s);
     mark(1);
     int buf = 0;                  // ring slot of tile kt
-    if constexpr (STAG) {
-        const int grp = wm / (WM / 2);                  // group 0: the upper row half of the tile, group 1: the lower
-        auto wait_tile = [&](int kt) {                 // this wave's loads of tile kt have landed; tiles kt + 1 .. kt + NS - 2 may stay in flight
-            if (kt + NS - 2 < nk) wait_vmem_le<(NS - 2) * PER_WAVE>(); else wait_vmem();
-        };
-        if (grp == 1) { wait_tile(0); sync_keep_dma(); }          // the stagger: g 0 = A0(0)
-        for (int kt = 0; kt < nk; ++kt) {
-            if (grp == 0) wait_tile(kt);
-            sync_keep_dma();                                       // A
-            if (kt == 0) mark(2);
-            if (kt + NS - 1 < nk) stage(kt + NS - 1, buf == 0 ? NS - 1 : buf - 1);
-            const bf16_t* base = lds + buf * (ROWS * BK);
-            buf = buf + 1 == NS ? 0 : buf + 1;
-            bf16x8 xb[BK / 32][TM], wa[BK / 32][TN];
-#pragma unroll
-            for (int ks = 0; ks < BK / 32; ++ks) {
-                const int c = ks * 4 + g;
-#pragma unroll
-                for (int j = 0; j < TN; ++j) wa[ks][j] = ld16<bf16x8>(base + woff[j] + ((c ^ wsw[j]) << 3));
-#pragma unroll
-                for (int a = 0; a < TM; ++a) xb[ks][a] = ld16<bf16x8>(base + xoff[a] + ((c ^ xsw[a]) << 3));
-            }
-            if (grp == 1 && kt + 1 < nk) wait_tile(kt + 1);        // before B1(kt) = g 2 kt + 2 = A0(kt + 1)
-            sync_keep_dma();                                       // B (retires this wave's fragment reads: lgkmcnt(0))
-            sched_fence();
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < BK / 32; ++ks)
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        if constexpr (F8) {
-                            const i64x2 w2 = __builtin_bit_cast(i64x2, wa[ks][j]), x2 = __builtin_bit_cast(i64x2, xb[ks][a]);
-                            acc[a][j] = mfma16_fp8(w2[0], x2[0], acc[a][j]);
-                            acc[a][j] = mfma16_fp8(w2[1], x2[1], acc[a][j]);
-                        } else {
-                            acc[a][j] = mfma16(wa[ks][j], xb[ks][a], acc[a][j]);
-                        }
-                    }
-            __builtin_amdgcn_s_setprio(0);
-            sched_fence();
-        }
-        if (grp == 0) sync_keep_dma();                             // pairs with group 1's last B
-    } else
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt must have landed; tiles kt+1 .. kt+NS-2 may stay in flight (none are left to wait on
         // at the tail, where the plain drain costs nothing extra)
@@ -648,7 +595,7 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 // ------------------------------------------------------------------------------------------------
 struct GemmShape { int BM, BN, WN; };
 
-template <int WM, int WN, int TM, int EPI, int NS = 2, int ABL = 0, int BK = 64, bool WNT = false, bool F8 = false, int TN = 4, bool STAG = false>
+template <int WM, int WN, int TM, int EPI, int NS = 2, int ABL = 0, int BK = 64, bool WNT = false, bool F8 = false, int TN = 4>
 inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     p.mblocks = (p.M + BM - 1) / BM;
@@ -664,7 +611,7 @@ inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
         p.xcd_xps = 8 / p.mblocks;
         p.xcd_nsplit = 0;
         const int per_xcd = (p.nblocks * nsplit + p.xcd_xps - 1) / p.xcd_xps;
-        NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT, F8, TN, STAG>), dim3(8 * per_xcd), dim3(WM * WN * 64), s, p);
+        NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT, F8, TN>), dim3(8 * per_xcd), dim3(WM * WN * 64), s, p);
         return;
     }
     p.xcd_maffine = 0;
@@ -672,11 +619,11 @@ inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
         p.xcd_nsplit = nsplit;
         const int xps = 8 / nsplit, tiles = p.mblocks * p.nblocks;
         p.xcd_per = (tiles + xps - 1) / xps;
-        NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT, F8, TN, STAG>), dim3(8 * p.xcd_per), dim3(WM * WN * 64), s, p);
+        NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT, F8, TN>), dim3(8 * p.xcd_per), dim3(WM * WN * 64), s, p);
         return;
     }
     p.xcd_nsplit = 0;
-    NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT, F8, TN, STAG>), dim3(p.mblocks * p.nblocks, nsplit), dim3(WM * WN * 64), s, p);
+    NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT, F8, TN>), dim3(p.mblocks * p.nblocks, nsplit), dim3(WM * WN * 64), s, p);
 }
 
 // tile families:  XL = 256x256 (4x4 waves = 1024 threads, 64x64 per wave, 128 KB LDS) -- big-M GEMMs (prefill, codec):

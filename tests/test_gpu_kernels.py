@@ -36,10 +36,6 @@ BIG = [  # the decode-batch and prefill shapes of NeuTTS-Air
     (1500, 1152, 896, 5, True),   # XL tile on the 4-slot ring of 32-wide K slices: prefill QKV, ragged M
     (3000, 896, 4864, 5, False),  # ... prefill down_proj (152 slices)
     (2000, 9728, 896, 5, False),  # ... prefill gate/up width
-    (1500, 1152, 896, 8, True),   # 256 x 256 tile, two staggered wave groups (gemm.h STAG): prefill QKV, ragged M
-    (3000, 896, 4864, 8, False),  # ... prefill down_proj (152 ring slots of K = 32)
-    (2000, 9728, 896, 8, False),  # ... prefill gate/up width
-    (300, 320, 64, 8, True),      # ... two ring slots in all (fewer than the ring holds)
     (1500, 1152, 896, 7, True),   # natural-order 256 x 288 tile: prefill QKV (4 column blocks, none padded), ragged M
     (700, 1000, 448, 7, False),   # ... N = 3 tiles + 136 columns
 ]
