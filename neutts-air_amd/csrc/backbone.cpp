@@ -141,6 +141,8 @@ struct ntts_backbone {
     bf16_t *h_pf = nullptr, *xn_pf = nullptr, *qkv_pf = nullptr, *attn_pf = nullptr, *o_pf = nullptr, *act_pf = nullptr;
     int* meta_dev = nullptr;
     size_t meta_cap = 0;
+    int pf_res_cap = kPfResPages * kPage;   // prompt-pass attention: queries below this position take the resident kernel (attn_prefill.h); NTTS_PF_RES_CAP
+
     // page-locked staging ring of the meta block: a host-to-device copy from pageable memory forced a stream synchronisation into
     // every prompt pass / decode call / code export (the host sat out the previous prompt pass before it could enqueue the next)
     static constexpr int kMetaStages = 4;
@@ -362,6 +364,10 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->ks_o = std::min(max_slabs, pick_split(H / 64, c->num_heads * 64 / ktile));
     e->ks_d = std::min(max_slabs, pick_split(H / 64, F / ktile));
     e->xl_min_m = env_int("NTTS_XL_MIN_M", 0);
+    {   // 0 = every query on the two-sweep kernel; whole pages, at most what the resident kernel holds
+        int cap = env_int("NTTS_PF_RES_CAP", kPfResPages * kPage) / kPage * kPage;
+        e->pf_res_cap = cap < 0 ? 0 : cap > kPfResPages * kPage ? kPfResPages * kPage : cap;
+    }
     e->xcd_xps = (B == 64 || B == 128 || B == 256 || B == 512) ? 8 / (B / 64) : 0;
     e->xcd_affine = env_int("NTTS_XCD_AFFINE", B > 128 ? 7 : 0);
     e->head_tile = env_int("NTTS_HEAD_TILE", B > 128 ? (e->fp8 ? 2 : 4) : B > 64 ? 1 : 0);
@@ -420,7 +426,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     CR_HIP(hipMalloc((void**)&e->attn_pf, T * c->num_heads * 64 * 2));
     CR_HIP(hipMalloc((void**)&e->o_pf, T * H * 2));
     CR_HIP(hipMalloc((void**)&e->act_pf, T * F * 2));
-    e->meta_cap = 2 * T + (size_t)B * (16 + e->max_pages) + (T / 64 + B) * 2 + 3 * (size_t)B * e->max_pages + 64;
+    e->meta_cap = 2 * T + (size_t)B * (16 + e->max_pages) + (T / 64 + 2 * B) * 2 + 4 * (size_t)B + 3 * (size_t)B * e->max_pages + 64;
     CR_HIP(hipMalloc((void**)&e->meta_dev, e->meta_cap * sizeof(int)));
     for (int i = 0; i < ntts_backbone::kMetaStages; ++i) {
         CR_HIP(hipHostMalloc((void**)&e->meta_host[i], e->meta_cap * sizeof(int), hipHostMallocDefault));
@@ -1210,7 +1216,7 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
     }
     // ---- meta block: [ids T][tok_seq T][tok_base n][seq_len n][slot n][min_new n][max_len n][eos n][last_row n]
     //                  [tile_seq nt][tile_q0 nt][bt_rows n*max_pages]
-    std::vector<int> tile_seq, tile_q0;
+    std::vector<int> tile_seq, tile_q0, rtile_seq, rtile_q0, rtile_key;
     std::vector<int> m;
     m.reserve(2 * T + 16 * n);
     for (int i = 0; i < n; ++i) m.insert(m.end(), ids + id_off[i] + pos0[i], ids + id_off[i] + lens[i]);   // packed: new tokens only
@@ -1220,20 +1226,30 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
     long acc = 0;
     for (int i = 0; i < n; ++i) {
         m.push_back((int)acc);
-        for (int q = pos0[i]; q < lens[i]; q += 64) { tile_seq.push_back(i); tile_q0.push_back(q); }
+        // attention work lists, split by POSITION: queries below pf_res_cap (512) go to the resident kernel in 128-query tiles (a tile there sees
+        // <= 16 pages), the rest to the two-sweep kernel in 64-query tiles -- which kernel computes a query depends on nothing but its position
+        const int cap = e->pf_res_cap;
+        const int a_end = lens[i] < cap ? lens[i] : cap;
+        if (a_end > pos0[i]) {   // one work item per 256 queries: (prompt, k) -- the kernel deals the prompt's 16-query blocks out from both ends
+            const int nb = (a_end - pos0[i] + 15) / 16, nwg = (nb + 15) / 16;
+            for (int k = 0; k < nwg; ++k) { rtile_seq.push_back(i); rtile_q0.push_back(k); rtile_key.push_back(nb); }
+        }
+        for (int q = pos0[i] > cap ? pos0[i] : cap; q < lens[i]; q += 64) { tile_seq.push_back(i); tile_q0.push_back(q); }
         acc += lens[i] - pos0[i];
     }
-    {
-        // Causal attention: a 64-query tile that starts at position q0 sweeps (q0 + 64) / 32 KV pages, 2 .. 16 for a 500-token
-        // prompt.  In prompt order the LAST workgroups dispatched are the deepest tiles of the last prompt and the pass ends on
-        // them; sorted by descending depth (stable: ties keep prompt order) the shallow tiles fill the tail instead.
-        std::vector<int> ord(tile_seq.size());
+    // Causal attention: a 64-query tile that starts at position q0 sweeps (q0 + 64) / 32 KV pages, 2 .. 16 for a 500-token
+    // prompt.  In prompt order the LAST workgroups dispatched are the deepest tiles of the last prompt and the pass ends on
+    // them; sorted by descending depth (stable: ties keep prompt order) the shallow tiles fill the tail instead.
+    auto deepest_first = [](std::vector<int>& seq, std::vector<int>& q0, const std::vector<int>& key) {
+        std::vector<int> ord(seq.size());
         for (size_t k = 0; k < ord.size(); ++k) ord[k] = (int)k;
-        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return tile_q0[a] > tile_q0[b]; });
+        std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return key[a] > key[b]; });
         std::vector<int> ts(ord.size()), tq(ord.size());
-        for (size_t k = 0; k < ord.size(); ++k) { ts[k] = tile_seq[ord[k]]; tq[k] = tile_q0[ord[k]]; }
-        tile_seq.swap(ts); tile_q0.swap(tq);
-    }
+        for (size_t k = 0; k < ord.size(); ++k) { ts[k] = seq[ord[k]]; tq[k] = q0[ord[k]]; }
+        seq.swap(ts); q0.swap(tq);
+    };
+    deepest_first(tile_seq, tile_q0, std::vector<int>(tile_q0));
+    deepest_first(rtile_seq, rtile_q0, rtile_key);   // (the work items of one prompt weigh the same: longest prompts first)
     const size_t o_len = m.size();   m.insert(m.end(), lens, lens + n);
     const size_t o_pos0 = m.size();  m.insert(m.end(), pos0.begin(), pos0.end());
     const size_t o_slot = m.size();  m.insert(m.end(), slots, slots + n);
@@ -1250,9 +1266,24 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
     for (int i = 0; i < n; ++i) { acc += lens[i] - pos0[i]; m.push_back((int)acc - 1); }
     const size_t o_tseq = m.size();  m.insert(m.end(), tile_seq.begin(), tile_seq.end());
     const size_t o_tq0 = m.size();   m.insert(m.end(), tile_q0.begin(), tile_q0.end());
-    // work list of the LAST layer's attention: the one tile per prompt that holds its last position
-    const size_t o_ltseq = m.size(); for (int i = 0; i < n; ++i) m.push_back(i);
-    const size_t o_ltq0 = m.size();  for (int i = 0; i < n; ++i) m.push_back(pos0[i] + (lens[i] - 1 - pos0[i]) / 64 * 64);
+    const size_t o_rtseq = m.size(); m.insert(m.end(), rtile_seq.begin(), rtile_seq.end());
+    const size_t o_rtq0 = m.size();  m.insert(m.end(), rtile_q0.begin(), rtile_q0.end());
+    // work lists of the LAST layer's attention: the one tile per prompt that holds its last position (same split by position)
+    std::vector<int> lt_seq, lt_q0, lrt_seq, lrt_q0;
+    for (int i = 0; i < n; ++i) {
+        const int last = lens[i] - 1, cap = e->pf_res_cap;
+        if (last < cap) {   // the work item that holds the prompt's last 16-query block (blocks below nbp / 2 are "lo" blocks of item b / 8, the others "hi" blocks)
+            const int a_end = lens[i] < cap ? lens[i] : cap;
+            const int nb = (a_end - pos0[i] + 15) / 16, nbp = (nb + 15) / 16 * 16, b = nb - 1;
+            lrt_seq.push_back(i);
+            lrt_q0.push_back(b < nbp / 2 ? b / 8 : (nbp - 1 - b) / 8);
+        }
+        else { const int b0 = pos0[i] > cap ? pos0[i] : cap; lt_seq.push_back(i); lt_q0.push_back(b0 + (last - b0) / 64 * 64); }
+    }
+    const size_t o_ltseq = m.size();  m.insert(m.end(), lt_seq.begin(), lt_seq.end());
+    const size_t o_ltq0 = m.size();   m.insert(m.end(), lt_q0.begin(), lt_q0.end());
+    const size_t o_lrtseq = m.size(); m.insert(m.end(), lrt_seq.begin(), lrt_seq.end());
+    const size_t o_lrtq0 = m.size();  m.insert(m.end(), lrt_q0.begin(), lrt_q0.end());
     const size_t o_bt = m.size();
     for (int i = 0; i < n; ++i) {
         const HostSlot& s = e->slots[slots[i]];
@@ -1337,9 +1368,12 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
         // it, then that row and its residual row are compacted and o_proj / the MLP run on n rows instead of T.
         // Row-wise results are unchanged (every GEMM / norm row is computed from that row's operands alone).
         const bool prune = last && T >= 4L * n;
-        int n_tiles = (int)tile_seq.size();
-        if (prune) { a.meta.tile_seq = md + o_ltseq; a.meta.tile_q0 = md + o_ltq0; n_tiles = n; }
-        attn_prefill_launch(a, n_tiles, st);
+        int n_tiles = (int)tile_seq.size(), n_rtiles = (int)rtile_seq.size();
+        if (prune) { a.meta.tile_seq = md + o_ltseq; a.meta.tile_q0 = md + o_ltq0; n_tiles = (int)lt_seq.size(); }
+        if (n_tiles) attn_prefill_launch(a, n_tiles, st);
+        a.meta.tile_seq = md + o_rtseq; a.meta.tile_q0 = md + o_rtq0;
+        if (prune) { a.meta.tile_seq = md + o_lrtseq; a.meta.tile_q0 = md + o_lrtq0; n_rtiles = (int)lrt_seq.size(); }
+        if (n_rtiles) attn_prefill_res_launch(a, n_rtiles, e->pf_res_cap, prune, st);
         const int Mi = prune ? n : Ti;                       // rows from here on
         const bf16_t* attn_in = e->attn_pf;
         bf16_t* hres = e->h_pf;

@@ -104,6 +104,9 @@ struct AttnPrefillArgs {
     int nh, nkv;
     const bf16_t* rope_cos;    // attn_prefill_gqa_kernel: non-null = `qkv` holds the q heads as the QKV GEMM left them and the kernel applies
     const bf16_t* rope_sin;    // RoPE while it loads its Q fragments (rope_kv_write_vec_kernel then only handles k and v: skip_q)
+    int q_cap;                 // attn_prefill_res_kernel: its queries (and, causally, its keys) are the positions below q_cap <= kPfResPages * 32
+    int heads_per_wg;          // attn_prefill_res_kernel: query heads of the group one workgroup walks (grid z covers the rest)
+    int only_last;             // attn_prefill_res_kernel: only the 16-query block that holds the prompt's last position is computed (last layer)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -354,6 +357,282 @@ NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same attention for the queries at positions below 512, with the K and V^T pages RESIDENT in LDS and ONE exp per score.
+// The two-sweep kernel above pays for the eager contract twice: P = bf16(exp(s - m) / sum) needs the row's maximum and denominator
+// before any P is rounded, so it walks the keys twice and computes QK^T and exp(s - m) in both sweeps (~25 issue slots + two quarter-rate
+// v_exp_f32 per score, one wave per SIMD at 256 + 134 registers, a third of the slots AGPR copies and MFMA hazards: 181-210 us per launch
+// at 64 x 500 tokens).  Here one workgroup (8 waves, 256 queries of one prompt and one kv-head: two 16-query blocks per wave, dealt out from
+// both ends of the prompt so that every wave and every workgroup carries the same causal depth) stages every page it can see ONCE (<= 16
+// pages: 64 KB of K + 64 KB of V^T, LDS-DMA, swizzled for the ds_read_b128 lane groups: no bank conflict) and walks the group's query heads
+// one after the other; per head a wave keeps the scores of its 16 queries against ALL keys in registers (16 pages x 8 per lane = 128 VGPRs):
+//   pass A  raw QK^T per page (matrix core) into the registers                                        (no transcendental)
+//   mask + row maximum
+//   pass B  in place: e = exp((bf16(s) - bf16(max)) / 8), denominator                                  (the row's ONE exp per score)
+//   pass C  P = bf16(e / sum) -> PV per page (matrix core)
+// which is torch's own softmax order (max, exp, sum, divide: hf:models/qwen2/modeling_qwen2.py:150-172) with every rounding point of the
+// eager contract kept: bf16(QK^T), the exact 2^-3 scaling, fp32 softmax, P rounded after the normalisation, fp32 PV accumulation in
+// page order.  Per query the arithmetic does not depend on the workgroup it sits in or on what else is in the pass.  One barrier when the
+// shallow blocks' pages are in, one when the rest is; two waves per SIMD (<= 256 registers, no AGPR copies).  103-107 us per launch
+// (profiles/r04j_*).  Queries at positions >= 512 (they would need more than 16 pages) stay with the two-sweep kernel: the host splits the
+// work list by POSITION (backbone.cpp prefill_impl), so which kernel computes a query depends on nothing but where it sits in its prompt.
+constexpr int kPfResPages = 16;
+constexpr int kPfResTile = 256;   // queries per work item: 8 waves x 2 blocks of 16
+// LDS swizzles of the resident images, built for the lane groups a ds_read_b128 is served in (MI355X_MICROARCH.md, LDS: {0-3, 12-15, 20-27},
+// {4-11, 16-19, 28-31} and the same + 32 -- one clock per group when its 16 lanes fall on 16 different 16-byte slots of the 256-byte bank row).
+// K row r (128 B = 8 chunks): chunk c sits at c ^ k_swz(r).  A group reads chunk c of rows {0-3, 12-15} and chunk c + 2 of rows {4-11} (lane group g
+// reads chunks 2g, 2g + 1): even / odd rows own the two halves of the bank row, (r >> 1) spreads a half's 8 rows, and the extra flip of bit 1 on
+// rows 4-11 keeps chunk c + 2 of those rows off the slots of chunk c of the others.  V^T row d (64 B = 4 units): unit u sits at u ^ v_swz(d); a group
+// reads unit g of rows {0-3, 12-15} and unit g + 1 of rows {4-11}: same construction one bit lower.
+NTTS_D int k_swz(int r) { return ((r >> 1) & 7) ^ ((((r + 4) >> 3) & 1) << 1); }
+NTTS_D int v_swz(int d) { return ((d >> 2) & 3) ^ (((d + 4) >> 3) & 1); }
+template <int NP>
+NTTS_KERNEL(512) void attn_prefill_res_kernel(AttnPrefillArgs p) {
+    NTTS_SHARED bf16_t kres[NP * kPage * 64];    // [page][32 keys][128 B], chunk c of key r at c ^ k_swz(r)
+    NTTS_SHARED bf16_t vres[NP * 64 * kPage];    // [page][64 d][64 B], 16-B unit u of row d at u ^ v_swz(d)
+    const int lane = lane_id(), w = wave_id();
+    const int g = lane >> 4, l15 = lane & 15;
+    const int tile = blockIdx.y, kvh = blockIdx.x;
+    const int sq = p.meta.tile_seq[tile];
+    const int S = p.meta.seq_len[sq];
+    const int Sq = S < p.q_cap ? S : p.q_cap;                 // this launch's queries end here
+    const int pos0 = p.meta.pos0[sq];
+    const int base = p.meta.tok_base[sq] - pos0;              // packed row of absolute position q is base + q
+    const int group = p.nh / p.nkv;
+    const int hb = kvh * group + blockIdx.z * p.heads_per_wg;
+    int he = hb + p.heads_per_wg;
+    if (he > (kvh + 1) * group) he = (kvh + 1) * group;
+    const int* bt = p.block_table + (long)p.meta.slot[sq] * p.max_pages;
+    // ---- the workgroup's queries: the prompt's 16-query blocks 0 .. nb - 1 (padded to a multiple of 16: nbp) are dealt out so that every workgroup
+    //      and every wave gets the same causal depth -- workgroup k takes the 8 blocks from 8 k up and the 8 blocks from nbp - 1 - 8 k down, wave w
+    //      block 8 k + w ("lo") and then block nbp - 1 - 8 k - w ("hi"): a shallow and a deep one, the same sum for every (k, w).  (A tile of 128
+    //      consecutive queries gave waves of 13 .. 16 pages next to waves of 1 .. 4: SIMD slots idle behind the 128 KB of LDS, 1.4 of 2 waves resident.)
+    const int nb = (Sq - pos0 + 15) >> 4;
+    const int nbp = (nb + 15) & ~15;
+    const int k8 = p.meta.tile_q0[tile] * 8;                  // tile_q0 = k
+    const int blk_lo = k8 + w, blk_hi = nbp - 1 - k8 - w;
+    int top_lo = k8 + 7;                                      // deepest live block of each half (workgroup-uniform)
+    if (top_lo > nb - 1) top_lo = nb - 1;
+    int top_hi = nbp - 1 - k8;
+    if (top_hi > nb - 1) top_hi = nb - 1;
+    auto pages_to = [&](int blk) { const int ql = pos0 + blk * 16 + 15; return (ql < Sq - 1 ? ql : Sq - 1) / kPage + 1; };
+    const int np_lo = pages_to(top_lo);                       // pages the lo blocks can see (causal), and all blocks: <= NP
+    const int npages = pages_to(top_hi > top_lo ? top_hi : top_lo);
+
+    // ---- every page the workgroup can see, requested in page order: wave w brings 1 KB piece w of each (0-3: K, 8 keys each; 4-7: V^T, 16 d-rows
+    //      each).  First the pages the lo blocks need, then the lo block's first q rows, then the rest: a wave's requests retire in order, so "at most
+    //      npages - np_lo still in flight" below means its pieces of pages 0 .. np_lo - 1 and those q rows have landed, and the lo blocks run while
+    //      the deep pages arrive (s_waitcnt takes an immediate: one case per count)
+    auto stage = [&](int pg) {
+        const long page = bt[pg];
+        if (w < 4) {
+            const int r = w * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ k_swz(r);
+            glds16(p.kpool + ((page * p.nkv + kvh) * kPage + r) * 64 + c * 8, kres + pg * (kPage * 64) + w * 512);
+        } else {
+            const int d = (w - 4) * 16 + (lane >> 2);
+            const int u = (lane & 3) ^ v_swz(d);
+            glds16(p.vpool + (page * p.nkv + kvh) * 64 * kPage + d * kPage + u * 8, vres + pg * (64 * kPage) + (w - 4) * 512);
+        }
+    };
+    // RoPE operands of a lane's query: d = 16 g .. 16 g + 15, the pair partner d +- 32 is the chunk of lane group g ^ 2 (read from the row directly:
+    // L2 hits instead of cross-lane traffic); o = bf16(bf16(x c) + bf16(x' s')), s' = -s below d = 32 -- rope_pair, the one output this lane keeps
+    bf16x8 qn[4];                                              // next head's raw chunks: own 2, partner 2
+    auto fetch_q = [&](const bf16_t* qrow, int h) {
+        const bf16_t* qr = qrow + h * 64;
+        qn[0] = ld16<bf16x8>(qr + g * 16);
+        qn[1] = ld16<bf16x8>(qr + g * 16 + 8);
+        if (p.rope_cos) {
+            qn[2] = ld16<bf16x8>(qr + (g ^ 2) * 16);
+            qn[3] = ld16<bf16x8>(qr + (g ^ 2) * 16 + 8);
+        }
+    };
+    auto qpos_of = [&](int blk) { const int q = pos0 + blk * 16 + l15; return q > Sq - 1 ? Sq - 1 : q; };
+    for (int pg = 0; pg < np_lo; ++pg) stage(pg);
+    const bool lo_live = blk_lo < nb && !(p.only_last && blk_lo != nb - 1);
+    if (lo_live) fetch_q(p.qkv + (long)(base + qpos_of(blk_lo)) * p.ld_qkv, hb);
+    for (int pg = np_lo; pg < npages; ++pg) stage(pg);
+    switch (npages - np_lo) {
+#define NTTS_PF_CASE(n) case n: wait_vmem_le<n>(); break;
+        NTTS_PF_CASE(0) NTTS_PF_CASE(1) NTTS_PF_CASE(2) NTTS_PF_CASE(3) NTTS_PF_CASE(4) NTTS_PF_CASE(5) NTTS_PF_CASE(6) NTTS_PF_CASE(7)
+        NTTS_PF_CASE(8) NTTS_PF_CASE(9) NTTS_PF_CASE(10) NTTS_PF_CASE(11) NTTS_PF_CASE(12) NTTS_PF_CASE(13) NTTS_PF_CASE(14) NTTS_PF_CASE(15)
+#undef NTTS_PF_CASE
+        default: wait_vmem(); break;
+    }
+    sync_keep_dma();
+
+    constexpr float kMasked = -1.0e30f;
+    for (int half = 0; half < 2; ++half) {
+    if (half == 1) { wait_vmem(); sync_keep_dma(); }           // the rest of the pages (every wave passes here, live or not)
+    const int blk = half == 0 ? blk_lo : blk_hi;
+    if (blk >= nb || blk < 0 || (p.only_last && blk != nb - 1)) continue;   // padding block (no barrier is skipped: the one above precedes this test)
+    const int qw0 = pos0 + blk * 16;                          // first query of this wave's block
+    const int qpos = qpos_of(blk);
+    const int qlast_w = (qw0 + 15 < Sq ? qw0 + 15 : Sq - 1);
+    const int npw = qlast_w / kPage + 1;                      // pages this block computes on; the last one holds its diagonal
+    const bf16_t* qrow = p.qkv + (long)(base + qpos) * p.ld_qkv;
+    bf16x8 cv[2], sv[2];
+    if (p.rope_cos) {
+        const bf16_t* cr = p.rope_cos + (long)qpos * 32 + (g & 1) * 16;
+        const bf16_t* sr = p.rope_sin + (long)qpos * 32 + (g & 1) * 16;
+        cv[0] = ld16<bf16x8>(cr); cv[1] = ld16<bf16x8>(cr + 8);
+        sv[0] = ld16<bf16x8>(sr); sv[1] = ld16<bf16x8>(sr + 8);
+    }
+    if (half == 1) fetch_q(qrow, hb);                          // (the lo block's first rows were requested ahead of the deep pages)
+    const bool vtail = npw * kPage > S;                        // the block's last page holds slots past the prompt: their V^T entries are not data
+    const int qrel = qpos - (npw - 1) * kPage;                 // this lane's query and the prompt's end relative to the block's last (diagonal) page
+    const int srel = S - (npw - 1) * kPage;
+    for (int h = hb; h < he; ++h) {
+        bf16x8 qB[2];
+        if (p.rope_cos) {
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float c = bf2f((bf16_t)cv[f][e]), s0 = bf2f((bf16_t)sv[f][e]);
+                    const float a = rbf(bf2f((bf16_t)qn[f][e]) * c);
+                    const float b = rbf(bf2f((bf16_t)qn[2 + f][e]) * (g < 2 ? -s0 : s0));
+                    qB[f][e] = (short)f2bf(a + b);
+                }
+        } else {
+            qB[0] = qn[0]; qB[1] = qn[1];
+        }
+        if (h + 1 < he) fetch_q(qrow, h + 1);                  // lands under this head's passes
+
+        // (every pass takes its own opaque copy of the wave's page count: a page guard is then one s_cmp + s_cbranch where it stands, instead of a lane
+        //  mask per (pass, page) computed ahead of the head loop and parked in spilled SGPR pairs)
+        // ---- pass A: raw scores into registers, four pages per guard (8 LDS reads in flight ahead of 16 matrix-core ops; a page past the wave's last
+        //      one is computed on whatever its LDS slot holds and never looked at again)
+        float sc[NP * 8];
+        {
+            const int n = opaque_u(npw);
+#pragma unroll
+            for (int pq = 0; pq < NP; pq += 4) {
+                if (pq < n) {
+#pragma unroll
+                    for (int pg = pq; pg < pq + 4; ++pg) {
+                        const bf16_t* kb = kres + pg * (kPage * 64);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int r = u * 16 + l15;
+                            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                            a = mfma16(ld16<bf16x8>(kb + r * 64 + (((2 * g) ^ k_swz(r)) << 3)), qB[0], a);
+                            a = mfma16(ld16<bf16x8>(kb + r * 64 + (((2 * g + 1) ^ k_swz(r)) << 3)), qB[1], a);
+#pragma unroll
+                            for (int rr = 0; rr < 4; ++rr) sc[pg * 8 + u * 4 + rr] = a[rr];
+                        }
+                    }
+                }
+            }
+        }
+        // ---- the diagonal page (the wave's last): causal mask (covers key >= S as qpos <= S - 1); then the row maximum
+        float mx = kMasked;
+        {
+            const int n = opaque_u(npw);
+            const int rel = opaque(qrel);
+#pragma unroll
+            for (int pg = 0; pg < NP; ++pg) {
+                if (pg < n) {
+                    if (pg + 1 == n) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) sc[pg * 8 + e] = (e >> 2) * 16 + g * 4 + (e & 3) > rel ? kMasked : sc[pg * 8 + e];
+                    }
+                    mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(sc[pg * 8], sc[pg * 8 + 1]), fmaxf(sc[pg * 8 + 2], sc[pg * 8 + 3])),
+                                         fmaxf(fmaxf(sc[pg * 8 + 4], sc[pg * 8 + 5]), fmaxf(sc[pg * 8 + 6], sc[pg * 8 + 7]))));
+                }
+            }
+        }
+        mx = fmaxf(mx, shfl_xor(mx, 16));
+        mx = fmaxf(mx, shfl_xor(mx, 32));                      // row maximum of query l15 (key 0 is never masked: finite)
+        const float mr = rbf(mx);                              // rounding is monotone: bf16(max) = max of the bf16 scores
+        // ---- pass B: e = exp((bf16(s) - bf16(max)) / 8) in place; the 2^-3 scaling of the eager contract is exact, so it rides in fexp_neg8's constants
+        float sum0 = 0.f, sum1 = 0.f;
+        {
+            const int n = opaque_u(npw);
+#pragma unroll
+            for (int pg = 0; pg < NP; ++pg) {
+                if (pg < n) {
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const float e0 = fexp_neg8(rbf(sc[pg * 8 + e]) - mr), e1 = fexp_neg8(rbf(sc[pg * 8 + e + 1]) - mr);
+                        sc[pg * 8 + e] = e0;
+                        sc[pg * 8 + e + 1] = e1;
+                        sum0 += e0;
+                        sum1 += e1;
+                    }
+                }
+            }
+        }
+        float sum = sum0 + sum1;
+        sum += shfl_xor(sum, 16);
+        sum += shfl_xor(sum, 32);
+        const float rs = frcp_refined(sum);
+        // ---- pass C: P = bf16(e / sum), O += P V (page order)
+        f32x4 oacc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) oacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const int n = opaque_u(npw);
+            const int lim = opaque(srel);
+#pragma unroll
+            for (int pg = 0; pg < NP; ++pg) {
+                if (pg < n) {
+                    const bf16_t* vb = vres + pg * (64 * kPage);
+                    bf16x8 vB[4];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int d = nt * 16 + l15;
+                        vB[nt] = ld16<bf16x8>(vb + d * kPage + ((g ^ v_swz(d)) << 3));   // 16-B unit g of the row = keys 4g..+3, 16+4g..+3
+                    }
+                    bf16x8 pA;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pA[e] = (short)f2bf(fdiv_r(sc[pg * 8 + e], sum, rs));
+                    if (vtail && pg + 1 == n) {
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if ((e < 4 ? g * 4 + e : 16 + g * 4 + e - 4) >= lim) vB[nt][e] = 0;
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) oacc[nt] = mfma16(pA, vB[nt], oacc[nt]);
+                }
+            }
+        }
+        // D: col = d (l15 of tile nt), row = query qw0 + g*4 + r
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = qw0 + g * 4 + r;
+            if (q < Sq) {
+                if (p.out_fp8_inv > 0.f) {
+                    unsigned char* o = (unsigned char*)p.out + (long)(base + q) * p.ld_out + h * 64 + l15;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) o[nt * 16] = f2fp8c(rbf(oacc[nt][r]) * p.out_fp8_inv);
+                } else {
+                    bf16_t* o = p.out + (long)(base + q) * p.ld_out + h * 64 + l15;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) o[nt * 16] = f2bf(oacc[nt][r]);
+                }
+            }
+        }
+    }
+    }
+}
+
+// host launcher of the resident kernel: short passes spread the group's heads over grid z while the grid stays within the CUs (as below)
+inline void attn_prefill_res_launch(AttnPrefillArgs p, int n_tiles, int q_cap, bool only_last, hipStream_t s) {
+    const int group = p.nh / p.nkv;
+    const long pairs = (long)p.nkv * n_tiles;
+    int hps = group;
+    if (pairs * group <= 256) hps = 1;
+    else if (pairs * ((group + 1) / 2) <= 256) hps = 2;
+    else if (pairs * ((group + 3) / 4) <= 256) hps = 4;
+    p.q_cap = q_cap;
+    p.heads_per_wg = hps;
+    p.only_last = only_last ? 1 : 0;
+    NTTS_LAUNCH((attn_prefill_res_kernel<kPfResPages>), dim3(p.nkv, n_tiles, (group + hps - 1) / hps), dim3(512), s, p);
 }
 
 // host launcher: GH = 7 covers NeuTTS-Air's group in one pass; other group sizes run ceil(group / GH) passes

@@ -96,6 +96,11 @@ NTTS_D void lds_barrier() { sync_keep_dma(); }
 // nothing is scheduled across this point by the compiler (issue order of memory requests matters: in-order returns)
 NTTS_D void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 
+// the value, opaque to the optimiser, with a side effect where it stands: code that uses it is neither hoisted out of its loop nor
+// if-converted out of its (wave-uniform) branch
+NTTS_D int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+NTTS_D int opaque_u(int v) { asm volatile("" : "+s"(v)); return v; }   // the same for a wave-uniform value (stays in a scalar register)
+
 NTTS_D unsigned int atomic_add_global(unsigned int* p, unsigned int v) { return atomicAdd(p, v); }
 NTTS_D unsigned int atomic_add_lds(unsigned int* p, unsigned int v) { return atomicAdd(p, v); }
 // constant-rate timestamp (s_memrealtime, 100 MHz): phase timelines of a kernel (diagnostics only)
@@ -112,6 +117,16 @@ NTTS_D float fexp_neg(float x) {
     const float t = x * hi;
     float r = __builtin_fmaf(x, hi, -t);
     r = __builtin_fmaf(x, lo, r);
+    const float y = __builtin_amdgcn_exp2f(t);
+    return __builtin_fmaf(y, r * 0.693147180559945309f, y);
+}
+// exp(d / 8) for finite d <= 0: fexp_neg(d * 0.125f) bit for bit with the exact 2^-3 scaling folded into the constants (every product
+// and fma below is the one fexp_neg forms, scaled by a power of two on both sides of its rounding)
+NTTS_D float fexp_neg8(float d) {
+    const float hi = 1.44269502162933349609375f * 0.125f, lo = 1.925963033500011e-8f * 0.125f;
+    const float t = d * hi;
+    float r = __builtin_fmaf(d, hi, -t);
+    r = __builtin_fmaf(d, lo, r);
     const float y = __builtin_amdgcn_exp2f(t);
     return __builtin_fmaf(y, r * 0.693147180559945309f, y);
 }

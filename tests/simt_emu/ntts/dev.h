@@ -248,6 +248,16 @@ inline float fexp_neg(float x) {
     const float y = exp2f(t);
     return fmaf(y, r * 0.693147180559945309f, y);
 }
+inline int opaque(int v) { return v; }
+inline int opaque_u(int v) { return v; }
+inline float fexp_neg8(float d) {
+    const float hi = 1.44269502162933349609375f * 0.125f, lo = 1.925963033500011e-8f * 0.125f;
+    const float t = d * hi;
+    float r = fmaf(d, hi, -t);
+    r = fmaf(d, lo, r);
+    const float y = exp2f(t);
+    return fmaf(y, r * 0.693147180559945309f, y);
+}
 inline float fdiv_r(float e, float d, float r) {
     const float q = e * r;
     return fmaf(fmaf(-q, d, e), r, q);

@@ -70,6 +70,27 @@ def test_short_sequence_beside_a_long_one_across_the_split_switch(emu_lib, monke
         assert fin and ids == want[s].ids, (s, ids, want[s].ids)
 
 
+@pytest.mark.parametrize("cap", ["512", "64", "0"])
+def test_prompt_pass_attention_split_by_position(emu_lib, monkeypatch, cap):
+    """Prompt-pass attention runs on two kernels, chosen by the query's POSITION alone (attn_prefill.h): below NTTS_PF_RES_CAP (512) the
+    resident kernel (pages in LDS, one exp per score, 16-query blocks dealt out from both ends of the prompt), from there on the two-sweep
+    kernel.  A 150-token and a 37-token prompt with everything on the resident kernel, with the cut at 64 (the long prompt uses both: four
+    blocks here, the rest there) and with everything on the two-sweep kernel: HF's ids bit for bit every time (walk weights)."""
+    monkeypatch.setenv("NTTS_PF_RES_CAP", cap)
+    z, cfg, w = load_fixture("backbone_small_walk")
+    wd = br.cast_weights(w, torch.bfloat16)
+    N, eos = 6, int(z["eos"])
+    prompts = [br.synthetic_prompt(cfg, 2, 150), br.synthetic_prompt(cfg, 5, 37)]
+    want = [br.generate(cfg, wd, p, len(p) + N, eos_id=eos, min_new_tokens=N, keep_logits=True) for p in prompts]
+    eng = make_engine(cfg, w, emu_lib, max_batch=2, max_context=192)
+    samp = [_hip.Sampling(max_length=len(p) + N, min_new_tokens=N, eos_token_id=eos, do_sample=False) for p in prompts]
+    eng.prefill(prompts, [1, 0], samp)
+    eng.decode(N - 1)
+    for s, u in ((1, 0), (0, 1)):
+        ids, fin = eng.read(s)
+        assert fin and ids == want[u].ids, (cap, u, ids, want[u].ids)
+
+
 def test_xcd_row_block_placement(emu_lib, monkeypatch):
     """NTTS_XCD_AFFINE=7 (the default above batch 128): split-K GEMMs, the norms behind them and decode attention place the rows of a
     64-row m-block on one group of XCDs (gemm.h xcd_maffine, norm.h xcd_row).  A pure permutation of which workgroup does what:
