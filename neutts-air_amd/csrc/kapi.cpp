@@ -304,7 +304,14 @@ extern "C" int ntts_k_launch_chain_probe(int32_t n_kernels, int32_t grid, int32_
 
 NTTS_KERNEL(256) void silu_probe_kernel(const bf16_t* in, bf16_t* out, long n, int variant) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = f2bf(variant ? silu_fast(bf2f(in[i])) : silu_f(bf2f(in[i])));
+    if (i >= n) return;
+    if (variant == 2) {   // the packed form of the GEMM epilogues with their guard: pairs (i, i ^ 1), silu_fast below -86.5
+        const float a = bf2f(in[i]), b = bf2f(in[(i ^ 1) < n ? (i ^ 1) : i]);
+        if (a < -86.5f || b < -86.5f) out[i] = f2bf(silu_fast(a));
+        else out[i] = f2bf(silu_fast2(f32x2{a, b})[0]);
+        return;
+    }
+    out[i] = f2bf(variant ? silu_fast(bf2f(in[i])) : silu_f(bf2f(in[i])));
 }
 extern "C" int ntts_k_silu_probe(const void* in_bf16_dev, void* out_bf16_dev, int64_t n, int32_t variant) {
     if (!in_bf16_dev || !out_bf16_dev || n < 1) return NTTS_EINVAL;

@@ -140,6 +140,19 @@ NTTS_D float frcp_refined(float d) {
     return __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
 }
 NTTS_D float frsqrt_exact(float x) { return 1.0f / sqrtf(x); }
+NTTS_D float frcp_raw(float d) { return __builtin_amdgcn_rcpf(d); }   // v_rcp_f32 (frcp_refined's first step)
+// two floats after one bf16 rounding each: ONE v_cvt_pk_bf16_f32 + two unpacks
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+NTTS_D f32x2_t rbf2(f32x2_t v) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+    const unsigned int u = __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf2_t));
+    f32x2_t o;
+    o[0] = __builtin_bit_cast(float, u << 16);
+    o[1] = __builtin_bit_cast(float, u & 0xffff0000u);
+    return o;
+}
+// true on every lane if the predicate holds on any lane of the wave
+NTTS_D bool any_lane(bool p) { return ballot(p) != 0; }
 
 template <typename T>
 NTTS_D T ld16(const void* p) { return *reinterpret_cast<const T*>(p); }

@@ -267,6 +267,10 @@ inline float frcp_refined(float d) {
     return fmaf(fmaf(-d, r, 1.0f), r, r);
 }
 inline float frsqrt_exact(float x) { return 1.0f / sqrtf(x); }
+inline float frcp_raw(float d) { return 1.0f / d; }
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+inline f32x2_t rbf2(f32x2_t v) { f32x2_t o; o[0] = rbf(v[0]); o[1] = rbf(v[1]); return o; }
+inline bool any_lane(bool p) { return ballot(p) != 0; }
 
 template <typename T>
 inline T ld16(const void* p) {

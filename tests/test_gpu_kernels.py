@@ -96,7 +96,7 @@ def test_silu_all_bf16_inputs(lib):
     """The SiLU of the gate/up epilogues on EVERY bf16 input: both forms (division by 1 + expf(-x); the fast form the kernels
     use) round to exactly torch's bf16 SiLU for every finite input, so swapping one for the other cannot move a token."""
     from test_emu_kernels import silu_all_bf16
-    for variant in (0, 1):
+    for variant in (0, 1, 2):      # 2 = the packed two-at-a-time form of the GEMM epilogues (silu_fast2)
         x, got, ref = silu_all_bf16(lib, "cuda", variant)
         fin = torch.isfinite(x.float())
         bad = (got.view(torch.int16)[fin] != ref.view(torch.int16)[fin])
