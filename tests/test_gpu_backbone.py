@@ -168,6 +168,30 @@ def test_prompt_pass_attention_split_by_position(lib, monkeypatch, cap):
     eng.close()
 
 
+@pytest.mark.parametrize("n_prompts", [24, 40, 70])
+def test_prompt_pass_attention_heads_spread_over_workgroups(lib, n_prompts):
+    """Short prompt passes spread a kv-group's query heads over workgroups while the grid stays within the CUs (attn_prefill_res_launch:
+    1 / 2 / 4 / all 7 heads per workgroup).  24 prompts of 200 tokens take 2 heads per workgroup, 40 take 4, 70 all 7; the checked rows must equal
+    the oracle's runs of those prompts alone whichever way the heads are dealt out (NeuTTS-Air's width and head counts, walk weights)."""
+    cfg = br.BackboneConfig(vocab_size=3000, hidden_size=896, intermediate_size=1216, num_layers=2)
+    w = br.make_weights(cfg, 35, walk_gain=4.0)
+    wd = br.cast_weights(w, torch.bfloat16)
+    N, eos = 6, cfg.vocab_size - 1
+    lens = [200 - 3 * (i % 5) for i in range(n_prompts)]
+    prompts = [br.synthetic_prompt(cfg, 10 + i, lens[i]) for i in range(n_prompts)]
+    check = [0, n_prompts // 2, n_prompts - 1]
+    want = {i: br.generate(cfg, wd, prompts[i], lens[i] + N, eos_id=eos, min_new_tokens=N, keep_logits=True) for i in check}
+    eng = make_engine(cfg, w, lib, max_batch=n_prompts, max_context=256, max_prefill_tokens=200 * n_prompts, bf16_upload=True)
+    samp = [_hip.Sampling(max_length=lens[i] + N, min_new_tokens=N, eos_token_id=eos, do_sample=False) for i in range(n_prompts)]
+    eng.prefill(prompts, list(range(n_prompts)), samp)
+    eng.decode(N - 1)
+    for i in check:
+        ids, fin = eng.read(i)
+        assert fin and len(ids) == N
+        assert_walk_exact(ids, want[i].ids)
+    eng.close()
+
+
 @pytest.mark.parametrize("max_batch", [2, 16])
 def test_short_sequence_beside_a_long_one_across_the_split_switch(lib, max_batch):
     """the choice between the single-workgroup attention and the context-split one follows the LONGEST running context
