@@ -142,6 +142,7 @@ struct ntts_backbone {
     int* meta_dev = nullptr;
     size_t meta_cap = 0;
     int pf_res_cap = kPfResPages * kPage;   // prompt-pass attention: queries below this position take the resident kernel (attn_prefill.h); NTTS_PF_RES_CAP
+    int pf_deep_cap = kPfDeepPages * kPage; // ... and from there up to this one the deep kernel; NTTS_PF_DEEP_CAP (<= pf_res_cap: tier off)
 
     // page-locked staging ring of the meta block: a host-to-device copy from pageable memory forced a stream synchronisation into
     // every prompt pass / decode call / code export (the host sat out the previous prompt pass before it could enqueue the next)
@@ -367,6 +368,9 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     {   // 0 = every query on the two-sweep kernel; whole pages, at most what the resident kernel holds
         int cap = env_int("NTTS_PF_RES_CAP", kPfResPages * kPage) / kPage * kPage;
         e->pf_res_cap = cap < 0 ? 0 : cap > kPfResPages * kPage ? kPfResPages * kPage : cap;
+        int dcap = env_int("NTTS_PF_DEEP_CAP", kPfDeepPages * kPage) / kPage * kPage;
+        dcap = dcap > kPfDeepPages * kPage ? kPfDeepPages * kPage : dcap;
+        e->pf_deep_cap = dcap < e->pf_res_cap ? e->pf_res_cap : dcap;
     }
     e->xcd_xps = (B == 64 || B == 128 || B == 256 || B == 512) ? 8 / (B / 64) : 0;
     e->xcd_affine = env_int("NTTS_XCD_AFFINE", B > 128 ? 7 : 0);
@@ -426,7 +430,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     CR_HIP(hipMalloc((void**)&e->attn_pf, T * c->num_heads * 64 * 2));
     CR_HIP(hipMalloc((void**)&e->o_pf, T * H * 2));
     CR_HIP(hipMalloc((void**)&e->act_pf, T * F * 2));
-    e->meta_cap = 2 * T + (size_t)B * (16 + e->max_pages) + (T / 64 + 2 * B) * 2 + 4 * (size_t)B + 3 * (size_t)B * e->max_pages + 64;
+    e->meta_cap = 2 * T + (size_t)B * (16 + e->max_pages) + (T / 64 + 3 * B) * 2 + 6 * (size_t)B + 3 * (size_t)B * e->max_pages + 64;
     CR_HIP(hipMalloc((void**)&e->meta_dev, e->meta_cap * sizeof(int)));
     for (int i = 0; i < ntts_backbone::kMetaStages; ++i) {
         CR_HIP(hipHostMalloc((void**)&e->meta_host[i], e->meta_cap * sizeof(int), hipHostMallocDefault));
@@ -1216,7 +1220,7 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
     }
     // ---- meta block: [ids T][tok_seq T][tok_base n][seq_len n][slot n][min_new n][max_len n][eos n][last_row n]
     //                  [tile_seq nt][tile_q0 nt][bt_rows n*max_pages]
-    std::vector<int> tile_seq, tile_q0, rtile_seq, rtile_q0, rtile_key;
+    std::vector<int> tile_seq, tile_q0, rtile_seq, rtile_q0, rtile_key, dtile_seq, dtile_q0, dtile_key;
     std::vector<int> m;
     m.reserve(2 * T + 16 * n);
     for (int i = 0; i < n; ++i) m.insert(m.end(), ids + id_off[i] + pos0[i], ids + id_off[i] + lens[i]);   // packed: new tokens only
@@ -1226,15 +1230,19 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
     long acc = 0;
     for (int i = 0; i < n; ++i) {
         m.push_back((int)acc);
-        // attention work lists, split by POSITION: queries below pf_res_cap (512) go to the resident kernel in 128-query tiles (a tile there sees
-        // <= 16 pages), the rest to the two-sweep kernel in 64-query tiles -- which kernel computes a query depends on nothing but its position
-        const int cap = e->pf_res_cap;
-        const int a_end = lens[i] < cap ? lens[i] : cap;
-        if (a_end > pos0[i]) {   // one work item per 256 queries: (prompt, k) -- the kernel deals the prompt's 16-query blocks out from both ends
-            const int nb = (a_end - pos0[i] + 15) / 16, nwg = (nb + 15) / 16;
-            for (int k = 0; k < nwg; ++k) { rtile_seq.push_back(i); rtile_q0.push_back(k); rtile_key.push_back(nb); }
-        }
-        for (int q = pos0[i] > cap ? pos0[i] : cap; q < lens[i]; q += 64) { tile_seq.push_back(i); tile_q0.push_back(q); }
+        // attention work lists, split by POSITION into three tiers (attn_prefill.h): queries below pf_res_cap (512) go to the resident kernel, those
+        // below pf_deep_cap (1024) to the deep one -- both take work items (prompt, k) of 256 queries whose 16-query blocks the kernel deals out from
+        // both ends of the tier -- the rest to the two-sweep kernel in 64-query tiles.  Which kernel computes a query depends on nothing but its position
+        const int cap = e->pf_res_cap, dcap = e->pf_deep_cap;
+        auto items = [&](int lo, int hi, std::vector<int>& seq, std::vector<int>& q0, std::vector<int>& key) {
+            const int b0 = pos0[i] > lo ? pos0[i] : lo, a_end = lens[i] < hi ? lens[i] : hi;
+            if (a_end <= b0) return;
+            const int nb = (a_end - b0 + 15) / 16, nwg = (nb + 15) / 16;
+            for (int k = 0; k < nwg; ++k) { seq.push_back(i); q0.push_back(k); key.push_back(nb); }
+        };
+        items(0, cap, rtile_seq, rtile_q0, rtile_key);
+        items(cap, dcap, dtile_seq, dtile_q0, dtile_key);
+        for (int q = pos0[i] > dcap ? pos0[i] : dcap; q < lens[i]; q += 64) { tile_seq.push_back(i); tile_q0.push_back(q); }
         acc += lens[i] - pos0[i];
     }
     // Causal attention: a 64-query tile that starts at position q0 sweeps (q0 + 64) / 32 KV pages, 2 .. 16 for a 500-token
@@ -1250,6 +1258,7 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
     };
     deepest_first(tile_seq, tile_q0, std::vector<int>(tile_q0));
     deepest_first(rtile_seq, rtile_q0, rtile_key);   // (the work items of one prompt weigh the same: longest prompts first)
+    deepest_first(dtile_seq, dtile_q0, dtile_key);
     const size_t o_len = m.size();   m.insert(m.end(), lens, lens + n);
     const size_t o_pos0 = m.size();  m.insert(m.end(), pos0.begin(), pos0.end());
     const size_t o_slot = m.size();  m.insert(m.end(), slots, slots + n);
@@ -1268,22 +1277,28 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
     const size_t o_tq0 = m.size();   m.insert(m.end(), tile_q0.begin(), tile_q0.end());
     const size_t o_rtseq = m.size(); m.insert(m.end(), rtile_seq.begin(), rtile_seq.end());
     const size_t o_rtq0 = m.size();  m.insert(m.end(), rtile_q0.begin(), rtile_q0.end());
-    // work lists of the LAST layer's attention: the one tile per prompt that holds its last position (same split by position)
-    std::vector<int> lt_seq, lt_q0, lrt_seq, lrt_q0;
+    const size_t o_dtseq = m.size(); m.insert(m.end(), dtile_seq.begin(), dtile_seq.end());
+    const size_t o_dtq0 = m.size();  m.insert(m.end(), dtile_q0.begin(), dtile_q0.end());
+    // work lists of the LAST layer's attention: the one tile / work item per prompt that holds its last position (same split by position)
+    std::vector<int> lt_seq, lt_q0, lrt_seq, lrt_q0, ldt_seq, ldt_q0;
     for (int i = 0; i < n; ++i) {
-        const int last = lens[i] - 1, cap = e->pf_res_cap;
-        if (last < cap) {   // the work item that holds the prompt's last 16-query block (blocks below nbp / 2 are "lo" blocks of item b / 8, the others "hi" blocks)
-            const int a_end = lens[i] < cap ? lens[i] : cap;
-            const int nb = (a_end - pos0[i] + 15) / 16, nbp = (nb + 15) / 16 * 16, b = nb - 1;
-            lrt_seq.push_back(i);
-            lrt_q0.push_back(b < nbp / 2 ? b / 8 : (nbp - 1 - b) / 8);
-        }
-        else { const int b0 = pos0[i] > cap ? pos0[i] : cap; lt_seq.push_back(i); lt_q0.push_back(b0 + (last - b0) / 64 * 64); }
+        const int last = lens[i] - 1, cap = e->pf_res_cap, dcap = e->pf_deep_cap;
+        // the work item that holds a tier's last 16-query block: blocks below nbp / 2 are "lo" blocks of item b / 8, the others "hi" blocks
+        auto last_item = [&](int lo, int hi) {
+            const int b0 = pos0[i] > lo ? pos0[i] : lo, a_end = lens[i] < hi ? lens[i] : hi;
+            const int nb = (a_end - b0 + 15) / 16, nbp = (nb + 15) / 16 * 16, b = nb - 1;
+            return b < nbp / 2 ? b / 8 : (nbp - 1 - b) / 8;
+        };
+        if (last < cap) { lrt_seq.push_back(i); lrt_q0.push_back(last_item(0, cap)); }
+        else if (last < dcap) { ldt_seq.push_back(i); ldt_q0.push_back(last_item(cap, dcap)); }
+        else { const int b0 = pos0[i] > dcap ? pos0[i] : dcap; lt_seq.push_back(i); lt_q0.push_back(b0 + (last - b0) / 64 * 64); }
     }
     const size_t o_ltseq = m.size();  m.insert(m.end(), lt_seq.begin(), lt_seq.end());
     const size_t o_ltq0 = m.size();   m.insert(m.end(), lt_q0.begin(), lt_q0.end());
     const size_t o_lrtseq = m.size(); m.insert(m.end(), lrt_seq.begin(), lrt_seq.end());
     const size_t o_lrtq0 = m.size();  m.insert(m.end(), lrt_q0.begin(), lrt_q0.end());
+    const size_t o_ldtseq = m.size(); m.insert(m.end(), ldt_seq.begin(), ldt_seq.end());
+    const size_t o_ldtq0 = m.size();  m.insert(m.end(), ldt_q0.begin(), ldt_q0.end());
     const size_t o_bt = m.size();
     for (int i = 0; i < n; ++i) {
         const HostSlot& s = e->slots[slots[i]];
@@ -1374,6 +1389,10 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
         a.meta.tile_seq = md + o_rtseq; a.meta.tile_q0 = md + o_rtq0;
         if (prune) { a.meta.tile_seq = md + o_lrtseq; a.meta.tile_q0 = md + o_lrtq0; n_rtiles = (int)lrt_seq.size(); }
         if (n_rtiles) attn_prefill_res_launch(a, n_rtiles, e->pf_res_cap, prune, st);
+        int n_dtiles = (int)dtile_seq.size();
+        a.meta.tile_seq = md + o_dtseq; a.meta.tile_q0 = md + o_dtq0;
+        if (prune) { a.meta.tile_seq = md + o_ldtseq; a.meta.tile_q0 = md + o_ldtq0; n_dtiles = (int)ldt_seq.size(); }
+        if (n_dtiles) attn_prefill_deep_launch(a, n_dtiles, e->pf_res_cap, e->pf_deep_cap, prune, st);
         const int Mi = prune ? n : Ti;                       // rows from here on
         const bf16_t* attn_in = e->attn_pf;
         bf16_t* hres = e->h_pf;

@@ -107,6 +107,7 @@ struct AttnPrefillArgs {
     int q_cap;                 // attn_prefill_res_kernel: its queries (and, causally, its keys) are the positions below q_cap <= kPfResPages * 32
     int heads_per_wg;          // attn_prefill_res_kernel: query heads of the group one workgroup walks (grid z covers the rest)
     int only_last;             // attn_prefill_res_kernel: only the 16-query block that holds the prompt's last position is computed (last layer)
+    int q_lo;                  // attn_prefill_deep_kernel: its queries are the positions q_lo <= q < q_cap (q_lo = the resident kernel's q_cap)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -619,6 +620,277 @@ NTTS_KERNEL(512) void attn_prefill_res_kernel(AttnPrefillArgs p) {
         }
     }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The next tier: queries at positions 512 .. 1023 (17 .. 32 pages deep; NeuTTS prompts with a long reference clip reach them).  Same decomposition
+// (256 queries per workgroup, 16-query blocks dealt out from both ends of the tier, one head at a time, passes A / max / B / C), cut to what a CU holds:
+//   * the K pages stay RESIDENT (32 x 4 KB = 128 KB); the V^T pages stream through a ring of two 4-page slots (32 KB: 160 KB in all) during pass C,
+//     one workgroup barrier per four pages;
+//   * a block's scores against up to 1024 keys stay in registers as PACKED bf16 pairs (they ARE bf16 values: 32 pages x 4 = 128 VGPRs), so e =
+//     exp((s - max) / 8) is formed twice from them -- once for the denominator, once for P -- instead of being kept (256 VGPRs of fp32 would leave
+//     one wave per SIMD and AGPR copies, the two-sweep kernel's own ailment).  QK^T still runs once, two waves per SIMD, no AGPR.
+// Rounding points and summation orders are the resident kernel's (bf16 scores, exact scaling, fp32 max / exp / sum in page order per lane then across
+// the four key groups, P rounded after the normalisation, PV in page order).  Positions >= 1024 stay with the two-sweep kernel.
+constexpr int kPfDeepPages = 32;
+constexpr int kPfDeepGroup = 4;      // V^T pages per ring slot
+template <int NP>
+NTTS_KERNEL(512) void attn_prefill_deep_kernel(AttnPrefillArgs p) {
+    NTTS_SHARED bf16_t kres[NP * kPage * 64];                       // [page][32 keys][128 B], chunk c of key r at c ^ k_swz(r)
+    NTTS_SHARED bf16_t vring[2 * kPfDeepGroup * 64 * kPage];        // [slot][page of the group][64 d][64 B], unit u of row d at u ^ v_swz(d)
+    const int lane = lane_id(), w = wave_id();
+    const int g = lane >> 4, l15 = lane & 15;
+    const int tile = blockIdx.y, kvh = blockIdx.x;
+    const int sq = p.meta.tile_seq[tile];
+    const int S = p.meta.seq_len[sq];
+    const int Sq = S < p.q_cap ? S : p.q_cap;                 // this launch's queries end here
+    const int pos0 = p.meta.pos0[sq];
+    const int qbase = pos0 > p.q_lo ? pos0 : p.q_lo;          // ... and start here
+    const int base = p.meta.tok_base[sq] - pos0;              // packed row of absolute position q is base + q
+    const int group = p.nh / p.nkv;
+    const int hb = kvh * group + blockIdx.z * p.heads_per_wg;
+    int he = hb + p.heads_per_wg;
+    if (he > (kvh + 1) * group) he = (kvh + 1) * group;
+    const int* bt = p.block_table + (long)p.meta.slot[sq] * p.max_pages;
+    const int nb = (Sq - qbase + 15) >> 4;                    // blocks of the tier, dealt out as in attn_prefill_res_kernel
+    const int nbp = (nb + 15) & ~15;
+    const int k8 = p.meta.tile_q0[tile] * 8;
+    const int blk_lo = k8 + w, blk_hi = nbp - 1 - k8 - w;
+    int top_lo = k8 + 7;
+    if (top_lo > nb - 1) top_lo = nb - 1;
+    int top_hi = nbp - 1 - k8;
+    if (top_hi > nb - 1) top_hi = nb - 1;
+    auto pages_to = [&](int blk) { const int ql = qbase + blk * 16 + 15; return (ql < Sq - 1 ? ql : Sq - 1) / kPage + 1; };
+    const int np_lo = pages_to(top_lo);
+    const int npages = pages_to(top_hi > top_lo ? top_hi : top_lo);   // <= NP
+    // ---- K: every page the workgroup can see; wave w brings 1 KB piece w & 3 (8 keys) of the pages of its parity
+    for (int pg = w >> 2; pg < npages; pg += 2) {
+        const long page = bt[pg];
+        const int r = (w & 3) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ k_swz(r);
+        glds16(p.kpool + ((page * p.nkv + kvh) * kPage + r) * 64 + c * 8, kres + pg * (kPage * 64) + (w & 3) * 512);
+    }
+    // V^T group gi (pages 4 gi .. 4 gi + 3 below `lim`) into ring slot gi & 1: 16 pieces of 1 KB, two per wave
+    auto stage_v = [&](int gi, int lim) {
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+            const int i = w * 2 + i2, pg = gi * kPfDeepGroup + (i >> 2);
+            if (pg < lim) {
+                const long page = bt[pg];
+                const int d = (i & 3) * 16 + (lane >> 2);
+                const int u = (lane & 3) ^ v_swz(d);
+                glds16(p.vpool + (page * p.nkv + kvh) * 64 * kPage + d * kPage + u * 8,
+                       vring + ((gi & 1) * kPfDeepGroup + (i >> 2)) * (64 * kPage) + (i & 3) * 512);
+            }
+        }
+    };
+    bf16x8 qn[4];                                              // next head's raw chunks: own 2, partner 2 (RoPE as in attn_prefill_res_kernel)
+    auto fetch_q = [&](const bf16_t* qrow, int h) {
+        const bf16_t* qr = qrow + h * 64;
+        qn[0] = ld16<bf16x8>(qr + g * 16);
+        qn[1] = ld16<bf16x8>(qr + g * 16 + 8);
+        if (p.rope_cos) {
+            qn[2] = ld16<bf16x8>(qr + (g ^ 2) * 16);
+            qn[3] = ld16<bf16x8>(qr + (g ^ 2) * 16 + 8);
+        }
+    };
+    wait_vmem();
+    sync();
+
+    constexpr float kMasked = -1.0e30f;
+    const unsigned int kMaskedBits = (unsigned int)f2bf(kMasked);   // bf16(-1e30): finite, exp -> 0
+    auto lo16 = [](unsigned int u) { return __builtin_bit_cast(float, u << 16); };
+    auto hi16 = [](unsigned int u) { return __builtin_bit_cast(float, u & 0xffff0000u); };
+    for (int half = 0; half < 2; ++half) {
+    const int blk = half == 0 ? blk_lo : blk_hi;
+    const int npmax = half == 0 ? np_lo : npages;             // workgroup-uniform: the pages pass C walks for this half
+    if (p.only_last) {                                        // workgroup-uniform: a half without the prompt's last block has nothing to do
+        const int b = nb - 1;
+        if (half == 0 ? !(b >= k8 && b <= k8 + 7) : !(b <= nbp - 1 - k8 && b >= nbp - 8 - k8)) continue;
+    }
+    const bool live = blk < nb && blk >= 0 && !(p.only_last && blk != nb - 1);   // dead waves stage and hit the barriers
+    const int qw0 = qbase + blk * 16;                         // first query of this wave's block
+    int qpos = qw0 + l15;
+    if (qpos > Sq - 1) qpos = Sq - 1;
+    if (qpos < 0) qpos = 0;
+    const int qlast_w = (qw0 + 15 < Sq ? qw0 + 15 : Sq - 1);
+    const int npw = live ? qlast_w / kPage + 1 : 0;           // pages this block computes on; the last one holds its diagonal
+    const bf16_t* qrow = p.qkv + (long)(base + qpos) * p.ld_qkv;
+    const bf16_t* cr = p.rope_cos + (long)qpos * 32 + (g & 1) * 16;
+    const bf16_t* sr = p.rope_sin + (long)qpos * 32 + (g & 1) * 16;
+    fetch_q(qrow, hb);
+    const bool vtail = npw * kPage > S;
+    const int qrel = qpos - (npw - 1) * kPage;
+    const int srel = S - (npw - 1) * kPage;
+    for (int h = hb; h < he; ++h) {
+        bf16x8 qB[2];
+        if (p.rope_cos) {
+            bf16x8 cv[2], sv[2];                               // (L1 / L2 hits, re-read per head: 16 registers less across the passes)
+            cv[0] = ld16<bf16x8>(cr); cv[1] = ld16<bf16x8>(cr + 8);
+            sv[0] = ld16<bf16x8>(sr); sv[1] = ld16<bf16x8>(sr + 8);
+#pragma unroll
+            for (int f = 0; f < 2; ++f)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float c = bf2f((bf16_t)cv[f][e]), s0 = bf2f((bf16_t)sv[f][e]);
+                    const float a = rbf(bf2f((bf16_t)qn[f][e]) * c);
+                    const float b = rbf(bf2f((bf16_t)qn[2 + f][e]) * (g < 2 ? -s0 : s0));
+                    qB[f][e] = (short)f2bf(a + b);
+                }
+        } else {
+            qB[0] = qn[0]; qB[1] = qn[1];
+        }
+        if (h + 1 < he) fetch_q(qrow, h + 1);                  // lands under this head's passes
+
+        // ---- pass A: bf16 scores, packed two per register (word 0 = the even element), four pages per guard
+        unsigned int sp[NP * 4];
+        {
+            const int n = opaque_u(npw);
+#pragma unroll
+            for (int pq = 0; pq < NP; pq += 4) {
+                if (pq < n) {
+#pragma unroll
+                    for (int pg = pq; pg < pq + 4; ++pg) {
+                        const bf16_t* kb = kres + pg * (kPage * 64);
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int r = u * 16 + l15;
+                            f32x4 a = {0.f, 0.f, 0.f, 0.f};
+                            a = mfma16(ld16<bf16x8>(kb + r * 64 + (((2 * g) ^ k_swz(r)) << 3)), qB[0], a);
+                            a = mfma16(ld16<bf16x8>(kb + r * 64 + (((2 * g + 1) ^ k_swz(r)) << 3)), qB[1], a);
+                            sp[pg * 4 + u * 2] = pack_bf2(a[0], a[1]);
+                            sp[pg * 4 + u * 2 + 1] = pack_bf2(a[2], a[3]);
+                        }
+                    }
+                }
+            }
+        }
+        // ---- the diagonal page: causal mask; then the row maximum (of bf16 values: no further rounding)
+        float mr = kMasked;
+        {
+            const int n = opaque_u(npw);
+            const int rel = opaque(qrel);
+#pragma unroll
+            for (int pg = 0; pg < NP; ++pg) {
+                if (pg < n) {
+                    if (pg + 1 == n) {
+#pragma unroll
+                        for (int e2 = 0; e2 < 4; ++e2) {
+                            const int k0 = (e2 >> 1) * 16 + g * 4 + (e2 & 1) * 2;   // key of word 0; word 1 = k0 + 1
+                            unsigned int v = sp[pg * 4 + e2];
+                            if (k0 > rel) v = (v & 0xffff0000u) | kMaskedBits;
+                            if (k0 + 1 > rel) v = (v & 0xffffu) | (kMaskedBits << 16);
+                            sp[pg * 4 + e2] = v;
+                        }
+                    }
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) mr = fmaxf(mr, fmaxf(lo16(sp[pg * 4 + e2]), hi16(sp[pg * 4 + e2])));
+                }
+            }
+        }
+        mr = fmaxf(mr, shfl_xor(mr, 16));
+        mr = fmaxf(mr, shfl_xor(mr, 32));
+        // ---- pass B: the denominator
+        float sum0 = 0.f, sum1 = 0.f;
+        {
+            const int n = opaque_u(npw);
+#pragma unroll
+            for (int pg = 0; pg < NP; ++pg) {
+                if (pg < n) {
+#pragma unroll
+                    for (int e2 = 0; e2 < 4; ++e2) {
+                        sum0 += fexp_neg8(lo16(sp[pg * 4 + e2]) - mr);
+                        sum1 += fexp_neg8(hi16(sp[pg * 4 + e2]) - mr);
+                    }
+                }
+            }
+        }
+        float sum = sum0 + sum1;
+        sum += shfl_xor(sum, 16);
+        sum += shfl_xor(sum, 32);
+        const float rs = frcp_refined(sum);
+        // ---- pass C: P = bf16(e / sum), O += P V (page order); V^T through the ring, four pages per barrier.  The first barrier keeps this head's
+        //      first group off a slot another wave may still be reading for the previous head
+        f32x4 oacc[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) oacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const int n = opaque_u(npw);
+            const int lim = opaque(srel);
+            const int ngrp = opaque_u((npmax + kPfDeepGroup - 1) / kPfDeepGroup);
+            sync_keep_dma();
+            stage_v(0, npmax);
+#pragma unroll
+            for (int gi = 0; gi < NP / kPfDeepGroup; ++gi) {
+                if (gi < ngrp) {
+                    wait_vmem();
+                    sync_keep_dma();                           // group gi landed for every wave; everyone is done with the other slot
+                    if (gi + 1 < ngrp) stage_v(gi + 1, npmax);
+#pragma unroll
+                    for (int pi = 0; pi < kPfDeepGroup; ++pi) {
+                        const int pg = gi * kPfDeepGroup + pi;
+                        if (pg < n) {
+                            const bf16_t* vb = vring + ((gi & 1) * kPfDeepGroup + pi) * (64 * kPage);
+                            bf16x8 vB[4];
+#pragma unroll
+                            for (int nt = 0; nt < 4; ++nt) {
+                                const int d = nt * 16 + l15;
+                                vB[nt] = ld16<bf16x8>(vb + d * kPage + ((g ^ v_swz(d)) << 3));
+                            }
+                            bf16x8 pA;
+#pragma unroll
+                            for (int e2 = 0; e2 < 4; ++e2) {
+                                const float e0 = fexp_neg8(lo16(sp[pg * 4 + e2]) - mr), e1 = fexp_neg8(hi16(sp[pg * 4 + e2]) - mr);
+                                pA[e2 * 2] = (short)f2bf(fdiv_r(e0, sum, rs));
+                                pA[e2 * 2 + 1] = (short)f2bf(fdiv_r(e1, sum, rs));
+                            }
+                            if (vtail && pg + 1 == n) {
+#pragma unroll
+                                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e)
+                                        if ((e < 4 ? g * 4 + e : 16 + g * 4 + e - 4) >= lim) vB[nt][e] = 0;
+                            }
+#pragma unroll
+                            for (int nt = 0; nt < 4; ++nt) oacc[nt] = mfma16(pA, vB[nt], oacc[nt]);
+                        }
+                    }
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = qw0 + g * 4 + r;
+                if (q < Sq) {
+                    if (p.out_fp8_inv > 0.f) {
+                        unsigned char* o = (unsigned char*)p.out + (long)(base + q) * p.ld_out + h * 64 + l15;
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) o[nt * 16] = f2fp8c(rbf(oacc[nt][r]) * p.out_fp8_inv);
+                    } else {
+                        bf16_t* o = p.out + (long)(base + q) * p.ld_out + h * 64 + l15;
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) o[nt * 16] = f2bf(oacc[nt][r]);
+                    }
+                }
+            }
+        }
+    }
+    }
+}
+
+inline void attn_prefill_deep_launch(AttnPrefillArgs p, int n_tiles, int q_lo, int q_cap, bool only_last, hipStream_t s) {
+    const int group = p.nh / p.nkv;
+    const long pairs = (long)p.nkv * n_tiles;
+    int hps = group;
+    if (pairs * group <= 256) hps = 1;
+    else if (pairs * ((group + 1) / 2) <= 256) hps = 2;
+    else if (pairs * ((group + 3) / 4) <= 256) hps = 4;
+    p.q_lo = q_lo;
+    p.q_cap = q_cap;
+    p.heads_per_wg = hps;
+    p.only_last = only_last ? 1 : 0;
+    NTTS_LAUNCH((attn_prefill_deep_kernel<kPfDeepPages>), dim3(p.nkv, n_tiles, (group + hps - 1) / hps), dim3(512), s, p);
 }
 
 // host launcher of the resident kernel: short passes spread the group's heads over grid z while the grid stays within the CUs (as below)

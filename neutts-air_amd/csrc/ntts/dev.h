@@ -151,6 +151,11 @@ NTTS_D f32x2_t rbf2(f32x2_t v) {
     o[1] = __builtin_bit_cast(float, u & 0xffff0000u);
     return o;
 }
+// two floats rounded to bf16, packed: word 0 = bf16(a), word 1 = bf16(b) (one v_cvt_pk_bf16_f32)
+NTTS_D unsigned int pack_bf2(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(f32x2_t{a, b}, bf2_t));
+}
 // true on every lane if the predicate holds on any lane of the wave
 NTTS_D bool any_lane(bool p) { return ballot(p) != 0; }
 

@@ -270,6 +270,7 @@ inline float frsqrt_exact(float x) { return 1.0f / sqrtf(x); }
 inline float frcp_raw(float d) { return 1.0f / d; }
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 inline f32x2_t rbf2(f32x2_t v) { f32x2_t o; o[0] = rbf(v[0]); o[1] = rbf(v[1]); return o; }
+inline unsigned int pack_bf2(float a, float b) { return (unsigned int)f2bf(a) | ((unsigned int)f2bf(b) << 16); }
 inline bool any_lane(bool p) { return ballot(p) != 0; }
 
 template <typename T>

@@ -70,13 +70,16 @@ def test_short_sequence_beside_a_long_one_across_the_split_switch(emu_lib, monke
         assert fin and ids == want[s].ids, (s, ids, want[s].ids)
 
 
-@pytest.mark.parametrize("cap", ["512", "64", "0"])
-def test_prompt_pass_attention_split_by_position(emu_lib, monkeypatch, cap):
-    """Prompt-pass attention runs on two kernels, chosen by the query's POSITION alone (attn_prefill.h): below NTTS_PF_RES_CAP (512) the
-    resident kernel (pages in LDS, one exp per score, 16-query blocks dealt out from both ends of the prompt), from there on the two-sweep
-    kernel.  A 150-token and a 37-token prompt with everything on the resident kernel, with the cut at 64 (the long prompt uses both: four
-    blocks here, the rest there) and with everything on the two-sweep kernel: HF's ids bit for bit every time (walk weights)."""
-    monkeypatch.setenv("NTTS_PF_RES_CAP", cap)
+@pytest.mark.parametrize("caps", [("512", "1024"), ("64", "128"), ("32", "96"), ("0", "1024"), ("0", "0")])
+def test_prompt_pass_attention_split_by_position(emu_lib, monkeypatch, caps):
+    """Prompt-pass attention runs on three kernels, chosen by the query's POSITION alone (attn_prefill.h): below NTTS_PF_RES_CAP (512) the
+    resident kernel (pages in LDS, one exp per score, 16-query blocks dealt out from both ends of the prompt), below NTTS_PF_DEEP_CAP (1024)
+    the deep one (K resident, V^T through a ring, packed scores), from there on the two-sweep kernel.  A 150-token and a 37-token prompt with
+    everything on the resident kernel, with cuts at 64 / 128 and 32 / 96 (the long prompt uses all three), with everything on the deep kernel
+    and with everything on the two-sweep kernel: HF's ids bit for bit every time (walk weights)."""
+    cap = caps
+    monkeypatch.setenv("NTTS_PF_RES_CAP", caps[0])
+    monkeypatch.setenv("NTTS_PF_DEEP_CAP", caps[1])
     z, cfg, w = load_fixture("backbone_small_walk")
     wd = br.cast_weights(w, torch.bfloat16)
     N, eos = 6, int(z["eos"])

@@ -144,24 +144,27 @@ def test_long_context_switches_to_split_attention(lib, monkeypatch, max_batch):
     assert got["8"] == got["0"], (got["8"], got["0"])
 
 
-@pytest.mark.parametrize("cap", ["512", "128", "0"])
-def test_prompt_pass_attention_split_by_position(lib, monkeypatch, cap):
-    """Prompt-pass attention runs on two kernels, chosen by the query's POSITION alone (attn_prefill.h): below NTTS_PF_RES_CAP (512) the
-    resident kernel (pages in LDS, one exp per score, blocks dealt out from both ends of the prompt), from there on the two-sweep kernel.
-    At NeuTTS-Air's width: a 700-, a 300- and a 21-token prompt with the cut at 512 (the default: the long prompt uses both kernels), at 128
-    and with everything on the two-sweep kernel -- each row equals the oracle's run of that prompt alone, id for id (walk weights)."""
-    monkeypatch.setenv("NTTS_PF_RES_CAP", cap)
+@pytest.mark.parametrize("caps", [("512", "1024"), ("128", "640"), ("512", "512"), ("0", "1024"), ("0", "0")])
+def test_prompt_pass_attention_split_by_position(lib, monkeypatch, caps):
+    """Prompt-pass attention runs on three kernels, chosen by the query's POSITION alone (attn_prefill.h): below NTTS_PF_RES_CAP (512) the
+    resident kernel (pages in LDS, one exp per score, blocks dealt out from both ends of the prompt), below NTTS_PF_DEEP_CAP (1024) the deep one
+    (K resident, V^T through a ring, scores packed), from there on the two-sweep kernel.  At NeuTTS-Air's width: a 1100-, a 700-, a 300- and a
+    21-token prompt with the default cuts (the longest prompt uses all three kernels), with cuts at 128 / 640, without the deep tier, with
+    everything below 1024 on the deep kernel and with everything on the two-sweep kernel -- each row equals the oracle's run of that prompt
+    alone, id for id (walk weights)."""
+    monkeypatch.setenv("NTTS_PF_RES_CAP", caps[0])
+    monkeypatch.setenv("NTTS_PF_DEEP_CAP", caps[1])
     cfg = br.BackboneConfig(vocab_size=3000, hidden_size=896, intermediate_size=1216, num_layers=3)
     w = br.make_weights(cfg, 34, walk_gain=4.0)
     wd = br.cast_weights(w, torch.bfloat16)
     N, eos = 12, cfg.vocab_size - 1
-    prompts = [br.synthetic_prompt(cfg, 1, 700), br.synthetic_prompt(cfg, 2, 300), br.synthetic_prompt(cfg, 3, 21)]
+    prompts = [br.synthetic_prompt(cfg, 1, 700), br.synthetic_prompt(cfg, 2, 300), br.synthetic_prompt(cfg, 3, 21), br.synthetic_prompt(cfg, 4, 1100)]
     want = [br.generate(cfg, wd, p, len(p) + N, eos_id=eos, min_new_tokens=N, keep_logits=True) for p in prompts]
-    eng = make_engine(cfg, w, lib, max_batch=4, max_context=768, max_prefill_tokens=1100, bf16_upload=True)
+    eng = make_engine(cfg, w, lib, max_batch=4, max_context=1152, max_prefill_tokens=2200, bf16_upload=True)
     samp = [_hip.Sampling(max_length=len(p) + N, min_new_tokens=N, eos_token_id=eos, do_sample=False) for p in prompts]
-    eng.prefill(prompts, [2, 0, 3], samp)
+    eng.prefill(prompts, [2, 0, 3, 1], samp)
     eng.decode(N - 1)
-    for s, u in ((2, 0), (0, 1), (3, 2)):
+    for s, u in ((2, 0), (0, 1), (3, 2), (1, 3)):
         ids, fin = eng.read(s)
         assert fin and len(ids) == N
         assert_walk_exact(ids, want[u].ids)
