@@ -144,6 +144,9 @@ def test_long_context_switches_to_split_attention(lib, monkeypatch, max_batch):
     assert got["8"] == got["0"], (got["8"], got["0"])
 
 
+_TIER_ORACLE = {}
+
+
 @pytest.mark.parametrize("caps", [("512", "1024"), ("128", "640"), ("512", "512"), ("0", "1024"), ("0", "0")])
 def test_prompt_pass_attention_split_by_position(lib, monkeypatch, caps):
     """Prompt-pass attention runs on three kernels, chosen by the query's POSITION alone (attn_prefill.h): below NTTS_PF_RES_CAP (512) the
@@ -156,10 +159,12 @@ def test_prompt_pass_attention_split_by_position(lib, monkeypatch, caps):
     monkeypatch.setenv("NTTS_PF_DEEP_CAP", caps[1])
     cfg = br.BackboneConfig(vocab_size=3000, hidden_size=896, intermediate_size=1216, num_layers=3)
     w = br.make_weights(cfg, 34, walk_gain=4.0)
-    wd = br.cast_weights(w, torch.bfloat16)
     N, eos = 12, cfg.vocab_size - 1
     prompts = [br.synthetic_prompt(cfg, 1, 700), br.synthetic_prompt(cfg, 2, 300), br.synthetic_prompt(cfg, 3, 21), br.synthetic_prompt(cfg, 4, 1100)]
-    want = [br.generate(cfg, wd, p, len(p) + N, eos_id=eos, min_new_tokens=N, keep_logits=True) for p in prompts]
+    if "want" not in _TIER_ORACLE:      # the oracle's runs do not depend on the tier setting: once for the five of them
+        wd = br.cast_weights(w, torch.bfloat16)
+        _TIER_ORACLE["want"] = [br.generate(cfg, wd, p, len(p) + N, eos_id=eos, min_new_tokens=N, keep_logits=True) for p in prompts]
+    want = _TIER_ORACLE["want"]
     eng = make_engine(cfg, w, lib, max_batch=4, max_context=1152, max_prefill_tokens=2200, bf16_upload=True)
     samp = [_hip.Sampling(max_length=len(p) + N, min_new_tokens=N, eos_token_id=eos, do_sample=False) for p in prompts]
     eng.prefill(prompts, [2, 0, 3, 1], samp)
