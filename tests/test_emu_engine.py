@@ -94,6 +94,38 @@ def test_prompt_pass_attention_split_by_position(emu_lib, monkeypatch, caps):
         assert fin and ids == want[u].ids, (cap, u, ids, want[u].ids)
 
 
+def test_prompt_pass_attention_tiers_logits(emu_lib, monkeypatch):
+    """The sensitive twin of the test above (walk ids barely depend on attention): RANDOM-init weights, first-token logits of a 150- and a
+    37-token prompt against the oracle's bf16 run, for the two-sweep kernel alone, the default tiers (all resident here), everything on the
+    deep kernel and cuts at 32 / 96 (all three kernels).  Every setting within the same distance of the oracle, and of each other."""
+    cfg = br.BackboneConfig(vocab_size=600, hidden_size=128, intermediate_size=256, num_layers=3, num_heads=2, num_kv_heads=1)
+    w = br.make_weights(cfg, 21)
+    wd = br.cast_weights(w, torch.bfloat16)
+    eos = cfg.vocab_size - 1
+    prompts = [br.synthetic_prompt(cfg, 2, 150), br.synthetic_prompt(cfg, 5, 37)]
+    ref = [br.generate(cfg, wd, p, len(p) + 1, eos, min_new_tokens=1, keep_logits=True).logits[0].double() for p in prompts]
+    rows = {}
+    for caps in (("0", "0"), ("512", "1024"), ("0", "1024"), ("32", "96")):
+        monkeypatch.setenv("NTTS_PF_RES_CAP", caps[0])
+        monkeypatch.setenv("NTTS_PF_DEEP_CAP", caps[1])
+        eng = make_engine(cfg, w, emu_lib, max_batch=2, max_context=192)
+        eng.set_debug(True)
+        samp = [_hip.Sampling(max_length=len(p) + 2, min_new_tokens=2, eos_token_id=eos, do_sample=False) for p in prompts]
+        eng.prefill(prompts, [1, 0], samp)
+        rows[caps] = [torch.from_numpy(eng.read_logits(s)).double() for s in (1, 0)]
+        eng.close()
+
+    def rel(a, b):
+        fin = torch.isfinite(a) & torch.isfinite(b)
+        return float((a[fin] - b[fin]).norm() / b[fin].norm())
+    for u in range(2):
+        r0 = rel(rows[("0", "0")][u], ref[u])
+        for caps, rr in rows.items():
+            assert rel(rr[u], ref[u]) <= 1.5 * r0 + 2e-3, (caps, u, rel(rr[u], ref[u]), r0)
+            assert rel(rr[u], rows[("0", "0")][u]) <= 2.0 * r0 + 2e-3, (caps, u)
+        assert torch.equal(rows[("512", "1024")][u], rows[("0", "1024")][u])    # the resident and the deep kernel are the same arithmetic
+
+
 def test_xcd_row_block_placement(emu_lib, monkeypatch):
     """NTTS_XCD_AFFINE=7 (the default above batch 128): split-K GEMMs, the norms behind them and decode attention place the rows of a
     64-row m-block on one group of XCDs (gemm.h xcd_maffine, norm.h xcd_row).  A pure permutation of which workgroup does what:

@@ -7,7 +7,7 @@ import torch
 
 from oracle import backbone_ref as br
 from neutts import _hip
-from common import assert_free_run_matches, assert_varied, assert_walk_exact, load_fixture, make_engine, teacher_forced_compare
+from common import bf16_ulp, assert_free_run_matches, assert_varied, assert_walk_exact, load_fixture, make_engine, teacher_forced_compare
 
 pytestmark = pytest.mark.gpu
 
@@ -174,6 +174,49 @@ def test_prompt_pass_attention_split_by_position(lib, monkeypatch, caps):
         assert fin and len(ids) == N
         assert_walk_exact(ids, want[u].ids)
     eng.close()
+
+
+def test_prompt_pass_attention_tiers_logits(lib, monkeypatch):
+    """The id-for-id tier tests above run on walk weights, whose next id barely depends on attention (that is their point).  This one is the
+    sensitive one: RANDOM-init weights (flat logits, every layer's attention matters), 4 layers at NeuTTS-Air's width, prompts of 1100 / 700 /
+    300 tokens, the first-token logits row of each against the oracle's bf16 run -- with the default tiers (the long prompts run through all
+    three kernels), with everything below 1024 on the deep kernel, with cuts at 128 / 640, and on the two-sweep kernel alone (the form the HF
+    goldens pin).  Every setting must sit as close to the oracle as the two-sweep kernel does, and the settings must agree with each other to
+    within the fp32-summation-order freedom (a few bf16 ulps at the top of the distribution)."""
+    cfg = br.BackboneConfig(vocab_size=3000, hidden_size=896, intermediate_size=1216, num_layers=4)
+    w = br.make_weights(cfg, 36)
+    wd = br.cast_weights(w, torch.bfloat16)
+    eos = cfg.vocab_size - 1
+    prompts = [br.synthetic_prompt(cfg, 1, 1100), br.synthetic_prompt(cfg, 2, 700), br.synthetic_prompt(cfg, 3, 300)]
+    ref = [br.generate(cfg, wd, p, len(p) + 1, eos, min_new_tokens=1, keep_logits=True).logits[0].double() for p in prompts]
+    rows = {}
+    for caps in (("0", "0"), ("512", "1024"), ("0", "1024"), ("128", "640")):
+        monkeypatch.setenv("NTTS_PF_RES_CAP", caps[0])
+        monkeypatch.setenv("NTTS_PF_DEEP_CAP", caps[1])
+        eng = make_engine(cfg, w, lib, max_batch=4, max_context=1152, max_prefill_tokens=2200, bf16_upload=True)
+        eng.set_debug(True)
+        samp = [_hip.Sampling(max_length=len(p) + 2, min_new_tokens=2, eos_token_id=eos, do_sample=False) for p in prompts]
+        eng.prefill(prompts, [0, 1, 2], samp)
+        rows[caps] = [torch.from_numpy(eng.read_logits(s)).double() for s in range(3)]
+        eng.close()
+
+    def dist(a, b):     # (relative RMS over the row, largest difference at b's top-8 entries in bf16 ulps of those entries)
+        fin = torch.isfinite(a) & torch.isfinite(b)                  # (the EOS column is masked to -inf by min_new_tokens)
+        a, b = a[fin], b[fin]
+        top = torch.topk(b, 8).indices
+        ulps = max(abs(float(a[i] - b[i])) / bf16_ulp(float(b[i])) for i in top)
+        return float((a - b).norm() / b.norm()), ulps
+    base = rows[("0", "0")]
+    for u in range(3):
+        r0, u0 = dist(base[u], ref[u])
+        print(f"prompt {len(prompts[u])}: two-sweep vs oracle rel RMS {r0:.2e}, top-8 within {u0:.1f} ulps")
+        for caps, rr in rows.items():
+            r1, u1 = dist(rr[u], ref[u])
+            r2, u2 = dist(rr[u], base[u])
+            print(f"   tiers {caps}: vs oracle {r1:.2e} / {u1:.1f} ulps; vs two-sweep {r2:.2e} / {u2:.1f} ulps")
+            assert r1 <= 1.5 * r0 + 1e-3 and u1 <= max(2.0 * u0, 4.0), (caps, u, r1, u1, r0, u0)
+            assert r2 <= 2.0 * r0 + 1e-3 and u2 <= max(2.0 * u0, 4.0), (caps, u, r2, u2)
+        assert torch.equal(rows[("512", "1024")][u], rows[("0", "1024")][u])    # the resident and the deep kernel are the same arithmetic
 
 
 @pytest.mark.parametrize("n_prompts", [24, 40, 70])
