@@ -47,7 +47,7 @@ def test_fp8_nano_width_batch64_vs_oracle(lib, batch):
 def test_fp8_nano_geometry_19_layers_batch512(lib):
     """BASELINE.json configs[4] at its own size: the ASSUMED NeuTTS-Nano geometry (hidden 768, 19 layers, 12:4 heads, FFN 2048,
     vocabulary 142 080), fp8 weights + GEMM inputs, batch 512 (one XCD per 64-row m-block, the 256 x 256 fp8 lm_head tile, 2048
-    attention workgroups), 70-token prompts, 24 greedy tokens.  First-token logits of the four distinct prompts against the fp8
+    attention workgroups), 70-token prompts, 10 greedy tokens.  First-token logits of the four distinct prompts against the fp8
     oracle, and identical rows for identical prompts across all 512 slots (batch / slot invariance).  The fp8 noise grows with
     the number of quantisation points (tests/test_emu_variants.py::check_fp8_model: ~1.3 % of the logits each): 19 layers x 4
     GEMM inputs measured 0.097-0.108 relative RMS on MI355X (correlation 0.994-0.995) against 0.21-0.28 for the quantisation
@@ -55,7 +55,7 @@ def test_fp8_nano_geometry_19_layers_batch512(lib):
     cfg = br.BackboneConfig.neutts_nano_like()
     base = [br.synthetic_prompt(cfg, i, 70) for i in range(4)]
     prompts = [base[i % 4] for i in range(512)]
-    rows, worst = cases.check_fp8_model(lib, cfg, prompts, 24, max_batch=512, bar=FP8_BAR_19_LAYERS, corr_bar=0.99)
+    rows, worst = cases.check_fp8_model(lib, cfg, prompts, 10, max_batch=512, bar=FP8_BAR_19_LAYERS, corr_bar=0.99)   # (10 tokens: the CPU oracle's steps are this test's minute)
     for s in range(512):
         assert rows[s] == rows[s % 4], s
 
