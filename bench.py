@@ -181,6 +181,11 @@ def main():
     ap.add_argument("--pipe-head", type=int, default=100,
                     help="pipelined static mode: decode steps of batch k enqueued BEFORE batch k + 1's prompt pass (0 = prompt pass first); "
                          "the prompt pass then runs beside the later, longer-context steps (profiles/r03i_sweep_pipeline_schedule.txt)")
+    ap.add_argument("--gang", type=int, default=2,
+                    help="pipelined static mode: 256-slot engines whose decode graphs are replayed ALTERNATELY from the one launching thread, each on "
+                         "its own stream (one batch per engine): a decode chain is latency-bound (a quarter of the HBM peak), two of them fill each "
+                         "other's launch gaps and first round trips (tools/probe_two_chains.py: 1.57 -> 1.15 ms per 256-row step).  The pipeline "
+                         "holds two gangs (2 x gang engines); 1 = the round-3 pipeline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-codec", action="store_true", help="backbone only (profiling aid; not the headline metric)")
@@ -303,11 +308,12 @@ def main():
                                    max_prefill_tokens=a.prefill_chunk * S, weight_dtype="fp8" if fp8 else "bf16"), dev, lib)
     codec = tts.codec.engine if strm else None
     if not a.no_codec and not strm:
-        codec = _hip.CodecEngine(dict(hidden_size=ccfg.hidden_size, intermediate_size=ccfg.intermediate_size,
-                                      num_layers=ccfg.num_layers, num_heads=ccfg.num_heads,
-                                      quantization_dim=ccfg.quantization_dim, levels=list(ccfg.levels),
-                                      hop_length=ccfg.hop_length, rms_eps=ccfg.rms_eps, max_frames=N_max,
-                                      max_rows=B * (N_max + 6)), dev, lib)
+        codec_cfg_d = dict(hidden_size=ccfg.hidden_size, intermediate_size=ccfg.intermediate_size,
+                           num_layers=ccfg.num_layers, num_heads=ccfg.num_heads,
+                           quantization_dim=ccfg.quantization_dim, levels=list(ccfg.levels),
+                           hop_length=ccfg.hop_length, rms_eps=ccfg.rms_eps, max_frames=N_max,
+                           max_rows=B * (N_max + 6))
+        codec = _hip.CodecEngine(codec_cfg_d, dev, lib)
     if not strm:
         w = cw = None
     t0 = time.time()
@@ -324,18 +330,41 @@ def main():
         tdev = torch.device("cpu") if emu_lib else None
         ndist.broadcast_weights(eng, src=0, device=tdev)  # RCCL over xGMI: packed backbone arena, one broadcast
         if codec is not None:
-            codec.load_state_dict(ndist.broadcast_state_dict(cw, src=0, device=tdev))
+            codec_sd = ndist.broadcast_state_dict(cw, src=0, device=tdev)
+            codec.load_state_dict(codec_sd)
         stage("weights received (one arena broadcast + one packed codec buffer)")
     elif codec is not None:
-        codec.load_state_dict({k: v.numpy() for k, v in cw.items()})
+        codec_sd = {k: v.numpy() for k, v in cw.items()}
+        codec.load_state_dict(codec_sd)
     # static mode: a TWIN engine (same configuration, its own KV pool and slot state, the arena copied device to device) so that
     # consecutive batches can overlap on the GPU: while engine A replays batch k's decode graphs, engine B runs batch k + 1's prompt pass
     pipe = (not cont) and (not strm) and (not a.no_pipeline) and B > 1
+    G = max(1, a.gang) if pipe else 1
     engs = [eng]
+    codecs = [codec]
     if pipe:
-        eng2 = eng.twin()
-        engs.append(eng2)
-        stage("twin engine ready (arena copied on the device)")
+        for _ in range(2 * G - 1):
+            engs.append(eng.twin(share=os.environ.get("NTTS_BENCH_TWIN_COPY") != "1"))   # (A/B aid: twins with arena copies of their own)
+        if codec is not None:
+            for _ in range(2 * G - 1):                  # one codec engine (stream, activations, pinned output) per backbone engine
+                c2 = _hip.CodecEngine(codec_cfg_d, dev, lib)
+                c2.load_state_dict(codec_sd)
+                codecs.append(c2)
+        stage(f"{len(engs) - 1} twin engine(s) ready (reading engine 0's arena)")
+        # Streams -> hardware queues.  The HIP runtime multiplexes all streams of the process onto four hardware queues (least-loaded
+        # at creation); two decode chains in one queue run one after the other, and a prompt pass in a chain's queue stalls it.  So:
+        # `gang` lane streams, created back to back (torch's pool: containers / streams only), engine i of either gang decodes on
+        # lane i (the gangs take turns), and ONE more stream carries every prompt pass and codec pass (matrix-core-bound, they
+        # time-slice with each other anyway).  profiles/r04o_*: with the engines' own streams a gang of three had two chains in one queue.
+        lanes = None
+        if not emu_lib and os.environ.get("NTTS_BENCH_LANES", "1") != "0":
+            lanes = [torch.cuda.Stream(device=dev) for _ in range(G + 1)]
+            for j, e in enumerate(engs):
+                e.set_stream(lanes[j % G].cuda_stream)
+                e.set_prefill_stream(lanes[G].cuda_stream)
+            for c2 in codecs:
+                if c2 is not None:
+                    c2.set_stream(lanes[G].cuda_stream)
     if os.environ.get("NTTS_BENCH_PRIME", "1") != "0" and not cont:
         for e2 in engs[1:]:
             e2.warm_up(int(os.environ.get("NTTS_BENCH_PRIME_STEPS", str(max(2, N - 1)))))
@@ -437,20 +466,19 @@ def main():
         ph["slot_occupancy"] = st8["tokens"] / max(1, ph["decode_steps"] * B)
         return ph, None, wavs
 
-    pending = {"codec": False, "lens": None}
-    pstate = {"cur": 0, "ready": [False] * len(engs)}     # pipelined static mode: whose turn it is, which engine holds a prefilled batch
+    pending = []                                          # codec passes in flight: (codec engine, the lens buffer its export filled)
+    pstate = {"cur": 0, "ready": [0, 0]}                  # pipelined static mode: whose turn it is, how many prefilled batches each gang holds
     async_codec = os.environ.get("NTTS_BENCH_ASYNC_CODEC", "1") != "0"
+    gangs = [list(range(0, G)), list(range(G, 2 * G))] if pipe else [[0], [0]]     # engine indices
 
     def finish_pending():
-        """Wait for the codec pass enqueued by the previous step (it is ordered behind that step's decode loop and code export, so
+        """Wait for the codec passes enqueued by the previous step (each is ordered behind its batch's decode loop and code export, so
         those are done too) and check that every utterance produced its N tokens: export_codes wrote the counts next to the codes."""
-        if codec is None or not pending["codec"]:
-            return
-        codec.sync()
-        pending["codec"] = False
-        lb = pending["lens"] if pending["lens"] is not None else lens_buf
-        got = lb if emu_lib else lb.cpu().numpy()
-        assert (np.asarray(got) == N).all(), "bench run did not produce the expected tokens"
+        while pending:
+            cdc, lb = pending.pop(0)
+            cdc.sync()
+            got = lb if emu_lib else lb.cpu().numpy()
+            assert (np.asarray(got) == N).all(), "bench run did not produce the expected tokens"
 
     def prefill_all(e):
         each = []
@@ -461,44 +489,58 @@ def main():
             each.append(round((time.time() - tc0) * 1e3, 1))
         return each
 
-    def one_step_pipelined(last=False):
-        """One batch through the two-engine pipeline: prompts -> codec-token ids -> 24 kHz waveforms.  The launching thread enqueues
-        the NEXT batch's prompt pass on the other engine's stream between this batch's decode graphs (after --pipe-head of the 249), and this batch's codec pass
-        (codec engine's stream) before the next iteration: the GPU runs decode (latency-bound, ~a quarter of the HBM peak) beside
-        the matrix-core-bound passes.  A timed region is self-contained: its first step runs its own prompt pass un-overlapped
-        (nothing is ready), its last step starts no further batch -- K steps hold K prompt passes, K decode loops, K codec passes."""
+    def decode_gang(es, n):
+        """n decode steps on every engine of the gang, the graph replays enqueued alternately (engine 0's step j, engine 1's step j, ...):
+        each engine's chain runs on its own stream, the GPU fills one chain's launch gaps and first round trips with the other's kernels."""
+        if n <= 0:
+            return
+        if len(es) == 1:
+            es[0].decode(n)
+            return
+        for _ in range(n):
+            for e in es:
+                e.decode(1)
+
+    def gang_step(nb, nb_next):
+        """`nb` batches (one per engine of the current gang) through the pipeline: prompts -> codec-token ids -> 24 kHz waveforms.  The
+        launching thread enqueues the NEXT gang's prompt passes (`nb_next` batches, the other gang's streams) between this gang's decode
+        graphs (after --pipe-head of the 249), and this gang's codec passes (codec engines' streams) before the next iteration.  A timed
+        region is self-contained: its first gang runs its own prompt passes un-overlapped (nothing is ready), its last gang starts no
+        further batch -- K batches hold K prompt passes, K decode loops, K codec passes."""
         i = pstate["cur"]
-        cur, other = engs[i], engs[1 - i]
+        cur, other = [engs[j] for j in gangs[i][:nb]], [engs[j] for j in gangs[1 - i][:nb_next]]
         ph = {}
         tw = [time.time()]
         each = []
-        if not pstate["ready"][i]:
-            each += prefill_all(cur)                               # pipeline ramp
+        for e in cur[pstate["ready"][i]:]:
+            each += prefill_all(e)                                 # pipeline ramp
         nd = N - 1
-        head = min(max(a.pipe_head, 0), nd) if not last else nd
+        head = min(max(a.pipe_head, 0), nd) if other else nd
         ph["host_wall_prefill_each"] = each
         tw.append(time.time())
-        if head > 0:
-            cur.decode(head)                                       # batch k: a head start of `head` decode steps ...
-        if not last:
-            prefill_all(other)                                     # ... then batch k + 1's prompt pass (the other engine's stream) ...
-            pstate["ready"][1 - i] = True
-            if nd > head:
-                cur.decode(nd - head)                              # ... beside the rest of batch k's decode steps
+        decode_gang(cur, head)                                     # gang k: a head start of `head` decode steps ...
+        for e in other:
+            prefill_all(e)                                         # ... then gang k + 1's prompt passes (the other gang's streams) ...
+        pstate["ready"][1 - i] = len(other)
+        decode_gang(cur, nd - head)                                # ... beside the rest of gang k's decode steps
         tw.append(time.time())
         wavs = None
         if codec is not None:
-            cur.export_codes(list(range(B)), 0, n_codes, codes_ptrs[i], N, lens_ptrs[i], modulo=True)
-        st, n_new = cur.poll()                                      # blocking: batch k's decode (+ export) done
-        assert (n_new == N).all() and (st == 2).all(), "bench run did not produce the expected tokens"
+            for j, e in zip(gangs[i], cur):
+                e.export_codes(list(range(B)), 0, n_codes, codes_ptrs[j], N, lens_ptrs[j], modulo=True)
+        for e in cur:
+            st, n_new = e.poll()                                    # blocking: this batch's decode (+ export) done
+            assert (n_new == N).all() and (st == 2).all(), "bench run did not produce the expected tokens"
         if codec is not None:
-            finish_pending()                                        # batch k - 1's waveforms have left the codec engine's pinned buffer
-            wavs = codec.decode_device(codes_ptrs[i], N, np.full(B, N, dtype=np.int32), producer_stream=cur.stream())
-            pending["codec"], pending["lens"] = True, lens_bufs[i]
-            assert wavs.shape == (B, ccfg.hop_length * N)
+            finish_pending()                                        # gang k - 1's waveforms have left the codec engines' pinned buffers
+            for j, e in zip(gangs[i], cur):
+                wavs = codecs[j].decode_device(codes_ptrs[j], N, np.full(B, N, dtype=np.int32), producer_stream=e.stream())
+                pending.append((codecs[j], lens_bufs[j]))
+                assert wavs.shape == (B, ccfg.hop_length * N)
         tw.append(time.time())
-        cur.release_many(list(range(B)))
-        pstate["ready"][i] = False
+        for e in cur:
+            e.release_many(list(range(B)))
+        pstate["ready"][i] = 0
         pstate["cur"] = 1 - i
         tw.append(time.time())
         ph["host_wall_prefill_calls"] = (tw[1] - tw[0]) * 1e3
@@ -508,18 +550,25 @@ def main():
         ph["host_wall_total"] = (tw[4] - tw[0]) * 1e3
         return ph, None, wavs
 
+    def run_pipelined(K):
+        """K batches through the two-gang pipeline; returns per-gang-step [batches, host wall ms, phases]."""
+        walls = []
+        done = 0
+        while done < K:
+            nb = min(G, K - done)
+            nb_next = min(G, K - done - nb)
+            ts = time.time()
+            ph_t = gang_step(nb, nb_next)[0]
+            walls.append((nb, round((time.time() - ts) * 1e3, 2), ph_t))
+            done += nb
+        return walls
+
     def one_step_static(collect=False, last=False):
         """One pass of the hot path over one batch: prompts -> codec-token ids -> 24 kHz waveforms."""
-        if pipe and not collect:
-            return one_step_pipelined(last)
-        if pipe:                                                     # the untimed phase split runs serially on engine 0: drain the pipeline first
-            finish_pending()
-            for j, e2 in enumerate(engs):
-                if pstate["ready"][j]:
-                    e2.sync()
-                    for s_ in range(B):
-                        e2.release(s_)
-                    pstate["ready"][j] = False
+        assert collect or not pipe, "pipelined static mode runs through run_pipelined()"
+        if pipe:                                                     # the untimed phase split runs serially on engine 0: the pipeline is drained
+            finish_pending()                                         # (run_pipelined's last gang starts no further batch)
+            assert pstate["ready"] == [0, 0]
             pstate["cur"] = 0
         ph = {"prefill": 0.0, "decode": 0.0, "codec": 0.0, "handoff_host": 0.0, "codec_call_wall": 0.0}
         tw = [time.time()]                                   # host wall-clock stamps (reported as phase_ms.host_wall_*)
@@ -565,7 +614,7 @@ def main():
                 # batch k's codec pass and the D2H of its waveforms run on the codec engine's stream while the host releases the slots
                 # and enqueues batch k + 1's prompt pass (independent data; the pass is waited for before its buffers are reused and
                 # inside the closing barrier, so every waveform has landed when the clock stops)
-                pending["codec"] = True
+                pending.append((codec, lens_buf))
             else:
                 codec.sync()
                 ph["codec"] = codec.last_timing()
@@ -619,13 +668,35 @@ def main():
         if not emu_lib:
             torch.cuda.synchronize()
 
-    for k in range(a.warmup):
+    staticpipe = pipe and one_step is one_step_static
+    if staticpipe and os.environ.get("NTTS_BENCH_PRIME", "1") != "0":
+        # start-up, like warm_up(): every engine pair (backbone + codec) sees one prompt-pass chunk, a decode step, an export and a codec
+        # pass of the real shapes once (pinned output buffers, runtime pools), whatever --warmup is -- the warm-up steps below go
+        # through gangs, i.e. through the first engines only
+        for j, e in enumerate(engs):
+            n = min(a.prefill_chunk, B)
+            e.prefill(prompts[:n], list(range(n)), samps[:n] if samps else [samp] * n)
+            e.decode(min(2, N - 1))
+            if codec is not None:
+                e.export_codes(list(range(n)), 0, n_codes, codes_ptrs[j], N, lens_ptrs[j], modulo=True)
+                codecs[j].decode_device(codes_ptrs[j], N, np.full(B, N, dtype=np.int32), producer_stream=e.stream())
+                codecs[j].sync()
+            e.sync()
+            e.release_many(list(range(n)))
+        stage("every engine primed")
+    if staticpipe:
+        run_pipelined(a.warmup)
+    for k in range(0 if staticpipe else a.warmup):
         one_step(last=(k == a.warmup - 1))
     barrier()
     t0 = time.time()
     step_wall = []                                   # per-step host wall time (diagnostic; `value` uses the barrier-bracketed total)
     step_host = []                                   # static mode: host wall of [prefill calls, decode enqueue, wait + codec] per step
-    for k in range(a.steps):
+    if staticpipe:                                   # K batches = K "steps" of the contract, `gang` of them in flight per gang step
+        for nb, wall_ms, ph_t in run_pipelined(a.steps):
+            step_wall.append([nb, wall_ms])
+            step_host.append([ph_t["host_wall_prefill_each"]] + [round(ph_t[k], 1) for k in ("host_wall_prefill_calls", "host_wall_decode_call", "host_wall_wait_and_codec")])
+    for k in range(0 if staticpipe else a.steps):
         ts = time.time()
         ph_t = one_step(collect=bool(os.environ.get("NTTS_BENCH_STEP_PHASES")), last=(k == a.steps - 1))[0]   # (diagnostic: per-step GPU phases add syncs)
         step_wall.append(round((time.time() - ts) * 1e3, 2))
@@ -737,7 +808,7 @@ def main():
         else:
             workload = (f"NeuTTS-Air bf16 {world}xMI355X batch={B} synthetic prompts per GPU, {S} prefill / {N} decode tokens, "
                         f"STATIC batch (all {B} slots of the continuous-batching engine filled at once, every utterance {N} tokens; the ragged "
-                        f"scheduler line is --mode continuous)" + (", consecutive batches pipelined over two engines" if pipe else "") + f" + hipGraph decode (BASELINE.json configs[{2 if world == 1 else 3}])")
+                        f"scheduler line is --mode continuous)" + ((f", {G} batches decoded side by side on {G} {B}-slot engines (graph replays alternated, one stream each), consecutive gangs pipelined ({2 * G} engines)" if G > 1 else ", consecutive batches pipelined over two engines") if pipe else "") + f" + hipGraph decode (BASELINE.json configs[{2 if world == 1 else 3}])")
         workload += ", sampling as the reference calls generate (do_sample, top_k=50, temperature=1.0, seeded)" if a.sample else ", greedy"
         if strm:
             workload = (f"STREAM mode: {B} concurrent infer_stream utterances per GPU (27-frame windows every 25 tokens, 0.5 s chunks, "
@@ -759,13 +830,15 @@ def main():
             "rtf": dt / (tokens / 50.0),
             "phase_ms": ph, "step_wall_ms": step_wall, "step_host_wall_ms": step_host,
             "roofline": roof, "decode_step": step_info, "cpu_baseline": cpu,
-            "timed_region": ("warm_up() before timing; TWO backbone engines, one launching thread: batch k + 1's prompt pass (engine B's stream) is enqueued "
-                             "before batch k's decode graphs (engine A's stream), batch k's codec pass + D2H run on the codec engine's stream under "
-                             "batch k + 1's decode; the timed region is self-contained (first step un-overlapped prompt pass, last step starts no "
-                             "further batch: K prompt passes, K decode loops, K codec passes, every waveform landed before the clock stops); "
-                             "phase_ms is a separate serial pass" if pipe else
+            "timed_region": (f"warm_up() before timing; {2 * G} backbone engines of {B} slots in two gangs of {G}, one launching thread: a gang's {G} batches decode side "
+                             f"by side (their step graphs replayed alternately, each engine on its own stream), gang k + 1's prompt passes are enqueued "
+                             "between gang k's decode graphs, gang k's codec passes + D2H run on the codec engines' streams under "
+                             "gang k + 1's decode; the timed region is self-contained (first gang un-overlapped prompt passes, last gang starts no "
+                             "further batch: K prompt passes, K decode loops, K codec passes, every waveform landed before the clock stops; a step of the "
+                             "contract = one batch); phase_ms is a separate serial pass on ONE engine" if pipe else
                              "warm_up() before timing, codec pass + D2H of batch k asynchronous under the prompt pass of batch k + 1 (static mode, one engine)"),
-            "pipeline": {"engines": len(engs), "overlap": "prefill(k+1) | decode(k) | codec(k-1)", "decode_head_start_steps": a.pipe_head} if pipe else None,
+            "pipeline": {"engines": len(engs), "gang": G, "overlap": "prefill(gang k+1) | decode(gang k: its batches side by side) | codec(gang k-1)",
+                         "decode_head_start_steps": a.pipe_head, "utterances_resident": len(engs) * B} if pipe else None,
         }
         if strm:
             rec["stream"] = stream_stats

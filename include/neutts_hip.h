@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define NTTS_ABI_VERSION 6
+#define NTTS_ABI_VERSION 7
 
 enum {
     NTTS_OK = 0,
@@ -117,6 +117,12 @@ int ntts_backbone_arena_derived(ntts_backbone* e, size_t* off, size_t* bytes);
 /* Device-to-device copy between the arena and a caller buffer of exactly the arena size (the staging
  * tensor torch.distributed broadcasts): to_arena = 0 arena -> buf, 1 buf -> arena.  Blocking. */
 int ntts_backbone_arena_copy(ntts_backbone* e, void* buf, size_t bytes, int to_arena);
+/* (ABI 7) A second engine on the SAME weights: `e` (created with the donor's configuration on the donor's device, nothing loaded
+ * yet) drops its own arena and reads the finalised donor's; KV pool, slots, workspaces, stream and step graph stay its own.  For
+ * several decode chains side by side on one GPU (ref:neutts/neutts.py:338-347 run for more than one batch at a time: each engine
+ * replays its own step graph on its own stream, the launching thread alternates between them).  The donor must outlive `e`;
+ * weight loads into either engine are refused from then on (NTTS_ESTATE). */
+int ntts_backbone_share_arena(ntts_backbone* e, ntts_backbone* donor);
 
 /* Sampling contract of one request = the keyword arguments of the reference's generate() call
  * (ref:neutts/neutts.py:338-347). */
@@ -211,6 +217,13 @@ int ntts_backbone_set_stream(ntts_backbone* e, void* stream);
  * to another engine's decode steps, which are latency-bound (bench.py pipelines consecutive batches this way).  n_words = 0
  * restores the default (prompt pass on the engine's stream, all CUs).  Blocking (drains the engine's streams). */
 int ntts_backbone_set_prefill_cu_mask(ntts_backbone* e, const uint32_t* mask, int32_t n_words);
+/* (ABI 7) The same side-stream arrangement on a stream the CALLER owns (no CU mask): every later prompt pass is enqueued there,
+ * ordered behind the work already on the engine's stream and before what follows on it by events -- nothing blocks per pass.
+ * For several engines side by side: all matrix-core-bound passes in one hardware queue, each engine's decode chain in its own
+ * (the HIP runtime multiplexes streams onto four hardware queues; a prompt pass in the queue of another engine's decode chain
+ * stalls that chain).  NULL restores the default.  Replaces a CU-masked side stream and vice versa.  Blocking (drains the engine's
+ * streams) at the switch itself. */
+int ntts_backbone_set_prefill_stream(ntts_backbone* e, void* stream);
 /* Return the slot's KV pages to the pool and mark it free. */
 int ntts_backbone_release(ntts_backbone* e, int32_t slot);
 /* ntts_backbone_release for `n` distinct slots with ONE stream operation (a server frees a whole batch at once); nothing is released if a

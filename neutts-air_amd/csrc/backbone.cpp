@@ -57,6 +57,7 @@ struct ntts_backbone {
     // weights
     bf16_t* arena = nullptr;
     size_t arena_elems = 0;
+    bool arena_shared = false;         // the arena is another engine's (ntts_backbone_share_arena): not freed here
     bf16_t *embed = nullptr, *final_norm = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
     bf16_t* embed_tm = nullptr;   // the lm_head's weight stream: tile-major copy of the tied embedding, the untied
                                   // "lm_head.weight", or (fp8) the e4m3 bytes of either
@@ -168,6 +169,7 @@ struct ntts_backbone {
     // on it leaves the other CUs to whatever else runs on the GPU -- another engine's decode steps, which are launch- and
     // latency-bound and lose little on fewer CUs, while an unrestricted prefill's 1024-thread workgroups would take every CU
     hipStream_t pf_stream = nullptr;
+    bool pf_lent = false;              // pf_stream is the caller's (ntts_backbone_set_prefill_stream): not destroyed here
     hipEvent_t pf_ev[2]{};
     bool have_pf_time = false, have_dec_time = false;
     unsigned long long* attn_tl = nullptr;   // diagnostics (ntts_backbone_attn_timeline)
@@ -450,7 +452,7 @@ extern "C" void ntts_backbone_destroy(ntts_backbone* e) {
     hipDeviceSynchronize();
     if (e->graph) hipGraphExecDestroy(e->graph);
     if (e->graph_split) hipGraphExecDestroy(e->graph_split);
-    void* bufs[] = {e->arena, e->gu_map_gate, e->gu_map_up, e->kv, e->ibuf, e->h_dec, e->xn_dec, e->qkv_dec, e->attn_dec,
+    void* bufs[] = {e->arena_shared ? nullptr : e->arena, e->gu_map_gate, e->gu_map_up, e->kv, e->ibuf, e->h_dec, e->xn_dec, e->qkv_dec, e->attn_dec,
                     e->act_dec, e->slabs, e->slabs2, e->h_alt, e->part_val, e->part_idx, e->logits, e->logits_bf16, e->h_pf, e->xn_pf, e->qkv_pf, e->attn_pf,
                     e->o_pf, e->act_pf, e->meta_dev, e->as_scores, e->as_stats, e->as_oslabs, e->step_meta, e->rope_rows};
     for (void* b : bufs)
@@ -464,7 +466,7 @@ extern "C" void ntts_backbone_destroy(ntts_backbone* e) {
     if (e->snap_host) hipHostFree(e->snap_host);
     if (e->snap_ev) hipEventDestroy(e->snap_ev);
     if (e->copy_stream) hipStreamDestroy(e->copy_stream);
-    if (e->pf_stream) { hipStreamDestroy(e->pf_stream); hipEventDestroy(e->pf_ev[0]); hipEventDestroy(e->pf_ev[1]); }
+    if (e->pf_stream) { if (!e->pf_lent) hipStreamDestroy(e->pf_stream); hipEventDestroy(e->pf_ev[0]); hipEventDestroy(e->pf_ev[1]); }
     if (e->own_stream) hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -787,6 +789,7 @@ extern "C" int ntts_backbone_arena(ntts_backbone* e, void** dev_ptr, size_t* byt
 }
 extern "C" int ntts_backbone_arena_copy(ntts_backbone* e, void* buf, size_t bytes, int to_arena) {
     if (!e || !buf || bytes != e->arena_elems * sizeof(bf16_t)) return fail(e, NTTS_EINVAL, "arena copy: bad buffer / size");
+    if (to_arena && e->arena_shared) return fail(e, NTTS_ESTATE, "arena copy: this engine reads another engine's arena");
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     if (to_arena) HIPCHK(e, hipMemcpy(e->arena, buf, bytes, hipMemcpyDeviceToDevice));
@@ -818,6 +821,39 @@ extern "C" int ntts_backbone_adopt_arena(ntts_backbone* e) {
     const int rc = sync_input_scales(e, false);   // fp8: the launches need the input scales on the host
     if (rc) return rc;
     e->finalized = true;  // arena (incl. the RoPE table) was filled by a broadcast from a finalised engine
+    return NTTS_OK;
+}
+
+// A second engine on the SAME weights: e gives up its own (still empty) arena and reads the donor's -- weights, scales and the RoPE
+// table are read-only once finalised.  Its KV pool, slot state, workspaces, stream and step graph stay its own.  What running
+// several decode chains side by side needs (two 256-slot engines whose step graphs are replayed alternately: each chain fills the
+// other's launch gaps, and the second chain finds the layer's weights in the memory-side cache).  The donor must outlive e.
+extern "C" int ntts_backbone_share_arena(ntts_backbone* e, ntts_backbone* donor) {
+    if (!e || !donor || e == donor) return NTTS_EINVAL;
+    if (!donor->finalized) return fail(e, NTTS_ESTATE, "share_arena: the donor engine is not finalised");
+    if (e->finalized || e->arena_shared || e->graph || e->graph_split) return fail(e, NTTS_ESTATE, "share_arena: this engine already holds weights");
+    const ntts_backbone_config &a = e->cfg, &b = donor->cfg;
+    if (e->device != donor->device || e->arena_elems != donor->arena_elems || a.vocab_size != b.vocab_size || a.hidden_size != b.hidden_size ||
+        a.intermediate_size != b.intermediate_size || a.num_layers != b.num_layers || a.num_heads != b.num_heads ||
+        a.num_kv_heads != b.num_kv_heads || a.max_context != b.max_context || e->fp8 != donor->fp8 || e->tied != donor->tied ||
+        e->has_bias != donor->has_bias)
+        return fail(e, NTTS_EINVAL, "share_arena: the two engines differ in device, geometry, weight type or context length");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipStreamSynchronize(donor->stream));
+    bf16_t* old = e->arena;
+    auto mv = [&](auto*& ptr) { if (ptr) ptr = (std::remove_reference_t<decltype(ptr)>)((char*)donor->arena + ((char*)ptr - (char*)old)); };
+    mv(e->embed); mv(e->embed_tm); mv(e->shead); mv(e->xs_head_dev); mv(e->final_norm); mv(e->rope_cos); mv(e->rope_sin);
+    for (LayerW& w : e->layers) {
+        mv(w.ln1); mv(w.wqkv); mv(w.bqkv); mv(w.wo); mv(w.ln2); mv(w.wgu); mv(w.wd);
+        mv(w.sqkv); mv(w.so); mv(w.sgu); mv(w.sd); mv(w.xs_dev);
+    }
+    HIPCHK(e, hipFree(old));
+    e->arena = donor->arena;
+    e->arena_shared = true;
+    const int rc = sync_input_scales(e, false);   // fp8: the launches need the input scales on the host
+    if (rc) return rc;
+    e->finalized = true;
     return NTTS_OK;
 }
 
@@ -1673,31 +1709,57 @@ extern "C" int ntts_backbone_set_stream(ntts_backbone* e, void* stream) {
     return NTTS_OK;
 }
 
-extern "C" int ntts_backbone_set_prefill_cu_mask(ntts_backbone* e, const uint32_t* mask, int32_t n_words) {
-    if (!e || n_words < 0 || (n_words > 0 && !mask)) return fail(e, NTTS_EINVAL, "bad CU mask");
+// Drop the side stream of the prompt passes (drained first; a lent one goes back to its owner).
+static int drop_prefill_stream(ntts_backbone* e) {
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     if (e->pf_stream) {
         HIPCHK(e, hipStreamSynchronize(e->pf_stream));
-        hipStreamDestroy(e->pf_stream); hipEventDestroy(e->pf_ev[0]); hipEventDestroy(e->pf_ev[1]);
+        if (!e->pf_lent) hipStreamDestroy(e->pf_stream);
+        hipEventDestroy(e->pf_ev[0]); hipEventDestroy(e->pf_ev[1]);
         e->pf_stream = nullptr;
+        e->pf_lent = false;
     }
-    if (n_words == 0) return NTTS_OK;
-    long bits = 0;
-    for (int i = 0; i < n_words; ++i) bits += __builtin_popcount(mask[i]);
-    if (bits < 1) return fail(e, NTTS_EINVAL, "empty CU mask");
-    HIPCHK(e, hipExtStreamCreateWithCUMask(&e->pf_stream, (uint32_t)n_words, mask));
+    return NTTS_OK;
+}
+static int make_prefill_events(ntts_backbone* e) {
     e->pf_ev[0] = e->pf_ev[1] = nullptr;
     if (hipEventCreateWithFlags(&e->pf_ev[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&e->pf_ev[1], hipEventDisableTiming) != hipSuccess) {   // no ordering events, no side stream
         if (e->pf_ev[0]) hipEventDestroy(e->pf_ev[0]);
         if (e->pf_ev[1]) hipEventDestroy(e->pf_ev[1]);
         e->pf_ev[0] = e->pf_ev[1] = nullptr;
-        hipStreamDestroy(e->pf_stream);
+        if (!e->pf_lent) hipStreamDestroy(e->pf_stream);
         e->pf_stream = nullptr;
+        e->pf_lent = false;
         return fail(e, NTTS_EHIP, "could not create the side stream's ordering events");
     }
     return NTTS_OK;
+}
+
+extern "C" int ntts_backbone_set_prefill_cu_mask(ntts_backbone* e, const uint32_t* mask, int32_t n_words) {
+    if (!e || n_words < 0 || (n_words > 0 && !mask)) return fail(e, NTTS_EINVAL, "bad CU mask");
+    const int rc = drop_prefill_stream(e);
+    if (rc) return rc;
+    if (n_words == 0) return NTTS_OK;
+    long bits = 0;
+    for (int i = 0; i < n_words; ++i) bits += __builtin_popcount(mask[i]);
+    if (bits < 1) return fail(e, NTTS_EINVAL, "empty CU mask");
+    HIPCHK(e, hipExtStreamCreateWithCUMask(&e->pf_stream, (uint32_t)n_words, mask));
+    return make_prefill_events(e);
+}
+
+// The prompt passes on a stream of the CALLER's, ordered behind and before the engine's stream by events (nothing blocks): a server
+// that runs several engines side by side keeps every matrix-core-bound pass (prompt passes, codec passes) in ONE hardware queue and
+// each engine's decode chain in a queue of its own -- the runtime maps streams onto four hardware queues, and a prompt pass that
+// lands in the queue of another engine's decode chain stalls that chain for its whole length.  nullptr: back to the engine's stream.
+extern "C" int ntts_backbone_set_prefill_stream(ntts_backbone* e, void* stream) {
+    if (!e) return NTTS_EINVAL;
+    const int rc = drop_prefill_stream(e);
+    if (rc || !stream) return rc;
+    e->pf_stream = (hipStream_t)stream;
+    e->pf_lent = true;
+    return make_prefill_events(e);
 }
 
 extern "C" int ntts_backbone_export_codes(ntts_backbone* e, int32_t n, const int32_t* slots, int32_t speech_base, int32_t n_codes,

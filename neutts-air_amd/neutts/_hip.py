@@ -18,7 +18,7 @@ DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "libneutts_hip.so")
 
 NTTS_DT_F32, NTTS_DT_BF16, NTTS_DT_I32, NTTS_DT_FP8_E4M3 = 0, 1, 2, 3
 NTTS_W_BF16, NTTS_W_FP8_E4M3 = 0, 1
-ABI_VERSION = 6
+ABI_VERSION = 7
 NTTS_PAGE_TOKENS = 32            # include/neutts_hip.h
 PAGE_TOKENS = 32
 ERRORS = {-1: "EINVAL", -2: "ENODEV", -3: "ENOMEM", -4: "ESTATE", -5: "EHIP"}
@@ -94,6 +94,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_backbone_adopt_arena": (C.c_int, [p]),
         "ntts_backbone_arena_derived": (C.c_int, [p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
         "ntts_backbone_arena_copy": (C.c_int, [p, p, C.c_size_t, C.c_int]),
+        "ntts_backbone_share_arena": (C.c_int, [p, p]),
+        "ntts_backbone_set_prefill_stream": (C.c_int, [p, p]),
         "ntts_backbone_time_kernel": (C.c_int, [p, i32, i32, C.POINTER(f32), C.POINTER(C.c_double), C.POINTER(i32)]),
         "ntts_backbone_prefill": (C.c_int, [p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(SamplingC)]),
         "ntts_backbone_prefill_shared": (C.c_int, [p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(SamplingC),
@@ -312,15 +314,21 @@ class BackboneEngine:
     def adopt_arena(self):
         self._chk(self.lib.ntts_backbone_adopt_arena(self.h))
 
-    def twin(self) -> "BackboneEngine":
-        """A second engine with this one's configuration and weights -- its own KV pool, slot state and stream -- filled by ONE
-        device-to-device copy of the finalised arena (no second upload, no re-quantisation).  What cross-batch pipelining needs:
-        while this engine replays batch k's decode graphs, the twin runs batch k + 1's prompt pass (bench.py static mode)."""
-        ptr, nbytes = self.arena()
+    def twin(self, share: bool = True) -> "BackboneEngine":
+        """A second engine with this one's configuration and weights -- its own KV pool, slot state, stream and step graph.  What
+        running several batches at once needs: the twins' step graphs replayed alternately (each chain fills the other's launch gaps),
+        one twin's prompt pass beside another's decode steps (bench.py static mode, EngineGang).  share=True: the twin READS THIS
+        ENGINE'S ARENA (ntts_backbone_share_arena: no second copy of the weights; this engine is kept alive by the twin);
+        share=False: its own arena, filled by one device-to-device copy."""
         self.sync()
         t = BackboneEngine(self.cfg, self._device, self._lib_path)
-        t.arena_copy(ptr, nbytes, True)
-        t.adopt_arena()
+        if share:
+            t._chk(self.lib.ntts_backbone_share_arena(t.h, self.h))
+            t._donor = self
+        else:
+            ptr, nbytes = self.arena()
+            t.arena_copy(ptr, nbytes, True)
+            t.adopt_arena()
         return t
 
     # -- requests
@@ -479,6 +487,11 @@ class BackboneEngine:
     def set_stream(self, stream: Optional[int]):
         """Run the engine's work on the caller's HIP stream (a hipStream_t as an integer, e.g. torch.cuda.Stream().cuda_stream); None = its own."""
         self._chk(self.lib.ntts_backbone_set_stream(self.h, C.c_void_p(stream or None)))
+
+    def set_prefill_stream(self, stream: Optional[int]):
+        """Prompt passes on the caller's HIP stream, event-ordered with the engine's stream (ntts_backbone_set_prefill_stream);
+        None = back on the engine's stream."""
+        self._chk(self.lib.ntts_backbone_set_prefill_stream(self.h, C.c_void_p(stream or None)))
 
     def set_debug(self, keep_logits: bool):
         self._chk(self.lib.ntts_backbone_set_debug(self.h, int(keep_logits)))

@@ -56,9 +56,10 @@ def test_bench_contract_world2(emu_lib):
         assert k in rec
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     assert abs(rec["value"] - 2 * 2 * 4 / (rec["ms_per_step"] / 1e3)) < 1e-6 * rec["value"] + 1e-9
-    # static mode pipelines consecutive batches over two engines (prompt pass of batch k + 1 beside the decode of batch k); every
-    # step asserts its token counts from the device-exported lengths, so three steps = both engines, both hand-off buffer pairs
-    assert rec["pipeline"]["engines"] == 2 and rec["steps"] == 3
+    # static mode decodes two batches side by side (a gang of two engines) and pipelines consecutive gangs (prompt passes of gang
+    # k + 1 beside the decode of gang k); every batch asserts its token counts from the device-exported lengths, so three steps =
+    # a full gang + a gang of one, and the warm-up batch before them went through the other gang's engines and hand-off buffers
+    assert rec["pipeline"]["engines"] == 4 and rec["pipeline"]["gang"] == 2 and rec["steps"] == 3
 
 
 def test_bench_contract_world8(emu_lib):

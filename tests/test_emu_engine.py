@@ -237,17 +237,18 @@ def test_warm_up_and_side_stream_prefill(emu_lib):
 
 
 def test_twin_engine_and_async_snapshots(emu_lib):
-    """BackboneEngine.twin(): a second engine filled by ONE device-to-device copy of the finalised arena (what bench.py's two-engine pipeline
-    runs on) generates the same ids as the engine it was cloned from; and the asynchronous snapshot calls (poll_begin / poll_end /
+    """BackboneEngine.twin(): a second engine that READS THE FIRST ONE'S ARENA (ntts_backbone_share_arena, ABI 7: what bench.py's engine gangs
+    run on) and one filled by a device-to-device copy of it (share=False) generate the same ids as the engine they were made from; and the asynchronous snapshot calls (poll_begin / poll_end /
     read_finished, ABI 5) report what the blocking poll / read report, refuse to be opened twice and refuse rows that were not finished."""
     z, cfg, w = load_fixture("backbone_tiny")
     S, N, mn, eos = int(z["s_len"]), 8, int(z["min_new"]), int(z["eos"])
     eng = make_engine(cfg, w, emu_lib, max_batch=2)
-    tw = eng.twin()
+    tw, tw_copy = eng.twin(), eng.twin(share=False)
+    assert tw.arena()[0] == eng.arena()[0] and tw_copy.arena()[0] != eng.arena()[0]
     samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
     prompts = [br.synthetic_prompt(cfg, u, S) for u in (0, 1)]
     got = []
-    for e in (eng, tw):
+    for e in (eng, tw, tw_copy):
         e.prefill(prompts, [0, 1], [samp] * 2)
         e.decode(3)
         e.poll_begin()
@@ -269,8 +270,52 @@ def test_twin_engine_and_async_snapshots(emu_lib):
         e.release_many([1, 0])                               # one stream operation for the whole set
         st, _ = e.poll()
         assert st.tolist() == [0, 0] and e.free_slots() == 2
-    assert got[0] == got[1]
+    assert got[0] == got[1] == got[2]
     assert got[0][0] == z["bf16_ids_0"][:N].tolist() or sum(a == b for a, b in zip(got[0][0], z["bf16_ids_0"][:N].tolist())) >= N - 2
+
+
+def test_share_arena_error_paths_and_side_by_side_chains(emu_lib):
+    """ntts_backbone_share_arena (ABI 7): refused for an engine that already holds weights, for a donor that is not finalised and for a
+    different geometry; no weight load or arena copy into an engine that reads another's arena; and two engines on one arena whose decode
+    steps are enqueued ALTERNATELY (bench.py's gang schedule) produce, each, the ids of the same prompts run alone."""
+    z, cfg, w = load_fixture("backbone_tiny")
+    S, N, eos = int(z["s_len"]), 6, int(z["eos"])
+    eng = make_engine(cfg, w, emu_lib, max_batch=2)
+    lib = eng.lib
+    fresh = _hip.BackboneEngine(eng.cfg, 0, emu_lib)
+    assert lib.ntts_backbone_share_arena(eng.h, fresh.h) == -4            # donor not finalised (and eng holds weights)
+    other = _hip.BackboneEngine(dict(eng.cfg, max_context=eng.cfg["max_context"] + 32), 0, emu_lib)
+    assert lib.ntts_backbone_share_arena(other.h, eng.h) == -1            # EINVAL: another RoPE table length
+    assert lib.ntts_backbone_share_arena(eng.h, eng.h) == -1
+    tw = eng.twin()
+    assert lib.ntts_backbone_share_arena(tw.h, eng.h) == -4               # already sharing
+    with pytest.raises(_hip.NeuTTSHipError):
+        tw.load_tensor("model.norm.weight", np.ones(cfg.hidden_size, dtype=np.float32))
+    buf = np.zeros(tw.arena()[1], dtype=np.uint8)
+    with pytest.raises(_hip.NeuTTSHipError):
+        tw.arena_copy(buf.ctypes.data, buf.nbytes, True)
+    samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
+    pa = [br.synthetic_prompt(cfg, u, S) for u in (0, 1)]
+    pb = [br.synthetic_prompt(cfg, u, S) for u in (2, 3)]
+    eng.prefill(pa, [0, 1], [samp] * 2)
+    eng.decode(N - 1)
+    alone_a = [eng.read(s)[0] for s in (0, 1)]
+    eng.release_many([0, 1])
+    eng.prefill(pb, [0, 1], [samp] * 2)
+    eng.decode(N - 1)
+    alone_b = [eng.read(s)[0] for s in (0, 1)]
+    eng.release_many([0, 1])
+    eng.prefill(pa, [0, 1], [samp] * 2)
+    tw.prefill(pb, [0, 1], [samp] * 2)
+    for _ in range(N - 1):
+        eng.decode(1)
+        tw.decode(1)
+    assert [eng.read(s)[0] for s in (0, 1)] == alone_a and [tw.read(s)[0] for s in (0, 1)] == alone_b
+    tw.close()                                                            # the donor's arena survives its reader
+    eng.release_many([0, 1])
+    eng.prefill(pa, [0, 1], [samp] * 2)
+    eng.decode(N - 1)
+    assert [eng.read(s)[0] for s in (0, 1)] == alone_a
 
 
 def test_read_finished_refuses_a_stale_snapshot(emu_lib):

@@ -606,17 +606,18 @@ def test_air_sampling_topk50_full_vocab(air):
 
 
 def test_twin_engine_and_async_snapshots(lib):
-    """BackboneEngine.twin(): a second engine filled by ONE device-to-device copy of the finalised arena (what bench.py's two-engine pipeline
-    runs on) generates the same ids as the engine it was cloned from; and the asynchronous snapshot calls (poll_begin / poll_end /
+    """BackboneEngine.twin(): a second engine that READS THE FIRST ONE'S ARENA (ntts_backbone_share_arena, ABI 7: what bench.py's engine gangs
+    run on) and one filled by a device-to-device copy of it (share=False) generate the same ids as the engine they were made from; and the asynchronous snapshot calls (poll_begin / poll_end /
     read_finished, ABI 5) report what the blocking poll / read report, refuse to be opened twice and refuse rows that were not finished."""
     z, cfg, w = load_fixture("backbone_tiny")
     S, N, mn, eos = int(z["s_len"]), 8, int(z["min_new"]), int(z["eos"])
     eng = make_engine(cfg, w, lib, max_batch=2)
-    tw = eng.twin()
+    tw, tw_copy = eng.twin(), eng.twin(share=False)
+    assert tw.arena()[0] == eng.arena()[0] and tw_copy.arena()[0] != eng.arena()[0]
     samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
     prompts = [br.synthetic_prompt(cfg, u, S) for u in (0, 1)]
     got = []
-    for e in (eng, tw):
+    for e in (eng, tw, tw_copy):
         e.prefill(prompts, [0, 1], [samp] * 2)
         e.decode(3)
         e.poll_begin()
@@ -638,7 +639,7 @@ def test_twin_engine_and_async_snapshots(lib):
         e.release_many([1, 0])                               # one stream operation for the whole set
         st, _ = e.poll()
         assert st.tolist() == [0, 0] and e.free_slots() == 2
-    assert got[0] == got[1]
+    assert got[0] == got[1] == got[2]
     assert got[0][0] == z["bf16_ids_0"][:N].tolist() or sum(a == b for a, b in zip(got[0][0], z["bf16_ids_0"][:N].tolist())) >= N - 2
 
 
