@@ -181,11 +181,15 @@ def main():
     ap.add_argument("--pipe-head", type=int, default=100,
                     help="pipelined static mode: decode steps of batch k enqueued BEFORE batch k + 1's prompt pass (0 = prompt pass first); "
                          "the prompt pass then runs beside the later, longer-context steps (profiles/r03i_sweep_pipeline_schedule.txt)")
-    ap.add_argument("--gang", type=int, default=2,
+    ap.add_argument("--gang", type=int, default=4,
                     help="pipelined static mode: 256-slot engines whose decode graphs are replayed ALTERNATELY from the one launching thread, each on "
                          "its own stream (one batch per engine): a decode chain is latency-bound (a quarter of the HBM peak), two of them fill each "
                          "other's launch gaps and first round trips (tools/probe_two_chains.py: 1.57 -> 1.15 ms per 256-row step).  The pipeline "
                          "holds two gangs (2 x gang engines); 1 = the round-3 pipeline")
+    ap.add_argument("--gangs", type=int, default=1, choices=[1, 2],
+                    help="pipelined static mode: 2 = two gangs take turns (gang k + 1's prompt passes beside gang k's decode steps, prompt and codec "
+                         "passes on one shared stream); 1 = ONE gang, every engine on a lane of its own for all of its work: prompt passes, decode "
+                         "chains and codec passes of the gang's batches each run side by side, phase after phase")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-codec", action="store_true", help="backbone only (profiling aid; not the headline metric)")
@@ -267,7 +271,7 @@ def main():
     B, S, N = a.batch, a.prefill, a.decode
     cont = a.mode == "continuous"
     strm = a.mode == "stream"
-    R = a.requests or 4 * B
+    R = a.requests or 4 * B * (max(1, a.gang) if (a.mode == "continuous" and B > 1) else 1)
     S_max, N_max = (int(S * 1.3) + 1, int(N * 1.4) + 1) if cont else (S, N)
     dev = 0 if emu_lib else local
     eos = cfg.vocab_size - 1
@@ -343,10 +347,11 @@ def main():
     engs = [eng]
     codecs = [codec]
     if pipe:
-        for _ in range(2 * G - 1):
+        NG = a.gangs
+        for _ in range(NG * G - 1):
             engs.append(eng.twin(share=os.environ.get("NTTS_BENCH_TWIN_COPY") != "1"))   # (A/B aid: twins with arena copies of their own)
         if codec is not None:
-            for _ in range(2 * G - 1):                  # one codec engine (stream, activations, pinned output) per backbone engine
+            for _ in range(NG * G - 1):                 # one codec engine (stream, activations, pinned output) per backbone engine
                 c2 = _hip.CodecEngine(codec_cfg_d, dev, lib)
                 c2.load_state_dict(codec_sd)
                 codecs.append(c2)
@@ -358,13 +363,14 @@ def main():
         # time-slice with each other anyway).  profiles/r04o_*: with the engines' own streams a gang of three had two chains in one queue.
         lanes = None
         if not emu_lib and os.environ.get("NTTS_BENCH_LANES", "1") != "0":
-            lanes = [torch.cuda.Stream(device=dev) for _ in range(G + 1)]
+            lanes = [torch.cuda.Stream(device=dev) for _ in range(G + (1 if NG == 2 else 0))]
             for j, e in enumerate(engs):
                 e.set_stream(lanes[j % G].cuda_stream)
-                e.set_prefill_stream(lanes[G].cuda_stream)
-            for c2 in codecs:
+                if NG == 2:
+                    e.set_prefill_stream(lanes[G].cuda_stream)
+            for j, c2 in enumerate(codecs):
                 if c2 is not None:
-                    c2.set_stream(lanes[G].cuda_stream)
+                    c2.set_stream(lanes[G if NG == 2 else j % G].cuda_stream)      # (one gang: engine j's codec pass on its own lane)
     if os.environ.get("NTTS_BENCH_PRIME", "1") != "0" and not cont:
         for e2 in engs[1:]:
             e2.warm_up(int(os.environ.get("NTTS_BENCH_PRIME_STEPS", str(max(2, N - 1)))))
@@ -403,73 +409,101 @@ def main():
 
     # continuous mode: finished utterances leave through the device-side hand-off as they finish (on_finished hook: export_codes
     # into a staging buffer before the slot is released); every B of them go through ONE codec pass on the codec engine's stream
-    # while the backbone keeps decoding the others
-    if cont and codec is not None and not emu_lib:
-        stage_codes = [torch.zeros((B, N_max), dtype=torch.int32, device=f"cuda:{dev}") for _ in range(2)]
-        stage_lens = [torch.zeros(B, dtype=torch.int32, device=f"cuda:{dev}") for _ in range(2)]
-    elif cont and codec is not None:
-        stage_codes = [np.zeros((B, N_max), dtype=np.int32) for _ in range(2)]
-        stage_lens = [np.zeros(B, dtype=np.int32) for _ in range(2)]
+    # while the backbone keeps decoding the others.  With --gang > 1 the requests are dealt out over that many engines on one arena
+    # (neutts._hip.EngineGang: the engines' schedulers advance in turn, their decode chains run side by side), each with a codec
+    # engine and staging buffers of its own.
+    Gc = max(1, a.gang) if (cont and B > 1) else 1
+    gangc = _hip.EngineGang(eng, Gc, lanes=not emu_lib) if Gc > 1 else None
+    cengs = gangc.engines if gangc else [eng]
+    ccodecs = [codec]
+    if cont and codec is not None:
+        for _ in range(Gc - 1):
+            c2 = _hip.CodecEngine(codec_cfg_d, dev, lib)
+            c2.load_state_dict(codec_sd)
+            ccodecs.append(c2)
+        if gangc is not None and gangc.lane(0):
+            for k, c2 in enumerate(ccodecs):
+                c2.set_stream(gangc.lane(k))                # engine k's codec passes in engine k's hardware queue (four queues, four lanes)
+    if gangc is not None and os.environ.get("NTTS_BENCH_PRIME", "1") != "0":
+        for e2 in cengs[1:]:
+            e2.warm_up(max(2, N - 1))
+    if cont and codec is not None:
+        if emu_lib:
+            stage_codes = [[np.zeros((B, N_max), dtype=np.int32) for _ in range(2)] for _ in cengs]
+            stage_lens = [[np.zeros(B, dtype=np.int32) for _ in range(2)] for _ in cengs]
+        else:
+            stage_codes = [[torch.zeros((B, N_max), dtype=torch.int32, device=f"cuda:{dev}") for _ in range(2)] for _ in cengs]
+            stage_lens = [[torch.zeros(B, dtype=torch.int32, device=f"cuda:{dev}") for _ in range(2)] for _ in cengs]
 
     def one_step_continuous(collect=False, last=False):
         """One pass over R ragged requests: continuous batching (BackboneEngine.generate: admission by free slots, KV pages and
         prefill budget; ONE burst of decode steps always queued ahead of the host's bookkeeping; finished slots exported on the
-        device, released and refilled, new prompts admitted 16 at a time), the codec over every B finished utterances on its own
+        device, released and refilled, new prompts admitted 24 at a time), the codec over every B finished utterances on its own
         stream beside the decode steps of the others."""
         ph = {"generate_wall": 0.0, "codec_tail_wall": 0.0, "codec_passes": 0}
-        c0 = dict(eng.counters)
+        c0 = {k: sum(e.counters[k] for e in cengs) for k in eng.counters}
         t1 = time.time()
-        st8 = {"n": 0, "buf": 0, "tokens": 0, "lens": np.zeros(B, dtype=np.int32), "wavs": None, "busy": False}
+        st8 = [{"n": 0, "buf": 0, "lens": np.zeros(B, dtype=np.int32), "wavs": None, "busy": False} for _ in cengs]
+        which = {id(e): k for k, e in enumerate(cengs)}
+        tokens = [0]
 
         def ptr(x, row):
             return x[row:row + 1].ctypes.data if emu_lib else x[row:row + 1].data_ptr()
 
-        def flush(nrows):
-            if st8["busy"]:
-                codec.sync()                                  # the previous pass has left the codec engine's pinned output buffer
-            cb = stage_codes[st8["buf"]]
-            wv = codec.decode_device(cb.ctypes.data if emu_lib else cb.data_ptr(), N_max, st8["lens"][:nrows].copy(), producer_stream=eng.stream())
-            st8["busy"], st8["wavs"] = True, wv
+        def flush(k, nrows):
+            s8 = st8[k]
+            if s8["busy"]:
+                ccodecs[k].sync()                             # the previous pass has left this codec engine's pinned output buffer
+            cb = stage_codes[k][s8["buf"]]
+            wv = ccodecs[k].decode_device(cb.ctypes.data if emu_lib else cb.data_ptr(), N_max, s8["lens"][:nrows].copy(), producer_stream=cengs[k].stream())
+            s8["busy"], s8["wavs"] = True, wv
             ph["codec_passes"] += 1
-            st8["buf"] ^= 1
-            st8["n"] = 0
+            s8["buf"] ^= 1
+            s8["n"] = 0
 
-        def hook(i, slot, n_new):
+        def hook(i, slot, n_new, e=eng):
             assert n_new == int(r_glen[i]), "continuous run did not produce the expected tokens"
-            st8["tokens"] += n_new
+            tokens[0] += n_new
             if codec is None:
                 return
-            row = st8["n"]
-            eng.export_codes([slot], 0, n_codes, ptr(stage_codes[st8["buf"]], row), N_max, ptr(stage_lens[st8["buf"]], row), modulo=True)
-            st8["lens"][row] = n_new
-            st8["n"] = row + 1
-            if st8["n"] == B:
-                flush(B)
+            k = which[id(e)]
+            s8 = st8[k]
+            row = s8["n"]
+            e.export_codes([slot], 0, n_codes, ptr(stage_codes[k][s8["buf"]], row), N_max, ptr(stage_lens[k][s8["buf"]], row), modulo=True)
+            s8["lens"][row] = n_new
+            s8["n"] = row + 1
+            if s8["n"] == B:
+                flush(k, B)
 
-        eng.generate(r_prompts, r_samp, steps_per_poll=int(os.environ.get("NTTS_BENCH_POLL", "4")), prefill_token_budget=a.prefill_chunk * S,
-                     min_admit=int(os.environ.get("NTTS_BENCH_MIN_ADMIT", "24")), on_finished=hook,
-                     run_ahead=os.environ.get("NTTS_BENCH_RUN_AHEAD", "1") != "0")
+        kw = dict(steps_per_poll=int(os.environ.get("NTTS_BENCH_POLL", "4")), prefill_token_budget=a.prefill_chunk * S,
+                  min_admit=int(os.environ.get("NTTS_BENCH_MIN_ADMIT", "24")), on_finished=hook,
+                  run_ahead=os.environ.get("NTTS_BENCH_RUN_AHEAD", "1") != "0")
+        (gangc or eng).generate(r_prompts, r_samp, **kw)
         ph["generate_wall"] = (time.time() - t1) * 1e3
         t1 = time.time()
         wavs = None
         if codec is not None:
-            if st8["n"]:
-                flush(st8["n"])
-            codec.sync()
-            wavs = st8["wavs"][:1, :4000].copy() if st8["wavs"] is not None else None
+            for k, s8 in enumerate(st8):
+                if s8["n"]:
+                    flush(k, s8["n"])
+            for k, s8 in enumerate(st8):
+                ccodecs[k].sync()
+                if s8["wavs"] is not None:
+                    wavs = s8["wavs"][:1, :4000].copy()
         else:
-            eng.sync()
+            for e in cengs:
+                e.sync()
         ph["codec_tail_wall"] = (time.time() - t1) * 1e3
-        cont_tokens[0] = st8["tokens"]
-        assert st8["tokens"] == int(r_glen.sum())
-        ph.update({k: eng.counters[k] - c0[k] for k in c0})       # scheduler diagnostics: decode steps issued, prompt passes and their sizes
-        ph["slot_occupancy"] = st8["tokens"] / max(1, ph["decode_steps"] * B)
+        cont_tokens[0] = tokens[0]
+        assert tokens[0] == int(r_glen.sum())
+        ph.update({k: sum(e.counters[k] for e in cengs) - c0[k] for k in c0})       # scheduler diagnostics: decode steps issued, prompt passes and their sizes
+        ph["slot_occupancy"] = tokens[0] / max(1, ph["decode_steps"] * B)
         return ph, None, wavs
 
     pending = []                                          # codec passes in flight: (codec engine, the lens buffer its export filled)
     pstate = {"cur": 0, "ready": [0, 0]}                  # pipelined static mode: whose turn it is, how many prefilled batches each gang holds
     async_codec = os.environ.get("NTTS_BENCH_ASYNC_CODEC", "1") != "0"
-    gangs = [list(range(0, G)), list(range(G, 2 * G))] if pipe else [[0], [0]]     # engine indices
+    gangs = ([list(range(0, G)), list(range(G, 2 * G))] if NG == 2 else [list(range(G)), list(range(G))]) if pipe else [[0], [0]]     # engine indices
 
     def finish_pending():
         """Wait for the codec passes enqueued by the previous step (each is ordered behind its batch's decode loop and code export, so
@@ -550,6 +584,43 @@ def main():
         ph["host_wall_total"] = (tw[4] - tw[0]) * 1e3
         return ph, None, wavs
 
+    def gang_step_single(nb, nb_next):
+        """--gangs 1: the one gang's `nb` batches, phase after phase, every engine on its own lane: [prompt passes side by side] (enqueued
+        at the end of the previous step, behind its codec passes) [decode chains side by side] [export + codec passes side by side]."""
+        cur = engs[:nb]
+        ph = {}
+        tw = [time.time()]
+        each = []
+        for e in cur[pstate["ready"][0]:]:
+            each += prefill_all(e)
+        ph["host_wall_prefill_each"] = each
+        tw.append(time.time())
+        decode_gang(cur, N - 1)
+        tw.append(time.time())
+        wavs = None
+        if codec is not None:
+            finish_pending()                                        # the previous step's waveforms have left the pinned buffers (enqueued a whole decode phase ago)
+            for j, e in enumerate(cur):
+                e.export_codes(list(range(B)), 0, n_codes, codes_ptrs[j], N, lens_ptrs[j], modulo=True)
+                wavs = codecs[j].decode_device(codes_ptrs[j], N, np.full(B, N, dtype=np.int32), producer_stream=e.stream())
+                pending.append((codecs[j], lens_bufs[j]))
+        for e in cur:
+            st, n_new = e.poll()                                    # blocking: this batch's decode (+ export) done
+            assert (n_new == N).all() and (st == 2).all(), "bench run did not produce the expected tokens"
+        tw.append(time.time())
+        for e in cur:
+            e.release_many(list(range(B)))
+        for e in engs[:nb_next]:
+            prefill_all(e)                                         # the next step's prompt passes, behind this step's codec passes on each lane
+        pstate["ready"][0] = nb_next
+        tw.append(time.time())
+        ph["host_wall_prefill_calls"] = (tw[1] - tw[0]) * 1e3
+        ph["host_wall_decode_call"] = (tw[2] - tw[1]) * 1e3
+        ph["host_wall_wait_and_codec"] = (tw[3] - tw[2]) * 1e3
+        ph["host_wall_release"] = (tw[4] - tw[3]) * 1e3
+        ph["host_wall_total"] = (tw[4] - tw[0]) * 1e3
+        return ph, None, wavs
+
     def run_pipelined(K):
         """K batches through the two-gang pipeline; returns per-gang-step [batches, host wall ms, phases]."""
         walls = []
@@ -558,7 +629,7 @@ def main():
             nb = min(G, K - done)
             nb_next = min(G, K - done - nb)
             ts = time.time()
-            ph_t = gang_step(nb, nb_next)[0]
+            ph_t = (gang_step if NG == 2 else gang_step_single)(nb, nb_next)[0]
             walls.append((nb, round((time.time() - ts) * 1e3, 2), ph_t))
             done += nb
         return walls
@@ -568,7 +639,7 @@ def main():
         assert collect or not pipe, "pipelined static mode runs through run_pipelined()"
         if pipe:                                                     # the untimed phase split runs serially on engine 0: the pipeline is drained
             finish_pending()                                         # (run_pipelined's last gang starts no further batch)
-            assert pstate["ready"] == [0, 0]
+            assert pstate["ready"] == [0, 0], pstate
             pstate["cur"] = 0
         ph = {"prefill": 0.0, "decode": 0.0, "codec": 0.0, "handoff_host": 0.0, "codec_call_wall": 0.0}
         tw = [time.time()]                                   # host wall-clock stamps (reported as phase_ms.host_wall_*)
@@ -728,6 +799,27 @@ def main():
         eng.decode(8)
         eng.sync()
         step_ms = eng.last_timing()[1] / 8
+        # the same step with the gang's other engines decoding beside it (what the timed region runs): G chains at the same context,
+        # step graphs replayed alternately; wall time of 16 steps each over G x 16 (HIP events see one stream, the chains run on G)
+        gang_step_ms = None
+        if pipe and G > 1:
+            for e2 in engs[1:G]:
+                for c in range(0, B, a.prefill_chunk):
+                    n = min(a.prefill_chunk, B - c)
+                    e2.prefill(prompts[c:c + n], list(range(c, c + n)), samps[c:c + n] if samps else [samp] * n)
+                e2.decode(N // 2 + 8)
+            for e2 in engs[:G]:
+                e2.sync()
+            decode_gang(engs[:G], 2)
+            for e2 in engs[:G]:
+                e2.sync()
+            tg = time.perf_counter()
+            decode_gang(engs[:G], 16)
+            for e2 in engs[:G]:
+                e2.sync()
+            gang_step_ms = (time.perf_counter() - tg) * 1e3 / (16 * G)
+            for e2 in engs[1:G]:
+                e2.release_many(list(range(B)))
         rows = []
         for k, name in enumerate(_hip.BackboneEngine.KERNELS):
             ms, nbytes, nl = eng.time_kernel(k, 48)   # 2 sweeps over the 24 layers: HBM-cold, like the step
@@ -779,6 +871,11 @@ def main():
                 "alg_bytes_per_launch": nbytes, "launches_per_step": nl,
                 # the quantity BASELINE's target is stated on ("decode step at >= 60 % of the HBM roofline"): the WHOLE step, not its best kernel
                 "step_frac": step_frac, "step_ms": step_ms, "step_alg_bytes": step_bytes,
+                # ... and the step as the timed region runs it: G engines' chains side by side (each chain's algorithmic bytes counted
+                # in full, the weights too -- every chain streams them, the second and third find most of a layer in the memory-side cache)
+                "gang_step": ({"chains": G, "ms_per_256_row_step": gang_step_ms, "frac_of_hbm_peak": step_bytes / (gang_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                               "measured": "host wall clock over 16 alternately replayed steps per engine at context ~S + N/2 + 10"}
+                              if gang_step_ms else None),
                 "dominant_choice": choice,
                 "pmc_per_kernel": pmc or None,
                 "rocprof": rocprof,
@@ -786,7 +883,9 @@ def main():
                                 "GBps": r[3] / (r[2] * 1e-3) / 1e9, "frac": r[3] / (r[2] * 1e-3) / 1e9 / HBM_PEAK_GBPS} for r in rows]}
         step_info = {"ms": step_ms, "alg_bytes": step_bytes, "achieved_GBps": step_bytes / (step_ms * 1e-3) / 1e9,
                      "frac_of_hbm_peak": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                     "sum_of_isolated_kernels_ms": sum(r[0] for r in rows)}
+                     "sum_of_isolated_kernels_ms": sum(r[0] for r in rows),
+                     "gang": ({"chains": G, "ms_per_256_row_step": gang_step_ms, "achieved_GBps": step_bytes / (gang_step_ms * 1e-3) / 1e9,
+                               "frac_of_hbm_peak": step_bytes / (gang_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS} if gang_step_ms else None)}
         for s in range(B):
             eng.release(s)
     cpu = None
@@ -808,15 +907,16 @@ def main():
         else:
             workload = (f"NeuTTS-Air bf16 {world}xMI355X batch={B} synthetic prompts per GPU, {S} prefill / {N} decode tokens, "
                         f"STATIC batch (all {B} slots of the continuous-batching engine filled at once, every utterance {N} tokens; the ragged "
-                        f"scheduler line is --mode continuous)" + ((f", {G} batches decoded side by side on {G} {B}-slot engines (graph replays alternated, one stream each), consecutive gangs pipelined ({2 * G} engines)" if G > 1 else ", consecutive batches pipelined over two engines") if pipe else "") + f" + hipGraph decode (BASELINE.json configs[{2 if world == 1 else 3}])")
+                        f"scheduler line is --mode continuous)" + ((f", {G} batches at a time on {G} {B}-slot engines reading ONE copy of the weights: their prompt passes, decode chains (step graphs replayed alternately, one stream = one hardware queue each) and codec passes side by side" + (f", two such gangs taking turns ({2 * G} engines)" if NG == 2 else "") if G > 1 else ", consecutive batches pipelined over two engines") if pipe else "") + f" + hipGraph decode (BASELINE.json configs[{2 if world == 1 else 3}])")
         workload += ", sampling as the reference calls generate (do_sample, top_k=50, temperature=1.0, seeded)" if a.sample else ", greedy"
         if strm:
             workload = (f"STREAM mode: {B} concurrent infer_stream utterances per GPU (27-frame windows every 25 tokens, 0.5 s chunks, "
                         f"ref:neutts/neutts.py:401-465), codec pass of chunk k on the codec engine's stream beside the decode graph of chunk k + 1; "
                         + workload)
         if cont:
-            workload = (f"CONTINUOUS mode (not BASELINE's static shape): {R} ragged requests per GPU through {B} decode slots, prompts "
-                        f"{int(S * 0.7)}-{int(S * 1.3)} tokens, {int(N * 0.6)}-{int(N * 1.4)} generated tokens each, slots recycled as utterances finish; "
+            workload = (f"CONTINUOUS mode (not BASELINE's static shape): {R} ragged requests per GPU through "
+                        + (f"{Gc} engines of {B} decode slots each (one arena, schedulers advanced in turn, decode chains side by side), prompts " if Gc > 1 else f"{B} decode slots, prompts ")
+                        + f"{int(S * 0.7)}-{int(S * 1.3)} tokens, {int(N * 0.6)}-{int(N * 1.4)} generated tokens each, slots recycled as utterances finish; "
                         + workload)
         rec = {
             "metric": "codec-tokens/s", "value": value, "unit": "codec-tokens/s", "n_gpus": world, "steps": a.steps,
@@ -830,15 +930,17 @@ def main():
             "rtf": dt / (tokens / 50.0),
             "phase_ms": ph, "step_wall_ms": step_wall, "step_host_wall_ms": step_host,
             "roofline": roof, "decode_step": step_info, "cpu_baseline": cpu,
-            "timed_region": (f"warm_up() before timing; {2 * G} backbone engines of {B} slots in two gangs of {G}, one launching thread: a gang's {G} batches decode side "
-                             f"by side (their step graphs replayed alternately, each engine on its own stream), gang k + 1's prompt passes are enqueued "
-                             "between gang k's decode graphs, gang k's codec passes + D2H run on the codec engines' streams under "
-                             "gang k + 1's decode; the timed region is self-contained (first gang un-overlapped prompt passes, last gang starts no "
-                             "further batch: K prompt passes, K decode loops, K codec passes, every waveform landed before the clock stops; a step of the "
-                             "contract = one batch); phase_ms is a separate serial pass on ONE engine" if pipe else
+            "timed_region": ((f"warm_up() before timing; {len(engs)} backbone engines of {B} slots on one weight arena, each with a codec engine, on {G} lane streams; one "
+                              f"launching thread; a gang step = {G} batches, one per engine: [prompt passes] [249 decode steps per engine, the engines' step graphs "
+                              f"replayed alternately] [code export + codec pass + D2H per engine]"
+                              + ("; the next gang step's prompt passes are enqueued behind this one's codec passes" if NG == 1 else
+                                 "; two gangs take turns: gang k + 1's prompt passes (one shared stream with the codec passes) between gang k's decode graphs")
+                              + f"; the timed region is self-contained (K prompt passes, K decode loops, K codec passes for --steps K, the last gang step takes "
+                              f"K mod {G} batches if that is not zero, nothing prefetched before the clock starts, every waveform landed before it stops; a "
+                              f"step of the contract = one batch of {B}); phase_ms is a separate serial pass on ONE engine") if pipe else
                              "warm_up() before timing, codec pass + D2H of batch k asynchronous under the prompt pass of batch k + 1 (static mode, one engine)"),
-            "pipeline": {"engines": len(engs), "gang": G, "overlap": "prefill(gang k+1) | decode(gang k: its batches side by side) | codec(gang k-1)",
-                         "decode_head_start_steps": a.pipe_head, "utterances_resident": len(engs) * B} if pipe else None,
+            "pipeline": {"engines": len(engs), "gang": G, "gangs": NG, "overlap": ("prefill x gang | decode x gang (chains side by side) | codec x gang" if NG == 1 else "prefill(gang k+1) | decode(gang k: its batches side by side) | codec(gang k-1)"),
+                         "decode_head_start_steps": a.pipe_head if NG == 2 else None, "utterances_resident": len(engs) * B} if pipe else None,
         }
         if strm:
             rec["stream"] = stream_stats

@@ -329,6 +329,11 @@ int ntts_codec_set_cu_mask(ntts_codec* c, const uint32_t* mask, int32_t n_words)
  * staged by the runtime at a fraction of it).  Plain malloc/free semantics; not tied to an engine. */
 int ntts_host_alloc(size_t bytes, void** out);
 int ntts_host_free(void* p);
+/* (ABI 7) A non-blocking HIP stream on `device` (hipStreamCreateWithFlags) to lend to ntts_backbone_set_stream /
+ * ntts_backbone_set_prefill_stream / ntts_codec_set_stream, for hosts that have no HIP runtime binding of their own (the Python
+ * host creates the lanes of an engine gang with it); destroy drains it first.  No reference counterpart (one utterance, one stream). */
+int ntts_stream_create(int32_t device, void** stream);
+int ntts_stream_destroy(int32_t device, void* stream);
 /* GPU milliseconds (hipEvents) of the most recent decode call, H2D/D2H excluded. */
 int ntts_codec_last_timing(ntts_codec* c, float* ms);
 

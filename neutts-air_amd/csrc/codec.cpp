@@ -576,6 +576,28 @@ extern "C" int ntts_host_alloc(size_t bytes, void** out) {
 }
 extern "C" int ntts_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? NTTS_OK : NTTS_EHIP; }
 
+// A plain non-blocking HIP stream on `device` for callers without a runtime of their own (neutts._hip.EngineGang: the lanes
+// several engines' decode chains and the shared matrix-pass stream run on).  Streams created back to back land in different
+// hardware queues (the runtime assigns the least-loaded of its four).
+extern "C" int ntts_stream_create(int32_t device, void** stream) {
+    if (!stream) return NTTS_EINVAL;
+    hipStream_t st = nullptr;
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+        (void)hipGetLastError();
+        return NTTS_EHIP;
+    }
+    *stream = (void*)st;
+    return NTTS_OK;
+}
+extern "C" int ntts_stream_destroy(int32_t device, void* stream) {
+    if (!stream) return NTTS_OK;
+    if (hipSetDevice(device) != hipSuccess || hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipStreamDestroy((hipStream_t)stream) != hipSuccess) {
+        (void)hipGetLastError();
+        return NTTS_EHIP;
+    }
+    return NTTS_OK;
+}
+
 extern "C" int ntts_codec_last_timing(ntts_codec* c, float* ms) {
     if (!c || !ms) return NTTS_EINVAL;
     *ms = 0;

@@ -156,6 +156,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_encoder_last_timing": (C.c_int, [p, C.POINTER(f32)]),
         "ntts_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(p)]),
         "ntts_host_free": (C.c_int, [p]),
+        "ntts_stream_create": (C.c_int, [i32, C.POINTER(p)]),
+        "ntts_stream_destroy": (C.c_int, [i32, p]),
         "ntts_k_gemm_bf16": (C.c_int, [p, i64, p, p, p, i64, i32, i32, i32, i32]),
         "ntts_k_gemm_probe": (C.c_int, [i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_double)]),
         "ntts_k_rmsnorm_bf16": (C.c_int, [p, p, p, i32, i32, f32]),
@@ -547,6 +549,19 @@ class BackboneEngine:
         on_finished(request_index, slot, n_new): called for every finished request BEFORE its slot is released, INSTEAD of
         copying its ids to the host (that request's entry of the result is then []): the hook of a device-side hand-off
         (ntts_backbone_export_codes enqueued from it is ordered before the slot's re-use)."""
+        it = self.generate_iter(prompts, sampling, steps_per_poll, prefill_token_budget, share_prefix, min_admit, on_finished, run_ahead)
+        while True:
+            try:
+                next(it)
+            except StopIteration as done:
+                return done.value
+
+    def generate_iter(self, prompts: Sequence[Sequence[int]], sampling, steps_per_poll: int = 16,
+                      prefill_token_budget: Optional[int] = None, share_prefix: bool = False, min_admit: int = 1,
+                      on_finished=None, run_ahead: bool = True):
+        """generate() as a generator: yields (None) once per scheduler iteration -- after this engine's next burst and snapshot
+        are enqueued -- and returns generate()'s result as the StopIteration value.  What EngineGang alternates between: while one
+        engine's scheduler waits for its previous snapshot, the other engines' bursts are already queued on their own streams."""
         if isinstance(sampling, Sampling):
             sampling = [sampling] * len(prompts)
         budget = prefill_token_budget or self.cfg.get("max_prefill_tokens", 0) or 16384
@@ -685,6 +700,7 @@ class BackboneEngine:
                     snap_seq += 1
                 elif owner and any(st[s] == 1 for s in owner):
                     self.decode(steps_per_poll)
+                yield None
         finally:
             # an exception (KV pool exhausted, a failed launch, ...) must not leave admitted slots RUNNING with their
             # pages held: the next call would find them busy
@@ -704,6 +720,92 @@ class BackboneEngine:
                     except NeuTTSHipError:
                         pass
         return [r if r is not None else [] for r in results]
+
+
+class EngineGang:
+    """Several BackboneEngines on ONE set of weights, run side by side on one GPU.  A decode step is a chain of 171 dependent
+    launches of 5-20 us each, latency-bound at a quarter of the HBM peak; several such chains on streams of their own fill each
+    other's launch gaps and first round trips (MI355X, 256 rows at context 625: 1.57 ms per step alone, 1.11 / 1.02 / 0.96 ms per
+    256-row step with two / three / four chains).  The gang creates n - 1 twins of `engine` that read its arena
+    (ntts_backbone_share_arena: KV pool, slots, workspaces and step graph per engine, the weights once), gives every engine a lane
+    stream of its own for all of its work -- the HIP runtime multiplexes streams onto FOUR hardware queues (more make it slower), and
+    two chains in one queue run one after the other, so n <= 4 and the lanes are created back to back -- and alternates between the
+    engines' schedulers from the calling thread.  Each request's arithmetic is that of a single engine (same kernels, same
+    slots per engine): ids are identical to BackboneEngine.generate's."""
+
+    def __init__(self, engine: "BackboneEngine", n: int = 4, lanes: bool = True):
+        if n < 1:
+            raise ValueError("an engine gang needs at least one engine")
+        self.engines: List[BackboneEngine] = [engine] + [engine.twin() for _ in range(n - 1)]
+        self.lib, self._device = engine.lib, engine._device
+        self._streams: List[int] = []
+        if lanes and n > 1:
+            for _ in range(n):                           # created back to back: up to four streams land in distinct hardware queues
+                st = C.c_void_p()
+                rc = self.lib.ntts_stream_create(self._device, C.byref(st))
+                if rc != 0:
+                    raise NeuTTSHipError(rc, "ntts_stream_create failed")
+                self._streams.append(st.value)
+            for e, st in zip(self.engines, self._streams):
+                e.set_stream(st)
+
+    def lane(self, k: int) -> Optional[int]:
+        """Engine k's lane stream (lend it to that engine's codec engine too: CodecEngine.set_stream), None without lanes."""
+        return self._streams[k] if self._streams else None
+
+    @property
+    def max_batch(self) -> int:
+        return sum(e.max_batch for e in self.engines)
+
+    def warm_up(self, decode_steps: int = 2):
+        for e in self.engines:
+            e.warm_up(decode_steps)
+
+    def generate(self, prompts: Sequence[Sequence[int]], sampling, on_finished=None, **kw) -> List[List[int]]:
+        """BackboneEngine.generate over the gang: request i goes to engine i % n (prompts of one speaker that follow each other
+        n apart still share their prefix pages inside an engine), the engines' schedulers advance in turn.  on_finished(request
+        index, slot, n_new, engine) -- the engine is passed along for the device-side hand-off.  Returns the new ids in request order."""
+        n = len(self.engines)
+        if isinstance(sampling, Sampling):
+            sampling = [sampling] * len(prompts)
+        parts = [list(range(k, len(prompts), n)) for k in range(n)]
+        its = []
+        for e, idx in zip(self.engines, parts):
+            if not idx:
+                continue
+            hook = None
+            if on_finished is not None:
+                hook = (lambda i, slot, n_new, _e=e, _idx=idx: on_finished(_idx[i], slot, n_new, _e))
+            its.append((idx, e.generate_iter([prompts[i] for i in idx], [sampling[i] for i in idx], on_finished=hook, **kw)))
+        results: List[List[int]] = [[] for _ in prompts]
+        try:
+            while its:
+                for item in list(its):
+                    idx, it = item
+                    try:
+                        next(it)
+                    except StopIteration as done:
+                        for i, r in zip(idx, done.value):
+                            results[i] = r
+                        its.remove(item)
+        finally:
+            for _, it in its:
+                it.close()                                # an exception in one engine: the others release their slots (generate_iter's finally)
+        return results
+
+    def sync(self):
+        for e in self.engines:
+            e.sync()
+
+    def close(self):
+        for e in reversed(self.engines[1:]):
+            e.close()
+        if self._streams:
+            self.engines[0].set_stream(None)
+            for st in self._streams:
+                self.lib.ntts_stream_destroy(self._device, C.c_void_p(st))
+            self._streams = []
+        self.engines = self.engines[:1]
 
 
 class CodecEngine:

@@ -161,6 +161,7 @@ class NeuTTS:
         codec_device="cuda",
         *,
         max_batch: int = 1,
+        engines: int = 1,
         lib_path: Optional[str] = None,
         do_sample: bool = True,
         seed: int = 0,
@@ -191,6 +192,10 @@ class NeuTTS:
         self.phonemizer = None       # created on first use: text front-end is off the hot path
         self._load_backbone(backbone_repo, backbone_device)
         self._load_codec(codec_repo, codec_device)
+        # engines > 1 (serving; the reference runs one utterance at a time): that many backbone engines of `max_batch` slots each on
+        # ONE copy of the weights, their decode chains side by side on the GPU (neutts._hip.EngineGang) -- infer_batch deals its
+        # utterances out over them.  infer / infer_stream stay on the first engine.
+        self.gang = _hip.EngineGang(self.backbone, engines) if engines > 1 else None
 
         try:  # optional watermarker, as the reference (ref:neutts/neutts.py:110-121)
             import perth
@@ -306,7 +311,8 @@ class NeuTTS:
         return wav if self.watermarker is None else self.watermarker.apply_watermark(wav, sample_rate=24_000)
 
     def infer_batch(self, texts: Sequence[str], ref_codes, ref_texts) -> List[np.ndarray]:
-        """Many utterances at once: continuous batching over the engine's decode slots, one codec pass."""
+        """Many utterances at once: continuous batching over the engine's decode slots (over every engine's, with engines > 1),
+        one codec pass."""
         if not isinstance(ref_texts, (list, tuple)):
             ref_texts = [ref_texts] * len(texts)
             ref_codes = [ref_codes] * len(texts)
@@ -365,8 +371,10 @@ class NeuTTS:
         self._seed += 1
         # utterances of one speaker start with the same tokens (chat header + reference-text phones, ref :307,:315-325):
         # the engine keeps one copy of those KV pages and computes only what differs
-        return self.backbone.generate(prompts, [self._sampling(len(p), i) for i, p in enumerate(prompts)],
-                                      share_prefix=len(prompts) > 1)
+        sampling = [self._sampling(len(p), i) for i, p in enumerate(prompts)]
+        if self.gang is not None and len(prompts) > 1:
+            return self.gang.generate(prompts, sampling, share_prefix=True)
+        return self.backbone.generate(prompts, sampling, share_prefix=len(prompts) > 1)
 
     def _ids_to_codes(self, ids: Sequence[int]) -> List[int]:
         """ref :349 (tokenizer.decode) + :276 (regex): keep `<|speech_N|>` tokens, N = id - id(<|speech_0|>)."""

@@ -56,10 +56,10 @@ def test_bench_contract_world2(emu_lib):
         assert k in rec
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
     assert abs(rec["value"] - 2 * 2 * 4 / (rec["ms_per_step"] / 1e3)) < 1e-6 * rec["value"] + 1e-9
-    # static mode decodes two batches side by side (a gang of two engines) and pipelines consecutive gangs (prompt passes of gang
-    # k + 1 beside the decode of gang k); every batch asserts its token counts from the device-exported lengths, so three steps =
-    # a full gang + a gang of one, and the warm-up batch before them went through the other gang's engines and hand-off buffers
-    assert rec["pipeline"]["engines"] == 4 and rec["pipeline"]["gang"] == 2 and rec["steps"] == 3
+    # static mode runs its batches four at a time, one per engine of a gang on one arena (prompt passes, decode chains and codec passes
+    # side by side, phase after phase); every batch asserts its token counts from the device-exported lengths: the three steps are
+    # a gang step of three batches, the warm-up batch before them went through the first engine alone
+    assert rec["pipeline"]["engines"] == 4 and rec["pipeline"]["gang"] == 4 and rec["pipeline"]["gangs"] == 1 and rec["steps"] == 3
 
 
 def test_bench_contract_world8(emu_lib):

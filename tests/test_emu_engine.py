@@ -181,6 +181,21 @@ def test_continuous_batching_ragged_vs_oracle(emu_lib):
     assert seen == {i: len(g) for i, g in enumerate(got)}
     for i, g in enumerate(got):
         assert lens_out[i] == len(g) and codes[i, :len(g)].tolist() == g
+    # the same requests dealt out over a GANG of three engines on one arena (EngineGang: schedulers advanced in turn, decode chains
+    # side by side on lane streams): id for id what one engine gives, hook and all
+    gang = _hip.EngineGang(eng, 3)
+    try:
+        assert gang.max_batch == 3 * eng.max_batch and len({e.arena()[0] for e in gang.engines}) == 1
+        assert gang.generate(prompts, samp, steps_per_poll=3, prefill_token_budget=70) == got
+        seen2 = {}
+
+        def hook2(i, slot, n_new, e):
+            seen2[i] = (n_new, e.read(slot)[0])
+        assert gang.generate(prompts, samp, steps_per_poll=2, prefill_token_budget=70, on_finished=hook2) == [[] for _ in prompts]
+        assert seen2 == {i: (len(g), g) for i, g in enumerate(got)}
+    finally:
+        gang.close()
+    assert eng.generate(prompts, samp, steps_per_poll=3, prefill_token_budget=70) == got     # engine 0 is back on its own stream
 
 
 def test_engine_error_paths(emu_lib):

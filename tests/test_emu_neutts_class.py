@@ -205,6 +205,29 @@ def test_infer_batch_shares_prompt_beginnings_and_matches_single_inference(tts):
         tts.max_context = 120
 
 
+def test_infer_batch_over_an_engine_gang_matches_single_inference(tts):
+    """NeuTTS(engines=n): infer_batch deals its utterances out over n backbone engines on one copy of the weights (EngineGang) -- more
+    utterances than one engine has slots -- and every waveform equals what `infer` gives for that utterance alone."""
+    from neutts import _hip
+    ref_codes = torch.tensor([3, 77, 200, 5, 18, 9], dtype=torch.int32)
+    ref_text = "So I'm live, and every prompt starts like this."
+    texts = ["First.", "Second one.", "And a third.", "Four.", "The fifth utterance."]
+    tts.max_context = 150
+    tts.gang = _hip.EngineGang(tts.backbone, 2)          # what NeuTTS(engines=2) sets up at construction
+    try:
+        batch = tts.infer_batch(texts, ref_codes, ref_text)
+        for e in tts.gang.engines:
+            st = e.kv_stats()
+            assert st["free_pages"] == st["total_pages"]
+        for text, wav in zip(texts, batch):
+            single = tts.infer(text, ref_codes, ref_text)        # (one utterance: the first engine, on its lane stream)
+            assert wav.shape == single.shape and np.array_equal(wav, single)
+    finally:
+        tts.gang.close()
+        tts.gang = None
+        tts.max_context = 120
+
+
 def test_infer_stream_batch_equals_single_streams(tts):
     """Two utterances streamed together: each one's chunks are exactly those of its own `infer_stream` -- the batch runs the DEVICE-side
     stream path (ntts_streams_*: append_codes / gather / codec / cross-fade kernels), the single streams the host loop: bit for bit."""

@@ -308,6 +308,21 @@ def test_continuous_batching_ragged_vs_oracle(lib):
     ch, lh = codes.cpu().numpy(), lens_out.cpu().numpy()
     for i, g in enumerate(got):
         assert lh[i] == len(g) and ch[i, :len(g)].tolist() == g
+    # the same requests dealt out over a GANG of three engines on one arena (EngineGang: schedulers advanced in turn, decode chains
+    # side by side on lane streams): id for id what one engine gives, hook and all
+    gang = _hip.EngineGang(eng, 3)
+    try:
+        assert gang.max_batch == 3 * eng.max_batch and len({e.arena()[0] for e in gang.engines}) == 1
+        assert gang.generate(prompts, samp, steps_per_poll=5, prefill_token_budget=150) == got
+        seen2 = {}
+
+        def hook2(i, slot, n_new, e):
+            seen2[i] = (n_new, e.read(slot)[0])
+        assert gang.generate(prompts, samp, steps_per_poll=2, prefill_token_budget=150, on_finished=hook2) == [[] for _ in prompts]
+        assert seen2 == {i: (len(g), g) for i, g in enumerate(got)}
+    finally:
+        gang.close()
+    assert eng.generate(prompts, samp, steps_per_poll=5, prefill_token_budget=150) == got     # engine 0 is back on its own stream
 
 
 @pytest.fixture(scope="module")
@@ -479,6 +494,45 @@ def test_air_walk8_free_running_exact_in_a_full_batch256_engine(lib):
             assert rows[s] == rows[u], (u, s)
     print(f"batch 256: 8 x {N} free-running ids equal to transformers', distinct ids per utterance: {[len(set(rows[u])) for u in range(8)]}")
     eng.close()
+
+
+def test_air_walk8_three_engines_side_by_side_exact(lib):
+    """bench.py's static schedule at BASELINE's shape: THREE 256-slot engines on one arena (EngineGang: ntts_backbone_share_arena, a lane
+    stream per engine), their 249 step graphs replayed ALTERNATELY so that the three decode
+    chains run side by side on the GPU, the third engine's prompt passes enqueued while the first two already decode.  768 free-running
+    utterances x 250 ids, each id for id transformers' run of its prompt (engine e, slot s runs utterance (s + 3 e) % 8), no tie clause."""
+    z, cfg, w = load_fixture("backbone_air_walk8")
+    S, N, eos = int(z["s_len"]), int(z["n_new"]), int(z["eos"])
+    eng = make_engine(cfg, w, lib, max_batch=256, max_context=768, max_prefill_tokens=64 * S, bf16_upload=True)
+    gang = _hip.EngineGang(eng, 3)
+    samp = _hip.Sampling(max_length=S + N, min_new_tokens=N, eos_token_id=eos, do_sample=False)
+    prompts = [br.synthetic_prompt(cfg, u, S) for u in range(8)]
+
+    def fill(k):
+        for c in range(0, 256, 64):
+            gang.engines[k].prefill([prompts[(s + 3 * k) % 8] for s in range(c, c + 64)], list(range(c, c + 64)), [samp] * 64)
+    try:
+        fill(0)
+        fill(1)
+        for _ in range(40):                              # two chains side by side ...
+            gang.engines[0].decode(1)
+            gang.engines[1].decode(1)
+        fill(2)                                          # ... the third engine's prompt passes (on its own lane) beside them ...
+        for j in range(N - 1):                           # ... then three
+            for k, e in enumerate(gang.engines):
+                if k < 2 and j >= N - 1 - 40:
+                    continue
+                e.decode(1)
+        for k, e in enumerate(gang.engines):
+            rows = [e.read(s)[0] for s in range(256)]
+            for s in range(256):
+                if s < 8:
+                    assert_walk_exact(rows[s], z[f"bf16_ids_{(s + 3 * k) % 8}"].tolist())
+                else:
+                    assert rows[s] == rows[s % 8], (k, s)
+    finally:
+        gang.close()
+        eng.close()
 
 
 @pytest.mark.parametrize("max_batch", [1, 8, 32])

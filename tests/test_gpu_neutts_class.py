@@ -30,6 +30,7 @@ test_decode_without_speech_tokens_raises = cases.test_decode_without_speech_toke
 test_infer_stream_matches_reference_windowing = cases.test_infer_stream_matches_reference_windowing
 test_infer_batch_shares_prompt_beginnings_and_matches_single_inference = \
     cases.test_infer_batch_shares_prompt_beginnings_and_matches_single_inference
+test_infer_batch_over_an_engine_gang_matches_single_inference = cases.test_infer_batch_over_an_engine_gang_matches_single_inference
 test_infer_stream_batch_equals_single_streams = cases.test_infer_stream_batch_equals_single_streams
 test_encode_reference_on_the_encoder_engine = cases.test_encode_reference_on_the_encoder_engine
 
