@@ -799,6 +799,12 @@ def main():
         eng.decode(8)
         eng.sync()
         step_ms = eng.last_timing()[1] / 8
+        rows = []
+        for k, name in enumerate(_hip.BackboneEngine.KERNELS):
+            ms, nbytes, nl = eng.time_kernel(k, 48)   # 2 sweeps over the 24 layers: HBM-cold, like the step
+            rows.append((ms * nl, name, ms, nbytes, nl))
+            log(f"[roofline] {name:24s} {ms * 1e3:8.1f} us/launch x {nl:3d} = {ms * nl:7.3f} ms/step   "
+                f"{nbytes / 1e6:9.2f} MB/launch   {nbytes / (ms * 1e-3) / 1e9:7.0f} GB/s")
         # the same step with the gang's other engines decoding beside it (what the timed region runs): G chains at the same context,
         # step graphs replayed alternately; wall time of 16 steps each over G x 16 (HIP events see one stream, the chains run on G)
         gang_step_ms = None
@@ -820,12 +826,6 @@ def main():
             gang_step_ms = (time.perf_counter() - tg) * 1e3 / (16 * G)
             for e2 in engs[1:G]:
                 e2.release_many(list(range(B)))
-        rows = []
-        for k, name in enumerate(_hip.BackboneEngine.KERNELS):
-            ms, nbytes, nl = eng.time_kernel(k, 48)   # 2 sweeps over the 24 layers: HBM-cold, like the step
-            rows.append((ms * nl, name, ms, nbytes, nl))
-            log(f"[roofline] {name:24s} {ms * 1e3:8.1f} us/launch x {nl:3d} = {ms * nl:7.3f} ms/step   "
-                f"{nbytes / 1e6:9.2f} MB/launch   {nbytes / (ms * 1e-3) / 1e9:7.0f} GB/s")
         rows.sort(reverse=True)
         live = {r[1]: (r[2], r[3], r[4]) for r in rows}
         std_cfg = not nano and B == 256 and S == 500          # the configuration the committed rocprofv3 / PMC passes were taken on
