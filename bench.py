@@ -808,6 +808,7 @@ def main():
         # the same step with the gang's other engines decoding beside it (what the timed region runs): G chains at the same context,
         # step graphs replayed alternately; wall time of 16 steps each over G x 16 (HIP events see one stream, the chains run on G)
         gang_step_ms = None
+        side = {}
         if pipe and G > 1:
             for e2 in engs[1:G]:
                 for c in range(0, B, a.prefill_chunk):
@@ -824,6 +825,27 @@ def main():
             for e2 in engs[:G]:
                 e2.sync()
             gang_step_ms = (time.perf_counter() - tg) * 1e3 / (16 * G)
+            # ... and the dominant kernels replayed on all G engines AT THE SAME TIME (one host thread per engine, ctypes releases the GIL;
+            # rocprofv3's kernel trace serialises the chains, HIP events per stream do not): per-launch time under G-way contention and
+            # the bytes per second the G launches move together -- what the kernel delivers inside the gang's decode phase
+            import threading
+            for k, name in enumerate(_hip.BackboneEngine.KERNELS):
+                if emu_lib or name not in ("attn_decode_kernel", "gemm_gate_up_silu", "gemm_down_splitk", "gemm_o_proj_splitk", "gemm_qkv"):
+                    continue                              # (the SIMT emulator runs one launch at a time)
+                res = [None] * G
+                bar = threading.Barrier(G)
+
+                def run_k(j, k=k):
+                    bar.wait()
+                    res[j] = engs[j].time_kernel(k, 240)
+                th = [threading.Thread(target=run_k, args=(j,)) for j in range(G)]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join()
+                side[name] = {"us_per_launch": [round(r[0] * 1e3, 2) for r in res],
+                              "GBps_total": sum(r[1] / (r[0] * 1e-3) / 1e9 for r in res),
+                              "frac_of_hbm_peak_total": sum(r[1] / (r[0] * 1e-3) / 1e9 for r in res) / HBM_PEAK_GBPS}
             for e2 in engs[1:G]:
                 e2.release_many(list(range(B)))
         rows.sort(reverse=True)
@@ -874,7 +896,9 @@ def main():
                 # ... and the step as the timed region runs it: G engines' chains side by side (each chain's algorithmic bytes counted
                 # in full, the weights too -- every chain streams them, the second and third find most of a layer in the memory-side cache)
                 "gang_step": ({"chains": G, "ms_per_256_row_step": gang_step_ms, "frac_of_hbm_peak": step_bytes / (gang_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                               "measured": "host wall clock over 16 alternately replayed steps per engine at context ~S + N/2 + 10"}
+                               "measured": "host wall clock over 16 alternately replayed steps per engine at context ~S + N/2 + 10",
+                               # the step's kernels launched on all G engines at the same time: [us per launch on each engine], bytes/s of the G launches together
+                               "kernels_side_by_side": side or None}
                               if gang_step_ms else None),
                 "dominant_choice": choice,
                 "pmc_per_kernel": pmc or None,
