@@ -311,6 +311,8 @@ int ntts_codec_decode(ntts_codec* c, int32_t n, const int32_t* codes, const int3
  * returns once everything is enqueued; ntts_codec_sync() waits for it.  SURVEY.md 8b: device pointers + caller stream. */
 int ntts_codec_decode_dev(ntts_codec* c, int32_t n, const int32_t* codes_dev, int32_t codes_stride, const int32_t* lens,
                           float* wav_out, int64_t wav_stride, int32_t wav_on_device, void* producer_stream);
+/* Waits for the engine's stream; on a stream lent with ntts_codec_set_stream: for the most recent asynchronous pass and its hand-over
+ * only (an event behind them), not for what the caller enqueued on that stream afterwards. */
 int ntts_codec_sync(ntts_codec* c);
 /* ABI 6.  Test taps (blocking), like ntts_encoder_read_stage: with keep_stages != 0 every decode call keeps the fp32 residual stream after
  * the stages of hf:models/xcodec2/modeling_xcodec2.py:838-862 -- 0 embed (fc + k = 7 conv :839-841), 1 prior_net (:845), 2 the transformer

@@ -49,6 +49,8 @@ struct ntts_codec {
     size_t wav_cap = 0;
     hipEvent_t ev[2]{};
     hipEvent_t ev_in = nullptr;   // orders a pass behind the stream that produced its device-side codes
+    hipEvent_t ev_done = nullptr; // behind the asynchronous hand-over of the most recent pass (what ntts_codec_sync waits for on a lent stream)
+    bool have_done = false;
     bool have_time = false;
     bool gn_reg = true;          // GroupNorm with the utterance slice in registers when it fits (NTTS_CODEC_GN_REG=0: the two-pass kernel)
     // per-stage taps of the residual stream (ntts_codec_set_debug / ntts_codec_read_stage: the error-budget tests): fp32 [4][max_rows][H]
@@ -92,6 +94,7 @@ extern "C" void ntts_codec_destroy(ntts_codec* c) {
     for (auto& e : c->ev)
         if (e) hipEventDestroy(e);
     if (c->ev_in) hipEventDestroy(c->ev_in);
+    if (c->ev_done) hipEventDestroy(c->ev_done);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -125,6 +128,7 @@ extern "C" int ntts_codec_create(const ntts_codec_config* cf, int device, ntts_c
     }
     c->stream = c->own_stream;
     hipEventCreate(&c->ev[0]); hipEventCreate(&c->ev[1]); hipEventCreate(&c->ev_in);
+    hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
     const size_t R = c->max_rows, H = c->H;
     const int npages_max = (cf->max_frames + kPage - 1) / kPage;
     const size_t max_utts = R / (1 + 2 * kPadRows) + 1;
@@ -483,6 +487,8 @@ static int codec_decode_impl(ntts_codec* c, int32_t n, const int32_t* codes, con
     else
         CHIP(c, hipMemcpy2DAsync(wav_out, (size_t)wav_stride * sizeof(float), c->wav, (size_t)hop * Tmax * sizeof(float),
                                  (size_t)hop * Tmax * sizeof(float), n, kind, st));
+    if (c->ev_done && hipEventRecord(c->ev_done, st) == hipSuccess) c->have_done = true;
+    else { (void)hipGetLastError(); c->have_done = false; }
     return NTTS_OK;
 }
 
@@ -524,7 +530,10 @@ extern "C" int ntts_codec_set_stream(ntts_codec* c, void* stream) {
 extern "C" int ntts_codec_sync(ntts_codec* c) {
     if (!c) return NTTS_EINVAL;
     CHIP(c, hipSetDevice(c->device));
-    CHIP(c, hipStreamSynchronize(c->stream));
+    // On a stream the caller lent, wait for the codec's own most recent pass only: the caller may have enqueued a whole decode phase
+    // behind it on the same stream (bench.py's lanes), which is none of this call's business.
+    if (c->stream != c->own_stream && c->have_done) CHIP(c, hipEventSynchronize(c->ev_done));
+    else CHIP(c, hipStreamSynchronize(c->stream));
     CHIP(c, hipGetLastError());
     return NTTS_OK;
 }
