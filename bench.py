@@ -963,6 +963,11 @@ def main():
                               f"K mod {G} batches if that is not zero, nothing prefetched before the clock starts, every waveform landed before it stops; a "
                               f"step of the contract = one batch of {B}); phase_ms is a separate serial pass on ONE engine") if pipe else
                              "warm_up() before timing, codec pass + D2H of batch k asynchronous under the prompt pass of batch k + 1 (static mode, one engine)"),
+            # the same batch through ONE engine, phase after phase (the untimed serial pass behind phase_ms): what a single 256-slot engine
+            # delivers on this box, next to the gang's line above
+            "one_engine_serial": ({"ms_per_batch": ph["prefill"] + ph["decode"] + ph["codec"],
+                                   "codec_tokens_per_s": B * N / ((ph["prefill"] + ph["decode"] + ph["codec"]) * 1e-3)}
+                                  if pipe and all(k in ph for k in ("prefill", "decode", "codec")) and ph["decode"] > 0 else None),
             "pipeline": {"engines": len(engs), "gang": G, "gangs": NG, "overlap": ("prefill x gang | decode x gang (chains side by side) | codec x gang" if NG == 1 else "prefill(gang k+1) | decode(gang k: its batches side by side) | codec(gang k-1)"),
                          "decode_head_start_steps": a.pipe_head if NG == 2 else None, "utterances_resident": len(engs) * B} if pipe else None,
         }

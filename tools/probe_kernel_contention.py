@@ -70,6 +70,31 @@ def main():
         rec["slowdown_x4"] = round(float(np.mean(rec["us_per_launch_x4"])) / rec["us_per_launch_x1"][0], 2)
         print(json.dumps(rec), flush=True)
         out.write(json.dumps(rec) + "\n")
+    # Mixed: ONE engine replays the attention launch while the other three replay a GEMM of the step -- what a chain's attention costs
+    # when the other chains are elsewhere in the layer (and what their GEMMs cost beside it).  The kernel given FEWER launches runs
+    # entirely under the other's, so its figure is the one to read; each pair is run both ways.
+    K = {n: i for i, n in enumerate(_hip.BackboneEngine.KERNELS)}
+    for other in ("gemm_gate_up_silu", "gemm_down_splitk", "gemm_o_proj_splitk", "gemm_qkv", "add_rmsnorm_kernel"):
+        rec = {"mixed": f"attn_decode_kernel on engine 0 | {other} on engines 1-3"}
+        for short in ("attn", "other"):
+            it_a, it_o = (300, 6000) if short == "attn" else (3000, 400)
+            res = [None] * 4
+            bar = threading.Barrier(4)
+
+            def run(j):
+                bar.wait()
+                res[j] = gang.engines[j].time_kernel(K["attn_decode_kernel"] if j == 0 else K[other], it_a if j == 0 else it_o)
+            th = [threading.Thread(target=run, args=(j,)) for j in range(4)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            if short == "attn":
+                rec["attn_us_under_3_others"] = round(res[0][0] * 1e3, 2)
+            else:
+                rec["other_us_x3_beside_1_attn"] = [round(r[0] * 1e3, 2) for r in res[1:]]
+        print(json.dumps(rec), flush=True)
+        out.write(json.dumps(rec) + "\n")
     gang.close()
 
 
