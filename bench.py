@@ -475,7 +475,10 @@ def main():
             if s8["n"] == B:
                 flush(k, B)
 
-        kw = dict(steps_per_poll=int(os.environ.get("NTTS_BENCH_POLL", "4")), prefill_token_budget=a.prefill_chunk * S,
+        # (burst length: 4 steps per poll on one engine, profiles/r02i_sweep_continuous_sched.txt; 2 on a gang -- the engines' bursts are
+        #  enqueued in turn, and the shorter the turn the closer the chains run side by side: 144.5 k at 1-2, 132.0 k at 4, 106.7 k at 8
+        #  steps per poll, profiles/r04s_sweep_continuous_gang_sched.txt)
+        kw = dict(steps_per_poll=int(os.environ.get("NTTS_BENCH_POLL", "2" if Gc > 1 else "4")), prefill_token_budget=a.prefill_chunk * S,
                   min_admit=int(os.environ.get("NTTS_BENCH_MIN_ADMIT", "24")), on_finished=hook,
                   run_ahead=os.environ.get("NTTS_BENCH_RUN_AHEAD", "1") != "0")
         (gangc or eng).generate(r_prompts, r_samp, **kw)
