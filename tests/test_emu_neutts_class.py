@@ -211,7 +211,7 @@ def test_infer_batch_over_an_engine_gang_matches_single_inference(tts):
     from neutts import _hip
     ref_codes = torch.tensor([3, 77, 200, 5, 18, 9], dtype=torch.int32)
     ref_text = "So I'm live, and every prompt starts like this."
-    texts = ["First.", "Second one.", "And a third.", "Four.", "The fifth utterance."]
+    texts = ["First.", "Second one.", "And a third."]
     tts.max_context = 150
     tts.gang = _hip.EngineGang(tts.backbone, 2)          # what NeuTTS(engines=2) sets up at construction
     try:
