@@ -176,16 +176,17 @@ def main():
                          "instead of greedy: radix select + Philox multinomial on the bf16 logits rows")
     ap.add_argument("--requests", type=int, default=None, help="continuous mode: requests per step (default 4 x batch)")
     ap.add_argument("--no-pipeline", action="store_true",
-                    help="static mode: ONE backbone engine, batches strictly one after the other (round-2 shape).  Default: two engines, "
-                         "batch k + 1's prompt pass enqueued before batch k's decode graphs, so the GPU runs them side by side")
+                    help="static mode: ONE backbone engine, batches strictly one after the other (round-2 shape).  Default: a gang of --gang engines "
+                         "on one weight arena, --gang batches in flight at a time")
     ap.add_argument("--pipe-head", type=int, default=100,
-                    help="pipelined static mode: decode steps of batch k enqueued BEFORE batch k + 1's prompt pass (0 = prompt pass first); "
-                         "the prompt pass then runs beside the later, longer-context steps (profiles/r03i_sweep_pipeline_schedule.txt)")
+                    help="--gangs 2 only: decode steps of gang k enqueued BEFORE gang k + 1's prompt passes (0 = prompt passes first); "
+                         "the prompt passes then run beside the later, longer-context steps (profiles/r03i_sweep_pipeline_schedule.txt)")
     ap.add_argument("--gang", type=int, default=4,
-                    help="pipelined static mode: 256-slot engines whose decode graphs are replayed ALTERNATELY from the one launching thread, each on "
-                         "its own stream (one batch per engine): a decode chain is latency-bound (a quarter of the HBM peak), two of them fill each "
-                         "other's launch gaps and first round trips (tools/probe_two_chains.py: 1.57 -> 1.15 ms per 256-row step).  The pipeline "
-                         "holds two gangs (2 x gang engines); 1 = the round-3 pipeline")
+                    help="static and continuous mode: that many engines of --batch slots each, reading ONE copy of the weights, each on a lane "
+                         "stream (= hardware queue) of its own; their step graphs are replayed ALTERNATELY from the one launching thread.  A decode "
+                         "chain is latency-bound (a quarter of the HBM peak alone), four of them fill each other's launch gaps and first round "
+                         "trips (tools/probe_two_chains.py: 1.57 -> 0.96-0.99 ms per 256-row step; the runtime has four hardware queues, more "
+                         "chains than that run one after the other).  1 = one engine (asynchronous codec pass only)")
     ap.add_argument("--gangs", type=int, default=1, choices=[1, 2],
                     help="pipelined static mode: 2 = two gangs take turns (gang k + 1's prompt passes beside gang k's decode steps, prompt and codec "
                          "passes on one shared stream); 1 = ONE gang, every engine on a lane of its own for all of its work: prompt passes, decode "
