@@ -81,6 +81,23 @@ def test_bench_contract_world8(emu_lib):
     assert r.stderr.count("weights received") == 8 and r.stderr.count("weights synthesised and uploaded (rank 0)") == 1
 
 
+def test_bench_two_gangs_taking_turns_emulator(emu_lib):
+    """`bench.py --gang 2 --gangs 2` (the schedule DESIGN.md section 4j measures against the default): two gangs of two engines take turns,
+    gang k + 1's prompt passes enqueued between gang k's decode graphs; five batches = two full gang steps and one of a single batch, every
+    batch's token counts asserted from the device-exported lengths."""
+    import subprocess
+    import sys
+    env = dict(os.environ, NTTS_BENCH_EMU_LIB=emu_lib)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--tiny", "--gang", "2", "--gangs", "2", "--batch", "2", "--prefill", "12",
+                        "--decode", "4", "--prefill-chunk", "2", "--steps", "5", "--warmup", "1", "--no-roofline", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["pipeline"]["engines"] == 4 and rec["pipeline"]["gangs"] == 2
+    assert [nb for nb, _ in rec["step_wall_ms"]] == [2, 2, 1]
+    assert abs(rec["value"] - 2 * 4 / (rec["ms_per_step"] / 1e3)) < 1e-6 * rec["value"] + 1e-9
+
+
 def test_bench_continuous_mode_emulator(emu_lib):
     """`bench.py --mode continuous` end to end on the emulator build: ragged requests through the run-ahead scheduler, every finished
     utterance exported on the "device" from the on_finished hook, one codec pass per `batch` finished utterances + the ragged tail,
