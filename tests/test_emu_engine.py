@@ -193,6 +193,13 @@ def test_continuous_batching_ragged_vs_oracle(emu_lib):
             seen2[i] = (n_new, e.read(slot)[0])
         assert gang.generate(prompts, samp, steps_per_poll=2, prefill_token_budget=70, on_finished=hook2) == [[] for _ in prompts]
         assert seen2 == {i: (len(g), g) for i, g in enumerate(got)}
+        # a request that cannot run (an empty prompt) fails the call; the engines that had already admitted theirs release them
+        with pytest.raises(ValueError):
+            gang.generate(prompts[:4] + [[]], samp, steps_per_poll=3, prefill_token_budget=70)
+        for e in gang.engines:
+            st = e.kv_stats()
+            assert e.free_slots() == e.max_batch and st["free_pages"] == st["total_pages"]
+        assert gang.generate(prompts, samp, prefill_token_budget=70) == got                  # (default burst length of a gang)
     finally:
         gang.close()
     assert eng.generate(prompts, samp, steps_per_poll=3, prefill_token_budget=70) == got     # engine 0 is back on its own stream
