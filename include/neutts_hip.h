@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define NTTS_ABI_VERSION 7
+#define NTTS_ABI_VERSION 8
 
 enum {
     NTTS_OK = 0,
@@ -120,9 +120,18 @@ int ntts_backbone_arena_copy(ntts_backbone* e, void* buf, size_t bytes, int to_a
 /* (ABI 7) A second engine on the SAME weights: `e` (created with the donor's configuration on the donor's device, nothing loaded
  * yet) drops its own arena and reads the finalised donor's; KV pool, slots, workspaces, stream and step graph stay its own.  For
  * several decode chains side by side on one GPU (ref:neutts/neutts.py:338-347 run for more than one batch at a time: each engine
- * replays its own step graph on its own stream, the launching thread alternates between them).  The donor must outlive `e`;
- * weight loads into either engine are refused from then on (NTTS_ESTATE). */
+ * replays its own step graph on its own stream, the launching thread alternates between them).   * weight loads into either engine are refused from then on (NTTS_ESTATE). */
 int ntts_backbone_share_arena(ntts_backbone* e, ntts_backbone* donor);
+
+/* ABI 8.  How many decode chains run side by side on this GPU, this engine's included (an engine gang: `chains` engines on one arena,
+ * each on a lane stream, their step graphs replayed alternately).  The decode step's shape follows it: alone, an engine tiles its
+ * GEMMs to fill the chip by itself (64-row m-blocks, split-K aimed at 224 workgroups, row-block XCD placement); in a gang the
+ * other chains fill the chip and what counts is how many bytes each CU pulls, so o_proj / down_proj take the 256-row tile (a weight
+ * tile passes through a CU's load path once per chain) and the XCD placement is off.  Same arithmetic, same
+ * summation order per output element: ids do not depend on it.  Drops the captured step graph (it is re-captured by the next decode
+ * call).  chains = 1 restores the single-chain shape.  Replaces nothing in the reference (ref:neutts/neutts.py runs one utterance at
+ * a time); the arena is reference-counted since this version: donor and readers may be destroyed in any order. */
+int ntts_backbone_set_gang(ntts_backbone* e, int32_t chains);
 
 /* Sampling contract of one request = the keyword arguments of the reference's generate() call
  * (ref:neutts/neutts.py:338-347). */

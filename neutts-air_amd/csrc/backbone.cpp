@@ -57,7 +57,9 @@ struct ntts_backbone {
     // weights
     bf16_t* arena = nullptr;
     size_t arena_elems = 0;
-    bool arena_shared = false;         // the arena is another engine's (ntts_backbone_share_arena): not freed here
+    bool arena_shared = false;         // the arena is another engine's (ntts_backbone_share_arena)
+    int* arena_refs = nullptr;         // engines that read `arena` (host counter shared by a donor and its readers): the LAST one to be destroyed frees
+                                       // it, in whatever order the caller destroys them (a donor destroyed first left its readers on freed memory)
     bf16_t *embed = nullptr, *final_norm = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
     bf16_t* embed_tm = nullptr;   // the lm_head's weight stream: tile-major copy of the tied embedding, the untied
                                   // "lm_head.weight", or (fp8) the e4m3 bytes of either
@@ -102,6 +104,15 @@ struct ntts_backbone {
     // ---- decode-step shape, fixed at create() from the batch size (every constant below was swept on MI355X; the losing variants and
     //      their knobs are gone -- DESIGN.md section 4 keeps the numbers, the git history the code)
     int ks_o = 1, ks_d = 1;          // split-K of o_proj / down_proj (fp32 slabs reduced by the norm kernel behind them)
+    // "Tall" decode tiles (NTTS_TALL; round 5): ALL rows of a <= 256-row chain in one m-block, so that a weight tile goes through a
+    // CU's load path once per chain instead of once per 64-row (128-row) m-block.  Alone on the chip such a GEMM has a quarter of the
+    // workgroups and loses; in an engine gang (four chains side by side) the other chains fill the CUs and what
+    // counts is the bytes every CU pulls.  bit 0: o_proj, bit 1: down_proj on the 256 x 64 / 8-wave tile; gu_tile picks the gate/up tile.
+    int tall = 0;
+    int gang = 1;                    // decode chains side by side on the GPU, this one included (ntts_backbone_set_gang); the defaults of tall / xcd_affine follow it
+    int tall_env = -1, affine_env = -1;   // NTTS_TALL / NTTS_XCD_AFFINE when set (sweeps, tests): they win over the gang's defaults
+    int gu_tile = 0;                 // gate/up tile (NTTS_GU_TILE): 0 = 128 x 128 / 8 waves / 3 slots (above batch 128; 64 x 64 below), 1 = 256 x 192 / 12 waves / 2 slots,
+                                     // 2 = 256 x 256 / 16 waves / 2 slots, 3 = 128 x 128 / 2 slots (two workgroups per CU)
     // Tile path: the QKV projection with bias, rounding, RoPE and the K append in its epilogue (qkv_rope.h); the attention kernel
     // then has no prologue.  step_meta / rope_rows: the per-step row records that kernel reads (step_meta_kernel, once per step).
     int* step_meta = nullptr;
@@ -208,6 +219,16 @@ static int env_int(const char* name, int dflt) {
     return v && *v ? atoi(v) : dflt;
 }
 
+// The decode step's shape as a function of how many chains share the chip (ntts_backbone_set_gang; measured on MI355X with
+// tools/sweep_gang.py, profiles/r05a_sweep_gang_*: four 256-row chains, ms per 256-row step -- single-chain shape 0.988, XCD placement
+// off 0.970, + o_proj / down_proj on the 256-row tile 0.953; the same tiles ALONE cost the single chain 1.64 -> 1.88 ms).
+static void apply_gang_shape(ntts_backbone* e) {
+    const int B = e->cfg.max_batch;
+    const bool side_by_side = e->gang >= 2 && B > 128 && B <= 256;
+    e->tall = (e->tall_env >= 0 ? e->tall_env : (side_by_side ? 3 : 0)) & 3;
+    e->xcd_affine = e->affine_env >= 0 ? e->affine_env : (B > 128 && !side_by_side ? 7 : 0);
+}
+
 extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, ntts_backbone** out) {
     if (!c || !out) return fail(nullptr, NTTS_EINVAL, "null argument");
     int ndev = 0;
@@ -282,6 +303,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->arena_elems = off;
     CR_HIP(hipMalloc((void**)&e->arena, off * sizeof(bf16_t)));
     CR_HIP(hipMemset(e->arena, 0, off * sizeof(bf16_t)));
+    e->arena_refs = new int(1);
     e->embed = e->arena + o_embed;
     e->embed_tm = e->arena + o_embed_tm;
     if (e->fp8) { e->shead = (float*)(e->arena + o_shead); e->xs_head_dev = (float*)(e->arena + o_xs_head); }
@@ -366,6 +388,11 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     const int max_slabs = 16;
     e->ks_o = std::min(max_slabs, pick_split(H / 64, c->num_heads * 64 / ktile));
     e->ks_d = std::min(max_slabs, pick_split(H / 64, F / ktile));
+    if (int k = env_int("NTTS_KS_O", 0); k > 0) e->ks_o = std::min(std::min(max_slabs, k), c->num_heads * 64 / ktile);
+    if (int k = env_int("NTTS_KS_D", 0); k > 0) e->ks_d = std::min(std::min(max_slabs, k), F / ktile);
+    e->tall_env = env_int("NTTS_TALL", -1);
+    e->gu_tile = env_int("NTTS_GU_TILE", 0);
+    if (e->gu_tile < 0 || e->gu_tile > 3) e->gu_tile = 0;
     e->xl_min_m = env_int("NTTS_XL_MIN_M", 0);
     {   // 0 = every query on the two-sweep kernel; whole pages, at most what the resident kernel holds
         int cap = env_int("NTTS_PF_RES_CAP", kPfResPages * kPage) / kPage * kPage;
@@ -375,7 +402,8 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
         e->pf_deep_cap = dcap < e->pf_res_cap ? e->pf_res_cap : dcap;
     }
     e->xcd_xps = (B == 64 || B == 128 || B == 256 || B == 512) ? 8 / (B / 64) : 0;
-    e->xcd_affine = env_int("NTTS_XCD_AFFINE", B > 128 ? 7 : 0);
+    e->affine_env = env_int("NTTS_XCD_AFFINE", -1);
+    apply_gang_shape(e);
     e->head_tile = env_int("NTTS_HEAD_TILE", B > 128 ? (e->fp8 ? 2 : 4) : B > 64 ? 1 : 0);
     if (e->head_tile != 0 && e->head_tile != 1 && e->head_tile != 2 && e->head_tile != 4) e->head_tile = 1;
     if (e->fp8 && e->head_tile == 4) e->head_tile = 2;          // (the natural-order tile is bf16 only)
@@ -452,7 +480,9 @@ extern "C" void ntts_backbone_destroy(ntts_backbone* e) {
     hipDeviceSynchronize();
     if (e->graph) hipGraphExecDestroy(e->graph);
     if (e->graph_split) hipGraphExecDestroy(e->graph_split);
-    void* bufs[] = {e->arena_shared ? nullptr : e->arena, e->gu_map_gate, e->gu_map_up, e->kv, e->ibuf, e->h_dec, e->xn_dec, e->qkv_dec, e->attn_dec,
+    bool last_reader = true;
+    if (e->arena_refs) { last_reader = --*e->arena_refs == 0; if (last_reader) delete e->arena_refs; }
+    void* bufs[] = {last_reader ? e->arena : nullptr, e->gu_map_gate, e->gu_map_up, e->kv, e->ibuf, e->h_dec, e->xn_dec, e->qkv_dec, e->attn_dec,
                     e->act_dec, e->slabs, e->slabs2, e->h_alt, e->part_val, e->part_idx, e->logits, e->logits_bf16, e->h_pf, e->xn_pf, e->qkv_pf, e->attn_pf,
                     e->o_pf, e->act_pf, e->meta_dev, e->as_scores, e->as_stats, e->as_oslabs, e->step_meta, e->rope_rows};
     for (void* b : bufs)
@@ -602,7 +632,8 @@ extern "C" int ntts_backbone_load_tensor(ntts_backbone* e, const char* name, con
             else if (t == "mlp.down_proj") { dst = w.sd; rows_n = H; }
         }
         if (!dst) return fail(e, NTTS_EINVAL, "unknown tensor '%s'", name);
-        if (cnt != 1 && cnt != rows_n) return fail(e, NTTS_EINVAL, "tensor '%s': %ld values, expected 1 or %ld (one per output channel)", name, cnt, rows_n);
+        if (cnt != 1 && (cnt != rows_n || shape[0] != rows_n))      // [rows] or [rows, 1]; never [1, rows] or a transposed block
+            return fail(e, NTTS_EINVAL, "tensor '%s': %ld values (leading dimension %ld), expected 1 or [%ld] / [%ld, 1] (one per output channel)", name, cnt, ndim ? (long)shape[0] : 0L, rows_n, rows_n);
         DevScratch tmp;
         const float* src = (const float*)data;
         if (!is_device) {
@@ -615,17 +646,27 @@ extern "C" int ntts_backbone_load_tensor(ntts_backbone* e, const char* name, con
         e->loaded.insert(n);
         return NTTS_OK;
     }
+    std::string mark_scale;
+    bool mark_quant = false;
     if (dtype == NTTS_DT_FP8_E4M3) {
         if (!e->fp8) return fail(e, NTTS_EINVAL, "tensor '%s': fp8 bytes for an engine created with weight_dtype = NTTS_W_BF16", name);
         const bool is_matrix = n.size() > 7 && n.compare(n.size() - 7, 7, ".weight") == 0 && (n.find("_proj.weight") != std::string::npos || (n == "lm_head.weight" && !e->tied));
         if (!is_matrix) return fail(e, NTTS_EINVAL, "tensor '%s': only the projection matrices (and an untied lm_head) can be pre-quantised", name);
-        e->needed.insert(n.substr(0, n.size() - 7) + ".weight_scale");     // finalize insists on its scales
+        mark_scale = n.substr(0, n.size() - 7) + ".weight_scale";          // finalize insists on its scales -- once the bytes are stored (stored())
     } else if (dtype != NTTS_DT_F32 && dtype != NTTS_DT_BF16) return fail(e, NTTS_EINVAL, "tensor '%s': dtype must be f32, bf16 or (fp8 model) e4m3 bytes", name);
     else if (e->fp8 && n.size() > 7 && n.compare(n.size() - 7, 7, ".weight") == 0) {
         if (e->loaded.count(n.substr(0, n.size() - 7) + ".weight_scale"))
             return fail(e, NTTS_EINVAL, "tensor '%s': its weight_scale was loaded, so the matrix must come as e4m3 bytes (NTTS_DT_FP8_E4M3)", name);
-        e->quantised_here.insert(n);
+        mark_quant = true;
     }
+    // Bookkeeping of a matrix of the fp8 model, applied only AFTER the tensor passed its shape check and was stored (a load
+    // rejected for its shape used to leave the engine demanding a scale, or refusing one, for a matrix it never stored); a matrix that is
+    // loaded again in the other form takes the other form's marker with it.
+    auto stored = [&](const std::string& as) {
+        e->loaded.insert(as);
+        if (!mark_scale.empty()) { e->needed.insert(mark_scale); e->quantised_here.erase(n); }
+        if (mark_quant) { e->quantised_here.insert(n); e->needed.erase(n.substr(0, n.size() - 7) + ".weight_scale"); }
+    };
     int rc = NTTS_EINVAL;
     const int tm = 1;   // GEMM weights are stored tile-major
     if (n == "model.embed_tokens.weight") {
@@ -650,27 +691,27 @@ extern "C" int ntts_backbone_load_tensor(ntts_backbone* e, const char* name, con
             HIPCHK(e, hipStreamSynchronize(e->stream));
             if (bad) return fail(e, NTTS_EINVAL, "tie_word_embeddings is set but 'lm_head.weight' differs from 'model.embed_tokens.weight' in %u values: "
                                                  "create the engine with tie_word_embeddings = 0 for an untied head", bad);
-            e->loaded.insert(n);
+            stored(n);
             return NTTS_OK;
         }
         rc = put_rows(e, data, dtype, is_device, c.vocab_size, H, e->embed, nullptr);
         if (rc == NTTS_OK && e->tied)   // the tied head's own copy (tile-major and / or fp8)
             rc = put_weight(e, data, dtype, is_device, c.vocab_size, H, e->embed_tm, 0, nullptr, tm, e->fp8 ? e->shead : nullptr);
-        if (rc == NTTS_OK) e->loaded.insert(n);
+        if (rc == NTTS_OK) stored(n);
         return rc;
     }
     if (n == "lm_head.weight") {
         if (!want(c.vocab_size, H)) return bad_shape();
         if (!e->tied) {             // a separate head matrix
             rc = put_weight(e, data, dtype, is_device, c.vocab_size, H, e->embed_tm, 0, nullptr, tm, e->fp8 ? e->shead : nullptr);
-            if (rc == NTTS_OK) e->loaded.insert(n);
+            if (rc == NTTS_OK) stored(n);
             return rc;
         }
         // tied: the tensor may be present in a checkpoint (safetensors of some exporters keep both names) but it must BE the embedding
         if (!e->loaded.count("model.embed_tokens.weight")) {
             rc = put_rows(e, data, dtype, is_device, c.vocab_size, H, e->embed, nullptr);
             if (rc == NTTS_OK) rc = put_weight(e, data, dtype, is_device, c.vocab_size, H, e->embed_tm, 0, nullptr, tm, e->fp8 ? e->shead : nullptr);
-            if (rc == NTTS_OK) { e->head_from_embed = true; e->loaded.insert("lm_head.weight"); }
+            if (rc == NTTS_OK) { e->head_from_embed = true; stored("lm_head.weight"); }
             return rc;
         }
         {
@@ -694,7 +735,7 @@ extern "C" int ntts_backbone_load_tensor(ntts_backbone* e, const char* name, con
             if (bad) return fail(e, NTTS_EINVAL, "tie_word_embeddings is set but 'lm_head.weight' differs from 'model.embed_tokens.weight' in %u values: "
                                                  "create the engine with tie_word_embeddings = 0 for an untied head", bad);
         }
-        e->loaded.insert("lm_head.weight");
+        stored("lm_head.weight");
         return NTTS_OK;
     }
     if (n == "model.norm.weight") {
@@ -726,7 +767,7 @@ extern "C" int ntts_backbone_load_tensor(ntts_backbone* e, const char* name, con
     } else {
         return fail(e, NTTS_EINVAL, "unknown tensor '%s'", name);
     }
-    if (rc == NTTS_OK) e->loaded.insert(n);
+    if (rc == NTTS_OK) stored(n);
     return rc;
 }
 
@@ -827,7 +868,8 @@ extern "C" int ntts_backbone_adopt_arena(ntts_backbone* e) {
 // A second engine on the SAME weights: e gives up its own (still empty) arena and reads the donor's -- weights, scales and the RoPE
 // table are read-only once finalised.  Its KV pool, slot state, workspaces, stream and step graph stay its own.  What running
 // several decode chains side by side needs (two 256-slot engines whose step graphs are replayed alternately: each chain fills the
-// other's launch gaps, and the second chain finds the layer's weights in the memory-side cache).  The donor must outlive e.
+// other's launch gaps, and the second chain finds the layer's weights in the memory-side cache).  Donor and readers may be destroyed in any order: the arena
+// is reference-counted and goes with its last reader.
 extern "C" int ntts_backbone_share_arena(ntts_backbone* e, ntts_backbone* donor) {
     if (!e || !donor || e == donor) return NTTS_EINVAL;
     if (!donor->finalized) return fail(e, NTTS_ESTATE, "share_arena: the donor engine is not finalised");
@@ -849,11 +891,28 @@ extern "C" int ntts_backbone_share_arena(ntts_backbone* e, ntts_backbone* donor)
         mv(w.sqkv); mv(w.so); mv(w.sgu); mv(w.sd); mv(w.xs_dev);
     }
     HIPCHK(e, hipFree(old));
+    delete e->arena_refs;
     e->arena = donor->arena;
+    e->arena_refs = donor->arena_refs;
+    ++*e->arena_refs;
     e->arena_shared = true;
     const int rc = sync_input_scales(e, false);   // fp8: the launches need the input scales on the host
     if (rc) return rc;
     e->finalized = true;
+    return NTTS_OK;
+}
+
+extern "C" int ntts_backbone_set_gang(ntts_backbone* e, int32_t chains) {
+    if (!e) return NTTS_EINVAL;
+    if (chains < 1) return fail(e, NTTS_EINVAL, "set_gang: %d chains", chains);
+    if (chains == e->gang) return NTTS_OK;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));       // the captured step may still be queued
+    e->gang = chains;
+    apply_gang_shape(e);
+    if (e->graph) { hipGraphExecDestroy(e->graph); e->graph = nullptr; }
+    if (e->graph_split) { hipGraphExecDestroy(e->graph_split); e->graph_split = nullptr; }
+    e->graph_tried = e->graph_split_tried = false;    // re-captured with the new launches by the next decode call
     return NTTS_OK;
 }
 
@@ -879,6 +938,13 @@ template <int EPI, int NS = 4>
 static void gemm_skinny(const GemmArgs& a, int ks, hipStream_t st) {
     if (a.wscale) gemm_launch<4, 1, 1, EPI, NS, 0, 64, false, true>(a, ks, st);   // fp8 operands
     else gemm_launch<4, 1, 1, EPI, NS>(a, ks, st);
+}
+
+// 256 x 64 tile, 8 waves (32 x 64 each), 3-slot ring of 40 KB: the whole decode batch of a <= 256-row chain is one m-block (ntts_backbone::tall)
+template <int EPI>
+static void gemm_tall(const GemmArgs& a, int ks, hipStream_t st) {
+    if (a.wscale) gemm_launch<8, 1, 2, EPI, 3, 0, 64, false, true>(a, ks, st);
+    else gemm_launch<8, 1, 2, EPI, 3>(a, ks, st);
 }
 
 template <int EPI>
@@ -987,6 +1053,7 @@ static void k_attn(ntts_backbone* e, int i) {
 static void k_o_proj(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, QD = e->cfg.num_heads * 64;
     GemmArgs a = gemm_args(e, e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->slabs, H, B, H, QD, e->layers[i].so, e->layers[i].xs[1]);
+    if (e->tall & 1) { gemm_tall<EPI_SPLITK>(a, e->ks_o, e->stream); return; }
     if ((e->xcd_affine & 1) && e->xcd_xps) a.xcd_maffine = -1;
     gemm_skinny<EPI_SPLITK>(a, e->ks_o, e->stream);
 }
@@ -999,7 +1066,16 @@ static void k_gate_up(ntts_backbone* e, int i) {
     //  bounds this kernel; profiles/r02h_sweep_gate_up_ring.log)
     // (natural-order gate/up tiles that use more CUs -- 128 x 80 as 244 workgroups of 4 or 8 waves, 128 x 96 as 204 -- measured
     //  15.5 / 13.7 / 14.1 vs 13.5 us and were removed: profiles/r02k_sweep_lpt_head_gu_tiles.log)
-    if (e->gu_128) {   // 128 x 128, 8 waves
+    if (e->gu_tile == 1) {          // 256 x 192, 12 waves
+        if (e->fp8) gemm_launch<4, 3, 4, EPI_SILU_MUL, 2, 0, 64, false, true>(gu, 1, e->stream);
+        else gemm_launch<4, 3, 4, EPI_SILU_MUL, 2>(gu, 1, e->stream);
+    } else if (e->gu_tile == 2) {   // 256 x 256, 16 waves
+        if (e->fp8) gemm_launch<4, 4, 4, EPI_SILU_MUL, 2, 0, 64, false, true>(gu, 1, e->stream);
+        else gemm_launch<4, 4, 4, EPI_SILU_MUL, 2>(gu, 1, e->stream);
+    } else if (e->gu_tile == 3) {   // 128 x 128, 8 waves, 2 slots
+        if (e->fp8) gemm_launch<4, 2, 2, EPI_SILU_MUL, 2, 0, 64, false, true>(gu, 1, e->stream);
+        else gemm_launch<4, 2, 2, EPI_SILU_MUL, 2>(gu, 1, e->stream);
+    } else if (e->gu_128) {   // 128 x 128, 8 waves
         if (e->fp8) gemm_launch<4, 2, 2, EPI_SILU_MUL, 3, 0, 64, false, true>(gu, 1, e->stream);
         else gemm_launch<4, 2, 2, EPI_SILU_MUL, 3>(gu, 1, e->stream);
     } else gemm_skinny<EPI_SILU_MUL, 3>(gu, 1, e->stream);
@@ -1008,6 +1084,7 @@ static void k_gate_up(ntts_backbone* e, int i) {
 static void k_down(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, F = e->F;
     GemmArgs a = gemm_args(e, e->act_dec, F, e->layers[i].wd, F, nullptr, e->slabs, H, B, H, F, e->layers[i].sd, e->layers[i].xs[3]);
+    if (e->tall & 2) { gemm_tall<EPI_SPLITK>(a, e->ks_d, e->stream); return; }
     a.xcd_nsplit = -1;   // one K slice per XCD (pair) unless the row-block placement below applies (FETCH 15.0 -> 6.8 MB per launch, profiles/r02f_*)
     if ((e->xcd_affine & 2) && e->xcd_xps) a.xcd_maffine = -1;
     gemm_skinny<EPI_SPLITK>(a, e->ks_d, e->stream);

@@ -46,6 +46,13 @@ struct ntts_codec {
     bf16_t *xa = nullptr, *xb = nullptr, *qkv = nullptr, *act = nullptr, *vt = nullptr, *s3 = nullptr;
     int* meta = nullptr;
     size_t meta_cap = 0;
+    // page-locked staging ring of the meta block (as backbone.cpp upload_meta): the copy from a pageable vector needed a stream-wide
+    // synchronisation, which on a LENT stream (an engine gang's lane with a whole decode phase queued) blocked the launching thread
+    static constexpr int kMetaStages = 2;
+    int* meta_host[kMetaStages] = {nullptr, nullptr};
+    hipEvent_t meta_ev[kMetaStages] = {nullptr, nullptr};
+    bool meta_used[kMetaStages] = {false, false};
+    int meta_next = 0;
     size_t wav_cap = 0;
     hipEvent_t ev[2]{};
     hipEvent_t ev_in = nullptr;   // orders a pass behind the stream that produced its device-side codes
@@ -95,6 +102,10 @@ extern "C" void ntts_codec_destroy(ntts_codec* c) {
         if (e) hipEventDestroy(e);
     if (c->ev_in) hipEventDestroy(c->ev_in);
     if (c->ev_done) hipEventDestroy(c->ev_done);
+    for (int i = 0; i < ntts_codec::kMetaStages; ++i) {
+        if (c->meta_host[i]) hipHostFree(c->meta_host[i]);
+        if (c->meta_ev[i]) hipEventDestroy(c->meta_ev[i]);
+    }
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -142,6 +153,9 @@ extern "C" int ntts_codec_create(const ntts_codec_config* cf, int device, ntts_c
     A(dalloc(c, &c->wav, c->wav_cap));
     c->meta_cap = R + 3 * max_utts + 64;
     A(dalloc(c, &c->meta, c->meta_cap));
+    for (int i = 0; i < ntts_codec::kMetaStages && rc == NTTS_OK; ++i)
+        if (hipHostMalloc((void**)&c->meta_host[i], c->meta_cap * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+            hipEventCreateWithFlags(&c->meta_ev[i], hipEventDisableTiming) != hipSuccess) rc = cfail(nullptr, NTTS_ENOMEM, "page-locked meta staging");
     (void)npages_max;
     if (rc == NTTS_OK) {
         hipMemset(c->h, 0, R * H * 4); hipMemset(c->t1, 0, R * H * 4);
@@ -388,20 +402,27 @@ static int codec_decode_impl(ntts_codec* c, int32_t n, const int32_t* codes, con
     // the V^T pages of the paged attention path are laid out per utterance x the LONGEST utterance's pages (not packed)
     if (!(c->attn_resident && npages <= kAttnResPages) && (long)n * npages * kPage > c->max_rows + (c->max_rows / (1 + 2 * kPadRows) + 1) * kPage)
         return cfail(c, NTTS_EINVAL, "%d utterances x %d pages exceed the V^T workspace: decode fewer utterances per call", n, npages);
-    // ---- meta: [lens n][code_off n][row_off n + 1][codes total]
-    std::vector<int> m;
-    m.reserve(3 * n + 1 + (codes ? total : 0));
-    m.insert(m.end(), lens, lens + n);
-    long off = 0;
-    for (int i = 0; i < n; ++i) { m.push_back(codes ? (int)off : i * codes_stride); off += lens[i]; }
-    long roff = 0;
-    for (int i = 0; i < n; ++i) { m.push_back((int)roff); roff += lens[i] + 2 * kPadRows; }
-    m.push_back((int)roff);
-    if (codes) m.insert(m.end(), codes, codes + total);
-    if (m.size() > c->meta_cap) return cfail(c, NTTS_EINVAL, "meta block too large");
+    // ---- meta: [lens n][code_off n][row_off n + 1][codes total], built in a page-locked ring slot: the copy is asynchronous, no stream-wide wait
+    const size_t m_size = 3 * (size_t)n + 1 + (codes ? (size_t)total : 0);
+    if (m_size > c->meta_cap) return cfail(c, NTTS_EINVAL, "meta block too large");
     hipStream_t st = c->stream;
-    CHIP(c, hipMemcpyAsync(c->meta, m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice, st));
-    CHIP(c, hipStreamSynchronize(st));   // m is pageable host memory
+    {
+        const int k = c->meta_next;
+        c->meta_next = (k + 1) % ntts_codec::kMetaStages;
+        if (c->meta_used[k]) CHIP(c, hipEventSynchronize(c->meta_ev[k]));     // (the copy out of this slot two passes ago)
+        int* m = c->meta_host[k];
+        size_t at = 0;
+        memcpy(m, lens, (size_t)n * sizeof(int)); at = n;
+        long off = 0;
+        for (int i = 0; i < n; ++i) { m[at++] = codes ? (int)off : i * codes_stride; off += lens[i]; }
+        long roff = 0;
+        for (int i = 0; i < n; ++i) { m[at++] = (int)roff; roff += lens[i] + 2 * kPadRows; }
+        m[at++] = (int)roff;
+        if (codes) { memcpy(m + at, codes, (size_t)total * sizeof(int)); at += total; }
+        CHIP(c, hipMemcpyAsync(c->meta, m, at * sizeof(int), hipMemcpyHostToDevice, st));
+        c->meta_used[k] = true;
+        CHIP(c, hipEventRecord(c->meta_ev[k], st));
+    }
     if (producer) {                        // the codes are being written on another stream: order this pass behind it
         CHIP(c, hipEventRecord(c->ev_in, producer));
         CHIP(c, hipStreamWaitEvent(st, c->ev_in, 0));

@@ -470,7 +470,6 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
     static_assert(ROWS % RPI == 0, "whole loader instructions");
     constexpr int NINST = ROWS / RPI;          // wave-instructions per slot
     constexpr int SPT = 64 / BK;               // ring slots per 64-wide K tile (GemmArgs counts K in tiles of 64)
-    static_assert(TN != 4 || NINST % NW == 0, "loader split");
     constexpr int PER_WAVE = (NINST + NW - 1) / NW;
     constexpr bool EVEN = NINST % NW == 0;     // every wave issues PER_WAVE instructions per slot (else the last waves issue one fewer)
     static_assert(NS >= 2 && (NS - 2) * PER_WAVE <= 63, "vmcnt range");

@@ -89,6 +89,11 @@ extern "C" int ntts_streams_create(ntts_backbone* e, ntts_codec* c, const ntts_s
         return sfail(nullptr, NTTS_EINVAL, "bad stream parameters");
     // one previous frame must be all that overlaps a new one (neutts.py _StreamBlender): frame = chunk + 2 overlap hops at a stride of chunk hops
     if (2 * prm->overlap >= prm->chunk) return sfail(nullptr, NTTS_EINVAL, "overlap %d too large for chunk %d", prm->overlap, prm->chunk);
+    // a regular window ends `lookforward` frames past the chunk, and the blend reads (chunk + 2 overlap) hops of it from the chunk's start
+    // on: with lookforward < 2 overlap it would read past the decoded window (the reference's slice is simply shorter there --
+    // those parameters stay on the host loop, neutts.py _stream_on_device)
+    if (prm->lookforward < 2 * prm->overlap)
+        return sfail(nullptr, NTTS_EINVAL, "lookforward %d < 2 x overlap %d: not supported on the device-side stream path", prm->lookforward, prm->overlap);
     ntts_streams* s = new ntts_streams();
     s->e = e; s->c = c; s->prm = *prm; s->device = device; s->n = n; s->hop = prm->hop_length;
     s->slots.assign(slots, slots + n);

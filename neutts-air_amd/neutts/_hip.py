@@ -18,7 +18,7 @@ DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "libneutts_hip.so")
 
 NTTS_DT_F32, NTTS_DT_BF16, NTTS_DT_I32, NTTS_DT_FP8_E4M3 = 0, 1, 2, 3
 NTTS_W_BF16, NTTS_W_FP8_E4M3 = 0, 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 NTTS_PAGE_TOKENS = 32            # include/neutts_hip.h
 PAGE_TOKENS = 32
 ERRORS = {-1: "EINVAL", -2: "ENODEV", -3: "ENOMEM", -4: "ESTATE", -5: "EHIP"}
@@ -100,6 +100,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_backbone_prefill": (C.c_int, [p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(SamplingC)]),
         "ntts_backbone_prefill_shared": (C.c_int, [p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(SamplingC),
                                                    C.POINTER(i32), C.POINTER(i32)]),
+        "ntts_backbone_set_gang": (C.c_int, [p, i32]),
         "ntts_backbone_kv_stats": (C.c_int, [p, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64), C.POINTER(i64)]),
         "ntts_backbone_decode": (C.c_int, [p, i32]),
         "ntts_backbone_read": (C.c_int, [p, i32, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(i32)]),
@@ -486,6 +487,11 @@ class BackboneEngine:
     def sync(self):
         self._chk(self.lib.ntts_backbone_sync(self.h))
 
+    def set_gang(self, chains: int):
+        """Tell the engine how many decode chains (engines of an EngineGang, itself included) run side by side on the GPU: the
+        decode step's GEMM tiles and XCD placement are chosen for that (ntts_backbone_set_gang); the captured step graph is dropped."""
+        self._chk(self.lib.ntts_backbone_set_gang(self.h, int(chains)))
+
     def set_stream(self, stream: Optional[int]):
         """Run the engine's work on the caller's HIP stream (a hipStream_t as an integer, e.g. torch.cuda.Stream().cuda_stream); None = its own."""
         self._chk(self.lib.ntts_backbone_set_stream(self.h, C.c_void_p(stream or None)))
@@ -577,11 +583,16 @@ class BackboneEngine:
         # KV admission control: a request is admitted only if the pool can hold it up to ITS max_length next to everything
         # already running (pages are allocated as the sequence grows; without the reservation two admitted requests could
         # starve each other in the middle of decoding)
-        total_pages = self.kv_stats()["total_pages"]
+        # Pages held OUTSIDE this call (a suspended infer_stream generator, slots another caller prefilled) are not this scheduler's
+        # to hand out: the reservation budget is what was free when the call started (comparing with the pool's size let
+        # the scheduler admit requests the pool could never hold, and the run-ahead loop then span on a burst that could not succeed).
+        st0 = self.kv_stats()
+        pool_pages = st0["total_pages"]
+        total_pages = st0["free_pages"]
         need_pages = [(sp.max_length - 1 + NTTS_PAGE_TOKENS - 1) // NTTS_PAGE_TOKENS for sp in sampling]
         for i, n in enumerate(need_pages):
             if n > total_pages:
-                raise NeuTTSHipError(-3, f"prompt {i}: max_length {sampling[i].max_length} needs {n} KV pages, the pool has {total_pages}")
+                raise NeuTTSHipError(-3, f"prompt {i}: max_length {sampling[i].max_length} needs {n} KV pages, the pool has {total_pages} free of {pool_pages}")
         committed: Dict[int, int] = {}                      # slot -> pages reserved for it
         results: List[Optional[List[int]]] = [None] * len(prompts)
         owner: Dict[int, int] = {}
@@ -678,6 +689,14 @@ class BackboneEngine:
                     else:
                         st, nn = self.poll_end()
                         q, open_snap = open_snap, None
+                        if burst_failed is not None and not any(valid_from.get(s, 0) <= q and st[s] == 2 for s in owner):
+                            # the burst could not reserve its pages and the snapshot in flight frees nothing: look at everything
+                            # enqueued so far; if no owner has finished there either, no later iteration can cure it (ADVICE r4:
+                            # this used to spin on poll_end / poll_begin forever, and an EngineGang with it)
+                            st, nn = self.poll()
+                            q = snap_seq
+                            if not any(st[s] == 2 for s in owner):
+                                raise burst_failed
                 else:
                     st, nn = self.poll()
                     q = snap_seq                                  # a blocking poll describes everything enqueued so far
@@ -733,21 +752,43 @@ class EngineGang:
     engines' schedulers from the calling thread.  Each request's arithmetic is that of a single engine (same kernels, same
     slots per engine): ids are identical to BackboneEngine.generate's."""
 
+    MAX_ENGINES = 4        # hardware queues the HIP runtime multiplexes streams onto: a fifth chain shares a queue and the gang gets SLOWER
+
     def __init__(self, engine: "BackboneEngine", n: int = 4, lanes: bool = True):
-        if n < 1:
-            raise ValueError("an engine gang needs at least one engine")
-        self.engines: List[BackboneEngine] = [engine] + [engine.twin() for _ in range(n - 1)]
+        if not 1 <= n <= self.MAX_ENGINES:
+            raise ValueError(f"an engine gang has 1..{self.MAX_ENGINES} engines (one hardware queue each), not {n}")
         self.lib, self._device = engine.lib, engine._device
         self._streams: List[int] = []
-        if lanes and n > 1:
-            for _ in range(n):                           # created back to back: up to four streams land in distinct hardware queues
-                st = C.c_void_p()
-                rc = self.lib.ntts_stream_create(self._device, C.byref(st))
-                if rc != 0:
-                    raise NeuTTSHipError(rc, "ntts_stream_create failed")
-                self._streams.append(st.value)
-            for e, st in zip(self.engines, self._streams):
-                e.set_stream(st)
+        self.engines: List[BackboneEngine] = [engine]
+        try:
+            for _ in range(n - 1):
+                self.engines.append(engine.twin())
+            if lanes and n > 1:
+                for _ in range(n):                       # created back to back: up to four streams land in distinct hardware queues
+                    st = C.c_void_p()
+                    rc = self.lib.ntts_stream_create(self._device, C.byref(st))
+                    if rc != 0:
+                        raise NeuTTSHipError(rc, "ntts_stream_create failed")
+                    self._streams.append(st.value)
+                for e, st in zip(self.engines, self._streams):
+                    e.set_stream(st)
+            for e in self.engines:
+                e.set_gang(n)                            # the decode step's tile family depends on how many chains share the chip
+        except Exception:
+            self.close()                                 # twins and lanes made so far must not leak
+            raise
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def lane(self, k: int) -> Optional[int]:
         """Engine k's lane stream (lend it to that engine's codec engine too: CodecEngine.set_stream), None without lanes."""
@@ -800,14 +841,17 @@ class EngineGang:
             e.sync()
 
     def close(self):
-        for e in reversed(self.engines[1:]):
+        """Twins destroyed, engine 0 back on its own stream and its single-chain tiles, lanes destroyed.  Idempotent."""
+        engines, self.engines = getattr(self, "engines", []), getattr(self, "engines", [])[:1]
+        for e in reversed(engines[1:]):
             e.close()
-        if self._streams:
-            self.engines[0].set_stream(None)
-            for st in self._streams:
-                self.lib.ntts_stream_destroy(self._device, C.c_void_p(st))
-            self._streams = []
-        self.engines = self.engines[:1]
+        if engines and getattr(engines[0], "h", None):
+            if self._streams:
+                engines[0].set_stream(None)
+            engines[0].set_gang(1)
+        for st in self._streams:
+            self.lib.ntts_stream_destroy(self._device, C.c_void_p(st))
+        self._streams = []
 
 
 class CodecEngine:

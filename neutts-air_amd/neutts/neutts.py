@@ -206,6 +206,23 @@ class NeuTTS:
             self.watermarker = None
 
     # ------------------------------------------------------------------------------------------ loading
+    def close(self):
+        """Release the GPU engines (not part of the reference's surface: its torch modules go with the garbage collector).  The gang
+        goes first -- its twins read the first engine's arena and its lane streams carry engine 0's work."""
+        gang, self.gang = getattr(self, "gang", None), None
+        if gang is not None:
+            gang.close()
+        for name in ("backbone",):
+            eng = getattr(self, name, None)
+            if eng is not None and hasattr(eng, "close"):
+                eng.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
     def _load_backbone(self, backbone_repo, backbone_device):
         print(f"Loading backbone from: {backbone_repo if isinstance(backbone_repo, str) else '<in-memory weights>'}"
               f" on {backbone_device} ...")
@@ -507,6 +524,8 @@ class NeuTTS:
             return False
         if not getattr(self, "_stream_modulo", 0) and (self._speech_base is None or "_ids_to_codes" in self.__dict__):
             return False
+        if self.streaming_lookforward < 2 * self.streaming_overlap_frames or 2 * self.streaming_overlap_frames >= self.streaming_frames_per_chunk:
+            return False                   # (ntts_streams_create refuses these; the host loop slices like the reference does)
         return min(len(rc) for rc in ref_codes) >= self.streaming_overlap_frames
 
     def _stream_batch_device(self, slots, ref_codes):

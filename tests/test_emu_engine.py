@@ -32,7 +32,12 @@ def test_tiny_teacher_forced(emu_lib):
      "NTTS_ATTN_SPLIT": "2", "NTTS_ATTN_SPLIT_CTX": "45"},   # large-batch path (gemm.h tiles, fused QKV + RoPE + K append), 256 x 256 lm_head tile, context-split attention + combine pass from context 45 on
     {"NTTS_SMALL_BATCH": "0", "NTTS_HEAD_TILE": "1"},        # ... 128 x 128 lm_head tile
     # the lm_head's natural-order tile (gemm.h TN = 6: 256 x 288, 12 waves, uneven LDS-DMA loader split, partial last tile)
-    {"NTTS_SMALL_BATCH": "0", "NTTS_HEAD_TILE": "4"}])
+    {"NTTS_SMALL_BATCH": "0", "NTTS_HEAD_TILE": "4"},
+    # round 5, the gang's "tall" decode tiles: o_proj / down_proj on 256 x 64 (8 waves, one m-block per chain), gate/up on 256 x 192 (12 waves,
+    # uneven loader split with TN = 4, partial last column block) / 256 x 256 / the 2-slot 128 x 128
+    {"NTTS_SMALL_BATCH": "0", "NTTS_TALL": "3", "NTTS_GU_TILE": "1", "NTTS_XCD_AFFINE": "0"},
+    {"NTTS_SMALL_BATCH": "0", "NTTS_TALL": "2", "NTTS_GU_TILE": "2", "NTTS_KS_D": "3"},
+    {"NTTS_SMALL_BATCH": "0", "NTTS_TALL": "1", "NTTS_GU_TILE": "3", "NTTS_KS_O": "2"}])
 def test_small_gqa2_page_crossing_walk_exact(emu_lib, knobs, monkeypatch):
     """2 kv heads, prompt of 70 (3 pages), decode crosses the 96-token page boundary; walk weights (wide margins, a new id every step) so the
     free-running greedy ids must be bit-identical to HF's -- on the small-batch decode path (wave-per-16-features GEMVs with
@@ -205,6 +210,38 @@ def test_continuous_batching_ragged_vs_oracle(emu_lib):
     assert eng.generate(prompts, samp, steps_per_poll=3, prefill_token_budget=70) == got     # engine 0 is back on its own stream
 
 
+@pytest.mark.timeout(300)
+def test_generate_with_pages_held_outside_the_call(emu_lib, monkeypatch):
+    """KV pages held outside a generate() call -- a suspended stream, a slot another caller prefilled -- are not
+    the scheduler's to hand out.  (1) Requests that fit beside the holder one at a time still complete, with the ids they have alone.
+    (2) A request the FREE pages can never hold is refused up front.  (3) With the up-front check blinded (kv_stats reporting the
+    whole pool as free, the round-4 behaviour) the run-ahead scheduler meets the exhausted pool in the middle of decoding: it must
+    raise and release its slots, not spin on poll_end / poll_begin."""
+    cfg = br.BackboneConfig.tiny(vocab_size=256, num_layers=1)
+    w = br.make_weights(cfg, 3)
+    eng = make_engine(cfg, w, emu_lib, max_batch=3, max_context=128, num_pages=4, max_prefill_tokens=128)
+    short = _hip.Sampling(max_length=60, min_new_tokens=40, eos_token_id=1, do_sample=False)      # 2 pages
+    prompts = [br.synthetic_prompt(cfg, i, 12) for i in range(2)]
+    alone = eng.generate(prompts, short, steps_per_poll=3)
+    holder = eng.acquire_slot()
+    eng.prefill([br.synthetic_prompt(cfg, 7, 40)], [holder], [_hip.Sampling(max_length=64, min_new_tokens=0, eos_token_id=1, do_sample=False)])   # holds 2 of the 4 pages
+    assert eng.kv_stats()["free_pages"] == 2
+    assert eng.generate(prompts, short, steps_per_poll=3) == alone                                 # one after the other beside the holder
+    long_ = _hip.Sampling(max_length=128, min_new_tokens=100, eos_token_id=1, do_sample=False)     # 4 pages: never beside the holder
+    with pytest.raises(_hip.NeuTTSHipError) as ei:
+        eng.generate(prompts[:1], long_, steps_per_poll=3)
+    assert ei.value.code == -3
+    real = eng.kv_stats
+    monkeypatch.setattr(eng, "kv_stats", lambda: dict(real(), free_pages=real()["total_pages"]))
+    with pytest.raises(_hip.NeuTTSHipError) as ei:                                                 # admitted, then the pool runs dry mid-decode
+        eng.generate(prompts[:1], long_, steps_per_poll=3)
+    assert ei.value.code == -3
+    monkeypatch.undo()
+    assert eng.free_slots() == 2 and eng.kv_stats()["free_pages"] == 2                             # everything the failed calls held is back
+    eng.release(holder)
+    assert eng.generate(prompts, short, steps_per_poll=3) == alone
+
+
 def test_engine_error_paths(emu_lib):
     cfg = br.BackboneConfig.tiny(vocab_size=256, num_layers=1)
     w = br.make_weights(cfg, 3)
@@ -338,6 +375,24 @@ def test_share_arena_error_paths_and_side_by_side_chains(emu_lib):
     eng.prefill(pa, [0, 1], [samp] * 2)
     eng.decode(N - 1)
     assert [eng.read(s)[0] for s in (0, 1)] == alone_a
+    # the arena is reference-counted -- a DONOR destroyed before its readers leaves them on live weights
+    tw2, tw3 = eng.twin(), eng.twin()
+    tw2._donor = tw3._donor = None
+    eng.close()
+    for t, p, want in ((tw2, pb, alone_b), (tw3, pa, alone_a)):
+        t.prefill(p, [0, 1], [samp] * 2)
+        t.decode(N - 1)
+        assert [t.read(s)[0] for s in (0, 1)] == want
+        t.close()
+    # an engine gang: 1..4 engines, a context manager, engine 0 back to its single-chain shape afterwards; more than four are refused
+    eng = make_engine(cfg, w, emu_lib, max_batch=2)
+    with pytest.raises(ValueError):
+        _hip.EngineGang(eng, 5)
+    with _hip.EngineGang(eng, 2) as gang:
+        assert len(gang.engines) == 2 and gang.lane(0) and gang.lane(1)
+        assert gang.generate(pa + pb, samp) == alone_a + alone_b
+    assert len(gang.engines) == 1 and gang.lane(0) is None
+    assert eng.generate(pa, samp) == alone_a
 
 
 def test_read_finished_refuses_a_stale_snapshot(emu_lib):
