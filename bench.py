@@ -125,6 +125,49 @@ def latest_profile(suffix):
     return c[-1] if c else os.path.join(ROOT, "profiles", "missing" + suffix)
 
 
+def mfma_util_table(path):
+    """Matrix-core utilisation per kernel symbol from the committed counter summary (tools/mfma_util_summary.py over a
+    `rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16` pass of bench.py):
+    {"source": file, "command": its header line, "kernels": {symbol: {"mfma_util_pct", "launches", "bf16_gflop_per_launch"}}}."""
+    try:
+        lines = open(path).read().splitlines()
+    except OSError:
+        return None
+    out = {}
+    for ln in lines:
+        if ln.startswith("#") or ln.startswith("kernel "):
+            continue
+        parts = ln.rsplit(None, 5)
+        if len(parts) != 6:
+            continue
+        try:
+            out[parts[0].strip()] = {"launches": int(parts[1]), "mfma_util_pct": float(parts[4]), "bf16_gflop_per_launch": float(parts[5])}
+        except ValueError:
+            continue
+    if not out:
+        return None
+    return {"source": os.path.relpath(path, ROOT), "command": lines[0].lstrip("# ") if lines and lines[0].startswith("#") else None,
+            "peak": "2.5 PFLOP/s dense bf16 (MI355X_MICROARCH.md); MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs)",
+            "kernels": {k: v for k, v in out.items() if v["mfma_util_pct"] > 0}}
+
+
+def continuous_leg(static_value, a):
+    import subprocess
+    req = int(os.environ.get("NTTS_BENCH_CONT_REQUESTS", "4096"))
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "continuous", "--requests", str(req), "--steps", "1", "--warmup", "1",
+           "--no-cpu-baseline", "--no-roofline", "--gang", str(max(1, a.gang)), "--prefill", str(a.prefill), "--decode", str(a.decode)]
+    t0 = time.time()
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=float(os.environ.get("NTTS_BENCH_CONT_TIMEOUT", "240")))
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+        r = json.loads(line)
+        return {"value": r["value"], "unit": r["unit"], "ratio_to_static": r["value"] / static_value, "requests": req,
+                "ms_per_step": r["ms_per_step"], "workload": r["config"]["workload"][:400], "command": " ".join(cmd[1:]),
+                "wall_s_incl_startup": round(time.time() - t0, 1), "phase_ms": r.get("phase_ms")}
+    except Exception as ex:  # noqa: BLE001  (a sub-record must never cost the headline line)
+        return {"error": repr(ex)[:300], "command": " ".join(cmd[1:])}
+
+
 def rocprof_symbols(path, live):
     """live: logical kernel -> (ms per launch, algorithmic bytes per launch, launches per step) from this run's HIP events."""
     try:
@@ -372,6 +415,9 @@ def main():
             for j, c2 in enumerate(codecs):
                 if c2 is not None:
                     c2.set_stream(lanes[G if NG == 2 else j % G].cuda_stream)      # (one gang: engine j's codec pass on its own lane)
+        if G > 1 and os.environ.get("NTTS_BENCH_GANG_SHAPE", "1") != "0":
+            for e in engs:
+                e.set_gang(G)       # round 5 (ABI 8): the decode step's tiles / XCD placement chosen for G chains side by side (A/B aid: =0 keeps the single-chain shape)
     if os.environ.get("NTTS_BENCH_PRIME", "1") != "0" and not cont:
         for e2 in engs[1:]:
             e2.warm_up(int(os.environ.get("NTTS_BENCH_PRIME_STEPS", str(max(2, N - 1)))))
@@ -787,6 +833,9 @@ def main():
         dt = float(t.item())
 
     # ---- untimed extra legs (phase split, roofline of the dominant kernel, CPU baseline)
+    gang_shape = pipe and G > 1 and os.environ.get("NTTS_BENCH_GANG_SHAPE", "1") != "0"
+    if gang_shape:
+        eng.set_gang(1)      # the serial pass and the per-kernel replays below describe ONE engine alone: its single-chain decode shape
     ph, ids, wavs = one_step(collect=True)
     if wavs is not None:
         assert np.isfinite(wavs[:4]).all(), "non-finite waveform"
@@ -813,6 +862,9 @@ def main():
         # step graphs replayed alternately; wall time of 16 steps each over G x 16 (HIP events see one stream, the chains run on G)
         gang_step_ms = None
         side = {}
+        if gang_shape:
+            eng.sync()
+            eng.set_gang(G)  # ... and from here on the step as the timed region runs it
         if pipe and G > 1:
             for e2 in engs[1:G]:
                 for c in range(0, B, a.prefill_chunk):
@@ -906,6 +958,7 @@ def main():
                               if gang_step_ms else None),
                 "dominant_choice": choice,
                 "pmc_per_kernel": pmc or None,
+                "mfma_util": mfma_util_table(latest_profile("_mfma_util.txt")) if std_cfg else None,
                 "rocprof": rocprof,
                 "per_kernel": [{"kernel": r[1], "us": r[2] * 1e3, "launches_per_step": r[4], "alg_bytes": r[3],
                                 "GBps": r[3] / (r[2] * 1e-3) / 1e9, "frac": r[3] / (r[2] * 1e-3) / 1e9 / HBM_PEAK_GBPS} for r in rows]}
@@ -933,7 +986,10 @@ def main():
         elif B == 1 and world == 1:
             workload = f"NeuTTS-Air bf16 1xMI355X, batch=1, {S} prefill / {N} decode tokens (BASELINE.json configs[1])"
         else:
-            workload = (f"NeuTTS-Air bf16 {world}xMI355X batch={B} synthetic prompts per GPU, {S} prefill / {N} decode tokens, "
+            one_eng = (B * N / ((ph["prefill"] + ph["decode"] + ph["codec"]) * 1e-3)) if (pipe and all(k in ph for k in ("prefill", "decode", "codec")) and ph["decode"] > 0) else None
+            head = (f"NeuTTS-Air bf16 {world}xMI355X: {G} batches of {B} IN FLIGHT per GPU ({G * B} resident; ONE {B}-slot engine alone = "
+                    f"{one_eng / 1e3:.1f}k tok/s), " if (pipe and G > 1 and one_eng) else f"NeuTTS-Air bf16 {world}xMI355X ")
+            workload = (head + f"batch={B} synthetic prompts per GPU, {S} prefill / {N} decode tokens, "
                         f"STATIC batch (all {B} slots of the continuous-batching engine filled at once, every utterance {N} tokens; the ragged "
                         f"scheduler line is --mode continuous)" + ((f", {G} batches at a time on {G} {B}-slot engines reading ONE copy of the weights: their prompt passes, decode chains (step graphs replayed alternately, one stream = one hardware queue each) and codec passes side by side" + (f", two such gangs taking turns ({2 * G} engines)" if NG == 2 else "") if G > 1 else ", consecutive batches pipelined over two engines") if pipe else "") + f" + hipGraph decode (BASELINE.json configs[{2 if world == 1 else 3}])")
         workload += ", sampling as the reference calls generate (do_sample, top_k=50, temperature=1.0, seeded)" if a.sample else ", greedy"
@@ -977,6 +1033,12 @@ def main():
         }
         if strm:
             rec["stream"] = stream_stats
+        # BASELINE.json configs[2] literally says "continuous batching": the ragged-request scheduler measured in the SAME driver
+        # invocation (its own process and engines -- the ragged requests need a longer context than the static engines were created
+        # with), as a sub-record with its ratio to the static line above.  Rank 0 of a 1-GPU run only; NTTS_BENCH_CONT_LEG=0 skips it.
+        if (world == 1 and not cont and not strm and not nano and not a.tiny and B == 256 and not emu_lib and not a.no_roofline
+                and os.environ.get("NTTS_BENCH_CONT_LEG", "1") != "0"):
+            rec["continuous"] = continuous_leg(value, a)
         print(json.dumps(rec), flush=True)
     if world > 1:
         import torch.distributed as dist

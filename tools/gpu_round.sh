@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call = everything we want from a GPU box, each leg under its own timeout, logs in gpurun_out/.
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_round.sh [legs...]'
-# legs: smoke tests bench b1 nano prof pmc sweep   (default: smoke tests bench prof)
+# legs: smoke tests bench b1 nano prof pmc mfma sweep   (default: smoke tests bench prof)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -28,6 +28,15 @@ for leg in $LEGS; do
              done
              python tools/pmc_summary.py $OUT/pmc_$ctr > $OUT/pmc_${ctr}_summary.txt 2>&1; head -14 $OUT/pmc_${ctr}_summary.txt; find $OUT/pmc_$ctr -name '*.csv' -size +8M -delete
            done;;
+    mfma)  # matrix-core utilisation per kernel (north_star: "MFMA utilisation against gfx950 peak"): SQ busy cycles / GRBM cycles / MFMA op counts
+           # in ONE counter pass (8 SQ slots, 2 GRBM), graph replay off, one engine, 8 decode steps (longer profiled passes hang since round 3)
+           for attempt in 1 2 3; do
+             rm -rf $OUT/pmc_mfma; NTTS_NO_GRAPH=1 NTTS_BENCH_PRIME=0 timeout 150 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 -f csv -d $OUT/pmc_mfma -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-pipeline --prefill 605 --decode 8 > $OUT/pmc_mfma_bench.json 2> $OUT/pmc_mfma.err; rc=$?; echo "mfma attempt $attempt rc=$rc"
+             [ $rc -eq 0 ] && break
+           done
+           { echo "# NTTS_NO_GRAPH=1 NTTS_BENCH_PRIME=0 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-pipeline --prefill 605 --decode 8"
+             echo "# python tools/mfma_util_summary.py <dir>   (formula and calibration in the tool's header; counter passes run at a lower clock than the bench)"
+             python tools/mfma_util_summary.py $OUT/pmc_mfma; } > $OUT/mfma_util.txt 2>&1; head -16 $OUT/mfma_util.txt; find $OUT/pmc_mfma -name '*.csv' -size +8M -delete;;
     sweep)  # SWEEP_KNOBS='[["NTTS_ATTN_DEPTH",[2]]]'
            timeout ${SWEEP_TIMEOUT:-400} python tools/sweep_decode.py --knobs "${SWEEP_KNOBS:-[[\"NTTS_ATTN_DEPTH\",[2]]]}" > $OUT/sweep.log 2>&1; echo "sweep rc=$?"; grep -v '^\[sweep\] weights' $OUT/sweep.log | tail -12;;
     nano)  for cfg in nano-fp8 nano-bf16; do timeout 300 python bench.py --config $cfg --steps ${BENCH_STEPS:-2} --warmup 1 --no-cpu-baseline > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err; echo "bench $cfg rc=$?"; cut -c1-1200 $OUT/bench_$cfg.json; tail -12 $OUT/bench_$cfg.err; done;;
