@@ -234,6 +234,9 @@ def main():
                     help="pipelined static mode: 2 = two gangs take turns (gang k + 1's prompt passes beside gang k's decode steps, prompt and codec "
                          "passes on one shared stream); 1 = ONE gang, every engine on a lane of its own for all of its work: prompt passes, decode "
                          "chains and codec passes of the gang's batches each run side by side, phase after phase")
+    ap.add_argument("--speech-range-head", action="store_true",
+                    help="OPT-IN serving option, NEVER the headline: lm_head over 65 536 speech ids + EOS only (ntts_backbone_set_logits_range); "
+                         "a separate line, labelled as such")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-codec", action="store_true", help="backbone only (profiling aid; not the headline metric)")
@@ -384,6 +387,12 @@ def main():
     elif codec is not None:
         codec_sd = {k: v.numpy() for k, v in cw.items()}
         codec.load_state_dict(codec_sd)
+    if a.speech_range_head:
+        if strm or cfg.vocab_size < 65536 + 2:
+            raise SystemExit("--speech-range-head: static / continuous mode at a vocabulary that holds 65 536 speech ids")
+        sp_lo = cfg.vocab_size - 16 - 65536              # the speech ids sit behind the 151 936 base ids, the specials last
+        eng.set_logits_range(sp_lo, sp_lo + 65536, eos)
+        stage(f"OPT-IN restricted lm_head: ids [{sp_lo}, {sp_lo + 65536}) + eos {eos}")
     # static mode: a TWIN engine (same configuration, its own KV pool and slot state, the arena copied device to device) so that
     # consecutive batches can overlap on the GPU: while engine A replays batch k's decode graphs, engine B runs batch k + 1's prompt pass
     pipe = (not cont) and (not strm) and (not a.no_pipeline) and B > 1
@@ -826,11 +835,27 @@ def main():
                              + ([round(ph_t[k], 1) for k in ("prefill", "decode", "codec")] if os.environ.get("NTTS_BENCH_STEP_PHASES") else []))
     barrier()
     dt = time.time() - t0
+    ranks_seen, host_stats = world, None
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if emu_lib else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # 8-GPU hedges: every rank must be IN the timed job (a rank that silently fell out of the group would make
+        # `value` = world x tokens a lie), and the launching threads' host time per step -- eight ranks' launch threads and pollers share one
+        # host -- is reported as max / mean over ranks so that a host-bound rank shows in the driver's line
+        one = torch.ones(1, dtype=torch.float64, device=t.device)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(one.item())))
+        assert ranks_seen == world == dist.get_world_size(), f"{ranks_seen} ranks took part in the timed region, WORLD_SIZE says {world}"
+        mine = [float(np.mean([sum(x[1:4]) if isinstance(x[0], list) else sum(x[:3]) for x in step_host])) if step_host else 0.0,
+                float(np.mean([w_[1] if isinstance(w_, list) else w_ for w_ in step_wall])) if step_wall else 0.0]
+        hm = torch.tensor(mine, dtype=torch.float64, device=t.device)
+        hmax, hsum = hm.clone(), hm.clone()
+        dist.all_reduce(hmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(hsum, op=dist.ReduceOp.SUM)
+        host_stats = {"host_ms_in_calls_per_step": {"max_over_ranks": float(hmax[0]), "mean_over_ranks": float(hsum[0]) / world},
+                      "step_wall_ms": {"max_over_ranks": float(hmax[1]), "mean_over_ranks": float(hsum[1]) / world}}
 
     # ---- untimed extra legs (phase split, roofline of the dominant kernel, CPU baseline)
     gang_shape = pipe and G > 1 and os.environ.get("NTTS_BENCH_GANG_SHAPE", "1") != "0"
@@ -906,7 +931,7 @@ def main():
                 e2.release_many(list(range(B)))
         rows.sort(reverse=True)
         live = {r[1]: (r[2], r[3], r[4]) for r in rows}
-        std_cfg = not nano and B == 256 and S == 500          # the configuration the committed rocprofv3 / PMC passes were taken on
+        std_cfg = not nano and B == 256 and S == 500 and not a.speech_range_head          # the configuration the committed rocprofv3 / PMC passes were taken on
         # rocprofv3 view of the same command (committed summary of the same configuration): per SYMBOL, since one gemm
         # template serves two launches per layer.  `agree` = its average duration is within 15 % of this run's HIP events.
         rocprof = rocprof_symbols(latest_profile("_bench_kernel_stats.txt"), live) if std_cfg else None
@@ -993,6 +1018,9 @@ def main():
                         f"STATIC batch (all {B} slots of the continuous-batching engine filled at once, every utterance {N} tokens; the ragged "
                         f"scheduler line is --mode continuous)" + ((f", {G} batches at a time on {G} {B}-slot engines reading ONE copy of the weights: their prompt passes, decode chains (step graphs replayed alternately, one stream = one hardware queue each) and codec passes side by side" + (f", two such gangs taking turns ({2 * G} engines)" if NG == 2 else "") if G > 1 else ", consecutive batches pipelined over two engines") if pipe else "") + f" + hipGraph decode (BASELINE.json configs[{2 if world == 1 else 3}])")
         workload += ", sampling as the reference calls generate (do_sample, top_k=50, temperature=1.0, seeded)" if a.sample else ", greedy"
+        if a.speech_range_head:
+            workload = ("OPT-IN --speech-range-head (NOT the headline, not the reference's arithmetic outside the range): lm_head over 65 536 speech ids + EOS "
+                        "instead of the whole vocabulary; " + workload)
         if strm:
             workload = (f"STREAM mode: {B} concurrent infer_stream utterances per GPU (27-frame windows every 25 tokens, 0.5 s chunks, "
                         f"ref:neutts/neutts.py:401-465), codec pass of chunk k on the codec engine's stream beside the decode graph of chunk k + 1; "
@@ -1013,6 +1041,7 @@ def main():
             "tokens_per_s_per_gpu": value / world,
             "rtf": dt / (tokens / 50.0),
             "phase_ms": ph, "step_wall_ms": step_wall, "step_host_wall_ms": step_host,
+            "ranks_in_timed_region": ranks_seen, "host_wall_over_ranks": host_stats,
             "roofline": roof, "decode_step": step_info, "cpu_baseline": cpu,
             "timed_region": ((f"warm_up() before timing; {len(engs)} backbone engines of {B} slots on one weight arena, each with a codec engine, on {G} lane streams; one "
                               f"launching thread; a gang step = {G} batches, one per engine: [prompt passes] [249 decode steps per engine, the engines' step graphs "
@@ -1037,7 +1066,7 @@ def main():
         # invocation (its own process and engines -- the ragged requests need a longer context than the static engines were created
         # with), as a sub-record with its ratio to the static line above.  Rank 0 of a 1-GPU run only; NTTS_BENCH_CONT_LEG=0 skips it.
         if (world == 1 and not cont and not strm and not nano and not a.tiny and B == 256 and not emu_lib and not a.no_roofline
-                and os.environ.get("NTTS_BENCH_CONT_LEG", "1") != "0"):
+                and not a.speech_range_head and os.environ.get("NTTS_BENCH_CONT_LEG", "1") != "0"):
             rec["continuous"] = continuous_leg(value, a)
         print(json.dumps(rec), flush=True)
     if world > 1:

@@ -133,6 +133,15 @@ int ntts_backbone_share_arena(ntts_backbone* e, ntts_backbone* donor);
  * a time); the arena is reference-counted since this version: donor and readers may be destroyed in any order. */
 int ntts_backbone_set_gang(ntts_backbone* e, int32_t chains);
 
+/* ABI 8, OPT-IN.  Restrict the lm_head to the token ids [lo, hi) plus eos_id: the decode step streams a compacted copy of those
+ * rows (NeuTTS-Air: 65 537 x 896 bf16 = 118 MB instead of 390 MB) and every other id is treated as logit -inf.  The reference
+ * only ever CONSUMES ids of that shape -- ref:neutts/neutts.py:276 keeps `<|speech_N|>` tokens, ref:neutts/neutts.py:336-341 stops
+ * at `<|SPEECH_GENERATION_END|>` -- but hf:generation/utils.py:2894-2925 takes the argmax / top-k over the WHOLE vocabulary: the
+ * ids are the reference's whenever its choice lies in the range, and differ otherwise.  Never the parity configuration.
+ * lo < 0 restores the full head.  While a range is set, requests must use eos_token_id == eos_id; no slot may be in use when this
+ * is called.  Per engine (twins of a gang each build their own 118 MB copy). */
+int ntts_backbone_set_logits_range(ntts_backbone* e, int32_t lo, int32_t hi, int32_t eos_id);
+
 /* Sampling contract of one request = the keyword arguments of the reference's generate() call
  * (ref:neutts/neutts.py:338-347). */
 typedef struct ntts_sampling {

@@ -109,6 +109,14 @@ struct ntts_backbone {
     // workgroups and loses; in an engine gang (four chains side by side) the other chains fill the CUs and what
     // counts is the bytes every CU pulls.  bit 0: o_proj, bit 1: down_proj on the 256 x 64 / 8-wave tile; gu_tile picks the gate/up tile.
     int tall = 0;
+    // Opt-in restricted lm_head (ntts_backbone_set_logits_range; SURVEY 7 "hard parts": the reference only ever consumes <|speech_N|> ids
+    // and the EOS, ref:neutts/neutts.py:276,336-341): a COMPACTED copy of the head -- rows [lr_lo, lr_hi) followed by the EOS row, padded to
+    // whole 64-row groups -- is what the lm_head streams (NeuTTS-Air: 118 MB instead of 390 MB); columns are mapped back to token ids
+    // in the sample kernel.  NOT the reference's arithmetic when the full-vocabulary argmax lies outside the range: never the default.
+    int lr_lo = -1, lr_hi = -1, lr_eos = -1, lr_rows = 0;   // lr_rows = lr_hi - lr_lo + 1 valid columns (0 = full head)
+    bf16_t* head_r = nullptr;        // compacted head matrix (tile-major; e4m3 bytes in the fp8 model)
+    float* shead_r = nullptr;        // fp8: its per-row scales
+    int n_part_full = 0;
     int gang = 1;                    // decode chains side by side on the GPU, this one included (ntts_backbone_set_gang); the defaults of tall / xcd_affine follow it
     int tall_env = -1, affine_env = -1;   // NTTS_TALL / NTTS_XCD_AFFINE when set (sweeps, tests): they win over the gang's defaults
     int gu_tile = 0;                 // gate/up tile (NTTS_GU_TILE): 0 = 128 x 128 / 8 waves / 3 slots (above batch 128; 64 x 64 below), 1 = 256 x 192 / 12 waves / 2 slots,
@@ -217,6 +225,11 @@ struct DevScratch {
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v && *v ? atoi(v) : dflt;
+}
+
+// (max, first index) pairs the lm_head leaves per row for a head of N columns (gemm.h / gemv.h EPI_ARGMAX: one per wave tile)
+static int n_part_for(const ntts_backbone* e, int N) {
+    return e->small ? (N + 15) / 16 : e->head_tile == 0 ? (N + 63) / 64 : e->head_tile == 4 ? ((N + 287) / 288) * 3 : e->head_tile == 2 ? ((N + 255) / 256) * 4 : ((N + 127) / 128) * 2;
 }
 
 // The decode step's shape as a function of how many chains share the chip (ntts_backbone_set_gang; measured on MI355X with
@@ -418,7 +431,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
         CR_HIP(hipMalloc((void**)&e->rope_rows, (size_t)B * 64 * 2));
         CR_HIP(hipMemset(e->rope_rows, 0, (size_t)B * 64 * 2));
     }
-    e->n_part = e->small ? V / 16 : e->head_tile == 0 ? (V + 63) / 64 : e->head_tile == 4 ? ((V + 287) / 288) * 3 : e->head_tile == 2 ? ((V + 255) / 256) * 4 : ((V + 127) / 128) * 2;
+    e->n_part = e->n_part_full = n_part_for(e, V);
     CR_HIP(hipMalloc((void**)&e->h_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->xn_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->qkv_dec, (size_t)B * e->NQKV * 2));
@@ -480,6 +493,8 @@ extern "C" void ntts_backbone_destroy(ntts_backbone* e) {
     hipDeviceSynchronize();
     if (e->graph) hipGraphExecDestroy(e->graph);
     if (e->graph_split) hipGraphExecDestroy(e->graph_split);
+    if (e->head_r) hipFree(e->head_r);
+    if (e->shead_r) hipFree(e->shead_r);
     bool last_reader = true;
     if (e->arena_refs) { last_reader = --*e->arena_refs == 0; if (last_reader) delete e->arena_refs; }
     void* bufs[] = {last_reader ? e->arena : nullptr, e->gu_map_gate, e->gu_map_up, e->kv, e->ibuf, e->h_dec, e->xn_dec, e->qkv_dec, e->attn_dec,
@@ -902,6 +917,59 @@ extern "C" int ntts_backbone_share_arena(ntts_backbone* e, ntts_backbone* donor)
     return NTTS_OK;
 }
 
+static void drop_graphs(ntts_backbone* e) {
+    if (e->graph) { hipGraphExecDestroy(e->graph); e->graph = nullptr; }
+    if (e->graph_split) { hipGraphExecDestroy(e->graph_split); e->graph_split = nullptr; }
+    e->graph_tried = e->graph_split_tried = false;
+}
+
+// Opt-in: the lm_head over the token ids [lo, hi) and `eos_id` only (ABI 8; SURVEY.md section 7 "hard parts").  Everything outside gets
+// logit -inf: greedy ids equal the full head's whenever the full-vocabulary argmax lies in the range (what a trained NeuTTS checkpoint
+// emits after its prompt: ref:neutts/neutts.py:276 keeps only <|speech_N|> ids, :336-341 stops at the one EOS id), and they DIFFER
+// otherwise -- this is a serving option, never the parity configuration.  lo < 0 restores the full head.  Requests must then carry
+// eos_token_id == eos_id (refused at prefill otherwise).  No slot may be running.
+extern "C" int ntts_backbone_set_logits_range(ntts_backbone* e, int32_t lo, int32_t hi, int32_t eos_id) {
+    if (!e) return NTTS_EINVAL;
+    if (!e->finalized) return fail(e, NTTS_ESTATE, "set_logits_range: weights not finalised");
+    const int V = e->cfg.vocab_size, H = e->H;
+    for (const HostSlot& sl : e->slots)
+        if (sl.state != SLOT_FREE) return fail(e, NTTS_ESTATE, "set_logits_range: a slot is in use");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    drop_graphs(e);
+    if (e->head_r) { hipFree(e->head_r); e->head_r = nullptr; }
+    if (e->shead_r) { hipFree(e->shead_r); e->shead_r = nullptr; }
+    e->lr_lo = e->lr_hi = e->lr_eos = -1; e->lr_rows = 0; e->n_part = e->n_part_full;
+    if (lo < 0) return NTTS_OK;
+    if (hi <= lo || hi > V || eos_id < 0 || eos_id >= V || (eos_id >= lo && eos_id < hi))
+        return fail(e, NTTS_EINVAL, "set_logits_range: need 0 <= lo < hi <= vocab_size (%d) and an eos id outside [lo, hi): got [%d, %d), eos %d", V, lo, hi, eos_id);
+    const int rows = hi - lo + 1, padded = (rows + 63) / 64 * 64;
+    std::vector<int> map(padded);
+    for (int r = 0; r < padded; ++r) map[r] = r < rows - 1 ? lo + r : eos_id;       // (padding rows repeat the EOS row; their columns are never valid)
+    DevScratch dmap;
+    HIPCHK(e, hipMalloc(&dmap.p, (size_t)padded * sizeof(int)));
+    HIPCHK(e, hipMemcpy(dmap.p, map.data(), (size_t)padded * sizeof(int), hipMemcpyHostToDevice));
+    const size_t kb = (size_t)H * (e->fp8 ? 1 : 2);
+    HIPCHK(e, hipMalloc((void**)&e->head_r, (size_t)padded * kb));
+    if (e->fp8) HIPCHK(e, hipMalloc((void**)&e->shead_r, (size_t)padded * sizeof(float)));
+    {   // (plain pointers for the launch: the emulator's launch captures its arguments by value)
+        const unsigned char* srcp = (const unsigned char*)e->embed_tm;
+        unsigned char* dstp = (unsigned char*)e->head_r;
+        const int* mapp = (const int*)dmap.p;
+        const float* scs = e->fp8 ? e->shead : nullptr;
+        float* scd = e->shead_r;
+        const long kbl = (long)kb;
+        NTTS_LAUNCH((gather_head_rows_kernel), dim3((unsigned)padded), dim3(64), e->stream, srcp, dstp, mapp, kbl, scs, scd);
+    }
+    // (the rows kept for the top-k sampler and the debug tap are in COLUMN order while a range is set: the sampler looks at the first
+    //  lr_rows columns, ntts_backbone_read_logits scatters them back to token ids)
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipGetLastError());
+    e->lr_lo = lo; e->lr_hi = hi; e->lr_eos = eos_id; e->lr_rows = rows;
+    e->n_part = n_part_for(e, rows);
+    return NTTS_OK;
+}
+
 extern "C" int ntts_backbone_set_gang(ntts_backbone* e, int32_t chains) {
     if (!e) return NTTS_EINVAL;
     if (chains < 1) return fail(e, NTTS_EINVAL, "set_gang: %d chains", chains);
@@ -910,9 +978,7 @@ extern "C" int ntts_backbone_set_gang(ntts_backbone* e, int32_t chains) {
     HIPCHK(e, hipStreamSynchronize(e->stream));       // the captured step may still be queued
     e->gang = chains;
     apply_gang_shape(e);
-    if (e->graph) { hipGraphExecDestroy(e->graph); e->graph = nullptr; }
-    if (e->graph_split) { hipGraphExecDestroy(e->graph_split); e->graph_split = nullptr; }
-    e->graph_tried = e->graph_split_tried = false;    // re-captured with the new launches by the next decode call
+    drop_graphs(e);                                   // re-captured with the new launches by the next decode call
     return NTTS_OK;
 }
 
@@ -928,6 +994,7 @@ static GemmArgs gemm_args(const ntts_backbone* e, const bf16_t* X, long ldx, con
     a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K;
     a.wscale = wscale; a.xscale = xscale;
     a.tl = e->gemv_tl;
+    a.eos_col = -1;
     return a;
 }
 static int ktile_of(const ntts_backbone* e) { return e->fp8 ? 128 : 64; }
@@ -978,7 +1045,9 @@ static void ks_lm_head(ntts_backbone* e, bool keep_logits);
 static void k_lm_head(ntts_backbone* e, bool keep_logits) {
     if (e->small) { ks_lm_head(e, keep_logits); return; }
     const int B = e->cfg.max_batch, H = e->H, V = e->cfg.vocab_size;
-    GemmArgs a = gemm_args(e, e->xn_dec, H, e->embed_tm, H, nullptr, nullptr, 0, B, V, H, e->shead, e->xs_head);
+    GemmArgs a = gemm_args(e, e->xn_dec, H, e->lr_rows ? e->head_r : e->embed_tm, H, nullptr, nullptr, 0, B, e->lr_rows ? e->lr_rows : V, H,
+                           e->lr_rows ? e->shead_r : e->shead, e->xs_head);
+    if (e->lr_rows) a.eos_col = e->lr_rows - 1;          // compacted head: columns = [range | EOS]
     a.part_val = e->part_val; a.part_idx = e->part_idx; a.mask_eos = e->sl.mask_eos;
     a.logits = keep_logits ? e->logits : nullptr; a.ld_logits = V;
     a.logits_bf16 = (keep_logits && e->n_sampling > 0) ? e->logits_bf16 : nullptr; a.ld_logits_bf16 = e->ldl;
@@ -1000,7 +1069,8 @@ static void lm_head_and_sample(ntts_backbone* e, int phase) {
     SampleArgs s{};
     s.part_val = e->part_val; s.part_idx = e->part_idx; s.n_part = e->n_part; s.sl = e->sl; s.phase = phase;
     s.part_width = e->small ? 16 : e->head_tile == 4 ? 96 : 64;
-    s.logits = e->n_sampling > 0 ? e->logits_bf16 : nullptr; s.ld_logits = e->ldl; s.vocab = e->cfg.vocab_size;
+    s.logits = e->n_sampling > 0 ? e->logits_bf16 : nullptr; s.ld_logits = e->ldl; s.vocab = e->lr_rows ? e->lr_rows : e->cfg.vocab_size;
+    if (e->lr_rows) { s.n_range = e->lr_rows - 1; s.id_base = e->lr_lo; s.id_tail = e->lr_eos; }
     NTTS_LAUNCH((sample_greedy_kernel), dim3(e->cfg.max_batch), dim3(256), e->stream, s);
 }
 
@@ -1109,6 +1179,7 @@ static GemvArgs gemv_args(const ntts_backbone* e, const bf16_t* X, long ldx, con
     a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.w_tile_major = 1; a.out = out; a.ldo = ldo;
     a.slab_rows = e->cfg.max_batch; a.M = e->cfg.max_batch; a.N = N; a.K = K;
     a.tl = e->gemv_tl;
+    a.eos_col = -1; a.n_valid = N;
     return a;
 }
 // the fused prologue of layer i's QKV GEMV: h = (i == 0 ? embed[cur_tok] : h + bf16(sum of the previous down_proj's slabs));
@@ -1183,7 +1254,9 @@ static void ks_final_norm(ntts_backbone* e) {   // h += down (last layer); xn = 
 }
 static void ks_lm_head(ntts_backbone* e, bool keep_logits) {
     const int H = e->H, V = e->cfg.vocab_size;
-    GemvArgs a = gemv_args(e, e->xn_dec, H, e->embed_tm, H, nullptr, 0, V, H, e->shead, e->xs_head);
+    GemvArgs a = gemv_args(e, e->xn_dec, H, e->lr_rows ? e->head_r : e->embed_tm, H, nullptr, 0, e->lr_rows ? (e->lr_rows + 15) / 16 * 16 : V, H,
+                           e->lr_rows ? e->shead_r : e->shead, e->xs_head);
+    if (e->lr_rows) { a.eos_col = e->lr_rows - 1; a.n_valid = e->lr_rows; }   // compacted head: columns = [range | EOS | padding to 16]
     a.part_val = e->part_val; a.part_idx = e->part_idx; a.mask_eos = e->sl.mask_eos;
     a.logits = keep_logits ? e->logits : nullptr; a.ld_logits = V;
     a.logits_bf16 = (keep_logits && e->n_sampling > 0) ? e->logits_bf16 : nullptr; a.ld_logits_bf16 = e->ldl;
@@ -1290,6 +1363,8 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
         if (samp[i].do_sample && (samp[i].top_k < 1 || !(samp[i].temperature > 0.f)))
             return fail(e, NTTS_EINVAL, "prompt %d: do_sample needs top_k >= 1 and temperature > 0 (got %d, %g)", i, samp[i].top_k, samp[i].temperature);
         if (samp[i].eos_token_id < 0 || samp[i].eos_token_id >= c.vocab_size) return fail(e, NTTS_EINVAL, "eos id out of range");
+        if (e->lr_rows && samp[i].eos_token_id != e->lr_eos)
+            return fail(e, NTTS_EINVAL, "prompt %d: eos id %d, but the restricted lm_head was set up for eos id %d (ntts_backbone_set_logits_range)", i, samp[i].eos_token_id, e->lr_eos);
         if (donor_slot && donor_slot[i] >= 0) {
             // the donor is a running slot, or a prompt given EARLIER in this call (its pages are filled by the same
             // launches: the rope/KV-write kernel of a layer completes before that layer's attention kernel starts)
@@ -1963,6 +2038,16 @@ extern "C" int ntts_backbone_read_logits(ntts_backbone* e, int32_t slot, float* 
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     if (n > e->cfg.vocab_size) n = e->cfg.vocab_size;
+    if (e->lr_rows) {        // restricted head: the kept row is in column order [range | EOS]; hand it out by token id, -inf elsewhere
+        std::vector<float> row(e->lr_rows);
+        HIPCHK(e, hipMemcpy(row.data(), e->logits + (size_t)slot * e->cfg.vocab_size, (size_t)e->lr_rows * sizeof(float), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) out[i] = -INFINITY;
+        for (int c = 0; c < e->lr_rows; ++c) {
+            const int id = c < e->lr_rows - 1 ? e->lr_lo + c : e->lr_eos;
+            if (id < n) out[id] = row[c];
+        }
+        return NTTS_OK;
+    }
     HIPCHK(e, hipMemcpy(out, e->logits + (size_t)slot * e->cfg.vocab_size, n * sizeof(float), hipMemcpyDeviceToHost));
     return NTTS_OK;
 }
@@ -1990,7 +2075,8 @@ extern "C" int ntts_backbone_step_bytes(ntts_backbone* e, double* bytes) {
     const double mats = (QD + 2 * KD) * H + H * QD + 3 * F * H, small = (QD + 2 * KD) + 2 * H;
     const double sc = e->fp8 ? ((QD + 2 * KD) + 2 * H + 2 * F) * 4.0 : 0.0;
     const double w_layers = (mats * wb + small * 2.0 + sc) * c.num_layers + H * 2.0;
-    const double w_head = (double)c.vocab_size * H * wb + (e->fp8 ? c.vocab_size * 4.0 : 0.0);
+    const double head_rows = e->lr_rows ? e->lr_rows : c.vocab_size;     // (restricted head: the rows it streams)
+    const double w_head = head_rows * H * wb + (e->fp8 ? head_rows * 4.0 : 0.0);
     const double kv_tok = (double)c.num_layers * 2 * KD * 2.0;  // bytes per cached token (K+V, all layers)
     double kv = 0;
     for (int b = 0; b < B; ++b)
@@ -2120,7 +2206,7 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
                 *launches_per_step = L; break;
         case 3: *alg_bytes = (double)2 * F * H * wb + act * (H + F); *launches_per_step = L; break;
         case 4: *alg_bytes = (double)H * F * wb + act * F + (double)gemm_nsplit(F, ksd, kt_) * B * H * 4.0; *launches_per_step = L; break;
-        case 5: *alg_bytes = (double)c.vocab_size * H * wb + act * H; *launches_per_step = 1; break;
+        case 5: *alg_bytes = (double)(e->lr_rows ? e->lr_rows : c.vocab_size) * H * wb + act * H; *launches_per_step = 1; break;
         case 6: *alg_bytes = (double)gemm_nsplit(e->small ? F : QD, e->small ? ksd : kso, kt_) * B * H * 4.0 + (double)B * 2.0 * H * 2 + act * H;
                 *launches_per_step = e->small ? 1 : 2 * L; break;
         default: return fail(e, NTTS_EINVAL, "unknown kernel id %d", which);

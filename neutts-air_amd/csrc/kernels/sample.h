@@ -46,6 +46,9 @@ struct SampleArgs {
     int vocab;
     SlotArrays sl;
     int phase;               // SLOT_RUNNING: decode step; SLOT_PREFILLED: first token after prefill
+    // compacted head (ntts_backbone_set_logits_range): column c of the lm_head is token id_base + c for c < n_range and the EOS id for
+    // c == n_range; n_range = 0: column = token id
+    int n_range, id_base, id_tail;
 };
 
 constexpr int kSampleCap = 512;   // candidates kept (k plus ties at the k-th value, capped)
@@ -264,7 +267,8 @@ NTTS_KERNEL(256) void sample_greedy_kernel(SampleArgs p) {
             if (sv[w] > best || (sv[w] == best && si[w] < bidx)) { best = sv[w]; bidx = si[w]; }
         SlotArrays& s = p.sl;
         if (live) {
-            const int tok = k > 0 ? sampled : bidx;
+            int tok = k > 0 ? sampled : bidx;
+            if (p.n_range > 0) tok = tok < p.n_range ? tok + p.id_base : p.id_tail;
             const int n = (p.phase == SLOT_PREFILLED) ? 0 : s.n_new[b];
             s.out_tokens[(long)b * s.out_stride + n] = tok;
             s.n_new[b] = n + 1;
@@ -344,6 +348,19 @@ NTTS_KERNEL(256) void pack_weight_kernel(const void* src, int src_is_f32, bf16_t
     }
 }
 
+// Compacted lm_head (ntts_backbone_set_logits_range): row r of dst = row rows[r] of src, both tile-major in 64-row x 128-byte blocks
+// (esz = 2: 64 bf16 per block row, esz = 1: 128 e4m3); one workgroup per destination row, 16 bytes per thread and k-tile; the fp8 head's
+// per-row scales travel along
+NTTS_KERNEL(64) void gather_head_rows_kernel(const unsigned char* src, unsigned char* dst, const int* rows, long K_bytes, const float* sc_src, float* sc_dst) {
+    const long r = blockIdx.x, sr = rows[r];
+    const long ktiles = K_bytes / 128;
+    for (long i = threadIdx.x; i < ktiles * 8; i += 64) {
+        const long kt = i >> 3, c = i & 7;
+        *(u32x4*)(dst + (r >> 6) * 64 * K_bytes + kt * 8192 + (r & 63) * 128 + c * 16) =
+            *(const u32x4*)(src + (sr >> 6) * 64 * K_bytes + kt * 8192 + (sr & 63) * 128 + c * 16);
+    }
+    if (sc_src && threadIdx.x == 0) sc_dst[r] = sc_src[sr];
+}
 // ids -> codec codes on the device (ref:neutts/neutts.py:349 tokenizer.decode + :276 regex, as one pass): of slot s's new ids
 // keep those in [speech_base, speech_base + n_codes), as id - speech_base, in order; `modulo` (synthetic benchmark only: random
 // weights do not stay in the speech range) maps every id to id mod n_codes instead.  One workgroup per utterance.

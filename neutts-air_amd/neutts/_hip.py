@@ -101,6 +101,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_backbone_prefill_shared": (C.c_int, [p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(SamplingC),
                                                    C.POINTER(i32), C.POINTER(i32)]),
         "ntts_backbone_set_gang": (C.c_int, [p, i32]),
+        "ntts_backbone_set_logits_range": (C.c_int, [p, i32, i32, i32]),
         "ntts_backbone_kv_stats": (C.c_int, [p, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64), C.POINTER(i64)]),
         "ntts_backbone_decode": (C.c_int, [p, i32]),
         "ntts_backbone_read": (C.c_int, [p, i32, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(i32)]),
@@ -332,6 +333,8 @@ class BackboneEngine:
             ptr, nbytes = self.arena()
             t.arena_copy(ptr, nbytes, True)
             t.adopt_arena()
+        if getattr(self, "logits_range", None):
+            t.set_logits_range(*self.logits_range)          # (an opt-in restricted lm_head goes along: its own compacted copy)
         return t
 
     # -- requests
@@ -491,6 +494,15 @@ class BackboneEngine:
         """Tell the engine how many decode chains (engines of an EngineGang, itself included) run side by side on the GPU: the
         decode step's GEMM tiles and XCD placement are chosen for that (ntts_backbone_set_gang); the captured step graph is dropped."""
         self._chk(self.lib.ntts_backbone_set_gang(self.h, int(chains)))
+
+    def set_logits_range(self, lo: Optional[int], hi: int = 0, eos_id: int = 0):
+        """OPT-IN: lm_head over the token ids [lo, hi) + eos_id only (ntts_backbone_set_logits_range; lo=None restores the full head).
+        The reference takes its argmax / top-k over the whole vocabulary: identical ids only while its choice lies in the range."""
+        if lo is None:
+            self._chk(self.lib.ntts_backbone_set_logits_range(self.h, -1, 0, 0))
+        else:
+            self._chk(self.lib.ntts_backbone_set_logits_range(self.h, int(lo), int(hi), int(eos_id)))
+        self.logits_range = None if lo is None else (int(lo), int(hi), int(eos_id))
 
     def set_stream(self, stream: Optional[int]):
         """Run the engine's work on the caller's HIP stream (a hipStream_t as an integer, e.g. torch.cuda.Stream().cuda_stream); None = its own."""

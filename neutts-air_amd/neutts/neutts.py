@@ -165,6 +165,7 @@ class NeuTTS:
         lib_path: Optional[str] = None,
         do_sample: bool = True,
         seed: int = 0,
+        speech_range_head: bool = False,
     ):
         # Consts (ref:neutts/neutts.py:84-91)
         self.sample_rate = 24_000
@@ -195,6 +196,14 @@ class NeuTTS:
         # engines > 1 (serving; the reference runs one utterance at a time): that many backbone engines of `max_batch` slots each on
         # ONE copy of the weights, their decode chains side by side on the GPU (neutts._hip.EngineGang) -- infer_batch deals its
         # utterances out over them.  infer / infer_stream stay on the first engine.
+        # speech_range_head=True (OPT-IN, off by default; SURVEY 7 "hard parts"): the lm_head over `<|speech_0|>` ... `<|speech_65535|>` +
+        # `<|SPEECH_GENERATION_END|>` only -- the ids ref:neutts/neutts.py:276,336-341 can do anything with -- a third of the head's
+        # bytes per decode step.  The reference samples over the whole vocabulary: the ids are its ids only while its choice lies in
+        # that range (a trained checkpoint after a well-formed prompt), so this is a serving option, not the parity configuration.
+        if speech_range_head:
+            if self._speech_base is None or self._eos_id is None:
+                raise RuntimeError("speech_range_head needs the ids of <|speech_0|> and <|SPEECH_GENERATION_END|> (tokenizer, or 'speech_base' / 'eos_token_id' with in-memory weights)")
+            self.backbone.set_logits_range(int(self._speech_base), int(self._speech_base) + 65536, int(self._eos_id))
         self.gang = _hip.EngineGang(self.backbone, engines) if engines > 1 else None
 
         try:  # optional watermarker, as the reference (ref:neutts/neutts.py:110-121)

@@ -79,6 +79,11 @@ def test_bench_contract_world8(emu_lib):
     for rank in range(8):          # the per-rank start-up timeline (library, engines, weights received, warm-up)
         assert f"rank {rank}/8" in r.stderr and "warm-up done" in r.stderr
     assert r.stderr.count("weights received") == 8 and r.stderr.count("weights synthesised and uploaded (rank 0)") == 1
+    # round 5: the job counts its ranks inside the timed region and reports the launching threads' host time over ranks
+    assert rec["ranks_in_timed_region"] == 8
+    hw = rec["host_wall_over_ranks"]
+    for k in ("host_ms_in_calls_per_step", "step_wall_ms"):
+        assert hw[k]["max_over_ranks"] >= hw[k]["mean_over_ranks"] > 0
 
 
 def test_bench_two_gangs_taking_turns_emulator(emu_lib):

@@ -262,3 +262,62 @@ def test_fp8_prequantised_checkpoint_equals_quantise_on_upload(lib):
     with pytest.raises(_hip.NeuTTSHipError):
         eng.load_tensor(k2, pre[k2])                                        # fp8 bytes for a bf16 engine
     eng.close()
+
+
+@pytest.mark.parametrize("knobs", [{"NTTS_SMALL_BATCH": "8"}, {"NTTS_SMALL_BATCH": "0"}, {"NTTS_SMALL_BATCH": "0", "NTTS_HEAD_TILE": "4"},
+                                   {"NTTS_SMALL_BATCH": "0", "NTTS_HEAD_TILE": "2"}, {"NTTS_SMALL_BATCH": "0", "NTTS_HEAD_TILE": "1"}],
+                         ids=["gemv", "tile64", "tile288", "tile256", "tile128"])
+def test_speech_range_head_is_the_full_head_inside_the_range(lib, knobs, monkeypatch):
+    """ABI 8 ntts_backbone_set_logits_range (OPT-IN; SURVEY 7 "hard parts"): the lm_head over the ids [lo, hi) + EOS only, as a compacted
+    copy of those rows.  (1) On walk weights that walk the ids of the range, the free-running ids are those of the full head -- on the
+    GEMV path and on every lm_head tile, 257 rows = padding in every one of them; (2) the logits tap hands the row out by token id: equal
+    to the full head's inside the range and at the EOS, -inf elsewhere; (3) top_k = 1 sampling is greedy; (4) a request with another EOS
+    id is refused; (5) on RANDOM weights every id lies in range + EOS and is the argmax of the oracle's logits over that set (teacher-forced
+    along the engine's path), EOS masked until min_new_tokens and taken once it wins; (6) lo = None restores the full head."""
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    cfg = br.BackboneConfig.tiny(vocab_size=512, num_layers=1)
+    lo, hi, eos, N = 200, 456, 500, 10
+    w = br.make_weights(cfg, 5, walk_gain=4.0, walk_range=(lo, hi))
+    eng = _engine(cfg, w, lib, max_batch=3)
+    prompts = [br.synthetic_prompt(cfg, i, n)[:-1] + [lo + 17 * (i + 1)] for i, n in enumerate((33, 7, 20))]
+    samp = [_hip.Sampling(max_length=len(p) + N, min_new_tokens=N, eos_token_id=eos, do_sample=False) for p in prompts]
+    full = eng.generate(prompts, samp, steps_per_poll=4)
+    assert all(lo <= t < hi for g in full for t in g) and all(len(set(g)) == N for g in full)
+    eng.set_debug(True)
+    eng.prefill(prompts[:1], [0], samp[:1])
+    row_full = eng.read_logits(0)
+    eng.release(0)
+    eng.set_logits_range(lo, hi, eos)
+    assert eng.generate(prompts, samp, steps_per_poll=4) == full
+    eng.prefill(prompts[:1], [0], samp[:1])
+    row = eng.read_logits(0)
+    eng.release(0)
+    keep = np.zeros(cfg.vocab_size, dtype=bool)
+    keep[lo:hi] = True
+    assert np.array_equal(row[keep], row_full[keep]) and np.isneginf(row[~keep]).all()          # (EOS is masked in both: min_new_tokens > 0)
+    k1 = [_hip.Sampling(max_length=len(p) + N, min_new_tokens=N, eos_token_id=eos, do_sample=True, top_k=1, temperature=0.8, seed=3 + i) for i, p in enumerate(prompts)]
+    assert eng.generate(prompts, k1, steps_per_poll=4) == full
+    with pytest.raises(_hip.NeuTTSHipError):
+        eng.prefill(prompts[:1], [0], [_hip.Sampling(max_length=64, min_new_tokens=2, eos_token_id=eos - 1, do_sample=False)])
+    with pytest.raises(_hip.NeuTTSHipError):
+        eng.set_logits_range(lo, hi, lo + 3)                      # an EOS id inside the range
+    eng.set_logits_range(None)
+    assert eng.generate(prompts, samp, steps_per_poll=4) == full
+    eng.close()
+    # (5) random weights: the restricted argmax, step by step, against the oracle's logits
+    w2 = br.make_weights(cfg, 9)
+    wd2 = br.cast_weights(w2, torch.bfloat16)
+    eng = _engine(cfg, w2, lib, max_batch=2)
+    eng.set_logits_range(lo, hi, eos)
+    M, mn = 12, 4
+    p2 = [br.synthetic_prompt(cfg, 40 + i, 9 + 20 * i) for i in range(2)]
+    got = eng.generate(p2, [_hip.Sampling(max_length=len(p) + M, min_new_tokens=mn, eos_token_id=eos, do_sample=False) for p in p2], steps_per_poll=3)
+    for p, ids in zip(p2, got):
+        assert 1 <= len(ids) <= M and all((lo <= t < hi) or t == eos for t in ids) and eos not in ids[:mn] and eos not in ids[:-1]
+        ref = br.generate(cfg, wd2, p, len(p) + len(ids), eos, min_new_tokens=0, force_ids=ids, keep_logits=True)
+        for k, (tok, lg) in enumerate(zip(ids, ref.logits)):
+            allowed = lg[lo:hi].max() if k < mn else torch.maximum(lg[lo:hi].max(), lg[eos])
+            assert float(lg[tok]) >= float(allowed) - 2.0 * br.bf16_ulp(float(allowed)), (k, tok, float(lg[tok]), float(allowed))
+        assert len(ids) == M or ids[-1] == eos
+    eng.close()
