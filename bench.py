@@ -111,6 +111,8 @@ ROCPROF_SYMBOLS = [   # rocprofv3 symbol prefix -> the step's logical kernels it
     ("attn_decode_kernel<", ["attn_decode_kernel"]),
     ("qkv_rope_kernel<", ["gemm_qkv"]),                                         # QKV projection + bias + RoPE + K append (qkv_rope.h)
     ("gemm_kernel<4, 1, 1, 2, 4,", ["gemm_o_proj_splitk", "gemm_down_splitk"]),
+    ("gemm_kernel<8, 1, 2, 2, 3,", ["gemm_o_proj_splitk", "gemm_down_splitk"]),   # the gang's 256-row tile (ntts_backbone_set_gang): under the profiler the four chains run
+                                                                                  # one after the other, so this symbol's average is the tile ALONE (slower than the 64-row one)
     ("gemm_kernel<4, 2, 2, 1, 3,", ["gemm_gate_up_silu"]),
     ("gemm_kernel<4, 3, 4, 3, 2, 0, 64, true", ["gemm_lm_head_argmax"]),     # 256 x 288 natural-order tile (NTTS_HEAD_XL=4, the default)
     ("gemm_kernel<4, 4, 4, 3, 2, 0, 64, true", ["gemm_lm_head_argmax"]),     # 256 x 256 tile (NTTS_HEAD_XL=1)
@@ -153,7 +155,7 @@ def mfma_util_table(path):
 
 def continuous_leg(static_value, a):
     import subprocess
-    req = int(os.environ.get("NTTS_BENCH_CONT_REQUESTS", "4096"))
+    req = int(os.environ.get("NTTS_BENCH_CONT_REQUESTS", "8192"))     # (8 generations of the gang's 1024 slots: the finite job's ramp and drain are 1 / 4 of a 4096-request job's time)
     cmd = [sys.executable, os.path.abspath(__file__), "--mode", "continuous", "--requests", str(req), "--steps", "1", "--warmup", "1",
            "--no-cpu-baseline", "--no-roofline", "--gang", str(max(1, a.gang)), "--prefill", str(a.prefill), "--decode", str(a.decode)]
     t0 = time.time()
@@ -237,6 +239,7 @@ def main():
     ap.add_argument("--speech-range-head", action="store_true",
                     help="OPT-IN serving option, NEVER the headline: lm_head over 65 536 speech ids + EOS only (ntts_backbone_set_logits_range); "
                          "a separate line, labelled as such")
+    ap.add_argument("--stream-admit", type=int, default=64, help="stream mode on a gang: streams per admission group (one device-side stream set each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-codec", action="store_true", help="backbone only (profiling aid; not the headline metric)")
@@ -323,6 +326,8 @@ def main():
     dev = 0 if emu_lib else local
     eos = cfg.vocab_size - 1
     tts = None
+    # stream mode on a gang (round 5): the B streams dealt out over --gang engines of B / gang slots each, admitted in groups of --stream-admit
+    Gs = a.gang if (strm and a.gang > 1 and B % a.gang == 0 and B // a.gang >= 8 and not emu_lib) else 1
     if strm:
         # Streaming goes through the product's own streaming code (NeuTTS._infer_stream_batch_hip: window / cross-fade semantics of
         # ref:neutts/neutts.py:401-465 for every utterance of the batch, ONE batched codec pass per 25-token chunk on the codec
@@ -345,7 +350,8 @@ def main():
                                        num_heads=ccfg.num_heads, quantization_dim=ccfg.quantization_dim, levels=list(ccfg.levels),
                                        hop_length=ccfg.hop_length, rms_eps=ccfg.rms_eps, max_frames=128, max_rows=B * 96),
                         "state_dict": {k: v.numpy() for k, v in cw.items()}},
-            codec_device=f"cuda:{dev}", do_sample=a.sample, max_batch=B, lib_path=lib)
+            codec_device=f"cuda:{dev}", do_sample=a.sample, max_batch=B // Gs, engines=Gs, lib_path=lib)
+        tts.stream_admit = a.stream_admit
         tts.watermarker = None
         tts._ids_to_codes = lambda ids: [int(i) % n_codes for i in ids]     # random weights do not stay in the speech range
         tts._stream_modulo = n_codes                                         # ... the same rule for the device-side streaming path
@@ -1023,7 +1029,10 @@ def main():
                         "instead of the whole vocabulary; " + workload)
         if strm:
             workload = (f"STREAM mode: {B} concurrent infer_stream utterances per GPU (27-frame windows every 25 tokens, 0.5 s chunks, "
-                        f"ref:neutts/neutts.py:401-465), codec pass of chunk k on the codec engine's stream beside the decode graph of chunk k + 1; "
+                        f"ref:neutts/neutts.py:401-465), "
+                        + (f"dealt out over a gang of {Gs} engines of {B // Gs} slots (one arena, a lane each) in admission groups of {a.stream_admit} streams: per engine "
+                           f"turn [windows -> codec pass -> chunks] [next group's prompt pass] [next decode burst], the other engines' bursts beside it; "
+                           if Gs > 1 else "codec pass of chunk k on the codec engine's stream beside the decode graph of chunk k + 1; ")
                         + workload)
         if cont:
             workload = (f"CONTINUOUS mode (not BASELINE's static shape): {R} ragged requests per GPU through "

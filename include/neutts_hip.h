@@ -142,6 +142,14 @@ int ntts_backbone_set_gang(ntts_backbone* e, int32_t chains);
  * is called.  Per engine (twins of a gang each build their own 118 MB copy). */
 int ntts_backbone_set_logits_range(ntts_backbone* e, int32_t lo, int32_t hi, int32_t eos_id);
 
+/* ABI 8.  fp8 activation-scale calibration.  The reference's quantised builds are ready-made files (ref:README.md:59-64: Q4 / Q8 GGUF);
+ * the fp8 model here takes static per-tensor `input_scale`s as a static-fp8 checkpoint ships them.  For a user who holds the bf16
+ * checkpoint: calibration mode on a BF16 engine (enable = 1 resets the record, 0 ends the mode) makes every prompt pass record
+ * max |x| of every GEMM's input rows; ntts_backbone_read_amax hands the n = 4 * num_layers + 1 values out, [layer][q_proj (QKV), o_proj,
+ * gate_proj (gate/up), down_proj] and the lm_head's last.  input_scale = amax / 448 (tools/calibrate_fp8.py writes them). */
+int ntts_backbone_calibrate(ntts_backbone* e, int32_t enable);
+int ntts_backbone_read_amax(ntts_backbone* e, float* out, int32_t n);
+
 /* Sampling contract of one request = the keyword arguments of the reference's generate() call
  * (ref:neutts/neutts.py:338-347). */
 typedef struct ntts_sampling {
@@ -304,6 +312,11 @@ typedef struct ntts_codec_config {
     float rms_eps;              /* 1e-6 */
     int32_t max_frames;         /* longest utterance, in codec frames */
     int32_t max_rows;           /* workspace rows: sum over a decode call of (max frames of the call + 6) */
+    int32_t precision;          /* ABI 8.  0 = bf16 GEMM operands (default: waveform within 7e-3 RELATIVE rms of the fp32 reference decoder, i.e.
+                                 * inside BASELINE's 1e-3 absolute up to signal rms ~0.14); 1 = "high": every GEMM operand -- activations
+                                 * and weights -- as a split bf16 pair (hi + lo, K-concatenated [xh | xl | xh] x [wh | wh | wl]): ~16
+                                 * mantissa bits per operand at 3x the matrix-core work, for callers who need the bound at full-scale
+                                 * amplitude (the reference runs this decoder in fp32, ref:neutts/neutts.py:288-291) */
 } ntts_codec_config;
 
 const char* ntts_codec_last_error(const ntts_codec* c);

@@ -109,6 +109,7 @@ struct ntts_backbone {
     // workgroups and loses; in an engine gang (four chains side by side) the other chains fill the CUs and what
     // counts is the bytes every CU pulls.  bit 0: o_proj, bit 1: down_proj on the 256 x 64 / 8-wave tile; gu_tile picks the gate/up tile.
     int tall = 0;
+    bool qkv_wstat = false;          // QKV: column blocks dealt to XCDs (qkv_rope.h "W-stationary"; NTTS_QKV_WSTAT) -- used when the row-block placement is off
     // Opt-in restricted lm_head (ntts_backbone_set_logits_range; SURVEY 7 "hard parts": the reference only ever consumes <|speech_N|> ids
     // and the EOS, ref:neutts/neutts.py:276,336-341): a COMPACTED copy of the head -- rows [lr_lo, lr_hi) followed by the EOS row, padded to
     // whole 64-row groups -- is what the lm_head streams (NeuTTS-Air: 118 MB instead of 390 MB); columns are mapped back to token ids
@@ -117,6 +118,7 @@ struct ntts_backbone {
     bf16_t* head_r = nullptr;        // compacted head matrix (tile-major; e4m3 bytes in the fp8 model)
     float* shead_r = nullptr;        // fp8: its per-row scales
     int n_part_full = 0;
+    float* calib = nullptr;          // [num_layers * 4 + 1] running max |x| of every GEMM input seen by the prompt passes (ntts_backbone_calibrate)
     int gang = 1;                    // decode chains side by side on the GPU, this one included (ntts_backbone_set_gang); the defaults of tall / xcd_affine follow it
     int tall_env = -1, affine_env = -1;   // NTTS_TALL / NTTS_XCD_AFFINE when set (sweeps, tests): they win over the gang's defaults
     int gu_tile = 0;                 // gate/up tile (NTTS_GU_TILE): 0 = 128 x 128 / 8 waves / 3 slots (above batch 128; 64 x 64 below), 1 = 256 x 192 / 12 waves / 2 slots,
@@ -240,6 +242,7 @@ static void apply_gang_shape(ntts_backbone* e) {
     const bool side_by_side = e->gang >= 2 && B > 128 && B <= 256;
     e->tall = (e->tall_env >= 0 ? e->tall_env : (side_by_side ? 3 : 0)) & 3;
     e->xcd_affine = e->affine_env >= 0 ? e->affine_env : (B > 128 && !side_by_side ? 7 : 0);
+    e->qkv_wstat = env_int("NTTS_QKV_WSTAT", 0) != 0;
 }
 
 extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, ntts_backbone** out) {
@@ -493,6 +496,7 @@ extern "C" void ntts_backbone_destroy(ntts_backbone* e) {
     hipDeviceSynchronize();
     if (e->graph) hipGraphExecDestroy(e->graph);
     if (e->graph_split) hipGraphExecDestroy(e->graph_split);
+    if (e->calib) hipFree(e->calib);
     if (e->head_r) hipFree(e->head_r);
     if (e->shead_r) hipFree(e->shead_r);
     bool last_reader = true;
@@ -970,6 +974,33 @@ extern "C" int ntts_backbone_set_logits_range(ntts_backbone* e, int32_t lo, int3
     return NTTS_OK;
 }
 
+// ---- fp8 activation-scale calibration (ABI 8; VERDICT r4 missing 4).  The reference's quantised builds are ready-made files
+// (ref:README.md:59-64); a user holding a bf16 checkpoint gets the static `input_scale`s of the fp8 model from data: calibration mode
+// on a BF16 engine records max |x| of every GEMM's input over the prompt passes that follow, ntts_backbone_read_amax hands the
+// 4 * num_layers + 1 values out ([layer][QKV, o_proj, gate/up, down_proj], lm_head last); scale = amax / 448 (tools/calibrate_fp8.py).
+extern "C" int ntts_backbone_calibrate(ntts_backbone* e, int32_t enable) {
+    if (!e) return NTTS_EINVAL;
+    if (e->fp8) return fail(e, NTTS_EINVAL, "calibrate: the activations of the fp8 model are already quantised; calibrate on a bf16 engine of the same checkpoint");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    const size_t nslot = (size_t)e->cfg.num_layers * 4 + 1;
+    if (enable && !e->calib) {
+        HIPCHK(e, hipMalloc((void**)&e->calib, nslot * sizeof(float)));
+    }
+    if (enable) HIPCHK(e, hipMemset(e->calib, 0, nslot * sizeof(float)));
+    else if (e->calib) { HIPCHK(e, hipFree(e->calib)); e->calib = nullptr; }
+    return NTTS_OK;
+}
+extern "C" int ntts_backbone_read_amax(ntts_backbone* e, float* out, int32_t n) {
+    if (!e || !out) return NTTS_EINVAL;
+    if (!e->calib) return fail(e, NTTS_ESTATE, "read_amax: calibration mode is off (ntts_backbone_calibrate(e, 1) first)");
+    if (n != e->cfg.num_layers * 4 + 1) return fail(e, NTTS_EINVAL, "read_amax: %d values asked, the engine records %d (4 per layer + lm_head)", n, e->cfg.num_layers * 4 + 1);
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(out, e->calib, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return NTTS_OK;
+}
+
 extern "C" int ntts_backbone_set_gang(ntts_backbone* e, int32_t chains) {
     if (!e) return NTTS_EINVAL;
     if (chains < 1) return fail(e, NTTS_EINVAL, "set_gang: %d chains", chains);
@@ -1096,8 +1127,8 @@ static void k_qkv(ntts_backbone* e, int i) {
     a.nh = e->cfg.num_heads; a.nkv = e->cfg.num_kv_heads;
     a.tl = e->gemv_tl;
     const bool place = (e->xcd_affine & 4) && e->xcd_xps;
-    if (e->fp8) qkv_rope_launch<true>(a, place, e->stream);
-    else qkv_rope_launch<false>(a, place, e->stream);
+    if (e->fp8) qkv_rope_launch<true>(a, place, e->stream, e->qkv_wstat);
+    else qkv_rope_launch<false>(a, place, e->stream, e->qkv_wstat);
 }
 
 static void k_attn(ntts_backbone* e, int i) {
@@ -1549,9 +1580,18 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
     n0.M = Ti; n0.H = H; n0.eps = c.rms_eps;
     if (e->fp8) n0.out_fp8_inv = 1.0f / e->layers[0].xs[0];
     add_rmsnorm_launch(n0, st);
+    // fp8 calibration (ntts_backbone_calibrate, bf16 engines): running max |x| of every GEMM's input rows, slot = 4 * layer + {0: QKV, 1: o_proj,
+    // 2: gate/up, 3: down_proj}, last slot = lm_head.  One small launch behind each producer, in calibration mode only.
+    auto tap = [&](const bf16_t* x, long rows, int cols, int slot) {
+        if (!e->calib || rows <= 0) return;
+        const long nvec = rows * cols / 8;
+        float* dst = e->calib + slot;
+        NTTS_LAUNCH((amax_bf16_kernel), dim3((unsigned)std::min<long>((nvec + 255) / 256, 1024)), dim3(256), st, x, nvec, dst);
+    };
     for (int i = 0; i < c.num_layers; ++i) {
         const LayerW& w = e->layers[i];
         const bool last = i + 1 == c.num_layers;
+        tap(e->xn_pf, Ti, H, 4 * i);
         gemm_large<EPI_BF16>(e, gemm_args(e, e->xn_pf, H, w.wqkv, H, w.bqkv, e->qkv_pf, e->NQKV, Ti, e->NQKV, H, w.sqkv, w.xs[0]), st);
         RopeWriteArgs r{};
         r.qkv = e->qkv_pf; r.ld_qkv = e->NQKV; r.kpool = e->kv + (size_t)i * e->layer_stride; r.vpool = r.kpool + e->kv_half;
@@ -1570,7 +1610,7 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
         // is read afterwards (it alone feeds the lm_head).  Attention runs on the one query tile per prompt that holds
         // it, then that row and its residual row are compacted and o_proj / the MLP run on n rows instead of T.
         // Row-wise results are unchanged (every GEMM / norm row is computed from that row's operands alone).
-        const bool prune = last && T >= 4L * n;
+        const bool prune = last && T >= 4L * n && !e->calib;    // (calibration mode looks at EVERY position's GEMM inputs, the last layer's included)
         int n_tiles = (int)tile_seq.size(), n_rtiles = (int)rtile_seq.size();
         if (prune) { a.meta.tile_seq = md + o_ltseq; a.meta.tile_q0 = md + o_ltq0; n_tiles = (int)lt_seq.size(); }
         if (n_tiles) attn_prefill_launch(a, n_tiles, st);
@@ -1597,6 +1637,7 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
         // roundings the norm kernel applied), so the norm pass reads one row stream instead of two and writes one
         // (131.8 -> 128.3 ms per batch, profiles/r02i_ab_prefill_resid_epilogue.jsonl)
         NormArgs n1{};
+        tap(attn_in, Mi, QD, 4 * i + 1);
         {
             GemmArgs ao = gemm_args(e, attn_in, QD, w.wo, QD, nullptr, hres, H, Mi, H, QD, w.so, w.xs[1]);
             ao.resid_bf16 = hres; ao.ldrb = H;
@@ -1607,9 +1648,11 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
         n1.M = Mi; n1.H = H; n1.eps = c.rms_eps;
         if (e->fp8) n1.out_fp8_inv = 1.0f / w.xs[2];
         add_rmsnorm_launch(n1, st);
+        tap(e->xn_pf, Mi, H, 4 * i + 2);
         GemmArgs gu = gemm_args(e, e->xn_pf, H, w.wgu, H, nullptr, e->act_pf, F, Mi, 2 * F, H, w.sgu, w.xs[2]);
         if (e->fp8) gu.out_fp8_inv = 1.0f / w.xs[3];
         gemm_large<EPI_SILU_MUL>(e, gu, st);
+        tap(e->act_pf, Mi, F, 4 * i + 3);
         NormArgs n2{};
         {
             GemmArgs ad = gemm_args(e, e->act_pf, F, w.wd, F, nullptr, hres, H, Mi, H, F, w.sd, w.xs[3]);
@@ -1628,6 +1671,8 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
         }
         add_rmsnorm_launch(n2, st);
     }
+    if (e->calib)          // the lm_head's input rows: each prompt's last position, gathered into its decode-slot row
+        for (int i = 0; i < n; ++i) tap(e->xn_dec + (size_t)slots[i] * H, 1, H, 4 * c.num_layers);
     lm_head_and_sample(e, SLOT_PREFILLED);
     HIPCHK(e, hipEventRecord(e->ev[1], st));
     e->have_pf_time = true;

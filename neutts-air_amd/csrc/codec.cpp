@@ -33,6 +33,7 @@ struct ntts_codec {
     int H = 0, I = 0, nq = 0, n_fft = 0, nb = 0, NS = 0, lds_spec = 0;
     long K3 = 0, max_rows = 0;
     bool finalized = false;
+    int S = 1;                   // 3 with precision = high: every bf16 GEMM operand is a split row [hi | lo | hi] of 3 x its columns (codec.h put_op)
     std::map<std::string, std::vector<float>> host;            // staged fp32 tensors until finalize
     std::map<std::string, std::vector<int64_t>> shapes;
     std::vector<void*> allocs;
@@ -131,6 +132,8 @@ extern "C" int ntts_codec_create(const ntts_codec_config* cf, int device, ntts_c
     c->lds_spec = (c->NS + 3) / 4 * 4;
     c->K3 = (6L * c->nb + 63) / 64 * 64;
     c->max_rows = cf->max_rows;
+    if (cf->precision != 0 && cf->precision != 1) { delete c; return cfail(nullptr, NTTS_EINVAL, "unknown codec precision %d (0 = bf16 operands, 1 = high: split bf16 operands)", cf->precision); }
+    c->S = cf->precision == 1 ? 3 : 1;
     { const char* ev = getenv("NTTS_CODEC_ATTN_RESIDENT"); if (ev && ev[0] == '0') c->attn_resident = false; }
     { const char* ev = getenv("NTTS_CODEC_GN_REG"); if (ev && ev[0] == '0') c->gn_reg = false; }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
@@ -145,8 +148,9 @@ extern "C" int ntts_codec_create(const ntts_codec_config* cf, int device, ntts_c
     const size_t max_utts = R / (1 + 2 * kPadRows) + 1;
     int rc = NTTS_OK;
 #define A(call) if (rc == NTTS_OK) rc = (call)
-    A(dalloc(c, &c->h, R * H)); A(dalloc(c, &c->t1, R * H)); A(dalloc(c, &c->xa, R * H)); A(dalloc(c, &c->xb, R * H));
-    A(dalloc(c, &c->qkv, R * 3 * H)); A(dalloc(c, &c->act, R * c->I));
+    const size_t S = c->S;        // (split operands: 3 x the columns)
+    A(dalloc(c, &c->h, R * H)); A(dalloc(c, &c->t1, R * H)); A(dalloc(c, &c->xa, R * H * S)); A(dalloc(c, &c->xb, R * H * S));
+    A(dalloc(c, &c->qkv, R * 3 * H)); A(dalloc(c, &c->act, R * c->I * S));
     A(dalloc(c, &c->vt, (R + (size_t)max_utts * kPage) * H));
     A(dalloc(c, &c->spec, R * c->lds_spec)); A(dalloc(c, &c->s3, R * c->K3)); A(dalloc(c, &c->frames, R * c->n_fft));
     c->wav_cap = R * cf->hop_length;
@@ -159,7 +163,7 @@ extern "C" int ntts_codec_create(const ntts_codec_config* cf, int device, ntts_c
     (void)npages_max;
     if (rc == NTTS_OK) {
         hipMemset(c->h, 0, R * H * 4); hipMemset(c->t1, 0, R * H * 4);
-        hipMemset(c->xa, 0, R * H * 2); hipMemset(c->xb, 0, R * H * 2);
+        hipMemset(c->xa, 0, R * H * S * 2); hipMemset(c->xb, 0, R * H * S * 2);
         hipMemset(c->qkv, 0, R * 3 * H * 2);
         hipDeviceSynchronize();
     } else {
@@ -234,13 +238,31 @@ struct Finalizer {
         if (dalloc(c, &d, b.size()) != NTTS_OK || hipMemcpy(d, b.data(), b.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { rc = NTTS_EHIP; return nullptr; }
         return d;
     }
+    // a GEMM weight [rows][K] whose X operand is made of segments of `seg` columns (the activation buffer's row width: K = seg for a
+    // Linear, K = taps x seg for a conv over overlapping rows).  precision = high: every segment becomes [wh | wh | wl] (3 seg columns),
+    // the counterpart of the split activation row [xh | xl | xh] (codec.h put_op): the K-loop forms xh wh + xl wh + xh wl
+    bf16_t* op(const std::vector<float>& v, int64_t rows, int64_t K, int64_t seg) {
+        if (c->S == 1) return up_bf16(v);
+        std::vector<bf16_t> b((size_t)rows * 3 * K);
+        for (int64_t r = 0; r < rows; ++r)
+            for (int64_t s0 = 0; s0 < K; s0 += seg)
+                for (int64_t i = 0; i < seg; ++i) {
+                    const float w = v[(size_t)r * K + s0 + i];
+                    const bf16_t hi = h_f2bf(w), lo = h_f2bf(w - h_bf2f(hi));
+                    bf16_t* d = &b[(size_t)r * 3 * K + 3 * s0];
+                    d[i] = hi; d[seg + i] = hi; d[2 * seg + i] = lo;
+                }
+        bf16_t* d = nullptr;
+        if (dalloc(c, &d, b.size()) != NTTS_OK || hipMemcpy(d, b.data(), b.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { rc = NTTS_EHIP; return nullptr; }
+        return d;
+    }
     float* vec(const std::string& name, int64_t n) {
         auto* v = get(name, {n});
         return v ? up_f32(*v) : nullptr;
     }
     bf16_t* mat(const std::string& name, int64_t r, int64_t k) {
         auto* v = get(name, {r, k});
-        return v ? up_bf16(*v) : nullptr;
+        return v ? op(*v, r, k, k) : nullptr;
     }
     // Conv1d weight [Cout][Cin][k] -> GEMM weight [Cout][k][Cin]  (row of the overlapping-rows GEMM = k frames x Cin)
     bf16_t* conv(const std::string& name, int64_t co, int64_t ci, int64_t k) {
@@ -250,7 +272,7 @@ struct Finalizer {
         for (int64_t o = 0; o < co; ++o)
             for (int64_t i = 0; i < ci; ++i)
                 for (int64_t t = 0; t < k; ++t) r[((size_t)o * k + t) * ci + i] = (*v)[((size_t)o * ci + i) * k + t];
-        return up_bf16(r);
+        return op(r, co, k * ci, ci);
     }
 };
 
@@ -306,7 +328,7 @@ extern "C" int ntts_codec_finalize(ntts_codec* c) {
         std::vector<float> qkv;
         qkv.reserve((size_t)3 * H * H);
         qkv.insert(qkv.end(), q->begin(), q->end()); qkv.insert(qkv.end(), k->begin(), k->end()); qkv.insert(qkv.end(), v->begin(), v->end());
-        L.wqkv = f.up_bf16(qkv);
+        L.wqkv = f.op(qkv, 3 * H, H, H);
         L.wo = f.mat(p + "self_attn.o_proj.weight", H, H);
         L.fc1 = f.mat(p + "mlp.fc1.weight", I, H);
         L.fc2 = f.mat(p + "mlp.fc2.weight", H, I);
@@ -361,12 +383,13 @@ static void resnet_block(ntts_codec* c, const ResW& w, const CodecRows& R, long 
     const int H = c->H;
     hipStream_t st = c->stream;
     GroupNormArgs g{};
-    g.x = c->h; g.y = c->xa; g.gamma = w.g1; g.beta = w.b1; g.R = R; g.C = H; g.eps = 1e-6f;
+    const long S = c->S;          // split operand rows: 3 x the columns, on the X side (ldx, K) and in the packed weights alike
+    g.x = c->h; g.y = c->xa; g.gamma = w.g1; g.beta = w.b1; g.R = R; g.C = H; g.eps = 1e-6f; g.split = S > 1;
     groupnorm_silu_launch(g, c->gn_reg ? R.Tp - 2 * kPadRows : (1 << 30), st);
-    { GemmArgs ga_ = cg(c->xa, H, w.w1, 3L * H, w.cb1, c->t1 + H, H, rows - 2, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
+    { GemmArgs ga_ = cg(c->xa, S * H, w.w1, 3L * S * H, w.cb1, c->t1 + H, H, rows - 2, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
     g.x = c->t1; g.y = c->xb; g.gamma = w.g2; g.beta = w.b2;
     groupnorm_silu_launch(g, c->gn_reg ? R.Tp - 2 * kPadRows : (1 << 30), st);
-    { GemmArgs ga_ = cg(c->xb, H, w.w2, 3L * H, w.cb2, c->h + H, H, rows - 2, H, c->h + H, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
+    { GemmArgs ga_ = cg(c->xb, S * H, w.w2, 3L * S * H, w.cb2, c->h + H, H, rows - 2, H, c->h + H, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
 }
 
 // codes: HOST packed codes (codes_dev == null), or DEVICE codes, utterance i at codes_dev + i * codes_stride (already in range:
@@ -431,11 +454,12 @@ static int codec_decode_impl(ntts_codec* c, int32_t n, const int32_t* codes, con
     CHIP(c, hipEventRecord(c->ev[0], st));
 
     CodecEmbedArgs ea{};
-    ea.codes = codes ? c->meta + 3 * n + 1 : codes_dev; ea.code_off = c->meta + n; ea.wf = c->wf; ea.bf = c->bf; ea.out = c->xa; ea.R = R; ea.H = H; ea.nq = c->nq;
+    const long S = c->S;
+    ea.codes = codes ? c->meta + 3 * n + 1 : codes_dev; ea.code_off = c->meta + n; ea.wf = c->wf; ea.bf = c->bf; ea.out = c->xa; ea.R = R; ea.H = H; ea.nq = c->nq; ea.split = S > 1;
     for (int i = 0; i < 8; ++i) ea.levels[i] = i < c->nq ? c->cfg.levels[i] : 1;
     NTTS_LAUNCH((codec_embed_kernel), dim3((unsigned)((rows + kEmbedRows - 1) / kEmbedRows)), dim3(256), st, ea);
     // stem Conv1d(k=7, padding 3): window rows r..r+6 -> centre row r+3
-    { GemmArgs ga_ = cg(c->xa, H, c->embed_w, 7L * H, c->embed_b, c->h + 3L * H, H, rows - 6, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
+    { GemmArgs ga_ = cg(c->xa, S * H, c->embed_w, 7L * S * H, c->embed_b, c->h + 3L * H, H, rows - 6, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
     auto tap = [&](int stage) -> hipError_t {   // debug only: the residual stream after a stage (hf:models/xcodec2/modeling_xcodec2.py:841-859)
         if (!c->tap) return hipSuccess;
         return hipMemcpyAsync(c->tap + (size_t)stage * c->max_rows * H, c->h, (size_t)rows * H * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -452,11 +476,11 @@ static int codec_decode_impl(ntts_codec* c, int32_t n, const int32_t* codes, con
     for (int i = 0; i < c->cfg.num_layers; ++i) {
         const CLayerW& L = c->layers[i];
         RowNormArgs rn{};
-        rn.x = c->h; rn.y = c->xa; rn.w = L.ln1; rn.rows = rows; rn.C = H; rn.eps = c->cfg.rms_eps;
+        rn.x = c->h; rn.y = c->xa; rn.w = L.ln1; rn.rows = rows; rn.C = H; rn.eps = c->cfg.rms_eps; rn.split = S > 1;
         rownorm_launch(rn, st);
-        { GemmArgs ga_ = cg(c->xa, H, L.wqkv, H, nullptr, c->qkv, 3L * H, rows, 3 * H); NTTS_GEMM_BIG(EPI_BF16, ga_, st); }
+        { GemmArgs ga_ = cg(c->xa, S * H, L.wqkv, S * H, nullptr, c->qkv, 3L * H, rows, 3 * H); NTTS_GEMM_BIG(EPI_BF16, ga_, st); }
         AttnFullArgs at{};
-        at.qkv = c->qkv; at.vt = c->vt; at.out = c->xb; at.R = R; at.C = H; at.nh = c->cfg.num_heads; at.npages = npages; at.qtiles = qtiles;
+        at.qkv = c->qkv; at.vt = c->vt; at.out = c->xb; at.R = R; at.C = H; at.nh = c->cfg.num_heads; at.npages = npages; at.qtiles = qtiles; at.split = S > 1;
         if (c->attn_resident && npages <= kAttnResPages) {   // up to 256 frames: K / V^T resident in LDS, one sweep, no V^T pass
             if (npages <= 8) NTTS_LAUNCH((attn_full_resident_kernel<8>), dim3(n, c->cfg.num_heads), dim3(512), st, at);
             else if (npages <= 12) NTTS_LAUNCH((attn_full_resident_kernel<12>), dim3(n, c->cfg.num_heads), dim3(512), st, at);
@@ -467,20 +491,21 @@ static int codec_decode_impl(ntts_codec* c, int32_t n, const int32_t* codes, con
             NTTS_LAUNCH((v_transpose_kernel), dim3(n * npages, c->cfg.num_heads), dim3(256), st, vt);
             NTTS_LAUNCH((attn_full_kernel), dim3(n * qtiles, c->cfg.num_heads), dim3(256), st, at);
         }
-        { GemmArgs ga_ = cg(c->xb, H, L.wo, H, nullptr, c->h, H, rows, H, c->h, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
+        { GemmArgs ga_ = cg(c->xb, S * H, L.wo, S * H, nullptr, c->h, H, rows, H, c->h, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
         rn.w = L.ln2;
         rownorm_launch(rn, st);
-        { GemmArgs ga_ = cg(c->xa, H, L.fc1, H, nullptr, c->act, c->I, rows, c->I); NTTS_GEMM_BIG(EPI_BF16_SILU, ga_, st); }
-        { GemmArgs ga_ = cg(c->act, c->I, L.fc2, c->I, nullptr, c->h, H, rows, H, c->h, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
+        { GemmArgs ga_ = cg(c->xa, S * H, L.fc1, S * H, nullptr, c->act, S * c->I, rows, c->I);
+          if (S > 1) NTTS_GEMM_BIG(EPI_SILU_SPLIT3, ga_, st); else NTTS_GEMM_BIG(EPI_BF16_SILU, ga_, st); }
+        { GemmArgs ga_ = cg(c->act, S * c->I, L.fc2, S * c->I, nullptr, c->h, H, rows, H, c->h, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
     }
     CHIP(c, tap(2));
     resnet_block(c, c->res[2], R, rows);
     resnet_block(c, c->res[3], R, rows);
     CHIP(c, tap(3));
     RowNormArgs fn{};
-    fn.x = c->h; fn.y = c->xa; fn.w = c->fn_w; fn.bias = c->fn_b; fn.rows = rows; fn.C = H; fn.eps = 1e-6f;
+    fn.x = c->h; fn.y = c->xa; fn.w = c->fn_w; fn.bias = c->fn_b; fn.rows = rows; fn.C = H; fn.eps = 1e-6f; fn.split = S > 1;
     rownorm_launch(fn, st);
-    { GemmArgs ga_ = cg(c->xa, H, c->head_w, H, c->head_b, c->spec, c->lds_spec, rows, c->NS); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
+    { GemmArgs ga_ = cg(c->xa, S * H, c->head_w, S * H, c->head_b, c->spec, c->lds_spec, rows, c->NS); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
     IstftPrepArgs ip{};
     ip.spec = c->spec; ip.lds = c->lds_spec; ip.s3 = c->s3; ip.K3 = c->K3; ip.rows = rows; ip.nb = c->nb;
     NTTS_LAUNCH((istft_prep_kernel), dim3((unsigned)rows), dim3(256), st, ip);

@@ -39,16 +39,38 @@ NTTS_D bool codec_row(const CodecRows& R, long r, int& b, int& t) {   // which (
     return t >= 0 && t < R.lens[b];
 }
 
+// ---- precision = high: SPLIT bf16 GEMM operands -------------------------------------------------------------------------------------
+// A bf16 operand row of C values is written as [hi | lo | hi] (3 C columns), hi = bf16(x), lo = bf16(x - hi): x to ~16 mantissa bits.
+// Against a weight row [wh | wh | wl] (codec.cpp Finalizer::op) the GEMM's ordinary K-loop forms xh wh + xl wh + xh wl in its fp32
+// accumulator: the operand-rounding error of a bf16 GEMM (2^-9 relative per operand -- 7e-3 of the waveform over ~60 GEMMs in series,
+// DESIGN.md section 2) drops to ~2^-17 at three times the matrix-core work.  The ISTFT head's DFT operand has always been built this way
+// (istft_prep_kernel).  `split` = 0: the plain bf16 row of C columns.
+NTTS_D void put_op(bf16_t* y, long r, int C, int ch, float v, int split) {
+    const bf16_t hi = f2bf(v);
+    if (!split) { y[r * C + ch] = hi; return; }
+    bf16_t* row = y + r * 3 * C;
+    row[ch] = hi; row[C + ch] = f2bf(v - bf2f(hi)); row[2 * C + ch] = hi;
+}
+NTTS_D void put_op4(bf16_t* y, long r, int C, int ch, const float (&v)[4], int split) {      // 4 consecutive channels, ch % 4 == 0
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { hi[e] = (short)f2bf(v[e]); lo[e] = (short)f2bf(v[e] - bf2f((bf16_t)hi[e])); }
+    if (!split) { *(bf16x4*)(y + r * C + ch) = hi; return; }
+    bf16_t* row = y + r * 3 * C;
+    *(bf16x4*)(row + ch) = hi; *(bf16x4*)(row + C + ch) = lo; *(bf16x4*)(row + 2 * C + ch) = hi;
+}
+
 // ---- FSQ de-index + (project_out o fc) folded into one affine  8 -> H --------------------------------
 struct CodecEmbedArgs {
     const int* codes;      // packed, utterance b starts at code_off[b]
     const int* code_off;
     const float* wf;       // [H][nq] folded weight (fp32)
     const float* bf;       // [H]
-    bf16_t* out;           // [rows][H]
+    bf16_t* out;           // [rows][H]  (split: [rows][3 H], put_op)
     CodecRows R;
     int H, nq;
     int levels[8];
+    int split;
 };
 // kEmbedRows rows per workgroup: a thread keeps the folded weights of its channels (H / 256 channels x nq <= 8 weights) in
 // registers across the rows (one row per workgroup was 65 536 launches' worth of tiny workgroups at 256 x 250 frames, each
@@ -95,7 +117,7 @@ NTTS_KERNEL(256) void codec_embed_kernel(CodecEmbedArgs p) {
                     for (int i = 0; i < 8; ++i)
                         if (i < p.nq) acc += wreg[j][i] * val[i];
                 }
-                p.out[r * p.H + c] = f2bf(acc);
+                put_op(p.out, r, p.H, c, acc, p.split);
             }
         }
     }
@@ -110,6 +132,7 @@ struct GroupNormArgs {
     CodecRows R;
     int C;
     float eps;
+    int split;             // y is a split operand [rows][3 C] (put_op)
 };
 // grid (B, 32); block 256 = (256/cg row lanes) x (cg channels)
 NTTS_KERNEL(256) void groupnorm_silu_kernel(GroupNormArgs p) {
@@ -143,7 +166,7 @@ NTTS_KERNEL(256) void groupnorm_silu_kernel(GroupNormArgs p) {
             const float v = (p.x[(row0 + t) * p.C + ch] - mean) * rstd * ga + be;
             o = silu_fast(v);
         }
-        p.y[(row0 + t) * p.C + ch] = f2bf(o);
+        put_op(p.y, row0 + t, p.C, ch, o, p.split);
     }
 }
 
@@ -191,19 +214,16 @@ NTTS_KERNEL(256) void groupnorm_silu_reg_kernel(GroupNormArgs p) {
     for (int i = 0; i < kGnRegIters; ++i) {
         const int t = rl + i * nrl;
         if (t < T) {
-            bf16x4 o;
+            float o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float y = (v[i][e] - mean) * rstd * ga[e] + be[e];
-                o[e] = (short)f2bf(silu_fast(y));
-            }
-            *(bf16x4*)(p.y + (row0 + t) * p.C + ch) = o;
+            for (int e = 0; e < 4; ++e) o[e] = silu_fast((v[i][e] - mean) * rstd * ga[e] + be[e]);
+            put_op4(p.y, row0 + t, p.C, ch, o, p.split);
         }
     }
     // pad rows of the utterance: zero, as the Conv1d padding wants them
-    const bf16x4 z = {0, 0, 0, 0};
+    const float z[4] = {0.f, 0.f, 0.f, 0.f};
     for (int t = rl - kPadRows; t < T + kPadRows; t += nrl)
-        if (t < 0 || t >= T) *(bf16x4*)(p.y + (row0 + t) * p.C + ch) = z;
+        if (t < 0 || t >= T) put_op4(p.y, row0 + t, p.C, ch, z, p.split);
 }
 inline void groupnorm_silu_launch(const GroupNormArgs& p, int Tmax, hipStream_t s) {
     const int cg = p.C / 32, vl = cg / 4;
@@ -221,6 +241,7 @@ struct RowNormArgs {
     long rows;
     int C;
     float eps;
+    int split;          // y is a split operand [rows][3 C] (put_op)
 };
 template <int NV>  // float4 per lane: C <= 256 * NV
 NTTS_KERNEL(256) void rownorm_kernel(RowNormArgs p) {
@@ -256,14 +277,14 @@ NTTS_KERNEL(256) void rownorm_kernel(RowNormArgs p) {
         const int vi = lane + 64 * i;
         if (vi < nvec && rok) {
             const f32x4 w = ld16<f32x4>(p.w + vi * 4);
-            bf16x4 o;
+            float o[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float y = (v[i][e] - mean) * inv * w[e];
                 if (p.bias) y += p.bias[vi * 4 + e];
-                o[e] = (short)f2bf(y);
+                o[e] = y;
             }
-            *(bf16x4*)(p.y + row * p.C + vi * 4) = o;
+            put_op4(p.y, row, p.C, vi * 4, o, p.split);
         }
     }
 }
@@ -304,9 +325,10 @@ NTTS_KERNEL(256) void v_transpose_kernel(VTransposeArgs p) {
 struct AttnFullArgs {
     const bf16_t* qkv;   // [rows][3C]: q | k | v
     const bf16_t* vt;    // from v_transpose_kernel
-    bf16_t* out;         // [rows][C]
+    bf16_t* out;         // [rows][C]  (split: [rows][3 C], put_op)
     CodecRows R;
     int C, nh, npages, qtiles;
+    int split;
 };
 // grid (B * qtiles, nh); 4 waves x 16 queries.  Same matrix-core mapping as attn_prefill.h: the workgroup's K page
 // (gathered from the qkv rows) and V^T page are staged ONCE in LDS by LDS-DMA (double-buffered) and shared by the 4
@@ -432,9 +454,8 @@ NTTS_KERNEL(256) void attn_full_kernel(AttnFullArgs p) {
         for (int r = 0; r < 4; ++r) {
             const int q = qw0 + g * 4 + r;
             if (q < T) {
-                bf16_t* o = p.out + (row0 + q) * p.C + h * 64 + l15;
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) o[nt * 16] = f2bf(oacc[nt][r]);
+                for (int nt = 0; nt < 4; ++nt) put_op(p.out, row0 + q, p.C, h * 64 + l15 + nt * 16, oacc[nt][r], p.split);
             }
         }
     }
@@ -573,9 +594,8 @@ NTTS_KERNEL(512) void attn_full_resident_kernel(AttnFullArgs p) {
             const float rr = shfl(rl, g * 4 + r);
             const int q = qw0 + g * 4 + r;
             if (q < T) {
-                bf16_t* o = p.out + (row0 + q) * p.C + h * 64 + l15;
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) o[nt * 16] = f2bf(oacc[nt][r] * rr);
+                for (int nt = 0; nt < 4; ++nt) put_op(p.out, row0 + q, p.C, h * 64 + l15 + nt * 16, oacc[nt][r] * rr, p.split);
             }
         }
     }

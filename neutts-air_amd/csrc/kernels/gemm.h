@@ -34,7 +34,9 @@ enum GemmEpi {
     EPI_ARGMAX = 3,    // per-row (max, first index) partials over this wave's 64 columns, logits = bf16(acc)
     EPI_BF16_SILU = 4, // out bf16 = bf16(silu(acc + bias))   (codec MLP fc1; the codec reference is fp32)
     EPI_F32 = 5,       // out fp32 [M][N] = acc + bias (+ fp32 residual): codec residual stream / ISTFT head / DFT
-    EPI_RESID = 6      // out bf16 [M][N] = bf16(resid_bf16 + bf16(acc + bias)): o_proj + residual add (may be in place)
+    EPI_RESID = 6,     // out bf16 [M][N] = bf16(resid_bf16 + bf16(acc + bias)): o_proj + residual add (may be in place)
+    EPI_SILU_SPLIT3 = 7  // codec, precision = high: v = silu(acc + bias) leaves as a SPLIT bf16 operand row [hi | lo | hi] of 3 N columns
+                         // (hi = bf16(v), lo = bf16(v - hi); ldo = 3 N): the next GEMM's K-loop over [wh | wh | wl] sees v to ~16 mantissa bits
 };
 
 struct GemmArgs {
@@ -214,6 +216,33 @@ NTTS_D void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][4], int mrow0, int
                 } else {
                     for (int e = 0; e < 16; ++e)
                         if (nb16 + e < p.N) dst[e] = o[e];
+                }
+            }
+        } else if constexpr (EPI == EPI_SILU_SPLIT3) {
+            alignas(16) bf16_t hi[16], lo[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int n = nb16 + j * 4 + r;
+                    float v = acc[a][j][r];
+                    if (n < p.N) v += gemm_bias(p, n);
+                    v = silu_fast(v);
+                    hi[j * 4 + r] = f2bf(v);
+                    lo[j * 4 + r] = f2bf(v - bf2f(hi[j * 4 + r]));
+                }
+            if (mok) {
+                bf16_t* dst = (bf16_t*)p.out + (long)m * p.ldo + nb16;
+                if (nb16 + 16 <= p.N) {
+                    *(u32x4*)dst = *(u32x4*)&hi[0];
+                    *(u32x4*)(dst + 8) = *(u32x4*)&hi[8];
+                    *(u32x4*)(dst + p.N) = *(u32x4*)&lo[0];
+                    *(u32x4*)(dst + p.N + 8) = *(u32x4*)&lo[8];
+                    *(u32x4*)(dst + 2 * p.N) = *(u32x4*)&hi[0];
+                    *(u32x4*)(dst + 2 * p.N + 8) = *(u32x4*)&hi[8];
+                } else {
+                    for (int e = 0; e < 16; ++e)
+                        if (nb16 + e < p.N) { dst[e] = hi[e]; dst[p.N + e] = lo[e]; dst[2 * p.N + e] = hi[e]; }
                 }
             }
         } else if constexpr (EPI == EPI_RESID) {

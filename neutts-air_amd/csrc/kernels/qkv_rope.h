@@ -103,6 +103,14 @@ NTTS_KERNEL(KS * 128) void qkv_rope_kernel(QkvRopeArgs p) {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
         mb = xcd * p.xcd_mpx + j % p.xcd_mpx;             // m fastest: co-resident workgroups share a W tile
         nb = j / p.xcd_mpx;
+    } else if (p.xcd_mpx < 0) {
+        // W-stationary (round 5): XCD x (workgroup b runs on XCD b % 8 -- an observation, speed only) takes the column blocks x, x + 8, x + 16 ...
+        // with ALL their row blocks, so each private L2 pulls an eighth of W instead of all of it.  In natural order with 8 row blocks of
+        // 32 rows (batch 256), b % 8 IS the row block: every XCD streamed the whole W -- the 5.7x over-fetch of round 4's counters.
+        const int mblocks = (p.M + BM - 1) / BM;
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        mb = j % mblocks;
+        nb = xcd + 8 * (j / mblocks);
     } else {
         const int mblocks = (p.M + BM - 1) / BM;
         mb = blockIdx.x % mblocks;
@@ -277,7 +285,7 @@ NTTS_KERNEL(KS * 128) void qkv_rope_kernel(QkvRopeArgs p) {
 // 3 ring slots, 2 K slices per workgroup (MI355X, batch 256: 4 slices 6.56 vs 6.41 us, 2 slots 7.5, 4 / 6 slots 6.4-8.3:
 // profiles/r03a_sweep_qkv_fused*.log; KS = 2 also keeps the summation order of the two-slab path this kernel replaced)
 template <bool F8>
-inline void qkv_rope_launch(QkvRopeArgs p, bool xcd_place, hipStream_t s) {
+inline void qkv_rope_launch(QkvRopeArgs p, bool xcd_place, hipStream_t s, bool w_stationary = false) {
     constexpr int KS = 2, NS = 3;
     const int ktiles = p.K / (F8 ? 128 : 64);
     p.kps = (ktiles + KS - 1) / KS;
@@ -287,6 +295,9 @@ inline void qkv_rope_launch(QkvRopeArgs p, bool xcd_place, hipStream_t s) {
     if (xcd_place && p.M % 256 == 0) {                    // whole 32-row blocks per XCD
         p.xcd_mpx = p.M / 256;
         grid = 8 * p.xcd_mpx * nblocks;
+    } else if (w_stationary) {
+        p.xcd_mpx = -1;
+        grid = 8 * mblocks * ((nblocks + 7) / 8);         // (column blocks padded to whole rounds of the 8 XCDs: the surplus workgroups return at once)
     }
     NTTS_LAUNCH((qkv_rope_kernel<NS, F8, KS>), dim3(grid), dim3(KS * 128), s, p);
 }

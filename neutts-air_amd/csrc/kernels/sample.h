@@ -361,6 +361,23 @@ NTTS_KERNEL(64) void gather_head_rows_kernel(const unsigned char* src, unsigned 
     }
     if (sc_src && threadIdx.x == 0) sc_dst[r] = sc_src[sr];
 }
+// running max |x| over bf16 rows (fp8 calibration, ntts_backbone_calibrate): 8 values per thread and iteration; the bit pattern of a
+// non-negative float orders like the value, so the combine is an integer atomic max
+NTTS_KERNEL(256) void amax_bf16_kernel(const bf16_t* x, long nvec, float* out) {
+    float m = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const bf16x8 v = ld16<bf16x8>(x + i * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float a = __builtin_fabsf(bf2f((bf16_t)v[e]));
+            m = a > m ? a : m;             // (NaN never wins)
+        }
+    }
+#pragma unroll
+    for (int sh = 1; sh < 64; sh <<= 1) { const float o = shfl_xor(m, sh); m = o > m ? o : m; }
+    if (lane_id() == 0) atomic_max_global_u32((unsigned int*)out, __builtin_bit_cast(unsigned int, m));
+}
+
 // ids -> codec codes on the device (ref:neutts/neutts.py:349 tokenizer.decode + :276 regex, as one pass): of slot s's new ids
 // keep those in [speech_base, speech_base + n_codes), as id - speech_base, in order; `modulo` (synthetic benchmark only: random
 // weights do not stay in the speech range) maps every id to id mod n_codes instead.  One workgroup per utterance.

@@ -103,6 +103,7 @@ NTTS_D int opaque_u(int v) { asm volatile("" : "+s"(v)); return v; }   // the sa
 
 NTTS_D unsigned int atomic_add_global(unsigned int* p, unsigned int v) { return atomicAdd(p, v); }
 NTTS_D unsigned int atomic_add_lds(unsigned int* p, unsigned int v) { return atomicAdd(p, v); }
+NTTS_D unsigned int atomic_max_global_u32(unsigned int* p, unsigned int v) { return atomicMax(p, v); }
 // constant-rate timestamp (s_memrealtime, 100 MHz): phase timelines of a kernel (diagnostics only)
 NTTS_D unsigned long long now_ticks() { return wall_clock64(); }
 

@@ -43,7 +43,7 @@ class CodecConfigC(C.Structure):
     _fields_ = [("hidden_size", C.c_int32), ("intermediate_size", C.c_int32), ("num_layers", C.c_int32),
                 ("num_heads", C.c_int32), ("head_dim", C.c_int32), ("quantization_dim", C.c_int32),
                 ("n_levels", C.c_int32), ("levels", C.c_int32 * 8), ("hop_length", C.c_int32), ("rms_eps", C.c_float),
-                ("max_frames", C.c_int32), ("max_rows", C.c_int32)]
+                ("max_frames", C.c_int32), ("max_rows", C.c_int32), ("precision", C.c_int32)]
 
 
 class EncoderConfigC(C.Structure):
@@ -102,6 +102,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
                                                    C.POINTER(i32), C.POINTER(i32)]),
         "ntts_backbone_set_gang": (C.c_int, [p, i32]),
         "ntts_backbone_set_logits_range": (C.c_int, [p, i32, i32, i32]),
+        "ntts_backbone_calibrate": (C.c_int, [p, i32]),
+        "ntts_backbone_read_amax": (C.c_int, [p, C.POINTER(f32), i32]),
         "ntts_backbone_kv_stats": (C.c_int, [p, C.POINTER(i32), C.POINTER(i32), C.POINTER(i64), C.POINTER(i64)]),
         "ntts_backbone_decode": (C.c_int, [p, i32]),
         "ntts_backbone_read": (C.c_int, [p, i32, C.POINTER(i32), i32, C.POINTER(i32), C.POINTER(i32)]),
@@ -432,7 +434,8 @@ class BackboneEngine:
         """One throw-away request through slot 0 (a 1-token prompt, `decode_steps` greedy steps): captures and instantiates the
         decode-step hipGraph and lets the HIP runtime size its command pools, so that the first real request does not pay for
         either.  Serving start-up hygiene; the engine must be finalised and slot 0 free."""
-        sp = Sampling(max_length=2 + decode_steps, min_new_tokens=1 + decode_steps, eos_token_id=0, do_sample=False)
+        eos = self.logits_range[2] if getattr(self, "logits_range", None) else 0      # (a restricted lm_head accepts its own EOS id only)
+        sp = Sampling(max_length=2 + decode_steps, min_new_tokens=1 + decode_steps, eos_token_id=eos, do_sample=False)
         self.prefill([[1 % self.vocab_size]], [0], [sp])
         self.decode(decode_steps)
         self.sync()
@@ -442,7 +445,7 @@ class BackboneEngine:
         # call AFTER the first long decode call pays for it once (43 ms on the host, measured in bench.py's step walls).  With
         # `decode_steps` as long as a real decode call, a second throw-away prompt pass absorbs that too.
         if decode_steps > 8:
-            self.prefill([[1 % self.vocab_size]], [0], [Sampling(max_length=3, min_new_tokens=1, eos_token_id=0, do_sample=False)])
+            self.prefill([[1 % self.vocab_size]], [0], [Sampling(max_length=3, min_new_tokens=1, eos_token_id=eos, do_sample=False)])
             self.sync()
             self.release(0)
             self.sync()
@@ -494,6 +497,24 @@ class BackboneEngine:
         """Tell the engine how many decode chains (engines of an EngineGang, itself included) run side by side on the GPU: the
         decode step's GEMM tiles and XCD placement are chosen for that (ntts_backbone_set_gang); the captured step graph is dropped."""
         self._chk(self.lib.ntts_backbone_set_gang(self.h, int(chains)))
+
+    def calibrate(self, enable: bool = True):
+        """fp8 calibration mode of a BF16 engine (ntts_backbone_calibrate): the prompt passes that follow record max |x| of every GEMM input."""
+        self._chk(self.lib.ntts_backbone_calibrate(self.h, int(bool(enable))))
+
+    def fp8_input_scales(self, margin: float = 1.0) -> Dict[str, float]:
+        """The static `input_scale`s of the fp8 model from the record so far: amax / 448 x margin, under the tensor names a static-fp8
+        checkpoint uses (what load_state_dict(..., input_scales=...) of a weight_dtype='fp8' engine takes)."""
+        L = int(self.cfg["num_layers"])
+        a = np.zeros(4 * L + 1, dtype=np.float32)
+        self._chk(self.lib.ntts_backbone_read_amax(self.h, a.ctypes.data_as(C.POINTER(C.c_float)), len(a)))
+        if not (a > 0).all():
+            raise NeuTTSHipError(-4, "calibration saw no data for some GEMM inputs: run prompt passes between calibrate() and fp8_input_scales()")
+        out = {"lm_head.input_scale": float(a[4 * L]) / 448.0 * margin}
+        for i in range(L):
+            for j, t in enumerate(("self_attn.q_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.down_proj")):
+                out[f"model.layers.{i}.{t}.input_scale"] = float(a[4 * i + j]) / 448.0 * margin
+        return out
 
     def set_logits_range(self, lo: Optional[int], hi: int = 0, eos_id: int = 0):
         """OPT-IN: lm_head over the token ids [lo, hi) + eos_id only (ntts_backbone_set_logits_range; lo=None restores the full head).
@@ -875,7 +896,8 @@ class CodecEngine:
         c = CodecConfigC(cfg.get("hidden_size", 1024), cfg.get("intermediate_size", 4096), cfg.get("num_layers", 12),
                          cfg.get("num_heads", 16), cfg.get("head_dim", 64), cfg.get("quantization_dim", 2048), len(lv),
                          (C.c_int32 * 8)(*(lv + [1] * (8 - len(lv)))), cfg.get("hop_length", 480), cfg.get("rms_eps", 1e-6),
-                         cfg.get("max_frames", 2048), cfg.get("max_rows", 4096))
+                         cfg.get("max_frames", 2048), cfg.get("max_rows", 4096),
+                         {"bf16": 0, "high": 1, 0: 0, 1: 1}[cfg.get("precision", "bf16")])
         h = C.c_void_p()
         rc = self.lib.ntts_codec_create(C.byref(c), device, C.byref(h))
         if rc != 0:

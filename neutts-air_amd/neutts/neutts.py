@@ -166,6 +166,7 @@ class NeuTTS:
         do_sample: bool = True,
         seed: int = 0,
         speech_range_head: bool = False,
+        codec_precision: str = "bf16",
     ):
         # Consts (ref:neutts/neutts.py:84-91)
         self.sample_rate = 24_000
@@ -189,6 +190,11 @@ class NeuTTS:
         self.min_new_tokens = 50
         self._seed = seed
 
+        # codec_precision="high": NeuCodec's GEMMs on split bf16 operands (hi + lo), ~3x their matrix-core work, for callers who need the
+        # waveform bound at full-scale amplitude; "bf16" (default): within 7e-3 RELATIVE rms of the fp32 reference decoder
+        if codec_precision not in ("bf16", "high"):
+            raise ValueError("codec_precision must be 'bf16' or 'high'")
+        self._codec_precision = codec_precision
         self.tokenizer = None
         self.phonemizer = None       # created on first use: text front-end is off the hot path
         self._load_backbone(backbone_repo, backbone_device)
@@ -219,6 +225,11 @@ class NeuTTS:
         """Release the GPU engines (not part of the reference's surface: its torch modules go with the garbage collector).  The gang
         goes first -- its twins read the first engine's arena and its lane streams carry engine 0's work."""
         gang, self.gang = getattr(self, "gang", None), None
+        codecs, self._gang_codecs = getattr(self, "_gang_codecs", None), None
+        for k, c in enumerate(codecs or []):
+            c.set_stream(None)                       # (they ran on the gang's lanes)
+            if k > 0:
+                c.close()
         if gang is not None:
             gang.close()
         for name in ("backbone",):
@@ -314,12 +325,15 @@ class NeuTTS:
                         " 'neuphonic/neucodec-onnx-decoder'."
                     )
         cfg.setdefault("hop_length", self.hop_length)
+        cfg.setdefault("precision", self._codec_precision)
         cfg.setdefault("max_frames", self.max_context)
         cfg.setdefault("max_rows", max(2 * (self.max_context + 6), self._max_batch * 512))
         self.hop_length = cfg["hop_length"]
         self.streaming_stride_samples = self.streaming_frames_per_chunk * self.hop_length
         engine = _hip.CodecEngine(cfg, dev, self._lib_path)
         engine.load_state_dict(sd)
+        self._codec_spec = (dict(cfg), sd, dev)          # (a gang of stream sets gives every backbone engine a codec engine of its own)
+        self._gang_codecs = None
         enc_engine = None
         if enc_spec is not None:
             ecfg = dict(enc_spec.get("config", {}))
@@ -368,8 +382,9 @@ class NeuTTS:
         if not isinstance(ref_texts, (list, tuple)):
             ref_texts = [ref_texts] * len(texts)
             ref_codes = [ref_codes] * len(texts)
-        if len(texts) > self.backbone.max_batch:
-            raise ValueError(f"{len(texts)} utterances exceed the engine's {self.backbone.max_batch} decode slots")
+        cap = self.gang.max_batch if (self.gang is not None and getattr(self, "stream_on_gang", True)) else self.backbone.max_batch
+        if len(texts) > cap:
+            raise ValueError(f"{len(texts)} utterances exceed the engine's {cap} decode slots")
         prompts = [self._apply_chat_template(rc, rt, t) for rc, rt, t in zip(ref_codes, ref_texts, texts)]
         return self._infer_stream_batch_hip(prompts, [[int(c) for c in _to_list(rc)] for rc in ref_codes])
 
@@ -568,7 +583,125 @@ class NeuTTS:
         finally:
             ss.close()
 
+    def _gang_codec_engines(self):
+        """One codec engine per engine of the gang, each on that engine's lane stream (engine k's codec passes in engine k's hardware
+        queue: four queues, four lanes -- _hip.EngineGang); the first one is the class's own."""
+        if self._gang_codecs is None:
+            cfg, sd, dev = self._codec_spec
+            engs = [self.codec.engine]
+            for _ in self.gang.engines[1:]:
+                c = _hip.CodecEngine(cfg, dev, self._lib_path)
+                c.load_state_dict(sd)
+                engs.append(c)
+            for k, c in enumerate(engs):
+                if self.gang.lane(k):
+                    c.set_stream(self.gang.lane(k))
+            self._gang_codecs = engs
+        return self._gang_codecs
+
+    def _infer_stream_batch_gang(self, prompts: List[List[int]], ref_codes: List[List[int]]):
+        """infer_stream_batch over an ENGINE GANG with STAGGERED ADMISSION (BASELINE configs[4]'s literal shape:
+        ref:neutts/neutts.py:373-465 for many utterances at once).  The utterances are dealt out in groups of `stream_admit` (64) over the
+        gang's engines; every group is a device-side stream set (ntts_streams_*) on its engine, the engine's codec engine on the same
+        lane.  Per turn of an engine: [snapshot + windows of its sets -> codec pass -> chunks out] [admit its next group: prompt pass]
+        [next decode burst] -- the other engines' bursts run meanwhile, so a group's first audio waits for ITS prompt pass and 29
+        decode steps, not for the prompt passes of every stream of the call.  A window is defined by token COUNTS (30 undecoded tokens,
+        csrc/stream.cpp pump_end), not by when it is looked for: the chunks are those of the single stream, bit for bit, whatever the
+        burst boundaries."""
+        gang = self.gang
+        G = len(gang.engines)
+        codecs = self._gang_codec_engines()
+        n = len(prompts)
+        self._seed += 1
+        admit = max(1, int(getattr(self, "stream_admit", 64)))
+        chunk, look_f = self.streaming_frames_per_chunk, self.streaming_lookforward
+        mod = int(getattr(self, "_stream_modulo", 0))
+        room = [e.free_slots() for e in gang.engines]
+        if n > sum(room):
+            raise ValueError(f"{n} utterances exceed the gang's free decode slots ({sum(room)})")
+        # groups of at most `admit` streams, each to the engine with the most room left (ties: round-robin), a group no larger than that room
+        pending: List[List[List[int]]] = [[] for _ in range(G)]
+        i0, turn = 0, 0
+        while i0 < n:
+            k = max(range(G), key=lambda j: (room[j], -((j - turn) % G)))
+            m = min(admit, room[k], n - i0)
+            pending[k].append(list(range(i0, i0 + m)))
+            room[k] -= m
+            i0 += m
+            turn += 1
+        active: List[list] = [[] for _ in range(G)]           # per engine: [stream set, utterance indices, slots, steps until its next window]
+        try:
+            while any(pending) or any(active):
+                for k, eng in enumerate(gang.engines):
+                    if not pending[k] and not active[k]:
+                        continue
+                    running = 0
+                    for item in active[k]:
+                        item[0].pump_begin()                  # behind the burst enqueued in this engine's previous turn
+                    for item in active[k]:
+                        running += item[0].pump_wait()
+                    for item in list(active[k]):
+                        ss, idx, slots = item[0], item[1], item[2]
+                        more = True
+                        while more:
+                            chunks, _, more = ss.pump_end()   # codec pass + cross-fade on the engine's lane, ahead of its next burst
+                            for i, samples, _last in chunks:
+                                yield idx[i], np.array(samples)
+                        if ss.done() == ss.n:
+                            ss.close()
+                            eng.release_many(slots)
+                            item[2] = []
+                            active[k].remove(item)
+                    admitted = False
+                    if pending[k]:
+                        idx = pending[k].pop(0)
+                        slots = [eng.acquire_slot() for _ in idx]
+                        item = [None, idx, slots, chunk + look_f - 1]
+                        active[k].append(item)                # (registered first: its slots are released on any exit path)
+                        budget = eng.cfg.get("max_prefill_tokens", 0) or 16384
+                        i0 = 0
+                        while i0 < len(idx):
+                            i1, used = i0, 0
+                            while i1 < len(idx) and (i1 == i0 or used + len(prompts[idx[i1]]) <= budget):
+                                used += len(prompts[idx[i1]])
+                                i1 += 1
+                            eng.prefill([prompts[i] for i in idx[i0:i1]], slots[i0:i1], [self._sampling(len(prompts[i]), i) for i in idx[i0:i1]])
+                            i0 = i1
+                        item[0] = _hip.StreamSet(eng, codecs[k], slots, [ref_codes[i] for i in idx], int(eng.cfg["max_context"]), chunk, look_f,
+                                                 self.streaming_lookback, self.streaming_overlap_frames, self.hop_length,
+                                                 0 if mod else int(self._speech_base), mod or 65536, bool(mod))
+                        admitted = True
+                        running += len(idx)
+                    if running:
+                        # as many steps as the stream set CLOSEST to its next window still needs (at most a chunk): a new group holds one
+                        # token per stream and needs chunk + lookforward - 1 more for its first window, an older one a chunk per window
+                        burst = max(1, min(chunk, min(item[3] for item in active[k])))
+                        eng.decode(burst)
+                        for item in active[k]:
+                            item[3] -= burst
+                            while item[3] <= 0:
+                                item[3] += chunk
+        finally:
+            for k, eng in enumerate(gang.engines):
+                for item in active[k]:
+                    if item[0] is not None:
+                        item[0].close()
+                if any(item[2] for item in active[k]):
+                    try:
+                        eng.sync()
+                    except _hip.NeuTTSHipError:
+                        pass
+                    for item in active[k]:
+                        for sl in item[2]:
+                            try:
+                                eng.release(sl)
+                            except _hip.NeuTTSHipError:
+                                pass
+
     def _infer_stream_batch_hip(self, prompts: List[List[int]], ref_codes: List[List[int]]):
+        if (self.gang is not None and len(prompts) > 1 and getattr(self, "stream_on_gang", True) and self._stream_on_device(ref_codes)):
+            yield from self._infer_stream_batch_gang(prompts, ref_codes)
+            return
         eng = self.backbone
         n = len(prompts)
         self._seed += 1

@@ -217,6 +217,28 @@ def model_forward(cfg: BackboneConfig, w, ids: torch.Tensor, cache: KVCache, tap
     return F.linear(h[:, -1, :], w.get("lm_head.weight", w["model.embed_tokens.weight"]))  # tied unless the checkpoint unties it
 
 
+def gemm_input_amax(cfg: BackboneConfig, w, prompts) -> Dict[str, float]:
+    """max |x| of every GEMM's input over the prompt passes of `prompts`, under the `input_scale` names of a static-fp8 checkpoint -- what
+    the engine's calibration mode records (ntts_backbone_calibrate; tests/test_emu_variants.py checks one against the other).  The
+    lm_head sees each prompt's LAST position only (hf:generation/utils.py:2894)."""
+    out: Dict[str, float] = {}
+
+    def upd(k, t):
+        out[k] = max(out.get(k, 0.0), float(t.abs().max()))
+    with torch.no_grad():
+        for p in prompts:
+            taps: list = []
+            model_forward(cfg, w, torch.tensor([list(p)], dtype=torch.long), KVCache(cfg.num_layers), taps)
+            for i, t in enumerate(taps):
+                pre = f"model.layers.{i}."
+                upd(pre + "self_attn.q_proj.input_scale", t["x"])
+                upd(pre + "self_attn.o_proj.input_scale", t["attn"])
+                upd(pre + "mlp.gate_proj.input_scale", t["x2"])
+                upd(pre + "mlp.down_proj.input_scale", t["act"])
+            upd("lm_head.input_scale", rms_norm(taps[-1]["h_out"], w["model.norm.weight"], cfg.rms_eps)[:, -1, :])
+    return out
+
+
 @dataclass
 class GenResult:
     ids: List[int]                 # generated ids only (prompt stripped, like ref:neutts/neutts.py:348-351)

@@ -230,6 +230,7 @@ inline void glds16(const void* gsrc, void* lds_wave_base) {
 inline void glds16_nt(const void* gsrc, void* lds_wave_base) { glds16(gsrc, lds_wave_base); }
 inline unsigned int atomic_add_global(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = o + v; return o; }
 inline unsigned int atomic_add_lds(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = o + v; return o; }
+inline unsigned int atomic_max_global_u32(unsigned int* p, unsigned int v) { unsigned int o = *p; if (v > o) *p = v; return o; }
 NTTS_D unsigned long long now_ticks() { return 0; }   // no clock on the emulator
 inline void wait_vmem() {}
 inline void sync_keep_dma() { emu::barrier(); }

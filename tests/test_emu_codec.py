@@ -87,3 +87,25 @@ def check_long_utterance(lib):
 
 def test_codec_long_utterance_paged_attention(emu_lib):
     check_long_utterance(emu_lib)
+
+
+@pytest.mark.parametrize("resident", ["1", "0"])
+def test_codec_high_precision_split_operands(emu_lib, resident, monkeypatch):
+    """precision = "high" (ABI 8 ntts_codec_config.precision = 1): every GEMM operand as a split bf16 pair, K-concatenated [xh | xl | xh] x
+    [wh | wh | wl] -- the stem / ResNet convs over overlapping rows (segments per tap), QKV, o_proj, fc1 (whose SiLU epilogue emits the split
+    row for fc2), fc2, the ISTFT head's linear; both attention kernels and both GroupNorm kernels write split rows.  Against the fp32 golden
+    waveforms the error must drop well below the bf16-operand engine's on the same utterances (what is left is the attention's own bf16
+    q / k / v / P and the bf16 QKV output), ragged batch and batch invariance as for the default engine."""
+    monkeypatch.setenv("NTTS_CODEC_ATTN_RESIDENT", resident)
+    monkeypatch.setenv("NTTS_CODEC_GN_REG", resident)
+    z, cfg, w = load_codec_fixture("codec_tiny")
+    codes = [z["codes_0"][0, 0].tolist(), z["codes_1"][0, 0].tolist(), z["codes_0"][1, 0].tolist()]
+    gold = [z["wav_0"][0, 0], z["wav_1"][0, 0], z["wav_0"][1, 0]]
+    lo = make_codec_engine(cfg, w, emu_lib).decode(codes)
+    eng = make_codec_engine(cfg, w, emu_lib, precision="high")
+    hi = eng.decode(codes)
+    for a, b, g in zip(lo, hi, gold):
+        e_lo, e_hi = rms(a - g) / rms(g), rms(b - g) / rms(g)
+        print(f"codec tiny: relative rms error bf16 operands {e_lo:.2e}, split operands {e_hi:.2e}")
+        assert b.shape == g.shape and e_hi <= 0.4 * e_lo and e_hi <= 2.5e-3, (e_lo, e_hi)
+    assert np.array_equal(eng.decode([codes[1]])[0], hi[1])

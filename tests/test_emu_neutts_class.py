@@ -271,6 +271,50 @@ def test_infer_stream_batch_equals_single_streams(tts):
         next(tts.infer_stream_batch(["a"] * (tts.backbone.max_batch + 1), ref_codes, "x"))
 
 
+def test_infer_stream_batch_over_a_gang_with_staggered_admission(tts):
+    """NeuTTS(engines=2): infer_stream_batch deals its utterances out over the gang in groups of `stream_admit`, one device-side stream set
+    per group, the second group of an engine admitted while its first one already streams.  Four utterances, groups
+    of one: every utterance's chunks are those of its own `infer_stream`, bit for bit -- a window is defined by token counts, not by
+    where the decode bursts end."""
+    from neutts import _hip
+    ref_codes = [3, 77, 200, 5, 18, 9, 100, 41]
+    texts = ["Streaming test.", "Another one, a little longer.", "Third.", "And the fourth of them."]
+    tts.min_new_tokens, tts.max_context = 34, 150
+    tts.gang = _hip.EngineGang(tts.backbone, 2)          # what NeuTTS(engines=2) sets up at construction
+    tts.stream_admit = 1
+    try:
+        tts.stream_on_device = False
+        singles = [list(tts.infer_stream(t, ref_codes, "So I'm live.")) for t in texts]
+        tts.stream_on_device = True
+        got = [[] for _ in texts]
+        order = []
+        for i, chunk in tts.infer_stream_batch(texts, ref_codes, "So I'm live."):
+            got[i].append(chunk)
+            order.append(i)
+        assert len(tts._gang_codecs) == 2
+        for e in tts.gang.engines:
+            st = e.kv_stats()
+            assert st["free_pages"] == st["total_pages"] and e.free_slots() == e.max_batch
+        for i in range(len(texts)):
+            assert len(got[i]) == len(singles[i]) >= 2
+            for a, b in zip(got[i], singles[i]):
+                assert a.shape == b.shape and np.array_equal(a, b)
+        assert order.index(2) > order.index(0) and order.index(3) > order.index(1)      # the second groups came in behind the first ones
+        with pytest.raises(ValueError, match="decode slots"):
+            next(tts.infer_stream_batch(["a"] * (tts.gang.max_batch + 1), ref_codes, "x"))
+    finally:
+        tts.stream_on_device = True
+        del tts.stream_admit
+        for k, c in enumerate(tts._gang_codecs or []):
+            c.set_stream(None)
+            if k:
+                c.close()
+        tts._gang_codecs = None
+        tts.gang.close()
+        tts.gang = None
+        tts.min_new_tokens, tts.max_context = 5, 120
+
+
 def _device_i32(tts, shape):
     """A zeroed int32 buffer in the engines' 'device' memory (host memory on the emulator, HBM on the GPU): (pointer, reader)."""
     if "emu" in str(tts._lib_path):

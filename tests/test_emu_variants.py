@@ -88,7 +88,7 @@ def fp8_distance(eng_logits, want8, want16):
             float(np.corrcoef(eng_logits[fin], want8[fin])[0, 1]))
 
 
-def check_fp8_model(lib, cfg, prompts, n_new, max_batch, bar=0.10, corr_bar=0.995):
+def check_fp8_model(lib, cfg, prompts, n_new, max_batch, bar=0.10, corr_bar=0.995, input_scales=None):
     """The fp8 engine against the oracle's restatement of the same quantisation scheme.  What can be asked of it: an fp8
     GEMM INPUT has 3 mantissa bits, so wherever two correct implementations differ by one bf16 rounding (fp32 summation
     order; the matrix core's own accumulation of e4m3 products, which is NOT an fp32 fma chain) a few per cent of the
@@ -98,8 +98,8 @@ def check_fp8_model(lib, cfg, prompts, n_new, max_batch, bar=0.10, corr_bar=0.99
     quantisation itself (fp8 oracle vs bf16 oracle, 12-18 % on these models): relative RMS <= 10 % on these 2-layer models
     (measured 5.0-6.8 %), correlation >= 0.995, the same argmax wherever the oracle's own top-2 margin is clear; the
     free-running ids are reported."""
-    w = br.make_weights(cfg, 23, peak_sigma=0.5)
-    scales = br.default_fp8_input_scales(cfg)
+    w = br.make_weights(cfg, 23, peak_sigma=0.5) if input_scales is None else br.make_weights(cfg, 19)   # (calibrated scales belong to the model they were taken on)
+    scales = input_scales or br.default_fp8_input_scales(cfg)
     wb = br.cast_weights(w, torch.bfloat16)
     wq = br.fp8_quantize_weights(wb, scales)
     eng = _engine(cfg, w, lib, max_batch=max_batch, input_scales=scales, weight_dtype="fp8",
@@ -321,3 +321,36 @@ def test_speech_range_head_is_the_full_head_inside_the_range(lib, knobs, monkeyp
             assert float(lg[tok]) >= float(allowed) - 2.0 * br.bf16_ulp(float(allowed)), (k, tok, float(lg[tok]), float(allowed))
         assert len(ids) == M or ids[-1] == eos
     eng.close()
+
+
+def test_fp8_calibration_from_a_bf16_engine(lib):
+    """ABI 8 ntts_backbone_calibrate / read_amax + tools/calibrate_fp8.py (VERDICT r4 missing 4): a BF16 engine in calibration mode records
+    max |x| of every GEMM's input over its prompt passes; scale = amax / 448.  (1) The record equals the maxima of the oracle's own
+    GEMM inputs on the same prompts (bf16 values: equal up to the engine's 1-2 ulp).  (2) The scales place the activations in e4m3's window
+    like the hand-set defaults of the synthetic model do (within 8x of them -- e4m3 is a floating-point format, a scale only has to place
+    the bulk) and NOTHING clips.  (3) An fp8 engine built with the calibrated scales meets the fp8 bars against the fp8 oracle with the
+    same scales.  (4) fp8 engines refuse the mode; reading without data is an error."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import calibrate_fp8
+    cfg = fp8_cfg()
+    w = br.make_weights(cfg, 19)
+    wd = br.cast_weights(w, torch.bfloat16)
+    eng = _engine(cfg, w, lib, max_batch=2)
+    with pytest.raises(_hip.NeuTTSHipError):
+        eng.fp8_input_scales()
+    prompts = [br.synthetic_prompt(cfg, 60 + i, 20 + 9 * i) for i in range(4)]
+    scales = calibrate_fp8.calibrate(eng, prompts)
+    assert eng.free_slots() == eng.max_batch
+    default = br.default_fp8_input_scales(cfg)
+    assert set(scales) == set(default)
+    for k in scales:
+        assert default[k] / 8 <= scales[k] <= default[k] * 8, (k, scales[k], default[k])
+    # (1) against the oracle's own activations
+    taps = br.gemm_input_amax(cfg, wd, prompts)
+    for k in scales:
+        assert abs(scales[k] * 448.0 - taps[k]) <= 0.02 * taps[k], (k, scales[k] * 448.0, taps[k])
+    # (3) the fp8 model on the calibrated scales
+    check_fp8_model(lib, cfg, prompts[:2], 4, 2, input_scales=scales)
+    with pytest.raises(_hip.NeuTTSHipError):
+        _engine(cfg, w, lib, input_scales=scales, weight_dtype="fp8").calibrate(True)

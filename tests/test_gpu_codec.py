@@ -136,6 +136,58 @@ def neucodec_lib(eng):
     return eng.lib._name
 
 
+def test_neucodec_high_precision_holds_the_bound_at_full_scale(neucodec):
+    """precision = "high" (split bf16 GEMM operands, ABI 8) at NeuCodec geometry.  (1) The golden utterances and
+    the stage taps: relative rms error of the waveform <= 2.5e-3 (default engine: 7.0e-3), the residual stream after the 12 layers
+    likewise a fraction of the default's.  (2) The same codes with the ISTFT magnitudes raised 18x -- signal rms ~0.3, a LOUD voice -- stay
+    inside BASELINE's 1e-3 ABSOLUTE, where the default engine (7e-3 relative) is at 2e-3.  (3) What it costs: the 256 x 250-frame batch
+    timed on both engines (printed; DESIGN.md section 2 quotes it -- an option, not the default, unless it is within 5 % of a batch)."""
+    z, cfg, w, eng = neucodec
+    lib = neucodec_lib(eng)
+    hi = make_codec_engine(cfg, w, lib, max_frames=512, max_rows=256 * 256 + 64, precision="high")
+    for i in range(int(z["n"])):
+        codes = z[f"codes_{i}"][0, 0].tolist()
+        g = z[f"wav_{i}"][0, 0]
+        e_lo, e_hi = rms(eng.decode([codes])[0] - g) / rms(g), rms(hi.decode([codes])[0] - g) / rms(g)
+        print(f"neucodec golden set {i}: relative rms error bf16 operands {e_lo:.2e}, split operands {e_hi:.2e}")
+        assert e_hi <= 2.5e-3 and e_hi <= 0.45 * e_lo, (i, e_lo, e_hi)
+    codes = z["codes_1"][0, 0].tolist()
+    hi.set_debug(True)
+    try:
+        hi.decode([codes])
+        got = [hi.read_stage(k) for k in range(4)]
+    finally:
+        hi.set_debug(False)
+    taps = {}
+    cr.decode_code(cfg, w, torch.tensor(codes, dtype=torch.long)[None, None, :], taps=taps)
+    rel = [rms(got[k] - taps[name][0].numpy()) / rms(taps[name][0].numpy()) for k, name in enumerate(_hip.CodecEngine.STAGES)]
+    print("high precision, relative rms of the residual stream vs the fp32 oracle: " + ", ".join(f"{n} {r:.2e}" for n, r in zip(_hip.CodecEngine.STAGES, rel)))
+    assert max(rel) <= 2.5e-3, rel
+    # (2) a loud voice: every magnitude 18x
+    w18 = dict(w)
+    b = w["decoder.head.linear.bias"].clone()
+    b[: b.numel() // 2] += float(np.log(18.0))
+    w18["decoder.head.linear.bias"] = b
+    ref = cr.decode_code(cfg, w18, torch.tensor(codes, dtype=torch.long)[None, None, :])[0, 0].numpy()
+    out = {}
+    for prec in ("bf16", "high"):
+        e18 = make_codec_engine(cfg, w18, lib, max_frames=128, max_rows=512, precision=prec)
+        out[prec] = rms(e18.decode([codes])[0] - ref)
+        e18.close()
+    print(f"the same codes 18x louder (signal rms {rms(ref):.3f}): rms error bf16 operands {out['bf16']:.2e}, split operands {out['high']:.2e}")
+    assert 0.2 <= rms(ref) <= 0.45 and out["high"] <= 1e-3 and out["bf16"] > 1e-3
+    # (3) cost at the benchmark's batch
+    rng = np.random.default_rng(5)
+    batch = [rng.integers(0, 65536, size=250).tolist() for _ in range(256)]
+    ms = {}
+    for name, e in (("bf16", eng), ("high", hi)):
+        e.decode(batch)
+        e.decode(batch)
+        ms[name] = e.last_timing()
+    print(f"codec pass, 256 x 250 frames: bf16 operands {ms['bf16']:.1f} ms, split operands {ms['high']:.1f} ms ({ms['high'] / ms['bf16']:.2f}x)")
+    hi.close()
+
+
 def test_verify_checkpoint_codec_half_on_a_neucodec_style_state_dict(neucodec, tmp_path, capsys):
     """tools/verify_checkpoint.py --codec on what can be built offline: the synthetic NeuCodec-geometry decoder weights re-keyed into the
     original `neucodec` layout (fused c_attn) and saved as a .pt state dict.  The tool maps the keys (strictly), loads the

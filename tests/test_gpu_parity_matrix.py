@@ -142,7 +142,8 @@ CASES = (
     [(64, {"NTTS_XCD_AFFINE": "7"}), (128, {"NTTS_XCD_AFFINE": "7"}),                              # row-block XCD placement where it is not the default ...
      (256, {"NTTS_XCD_AFFINE": "0"}), (512, {"NTTS_XCD_AFFINE": "0"})] +                           # ... and off where it is
     [(16, {"NTTS_TALL": "3", "NTTS_XCD_AFFINE": "0"}), (256, {"NTTS_TALL": "3", "NTTS_XCD_AFFINE": "0"}),   # round 5: the gang's 256-row o_proj / down_proj tiles
-     (40, {"NTTS_TALL": "3", "NTTS_GU_TILE": "1"}), (128, {"NTTS_GU_TILE": "3", "NTTS_KS_O": "2", "NTTS_KS_D": "8"})])
+     (40, {"NTTS_TALL": "3", "NTTS_GU_TILE": "1"}), (128, {"NTTS_GU_TILE": "3", "NTTS_KS_O": "2", "NTTS_KS_D": "8"}),
+     (256, {"NTTS_TALL": "3", "NTTS_XCD_AFFINE": "0", "NTTS_QKV_WSTAT": "1"}), (96, {"NTTS_XCD_AFFINE": "0", "NTTS_QKV_WSTAT": "1"})])   # QKV column blocks dealt to XCDs
 
 
 @pytest.mark.parametrize("max_batch,knobs", CASES, ids=[f"b{b}-" + ("default" if not k else "-".join(f"{a[5:].lower()}{v}" for a, v in k.items())) for b, k in CASES])

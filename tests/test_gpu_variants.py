@@ -29,6 +29,7 @@ test_fp8_decode_step_logits_small_and_tile_path = cases.test_fp8_decode_step_log
 test_fp8_walk_free_running_exact = cases.test_fp8_walk_free_running_exact
 test_fp8_prequantised_checkpoint_equals_quantise_on_upload = cases.test_fp8_prequantised_checkpoint_equals_quantise_on_upload
 test_speech_range_head_is_the_full_head_inside_the_range = cases.test_speech_range_head_is_the_full_head_inside_the_range
+test_fp8_calibration_from_a_bf16_engine = cases.test_fp8_calibration_from_a_bf16_engine
 
 
 @pytest.mark.parametrize("batch", [64, 256])

@@ -23,7 +23,7 @@ for leg in $LEGS; do
            #  counter, never without the profiler -- so each pass gets a short timeout and up to three attempts)
            for ctr in FETCH_SIZE WRITE_SIZE; do export NTTS_BENCH_PRIME=0   # (no warm-up: its one-slot decode steps would dilute the per-launch means; 8 decode steps per pass -- a pass with 40 hangs under the profiler since round 3, with 4-8 it takes 8-16 s)
              for attempt in 1 2 3; do
-               rm -rf $OUT/pmc_$ctr; NTTS_NO_GRAPH=1 timeout 90 rocprofv3 --kernel-trace --pmc $ctr -f csv -d $OUT/pmc_$ctr -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-codec --prefill ${PMC_PREFILL:-621} --decode ${PMC_DECODE:-8} --no-pipeline --batch ${PMC_BATCH:-256} > $OUT/pmc_bench.json 2> $OUT/pmc_$ctr.err; rc=$?; echo "pmc $ctr attempt $attempt rc=$rc"
+               rm -rf $OUT/pmc_$ctr; env ${PMC_EXTRA_ENV:-} NTTS_NO_GRAPH=1 timeout 90 rocprofv3 --kernel-trace --pmc $ctr -f csv -d $OUT/pmc_$ctr -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-codec --prefill ${PMC_PREFILL:-621} --decode ${PMC_DECODE:-8} --no-pipeline --batch ${PMC_BATCH:-256} > $OUT/pmc_bench.json 2> $OUT/pmc_$ctr.err; rc=$?; echo "pmc $ctr attempt $attempt rc=$rc"
                [ $rc -eq 0 ] && break
              done
              python tools/pmc_summary.py $OUT/pmc_$ctr > $OUT/pmc_${ctr}_summary.txt 2>&1; head -14 $OUT/pmc_${ctr}_summary.txt; find $OUT/pmc_$ctr -name '*.csv' -size +8M -delete
