@@ -239,6 +239,7 @@ def main():
     ap.add_argument("--speech-range-head", action="store_true",
                     help="OPT-IN serving option, NEVER the headline: lm_head over 65 536 speech ids + EOS only (ntts_backbone_set_logits_range); "
                          "a separate line, labelled as such")
+    ap.add_argument("--stream-gang", action="store_true", help="stream mode: the streams dealt out over --gang engines of batch / gang slots (measured: no faster than one engine, DESIGN.md section 5)")
     ap.add_argument("--stream-admit", type=int, default=64, help="stream mode on a gang: streams per admission group (one device-side stream set each)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -327,7 +328,7 @@ def main():
     eos = cfg.vocab_size - 1
     tts = None
     # stream mode on a gang (round 5): the B streams dealt out over --gang engines of B / gang slots each, admitted in groups of --stream-admit
-    Gs = a.gang if (strm and a.gang > 1 and B % a.gang == 0 and B // a.gang >= 8 and not emu_lib) else 1
+    Gs = a.gang if (strm and a.stream_gang and a.gang > 1 and B % a.gang == 0 and B // a.gang >= 8 and not emu_lib) else 1
     if strm:
         # Streaming goes through the product's own streaming code (NeuTTS._infer_stream_batch_hip: window / cross-fade semantics of
         # ref:neutts/neutts.py:401-465 for every utterance of the batch, ONE batched codec pass per 25-token chunk on the codec
@@ -352,6 +353,7 @@ def main():
                         "state_dict": {k: v.numpy() for k, v in cw.items()}},
             codec_device=f"cuda:{dev}", do_sample=a.sample, max_batch=B // Gs, engines=Gs, lib_path=lib)
         tts.stream_admit = a.stream_admit
+        tts.stream_on_gang = Gs > 1
         tts.watermarker = None
         tts._ids_to_codes = lambda ids: [int(i) % n_codes for i in ids]     # random weights do not stay in the speech range
         tts._stream_modulo = n_codes                                         # ... the same rule for the device-side streaming path

@@ -109,6 +109,7 @@ struct ntts_backbone {
     // workgroups and loses; in an engine gang (four chains side by side) the other chains fill the CUs and what
     // counts is the bytes every CU pulls.  bit 0: o_proj, bit 1: down_proj on the 256 x 64 / 8-wave tile; gu_tile picks the gate/up tile.
     int tall = 0;
+    bool tall_xcd_split = true;      // the 256-row split-K tiles with ONE K slice per XCD (pair) (gemm.h xcd_nsplit; NTTS_TALL_XCD_SPLIT=0: slices in gridDim.y)
     bool qkv_wstat = false;          // QKV: column blocks dealt to XCDs (qkv_rope.h "W-stationary"; NTTS_QKV_WSTAT) -- used when the row-block placement is off
     // Opt-in restricted lm_head (ntts_backbone_set_logits_range; SURVEY 7 "hard parts": the reference only ever consumes <|speech_N|> ids
     // and the EOS, ref:neutts/neutts.py:276,336-341): a COMPACTED copy of the head -- rows [lr_lo, lr_hi) followed by the EOS row, padded to
@@ -242,7 +243,11 @@ static void apply_gang_shape(ntts_backbone* e) {
     const bool side_by_side = e->gang >= 2 && B > 128 && B <= 256;
     e->tall = (e->tall_env >= 0 ? e->tall_env : (side_by_side ? 3 : 0)) & 3;
     e->xcd_affine = e->affine_env >= 0 ? e->affine_env : (B > 128 && !side_by_side ? 7 : 0);
-    e->qkv_wstat = env_int("NTTS_QKV_WSTAT", 0) != 0;
+    // QKV column blocks dealt to XCDs whenever the row-block placement is off for a gang (FETCH per launch 17.1 -> 6.1 MB, step -0.7 %:
+    // profiles/r05g_*); NTTS_QKV_WSTAT = 0 / 1 overrides
+    const int ws = env_int("NTTS_QKV_WSTAT", -1);
+    e->qkv_wstat = ws >= 0 ? ws != 0 : side_by_side;
+    e->tall_xcd_split = env_int("NTTS_TALL_XCD_SPLIT", 1) != 0;
 }
 
 extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, ntts_backbone** out) {
@@ -1154,7 +1159,7 @@ static void k_attn(ntts_backbone* e, int i) {
 static void k_o_proj(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, QD = e->cfg.num_heads * 64;
     GemmArgs a = gemm_args(e, e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->slabs, H, B, H, QD, e->layers[i].so, e->layers[i].xs[1]);
-    if (e->tall & 1) { gemm_tall<EPI_SPLITK>(a, e->ks_o, e->stream); return; }
+    if (e->tall & 1) { a.xcd_nsplit = e->tall_xcd_split ? -1 : 0; gemm_tall<EPI_SPLITK>(a, e->ks_o, e->stream); return; }   // (one K slice per XCD pair: its X columns enter two L2s, not eight)
     if ((e->xcd_affine & 1) && e->xcd_xps) a.xcd_maffine = -1;
     gemm_skinny<EPI_SPLITK>(a, e->ks_o, e->stream);
 }
@@ -1185,7 +1190,7 @@ static void k_gate_up(ntts_backbone* e, int i) {
 static void k_down(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, F = e->F;
     GemmArgs a = gemm_args(e, e->act_dec, F, e->layers[i].wd, F, nullptr, e->slabs, H, B, H, F, e->layers[i].sd, e->layers[i].xs[3]);
-    if (e->tall & 2) { gemm_tall<EPI_SPLITK>(a, e->ks_d, e->stream); return; }
+    if (e->tall & 2) { a.xcd_nsplit = e->tall_xcd_split ? -1 : 0; gemm_tall<EPI_SPLITK>(a, e->ks_d, e->stream); return; }
     a.xcd_nsplit = -1;   // one K slice per XCD (pair) unless the row-block placement below applies (FETCH 15.0 -> 6.8 MB per launch, profiles/r02f_*)
     if ((e->xcd_affine & 2) && e->xcd_xps) a.xcd_maffine = -1;
     gemm_skinny<EPI_SPLITK>(a, e->ks_d, e->stream);

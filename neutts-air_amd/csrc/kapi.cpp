@@ -187,6 +187,10 @@ extern "C" int ntts_k_gemm_probe(int32_t M, int32_t N, int32_t K, int32_t config
             case 52: probe_launch<8, 1, 2, 2>(a, ks, abl); break;
             case 53: probe_launch<8, 2, 2, 2>(a, ks, abl); break;   // 256 x 128, 16 waves
             case 54: probe_launch<4, 2, 2, 3>(a, ks, abl); break;   // 128 x 128, 8 waves
+            case 55: probe_launch<4, 4, 5, 2>(a, ks, abl); break;   // 320 x 256, 16 waves (80 x 64 per wave): 11 % fewer LDS-DMA bytes per FLOP than 256 x 256; 144 KB
+            case 57: probe_launch<2, 4, 10, 2>(a, ks, abl); break;  // 320 x 256, 8 waves (160 x 64 per wave, 2 waves per SIMD: up to 256 registers each)
+            case 58: probe_launch<2, 4, 12, 2>(a, ks, abl); break;  // 384 x 256, 8 waves (192 x 64 per wave)
+            case 56: probe_launch<4, 4, 6, 2>(a, ks, abl); break;   // 384 x 256, 16 waves (96 x 64 per wave): 17 % fewer; 160 KB = all of a CU's LDS
             default: break;
         }
     };

@@ -382,7 +382,7 @@ class NeuTTS:
         if not isinstance(ref_texts, (list, tuple)):
             ref_texts = [ref_texts] * len(texts)
             ref_codes = [ref_codes] * len(texts)
-        cap = self.gang.max_batch if (self.gang is not None and getattr(self, "stream_on_gang", True)) else self.backbone.max_batch
+        cap = self.gang.max_batch if (self.gang is not None and getattr(self, "stream_on_gang", False)) else self.backbone.max_batch
         if len(texts) > cap:
             raise ValueError(f"{len(texts)} utterances exceed the engine's {cap} decode slots")
         prompts = [self._apply_chat_template(rc, rt, t) for rc, rt, t in zip(ref_codes, ref_texts, texts)]
@@ -629,7 +629,7 @@ class NeuTTS:
             room[k] -= m
             i0 += m
             turn += 1
-        active: List[list] = [[] for _ in range(G)]           # per engine: [stream set, utterance indices, slots, steps until its next window]
+        active: List[list] = [[] for _ in range(G)]           # per engine: [stream set, utterance indices, slots]
         try:
             while any(pending) or any(active):
                 for k, eng in enumerate(gang.engines):
@@ -656,7 +656,7 @@ class NeuTTS:
                     if pending[k]:
                         idx = pending[k].pop(0)
                         slots = [eng.acquire_slot() for _ in idx]
-                        item = [None, idx, slots, chunk + look_f - 1]
+                        item = [None, idx, slots]
                         active[k].append(item)                # (registered first: its slots are released on any exit path)
                         budget = eng.cfg.get("max_prefill_tokens", 0) or 16384
                         i0 = 0
@@ -673,14 +673,12 @@ class NeuTTS:
                         admitted = True
                         running += len(idx)
                     if running:
-                        # as many steps as the stream set CLOSEST to its next window still needs (at most a chunk): a new group holds one
-                        # token per stream and needs chunk + lookforward - 1 more for its first window, an older one a chunk per window
-                        burst = max(1, min(chunk, min(item[3] for item in active[k])))
-                        eng.decode(burst)
-                        for item in active[k]:
-                            item[3] -= burst
-                            while item[3] <= 0:
-                                item[3] += chunk
+                        # a new group holds one token per stream: lookforward - 1 steps now and whole chunks from then on complete its
+                        # first window (chunk + lookforward tokens) exactly at a burst boundary; the older groups just run ahead.
+                        # (Measured and not kept: bursts sized to whatever the set nearest to its next window needs -- more, shorter
+                        #  bursts and pump rounds: 127.0 k instead of 143.5 k codec-tokens/s at 512 streams, first audio 182 instead of
+                        #  157 ms; profiles/r05g_bench_nano-fp8_stream_*.json)
+                        eng.decode(look_f - 1 if (admitted and look_f > 1) else chunk)
         finally:
             for k, eng in enumerate(gang.engines):
                 for item in active[k]:
@@ -699,7 +697,11 @@ class NeuTTS:
                                 pass
 
     def _infer_stream_batch_hip(self, prompts: List[List[int]], ref_codes: List[List[int]]):
-        if (self.gang is not None and len(prompts) > 1 and getattr(self, "stream_on_gang", True) and self._stream_on_device(ref_codes)):
+        # (stream_on_gang: off unless the caller sets it.  Measured on MI355X, 512 streams of the fp8 Nano-sized model: a gang of four 128-slot
+        #  engines streams 143.5 k codec-tokens/s with first audio after 157 / 178 / 203 ms (first / median / last stream), ONE 512-slot engine
+        #  144.2 k with 182 ms for every stream -- the decode steps of 4 x 128 rows cost what those of 512 rows cost, and the prompt passes of
+        #  all streams stand before the last stream's first window either way)
+        if (self.gang is not None and len(prompts) > 1 and getattr(self, "stream_on_gang", False) and self._stream_on_device(ref_codes)):
             yield from self._infer_stream_batch_gang(prompts, ref_codes)
             return
         eng = self.backbone

@@ -282,6 +282,7 @@ def test_infer_stream_batch_over_a_gang_with_staggered_admission(tts):
     tts.min_new_tokens, tts.max_context = 34, 150
     tts.gang = _hip.EngineGang(tts.backbone, 2)          # what NeuTTS(engines=2) sets up at construction
     tts.stream_admit = 1
+    tts.stream_on_gang = True                            # (opt-in: off by default)
     try:
         tts.stream_on_device = False
         singles = [list(tts.infer_stream(t, ref_codes, "So I'm live.")) for t in texts]
@@ -304,7 +305,7 @@ def test_infer_stream_batch_over_a_gang_with_staggered_admission(tts):
             next(tts.infer_stream_batch(["a"] * (tts.gang.max_batch + 1), ref_codes, "x"))
     finally:
         tts.stream_on_device = True
-        del tts.stream_admit
+        del tts.stream_admit, tts.stream_on_gang
         for k, c in enumerate(tts._gang_codecs or []):
             c.set_stream(None)
             if k:

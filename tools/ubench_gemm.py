@@ -16,7 +16,7 @@ CONFIGS = {10: "64x64 4w NS2", 11: "64x64 4w NS3", 12: "64x64 4w NS4", 13: "64x6
            21: "64x64 2w NS4", 22: "64x64 1w NS4", 23: "64x128 4w NS3", 24: "64x128 8w NS3", 25: "128x64 8w NS3",
            26: "128x64 4w NS3", 30: "128x128 4w NS2", 31: "128x128 4w NS3", 40: "256x128 8w NS2", 41: "128x256 8w NS2",
            42: "256x256 16w NS2", 43: "256x128 8w NS3", 44: "256x128 4w NS2", 45: "256x256 8w NS2", 46: "256x256 16w 4xK32", 47: "256x256 16w 3xK32", 48: "256x256 8w 4xK32", 49: "128x128 4w 4xK32", 60: "256x256 16w persist", 50: "256x64 4w NS3", 51: "256x64 8w NS3",
-           52: "256x64 8w NS2", 53: "256x128 16w NS2", 54: "128x128 8w NS3"}
+           52: "256x64 8w NS2", 53: "256x128 16w NS2", 54: "128x128 8w NS3", 55: "320x256 16w NS2", 56: "384x256 16w NS2", 57: "320x256 8w NS2", 58: "384x256 8w NS2"}
 
 
 def probe(M, N, K, cfg, abl, copies, iters=200):
@@ -38,6 +38,19 @@ def prefill():
             t = probe(M, N, K, cfg, 0, 1, iters=5)
             ab = [probe(M, N, K, cfg, a, 1, iters=5) for a in (1, 2, 3, 4)]
             print(f"{CONFIGS[cfg]:18s} {t:9.1f} {fl / t / 1e6:7.0f} | {'':14s} {ab[0]:9.1f} {ab[1]:9.1f} {ab[2]:9.1f} {ab[3]:9.1f}", flush=True)
+
+
+def prefill_big():
+    """round 5: tiles with MORE rows than 256 x 256 (fewer LDS-DMA bytes per FLOP: the prompt-pass GEMMs run at the per-CU DMA rate,
+    profiles/r01e_ubench_prefill_ring_variants.txt ablations), random operands, sustained."""
+    for name, (M, N, K) in PREFILL.items():
+        fl = 2.0 * M * N * K
+        print(f"== {name}  M={M} N={N} K={K}  {fl / 1e12:.2f} TFLOP, random operands")
+        print(f"{'config':18s} {'us':>9s} {'TF/s':>7s} | ablations us: {'noMFMA':>9s} {'noDMA':>9s} {'noStore':>9s}")
+        for cfg in (42, 45, 55, 56, 57, 58, 42):
+            t = probe(M, N, K, cfg, 32, 1, iters=60)
+            ab = [probe(M, N, K, cfg, 32 | a_, 1, iters=20) for a_ in (1, 2, 4)]
+            print(f"{CONFIGS[cfg]:18s} {t:9.1f} {fl / t / 1e6:7.0f} | {'':14s} {ab[0]:9.1f} {ab[1]:9.1f} {ab[2]:9.1f}", flush=True)
 
 
 def power():
@@ -119,6 +132,8 @@ def main():
         return layout()
     if "--tall" in sys.argv:
         return tall()
+    if "--prefill-big" in sys.argv:
+        return prefill_big()
     if "--prefill" in sys.argv:
         return prefill()
     if "--mall" in sys.argv:
