@@ -962,6 +962,25 @@ def main():
                         pmc["+".join(names)] = {"traffic_bytes_per_launch": tr, "alg_bytes_per_launch": alg, "overfetch": tr / alg}
         except (OSError, KeyError, ValueError, TypeError):
             pass
+        # ... and the same counters taken on the GANG's decode shape (NTTS_TALL=3 NTTS_XCD_AFFINE=0 NTTS_QKV_WSTAT=1 on one engine: 256-row
+        # o_proj / down_proj tiles with a K slice per XCD pair, QKV column blocks dealt to XCDs) -- what each chain of the timed region moves
+        pmc_gang = {}
+        try:
+            if not std_cfg:
+                raise OSError("no PMC pass for this configuration")
+            pg_path = latest_profile("_pmc_traffic_gang_shape.json")
+            with open(pg_path) as fh:
+                pg = json.load(fh)
+            for prefix, names in ROCPROF_SYMBOLS:
+                for kname, rec in pg["kernels"].items():
+                    if kname.startswith(prefix.rstrip(", ")) and all(n in live for n in names):
+                        tr = rec["fetch_bytes_per_launch"] + rec.get("write_bytes_per_launch_uncorrected", 0.0)
+                        nl_ = sum(live[n][2] for n in names)
+                        alg = sum(live[n][1] * live[n][2] for n in names) / nl_
+                        pmc_gang["+".join(names)] = {"traffic_bytes_per_launch": tr, "alg_bytes_per_launch": alg, "overfetch": tr / alg, "symbol": kname[:48]}
+            pmc_gang["source"] = os.path.relpath(pg_path, ROOT)
+        except (OSError, KeyError, ValueError, TypeError):
+            pass
         # The dominant kernel: by rocprofv3 SYMBOL share of the same command when the committed summary covers this configuration
         # (VERDICT r3 item 5), else by this run's ms per step.  A symbol that serves several logical kernels (the split-K template:
         # o_proj + down_proj) is reported as their launch-weighted mean.
@@ -991,6 +1010,7 @@ def main():
                               if gang_step_ms else None),
                 "dominant_choice": choice,
                 "pmc_per_kernel": pmc or None,
+                "pmc_per_kernel_gang_shape": pmc_gang or None,
                 "mfma_util": mfma_util_table(latest_profile("_mfma_util.txt")) if std_cfg else None,
                 "rocprof": rocprof,
                 "per_kernel": [{"kernel": r[1], "us": r[2] * 1e3, "launches_per_step": r[4], "alg_bytes": r[3],

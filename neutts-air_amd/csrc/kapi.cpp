@@ -151,12 +151,14 @@ extern "C" int ntts_k_gemm_probe(int32_t M, int32_t N, int32_t K, int32_t config
     config %= 1000;
     const bool pf = (abl & 8) != 0;
     const int tile_major = (abl & 16) ? 1 : 0;     // weights addressed tile-major (same bytes, sequential per workgroup)
-    abl &= 7;   // (bits 8, 16, 32 are handled here)
+    const bool x_ktm = (abl & 64) != 0;            // X addressed k-tile-major ([K / 64][M][64]: a block's X tile is one contiguous run; timing only)
+    abl &= 7;   // (bits 8, 16, 32, 64 are handled here)
     auto run = [&](int i) {
         if (pf) NTTS_LAUNCH((prefetch_kernel), dim3(256), dim3(256), (hipStream_t)0, (const u32x4*)(W + (size_t)((i + 1) % copies) * wn), (long)(wn / 8), (int*)nullptr);
         GemmArgs a{};
         a.X = X; a.ldx = K; a.W = W + (size_t)(i % copies) * wn; a.ldw = K; a.out = C; a.ldo = N; a.M = M; a.N = N; a.K = K;
         a.w_tile_major = tile_major;
+        if (x_ktm) { a.ldx = 64; a.x_kt_stride = (long)M * 128; }
         switch (config) {
             case 0: NTTS_LAUNCH((empty_kernel), dim3(256), dim3(64), (hipStream_t)0, (int*)nullptr); break;
             case 10: probe_launch<4, 1, 1, 2>(a, ks, abl); break;   // 64 x 64, 4 waves

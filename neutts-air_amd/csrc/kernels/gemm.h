@@ -90,6 +90,8 @@ struct GemmArgs {
     // at every kernel boundary; xcd_maffine = number of K slices.  Every group then streams the whole W (fetched from HBM once, from the
     // memory-side cache by the other groups).  Speed only, like xcd_nsplit: block b on XCD b % 8 is an observation, not a contract.
     int xcd_maffine, xcd_xps;
+    long x_kt_stride;         // probe (tools/ubench_gemm.py --x-layout): > 0: X is stored K-TILE-MAJOR -- [K / 64][M] rows of 128 bytes (ldx = 64), this many
+                              // bytes between consecutive K tiles of a row -- so that a block's X tile is one contiguous run; 0: row-major rows of ldx elements
     unsigned long long* tl;   // diagnostics (ntts_backbone_gemv_timeline on a large-batch engine): [workgroups][16] timestamps of wave 0 -- 0 entry,
                               // 1 first ring slots requested, 2 first tile landed (past the first barrier), 3 k-loop done, 4 epilogue issued, 5 stores drained
 };
@@ -560,7 +562,7 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
                                     : (const char*)p.W + (long)n * p.ldw * ESZ + c * 16;
         }
     }
-    const long xstep = BK * 2;                           // bytes between consecutive K tiles of a row (128; 64 for BK = 32)
+    const long xstep = p.x_kt_stride > 0 ? p.x_kt_stride : BK * 2;   // bytes between consecutive K tiles of a row (128; 64 for BK = 32)
     const long wstep = p.w_tile_major ? 8192 : xstep;   // tile-major: the next 64 x 128-byte block (BK = 64 only)
     auto stage = [&](int kt, int buf) {
         if constexpr (ABL & 2) return;

@@ -53,6 +53,18 @@ def prefill_big():
             print(f"{CONFIGS[cfg]:18s} {t:9.1f} {fl / t / 1e6:7.0f} | {'':14s} {ab[0]:9.1f} {ab[1]:9.1f} {ab[2]:9.1f}", flush=True)
 
 
+def x_layout():
+    """round 5: does the LAYOUT of the activation operand bound the LDS-DMA rate of the big GEMMs?  X row-major (a block's 256 x 64 tile = 256 lines of
+    128 B, 2 K bytes apart) vs X k-tile-major (the tile = 32 KB contiguous), W row-major / tile-major, random operands; noMFMA = the DMA stream alone."""
+    for name, (M, N, K) in PREFILL.items():
+        fl = 2.0 * M * N * K
+        print(f"== {name}  M={M} N={N} K={K}  {fl / 1e12:.2f} TFLOP, 256x256 16w NS2, random operands")
+        for label, bits in (("X rows, W rows", 0), ("X k-tile-major, W rows", 64), ("X rows, W tile-major", 16), ("X k-tile-major, W tile-major", 80), ("X rows, W rows", 0)):
+            t = probe(M, N, K, 42, 32 | bits, 1, iters=60)
+            t1 = probe(M, N, K, 42, 32 | bits | 1, 1, iters=20)
+            print(f"  {label:30s} {t:8.1f} us {fl / t / 1e6:6.0f} TF/s   noMFMA {t1:8.1f} us", flush=True)
+
+
 def power():
     """The same prefill / codec GEMMs on constant-filled operands (hipMemset) and on operands with the bit statistics of real
     data: how much of the distance to the 2.5 PFLOP/s matrix-core peak is the clock the chip sustains under real toggling."""
@@ -132,6 +144,8 @@ def main():
         return layout()
     if "--tall" in sys.argv:
         return tall()
+    if "--x-layout" in sys.argv:
+        return x_layout()
     if "--prefill-big" in sys.argv:
         return prefill_big()
     if "--prefill" in sys.argv:
