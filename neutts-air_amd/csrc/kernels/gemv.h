@@ -148,7 +148,9 @@ NTTS_KERNEL((FW + 4) * 64) void gemv_kernel(GemvArgs p) {
     if (p.w_tile_major) { wbase = (const bf16_t*)((const char*)p.W + (long)(f0 >> 6) * 64 * p.K * ESZ) + ((f0 & 63) + l15) * 64 + g * 16; wstep = 4096; }
     else wbase = (const bf16_t*)((const char*)p.W + (long)(f0 + l15) * p.ldw * ESZ) + g * 16;
     bf16x8 wa[KT][2];
-    if constexpr (PRO) sync_keep_dma();                           // the helpers' requests go first (norm.h issue_barrier)
+    if constexpr (PRO) sync_keep_dma();                           // the helpers' requests go first (norm.h issue_barrier).  Round 5 re-measured the other order --
+                                                                  // weights requested before the prologue's rows are out -- at batch 1 / 8: step 0.807 -> 0.843 (gate/up), 0.820 (QKV),
+                                                                  // 0.856 (both); 1.029 -> 1.049 / 1.066 (profiles/r05j_sweep_b*_gemv_weights_first.log): not kept
 #pragma unroll
     for (int j = 0; j < KT; ++j) {
         const bf16_t* src = wbase + (long)(kt0 + (j < nk ? j : nk - 1)) * wstep;
