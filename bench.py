@@ -163,7 +163,10 @@ def continuous_leg(static_value, a):
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=float(os.environ.get("NTTS_BENCH_CONT_TIMEOUT", "240")))
         line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
         r = json.loads(line)
+        ss = (r.get("phase_ms") or {}).get("steady_state_tokens_per_s")
         return {"value": r["value"], "unit": r["unit"], "ratio_to_static": r["value"] / static_value, "requests": req,
+                "steady_state_value": ss, "steady_state_ratio_to_static": (ss / static_value) if ss else None,
+                "steady_state_note": "tokens of the requests finished between the 25 % and 75 % marks of the job over that time: the finite job's ramp and drain left out",
                 "ms_per_step": r["ms_per_step"], "workload": r["config"]["workload"][:400], "command": " ".join(cmd[1:]),
                 "wall_s_incl_startup": round(time.time() - t0, 1), "phase_ms": r.get("phase_ms")}
     except Exception as ex:  # noqa: BLE001  (a sub-record must never cost the headline line)
@@ -525,9 +528,12 @@ def main():
             s8["buf"] ^= 1
             s8["n"] = 0
 
+        done_at = []                                      # (wall time, tokens) of every finished request: the steady-state rate below
+
         def hook(i, slot, n_new, e=eng):
             assert n_new == int(r_glen[i]), "continuous run did not produce the expected tokens"
             tokens[0] += n_new
+            done_at.append((time.time(), n_new))
             if codec is None:
                 return
             k = which[id(e)]
@@ -565,6 +571,14 @@ def main():
         assert tokens[0] == int(r_glen.sum())
         ph.update({k: sum(e.counters[k] for e in cengs) - c0[k] for k in c0})       # scheduler diagnostics: decode steps issued, prompt passes and their sizes
         ph["slot_occupancy"] = tokens[0] / max(1, ph["decode_steps"] * B)
+        # steady state: the tokens of the requests that finished between the moments 25 % and 75 % of all requests were done, over that time
+        # -- the finite job's ramp (every slot waits for the first prompt passes) and drain (the last generation thins out) left out
+        if len(done_at) >= 64:
+            done_at.sort()
+            a25, a75 = done_at[len(done_at) // 4], done_at[(3 * len(done_at)) // 4]
+            mid = sum(nn for t, nn in done_at if a25[0] < t <= a75[0])
+            if a75[0] > a25[0]:
+                ph["steady_state_tokens_per_s"] = mid / (a75[0] - a25[0])
         return ph, None, wavs
 
     pending = []                                          # codec passes in flight: (codec engine, the lens buffer its export filled)

@@ -390,7 +390,7 @@ def test_share_arena_error_paths_and_side_by_side_chains(emu_lib):
     with pytest.raises(ValueError):
         _hip.EngineGang(eng, 5)
     with _hip.EngineGang(eng, 2) as gang:
-        assert len(gang.engines) == 2 and gang.lane(0) and gang.lane(1)
+        assert len(gang.engines) == 2 and len(gang._streams) == 2          # (a lane per engine; the emulator's streams are null handles)
         assert gang.generate(pa + pb, samp) == alone_a + alone_b
     assert len(gang.engines) == 1 and gang.lane(0) is None
     assert eng.generate(pa, samp) == alone_a
