@@ -273,12 +273,12 @@ def test_infer_stream_batch_equals_single_streams(tts):
 
 def test_infer_stream_batch_over_a_gang_with_staggered_admission(tts):
     """NeuTTS(engines=2): infer_stream_batch deals its utterances out over the gang in groups of `stream_admit`, one device-side stream set
-    per group, the second group of an engine admitted while its first one already streams.  Four utterances, groups
+    per group, the second group of an engine admitted while its first one already streams.  Three utterances, groups
     of one: every utterance's chunks are those of its own `infer_stream`, bit for bit -- a window is defined by token counts, not by
     where the decode bursts end."""
     from neutts import _hip
     ref_codes = [3, 77, 200, 5, 18, 9, 100, 41]
-    texts = ["Streaming test.", "Another one, a little longer.", "Third.", "And the fourth of them."]
+    texts = ["Streaming test.", "Another one, a little longer.", "Third."]       # three groups over two engines: engine 0 admits its second group while its first one streams
     tts.min_new_tokens, tts.max_context = 34, 150
     tts.gang = _hip.EngineGang(tts.backbone, 2)          # what NeuTTS(engines=2) sets up at construction
     tts.stream_admit = 1
@@ -300,7 +300,7 @@ def test_infer_stream_batch_over_a_gang_with_staggered_admission(tts):
             assert len(got[i]) == len(singles[i]) >= 2
             for a, b in zip(got[i], singles[i]):
                 assert a.shape == b.shape and np.array_equal(a, b)
-        assert order.index(2) > order.index(0) and order.index(3) > order.index(1)      # the second groups came in behind the first ones
+        assert order.index(2) > order.index(0)                                          # the second group of engine 0 came in behind its first one
         with pytest.raises(ValueError, match="decode slots"):
             next(tts.infer_stream_batch(["a"] * (tts.gang.max_batch + 1), ref_codes, "x"))
     finally:

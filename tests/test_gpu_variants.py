@@ -28,7 +28,13 @@ test_fp8_needs_its_input_scales = cases.test_fp8_needs_its_input_scales
 test_fp8_decode_step_logits_small_and_tile_path = cases.test_fp8_decode_step_logits_small_and_tile_path
 test_fp8_walk_free_running_exact = cases.test_fp8_walk_free_running_exact
 test_fp8_prequantised_checkpoint_equals_quantise_on_upload = cases.test_fp8_prequantised_checkpoint_equals_quantise_on_upload
-test_speech_range_head_is_the_full_head_inside_the_range = cases.test_speech_range_head_is_the_full_head_inside_the_range
+
+
+@pytest.mark.parametrize("knobs", [k for k, _ in cases.HEAD_TILES], ids=[i for _, i in cases.HEAD_TILES])
+def test_speech_range_head_is_the_full_head_inside_the_range(lib, knobs, monkeypatch):
+    cases._speech_range_body(lib, knobs, monkeypatch)
+
+
 test_fp8_calibration_from_a_bf16_engine = cases.test_fp8_calibration_from_a_bf16_engine
 
 
