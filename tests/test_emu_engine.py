@@ -36,8 +36,9 @@ def test_tiny_teacher_forced(emu_lib):
     # round 5, the gang's "tall" decode tiles: o_proj / down_proj on 256 x 64 (8 waves, one m-block per chain), gate/up on 256 x 192 (12 waves,
     # uneven loader split with TN = 4, partial last column block) / 256 x 256 / the 2-slot 128 x 128
     # + QKV column blocks dealt to XCDs (surplus workgroups return at once).  ONE run on the emulator (a 256-row tile costs it minutes): the 256 x 256
-    # gate/up instantiation is the prompt pass's, the 2-slot 128 x 128 tile and the other split factors run in the GPU matrix (tests/test_gpu_parity_matrix.py)
-    {"NTTS_SMALL_BATCH": "0", "NTTS_TALL": "3", "NTTS_GU_TILE": "1", "NTTS_XCD_AFFINE": "0", "NTTS_KS_O": "2", "NTTS_KS_D": "3", "NTTS_QKV_WSTAT": "1"}])
+    # gate/up instantiation is the prompt pass's, the 256 x 192 and 2-slot 128 x 128 tiles and the other split factors run in the GPU matrix (tests/test_gpu_parity_matrix.py)
+    # (gate/up on 256 x 192 -- 12 waves, uneven loader split with TN = 4 -- costs the emulator three minutes: GPU matrix only, case b40-tall3-gu_tile1)
+    {"NTTS_SMALL_BATCH": "0", "NTTS_TALL": "3", "NTTS_XCD_AFFINE": "0", "NTTS_KS_O": "2", "NTTS_KS_D": "3", "NTTS_QKV_WSTAT": "1"}])
 def test_small_gqa2_page_crossing_walk_exact(emu_lib, knobs, monkeypatch):
     """2 kv heads, prompt of 70 (3 pages), decode crosses the 96-token page boundary; walk weights (wide margins, a new id every step) so the
     free-running greedy ids must be bit-identical to HF's -- on the small-batch decode path (wave-per-16-features GEMVs with
