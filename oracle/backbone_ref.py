@@ -62,8 +62,13 @@ def fp8_quantize_weights(w: Dict[str, torch.Tensor], input_scales: Dict[str, flo
     return out
 
 
+FP8_ACT_HOOK = None     # tests only (tests/test_oracle_fp8_sensitivity.py): applied to a GEMM input right before its e4m3 quantisation
+
+
 def fp8_act(x: torch.Tensor, in_scale: float) -> torch.Tensor:
     """e4m3 VALUES (as fp32) of a GEMM input: e4m3(clamp(x / in_scale)), RNE."""
+    if FP8_ACT_HOOK is not None:
+        x = FP8_ACT_HOOK(x)
     return (x.to(torch.float32) * (1.0 / in_scale)).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).to(torch.float32)
 
 
