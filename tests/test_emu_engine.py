@@ -32,13 +32,7 @@ def test_tiny_teacher_forced(emu_lib):
      "NTTS_ATTN_SPLIT": "2", "NTTS_ATTN_SPLIT_CTX": "45"},   # large-batch path (gemm.h tiles, fused QKV + RoPE + K append), 256 x 256 lm_head tile, context-split attention + combine pass from context 45 on
     {"NTTS_SMALL_BATCH": "0", "NTTS_HEAD_TILE": "1"},        # ... 128 x 128 lm_head tile
     # the lm_head's natural-order tile (gemm.h TN = 6: 256 x 288, 12 waves, uneven LDS-DMA loader split, partial last tile)
-    {"NTTS_SMALL_BATCH": "0", "NTTS_HEAD_TILE": "4"},
-    # round 5, the gang's "tall" decode tiles: o_proj / down_proj on 256 x 64 (8 waves, one m-block per chain), gate/up on 256 x 192 (12 waves,
-    # uneven loader split with TN = 4, partial last column block) / 256 x 256 / the 2-slot 128 x 128
-    # + QKV column blocks dealt to XCDs (surplus workgroups return at once).  ONE run on the emulator (a 256-row tile costs it minutes): the 256 x 256
-    # gate/up instantiation is the prompt pass's, the 256 x 192 and 2-slot 128 x 128 tiles and the other split factors run in the GPU matrix (tests/test_gpu_parity_matrix.py)
-    # (gate/up on 256 x 192 -- 12 waves, uneven loader split with TN = 4 -- costs the emulator three minutes: GPU matrix only, case b40-tall3-gu_tile1)
-    {"NTTS_SMALL_BATCH": "0", "NTTS_TALL": "3", "NTTS_XCD_AFFINE": "0", "NTTS_KS_O": "2", "NTTS_KS_D": "3", "NTTS_QKV_WSTAT": "1"}])
+        {"NTTS_SMALL_BATCH": "0", "NTTS_HEAD_TILE": "4"}])
 def test_small_gqa2_page_crossing_walk_exact(emu_lib, knobs, monkeypatch):
     """2 kv heads, prompt of 70 (3 pages), decode crosses the 96-token page boundary; walk weights (wide margins, a new id every step) so the
     free-running greedy ids must be bit-identical to HF's -- on the small-batch decode path (wave-per-16-features GEMVs with
@@ -241,6 +235,61 @@ def test_generate_with_pages_held_outside_the_call(emu_lib, monkeypatch):
     assert eng.free_slots() == 2 and eng.kv_stats()["free_pages"] == 2                             # everything the failed calls held is back
     eng.release(holder)
     assert eng.generate(prompts, short, steps_per_poll=3) == alone
+
+
+def test_gang_decode_shape_matches_the_single_chain_shape(emu_lib, monkeypatch):
+    """Round 5 (ABI 8 ntts_backbone_set_gang): the gang's decode shape -- o_proj / down_proj on the 256 x 64 tile (8 waves, all rows of a
+    chain in one m-block, one K slice per XCD pair), QKV column blocks dealt to XCDs (surplus workgroups return at once), no row-block
+    placement -- computes what the single-chain shape computes: the ids of walk weights are the same at every step, every logits row
+    agrees to fp32-summation-order noise (the K slices are cut differently), re-capturing the step graph (set_gang) changes
+    nothing bit for bit, and other split-K factors keep the ids.  (A 2-slot engine takes the shape from the NTTS_TALL / NTTS_QKV_WSTAT /
+    NTTS_XCD_AFFINE overrides -- set_gang picks it from 129 slots up, and a 256-row tile costs the emulator a minute per dozen steps; the
+    GPU suite runs the real shapes at batch 16 ... 512 against the oracle, tests/test_gpu_parity_matrix.py, and at full depth,
+    test_air_golden_slot_in_a_full_ragged_dirty_batch.)"""
+    monkeypatch.setenv("NTTS_SMALL_BATCH", "0")
+    z, cfg, w = load_fixture("backbone_small_walk")
+    S, N, eos = 40, 5, int(z["eos"])
+    prompts = [br.synthetic_prompt(cfg, 0, S), br.synthetic_prompt(cfg, 1, S - 7)]
+    samp = [_hip.Sampling(max_length=len(p) + N, min_new_tokens=N, eos_token_id=eos, do_sample=False) for p in prompts]
+
+    def run(eng):
+        eng.prefill(prompts, [0, 1], samp)
+        rows = []
+        for k in range(N):
+            if k:
+                eng.decode(1)
+            rows.append([eng.read_logits(s).copy() for s in (0, 1)])
+        ids = [eng.read(s)[0] for s in (0, 1)]
+        eng.release_many([0, 1])
+        return rows, ids
+
+    eng = make_engine(cfg, w, emu_lib, max_batch=2, max_context=96, bf16_upload=True)
+    eng.set_debug(True)
+    rows1, ids1 = run(eng)
+    eng.close()
+    assert all(len(set(i)) == N for i in ids1)
+    for k, v in {"NTTS_TALL": "3", "NTTS_QKV_WSTAT": "1", "NTTS_XCD_AFFINE": "0"}.items():
+        monkeypatch.setenv(k, v)
+    eng = make_engine(cfg, w, emu_lib, max_batch=2, max_context=96, bf16_upload=True)
+    eng.set_debug(True)
+    rows4, ids4 = run(eng)
+    eng.set_gang(4)
+    rows4b, ids4b = run(eng)
+    eng.close()
+    assert ids4 == ids1 and ids4b == ids1
+    for a, b, c in zip(rows1, rows4, rows4b):
+        for s in (0, 1):
+            assert np.array_equal(b[s], c[s])
+            fin = np.isfinite(a[s])                                              # (the masked EOS column is -inf in both)
+            assert np.array_equal(fin, np.isfinite(b[s])) and fin.sum() == len(fin) - 1
+            assert np.abs(a[s][fin] - b[s][fin]).max() <= 2.0 ** -6 * np.abs(a[s][fin]).max()       # a couple of bf16 ulps of the largest logit
+    monkeypatch.setenv("NTTS_KS_O", "2")
+    monkeypatch.setenv("NTTS_KS_D", "3")
+    eng = make_engine(cfg, w, emu_lib, max_batch=2, max_context=96, bf16_upload=True)
+    eng.prefill(prompts, [0, 1], samp)
+    eng.decode(N - 1)
+    assert [eng.read(s)[0] for s in (0, 1)] == ids1          # (other slab counts: other fp32 sums, the walk's margins hold the ids)
+    eng.close()
 
 
 def test_engine_error_paths(emu_lib):
