@@ -505,7 +505,7 @@ def main():
     def one_step_continuous(collect=False, last=False):
         """One pass over R ragged requests: continuous batching (BackboneEngine.generate: admission by free slots, KV pages and
         prefill budget; ONE burst of decode steps always queued ahead of the host's bookkeeping; finished slots exported on the
-        device, released and refilled, new prompts admitted 24 at a time), the codec over every B finished utterances on its own
+        device, released and refilled, new prompts admitted 24 at a time and the engines of a gang in waves -- EngineGang.generate), the codec over every B finished utterances on its own
         stream beside the decode steps of the others."""
         ph = {"generate_wall": 0.0, "codec_tail_wall": 0.0, "codec_passes": 0}
         c0 = {k: sum(e.counters[k] for e in cengs) for k in eng.counters}
@@ -529,6 +529,8 @@ def main():
             s8["n"] = 0
 
         done_at = []                                      # (wall time, tokens) of every finished request: the steady-state rate below
+        codec_rows = min(B, int(os.environ.get("NTTS_BENCH_CODEC_ROWS", str(B))))       # finished utterances per codec pass
+        codec_on_wave = int(os.environ.get("NTTS_BENCH_CODEC_ON_WAVE", "0"))           # > 0: also flush that many or more at an engine's admission
 
         def hook(i, slot, n_new, e=eng):
             assert n_new == int(r_glen[i]), "continuous run did not produce the expected tokens"
@@ -542,15 +544,21 @@ def main():
             e.export_codes([slot], 0, n_codes, ptr(stage_codes[k][s8["buf"]], row), N_max, ptr(stage_lens[k][s8["buf"]], row), modulo=True)
             s8["lens"][row] = n_new
             s8["n"] = row + 1
-            if s8["n"] == B:
-                flush(k, B)
+            if s8["n"] >= codec_rows:
+                flush(k, s8["n"])
 
-        # (burst length: 4 steps per poll on one engine, profiles/r02i_sweep_continuous_sched.txt; 2 on a gang -- the engines' bursts are
+        # (burst length: 4 steps per poll on one engine, profiles/r02i_sweep_continuous_sched.txt; 1 on a gang -- the engines' bursts are
         #  enqueued in turn, and the shorter the turn the closer the chains run side by side: 144.5 k at 1-2, 132.0 k at 4, 106.7 k at 8
-        #  steps per poll, profiles/r04s_sweep_continuous_gang_sched.txt)
-        kw = dict(steps_per_poll=int(os.environ.get("NTTS_BENCH_POLL", "2" if Gc > 1 else "4")), prefill_token_budget=a.prefill_chunk * S,
+        #  steps per poll, profiles/r04s_sweep_continuous_gang_sched.txt; with the engines' admissions in waves 149.8 k at 1, 146.3-147.0 k
+        #  at 2 against 144.3-145.6 k for independent admissions, profiles/r05m_sweep_continuous_admission_*.txt)
+        kw = dict(steps_per_poll=int(os.environ.get("NTTS_BENCH_POLL", "1" if Gc > 1 else "4")), prefill_token_budget=a.prefill_chunk * S,
                   min_admit=int(os.environ.get("NTTS_BENCH_MIN_ADMIT", "24")), on_finished=hook,
                   run_ahead=os.environ.get("NTTS_BENCH_RUN_AHEAD", "1") != "0")
+        if gangc is not None:
+            kw["admit"] = os.environ.get("NTTS_BENCH_ADMIT", "wave")
+            if codec is not None and codec_on_wave > 0:
+                # a codec pass holds its engine's lane like a prompt pass does: put it next to the admission wave
+                kw["on_admit"] = lambda e, n_prompts: flush(which[id(e)], st8[which[id(e)]]["n"]) if st8[which[id(e)]]["n"] >= codec_on_wave else None      # EngineGang.generate: how the engines' prompt passes are placed against each other
         (gangc or eng).generate(r_prompts, r_samp, **kw)
         ph["generate_wall"] = (time.time() - t1) * 1e3
         t1 = time.time()

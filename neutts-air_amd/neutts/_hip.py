@@ -572,7 +572,7 @@ class BackboneEngine:
     # -- continuous batching (host scheduler): keep every slot busy until all prompts are done
     def generate(self, prompts: Sequence[Sequence[int]], sampling, steps_per_poll: int = 16,
                  prefill_token_budget: Optional[int] = None, share_prefix: bool = False, min_admit: int = 1,
-                 on_finished=None, run_ahead: bool = True) -> List[List[int]]:
+                 on_finished=None, run_ahead: bool = True, admit_gate=None, on_admit=None) -> List[List[int]]:
         """Batched equivalent of calling ref:neutts/neutts.py:338-351 once per prompt.
         Returns the NEW ids of each prompt (prompt stripped), in order.
         share_prefix=True: a prompt that starts like one already in flight (same speaker: chat header + reference
@@ -587,8 +587,13 @@ class BackboneEngine:
         device, the ids cannot differ).
         on_finished(request_index, slot, n_new): called for every finished request BEFORE its slot is released, INSTEAD of
         copying its ids to the host (that request's entry of the result is then []): the hook of a device-side hand-off
-        (ntts_backbone_export_codes enqueued from it is ordered before the slot's re-use)."""
-        it = self.generate_iter(prompts, sampling, steps_per_poll, prefill_token_budget, share_prefix, min_admit, on_finished, run_ahead)
+        (ntts_backbone_export_codes enqueued from it is ordered before the slot's re-use).
+        admit_gate(n_free, n_wanted) -> bool replaces the `min_admit` test while requests are running (n_wanted = min(min_admit,
+        requests waiting)); on_admit(n_prompts) is called after every prompt pass: the two hooks by which an EngineGang coordinates
+        its engines' admissions (a prompt pass takes an engine's lane for ~ 0.8 us per prompt token; with nothing running the gate
+        is not asked)."""
+        it = self.generate_iter(prompts, sampling, steps_per_poll, prefill_token_budget, share_prefix, min_admit, on_finished, run_ahead,
+                                admit_gate, on_admit)
         while True:
             try:
                 next(it)
@@ -597,7 +602,7 @@ class BackboneEngine:
 
     def generate_iter(self, prompts: Sequence[Sequence[int]], sampling, steps_per_poll: int = 16,
                       prefill_token_budget: Optional[int] = None, share_prefix: bool = False, min_admit: int = 1,
-                      on_finished=None, run_ahead: bool = True):
+                      on_finished=None, run_ahead: bool = True, admit_gate=None, on_admit=None):
         """generate() as a generator: yields (None) once per scheduler iteration -- after this engine's next burst and snapshot
         are enqueued -- and returns generate()'s result as the StopIteration value.  What EngineGang alternates between: while one
         engine's scheduler waits for its previous snapshot, the other engines' bursts are already queued on their own streams."""
@@ -651,10 +656,17 @@ class BackboneEngine:
             return best
 
         nxt = 0
+
+        def may_admit():
+            if not owner:
+                return True
+            want = min(min_admit, len(prompts) - nxt)
+            return admit_gate(len(self._free), want) if admit_gate is not None else len(self._free) >= want
+
         try:
             while nxt < len(prompts) or owner:
                 # admit as many waiting prompts as slots / prefill workspace allow
-                while nxt < len(prompts) and self._free and (not owner or len(self._free) >= min(min_admit, len(prompts) - nxt)):
+                while nxt < len(prompts) and self._free and may_admit():
                     batch, used, donors = [], 0, []
                     while nxt < len(prompts) and self._free:
                         d = find_donor(nxt) if share_prefix else None
@@ -691,6 +703,8 @@ class BackboneEngine:
                             self._free.append(s)
                         nxt = batch[0][0]
                         break
+                    if on_admit is not None:
+                        on_admit(len(batch))
                 if not owner:
                     raise NeuTTSHipError(-4, "no decode slot is free (held by an unfinished stream?)")
                 if run_ahead:
@@ -835,13 +849,48 @@ class EngineGang:
         for e in self.engines:
             e.warm_up(decode_steps)
 
-    def generate(self, prompts: Sequence[Sequence[int]], sampling, on_finished=None, steps_per_poll: int = 2, **kw) -> List[List[int]]:
-        """BackboneEngine.generate over the gang (bursts of `steps_per_poll` = 2 steps by default: the engines' bursts are enqueued in
-        turn, and the shorter the turn the closer their chains run side by side -- 144.5 k codec-tokens/s at 1-2, 132.0 k at 4,
-        106.7 k at 8 on 8192 ragged requests, profiles/r04s_sweep_continuous_gang_sched.txt): request i goes to engine i % n (prompts of one speaker that follow each other
-        n apart still share their prefix pages inside an engine), the engines' schedulers advance in turn.  on_finished(request
-        index, slot, n_new, engine) -- the engine is passed along for the device-side hand-off.  Returns the new ids in request order."""
+    def generate(self, prompts: Sequence[Sequence[int]], sampling, on_finished=None, steps_per_poll: int = 1, admit: str = "wave",
+                 on_admit=None, **kw) -> List[List[int]]:
+        """BackboneEngine.generate over the gang: request i goes to engine i % n (prompts of one speaker that follow each other n apart
+        still share their prefix pages inside an engine), the engines' schedulers advance in turn.  Bursts of `steps_per_poll` = 1 step
+        by default: the engines' bursts are enqueued in turn, and the shorter the turn the closer their chains run side by side (8192
+        ragged requests, round 4: 144.5 k codec-tokens/s at 1-2 steps, 132.0 k at 4, 106.7 k at 8, profiles/r04s_sweep_continuous_gang_sched.txt;
+        round 5 with admission waves: 149.8 k at 1, 146.3-147.0 k at 2).  on_finished(request index, slot, n_new, engine) -- the engine is
+        passed along for the device-side hand-off.  Returns the new ids in request order.
+        admit: how the engines' prompt passes are placed against each other once `min_admit` > 1 (a pass holds its engine's lane for
+        ~ 0.8 us per prompt token while the other chains go on).  "wave[:F[:W]]" (default) -- when one engine admits `min_admit`
+        prompts, the others admit within W rounds (default 1) with min_admit / F (default a third) of their slots free: all prompt
+        passes at once, then four decode chains side by side again, the static schedule's pattern -- 149.8 k against 145.6 k for
+        "independent" (each engine admits when `min_admit` of ITS slots are free; steady state 156.3 k against 149.7 k), flat over
+        min_admit 20-28, F 2-3, W 1-2; "spaced:R" -- not within R rounds of ANY engine's last pass (at most one engine out of the
+        decode gang at a time): 142.0 k at R = 3, 121.5 k at 6 (profiles/r05m_sweep_continuous_admission_*.txt).  Scheduling only:
+        ids cannot differ.  on_admit(engine, n_prompts): called after each prompt pass of an engine is enqueued (the moment to put
+        other lane-holding work of that engine -- a codec pass over what it has finished -- next to the wave)."""
         n = len(self.engines)
+        sched = {"round": 0, "last": -(1 << 30)}
+        space, follow, window = 0, 3, 1
+        try:
+            kind, *num = admit.split(":")
+            num = [int(x) for x in num]
+            if kind == "spaced" and len(num) == 1 and num[0] > 0:
+                space = num[0]
+            elif kind == "wave" and len(num) <= 2 and all(x > 0 for x in num):
+                follow, window = (num + [3, 1][len(num):])
+            elif kind != "independent" or num:
+                raise ValueError
+        except ValueError:
+            raise ValueError(f"admit = {admit!r}: 'independent', 'spaced:<rounds>' or 'wave[:<follower divisor>[:<rounds>]]'") from None
+
+        def gate(n_free, want):
+            if space:
+                return n_free >= want and sched["round"] - sched["last"] >= space
+            return n_free >= want or (sched["round"] - sched["last"] <= window and n_free >= max(1, want // follow))
+
+        def admitted(n_prompts):
+            if space or n_prompts >= kw.get("min_admit", 1):     # (a follower's small pass does not re-arm the wave)
+                sched["last"] = sched["round"]
+        if admit != "independent":
+            kw = dict(kw, admit_gate=gate)
         if isinstance(sampling, Sampling):
             sampling = [sampling] * len(prompts)
         parts = [list(range(k, len(prompts), n)) for k in range(n)]
@@ -852,10 +901,19 @@ class EngineGang:
             hook = None
             if on_finished is not None:
                 hook = (lambda i, slot, n_new, _e=e, _idx=idx: on_finished(_idx[i], slot, n_new, _e))
-            its.append((idx, e.generate_iter([prompts[i] for i in idx], [sampling[i] for i in idx], steps_per_poll=steps_per_poll, on_finished=hook, **kw)))
+            note = None
+            if admit != "independent" or on_admit is not None:
+                def note(n_prompts, _e=e):
+                    if admit != "independent":
+                        admitted(n_prompts)
+                    if on_admit is not None:
+                        on_admit(_e, n_prompts)
+            its.append((idx, e.generate_iter([prompts[i] for i in idx], [sampling[i] for i in idx], steps_per_poll=steps_per_poll, on_finished=hook,
+                                             on_admit=note, **kw)))
         results: List[List[int]] = [[] for _ in prompts]
         try:
             while its:
+                sched["round"] += 1
                 for item in list(its):
                     idx, it = item
                     try:

@@ -200,6 +200,12 @@ def test_continuous_batching_ragged_vs_oracle(emu_lib):
             st = e.kv_stats()
             assert e.free_slots() == e.max_batch and st["free_pages"] == st["total_pages"]
         assert gang.generate(prompts, samp, prefill_token_budget=70) == got                  # (default burst length of a gang)
+        # how the engines' prompt passes are placed against each other is scheduling only (one engine out of the gang at a time /
+        # all at once): the ids stay, and the gate never starves an engine with nothing running
+        for admit in ("spaced:2", "spaced:50", "wave", "wave:2:3"):
+            assert gang.generate(prompts, samp, prefill_token_budget=70, min_admit=2, admit=admit) == got, admit
+        with pytest.raises(ValueError):
+            gang.generate(prompts, samp, admit="sometimes")
     finally:
         gang.close()
     assert eng.generate(prompts, samp, steps_per_poll=3, prefill_token_budget=70) == got     # engine 0 is back on its own stream
