@@ -413,9 +413,15 @@ class NeuTTS:
         # utterances of one speaker start with the same tokens (chat header + reference-text phones, ref :307,:315-325):
         # the engine keeps one copy of those KV pages and computes only what differs
         sampling = [self._sampling(len(p), i) for i, p in enumerate(prompts)]
+        # more utterances than decode slots: freed slots are refilled about a tenth of an engine's slots at a time (24 of 256) -- a prompt
+        # pass over a handful of prompts costs 1.5-2 us per token against 0.84 for 32 and more, an idle slot a step each
+        # (profiles/r05m_probe_prefill_size.txt); scheduling only, the ids do not depend on it
+        eng_slots = self.backbone.max_batch
+        slots = eng_slots * (len(self.gang.engines) if self.gang is not None else 1)
+        min_admit = max(1, min(24, eng_slots // 10)) if len(prompts) > slots else 1
         if self.gang is not None and len(prompts) > 1:
-            return self.gang.generate(prompts, sampling, share_prefix=True)
-        return self.backbone.generate(prompts, sampling, share_prefix=len(prompts) > 1)
+            return self.gang.generate(prompts, sampling, share_prefix=True, min_admit=min_admit)
+        return self.backbone.generate(prompts, sampling, share_prefix=len(prompts) > 1, min_admit=min_admit)
 
     def _ids_to_codes(self, ids: Sequence[int]) -> List[int]:
         """ref :349 (tokenizer.decode) + :276 (regex): keep `<|speech_N|>` tokens, N = id - id(<|speech_0|>)."""
