@@ -155,7 +155,7 @@ def mfma_util_table(path):
 
 def continuous_leg(static_value, a):
     import subprocess
-    req = int(os.environ.get("NTTS_BENCH_CONT_REQUESTS", "8192"))     # (8 generations of the gang's 1024 slots: the finite job's ramp and drain are 1 / 4 of a 4096-request job's time)
+    req = int(os.environ.get("NTTS_BENCH_CONT_REQUESTS", "16384"))    # (16 generations of the gang's 1024 slots, ~ 27 s: the finite job's ramp and drain cost 4 % of an 8192-request job, 1 / 4 of a 4096-request job's time)
     cmd = [sys.executable, os.path.abspath(__file__), "--mode", "continuous", "--requests", str(req), "--steps", "1", "--warmup", "1",
            "--no-cpu-baseline", "--no-roofline", "--gang", str(max(1, a.gang)), "--prefill", str(a.prefill), "--decode", str(a.decode)]
     t0 = time.time()
