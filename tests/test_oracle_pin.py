@@ -37,3 +37,46 @@ def test_bit_exact_vs_hf(dtype):
     assert out.sequences[0, len(prompt):].tolist() == r.ids
     for k in range(1, len(r.ids)):
         assert torch.equal(out.scores[k][0], r.logits[k])
+
+
+def test_fp8_linear_vs_torch_scaled_mm():
+    """The fp8 variant has no third-party MODEL to pin against (oracle/backbone_ref.py header: parity unpinned), but its one arithmetic
+    building block has a third-party implementation in this image: torch._scaled_mm on CPU (oneDNN) -- e4m3 x e4m3 products, fp32
+    accumulation, per-tensor scales.  The oracle's `linear` on fp8 entries -- e4m3(x / in_scale) @ e4m3(W / w_scale[n])^T, scaled by
+    in_scale * w_scale[n], bias added, one rounding to bf16 -- must agree with it: same e4m3 operands bit for bit (torch's own
+    conversion), results equal up to the order of the fp32 sums (at most one bf16 ulp, on a few elements in a thousand)."""
+    if not hasattr(torch, "_scaled_mm"):
+        pytest.skip("torch._scaled_mm not available")
+    torch.manual_seed(5)
+    M, K, N = 48, 896, 320
+    x = (torch.randn(M, K) * 1.7).to(torch.bfloat16)
+    wt = torch.randn(N, K) * 0.05
+    wt[7] = 0                                                               # an all-zero output row: scale 1, result = bias
+    bias = torch.randn(N).to(torch.bfloat16)
+    name = "model.layers.0.self_attn.o_proj.weight"
+    scales = {f"model.layers.0.{t}.input_scale": float(x.float().abs().max()) / br.FP8_MAX * 1.1
+              for t in ("self_attn.q_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.down_proj")}
+    scales["lm_head.input_scale"] = 1.0
+    w = {f"model.layers.0.{t}.weight": wt for t in ("self_attn.q_proj", "self_attn.k_proj", "self_attn.v_proj", "self_attn.o_proj",
+                                                     "mlp.gate_proj", "mlp.up_proj", "mlp.down_proj")}
+    w["model.embed_tokens.weight"] = torch.randn(16, K)
+    wq = br.fp8_quantize_weights(w, scales)
+    got = br.linear(x, wq, name, bias)
+    assert got.dtype == torch.bfloat16
+    xs = scales["model.layers.0.self_attn.o_proj.input_scale"]
+    a8 = (x.float() * (1.0 / xs)).clamp(-br.FP8_MAX, br.FP8_MAX).to(torch.float8_e4m3fn)
+    b8 = wq[name + "::q"].to(torch.float8_e4m3fn)
+    assert torch.equal(b8.float(), wq[name + "::q"]) and torch.equal(a8.float(), br.fp8_act(x, xs))      # the stored VALUES are e4m3 numbers
+    try:
+        acc = torch._scaled_mm(a8, b8.t(), scale_a=torch.tensor(1.0), scale_b=torch.tensor(1.0), out_dtype=torch.float32)
+    except (RuntimeError, NotImplementedError) as ex:
+        pytest.skip(f"torch._scaled_mm has no CPU path here: {ex}")
+    want = (acc.double() * (xs * wq[name + "::scale"].double()) + bias.double()).float().to(torch.bfloat16)
+    assert torch.equal(want[:, 7], bias.expand(M, N)[:, 7])
+    neq = got != want
+    assert neq.float().mean() < 5e-3, float(neq.float().mean())
+    ulp = torch.abs(got.view(torch.int16).int() - want.view(torch.int16).int())
+    assert int(ulp.max()) <= 1
+    # and through the per-tensor scale path of the library itself (scale_a = in_scale): the same numbers before the per-row factor
+    acc2 = torch._scaled_mm(a8, b8.t(), scale_a=torch.tensor(xs, dtype=torch.float32), scale_b=torch.tensor(1.0), out_dtype=torch.float32)
+    assert torch.allclose(acc2, acc * xs, rtol=1e-6, atol=0)
