@@ -242,8 +242,10 @@ def main():
     ap.add_argument("--speech-range-head", action="store_true",
                     help="OPT-IN serving option, NEVER the headline: lm_head over 65 536 speech ids + EOS only (ntts_backbone_set_logits_range); "
                          "a separate line, labelled as such")
-    ap.add_argument("--stream-gang", action="store_true", help="stream mode: the streams dealt out over --gang engines of batch / gang slots (measured: no faster than one engine, DESIGN.md section 5)")
-    ap.add_argument("--stream-admit", type=int, default=64, help="stream mode on a gang: streams per admission group (one device-side stream set each)")
+    ap.add_argument("--stream-gang", action=argparse.BooleanOptionalAction, default=False,
+                    help="stream mode: the streams dealt out over --gang engines of batch / gang slots (fp8 Nano-sized model, 512 streams: 150.2 k against "
+                         "144.2 k on one engine; NeuTTS-Air bf16 loses: 80.3 k against 100.5 k at 256 streams -- off by default)")
+    ap.add_argument("--stream-admit", type=int, default=0, help="stream mode on a gang: streams per admission group (one device-side stream set each); 0 = one group per engine")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-codec", action="store_true", help="backbone only (profiling aid; not the headline metric)")
@@ -355,7 +357,8 @@ def main():
                                        hop_length=ccfg.hop_length, rms_eps=ccfg.rms_eps, max_frames=128, max_rows=B * 96),
                         "state_dict": {k: v.numpy() for k, v in cw.items()}},
             codec_device=f"cuda:{dev}", do_sample=a.sample, max_batch=B // Gs, engines=Gs, lib_path=lib)
-        tts.stream_admit = a.stream_admit
+        if a.stream_admit > 0:
+            tts.stream_admit = a.stream_admit
         tts.stream_on_gang = Gs > 1
         tts.watermarker = None
         tts._ids_to_codes = lambda ids: [int(i) % n_codes for i in ids]     # random weights do not stay in the speech range
@@ -1074,7 +1077,7 @@ def main():
         if strm:
             workload = (f"STREAM mode: {B} concurrent infer_stream utterances per GPU (27-frame windows every 25 tokens, 0.5 s chunks, "
                         f"ref:neutts/neutts.py:401-465), "
-                        + (f"dealt out over a gang of {Gs} engines of {B // Gs} slots (one arena, a lane each) in admission groups of {a.stream_admit} streams: per engine "
+                        + (f"dealt out over a gang of {Gs} engines of {B // Gs} slots (one arena, a lane each) in admission groups of {a.stream_admit or B // Gs} streams: per engine "
                            f"turn [windows -> codec pass -> chunks] [next group's prompt pass] [next decode burst], the other engines' bursts beside it; "
                            if Gs > 1 else "codec pass of chunk k on the codec engine's stream beside the decode graph of chunk k + 1; ")
                         + workload)

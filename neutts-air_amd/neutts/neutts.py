@@ -606,20 +606,28 @@ class NeuTTS:
         return self._gang_codecs
 
     def _infer_stream_batch_gang(self, prompts: List[List[int]], ref_codes: List[List[int]]):
-        """infer_stream_batch over an ENGINE GANG with STAGGERED ADMISSION (BASELINE configs[4]'s literal shape:
-        ref:neutts/neutts.py:373-465 for many utterances at once).  The utterances are dealt out in groups of `stream_admit` (64) over the
-        gang's engines; every group is a device-side stream set (ntts_streams_*) on its engine, the engine's codec engine on the same
-        lane.  Per turn of an engine: [snapshot + windows of its sets -> codec pass -> chunks out] [admit its next group: prompt pass]
-        [next decode burst] -- the other engines' bursts run meanwhile, so a group's first audio waits for ITS prompt pass and 29
-        decode steps, not for the prompt passes of every stream of the call.  A window is defined by token COUNTS (30 undecoded tokens,
-        csrc/stream.cpp pump_end), not by when it is looked for: the chunks are those of the single stream, bit for bit, whatever the
-        burst boundaries."""
+        """infer_stream_batch over an ENGINE GANG (BASELINE configs[4]'s literal shape: ref:neutts/neutts.py:373-465
+        for many utterances at once).  The utterances are dealt out in admission groups over the gang's engines; every group is a
+        device-side stream set (ntts_streams_*) on its engine, the engine's codec engine on the same lane.  Per turn of an engine:
+        [snapshot + windows of its sets -> codec pass -> chunks out] [admit its next group: prompt pass] [next decode burst] -- the other
+        engines' bursts run meanwhile.  Opt-in (`stream_on_gang = True`: it pays for the fp8 Nano-sized model, not for NeuTTS-Air bf16, see
+        _infer_stream_batch_hip).  Group size `stream_admit`: by default ONE group per engine (the streams split evenly, at least 64
+        per engine), all prompt passes at once and the chains side by side from then on -- 512 streams of the fp8 Nano-sized model over
+        four 128-slot engines: 150.2 k codec-tokens/s, first audio 152 / 168 / 186 ms (first / median / last stream) against 144.2 k and
+        182 ms on one 512-slot engine; smaller groups stagger the admissions (a group's first audio waits for ITS prompt pass only) but a
+        decode chain next to another engine's prompt pass crawls: groups of 64 144.1 k, 157 / 177 / 203 ms; of 32 125.3 k
+        (profiles/r05o_sweep_stream_gang.txt).  A window is defined by token COUNTS (30 undecoded tokens, csrc/stream.cpp pump_end), not
+        by when it is looked for: the chunks are those of the single stream, bit for bit, whatever the burst boundaries."""
         gang = self.gang
         G = len(gang.engines)
         codecs = self._gang_codec_engines()
         n = len(prompts)
         self._seed += 1
-        admit = max(1, int(getattr(self, "stream_admit", 64)))
+        admit = getattr(self, "stream_admit", None)
+        if not admit:
+            groups = min(G, max(1, n // 64))
+            admit = (n + groups - 1) // groups
+        admit = max(1, int(admit))
         chunk, look_f = self.streaming_frames_per_chunk, self.streaming_lookforward
         mod = int(getattr(self, "_stream_modulo", 0))
         room = [e.free_slots() for e in gang.engines]
@@ -703,10 +711,10 @@ class NeuTTS:
                                 pass
 
     def _infer_stream_batch_hip(self, prompts: List[List[int]], ref_codes: List[List[int]]):
-        # (stream_on_gang: off unless the caller sets it.  Measured on MI355X, 512 streams of the fp8 Nano-sized model: a gang of four 128-slot
-        #  engines streams 143.5 k codec-tokens/s with first audio after 157 / 178 / 203 ms (first / median / last stream), ONE 512-slot engine
-        #  144.2 k with 182 ms for every stream -- the decode steps of 4 x 128 rows cost what those of 512 rows cost, and the prompt passes of
-        #  all streams stand before the last stream's first window either way)
+        # (stream_on_gang: off unless the caller sets it -- it pays for one of the two models measured.  512 streams of the fp8 Nano-sized model
+        #  over four 128-slot engines, one admission group per engine: 150.2 k codec-tokens/s and first audio 152 / 168 / 186 ms against 144.2 k /
+        #  182 ms on ONE 512-slot engine; NeuTTS-Air bf16: 256 streams over 4 x 64 slots 80.3 k against 100.5 k on one engine, 512 streams over
+        #  4 x 128 111.9 k against 114.9 k -- four chains stream Air's larger weights four times; profiles/r05o_sweep_stream_gang*.txt)
         if (self.gang is not None and len(prompts) > 1 and getattr(self, "stream_on_gang", False) and self._stream_on_device(ref_codes)):
             yield from self._infer_stream_batch_gang(prompts, ref_codes)
             return
