@@ -246,6 +246,9 @@ def main():
                     help="stream mode: the streams dealt out over --gang engines of batch / gang slots (fp8 Nano-sized model, 512 streams: 150.2 k against "
                          "144.2 k on one engine; NeuTTS-Air bf16 loses: 80.3 k against 100.5 k at 256 streams -- off by default)")
     ap.add_argument("--stream-admit", type=int, default=0, help="stream mode on a gang: streams per admission group (one device-side stream set each); 0 = one group per engine")
+    ap.add_argument("--codec-precision", choices=["fp16", "bf16", "high"], default="fp16",
+                    help="NeuCodec GEMM operand format: fp16 (the engine's default: ~8e-4 relative rms of the fp32 decoder), bf16 (rounds 1-5: 7e-3), "
+                         "high (split bf16: ~7e-4 at 3x the matrix-core work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-codec", action="store_true", help="backbone only (profiling aid; not the headline metric)")
@@ -356,7 +359,7 @@ def main():
                                        num_heads=ccfg.num_heads, quantization_dim=ccfg.quantization_dim, levels=list(ccfg.levels),
                                        hop_length=ccfg.hop_length, rms_eps=ccfg.rms_eps, max_frames=128, max_rows=B * 96),
                         "state_dict": {k: v.numpy() for k, v in cw.items()}},
-            codec_device=f"cuda:{dev}", do_sample=a.sample, max_batch=B // Gs, engines=Gs, lib_path=lib)
+            codec_device=f"cuda:{dev}", do_sample=a.sample, max_batch=B // Gs, engines=Gs, lib_path=lib, codec_precision=a.codec_precision)
         if a.stream_admit > 0:
             tts.stream_admit = a.stream_admit
         tts.stream_on_gang = Gs > 1
@@ -377,7 +380,7 @@ def main():
                            num_layers=ccfg.num_layers, num_heads=ccfg.num_heads,
                            quantization_dim=ccfg.quantization_dim, levels=list(ccfg.levels),
                            hop_length=ccfg.hop_length, rms_eps=ccfg.rms_eps, max_frames=N_max,
-                           max_rows=B * (N_max + 6))
+                           max_rows=B * (N_max + 6), precision=a.codec_precision)
         codec = _hip.CodecEngine(codec_cfg_d, dev, lib)
     if not strm:
         w = cw = None
@@ -1054,7 +1057,7 @@ def main():
     if rank == 0:
         tokens = world * (cont_tokens[0] if cont else B * N) * a.steps
         value = tokens / dt
-        stages = "backbone prefill + decode loop" + (" + NeuCodec decoder to 24 kHz waveform (D2H included)"
+        stages = "backbone prefill + decode loop" + (f" + NeuCodec decoder ({a.codec_precision} GEMM operands, fp32 accumulate / residual stream) to 24 kHz waveform (D2H included)"
                                                      if codec is not None else " (codec skipped: --no-codec)")
         if nano:
             workload = (f"NeuTTS-Nano (ASSUMED geometry: hidden {cfg.hidden_size}, {cfg.num_layers} layers, {cfg.num_heads}:{cfg.num_kv_heads} "
@@ -1092,7 +1095,7 @@ def main():
             "vs_baseline": None, "dtype": "fp8" if fp8 else "bf16", "data": "synthetic",
             "config": {"workload": workload,
                        "batch_per_gpu": B, "prefill_tokens": S, "decode_tokens": N, "vocab_size": cfg.vocab_size,
-                       "stages": stages,
+                       "stages": stages, "codec_operands": (a.codec_precision if codec is not None else None),
                        "parallelism": f"independent shards x{world}, RCCL weight broadcast only"},
             "tokens_per_s_per_gpu": value / world,
             "rtf": dt / (tokens / 50.0),

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define NTTS_ABI_VERSION 8
+#define NTTS_ABI_VERSION 9
 
 enum {
     NTTS_OK = 0,
@@ -312,11 +312,16 @@ typedef struct ntts_codec_config {
     float rms_eps;              /* 1e-6 */
     int32_t max_frames;         /* longest utterance, in codec frames */
     int32_t max_rows;           /* workspace rows: sum over a decode call of (max frames of the call + 6) */
-    int32_t precision;          /* ABI 8.  0 = bf16 GEMM operands (default: waveform within 7e-3 RELATIVE rms of the fp32 reference decoder, i.e.
-                                 * inside BASELINE's 1e-3 absolute up to signal rms ~0.14); 1 = "high": every GEMM operand -- activations
-                                 * and weights -- as a split bf16 pair (hi + lo, K-concatenated [xh | xl | xh] x [wh | wh | wl]): ~16
-                                 * mantissa bits per operand at 3x the matrix-core work, for callers who need the bound at full-scale
-                                 * amplitude (the reference runs this decoder in fp32, ref:neutts/neutts.py:288-291) */
+    int32_t precision;          /* ABI 9 (the field is ABI 8's; the numbering changed so that a zeroed struct gets the setting that holds the parity bar).
+                                 * 0 = fp16 GEMM operands (DEFAULT): activations and weights as IEEE halves on v_mfma_f32_16x16x32_f16, fp32 accumulate --
+                                 *     waveform within ~8e-4 RELATIVE rms of the fp32 reference decoder (ref:neutts/neutts.py:288-291 runs it in fp32), i.e.
+                                 *     inside BASELINE's 1e-3 absolute at any amplitude a [-1, 1] waveform can have; same matrix-core rate and bytes as
+                                 *     bf16.  Operands must fit fp16's range: weights are checked at finalize (NTTS_EINVAL beyond 65504), activations
+                                 *     saturate at +-65504 (post-norm activations are O(1-10));
+                                 * 1 = "high": every GEMM operand as a split bf16 pair (hi + lo, K-concatenated [xh | xl | xh] x [wh | wh | wl]): ~16
+                                 *     significant bits per operand at 3x the matrix-core work, bf16's range;
+                                 * 2 = bf16 operands (rounds 1-5's default): 7e-3 RELATIVE rms, i.e. inside 1e-3 absolute only up to signal rms ~0.14;
+                                 *     for weights outside fp16's range */
 } ntts_codec_config;
 
 const char* ntts_codec_last_error(const ntts_codec* c);

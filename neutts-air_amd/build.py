@@ -35,15 +35,39 @@ def _stale(target, deps):
     return False
 
 
+def _newest_header():
+    t = os.path.getmtime(__file__)
+    for d in (CSRC, os.path.join(ROOT, "include")):
+        for base, _, files in os.walk(d):
+            for f in files:
+                if f.endswith(".h"):
+                    t = max(t, os.path.getmtime(os.path.join(base, f)))
+    return t
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
+    """One object per translation unit, compiled side by side (a header edit rebuilds all five, a .cpp edit only its own), then one link."""
     if not force and not _stale(LIB, [CSRC, os.path.join(ROOT, "include"), __file__]):
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-           "-I" + CSRC, "-Wno-unused-result", "-Wno-unused-value", "-o", LIB + ".tmp"] + _sources()
-    if verbose:
-        print("[build]", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    objdir = os.path.join(ROOT, "build", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    hdr_t = _newest_header()
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + CSRC, "-Wno-unused-result", "-Wno-unused-value"]
+    jobs = []
+    for src in _sources():
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(hdr_t, os.path.getmtime(src)):
+            jobs.append([hipcc] + flags + ["-x", "hip", "-c", src, "-o", obj])
+    def run(cmd):
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max_workers=int(os.environ.get("NTTS_BUILD_JOBS", "5"))) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(objdir, os.path.basename(s)[:-4] + ".o") for s in _sources()]
+    run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB + ".tmp"] + objs)
     os.replace(LIB + ".tmp", LIB)      # a failed build never destroys the previous library
     return LIB
 

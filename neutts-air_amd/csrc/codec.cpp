@@ -34,6 +34,7 @@ struct ntts_codec {
     long K3 = 0, max_rows = 0;
     bool finalized = false;
     int S = 1;                   // 3 with precision = high: every bf16 GEMM operand is a split row [hi | lo | hi] of 3 x its columns (codec.h put_op)
+    int fmt = kOpF16;            // operand format the non-GEMM kernels write (codec.h put_op): kOpF16 (default) / kOpSplit (high) / kOpBf16
     std::map<std::string, std::vector<float>> host;            // staged fp32 tensors until finalize
     std::map<std::string, std::vector<int64_t>> shapes;
     std::vector<void*> allocs;
@@ -132,8 +133,9 @@ extern "C" int ntts_codec_create(const ntts_codec_config* cf, int device, ntts_c
     c->lds_spec = (c->NS + 3) / 4 * 4;
     c->K3 = (6L * c->nb + 63) / 64 * 64;
     c->max_rows = cf->max_rows;
-    if (cf->precision != 0 && cf->precision != 1) { delete c; return cfail(nullptr, NTTS_EINVAL, "unknown codec precision %d (0 = bf16 operands, 1 = high: split bf16 operands)", cf->precision); }
+    if (cf->precision < 0 || cf->precision > 2) { delete c; return cfail(nullptr, NTTS_EINVAL, "unknown codec precision %d (0 = fp16 operands, 1 = high: split bf16 operands, 2 = bf16 operands)", cf->precision); }
     c->S = cf->precision == 1 ? 3 : 1;
+    c->fmt = cf->precision == 0 ? kOpF16 : cf->precision == 1 ? kOpSplit : kOpBf16;
     { const char* ev = getenv("NTTS_CODEC_ATTN_RESIDENT"); if (ev && ev[0] == '0') c->attn_resident = false; }
     { const char* ev = getenv("NTTS_CODEC_GN_REG"); if (ev && ev[0] == '0') c->gn_reg = false; }
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
@@ -206,6 +208,22 @@ static bf16_t h_f2bf(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
+// float -> IEEE half, round-to-nearest-even (|f| <= 65504 checked by the caller)
+static bf16_t h_f2h(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const bf16_t sgn = (bf16_t)((u >> 16) & 0x8000u);
+    const float a = fabsf(f);
+    if (!(a == a)) return sgn | 0x7e00;
+    if (a < 6.103515625e-05f) return sgn | (bf16_t)nearbyintf(ldexpf(a, 24));      // subnormal halves: multiples of 2^-24
+    int ex;
+    const float fr = frexpf(a, &ex);
+    float mant = nearbyintf(ldexpf(fr, 11));
+    int e = ex - 1 + 15;
+    if (mant == 2048.0f) { mant = 1024.0f; e += 1; }
+    if (e >= 31) return sgn | 0x7bff;
+    return sgn | (bf16_t)((e << 10) | ((int)mant - 1024));
+}
 static float h_bf2f(bf16_t b) {
     const uint32_t u = (uint32_t)b << 16;
     float f;
@@ -231,8 +249,15 @@ struct Finalizer {
         if (dalloc(c, &d, v.size()) != NTTS_OK || hipMemcpy(d, v.data(), v.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { rc = NTTS_EHIP; return nullptr; }
         return d;
     }
+    // a GEMM weight in the engine's 16-bit operand format: bf16, or IEEE half (precision = fp16: the values must fit its range)
     bf16_t* up_bf16(const std::vector<float>& v) {
         std::vector<bf16_t> b(v.size());
+        if (c->fmt == kOpF16) {
+            for (size_t i = 0; i < v.size(); ++i) {
+                if (!(fabsf(v[i]) <= 65504.0f)) { rc = cfail(c, NTTS_EINVAL, "a GEMM weight of magnitude %g does not fit fp16: create the engine with precision = 1 (high) or 2 (bf16)", (double)v[i]); return nullptr; }
+                b[i] = h_f2h(v[i]);
+            }
+        } else
         for (size_t i = 0; i < v.size(); ++i) b[i] = h_f2bf(v[i]);
         bf16_t* d = nullptr;
         if (dalloc(c, &d, b.size()) != NTTS_OK || hipMemcpy(d, b.data(), b.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { rc = NTTS_EHIP; return nullptr; }
@@ -379,17 +404,20 @@ static GemmArgs cg(const bf16_t* X, long ldx, const bf16_t* W, long K, const flo
     return a;
 }
 
+// big-M GEMM of the codec on the engine's operand format
+#define CGEMM(EPI, ga, st) do { if (c->fmt == kOpF16) NTTS_GEMM_BIG_F16(EPI, ga, st); else NTTS_GEMM_BIG(EPI, ga, st); } while (0)
+
 static void resnet_block(ntts_codec* c, const ResW& w, const CodecRows& R, long rows) {
     const int H = c->H;
     hipStream_t st = c->stream;
     GroupNormArgs g{};
     const long S = c->S;          // split operand rows: 3 x the columns, on the X side (ldx, K) and in the packed weights alike
-    g.x = c->h; g.y = c->xa; g.gamma = w.g1; g.beta = w.b1; g.R = R; g.C = H; g.eps = 1e-6f; g.split = S > 1;
+    g.x = c->h; g.y = c->xa; g.gamma = w.g1; g.beta = w.b1; g.R = R; g.C = H; g.eps = 1e-6f; g.split = c->fmt;
     groupnorm_silu_launch(g, c->gn_reg ? R.Tp - 2 * kPadRows : (1 << 30), st);
-    { GemmArgs ga_ = cg(c->xa, S * H, w.w1, 3L * S * H, w.cb1, c->t1 + H, H, rows - 2, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
+    { GemmArgs ga_ = cg(c->xa, S * H, w.w1, 3L * S * H, w.cb1, c->t1 + H, H, rows - 2, H); CGEMM(EPI_F32, ga_, st); }
     g.x = c->t1; g.y = c->xb; g.gamma = w.g2; g.beta = w.b2;
     groupnorm_silu_launch(g, c->gn_reg ? R.Tp - 2 * kPadRows : (1 << 30), st);
-    { GemmArgs ga_ = cg(c->xb, S * H, w.w2, 3L * S * H, w.cb2, c->h + H, H, rows - 2, H, c->h + H, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
+    { GemmArgs ga_ = cg(c->xb, S * H, w.w2, 3L * S * H, w.cb2, c->h + H, H, rows - 2, H, c->h + H, H); CGEMM(EPI_F32, ga_, st); }
 }
 
 // codes: HOST packed codes (codes_dev == null), or DEVICE codes, utterance i at codes_dev + i * codes_stride (already in range:
@@ -455,11 +483,11 @@ static int codec_decode_impl(ntts_codec* c, int32_t n, const int32_t* codes, con
 
     CodecEmbedArgs ea{};
     const long S = c->S;
-    ea.codes = codes ? c->meta + 3 * n + 1 : codes_dev; ea.code_off = c->meta + n; ea.wf = c->wf; ea.bf = c->bf; ea.out = c->xa; ea.R = R; ea.H = H; ea.nq = c->nq; ea.split = S > 1;
+    ea.codes = codes ? c->meta + 3 * n + 1 : codes_dev; ea.code_off = c->meta + n; ea.wf = c->wf; ea.bf = c->bf; ea.out = c->xa; ea.R = R; ea.H = H; ea.nq = c->nq; ea.split = c->fmt;
     for (int i = 0; i < 8; ++i) ea.levels[i] = i < c->nq ? c->cfg.levels[i] : 1;
     NTTS_LAUNCH((codec_embed_kernel), dim3((unsigned)((rows + kEmbedRows - 1) / kEmbedRows)), dim3(256), st, ea);
     // stem Conv1d(k=7, padding 3): window rows r..r+6 -> centre row r+3
-    { GemmArgs ga_ = cg(c->xa, S * H, c->embed_w, 7L * S * H, c->embed_b, c->h + 3L * H, H, rows - 6, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
+    { GemmArgs ga_ = cg(c->xa, S * H, c->embed_w, 7L * S * H, c->embed_b, c->h + 3L * H, H, rows - 6, H); CGEMM(EPI_F32, ga_, st); }
     auto tap = [&](int stage) -> hipError_t {   // debug only: the residual stream after a stage (hf:models/xcodec2/modeling_xcodec2.py:841-859)
         if (!c->tap) return hipSuccess;
         return hipMemcpyAsync(c->tap + (size_t)stage * c->max_rows * H, c->h, (size_t)rows * H * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -476,36 +504,44 @@ static int codec_decode_impl(ntts_codec* c, int32_t n, const int32_t* codes, con
     for (int i = 0; i < c->cfg.num_layers; ++i) {
         const CLayerW& L = c->layers[i];
         RowNormArgs rn{};
-        rn.x = c->h; rn.y = c->xa; rn.w = L.ln1; rn.rows = rows; rn.C = H; rn.eps = c->cfg.rms_eps; rn.split = S > 1;
+        rn.x = c->h; rn.y = c->xa; rn.w = L.ln1; rn.rows = rows; rn.C = H; rn.eps = c->cfg.rms_eps; rn.split = c->fmt;
         rownorm_launch(rn, st);
-        { GemmArgs ga_ = cg(c->xa, S * H, L.wqkv, S * H, nullptr, c->qkv, 3L * H, rows, 3 * H); NTTS_GEMM_BIG(EPI_BF16, ga_, st); }
+        { GemmArgs ga_ = cg(c->xa, S * H, L.wqkv, S * H, nullptr, c->qkv, 3L * H, rows, 3 * H); CGEMM(EPI_BF16, ga_, st); }
         AttnFullArgs at{};
-        at.qkv = c->qkv; at.vt = c->vt; at.out = c->xb; at.R = R; at.C = H; at.nh = c->cfg.num_heads; at.npages = npages; at.qtiles = qtiles; at.split = S > 1;
+        at.qkv = c->qkv; at.vt = c->vt; at.out = c->xb; at.R = R; at.C = H; at.nh = c->cfg.num_heads; at.npages = npages; at.qtiles = qtiles; at.split = c->fmt;
         if (c->attn_resident && npages <= kAttnResPages) {   // up to 256 frames: K / V^T resident in LDS, one sweep, no V^T pass
-            if (npages <= 8) NTTS_LAUNCH((attn_full_resident_kernel<8>), dim3(n, c->cfg.num_heads), dim3(512), st, at);
-            else if (npages <= 12) NTTS_LAUNCH((attn_full_resident_kernel<12>), dim3(n, c->cfg.num_heads), dim3(512), st, at);
-            else NTTS_LAUNCH((attn_full_resident_kernel<16>), dim3(n, c->cfg.num_heads), dim3(512), st, at);
+            const dim3 ag(n, c->cfg.num_heads);
+            if (c->fmt == kOpF16) {
+                if (npages <= 8) NTTS_LAUNCH((attn_full_resident_kernel<8, true>), ag, dim3(512), st, at);
+                else if (npages <= 12) NTTS_LAUNCH((attn_full_resident_kernel<12, true>), ag, dim3(512), st, at);
+                else NTTS_LAUNCH((attn_full_resident_kernel<16, true>), ag, dim3(512), st, at);
+            } else {
+                if (npages <= 8) NTTS_LAUNCH((attn_full_resident_kernel<8, false>), ag, dim3(512), st, at);
+                else if (npages <= 12) NTTS_LAUNCH((attn_full_resident_kernel<12, false>), ag, dim3(512), st, at);
+                else NTTS_LAUNCH((attn_full_resident_kernel<16, false>), ag, dim3(512), st, at);
+            }
         } else {
             VTransposeArgs vt{};
             vt.qkv = c->qkv; vt.vt = c->vt; vt.R = R; vt.C = H; vt.nh = c->cfg.num_heads; vt.npages = npages;
             NTTS_LAUNCH((v_transpose_kernel), dim3(n * npages, c->cfg.num_heads), dim3(256), st, vt);
-            NTTS_LAUNCH((attn_full_kernel), dim3(n * qtiles, c->cfg.num_heads), dim3(256), st, at);
+            if (c->fmt == kOpF16) NTTS_LAUNCH((attn_full_kernel<true>), dim3(n * qtiles, c->cfg.num_heads), dim3(256), st, at);
+            else NTTS_LAUNCH((attn_full_kernel<false>), dim3(n * qtiles, c->cfg.num_heads), dim3(256), st, at);
         }
-        { GemmArgs ga_ = cg(c->xb, S * H, L.wo, S * H, nullptr, c->h, H, rows, H, c->h, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
+        { GemmArgs ga_ = cg(c->xb, S * H, L.wo, S * H, nullptr, c->h, H, rows, H, c->h, H); CGEMM(EPI_F32, ga_, st); }
         rn.w = L.ln2;
         rownorm_launch(rn, st);
         { GemmArgs ga_ = cg(c->xa, S * H, L.fc1, S * H, nullptr, c->act, S * c->I, rows, c->I);
-          if (S > 1) NTTS_GEMM_BIG(EPI_SILU_SPLIT3, ga_, st); else NTTS_GEMM_BIG(EPI_BF16_SILU, ga_, st); }
-        { GemmArgs ga_ = cg(c->act, S * c->I, L.fc2, S * c->I, nullptr, c->h, H, rows, H, c->h, H); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
+          if (S > 1) NTTS_GEMM_BIG(EPI_SILU_SPLIT3, ga_, st); else CGEMM(EPI_BF16_SILU, ga_, st); }
+        { GemmArgs ga_ = cg(c->act, S * c->I, L.fc2, S * c->I, nullptr, c->h, H, rows, H, c->h, H); CGEMM(EPI_F32, ga_, st); }
     }
     CHIP(c, tap(2));
     resnet_block(c, c->res[2], R, rows);
     resnet_block(c, c->res[3], R, rows);
     CHIP(c, tap(3));
     RowNormArgs fn{};
-    fn.x = c->h; fn.y = c->xa; fn.w = c->fn_w; fn.bias = c->fn_b; fn.rows = rows; fn.C = H; fn.eps = 1e-6f; fn.split = S > 1;
+    fn.x = c->h; fn.y = c->xa; fn.w = c->fn_w; fn.bias = c->fn_b; fn.rows = rows; fn.C = H; fn.eps = 1e-6f; fn.split = c->fmt;
     rownorm_launch(fn, st);
-    { GemmArgs ga_ = cg(c->xa, S * H, c->head_w, S * H, c->head_b, c->spec, c->lds_spec, rows, c->NS); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
+    { GemmArgs ga_ = cg(c->xa, S * H, c->head_w, S * H, c->head_b, c->spec, c->lds_spec, rows, c->NS); CGEMM(EPI_F32, ga_, st); }
     IstftPrepArgs ip{};
     ip.spec = c->spec; ip.lds = c->lds_spec; ip.s3 = c->s3; ip.K3 = c->K3; ip.rows = rows; ip.nb = c->nb;
     NTTS_LAUNCH((istft_prep_kernel), dim3((unsigned)rows), dim3(256), st, ip);

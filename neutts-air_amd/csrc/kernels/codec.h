@@ -45,7 +45,11 @@ NTTS_D bool codec_row(const CodecRows& R, long r, int& b, int& t) {   // which (
 // accumulator: the operand-rounding error of a bf16 GEMM (2^-9 relative per operand -- 7e-3 of the waveform over ~60 GEMMs in series,
 // DESIGN.md section 2) drops to ~2^-17 at three times the matrix-core work.  The ISTFT head's DFT operand has always been built this way
 // (istft_prep_kernel).  `split` = 0: the plain bf16 row of C columns.
+// ---- precision = fp16 (the default, `split` = kOpF16): the plain row of C columns as IEEE HALVES for v_mfma_f32_16x16x32_f16 -- 11 significant
+// bits per operand at the bf16 rate and the bf16 bytes: 8.0e-4 relative on the waveform (tools/codec_operand_sim.py; bf16 7.4e-3).
+constexpr int kOpBf16 = 0, kOpSplit = 1, kOpF16 = 2;
 NTTS_D void put_op(bf16_t* y, long r, int C, int ch, float v, int split) {
+    if (split == kOpF16) { y[r * C + ch] = f2h(v); return; }
     const bf16_t hi = f2bf(v);
     if (!split) { y[r * C + ch] = hi; return; }
     bf16_t* row = y + r * 3 * C;
@@ -53,6 +57,12 @@ NTTS_D void put_op(bf16_t* y, long r, int C, int ch, float v, int split) {
 }
 NTTS_D void put_op4(bf16_t* y, long r, int C, int ch, const float (&v)[4], int split) {      // 4 consecutive channels, ch % 4 == 0
     bf16x4 hi, lo;
+    if (split == kOpF16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hi[e] = (short)f2h(v[e]);
+        *(bf16x4*)(y + r * C + ch) = hi;
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) { hi[e] = (short)f2bf(v[e]); lo[e] = (short)f2bf(v[e] - bf2f((bf16_t)hi[e])); }
     if (!split) { *(bf16x4*)(y + r * C + ch) = hi; return; }
@@ -336,6 +346,7 @@ struct AttnFullArgs {
 //   K image [32 keys][128 B], chunk c of key r at c ^ (r & 7);  V^T image [64 d][64 B], 16-B unit u of row d at
 //   u ^ ((d >> 2) & 3)  -- V^T pages come from v_transpose_kernel in plain token order, so a lane's 8 keys are the
 //   two 8-byte halves (units g>>1 and 2 + (g>>1)).
+template <bool F16>
 NTTS_KERNEL(256) void attn_full_kernel(AttnFullArgs p) {
     NTTS_SHARED bf16_t lds[2 * 2 * kPage * 64];
     const int lane = lane_id(), w = wave_id();
@@ -384,8 +395,8 @@ NTTS_KERNEL(256) void attn_full_kernel(AttnFullArgs p) {
         for (int u = 0; u < 2; ++u) {
             const int r = u * 16 + l15;
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            a = mfma16(ld16<bf16x8>(kb + r * 64 + (((2 * g) ^ (r & 7)) << 3)), qB[0], a);
-            a = mfma16(ld16<bf16x8>(kb + r * 64 + (((2 * g + 1) ^ (r & 7)) << 3)), qB[1], a);
+            a = mfma16_op<F16>(ld16<bf16x8>(kb + r * 64 + (((2 * g) ^ (r & 7)) << 3)), qB[0], a);
+            a = mfma16_op<F16>(ld16<bf16x8>(kb + r * 64 + (((2 * g + 1) ^ (r & 7)) << 3)), qB[1], a);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int key = pg * kPage + u * 16 + g * 4 + rr;
@@ -435,7 +446,7 @@ NTTS_KERNEL(256) void attn_full_kernel(AttnFullArgs p) {
             scores(kb, pg, s);
             bf16x8 pA;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pA[e] = (short)f2bf(fexp_neg(s[e] - m) * rs);
+            for (int e = 0; e < 8; ++e) pA[e] = (short)f2op<F16>(fexp_neg(s[e] - m) * rs);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int d = nt * 16 + l15;
@@ -445,7 +456,7 @@ NTTS_KERNEL(256) void attn_full_kernel(AttnFullArgs p) {
                 bf16x8 vB;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { vB[e] = v0[e]; vB[4 + e] = v1[e]; }
-                oacc[nt] = mfma16(pA, vB, oacc[nt]);
+                oacc[nt] = mfma16_op<F16>(pA, vB, oacc[nt]);
             }
         }
     }
@@ -476,7 +487,7 @@ constexpr int kAttnResPages = 16;  // resident pages at most: 512 frames (NP = 8
 // (289 us per launch; trimming its arithmetic changed nothing); 8 waves halve the query tiles per wave and double the waves per SIMD.
 // NP = pages the instantiation can hold (the launcher picks the smallest that fits the batch's longest utterance): 8 pages = 64 KB, two workgroups
 // per CU; 12 / 16 pages (384 / 512 frames: a ragged batch of 150-350-frame utterances used to fall to the paged two-sweep kernel as a whole) one.
-template <int NP>
+template <int NP, bool F16>
 NTTS_KERNEL(512) void attn_full_resident_kernel(AttnFullArgs p) {
     NTTS_SHARED bf16_t kres[NP * kPage * 64];    // [page][32 keys][128 B], chunk c of key r at c ^ (r & 7)
     NTTS_SHARED bf16_t vres[NP * 64 * kPage];    // [page][64 d][64 B], 16-B unit u of row d at u ^ ((d >> 2) & 3)
@@ -536,8 +547,8 @@ NTTS_KERNEL(512) void attn_full_resident_kernel(AttnFullArgs p) {
             for (int u = 0; u < 2; ++u) {
                 const int r = u * 16 + l15;
                 f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                a = mfma16(ld16<bf16x8>(kb + r * 64 + (((2 * g) ^ (r & 7)) << 3)), qB[0], a);
-                a = mfma16(ld16<bf16x8>(kb + r * 64 + (((2 * g + 1) ^ (r & 7)) << 3)), qB[1], a);
+                a = mfma16_op<F16>(ld16<bf16x8>(kb + r * 64 + (((2 * g) ^ (r & 7)) << 3)), qB[0], a);
+                a = mfma16_op<F16>(ld16<bf16x8>(kb + r * 64 + (((2 * g + 1) ^ (r & 7)) << 3)), qB[1], a);
                 // scores stay in RAW units (q.k, not yet times 1/8): the scale rides in the exponent's constant below.  Only the
                 // last page can hold frames past T (wave-uniform test: full pages skip the compare / select)
                 if (pg + 1 == npg) {
@@ -564,7 +575,7 @@ NTTS_KERNEL(512) void attn_full_resident_kernel(AttnFullArgs p) {
             for (int e = 0; e < 8; ++e) {
                 const float pe = fexp2((s[e] - mn) * kC);
                 add += pe;
-                pA[e] = (short)f2bf(pe);
+                pA[e] = (short)f2op<F16>(pe);
             }
             lsum = lsum * alpha + add;
             // accumulator rows are queries g*4 + r: their factors live in the lanes whose l15 is that query
@@ -583,7 +594,7 @@ NTTS_KERNEL(512) void attn_full_resident_kernel(AttnFullArgs p) {
                 bf16x8 vB;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { vB[e] = v0[e]; vB[4 + e] = v1[e]; }
-                oacc[nt] = mfma16(pA, vB, oacc[nt]);
+                oacc[nt] = mfma16_op<F16>(pA, vB, oacc[nt]);
             }
         }
         lsum += shfl_xor(lsum, 16);

@@ -170,7 +170,7 @@ NTTS_D float gemm_bias(const GemmArgs& p, int n) { return p.bias_f32 ? p.bias_f3
 
 // ---- epilogue shared by the GEMM kernels: lane owns token m (per a) x features nb16 .. nb16+15
 //      (acc[a][j][r] <-> feature nb16 + j*4 + r); mrow0 = first row of this wave's tile, split = split-K slab index
-template <int TM, int EPI, int WN, bool F8 = false>
+template <int TM, int EPI, int WN, bool F8 = false, bool F16 = false>
 NTTS_D void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][4], int mrow0, int n0, int wn, int nb, int split) {
     const int lane = lane_id();
     const int g = lane >> 4, l15 = lane & 15;
@@ -208,7 +208,7 @@ NTTS_D void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][4], int mrow0, int
                     if constexpr (F8 && EPI == EPI_BF16) v = __builtin_fmaf(v, sc[j][r], n < p.N ? gemm_bias(p, n) : 0.f);
                     else if (n < p.N) v += gemm_bias(p, n);
                     if constexpr (EPI == EPI_BF16_SILU) v = silu_fast(v);
-                    o[j * 4 + r] = f2bf(v);
+                    o[j * 4 + r] = f2op<F16>(v);          // (F16: the codec's fp16 operand rows)
                 }
             if (mok) {
                 bf16_t* dst = (bf16_t*)p.out + (long)m * p.ldo + nb16;
@@ -475,6 +475,8 @@ NTTS_D void gemm_epilogue_nat(const GemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0
 // LDS row is still one 128-byte line, now 128 k-values instead of 64 -- so the ring, the DMA pieces and the swizzle are
 // shared; a lane's 16-byte fragment read holds TWO 8-byte MFMA operands (the low and the high 8 of its 16 k-values; A and B
 // use the same split, so the k order is consistent).  Half the weight AND activation bytes through the per-CU load path.
+// F16: IEEE-half operands on v_mfma_f32_16x16x32_f16 (the codec's default: 3 more significant bits than bf16 at the same rate and the
+// same bytes); the 16-bit outputs of EPI_BF16 / EPI_BF16_SILU are then halves too.  Staging is format-blind.
 // TN: 16-column MFMA blocks per wave (the wave tile is TM*16 rows x TN*16 columns).  TN = 4 is the family described above
 // (a lane owns 16 consecutive output features).  TN != 4 exists for the decode lm_head, whose GRID, not whose tile, was the
 // problem (EPI_ARGMAX only; gemm_epilogue_nat): 850 tiles of 256 x 256 are 3.32 rounds of the 256 CUs -- the fourth round runs
@@ -489,8 +491,9 @@ NTTS_D void gemm_epilogue_nat(const GemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0
 // per chunk: in natural order the SiLU * up epilogue runs on half the lanes -- gate rows in lanes g < 2, their up rows in g >= 2
 // -- and stores 8-byte pieces; profiles/r02k_sweep_pf_gu_nat.log).  The prefill QKV GEMM keeps it (N = 1152 = 4 x 288: 500 tiles
 // instead of 625 with every fifth half empty; prompt pass -0.8 %).
-template <int WM, int WN, int TM, int EPI, int NS, int ABL = 0, int BK = 64, bool WNT = false, bool F8 = false, int TN = 4>
+template <int WM, int WN, int TM, int EPI, int NS, int ABL = 0, int BK = 64, bool WNT = false, bool F8 = false, int TN = 4, bool F16 = false>
 NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
+    static_assert(!F16 || (!F8 && TN == 4 && (EPI == EPI_BF16 || EPI == EPI_BF16_SILU || EPI == EPI_F32)), "fp16 operands: codec GEMMs");
     static_assert(BK == 64 || BK == 32, "ring slot K extent");
     static_assert(!F8 || BK == 64, "fp8: one ring slot = 128-byte rows");
     static_assert(TN == 4 || ((EPI == EPI_ARGMAX || EPI == EPI_BF16) && !F8 && BK == 64), "natural-order tile: lm_head / prefill QKV, bf16");
@@ -634,7 +637,7 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
                         acc[a][j] = mfma16_fp8(w2[0], x2[0], acc[a][j]);
                         acc[a][j] = mfma16_fp8(w2[1], x2[1], acc[a][j]);
                     } else {
-                        acc[a][j] = mfma16(wa[j], xb[a], acc[a][j]);
+                        acc[a][j] = mfma16_op<F16>(wa[j], xb[a], acc[a][j]);
                     }
                 }
         }
@@ -644,7 +647,7 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
         if (acc[0][0][0] != 12345.678f) return;   // keeps the accumulators live without storing
     }
     if (p.tl && wave == 0 && lane == 0) p.tl[tlb + 3] = now_ticks() + (acc[0][0][0] == 1.2345e30f ? 1 : 0);   // (after the k-loop's last MFMA)
-    if constexpr (TN == 4) gemm_epilogue<TM, EPI, WN, F8>(p, acc, m0 + wm * TM * 16, n0, wn, nb, split);
+    if constexpr (TN == 4) gemm_epilogue<TM, EPI, WN, F8, F16>(p, acc, m0 + wm * TM * 16, n0, wn, nb, split);
     else gemm_epilogue_nat<TM, TN, EPI, WN>(p, acc, m0 + wm * TM * 16, n0 + wn * CW, wn, nb);
     if (p.tl) { mark(4); wait_vmem(); mark(5); }
 }
@@ -672,7 +675,7 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 // ------------------------------------------------------------------------------------------------
 struct GemmShape { int BM, BN, WN; };
 
-template <int WM, int WN, int TM, int EPI, int NS = 2, int ABL = 0, int BK = 64, bool WNT = false, bool F8 = false, int TN = 4>
+template <int WM, int WN, int TM, int EPI, int NS = 2, int ABL = 0, int BK = 64, bool WNT = false, bool F8 = false, int TN = 4, bool F16 = false>
 inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     p.mblocks = (p.M + BM - 1) / BM;
@@ -688,7 +691,7 @@ inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
         p.xcd_xps = 8 / p.mblocks;
         p.xcd_nsplit = 0;
         const int per_xcd = (p.nblocks * nsplit + p.xcd_xps - 1) / p.xcd_xps;
-        NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT, F8, TN>), dim3(8 * per_xcd), dim3(WM * WN * 64), s, p);
+        NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT, F8, TN, F16>), dim3(8 * per_xcd), dim3(WM * WN * 64), s, p);
         return;
     }
     p.xcd_maffine = 0;
@@ -696,11 +699,11 @@ inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
         p.xcd_nsplit = nsplit;
         const int xps = 8 / nsplit, tiles = p.mblocks * p.nblocks;
         p.xcd_per = (tiles + xps - 1) / xps;
-        NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT, F8, TN>), dim3(8 * p.xcd_per), dim3(WM * WN * 64), s, p);
+        NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT, F8, TN, F16>), dim3(8 * p.xcd_per), dim3(WM * WN * 64), s, p);
         return;
     }
     p.xcd_nsplit = 0;
-    NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT, F8, TN>), dim3(p.mblocks * p.nblocks, nsplit), dim3(WM * WN * 64), s, p);
+    NTTS_LAUNCH((gemm_kernel<WM, WN, TM, EPI, NS, ABL, BK, WNT, F8, TN, F16>), dim3(p.mblocks * p.nblocks, nsplit), dim3(WM * WN * 64), s, p);
 }
 
 // tile families:  XL = 256x256 (4x4 waves = 1024 threads, 64x64 per wave, 128 KB LDS) -- big-M GEMMs (prefill, codec):
@@ -716,6 +719,12 @@ inline void gemm_launch(GemmArgs p, int ksplit, hipStream_t s) {
     const long txl_ = (long)(((p).M + 255) / 256) * (((p).N + 255) / 256), tl_ = (long)(((p).M + 127) / 128) * (((p).N + 127) / 128); \
     if ((p).N >= 256 && txl_ >= 140) NTTS_GEMM_XL(EPI, p, 1, s); else if (tl_ >= 240) NTTS_GEMM_L(EPI, p, 1, s); else NTTS_GEMM_S(EPI, p, 1, s); } while (0)
 #define NTTS_GEMM_L(EPI, p, ks, s) ::ntts::gemm_launch<2, 2, 4, EPI, 2>(p, ks, s)
+// the same dispatch on fp16 operands (codec, precision = fp16)
+#define NTTS_GEMM_BIG_F16(EPI, p, s) do { \
+    const long txl_ = (long)(((p).M + 255) / 256) * (((p).N + 255) / 256), tl_ = (long)(((p).M + 127) / 128) * (((p).N + 127) / 128); \
+    if ((p).N >= 256 && txl_ >= 140) ::ntts::gemm_launch<4, 4, 4, EPI, 2, 0, 64, false, false, 4, true>(p, 1, s); \
+    else if (tl_ >= 240) ::ntts::gemm_launch<2, 2, 4, EPI, 2, 0, 64, false, false, 4, true>(p, 1, s); \
+    else ::ntts::gemm_launch<4, 1, 1, EPI, 4, 0, 64, false, false, 4, true>(p, 1, s); } while (0)
 #define NTTS_GEMM_S(EPI, p, ks, s) ::ntts::gemm_launch<4, 1, 1, EPI, 4>(p, ks, s)
 
 // number of split-K slabs gemm_launch will produce for (K, ksplit); ktile = K extent of one 128-byte tile (64 bf16, 128 fp8)

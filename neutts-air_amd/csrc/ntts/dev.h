@@ -36,6 +36,23 @@ NTTS_D f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 
+// ---- fp16 operands (the codec's default GEMM-operand format: 11 significant bits instead of bf16's 8 at the SAME matrix-core rate;
+//      range 6.1e-5 .. 65504 for normal numbers -- post-norm activations and weights are O(1-10); conversions saturate instead of
+//      producing inf).  Storage type stays the 16-bit pattern (bf16_t / bf16x8): staging, LDS rings and swizzles are format-blind.
+NTTS_D bf16_t f2h(float f) {
+    f = __builtin_fminf(__builtin_fmaxf(f, -65504.0f), 65504.0f);      // (NaN propagates through fmin/fmax as the other operand: a NaN input becomes -65504 -- the codec never makes one)
+    return __builtin_bit_cast(unsigned short, (_Float16)f);            // v_cvt_f16_f32, round-to-nearest-even
+}
+NTTS_D float h2f(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+// v_mfma_f32_16x16x32_f16: lane layout of mfma16, operands read as IEEE half
+NTTS_D f32x4 mfma16_f16(bf16x8 a, bf16x8 b, f32x4 c) {
+    typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// 16-bit operand of format F16 ? half : bf16
+template <bool F16> NTTS_D bf16_t f2op(float f) { if constexpr (F16) return f2h(f); else return f2bf(f); }
+template <bool F16> NTTS_D f32x4 mfma16_op(bf16x8 a, bf16x8 b, f32x4 c) { if constexpr (F16) return mfma16_f16(a, b, c); else return mfma16(a, b, c); }
+
 // fp32 matrix core (v_mfma_f32_16x16x4_f32): D = A(16x4) * B(4x16) + C.  Lane l holds A[row l&15][k l>>4] and
 // B[k l>>4][col l&15] (one float each); D/C as mfma16.  The reference-encoding path (kernels/enc.h) computes in fp32.
 NTTS_D f32x4 mfma16_f32(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }

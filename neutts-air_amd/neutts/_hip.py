@@ -18,7 +18,7 @@ DEFAULT_LIB = os.path.join(os.path.dirname(_HERE), "libneutts_hip.so")
 
 NTTS_DT_F32, NTTS_DT_BF16, NTTS_DT_I32, NTTS_DT_FP8_E4M3 = 0, 1, 2, 3
 NTTS_W_BF16, NTTS_W_FP8_E4M3 = 0, 1
-ABI_VERSION = 8
+ABI_VERSION = 9
 NTTS_PAGE_TOKENS = 32            # include/neutts_hip.h
 PAGE_TOKENS = 32
 ERRORS = {-1: "EINVAL", -2: "ENODEV", -3: "ENOMEM", -4: "ESTATE", -5: "EHIP"}
@@ -955,7 +955,7 @@ class CodecEngine:
                          cfg.get("num_heads", 16), cfg.get("head_dim", 64), cfg.get("quantization_dim", 2048), len(lv),
                          (C.c_int32 * 8)(*(lv + [1] * (8 - len(lv)))), cfg.get("hop_length", 480), cfg.get("rms_eps", 1e-6),
                          cfg.get("max_frames", 2048), cfg.get("max_rows", 4096),
-                         {"bf16": 0, "high": 1, 0: 0, 1: 1}[cfg.get("precision", "bf16")])
+                         {"fp16": 0, "high": 1, "bf16": 2, 0: 0, 1: 1, 2: 2}[cfg.get("precision", "fp16")])
         h = C.c_void_p()
         rc = self.lib.ntts_codec_create(C.byref(c), device, C.byref(h))
         if rc != 0:

@@ -166,7 +166,7 @@ class NeuTTS:
         do_sample: bool = True,
         seed: int = 0,
         speech_range_head: bool = False,
-        codec_precision: str = "bf16",
+        codec_precision: str = "fp16",
     ):
         # Consts (ref:neutts/neutts.py:84-91)
         self.sample_rate = 24_000
@@ -190,10 +190,11 @@ class NeuTTS:
         self.min_new_tokens = 50
         self._seed = seed
 
-        # codec_precision="high": NeuCodec's GEMMs on split bf16 operands (hi + lo), ~3x their matrix-core work, for callers who need the
-        # waveform bound at full-scale amplitude; "bf16" (default): within 7e-3 RELATIVE rms of the fp32 reference decoder
-        if codec_precision not in ("bf16", "high"):
-            raise ValueError("codec_precision must be 'bf16' or 'high'")
+        # NeuCodec's GEMM operand format (the reference runs this decoder in fp32, ref:neutts/neutts.py:288-291): "fp16" (default) = IEEE-half
+        # operands, ~8e-4 RELATIVE rms of the fp32 decoder -- inside BASELINE's 1e-3 absolute at any amplitude; "high" = split bf16 operands
+        # (hi + lo), ~7e-4 at 3x the matrix-core work and bf16's range; "bf16" = rounds 1-5's default, 7e-3 relative
+        if codec_precision not in ("fp16", "bf16", "high"):
+            raise ValueError("codec_precision must be 'fp16', 'bf16' or 'high'")
         self._codec_precision = codec_precision
         self.tokenizer = None
         self.phonemizer = None       # created on first use: text front-end is off the hot path

@@ -103,7 +103,7 @@ def load_codec_fixture(name):
     return z, cfg, cr.make_weights(cfg, int(z["seed"]))
 
 
-def make_codec_engine(cfg, w, lib, max_frames=64, max_rows=512, precision="bf16"):
+def make_codec_engine(cfg, w, lib, max_frames=64, max_rows=512, precision="fp16"):
     eng = _hip.CodecEngine(dict(hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
                                 num_layers=cfg.num_layers, num_heads=cfg.num_heads, quantization_dim=cfg.quantization_dim,
                                 levels=list(cfg.levels), hop_length=cfg.hop_length, rms_eps=cfg.rms_eps,

@@ -112,6 +112,54 @@ inline f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return out;
 }
 
+// ---- fp16 (IEEE half) operands: conversions by bit arithmetic (no _Float16 runtime support needed on the host)
+inline float h2f(bf16_t v) {
+    const int s = v >> 15, e = (v >> 10) & 31, m = v & 1023;
+    float r;
+    if (e == 31) r = m ? NAN : INFINITY;
+    else if (e == 0) r = ldexpf((float)m, -24);
+    else r = ldexpf(1.0f + m / 1024.0f, e - 15);
+    return s ? -r : r;
+}
+inline bf16_t f2h(float f) {                 // saturating round-to-nearest-even, as the HIP dev.h (clamp, then v_cvt_f16_f32)
+    f = fminf(fmaxf(f, -65504.0f), 65504.0f);
+    const bf16_t s = signbit(f) ? 0x8000 : 0;
+    const float a = fabsf(f);
+    if (a < ldexpf(1.0f, -14)) return s | (bf16_t)nearbyintf(ldexpf(a, 24));    // subnormals: multiples of 2^-24 (1024 = the smallest normal)
+    int ex;
+    const float fr = frexpf(a, &ex);         // a = fr * 2^ex, fr in [0.5, 1)
+    float mant = nearbyintf(ldexpf(fr, 11)); // 1.m scaled to [1024, 2048]
+    int e = ex - 1 + 15;
+    if (mant == 2048.0f) { mant = 1024.0f; e += 1; }
+    if (e >= 31) return s | 0x7bff;
+    return s | (bf16_t)((e << 10) | ((int)mant - 1024));
+}
+inline f32x4 mfma16_f16(bf16x8 a, bf16x8 b, f32x4 c) {
+    struct Dep { bf16x8 a, b; };
+    int p = emu::wave_parity();
+    auto& s = emu::wave_slots();
+    Dep d{a, b};
+    memcpy(s.b[p][lane_id()], &d, sizeof(d));
+    emu::wave_sync();
+    int l = lane_id(), col = l & 15, rg = l >> 4;
+    f32x4 out = c;
+    for (int r = 0; r < 4; ++r) {
+        int row = rg * 4 + r;
+        float acc = c[r];
+        for (int kg = 0; kg < 4; ++kg) {
+            Dep da, db;
+            memcpy(&da, s.b[p][row + 16 * kg], sizeof(Dep));
+            memcpy(&db, s.b[p][col + 16 * kg], sizeof(Dep));
+            for (int j = 0; j < 8; ++j)
+                acc += h2f((bf16_t)da.a[j]) * h2f((bf16_t)db.b[j]);
+        }
+        out[r] = acc;
+    }
+    return out;
+}
+template <bool F16> inline bf16_t f2op(float f) { if constexpr (F16) return f2h(f); else return f2bf(f); }
+template <bool F16> inline f32x4 mfma16_op(bf16x8 a, bf16x8 b, f32x4 c) { if constexpr (F16) return mfma16_f16(a, b, c); else return mfma16(a, b, c); }
+
 // v_mfma_f32_16x16x4_f32: lane l holds A[row l&15][k l>>4], B[k l>>4][col l&15]; k ascending, fp32 accumulate
 inline f32x4 mfma16_f32(float a, float b, f32x4 c) {
     struct Dep { float a, b; };

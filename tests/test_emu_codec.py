@@ -8,24 +8,43 @@ from neutts import _hip
 from common import load_codec_fixture, make_codec_engine, rms
 
 
+# relative rms bound of the waveform by GEMM-operand format (fp32 golden waveforms; tools/codec_operand_sim.py predicts 8e-4 / 7e-3 at NeuCodec geometry)
+REL = {"fp16": 2.5e-3, "bf16": 0.02}
+
+
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
 @pytest.mark.parametrize("resident", ["1", "0"])
-def test_codec_tiny_vs_golden_ragged_batch(emu_lib, resident, monkeypatch):
+def test_codec_tiny_vs_golden_ragged_batch(emu_lib, resident, precision, monkeypatch):
     """Both attention kernels of the decoder layers: K / V^T resident in LDS with ONE online-softmax sweep (utterances of up to
-    256 frames: the default), and the paged two-sweep kernel behind the V^T transpose pass (longer utterances; forced here)."""
+    256 frames: the default), and the paged two-sweep kernel behind the V^T transpose pass (longer utterances; forced here); both 16-bit
+    operand formats: IEEE half (ABI 9 default: v_mfma_f32_16x16x32_f16, 11 significant bits) and bf16 (rounds 1-5)."""
     monkeypatch.setenv("NTTS_CODEC_ATTN_RESIDENT", resident)
     monkeypatch.setenv("NTTS_CODEC_GN_REG", resident)          # likewise GroupNorm: utterance slice in registers / two-pass kernel
     z, cfg, w = load_codec_fixture("codec_tiny")
-    eng = make_codec_engine(cfg, w, emu_lib)
+    eng = make_codec_engine(cfg, w, emu_lib, precision=precision)
     codes = [z["codes_0"][0, 0].tolist(), z["codes_1"][0, 0].tolist(), z["codes_0"][1, 0].tolist()]
     gold = [z["wav_0"][0, 0], z["wav_1"][0, 0], z["wav_0"][1, 0]]
     wavs = eng.decode(codes)                          # 37-, 5- and 37-frame utterances in ONE call
     for wv, g in zip(wavs, gold):
         assert wv.dtype == np.float32 and wv.shape == g.shape and not np.isnan(wv).any()
+        print(f"codec tiny, {precision} operands: rms error {rms(wv - g):.2e}, relative {rms(wv - g) / rms(g):.2e}")
         assert rms(wv - g) <= 1e-3, rms(wv - g)       # BASELINE.json: waveform RMS within 1e-3 of the fp32 reference
-        assert rms(wv - g) <= 0.02 * rms(g)
+        assert rms(wv - g) <= REL[precision] * rms(g)
     # batch invariance: decoding an utterance alone gives the same samples as inside the ragged batch
     alone = eng.decode([codes[1]])[0]
     assert np.array_equal(alone, wavs[1])
+
+
+def test_codec_fp16_weight_out_of_range_is_refused(emu_lib):
+    """precision = fp16 checks every GEMM weight against the half range at finalize (NTTS_EINVAL names the alternative); bf16 takes the same dict."""
+    z, cfg, w = load_codec_fixture("codec_tiny")
+    w = dict(w)
+    big = w["decoder.layers.0.mlp.fc1.weight"].clone()
+    big[0, 0] = 1.0e5
+    w["decoder.layers.0.mlp.fc1.weight"] = big
+    with pytest.raises(_hip.NeuTTSHipError, match="fp16"):
+        make_codec_engine(cfg, w, emu_lib)
+    make_codec_engine(cfg, w, emu_lib, precision="bf16").close()
 
 
 def test_codec_splits_calls_when_rows_exceed_workspace(emu_lib):
@@ -80,7 +99,7 @@ def check_long_utterance(lib):
     alone = eng.decode([codes[1]])[0]
     for c, wv in zip(codes, wavs):
         ref = cr.decode_code(cfg, w, torch.tensor(c, dtype=torch.long)[None, None, :])[0, 0].numpy()
-        assert wv.shape == ref.shape and rms(wv - ref) <= 1e-3 and rms(wv - ref) <= 0.02 * rms(ref), (len(c), rms(wv - ref), rms(ref))
+        assert wv.shape == ref.shape and rms(wv - ref) <= 1e-3 and rms(wv - ref) <= 2.5e-3 * rms(ref), (len(c), rms(wv - ref), rms(ref))
     ref1 = cr.decode_code(cfg, w, torch.tensor(codes[1], dtype=torch.long)[None, None, :])[0, 0].numpy()
     assert rms(alone - ref1) <= 1e-3 and rms(alone - wavs[1]) <= 1e-3      # two kernels, one answer within the bound (not bit-identical)
 
@@ -101,7 +120,7 @@ def test_codec_high_precision_split_operands(emu_lib, resident, monkeypatch):
     z, cfg, w = load_codec_fixture("codec_tiny")
     codes = [z["codes_0"][0, 0].tolist(), z["codes_1"][0, 0].tolist(), z["codes_0"][1, 0].tolist()]
     gold = [z["wav_0"][0, 0], z["wav_1"][0, 0], z["wav_0"][1, 0]]
-    lo = make_codec_engine(cfg, w, emu_lib).decode(codes)
+    lo = make_codec_engine(cfg, w, emu_lib, precision="bf16").decode(codes)
     eng = make_codec_engine(cfg, w, emu_lib, precision="high")
     hi = eng.decode(codes)
     for a, b, g in zip(lo, hi, gold):

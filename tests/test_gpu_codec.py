@@ -10,10 +10,13 @@ from common import load_codec_fixture, make_codec_engine, rms
 
 pytestmark = pytest.mark.gpu
 
-# bf16 GEMM operands against an fp32 reference.  Measured on MI355X (profiles/r02a_pytest_gpu.log): NeuCodec geometry
-# RMS error 1.10e-4 .. 1.15e-4 at signal RMS 1.6e-2 (relative 6.9e-3 .. 7.2e-3); the bounds below are 2x what was measured.
-REL_BOUND = 0.015
-ABS_BOUND = 2.5e-4      # BASELINE.json asks for 1e-3
+# DEFAULT engine (ABI 9): fp16 GEMM operands (v_mfma_f32_16x16x32_f16, fp32 accumulate) against an fp32 reference.  Predicted by rounding
+# exactly those operands in the oracle (tools/codec_operand_sim.py): 8.0e-4 relative at NeuCodec geometry (bf16 operands: 7.4e-3).  Measured on
+# MI355X: see profiles/r06*_pytest_gpu*.log; the bounds are VERDICT r5's bar for the default engine (relative <= 2.5e-3, and 1e-3 ABSOLUTE at the
+# amplitude of a loud voice, signal rms 0.29 -- test_neucodec_error_budget...).
+REL_BOUND = 2.5e-3
+ABS_BOUND = 5e-5        # at the goldens' signal rms 1.6e-2; BASELINE.json asks for 1e-3
+REL_BOUND_BF16 = 0.015  # precision = "bf16" (rounds 1-5's default): measured 6.9e-3 .. 7.2e-3
 
 
 @pytest.fixture(scope="module")
@@ -23,20 +26,21 @@ def lib(hip_lib):
     return hip_lib
 
 
+@pytest.mark.parametrize("precision", ["fp16", "bf16"])
 @pytest.mark.parametrize("resident", ["1", "0"])
-def test_codec_tiny(lib, resident, monkeypatch):
+def test_codec_tiny(lib, resident, precision, monkeypatch):
     monkeypatch.setenv("NTTS_CODEC_ATTN_RESIDENT", resident)
     monkeypatch.setenv("NTTS_CODEC_GN_REG", resident)          # likewise GroupNorm: utterance slice in registers / two-pass kernel   # resident single-sweep attention kernel (default) / paged two-sweep kernel
     z, cfg, w = load_codec_fixture("codec_tiny")
-    eng = make_codec_engine(cfg, w, lib)
+    eng = make_codec_engine(cfg, w, lib, precision=precision)
     codes = [z["codes_0"][0, 0].tolist(), z["codes_1"][0, 0].tolist(), z["codes_0"][1, 0].tolist()]
     gold = [z["wav_0"][0, 0], z["wav_1"][0, 0], z["wav_0"][1, 0]]
     wavs = eng.decode(codes)
     for wv, g in zip(wavs, gold):
         assert wv.shape == g.shape and not np.isnan(wv).any()
-        print(f"codec_tiny: RMS error {rms(wv - g):.3e}, signal RMS {rms(g):.3e}, relative {rms(wv - g) / rms(g):.3e}")
-        # measured: 4.5e-4 .. 5.9e-4 at signal RMS 7e-2 .. 8.6e-2 (relative 5.4e-3 .. 8.5e-3)
-        assert rms(wv - g) <= 1e-3 and rms(wv - g) <= 0.017 * rms(g), (rms(wv - g), rms(g))
+        print(f"codec_tiny, {precision} operands: RMS error {rms(wv - g):.3e}, signal RMS {rms(g):.3e}, relative {rms(wv - g) / rms(g):.3e}")
+        # bf16 measured: 4.5e-4 .. 5.9e-4 at signal RMS 7e-2 .. 8.6e-2 (relative 5.4e-3 .. 8.5e-3); fp16 on the emulator: 7e-4 .. 1.25e-3 relative
+        assert rms(wv - g) <= 1e-3 and rms(wv - g) <= (2.5e-3 if precision == "fp16" else 0.017) * rms(g), (rms(wv - g), rms(g))
     assert np.array_equal(eng.decode([codes[1]])[0], wavs[1])
 
 
@@ -86,17 +90,16 @@ def test_codec_long_utterance_paged_attention(lib):
 
 
 def test_neucodec_error_budget_by_stage_and_at_realistic_amplitude(neucodec):
-    """WHERE the waveform error comes from, and what it is at the amplitude of a real voice.
+    """WHERE the waveform error comes from, and what it is at the amplitude of a real voice -- on the DEFAULT engine.
     (1) Stage taps (ntts_codec_read_stage, ABI 6) against the oracle's taps (oracle/codec_ref.py decode_code(taps=...)): relative RMS
         error of the fp32 residual stream after the stem, the prior ResNet blocks, the 12 transformer layers and the post ResNet
-        blocks.  Every GEMM runs bf16 operands (weights AND activations rounded to 8 bits of mantissa, fp32 accumulation) against a
-        reference that is fp32 throughout: ~1.1e-3 relative per rounded operand, accumulating over ~60 GEMMs in series.  A CPU
-        simulation that rounds exactly those operands in the oracle reproduces the total (7.05e-3) and attributes it -- stem 2.6e-3,
-        prior 2.3e-3, layers 5.0e-3, post 0.8e-3, head 2.7e-3, in quadrature: 71 % of the squared error is made
-        inside the transformer layers, i.e. inside 88 % of the pass's FLOPs -- it cannot be bought down without doubling the pass.
-    (2) The bound is RELATIVE (weak 2): the same codes with the magnitude bias of the ISTFT head raised by ln 6 -- every STFT magnitude,
-        hence every sample, exactly 6x larger in the reference -- give signal RMS ~0.1 like a real voice: relative error unchanged,
-        absolute error 6x, still inside BASELINE's 1e-3."""
+        blocks.  Every GEMM runs 16-bit operands (weights AND activations, fp32 accumulation) against a reference that is fp32
+        throughout; with bf16 operands (8 significant bits) that was ~1.1e-3 relative per rounded operand, accumulating over ~60 GEMMs in
+        series to 7.0e-3 (71 % of the squared error inside the transformer layers); fp16 operands (11 bits, the default since ABI 9) carry an
+        eighth of that per operand at the same matrix-core rate -- tools/codec_operand_sim.py reproduces both totals on the CPU.
+    (2) The bound is RELATIVE: the same codes with the magnitude bias of the ISTFT head raised by ln 6 / ln 18 -- every STFT magnitude,
+        hence every sample, exactly 6x / 18x larger in the reference -- give signal rms ~0.1 (a real voice) / ~0.29 (a LOUD one): relative
+        error unchanged, absolute error inside BASELINE's 1e-3 on the default engine at both (the bf16 engine: 2.0e-3 at 18x)."""
     z, cfg, w, eng = neucodec
     codes = z["codes_1"][0, 0].tolist()                      # ref:samples/dave.pt[:100]
     eng.set_debug(True)
@@ -113,23 +116,40 @@ def test_neucodec_error_budget_by_stage_and_at_realistic_amplitude(neucodec):
         assert got[k].shape == want.shape, (name, got[k].shape, want.shape)
         rel.append(rms(got[k] - want) / rms(want))
     err, sig = rms(wv - ref), rms(ref)
-    print("codec error budget, relative RMS of the residual stream vs the fp32 oracle: "
+    print("codec error budget (default engine, fp16 operands), relative RMS of the residual stream vs the fp32 oracle: "
           + ", ".join(f"{n} {r:.2e}" for n, r in zip(_hip.CodecEngine.STAGES, rel)) + f"; waveform {err / sig:.2e} (RMS error {err:.2e} at signal RMS {sig:.2e})")
-    # measured on MI355X (profiles/r04d_pytest_gpu_codec.log); bars at ~1.5x
-    assert rel[0] <= 3.5e-3 and rel[1] <= 6e-3 and rel[2] <= 8e-3 and rel[3] <= 8e-3, rel   # measured 2.29e-3, 3.84e-3, 5.49e-3, 5.60e-3
+    # bf16 operands measured 2.29e-3, 3.84e-3, 5.49e-3, 5.60e-3 (profiles/r04d_pytest_gpu_codec.log); fp16 bars = a quarter of 1.5x that
+    assert rel[0] <= 9e-4 and rel[1] <= 1.5e-3 and rel[2] <= 2e-3 and rel[3] <= 2e-3, rel
     assert err <= REL_BOUND * sig
-    # ---- the same utterance at the amplitude of a real voice
-    w6 = dict(w)
-    b = w["decoder.head.linear.bias"].clone()
-    b[: b.numel() // 2] += float(np.log(6.0))               # magnitude half of the head's output (hf:models/xcodec2/modeling_xcodec2.py:771-773)
-    w6["decoder.head.linear.bias"] = b
-    eng6 = make_codec_engine(cfg, w6, neucodec_lib(eng), max_frames=128, max_rows=512)
-    wv6 = eng6.decode([codes])[0]
-    ref6 = cr.decode_code(cfg, w6, torch.tensor(codes, dtype=torch.long)[None, None, :])[0, 0].numpy()
-    err6, sig6 = rms(wv6 - ref6), rms(ref6)
-    print(f"the same codes 6x louder: RMS error {err6:.2e} at signal RMS {sig6:.2e}, relative {err6 / sig6:.2e}")
-    assert 0.08 <= sig6 <= 0.13 and err6 <= 1e-3 and err6 <= REL_BOUND * sig6
-    eng6.close()
+    # ---- the same utterance at the amplitude of a real voice (6x) and of a loud one (18x), default engine
+    for gain, lo, hi in ((6.0, 0.08, 0.13), (18.0, 0.2, 0.45)):
+        wg = dict(w)
+        b = w["decoder.head.linear.bias"].clone()
+        b[: b.numel() // 2] += float(np.log(gain))          # magnitude half of the head's output (hf:models/xcodec2/modeling_xcodec2.py:771-773)
+        wg["decoder.head.linear.bias"] = b
+        engg = make_codec_engine(cfg, wg, neucodec_lib(eng), max_frames=128, max_rows=512)
+        wvg = engg.decode([codes])[0]
+        refg = cr.decode_code(cfg, wg, torch.tensor(codes, dtype=torch.long)[None, None, :])[0, 0].numpy()
+        errg, sigg = rms(wvg - refg), rms(refg)
+        print(f"the same codes {gain:g}x louder: RMS error {errg:.2e} at signal RMS {sigg:.2e}, relative {errg / sigg:.2e}")
+        assert lo <= sigg <= hi and errg <= 1e-3 and errg <= REL_BOUND * sigg
+        engg.close()
+
+
+def test_neucodec_bf16_operands_option(neucodec):
+    """precision = "bf16" (rounds 1-5's default, kept for weights outside fp16's range): the goldens inside its own bars, and the error it makes
+    next to the default engine's on the same utterances (what ABI 9 changed the default for)."""
+    z, cfg, w, eng = neucodec
+    lo = make_codec_engine(cfg, w, neucodec_lib(eng), max_frames=128, max_rows=512, precision="bf16")
+    for i in range(int(z["n"])):
+        codes = z[f"codes_{i}"][0, 0].tolist()
+        if len(codes) > 128:
+            continue
+        g = z[f"wav_{i}"][0, 0]
+        e_bf, e_h = rms(lo.decode([codes])[0] - g) / rms(g), rms(eng.decode([codes])[0] - g) / rms(g)
+        print(f"neucodec golden set {i}: relative rms error bf16 operands {e_bf:.2e}, fp16 operands (default) {e_h:.2e}")
+        assert e_bf <= REL_BOUND_BF16 and e_h <= 0.35 * e_bf
+    lo.close()
 
 
 def neucodec_lib(eng):
@@ -145,10 +165,11 @@ def test_neucodec_high_precision_holds_the_bound_at_full_scale(neucodec):
     z, cfg, w, eng = neucodec
     lib = neucodec_lib(eng)
     hi = make_codec_engine(cfg, w, lib, max_frames=512, max_rows=256 * 256 + 64, precision="high")
+    bf = make_codec_engine(cfg, w, lib, max_frames=512, max_rows=256 * 256 + 64, precision="bf16")
     for i in range(int(z["n"])):
         codes = z[f"codes_{i}"][0, 0].tolist()
         g = z[f"wav_{i}"][0, 0]
-        e_lo, e_hi = rms(eng.decode([codes])[0] - g) / rms(g), rms(hi.decode([codes])[0] - g) / rms(g)
+        e_lo, e_hi = rms(bf.decode([codes])[0] - g) / rms(g), rms(hi.decode([codes])[0] - g) / rms(g)
         print(f"neucodec golden set {i}: relative rms error bf16 operands {e_lo:.2e}, split operands {e_hi:.2e}")
         assert e_hi <= 2.5e-3 and e_hi <= 0.45 * e_lo, (i, e_lo, e_hi)
     codes = z["codes_1"][0, 0].tolist()
@@ -170,22 +191,24 @@ def test_neucodec_high_precision_holds_the_bound_at_full_scale(neucodec):
     w18["decoder.head.linear.bias"] = b
     ref = cr.decode_code(cfg, w18, torch.tensor(codes, dtype=torch.long)[None, None, :])[0, 0].numpy()
     out = {}
-    for prec in ("bf16", "high"):
+    for prec in ("bf16", "high", "fp16"):
         e18 = make_codec_engine(cfg, w18, lib, max_frames=128, max_rows=512, precision=prec)
         out[prec] = rms(e18.decode([codes])[0] - ref)
         e18.close()
-    print(f"the same codes 18x louder (signal rms {rms(ref):.3f}): rms error bf16 operands {out['bf16']:.2e}, split operands {out['high']:.2e}")
-    assert 0.2 <= rms(ref) <= 0.45 and out["high"] <= 1e-3 and out["bf16"] > 1e-3
+    print(f"the same codes 18x louder (signal rms {rms(ref):.3f}): rms error bf16 operands {out['bf16']:.2e}, split operands {out['high']:.2e}, fp16 operands (default) {out['fp16']:.2e}")
+    assert 0.2 <= rms(ref) <= 0.45 and out["high"] <= 1e-3 and out["fp16"] <= 1e-3 and out["bf16"] > 1e-3
     # (3) cost at the benchmark's batch
     rng = np.random.default_rng(5)
     batch = [rng.integers(0, 65536, size=250).tolist() for _ in range(256)]
     ms = {}
-    for name, e in (("bf16", eng), ("high", hi)):
+    for name, e in (("bf16", bf), ("high", hi), ("fp16", eng)):
         e.decode(batch)
         e.decode(batch)
         ms[name] = e.last_timing()
-    print(f"codec pass, 256 x 250 frames: bf16 operands {ms['bf16']:.1f} ms, split operands {ms['high']:.1f} ms ({ms['high'] / ms['bf16']:.2f}x)")
+    print(f"codec pass, 256 x 250 frames: fp16 operands (default) {ms['fp16']:.1f} ms, bf16 operands {ms['bf16']:.1f} ms, split operands {ms['high']:.1f} ms ({ms['high'] / ms['bf16']:.2f}x)")
+    assert ms["fp16"] <= 1.06 * ms["bf16"]       # the default holds the bound at the bf16 engine's cost (<= 5 % of a batch)
     hi.close()
+    bf.close()
 
 
 def test_verify_checkpoint_codec_half_on_a_neucodec_style_state_dict(neucodec, tmp_path, capsys):
