@@ -120,24 +120,33 @@ int ntts_backbone_arena_copy(ntts_backbone* e, void* buf, size_t bytes, int to_a
 /* (ABI 7) A second engine on the SAME weights: `e` (created with the donor's configuration on the donor's device, nothing loaded
  * yet) drops its own arena and reads the finalised donor's; KV pool, slots, workspaces, stream and step graph stay its own.  For
  * several decode chains side by side on one GPU (ref:neutts/neutts.py:338-347 run for more than one batch at a time: each engine
- * replays its own step graph on its own stream, the launching thread alternates between them).   * weight loads into either engine are refused from then on (NTTS_ESTATE). */
+ * replays its own step graph on its own stream, the launching thread alternates between them).  Weight loads into either
+ * engine are refused from then on (NTTS_ESTATE); at most 16 engines per arena. */
 int ntts_backbone_share_arena(ntts_backbone* e, ntts_backbone* donor);
 
-/* ABI 8.  How many decode chains run side by side on this GPU, this engine's included (an engine gang: `chains` engines on one arena,
- * each on a lane stream, their step graphs replayed alternately).  The decode step's shape follows it: alone, an engine tiles its
+/* How many decode chains run side by side on this GPU, this engine's included (an engine gang: several engines on one arena, each
+ * on a lane stream, their step graphs replayed alternately).  The decode step's shape follows it: alone, an engine tiles its
  * GEMMs to fill the chip by itself (64-row m-blocks, split-K aimed at 224 workgroups, row-block XCD placement); in a gang the
  * other chains fill the chip and what counts is how many bytes each CU pulls, so o_proj / down_proj take the 256-row tile (a weight
  * tile passes through a CU's load path once per chain) and the XCD placement is off.  Same arithmetic, same
- * summation order per output element: ids do not depend on it.  Drops the captured step graph (it is re-captured by the next decode
- * call).  chains = 1 restores the single-chain shape.  Replaces nothing in the reference (ref:neutts/neutts.py runs one utterance at
- * a time); the arena is reference-counted since this version: donor and readers may be destroyed in any order. */
+ * summation order per output element: ids and logits do not depend on it, bit for bit.
+ * ABI 9: the engine COUNTS the chains itself -- at every ntts_backbone_decode call, the engines of its arena (ntts_backbone_share_arena)
+ * whose latest decode call lies within the last 50 ms, itself included -- and keeps one captured step graph per shape, so a caller
+ * that never heard of this function gets the right shape, and an engine that leaves its gang for a while (one utterance on engine 0)
+ * runs the single-chain shape meanwhile.  This call PINS the count instead (chains > 0: tests, sweeps, profiling one engine in the
+ * gang's shape); chains = 0 returns to counting.  ABI 8 had only the pinned form (and dropped the captured graph on every call).
+ * Replaces nothing in the reference (ref:neutts/neutts.py runs one utterance at a time); the arena is reference-counted (atomically since
+ * ABI 9): donor and readers may be destroyed in any order, from any thread. */
 int ntts_backbone_set_gang(ntts_backbone* e, int32_t chains);
 
 /* ABI 8, OPT-IN.  Restrict the lm_head to the token ids [lo, hi) plus eos_id: the decode step streams a compacted copy of those
  * rows (NeuTTS-Air: 65 537 x 896 bf16 = 118 MB instead of 390 MB) and every other id is treated as logit -inf.  The reference
  * only ever CONSUMES ids of that shape -- ref:neutts/neutts.py:276 keeps `<|speech_N|>` tokens, ref:neutts/neutts.py:336-341 stops
  * at `<|SPEECH_GENERATION_END|>` -- but hf:generation/utils.py:2894-2925 takes the argmax / top-k over the WHOLE vocabulary: the
- * ids are the reference's whenever its choice lies in the range, and differ otherwise.  Never the parity configuration.
+ * GREEDY ids are the reference's whenever its argmax lies in the range, and differ otherwise; a SAMPLED draw (do_sample, top_k)
+ * matches the reference's only when the WHOLE full-vocabulary top-k set lies in range + EOS (one candidate outside changes the
+ * candidate set and the softmax normaliser) and eos_id > hi (the compacted columns are in column order = token-id order only
+ * then; true for NeuTTS-Air).  Never the parity configuration.
  * lo < 0 restores the full head.  While a range is set, requests must use eos_token_id == eos_id; no slot may be in use when this
  * is called.  Per engine (twins of a gang each build their own 118 MB copy). */
 int ntts_backbone_set_logits_range(ntts_backbone* e, int32_t lo, int32_t hi, int32_t eos_id);

@@ -11,6 +11,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <set>
 #include <string>
 #include <vector>
@@ -46,6 +48,18 @@ struct HostSlot {
     unsigned gen = 0;           // bumped whenever the slot changes hands (release, prefill): a snapshot entry only speaks for the occupant it saw
 };
 
+// What the engines that read ONE weight arena share on the host (ntts_backbone_share_arena): the reference count that frees the arena
+// with its last reader -- atomic: twins may be destroyed from different threads -- and the time of every engine's most recent
+// decode call, from which each engine tells how many decode chains run side by side right now (its decode shape follows: apply_gang_shape).
+struct ArenaShare {
+    static constexpr int kMaxEngines = 16;
+    std::atomic<int> refs{1};
+    std::atomic<int> next_idx{1};                              // the donor is engine 0
+    std::atomic<long long> last_decode_ns[kMaxEngines];
+    ArenaShare() { for (auto& t : last_decode_ns) t.store(0); }
+};
+static long long now_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 struct ntts_backbone {
     ntts_backbone_config cfg{};
     int device = 0;
@@ -58,8 +72,8 @@ struct ntts_backbone {
     bf16_t* arena = nullptr;
     size_t arena_elems = 0;
     bool arena_shared = false;         // the arena is another engine's (ntts_backbone_share_arena)
-    int* arena_refs = nullptr;         // engines that read `arena` (host counter shared by a donor and its readers): the LAST one to be destroyed frees
-                                       // it, in whatever order the caller destroys them (a donor destroyed first left its readers on freed memory)
+    ArenaShare* share = nullptr;       // host state shared by the engines that read `arena` (a donor and its readers): the LAST one to be destroyed frees
+    int share_idx = 0;                 // the arena, in whatever order -- and from whatever threads -- the caller destroys them; this engine's index in it
     bf16_t *embed = nullptr, *final_norm = nullptr, *rope_cos = nullptr, *rope_sin = nullptr;
     bf16_t* embed_tm = nullptr;   // the lm_head's weight stream: tile-major copy of the tied embedding, the untied
                                   // "lm_head.weight", or (fp8) the e4m3 bytes of either
@@ -120,8 +134,21 @@ struct ntts_backbone {
     float* shead_r = nullptr;        // fp8: its per-row scales
     int n_part_full = 0;
     float* calib = nullptr;          // [num_layers * 4 + 1] running max |x| of every GEMM input seen by the prompt passes (ntts_backbone_calibrate)
-    int gang = 1;                    // decode chains side by side on the GPU, this one included (ntts_backbone_set_gang); the defaults of tall / xcd_affine follow it
+    int gang = 1;                    // decode chains side by side on the GPU, this one included: the defaults of tall / xcd_affine follow it.  ABI 9: counted by
+                                     // the engine itself at every decode call (engines of the same arena that decoded within kGangWindowNs) unless
+    int gang_forced = 0;             // ntts_backbone_set_gang pinned it (> 0; tests, sweeps, profiling passes of one engine in the gang's shape)
+    static constexpr long long kGangWindowNs = 50LL * 1000 * 1000;
+    hipGraphExec_t graph_shape[2] = {nullptr, nullptr};   // the captured step of the shape not in use (index = side-by-side shape?), kept across switches
+    bool graph_tried_shape[2] = {false, false};
+    int shape = 0;                   // 0 = single-chain shape, 1 = side-by-side shape (what `graph` / `graph_tried` currently belong to)
     int tall_env = -1, affine_env = -1;   // NTTS_TALL / NTTS_XCD_AFFINE when set (sweeps, tests): they win over the gang's defaults
+    // WIDE decode step (round 6; max_batch >= 512, e.g. the four 256-utterance batches of the static benchmark as ONE 1024-row chain instead of
+    // four 256-row chains side by side): every GEMM of the step sees M = 1024 -- a weight tile enters a CU's LDS once per 64-256 rows, not once per
+    // chain -- at the price of one chain's launch boundaries.  Tiles per GEMM (NTTS_WIDE_* override; DESIGN.md section 4l has the sweep):
+    //   QKV + RoPE: 32 * wide_qkv batch rows per workgroup (qkv_rope.h TMQ);  o_proj: 1 = 64 x 64 tiles, whole K, residual add in the epilogue (no
+    //   fp32 slabs; the norm behind it reads one bf16 stream), 0 = the split-K tiles of the narrow step;  down_proj: 1 = 128 x 128 / 8 waves split-K
+    bool wide = false;
+    int wide_qkv = 2, wide_o = 1, wide_down = 1;
     int gu_tile = 0;                 // gate/up tile (NTTS_GU_TILE): 0 = 128 x 128 / 8 waves / 3 slots (above batch 128; 64 x 64 below), 1 = 256 x 192 / 12 waves / 2 slots,
                                      // 2 = 256 x 256 / 16 waves / 2 slots, 3 = 128 x 128 / 2 slots (two workgroups per CU)
     // Tile path: the QKV projection with bias, rounding, RoPE and the K append in its epilogue (qkv_rope.h); the attention kernel
@@ -324,7 +351,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->arena_elems = off;
     CR_HIP(hipMalloc((void**)&e->arena, off * sizeof(bf16_t)));
     CR_HIP(hipMemset(e->arena, 0, off * sizeof(bf16_t)));
-    e->arena_refs = new int(1);
+    e->share = new ArenaShare();
     e->embed = e->arena + o_embed;
     e->embed_tm = e->arena + o_embed_tm;
     if (e->fp8) { e->shead = (float*)(e->arena + o_shead); e->xs_head_dev = (float*)(e->arena + o_xs_head); }
@@ -412,8 +439,14 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     if (int k = env_int("NTTS_KS_O", 0); k > 0) e->ks_o = std::min(std::min(max_slabs, k), c->num_heads * 64 / ktile);
     if (int k = env_int("NTTS_KS_D", 0); k > 0) e->ks_d = std::min(std::min(max_slabs, k), F / ktile);
     e->tall_env = env_int("NTTS_TALL", -1);
-    e->gu_tile = env_int("NTTS_GU_TILE", 0);
+    e->wide = env_int("NTTS_WIDE", B >= 512 && !e->fp8 ? 1 : 0) != 0;
+    e->wide_qkv = env_int("NTTS_WIDE_QKV", 2);
+    if (e->wide_qkv != 1 && e->wide_qkv != 2 && e->wide_qkv != 4) e->wide_qkv = 2;
+    e->wide_o = env_int("NTTS_WIDE_O", 1);
+    e->wide_down = env_int("NTTS_WIDE_DOWN", 1);
+    e->gu_tile = env_int("NTTS_GU_TILE", e->wide ? 1 : 0);
     if (e->gu_tile < 0 || e->gu_tile > 3) e->gu_tile = 0;
+    if (e->wide && e->wide_down == 1 && env_int("NTTS_KS_D", 0) <= 0) e->ks_d = 4;   // 8 x 7 tiles of 128 x 128 x 4 K slices = 224 workgroups
     e->xl_min_m = env_int("NTTS_XL_MIN_M", 0);
     {   // 0 = every query on the two-sweep kernel; whole pages, at most what the resident kernel holds
         int cap = env_int("NTTS_PF_RES_CAP", kPfResPages * kPage) / kPage * kPage;
@@ -425,7 +458,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->xcd_xps = (B == 64 || B == 128 || B == 256 || B == 512) ? 8 / (B / 64) : 0;
     e->affine_env = env_int("NTTS_XCD_AFFINE", -1);
     apply_gang_shape(e);
-    e->head_tile = env_int("NTTS_HEAD_TILE", B > 128 ? (e->fp8 ? 2 : 4) : B > 64 ? 1 : 0);
+    e->head_tile = env_int("NTTS_HEAD_TILE", B > 128 ? (e->fp8 || e->wide ? 2 : 4) : B > 64 ? 1 : 0);   // (1024 rows: 256 x 256 424 us, 256 x 288 438)
     if (e->head_tile != 0 && e->head_tile != 1 && e->head_tile != 2 && e->head_tile != 4) e->head_tile = 1;
     if (e->fp8 && e->head_tile == 4) e->head_tile = 2;          // (the natural-order tile is bf16 only)
     e->gu_128 = B > 128;
@@ -504,8 +537,10 @@ extern "C" void ntts_backbone_destroy(ntts_backbone* e) {
     if (e->calib) hipFree(e->calib);
     if (e->head_r) hipFree(e->head_r);
     if (e->shead_r) hipFree(e->shead_r);
+    for (hipGraphExec_t g : e->graph_shape)
+        if (g && g != e->graph) hipGraphExecDestroy(g);
     bool last_reader = true;
-    if (e->arena_refs) { last_reader = --*e->arena_refs == 0; if (last_reader) delete e->arena_refs; }
+    if (e->share) { last_reader = e->share->refs.fetch_sub(1) == 1; if (last_reader) delete e->share; else e->share->last_decode_ns[e->share_idx].store(0); }
     void* bufs[] = {last_reader ? e->arena : nullptr, e->gu_map_gate, e->gu_map_up, e->kv, e->ibuf, e->h_dec, e->xn_dec, e->qkv_dec, e->attn_dec,
                     e->act_dec, e->slabs, e->slabs2, e->h_alt, e->part_val, e->part_idx, e->logits, e->logits_bf16, e->h_pf, e->xn_pf, e->qkv_pf, e->attn_pf,
                     e->o_pf, e->act_pf, e->meta_dev, e->as_scores, e->as_stats, e->as_oslabs, e->step_meta, e->rope_rows};
@@ -914,11 +949,13 @@ extern "C" int ntts_backbone_share_arena(ntts_backbone* e, ntts_backbone* donor)
         mv(w.ln1); mv(w.wqkv); mv(w.bqkv); mv(w.wo); mv(w.ln2); mv(w.wgu); mv(w.wd);
         mv(w.sqkv); mv(w.so); mv(w.sgu); mv(w.sd); mv(w.xs_dev);
     }
+    if (donor->share->next_idx.load() >= ArenaShare::kMaxEngines) return fail(e, NTTS_EINVAL, "share_arena: at most %d engines on one arena", ArenaShare::kMaxEngines);
     HIPCHK(e, hipFree(old));
-    delete e->arena_refs;
+    delete e->share;
     e->arena = donor->arena;
-    e->arena_refs = donor->arena_refs;
-    ++*e->arena_refs;
+    e->share = donor->share;
+    e->share->refs.fetch_add(1);
+    e->share_idx = e->share->next_idx.fetch_add(1);
     e->arena_shared = true;
     const int rc = sync_input_scales(e, false);   // fp8: the launches need the input scales on the host
     if (rc) return rc;
@@ -927,6 +964,11 @@ extern "C" int ntts_backbone_share_arena(ntts_backbone* e, ntts_backbone* donor)
 }
 
 static void drop_graphs(ntts_backbone* e) {
+    for (hipGraphExec_t& g : e->graph_shape) {           // (the other shape's parked capture)
+        if (g && g != e->graph) hipGraphExecDestroy(g);
+        g = nullptr;
+    }
+    e->graph_tried_shape[0] = e->graph_tried_shape[1] = false;
     if (e->graph) { hipGraphExecDestroy(e->graph); e->graph = nullptr; }
     if (e->graph_split) { hipGraphExecDestroy(e->graph_split); e->graph_split = nullptr; }
     e->graph_tried = e->graph_split_tried = false;
@@ -1006,15 +1048,41 @@ extern "C" int ntts_backbone_read_amax(ntts_backbone* e, float* out, int32_t n) 
     return NTTS_OK;
 }
 
+// The decode shape for `chains` chains side by side, with that shape's captured step: both shapes keep their capture, so an engine that
+// leaves a gang for a while (NeuTTS.infer on engine 0 of a gang: ADVICE r5) and comes back re-captures nothing.  Same arithmetic and the
+// same summation order per output element in both shapes (tests/test_gpu_parity_matrix.py asserts the logits rows bit-identical).
+static void use_shape_for(ntts_backbone* e, int chains) {
+    const int B = e->cfg.max_batch;
+    const int want = (chains >= 2 && B > 128 && B <= 256) ? 1 : 0;
+    e->gang = chains;
+    if (want == e->shape) return;
+    e->graph_shape[e->shape] = e->graph; e->graph_tried_shape[e->shape] = e->graph_tried;
+    e->shape = want;
+    e->graph = e->graph_shape[want]; e->graph_tried = e->graph_tried_shape[want];
+    e->graph_shape[want] = nullptr;
+    apply_gang_shape(e);
+}
+// engines of this arena with a decode call inside the window, this one included
+static int chains_now(ntts_backbone* e) {
+    const long long t = now_ns();
+    e->share->last_decode_ns[e->share_idx].store(t);
+    int n = 1;
+    const int hi = e->share->next_idx.load();
+    for (int i = 0; i < hi && i < ArenaShare::kMaxEngines; ++i) {
+        if (i == e->share_idx) continue;
+        const long long o = e->share->last_decode_ns[i].load();
+        if (o != 0 && t - o < ntts_backbone::kGangWindowNs) ++n;
+    }
+    return n;
+}
+
+// chains > 0 pins the count (the engine keeps that shape whoever else decodes; in effect at once, e.g. for ntts_backbone_time_kernel);
+// 0 returns to counting (the default since ABI 9)
 extern "C" int ntts_backbone_set_gang(ntts_backbone* e, int32_t chains) {
     if (!e) return NTTS_EINVAL;
-    if (chains < 1) return fail(e, NTTS_EINVAL, "set_gang: %d chains", chains);
-    if (chains == e->gang) return NTTS_OK;
-    HIPCHK(e, hipSetDevice(e->device));
-    HIPCHK(e, hipStreamSynchronize(e->stream));       // the captured step may still be queued
-    e->gang = chains;
-    apply_gang_shape(e);
-    drop_graphs(e);                                   // re-captured with the new launches by the next decode call
+    if (chains < 0) return fail(e, NTTS_EINVAL, "set_gang: %d chains", chains);
+    e->gang_forced = chains;
+    if (chains > 0) use_shape_for(e, chains);
     return NTTS_OK;
 }
 
@@ -1030,7 +1098,6 @@ static GemmArgs gemm_args(const ntts_backbone* e, const bf16_t* X, long ldx, con
     a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = bias; a.out = out; a.ldo = ldo; a.M = M; a.N = N; a.K = K;
     a.wscale = wscale; a.xscale = xscale;
     a.tl = e->gemv_tl;
-    a.eos_col = -1;
     return a;
 }
 static int ktile_of(const ntts_backbone* e) { return e->fp8 ? 128 : 64; }
@@ -1083,7 +1150,7 @@ static void k_lm_head(ntts_backbone* e, bool keep_logits) {
     const int B = e->cfg.max_batch, H = e->H, V = e->cfg.vocab_size;
     GemmArgs a = gemm_args(e, e->xn_dec, H, e->lr_rows ? e->head_r : e->embed_tm, H, nullptr, nullptr, 0, B, e->lr_rows ? e->lr_rows : V, H,
                            e->lr_rows ? e->shead_r : e->shead, e->xs_head);
-    if (e->lr_rows) a.eos_col = e->lr_rows - 1;          // compacted head: columns = [range | EOS]
+    if (e->lr_rows) a.eos_col1 = e->lr_rows;          // compacted head: columns = [range | EOS]
     a.part_val = e->part_val; a.part_idx = e->part_idx; a.mask_eos = e->sl.mask_eos;
     a.logits = keep_logits ? e->logits : nullptr; a.ld_logits = V;
     a.logits_bf16 = (keep_logits && e->n_sampling > 0) ? e->logits_bf16 : nullptr; a.ld_logits_bf16 = e->ldl;
@@ -1131,6 +1198,11 @@ static void k_qkv(ntts_backbone* e, int i) {
     a.q_out = e->qkv_dec; a.ld_q = e->NQKV; a.kpool = e->kv + (size_t)i * e->layer_stride;
     a.nh = e->cfg.num_heads; a.nkv = e->cfg.num_kv_heads;
     a.tl = e->gemv_tl;
+    if (e->wide && !e->fp8 && e->wide_qkv > 1) {
+        if (e->wide_qkv == 4) qkv_rope_launch_wide<false, 4>(a, e->stream);
+        else qkv_rope_launch_wide<false, 2>(a, e->stream);
+        return;
+    }
     const bool place = (e->xcd_affine & 4) && e->xcd_xps;
     if (e->fp8) qkv_rope_launch<true>(a, place, e->stream, e->qkv_wstat);
     else qkv_rope_launch<false>(a, place, e->stream, e->qkv_wstat);
@@ -1145,6 +1217,7 @@ static void k_attn(ntts_backbone* e, int i) {
     a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
     a.tl = e->attn_tl;
     a.xcd_rows = ((e->xcd_affine & 4) && !e->attn_tl) ? e->xcd_xps : 0;
+    a.nt_pages = e->wide && !e->attn_tl;
     if (e->fp8) a.out_fp8_inv = 1.0f / e->layers[i].xs[1];   // attention output = o_proj's input
     if (e->split_active && !e->attn_tl) {       // long contexts below 2 workgroups per CU: context-split attention + combine
         AttnSplitArgs q{};
@@ -1159,6 +1232,11 @@ static void k_attn(ntts_backbone* e, int i) {
 static void k_o_proj(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, QD = e->cfg.num_heads * 64;
     GemmArgs a = gemm_args(e, e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->slabs, H, B, H, QD, e->layers[i].so, e->layers[i].xs[1]);
+    if (e->wide && e->wide_o == 1) {   // whole K per tile: h = bf16(h + bf16(acc)) in the epilogue (hf:models/qwen2/modeling_qwen2.py:233,291), in place
+        a.out = e->h_dec; a.resid_bf16 = e->h_dec; a.ldrb = H;
+        gemm_skinny<EPI_RESID>(a, 1, e->stream);
+        return;
+    }
     if (e->tall & 1) { a.xcd_nsplit = e->tall_xcd_split ? -1 : 0; gemm_tall<EPI_SPLITK>(a, e->ks_o, e->stream); return; }   // (one K slice per XCD pair: its X columns enter two L2s, not eight)
     if ((e->xcd_affine & 1) && e->xcd_xps) a.xcd_maffine = -1;
     gemm_skinny<EPI_SPLITK>(a, e->ks_o, e->stream);
@@ -1190,6 +1268,11 @@ static void k_gate_up(ntts_backbone* e, int i) {
 static void k_down(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H, F = e->F;
     GemmArgs a = gemm_args(e, e->act_dec, F, e->layers[i].wd, F, nullptr, e->slabs, H, B, H, F, e->layers[i].sd, e->layers[i].xs[3]);
+    if (e->wide && e->wide_down == 1 && !e->fp8) {   // 128 x 128 / 8 waves / 3-slot ring: a W tile enters LDS once per 128 rows (64 x 64: 622 KB through a CU per tile)
+        a.xcd_nsplit = -1;
+        gemm_launch<4, 2, 2, EPI_SPLITK, 3>(a, e->ks_d, e->stream);
+        return;
+    }
     if (e->tall & 2) { a.xcd_nsplit = e->tall_xcd_split ? -1 : 0; gemm_tall<EPI_SPLITK>(a, e->ks_d, e->stream); return; }
     a.xcd_nsplit = -1;   // one K slice per XCD (pair) unless the row-block placement below applies (FETCH 15.0 -> 6.8 MB per launch, profiles/r02f_*)
     if ((e->xcd_affine & 2) && e->xcd_xps) a.xcd_maffine = -1;
@@ -1200,6 +1283,12 @@ static void k_down(ntts_backbone* e, int i) {
 // next_scale: fp8 model, the static input scale of the GEMM that consumes the normalised rows (0 = bf16 output)
 static void k_add_norm(ntts_backbone* e, int K, int ks, const bf16_t* norm_w, bf16_t* resid_out, bf16_t* normed_out, float next_scale = 0.f, int affine_bit = 0) {
     NormArgs n{};
+    if (e->wide && e->wide_o == 1 && affine_bit == 1) {   // behind the wide o_proj: the residual stream is already summed (EPI_RESID), this pass only normalises it
+        n.o_bf16 = e->h_dec; n.norm_w = norm_w; n.normed_out = normed_out; n.M = e->cfg.max_batch; n.H = e->H; n.eps = e->cfg.rms_eps;
+        if (e->fp8 && next_scale > 0.f) n.out_fp8_inv = 1.0f / next_scale;
+        add_rmsnorm_launch(n, e->stream, true);
+        return;
+    }
     n.xcd_rows = (e->xcd_affine & affine_bit) ? e->xcd_xps : 0;
     n.slabs = e->slabs; n.nslab = gemm_nsplit(K, ks, ktile_of(e)); n.slab_rows = e->cfg.max_batch; n.resid_in = e->h_dec; n.resid_out = resid_out;
     n.norm_w = norm_w; n.normed_out = normed_out; n.M = e->cfg.max_batch; n.H = e->H; n.eps = e->cfg.rms_eps;
@@ -1215,7 +1304,7 @@ static GemvArgs gemv_args(const ntts_backbone* e, const bf16_t* X, long ldx, con
     a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.w_tile_major = 1; a.out = out; a.ldo = ldo;
     a.slab_rows = e->cfg.max_batch; a.M = e->cfg.max_batch; a.N = N; a.K = K;
     a.tl = e->gemv_tl;
-    a.eos_col = -1; a.n_valid = N;
+    a.n_valid = N;
     return a;
 }
 // the fused prologue of layer i's QKV GEMV: h = (i == 0 ? embed[cur_tok] : h + bf16(sum of the previous down_proj's slabs));
@@ -1292,7 +1381,7 @@ static void ks_lm_head(ntts_backbone* e, bool keep_logits) {
     const int H = e->H, V = e->cfg.vocab_size;
     GemvArgs a = gemv_args(e, e->xn_dec, H, e->lr_rows ? e->head_r : e->embed_tm, H, nullptr, 0, e->lr_rows ? (e->lr_rows + 15) / 16 * 16 : V, H,
                            e->lr_rows ? e->shead_r : e->shead, e->xs_head);
-    if (e->lr_rows) { a.eos_col = e->lr_rows - 1; a.n_valid = e->lr_rows; }   // compacted head: columns = [range | EOS | padding to 16]
+    if (e->lr_rows) { a.eos_col1 = e->lr_rows; a.n_valid = e->lr_rows; }   // compacted head: columns = [range | EOS | padding to 16]
     a.part_val = e->part_val; a.part_idx = e->part_idx; a.mask_eos = e->sl.mask_eos;
     a.logits = keep_logits ? e->logits : nullptr; a.ld_logits = V;
     a.logits_bf16 = (keep_logits && e->n_sampling > 0) ? e->logits_bf16 : nullptr; a.ld_logits_bf16 = e->ldl;
@@ -1587,7 +1676,7 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
     add_rmsnorm_launch(n0, st);
     // fp8 calibration (ntts_backbone_calibrate, bf16 engines): running max |x| of every GEMM's input rows, slot = 4 * layer + {0: QKV, 1: o_proj,
     // 2: gate/up, 3: down_proj}, last slot = lm_head.  One small launch behind each producer, in calibration mode only.
-    auto tap = [&](const bf16_t* x, long rows, int cols, int slot) {
+    auto tap = [&](const bf16_t* x, long rows, int cols, int slot) {   // x: DENSE rows (leading dimension == cols, as every workspace tapped below is)
         if (!e->calib || rows <= 0) return;
         const long nvec = rows * cols / 8;
         float* dst = e->calib + slot;
@@ -1676,8 +1765,13 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
         }
         add_rmsnorm_launch(n2, st);
     }
-    if (e->calib)          // the lm_head's input rows: each prompt's last position, gathered into its decode-slot row
-        for (int i = 0; i < n; ++i) tap(e->xn_dec + (size_t)slots[i] * H, 1, H, 4 * c.num_layers);
+    if (e->calib) {        // the lm_head's input: the final norm of EVERY position (the decode steps feed the head one row per step and
+        NormArgs nc{};     // sequence -- a record of the prompts' last positions only would be 64 rows for 64 calibration prompts); scratch output
+        nc.o_bf16 = e->h_pf; nc.norm_w = e->final_norm;   // (no pruning in calibration mode: h_pf holds every row)
+        nc.norm_w = e->final_norm; nc.normed_out = e->xn_pf; nc.M = Ti; nc.H = H; nc.eps = c.rms_eps;
+        add_rmsnorm_launch(nc, st);
+        tap(e->xn_pf, Ti, H, 4 * c.num_layers);
+    }
     lm_head_and_sample(e, SLOT_PREFILLED);
     HIPCHK(e, hipEventRecord(e->ev[1], st));
     e->have_pf_time = true;
@@ -1720,6 +1814,10 @@ extern "C" int ntts_backbone_decode(ntts_backbone* e, int32_t n_steps) {
     if (!e->finalized) return fail(e, NTTS_ESTATE, "weights not finalised");
     HIPCHK(e, hipSetDevice(e->device));
     hipStream_t st = e->stream;
+    {   // how many chains share the chip right now decides the step's tiles (both shapes' graphs are kept)
+        const int counted = chains_now(e);
+        use_shape_for(e, e->gang_forced > 0 ? e->gang_forced : counted);
+    }
     // ---- reserve KV pages for the positions these steps can write (pos <= max_len - 2)
     std::vector<int> trip;
     std::vector<std::pair<int, size_t>> undo;
@@ -1746,11 +1844,8 @@ extern "C" int ntts_backbone_decode(ntts_backbone* e, int32_t n_steps) {
         const int nt = (int)trip.size() / 3;
         NTTS_LAUNCH((bt_update_kernel), dim3((nt + 63) / 64), dim3(64), st, (const int*)e->meta_dev, nt, e->block_table, e->max_pages);
     }
-    if ((e->graph || e->graph_split) && e->graph_has_logits != (e->n_sampling > 0)) {   // the step's launch arguments changed: both captures are stale
-        if (e->graph) { hipGraphExecDestroy(e->graph); e->graph = nullptr; }
-        if (e->graph_split) { hipGraphExecDestroy(e->graph_split); e->graph_split = nullptr; }
-        e->graph_tried = e->graph_split_tried = false;
-    }
+    if ((e->graph || e->graph_split || e->graph_shape[0] || e->graph_shape[1]) && e->graph_has_logits != (e->n_sampling > 0))   // the step's launch arguments changed:
+        drop_graphs(e);                                                                                                            // every capture is stale
     // small-batch path: steps whose longest context has reached attn_split_ctx run the context-split attention (its own graph)
     const bool can_split = e->attn_split > 0 && !e->attn_tl;
     auto wants_split = [&](int step) { return can_split && ctx_now + step >= e->attn_split_ctx; };
@@ -2064,9 +2159,7 @@ extern "C" int ntts_backbone_set_debug(ntts_backbone* e, int32_t keep_logits) {
         HIPCHK(e, hipFree(e->logits));
         e->logits = nullptr;
     }
-    if (e->graph) { hipGraphExecDestroy(e->graph); e->graph = nullptr; }
-    if (e->graph_split) { hipGraphExecDestroy(e->graph_split); e->graph_split = nullptr; }
-    e->graph_tried = e->graph_split_tried = false;  // the logits pointer is baked into the captured step
+    drop_graphs(e);  // the logits pointer is baked into the captured step
     return NTTS_OK;
 }
 

@@ -45,6 +45,9 @@ struct AttnDecodeArgs {
     int nh, nkv;
     long slab_rows;        // context-split form: rows per chunk slab of the partial outputs (AttnSplitArgs::oslabs)
     unsigned long long* tl;   // diagnostics: [B][nkv][4 waves][8] phase timestamps (now_ticks), null in the product path
+    int nt_pages;             // K / V^T pages with the non-temporal load policy (kVar & 2).  Round 6, ONE 1024-row launch (2048 workgroups, 315 MB): 66.4 -> 60.4 us
+                              // (4.75 -> 5.2 TB/s) and the QKV GEMM behind it 11.2 -> 10.1 us (its X / W stay in L2); kDepth 2, early V^T requests and 8-wave
+                              // workgroups on top: nothing (profiles/r06b_sweep_wide_*).  At 256 rows, alone or four chains side by side: no gain (0.970 vs 0.965 ms)
     int xcd_rows;             // xps = 8 / (batch / 64), 0 = off: workgroup x takes sequence xcd_row(x, xps) (norm.h) -- the rows of m-block p on XCD group p,
                               // where the QKV GEMM left their split-K slabs and the o_proj GEMM will read their outputs (gemm.h xcd_maffine); speed only
 };
@@ -527,6 +530,8 @@ inline void attn_decode_launch(const AttnDecodeArgs& p, int batch, hipStream_t s
         return;
     }
     if (p.tl) NTTS_LAUNCH((attn_decode_kernel<1, true, 1, 4, kAttnLMax>), grid, block, s, p);   // diagnostics: phase timestamps
+    else if (max_ctx <= 1024 && p.nt_pages) NTTS_LAUNCH((attn_decode_kernel<1, false, 3, 4, 1024>), grid, block, s, p);
+    else if (p.nt_pages) NTTS_LAUNCH((attn_decode_kernel<1, false, 3, 4, kAttnLMax>), grid, block, s, p);
     else if (max_ctx <= 1024) NTTS_LAUNCH((attn_decode_kernel<1, false, 1, 4, 1024>), grid, block, s, p);
     else NTTS_LAUNCH((attn_decode_kernel<1, false, 1, 4, kAttnLMax>), grid, block, s, p);
 }

@@ -60,8 +60,8 @@ struct GemmArgs {
     int* part_idx;
     int part_stride;       // partials per row = nblocks * WN
     const int* mask_eos;   // [M] value e+1 > 0 -> logit[e] = -inf for that row (MinNewTokens processor)
-    int eos_col;           // >= 0: W is a COMPACTED head (ntts_backbone_set_logits_range: the rows of a token range + the EOS row) and the EOS row is
-                           // this column -- the mask applies there whatever id mask_eos carries; -1: column = token id
+    int eos_col1;          // > 0: W is a COMPACTED head (ntts_backbone_set_logits_range: the rows of a token range + the EOS row) and the EOS row is
+                           // column eos_col1 - 1 -- the mask applies there whatever id mask_eos carries; 0 (a zeroed struct): column = token id
     float* logits;         // optional fp32 [M][ld_logits] dump of the processed logits
     long ld_logits;
     bf16_t* logits_bf16;   // optional bf16 [M][ld_logits_bf16] processed logits for the top-k sampler
@@ -367,7 +367,7 @@ NTTS_D void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[TM][4], int mrow0, int
                 for (int r = 0; r < 4; ++r) {
                     const int n = nb16 + j * 4 + r;
                     float v = rbf(acc[a][j][r]);                  // lm_head output is bf16, then .float()
-                    if (meos && n == (p.eos_col >= 0 ? p.eos_col : meos - 1)) v = -INFINITY;
+                    if (meos && n == (p.eos_col1 > 0 ? p.eos_col1 - 1 : meos - 1)) v = -INFINITY;
                     lo[j * 4 + r] = f2bf(v);
                     if (n < p.N) {
                         if (mok && p.logits) p.logits[(long)m * p.ld_logits + n] = v;
@@ -433,7 +433,7 @@ NTTS_D void gemm_epilogue_nat(const GemmArgs& p, f32x4 (&acc)[TM][TN], int mrow0
                 for (int r = 0; r < 4; ++r) {
                     const int n = nw0 + j * 16 + g * 4 + r;
                     float v = rbf(acc[a][j][r]);                  // lm_head output is bf16, then .float()
-                    if (meos && n == (p.eos_col >= 0 ? p.eos_col : meos - 1)) v = -INFINITY;
+                    if (meos && n == (p.eos_col1 > 0 ? p.eos_col1 - 1 : meos - 1)) v = -INFINITY;
                     lo[r] = f2bf(v);
                     if (n < p.N) {
                         if (mok && p.logits) p.logits[(long)m * p.ld_logits + n] = v;

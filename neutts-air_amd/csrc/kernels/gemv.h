@@ -56,7 +56,7 @@ struct GemvArgs {
     int* part_idx;
     int part_stride;       // partials per row = N / 16
     const int* mask_eos;
-    int eos_col;           // compacted head (gemm.h GemmArgs::eos_col): the EOS row's column, -1 = column is the token id
+    int eos_col1;          // compacted head (gemm.h GemmArgs::eos_col1): the EOS row's column + 1, 0 = column is the token id
     int n_valid;           // columns >= n_valid are padding of a compacted head (N is a multiple of 16): their logits are -inf
     float* logits;
     long ld_logits;
@@ -241,7 +241,7 @@ NTTS_KERNEL((FW + 4) * 64) void gemv_kernel(GemvArgs p) {
         for (int r = 0; r < 4; ++r) {
             const int n = nf + r;
             float v = rbf(acc[r]);                                   // lm_head output is bf16, then .float()
-            if ((meos && n == (p.eos_col >= 0 ? p.eos_col : meos - 1)) || n >= p.n_valid) v = -INFINITY;
+            if ((meos && n == (p.eos_col1 > 0 ? p.eos_col1 - 1 : meos - 1)) || n >= p.n_valid) v = -INFINITY;
             lo[r] = f2bf(v);
             if (mok && p.logits) p.logits[(long)m * p.ld_logits + n] = v;
             if (v > best) { best = v; bidx = n; }                     // ascending n + strict '>' = first max wins

@@ -80,18 +80,21 @@ struct QkvRopeArgs {
 // KS = K slices inside the workgroup (2 or 4): the workgroup is 2 row halves x KS slices = 2 * KS waves, a k-step brings in one
 //   128-byte tile of EVERY slice (KS x 12 KB), so K = 896 is 7 steps at KS = 2 and 4 at KS = 4 (slices 4 + 4 + 3 + 3 tiles).
 //   The partial sums meet in LDS and are added in slice order.
-template <int NS, bool F8, int KS>
+// TMQ = 16-row blocks per wave (1: the 32 x 64 tile of the <= 256-row decode batch; 2 / 4: 64 / 128 batch rows per workgroup for the WIDE
+//   decode step -- 1024 rows, round 6: a W tile then enters LDS once per 64 / 128 rows instead of once per 32, 66 / 50 MB of LDS-DMA
+//   traffic per launch instead of 99)
+template <int NS, bool F8, int KS, int TMQ = 1>
 NTTS_KERNEL(KS * 128) void qkv_rope_kernel(QkvRopeArgs p) {
     constexpr int ESZ = F8 ? 1 : 2;
-    constexpr int BM = 32, BN = 64, ROWS = BM + BN;      // LDS rows (128 bytes each) per ring slot and K slice
+    constexpr int BM = 32 * TMQ, BN = 64, ROWS = BM + BN;      // LDS rows (128 bytes each) per ring slot and K slice
     constexpr int NINST = ROWS / 8;                       // wave-instructions (8 rows x 128 B) per slot and slice: 12
     constexpr int PER_WAVE = NINST / 2;                   // the two waves of a K slice split them
     static_assert(KS == 2 || KS == 4, "K slices per workgroup");
-    static_assert(NS >= 2 && (NS - 1) * PER_WAVE + 13 <= 63, "vmcnt range (ring + the epilogue operands requested at entry)");
+    static_assert(NS >= 2 && (NS - 1) * PER_WAVE + 3 * TMQ * (4 / KS) + 4 * (4 / KS) + 1 <= 63, "vmcnt range (ring + the epilogue operands requested at entry)");
     NTTS_SHARED bf16_t lds[NS * KS * ROWS * 64];
-    static_assert(sizeof(f32x4) * KS * 2 * 4 * 64 <= sizeof(bf16_t) * NS * KS * ROWS * 64, "exchange area fits the ring");
-    typedef f32x4 (*XchT)[2][4][64];
-    XchT xch = (XchT)lds;                                 // [slice][row half][j][lane] partial sums (the ring, once everybody is done with it)
+    static_assert(sizeof(f32x4) * KS * 2 * TMQ * 4 * 64 <= sizeof(bf16_t) * NS * KS * ROWS * 64, "exchange area fits the ring");
+    typedef f32x4 (*XchT)[2][TMQ][4][64];
+    XchT xch = (XchT)lds;                                 // [slice][row half][row block][j][lane] partial sums (the ring, once everybody is done with it)
     auto swz = [](int rho) { return (rho >> 1) & 7; };
 
     const int lane = lane_id(), wave = wave_id();
@@ -130,25 +133,30 @@ NTTS_KERNEL(KS * 128) void qkv_rope_kernel(QkvRopeArgs p) {
     //      and every later counted wait covers them.  The epilogue is shared out: wave (wm, kh) finishes NJ = 4 / KS of the four
     //      4-feature groups j of its row half -- features nb16 + e0 .. + 4 NJ - 1 of token m in lane (g, l15)
     constexpr int NJ = 4 / KS;
-    const int m = m0 + wm * 16 + l15;
-    const int mc = m < p.M ? m : p.M - 1;
     const int e0 = kh * NJ * 4;
     const int nb16 = n0 + g * 16, nb16p = n0 + (g ^ 2) * 16;             // own features / their RoPE partners (i <-> i + 32)
-    const u32x4 meta = ld16<u32x4>(p.meta + (long)mc * 4);
-    bf16x4 cs[NJ], sn[NJ], bs[NJ], bsp[NJ];
+    u32x4 meta[TMQ];
+    bf16x4 cs[TMQ][NJ], sn[TMQ][NJ], bs[NJ], bsp[NJ];
     f32x4 wsc[NJ], wscp[NJ];
-    {
+#pragma unroll
+    for (int a = 0; a < TMQ; ++a) {                                     // this wave's row blocks: rows m0 + (wm * TMQ + a) * 16 + l15
+        const int m = m0 + (wm * TMQ + a) * 16 + l15;
+        const int mc = m < p.M ? m : p.M - 1;
+        meta[a] = ld16<u32x4>(p.meta + (long)mc * 4);
         const bf16_t* rr = p.rope_rows + (long)mc * 64 + (g & 1) * 16 + e0;
 #pragma unroll
         for (int jj = 0; jj < NJ; ++jj) {
-            cs[jj] = *(const bf16x4*)(rr + jj * 4);
-            sn[jj] = *(const bf16x4*)(rr + 32 + jj * 4);
-            bs[jj] = *(const bf16x4*)(p.bias + nb16 + e0 + jj * 4);
-            bsp[jj] = *(const bf16x4*)(p.bias + nb16p + e0 + jj * 4);
-            if constexpr (F8) {
-                wsc[jj] = ld16<f32x4>(p.wscale + nb16 + e0 + jj * 4);
-                wscp[jj] = ld16<f32x4>(p.wscale + nb16p + e0 + jj * 4);
-            }
+            cs[a][jj] = *(const bf16x4*)(rr + jj * 4);
+            sn[a][jj] = *(const bf16x4*)(rr + 32 + jj * 4);
+        }
+    }
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+        bs[jj] = *(const bf16x4*)(p.bias + nb16 + e0 + jj * 4);
+        bsp[jj] = *(const bf16x4*)(p.bias + nb16p + e0 + jj * 4);
+        if constexpr (F8) {
+            wsc[jj] = ld16<f32x4>(p.wscale + nb16 + e0 + jj * 4);
+            wscp[jj] = ld16<f32x4>(p.wscale + nb16p + e0 + jj * 4);
         }
     }
 
@@ -182,11 +190,18 @@ NTTS_KERNEL(KS * 128) void qkv_rope_kernel(QkvRopeArgs p) {
         }
     };
 
-    f32x4 acc[4];
+    f32x4 acc[TMQ][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int xrho = wm * 16 + l15;
-    const int xoff = xrho * 64, xsw = swz(xrho);
+    for (int a = 0; a < TMQ; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int xoff[TMQ], xsw[TMQ];
+#pragma unroll
+    for (int a = 0; a < TMQ; ++a) {
+        const int xrho = (wm * TMQ + a) * 16 + l15;
+        xoff[a] = xrho * 64;
+        xsw[a] = swz(xrho);
+    }
     int woff[4], wsw[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -213,48 +228,56 @@ NTTS_KERNEL(KS * 128) void qkv_rope_kernel(QkvRopeArgs p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int c = ks * 4 + g;
-            const bf16x8 xb = ld16<bf16x8>(base + xoff + ((c ^ xsw) << 3));
-            bf16x8 wa[4];
+            bf16x8 xb[TMQ], wa[4];
+#pragma unroll
+            for (int a = 0; a < TMQ; ++a) xb[a] = ld16<bf16x8>(base + xoff[a] + ((c ^ xsw[a]) << 3));
 #pragma unroll
             for (int j = 0; j < 4; ++j) wa[j] = ld16<bf16x8>(base + woff[j] + ((c ^ wsw[j]) << 3));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if constexpr (F8) {
-                    const i64x2 w2 = __builtin_bit_cast(i64x2, wa[j]), x2 = __builtin_bit_cast(i64x2, xb);
-                    acc[j] = mfma16_fp8(w2[0], x2[0], acc[j]);
-                    acc[j] = mfma16_fp8(w2[1], x2[1], acc[j]);
-                } else {
-                    acc[j] = mfma16(wa[j], xb, acc[j]);
+            for (int a = 0; a < TMQ; ++a)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if constexpr (F8) {
+                        const i64x2 w2 = __builtin_bit_cast(i64x2, wa[j]), x2 = __builtin_bit_cast(i64x2, xb[a]);
+                        acc[a][j] = mfma16_fp8(w2[0], x2[0], acc[a][j]);
+                        acc[a][j] = mfma16_fp8(w2[1], x2[1], acc[a][j]);
+                    } else {
+                        acc[a][j] = mfma16(wa[j], xb[a], acc[a][j]);
+                    }
                 }
-            }
         }
     }
 
     // ---- the K slices meet in LDS (every wave parks its partial sums; the ring is free once everybody is past the k-loop), and
     //      every wave finishes its share: sums in slice order + bias -> ONE rounding (the nn.Linear output), then RoPE against the
     //      partner feature i +- 32, which sits in the same table at lane ^ 32 -- no shuffles
-    if (p.tl && wave == 0 && lane == 0) p.tl[tlb + 3] = now_ticks() + (acc[0][0] == 1.2345e30f ? 1 : 0);
+    if (p.tl && wave == 0 && lane == 0) p.tl[tlb + 3] = now_ticks() + (acc[0][0][0] == 1.2345e30f ? 1 : 0);
     sync();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xch[kh][wm][j][lane] = acc[j];
+    for (int a = 0; a < TMQ; ++a)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xch[kh][wm][a][j][lane] = acc[a][j];
     sync();
     mark(4);
     const int hd = n0 >> 6;                               // which head this workgroup's 64 columns are
-    const int st = (int)meta[0], page = (int)meta[2], slot = (int)meta[3];
-    const bool mok = m < p.M, run = mok && st == 1;
     const bool rot = hd < p.nh + p.nkv;                   // a q or k head: rotate (rope_pair: every op rounded to bf16)
+#pragma unroll
+    for (int a = 0; a < TMQ; ++a) {
+    const int m = m0 + (wm * TMQ + a) * 16 + l15;
+    const int st = (int)meta[a][0], page = (int)meta[a][2], slot = (int)meta[a][3];
+    const bool mok = m < p.M, run = mok && st == 1;
     alignas(16) bf16_t out[NJ * 4];
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
         const int j = kh * NJ + jj;
-        f32x4 so = xch[0][wm][j][lane], sp = xch[0][wm][j][lane ^ 32];
+        f32x4 so = xch[0][wm][a][j][lane], sp = xch[0][wm][a][j][lane ^ 32];
         if constexpr (F8) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { so[r] *= p.xscale * wsc[jj][r]; sp[r] *= p.xscale * wscp[jj][r]; }
         }
 #pragma unroll
         for (int q = 1; q < KS; ++q) {
-            const f32x4 o = xch[q][wm][j][lane], op = xch[q][wm][j][lane ^ 32];
+            const f32x4 o = xch[q][wm][a][j][lane], op = xch[q][wm][a][j][lane ^ 32];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if constexpr (F8) { so[r] += o[r] * (p.xscale * wsc[jj][r]); sp[r] += op[r] * (p.xscale * wscp[jj][r]); }
@@ -264,7 +287,7 @@ NTTS_KERNEL(KS * 128) void qkv_rope_kernel(QkvRopeArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bf16_t vo = f2bf(so[r] + bf2f((bf16_t)bs[jj][r])), vp = f2bf(sp[r] + bf2f((bf16_t)bsp[jj][r]));
-            const float xo = bf2f(vo), xp = bf2f(vp), c = bf2f((bf16_t)cs[jj][r]), sv = bf2f((bf16_t)sn[jj][r]);
+            const float xo = bf2f(vo), xp = bf2f(vp), c = bf2f((bf16_t)cs[a][jj][r]), sv = bf2f((bf16_t)sn[a][jj][r]);
             // g < 2: o1 = x1*c - x2*s with x1 = own, x2 = partner;  g >= 2: o2 = x2*c + x1*s with x2 = own, x1 = partner
             out[jj * 4 + r] = rot ? f2bf(rbf(xo * c) + (g < 2 ? rbf(-xp * sv) : rbf(xp * sv))) : vo;
         }
@@ -279,11 +302,23 @@ NTTS_KERNEL(KS * 128) void qkv_rope_kernel(QkvRopeArgs p) {
         if constexpr (NJ == 2) *(u32x4*)dst = *(u32x4*)&out[0];
         else *(u32x2*)dst = *(u32x2*)&out[0];
     }
+    }   // row blocks
     if (p.tl) { wait_vmem(); mark(5); }
 }
 
 // 3 ring slots, 2 K slices per workgroup (MI355X, batch 256: 4 slices 6.56 vs 6.41 us, 2 slots 7.5, 4 / 6 slots 6.4-8.3:
 // profiles/r03a_sweep_qkv_fused*.log; KS = 2 also keeps the summation order of the two-slab path this kernel replaced)
+// the wide decode step (>= 512 rows): 64 or 128 batch rows per workgroup, 2-slot ring (64 rows: two workgroups per CU)
+template <bool F8, int TMQ>
+inline void qkv_rope_launch_wide(QkvRopeArgs p, hipStream_t s) {
+    constexpr int KS = 2, NS = TMQ == 2 ? 2 : 3;
+    const int ktiles = p.K / (F8 ? 128 : 64);
+    p.kps = (ktiles + KS - 1) / KS;
+    const int mblocks = (p.M + 32 * TMQ - 1) / (32 * TMQ), nblocks = p.N / 64;
+    p.xcd_mpx = 0;
+    NTTS_LAUNCH((qkv_rope_kernel<NS, F8, KS, TMQ>), dim3(mblocks * nblocks), dim3(KS * 128), s, p);
+}
+
 template <bool F8>
 inline void qkv_rope_launch(QkvRopeArgs p, bool xcd_place, hipStream_t s, bool w_stationary = false) {
     constexpr int KS = 2, NS = 3;

@@ -494,8 +494,9 @@ class BackboneEngine:
         self._chk(self.lib.ntts_backbone_sync(self.h))
 
     def set_gang(self, chains: int):
-        """Tell the engine how many decode chains (engines of an EngineGang, itself included) run side by side on the GPU: the
-        decode step's GEMM tiles and XCD placement are chosen for that (ntts_backbone_set_gang); the captured step graph is dropped."""
+        """PIN how many decode chains (engines of an EngineGang, itself included) the engine assumes side by side on the GPU: the decode
+        step's GEMM tiles and XCD placement are chosen for that (ntts_backbone_set_gang).  0 = count them (the default since ABI 9: engines
+        of the same arena that decoded within the last 50 ms); both shapes keep their captured step graph.  Tests, sweeps, profiling."""
         self._chk(self.lib.ntts_backbone_set_gang(self.h, int(chains)))
 
     def calibrate(self, enable: bool = True):
@@ -819,8 +820,9 @@ class EngineGang:
                     self._streams.append(st.value)
                 for e, st in zip(self.engines, self._streams):
                     e.set_stream(st)
-            for e in self.engines:
-                e.set_gang(n)                            # the decode step's tile family depends on how many chains share the chip
+            # (the decode step's tile family depends on how many chains share the chip: since ABI 9 every engine counts them itself at each
+            #  decode call -- ntts_backbone_set_gang only pins the count for tests and sweeps -- so an engine of the gang that decodes alone
+            #  for a while, e.g. NeuTTS.infer on engine 0, runs the single-chain shape meanwhile)
         except Exception:
             self.close()                                 # twins and lanes made so far must not leak
             raise
@@ -939,7 +941,7 @@ class EngineGang:
         if engines and getattr(engines[0], "h", None):
             if self._streams:
                 engines[0].set_stream(None)
-            engines[0].set_gang(1)
+            engines[0].set_gang(0)
         for st in self._streams:
             self.lib.ntts_stream_destroy(self._device, C.c_void_p(st))
         self._streams = []

@@ -237,6 +237,10 @@ class NeuTTS:
             eng = getattr(self, name, None)
             if eng is not None and hasattr(eng, "close"):
                 eng.close()
+        codec = getattr(self, "codec", None)             # the class's own codec engine (gang codec 0) and the encoder engine: their GPU buffers and
+        for eng in (getattr(codec, "engine", None), getattr(codec, "enc_engine", None)):   # page-locked staging rings do not wait for the collector
+            if eng is not None and hasattr(eng, "close"):
+                eng.close()
 
     def __enter__(self):
         return self
@@ -604,6 +608,10 @@ class NeuTTS:
                 if self.gang.lane(k):
                     c.set_stream(self.gang.lane(k))
             self._gang_codecs = engs
+            self._gang_codec0_lent = True
+        elif not getattr(self, "_gang_codec0_lent", False) and self.gang.lane(0):
+            self._gang_codecs[0].set_stream(self.gang.lane(0))     # (handed back at the end of the previous gang call)
+            self._gang_codec0_lent = True
         return self._gang_codecs
 
     def _infer_stream_batch_gang(self, prompts: List[List[int]], ref_codes: List[List[int]]):
@@ -695,6 +703,11 @@ class NeuTTS:
                         #  157 ms; profiles/r05g_bench_nano-fp8_stream_*.json)
                         eng.decode(look_f - 1 if (admitted and look_f > 1) else chunk)
         finally:
+            try:
+                codecs[0].set_stream(None)               # the class's own codec engine goes back to its stream for the non-gang calls that follow
+            except _hip.NeuTTSHipError:                  # (infer, infer_stream, infer_stream_batch on engine 0); re-lent by the next gang call
+                pass
+            self._gang_codec0_lent = False
             for k, eng in enumerate(gang.engines):
                 for item in active[k]:
                     if item[0] is not None:

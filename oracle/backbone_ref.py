@@ -228,7 +228,8 @@ def model_forward(cfg: BackboneConfig, w, ids: torch.Tensor, cache: KVCache, tap
 def gemm_input_amax(cfg: BackboneConfig, w, prompts) -> Dict[str, float]:
     """max |x| of every GEMM's input over the prompt passes of `prompts`, under the `input_scale` names of a static-fp8 checkpoint -- what
     the engine's calibration mode records (ntts_backbone_calibrate; tests/test_emu_variants.py checks one against the other).  The
-    lm_head sees each prompt's LAST position only (hf:generation/utils.py:2894)."""
+    lm_head's record covers the final norm of EVERY position: generation feeds it one new position per step (hf:generation/utils.py:2894),
+    and a record of the prompts' last positions alone would rest on one row per calibration prompt."""
     out: Dict[str, float] = {}
 
     def upd(k, t):
@@ -243,7 +244,7 @@ def gemm_input_amax(cfg: BackboneConfig, w, prompts) -> Dict[str, float]:
                 upd(pre + "self_attn.o_proj.input_scale", t["attn"])
                 upd(pre + "mlp.gate_proj.input_scale", t["x2"])
                 upd(pre + "mlp.down_proj.input_scale", t["act"])
-            upd("lm_head.input_scale", rms_norm(taps[-1]["h_out"], w["model.norm.weight"], cfg.rms_eps)[:, -1, :])
+            upd("lm_head.input_scale", rms_norm(taps[-1]["h_out"], w["model.norm.weight"], cfg.rms_eps))
     return out
 
 

@@ -243,6 +243,52 @@ def test_generate_with_pages_held_outside_the_call(emu_lib, monkeypatch):
     assert eng.generate(prompts, short, steps_per_poll=3) == alone
 
 
+@pytest.mark.parametrize("qkv_rows", ["2", "4"])
+def test_wide_decode_shape_matches_the_narrow_shape(emu_lib, qkv_rows, monkeypatch):
+    """Round 6: the WIDE decode step (engines of >= 512 slots -- the static benchmark's four 256-utterance batches as ONE 1024-row chain): QKV +
+    RoPE + K append on 64 / 128 batch rows per workgroup (qkv_rope.h TMQ = 2 / 4), o_proj on whole-K 64 x 64 tiles with the residual add in
+    the epilogue (no fp32 slabs; the norm behind it only normalises), down_proj on the 128 x 128 / 8-wave split-K tile, gate/up on 256 x 192.
+    Forced on a 3-slot engine through NTTS_WIDE (the GPU suite runs it at 1024 slots against the oracle, tests/test_gpu_parity_matrix.py):
+    the ids of walk weights are those of the narrow step at every step, every logits row agrees to fp32-summation-order noise (o_proj sums
+    its K in one chain instead of four slabs), ragged contexts incl. a free slot between running ones."""
+    monkeypatch.setenv("NTTS_SMALL_BATCH", "0")
+    z, cfg, w = load_fixture("backbone_small_walk")
+    S, N, eos = 40, 5, int(z["eos"])
+    prompts = [br.synthetic_prompt(cfg, 0, S), br.synthetic_prompt(cfg, 1, S - 7)]
+    samp = [_hip.Sampling(max_length=len(p) + N, min_new_tokens=N, eos_token_id=eos, do_sample=False) for p in prompts]
+
+    def run(eng):
+        eng.prefill(prompts, [0, 2], samp)                       # slot 1 stays free
+        rows = []
+        for k in range(N):
+            if k:
+                eng.decode(1)
+            rows.append([eng.read_logits(s).copy() for s in (0, 2)])
+        ids = [eng.read(s)[0] for s in (0, 2)]
+        eng.release_many([0, 2])
+        return rows, ids
+
+    eng = make_engine(cfg, w, emu_lib, max_batch=3, max_context=96, bf16_upload=True)
+    eng.set_debug(True)
+    rows1, ids1 = run(eng)
+    eng.close()
+    assert all(len(set(i)) == N for i in ids1)
+    monkeypatch.setenv("NTTS_WIDE", "1")
+    monkeypatch.setenv("NTTS_WIDE_QKV", qkv_rows)
+    eng = make_engine(cfg, w, emu_lib, max_batch=3, max_context=96, bf16_upload=True)
+    eng.set_debug(True)
+    rowsw, idsw = run(eng)
+    rowsw2, idsw2 = run(eng)                                     # recycled slots, dirty pages: same bits
+    eng.close()
+    assert idsw == ids1 and idsw2 == ids1
+    for a, b, c in zip(rows1, rowsw, rowsw2):
+        for s in (0, 1):
+            assert np.array_equal(b[s], c[s])
+            fin = np.isfinite(a[s])
+            assert np.array_equal(fin, np.isfinite(b[s])) and fin.sum() == len(fin) - 1
+            assert np.abs(a[s][fin] - b[s][fin]).max() <= 2.0 ** -6 * np.abs(a[s][fin]).max()
+
+
 def test_gang_decode_shape_matches_the_single_chain_shape(emu_lib, monkeypatch):
     """Round 5 (ABI 8 ntts_backbone_set_gang): the gang's decode shape -- o_proj / down_proj on the 256 x 64 tile (8 waves, all rows of a
     chain in one m-block, one K slice per XCD pair), QKV column blocks dealt to XCDs (surplus workgroups return at once), no row-block
