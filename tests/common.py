@@ -154,3 +154,32 @@ def check_encoder_codes(cfg, got_codes, got_lat, gold_codes, gold_lat, lat_tol, 
         bad = np.nonzero(dg != dr)[0]
         assert (np.abs(dg[bad] - dr[bad]) == 1).all() and (dist[t, bad] <= 2 * lat_tol).all(), (t, dg, dr, dist[t])
     return err
+
+
+# ------------------------------------------------------------------------------------------------ streaming (ref:neutts/neutts.py:373-465)
+def reference_stream_chunks(ref_codes, new_codes, dec, hop, chunk=25, lookforward=5, lookback=50, overlap=1):
+    """The reference's streaming algorithm (ref:neutts/neutts.py:385-465) restated on a FINISHED code sequence: the chunks `infer_stream`
+    must yield, in order.  `dec(codes) -> waveform` is the codec (the oracle's, in the tests).  A window becomes decodable once
+    chunk + lookforward undecoded tokens exist; it spans lookback + overlap frames of left context (the reference voice's codes first),
+    the chunk and the lookforward, of which chunk + 2 * overlap frames starting at the first undecoded one are kept and cross-faded
+    (linear_overlap_add) at a stride of `chunk` frames; the tail takes one overlap frame BEFORE its first undecoded token (asymmetric
+    in the reference: kept)."""
+    from oracle import codec_ref as cr
+    cache, audio, out = list(ref_codes), [], []
+    n_tok, n_samp = len(ref_codes), 0
+    for c in new_codes:
+        cache.append(c)
+        if len(cache) - n_tok >= chunk + lookforward:
+            t0 = max(n_tok - (lookback + overlap), 0)
+            s0 = (n_tok - t0) * hop
+            audio.append(dec(cache[t0:n_tok + chunk + lookforward + overlap])[s0:s0 + (chunk + 2 * overlap) * hop])
+            mixed = cr.linear_overlap_add(audio, chunk * hop)
+            out.append(mixed[n_samp:len(audio) * chunk * hop])
+            n_samp = len(audio) * chunk * hop
+            n_tok += chunk
+    rem = len(cache) - n_tok
+    if rem > 0:
+        t0 = max(len(cache) - (lookback + overlap + rem), 0)
+        audio.append(dec(cache[t0:])[(len(cache) - t0 - rem - overlap) * hop:])
+        out.append(cr.linear_overlap_add(audio, chunk * hop)[n_samp:])
+    return out

@@ -59,7 +59,7 @@ def test_fp8_nano_geometry_19_layers_batch512(lib):
     oracle, and identical rows for identical prompts across all 512 slots (batch / slot invariance).  The fp8 noise grows with
     the number of quantisation points (tests/test_emu_variants.py::check_fp8_model: ~1.3 % of the logits each): 19 layers x 4
     GEMM inputs measured 0.097-0.108 relative RMS on MI355X (correlation 0.994-0.995) against 0.21-0.28 for the quantisation
-    itself (fp8 oracle vs bf16 oracle) -> bars at 1.5 x the measured distance / correlation >= 0.99."""
+    itself (fp8 oracle vs bf16 oracle) -> bar at 1.2 x the largest measured distance / correlation >= 0.99."""
     cfg = br.BackboneConfig.neutts_nano_like()
     base = [br.synthetic_prompt(cfg, i, 70) for i in range(4)]
     prompts = [base[i % 4] for i in range(512)]
@@ -68,4 +68,4 @@ def test_fp8_nano_geometry_19_layers_batch512(lib):
         assert rows[s] == rows[s % 4], s
 
 
-FP8_BAR_19_LAYERS = 0.16   # 1.5 x the measured 0.097-0.108 (profiles/r03b_pytest_gpu.log); the quantisation itself is 0.21-0.28 there
+FP8_BAR_19_LAYERS = 0.13   # 1.2 x the largest distance measured on MI355X (0.097-0.108: profiles/r03b_pytest_gpu.log ... r05o); the quantisation itself is 0.21-0.28 there.  What the bar sees of a wrong scale: tests/test_gpu_config4.py

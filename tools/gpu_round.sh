@@ -28,6 +28,16 @@ for leg in $LEGS; do
              done
              python tools/pmc_summary.py $OUT/pmc_$ctr > $OUT/pmc_${ctr}_summary.txt 2>&1; head -14 $OUT/pmc_${ctr}_summary.txt; find $OUT/pmc_$ctr -name '*.csv' -size +8M -delete
            done;;
+    pmcgang) # HBM traffic counters over GANG steps -- four 256-slot engines on one arena, step graphs off, the chains' launches enqueued
+           # alternately on their lanes as in the timed region (one pass per counter; --kernel-trace only, as the pool rules require).  Whether the chains'
+           # kernels really overlapped under the profiler is read from the kernel trace of the same pass (tools/pmc_gang_summary.py).
+           for ctr in FETCH_SIZE WRITE_SIZE; do export NTTS_BENCH_PRIME=0
+             for attempt in 1 2 3; do
+               rm -rf $OUT/pmcg_$ctr; NTTS_NO_GRAPH=1 timeout 150 rocprofv3 --kernel-trace --pmc $ctr -f csv -d $OUT/pmcg_$ctr -o pmc -- python bench.py --steps 4 --warmup 0 --no-cpu-baseline --no-roofline --no-codec --prefill ${PMC_PREFILL:-621} --decode ${PMC_DECODE:-8} --batch 256 > $OUT/pmcg_bench.json 2> $OUT/pmcg_$ctr.err; rc=$?; echo "pmcgang $ctr attempt $attempt rc=$rc"
+               [ $rc -eq 0 ] && break
+             done
+             python tools/pmc_gang_summary.py $OUT/pmcg_$ctr $ctr > $OUT/pmcg_${ctr}_summary.txt 2>&1; head -30 $OUT/pmcg_${ctr}_summary.txt; find $OUT/pmcg_$ctr -name '*.csv' -size +8M -delete
+           done;;
     mfma)  # matrix-core utilisation per kernel (north_star: "MFMA utilisation against gfx950 peak"): SQ busy cycles / GRBM cycles / MFMA op counts
            # in ONE counter pass (8 SQ slots, 2 GRBM), graph replay off, one engine, 8 decode steps (longer profiled passes hang since round 3)
            for attempt in 1 2 3; do
