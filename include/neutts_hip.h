@@ -62,7 +62,9 @@ typedef struct ntts_backbone_config {
     int32_t num_layers;         /* 24 */
     int32_t num_heads;          /* 14 */
     int32_t num_kv_heads;       /* 2  (num_heads / num_kv_heads must be <= 16) */
-    int32_t head_dim;           /* 64 (only 64 is implemented) */
+    int32_t head_dim;           /* 64 (NeuTTS-Air: the fused / tiered attention kernels) or 128 (ABI 9: the general attention path -- plain QKV GEMM +
+                                 * a norm / RoPE / KV-append pass, head_dim-templated two-sweep prompt attention and decode attention; bf16 only;
+                                 * the small-batch GEMV step, context-split attention and the resident / deep prompt tiers are off) */
     float rms_eps;              /* 1e-6 */
     int32_t max_context;        /* ref:neutts/neutts.py:85  (2048) */
     int32_t max_batch;          /* number of decode slots (rows of the decode step) */
@@ -72,7 +74,8 @@ typedef struct ntts_backbone_config {
      * (ref:neutts/neutts.py:164: NeuTTS-Air = Qwen2; NeuTTS-Nano ships under the same class surface). */
     int32_t tie_word_embeddings; /* 1: lm_head = embedding (Qwen2.5-0.5B / NeuTTS-Air); 0: a separate "lm_head.weight" must be loaded */
     int32_t attention_bias;      /* 1: q/k/v_proj carry a bias (Qwen2); 0: none (Llama-style) */
-    int32_t qk_norm;             /* must be 0 (Qwen3-style per-head q/k RMSNorm is not implemented: create fails) */
+    int32_t qk_norm;             /* ABI 9: 1 = Qwen3-style per-head RMSNorm of q and k (over head_dim, weights "self_attn.q_norm.weight" / "k_norm.weight",
+                                  * before RoPE: hf:models/qwen3/modeling_qwen3.py Qwen3Attention.forward); takes the general attention path like head_dim 128 */
     int32_t weight_dtype;        /* NTTS_W_BF16 | NTTS_W_FP8_E4M3: fp8 weights with per-output-channel scales, fp8 GEMM inputs with
                                     static per-tensor scales ("*.input_scale" tensors), bf16 residual stream / KV / attention */
 } ntts_backbone_config;

@@ -32,6 +32,7 @@ static std::string g_create_err;
 
 struct LayerW {
     bf16_t *ln1, *wqkv, *bqkv, *wo, *ln2, *wgu, *wd;
+    bf16_t *qn = nullptr, *kn = nullptr;   // qk_norm models (Qwen3-style): self_attn.q_norm / k_norm weights [head_dim]
     // fp8 model (NTTS_W_FP8_E4M3): the four matrices hold e4m3 bytes; per-output-channel weight scales (device fp32, in the
     // arena) and the static input scales of the four GEMMs (device copy in the arena for the broadcast, host copy for launches)
     float *sqkv = nullptr, *so = nullptr, *sgu = nullptr, *sd = nullptr, *xs_dev = nullptr;
@@ -67,6 +68,13 @@ struct ntts_backbone {
     hipStream_t own_stream = nullptr;
     std::string err;
     int H = 0, F = 0, NQKV = 0, max_pages = 0;
+    // Attention geometry (round 6): head_dim 64 (NeuTTS-Air; the fused / tiered kernels) or 128, optional per-head q / k RMSNorm -- what the
+    // reference's AutoModelForCausalLM dispatch (ref:neutts/neutts.py:164) may hand over for another backbone (Qwen3-style).  `generic` = any of the
+    // two differs from NeuTTS-Air: the QKV projection is then a plain GEMM followed by rope_norm_kv_write_kernel (attn_prefill.h), attention runs
+    // on the head_dim-templated two-sweep / decode kernels, and the small-batch GEMV step, the context-split attention, the resident / deep prompt
+    // tiers and fp8 are off (correct first; none of it is on the benchmark's path).
+    int HD = 64;
+    bool qk_norm = false, generic = false;
 
     // weights
     bf16_t* arena = nullptr;
@@ -285,16 +293,17 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess || strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(nullptr, NTTS_ENODEV, "device %d is '%s', kernels are built for gfx950 only", device, prop.gcnArchName);
-    if (c->head_dim != 64) return fail(nullptr, NTTS_EINVAL, "head_dim %d unsupported (64 only)", c->head_dim);
+    if (c->head_dim != 64 && c->head_dim != 128) return fail(nullptr, NTTS_EINVAL, "head_dim %d unsupported (64 or 128)", c->head_dim);
     if (c->num_heads % c->num_kv_heads || c->num_heads / c->num_kv_heads > kGroupMax)
         return fail(nullptr, NTTS_EINVAL, "GQA group %d/%d unsupported (<= %d)", c->num_heads, c->num_kv_heads, kGroupMax);
     if (c->hidden_size % 64 || c->intermediate_size % 64 || c->hidden_size > 2048)
         return fail(nullptr, NTTS_EINVAL, "hidden/intermediate size must be multiples of 64 (hidden <= 2048)");
     if (c->max_context > kAttnLMax || c->max_context % kPage) return fail(nullptr, NTTS_EINVAL, "max_context must be <= %d and a multiple of %d", kAttnLMax, kPage);
     if (c->max_batch < 1 || c->vocab_size < 2) return fail(nullptr, NTTS_EINVAL, "bad max_batch / vocab_size");
-    if (c->qk_norm) return fail(nullptr, NTTS_EINVAL, "qk_norm (Qwen3-style per-head q/k RMSNorm) is not implemented");
+    if ((c->qk_norm || c->head_dim != 64) && c->weight_dtype != NTTS_W_BF16)
+        return fail(nullptr, NTTS_EINVAL, "qk_norm / head_dim %d are bf16-only (the fp8 model variant covers the head_dim 64, no-qk-norm family)", c->head_dim);
     if (c->weight_dtype != NTTS_W_BF16 && c->weight_dtype != NTTS_W_FP8_E4M3) return fail(nullptr, NTTS_EINVAL, "unknown weight_dtype %d", c->weight_dtype);
-    if (c->weight_dtype == NTTS_W_FP8_E4M3 && (c->hidden_size % 128 || c->intermediate_size % 128 || (c->num_heads * 64) % 128))
+    if (c->weight_dtype == NTTS_W_FP8_E4M3 && (c->hidden_size % 128 || c->intermediate_size % 128 || (c->num_heads * c->head_dim) % 128))
         return fail(nullptr, NTTS_EINVAL, "fp8 weights need hidden / intermediate / q width to be multiples of 128 (one 128-byte K tile)");
 
     ntts_backbone* e = new ntts_backbone();
@@ -302,7 +311,10 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->device = device;
     e->H = c->hidden_size;
     e->F = c->intermediate_size;
-    e->NQKV = (c->num_heads + 2 * c->num_kv_heads) * 64;
+    e->HD = c->head_dim;
+    e->qk_norm = c->qk_norm != 0;
+    e->generic = e->qk_norm || e->HD != 64;
+    e->NQKV = (c->num_heads + 2 * c->num_kv_heads) * e->HD;
     e->max_pages = c->max_context / kPage;
     e->Tmax = c->max_prefill_tokens > 0 ? c->max_prefill_tokens : 16384;
     e->num_pages = c->num_pages > 0 ? c->num_pages : c->max_batch * e->max_pages;
@@ -339,15 +351,16 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     auto take_f = [&](size_t n) { return take(2 * n); };
     const size_t o_embed_tm = take_w((size_t)((V + 63) / 64) * 64 * H);   // the head's own copy (layout / values / precision differ)
     const size_t o_shead = e->fp8 ? take_f((size_t)((V + 63) / 64) * 64) : 0, o_xs_head = e->fp8 ? take_f(4) : 0;
-    struct LO { size_t ln1, wqkv, bqkv, wo, ln2, wgu, wd, sqkv, so, sgu, sd, xs; };
+    struct LO { size_t ln1, wqkv, bqkv, wo, ln2, wgu, wd, sqkv, so, sgu, sd, xs, qn, kn; };
     std::vector<LO> lo(L);
     for (int i = 0; i < L; ++i) {
         lo[i].ln1 = take(H); lo[i].wqkv = take_w((size_t)e->NQKV * H); lo[i].bqkv = take(e->NQKV);
-        lo[i].wo = take_w((size_t)H * c->num_heads * 64); lo[i].ln2 = take(H);
+        lo[i].wo = take_w((size_t)H * c->num_heads * e->HD); lo[i].ln2 = take(H);
+        if (e->qk_norm) { lo[i].qn = take(e->HD); lo[i].kn = take(e->HD); }
         lo[i].wgu = take_w((size_t)2 * F * H); lo[i].wd = take_w((size_t)H * F);
         if (e->fp8) { lo[i].sqkv = take_f(e->NQKV); lo[i].so = take_f(H); lo[i].sgu = take_f(2 * (size_t)F); lo[i].sd = take_f(H); lo[i].xs = take_f(4); }
     }
-    const size_t o_fn = take(H), o_cos = take((size_t)c->max_context * 32), o_sin = take((size_t)c->max_context * 32);
+    const size_t o_fn = take(H), o_cos = take((size_t)c->max_context * (e->HD / 2)), o_sin = take((size_t)c->max_context * (e->HD / 2));
     e->arena_elems = off;
     CR_HIP(hipMalloc((void**)&e->arena, off * sizeof(bf16_t)));
     CR_HIP(hipMemset(e->arena, 0, off * sizeof(bf16_t)));
@@ -360,6 +373,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
         LayerW& w = e->layers[i];
         w.ln1 = e->arena + lo[i].ln1; w.wqkv = e->arena + lo[i].wqkv; w.bqkv = e->arena + lo[i].bqkv; w.wo = e->arena + lo[i].wo;
         w.ln2 = e->arena + lo[i].ln2; w.wgu = e->arena + lo[i].wgu; w.wd = e->arena + lo[i].wd;
+        if (e->qk_norm) { w.qn = e->arena + lo[i].qn; w.kn = e->arena + lo[i].kn; }
         if (e->fp8) {
             w.sqkv = (float*)(e->arena + lo[i].sqkv); w.so = (float*)(e->arena + lo[i].so); w.sgu = (float*)(e->arena + lo[i].sgu);
             w.sd = (float*)(e->arena + lo[i].sd); w.xs_dev = (float*)(e->arena + lo[i].xs);
@@ -376,6 +390,8 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
             e->needed.insert(pre + t);
         if (e->has_bias)
             for (const char* t : {"self_attn.q_proj.bias", "self_attn.k_proj.bias", "self_attn.v_proj.bias"}) e->needed.insert(pre + t);
+        if (e->qk_norm)
+            for (const char* t : {"self_attn.q_norm.weight", "self_attn.k_norm.weight"}) e->needed.insert(pre + t);
         if (e->fp8)
             for (const char* t : {"self_attn.q_proj.input_scale", "self_attn.o_proj.input_scale", "mlp.gate_proj.input_scale", "mlp.down_proj.input_scale"})
                 e->needed.insert(pre + t);
@@ -399,7 +415,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     }
 
     // ---- KV pool: per layer [K pages | V^T pages], page-head = 32 tokens x 64 d
-    e->kv_half = (size_t)e->num_pages * c->num_kv_heads * kPage * 64;
+    e->kv_half = (size_t)e->num_pages * c->num_kv_heads * kPage * e->HD;
     e->layer_stride = 2 * e->kv_half;
     CR_HIP(hipMalloc((void**)&e->kv, (size_t)L * e->layer_stride * sizeof(bf16_t)));
     CR_HIP(hipMemset(e->kv, 0, (size_t)L * e->layer_stride * sizeof(bf16_t)));
@@ -434,9 +450,9 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     };
     const int ktile = e->fp8 ? 128 : 64;   // K extent of one 128-byte tile
     const int max_slabs = 16;
-    e->ks_o = std::min(max_slabs, pick_split(H / 64, c->num_heads * 64 / ktile));
+    e->ks_o = std::min(max_slabs, pick_split(H / 64, c->num_heads * e->HD / ktile));
     e->ks_d = std::min(max_slabs, pick_split(H / 64, F / ktile));
-    if (int k = env_int("NTTS_KS_O", 0); k > 0) e->ks_o = std::min(std::min(max_slabs, k), c->num_heads * 64 / ktile);
+    if (int k = env_int("NTTS_KS_O", 0); k > 0) e->ks_o = std::min(std::min(max_slabs, k), c->num_heads * e->HD / ktile);
     if (int k = env_int("NTTS_KS_D", 0); k > 0) e->ks_d = std::min(std::min(max_slabs, k), F / ktile);
     e->tall_env = env_int("NTTS_TALL", -1);
     e->wide = env_int("NTTS_WIDE", B >= 512 && !e->fp8 ? 1 : 0) != 0;
@@ -454,6 +470,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
         int dcap = env_int("NTTS_PF_DEEP_CAP", kPfDeepPages * kPage) / kPage * kPage;
         dcap = dcap > kPfDeepPages * kPage ? kPfDeepPages * kPage : dcap;
         e->pf_deep_cap = dcap < e->pf_res_cap ? e->pf_res_cap : dcap;
+        if (e->generic) e->pf_res_cap = e->pf_deep_cap = 0;     // every query on the (head_dim-templated) two-sweep kernel
     }
     e->xcd_xps = (B == 64 || B == 128 || B == 256 || B == 512) ? 8 / (B / 64) : 0;
     e->affine_env = env_int("NTTS_XCD_AFFINE", -1);
@@ -464,19 +481,19 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->gu_128 = B > 128;
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
-    e->small = B <= env_int("NTTS_SMALL_BATCH", 8) && B <= kGemvRows && H <= 1024 && V % 16 == 0 && e->NQKV % 16 == 0 && F % 32 == 0;   // (bf16 and fp8 models alike: gemv.h / qkv_rope.h F8 instantiations)
+    e->small = !e->generic && B <= env_int("NTTS_SMALL_BATCH", 8) && B <= kGemvRows && H <= 1024 && V % 16 == 0 && e->NQKV % 16 == 0 && F % 32 == 0;   // (bf16 and fp8 models alike: gemv.h / qkv_rope.h F8 instantiations)
     static_assert(ntts_backbone::kSksO <= 16 && ntts_backbone::kSksD <= 16, "slab counts");
     {
         CR_HIP(hipMalloc((void**)&e->step_meta, (size_t)B * 4 * sizeof(int)));
         CR_HIP(hipMemset(e->step_meta, 0, (size_t)B * 4 * sizeof(int)));
-        CR_HIP(hipMalloc((void**)&e->rope_rows, (size_t)B * 64 * 2));
-        CR_HIP(hipMemset(e->rope_rows, 0, (size_t)B * 64 * 2));
+        CR_HIP(hipMalloc((void**)&e->rope_rows, (size_t)B * e->HD * 2));
+        CR_HIP(hipMemset(e->rope_rows, 0, (size_t)B * e->HD * 2));
     }
     e->n_part = e->n_part_full = n_part_for(e, V);
     CR_HIP(hipMalloc((void**)&e->h_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->xn_dec, (size_t)B * H * 2));
     CR_HIP(hipMalloc((void**)&e->qkv_dec, (size_t)B * e->NQKV * 2));
-    CR_HIP(hipMalloc((void**)&e->attn_dec, (size_t)B * c->num_heads * 64 * 2));
+    CR_HIP(hipMalloc((void**)&e->attn_dec, (size_t)B * c->num_heads * e->HD * 2));
     CR_HIP(hipMalloc((void**)&e->act_dec, (size_t)B * F * 2));
     CR_HIP(hipMalloc((void**)&e->slabs, (size_t)max_slabs * B * H * 4));
     if (e->small) {
@@ -487,7 +504,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
         e->attn_split = env_int("NTTS_ATTN_SPLIT", 0);
         e->attn_split_ctx = env_int("NTTS_ATTN_SPLIT_CTX", 896);
         if (e->attn_split < 2 || e->attn_split > 32) e->attn_split = 0;
-        if (e->fp8 || (!e->small && B * c->num_kv_heads >= 512)) e->attn_split = 0;   // (fp8: the combine pass writes bf16 rows / fp32 chunk slabs)
+        if (e->fp8 || e->generic || (!e->small && B * c->num_kv_heads >= 512)) e->attn_split = 0;   // (fp8: the combine pass writes bf16 rows / fp32 chunk slabs)
         if (e->attn_split) {
             const size_t n_sc = (size_t)B * c->num_kv_heads * kGroupMax * (c->max_context + 16), n_st = (size_t)B * c->num_kv_heads * e->attn_split * kGroupMax * 2,
                          n_os = (size_t)e->attn_split * B * c->num_heads * 64;
@@ -504,14 +521,14 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     CR_HIP(hipMemset(e->h_dec, 0, (size_t)B * H * 2));
     CR_HIP(hipMemset(e->xn_dec, 0, (size_t)B * H * 2));
     CR_HIP(hipMemset(e->qkv_dec, 0, (size_t)B * e->NQKV * 2));
-    CR_HIP(hipMemset(e->attn_dec, 0, (size_t)B * c->num_heads * 64 * 2));
+    CR_HIP(hipMemset(e->attn_dec, 0, (size_t)B * c->num_heads * e->HD * 2));
 
     // ---- prefill workspaces
     const size_t T = e->Tmax;
     CR_HIP(hipMalloc((void**)&e->h_pf, T * H * 2));
     CR_HIP(hipMalloc((void**)&e->xn_pf, T * H * 2));
     CR_HIP(hipMalloc((void**)&e->qkv_pf, T * e->NQKV * 2));
-    CR_HIP(hipMalloc((void**)&e->attn_pf, T * c->num_heads * 64 * 2));
+    CR_HIP(hipMalloc((void**)&e->attn_pf, T * c->num_heads * e->HD * 2));
     CR_HIP(hipMalloc((void**)&e->o_pf, T * H * 2));
     CR_HIP(hipMalloc((void**)&e->act_pf, T * F * 2));
     e->meta_cap = 2 * T + (size_t)B * (16 + e->max_pages) + (T / 64 + 3 * B) * 2 + 6 * (size_t)B + 3 * (size_t)B * e->max_pages + 64;
@@ -618,16 +635,17 @@ extern "C" int ntts_backbone_load_tensor(ntts_backbone* e, const char* name, con
     if (e->finalized) return fail(e, NTTS_ESTATE, "weights already finalised");
     HIPCHK(e, hipSetDevice(e->device));
     const ntts_backbone_config& c = e->cfg;
-    const long H = e->H, F = e->F, QD = c.num_heads * 64, KD = c.num_kv_heads * 64;
+    const long H = e->H, F = e->F, QD = c.num_heads * e->HD, KD = c.num_kv_heads * e->HD;
     std::string n(name);
     auto want = [&](long r, long cc) -> bool {
         return (cc == 0 && ndim == 1 && shape[0] == r) || (cc != 0 && ndim == 2 && shape[0] == r && shape[1] == cc);
     };
     auto bad_shape = [&]() { return fail(e, NTTS_EINVAL, "tensor '%s': unexpected shape", name); };
     if (n == "rope.inv_freq") {
-        if (dtype != NTTS_DT_F32 || !want(32, 0)) return fail(e, NTTS_EINVAL, "rope.inv_freq must be fp32 [32]");
-        if (is_device) HIPCHK(e, hipMemcpy(e->inv_freq, data, 32 * 4, hipMemcpyDeviceToHost));
-        else memcpy(e->inv_freq, data, 32 * 4);
+        const int nf = e->HD / 2;
+        if (dtype != NTTS_DT_F32 || !want(nf, 0)) return fail(e, NTTS_EINVAL, "rope.inv_freq must be fp32 [%d] (head_dim / 2)", nf);
+        if (is_device) HIPCHK(e, hipMemcpy(e->inv_freq, data, nf * 4, hipMemcpyDeviceToHost));
+        else memcpy(e->inv_freq, data, nf * 4);
         e->have_inv_freq = true;
         e->loaded.insert(n);
         return NTTS_OK;
@@ -818,6 +836,11 @@ extern "C" int ntts_backbone_load_tensor(ntts_backbone* e, const char* name, con
             if (!want(rows_n, 0)) return bad_shape();
             rc = put_rows(e, data, dtype, is_device, 1, rows_n, w.bqkv + at, nullptr);
         }
+        else if (t == "self_attn.q_norm.weight" || t == "self_attn.k_norm.weight") {
+            if (!e->qk_norm) return fail(e, NTTS_EINVAL, "tensor '%s': the engine was created with qk_norm = 0", name);
+            if (!want(e->HD, 0)) return bad_shape();
+            rc = put_rows(e, data, dtype, is_device, 1, e->HD, t[10] == 'q' ? w.qn : w.kn, nullptr);
+        }
         else if (t == "self_attn.o_proj.weight") { if (!want(H, QD)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, H, QD, w.wo, 0, nullptr, tm, w.so); }
         else if (t == "mlp.gate_proj.weight") { if (!want(F, H)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, F, H, w.wgu, 0, e->gu_map_gate, tm, w.sgu); }
         else if (t == "mlp.up_proj.weight") { if (!want(F, H)) return bad_shape(); rc = put_weight(e, data, dtype, is_device, F, H, w.wgu, 0, e->gu_map_up, tm, w.sgu); }
@@ -833,8 +856,8 @@ extern "C" int ntts_backbone_load_tensor(ntts_backbone* e, const char* name, con
 static int build_rope(ntts_backbone* e) {
     // Qwen2RotaryEmbedding.forward hf:models/qwen2/modeling_qwen2.py:91-102: angle = fp32(pos * inv_freq),
     // cos/sin in fp32, cast to bf16.  cos/sin are evaluated in double and rounded once to fp32.
-    const int n = e->cfg.max_context;
-    std::vector<bf16_t> c((size_t)n * 32), s((size_t)n * 32);
+    const int n = e->cfg.max_context, nf = e->HD / 2;
+    std::vector<bf16_t> c((size_t)n * nf), s((size_t)n * nf);
     auto tobf = [](float f) {
         uint32_t u;
         memcpy(&u, &f, 4);
@@ -842,10 +865,10 @@ static int build_rope(ntts_backbone* e) {
         return (bf16_t)(u >> 16);
     };
     for (int p = 0; p < n; ++p)
-        for (int i = 0; i < 32; ++i) {
+        for (int i = 0; i < nf; ++i) {
             const float ang = (float)p * e->inv_freq[i];
-            c[(size_t)p * 32 + i] = tobf((float)cos((double)ang));
-            s[(size_t)p * 32 + i] = tobf((float)sin((double)ang));
+            c[(size_t)p * nf + i] = tobf((float)cos((double)ang));
+            s[(size_t)p * nf + i] = tobf((float)sin((double)ang));
         }
     HIPCHK(e, hipMemcpy(e->rope_cos, c.data(), c.size() * 2, hipMemcpyHostToDevice));
     HIPCHK(e, hipMemcpy(e->rope_sin, s.data(), s.size() * 2, hipMemcpyHostToDevice));
@@ -936,7 +959,7 @@ extern "C" int ntts_backbone_share_arena(ntts_backbone* e, ntts_backbone* donor)
     const ntts_backbone_config &a = e->cfg, &b = donor->cfg;
     if (e->device != donor->device || e->arena_elems != donor->arena_elems || a.vocab_size != b.vocab_size || a.hidden_size != b.hidden_size ||
         a.intermediate_size != b.intermediate_size || a.num_layers != b.num_layers || a.num_heads != b.num_heads ||
-        a.num_kv_heads != b.num_kv_heads || a.max_context != b.max_context || e->fp8 != donor->fp8 || e->tied != donor->tied ||
+        a.num_kv_heads != b.num_kv_heads || a.max_context != b.max_context || e->fp8 != donor->fp8 || e->tied != donor->tied || e->HD != donor->HD || e->qk_norm != donor->qk_norm ||
         e->has_bias != donor->has_bias)
         return fail(e, NTTS_EINVAL, "share_arena: the two engines differ in device, geometry, weight type or context length");
     HIPCHK(e, hipSetDevice(e->device));
@@ -946,7 +969,7 @@ extern "C" int ntts_backbone_share_arena(ntts_backbone* e, ntts_backbone* donor)
     auto mv = [&](auto*& ptr) { if (ptr) ptr = (std::remove_reference_t<decltype(ptr)>)((char*)donor->arena + ((char*)ptr - (char*)old)); };
     mv(e->embed); mv(e->embed_tm); mv(e->shead); mv(e->xs_head_dev); mv(e->final_norm); mv(e->rope_cos); mv(e->rope_sin);
     for (LayerW& w : e->layers) {
-        mv(w.ln1); mv(w.wqkv); mv(w.bqkv); mv(w.wo); mv(w.ln2); mv(w.wgu); mv(w.wd);
+        mv(w.ln1); mv(w.wqkv); mv(w.bqkv); mv(w.wo); mv(w.ln2); mv(w.wgu); mv(w.wd); mv(w.qn); mv(w.kn);
         mv(w.sqkv); mv(w.so); mv(w.sgu); mv(w.sd); mv(w.xs_dev);
     }
     if (donor->share->next_idx.load() >= ArenaShare::kMaxEngines) return fail(e, NTTS_EINVAL, "share_arena: at most %d engines on one arena", ArenaShare::kMaxEngines);
@@ -1189,9 +1212,28 @@ static void k_step_meta(ntts_backbone* e) {   // once per decode step, before th
 
 // QKV projection + bias + rounding + RoPE + K append (qkv_rope.h); 3 ring slots, 2 K slices per workgroup (swept: 4 slices / 4 and
 // 6 slots are equal or slower, profiles/r03a_sweep_qkv_fused.log)
+// the rope / qk-norm / KV-append step of the generic attention geometry (attn_prefill.h rope_norm_kv_write_kernel), decode rows
+static void k_rope_norm_decode(ntts_backbone* e, int i) {
+    const ntts_backbone_config& c = e->cfg;
+    RopeNormArgs r{};
+    r.qkv = e->qkv_dec; r.ld_qkv = e->NQKV; r.kpool = e->kv + (size_t)i * e->layer_stride; r.vpool = r.kpool + e->kv_half;
+    r.block_table = e->block_table; r.max_pages = e->max_pages; r.dec_pos = e->sl.pos; r.dec_state = e->sl.state;
+    r.rope_cos = e->rope_cos; r.rope_sin = e->rope_sin; r.q_norm = e->layers[i].qn; r.k_norm = e->layers[i].kn; r.eps = c.rms_eps;
+    r.nh = c.num_heads; r.nkv = c.num_kv_heads; r.rows = c.max_batch; r.write_v = 0;
+    const long items = (long)r.rows * (c.num_heads + 2 * c.num_kv_heads);
+    if (e->HD == 128) NTTS_LAUNCH((rope_norm_kv_write_kernel<128>), dim3((unsigned)((items + 3) / 4)), dim3(256), e->stream, r);
+    else NTTS_LAUNCH((rope_norm_kv_write_kernel<64>), dim3((unsigned)((items + 3) / 4)), dim3(256), e->stream, r);
+}
+
 static void k_qkv(ntts_backbone* e, int i) {
     const int B = e->cfg.max_batch, H = e->H;
     const LayerW& w = e->layers[i];
+    if (e->generic) {     // plain GEMM (bias, one rounding) into the q|k|v row, then norm + RoPE + K append as one small launch
+        GemmArgs g = gemm_args(e, e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H);
+        if (B > 128) gemm_launch<2, 2, 4, EPI_BF16, 2>(g, 1, e->stream); else gemm_skinny<EPI_BF16>(g, 1, e->stream);
+        k_rope_norm_decode(e, i);
+        return;
+    }
     QkvRopeArgs a{};
     a.X = e->xn_dec; a.ldx = H; a.W = w.wqkv; a.bias = w.bqkv; a.wscale = w.sqkv; a.xscale = w.xs[0];
     a.M = B; a.N = e->NQKV; a.K = H; a.meta = e->step_meta; a.rope_rows = e->rope_rows;
@@ -1211,11 +1253,12 @@ static void k_qkv(ntts_backbone* e, int i) {
 static void k_attn(ntts_backbone* e, int i) {
     const ntts_backbone_config& c = e->cfg;
     AttnDecodeArgs a{};
-    a.qkv = e->qkv_dec; a.ld_qkv = e->NQKV; a.out = e->attn_dec; a.ld_out = c.num_heads * 64;
+    a.qkv = e->qkv_dec; a.ld_qkv = e->NQKV; a.out = e->attn_dec; a.ld_out = c.num_heads * e->HD;
     a.kpool = e->kv + (size_t)i * e->layer_stride; a.vpool = a.kpool + e->kv_half;
     a.block_table = e->block_table; a.max_pages = e->max_pages; a.pos = e->sl.pos; a.state = e->sl.state;
     a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
     a.tl = e->attn_tl;
+    if (e->HD == 128) { attn_decode_launch_hd128(a, c.max_batch, e->stream, c.max_context); return; }
     a.xcd_rows = ((e->xcd_affine & 4) && !e->attn_tl) ? e->xcd_xps : 0;
     a.nt_pages = e->wide && !e->attn_tl;
     if (e->fp8) a.out_fp8_inv = 1.0f / e->layers[i].xs[1];   // attention output = o_proj's input
@@ -1230,7 +1273,7 @@ static void k_attn(ntts_backbone* e, int i) {
 }
 
 static void k_o_proj(ntts_backbone* e, int i) {
-    const int B = e->cfg.max_batch, H = e->H, QD = e->cfg.num_heads * 64;
+    const int B = e->cfg.max_batch, H = e->H, QD = e->cfg.num_heads * e->HD;
     GemmArgs a = gemm_args(e, e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->slabs, H, B, H, QD, e->layers[i].so, e->layers[i].xs[1]);
     if (e->wide && e->wide_o == 1) {   // whole K per tile: h = bf16(h + bf16(acc)) in the epilogue (hf:models/qwen2/modeling_qwen2.py:233,291), in place
         a.out = e->h_dec; a.resid_bf16 = e->h_dec; a.ldrb = H;
@@ -1405,7 +1448,7 @@ static void decode_step_small(ntts_backbone* e) {
 static void decode_step(ntts_backbone* e) {
     if (e->small) { decode_step_small(e); return; }
     const ntts_backbone_config& c = e->cfg;
-    const int B = c.max_batch, H = e->H, F = e->F, QD = c.num_heads * 64;
+    const int B = c.max_batch, H = e->H, F = e->F, QD = c.num_heads * e->HD;
     NormArgs n0{};
     n0.gather_ids = e->sl.cur_tok; n0.embed = e->embed; n0.resid_out = e->h_dec; n0.norm_w = e->layers[0].ln1;
     n0.normed_out = e->xn_dec; n0.M = B; n0.H = H; n0.eps = c.rms_eps;
@@ -1473,7 +1516,7 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
     if (!e->finalized) return fail(e, NTTS_ESTATE, "weights not finalised");
     HIPCHK(e, hipSetDevice(e->device));
     const ntts_backbone_config& c = e->cfg;
-    const int B = c.max_batch, H = e->H, F = e->F, QD = c.num_heads * 64;
+    const int B = c.max_batch, H = e->H, F = e->F, QD = c.num_heads * e->HD;
     long T = 0, Tfull = 0;
     std::vector<int> pos0(n, 0), id_off(n, 0);
     for (int i = 0; i < n; ++i) { id_off[i] = (int)Tfull; Tfull += lens[i] > 0 ? lens[i] : 0; }
@@ -1694,12 +1737,22 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
         // the q heads are rotated by the attention kernel as it loads them (one read + one write of T x 896 values less per layer:
         // prompt pass 28.16 -> 27.94 ms per chunk, profiles/r02k_sweep_pf_rope_q_fused.log); this kernel rotates k and scatters v
         r.skip_q = 1;
+        if (e->generic) {   // head_dim 128 and / or qk-norm: q AND k normalised + rotated here (q in place), v scattered (attn_prefill.h)
+            RopeNormArgs g{};
+            g.qkv = e->qkv_pf; g.ld_qkv = e->NQKV; g.kpool = r.kpool; g.vpool = r.vpool; g.block_table = e->block_table; g.max_pages = e->max_pages;
+            g.meta = meta; g.rope_cos = e->rope_cos; g.rope_sin = e->rope_sin; g.q_norm = w.qn; g.k_norm = w.kn; g.eps = c.rms_eps;
+            g.nh = c.num_heads; g.nkv = c.num_kv_heads; g.rows = Ti; g.write_v = 1;
+            const long items = (long)Ti * (c.num_heads + 2 * c.num_kv_heads);
+            if (e->HD == 128) NTTS_LAUNCH((rope_norm_kv_write_kernel<128>), dim3((unsigned)((items + 3) / 4)), dim3(256), st, g);
+            else NTTS_LAUNCH((rope_norm_kv_write_kernel<64>), dim3((unsigned)((items + 3) / 4)), dim3(256), st, g);
+        } else
         NTTS_LAUNCH((rope_kv_write_vec_kernel), dim3((Ti + kRopeTokPerBlock - 1) / kRopeTokPerBlock), dim3(256), st, r);
         AttnPrefillArgs a{};
         a.qkv = e->qkv_pf; a.ld_qkv = e->NQKV; a.out = e->attn_pf; a.ld_out = QD; a.kpool = r.kpool; a.vpool = r.vpool;
         a.block_table = e->block_table; a.max_pages = e->max_pages; a.meta = meta; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
         if (e->fp8) a.out_fp8_inv = 1.0f / w.xs[1];     // attn_pf rows hold QD e4m3 BYTES (ld_out counts bytes then)
         a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin;
+        if (e->generic) a.rope_cos = a.rope_sin = nullptr;   // (q is already normalised and rotated)
         // Last layer: the KV pages are complete after the rope/KV-write above, and nothing but each prompt's LAST position
         // is read afterwards (it alone feeds the lm_head).  Attention runs on the one query tile per prompt that holds
         // it, then that row and its residual row are compacted and o_proj / the MLP run on n rows instead of T.
@@ -1707,7 +1760,7 @@ static int prefill_impl(ntts_backbone* e, int32_t n, const int32_t* ids, const i
         const bool prune = last && T >= 4L * n && !e->calib;    // (calibration mode looks at EVERY position's GEMM inputs, the last layer's included)
         int n_tiles = (int)tile_seq.size(), n_rtiles = (int)rtile_seq.size();
         if (prune) { a.meta.tile_seq = md + o_ltseq; a.meta.tile_q0 = md + o_ltq0; n_tiles = (int)lt_seq.size(); }
-        if (n_tiles) attn_prefill_launch(a, n_tiles, st);
+        if (n_tiles) { if (e->HD == 128) attn_prefill_launch_hd128(a, n_tiles, st); else attn_prefill_launch(a, n_tiles, st); }
         a.meta.tile_seq = md + o_rtseq; a.meta.tile_q0 = md + o_rtq0;
         if (prune) { a.meta.tile_seq = md + o_lrtseq; a.meta.tile_q0 = md + o_lrtq0; n_rtiles = (int)lrt_seq.size(); }
         if (n_rtiles) attn_prefill_res_launch(a, n_rtiles, e->pf_res_cap, prune, st);
@@ -2213,7 +2266,7 @@ extern "C" int ntts_backbone_step_bytes(ntts_backbone* e, double* bytes) {
     HIPCHK(e, hipStreamSynchronize(e->stream));
     HIPCHK(e, hipMemcpy(st.data(), e->sl.state, B * sizeof(int), hipMemcpyDeviceToHost));
     HIPCHK(e, hipMemcpy(pos.data(), e->sl.pos, B * sizeof(int), hipMemcpyDeviceToHost));
-    const double H = e->H, F = e->F, QD = c.num_heads * 64, KD = c.num_kv_heads * 64;
+    const double H = e->H, F = e->F, QD = c.num_heads * e->HD, KD = c.num_kv_heads * e->HD;
     const double wb = e->fp8 ? 1.0 : 2.0;      // bytes per matrix weight (+ 4 per output channel for the fp8 scales)
     const double mats = (QD + 2 * KD) * H + H * QD + 3 * F * H, small = (QD + 2 * KD) + 2 * H;
     const double sc = e->fp8 ? ((QD + 2 * KD) + 2 * H + 2 * F) * 4.0 : 0.0;
@@ -2296,7 +2349,7 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
     if (!e->finalized) return fail(e, NTTS_ESTATE, "weights not finalised");
     HIPCHK(e, hipSetDevice(e->device));
     const ntts_backbone_config& c = e->cfg;
-    const int B = c.max_batch, H = e->H, F = e->F, QD = c.num_heads * 64, KD = c.num_kv_heads * 64, L = c.num_layers;
+    const int B = c.max_batch, H = e->H, F = e->F, QD = c.num_heads * e->HD, KD = c.num_kv_heads * e->HD, L = c.num_layers;
     hipStream_t st = e->stream;
     HIPCHK(e, hipStreamSynchronize(st));
     std::vector<int> sst(B), pos(B);

@@ -79,17 +79,24 @@ NTTS_D void rope_pair(float x1, float x2, float c, float s, float& o1, float& o2
 //   dimensions -- V^T rows 16 z .. 16 z + 15, a quarter of the V^T bytes, one PV tile per page instead of four.  At batch 1 a (sequence, kv-head)
 //   is then four workgroups of 100 KB each instead of one pulling 160 KB through a single CU's load path; P, and with it every output element,
 //   is computed exactly as before (the other three quarters of the K stream are L2 hits).  No cross-workgroup exchange.
-template <int kDepth, bool kTimeline = false, int kVar = 1, int NW = 4, int LMAX = kAttnLMax, int DS = 1>
+// HD = head_dim (round 6: 128 for Qwen3-style checkpoints, ref:neutts/neutts.py:164 dispatches through AutoModelForCausalLM): a K page row is HD values
+//   (HD / 32 matrix-core k-steps per 16-key sub-tile), the V^T page has HD rows (HD / 16 PV tiles), scores = bf16(bf16(q . k) * HD^-0.5) -- for 64
+//   the factor 2^-3 is exact and the second rounding a no-op; for 128 it is not (hf:models/qwen3/modeling_qwen3.py eager_attention_forward:
+//   `torch.matmul(query, key.transpose(2, 3)) * scaling` rounds the product to bf16).  The HD = 64 instantiations are what they were, bit for bit.
+NTTS_HD float attn_scale(int hd) { return hd == 64 ? 0.125f : hd == 128 ? 0.088388346f /* (float)(128 ** -0.5), torch's opmath scalar */ : 0.f; }
+template <int kDepth, bool kTimeline = false, int kVar = 1, int NW = 4, int LMAX = kAttnLMax, int DS = 1, int HD = 64>
 NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
     static_assert(DS == 1 || DS == 2 || DS == 4, "output-dimension split");
+    static_assert(HD == 64 || HD == 128, "head_dim");
     constexpr int NT = NW * 64;
-    constexpr int NTL = 4 / DS;                         // PV tiles (16 output dimensions each) this workgroup computes
+    constexpr int KS = HD / 32;                         // matrix-core k-steps per key (32 of the HD values each)
+    constexpr int NTL = (HD / 16) / DS;                 // PV tiles (16 output dimensions each) this workgroup computes
     const int nt0 = DS == 1 ? 0 : (int)blockIdx.z * NTL;   // ... starting at tile nt0
     NTTS_SHARED bf16_t sc[kGroupMax][LMAX + 16];        // rounded scores, 33 KB at 2048; +32 B/row de-aliases the LDS banks
-    NTTS_SHARED bf16_t vnew[64];
+    NTTS_SHARED bf16_t vnew[HD];
     NTTS_SHARED float wred[NW][kGroupMax];
     NTTS_SHARED float wsum[NW][kGroupMax];
-    NTTS_SHARED float ored[NW][kGroupMax][64];
+    NTTS_SHARED float ored[NW][kGroupMax][HD];
 
     const int b = p.xcd_rows ? xcd_row((int)blockIdx.x, p.xcd_rows) : (int)blockIdx.x;
     const int kvh = blockIdx.y;
@@ -111,45 +118,49 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
     for (int j = 0; j < kDepth; ++j) bt0[j] = bt[w + NW * j < p.max_pages ? w + NW * j : 0];
     const int st = p.state[b];
     const int P = p.pos[b];
-    auto load_k_at = [&](long page, bf16x8 (&k)[2][2]) {
-        const bf16_t* kp = p.kpool + (page * p.nkv + kvh) * kPage * 64;
+    // K fragments of a page: key row u * 16 + l15, k-step f = d values f * 32 + g * 8 .. + 7 (HD = 64: the two steps are the lane's 16 consecutive
+    // values g * 16 .. + 15 split in halves -- the same pairing of A and B operand slots, the same bits)
+    auto load_k_at = [&](long page, bf16x8 (&k)[2][KS]) {
+        const bf16_t* kp = p.kpool + (page * p.nkv + kvh) * kPage * HD;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const bf16_t* kr = kp + (u * 16 + l15) * 64 + g * 16;
-            if constexpr (kVar & 2) { k[u][0] = ld16_nt<bf16x8>(kr); k[u][1] = ld16_nt<bf16x8>(kr + 8); }
-            else { k[u][0] = ld16<bf16x8>(kr); k[u][1] = ld16<bf16x8>(kr + 8); }
+#pragma unroll
+            for (int f = 0; f < KS; ++f) {
+                const bf16_t* kr = kp + (u * 16 + l15) * HD + (HD == 64 ? g * 16 + f * 8 : f * 32 + g * 8);
+                if constexpr (kVar & 2) k[u][f] = ld16_nt<bf16x8>(kr); else k[u][f] = ld16<bf16x8>(kr);
+            }
         }
     };
     auto load_v_at = [&](long page, bf16x8 (&v)[NTL]) {
-        const bf16_t* vp = p.vpool + (page * p.nkv + kvh) * 64 * kPage;
+        const bf16_t* vp = p.vpool + (page * p.nkv + kvh) * HD * kPage;
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) {
             if constexpr (kVar & 2) v[nt] = ld16_nt<bf16x8>(vp + ((nt0 + nt) * 16 + l15) * kPage + g * 8);   // K/V pages: read once per step
             else v[nt] = ld16<bf16x8>(vp + ((nt0 + nt) * 16 + l15) * kPage + g * 8);
         }
     };
-    auto load_k = [&](int pg, bf16x8 (&k)[2][2]) { load_k_at(bt[pg], k); };
+    auto load_k = [&](int pg, bf16x8 (&k)[2][KS]) { load_k_at(bt[pg], k); };
     auto load_v = [&](int pg, bf16x8 (&v)[NTL]) { load_v_at(bt[pg], v); };
-    bf16x8 kq[kDepth][2][2];   // register rings of kDepth pages per wave
+    bf16x8 kq[kDepth][2][KS];  // register rings of kDepth pages per wave
     bf16x8 vq[kDepth][NTL];
-    bf16x8 qB[2];
-    bf16_t vrow_new = 0;       // element tid of this step's v row / the page of position P (threads 0..63)
+    bf16x8 qB[KS];
+    bf16_t vrow_new = 0;       // element tid of this step's v row / the page of position P (threads 0..HD-1)
     long vpage_new = 0;
     const int L = P + 1;
     const int npages = (L + kPage - 1) / kPage;
     const int last_page = npages - 1;
     {
-        const bf16_t* qrow = p.qkv + (long)b * p.ld_qkv + (long)(kvh * group + (l15 < group ? l15 : 0)) * 64 + g * 16;
-        qB[0] = ld16<bf16x8>(qrow);
-        qB[1] = ld16<bf16x8>(qrow + 8);
+        const bf16_t* qrow = p.qkv + (long)b * p.ld_qkv + (long)(kvh * group + (l15 < group ? l15 : 0)) * HD;
+#pragma unroll
+        for (int f = 0; f < KS; ++f) qB[f] = ld16<bf16x8>(qrow + (HD == 64 ? g * 16 + f * 8 : f * 32 + g * 8));
     }
     // this step's v row (bf16, from the fused QKV kernel) and the page it belongs in: requested BEFORE the K pages (a wave's loads
     // return in order), used only after pass 1 -- a wave that had to wait for them first would issue its next K page a whole memory
     // latency late and hold the other three up at the merge barrier (measured: +1 us per launch)
-    if (tid < 64) vrow_new = p.qkv[(long)b * p.ld_qkv + (long)(p.nh + p.nkv + kvh) * 64 + tid];
+    if (tid < HD) vrow_new = p.qkv[(long)b * p.ld_qkv + (long)(p.nh + p.nkv + kvh) * HD + tid];
     if (st != 1) return;  // block-uniform
     mark(1);
-    if (tid < 64) vpage_new = bt[P / kPage];
+    if (tid < HD) vpage_new = bt[P / kPage];
 #pragma unroll
     for (int j = 0; j < kDepth; ++j) load_k_at(bt0[j], kq[j]);
     if constexpr (kVar & 4) {
@@ -158,7 +169,9 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
     }
     if (l15 >= group) {   // heads beyond the GQA group: zero columns of Q^T
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { qB[0][e] = 0; qB[1][e] = 0; }
+        for (int f = 0; f < KS; ++f)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qB[f][e] = 0;
     }
     mark(2);
     // ---- pass 1: S^T = K Q^T per 16-key sub-tile, bf16-rounded scores -> LDS, with the softmax statistics carried
@@ -171,21 +184,24 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
         for (int j = 0; j < kDepth; ++j) {
             const int pg = pg0 + NW * j;
             if (pg < npages) {
-                bf16x8 kc[2][2];
+                bf16x8 kc[2][KS];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) { kc[u][0] = kq[j][u][0]; kc[u][1] = kq[j][u][1]; }
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int f = 0; f < KS; ++f) kc[u][f] = kq[j][u][f];
                 if (pg + NW * kDepth < npages) load_k(pg + NW * kDepth, kq[j]);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     f32x4 a = {0.f, 0.f, 0.f, 0.f};
-                    a = mfma16(kc[u][0], qB[0], a);
-                    a = mfma16(kc[u][1], qB[1], a);
+#pragma unroll
+                    for (int f = 0; f < KS; ++f) a = mfma16(kc[u][f], qB[f], a);
                     const int key0 = pg * kPage + u * 16 + g * 4;
                     bf16x4 sv;
                     float s4[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float s = rbf(a[r]) * 0.125f;        // matmul out (bf16) * scaling (bf16): the x 2^-3 is exact
+                        float s = rbf(a[r]) * attn_scale(HD);   // matmul out (bf16) * scaling (bf16): the x 2^-3 of HD = 64 is exact,
+                        if constexpr (HD != 64) s = rbf(s);     // the x 128^-0.5 rounds
                         if (key0 + r >= L) s = kMasked;
                         s4[r] = s;
                         sv[r] = (short)f2bf(s);
@@ -201,10 +217,10 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
         }
     }
     mark(4);
-    if (tid < 64) {   // v row -> its slot of the transposed page, and LDS (pass 2 reads it there, behind the merge barrier)
+    if (tid < HD) {   // v row -> its slot of the transposed page, and LDS (pass 2 reads it there, behind the merge barrier)
         vnew[tid] = vrow_new;
         if (nt0 == 0)           // (DS = 4: one of the four workgroups appends; the others take the row from their own LDS copy like this one)
-            p.vpool[(vpage_new * p.nkv + kvh) * 64 * kPage + (long)tid * kPage + v_slot(P % kPage)] = vrow_new;
+            p.vpool[(vpage_new * p.nkv + kvh) * HD * kPage + (long)tid * kPage + v_slot(P % kPage)] = vrow_new;
     }
     // ---- V^T pages are independent of the scores: (kVar & 4: already requested next to the K pages) else get the first
     //      ones in flight under the softmax reductions
@@ -292,8 +308,8 @@ NTTS_KERNEL(NW * 64) void attn_decode_kernel(AttnDecodeArgs p) {
         float o = ored[0][hh][d];
 #pragma unroll
         for (int ww = 1; ww < NW; ++ww) o += ored[ww][hh][d];            // ascending wave order
-        if (p.out_fp8_inv > 0.f) ((unsigned char*)p.out)[(long)b * p.ld_out + (kvh * group + hh) * 64 + d] = f2fp8c(rbf(o) * p.out_fp8_inv);
-        else p.out[(long)b * p.ld_out + (kvh * group + hh) * 64 + d] = f2bf(o);
+        if (p.out_fp8_inv > 0.f) ((unsigned char*)p.out)[(long)b * p.ld_out + (kvh * group + hh) * HD + d] = f2fp8c(rbf(o) * p.out_fp8_inv);
+        else p.out[(long)b * p.ld_out + (kvh * group + hh) * HD + d] = f2bf(o);
     }
     mark(7);
 }
@@ -534,6 +550,12 @@ inline void attn_decode_launch(const AttnDecodeArgs& p, int batch, hipStream_t s
     else if (p.nt_pages) NTTS_LAUNCH((attn_decode_kernel<1, false, 3, 4, kAttnLMax>), grid, block, s, p);
     else if (max_ctx <= 1024) NTTS_LAUNCH((attn_decode_kernel<1, false, 1, 4, 1024>), grid, block, s, p);
     else NTTS_LAUNCH((attn_decode_kernel<1, false, 1, 4, kAttnLMax>), grid, block, s, p);
+}
+// head_dim 128 (round 6; the generic attention geometry): one instantiation per score-row length, 4 waves, one page per wave in flight
+inline void attn_decode_launch_hd128(const AttnDecodeArgs& p, int batch, hipStream_t s, int max_ctx) {
+    const dim3 grid(batch, p.nkv), block(256);
+    if (max_ctx <= 1024) NTTS_LAUNCH((attn_decode_kernel<1, false, 1, 4, 1024, 1, 128>), grid, block, s, p);
+    else NTTS_LAUNCH((attn_decode_kernel<1, false, 1, 4, kAttnLMax, 1, 128>), grid, block, s, p);
 }
 // small batch (gemv.h path): 8 waves, one page each in flight, V^T requested next to K (kVar 5): at batch 1 the kernel is one
 // chain of dependent round trips through ONE CU's load path

@@ -90,6 +90,83 @@ NTTS_KERNEL(256) void rope_kv_write_vec_kernel(RopeWriteArgs p) {
     }
 }
 
+// ---- The same step for the GENERAL attention geometry (round 6): head_dim HD = 64 or 128, optional per-head q / k RMSNorm (Qwen3-style
+// `self_attn.q_norm` / `k_norm`, hf:models/qwen3/modeling_qwen3.py Qwen3Attention.forward: norm over head_dim on the projected heads BEFORE
+// RoPE).  One wave per (row, head): lane l holds the head's values l and l + HD / 2 -- a RoPE pair (HD = 128; for 64 lanes 0..31 hold one pair
+// each) -- so the norm is one cross-lane sum and the rotation needs no exchange.  q heads are normalised + rotated IN PLACE (the attention
+// kernels then load them as they are), k heads go into their page row, v heads into the transposed page.  Used for the prompt pass (rows =
+// packed prompt tokens, positions from PrefillMeta) and for the decode step (rows = decode slots, positions from the slot arrays: `dec_*`).
+// Arithmetic per element = Qwen2RMSNorm (norm.h rmsnorm: fp32 mean of squares, rsqrt, ONE rounding, times the bf16 weight, one rounding) and
+// rope_pair; nothing here is on the NeuTTS-Air path (head_dim 64, no qk-norm keeps the fused kernels above / qkv_rope.h).
+struct RopeNormArgs {
+    bf16_t* qkv;               // [rows][ld_qkv]
+    long ld_qkv;
+    bf16_t* kpool;
+    bf16_t* vpool;
+    const int* block_table;
+    int max_pages;
+    PrefillMeta meta;          // prompt pass (dec_pos == null)
+    const int* dec_pos;        // decode step: [rows] position of the token being decoded (= tokens already cached), row = decode slot
+    const int* dec_state;      //              [rows] 1 = running (others are skipped)
+    const bf16_t* rope_cos;    // [max_ctx][HD / 2]
+    const bf16_t* rope_sin;
+    const bf16_t* q_norm;      // [HD] or null (no qk-norm)
+    const bf16_t* k_norm;
+    float eps;
+    int nh, nkv, rows;
+    int write_v;               // prompt pass: v heads into the transposed pages here; decode step: the attention kernel places its own v row (0)
+};
+template <int HD>
+NTTS_KERNEL(256) void rope_norm_kv_write_kernel(RopeNormArgs p) {
+    constexpr int HALF = HD / 2;
+    const int lane = lane_id();
+    const int nheads = p.nh + 2 * p.nkv;
+    const long item = (long)blockIdx.x * 4 + wave_id();            // (row, head)
+    if (item >= (long)p.rows * nheads) return;                       // wave-uniform
+    const int t = (int)(item / nheads), hh = (int)(item % nheads);
+    int pos, slot_row;
+    if (p.dec_pos) {
+        if (p.dec_state[t] != 1) return;
+        pos = p.dec_pos[t];
+        slot_row = t;
+    } else {
+        const int sq = p.meta.tok_seq[t];
+        pos = p.meta.pos0[sq] + t - p.meta.tok_base[sq];
+        slot_row = p.meta.slot[sq];
+    }
+    bf16_t* h = p.qkv + (long)t * p.ld_qkv + (long)hh * HD;
+    const bool live = lane < HALF;                                  // HD = 64: half the wave idles (this is not the NeuTTS-Air path)
+    const int i = live ? lane : 0;
+    float x1 = bf2f(h[i]), x2 = bf2f(h[i + HALF]);
+    const int* bt = p.block_table + (long)slot_row * p.max_pages;
+    if (hh >= p.nh + p.nkv) {                                       // v head: transposed page, element-wise scatter
+        if (p.write_v && live) {
+            const long pg = bt[pos / kPage];
+            bf16_t* vd = p.vpool + (pg * p.nkv + (hh - p.nh - p.nkv)) * HD * kPage + v_slot(pos % kPage);
+            vd[(long)i * kPage] = h[i];
+            vd[(long)(i + HALF) * kPage] = h[i + HALF];
+        }
+        return;
+    }
+    const bf16_t* nw = hh < p.nh ? p.q_norm : p.k_norm;
+    if (nw) {                                                       // Qwen3RMSNorm over the head (wave-uniform branch)
+        float ss = live ? x1 * x1 + x2 * x2 : 0.f;
+#pragma unroll
+        for (int sh = 1; sh < 64; sh <<= 1) ss += shfl_xor(ss, sh);
+        const float inv = frsqrt_exact(ss / (float)HD + p.eps);
+        x1 = rbf(bf2f(nw[i]) * rbf(x1 * inv));
+        x2 = rbf(bf2f(nw[i + HALF]) * rbf(x2 * inv));
+    }
+    float o1, o2;
+    rope_pair(x1, x2, bf2f(p.rope_cos[(long)pos * HALF + i]), bf2f(p.rope_sin[(long)pos * HALF + i]), o1, o2);
+    bf16_t* dst = h;
+    if (hh >= p.nh) {
+        const long pg = bt[pos / kPage];
+        dst = p.kpool + ((pg * p.nkv + (hh - p.nh)) * kPage + pos % kPage) * HD;
+    }
+    if (live) { dst[i] = f2bf(o1); dst[i + HALF] = f2bf(o2); }
+}
+
 struct AttnPrefillArgs {
     const bf16_t* qkv;         // q already rotated
     long ld_qkv;
@@ -123,9 +200,11 @@ struct AttnPrefillArgs {
 // 8-wave workgroup (231 VGPRs, two waves per SIMD instead of one at 256 + 138 AGPRs; pages still staged once): prefill chunk
 // 28.23-28.29 vs 28.31-28.42 ms -- the kernel is bound by the softmax arithmetic itself (two exp per score: the eager contract
 // needs the global denominator before P is rounded), not by what one wave per SIMD cannot hide.
-template <int GH>
+// HD = head_dim (64; 128 for Qwen3-style checkpoints, round 6: attn_decode.h).  The HD = 64 instantiations are what they were, bit for bit.
+template <int GH, int HD = 64>
 NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
-    NTTS_SHARED bf16_t lds[2 * 2 * kPage * 64];   // [buf][K | V^T] 4 KB each
+    constexpr int KS = HD / 32, NTV = HD / 16, PB = kPage * HD;      // matrix-core k-steps per key, PV tiles, elements of one page image
+    NTTS_SHARED bf16_t lds[2 * 2 * PB];            // [buf][K | V^T] 4 KB (8 KB at HD = 128) each
     const int lane = lane_id(), w = wave_id();
     const int g = lane >> 4, l15 = lane & 15;
     // grid = (kv-head, tile, pass): the kv-head is the FAST index, so that with the work list sorted by descending causal
@@ -151,15 +230,15 @@ NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
     const int npages_w = wave_live ? qlast_w / kPage + 1 : 0; // pages this wave computes on
 
     // ---- Q fragments of all heads (B operand: column = query l15, k = d g*8.. within each 32-wide half)
-    bf16x8 qB[GH][2];
+    bf16x8 qB[GH][KS];
 #pragma unroll
     for (int h = 0; h < GH; ++h) {
         const int hh = h < nhd ? h0 + h : h0;
-        const bf16_t* qr = p.qkv + (long)(base + qpos) * p.ld_qkv + hh * 64 + g * 16;
-        qB[h][0] = ld16<bf16x8>(qr);
-        qB[h][1] = ld16<bf16x8>(qr + 8);
+        const bf16_t* qr = p.qkv + (long)(base + qpos) * p.ld_qkv + hh * HD;
+#pragma unroll
+        for (int f = 0; f < KS; ++f) qB[h][f] = ld16<bf16x8>(qr + (HD == 64 ? g * 16 + f * 8 : f * 32 + g * 8));
     }
-    if (p.rope_cos) {
+    if constexpr (HD == 64) if (p.rope_cos) {
         // RoPE of the queries on the way in (hf:models/qwen2/modeling_qwen2.py:113-135, the same rope_pair arithmetic the rope kernel
         // applies: bit-identical q): lane (g, l15) holds d = 16 g .. 16 g + 15 of query qpos; the pair partner d +- 32 sits in lane g ^ 2
         const bf16_t* cr = p.rope_cos + (long)qpos * 32 + (g & 1) * 16;
@@ -189,52 +268,57 @@ NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
     }
 
     // ---- page loader: wave 0/1 bring K (2 KB each), wave 2/3 bring V^T; one LDS-DMA instruction covers 1 KB
+    constexpr int KC = HD / 8;                                // 16-byte chunks per key row (8 / 16): chunk c of key r sits at c ^ (r & (KC - 1))
     auto stage = [&](int pg, int buf) {
         const long page = bt[pg];
-        bf16_t* dst = lds + buf * (2 * kPage * 64);
+        bf16_t* dst = lds + buf * (2 * PB);
         if (w < 2) {
-            const bf16_t* kp = p.kpool + (page * p.nkv + kvh) * kPage * 64;
+            const bf16_t* kp = p.kpool + (page * p.nkv + kvh) * PB;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int inst = w * 2 + i;                    // 8 keys per instruction
-                const int r = inst * 8 + (lane >> 3);
-                const int c = (lane & 7) ^ (r & 7);
-                glds16(kp + r * 64 + c * 8, dst + inst * 512);
+            for (int i = 0; i < KS; ++i) {
+                const int inst = w * KS + i;                   // 64 / KC keys per instruction (8; 4 at HD = 128)
+                const int r = inst * (64 / KC) + lane / KC;
+                const int c = (lane % KC) ^ (r & (KC - 1));
+                glds16(kp + r * HD + c * 8, dst + inst * 512);
             }
         } else {
-            const bf16_t* vp = p.vpool + (page * p.nkv + kvh) * 64 * kPage;
+            const bf16_t* vp = p.vpool + (page * p.nkv + kvh) * PB;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int inst = (w - 2) * 2 + i;              // 16 d-rows per instruction (64 B each)
+            for (int i = 0; i < KS; ++i) {
+                const int inst = (w - 2) * KS + i;             // 16 d-rows per instruction (64 B each)
                 const int d = inst * 16 + (lane >> 2);
                 const int u = (lane & 3) ^ ((d >> 2) & 3);
-                glds16(vp + d * kPage + u * 8, dst + kPage * 64 + inst * 512);
+                glds16(vp + d * kPage + u * 8, dst + PB + inst * 512);
             }
         }
     };
-    // K fragments of a page for this lane: key row u*16 + l15, logical chunks 2g, 2g+1
-    auto load_k = [&](const bf16_t* kb, bf16x8 (&kf)[2][2]) {
+    // K fragments of a page for this lane: key row u*16 + l15, k-step f = logical chunk 2g + f (HD = 64) / 4f + g (HD = 128: d = 32 f + 8 g)
+    auto load_k = [&](const bf16_t* kb, bf16x8 (&kf)[2][KS]) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int r = u * 16 + l15;
-            kf[u][0] = ld16<bf16x8>(kb + r * 64 + (((2 * g) ^ (r & 7)) << 3));
-            kf[u][1] = ld16<bf16x8>(kb + r * 64 + (((2 * g + 1) ^ (r & 7)) << 3));
+#pragma unroll
+            for (int f = 0; f < KS; ++f) {
+                const int ch = HD == 64 ? 2 * g + f : 4 * f + g;
+                kf[u][f] = ld16<bf16x8>(kb + r * HD + ((ch ^ (r & (KC - 1))) << 3));
+            }
         }
     };
     // scores of one head against one page.  bf16(QK^T) * scaling: the product by 2^-3 is exact, one rounding suffices.
     // MASKED pages (those reaching past the wave's first query) apply the causal mask with a large finite value so the
     // fast exp never sees an infinity; pages entirely below the diagonal skip the compare/select.
     constexpr float kMasked = -1.0e30f;
-    auto scores = [&](const bf16x8 (&kf)[2][2], int h, int pg, float (&sc)[8], auto masked_c) {
+    auto scores = [&](const bf16x8 (&kf)[2][KS], int h, int pg, float (&sc)[8], auto masked_c) {
         constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             f32x4 a = {0.f, 0.f, 0.f, 0.f};
-            a = mfma16(kf[u][0], qB[h][0], a);
-            a = mfma16(kf[u][1], qB[h][1], a);
+#pragma unroll
+            for (int f = 0; f < KS; ++f) a = mfma16(kf[u][f], qB[h][f], a);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float v = rbf(a[r]) * 0.125f;
+                float v = rbf(a[r]) * attn_scale(HD);
+                if constexpr (HD != 64) v = rbf(v);            // (x 128^-0.5 rounds; x 2^-3 is exact)
                 if constexpr (MASKED) {
                     const int key = pg * kPage + u * 16 + g * 4 + r;
                     if (key > qpos) v = kMasked;               // causal (covers key >= S as qpos <= S-1)
@@ -250,7 +334,7 @@ NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
     float m[GH], sum[GH];
 #pragma unroll
     for (int h = 0; h < GH; ++h) { m[h] = kMasked; sum[h] = 0.f; }
-    auto sweep1_page = [&](const bf16x8 (&kf)[2][2], int pg, auto masked_c) {
+    auto sweep1_page = [&](const bf16x8 (&kf)[2][KS], int pg, auto masked_c) {
 #pragma unroll
         for (int h = 0; h < GH; ++h) {
             float sc[8];
@@ -270,8 +354,8 @@ NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
         sync();                                               // page pg landed; everyone done with the other buffer
         if (pg + 1 < npages) stage(pg + 1, (pg + 1) & 1);
         if (pg < npages_w) {
-            bf16x8 kf[2][2];
-            load_k(lds + (pg & 1) * (2 * kPage * 64), kf);
+            bf16x8 kf[2][KS];
+            load_k(lds + (pg & 1) * (2 * PB), kf);
             if (pg * kPage + kPage - 1 > qw0) sweep1_page(kf, pg, Masked{}); else sweep1_page(kf, pg, Clear{});
         }
     }
@@ -289,12 +373,12 @@ NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
     }
 
     // ---- sweep 2: P = bf16(exp(s - m) / sum), O += P V
-    f32x4 oacc[GH][4];
+    f32x4 oacc[GH][NTV];
 #pragma unroll
     for (int h = 0; h < GH; ++h)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) oacc[h][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto sweep2_page = [&](const bf16x8 (&kf)[2][2], const bf16x8 (&vB)[4], int pg, auto masked_c) {
+        for (int nt = 0; nt < NTV; ++nt) oacc[h][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto sweep2_page = [&](const bf16x8 (&kf)[2][KS], const bf16x8 (&vB)[NTV], int pg, auto masked_c) {
 #pragma unroll
         for (int h = 0; h < GH; ++h) {
             float sc[8];
@@ -303,7 +387,7 @@ NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) pA[e] = (short)f2bf(fdiv_r(fexp_neg(sc[e] - m[h]), sum[h], rs[h]));
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) oacc[h][nt] = mfma16(pA, vB[nt], oacc[h][nt]);
+            for (int nt = 0; nt < NTV; ++nt) oacc[h][nt] = mfma16(pA, vB[nt], oacc[h][nt]);
         }
     };
     sync();                                                   // sweep 1's last reads are done before buffer 0 is refilled
@@ -313,14 +397,14 @@ NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
         sync();
         if (pg + 1 < npages) stage(pg + 1, (pg + 1) & 1);
         if (pg < npages_w) {
-            const bf16_t* kb = lds + (pg & 1) * (2 * kPage * 64);
-            const bf16_t* vb = kb + kPage * 64;
-            bf16x8 kf[2][2];
+            const bf16_t* kb = lds + (pg & 1) * (2 * PB);
+            const bf16_t* vb = kb + PB;
+            bf16x8 kf[2][KS];
             load_k(kb, kf);
-            bf16x8 vB[4];
+            bf16x8 vB[NTV];
             const bool tail = (pg + 1) * kPage > S;            // page holds slots past the prompt: mask them
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
+            for (int nt = 0; nt < NTV; ++nt) {
                 const int d = nt * 16 + l15;
                 const int sw = (d >> 2) & 3;
                 vB[nt] = ld16<bf16x8>(vb + d * kPage + ((g ^ sw) << 3));   // 16-B unit g of the row = keys 4g..+3, 16+4g..+3
@@ -345,13 +429,13 @@ NTTS_KERNEL(256) void attn_prefill_gqa_kernel(AttnPrefillArgs p) {
                     const int q = qw0 + g * 4 + r;
                     if (q < S) {
                         if (p.out_fp8_inv > 0.f) {
-                            unsigned char* o = (unsigned char*)p.out + (long)(base + q) * p.ld_out + (h0 + h) * 64 + l15;
+                            unsigned char* o = (unsigned char*)p.out + (long)(base + q) * p.ld_out + (h0 + h) * HD + l15;
 #pragma unroll
-                            for (int nt = 0; nt < 4; ++nt) o[nt * 16] = f2fp8c(rbf(oacc[h][nt][r]) * p.out_fp8_inv);
+                            for (int nt = 0; nt < NTV; ++nt) o[nt * 16] = f2fp8c(rbf(oacc[h][nt][r]) * p.out_fp8_inv);
                         } else {
-                            bf16_t* o = p.out + (long)(base + q) * p.ld_out + (h0 + h) * 64 + l15;
+                            bf16_t* o = p.out + (long)(base + q) * p.ld_out + (h0 + h) * HD + l15;
 #pragma unroll
-                            for (int nt = 0; nt < 4; ++nt) o[nt * 16] = f2bf(oacc[h][nt][r]);
+                            for (int nt = 0; nt < NTV; ++nt) o[nt * 16] = f2bf(oacc[h][nt][r]);
                         }
                     }
                 }
@@ -922,6 +1006,15 @@ inline void attn_prefill_launch(const AttnPrefillArgs& p, int n_tiles, hipStream
     }
     if (group <= 4) NTTS_LAUNCH((attn_prefill_gqa_kernel<4>), dim3(p.nkv, n_tiles, 1), dim3(256), s, p);
     else NTTS_LAUNCH((attn_prefill_gqa_kernel<7>), dim3(p.nkv, n_tiles, (group + 6) / 7), dim3(256), s, p);
+}
+
+// head_dim 128 (round 6): 1 / 2 / 4 heads of the group per workgroup (registers: 4 heads x 8 PV tiles are 128 accumulator registers)
+inline void attn_prefill_launch_hd128(const AttnPrefillArgs& p, int n_tiles, hipStream_t s) {
+    const int group = p.nh / p.nkv;
+    const long pairs = (long)p.nkv * n_tiles;
+    if (group == 1 || pairs * group <= 256) { NTTS_LAUNCH((attn_prefill_gqa_kernel<1, 128>), dim3(p.nkv, n_tiles, group), dim3(256), s, p); return; }
+    if (group == 2 || pairs * ((group + 1) / 2) <= 256) { NTTS_LAUNCH((attn_prefill_gqa_kernel<2, 128>), dim3(p.nkv, n_tiles, (group + 1) / 2), dim3(256), s, p); return; }
+    NTTS_LAUNCH((attn_prefill_gqa_kernel<4, 128>), dim3(p.nkv, n_tiles, (group + 3) / 4), dim3(256), s, p);
 }
 
 }  // namespace ntts

@@ -829,18 +829,16 @@ class NeuTTS:
 
 def _engine_config_from_hf(hc) -> Dict[str, object]:
     """AutoModelForCausalLM's dispatch (ref:neutts/neutts.py:164), restated for the decoder family the engine implements:
-    the pre-norm RoPE / GQA / SwiGLU decoder of Qwen2 (NeuTTS-Air) and Llama-style checkpoints (no q/k/v bias, possibly an
-    untied head).  Everything is read from config.json; what the kernels cannot do fails HERE with the reason, not later
+    the pre-norm RoPE / GQA / SwiGLU decoder of Qwen2 (NeuTTS-Air), Llama-style checkpoints (no q/k/v bias, possibly an
+    untied head) and Qwen3 (per-head q/k RMSNorm, head_dim 128: the engine's general attention path, round 6).  Everything is read from config.json; what the kernels cannot do fails HERE with the reason, not later
     with wrong audio."""
     mt = getattr(hc, "model_type", "")
     if mt not in ("qwen2", "llama", "mistral", "qwen3"):
         raise NotImplementedError(f"backbone model_type {mt!r}: the MI355X engine implements the Qwen2 / Llama decoder "
                                   "family (NeuTTS-Air is 'qwen2')")
-    if mt == "qwen3":
-        raise NotImplementedError("backbone model_type 'qwen3': per-head q/k RMSNorm (qk_norm) is not implemented by the engine")
     head_dim = getattr(hc, "head_dim", None) or hc.hidden_size // hc.num_attention_heads
-    if head_dim != 64:
-        raise NotImplementedError(f"backbone head_dim {head_dim}: the attention kernels are built for head_dim 64")
+    if head_dim not in (64, 128):
+        raise NotImplementedError(f"backbone head_dim {head_dim}: the attention kernels are built for head_dim 64 and 128")
     if getattr(hc, "sliding_window", None) and getattr(hc, "use_sliding_window", False):
         raise NotImplementedError("sliding-window attention is not implemented")
     if getattr(hc, "mlp_bias", False):
@@ -849,7 +847,8 @@ def _engine_config_from_hf(hc) -> Dict[str, object]:
                 num_layers=hc.num_hidden_layers, num_heads=hc.num_attention_heads,
                 num_kv_heads=getattr(hc, "num_key_value_heads", None) or hc.num_attention_heads, rms_eps=hc.rms_norm_eps,
                 head_dim=head_dim, tie_word_embeddings=bool(getattr(hc, "tie_word_embeddings", True)),
-                attention_bias=bool(getattr(hc, "attention_bias", mt == "qwen2")))
+                attention_bias=bool(getattr(hc, "attention_bias", mt == "qwen2")),
+                qk_norm=(mt == "qwen3"))       # Qwen3Attention: q_norm / k_norm (RMSNorm over head_dim) on every head before RoPE
 
 
 def _to_list(codes) -> List[int]:

@@ -187,6 +187,11 @@ def decoder_layer(cfg, w, i, h, cos, sin, cache: KVCache, taps=None):
     q = linear(x, w, p + "self_attn.q_proj.weight", w.get(p + "self_attn.q_proj.bias")).view(B, S, nh, d).transpose(1, 2)
     k = linear(x, w, p + "self_attn.k_proj.weight", w.get(p + "self_attn.k_proj.bias")).view(B, S, nkv, d).transpose(1, 2)
     v = linear(x, w, p + "self_attn.v_proj.weight", w.get(p + "self_attn.v_proj.bias")).view(B, S, nkv, d).transpose(1, 2)
+    if getattr(cfg, "qk_norm", False):
+        # Qwen3Attention.forward  hf:models/qwen3/modeling_qwen3.py: q_norm / k_norm (Qwen3RMSNorm over head_dim, same arithmetic as
+        # Qwen2RMSNorm) on the projected heads, BEFORE RoPE; applied on [B, S, heads, d] there, on [B, heads, S, d] here: per (token, head) alike
+        q = rms_norm(q, w[p + "self_attn.q_norm.weight"], cfg.rms_eps)
+        k = rms_norm(k, w[p + "self_attn.k_norm.weight"], cfg.rms_eps)
     q, k = apply_rope(q, k, cos, sin)
     kk, vv = cache.update(i, k, v)
     mask = causal_mask(S, kk.shape[-2], h.dtype)

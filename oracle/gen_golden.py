@@ -32,14 +32,22 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 
 def hf_backbone(cfg: br.BackboneConfig, w, dtype):
     from transformers import Qwen2Config, Qwen2ForCausalLM
-    hc = Qwen2Config(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
-                     intermediate_size=cfg.intermediate_size, num_hidden_layers=cfg.num_layers,
-                     num_attention_heads=cfg.num_heads, num_key_value_heads=cfg.num_kv_heads,
-                     max_position_embeddings=32768, rms_norm_eps=cfg.rms_eps, tie_word_embeddings=True,
-                     rope_parameters={"rope_type": "default", "rope_theta": cfg.rope_theta},
-                     attn_implementation="eager")
-    with torch.device("meta"):
-        m = Qwen2ForCausalLM(hc)
+    kw = dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size,
+              intermediate_size=cfg.intermediate_size, num_hidden_layers=cfg.num_layers,
+              num_attention_heads=cfg.num_heads, num_key_value_heads=cfg.num_kv_heads,
+              max_position_embeddings=32768, rms_norm_eps=cfg.rms_eps, tie_word_embeddings=True,
+              rope_parameters={"rope_type": "default", "rope_theta": cfg.rope_theta},
+              attn_implementation="eager")
+    if getattr(cfg, "qk_norm", False):          # Qwen3-style: per-head q/k RMSNorm, explicit head_dim, bias-free projections
+        from transformers import Qwen3Config, Qwen3ForCausalLM
+        assert not cfg.attention_bias
+        hc = Qwen3Config(head_dim=cfg.head_dim, attention_bias=False, **kw)
+        with torch.device("meta"):
+            m = Qwen3ForCausalLM(hc)
+    else:
+        hc = Qwen2Config(**kw)
+        with torch.device("meta"):
+            m = Qwen2ForCausalLM(hc)
     m = m.to_empty(device="cpu").eval()
     sd = {k: v.to(dtype) for k, v in w.items()}
     sd["lm_head.weight"] = sd["model.embed_tokens.weight"]

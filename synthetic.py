@@ -28,6 +28,7 @@ class BackboneConfig:
     rope_theta: float = 1e6
     attention_bias: bool = True       # Qwen2: q/k/v_proj carry a bias; Llama-style decoders do not
     tie_word_embeddings: bool = True  # False: a separate lm_head.weight
+    qk_norm: bool = False             # Qwen3-style: RMSNorm over head_dim on every q and k head before RoPE (self_attn.q_norm / k_norm weights)
 
     @staticmethod
     def neutts_air(vocab_size: int = 217488) -> "BackboneConfig":
@@ -41,6 +42,14 @@ class BackboneConfig:
         (19 x 6.29 M = 119.6 M) and 142 080 x 768 = 109.1 M tied embedding weights."""
         return BackboneConfig(vocab_size=vocab_size, hidden_size=768, intermediate_size=2048, num_layers=19, num_heads=12,
                               num_kv_heads=4, head_dim=64)
+
+    @staticmethod
+    def qwen3_like(vocab_size: int = 8192, num_layers: int = 2) -> "BackboneConfig":
+        """Qwen3-0.6B's attention geometry (hidden 1024, 16 query / 8 kv heads of head_dim 128 -- q width 2048 != hidden --, per-head q/k
+        RMSNorm, no attention bias, FFN 3072) at a depth and vocabulary the CPU oracle finishes quickly: what the reference's
+        AutoModelForCausalLM dispatch (ref:neutts/neutts.py:164) would hand the engine for a Qwen3-based checkpoint."""
+        return BackboneConfig(vocab_size=vocab_size, hidden_size=1024, intermediate_size=3072, num_layers=num_layers, num_heads=16,
+                              num_kv_heads=8, head_dim=128, attention_bias=False, qk_norm=True)
 
     @staticmethod
     def tiny(vocab_size: int = 1024, num_layers: int = 2) -> "BackboneConfig":
@@ -93,6 +102,9 @@ def make_weights(cfg: BackboneConfig, seed: int = 0, init: str = "unit",
             w[p + f"self_attn.{name}.weight"] = mat(rows, H)
             if cfg.attention_bias:
                 w[p + f"self_attn.{name}.bias"] = normal(rows)
+        if cfg.qk_norm:                                         # (drawn only for qk_norm models: the existing fixtures' draw order is untouched)
+            w[p + "self_attn.q_norm.weight"] = 1.0 + normal(d, s=0.1)
+            w[p + "self_attn.k_norm.weight"] = 1.0 + normal(d, s=0.1)
         w[p + "self_attn.o_proj.weight"] = mat(H, nh * d)
         w[p + "post_attention_layernorm.weight"] = 1.0 + normal(H, s=0.1)
         w[p + "mlp.gate_proj.weight"] = mat(F_, H)

@@ -126,7 +126,7 @@ def run_llama_dispatch_case(tmp_path, lib, wide=False):
     """The AutoModelForCausalLM dispatch of ref:neutts/neutts.py:164 beyond Qwen2: a Llama checkpoint (no q/k/v bias, UNTIED
     lm_head -- `model_type: llama`, `tie_word_embeddings: false`, `attention_bias: false` in its config.json) saved by
     transformers, loaded through `NeuTTS(backbone_repo=dir)`, gives the ids of transformers' own LlamaForCausalLM.generate
-    on that checkpoint (bf16, eager attention, greedy).  A `qwen3` config is refused with the reason."""
+    on that checkpoint (bf16, eager attention, greedy)."""
     from transformers import AutoModelForCausalLM, LlamaConfig, LlamaForCausalLM
     from neutts import NeuTTS
     from neutts.neutts import _engine_config_from_hf
@@ -160,6 +160,44 @@ def run_llama_dispatch_case(tmp_path, lib, wide=False):
     got = tts.generate_codes([prompt])[0]
     n = assert_ids_match_hf(got, want, scores)
     assert n >= 20 and len(set(got[:n])) >= n - 1          # the whole run, a new id every step (walk weights)
-    from transformers import Qwen3Config
-    with pytest.raises(NotImplementedError, match="qk_norm"):
-        _engine_config_from_hf(Qwen3Config(hidden_size=448, num_attention_heads=7, num_key_value_heads=1, head_dim=64))
+
+
+def run_qwen3_dispatch_case(tmp_path, lib, hidden=256, heads=2, kv_heads=1, ffn=512, layers=2):
+    """Round 6: a Qwen3 checkpoint -- `model_type: qwen3`: per-head q/k RMSNorm before RoPE, head_dim 128 (q width != hidden),
+    bias-free projections -- saved by transformers and loaded through `NeuTTS(backbone_repo=dir)` (config dispatch, safetensors streaming incl. the
+    `self_attn.q_norm / k_norm` weights) gives the ids of transformers' own Qwen3ForCausalLM.generate on that checkpoint (bf16, eager attention,
+    greedy).  The reference would reach this through AutoModelForCausalLM (ref:neutts/neutts.py:164) if its default repo were Qwen3-based."""
+    from transformers import AutoModelForCausalLM, Qwen3Config, Qwen3ForCausalLM
+    from neutts import NeuTTS
+    ccfg = cr.CodecConfig.tiny()
+    n_codes = int(np.prod(ccfg.levels))
+    tok = build_tokenizer(n_codes)
+    cfg = br.BackboneConfig(vocab_size=len(tok), hidden_size=hidden, intermediate_size=ffn, num_layers=layers, num_heads=heads, num_kv_heads=kv_heads,
+                            head_dim=128, attention_bias=False, qk_norm=True)
+    base = tok.convert_tokens_to_ids("<|speech_0|>")
+    w = br.make_weights(cfg, 91, walk_gain=4.0, walk_range=(base, base + n_codes))
+    hc = Qwen3Config(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
+                     num_hidden_layers=cfg.num_layers, num_attention_heads=cfg.num_heads, num_key_value_heads=cfg.num_kv_heads,
+                     head_dim=128, rms_norm_eps=cfg.rms_eps, rope_theta=cfg.rope_theta, max_position_embeddings=2048,
+                     tie_word_embeddings=True, attention_bias=False)
+    m = Qwen3ForCausalLM(hc).eval()
+    sd = dict(w)
+    sd["lm_head.weight"] = sd["model.embed_tokens.weight"]
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert not unexpected and all("inv_freq" in k for k in missing), (missing, unexpected)
+    d = str(tmp_path)
+    m.save_pretrained(d)
+    tok.save_pretrained(d)
+    cw = cr.make_weights(ccfg, 4)
+    tts = NeuTTS(backbone_repo=d, backbone_device="cuda", codec_repo=codec_spec(ccfg, cw), codec_device="cuda", lib_path=lib, do_sample=False)
+    assert tts.backbone.cfg["qk_norm"] is True and tts.backbone.cfg["head_dim"] == 128 and tts.backbone.cfg["attention_bias"] is False
+    prompt = list(b"hello") + [tok.convert_tokens_to_ids("<|SPEECH_GENERATION_START|>")] + [base + c for c in (3, 77, 200, 5, 18, 9)]
+    tts.max_context, tts.min_new_tokens = len(prompt) + 20, 6
+    hf = AutoModelForCausalLM.from_pretrained(d, attn_implementation="eager").to(torch.bfloat16).eval()
+    hf.model.rotary_emb.inv_freq = br.rope_inv_freq(cfg)
+    hf.model.rotary_emb.original_inv_freq = br.rope_inv_freq(cfg)
+    want, scores = hf_greedy(hf, prompt, tts.max_context, tts._eos_id, 6)
+    got = tts.generate_codes([prompt])[0]
+    n = assert_ids_match_hf(got, want, scores)
+    assert n >= 20 and len(set(got[:n])) >= n - 1
+    tts.close()

@@ -22,7 +22,9 @@ def load_fixture(name):
 
 def engine_cfg(cfg: br.BackboneConfig, **kw):
     d = dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
-             num_layers=cfg.num_layers, num_heads=cfg.num_heads, num_kv_heads=cfg.num_kv_heads, rms_eps=cfg.rms_eps)
+             num_layers=cfg.num_layers, num_heads=cfg.num_heads, num_kv_heads=cfg.num_kv_heads, rms_eps=cfg.rms_eps,
+             head_dim=cfg.head_dim, qk_norm=getattr(cfg, "qk_norm", False), attention_bias=cfg.attention_bias,
+             tie_word_embeddings=cfg.tie_word_embeddings)
     d.update(kw)
     return d
 

@@ -16,3 +16,7 @@ def test_checkpoint_dir_through_the_reference_loading_path(ckpt, emu_lib):
 
 def test_llama_style_checkpoint_dispatch(tmp_path, emu_lib):
     cases.run_llama_dispatch_case(tmp_path, emu_lib)
+
+
+def test_qwen3_style_checkpoint_dispatch(tmp_path, emu_lib):
+    cases.run_qwen3_dispatch_case(tmp_path, emu_lib)

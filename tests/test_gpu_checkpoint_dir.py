@@ -20,3 +20,8 @@ def test_checkpoint_dir_through_the_reference_loading_path(ckpt, hip_lib):
 
 def test_llama_style_checkpoint_dispatch(tmp_path, hip_lib):
     cases.run_llama_dispatch_case(tmp_path, hip_lib, wide=True)
+
+
+def test_qwen3_style_checkpoint_dispatch(tmp_path, hip_lib):
+    """Qwen3-0.6B's attention geometry (hidden 1024, 16:8 heads of head_dim 128, FFN 3072), 2 layers."""
+    cases.run_qwen3_dispatch_case(tmp_path, hip_lib, hidden=1024, heads=16, kv_heads=8, ffn=3072, layers=2)

@@ -146,8 +146,13 @@ def test_hf_config_dispatch():
     l = _engine_config_from_hf(LlamaConfig(hidden_size=768, num_attention_heads=12, num_key_value_heads=4, intermediate_size=2048,
                                            num_hidden_layers=2, vocab_size=1000, tie_word_embeddings=False))
     assert l["attention_bias"] is False and l["tie_word_embeddings"] is False
-    with pytest.raises(NotImplementedError, match="head_dim 128"):
-        _engine_config_from_hf(LlamaConfig(hidden_size=1024, num_attention_heads=8, num_key_value_heads=8, vocab_size=100))
+    l128 = _engine_config_from_hf(LlamaConfig(hidden_size=1024, num_attention_heads=8, num_key_value_heads=8, vocab_size=100))
+    assert l128["head_dim"] == 128 and l128["qk_norm"] is False          # round 6: the general attention path
+    with pytest.raises(NotImplementedError, match="head_dim 256"):
+        _engine_config_from_hf(LlamaConfig(hidden_size=1024, num_attention_heads=4, num_key_value_heads=4, vocab_size=100))
+    from transformers import Qwen3Config
+    q3 = _engine_config_from_hf(Qwen3Config(hidden_size=1024, num_attention_heads=16, num_key_value_heads=8, head_dim=128, vocab_size=100))
+    assert q3["qk_norm"] is True and q3["head_dim"] == 128 and q3["attention_bias"] is False and q3["num_kv_heads"] == 8
 
     class Other:
         model_type = "gpt2"

@@ -10,10 +10,18 @@ from oracle import backbone_ref as br
 transformers = pytest.importorskip("transformers")
 
 
+@pytest.mark.parametrize("arch", ["qwen2", "qwen3"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_bit_exact_vs_hf(dtype):
+def test_bit_exact_vs_hf(dtype, arch):
+    """qwen2: NeuTTS-Air's family (transformers.Qwen2ForCausalLM).  qwen3 (round 6): the oracle's qk_norm / head_dim 128 switch against
+    transformers.Qwen3ForCausalLM -- per-head q/k RMSNorm before RoPE, q width != hidden, scaling 128^-0.5 (not a power of two: the
+    product with the bf16 scores rounds), bias-free projections."""
     from oracle.gen_golden import hf_backbone
-    cfg = br.BackboneConfig(vocab_size=512, hidden_size=896, intermediate_size=640, num_layers=2)
+    if arch == "qwen3":
+        cfg = br.BackboneConfig(vocab_size=512, hidden_size=512, intermediate_size=640, num_layers=2, num_heads=4, num_kv_heads=2, head_dim=128,
+                                attention_bias=False, qk_norm=True)
+    else:
+        cfg = br.BackboneConfig(vocab_size=512, hidden_size=896, intermediate_size=640, num_layers=2)
     w = br.make_weights(cfg, 7)
     m = hf_backbone(cfg, w, dtype)
     wd = br.cast_weights(w, dtype)
