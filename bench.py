@@ -249,6 +249,9 @@ def main():
     ap.add_argument("--codec-precision", choices=["fp16", "bf16", "high"], default="fp16",
                     help="NeuCodec GEMM operand format: fp16 (the engine's default: ~8e-4 relative rms of the fp32 decoder), bf16 (rounds 1-5: 7e-3), "
                          "high (split bf16: ~7e-4 at 3x the matrix-core work)")
+    ap.add_argument("--park", type=int, default=None,
+                    help="continuous mode: PARKING rows per engine (ABI 9 park_slots): prompts are admitted in waves into them and move into a decode "
+                         "slot the moment one is released, so no decode row idles waiting for a wave; default 32 in continuous mode, 0 otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-codec", action="store_true", help="backbone only (profiling aid; not the headline metric)")
@@ -373,7 +376,8 @@ def main():
                                    intermediate_size=cfg.intermediate_size, num_layers=cfg.num_layers,
                                    num_heads=cfg.num_heads, num_kv_heads=cfg.num_kv_heads, rms_eps=cfg.rms_eps,
                                    max_context=((S_max + N_max + 31) // 32) * 32, max_batch=B,
-                                   max_prefill_tokens=a.prefill_chunk * S, weight_dtype="fp8" if fp8 else "bf16"), dev, lib)
+                                   max_prefill_tokens=a.prefill_chunk * S, weight_dtype="fp8" if fp8 else "bf16",
+                                   park_slots=(a.park if a.park is not None else (32 if a.mode == "continuous" and B > 1 else 0))), dev, lib)
     codec = tts.codec.engine if strm else None
     if not a.no_codec and not strm:
         codec_cfg_d = dict(hidden_size=ccfg.hidden_size, intermediate_size=ccfg.intermediate_size,
@@ -585,6 +589,7 @@ def main():
         assert tokens[0] == int(r_glen.sum())
         ph.update({k: sum(e.counters[k] for e in cengs) - c0[k] for k in c0})       # scheduler diagnostics: decode steps issued, prompt passes and their sizes
         ph["slot_occupancy"] = tokens[0] / max(1, ph["decode_steps"] * B)
+        ph["park_slots_per_engine"] = eng.park_slots
         # steady state: the tokens of the requests that finished between the moments 25 % and 75 % of all requests were done, over that time
         # -- the finite job's ramp (every slot waits for the first prompt passes) and drain (the last generation thins out) left out
         if len(done_at) >= 64:

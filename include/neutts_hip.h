@@ -67,7 +67,7 @@ typedef struct ntts_backbone_config {
                                  * the small-batch GEMV step, context-split attention and the resident / deep prompt tiers are off) */
     float rms_eps;              /* 1e-6 */
     int32_t max_context;        /* ref:neutts/neutts.py:85  (2048) */
-    int32_t max_batch;          /* number of decode slots (rows of the decode step) */
+    int32_t max_batch;          /* number of slots; the decode step runs over the first max_batch - park_slots of them */
     int32_t num_pages;          /* KV pool size in pages of NTTS_PAGE_TOKENS tokens; 0 = max_batch * max_context / page */
     int32_t max_prefill_tokens; /* workspace rows for one packed prefill call; 0 = 16384 */
     /* ABI 2: architecture / precision switches of the decoder family the reference's AutoModelForCausalLM dispatch covers
@@ -78,6 +78,10 @@ typedef struct ntts_backbone_config {
                                   * before RoPE: hf:models/qwen3/modeling_qwen3.py Qwen3Attention.forward); takes the general attention path like head_dim 128 */
     int32_t weight_dtype;        /* NTTS_W_BF16 | NTTS_W_FP8_E4M3: fp8 weights with per-output-channel scales, fp8 GEMM inputs with
                                     static per-tensor scales ("*.input_scale" tensors), bf16 residual stream / KV / attention */
+    int32_t park_slots;          /* ABI 9.  The LAST park_slots slots are PARKING rows: a prompt pass fills them like any slot (KV pages, first token) but no
+                                  * decode step touches them; ntts_backbone_activate moves a parked request into a free decode slot.  A continuous-batching
+                                  * scheduler admits prompts in efficient waves into the parking rows while every decode row stays busy (the reference has no
+                                  * scheduler: ref:neutts/neutts.py:335 runs one utterance at a time).  0 = none (a zeroed field: ABI 8 behaviour) */
 } ntts_backbone_config;
 enum { NTTS_W_BF16 = 0, NTTS_W_FP8_E4M3 = 1 };
 
@@ -161,6 +165,12 @@ int ntts_backbone_set_logits_range(ntts_backbone* e, int32_t lo, int32_t hi, int
  * gate_proj (gate/up), down_proj] and the lm_head's last.  input_scale = amax / 448 (tools/calibrate_fp8.py writes them). */
 int ntts_backbone_calibrate(ntts_backbone* e, int32_t enable);
 int ntts_backbone_read_amax(ntts_backbone* e, float* out, int32_t n);
+
+/* ABI 9.  Move `n` parked requests into free decode slots: park_slots[i] (a parking row holding a prefilled request: its KV pages, position, first token and
+ * sampling state) -> slots[i] (a FREE decode slot, < max_batch - park_slots).  Stream-ordered behind the prompt pass that filled the parking row and ahead of
+ * the next decode step, which then treats the request like any other; the parking row is free again.  Ids cannot depend on it: a request's arithmetic does
+ * not depend on the slot it runs in (tests/test_gpu_backbone.py slot-invariance tests). */
+int ntts_backbone_activate(ntts_backbone* e, int32_t n, const int32_t* park_slots, const int32_t* slots);
 
 /* Sampling contract of one request = the keyword arguments of the reference's generate() call
  * (ref:neutts/neutts.py:338-347). */

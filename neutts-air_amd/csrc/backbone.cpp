@@ -75,6 +75,11 @@ struct ntts_backbone {
     // tiers and fp8 are off (correct first; none of it is on the benchmark's path).
     int HD = 64;
     bool qk_norm = false, generic = false;
+    // PARKING (round 6; ntts_backbone_config::park_slots): the LAST park_slots of the cfg.max_batch slots never decode -- the decode step's launches cover
+    // rows [0, dec_rows) only.  A prompt pass may fill a parked slot like any other (its KV pages, its first token); ntts_backbone_activate moves it into
+    // a free decode slot later.  What it is for: a continuous-batching scheduler admits prompts in efficient waves of 24-32 INTO the parking rows while
+    // every decode row stays busy, instead of letting freed decode rows idle until the next wave (slot occupancy 0.92 -> ~0.99 of the decode rows).
+    int dec_rows = 0;
 
     // weights
     bf16_t* arena = nullptr;
@@ -274,7 +279,7 @@ static int n_part_for(const ntts_backbone* e, int N) {
 // tools/sweep_gang.py, profiles/r05a_sweep_gang_*: four 256-row chains, ms per 256-row step -- single-chain shape 0.988, XCD placement
 // off 0.970, + o_proj / down_proj on the 256-row tile 0.953; the same tiles ALONE cost the single chain 1.64 -> 1.88 ms).
 static void apply_gang_shape(ntts_backbone* e) {
-    const int B = e->cfg.max_batch;
+    const int B = e->dec_rows;
     const bool side_by_side = e->gang >= 2 && B > 128 && B <= 256;
     e->tall = (e->tall_env >= 0 ? e->tall_env : (side_by_side ? 3 : 0)) & 3;
     e->xcd_affine = e->affine_env >= 0 ? e->affine_env : (B > 128 && !side_by_side ? 7 : 0);
@@ -300,6 +305,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
         return fail(nullptr, NTTS_EINVAL, "hidden/intermediate size must be multiples of 64 (hidden <= 2048)");
     if (c->max_context > kAttnLMax || c->max_context % kPage) return fail(nullptr, NTTS_EINVAL, "max_context must be <= %d and a multiple of %d", kAttnLMax, kPage);
     if (c->max_batch < 1 || c->vocab_size < 2) return fail(nullptr, NTTS_EINVAL, "bad max_batch / vocab_size");
+    if (c->park_slots < 0 || c->park_slots >= c->max_batch) return fail(nullptr, NTTS_EINVAL, "park_slots %d: need 0 <= park_slots < max_batch (%d)", c->park_slots, c->max_batch);
     if ((c->qk_norm || c->head_dim != 64) && c->weight_dtype != NTTS_W_BF16)
         return fail(nullptr, NTTS_EINVAL, "qk_norm / head_dim %d are bf16-only (the fp8 model variant covers the head_dim 64, no-qk-norm family)", c->head_dim);
     if (c->weight_dtype != NTTS_W_BF16 && c->weight_dtype != NTTS_W_FP8_E4M3) return fail(nullptr, NTTS_EINVAL, "unknown weight_dtype %d", c->weight_dtype);
@@ -318,6 +324,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->max_pages = c->max_context / kPage;
     e->Tmax = c->max_prefill_tokens > 0 ? c->max_prefill_tokens : 16384;
     e->num_pages = c->num_pages > 0 ? c->num_pages : c->max_batch * e->max_pages;
+    e->dec_rows = c->max_batch - c->park_slots;
     e->use_graph = env_int("NTTS_NO_GRAPH", 0) == 0;
     e->fp8 = c->weight_dtype == NTTS_W_FP8_E4M3;
     e->tied = c->tie_word_embeddings != 0;
@@ -440,7 +447,8 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     e->block_table = ip;
 
     // ---- decode workspaces + tile choices (decode GEMMs are weight-streaming, M = max_batch)
-    const int mblocks_s = (B + 63) / 64;
+    const int D = e->dec_rows;                 // rows of the decode step (the slots that are not parking rows): what the step's tiles are chosen for
+    const int mblocks_s = (D + 63) / 64;
     auto pick_split = [&](int nblocks, int ktiles) {
         int blocks = nblocks * mblocks_s, ks = (224 + blocks - 1) / blocks;
         if (ks < 1) ks = 1;
@@ -455,7 +463,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     if (int k = env_int("NTTS_KS_O", 0); k > 0) e->ks_o = std::min(std::min(max_slabs, k), c->num_heads * e->HD / ktile);
     if (int k = env_int("NTTS_KS_D", 0); k > 0) e->ks_d = std::min(std::min(max_slabs, k), F / ktile);
     e->tall_env = env_int("NTTS_TALL", -1);
-    e->wide = env_int("NTTS_WIDE", B >= 512 && !e->fp8 ? 1 : 0) != 0;
+    e->wide = env_int("NTTS_WIDE", D >= 512 && !e->fp8 ? 1 : 0) != 0;
     e->wide_qkv = env_int("NTTS_WIDE_QKV", 2);
     if (e->wide_qkv != 1 && e->wide_qkv != 2 && e->wide_qkv != 4) e->wide_qkv = 2;
     e->wide_o = env_int("NTTS_WIDE_O", 1);
@@ -472,16 +480,16 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
         e->pf_deep_cap = dcap < e->pf_res_cap ? e->pf_res_cap : dcap;
         if (e->generic) e->pf_res_cap = e->pf_deep_cap = 0;     // every query on the (head_dim-templated) two-sweep kernel
     }
-    e->xcd_xps = (B == 64 || B == 128 || B == 256 || B == 512) ? 8 / (B / 64) : 0;
+    e->xcd_xps = (D == 64 || D == 128 || D == 256 || D == 512) ? 8 / (D / 64) : 0;
     e->affine_env = env_int("NTTS_XCD_AFFINE", -1);
     apply_gang_shape(e);
-    e->head_tile = env_int("NTTS_HEAD_TILE", B > 128 ? (e->fp8 || e->wide ? 2 : 4) : B > 64 ? 1 : 0);   // (1024 rows: 256 x 256 424 us, 256 x 288 438)
+    e->head_tile = env_int("NTTS_HEAD_TILE", D > 128 ? (e->fp8 || e->wide ? 2 : 4) : D > 64 ? 1 : 0);   // (1024 rows: 256 x 256 424 us, 256 x 288 438)
     if (e->head_tile != 0 && e->head_tile != 1 && e->head_tile != 2 && e->head_tile != 4) e->head_tile = 1;
     if (e->fp8 && e->head_tile == 4) e->head_tile = 2;          // (the natural-order tile is bf16 only)
-    e->gu_128 = B > 128;
+    e->gu_128 = D > 128;
     e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 
-    e->small = !e->generic && B <= env_int("NTTS_SMALL_BATCH", 8) && B <= kGemvRows && H <= 1024 && V % 16 == 0 && e->NQKV % 16 == 0 && F % 32 == 0;   // (bf16 and fp8 models alike: gemv.h / qkv_rope.h F8 instantiations)
+    e->small = !e->generic && c->park_slots == 0 && B <= env_int("NTTS_SMALL_BATCH", 8) && B <= kGemvRows && H <= 1024 && V % 16 == 0 && e->NQKV % 16 == 0 && F % 32 == 0;   // (bf16 and fp8 models alike: gemv.h / qkv_rope.h F8 instantiations)
     static_assert(ntts_backbone::kSksO <= 16 && ntts_backbone::kSksD <= 16, "slab counts");
     {
         CR_HIP(hipMalloc((void**)&e->step_meta, (size_t)B * 4 * sizeof(int)));
@@ -1075,7 +1083,7 @@ extern "C" int ntts_backbone_read_amax(ntts_backbone* e, float* out, int32_t n) 
 // leaves a gang for a while (NeuTTS.infer on engine 0 of a gang: ADVICE r5) and comes back re-captures nothing.  Same arithmetic and the
 // same summation order per output element in both shapes (tests/test_gpu_parity_matrix.py asserts the logits rows bit-identical).
 static void use_shape_for(ntts_backbone* e, int chains) {
-    const int B = e->cfg.max_batch;
+    const int B = e->dec_rows;
     const int want = (chains >= 2 && B > 128 && B <= 256) ? 1 : 0;
     e->gang = chains;
     if (want == e->shape) return;
@@ -1168,9 +1176,10 @@ static void gemm_large(ntts_backbone* e, const GemmArgs& a, hipStream_t st) {
 }
 
 static void ks_lm_head(ntts_backbone* e, bool keep_logits);
-static void k_lm_head(ntts_backbone* e, bool keep_logits) {
+// rows: e->dec_rows for a decode step; every slot (cfg.max_batch, parked ones included) for the first token behind a prompt pass
+static void k_lm_head(ntts_backbone* e, bool keep_logits, int rows) {
     if (e->small) { ks_lm_head(e, keep_logits); return; }
-    const int B = e->cfg.max_batch, H = e->H, V = e->cfg.vocab_size;
+    const int B = rows, H = e->H, V = e->cfg.vocab_size;
     GemmArgs a = gemm_args(e, e->xn_dec, H, e->lr_rows ? e->head_r : e->embed_tm, H, nullptr, nullptr, 0, B, e->lr_rows ? e->lr_rows : V, H,
                            e->lr_rows ? e->shead_r : e->shead, e->xs_head);
     if (e->lr_rows) a.eos_col1 = e->lr_rows;          // compacted head: columns = [range | EOS]
@@ -1191,23 +1200,24 @@ static void k_lm_head(ntts_backbone* e, bool keep_logits) {
 }
 
 static void lm_head_and_sample(ntts_backbone* e, int phase) {
-    k_lm_head(e, true);
+    const int rows = phase == SLOT_PREFILLED ? e->cfg.max_batch : e->dec_rows;
+    k_lm_head(e, true, rows);
     SampleArgs s{};
     s.part_val = e->part_val; s.part_idx = e->part_idx; s.n_part = e->n_part; s.sl = e->sl; s.phase = phase;
     s.part_width = e->small ? 16 : e->head_tile == 4 ? 96 : 64;
     s.logits = e->n_sampling > 0 ? e->logits_bf16 : nullptr; s.ld_logits = e->ldl; s.vocab = e->lr_rows ? e->lr_rows : e->cfg.vocab_size;
     if (e->lr_rows) { s.n_range = e->lr_rows - 1; s.id_base = e->lr_lo; s.id_tail = e->lr_eos; }
-    NTTS_LAUNCH((sample_greedy_kernel), dim3(e->cfg.max_batch), dim3(256), e->stream, s);
+    NTTS_LAUNCH((sample_greedy_kernel), dim3(rows), dim3(256), e->stream, s);
 }
 
 static StepMetaArgs step_meta_args(ntts_backbone* e) {
     StepMetaArgs m{};
     m.pos = e->sl.pos; m.state = e->sl.state; m.block_table = e->block_table; m.max_pages = e->max_pages; m.max_ctx = e->cfg.max_context;
-    m.M = e->cfg.max_batch; m.rope_cos = e->rope_cos; m.rope_sin = e->rope_sin; m.meta = e->step_meta; m.rope_rows = e->rope_rows;
+    m.M = e->dec_rows; m.rope_cos = e->rope_cos; m.rope_sin = e->rope_sin; m.meta = e->step_meta; m.rope_rows = e->rope_rows;
     return m;
 }
 static void k_step_meta(ntts_backbone* e) {   // once per decode step, before the first fused QKV kernel
-    NTTS_LAUNCH((step_meta_kernel), dim3((e->cfg.max_batch + 3) / 4), dim3(256), e->stream, step_meta_args(e));
+    NTTS_LAUNCH((step_meta_kernel), dim3((e->dec_rows + 3) / 4), dim3(256), e->stream, step_meta_args(e));
 }
 
 // QKV projection + bias + rounding + RoPE + K append (qkv_rope.h); 3 ring slots, 2 K slices per workgroup (swept: 4 slices / 4 and
@@ -1219,14 +1229,14 @@ static void k_rope_norm_decode(ntts_backbone* e, int i) {
     r.qkv = e->qkv_dec; r.ld_qkv = e->NQKV; r.kpool = e->kv + (size_t)i * e->layer_stride; r.vpool = r.kpool + e->kv_half;
     r.block_table = e->block_table; r.max_pages = e->max_pages; r.dec_pos = e->sl.pos; r.dec_state = e->sl.state;
     r.rope_cos = e->rope_cos; r.rope_sin = e->rope_sin; r.q_norm = e->layers[i].qn; r.k_norm = e->layers[i].kn; r.eps = c.rms_eps;
-    r.nh = c.num_heads; r.nkv = c.num_kv_heads; r.rows = c.max_batch; r.write_v = 0;
+    r.nh = c.num_heads; r.nkv = c.num_kv_heads; r.rows = e->dec_rows; r.write_v = 0;
     const long items = (long)r.rows * (c.num_heads + 2 * c.num_kv_heads);
     if (e->HD == 128) NTTS_LAUNCH((rope_norm_kv_write_kernel<128>), dim3((unsigned)((items + 3) / 4)), dim3(256), e->stream, r);
     else NTTS_LAUNCH((rope_norm_kv_write_kernel<64>), dim3((unsigned)((items + 3) / 4)), dim3(256), e->stream, r);
 }
 
 static void k_qkv(ntts_backbone* e, int i) {
-    const int B = e->cfg.max_batch, H = e->H;
+    const int B = e->dec_rows, H = e->H;
     const LayerW& w = e->layers[i];
     if (e->generic) {     // plain GEMM (bias, one rounding) into the q|k|v row, then norm + RoPE + K append as one small launch
         GemmArgs g = gemm_args(e, e->xn_dec, H, w.wqkv, H, w.bqkv, e->qkv_dec, e->NQKV, B, e->NQKV, H);
@@ -1258,22 +1268,22 @@ static void k_attn(ntts_backbone* e, int i) {
     a.block_table = e->block_table; a.max_pages = e->max_pages; a.pos = e->sl.pos; a.state = e->sl.state;
     a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
     a.tl = e->attn_tl;
-    if (e->HD == 128) { attn_decode_launch_hd128(a, c.max_batch, e->stream, c.max_context); return; }
+    if (e->HD == 128) { attn_decode_launch_hd128(a, e->dec_rows, e->stream, c.max_context); return; }
     a.xcd_rows = ((e->xcd_affine & 4) && !e->attn_tl) ? e->xcd_xps : 0;
     a.nt_pages = e->wide && !e->attn_tl;
     if (e->fp8) a.out_fp8_inv = 1.0f / e->layers[i].xs[1];   // attention output = o_proj's input
     if (e->split_active && !e->attn_tl) {       // long contexts below 2 workgroups per CU: context-split attention + combine
         AttnSplitArgs q{};
         q.a = a; q.scores = e->as_scores; q.ld_scores = c.max_context + 16; q.stats = e->as_stats; q.oslabs = e->as_oslabs; q.nsplit = e->attn_split;
-        q.a.slab_rows = c.max_batch;
-        attn_split_launch(q, c.max_batch, e->stream, true);
+        q.a.slab_rows = e->dec_rows;
+        attn_split_launch(q, e->dec_rows, e->stream, true);
         return;
     }
-    attn_decode_launch(a, c.max_batch, e->stream, c.max_context);
+    attn_decode_launch(a, e->dec_rows, e->stream, c.max_context);
 }
 
 static void k_o_proj(ntts_backbone* e, int i) {
-    const int B = e->cfg.max_batch, H = e->H, QD = e->cfg.num_heads * e->HD;
+    const int B = e->dec_rows, H = e->H, QD = e->cfg.num_heads * e->HD;
     GemmArgs a = gemm_args(e, e->attn_dec, QD, e->layers[i].wo, QD, nullptr, e->slabs, H, B, H, QD, e->layers[i].so, e->layers[i].xs[1]);
     if (e->wide && e->wide_o == 1) {   // whole K per tile: h = bf16(h + bf16(acc)) in the epilogue (hf:models/qwen2/modeling_qwen2.py:233,291), in place
         a.out = e->h_dec; a.resid_bf16 = e->h_dec; a.ldrb = H;
@@ -1286,7 +1296,7 @@ static void k_o_proj(ntts_backbone* e, int i) {
 }
 
 static void k_gate_up(ntts_backbone* e, int i) {
-    const int B = e->cfg.max_batch, H = e->H, F = e->F;
+    const int B = e->dec_rows, H = e->H, F = e->F;
     GemmArgs gu = gemm_args(e, e->xn_dec, H, e->layers[i].wgu, H, nullptr, e->act_dec, F, B, 2 * F, H, e->layers[i].sgu, e->layers[i].xs[2]);
     if (e->fp8) gu.out_fp8_inv = 1.0f / e->layers[i].xs[3];            // the activation is down_proj's input
     // (a 4-slot ring on the 128 x 128 tile, 96 KB in flight per CU instead of 64: 13.3 vs 13.4 us -- ring depth is not what
@@ -1309,7 +1319,7 @@ static void k_gate_up(ntts_backbone* e, int i) {
 }
 
 static void k_down(ntts_backbone* e, int i) {
-    const int B = e->cfg.max_batch, H = e->H, F = e->F;
+    const int B = e->dec_rows, H = e->H, F = e->F;
     GemmArgs a = gemm_args(e, e->act_dec, F, e->layers[i].wd, F, nullptr, e->slabs, H, B, H, F, e->layers[i].sd, e->layers[i].xs[3]);
     if (e->wide && e->wide_down == 1 && !e->fp8) {   // 128 x 128 / 8 waves / 3-slot ring: a W tile enters LDS once per 128 rows (64 x 64: 622 KB through a CU per tile)
         a.xcd_nsplit = -1;
@@ -1327,14 +1337,14 @@ static void k_down(ntts_backbone* e, int i) {
 static void k_add_norm(ntts_backbone* e, int K, int ks, const bf16_t* norm_w, bf16_t* resid_out, bf16_t* normed_out, float next_scale = 0.f, int affine_bit = 0) {
     NormArgs n{};
     if (e->wide && e->wide_o == 1 && affine_bit == 1) {   // behind the wide o_proj: the residual stream is already summed (EPI_RESID), this pass only normalises it
-        n.o_bf16 = e->h_dec; n.norm_w = norm_w; n.normed_out = normed_out; n.M = e->cfg.max_batch; n.H = e->H; n.eps = e->cfg.rms_eps;
+        n.o_bf16 = e->h_dec; n.norm_w = norm_w; n.normed_out = normed_out; n.M = e->dec_rows; n.H = e->H; n.eps = e->cfg.rms_eps;
         if (e->fp8 && next_scale > 0.f) n.out_fp8_inv = 1.0f / next_scale;
         add_rmsnorm_launch(n, e->stream, true);
         return;
     }
     n.xcd_rows = (e->xcd_affine & affine_bit) ? e->xcd_xps : 0;
-    n.slabs = e->slabs; n.nslab = gemm_nsplit(K, ks, ktile_of(e)); n.slab_rows = e->cfg.max_batch; n.resid_in = e->h_dec; n.resid_out = resid_out;
-    n.norm_w = norm_w; n.normed_out = normed_out; n.M = e->cfg.max_batch; n.H = e->H; n.eps = e->cfg.rms_eps;
+    n.slabs = e->slabs; n.nslab = gemm_nsplit(K, ks, ktile_of(e)); n.slab_rows = e->dec_rows; n.resid_in = e->h_dec; n.resid_out = resid_out;
+    n.norm_w = norm_w; n.normed_out = normed_out; n.M = e->dec_rows; n.H = e->H; n.eps = e->cfg.rms_eps;
     if (e->fp8 && next_scale > 0.f) n.out_fp8_inv = 1.0f / next_scale;
     add_rmsnorm_launch(n, e->stream, true);   // one row per workgroup: 256 CUs pull the slabs instead of 64 (5.5 -> 4.0 us per launch)
 }
@@ -1345,7 +1355,7 @@ static GemvArgs gemv_args(const ntts_backbone* e, const bf16_t* X, long ldx, con
     GemvArgs a{};
     a.wscale = wscale; a.xscale = xscale;
     a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.w_tile_major = 1; a.out = out; a.ldo = ldo;
-    a.slab_rows = e->cfg.max_batch; a.M = e->cfg.max_batch; a.N = N; a.K = K;
+    a.slab_rows = e->dec_rows; a.M = e->dec_rows; a.N = N; a.K = K;
     a.tl = e->gemv_tl;
     a.n_valid = N;
     return a;
@@ -1354,9 +1364,9 @@ static GemvArgs gemv_args(const ntts_backbone* e, const bf16_t* X, long ldx, con
 // x = rmsnorm(h) * ln1.  The residual stream alternates between h_dec and h_alt (block 0 writes, every block reads).
 static NormArgs pro_qkv(ntts_backbone* e, int i) {
     NormArgs n{};
-    n.M = e->cfg.max_batch; n.H = e->H; n.eps = e->cfg.rms_eps; n.norm_w = e->layers[i].ln1;
+    n.M = e->dec_rows; n.H = e->H; n.eps = e->cfg.rms_eps; n.norm_w = e->layers[i].ln1;
     if (i == 0) { n.gather_ids = e->sl.cur_tok; n.embed = e->embed; }
-    else { n.slabs = e->slabs2; n.nslab = gemv_nsplit(e->F, ntts_backbone::kSksD, e->fp8); n.slab_rows = e->cfg.max_batch; n.resid_in = e->h_dec; }
+    else { n.slabs = e->slabs2; n.nslab = gemv_nsplit(e->F, ntts_backbone::kSksD, e->fp8); n.slab_rows = e->dec_rows; n.resid_in = e->h_dec; }
     n.resid_out = e->h_alt;
     if (e->fp8) n.out_fp8_inv = 1.0f / e->layers[i].xs[0];       // the panel holds the QKV GEMV's e4m3 input
     return n;
@@ -1365,7 +1375,7 @@ static NormArgs pro_qkv(ntts_backbone* e, int i) {
 // with the 8-wave prologue-free attention (profiles/r03c_sweep_b1_fused_qkv_attn_waves.log)
 static void ks_qkv(ntts_backbone* e, int i) {
     GemvQkvArgs a{};
-    a.pro = pro_qkv(e, i); a.W = e->layers[i].wqkv; a.bias = e->layers[i].bqkv; a.M = e->cfg.max_batch; a.N = e->NQKV; a.K = e->H;
+    a.pro = pro_qkv(e, i); a.W = e->layers[i].wqkv; a.bias = e->layers[i].bqkv; a.M = e->dec_rows; a.N = e->NQKV; a.K = e->H;
     if (e->fp8) { a.wscale = e->layers[i].sqkv; a.xscale = e->layers[i].xs[0]; }
     a.meta = e->step_meta; a.rope_rows = e->rope_rows; a.q_out = e->qkv_dec; a.ld_q = e->NQKV;
     a.kpool = e->kv + (size_t)i * e->layer_stride; a.nh = e->cfg.num_heads; a.nkv = e->cfg.num_kv_heads;
@@ -1376,7 +1386,7 @@ static void ks_attn(ntts_backbone* e, int i) {
     const ntts_backbone_config& c = e->cfg;
     AttnDecodeArgs a{};
     a.qkv = e->qkv_dec; a.ld_qkv = e->NQKV; a.out = e->attn_dec; a.ld_out = c.num_heads * 64;
-    a.slab_rows = c.max_batch;
+    a.slab_rows = e->dec_rows;
     a.kpool = e->kv + (size_t)i * e->layer_stride; a.vpool = a.kpool + e->kv_half;
     a.block_table = e->block_table; a.max_pages = e->max_pages; a.pos = e->sl.pos; a.state = e->sl.state;
     a.rope_cos = e->rope_cos; a.rope_sin = e->rope_sin; a.nh = c.num_heads; a.nkv = c.num_kv_heads;
@@ -1385,10 +1395,10 @@ static void ks_attn(ntts_backbone* e, int i) {
     if (e->split_active && !e->attn_tl) {
         AttnSplitArgs q{};
         q.a = a; q.scores = e->as_scores; q.ld_scores = c.max_context + 16; q.stats = e->as_stats; q.oslabs = e->as_oslabs; q.nsplit = e->attn_split;
-        attn_split_launch(q, c.max_batch, e->stream);
+        attn_split_launch(q, e->dec_rows, e->stream);
         return;
     }
-    attn_decode_launch_small(a, c.max_batch, e->stream);
+    attn_decode_launch_small(a, e->dec_rows, e->stream);
 }
 static void ks_o_proj(ntts_backbone* e, int i) {
     const int QD = e->cfg.num_heads * 64;
@@ -1400,8 +1410,8 @@ static void ks_o_proj(ntts_backbone* e, int i) {
 static void ks_gate_up(ntts_backbone* e, int i) {
     GemvArgs a = gemv_args(e, nullptr, 0, e->layers[i].wgu, e->H, e->act_dec, e->F, 2 * e->F, e->H, e->layers[i].sgu, e->layers[i].xs[2]);
     NormArgs n{};
-    n.M = e->cfg.max_batch; n.H = e->H; n.eps = e->cfg.rms_eps; n.norm_w = e->layers[i].ln2;
-    n.slabs = e->slabs; n.nslab = gemv_nsplit(e->cfg.num_heads * 64, ntts_backbone::kSksO, e->fp8); n.slab_rows = e->cfg.max_batch;
+    n.M = e->dec_rows; n.H = e->H; n.eps = e->cfg.rms_eps; n.norm_w = e->layers[i].ln2;
+    n.slabs = e->slabs; n.nslab = gemv_nsplit(e->cfg.num_heads * 64, ntts_backbone::kSksO, e->fp8); n.slab_rows = e->dec_rows;
     n.resid_in = e->h_alt; n.resid_out = e->h_dec;
     if (e->fp8) { n.out_fp8_inv = 1.0f / e->layers[i].xs[2]; a.out_fp8_inv = 1.0f / e->layers[i].xs[3]; }   // e4m3 panel in, e4m3 activation out (down_proj's input)
     a.pro = n;
@@ -1415,8 +1425,8 @@ static void ks_down(ntts_backbone* e, int i) {
 }
 static void ks_final_norm(ntts_backbone* e) {   // h += down (last layer); xn = rmsnorm(h) * final_norm  -> the lm_head's input
     NormArgs n{};
-    n.slabs = e->slabs2; n.nslab = gemv_nsplit(e->F, ntts_backbone::kSksD, e->fp8); n.slab_rows = e->cfg.max_batch; n.resid_in = e->h_dec; n.resid_out = e->h_dec;
-    n.norm_w = e->final_norm; n.normed_out = e->xn_dec; n.M = e->cfg.max_batch; n.H = e->H; n.eps = e->cfg.rms_eps;
+    n.slabs = e->slabs2; n.nslab = gemv_nsplit(e->F, ntts_backbone::kSksD, e->fp8); n.slab_rows = e->dec_rows; n.resid_in = e->h_dec; n.resid_out = e->h_dec;
+    n.norm_w = e->final_norm; n.normed_out = e->xn_dec; n.M = e->dec_rows; n.H = e->H; n.eps = e->cfg.rms_eps;
     if (e->fp8) n.out_fp8_inv = 1.0f / e->xs_head;
     add_rmsnorm_launch(n, e->stream, true);
 }
@@ -1448,7 +1458,7 @@ static void decode_step_small(ntts_backbone* e) {
 static void decode_step(ntts_backbone* e) {
     if (e->small) { decode_step_small(e); return; }
     const ntts_backbone_config& c = e->cfg;
-    const int B = c.max_batch, H = e->H, F = e->F, QD = c.num_heads * e->HD;
+    const int B = e->dec_rows, H = e->H, F = e->F, QD = c.num_heads * e->HD;
     NormArgs n0{};
     n0.gather_ids = e->sl.cur_tok; n0.embed = e->embed; n0.resid_out = e->h_dec; n0.norm_w = e->layers[0].ln1;
     n0.normed_out = e->xn_dec; n0.M = B; n0.H = H; n0.eps = c.rms_eps;
@@ -1875,7 +1885,7 @@ extern "C" int ntts_backbone_decode(ntts_backbone* e, int32_t n_steps) {
     std::vector<int> trip;
     std::vector<std::pair<int, size_t>> undo;
     int ctx_now = 0;                                             // longest context a running slot may have at the first of these steps
-    for (int b = 0; b < e->cfg.max_batch; ++b) {
+    for (int b = 0; b < e->dec_rows; ++b) {                      // (parked slots do not decode: nothing to reserve for them)
         HostSlot& s = e->slots[b];
         if (s.state != SLOT_RUNNING) continue;
         if (s.pos_upper > ctx_now) ctx_now = s.pos_upper;
@@ -2201,6 +2211,38 @@ extern "C" int ntts_backbone_release_many(ntts_backbone* e, int32_t n, const int
     return NTTS_OK;
 }
 
+extern "C" int ntts_backbone_activate(ntts_backbone* e, int32_t n, const int32_t* park_slots, const int32_t* slots) {
+    if (!e || n < 1 || !park_slots || !slots) return fail(e, NTTS_EINVAL, "null/empty argument");
+    const int B = e->cfg.max_batch, D = e->dec_rows;
+    if ((size_t)(2 * n) > e->meta_cap) return fail(e, NTTS_EINVAL, "too many slots");
+    std::vector<char> seen(B, 0);
+    for (int i = 0; i < n; ++i) {
+        const int ps = park_slots[i], s = slots[i];
+        if (ps < D || ps >= B || s < 0 || s >= D || seen[ps] || seen[s]) return fail(e, NTTS_EINVAL, "activate: parking row %d -> decode slot %d (parking rows are %d..%d)", ps, s, D, B - 1);
+        seen[ps] = seen[s] = 1;
+        if (e->slots[ps].state != SLOT_RUNNING) return fail(e, NTTS_ESTATE, "activate: parking row %d holds no request", ps);
+        if (e->slots[s].state != SLOT_FREE) return fail(e, NTTS_ESTATE, "activate: decode slot %d is in use", s);
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    std::vector<int> pairs(2 * (size_t)n);
+    for (int i = 0; i < n; ++i) { pairs[2 * i] = park_slots[i]; pairs[2 * i + 1] = slots[i]; }
+    HIPCHK(e, upload_meta(e, pairs.data(), pairs.size(), e->stream));
+    ActivateArgs a{};
+    a.pairs = e->meta_dev; a.sl = e->sl; a.block_table = e->block_table; a.max_pages = e->max_pages;
+    NTTS_LAUNCH((activate_slots_kernel), dim3(n), dim3(64), e->stream, a);
+    for (int i = 0; i < n; ++i) {
+        HostSlot& src = e->slots[park_slots[i]];
+        HostSlot& dst = e->slots[slots[i]];
+        const unsigned gd = dst.gen, gs = src.gen;
+        dst = std::move(src);
+        dst.gen = gd + 1;             // (both rows changed hands: open snapshots no longer speak for either)
+        src = HostSlot{};
+        src.gen = gs + 1;
+    }
+    HIPCHK(e, hipGetLastError());
+    return NTTS_OK;
+}
+
 extern "C" int ntts_backbone_set_debug(ntts_backbone* e, int32_t keep_logits) {
     if (!e) return NTTS_EINVAL;
     HIPCHK(e, hipSetDevice(e->device));
@@ -2372,7 +2414,7 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
                 case 2: ks_o_proj(e, i); break;
                 case 3: ks_gate_up(e, i); break;     // incl. its fused prologue
                 case 4: ks_down(e, i); break;
-                case 5: k_lm_head(e, false); break;
+                case 5: k_lm_head(e, false, e->dec_rows); break;
                 case 6: ks_final_norm(e); break;
                 default: break;
             }
@@ -2384,7 +2426,7 @@ extern "C" int ntts_backbone_time_kernel(ntts_backbone* e, int32_t which, int32_
             case 2: k_o_proj(e, i); break;
             case 3: k_gate_up(e, i); break;
             case 4: k_down(e, i); break;
-            case 5: k_lm_head(e, false); break;
+            case 5: k_lm_head(e, false, e->dec_rows); break;
             case 6: k_add_norm(e, QD, e->ks_o, e->layers[i].ln2, e->o_pf, e->xn_pf, e->layers[i].xs[2]); break;   // scratch outputs
             default: break;
         }

@@ -378,6 +378,29 @@ NTTS_KERNEL(256) void amax_bf16_kernel(const bf16_t* x, long nvec, float* out) {
     if (lane_id() == 0) atomic_max_global_u32((unsigned int*)out, __builtin_bit_cast(unsigned int, m));
 }
 
+// ---- parking (ntts_backbone_activate): the per-slot state of parked request src[i] becomes decode slot dst[i]'s; one workgroup per pair
+struct ActivateArgs {
+    const int* pairs;        // [n][2] = (parking row, decode slot)
+    SlotArrays sl;
+    int* block_table;        // [slots][max_pages]
+    int max_pages;
+};
+NTTS_KERNEL(64) void activate_slots_kernel(ActivateArgs p) {
+    const int src = p.pairs[2 * blockIdx.x], dst = p.pairs[2 * blockIdx.x + 1];
+    const int lane = threadIdx.x;
+    const int nn = p.sl.n_new[src];
+    for (int k = lane; k < nn; k += 64) p.sl.out_tokens[(long)dst * p.sl.out_stride + k] = p.sl.out_tokens[(long)src * p.sl.out_stride + k];
+    for (int k = lane; k < p.max_pages; k += 64) p.block_table[(long)dst * p.max_pages + k] = p.block_table[(long)src * p.max_pages + k];
+    if (lane == 0) {
+        p.sl.pos[dst] = p.sl.pos[src]; p.sl.n_new[dst] = nn; p.sl.cur_tok[dst] = p.sl.cur_tok[src]; p.sl.prompt_len[dst] = p.sl.prompt_len[src];
+        p.sl.min_new[dst] = p.sl.min_new[src]; p.sl.max_len[dst] = p.sl.max_len[src]; p.sl.eos[dst] = p.sl.eos[src]; p.sl.mask_eos[dst] = p.sl.mask_eos[src];
+        p.sl.top_k[dst] = p.sl.top_k[src]; p.sl.temperature[dst] = p.sl.temperature[src];
+        p.sl.seed[2 * dst] = p.sl.seed[2 * src]; p.sl.seed[2 * dst + 1] = p.sl.seed[2 * src + 1];
+        p.sl.state[dst] = p.sl.state[src];
+        p.sl.state[src] = SLOT_FREE;
+    }
+}
+
 // ids -> codec codes on the device (ref:neutts/neutts.py:349 tokenizer.decode + :276 regex, as one pass): of slot s's new ids
 // keep those in [speech_base, speech_base + n_codes), as id - speech_base, in order; `modulo` (synthetic benchmark only: random
 // weights do not stay in the speech range) maps every id to id mod n_codes instead.  One workgroup per utterance.

@@ -36,7 +36,7 @@ class BackboneConfigC(C.Structure):
                 ("head_dim", C.c_int32), ("rms_eps", C.c_float), ("max_context", C.c_int32),
                 ("max_batch", C.c_int32), ("num_pages", C.c_int32), ("max_prefill_tokens", C.c_int32),
                 ("tie_word_embeddings", C.c_int32), ("attention_bias", C.c_int32), ("qk_norm", C.c_int32),
-                ("weight_dtype", C.c_int32)]
+                ("weight_dtype", C.c_int32), ("park_slots", C.c_int32)]
 
 
 class CodecConfigC(C.Structure):
@@ -101,6 +101,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_backbone_prefill_shared": (C.c_int, [p, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(SamplingC),
                                                    C.POINTER(i32), C.POINTER(i32)]),
         "ntts_backbone_set_gang": (C.c_int, [p, i32]),
+        "ntts_backbone_activate": (C.c_int, [p, i32, C.POINTER(i32), C.POINTER(i32)]),
         "ntts_backbone_set_logits_range": (C.c_int, [p, i32, i32, i32]),
         "ntts_backbone_calibrate": (C.c_int, [p, i32]),
         "ntts_backbone_read_amax": (C.c_int, [p, C.POINTER(f32), i32]),
@@ -226,17 +227,23 @@ class BackboneEngine:
         self._device, self._lib_path = device, lib_path
         c = BackboneConfigC(cfg["vocab_size"], cfg["hidden_size"], cfg["intermediate_size"], cfg["num_layers"],
                             cfg["num_heads"], cfg["num_kv_heads"], cfg.get("head_dim", 64), cfg.get("rms_eps", 1e-6),
-                            cfg.get("max_context", 2048), cfg.get("max_batch", 1), cfg.get("num_pages", 0),
+                            cfg.get("max_context", 2048), cfg.get("max_batch", 1) + int(cfg.get("park_slots", 0)), cfg.get("num_pages", 0),
                             cfg.get("max_prefill_tokens", 0), int(cfg.get("tie_word_embeddings", True)),
                             int(cfg.get("attention_bias", True)), int(cfg.get("qk_norm", False)),
-                            {"bf16": NTTS_W_BF16, "fp8": NTTS_W_FP8_E4M3, "fp8_e4m3": NTTS_W_FP8_E4M3}[str(cfg.get("weight_dtype", "bf16"))])
+                            {"bf16": NTTS_W_BF16, "fp8": NTTS_W_FP8_E4M3, "fp8_e4m3": NTTS_W_FP8_E4M3}[str(cfg.get("weight_dtype", "bf16"))],
+                            int(cfg.get("park_slots", 0)))
         self.fp8 = c.weight_dtype == NTTS_W_FP8_E4M3
         h = C.c_void_p()
         rc = self.lib.ntts_backbone_create(C.byref(c), device, C.byref(h))
         if rc != 0:
             raise NeuTTSHipError(rc, (self.lib.ntts_last_error(None) or b"").decode())
         self.h = h
-        self.max_batch = c.max_batch
+        # cfg["park_slots"] = P extra PARKING rows behind the cfg["max_batch"] decode slots (ABI 9 ntts_backbone_config.park_slots: the library counts
+        # them into its max_batch): rows max_batch .. max_batch + P - 1 take prompt passes but never decode; activate() moves one into a decode slot
+        self.park_slots = c.park_slots
+        self.n_rows = c.max_batch                         # every slot, parking rows included (the library's max_batch)
+        self.max_batch = c.max_batch - c.park_slots       # decode slots (rows of the decode step)
+        self._free_park: List[int] = list(range(self.n_rows - 1, self.max_batch - 1, -1))
         self.max_context = c.max_context
         self.vocab_size = c.vocab_size
         self._free: List[int] = list(range(self.max_batch - 1, -1, -1))   # host-side pool of decode slots (pop -> slot 0 first)
@@ -394,8 +401,8 @@ class BackboneEngine:
 
     def poll_end(self):
         """(state, n_new) of the snapshot opened by poll_begin; waits for that copy only, not for work enqueued after it."""
-        st = np.empty(self.max_batch, dtype=np.int32)
-        nn = np.empty(self.max_batch, dtype=np.int32)
+        st = np.empty(self.n_rows, dtype=np.int32)
+        nn = np.empty(self.n_rows, dtype=np.int32)
         i32p = C.POINTER(C.c_int32)
         self._chk(self.lib.ntts_backbone_poll_end(self.h, st.ctypes.data_as(i32p), nn.ctypes.data_as(i32p)))
         return st, nn
@@ -410,9 +417,9 @@ class BackboneEngine:
     def read_all_array(self):
         """Every slot's new ids in one call, as arrays: (ids [max_batch, max_context] int32 -- row s valid up to n[s]),
         n [max_batch], finished [max_batch] bool).  The batch hand-off to the codec stays in numpy (no Python lists)."""
-        out = np.empty((self.max_batch, self.max_context), dtype=np.int32)
-        n = np.empty(self.max_batch, dtype=np.int32)
-        fin = np.empty(self.max_batch, dtype=np.int32)
+        out = np.empty((self.n_rows, self.max_context), dtype=np.int32)
+        n = np.empty(self.n_rows, dtype=np.int32)
+        fin = np.empty(self.n_rows, dtype=np.int32)
         i32p = C.POINTER(C.c_int32)
         self._chk(self.lib.ntts_backbone_read_all(self.h, out.ctypes.data_as(i32p), self.max_context,
                                                   n.ctypes.data_as(i32p), fin.ctypes.data_as(i32p)))
@@ -424,8 +431,8 @@ class BackboneEngine:
         return [out[s, : n[s]].tolist() for s in range(self.max_batch)], [bool(f) for f in fin]
 
     def poll(self):
-        st = np.empty(self.max_batch, dtype=np.int32)
-        nn = np.empty(self.max_batch, dtype=np.int32)
+        st = np.empty(self.n_rows, dtype=np.int32)
+        nn = np.empty(self.n_rows, dtype=np.int32)
         i32p = C.POINTER(C.c_int32)
         self._chk(self.lib.ntts_backbone_poll(self.h, st.ctypes.data_as(i32p), nn.ctypes.data_as(i32p)))
         return st, nn
@@ -473,16 +480,33 @@ class BackboneEngine:
 
     def release(self, slot: int):
         self._chk(self.lib.ntts_backbone_release(self.h, slot))
-        if slot not in self._free:
-            self._free.append(slot)
+        pool = self._free if slot < self.max_batch else self._free_park
+        if slot not in pool:
+            pool.append(slot)
+
+    def acquire_park(self) -> int:
+        if not self._free_park:
+            raise NeuTTSHipError(-4, f"all {self.park_slots} parking rows are in use")
+        return self._free_park.pop()
+
+    def activate(self, park_rows: Sequence[int], slots: Sequence[int]):
+        """Parked requests -> free decode slots (ntts_backbone_activate): stream-ordered behind the prompt pass that filled the parking rows and
+        ahead of the next decode step.  The caller holds the slots (acquire_slot) and gets the parking rows back."""
+        a = np.ascontiguousarray(park_rows, dtype=np.int32)
+        b = np.ascontiguousarray(slots, dtype=np.int32)
+        self._chk(self.lib.ntts_backbone_activate(self.h, len(a), a.ctypes.data_as(C.POINTER(C.c_int32)), b.ctypes.data_as(C.POINTER(C.c_int32))))
+        for r in a.tolist():
+            if r not in self._free_park:
+                self._free_park.append(r)
 
     def release_many(self, slots: Sequence[int]):
         """release() for a whole set of slots with one stream operation."""
         sl = np.ascontiguousarray(slots, dtype=np.int32)
         self._chk(self.lib.ntts_backbone_release_many(self.h, len(sl), sl.ctypes.data_as(C.POINTER(C.c_int32))))
         for s in sl.tolist():
-            if s not in self._free:
-                self._free.append(s)
+            pool = self._free if s < self.max_batch else self._free_park
+            if s not in pool:
+                pool.append(s)
 
     def _mark_busy(self, slots: Sequence[int]):
         """Callers that choose slot numbers themselves (tests, bench): keep the pool consistent."""
@@ -658,23 +682,52 @@ class BackboneEngine:
 
         nxt = 0
 
+        # Parking (cfg["park_slots"] > 0): a prompt pass may also fill PARKING rows -- the requests wait there, prefilled, and move into a decode slot
+        # the moment one is released.  Admission then counts the free parking rows as well: the waves of `min_admit` prompts keep their
+        # efficient size while no decode row idles waiting for the next wave (slot occupancy 0.92 -> ~0.99: bench.py --mode continuous).
+        from collections import deque
+        parked: "deque[int]" = deque()   # parking rows holding a prefilled request, oldest first
+
+        def n_free():
+            return len(self._free) + len(self._free_park)
+
         def may_admit():
             if not owner:
                 return True
             want = min(min_admit, len(prompts) - nxt)
-            return admit_gate(len(self._free), want) if admit_gate is not None else len(self._free) >= want
+            return admit_gate(n_free(), want) if admit_gate is not None else n_free() >= want
+
+        def activate_parked():
+            """parked requests into the decode slots that are free right now; their bookkeeping moves along"""
+            nonlocal anchors
+            rows, slots_ = [], []
+            while parked and self._free:
+                rows.append(parked.popleft())
+                slots_.append(self.acquire_slot())
+            if not rows:
+                return
+            self.activate(rows, slots_)
+            for r, s in zip(rows, slots_):
+                owner[s] = owner.pop(r)
+                committed[s] = committed.pop(r)
+                steps_left[s] = steps_left.pop(r)
+                valid_from.pop(r, None)
+                valid_from[s] = snap_seq                  # the snapshots enqueued from here on describe it in its decode slot
+                anchors = [(s if a[0] == r else a[0], a[1]) for a in anchors]
 
         try:
             while nxt < len(prompts) or owner:
                 # admit as many waiting prompts as slots / prefill workspace allow
-                while nxt < len(prompts) and self._free and may_admit():
+                while nxt < len(prompts) and n_free() and may_admit():
                     batch, used, donors = [], 0, []
-                    while nxt < len(prompts) and self._free:
+                    while nxt < len(prompts) and n_free():
                         d = find_donor(nxt) if share_prefix else None
                         cost = len(prompts[nxt]) - (d[1] // NTTS_PAGE_TOKENS * NTTS_PAGE_TOKENS if d else 0)
                         if used + cost > budget or sum(committed.values()) + need_pages[nxt] > total_pages:
                             break
-                        s = self.acquire_slot()
+                        s = self.acquire_slot() if self._free else self.acquire_park()    # decode slots first, then parking rows
+                        if s >= self.max_batch:
+                            parked.append(s)
                         committed[s] = need_pages[nxt]
                         batch.append((nxt, s))
                         donors.append(d)
@@ -701,24 +754,30 @@ class BackboneEngine:
                             steps_left.pop(s, None)
                             committed.pop(s, None)
                             anchors = [a for a in anchors if a[0] != s]
-                            self._free.append(s)
+                            if s >= self.max_batch:
+                                parked.remove(s)
+                                self._free_park.append(s)
+                            else:
+                                self._free.append(s)
                         nxt = batch[0][0]
                         break
                     if on_admit is not None:
                         on_admit(len(batch))
                 if not owner:
                     raise NeuTTSHipError(-4, "no decode slot is free (held by an unfinished stream?)")
+                activate_parked()                                 # (decode slots freed in the previous iteration)
                 if run_ahead:
                     # keep the GPU fed: this burst goes in BEFORE the host looks at the previous burst's outcome.  Stream order per
                     # iteration j: [prompt pass j] [burst j] [exports / releases j] [snapshot j]; the host waits for snapshot j - 1
                     # only, with burst j queued behind it.  No burst when every owner has certainly stopped already (each has been
                     # given the decode steps its max_length allows: the snapshots in flight will show them finished).
                     burst_failed = None
-                    if any(steps_left.get(s, 1) > 0 for s in owner):
+                    if any(steps_left.get(s, 1) > 0 for s in owner if s < self.max_batch):
                         try:
                             self.decode(steps_per_poll)
                             for s in owner:
-                                steps_left[s] = steps_left.get(s, 0) - steps_per_poll
+                                if s < self.max_batch:            # (parked requests take no decode steps)
+                                    steps_left[s] = steps_left.get(s, 0) - steps_per_poll
                         except NeuTTSHipError as ex:
                             # Running one burst ahead, rows that have finished on the device still count as running on the host and
                             # ntts_backbone_decode reserves KV pages for them (up to one page per slot): with a tightly sized pool that
@@ -732,24 +791,24 @@ class BackboneEngine:
                         if burst_failed is not None:
                             st, nn = self.poll()                      # blocking: everything enqueued so far
                             q = snap_seq
-                            if not any(st[s] == 2 for s in owner):
+                            if not any(st[s] == 2 for s in owner if s < self.max_batch):
                                 raise burst_failed                    # nothing to drain: the pool really is too small
                     else:
                         st, nn = self.poll_end()
                         q, open_snap = open_snap, None
-                        if burst_failed is not None and not any(valid_from.get(s, 0) <= q and st[s] == 2 for s in owner):
+                        if burst_failed is not None and not any(valid_from.get(s, 0) <= q and st[s] == 2 for s in owner if s < self.max_batch):
                             # the burst could not reserve its pages and the snapshot in flight frees nothing: look at everything
                             # enqueued so far; if no owner has finished there either, no later iteration can cure it (ADVICE r4:
                             # this used to spin on poll_end / poll_begin forever, and an EngineGang with it)
                             st, nn = self.poll()
                             q = snap_seq
-                            if not any(st[s] == 2 for s in owner):
+                            if not any(st[s] == 2 for s in owner if s < self.max_batch):
                                 raise burst_failed
                 else:
                     st, nn = self.poll()
                     q = snap_seq                                  # a blocking poll describes everything enqueued so far
                 if st is not None:
-                    for s in [s for s in list(owner) if valid_from.get(s, 0) <= q and st[s] == 2]:
+                    for s in [s for s in list(owner) if s < self.max_batch and valid_from.get(s, 0) <= q and st[s] == 2]:
                         i = owner.pop(s)
                         if on_finished is not None:
                             on_finished(i, s, int(nn[s]))
@@ -765,7 +824,8 @@ class BackboneEngine:
                     self.poll_begin()
                     open_snap = snap_seq
                     snap_seq += 1
-                elif owner and any(st[s] == 1 for s in owner):
+                elif owner and (parked or any(st[s] == 1 for s in owner if s < self.max_batch)):
+                    activate_parked()
                     self.decode(steps_per_poll)
                 yield None
         finally:

@@ -211,6 +211,57 @@ def test_continuous_batching_ragged_vs_oracle(emu_lib):
     assert eng.generate(prompts, samp, steps_per_poll=3, prefill_token_budget=70) == got     # engine 0 is back on its own stream
 
 
+def test_parking_rows_keep_decode_slots_busy_and_the_ids(emu_lib):
+    """Round 6 (ABI 9 ntts_backbone_config.park_slots + ntts_backbone_activate): an engine of 2 decode slots + 3 PARKING rows.  The scheduler
+    admits prompts into decode slots first and into parking rows next (their prompt pass, KV pages and first token happen there); a parked
+    request moves into a decode slot as soon as one is released.  Same ids as the engine without parking -- a request's arithmetic does not
+    depend on its row, nor on the row it was prefilled in --, for the run-ahead and the blocking scheduler, with the hand-off hook, and with
+    an early-EOS request that is already FINISHED when it is activated; slots, parking rows and KV pages all come back; misuse is refused."""
+    cfg = br.BackboneConfig.tiny(vocab_size=512, num_layers=1)
+    w = br.make_weights(cfg, 11, walk_gain=4.0)
+    wd = br.cast_weights(w, torch.bfloat16)
+    lens = [5, 33, 64, 17, 40, 9, 21]
+    prompts = [br.synthetic_prompt(cfg, 10 + i, n) for i, n in enumerate(lens)]
+    probe = br.generate(cfg, wd, prompts[3], lens[3] + 12, eos_id=cfg.vocab_size - 1, min_new_tokens=0)
+    eos = probe.ids[4]
+    want = [br.generate(cfg, wd, p, len(p) + 10, eos_id=eos, min_new_tokens=3).ids for p in prompts]
+    samp = [_hip.Sampling(max_length=len(p) + 10, min_new_tokens=3, eos_token_id=eos, do_sample=False) for p in prompts]
+    eng = make_engine(cfg, w, emu_lib, max_batch=2, max_prefill_tokens=256, park_slots=3)
+    assert eng.max_batch == 2 and eng.park_slots == 3 and eng.n_rows == 5
+    assert eng.generate(prompts, samp, steps_per_poll=3) == want
+    assert eng.counters["prefill_calls"] <= 3              # 7 prompts through 2 decode slots in waves of up to 5, not one pass per freed slot
+    assert eng.generate(prompts, samp, steps_per_poll=2, run_ahead=False) == want
+    assert eng.generate(prompts, samp, steps_per_poll=1, min_admit=3) == want
+    seen = {}
+
+    def hook(i, slot, n_new):
+        assert slot < eng.max_batch                        # requests finish in decode slots only
+        seen[i] = (n_new, eng.read(slot)[0])
+    assert eng.generate(prompts, samp, steps_per_poll=3, on_finished=hook) == [[] for _ in prompts]
+    assert seen == {i: (len(g), g) for i, g in enumerate(want)}
+    st = eng.kv_stats()
+    assert eng.free_slots() == 2 and len(eng._free_park) == 3 and st["free_pages"] == st["total_pages"]
+    # a request whose FIRST token already ends it (max_length = prompt + 1) is activated in the FINISHED state and leaves through the ordinary path
+    one = [_hip.Sampling(max_length=len(p) + 1, min_new_tokens=0, eos_token_id=eos, do_sample=False) for p in prompts]
+    assert eng.generate(prompts, one, steps_per_poll=2) == [g[:1] for g in want]
+    # by hand: prefill into a parking row, activate, decode
+    p_row, slot = eng.acquire_park(), eng.acquire_slot()
+    eng.prefill([prompts[1]], [p_row], [samp[1]])
+    with pytest.raises(_hip.NeuTTSHipError):
+        eng.activate([slot], [p_row])                      # (the wrong way round)
+    eng.activate([p_row], [slot])
+    with pytest.raises(_hip.NeuTTSHipError):
+        eng.activate([p_row], [slot])                      # the parking row is empty now, the slot taken
+    eng.decode(9)
+    assert eng.read(slot)[0] == want[1]
+    eng.release(slot)
+    st = eng.kv_stats()
+    assert eng.free_slots() == 2 and len(eng._free_park) == 3 and st["free_pages"] == st["total_pages"]
+    with pytest.raises(_hip.NeuTTSHipError):
+        make_engine(cfg, w, emu_lib, max_batch=2, park_slots=-1)
+    eng.close()
+
+
 @pytest.mark.timeout(300)
 def test_generate_with_pages_held_outside_the_call(emu_lib, monkeypatch):
     """KV pages held outside a generate() call -- a suspended stream, a slot another caller prefilled -- are not
