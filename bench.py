@@ -1029,6 +1029,9 @@ def main():
         ach = nbytes / (ms * 1e-3) / 1e9
         traffic = pmc.get(name, {}).get("traffic_bytes_per_launch")
         step_frac = step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+        wb_ = 1.0 if fp8 else 2.0
+        weight_bytes = wb_ * (cfg.num_layers * ((cfg.num_heads + 2 * cfg.num_kv_heads) * cfg.head_dim * cfg.hidden_size + cfg.hidden_size * cfg.num_heads * cfg.head_dim
+                                                + 3 * cfg.intermediate_size * cfg.hidden_size) + cfg.vocab_size * cfg.hidden_size)   # W_layers + W_head
         roof = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": pmc_src if traffic is not None else None, "avg_launch_us": ms * 1e3,
                 "alg_bytes_per_launch": nbytes, "launches_per_step": nl,
@@ -1037,6 +1040,13 @@ def main():
                 # ... and the step as the timed region runs it: G engines' chains side by side (each chain's algorithmic bytes counted
                 # in full, the weights too -- every chain streams them, the second and third find most of a layer in the memory-side cache)
                 "gang_step": ({"chains": G, "ms_per_256_row_step": gang_step_ms, "frac_of_hbm_peak": step_bytes / (gang_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                               # BOTH accountings: `frac_of_hbm_peak` charges every chain its own copy of the weights (G x step_alg_bytes per
+                               # gang step); SURVEY 8(d)'s formula at the B = G x 256 rows the GPU actually holds charges them ONCE:
+                               "alg_bytes_weights_once": weight_bytes + G * (step_bytes - weight_bytes),
+                               "frac_of_hbm_peak_weights_once": (weight_bytes + G * (step_bytes - weight_bytes)) / (G * gang_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                               "counters_note": "rocprofv3 --pmc over gang steps serialises the dispatches (sum of durations / busy time = 1.00 in the kernel trace of the "
+                                                "same pass: profiles/r06c_pmc_gang_concurrent_*.txt): per dispatch each chain moves what pmc_per_kernel_gang_shape "
+                                                "lists; how much of the second to fourth chain's weight stream the memory-side cache serves is not observable with this tool",
                                "measured": "host wall clock over 16 alternately replayed steps per engine at context ~S + N/2 + 10",
                                # the step's kernels launched on all G engines at the same time: [us per launch on each engine], bytes/s of the G launches together
                                "kernels_side_by_side": side or None}
