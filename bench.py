@@ -247,7 +247,7 @@ def main():
                          "144.2 k on one engine; NeuTTS-Air bf16 loses: 80.3 k against 100.5 k at 256 streams -- off by default)")
     ap.add_argument("--stream-admit", type=int, default=0, help="stream mode on a gang: streams per admission group (one device-side stream set each); 0 = one group per engine")
     ap.add_argument("--codec-precision", choices=["fp16", "bf16", "high"], default="fp16",
-                    help="NeuCodec GEMM operand format: fp16 (the engine's default: ~8e-4 relative rms of the fp32 decoder), bf16 (rounds 1-5: 7e-3), "
+                    help="NeuCodec GEMM operand format: fp16 (the engine's default: ~9.5e-4 relative rms of the fp32 decoder), bf16 (rounds 1-5: 7e-3), "
                          "high (split bf16: ~7e-4 at 3x the matrix-core work)")
     ap.add_argument("--park", type=int, default=None,
                     help="continuous mode: PARKING rows per engine (ABI 9 park_slots): prompts are admitted in waves into them and move into a decode "

@@ -336,7 +336,7 @@ typedef struct ntts_codec_config {
     int32_t max_rows;           /* workspace rows: sum over a decode call of (max frames of the call + 6) */
     int32_t precision;          /* ABI 9 (the field is ABI 8's; the numbering changed so that a zeroed struct gets the setting that holds the parity bar).
                                  * 0 = fp16 GEMM operands (DEFAULT): activations and weights as IEEE halves on v_mfma_f32_16x16x32_f16, fp32 accumulate --
-                                 *     waveform within ~8e-4 RELATIVE rms of the fp32 reference decoder (ref:neutts/neutts.py:288-291 runs it in fp32), i.e.
+                                 *     waveform within ~1e-3 RELATIVE rms (measured 9.5e-4) of the fp32 reference decoder (ref:neutts/neutts.py:288-291 runs it in fp32), i.e.
                                  *     inside BASELINE's 1e-3 absolute at any amplitude a [-1, 1] waveform can have; same matrix-core rate and bytes as
                                  *     bf16.  Operands must fit fp16's range: weights are checked at finalize (NTTS_EINVAL beyond 65504), activations
                                  *     saturate at +-65504 (post-norm activations are O(1-10));

@@ -131,7 +131,7 @@ extern "C" int ntts_codec_create(const ntts_codec_config* cf, int device, ntts_c
     c->H = cf->hidden_size; c->I = cf->intermediate_size; c->nq = cf->n_levels;
     c->n_fft = cf->hop_length * 4; c->nb = c->n_fft / 2 + 1; c->NS = c->n_fft + 2;
     c->lds_spec = (c->NS + 3) / 4 * 4;
-    c->K3 = (6L * c->nb + 63) / 64 * 64;
+    c->K3 = ((cf->precision == 0 ? 2L : 6L) * c->nb + 63) / 64 * 64;      // fp16: one term per (re, im) bin; bf16 engines: the hi / lo split, three terms
     c->max_rows = cf->max_rows;
     if (cf->precision < 0 || cf->precision > 2) { delete c; return cfail(nullptr, NTTS_EINVAL, "unknown codec precision %d (0 = fp16 operands, 1 = high: split bf16 operands, 2 = bf16 operands)", cf->precision); }
     c->S = cf->precision == 1 ? 3 : 1;
@@ -378,6 +378,11 @@ extern "C" int ntts_codec_finalize(ntts_codec* c) {
                 const double ang = 2.0 * M_PI * (double)((long)k * n % N) / N;
                 const float cr = (float)(win * ck * cos(ang) / N);
                 const float ci = (k == 0 || k == N / 2) ? 0.f : (float)(-win * ck * sin(ang) / N);
+                if (c->fmt == kOpF16) {       // ONE fp16 term per bin, basis scaled by 2^9 into fp16's normal range (codec.h kDftScale; ola_kernel takes it back)
+                    bf16_t* row = &B[(size_t)n * K3];
+                    row[k] = h_f2h(cr * kDftScale); row[nb + k] = h_f2h(ci * kDftScale);
+                    continue;
+                }
                 const bf16_t crh = h_f2bf(cr), cih = h_f2bf(ci);
                 const bf16_t crl = h_f2bf(cr - h_bf2f(crh)), cil = h_f2bf(ci - h_bf2f(cih));
                 bf16_t* row = &B[(size_t)n * K3];
@@ -543,11 +548,12 @@ static int codec_decode_impl(ntts_codec* c, int32_t n, const int32_t* codes, con
     rownorm_launch(fn, st);
     { GemmArgs ga_ = cg(c->xa, S * H, c->head_w, S * H, c->head_b, c->spec, c->lds_spec, rows, c->NS); CGEMM(EPI_F32, ga_, st); }
     IstftPrepArgs ip{};
-    ip.spec = c->spec; ip.lds = c->lds_spec; ip.s3 = c->s3; ip.K3 = c->K3; ip.rows = rows; ip.nb = c->nb;
+    ip.spec = c->spec; ip.lds = c->lds_spec; ip.s3 = c->s3; ip.K3 = c->K3; ip.rows = rows; ip.nb = c->nb; ip.f16 = c->fmt == kOpF16;
     NTTS_LAUNCH((istft_prep_kernel), dim3((unsigned)rows), dim3(256), st, ip);
-    { GemmArgs ga_ = cg(c->s3, c->K3, c->basis3, c->K3, nullptr, c->frames, c->n_fft, rows, c->n_fft); NTTS_GEMM_BIG(EPI_F32, ga_, st); }
+    { GemmArgs ga_ = cg(c->s3, c->K3, c->basis3, c->K3, nullptr, c->frames, c->n_fft, rows, c->n_fft); CGEMM(EPI_F32, ga_, st); }
     OlaArgs oa{};
     oa.frames = c->frames; oa.win2 = c->win2; oa.wav = c->wav; oa.wav_stride = (long)hop * Tmax; oa.R = R; oa.hop = hop; oa.n_fft = c->n_fft;
+    oa.scale = c->fmt == kOpF16 ? 1.0f / kDftScale : 1.0f;
     NTTS_LAUNCH((ola_kernel), dim3(n, (unsigned)(((long)hop * Tmax + 255) / 256)), dim3(256), st, oa);
     CHIP(c, hipEventRecord(c->ev[1], st));
     c->have_time = true;

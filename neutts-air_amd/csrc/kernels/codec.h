@@ -46,7 +46,7 @@ NTTS_D bool codec_row(const CodecRows& R, long r, int& b, int& t) {   // which (
 // DESIGN.md section 2) drops to ~2^-17 at three times the matrix-core work.  The ISTFT head's DFT operand has always been built this way
 // (istft_prep_kernel).  `split` = 0: the plain bf16 row of C columns.
 // ---- precision = fp16 (the default, `split` = kOpF16): the plain row of C columns as IEEE HALVES for v_mfma_f32_16x16x32_f16 -- 11 significant
-// bits per operand at the bf16 rate and the bf16 bytes: 8.0e-4 relative on the waveform (tools/codec_operand_sim.py; bf16 7.4e-3).
+// bits per operand at the bf16 rate and the bf16 bytes: 8.1e-4 relative on the waveform from the GEMM operands (tools/codec_operand_sim.py predicts 8.0e-4; bf16 7.4e-3), 9.5e-4 with the ISTFT as ONE fp16 term per bin (istft_prep_kernel: 37.6 -> 37.0 ms per 256 x 250 frames).
 constexpr int kOpBf16 = 0, kOpSplit = 1, kOpF16 = 2;
 NTTS_D void put_op(bf16_t* y, long r, int C, int ch, float v, int split) {
     if (split == kOpF16) { y[r * C + ch] = f2h(v); return; }
@@ -622,7 +622,11 @@ struct IstftPrepArgs {
     long K3;
     long rows;
     int nb;
+    int f16;               // precision = fp16 (round 6): s3 = [re | im | 0...] as IEEE halves, ONE term per bin (K3 = 2 nb padded) -- against the basis
+                           // [B | ...] in halves scaled by kDftScale (codec.cpp); the bf16 engines keep the three-term split below
 };
+constexpr float kDftScale = 512.0f;   // fp16 DFT basis = window * ck * cos / N * 2^9 (largest entry 0.53; entries below 2^-14 / 2^9 = 1.2e-7 -- 1e-4 of the largest --
+                                      // are the only ones in the subnormal range); ola_kernel multiplies by 2^-9 (exact)
 NTTS_KERNEL(256) void istft_prep_kernel(IstftPrepArgs p) {
     const long r = blockIdx.x;
     const float* x = p.spec + r * p.lds;
@@ -632,13 +636,14 @@ NTTS_KERNEL(256) void istft_prep_kernel(IstftPrepArgs p) {
         if (mag > 100.f) mag = 100.f;              // hf:...modeling_xcodec2.py:771
         const float ph = x[p.nb + k];
         const float re = mag * cosf(ph), im = mag * sinf(ph);
+        if (p.f16) { o[k] = f2h(re); o[p.nb + k] = f2h(im); continue; }
         const bf16_t rh = f2bf(re), ih = f2bf(im);
         const bf16_t rl = f2bf(re - bf2f(rh)), il = f2bf(im - bf2f(ih));
         o[k] = rh; o[p.nb + k] = ih;
         o[2 * p.nb + k] = rl; o[3 * p.nb + k] = il;
         o[4 * p.nb + k] = rh; o[5 * p.nb + k] = ih;
     }
-    for (long k = 6L * p.nb + threadIdx.x; k < p.K3; k += 256) o[k] = 0;
+    for (long k = (p.f16 ? 2L : 6L) * p.nb + threadIdx.x; k < p.K3; k += 256) o[k] = 0;
 }
 
 // ---- overlap-add of the windowed frames, trim, divide by the window envelope -------------------------------
@@ -649,6 +654,7 @@ struct OlaArgs {
     long wav_stride;
     CodecRows R;
     int hop, n_fft;
+    float scale;           // 1, or 1 / kDftScale when the frames come from the fp16 DFT basis
 };
 // grid (B, ceil(hop*Tmax / 256))
 NTTS_KERNEL(256) void ola_kernel(OlaArgs p) {
@@ -669,7 +675,7 @@ NTTS_KERNEL(256) void ola_kernel(OlaArgs p) {
         env += p.win2[n];
     }
     if (env < 1e-11f) env = 1e-11f;                 // hf:...modeling_xcodec2.py:793
-    p.wav[(long)b * p.wav_stride + s] = acc / env;
+    p.wav[(long)b * p.wav_stride + s] = acc * p.scale / env;
 }
 
 }  // namespace ntts

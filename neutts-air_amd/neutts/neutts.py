@@ -191,7 +191,7 @@ class NeuTTS:
         self._seed = seed
 
         # NeuCodec's GEMM operand format (the reference runs this decoder in fp32, ref:neutts/neutts.py:288-291): "fp16" (default) = IEEE-half
-        # operands, ~8e-4 RELATIVE rms of the fp32 decoder -- inside BASELINE's 1e-3 absolute at any amplitude; "high" = split bf16 operands
+        # operands, ~9.5e-4 RELATIVE rms of the fp32 decoder (8.1e-4 from the GEMM operands, the rest from the single-term fp16 ISTFT) -- inside BASELINE's 1e-3 absolute at any amplitude; "high" = split bf16 operands
         # (hi + lo), ~7e-4 at 3x the matrix-core work and bf16's range; "bf16" = rounds 1-5's default, 7e-3 relative
         if codec_precision not in ("fp16", "bf16", "high"):
             raise ValueError("codec_precision must be 'fp16', 'bf16' or 'high'")
