@@ -242,6 +242,52 @@ def test_generate_with_slot_and_page_recycling_logits(lib, model, monkeypatch):
         eng.close()
 
 
+def test_shared_prefix_slots_logits_vs_oracle(lib, model):
+    """prefix KV sharing (ntts_backbone_prefill_shared) against the ORACLE directly, not against
+    the engine's own plain prefill: six utterances of one "speaker" -- a common 200-token beginning, then 37 ... 120 tokens of their own -- are
+    prefilled with five of them re-using the first one's KV pages (192 tokens = 6 whole pages); the donor is released after two steps; every
+    step's logits row of the five SHARING slots (and of the donor while it lives) against the oracle's run of the full prompt, teacher-forced,
+    at the bars of the matrix above."""
+    w, wd, golds = model
+    rng = np.random.default_rng(77)
+    head = rng.integers(0, CFG.vocab_size - 1, 200).tolist()
+    tails = [37, 64, 65, 100, 120, 90]
+    prompts = [head + rng.integers(0, CFG.vocab_size - 1, t).tolist() for t in tails]
+    n = 10
+    gs = [Gold(p, br.generate(CFG, wd, p, len(p) + n, EOS, min_new_tokens=n, keep_logits=True)) for p in prompts]
+    eng = make_engine(CFG, w, lib, max_batch=16, max_context=384, max_prefill_tokens=4096, bf16_upload=True)
+    try:
+        eng.set_debug(True)
+        slots = [3, 0, 7, 15, 8, 12]
+        st0 = eng.kv_stats()
+        eng.prefill(prompts, slots, [samp_for(p, n) for p in prompts], [None] + [(slots[0], 200)] * 5)
+        assert eng.kv_stats()["prompt_tokens_shared"] - st0["prompt_tokens_shared"] == 5 * 192
+        e1, t1, s1 = teacher_forced_many(eng, slots, gs, 2)                       # donor + sharers, first token and one decode step
+        eng.release(slots[0])                                                     # the shared pages outlive their donor
+        stats, exact, tie = [s1], e1, t1
+        for k in range(2, n):
+            eng.decode(1)
+            for s, g in zip(slots[1:], gs[1:]):
+                ids, _ = eng.read(s)
+                assert len(ids) == k + 1
+                row = eng.read_logits(s)
+                stats.append(np.asarray([abs(float(row[int(i)]) - float(v)) / bf16_ulp(float(v)) for i, v in zip(g.topi[k], g.topv[k]) if np.isfinite(v)]))
+                if ids[-1] == g.ids[k]:
+                    exact += 1
+                else:
+                    cand = {int(i): float(v) for i, v in zip(g.topi[k], g.topv[k])}
+                    assert ids[-1] in cand and g.topv[k][0] - cand[ids[-1]] <= 2.0 * bf16_ulp(g.topv[k][0]), (s, k)
+                    tie += 1
+                    if k + 1 < n:
+                        eng.debug_force(s, g.ids[k])
+        check_stats("shared-prefix slots vs the oracle", exact, tie, np.concatenate(stats), 2 * 6 + (n - 2) * 5)
+        eng.release_many(slots[1:])
+        st = eng.kv_stats()
+        assert st["free_pages"] == st["total_pages"]
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("temperature", [0.7, 1.5])
 def test_sampling_draw_with_temperature(lib, model, temperature, monkeypatch):
     """north_star "greedy/temperature sampling": the device sampler's draw at temperature != 1 (the reference passes 1.0,
