@@ -242,6 +242,38 @@ def test_generate_with_slot_and_page_recycling_logits(lib, model, monkeypatch):
         eng.close()
 
 
+def test_both_decode_shapes_of_a_256_row_engine_give_the_same_bits(lib, model):
+    """ABI 9: an engine counts the decode chains of its arena at every decode call and switches between the single-chain shape and the gang's
+    (256-row o_proj / down_proj tiles, QKV column blocks per XCD, no row-block placement) with a captured graph per shape -- which is only safe
+    if the two shapes compute the same BITS (same K slices, same summation order per output element).  256 slots, the eight ragged prompts +
+    fillers, 6 steps: every checked slot's logits row identical between ntts_backbone_set_gang(1), (4), and (0) = counting (alone: the
+    single-chain shape)."""
+    w, wd, golds = model
+    B = 256
+    eng = make_engine(CFG, w, lib, max_batch=B, max_context=MAX_CTX, max_prefill_tokens=4096, bf16_upload=True)
+    try:
+        eng.set_debug(True)
+        slots = checked_slots(B)
+        rows = {}
+        for chains in (1, 4, 0):
+            eng.set_gang(chains)
+            fillers = fill(eng, B, slots, [g.prompt for g in golds], 7000, 8)
+            got = []
+            for k in range(6):
+                if k:
+                    eng.decode(1)
+                got.append([eng.read_logits(s).copy() for s in slots])
+            rows[chains] = got
+            eng.release_many(slots + fillers)
+        for k in range(6):
+            for j in range(len(slots)):
+                assert np.array_equal(rows[1][k][j], rows[4][k][j]), (k, j)
+                assert np.array_equal(rows[1][k][j], rows[0][k][j]), (k, j)
+    finally:
+        eng.set_gang(0)
+        eng.close()
+
+
 def test_shared_prefix_slots_logits_vs_oracle(lib, model):
     """prefix KV sharing (ntts_backbone_prefill_shared) against the ORACLE directly, not against
     the engine's own plain prefill: six utterances of one "speaker" -- a common 200-token beginning, then 37 ... 120 tokens of their own -- are
