@@ -477,8 +477,10 @@ def main():
 
     if cont:   # ragged requests, seeded: prompt lengths 0.7 .. 1.3 x S, generated lengths 0.6 .. 1.4 x N (means S and N)
         rng = np.random.default_rng(4321 + rank)
-        r_plen = rng.integers(int(S * 0.7), int(S * 1.3) + 1, size=R)
-        r_glen = rng.integers(int(N * 0.6), int(N * 1.4) + 1, size=R)
+        # (NTTS_BENCH_PSPREAD / _GSPREAD: diagnostic only -- 0 makes the prompts / the generated lengths all equal, to price raggedness itself)
+        psp, gsp = float(os.environ.get("NTTS_BENCH_PSPREAD", "0.3")), float(os.environ.get("NTTS_BENCH_GSPREAD", "0.4"))
+        r_plen = rng.integers(int(S * (1 - psp)), int(S * (1 + psp)) + 1, size=R)
+        r_glen = rng.integers(int(N * (1 - gsp)), int(N * (1 + gsp)) + 1, size=R)
         r_prompts = [syn.synthetic_prompt(cfg, lo * 8 + i, int(r_plen[i])) for i in range(R)]
         r_samp = [_hip.Sampling(max_length=int(r_plen[i] + r_glen[i]), min_new_tokens=int(r_glen[i]), eos_token_id=eos, do_sample=False)
                   for i in range(R)]
@@ -519,6 +521,24 @@ def main():
         stream beside the decode steps of the others."""
         ph = {"generate_wall": 0.0, "codec_tail_wall": 0.0, "codec_passes": 0}
         c0 = {k: sum(e.counters[k] for e in cengs) for k in eng.counters}
+        # where the launching thread's time goes: blocked on a snapshot (the GPU is ahead of the host: good) vs inside the enqueueing calls
+        host = {"poll_end": 0.0, "poll_begin": 0.0, "decode": 0.0, "prefill": 0.0, "activate": 0.0}
+        undo = []
+
+        def timed(e, name):
+            f = getattr(e, name)
+
+            def g(*aa, **kk):
+                t = time.perf_counter()
+                try:
+                    return f(*aa, **kk)
+                finally:
+                    host[name] += time.perf_counter() - t
+            setattr(e, name, g)
+            undo.append((e, name))
+        for e in cengs:
+            for name in list(host):
+                timed(e, name)
         t1 = time.time()
         st8 = [{"n": 0, "buf": 0, "lens": np.zeros(B, dtype=np.int32), "wavs": None, "busy": False} for _ in cengs]
         which = {id(e): k for k, e in enumerate(cengs)}
@@ -543,6 +563,13 @@ def main():
         codec_on_wave = int(os.environ.get("NTTS_BENCH_CODEC_ON_WAVE", "0"))           # > 0: also flush that many or more at an engine's admission
 
         def hook(i, slot, n_new, e=eng):
+            t = time.perf_counter()
+            try:
+                hook_body(i, slot, n_new, e)
+            finally:
+                host["on_finished"] = host.get("on_finished", 0.0) + time.perf_counter() - t
+
+        def hook_body(i, slot, n_new, e):
             assert n_new == int(r_glen[i]), "continuous run did not produce the expected tokens"
             tokens[0] += n_new
             done_at.append((time.time(), n_new))
@@ -569,8 +596,14 @@ def main():
             if codec is not None and codec_on_wave > 0:
                 # a codec pass holds its engine's lane like a prompt pass does: put it next to the admission wave
                 kw["on_admit"] = lambda e, n_prompts: flush(which[id(e)], st8[which[id(e)]]["n"]) if st8[which[id(e)]]["n"] >= codec_on_wave else None      # EngineGang.generate: how the engines' prompt passes are placed against each other
-        (gangc or eng).generate(r_prompts, r_samp, **kw)
+        try:
+            (gangc or eng).generate(r_prompts, r_samp, **kw)
+        finally:
+            for e, name in undo:
+                delattr(e, name)                              # (the instance attribute shadowing the method)
         ph["generate_wall"] = (time.time() - t1) * 1e3
+        ph["host_ms"] = {k: round(v * 1e3, 1) for k, v in host.items()}
+        ph["host_ms"]["python_between_calls"] = round(ph["generate_wall"] - sum(host.values()) * 1e3, 1)
         t1 = time.time()
         wavs = None
         if codec is not None:

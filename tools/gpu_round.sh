@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call = everything we want from a GPU box, each leg under its own timeout, logs in gpurun_out/.
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_round.sh [legs...]'
-# legs: smoke tests bench b1 nano prof pmc mfma sweep   (default: smoke tests bench prof)
+# legs: smoke tests bench b1 nano prof profcont pmc pmcgang mfma sweep   (default: smoke tests bench prof)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
@@ -49,6 +49,15 @@ for leg in $LEGS; do
              python tools/mfma_util_summary.py $OUT/pmc_mfma; } > $OUT/mfma_util.txt 2>&1; head -16 $OUT/mfma_util.txt; find $OUT/pmc_mfma -name '*.csv' -size +8M -delete;;
     sweep)  # SWEEP_KNOBS='[["NTTS_ATTN_DEPTH",[2]]]'
            timeout ${SWEEP_TIMEOUT:-400} python tools/sweep_decode.py --knobs "${SWEEP_KNOBS:-[[\"NTTS_ATTN_DEPTH\",[2]]]}" > $OUT/sweep.log 2>&1; echo "sweep rc=$?"; grep -v '^\[sweep\] weights' $OUT/sweep.log | tail -12;;
+    profcont) # where the ragged scheduler's time goes against the static schedule's: kernel traces of both, classed by phase over the middle of the run
+           for mode in static continuous; do
+             rm -rf $OUT/profcont_$mode
+             if [ $mode = static ]; then args="--steps 12 --warmup 0"; else args="--mode continuous --requests ${PROFCONT_REQUESTS:-4096} --steps 1 --warmup 0 --gang 4"; fi
+             NTTS_BENCH_PRIME_STEPS=2 timeout 600 rocprofv3 --kernel-trace -f csv -d $OUT/profcont_$mode -o t -- python bench.py $args --no-cpu-baseline --no-roofline > $OUT/profcont_$mode.json 2> $OUT/profcont_$mode.err; echo "profcont $mode rc=$?"
+             { echo "# rocprofv3 --kernel-trace -- python bench.py $args --no-cpu-baseline --no-roofline"; python tools/trace_classes.py $OUT/profcont_$mode 0.35 0.85; } > $OUT/profcont_${mode}_classes.txt 2>&1
+             cat $OUT/profcont_${mode}_classes.txt | cut -c1-170; cut -c1-600 $OUT/profcont_$mode.json; tail -3 $OUT/profcont_$mode.err
+             find $OUT/profcont_$mode -name '*.csv' -size +1M -delete
+           done;;
     nano)  for cfg in nano-fp8 nano-bf16; do timeout 300 python bench.py --config $cfg --steps ${BENCH_STEPS:-2} --warmup 1 --no-cpu-baseline > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err; echo "bench $cfg rc=$?"; cut -c1-1200 $OUT/bench_$cfg.json; tail -12 $OUT/bench_$cfg.err; done;;
     *) echo "unknown leg $leg";;
   esac

@@ -23,19 +23,22 @@ def main():
     ap.add_argument("--prefill", type=int, default=500)
     ap.add_argument("--sizes", type=int, nargs="*", default=[4, 8, 12, 16, 24, 32, 48, 64])
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--spread", type=float, default=0.0, help="prompt lengths uniform in prefill x (1 -+ spread) instead of all equal (what raggedness costs)")
     a = ap.parse_args()
     cfg = br.BackboneConfig.neutts_air(217488)
     w = br.make_weights(cfg, 0)
     wd = {k: v.to(torch.bfloat16).cuda() for k, v in w.items()}
     del w
     S, B = a.prefill, 256
-    prompts = [br.synthetic_prompt(cfg, i, S) for i in range(64)]
+    import numpy as np
+    lens = np.random.default_rng(5).integers(int(S * (1 - a.spread)), int(S * (1 + a.spread)) + 1, size=64) if a.spread > 0 else np.full(64, S)
+    prompts = [br.synthetic_prompt(cfg, i, int(lens[i])) for i in range(64)]
     e0 = _hip.BackboneEngine(dict(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
                                   num_layers=cfg.num_layers, num_heads=cfg.num_heads, num_kv_heads=cfg.num_kv_heads, rms_eps=cfg.rms_eps,
-                                  max_context=768, max_batch=B, max_prefill_tokens=64 * S, weight_dtype="bf16"), 0)
+                                  max_context=1024, max_batch=B, max_prefill_tokens=int(64 * S * (1 + a.spread)), weight_dtype="bf16"), 0)
     e0.load_state_dict(wd, inv_freq=br.rope_inv_freq(cfg).numpy())
     gang = _hip.EngineGang(e0, 4)
-    samp = _hip.Sampling(max_length=S + 250, min_new_tokens=250, eos_token_id=cfg.vocab_size - 1, do_sample=False)
+    samp = _hip.Sampling(max_length=int(S * (1 + a.spread)) + 250, min_new_tokens=250, eos_token_id=cfg.vocab_size - 1, do_sample=False)
 
     def run(engs, n):
         best = 1e9
@@ -52,8 +55,9 @@ def main():
 
     for n in a.sizes:
         one, four = run(gang.engines[:1], n), run(gang.engines, n)
-        print(json.dumps({"prompts": n, "tokens": n * S, "one_engine_ms": round(one, 3), "one_engine_us_per_token": round(one * 1e3 / (n * S), 3),
-                          "four_engines_at_once_ms": round(four, 3), "four_us_per_token": round(four * 1e3 / (4 * n * S), 3)}), flush=True)
+        T = int(lens[:n].sum())
+        print(json.dumps({"prompts": n, "tokens": T, "spread": a.spread, "one_engine_ms": round(one, 3), "one_engine_us_per_token": round(one * 1e3 / T, 3),
+                          "four_engines_at_once_ms": round(four, 3), "four_us_per_token": round(four * 1e3 / (4 * T), 3)}), flush=True)
     gang.close()
 
 
