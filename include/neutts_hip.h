@@ -505,9 +505,6 @@ int ntts_k_rmsnorm_bf16(const void* x, const void* w, void* y, int32_t rows, int
 /* Micro-benchmark of one GEMM tile configuration on synthetic operands (tools/ubench_gemm.py); see csrc/kapi.cpp. */
 int ntts_k_gemm_probe(int32_t M, int32_t N, int32_t K, int32_t config, int32_t abl, int32_t copies, int32_t iters,
                       double* us);
-/* Does GEMM tile configuration `config` of the probe above give the same BITS as the 256 x 256 / 16-wave tile (config 42)?  Random operands,
- * `reps` launches each compared on the device: *ndiff = differing outputs summed over the launches (0 = identical; the race screen of a schedule). */
-int ntts_k_gemm_check(int32_t M, int32_t N, int32_t K, int32_t config, int32_t reps, int64_t* ndiff);
 /* Achieved HBM copy bandwidth probe: copies `bytes` device->device `iters` times, returns GB/s. */
 int ntts_k_membw(size_t bytes, int32_t iters, double* gbps);
 /* Diagnostics: writes 3 x 64 x 4 floats describing the MFMA 16x16x32 lane layout (see csrc/kapi.cpp). */

@@ -130,9 +130,6 @@ static void probe_launch(const GemmArgs& a, int ks, int abl) {
     }
 }
 
-template <int ABL>
-static void probe_launch_8p(const GemmArgs& a) { gemm8p_launch<EPI_BF16, false, false, ABL>(a, 0); }
-
 static void probe_dispatch(int config, const GemmArgs& a, int ks, int abl) {
     switch (config) {
         case 0: NTTS_LAUNCH((empty_kernel), dim3(256), dim3(64), (hipStream_t)0, (int*)nullptr); break;
@@ -168,10 +165,6 @@ static void probe_dispatch(int config, const GemmArgs& a, int ks, int abl) {
         case 57: probe_launch<2, 4, 10, 2>(a, ks, abl); break;  // 320 x 256, 8 waves (160 x 64 per wave, 2 waves per SIMD: up to 256 registers each)
         case 58: probe_launch<2, 4, 12, 2>(a, ks, abl); break;  // 384 x 256, 8 waves (192 x 64 per wave)
         case 56: probe_launch<4, 4, 6, 2>(a, ks, abl); break;   // 384 x 256, 16 waves (96 x 64 per wave): 17 % fewer; 160 KB = all of a CU's LDS
-        case 70:   // 256 x 256, 8 waves in two alternating groups, staged in 16 KB units six phases ahead (gemm8p_kernel)
-            switch (abl) { case 1: probe_launch_8p<1>(a); break; case 2: probe_launch_8p<2>(a); break; case 3: probe_launch_8p<3>(a); break; case 4: probe_launch_8p<4>(a); break;
-                           case 7: probe_launch_8p<7>(a); break; default: probe_launch_8p<0>(a); break; }
-            break;
         default: break;
     }
 }
@@ -218,43 +211,6 @@ extern "C" int ntts_k_gemm_probe(int32_t M, int32_t N, int32_t K, int32_t config
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(X); hipFree(W); hipFree(C);
     return hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess ? NTTS_OK : NTTS_EHIP;
-}
-
-// Does tile configuration `config` compute the same BITS as the 256 x 256 / 16-wave tile (config 42)?  Random operands (the probe's hashed bf16
-// values), `reps` launches of `config`, each compared element by element on the device with one launch of 42: *ndiff = differing outputs
-// summed over the launches (0 = identical every time: also the race screen of a new schedule -- run it at several sizes, repeatedly).
-NTTS_KERNEL(256) void count_diff_kernel(const unsigned short* a, const unsigned short* b, long n, unsigned int* cnt) {
-    unsigned int c = 0;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) c += a[i] != b[i];
-    if (c) atomic_add_global(cnt, c);
-}
-extern "C" int ntts_k_gemm_check(int32_t M, int32_t N, int32_t K, int32_t config, int32_t reps, int64_t* ndiff) {
-    if (!ndiff || M < 1 || N < 16 || K < 64 || (K % 64) || reps < 1) return NTTS_EINVAL;
-    bf16_t *X = nullptr, *W = nullptr, *C0 = nullptr, *C1 = nullptr;
-    unsigned int* cnt = nullptr;
-    if (hipMalloc((void**)&X, (size_t)M * K * 2) != hipSuccess || hipMalloc((void**)&W, (size_t)N * K * 2) != hipSuccess ||
-        hipMalloc((void**)&C0, (size_t)M * N * 2) != hipSuccess || hipMalloc((void**)&C1, (size_t)M * N * 2) != hipSuccess ||
-        hipMalloc((void**)&cnt, 4) != hipSuccess)
-        return NTTS_ENOMEM;
-    NTTS_LAUNCH((random_fill_kernel), dim3(2048), dim3(256), (hipStream_t)0, X, (long)M * K, 0x9e3779b9u);
-    NTTS_LAUNCH((random_fill_kernel), dim3(2048), dim3(256), (hipStream_t)0, W, (long)N * K, 0x85ebca6bu);
-    hipMemset(cnt, 0, 4);
-    hipMemset(C0, 0xff, (size_t)M * N * 2);
-    GemmArgs a{};
-    a.X = X; a.ldx = K; a.W = W; a.ldw = K; a.ldo = N; a.M = M; a.N = N; a.K = K;
-    a.out = C0;
-    probe_dispatch(42, a, 1, 0);
-    for (int r = 0; r < reps; ++r) {
-        hipMemsetAsync(C1, 0xee, (size_t)M * N * 2, 0);
-        a.out = C1;
-        probe_dispatch(config, a, 1, 0);
-        NTTS_LAUNCH((count_diff_kernel), dim3(1024), dim3(256), (hipStream_t)0, (const unsigned short*)C0, (const unsigned short*)C1, (long)M * N, cnt);
-    }
-    unsigned int h = 0;
-    const bool ok = hipMemcpy(&h, cnt, 4, hipMemcpyDeviceToHost) == hipSuccess && hipDeviceSynchronize() == hipSuccess;
-    *ndiff = h;
-    hipFree(X); hipFree(W); hipFree(C0); hipFree(C1); hipFree(cnt);
-    return ok && hipGetLastError() == hipSuccess ? NTTS_OK : NTTS_EHIP;
 }
 
 // MFMA lane-layout probe (diagnostics): three products whose results spell out which (row, col) each

@@ -23,7 +23,6 @@
 //   * split-K (gridDim.y) writes fp32 slabs that the consumer kernel reduces (no in-launch hand-off).
 #pragma once
 #include <ntts/dev.h>
-#include <type_traits>
 
 namespace ntts {
 
@@ -670,196 +669,15 @@ NTTS_KERNEL(WM * WN * 64) void gemm_kernel(GemmArgs p) {
 // prologues (2.33 vs 1.95 ms per decode step at batch 256: one 4-wave workgroup per CU cannot overlap its LDS-read -> MFMA
 // chains).
 
-// ------------------------------------------------------------------------------------------------
-// The 256 x 256 tile on EIGHT waves in two groups that take turns on the matrix cores (round 6; the "8-phase" schedule of
-// cdna_hip_programming.md section 5, laid out for this file's operand images and epilogues).  The 16-wave kernel above reads 64 x 64 per
-// wave -- 256 KB of LDS fragment reads per 64-wide K tile next to the 64 KB the LDS-DMA writes: the LDS port is as busy as the matrix
-// cores, and every tile ends at a barrier that waits for the NEXT tile's slowest line with one tile in flight.  Here
-//   * a wave owns 128 rows x 64 features (wave (wr, wc) of 2 x 4): 192 KB of fragment reads per K tile;
-//   * a K tile is computed in FOUR phases of 16 matrix-core instructions (one 64 x 32 quadrant of the wave's tile, K = 64), each with
-//     its own small load section in front: phase 0 reads W0 | X0 (the quarter's features 0-31, the half's rows 0-63), 1 reads W1,
-//     2 reads X1 over X0's registers, 3 reads nothing -- quadrants (X0,W0) (X0,W1) (X1,W1) (X1,W0), every accumulator element still
-//     sees the K tiles in ascending order and k-step 0 before 1: the same bits as gemm_kernel;
-//   * group wr = 1 runs ONE barrier behind group 0, so between two consecutive barriers one wave of every SIMD issues its 16 matrix-core
-//     instructions (at raised priority) while the other issues its LDS reads and LDS-DMA requests: the pipe does not wait for a read;
-//   * the K tile is staged in four UNITS of 16 KB -- UX0 / UW0 / UW1 / UX1, exactly what phases 0 / 0 / 1 / 2 read -- one unit per phase,
-//     D = 6 phases ahead of the phase that reads it, into the two tile buffers (128 KB): four to six units (64-96 KB) are in flight at
-//     any time and no wait ever drains the queue.  Ordering rules (MI355X_MICROARCH.md, LDS-DMA visibility): unit k is needed in phase
-//     k, k - 1, k - 1, k - 1 (by type); every wave waits in the load section of phase f until its pieces of the units <= f + 2 have
-//     landed (a counted vmcnt: D - 2 units may stay outstanding), i.e. ONE PHASE BEFORE they are read -- with the groups one barrier
-//     apart, that is the barrier both have passed; unit k overwrites unit k - 8, last read in phase k - 8 or k - 9: staged in phase
-//     k - 6, two phases (>= three barriers for either group) after those reads were retired by the reader's lgkmcnt(0).
-// Everything else -- operand images (128-byte rows, chunk c of row r at c ^ ((r >> 1) & 7)), the feature permutation of the W rows, the
-// tile map, the epilogues (called once per 64-row half of the wave's tile) -- is gemm_kernel's.
-template <int EPI, bool F8 = false, bool F16 = false, int ABL = 0>
-NTTS_KERNEL(512) void gemm8p_kernel(GemmArgs p) {
-    static_assert(!F16 || (!F8 && (EPI == EPI_BF16 || EPI == EPI_BF16_SILU || EPI == EPI_F32)), "fp16 operands: codec GEMMs");
-    constexpr int ESZ = F8 ? 1 : 2;
-    constexpr int BM = 256, BN = 256, BK = 64, ROWS = BM + BN, D = 6;
-    NTTS_SHARED bf16_t lds[2 * ROWS * BK];
-    const int lane = lane_id(), wave = wave_id();
-    const int wr = wave >> 2, wc = wave & 3;
-    const int g = lane >> 4, l15 = lane & 15;
-    int mb, nb;
-    gemm_tile_coords(blockIdx.x, p.mblocks, p.nblocks, mb, nb);
-    const int m0 = mb * BM, n0 = nb * BN;
-    const int nk = F8 ? p.K >> 7 : p.K >> 6;
-    const int nunits = nk * 4;
-
-    // ---- loader: unit type i = 0 UX0, 1 UW0, 2 UW1, 3 UX1; a unit is 16 pieces of 1 KB (8 LDS rows), wave w brings pieces w and w + 8
-    const char* src[4][2];
-    int dst[4][2];                                    // element offset of the piece inside a tile buffer (wave-uniform)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int i2 = 0; i2 < 2; ++i2) {
-            const bool isx = i == 0 || i == 3;
-            const int rho0 = isx ? i2 * 128 + (i == 3 ? 64 : 0) + wave * 8
-                                 : BM + ((wave >> 2) + 2 * i2) * 64 + (i == 2 ? 32 : 0) + (wave & 3) * 8;
-            const int rho = rho0 + (lane >> 3);
-            const int c = (lane & 7) ^ ((rho >> 1) & 7);
-            dst[i][i2] = rho0 * BK;
-            if (isx) {
-                int m = m0 + rho;
-                if (m > p.M - 1) m = p.M - 1;
-                src[i][i2] = (const char*)p.X + (long)m * p.ldx * ESZ + c * 16;
-            } else {
-                const int q = rho - BM;                // tile-major W row: q = wq*64 + j*16 + i16 (gemm_kernel)
-                const int wq = q >> 6, j = (q >> 4) & 3, i16 = q & 15;
-                int n = n0 + wq * 64 + (i16 >> 2) * 16 + j * 4 + (i16 & 3);
-                if (n > p.N - 1) n = p.N - 1;
-                src[i][i2] = p.w_tile_major ? (const char*)p.W + (long)(n >> 6) * 64 * p.K * ESZ + (n & 63) * 128 + c * 16
-                                            : (const char*)p.W + (long)n * p.ldw * ESZ + c * 16;
-            }
-        }
-    const long xstep = p.x_kt_stride > 0 ? p.x_kt_stride : 128;
-    const long wstep = p.w_tile_major ? 8192 : 128;
-    auto stage = [&](auto IC, int u) {                // unit type IC of K tile u
-        constexpr int I = decltype(IC)::value;
-        if constexpr (ABL & 2) return;
-        bf16_t* b = lds + (u & 1) * (ROWS * BK);
-        const long off = (long)u * ((I == 0 || I == 3) ? xstep : wstep);
-        glds16(src[I][0] + off, b + dst[I][0]);
-        glds16(src[I][1] + off, b + dst[I][1]);
-    };
-    // at most n UNITS (two requests each) of this wave may still be outstanding
-    auto wait_units = [&](int n) {
-        if (n >= 4) wait_vmem_le<8>();
-        else if (n == 3) wait_vmem_le<6>();
-        else if (n == 2) wait_vmem_le<4>();
-        else if (n == 1) wait_vmem_le<2>();
-        else wait_vmem();
-    };
-
-    f32x4 acc[8][4];
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[a][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // ---- fragment addresses (elements inside a tile buffer): row * 64 + swizzled chunk; blocks of 16 rows are 1024 elements apart
-    const int sw = (l15 >> 1) & 7;
-    int xa[2], wb[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        xa[ks] = (wr * 128 + l15) * BK + (((ks * 4 + g) ^ sw) << 3);
-        wb[ks] = (BM + wc * 64 + l15) * BK + (((ks * 4 + g) ^ sw) << 3);
-    }
-    bf16x8 xb[4][2], wa[4][2];                         // X0 or X1 (64 rows), W0 | W1 (32 + 32 features), both k-steps
-
-    // ---- prologue: the first D units on their way, the two that phase 0 reads landed
-    static_assert(D == 6, "the prologue below stages units 0 .. 5");
-    stage(std::integral_constant<int, 0>{}, 0);
-    stage(std::integral_constant<int, 1>{}, 0);
-    stage(std::integral_constant<int, 2>{}, 0);
-    stage(std::integral_constant<int, 3>{}, 0);
-    if (nk > 1) {
-        stage(std::integral_constant<int, 0>{}, 1);
-        stage(std::integral_constant<int, 1>{}, 1);
-    }
-    wait_units((D - 1 < nunits - 1 ? D - 1 : nunits - 1) - 1);
-    barrier_raw();
-    if (wr == 1) barrier_raw();                        // group 1 runs one barrier behind group 0 from here to the end of the loop
-
-    auto phase = [&](auto PC, int t) {
-        constexpr int P = decltype(PC)::value;
-        const bf16_t* base = lds + (t & 1) * (ROWS * BK);
-        // -- load section: this phase's fragments, the unit D phases ahead, the counted wait for the units the NEXT phase reads
-        if constexpr (!(ABL & 1)) {
-            if constexpr (P == 0) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) wa[j][ks] = ld16<bf16x8>(base + wb[ks] + j * 1024);
-                sched_fence();
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) xb[a][ks] = ld16<bf16x8>(base + xa[ks] + a * 1024);
-            } else if constexpr (P == 1) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int j = 2; j < 4; ++j) wa[j][ks] = ld16<bf16x8>(base + wb[ks] + j * 1024);
-            } else if constexpr (P == 2) {
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) xb[a][ks] = ld16<bf16x8>(base + xa[ks] + (4 + a) * 1024);
-            }
-        }
-        const int k = 4 * t + P + D;
-        if (k < nunits) stage(std::integral_constant<int, ((P + D) & 3)>{}, k >> 2);
-        wait_units((k < nunits ? k : nunits - 1) - (4 * t + P + 2));
-        barrier_raw();
-        // -- matrix-core section: one quadrant, K = 64
-        wait_lds();
-        if constexpr (!(ABL & 1)) {
-            prio_hi();
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        constexpr int jb = (P == 0 || P == 3) ? 0 : 2, ab = P < 2 ? 0 : 4;
-                        const int j = jb + jj, A = ab + a;
-                        if constexpr (F8) {
-                            const i64x2 w2 = __builtin_bit_cast(i64x2, wa[j][ks]), x2 = __builtin_bit_cast(i64x2, xb[a][ks]);
-                            acc[A][j] = mfma16_fp8(w2[0], x2[0], acc[A][j]);
-                            acc[A][j] = mfma16_fp8(w2[1], x2[1], acc[A][j]);
-                        } else {
-                            acc[A][j] = mfma16_op<F16>(wa[j][ks], xb[a][ks], acc[A][j]);
-                        }
-                    }
-            prio_lo();
-        }
-        barrier_raw();
-    };
-    for (int t = 0; t < nk; ++t) {
-        phase(std::integral_constant<int, 0>{}, t);
-        phase(std::integral_constant<int, 1>{}, t);
-        phase(std::integral_constant<int, 2>{}, t);
-        phase(std::integral_constant<int, 3>{}, t);
-    }
-    if (wr == 0) barrier_raw();                        // (every wave has called the barrier the same number of times)
-
-    if constexpr (ABL & 4) {
-        if (acc[0][0][0] != 12345.678f) return;        // keeps the accumulators live without storing
-    }
-    gemm_epilogue<4, EPI, 4, F8, F16>(p, *reinterpret_cast<f32x4 (*)[4][4]>(&acc[0]), m0 + wr * 128, n0, wc, nb, 0);
-    gemm_epilogue<4, EPI, 4, F8, F16>(p, *reinterpret_cast<f32x4 (*)[4][4]>(&acc[4]), m0 + wr * 128 + 64, n0, wc, nb, 0);
-}
-
-template <int EPI, bool F8 = false, bool F16 = false, int ABL = 0>
-inline void gemm8p_launch(GemmArgs p, hipStream_t s) {
-    p.mblocks = (p.M + 255) / 256;
-    p.nblocks = (p.N + 255) / 256;
-    p.k_tiles_per_split = p.K / (F8 ? 128 : 64);
-    p.xcd_maffine = 0;
-    p.xcd_nsplit = 0;
-    NTTS_LAUNCH((gemm8p_kernel<EPI, F8, F16, ABL>), dim3(p.mblocks * p.nblocks), dim3(512), s, p);
-}
+// Measured on MI355X and removed (round 6; profiles/r06g_ubench_gemm_8phase.txt, the kernel is in the history: commit "Experiment: 256x256 GEMM on
+// eight waves ..."): the 256 x 256 tile on EIGHT waves (128 x 64 per wave) in two groups one barrier apart that take turns on the matrix cores, a K tile
+// computed in four phases of 16 matrix-core instructions and staged in four 16 KB units six phases ahead with counted waits that never drain the queue
+// (the guide's "8-phase" schedule on this file's operand images and epilogues; bit-identical to the tile above at every size tried, 48 launches).  Its
+// LDS-DMA stream alone runs 1.4x faster than this kernel's (8192^3: 535 vs 763 us with the matrix cores ablated) and its matrix cores alone slightly
+// slower (545 vs 512 us), but together on random operands: 8192^3 1278-1287 vs 1206-1242 TFLOP/s, 4096^3 1171-1247 vs 1157-1197, codec fc1 965-981 vs
+// 935-947, prefill down_proj 1023-1028 vs 990-1018, prefill gate/up 898-901 vs 939-952, prefill QKV 728-732 vs 776-779, lm_head (stores ablated) 100.6 vs
+// 104.7 us.  Under the board's power limit the two halves do not overlap any better than before, and at K = 896 a quarter to a third of a tile's time is
+// its epilogue on two waves per SIMD (gate/up: 620 -> 430 us with the stores ablated), which no main-loop schedule touches: +-5 % by shape, not adopted.
 
 // ------------------------------------------------------------------------------------------------
 // host launchers

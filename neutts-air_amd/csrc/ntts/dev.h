@@ -110,14 +110,6 @@ NTTS_D void sync_keep_dma() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" :
 // The same instruction sequence where the point is that ordinary global loads (register prefetch rings) stay in flight:
 // a workgroup barrier that orders LDS traffic only.  Use it when what the barrier publishes lives in LDS.
 NTTS_D void lds_barrier() { sync_keep_dma(); }
-// The pieces of sync_keep_dma() on their own, for schedules that put work between them (gemm8p_kernel: the rendezvous first, the wait
-// for the wave's own LDS reads after it, so that the read latency runs under the barrier): a bare s_barrier -- no counter is drained --
-// and the lgkmcnt wait.  prio_hi / prio_lo: the wave's issue priority around a matrix-core cluster (the partner wave on the SIMD fills
-// the gaps with its LDS reads and LDS-DMA requests instead of competing for the MFMA pipe).
-NTTS_D void barrier_raw() { asm volatile("s_barrier" ::: "memory"); }
-NTTS_D void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-NTTS_D void prio_hi() { __builtin_amdgcn_s_setprio(1); }
-NTTS_D void prio_lo() { __builtin_amdgcn_s_setprio(0); }
 // nothing is scheduled across this point by the compiler (issue order of memory requests matters: in-order returns)
 NTTS_D void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 

@@ -165,7 +165,6 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "ntts_stream_destroy": (C.c_int, [i32, p]),
         "ntts_k_gemm_bf16": (C.c_int, [p, i64, p, p, p, i64, i32, i32, i32, i32]),
         "ntts_k_gemm_probe": (C.c_int, [i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_double)]),
-        "ntts_k_gemm_check": (C.c_int, [i32, i32, i32, i32, i32, C.POINTER(i64)]),
         "ntts_k_rmsnorm_bf16": (C.c_int, [p, p, p, i32, i32, f32]),
         "ntts_k_fp8_quantize": (C.c_int, [p, p, i64, f32]),
         "ntts_k_gemm_fp8": (C.c_int, [p, p, p, f32, p, p, i32, i32, i32, i32]),

@@ -283,10 +283,6 @@ NTTS_D unsigned long long now_ticks() { return 0; }   // no clock on the emulato
 inline void wait_vmem() {}
 inline void sync_keep_dma() { emu::barrier(); }
 inline void lds_barrier() { emu::barrier(); }
-inline void barrier_raw() { emu::barrier(); }
-inline void wait_lds() {}
-inline void prio_hi() {}
-inline void prio_lo() {}
 inline void sched_fence() {}
 template <int N>
 inline void wait_vmem_le() {}

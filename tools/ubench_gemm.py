@@ -16,7 +16,7 @@ CONFIGS = {10: "64x64 4w NS2", 11: "64x64 4w NS3", 12: "64x64 4w NS4", 13: "64x6
            21: "64x64 2w NS4", 22: "64x64 1w NS4", 23: "64x128 4w NS3", 24: "64x128 8w NS3", 25: "128x64 8w NS3",
            26: "128x64 4w NS3", 30: "128x128 4w NS2", 31: "128x128 4w NS3", 40: "256x128 8w NS2", 41: "128x256 8w NS2",
            42: "256x256 16w NS2", 43: "256x128 8w NS3", 44: "256x128 4w NS2", 45: "256x256 8w NS2", 46: "256x256 16w 4xK32", 47: "256x256 16w 3xK32", 48: "256x256 8w 4xK32", 49: "128x128 4w 4xK32", 60: "256x256 16w persist", 50: "256x64 4w NS3", 51: "256x64 8w NS3",
-           52: "256x64 8w NS2", 53: "256x128 16w NS2", 54: "128x128 8w NS3", 55: "320x256 16w NS2", 56: "384x256 16w NS2", 57: "320x256 8w NS2", 58: "384x256 8w NS2", 70: "256x256 8w 8-phase"}
+           52: "256x64 8w NS2", 53: "256x128 16w NS2", 54: "128x128 8w NS3", 55: "320x256 16w NS2", 56: "384x256 16w NS2", 57: "320x256 8w NS2", 58: "384x256 8w NS2"}
 
 
 def probe(M, N, K, cfg, abl, copies, iters=200):
@@ -136,31 +136,7 @@ def layout():
             print(f"  {CONFIGS[cfg]:18s} row-major {c0:7.2f}  tile-major {c1:7.2f}", flush=True)
 
 
-def eight_phase():
-    """round 6: the 8-wave / two-group / unit-staged 256 x 256 schedule (gemm8p_kernel, config 70) against the 16-wave tile (42): first the
-    bits (ntts_k_gemm_check: every output element of `reps` launches compared with config 42's, random operands, sizes with edges), then
-    the time on random operands, sustained, A/B/A in one process."""
-    for (M, N, K) in ((256, 256, 64), (256, 256, 128), (256, 256, 896), (512, 768, 448), (300, 520, 192), (1000, 1000, 1024), (4096, 4096, 4096), (32000, 9728, 896)):
-        nd = C.c_int64(-1)
-        rc = lib.ntts_k_gemm_check(M, N, K, 70, 6, C.byref(nd))
-        print(f"check M={M} N={N} K={K}: rc {rc}, differing outputs over 6 launches: {nd.value}", flush=True)
-    shapes = dict(PREFILL)
-    shapes["square_4096"] = (4096, 4096, 4096)
-    shapes["square_8192"] = (8192, 8192, 8192)
-    for name, (M, N, K) in shapes.items():
-        fl = 2.0 * M * N * K
-        it = 40 if fl < 2e11 else 12
-        print(f"== {name}  M={M} N={N} K={K}  {fl / 1e12:.2f} TFLOP, random operands")
-        print(f"{'config':20s} {'us':>9s} {'TF/s':>7s} | ablations us: {'noMFMA':>9s} {'noDMA':>9s} {'noStore':>9s}")
-        for cfg in (42, 70, 42, 70):
-            t = probe(M, N, K, cfg, 32, 1, iters=it)
-            ab = [probe(M, N, K, cfg, 32 | a_, 1, iters=max(4, it // 3)) for a_ in (1, 2, 4)]
-            print(f"{CONFIGS[cfg]:20s} {t:9.1f} {fl / t / 1e6:7.0f} | {'':14s} {ab[0]:9.1f} {ab[1]:9.1f} {ab[2]:9.1f}", flush=True)
-
-
 def main():
-    if "--8p" in sys.argv:
-        return eight_phase()
     if "--head" in sys.argv:
         return head()
     if "--layout" in sys.argv:
