@@ -25,13 +25,13 @@
 #define NTTS_HD inline
 #define NTTS_D inline
 #define NTTS_KERNEL(threads) static
-#define NTTS_SHARED static __attribute__((aligned(16)))
+#define NTTS_SHARED static thread_local __attribute__((aligned(16)))   // one "LDS" per OS thread that runs workgroups (emu.cpp)
 
 struct dim3 {
     unsigned x, y, z;
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
-extern dim3 threadIdx, blockIdx, blockDim, gridDim;
+extern thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
 
 namespace emu {
 void launch(const std::function<void()>& body, dim3 grid, dim3 block);
@@ -276,9 +276,13 @@ inline void glds16(const void* gsrc, void* lds_wave_base) {
     memcpy((char*)d0.l + lane_id() * 16, gsrc, 16);
 }
 inline void glds16_nt(const void* gsrc, void* lds_wave_base) { glds16(gsrc, lds_wave_base); }
-inline unsigned int atomic_add_global(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = o + v; return o; }
+inline unsigned int atomic_add_global(unsigned int* p, unsigned int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }   // (workgroups run on several OS threads)
 inline unsigned int atomic_add_lds(unsigned int* p, unsigned int v) { unsigned int o = *p; *p = o + v; return o; }
-inline unsigned int atomic_max_global_u32(unsigned int* p, unsigned int v) { unsigned int o = *p; if (v > o) *p = v; return o; }
+inline unsigned int atomic_max_global_u32(unsigned int* p, unsigned int v) {
+    unsigned int o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v > o && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return o;
+}
 NTTS_D unsigned long long now_ticks() { return 0; }   // no clock on the emulator
 inline void wait_vmem() {}
 inline void sync_keep_dma() { emu::barrier(); }
