@@ -155,9 +155,11 @@ def mfma_util_table(path):
 
 def continuous_leg(static_value, a):
     import subprocess
-    req = int(os.environ.get("NTTS_BENCH_CONT_REQUESTS", "16384"))    # (16 generations of the gang's 1024 slots, ~ 27 s: the finite job's ramp and drain cost 4 % of an 8192-request job, 1 / 4 of a 4096-request job's time)
-    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "continuous", "--requests", str(req), "--steps", "1", "--warmup", "1",
+    req = int(os.environ.get("NTTS_BENCH_CONT_REQUESTS", "32768"))    # (16 generations of the gang's 2048 slots, ~ 48 s: the finite job's ramp and drain cost 4 % of half that job, 1 / 4 of an eighth's time)
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "continuous", "--requests", str(req), "--steps", "1", "--warmup", "1", "--warmup-requests", str(req // 8),
            "--no-cpu-baseline", "--no-roofline", "--gang", str(max(1, a.gang)), "--prefill", str(a.prefill), "--decode", str(a.decode)]
+    if os.environ.get("NTTS_BENCH_CONT_SLOTS"):
+        cmd += ["--engine-slots", os.environ["NTTS_BENCH_CONT_SLOTS"]]
     t0 = time.time()
     try:
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=float(os.environ.get("NTTS_BENCH_CONT_TIMEOUT", "240")))
@@ -202,12 +204,19 @@ def rocprof_symbols(path, live):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)       # (the driver's own --steps 20 --warmup 5: the no-flag run is the same measurement)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=["air-bf16", "nano-fp8", "nano-bf16"], default="air-bf16",
                     help="air-bf16: NeuTTS-Air bf16 (BASELINE.json configs[1..3], the headline metric); nano-fp8: the assumed NeuTTS-Nano "
                          "geometry with fp8 weights / GEMM inputs, batch 512 (configs[4])")
     ap.add_argument("--batch", type=int, default=None, help="utterances per GPU (default 256; 512 for --config nano-fp8)")
+    ap.add_argument("--engine-slots", type=int, default=None,
+                    help="static (one gang) and continuous mode: decode slots of every engine of the gang.  An engine steps ALL its rows in lock-step "
+                         "(one chain; from 512 rows its wide decode shape, GEMMs of that many rows), so a gang step holds gang x slots utterances = "
+                         "gang x slots / batch batches of the contract (a `step` stays ONE batch of --batch utterances).  Default for NeuTTS-Air with "
+                         "--gang > 1: static -- the --steps K batches are spread evenly over the fewest gang steps of at most 1024 slots per engine "
+                         "(K = 20: two gang steps of 10 batches, 640 slots; K = 16: one of 16, 1024 slots; K <= 4: 256 slots); continuous -- 512.  "
+                         "Round 6, 4 engines, codec-tokens/s: 256 slots 166 k, 512 191 k, 640 190 k, 768 195 k, 1024 196 k (profiles/r06h_*).")
     ap.add_argument("--prefill", type=int, default=500)
     ap.add_argument("--decode", type=int, default=250)
     ap.add_argument("--vocab", type=int, default=None, help="default: 217488 (NeuTTS-Air), 142080 (assumed Nano)")
@@ -222,6 +231,7 @@ def main():
     ap.add_argument("--sample", action="store_true",
                     help="the reference's own sampling call (ref:neutts/neutts.py:338-347: do_sample=True, top_k=50, temperature=1.0; seeded) "
                          "instead of greedy: radix select + Philox multinomial on the bf16 logits rows")
+    ap.add_argument("--warmup-requests", type=int, default=None, help="continuous mode: a warm-up step runs the first that many requests only (default: all of them)")
     ap.add_argument("--requests", type=int, default=None, help="continuous mode: requests per step (default 4 x batch)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="static mode: ONE backbone engine, batches strictly one after the other (round-2 shape).  Default: a gang of --gang engines "
@@ -330,9 +340,22 @@ def main():
     fp8_scales = syn.default_fp8_input_scales(cfg) if fp8 else None
     ccfg = syn.CodecConfig.tiny() if a.tiny else syn.CodecConfig.neucodec()
     n_codes = int(np.prod(ccfg.levels))
-    B, S, N = a.batch, a.prefill, a.decode
+    Q, S, N = a.batch, a.prefill, a.decode          # Q = the batch of BASELINE's metric = one `step` of the contract
     cont = a.mode == "continuous"
     strm = a.mode == "stream"
+    # B = decode slots per engine.  An engine of the gang steps all its rows in lock-step, so it may hold more than one batch of the contract:
+    # static mode spreads the K batches of the timed region evenly over the fewest gang steps (at most 1024 slots per engine)
+    wide_ok = Q > 1 and a.gang > 1 and (cont or (a.mode == "static" and not a.no_pipeline and a.gangs == 1))
+    B = Q
+    if wide_ok and a.engine_slots is not None:
+        B = max(1, a.engine_slots)
+    elif wide_ok and not nano and not a.tiny:
+        if cont:
+            B = 2 * Q
+        else:
+            n_gs = -(-(a.steps * Q) // (a.gang * 1024))                       # gang steps in the timed region
+            per_gs = -(-a.steps // n_gs)                                      # batches per gang step
+            B = max(Q, -(-(per_gs * Q) // (a.gang * 64)) * 64)
     R = a.requests or 4 * B * (max(1, a.gang) if (a.mode == "continuous" and B > 1) else 1)
     S_max, N_max = (int(S * 1.3) + 1, int(N * 1.4) + 1) if cont else (S, N)
     dev = 0 if emu_lib else local
@@ -514,7 +537,7 @@ def main():
             stage_codes = [[torch.zeros((B, N_max), dtype=torch.int32, device=f"cuda:{dev}") for _ in range(2)] for _ in cengs]
             stage_lens = [[torch.zeros(B, dtype=torch.int32, device=f"cuda:{dev}") for _ in range(2)] for _ in cengs]
 
-    def one_step_continuous(collect=False, last=False):
+    def one_step_continuous(collect=False, last=False, nreq=None):
         """One pass over R ragged requests: continuous batching (BackboneEngine.generate: admission by free slots, KV pages and
         prefill budget; ONE burst of decode steps always queued ahead of the host's bookkeeping; finished slots exported on the
         device, released and refilled, new prompts admitted 24 at a time and the engines of a gang in waves -- EngineGang.generate), the codec over every B finished utterances on its own
@@ -597,7 +620,8 @@ def main():
                 # a codec pass holds its engine's lane like a prompt pass does: put it next to the admission wave
                 kw["on_admit"] = lambda e, n_prompts: flush(which[id(e)], st8[which[id(e)]]["n"]) if st8[which[id(e)]]["n"] >= codec_on_wave else None      # EngineGang.generate: how the engines' prompt passes are placed against each other
         try:
-            (gangc or eng).generate(r_prompts, r_samp, **kw)
+            nreq = len(r_prompts) if nreq is None else min(nreq, len(r_prompts))       # (a warm-up pass may take the first requests only)
+            (gangc or eng).generate(r_prompts[:nreq], r_samp[:nreq], **kw)
         finally:
             for e, name in undo:
                 delattr(e, name)                              # (the instance attribute shadowing the method)
@@ -619,7 +643,7 @@ def main():
                 e.sync()
         ph["codec_tail_wall"] = (time.time() - t1) * 1e3
         cont_tokens[0] = tokens[0]
-        assert tokens[0] == int(r_glen.sum())
+        assert tokens[0] == int(r_glen[:nreq].sum())
         ph.update({k: sum(e.counters[k] for e in cengs) - c0[k] for k in c0})       # scheduler diagnostics: decode steps issued, prompt passes and their sizes
         ph["slot_occupancy"] = tokens[0] / max(1, ph["decode_steps"] * B)
         ph["park_slots_per_engine"] = eng.park_slots
@@ -642,15 +666,17 @@ def main():
         """Wait for the codec passes enqueued by the previous step (each is ordered behind its batch's decode loop and code export, so
         those are done too) and check that every utterance produced its N tokens: export_codes wrote the counts next to the codes."""
         while pending:
-            cdc, lb = pending.pop(0)
+            cdc, lb, *rows_ = pending.pop(0)
             cdc.sync()
             got = lb if emu_lib else lb.cpu().numpy()
-            assert (np.asarray(got) == N).all(), "bench run did not produce the expected tokens"
+            assert (np.asarray(got)[:rows_[0] if rows_ else B] == N).all(), "bench run did not produce the expected tokens"
 
-    def prefill_all(e):
+    def prefill_all(e, rows=None):
+        """prompt passes of the first `rows` slots of engine e (default: all of its B slots), --prefill-chunk prompts per call"""
+        rows = B if rows is None else rows
         each = []
-        for c in range(0, B, a.prefill_chunk):
-            n = min(a.prefill_chunk, B - c)
+        for c in range(0, rows, a.prefill_chunk):
+            n = min(a.prefill_chunk, rows - c)
             tc0 = time.time()
             e.prefill(prompts[c:c + n], list(range(c, c + n)), samps[c:c + n] if samps else [samp] * n)
             each.append(round((time.time() - tc0) * 1e3, 1))
@@ -717,15 +743,22 @@ def main():
         ph["host_wall_total"] = (tw[4] - tw[0]) * 1e3
         return ph, None, wavs
 
+    def rows_of(nbq):
+        """`nbq` batches of Q utterances dealt out over the gang's engines, B rows each: the rows each engine holds (the last one may be part-filled)"""
+        total = nbq * Q
+        return [min(B, total - k * B) for k in range((total + B - 1) // B)]
+
     def gang_step_single(nb, nb_next):
-        """--gangs 1: the one gang's `nb` batches, phase after phase, every engine on its own lane: [prompt passes side by side] (enqueued
-        at the end of the previous step, behind its codec passes) [decode chains side by side] [export + codec passes side by side]."""
-        cur = engs[:nb]
+        """--gangs 1: the one gang's `nb` batches (dealt out B rows per engine, in lock-step there), phase after phase, every engine on its own lane:
+        [prompt passes side by side] (enqueued at the end of the previous step, behind its codec passes) [decode chains side by side]
+        [export + codec passes side by side]."""
+        rows = rows_of(nb)
+        cur = engs[:len(rows)]
         ph = {}
         tw = [time.time()]
         each = []
-        for e in cur[pstate["ready"][0]:]:
-            each += prefill_all(e)
+        for e, r in list(zip(cur, rows))[pstate["ready"][0]:]:
+            each += prefill_all(e, r)
         ph["host_wall_prefill_each"] = each
         tw.append(time.time())
         decode_gang(cur, N - 1)
@@ -733,19 +766,20 @@ def main():
         wavs = None
         if codec is not None:
             finish_pending()                                        # the previous step's waveforms have left the pinned buffers (enqueued a whole decode phase ago)
-            for j, e in enumerate(cur):
-                e.export_codes(list(range(B)), 0, n_codes, codes_ptrs[j], N, lens_ptrs[j], modulo=True)
-                wavs = codecs[j].decode_device(codes_ptrs[j], N, np.full(B, N, dtype=np.int32), producer_stream=e.stream())
-                pending.append((codecs[j], lens_bufs[j]))
-        for e in cur:
+            for j, (e, r) in enumerate(zip(cur, rows)):
+                e.export_codes(list(range(r)), 0, n_codes, codes_ptrs[j], N, lens_ptrs[j], modulo=True)
+                wavs = codecs[j].decode_device(codes_ptrs[j], N, np.full(r, N, dtype=np.int32), producer_stream=e.stream())
+                pending.append((codecs[j], lens_bufs[j], r))
+        for e, r in zip(cur, rows):
             st, n_new = e.poll()                                    # blocking: this batch's decode (+ export) done
-            assert (n_new == N).all() and (st == 2).all(), "bench run did not produce the expected tokens"
+            assert (n_new[:r] == N).all() and (st[:r] == 2).all(), "bench run did not produce the expected tokens"
         tw.append(time.time())
-        for e in cur:
-            e.release_many(list(range(B)))
-        for e in engs[:nb_next]:
-            prefill_all(e)                                         # the next step's prompt passes, behind this step's codec passes on each lane
-        pstate["ready"][0] = nb_next
+        for e, r in zip(cur, rows):
+            e.release_many(list(range(r)))
+        nxt = rows_of(nb_next)
+        for e, r in zip(engs, nxt):
+            prefill_all(e, r)                                      # the next step's prompt passes, behind this step's codec passes on each lane
+        pstate["ready"][0] = len(nxt)
         tw.append(time.time())
         ph["host_wall_prefill_calls"] = (tw[1] - tw[0]) * 1e3
         ph["host_wall_decode_call"] = (tw[2] - tw[1]) * 1e3
@@ -758,9 +792,10 @@ def main():
         """K batches through the two-gang pipeline; returns per-gang-step [batches, host wall ms, phases]."""
         walls = []
         done = 0
+        cap = (G * B) // Q if NG == 1 else G                       # batches per gang step
         while done < K:
-            nb = min(G, K - done)
-            nb_next = min(G, K - done - nb)
+            nb = min(cap, K - done)
+            nb_next = min(cap, K - done - nb)
             ts = time.time()
             ph_t = (gang_step if NG == 2 else gang_step_single)(nb, nb_next)[0]
             walls.append((nb, round((time.time() - ts) * 1e3, 2), ph_t))
@@ -891,7 +926,10 @@ def main():
     if staticpipe:
         run_pipelined(a.warmup)
     for k in range(0 if staticpipe else a.warmup):
-        one_step(last=(k == a.warmup - 1))
+        if cont and a.warmup_requests:
+            one_step(last=(k == a.warmup - 1), nreq=a.warmup_requests)
+        else:
+            one_step(last=(k == a.warmup - 1))
     barrier()
     t0 = time.time()
     step_wall = []                                   # per-step host wall time (diagnostic; `value` uses the barrier-bracketed total)
@@ -1005,7 +1043,7 @@ def main():
                 e2.release_many(list(range(B)))
         rows.sort(reverse=True)
         live = {r[1]: (r[2], r[3], r[4]) for r in rows}
-        std_cfg = not nano and B == 256 and S == 500 and not a.speech_range_head          # the configuration the committed rocprofv3 / PMC passes were taken on
+        std_cfg = not nano and B == 640 and S == 500 and not a.speech_range_head          # the configuration the committed rocprofv3 / PMC passes were taken on (round 6: the driver's --steps 20 = engines of 640 slots)
         # rocprofv3 view of the same command (committed summary of the same configuration): per SYMBOL, since one gemm
         # template serves two launches per layer.  `agree` = its average duration is within 15 % of this run's HIP events.
         rocprof = rocprof_symbols(latest_profile("_bench_kernel_stats.txt"), live) if std_cfg else None
@@ -1072,7 +1110,7 @@ def main():
                 "step_frac": step_frac, "step_ms": step_ms, "step_alg_bytes": step_bytes,
                 # ... and the step as the timed region runs it: G engines' chains side by side (each chain's algorithmic bytes counted
                 # in full, the weights too -- every chain streams them, the second and third find most of a layer in the memory-side cache)
-                "gang_step": ({"chains": G, "ms_per_256_row_step": gang_step_ms, "frac_of_hbm_peak": step_bytes / (gang_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "gang_step": ({"chains": G, "rows_per_chain": B, "ms_per_chain_step": gang_step_ms, "ms_per_256_row_step": gang_step_ms * 256.0 / B, "frac_of_hbm_peak": step_bytes / (gang_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                # BOTH accountings: `frac_of_hbm_peak` charges every chain its own copy of the weights (G x step_alg_bytes per
                                # gang step); SURVEY 8(d)'s formula at the B = G x 256 rows the GPU actually holds charges them ONCE:
                                "alg_bytes_weights_once": weight_bytes + G * (step_bytes - weight_bytes),
@@ -1094,7 +1132,7 @@ def main():
         step_info = {"ms": step_ms, "alg_bytes": step_bytes, "achieved_GBps": step_bytes / (step_ms * 1e-3) / 1e9,
                      "frac_of_hbm_peak": step_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                      "sum_of_isolated_kernels_ms": sum(r[0] for r in rows),
-                     "gang": ({"chains": G, "ms_per_256_row_step": gang_step_ms, "achieved_GBps": step_bytes / (gang_step_ms * 1e-3) / 1e9,
+                     "gang": ({"chains": G, "rows_per_chain": B, "ms_per_256_row_step": gang_step_ms * 256.0 / B, "achieved_GBps": step_bytes / (gang_step_ms * 1e-3) / 1e9,
                                "frac_of_hbm_peak": step_bytes / (gang_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS} if gang_step_ms else None)}
         for s in range(B):
             eng.release(s)
@@ -1103,7 +1141,7 @@ def main():
         cpu = cpu_baseline(cfg, w, prompts[0], N, eos, ccfg, cw)
 
     if rank == 0:
-        tokens = world * (cont_tokens[0] if cont else B * N) * a.steps
+        tokens = world * (cont_tokens[0] if cont else Q * N) * a.steps
         value = tokens / dt
         stages = "backbone prefill + decode loop" + (f" + NeuCodec decoder ({a.codec_precision} GEMM operands, fp32 accumulate / residual stream) to 24 kHz waveform (D2H included)"
                                                      if codec is not None else " (codec skipped: --no-codec)")
@@ -1116,11 +1154,13 @@ def main():
             workload = f"NeuTTS-Air bf16 1xMI355X, batch=1, {S} prefill / {N} decode tokens (BASELINE.json configs[1])"
         else:
             one_eng = (B * N / ((ph["prefill"] + ph["decode"] + ph["codec"]) * 1e-3)) if (pipe and all(k in ph for k in ("prefill", "decode", "codec")) and ph["decode"] > 0) else None
-            head = (f"NeuTTS-Air bf16 {world}xMI355X: {G} batches of {B} IN FLIGHT per GPU ({G * B} resident; ONE {B}-slot engine alone = "
-                    f"{one_eng / 1e3:.1f}k tok/s), " if (pipe and G > 1 and one_eng) else f"NeuTTS-Air bf16 {world}xMI355X ")
-            workload = (head + f"batch={B} synthetic prompts per GPU, {S} prefill / {N} decode tokens, "
+            head = (f"NeuTTS-Air bf16 {world}xMI355X: {(G * B) // Q} batches of {Q} IN FLIGHT per GPU ({G * B} resident"
+                    + (f" on {G} engines of {B} slots, each stepping its rows in lock-step" if B > Q else "") + f"; ONE {B}-slot engine alone = "
+                    f"{one_eng / 1e3:.1f}k tok/s" + ("; 4 x 256 in flight, round 5's shape: 166.2 k, profiles/r06f_bench.json" if (B > Q and Q == 256 and G == 4) else "") + "), "
+                    if (pipe and G > 1 and one_eng) else f"NeuTTS-Air bf16 {world}xMI355X ")
+            workload = (head + f"batch={Q} synthetic prompts per GPU, {S} prefill / {N} decode tokens, "
                         f"STATIC batch (all {B} slots of the continuous-batching engine filled at once, every utterance {N} tokens; the ragged "
-                        f"scheduler line is --mode continuous)" + ((f", {G} batches at a time on {G} {B}-slot engines reading ONE copy of the weights: their prompt passes, decode chains (step graphs replayed alternately, one stream = one hardware queue each) and codec passes side by side" + (f", two such gangs taking turns ({2 * G} engines)" if NG == 2 else "") if G > 1 else ", consecutive batches pipelined over two engines") if pipe else "") + f" + hipGraph decode (BASELINE.json configs[{2 if world == 1 else 3}])")
+                        f"scheduler line is --mode continuous)" + ((f", {(G * B) // Q} batches at a time on {G} {B}-slot engines reading ONE copy of the weights: their prompt passes, decode chains (step graphs replayed alternately, one stream = one hardware queue each) and codec passes side by side" + (f", two such gangs taking turns ({2 * G} engines)" if NG == 2 else "") if G > 1 else ", consecutive batches pipelined over two engines") if pipe else "") + f" + hipGraph decode (BASELINE.json configs[{2 if world == 1 else 3}])")
         workload += ", sampling as the reference calls generate (do_sample, top_k=50, temperature=1.0, seeded)" if a.sample else ", greedy"
         if a.speech_range_head:
             workload = ("OPT-IN --speech-range-head (NOT the headline, not the reference's arithmetic outside the range): lm_head over 65 536 speech ids + EOS "
@@ -1142,7 +1182,7 @@ def main():
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "fp8" if fp8 else "bf16", "data": "synthetic",
             "config": {"workload": workload,
-                       "batch_per_gpu": B, "prefill_tokens": S, "decode_tokens": N, "vocab_size": cfg.vocab_size,
+                       "batch_per_gpu": Q, "engine_slots": B, "prefill_tokens": S, "decode_tokens": N, "vocab_size": cfg.vocab_size,
                        "stages": stages, "codec_operands": (a.codec_precision if codec is not None else None),
                        "parallelism": f"independent shards x{world}, RCCL weight broadcast only"},
             "tokens_per_s_per_gpu": value / world,
@@ -1151,13 +1191,13 @@ def main():
             "ranks_in_timed_region": ranks_seen, "host_wall_over_ranks": host_stats,
             "roofline": roof, "decode_step": step_info, "cpu_baseline": cpu,
             "timed_region": ((f"warm_up() before timing; {len(engs)} backbone engines of {B} slots on one weight arena, each with a codec engine, on {G} lane streams; one "
-                              f"launching thread; a gang step = {G} batches, one per engine: [prompt passes] [249 decode steps per engine, the engines' step graphs "
+                              f"launching thread; a gang step = {(G * B) // Q if NG == 1 else G} batches of {Q} ({B} utterances per engine): [prompt passes] [{N - 1} decode steps per engine, the engines' step graphs "
                               f"replayed alternately] [code export + codec pass + D2H per engine]"
                               + ("; the next gang step's prompt passes are enqueued behind this one's codec passes" if NG == 1 else
                                  "; two gangs take turns: gang k + 1's prompt passes (one shared stream with the codec passes) between gang k's decode graphs")
                               + f"; the timed region is self-contained (K prompt passes, K decode loops, K codec passes for --steps K, the last gang step takes "
-                              f"K mod {G} batches if that is not zero, nothing prefetched before the clock starts, every waveform landed before it stops; a "
-                              f"step of the contract = one batch of {B}); phase_ms is a separate serial pass on ONE engine") if pipe else
+                              f"K mod {(G * B) // Q if NG == 1 else G} batches if that is not zero (its last engine part-filled), nothing prefetched before the clock starts, every waveform landed before it stops; a "
+                              f"step of the contract = one batch of {Q}); phase_ms is a separate serial pass of {B} utterances on ONE engine") if pipe else
                              "warm_up() before timing, codec pass + D2H of batch k asynchronous under the prompt pass of batch k + 1 (static mode, one engine)"),
             # the same batch through ONE engine, phase after phase (the untimed serial pass behind phase_ms): what a single 256-slot engine
             # delivers on this box, next to the gang's line above
@@ -1172,7 +1212,7 @@ def main():
         # BASELINE.json configs[2] literally says "continuous batching": the ragged-request scheduler measured in the SAME driver
         # invocation (its own process and engines -- the ragged requests need a longer context than the static engines were created
         # with), as a sub-record with its ratio to the static line above.  Rank 0 of a 1-GPU run only; NTTS_BENCH_CONT_LEG=0 skips it.
-        if (world == 1 and not cont and not strm and not nano and not a.tiny and B == 256 and not emu_lib and not a.no_roofline
+        if (world == 1 and not cont and not strm and not nano and not a.tiny and Q == 256 and not emu_lib and not a.no_roofline
                 and not a.speech_range_head and os.environ.get("NTTS_BENCH_CONT_LEG", "1") != "0"):
             rec["continuous"] = continuous_leg(value, a)
         print(json.dumps(rec), flush=True)

@@ -103,6 +103,24 @@ def test_bench_two_gangs_taking_turns_emulator(emu_lib):
     assert abs(rec["value"] - 2 * 4 / (rec["ms_per_step"] / 1e3)) < 1e-6 * rec["value"] + 1e-9
 
 
+def test_bench_engines_wider_than_a_batch_emulator(emu_lib):
+    """`bench.py --engine-slots`: engines of the gang that hold more than one batch of the contract and step their rows in lock-step (round 6: the
+    default on the GPU is gang x 640 slots for the driver's --steps 20).  Two engines of 5 slots at --batch 2: a gang step takes 5 batches, seven
+    batches = one full gang step and one of two batches (one engine, part-filled); `steps`, `value` and `ms_per_step` stay in batches of --batch."""
+    import subprocess
+    import sys
+    env = dict(os.environ, NTTS_BENCH_EMU_LIB=emu_lib)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--tiny", "--gang", "2", "--batch", "2", "--engine-slots", "5", "--prefill", "12",
+                        "--decode", "4", "--prefill-chunk", "2", "--steps", "7", "--warmup", "1", "--no-roofline", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    rec = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert rec["steps"] == 7 and rec["config"]["batch_per_gpu"] == 2 and rec["config"]["engine_slots"] == 5
+    assert rec["pipeline"]["engines"] == 2 and rec["pipeline"]["utterances_resident"] == 10
+    assert [nb for nb, _ in rec["step_wall_ms"]] == [5, 2]
+    assert abs(rec["value"] - 2 * 4 / (rec["ms_per_step"] / 1e3)) < 1e-6 * rec["value"] + 1e-9
+
+
 def test_bench_continuous_mode_emulator(emu_lib):
     """`bench.py --mode continuous` end to end on the emulator build: ragged requests through the run-ahead scheduler, every finished
     utterance exported on the "device" from the on_finished hook, one codec pass per `batch` finished utterances + the ragged tail,

@@ -12,9 +12,9 @@ for leg in $LEGS; do
   case $leg in
     smoke) timeout 420 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -5 $OUT/smoke.log;;
     tests) timeout ${TESTS_TIMEOUT:-900} python -m pytest tests -m gpu -q -rA --durations=10 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -45 $OUT/pytest_gpu.log;;
-    bench) timeout 600 python bench.py --steps ${BENCH_STEPS:-10} --warmup 2 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -25 $OUT/bench.err;;
+    bench) timeout 900 python bench.py --gpus 1 --steps ${BENCH_STEPS:-20} --warmup ${BENCH_WARMUP:-5} > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; cat $OUT/bench.json; tail -25 $OUT/bench.err;;
     b1)    timeout 300 python bench.py --batch 1 --steps ${BENCH_STEPS:-3} --warmup 1 --no-cpu-baseline > $OUT/bench_b1.json 2> $OUT/bench_b1.err; echo "bench b1 rc=$?"; cat $OUT/bench_b1.json | cut -c1-1500; tail -12 $OUT/bench_b1.err;;
-    prof)  rm -rf $OUT/prof; NTTS_BENCH_PRIME_STEPS=2 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof -o bench -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $OUT/prof_bench.json 2> $OUT/prof.err; echo "prof rc=$?"
+    prof)  rm -rf $OUT/prof; NTTS_BENCH_PRIME_STEPS=2 timeout 600 rocprofv3 --kernel-trace --stats -f csv -d $OUT/prof -o bench -- python bench.py --steps ${PROF_STEPS:-10} --warmup 0 --engine-slots ${PMC_BATCH:-640} --no-cpu-baseline --no-roofline > $OUT/prof_bench.json 2> $OUT/prof.err; echo "prof rc=$?"
            python tools/prof_summary.py $OUT/prof > $OUT/prof_summary.txt 2>&1; head -40 $OUT/prof_summary.txt; cat $OUT/prof_bench.json; tail -3 $OUT/prof.err
            find $OUT/prof -name '*kernel_trace.csv' -size +20M -delete;;
     pmc)   # HBM traffic counters, each in its own pass (FETCH_SIZE and WRITE_SIZE do not fit one pass); hipGraph replay off
@@ -23,11 +23,14 @@ for leg in $LEGS; do
            #  counter, never without the profiler -- so each pass gets a short timeout and up to three attempts)
            for ctr in FETCH_SIZE WRITE_SIZE; do export NTTS_BENCH_PRIME=0   # (no warm-up: its one-slot decode steps would dilute the per-launch means; 8 decode steps per pass -- a pass with 40 hangs under the profiler since round 3, with 4-8 it takes 8-16 s)
              for attempt in 1 2 3; do
-               rm -rf $OUT/pmc_$ctr; env ${PMC_EXTRA_ENV:-} NTTS_NO_GRAPH=1 timeout 90 rocprofv3 --kernel-trace --pmc $ctr -f csv -d $OUT/pmc_$ctr -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-codec --prefill ${PMC_PREFILL:-621} --decode ${PMC_DECODE:-8} --no-pipeline --batch ${PMC_BATCH:-256} > $OUT/pmc_bench.json 2> $OUT/pmc_$ctr.err; rc=$?; echo "pmc $ctr attempt $attempt rc=$rc"
+               rm -rf $OUT/pmc_$ctr; env ${PMC_EXTRA_ENV:-} NTTS_NO_GRAPH=1 timeout 90 rocprofv3 --kernel-trace --pmc $ctr -f csv -d $OUT/pmc_$ctr -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-codec --prefill ${PMC_PREFILL:-621} --decode ${PMC_DECODE:-8} --no-pipeline --batch ${PMC_BATCH:-640} > $OUT/pmc_bench.json 2> $OUT/pmc_$ctr.err; rc=$?; echo "pmc $ctr attempt $attempt rc=$rc"
                [ $rc -eq 0 ] && break
              done
-             python tools/pmc_summary.py $OUT/pmc_$ctr > $OUT/pmc_${ctr}_summary.txt 2>&1; head -14 $OUT/pmc_${ctr}_summary.txt; find $OUT/pmc_$ctr -name '*.csv' -size +8M -delete
-           done;;
+             python tools/pmc_summary.py $OUT/pmc_$ctr > $OUT/pmc_${ctr}_summary.txt 2>&1; head -14 $OUT/pmc_${ctr}_summary.txt
+           done
+           # the record bench.py quotes as roofline.traffic (one engine of PMC_BATCH slots = the engines of the default run: the driver's --steps 20 -> 640)
+           python tools/pmc_to_json.py $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE --prefill=${PMC_PREFILL:-621} --decode=${PMC_DECODE:-8} --batch=${PMC_BATCH:-640} > $OUT/pmc_traffic.json 2> $OUT/pmc_to_json.err; head -c 600 $OUT/pmc_traffic.json; echo
+           find $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE -name '*.csv' -size +8M -delete;;
     pmcgang) # HBM traffic counters over GANG steps -- four 256-slot engines on one arena, step graphs off, the chains' launches enqueued
            # alternately on their lanes as in the timed region (one pass per counter; --kernel-trace only, as the pool rules require).  Whether the chains'
            # kernels really overlapped under the profiler is read from the kernel trace of the same pass (tools/pmc_gang_summary.py).
@@ -41,10 +44,10 @@ for leg in $LEGS; do
     mfma)  # matrix-core utilisation per kernel (north_star: "MFMA utilisation against gfx950 peak"): SQ busy cycles / GRBM cycles / MFMA op counts
            # in ONE counter pass (8 SQ slots, 2 GRBM), graph replay off, one engine, 8 decode steps (longer profiled passes hang since round 3)
            for attempt in 1 2 3; do
-             rm -rf $OUT/pmc_mfma; NTTS_NO_GRAPH=1 NTTS_BENCH_PRIME=0 timeout 150 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 -f csv -d $OUT/pmc_mfma -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-pipeline --prefill 605 --decode 8 > $OUT/pmc_mfma_bench.json 2> $OUT/pmc_mfma.err; rc=$?; echo "mfma attempt $attempt rc=$rc"
+             rm -rf $OUT/pmc_mfma; NTTS_NO_GRAPH=1 NTTS_BENCH_PRIME=0 timeout 150 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 -f csv -d $OUT/pmc_mfma -o pmc -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-pipeline --prefill 605 --decode 8 --batch ${PMC_BATCH:-640} > $OUT/pmc_mfma_bench.json 2> $OUT/pmc_mfma.err; rc=$?; echo "mfma attempt $attempt rc=$rc"
              [ $rc -eq 0 ] && break
            done
-           { echo "# NTTS_NO_GRAPH=1 NTTS_BENCH_PRIME=0 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-pipeline --prefill 605 --decode 8"
+           { echo "# NTTS_NO_GRAPH=1 NTTS_BENCH_PRIME=0 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-pipeline --prefill 605 --decode 8 --batch ${PMC_BATCH:-640}"
              echo "# python tools/mfma_util_summary.py <dir>   (formula and calibration in the tool's header; counter passes run at a lower clock than the bench)"
              python tools/mfma_util_summary.py $OUT/pmc_mfma; } > $OUT/mfma_util.txt 2>&1; head -16 $OUT/mfma_util.txt; find $OUT/pmc_mfma -name '*.csv' -size +8M -delete;;
     sweep)  # SWEEP_KNOBS='[["NTTS_ATTN_DEPTH",[2]]]'
