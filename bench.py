@@ -114,6 +114,11 @@ ROCPROF_SYMBOLS = [   # rocprofv3 symbol prefix -> the step's logical kernels it
     ("gemm_kernel<8, 1, 2, 2, 3,", ["gemm_o_proj_splitk", "gemm_down_splitk"]),   # the gang's 256-row tile (ntts_backbone_set_gang): under the profiler the four chains run
                                                                                   # one after the other, so this symbol's average is the tile ALONE (slower than the 64-row one)
     ("gemm_kernel<4, 2, 2, 1, 3,", ["gemm_gate_up_silu"]),
+    # the WIDE decode shape (engines of 512+ slots: bench.py's default since round 6): gate/up on 256 x 192, down_proj on 128 x 128 / 8 waves / 4 K slices,
+    # o_proj on whole-K 64 x 64 tiles with the residual add in the epilogue
+    ("gemm_kernel<4, 3, 4, 1, 2,", ["gemm_gate_up_silu"]),
+    ("gemm_kernel<4, 2, 2, 2, 3,", ["gemm_down_splitk"]),
+    ("gemm_kernel<4, 1, 1, 6, 4,", ["gemm_o_proj_splitk"]),
     ("gemm_kernel<4, 3, 4, 3, 2, 0, 64, true", ["gemm_lm_head_argmax"]),     # 256 x 288 natural-order tile (NTTS_HEAD_XL=4, the default)
     ("gemm_kernel<4, 4, 4, 3, 2, 0, 64, true", ["gemm_lm_head_argmax"]),     # 256 x 256 tile (NTTS_HEAD_XL=1)
     ("add_rmsnorm_row_kernel", ["add_rmsnorm_kernel"]),
@@ -197,7 +202,7 @@ def rocprof_symbols(path, live):
     if not out:
         return None
     out.sort(key=lambda r: -r["share_pct"])
-    return {"summary": os.path.relpath(path, ROOT), "command": "NTTS_BENCH_PRIME_STEPS=2 rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 0 "
+    return {"summary": os.path.relpath(path, ROOT), "command": "NTTS_BENCH_PRIME_STEPS=2 rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 0 --engine-slots 640 "
             "--no-cpu-baseline --no-roofline", "dominant_symbol_by_share": out[0]["symbol"], "symbols": out}
 
 

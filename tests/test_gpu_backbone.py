@@ -70,7 +70,7 @@ def test_small_walk_exact_tile_variants(lib, knobs, monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("max_batch", [16, 40, 64, 128, 256, 512])
+@pytest.mark.parametrize("max_batch", [16, 40, 64, 128, 256, 512, 640])
 def test_xcd_row_block_placement(lib, max_batch, monkeypatch):
     """NTTS_XCD_AFFINE=7 at every batch size it applies to (8 / 4 / 2 / 1 XCDs per 64-row m-block): the split-K GEMMs, the norms
     behind them and decode attention place an m-block's rows on one group of XCDs -- a permutation of which workgroup does what.

@@ -136,7 +136,7 @@ def check_stats(tag, exact, tie, stats, n_rows):
 
 
 CASES = (
-    [(b, {}) for b in (1, 8, 16, 40, 64, 96, 128, 256, 512)] +                                    # small-batch path (<= 8), tile path, every attention form by batch size
+    [(b, {}) for b in (1, 8, 16, 40, 64, 96, 128, 256, 512, 640, 768, 1024)] +                    # small-batch path (<= 8), tile path, every attention form by batch size; from 512 the wide shape (640 = bench.py's engines, part-filled last tiles)
     [(8, {"NTTS_SMALL_BATCH": "0"})] +                                                             # the tile path at 8 rows
     [(b, {"NTTS_ATTN_SPLIT": "8", "NTTS_ATTN_SPLIT_CTX": "64"}) for b in (1, 16, 64, 128)] +       # context-split attention from context 64 on: two launches + statistics (+ combine pass)
     [(64, {"NTTS_XCD_AFFINE": "7"}), (128, {"NTTS_XCD_AFFINE": "7"}),                              # row-block XCD placement where it is not the default ...
