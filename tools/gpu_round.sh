@@ -61,7 +61,7 @@ for leg in $LEGS; do
              cat $OUT/profcont_${mode}_classes.txt | cut -c1-170; cut -c1-600 $OUT/profcont_$mode.json; tail -3 $OUT/profcont_$mode.err
              find $OUT/profcont_$mode -name '*.csv' -size +1M -delete
            done;;
-    nano)  for cfg in nano-fp8 nano-bf16; do timeout 300 python bench.py --config $cfg --steps ${BENCH_STEPS:-2} --warmup 1 --no-cpu-baseline > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err; echo "bench $cfg rc=$?"; cut -c1-1200 $OUT/bench_$cfg.json; tail -12 $OUT/bench_$cfg.err; done;;
+    nano)  for cfg in nano-fp8 nano-bf16; do timeout 300 python bench.py --config $cfg --steps ${NANO_STEPS:-20} --warmup 1 --no-cpu-baseline > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err; echo "bench $cfg rc=$?"; cut -c1-1200 $OUT/bench_$cfg.json; tail -12 $OUT/bench_$cfg.err; done;;
     *) echo "unknown leg $leg";;
   esac
 done
