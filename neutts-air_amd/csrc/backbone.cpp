@@ -468,7 +468,9 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     if (e->wide_qkv != 1 && e->wide_qkv != 2 && e->wide_qkv != 4) e->wide_qkv = 2;
     e->wide_o = env_int("NTTS_WIDE_O", 1);
     e->wide_down = env_int("NTTS_WIDE_DOWN", 1);
-    e->gu_tile = env_int("NTTS_GU_TILE", e->wide ? 1 : 0);
+    // (wide engines whose rows are a multiple of 128 but not of 256 -- 640: bench.py's engines for the driver's --steps 20 -- would leave half of the last
+    //  256-row block empty: the 2-slot 128 x 128 tile instead, 3.02 -> 2.89 ms per step alone, 1.97 -> 1.95 in a gang of four; same bits, profiles/r06h_sweep_gang_640.txt)
+    e->gu_tile = env_int("NTTS_GU_TILE", e->wide ? ((D % 256) == 128 ? 3 : 1) : 0);
     if (e->gu_tile < 0 || e->gu_tile > 3) e->gu_tile = 0;
     if (e->wide && e->wide_down == 1 && env_int("NTTS_KS_D", 0) <= 0) e->ks_d = 4;   // 8 x 7 tiles of 128 x 128 x 4 K slices = 224 workgroups
     e->xl_min_m = env_int("NTTS_XL_MIN_M", 0);
