@@ -125,6 +125,15 @@ ROCPROF_SYMBOLS = [   # rocprofv3 symbol prefix -> the step's logical kernels it
 ]
 
 
+def engine_slots_for(steps, batch, gang, cap=1024):
+    """Decode slots per engine of the static gang for a timed region of `steps` batches of `batch` utterances: the batches are spread evenly over the
+    fewest gang steps whose engines stay within `cap` slots (a gang step of 4 x 1024 utterances takes 3.7 s: a batch still finishes sooner than the 5 s of
+    audio it carries), slots rounded up to whole 64-row tiles and never below one batch.  20 batches -> two gang steps of ten = 640 slots on four engines."""
+    n_gs = -(-(steps * batch) // (gang * cap))            # gang steps
+    per_gs = -(-steps // n_gs)                            # batches per gang step
+    return max(batch, -(-(per_gs * batch) // (gang * 64)) * 64)
+
+
 def latest_profile(suffix):
     """The newest committed profiles/rNN*<suffix> (files are named per round and session: r03i_..., r04b_...)."""
     import glob
@@ -358,9 +367,7 @@ def main():
         if cont:
             B = 2 * Q
         else:
-            n_gs = -(-(a.steps * Q) // (a.gang * 1024))                       # gang steps in the timed region
-            per_gs = -(-a.steps // n_gs)                                      # batches per gang step
-            B = max(Q, -(-(per_gs * Q) // (a.gang * 64)) * 64)
+            B = engine_slots_for(a.steps, Q, a.gang)
     R = a.requests or 4 * B * (max(1, a.gang) if (a.mode == "continuous" and B > 1) else 1)
     S_max, N_max = (int(S * 1.3) + 1, int(N * 1.4) + 1) if cont else (S, N)
     dev = 0 if emu_lib else local

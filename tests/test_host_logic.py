@@ -193,3 +193,20 @@ def test_engine_slot_pool_and_generate_cleanup(emu_lib):
     assert all(len(g) >= 4 for g in got)
     eng.release(s)
     assert eng.free_slots() == 2
+
+
+def test_bench_engine_slots_rule():
+    """bench.py sizes the static gang's engines from the job: even gang steps, at most 1024 slots, whole 64-row tiles, never
+    less than a batch."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    f = bench.engine_slots_for
+    assert [f(k, 256, 4) for k in (1, 3, 4, 5, 8, 10, 16, 20, 32, 40)] == [256, 256, 256, 320, 512, 640, 1024, 640, 1024, 896]
+    assert f(20, 256, 2) == 896 and f(2, 2, 2) == 64 and f(20, 512, 4) == 896
+    for k in range(1, 70):
+        b = f(k, 256, 4)
+        n_gs = -(-(k * 256) // (4 * 1024))
+        assert 256 <= b <= 1024 and b % 64 == 0 and 4 * b * n_gs >= k * 256        # the gang steps hold the job
