@@ -607,7 +607,7 @@ def main():
         def hook_body(i, slot, n_new, e):
             assert n_new == int(r_glen[i]), "continuous run did not produce the expected tokens"
             tokens[0] += n_new
-            done_at.append((time.time(), n_new))
+            done_at.append((time.time(), n_new, sum(e_.counters["decode_steps"] for e_ in cengs)))
             if codec is None:
                 return
             k = which[id(e)]
@@ -664,7 +664,9 @@ def main():
         if len(done_at) >= 64:
             done_at.sort()
             a25, a75 = done_at[len(done_at) // 4], done_at[(3 * len(done_at)) // 4]
-            mid = sum(nn for t, nn in done_at if a25[0] < t <= a75[0])
+            mid = sum(x[1] for x in done_at if a25[0] < x[0] <= a75[0])
+            if a75[2] > a25[2]:                                             # ... and how full the decode rows were over the same stretch
+                ph["steady_state_slot_occupancy"] = mid / ((a75[2] - a25[2]) * B)
             if a75[0] > a25[0]:
                 ph["steady_state_tokens_per_s"] = mid / (a75[0] - a25[0])
         return ph, None, wavs

@@ -221,6 +221,16 @@ struct ntts_backbone {
     hipStream_t copy_stream = nullptr;
     bool meta_used[kMetaStages] = {false, false, false, false};
     int meta_next = 0;
+    // ... and a deeper ring of SMALL slots for the uploads a scheduler makes per finished request / per step (slot lists of code exports, activations,
+    // block-table updates): with four slots the fifth export of a poll waited for the engine's stream to reach the first one -- i.e. for the decode
+    // step in flight -- and the launching thread sat out a whole gang round inside a hook while the other engines' queues ran dry
+    // (bench.py --mode continuous on four 512-slot engines: 4.8 of 24 s in the on_finished hooks, profiles/r06j_*)
+    static constexpr int kSmallStages = 32;
+    size_t small_cap = 0;
+    int* small_host = nullptr;                 // kSmallStages x small_cap ints, one page-locked block
+    hipEvent_t small_ev[kSmallStages] = {};
+    bool small_used[kSmallStages] = {};
+    int small_next = 0;
 
     hipGraphExec_t graph = nullptr;
     hipGraphExec_t graph_split = nullptr;   // the small-batch step with context-split attention (long contexts)
@@ -547,6 +557,9 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
         CR_HIP(hipHostMalloc((void**)&e->meta_host[i], e->meta_cap * sizeof(int), hipHostMallocDefault));
         CR_HIP(hipEventCreateWithFlags(&e->meta_ev[i], hipEventDisableTiming));
     }
+    e->small_cap = 4 * (size_t)B + 64;
+    CR_HIP(hipHostMalloc((void**)&e->small_host, ntts_backbone::kSmallStages * e->small_cap * sizeof(int), hipHostMallocDefault));
+    for (int i = 0; i < ntts_backbone::kSmallStages; ++i) CR_HIP(hipEventCreateWithFlags(&e->small_ev[i], hipEventDisableTiming));
     CR_HIP(hipHostMalloc((void**)&e->snap_host, 2 * (size_t)B * sizeof(int), hipHostMallocDefault));
     CR_HIP(hipEventCreateWithFlags(&e->snap_ev, hipEventDisableTiming));
     CR_HIP(hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
@@ -579,6 +592,9 @@ extern "C" void ntts_backbone_destroy(ntts_backbone* e) {
         if (e->meta_host[i]) hipHostFree(e->meta_host[i]);
         if (e->meta_ev[i]) hipEventDestroy(e->meta_ev[i]);
     }
+    if (e->small_host) hipHostFree(e->small_host);
+    for (int i = 0; i < ntts_backbone::kSmallStages; ++i)
+        if (e->small_ev[i]) hipEventDestroy(e->small_ev[i]);
     if (e->snap_host) hipHostFree(e->snap_host);
     if (e->snap_ev) hipEventDestroy(e->snap_ev);
     if (e->copy_stream) hipStreamDestroy(e->copy_stream);
@@ -1508,6 +1524,17 @@ static void drop_pages(ntts_backbone* e, HostSlot& s, size_t keep = 0) {
 // used that slot -- four uploads ago -- has not executed yet)
 static hipError_t upload_meta(ntts_backbone* e, const int* src, size_t n, hipStream_t st) {
     if (n > e->meta_cap) return hipErrorInvalidValue;   // (every caller checks first; the ring slots hold meta_cap ints)
+    if (n <= e->small_cap && e->small_host) {            // a scheduler's small upload: the deep ring (the device copies execute in stream order either way)
+        const int k = e->small_next;
+        e->small_next = (k + 1) % ntts_backbone::kSmallStages;
+        if (e->small_used[k]) { const hipError_t rc = hipEventSynchronize(e->small_ev[k]); if (rc != hipSuccess) return rc; }
+        int* h = e->small_host + (size_t)k * e->small_cap;
+        memcpy(h, src, n * sizeof(int));
+        hipError_t rc = hipMemcpyAsync(e->meta_dev, h, n * sizeof(int), hipMemcpyHostToDevice, st);
+        if (rc != hipSuccess) return rc;
+        e->small_used[k] = true;
+        return hipEventRecord(e->small_ev[k], st);
+    }
     const int k = e->meta_next;
     e->meta_next = (k + 1) % ntts_backbone::kMetaStages;
     if (e->meta_used[k]) { const hipError_t rc = hipEventSynchronize(e->meta_ev[k]); if (rc != hipSuccess) return rc; }
