@@ -484,7 +484,7 @@ extern "C" int ntts_backbone_create(const ntts_backbone_config* c, int device, n
     //  256-row block empty: the 2-slot 128 x 128 tile instead, 3.02 -> 2.89 ms per step alone, 1.97 -> 1.95 in a gang of four; same bits, profiles/r06h_sweep_gang_640.txt)
     e->gu_tile = env_int("NTTS_GU_TILE", e->wide ? ((D % 256) == 128 ? 3 : 1) : 0);
     if (e->gu_tile < 0 || e->gu_tile > 3) e->gu_tile = 0;
-    if (e->wide && e->wide_down == 1 && env_int("NTTS_KS_D", 0) <= 0) e->ks_d = 4;   // 8 x 7 tiles of 128 x 128 x 4 K slices = 224 workgroups
+    if (e->wide && e->wide_down == 1 && !e->fp8 && env_int("NTTS_KS_D", 0) <= 0) e->ks_d = 4;   // 8 x 7 tiles of 128 x 128 x 4 K slices = 224 workgroups
     e->xl_min_m = env_int("NTTS_XL_MIN_M", 0);
     {   // 0 = every query on the two-sweep kernel; whole pages, at most what the resident kernel holds
         int cap = env_int("NTTS_PF_RES_CAP", kPfResPages * kPage) / kPage * kPage;
@@ -1270,7 +1270,7 @@ static void k_qkv(ntts_backbone* e, int i) {
     a.q_out = e->qkv_dec; a.ld_q = e->NQKV; a.kpool = e->kv + (size_t)i * e->layer_stride;
     a.nh = e->cfg.num_heads; a.nkv = e->cfg.num_kv_heads;
     a.tl = e->gemv_tl;
-    if (e->wide && !e->fp8 && e->wide_qkv > 1) {
+    if (e->wide && !e->fp8 && e->wide_qkv > 1) {   // (fp8: the 64-row kernel measured the same, 241.7 vs 241.3 k on nano-fp8: kept narrow)
         if (e->wide_qkv == 4) qkv_rope_launch_wide<false, 4>(a, e->stream);
         else qkv_rope_launch_wide<false, 2>(a, e->stream);
         return;
@@ -1341,7 +1341,7 @@ static void k_gate_up(ntts_backbone* e, int i) {
 static void k_down(ntts_backbone* e, int i) {
     const int B = e->dec_rows, H = e->H, F = e->F;
     GemmArgs a = gemm_args(e, e->act_dec, F, e->layers[i].wd, F, nullptr, e->slabs, H, B, H, F, e->layers[i].sd, e->layers[i].xs[3]);
-    if (e->wide && e->wide_down == 1 && !e->fp8) {   // 128 x 128 / 8 waves / 3-slot ring: a W tile enters LDS once per 128 rows (64 x 64: 622 KB through a CU per tile)
+    if (e->wide && e->wide_down == 1 && !e->fp8) {   // 128 x 128 / 8 waves / 3-slot ring: a W tile enters LDS once per 128 rows (64 x 64: 622 KB through a CU per tile); fp8: no gain (241.1 vs 241.3 k), kept narrow
         a.xcd_nsplit = -1;
         gemm_launch<4, 2, 2, EPI_SPLITK, 3>(a, e->ks_d, e->stream);
         return;
